@@ -1,0 +1,276 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see jdk.hpp header).
+// Flat C API over the oracle so tests/, smoke() and bench.py's cpu_baseline leg can drive it via
+// ctypes. Every function returns 0 on success, negative on a restated Java exception
+// (-1 IllegalArgumentException, -2 IllegalStateException, -3 other); orc_last_error() has the text.
+#include <cstring>
+#include <chrono>
+#include "handel.hpp"
+#include "pingpong.hpp"
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+#define ORC_TRY try {
+#define ORC_CATCH                                  \
+  }                                                \
+  catch (const IllegalArgumentException& e) {      \
+    g_err = e.what();                              \
+    return -1;                                     \
+  }                                                \
+  catch (const IllegalStateException& e) {         \
+    g_err = e.what();                              \
+    return -2;                                     \
+  }                                                \
+  catch (const std::exception& e) {                \
+    g_err = e.what();                              \
+    return -3;                                     \
+  }                                                \
+  return 0;
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// ---- JDK kit
+int orc_jrandom_ints(int64_t seed, int n, int32_t* out) {
+  JRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextInt();
+  return 0;
+}
+int orc_jrandom_bounded(int64_t seed, int32_t bound, int n, int32_t* out) {
+  ORC_TRY JRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextInt(bound);
+  ORC_CATCH
+}
+int orc_jrandom_doubles(int64_t seed, int n, double* out) {
+  JRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextDouble();
+  return 0;
+}
+int orc_jrandom_booleans(int64_t seed, int n, uint8_t* out) {
+  JRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextBoolean();
+  return 0;
+}
+int orc_jshuffle_iota(int64_t seed, int n, int rounds, int32_t* out) {
+  JRandom r(seed);
+  std::vector<int32_t> v(n);
+  for (int i = 0; i < n; i++) v[i] = i;
+  for (int k = 0; k < rounds; k++) jshuffle(v, r);
+  memcpy(out, v.data(), sizeof(int32_t) * n);
+  return 0;
+}
+int32_t orc_pseudo_random(int32_t nodeId, int32_t seed) { return Network::getPseudoRandom(nodeId, seed); }
+// NetworkLatencyByDistanceWJitter.getExtendedLatency as a (dist, delta) table entry
+int32_t orc_latency_bydistance(int32_t dist, int32_t delta) {
+  NetworkLatencyByDistanceWJitter nl;
+  double raw = nl.getFixedLatency(dist) + nl.getJitter(delta);
+  return (int)(raw / 2);
+}
+int32_t orc_max_dist() { return Node::MAX_DIST(); }
+int orc_node_xy(int32_t rdInt, int32_t* x, int32_t* y) {
+  NodeBuilderWithRandomPosition nb;
+  *x = nb.getX(rdInt);
+  *y = nb.getY(rdInt);
+  return 0;
+}
+
+// ---- PingPong
+struct OrcPingPong {
+  std::unique_ptr<PingPong> p;
+};
+int orc_pingpong_create(int nodeCt, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY PingPong::PingPongParameters pr;
+  pr.nodeCt = nodeCt;
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcPingPong();
+  h->p = std::make_unique<PingPong>(pr);
+  h->p->network().rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_pingpong_destroy(void* h) { delete (OrcPingPong*)h; }
+int orc_pingpong_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcPingPong*)h)->p->network().runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 pong, 1 msgReceived, 2 msgSent, 3 bytesSent, 4 bytesReceived, 5 x, 6 y, 7 down
+int orc_pingpong_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcPingPong*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.pong; break;
+      case 1: v = n.msgReceived; break;
+      case 2: v = n.msgSent; break;
+      case 3: v = n.bytesSent; break;
+      case 4: v = n.bytesReceived; break;
+      case 5: v = n.x; break;
+      case 6: v = n.y; break;
+      case 7: v = n.down; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_pingpong_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcPingPong*)h)->p;
+  *time = p.network().time;
+  *queueSize = p.network().msgs.size();
+  *rngState = p.network().rd.rawState();
+  *delivered = p.network().statDelivered;
+  return 0;
+}
+
+// ---- Handel
+struct OrcHandel {
+  std::unique_ptr<Handel> p;
+  double initSeconds = 0;
+};
+// iparams: nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs,
+//          fastPath, nodesDown, desynchronizedStart   (P/Handel.java:97-111 ctor order, ints only)
+int orc_handel_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY Handel::HandelParameters pr(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], nb ? nb : "",
+                                      nl ? nl : "", ip[8], false, false, nullptr);
+  auto* h = new OrcHandel();
+  h->p = std::make_unique<Handel>(pr);
+  h->p->network().rd.setSeed(seed);
+  auto t0 = std::chrono::steady_clock::now();
+  h->p->init();
+  h->initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
+  ORC_CATCH
+}
+void orc_handel_destroy(void* h) { delete (OrcHandel*)h; }
+int orc_handel_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcHandel*)h)->p->network().runMs(ms);
+  ORC_CATCH
+}
+int orc_handel_cont_if(void* h) { return ((OrcHandel*)h)->p->contIf(); }
+int orc_handel_levels(void* h) { return (int)((OrcHandel*)h)->p->node(0)->levels.size(); }
+double orc_handel_init_seconds(void* h) { return ((OrcHandel*)h)->initSeconds; }
+// per-node scalar fields: 0 doneAt 1 msgReceived 2 msgSent 3 bytesSent 4 bytesReceived 5 sigsChecked
+// 6 sigQueueSize 7 msgFiltered 8 currWindowSize 9 addedCycle 10 down 11 x 12 y 13 startAt
+// 14 nodePairingTime 15 extraLatency
+int orc_handel_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcHandel*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.doneAt; break;
+      case 1: v = n.msgReceived; break;
+      case 2: v = n.msgSent; break;
+      case 3: v = n.bytesSent; break;
+      case 4: v = n.bytesReceived; break;
+      case 5: v = n.sigsChecked; break;
+      case 6: v = n.sigQueueSize; break;
+      case 7: v = n.msgFiltered; break;
+      case 8: v = n.currWindowSize; break;
+      case 9: v = n.addedCycle; break;
+      case 10: v = n.down; break;
+      case 11: v = n.x; break;
+      case 12: v = n.y; break;
+      case 13: v = n.startAt; break;
+      case 14: v = n.nodePairingTime; break;
+      case 15: v = n.extraLatency; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+// per (node, level) ints, row-major [node][level]: 0 posInLevel 1 outgoingFinished 2 toVerifyAgg.size
+int orc_handel_read_level(void* h, int field, int32_t* out) {
+  ORC_TRY auto& p = *((OrcHandel*)h)->p;
+  int L = (int)p.node(0)->levels.size();
+  for (size_t i = 0; i < p.nodes.size(); i++)
+    for (int l = 0; l < L; l++) {
+      auto& n = *p.nodes[i];
+      if (n.levels.empty()) {
+        out[i * L + l] = 0;
+        continue;
+      }
+      auto& lv = *n.levels[l];
+      int v = 0;
+      switch (field) {
+        case 0: v = lv.posInLevel; break;
+        case 1: v = lv.outgoingFinished; break;
+        case 2: v = (int)lv.toVerifyAgg.size(); break;
+        default: throw IllegalArgumentException("field");
+      }
+      out[i * L + l] = v;
+    }
+  ORC_CATCH
+}
+// Bitsets in "natural layout": one nodeCount-bit row per node (words = nodeCount/64 rounded up),
+// bit j = node id j, union over levels (level blocks are disjoint, P/Handel.java:671-684).
+// which: 0 totalIncoming 1 lastAggVerified 2 verifiedIndSignatures 3 toVerifyInd 4 finishedPeers
+//        5 totalOutgoing of the LAST level only 6 waitedSigs
+int orc_handel_read_bits(void* h, int which, uint64_t* out) {
+  ORC_TRY auto& p = *((OrcHandel*)h)->p;
+  int N = p.params.nodeCount;
+  int W = (N + 63) / 64;
+  memset(out, 0, sizeof(uint64_t) * (size_t)W * p.nodes.size());
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    uint64_t* row = out + i * W;
+    for (size_t l = 0; l < n.levels.size(); l++) {
+      auto& lv = *n.levels[l];
+      const BitSet* b = nullptr;
+      switch (which) {
+        case 0: b = &lv.totalIncoming; break;
+        case 1: b = &lv.lastAggVerified; break;
+        case 2: b = &lv.verifiedIndSignatures; break;
+        case 3: b = &lv.toVerifyInd; break;
+        case 4: b = &lv.finishedPeers; break;
+        case 5: b = (l + 1 == n.levels.size()) ? &lv.totalOutgoing : nullptr; break;
+        case 6: b = &lv.waitedSigs; break;
+        default: throw IllegalArgumentException("which");
+      }
+      if (b)
+        for (int w = 0; w < W; w++) row[w] |= b->wordAt(w);
+    }
+  }
+  ORC_CATCH
+}
+int orc_handel_read_ranks(void* h, int node, int32_t* out) {
+  auto& n = *((OrcHandel*)h)->p->node(node);
+  memcpy(out, n.receptionRanks.data(), sizeof(int32_t) * n.receptionRanks.size());
+  return 0;
+}
+// peers of (node, level) -> ids; returns count via *cnt
+int orc_handel_read_peers(void* h, int node, int level, int32_t* out, int32_t* cnt) {
+  auto& n = *((OrcHandel*)h)->p->node(node);
+  if (n.levels.empty()) {
+    *cnt = 0;
+    return 0;
+  }
+  auto& lv = *n.levels[level];
+  *cnt = (int)lv.peers.size();
+  for (size_t i = 0; i < lv.peers.size(); i++) out[i] = lv.peers[i]->nodeId;
+  return 0;
+}
+int orc_handel_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered,
+                    uint64_t* tasks) {
+  auto& p = *((OrcHandel*)h)->p;
+  *time = p.network().time;
+  if (queueSize) *queueSize = p.network().msgs.size();
+  *rngState = p.network().rd.rawState();
+  *delivered = p.network().statDelivered;
+  *tasks = p.network().statTasks;
+  return 0;
+}
+int orc_handel_stats(void* h, uint64_t* deliveredByLevel32, int32_t* queueMax32) {
+  auto& p = *((OrcHandel*)h)->p;
+  memcpy(deliveredByLevel32, p.statDeliveredByLevel, sizeof(uint64_t) * 32);
+  memcpy(queueMax32, p.statQueueMax, sizeof(int32_t) * 32);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. The product package (wittgenstein_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_last_error.restype = C.c_char_p
+        _LIB.orc_handel_init_seconds.restype = C.c_double
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("oracle error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ck(rc):
+    if rc != 0:
+        raise OracleError(rc, lib().orc_last_error().decode())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def jrandom_ints(seed, n):
+    out = np.zeros(n, np.int32)
+    _ck(lib().orc_jrandom_ints(C.c_int64(seed), n, _p(out, C.c_int32)))
+    return out
+
+
+def jrandom_bounded(seed, bound, n):
+    out = np.zeros(n, np.int32)
+    _ck(lib().orc_jrandom_bounded(C.c_int64(seed), bound, n, _p(out, C.c_int32)))
+    return out
+
+
+def jrandom_doubles(seed, n):
+    out = np.zeros(n, np.float64)
+    _ck(lib().orc_jrandom_doubles(C.c_int64(seed), n, _p(out, C.c_double)))
+    return out
+
+
+def jrandom_booleans(seed, n):
+    out = np.zeros(n, np.uint8)
+    _ck(lib().orc_jrandom_booleans(C.c_int64(seed), n, _p(out, C.c_uint8)))
+    return out
+
+
+def jshuffle_iota(seed, n, rounds=1):
+    out = np.zeros(n, np.int32)
+    _ck(lib().orc_jshuffle_iota(C.c_int64(seed), n, rounds, _p(out, C.c_int32)))
+    return out
+
+
+def pseudo_random(node_id, seed):
+    return lib().orc_pseudo_random(C.c_int32(node_id), C.c_int32(seed))
+
+
+def latency_bydistance(dist, delta):
+    return lib().orc_latency_bydistance(dist, delta)
+
+
+def latency_table():
+    md = lib().orc_max_dist()
+    t = np.zeros((md + 1, 100), np.int32)
+    for d in range(md + 1):
+        for k in range(100):
+            t[d, k] = latency_bydistance(d, k)
+    return t
+
+
+def node_xy(rd_int):
+    x, y = C.c_int32(), C.c_int32()
+    lib().orc_node_xy(C.c_int32(rd_int), C.byref(x), C.byref(y))
+    return x.value, y.value
+
+
+class PingPong:
+    FIELDS = {"pong": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesReceived": 4, "x": 5, "y": 6,
+              "down": 7}
+
+    def __init__(self, node_ct=1000, nb=None, nl=None, seed=0):
+        self.h = C.c_void_p()
+        self.n = node_ct
+        _ck(lib().orc_pingpong_create(node_ct, nb.encode() if nb else None, nl.encode() if nl else None,
+                                      C.c_int64(seed), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pingpong_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_pingpong_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_pingpong_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_pingpong_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
+class Handel:
+    FIELDS = {"doneAt": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesReceived": 4, "sigsChecked": 5,
+              "sigQueueSize": 6, "msgFiltered": 7, "currWindowSize": 8, "addedCycle": 9, "down": 10, "x": 11,
+              "y": 12, "startAt": 13, "nodePairingTime": 14, "extraLatency": 15}
+    LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2}
+    BITS = {"totalIncoming": 0, "lastAggVerified": 1, "verifiedIndSignatures": 2, "toVerifyInd": 3,
+            "finishedPeers": 4, "totalOutgoingLast": 5, "waitedSigs": 6}
+
+    def __init__(self, node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
+                 nodes_down, nb=None, nl=None, desync=0, seed=0):
+        ip = (C.c_int32 * 9)(node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
+                             nodes_down, desync)
+        self.h = C.c_void_p()
+        self.n = node_count
+        _ck(lib().orc_handel_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                    C.byref(self.h)))
+        self.levels = lib().orc_handel_levels(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_handel_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_handel_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def cont_if(self):
+        return bool(lib().orc_handel_cont_if(self.h))
+
+    def init_seconds(self):
+        return lib().orc_handel_init_seconds(self.h)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_handel_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def read_level(self, field):
+        out = np.zeros((self.n, self.levels), np.int32)
+        _ck(lib().orc_handel_read_level(self.h, self.LEVEL_FIELDS[field], _p(out, C.c_int32)))
+        return out
+
+    def read_bits(self, which):
+        w = (self.n + 63) // 64
+        out = np.zeros((self.n, w), np.uint64)
+        _ck(lib().orc_handel_read_bits(self.h, self.BITS[which], _p(out, C.c_uint64)))
+        return out
+
+    def read_ranks(self, node):
+        out = np.zeros(self.n, np.int32)
+        lib().orc_handel_read_ranks(self.h, node, _p(out, C.c_int32))
+        return out
+
+    def read_peers(self, node, level):
+        out = np.zeros(self.n, np.int32)
+        cnt = C.c_int32()
+        lib().orc_handel_read_peers(self.h, node, level, _p(out, C.c_int32), C.byref(cnt))
+        return out[:cnt.value].copy()
+
+    def info(self, with_queue=True):
+        t, q, r, d, k = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().orc_handel_info(self.h, C.byref(t), C.byref(q) if with_queue else None, C.byref(r), C.byref(d),
+                              C.byref(k))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value}
+
+    def stats(self):
+        dl = np.zeros(32, np.uint64)
+        qm = np.zeros(32, np.int32)
+        lib().orc_handel_stats(self.h, _p(dl, C.c_uint64), _p(qm, C.c_int32))
+        return {"deliveredByLevel": dl[:self.levels].copy(), "queueMax": qm[:self.levels].copy()}
