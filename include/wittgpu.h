@@ -1,0 +1,161 @@
+/*
+ * wittgpu.h — C ABI of libwittgpu.so, the MI355X-native engine behind Wittgenstein's
+ * core.Network scheduler (runMs / send / message queue / NetworkLatency sampling).
+ *
+ * The reference has no FFI boundary for this path: protocols are written against the Java class
+ * core.Network (core/src/main/java/net/consensys/wittgenstein/core/Network.java, "C/Network.java"
+ * below). Each entry point cites the reference method(s) it replaces. A JNI shim binding these is
+ * shown in INTEGRATION.md. Conventions:
+ *   - plain pointers and sizes; caller owns every buffer; the engine copies before returning;
+ *   - single caller thread per engine (C/Network.java:7-11); not re-entrant;
+ *   - every call returns a wg_status; WG_EINVAL <=> the reference's IllegalArgumentException sites
+ *     (C/Network.java:320,371,374,386,427,695), WG_ESTATE <=> its IllegalStateException sites
+ *     (:137,250,333,472,599,609,656,671); wg_last_error() has the message text.
+ */
+#ifndef WITTGPU_H
+#define WITTGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wg_engine wg_engine;
+
+typedef enum {
+  WG_OK = 0,
+  WG_EINVAL = -1,   /* IllegalArgumentException */
+  WG_ESTATE = -2,   /* IllegalStateException */
+  WG_ENOMEM = -3,   /* a device pool/ring overflowed (raise the wg_config capacity named in the message) */
+  WG_EHIP = -4,     /* HIP runtime error / no device */
+  WG_EUNSUPPORTED = -5 /* a reference feature the resident protocol does not cover (message says which) */
+} wg_status;
+
+/* Engine capacities. 0 = pick a default from node count / protocol. */
+typedef struct {
+  int32_t device;               /* HIP device ordinal */
+  int32_t horizon_ms;           /* power of two > max(arrival - time); ring of per-ms buckets (C/Network.java:116-132) */
+  int64_t bucket_pool_records;  /* total in-flight envelope records (paged) */
+  int64_t payload_words;        /* 64-bit words of in-flight message payload (bitsets) */
+  int64_t outbox_records;       /* max records emitted within one simulated ms */
+  int64_t chain_dests;          /* total destination ids held by in-flight multi-destination envelopes */
+  int32_t chain_slots;          /* in-flight multi-destination envelopes (C/Envelope.java:57) */
+  int32_t queue_cap;            /* Handel: per (node, level) toVerifyAgg capacity (P/Handel.java:385), <= 64 */
+} wg_config;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int32_t wg_create(const wg_config* cfg, wg_engine** out);       /* new Network<>()  C/Network.java:14-49 */
+void wg_destroy(wg_engine* e);
+const char* wg_last_error(wg_engine* e);                        /* e may be NULL: error of a failed wg_create */
+
+/* ---- topology --------------------------------------------------------------------------- */
+/* Network.addNode for n nodes with dense ids continuing from the current count (C/Network.java:651-659);
+ * fields are Node's (C/Node.java:22-79). down/byzantine/speedRatio/extraLatency may be NULL (0 / 0 / 1.0 / 0). */
+int32_t wg_add_nodes(wg_engine* e, int32_t n, const int32_t* x, const int32_t* y, const int32_t* extraLatency,
+                     const uint8_t* down, const uint8_t* byzantine, const double* speedRatio);
+int32_t wg_node_count(wg_engine* e);
+
+typedef enum {
+  WG_LAT_BY_DISTANCE_WJITTER = 0, /* NetworkLatency.NetworkLatencyByDistanceWJitter  C/NetworkLatency.java:49-73 */
+  WG_LAT_FIXED = 1,               /* NetworkFixedLatency(params[0])    :235-249 */
+  WG_LAT_UNIFORM = 2,             /* NetworkUniformLatency(params[0])  :255-269 */
+  WG_LAT_NONE = 3,                /* NetworkNoLatency                  :271-275 */
+  WG_LAT_MEASURED = 4,            /* MeasuredNetworkLatency, params = longDistrib[100]  :277-313 */
+  WG_LAT_IC3 = 5,                 /* IC3NetworkLatency                 :399-417 */
+  WG_LAT_ETHSCAN = 6              /* EthScanNetworkLatency             :366-384 */
+} wg_latency_kind;
+/* Network.setNetworkLatency (C/Network.java:666-678): WG_ESTATE if messages are in flight. */
+int32_t wg_set_latency(wg_engine* e, int32_t kind, const int32_t* params, int32_t nparams);
+/* RegistryNetworkLatencies.getByName (C/RegistryNetworkLatencies.java:42-58); NULL = ByDistanceWJitter */
+int32_t wg_set_latency_by_name(wg_engine* e, const char* name);
+/* getLatency(from, to, delta) of the installed model, evaluated by the device kernel (tests, estimateLatency) */
+int32_t wg_latency_probe(wg_engine* e, int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta,
+                         int32_t* out);
+int32_t wg_set_partitions(wg_engine* e, const int32_t* xcuts, int32_t k); /* partition()/endPartition()  :693-707 */
+int32_t wg_set_node_down(wg_engine* e, int32_t id, int32_t down);        /* Node.stop()/start()  C/Node.java:120-131 */
+int32_t wg_set_discard_time(wg_engine* e, int32_t ms);                   /* setMsgDiscardTime  C/Network.java:103-107 */
+
+/* ---- RNG: the single shared java.util.Random `rd` (C/Network.java:32) --------------------- */
+int32_t wg_rng_set_seed(wg_engine* e, int64_t seed);            /* rd.setSeed  C/RunMultipleTimes.java:47 */
+int32_t wg_rng_get_state(wg_engine* e, uint64_t* s48);
+int32_t wg_rng_set_state(wg_engine* e, uint64_t s48);
+
+/* ---- host-side sends / tasks (init() code paths; action() of resident protocols runs on device) */
+/* Network.send(m, sendTime, from, dests, delayBetween) C/Network.java:369-382,418-447 (n==1: single-dest
+ * overload). msg = protocol message word, payload = protocol payload handle. Draws one rd.nextInt(). */
+int32_t wg_send(wg_engine* e, uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests,
+                int32_t n, int32_t delayBetween);
+/* Network.registerTask / registerPeriodicTask (C/Network.java:505-519): task = protocol task word */
+int32_t wg_register_task(wg_engine* e, uint32_t task, uint32_t arg, int32_t startAt, int32_t node);
+int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, int32_t period, int32_t node);
+
+/* ---- resident protocols ----------------------------------------------------------------- */
+typedef enum { WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2 } wg_proto_id;
+
+/* Handel parameters: HandelParameters ctor order (P/Handel.java:97-142) + WindowParameters (:147-174) */
+typedef struct {
+  int32_t nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath, nodesDown;
+  int32_t desynchronizedStart;
+  int32_t windowInitial, windowMinimum, windowMaximum; /* 16, 1, 128 */
+} wg_handel_params;
+
+/* Per-node state produced by Handel.init() (P/Handel.java:957-1014), uploaded once:
+ *   startAt[n], nodePairingTime[n]   HNode fields (:280-283)
+ *   receptionRanks[n*n]              row i = HNode i's receptionRanks (:285, :940-948)
+ *   peers[n*(n-1)]                   row i = concatenation over levels 1..L-1 of HLevel.peers (emission
+ *                                    order, :510-522); level l occupies [2^(l-1)-1, 2^l-1). Ignored for down nodes. */
+typedef struct {
+  const int32_t* startAt;
+  const int32_t* nodePairingTime;
+  const int32_t* receptionRanks;
+  const int32_t* peers;
+} wg_handel_init_state;
+
+int32_t wg_protocol_load(wg_engine* e, int32_t proto_id, const void* params, const void* init_state);
+
+/* ---- run -------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t delivered;     /* sum of msgReceived increments (C/Network.java:607-613) during this call */
+  int64_t tasks;         /* Task envelopes executed */
+  int64_t events;        /* envelopes polled (delivered + tasks + skipped because down/partitioned) */
+  int64_t draws;         /* rd draws consumed */
+  int64_t simulated_ms;
+  int64_t wall_ns;       /* host wall time of the call, device idle at both ends */
+  int64_t payload_bytes; /* message payload bytes read at delivery (roofline accounting) */
+} wg_run_stats;
+/* Network.runMs (C/Network.java:318-338). stats may be NULL. */
+int32_t wg_run_ms(wg_engine* e, int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
+int32_t wg_time(wg_engine* e, int32_t* time);                   /* Network.time  :49 */
+int32_t wg_queue_size(wg_engine* e, int64_t* size);             /* msgs.size()   :204-210 */
+int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt(t) :212-220 */
+
+/* ---- read-back -------------------------------------------------------------------------- */
+typedef enum {
+  /* Node counters (C/Node.java:69-79) */
+  WG_F_DONE_AT = 0, WG_F_MSG_RECEIVED = 1, WG_F_MSG_SENT = 2, WG_F_BYTES_SENT = 3, WG_F_BYTES_RECEIVED = 4,
+  WG_F_DOWN = 5, WG_F_X = 6, WG_F_Y = 7, WG_F_EXTRA_LATENCY = 8,
+  /* PingPong (P/PingPong.java:61) */
+  WG_F_PONG = 16,
+  /* Handel HNode (P/Handel.java:280-299) */
+  WG_F_SIGS_CHECKED = 32, WG_F_SIG_QUEUE_SIZE = 33, WG_F_MSG_FILTERED = 34, WG_F_CURR_WINDOW_SIZE = 35,
+  WG_F_ADDED_CYCLE = 36, WG_F_START_AT = 37, WG_F_NODE_PAIRING_TIME = 38
+} wg_field;
+int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
+typedef enum { /* per (node, level), row-major [node][level] */
+  WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2
+} wg_level_field;
+int32_t wg_read_level_i32(wg_engine* e, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels);
+typedef enum { /* Handel HLevel bitsets (P/Handel.java:373-394) as one nodeCount-bit row per node, bit j = node j */
+  WG_B_TOTAL_INCOMING = 0, WG_B_LAST_AGG_VERIFIED = 1, WG_B_VERIFIED_IND = 2, WG_B_TO_VERIFY_IND = 3,
+  WG_B_FINISHED_PEERS = 4
+} wg_bits_field;
+int32_t wg_read_bits(wg_engine* e, int32_t field, uint64_t* dst, int32_t n_nodes, int32_t words_per_node);
+int32_t wg_levels(wg_engine* e, int32_t* levels);
+/* per-level count of SendSigs delivered so far (roofline accounting); dst[32] */
+int32_t wg_delivered_by_level(wg_engine* e, int64_t* dst32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WITTGPU_H */

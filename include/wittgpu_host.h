@@ -1,0 +1,37 @@
+/*
+ * wittgpu_host.h — host-side mirror of the reference's Protocol objects for the resident
+ * protocols, written in C++ because no JVM exists in the build environment (INTEGRATION.md shows
+ * the Java-side equivalent). Each call restates `new P(params); network.rd.setSeed(seed); p.init()`
+ * with java.util.Random semantics and hands the result to the C ABI of wittgpu.h:
+ *   PingPong.init()  P/PingPong.java:81-87
+ *   Handel.init()    P/Handel.java:957-1014  (+ HandelParameters checks :113-125)
+ * (P/ = protocols/src/main/java/net/consensys/wittgenstein/protocols/)
+ */
+#ifndef WITTGPU_HOST_H
+#define WITTGPU_HOST_H
+#include "wittgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nodeBuilderName: RegistryNodeBuilders name, RANDOM location only ("RANDOM_SPEED=CONSTANT_TOR=0.00",
+ * NULL = that default; C/RegistryNodeBuilders.java:28-81). latencyName: RegistryNetworkLatencies name
+ * (NULL = NetworkLatencyByDistanceWJitter). On failure *out is NULL and wgh_last_error() has the text. */
+int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                            const wg_config* cfg, wg_engine** out);
+int32_t wgh_handel_create(const wg_handel_params* params, const char* nodeBuilderName, const char* latencyName,
+                          int64_t seed, const wg_config* cfg, wg_engine** out);
+const char* wgh_last_error(void);
+/* seconds spent in the host-side init() of the last wgh_*_create on this thread */
+double wgh_last_init_seconds(void);
+
+/* java.util.Random known-answer probes of the product's own generator (tests) */
+int32_t wgh_jrandom_ints(int64_t seed, int32_t n, int32_t* out);
+int32_t wgh_jrandom_skip_ints(int64_t seed, int32_t n, int32_t* out); /* same values via LCG jump-ahead */
+int32_t wgh_jrandom_bounded(int64_t seed, int32_t bound, int32_t n, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

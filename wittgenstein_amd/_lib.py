@@ -1,0 +1,61 @@
+"""ctypes binding of libwittgpu.so (include/wittgpu.h, include/wittgpu_host.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the
+package raises instead of computing anything on the host.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwittgpu.so")
+
+
+class wg_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("horizon_ms", C.c_int32), ("bucket_pool_records", C.c_int64),
+                ("payload_words", C.c_int64), ("outbox_records", C.c_int64), ("chain_dests", C.c_int64),
+                ("chain_slots", C.c_int32), ("queue_cap", C.c_int32)]
+
+
+class wg_handel_params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nodeCount", "threshold", "pairingTime", "levelWaitTime", "extraCycle", "disseminationPeriodMs", "fastPath",
+        "nodesDown", "desynchronizedStart", "windowInitial", "windowMinimum", "windowMaximum")]
+
+
+class wg_run_stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("delivered", "tasks", "events", "draws", "simulated_ms", "wall_ns",
+                                         "payload_bytes")]
+
+
+# every symbol include/wittgpu.h and include/wittgpu_host.h declare
+ABI_SYMBOLS = [
+    "wg_create", "wg_destroy", "wg_last_error", "wg_add_nodes", "wg_node_count", "wg_set_latency",
+    "wg_set_latency_by_name", "wg_latency_probe", "wg_set_partitions", "wg_set_node_down", "wg_set_discard_time",
+    "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_register_task",
+    "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
+    "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
+    "wgh_pingpong_create", "wgh_handel_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
+    "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",
+]
+
+WG_OK, WG_EINVAL, WG_ESTATE, WG_ENOMEM, WG_EHIP, WG_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(wittgenstein_amd has no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.wg_last_error.restype = C.c_char_p
+        l.wg_last_error.argtypes = [C.c_void_p]
+        l.wgh_last_error.restype = C.c_char_p
+        l.wgh_last_init_seconds.restype = C.c_double
+        l.wg_destroy.restype = None
+        l.wg_destroy.argtypes = [C.c_void_p]
+        _lib = l
+    return _lib

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's `core` package surface for the scheduler path:
+Network (C/Network.java), the exceptions it throws, node read-back.
+
+Method names follow the Java API (runMs, run, time, msgs.size()) so tests read like the
+reference's own; everything executes in libwittgpu.so on the MI355X.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class IllegalArgumentException(ValueError):
+    """java.lang.IllegalArgumentException sites of C/Network.java (:320,371,374,386,427,695)."""
+
+
+class IllegalStateException(RuntimeError):
+    """java.lang.IllegalStateException sites of C/Network.java (:137,250,333,472,599,609,656,671)."""
+
+
+class EngineCapacityError(MemoryError):
+    """A device ring / pool configured through wg_config overflowed (WG_ENOMEM)."""
+
+
+class HipError(RuntimeError):
+    """HIP runtime failure or no device (WG_EHIP)."""
+
+
+class UnsupportedError(NotImplementedError):
+    """A reference feature the resident device protocol does not cover (WG_EUNSUPPORTED)."""
+
+
+_EXC = {L.WG_EINVAL: IllegalArgumentException, L.WG_ESTATE: IllegalStateException, L.WG_ENOMEM: EngineCapacityError,
+        L.WG_EHIP: HipError, L.WG_EUNSUPPORTED: UnsupportedError}
+
+
+def _raise(rc, msg):
+    raise _EXC.get(rc, RuntimeError)(msg)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+FIELDS = {"doneAt": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesReceived": 4, "down": 5, "x": 6, "y": 7,
+          "extraLatency": 8, "pong": 16, "sigsChecked": 32, "sigQueueSize": 33, "msgFiltered": 34,
+          "currWindowSize": 35, "addedCycle": 36, "startAt": 37, "nodePairingTime": 38}
+LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2}
+BITS = {"totalIncoming": 0, "lastAggVerified": 1, "verifiedIndSignatures": 2, "toVerifyInd": 3, "finishedPeers": 4}
+
+
+class MessageStorage:
+    """Network.msgs (C/Network.java:201-299): size() and sizeAt(t) only — the queue lives in HBM."""
+
+    def __init__(self, net):
+        self._net = net
+
+    def size(self):
+        v = C.c_int64()
+        self._net._ck(L.lib().wg_queue_size(self._net._h, C.byref(v)))
+        return v.value
+
+    def sizeAt(self, t):
+        v = C.c_int64()
+        self._net._ck(L.lib().wg_queue_size_at(self._net._h, int(t), C.byref(v)))
+        return v.value
+
+
+class Network:
+    """core.Network over a wg_engine handle."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.msgs = MessageStorage(self)
+        self.last_stats = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().wg_destroy(h)
+
+    def _ck(self, rc):
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wg_last_error(self._h).decode())
+
+    @property
+    def time(self):
+        t = C.c_int32()
+        self._ck(L.lib().wg_time(self._h, C.byref(t)))
+        return t.value
+
+    @property
+    def node_count(self):
+        return L.lib().wg_node_count(self._h)
+
+    def runMs(self, ms):
+        """Network.runMs (C/Network.java:318-338); returns didSomething."""
+        did = C.c_uint8()
+        st = L.wg_run_stats()
+        self._ck(L.lib().wg_run_ms(self._h, int(ms), C.byref(did), C.byref(st)))
+        self.last_stats = {n: getattr(st, n) for n, _ in L.wg_run_stats._fields_}
+        return bool(did.value)
+
+    def run(self, seconds):
+        return self.runMs(seconds * 1000)
+
+    def partition(self, part):
+        """Network.partition (C/Network.java:693-703): cut at (int)(MAX_X * part)."""
+        if part <= 0 or part >= 1:
+            raise IllegalArgumentException("part needs to be a percentage between 0 & 100 excluded")
+        cuts = getattr(self, "_cuts", [])
+        x = int(np.float32(2000) * np.float32(part))
+        if x in cuts:
+            raise IllegalArgumentException("this partition exists already")
+        cuts = sorted(cuts + [x])
+        arr = (C.c_int32 * len(cuts))(*cuts)
+        self._ck(L.lib().wg_set_partitions(self._h, arr, len(cuts)))
+        self._cuts = cuts
+
+    def endPartition(self):
+        self._ck(L.lib().wg_set_partitions(self._h, None, 0))
+        self._cuts = []
+
+    def rng_state(self):
+        s = C.c_uint64()
+        self._ck(L.lib().wg_rng_get_state(self._h, C.byref(s)))
+        return s.value
+
+    def read(self, field):
+        n = self.node_count
+        out = np.zeros(n, np.int64)
+        self._ck(L.lib().wg_read_i64(self._h, FIELDS[field], _p(out, C.c_int64), n))
+        return out
+
+    def levels(self):
+        v = C.c_int32()
+        self._ck(L.lib().wg_levels(self._h, C.byref(v)))
+        return v.value
+
+    def read_level(self, field):
+        n, l = self.node_count, self.levels()
+        out = np.zeros((n, l), np.int32)
+        self._ck(L.lib().wg_read_level_i32(self._h, LEVEL_FIELDS[field], _p(out, C.c_int32), n, l))
+        return out
+
+    def read_bits(self, field):
+        n = self.node_count
+        w = max(1, n // 64)
+        out = np.zeros((n, w), np.uint64)
+        self._ck(L.lib().wg_read_bits(self._h, BITS[field], _p(out, C.c_uint64), n, w))
+        return out
+
+    def delivered_by_level(self):
+        out = np.zeros(32, np.int64)
+        self._ck(L.lib().wg_delivered_by_level(self._h, _p(out, C.c_int64)))
+        return out
+
+    def latency_probe(self, frm, to, delta):
+        frm = np.ascontiguousarray(frm, np.int32)
+        to = np.ascontiguousarray(to, np.int32)
+        delta = np.ascontiguousarray(delta, np.int32)
+        out = np.zeros(len(frm), np.int32)
+        self._ck(L.lib().wg_latency_probe(self._h, len(frm), _p(frm, C.c_int32), _p(to, C.c_int32),
+                                          _p(delta, C.c_int32), _p(out, C.c_int32)))
+        return out

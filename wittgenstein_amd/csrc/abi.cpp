@@ -1,0 +1,166 @@
+// extern "C" surface of libwittgpu.so (include/wittgpu.h). Thin: argument checks, exception ->
+// status mapping, no engine logic.
+#include <cstring>
+#include "engine_host.h"
+
+using namespace wg;
+
+struct wg_engine {
+  Engine* e;
+};
+static thread_local std::string g_createError;
+
+#define WG_TRY(h)                       \
+  if (!(h)) return WG_EINVAL;           \
+  Engine& E = *(h)->e;                  \
+  try {
+#define WG_END                          \
+  }                                     \
+  catch (const WgError& x) {            \
+    E.lastError = x.what();             \
+    return x.code;                      \
+  }                                     \
+  catch (const std::bad_alloc&) {       \
+    E.lastError = "host out of memory"; \
+    return WG_ENOMEM;                   \
+  }                                     \
+  catch (const std::exception& x) {     \
+    E.lastError = x.what();             \
+    return WG_ESTATE;                   \
+  }                                     \
+  return WG_OK;
+
+extern "C" {
+
+int32_t wg_create(const wg_config* cfg, wg_engine** out) {
+  if (!out) return WG_EINVAL;
+  *out = nullptr;
+  wg_config c;
+  memset(&c, 0, sizeof(c));
+  if (cfg) c = *cfg;
+  try {
+    Engine* e = new Engine(c);
+    *out = new wg_engine{e};
+  } catch (const WgError& x) {
+    g_createError = x.what();
+    return x.code;
+  } catch (const std::exception& x) {
+    g_createError = x.what();
+    return WG_EHIP;
+  }
+  return WG_OK;
+}
+void wg_destroy(wg_engine* h) {
+  if (!h) return;
+  delete h->e;
+  delete h;
+}
+const char* wg_last_error(wg_engine* h) { return h ? h->e->lastError.c_str() : g_createError.c_str(); }
+
+int32_t wg_add_nodes(wg_engine* h, int32_t n, const int32_t* x, const int32_t* y, const int32_t* extraLatency,
+                     const uint8_t* down, const uint8_t* byzantine, const double* speedRatio) {
+  WG_TRY(h) E.add_nodes(n, x, y, extraLatency, down, byzantine, speedRatio);
+  WG_END
+}
+int32_t wg_node_count(wg_engine* h) { return h ? (int32_t)h->e->hx.size() : 0; }
+int32_t wg_set_latency(wg_engine* h, int32_t kind, const int32_t* params, int32_t nparams) {
+  WG_TRY(h) E.set_latency(kind, params, nparams);
+  WG_END
+}
+int32_t wg_set_latency_by_name(wg_engine* h, const char* name) {
+  WG_TRY(h) E.set_latency_by_name(name);
+  WG_END
+}
+int32_t wg_latency_probe(wg_engine* h, int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta,
+                         int32_t* out) {
+  WG_TRY(h) E.latency_probe(n, from, to, delta, out);
+  WG_END
+}
+int32_t wg_set_partitions(wg_engine* h, const int32_t* xcuts, int32_t k) {
+  WG_TRY(h) E.set_partitions(xcuts, k);
+  WG_END
+}
+int32_t wg_set_node_down(wg_engine* h, int32_t id, int32_t down) {
+  WG_TRY(h) E.set_node_down(id, down != 0);
+  WG_END
+}
+int32_t wg_set_discard_time(wg_engine* h, int32_t ms) {
+  WG_TRY(h)
+  if (E.allocated) throw WgError(WG_ESTATE, "set the discard time before the first run");
+  E.discardTime = ms;
+  WG_END
+}
+int32_t wg_rng_set_seed(wg_engine* h, int64_t seed) {
+  WG_TRY(h) E.gh.rng = lcg_scramble(seed);
+  E.globalsDirty = true;
+  WG_END
+}
+int32_t wg_rng_get_state(wg_engine* h, uint64_t* s48) {
+  WG_TRY(h)* s48 = E.gh.rng;
+  WG_END
+}
+int32_t wg_rng_set_state(wg_engine* h, uint64_t s48) {
+  WG_TRY(h) E.gh.rng = s48 & LCG_MASK;
+  E.globalsDirty = true;
+  WG_END
+}
+int32_t wg_send(wg_engine* h, uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests,
+                int32_t n, int32_t delayBetween) {
+  WG_TRY(h) E.send(msg, payload, sendTime, from, dests, n, delayBetween);
+  WG_END
+}
+int32_t wg_register_task(wg_engine* h, uint32_t task, uint32_t arg, int32_t startAt, int32_t node) {
+  WG_TRY(h) E.register_task(task, arg, startAt, node);
+  WG_END
+}
+int32_t wg_register_periodic_task(wg_engine* h, uint32_t task, int32_t startAt, int32_t period, int32_t node) {
+  WG_TRY(h) E.register_periodic_task(task, startAt, period, node);
+  WG_END
+}
+int32_t wg_protocol_load(wg_engine* h, int32_t proto_id, const void* params, const void* init_state) {
+  WG_TRY(h) E.load_protocol(proto_id, params, init_state);
+  WG_END
+}
+int32_t wg_run_ms(wg_engine* h, int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
+  WG_TRY(h) E.run_ms(ms, didSomething, stats);
+  WG_END
+}
+int32_t wg_time(wg_engine* h, int32_t* time) {
+  WG_TRY(h)* time = E.time;
+  WG_END
+}
+int32_t wg_queue_size(wg_engine* h, int64_t* size) {
+  WG_TRY(h)* size = E.queue_size();
+  WG_END
+}
+int32_t wg_queue_size_at(wg_engine* h, int32_t t, int64_t* size) {
+  WG_TRY(h)* size = E.queue_size_at(t);
+  WG_END
+}
+int32_t wg_read_i64(wg_engine* h, int32_t field, int64_t* dst, int32_t n) {
+  WG_TRY(h) E.read_i64(field, dst, n);
+  WG_END
+}
+int32_t wg_read_level_i32(wg_engine* h, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels) {
+  WG_TRY(h)
+  if (!E.proto || !E.proto->read_level_i32(E, field, dst, n_nodes, n_levels))
+    throw WgError(WG_EINVAL, "unknown level field for the resident protocol");
+  WG_END
+}
+int32_t wg_read_bits(wg_engine* h, int32_t field, uint64_t* dst, int32_t n_nodes, int32_t words_per_node) {
+  WG_TRY(h)
+  if (!E.proto || !E.proto->read_bits(E, field, dst, n_nodes, words_per_node))
+    throw WgError(WG_EINVAL, "unknown bitset field for the resident protocol");
+  WG_END
+}
+int32_t wg_levels(wg_engine* h, int32_t* levels) {
+  WG_TRY(h)* levels = E.proto ? E.proto->levels() : 0;
+  WG_END
+}
+int32_t wg_delivered_by_level(wg_engine* h, int64_t* dst32) {
+  WG_TRY(h)
+  for (int i = 0; i < 32; i++) dst32[i] = (int64_t)E.gh.deliveredByLevel[i];
+  WG_END
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// Shared host/device definitions of the time-stepped engine that replaces core.Network's
+// runMs()/receiveUntil()/nextMessage()/send() loop (C/Network.java:318-338,533-637,369-487).
+//
+// Data layout in HBM (all struct-of-arrays, one simulated node per index):
+//   nodes      x,y (int16), extraLatency, down, partition id, 4 x int64 counters, doneAt
+//   buckets    ring of `horizon` per-ms buckets (the reference's MsgsSlot array, :116-132); a bucket is
+//              a list of 16-byte envelope records kept in PUSH ORDER inside 1024-record pages drawn
+//              from one pool. LIFO drain (:145-161) = reverse iteration.
+//   chains     MultipleDestEnvelope (C/Envelope.java:57-155): {from, seed, sendTime, ndest, destOff}
+//              + a ring of destination ids sorted by arrival.
+//   payload    ring of 64-bit words holding immutable message payloads (Handel bitsets).
+//   per-ms scratch: events (expanded bucket), per-node inbox, unordered outbox, ordered outbox.
+#pragma once
+#include <stdint.h>
+#include "jdk_random.h"
+
+namespace wg {
+
+constexpr int PAGE_SHIFT = 10;
+constexpr int PAGE_RECS = 1 << PAGE_SHIFT;
+constexpr int MAX_CUTS = 8;
+constexpr int MAX_LEVELS = 24;
+
+enum RecKind : uint32_t { K_MSG = 0, K_TASK = 1, K_PERIODIC = 2, K_CHAIN = 3 };
+
+// 16-byte envelope record (SingleDestEnvelope C/Envelope.java:230-234 is {from,to,arrival,message};
+// arrival is implied by the bucket).
+struct Rec {
+  uint32_t w0;  // kind << 28 | from
+  uint32_t w1;  // MSG: to | TASK/PERIODIC: node | CHAIN: chain slot
+  uint32_t w2;  // MSG: message word | TASK/PERIODIC: task word | CHAIN: curPos
+  uint32_t w3;  // MSG: payload ref | TASK: arg | PERIODIC: period | CHAIN: 0
+};
+WG_HD inline uint32_t rec_kind(const Rec& r) { return r.w0 >> 28; }
+WG_HD inline int32_t rec_from(const Rec& r) { return (int32_t)(r.w0 & 0x0FFFFFFFu); }
+WG_HD inline Rec make_rec(uint32_t kind, int32_t from, uint32_t w1, uint32_t w2, uint32_t w3) {
+  Rec r;
+  r.w0 = (kind << 28) | (uint32_t)from;
+  r.w1 = w1;
+  r.w2 = w2;
+  r.w3 = w3;
+  return r;
+}
+
+struct Chain {  // 32 bytes
+  int32_t from;
+  int32_t seed;
+  int32_t sendTime;
+  int32_t ndest;
+  uint32_t destOff;   // into the dest ring; explicit arrivals (WithDelay envelopes) follow at destOff+ndest
+  uint32_t msg;
+  uint32_t payload;
+  uint32_t flags;     // bit0: busy, bit1: explicit arrivals (MultipleDestWithDelayEnvelope :157-228)
+};
+
+enum OutKind : uint32_t { O_SEND = 0, O_MULTI = 1, O_TASK = 2, O_PERIODIC = 3, O_CHAINCONT = 4 };
+
+// 32-byte unordered outbox record written by action() code; (ev, sub) is its place in the global
+// push order, drawsub its rd.nextInt() ordinal inside the event.
+struct Out {
+  uint32_t ev;
+  uint32_t subs;      // sub | drawsub << 16
+  uint32_t kindfrom;  // OutKind << 28 | from
+  int32_t to;         // SEND: dest | MULTI: ndest | TASK/PERIODIC: node | CHAINCONT: chain slot
+  uint32_t a;         // SEND/MULTI: message word | TASK/PERIODIC: task word | CHAINCONT: pos
+  uint32_t b;         // SEND/MULTI: payload | TASK: arg | PERIODIC: period
+  int32_t t;          // SEND/MULTI: sendTime | TASK/PERIODIC: arrival
+  uint32_t destOff;   // MULTI: offset of the (unsorted) dest list in the dest ring
+};
+
+enum LatKind : int32_t { LAT_BYDIST = 0, LAT_FIXED = 1, LAT_UNIFORM = 2, LAT_NONE = 3, LAT_MEASURED = 4, LAT_IC3 = 5, LAT_ETHSCAN = 6 };
+
+enum ErrBits : uint32_t {
+  ERR_BUCKET_POOL = 1u << 0,   // out of bucket pages
+  ERR_BUCKET_PAGES = 1u << 1,  // one bucket exceeded max pages per bucket
+  ERR_OUTBOX = 1u << 2,
+  ERR_HORIZON = 1u << 3,       // arrival - time >= horizon
+  ERR_SAME_MS = 1u << 4,       // device action pushed into the bucket being drained
+  ERR_CHAIN_SLOTS = 1u << 5,
+  ERR_CHAIN_DESTS = 1u << 6,
+  ERR_PAYLOAD = 1u << 7,
+  ERR_QUEUE_CAP = 1u << 8,     // Handel toVerifyAgg capacity
+  ERR_MULTI_TOO_BIG = 1u << 9, // device multi-dest send with > 64 destinations
+  ERR_PENDING = 1u << 10,      // Handel pending-verification table full
+  ERR_PROTOCOL = 1u << 11,     // a reference IllegalStateException site inside action()
+  ERR_EVENTS = 1u << 12,       // events in one ms exceed scratch capacity
+  ERR_ARRIVAL_PAST = 1u << 13
+};
+
+// Device-resident engine globals (one instance).
+struct Globals {
+  uint64_t rng;            // rd's 48-bit state (C/Network.java:32)
+  uint32_t epoch;          // nextMessage() call counter
+  uint32_t err;
+  // cumulative statistics
+  unsigned long long delivered, tasks, events, draws, payloadBytes;
+  unsigned long long deliveredByLevel[32];
+  uint32_t anyEvent;       // receiveUntil's didSomething
+  // per-ms scratch counters
+  uint32_t nEvents;        // events in the bucket being drained (after chain-run expansion)
+  uint32_t nActive;        // nodes with >= 1 event
+  uint32_t nOutTmp;        // unordered outbox fill
+  uint32_t nOut;           // ordered outbox length
+  uint32_t nDraws;         // draws in this phase
+  uint32_t rejectSeen;     // a nextInt(bound) rejection happened in this phase
+  // allocators
+  uint32_t freeTop;        // free bucket pages
+  uint32_t chainHead;      // monotone
+  unsigned long long destHead;     // monotone (ring index = destHead % chainDests)
+  unsigned long long payloadHead;  // monotone, in 64-bit words
+};
+
+struct LatencyModel {
+  int32_t kind;
+  int32_t param;            // FIXED: latency, UNIFORM: maxLatency
+  const uint8_t* lutDist;   // BYDIST: [1145][100]
+  const int32_t* tabDelta;  // MEASURED/ETHSCAN/UNIFORM: [100]
+  const int32_t* tabDist;   // IC3: [1145]
+};
+
+struct NodeArrays {
+  int32_t n;
+  int16_t* x;
+  int16_t* y;
+  int32_t* extraLatency;
+  uint8_t* down;
+  uint8_t* part;            // partitionId (C/Network.java:639-649), recomputed on partition()
+  long long* msgReceived;
+  long long* msgSent;
+  long long* bytesSent;
+  long long* bytesReceived;
+  long long* doneAt;
+};
+
+// Everything a kernel needs, passed by value.
+struct EngineDev {
+  Globals* g;
+  NodeArrays nodes;
+  LatencyModel lat;
+  int32_t discardTime;
+  // buckets
+  int32_t horizon;          // D (power of two)
+  int32_t maxPagesPerBucket;
+  uint32_t nPages;
+  Rec* pool;
+  uint32_t* freeStack;
+  uint32_t* pagetab;        // [D][maxPagesPerBucket]
+  uint32_t* bcnt;           // [D]
+  // chains
+  Chain* chains;
+  uint32_t chainSlots;
+  int32_t* dests;
+  unsigned long long chainDests;
+  // payload ring
+  uint64_t* payload;
+  unsigned long long payloadWords;
+  // ring-safety bookkeeping: allocator heads at the end of each of the last `horizon` ms. Everything
+  // allocated at ms s is dead by s + horizon (arrival - time < horizon is enforced), so a ring is
+  // safe iff head(t) - head(t - horizon) <= capacity.
+  unsigned long long* destHeadAt;     // [D]
+  unsigned long long* payloadHeadAt;  // [D]
+  // per-ms scratch
+  uint32_t maxEvents;
+  Rec* ev;                  // expanded events (MSG/TASK/PERIODIC form)
+  int32_t* evChain;         // chain slot of a chain hop, else -1
+  int32_t* evCpos;          // position inside the chain
+  uint8_t* evLast;          // 1 = last event of its chain run
+  uint32_t* evNrec;         // records emitted by the event
+  uint32_t* evNdraw;
+  uint32_t* evRecOff;
+  uint32_t* evDrawOff;
+  uint32_t* cntN;           // [n] events per node this ms
+  uint32_t* fillN;
+  uint32_t* nodeOff;
+  uint32_t* active;
+  uint32_t* inbox;
+  uint32_t* inbox2;
+  uint32_t maxOut;
+  Out* outTmp;
+  Rec* fin;                 // ordered outbox
+  int32_t* arr;             // arrival per ordered record, -1 = dropped at send time
+  // multisplit scratch
+  uint32_t* tileHist;       // [maxTiles][D]
+  uint32_t* binBase;        // [D] position of this phase's first record inside each bucket
+  // scan scratch
+  unsigned long long* scanPartials;
+};
+
+WG_HD inline int32_t isqrt_floor(int32_t v) {  // (int) Math.sqrt(v), C/Node.java:281
+  int32_t r = (int32_t)
+#if defined(__HIP_DEVICE_COMPILE__)
+      __fsqrt_rn((float)v);
+#else
+      __builtin_sqrtf((float)v);
+#endif
+  while (r * r > v) r--;
+  while ((r + 1) * (r + 1) <= v) r++;
+  return r;
+}
+
+WG_HD inline int32_t node_dist(int32_t x1, int32_t y1, int32_t x2, int32_t y2) {  // C/Node.java:278-282
+  int32_t ax = x1 > x2 ? x1 - x2 : x2 - x1;
+  int32_t ay = y1 > y2 ? y1 - y2 : y2 - y1;
+  int32_t dx = ax < 2000 - ax ? ax : 2000 - ax;
+  int32_t dy = ay < 1112 - ay ? ay : 1112 - ay;
+  return isqrt_floor(dx * dx + dy * dy);
+}
+
+// NetworkLatency.getLatency (C/NetworkLatency.java:27-34) over the table-ised models.
+WG_HD inline int32_t latency_of(const LatencyModel& m, int32_t from, int32_t to, int32_t x1, int32_t y1, int32_t e1,
+                                int32_t x2, int32_t y2, int32_t e2, int32_t delta) {
+  if (from == to) return 1;
+  int32_t base = e1 + e2;
+  int32_t ext;
+  switch (m.kind) {
+    case LAT_BYDIST: ext = m.lutDist[node_dist(x1, y1, x2, y2) * 100 + delta]; break;
+    case LAT_FIXED: ext = m.param; break;
+    case LAT_NONE: ext = 1; break;
+    case LAT_UNIFORM:
+    case LAT_MEASURED: ext = m.tabDelta[delta]; break;
+    case LAT_IC3: ext = m.tabDist[node_dist(x1, y1, x2, y2)]; break;
+    default: {  // LAT_ETHSCAN delegates to an inner MeasuredNetworkLatency.getLatency (:366-384)
+      int32_t inner = base + m.tabDelta[delta];
+      ext = inner > 1 ? inner : 1;
+    }
+  }
+  base += ext;
+  return base > 1 ? base : 1;
+}
+
+}  // namespace wg

@@ -1,0 +1,884 @@
+// Host runtime of the engine + the PingPong resident protocol (P/PingPong.java).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include "engine_host.h"
+#include "engine_kernels.hip.h"
+
+namespace wg {
+
+// ------------------------------------------------------------------------------------------------
+// PingPong (P/PingPong.java:20-32,60-74): Ping -> send(Pong) to the sender; Pong -> pong++.
+struct PingPongProto {
+  struct State {
+    int32_t* pong;
+  };
+  enum : uint32_t { MSG_PING = 0, MSG_PONG = 1 };
+  __device__ static int msg_size(const State&, uint32_t) { return 1; }  // Message.size() default
+  __device__ static void node_begin(Ctx&, const State&) {}
+  __device__ static void node_end(Ctx&, const State&) {}
+  __device__ static void on_message(Ctx& c, const State& s, int32_t from, uint32_t msg, uint32_t) {
+    if (msg == MSG_PING) {
+      c.send(from, MSG_PONG, 0, 1);  // onPing :67-69
+    } else if (WG_LANE == 0) {
+      s.pong[c.node]++;  // onPong :71-73
+    }
+  }
+  __device__ static void on_task(Ctx&, const State&, uint32_t, uint32_t) {}
+};
+
+struct PingPongHost : ProtoHost {
+  PingPongProto::State st{};
+  explicit PingPongHost(Engine& e) { st.pong = e.dalloc<int32_t>(e.dev.nodes.n); }
+  void launch_deliver(Engine& e, int32_t t) override {
+    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512), dim3(256), 0, e.stream, e.dev, st, t);
+  }
+  bool read_i64(Engine& e, int32_t field, int64_t* dst, int32_t n) override {
+    if (field != WG_F_PONG) return false;
+    std::vector<int32_t> h(n);
+    WG_HIP(hipMemcpy(h.data(), st.pong, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) dst[i] = h[i];
+    return true;
+  }
+};
+ProtoHost* make_pingpong_host(Engine& e) { return new PingPongHost(e); }
+
+// ------------------------------------------------------------------------------------------------
+static uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+Engine::Engine(const wg_config& c) : cfg(c) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) throw WgError(WG_EHIP, "no HIP device visible (libwittgpu.so has no CPU fallback)");
+  if (cfg.device < 0 || cfg.device >= count) throw WgError(WG_EINVAL, "bad device ordinal");
+  WG_HIP(hipSetDevice(cfg.device));
+  WG_HIP(hipStreamCreate(&stream));
+  gh.rng = lcg_scramble(0);  // new Random(0)  C/Network.java:32
+  set_latency(WG_LAT_IC3, nullptr, 0);
+}
+
+Engine::~Engine() {
+  delete proto;
+  for (void* p : allocs) (void)hipFree(p);
+  if (dLut) (void)hipFree(dLut);
+  if (dTabDelta) (void)hipFree(dTabDelta);
+  if (dTabDist) (void)hipFree(dTabDist);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::add_nodes(int32_t n, const int32_t* x, const int32_t* y, const int32_t* extra, const uint8_t* down,
+                       const uint8_t* byz, const double* speed) {
+  if (allocated) throw WgError(WG_ESTATE, "nodes cannot be added after the first run / protocol load");
+  if (n < 0 || !x || !y) throw WgError(WG_EINVAL, "wg_add_nodes: n/x/y");
+  for (int i = 0; i < n; i++) {
+    if (x[i] <= 0 || x[i] > 2000) throw WgError(WG_EINVAL, "bad x=" + std::to_string(x[i]));  // C/Node.java:256-261
+    if (y[i] <= 0 || y[i] > 1112) throw WgError(WG_EINVAL, "bad y=" + std::to_string(y[i]));
+    if (speed && speed[i] <= 0) throw WgError(WG_EINVAL, "speedRatio");
+    hx.push_back(x[i]);
+    hy.push_back(y[i]);
+    hextra.push_back(extra ? extra[i] : 0);
+    hdown.push_back(down ? down[i] : 0);
+    hbyz.push_back(byz ? byz[i] : 0);
+    hspeed.push_back(speed ? speed[i] : 1.0);
+  }
+}
+
+// ---- latency models -> tables (C/NetworkLatency.java). All FP happens here, once, on the host.
+static double gpd_inverseF(double y) {  // GeneralizedParetoDistribution(1.4, -0.3, 0.35).inverseF
+  const double shape = 1.4, location = -0.3, scale = 0.35;
+  if (y < 0.000001) return location;
+  if (y > 0.999999) return INFINITY;
+  return location + scale / shape * (-1 + std::pow(1 - y, -shape));
+}
+static const int kMaxDist = 1144;  // Node.MAX_DIST = (int) sqrt(1000^2 + 556^2)
+
+void Engine::set_latency(int32_t kind, const int32_t* params, int32_t nparams) {
+  if (queue_size() != 0)
+    throw WgError(WG_ESTATE, "You can't change the latency while the system as on going messages");
+  lutDist.clear();
+  tabDelta.clear();
+  tabDist.clear();
+  latParam = 0;
+  switch (kind) {
+    case WG_LAT_BY_DISTANCE_WJITTER: {  // :49-73
+      lutDist.resize((kMaxDist + 1) * 100);
+      const double pointValue = (24860.0 / 2) / kMaxDist;
+      for (int dist = 0; dist <= kMaxDist; dist++)
+        for (int delta = 0; delta < 100; delta++) {
+          double raw = (pointValue * dist) * 0.022 + 4.862 + gpd_inverseF(delta / 100.0);
+          int v = (int)(raw / 2);
+          if (v < 0 || v > 255) throw WgError(WG_ESTATE, "latency LUT out of u8 range");
+          lutDist[dist * 100 + delta] = (uint8_t)v;
+        }
+      break;
+    }
+    case WG_LAT_FIXED:
+      if (nparams < 1) throw WgError(WG_EINVAL, "NetworkFixedLatency needs 1 parameter");
+      latParam = std::max(1, params[0]);
+      break;
+    case WG_LAT_UNIFORM: {
+      if (nparams < 1) throw WgError(WG_EINVAL, "NetworkUniformLatency needs 1 parameter");
+      latParam = std::max(1, params[0]);
+      tabDelta.resize(100);
+      for (int d = 0; d < 100; d++) tabDelta[d] = (int)((d / 99.0) * latParam);
+      break;
+    }
+    case WG_LAT_NONE: break;
+    case WG_LAT_MEASURED:
+      if (nparams != 100) throw WgError(WG_EINVAL, "MeasuredNetworkLatency needs longDistrib[100]");
+      tabDelta.assign(params, params + 100);
+      break;
+    case WG_LAT_ETHSCAN: {  // :366-384 over MeasuredNetworkLatency.setLatency :284-302
+      static const int prop[] = {16, 18, 17, 12, 8, 5, 4, 3, 3, 1, 1, 2, 1, 1, 8};
+      static const int val[] = {250, 500, 1000, 1250, 1500, 1750, 2000, 2250, 2500, 2750, 4500, 6000, 8500, 9750, 10000};
+      int cur = 0;
+      for (int i = 0; i < 15; i++) {
+        int step = (val[i] - cur) / prop[i];
+        for (int k = 0; k < prop[i]; k++) {
+          cur += step;
+          tabDelta.push_back(cur);
+        }
+      }
+      break;
+    }
+    case WG_LAT_IC3: {  // :399-417
+      tabDist.resize(kMaxDist + 1);
+      for (int dist = 0; dist <= kMaxDist; dist++) {
+        double dd = dist;
+        double surface = dd * dd * M_PI;
+        double totalSurface = 2000 * 1112;
+        int position = (int)((surface * 100) / totalSurface);
+        int v;
+        if (position <= 10) v = 92 / 2;
+        else if (position <= 33) v = 125 / 2;
+        else if (position <= 50) v = 152 / 2;
+        else if (position <= 67) v = 200 / 2;
+        else if (position <= 90) v = 276 / 2;
+        else v = 350 / 2;
+        tabDist[dist] = v;
+      }
+      break;
+    }
+    default: throw WgError(WG_EINVAL, "unknown latency kind");
+  }
+  latKind = kind;
+  if (allocated) upload_latency();
+}
+
+void Engine::set_latency_by_name(const char* name) {  // C/RegistryNetworkLatencies.java:42-58
+  std::string s = name ? name : "";
+  int32_t p;
+  if (s.empty() || s == "NetworkLatencyByDistanceWJitter") return set_latency(WG_LAT_BY_DISTANCE_WJITTER, nullptr, 0);
+  if (s.rfind("NetworkFixedLatency(", 0) == 0) {
+    p = atoi(s.c_str() + 20);
+    return set_latency(WG_LAT_FIXED, &p, 1);
+  }
+  if (s.rfind("NetworkUniformLatency(", 0) == 0) {
+    p = atoi(s.c_str() + 22);
+    return set_latency(WG_LAT_UNIFORM, &p, 1);
+  }
+  if (s == "NetworkNoLatency") return set_latency(WG_LAT_NONE, nullptr, 0);
+  if (s == "IC3NetworkLatency") return set_latency(WG_LAT_IC3, nullptr, 0);
+  if (s == "EthScanNetworkLatency") return set_latency(WG_LAT_ETHSCAN, nullptr, 0);
+  throw WgError(WG_EINVAL, "latency model not available on the device engine: " + s);
+}
+
+void Engine::upload_latency() {
+  auto up = [&](void*& dptr, const void* src, size_t bytes) {
+    if (dptr) {
+      WG_HIP(hipFree(dptr));
+      dptr = nullptr;
+    }
+    if (bytes == 0) return;
+    WG_HIP(hipMalloc(&dptr, bytes));
+    WG_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+  };
+  up(dLut, lutDist.data(), lutDist.size());
+  up(dTabDelta, tabDelta.data(), tabDelta.size() * sizeof(int32_t));
+  up(dTabDist, tabDist.data(), tabDist.size() * sizeof(int32_t));
+  dev.lat.kind = latKind;
+  dev.lat.param = latParam;
+  dev.lat.lutDist = (const uint8_t*)dLut;
+  dev.lat.tabDelta = (const int32_t*)dTabDelta;
+  dev.lat.tabDist = (const int32_t*)dTabDist;
+}
+
+int32_t Engine::host_latency(int32_t from, int32_t to, int32_t seed) const {
+  LatencyModel m;
+  m.kind = latKind;
+  m.param = latParam;
+  m.lutDist = lutDist.data();
+  m.tabDelta = tabDelta.data();
+  m.tabDist = tabDist.data();
+  return latency_of(m, from, to, hx[from], hy[from], hextra[from], hx[to], hy[to], hextra[to], pseudo_delta(to, seed));
+}
+
+int32_t Engine::part_of(int32_t x) const {  // partitionId  C/Network.java:639-649
+  int p = 0;
+  for (int c : cuts) {
+    if (c > x) return p;
+    p++;
+  }
+  return p;
+}
+
+void Engine::rebuild_partitions() {
+  if (!allocated) return;
+  std::vector<uint8_t> part(hx.size());
+  for (size_t i = 0; i < hx.size(); i++) part[i] = (uint8_t)part_of(hx[i]);
+  WG_HIP(hipMemcpy(dev.nodes.part, part.data(), part.size(), hipMemcpyHostToDevice));
+}
+
+void Engine::set_partitions(const int32_t* c, int32_t k) {
+  if (k < 0 || k > MAX_CUTS) throw WgError(WG_EINVAL, "too many partitions");
+  cuts.assign(c, c + k);
+  std::sort(cuts.begin(), cuts.end());
+  rebuild_partitions();
+}
+
+void Engine::set_node_down(int32_t id, bool down) {
+  if (id < 0 || id >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
+  hdown[id] = down;
+  if (allocated) {
+    uint8_t v = down;
+    WG_HIP(hipMemcpy(dev.nodes.down + id, &v, 1, hipMemcpyHostToDevice));
+  }
+}
+
+// ---- device allocation
+void Engine::ensure_device() {
+  if (allocated) return;
+  const int32_t n = (int32_t)hx.size();
+  if (n == 0) throw WgError(WG_ESTATE, "no nodes in the network");
+  int32_t maxExtra = 0;
+  for (int v : hextra) maxExtra = std::max(maxExtra, v);
+  int32_t maxLat = 1;
+  switch (latKind) {
+    case LAT_BYDIST: maxLat = *std::max_element(lutDist.begin(), lutDist.end()) + 2 * maxExtra; break;
+    case LAT_FIXED:
+    case LAT_UNIFORM: maxLat = latParam + 2 * maxExtra; break;
+    case LAT_NONE: maxLat = 1 + 2 * maxExtra; break;
+    case LAT_MEASURED: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 2 * maxExtra; break;
+    case LAT_ETHSCAN: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 4 * maxExtra; break;
+    case LAT_IC3: maxLat = 175 + 2 * maxExtra; break;
+  }
+  uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms : next_pow2((uint32_t)std::max(256, maxLat + 8));
+  if ((D & (D - 1)) != 0 || D > 32768) throw WgError(WG_EINVAL, "horizon_ms must be a power of two <= 32768");
+  binBits = 0;
+  while ((1u << binBits) < D) binBits++;
+
+  uint64_t poolRecs = cfg.bucket_pool_records > 0 ? (uint64_t)cfg.bucket_pool_records
+                                                   : std::max<uint64_t>(1u << 20, 256ull * n);
+  uint32_t nPages = (uint32_t)((poolRecs + PAGE_RECS - 1) / PAGE_RECS) + D;  // + one partial page per bucket
+  uint32_t maxOut = cfg.outbox_records > 0 ? (uint32_t)cfg.outbox_records : (uint32_t)std::max<uint64_t>(1u << 16, 24ull * n);
+  uint32_t chainSlots = cfg.chain_slots > 0 ? (uint32_t)cfg.chain_slots : (uint32_t)std::max<uint64_t>(4096, 16ull * n);
+  uint64_t chainDests = cfg.chain_dests > 0 ? (uint64_t)cfg.chain_dests : std::max<uint64_t>(1u << 20, 256ull * n);
+  uint64_t payloadWords = cfg.payload_words > 0 ? (uint64_t)cfg.payload_words : (1u << 16);
+
+  dev.g = dalloc<Globals>(1);
+  NodeArrays& nd = dev.nodes;
+  nd.n = n;
+  nd.x = dalloc<int16_t>(n);
+  nd.y = dalloc<int16_t>(n);
+  nd.extraLatency = dalloc<int32_t>(n);
+  nd.down = dalloc<uint8_t>(n);
+  nd.part = dalloc<uint8_t>(n);
+  nd.msgReceived = dalloc<long long>(n);
+  nd.msgSent = dalloc<long long>(n);
+  nd.bytesSent = dalloc<long long>(n);
+  nd.bytesReceived = dalloc<long long>(n);
+  nd.doneAt = dalloc<long long>(n);
+  std::vector<int16_t> x16(n), y16(n);
+  for (int i = 0; i < n; i++) {
+    x16[i] = (int16_t)hx[i];
+    y16[i] = (int16_t)hy[i];
+  }
+  WG_HIP(hipMemcpy(nd.x, x16.data(), n * 2, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy(nd.y, y16.data(), n * 2, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy(nd.extraLatency, hextra.data(), n * 4, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy(nd.down, hdown.data(), n, hipMemcpyHostToDevice));
+
+  dev.discardTime = discardTime;
+  dev.horizon = (int32_t)D;
+  dev.nPages = nPages;
+  dev.maxPagesPerBucket = (int32_t)std::min<uint32_t>(nPages, 4096);
+  dev.pool = dalloc<Rec>((size_t)nPages * PAGE_RECS, false);
+  dev.freeStack = dalloc<uint32_t>(nPages, false);
+  dev.pagetab = dalloc<uint32_t>((size_t)D * dev.maxPagesPerBucket);
+  dev.bcnt = dalloc<uint32_t>(D);
+  {
+    std::vector<uint32_t> fs(nPages);
+    for (uint32_t i = 0; i < nPages; i++) fs[i] = nPages - 1 - i;
+    WG_HIP(hipMemcpy(dev.freeStack, fs.data(), sizeof(uint32_t) * nPages, hipMemcpyHostToDevice));
+  }
+  gh.freeTop = nPages;
+  dev.chainSlots = chainSlots;
+  dev.chains = dalloc<Chain>(chainSlots);
+  dev.chainDests = chainDests;
+  dev.dests = dalloc<int32_t>(chainDests, false);
+  dev.payloadWords = payloadWords;
+  dev.payload = dalloc<uint64_t>(payloadWords, false);
+  dev.destHeadAt = dalloc<unsigned long long>(D);
+  dev.payloadHeadAt = dalloc<unsigned long long>(D);
+
+  dev.maxEvents = maxOut;
+  dev.ev = dalloc<Rec>(maxOut, false);
+  dev.evChain = dalloc<int32_t>(maxOut, false);
+  dev.evCpos = dalloc<int32_t>(maxOut, false);
+  dev.evLast = dalloc<uint8_t>(maxOut, false);
+  dev.evNrec = dalloc<uint32_t>(maxOut);
+  dev.evNdraw = dalloc<uint32_t>(maxOut);
+  dev.evRecOff = dalloc<uint32_t>(maxOut);
+  dev.evDrawOff = dalloc<uint32_t>(maxOut);
+  dev.cntN = dalloc<uint32_t>(n);
+  dev.fillN = dalloc<uint32_t>(n);
+  dev.nodeOff = dalloc<uint32_t>(n);
+  dev.active = dalloc<uint32_t>(n);
+  dev.inbox = dalloc<uint32_t>(maxOut, false);
+  dev.inbox2 = dalloc<uint32_t>(maxOut, false);
+  dev.maxOut = maxOut;
+  dev.outTmp = dalloc<Out>(maxOut, false);
+  dev.fin = dalloc<Rec>(maxOut, false);
+  dev.arr = dalloc<int32_t>(maxOut, false);
+  maxTiles = (maxOut + TILE - 1) / TILE;
+  dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D, false);
+  dev.binBase = dalloc<uint32_t>(D);
+  dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID);
+  allocated = true;
+  upload_latency();
+  rebuild_partitions();
+  globalsDirty = true;
+  WG_HIP(hipStreamSynchronize(stream));
+}
+
+void Engine::sync_globals_to_device() {
+  if (!globalsDirty) return;
+  WG_HIP(hipMemcpyAsync(dev.g, &gh, sizeof(Globals), hipMemcpyHostToDevice, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+  globalsDirty = false;
+}
+void Engine::sync_globals_to_host() {
+  WG_HIP(hipMemcpyAsync(&gh, dev.g, sizeof(Globals), hipMemcpyDeviceToHost, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+}
+
+void Engine::latency_probe(int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta, int32_t* out) {
+  ensure_device();
+  for (int i = 0; i < n; i++)
+    if (from[i] < 0 || from[i] >= dev.nodes.n || to[i] < 0 || to[i] >= dev.nodes.n || delta[i] < 0 || delta[i] > 99)
+      throw WgError(WG_EINVAL, "delta=" + std::to_string(delta[i]));  // checkDelta  C/NetworkLatency.java:21-25
+  int32_t *df, *dt, *dd, *dout;
+  WG_HIP(hipMalloc((void**)&df, 4 * n));
+  WG_HIP(hipMalloc((void**)&dt, 4 * n));
+  WG_HIP(hipMalloc((void**)&dd, 4 * n));
+  WG_HIP(hipMalloc((void**)&dout, 4 * n));
+  WG_HIP(hipMemcpy(df, from, 4 * n, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy(dt, to, 4 * n, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy(dd, delta, 4 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_latency_probe, dim3((n + 255) / 256), dim3(256), 0, stream, dev, n, df, dt, dd, dout);
+  WG_HIP(hipStreamSynchronize(stream));
+  WG_HIP(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(df);
+  (void)hipFree(dt);
+  (void)hipFree(dd);
+  (void)hipFree(dout);
+}
+
+// ---- host-side Network API (init() code paths)
+void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+                  int32_t delayBetween) {
+  const int32_t N = (int32_t)hx.size();
+  if (from < 0 || from >= N) throw WgError(WG_EINVAL, "The from node is not in the network.");  // :371,:427
+  for (int i = 0; i < n; i++)
+    if (dests[i] < 0 || dests[i] >= N) throw WgError(WG_EINVAL, "The to node is not in the network.");  // :374
+  if (n <= 0) return;
+  if (sendTime <= time) throw WgError(WG_ESTATE, "sendTime=" + std::to_string(sendTime) + ", time=" + std::to_string(time));  // :471
+  if (!proto) throw WgError(WG_ESTATE, "load a protocol before sending (message sizes are protocol-defined)");
+  JavaRandom rd;
+  rd.s = gh.rng;
+  int32_t seed = rd.nextInt();  // :377 / :430 — drawn before arrivals are computed
+  gh.rng = rd.s;
+  gh.draws++;
+  globalsDirty = true;
+  // sender statistics are applied on the device at flush time; host keeps them in staged counters
+  struct Arr {
+    int32_t dest, arrival;
+  };
+  std::vector<Arr> da;
+  int32_t st = sendTime;
+  int64_t sentMsgs = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t to = dests[i];
+    sentMsgs++;
+    if (part_of(hx[from]) == part_of(hx[to]) && !hdown[from] && !hdown[to]) {
+      int32_t nt = host_latency(from, to, seed);
+      if (nt < discardTime) da.push_back({to, st + nt});
+    }
+    st += delayBetween + (delayBetween > 0 ? 1 : 0);  // :459
+  }
+  pendingSent.push_back({from, sentMsgs, msg});
+  if (n > 1) std::stable_sort(da.begin(), da.end(), [](const Arr& a, const Arr& b) { return a.arrival < b.arrival; });
+  if (da.empty()) return;
+  if (da.size() == 1) {
+    staged.push_back({da[0].arrival, make_rec(K_MSG, from, (uint32_t)da[0].dest, msg, payload)});
+    return;
+  }
+  ensure_device();
+  StagedChain sc;
+  sc.slot = gh.chainHead++ % dev.chainSlots;
+  sc.c.from = from;
+  sc.c.seed = seed;
+  sc.c.sendTime = sendTime;
+  sc.c.ndest = (int32_t)da.size();
+  size_t words = da.size() * (delayBetween == 0 ? 1 : 2);
+  if (words > dev.chainDests) throw WgError(WG_ENOMEM, "chain_dests too small for this multi-destination send");
+  sc.c.destOff = (uint32_t)(gh.destHead % dev.chainDests);
+  gh.destHead += words;
+  sc.c.msg = msg;
+  sc.c.payload = payload;
+  sc.c.flags = 1u | (delayBetween == 0 ? 0u : 2u);
+  for (auto& a : da) sc.words.push_back(a.dest);
+  if (delayBetween != 0)
+    for (auto& a : da) sc.words.push_back(a.arrival);
+  staged.push_back({da[0].arrival, make_rec(K_CHAIN, from, sc.slot, 0, 0)});
+  stagedChains.push_back(std::move(sc));
+}
+
+void Engine::register_task(uint32_t task, uint32_t arg, int32_t startAt, int32_t node) {  // :505-508
+  if (node < 0 || node >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
+  if (startAt < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(startAt));  // :249-252
+  staged.push_back({startAt, make_rec(K_TASK, node, (uint32_t)node, task, arg)});
+}
+void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t period, int32_t node) {  // :510-513
+  if (node < 0 || node >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
+  if (period <= 0) throw WgError(WG_EINVAL, "period");
+  if (startAt < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(startAt));
+  staged.push_back({startAt, make_rec(K_PERIODIC, node, (uint32_t)node, task, (uint32_t)period)});
+}
+
+template <class F>
+void Engine::scan(const F& f) {
+  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID), dim3(SCAN_BLOCK), 0, stream, f, dev.scanPartials);
+  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID), dim3(SCAN_BLOCK), 0, stream, f, dev.scanPartials);
+}
+template void Engine::scan<ExpandF>(const ExpandF&);
+template void Engine::scan<NodesF>(const NodesF&);
+template void Engine::scan<RecsF>(const RecsF&);
+
+void Engine::append_phase(int32_t t) {
+  size_t lds = sizeof(uint32_t) * (size_t)dev.horizon;
+  hipLaunchKernelGGL(k_tile_hist, dim3(256), dim3(TILE), lds, stream, dev, t, binBits);
+  hipLaunchKernelGGL(k_col_reserve, dim3(1), dim3(1024), 0, stream, dev);
+  hipLaunchKernelGGL(k_scatter, dim3(256), dim3(TILE), lds, stream, dev, t, binBits);
+}
+void Engine::end_phase(int32_t t, bool drained) {
+  hipLaunchKernelGGL(k_end_phase, dim3(1), dim3(256), 0, stream, dev, t, drained ? 1 : 0);
+}
+
+__global__ void k_apply_sent(NodeArrays nd, int n, const int32_t* node, const long long* msgs, const long long* bytes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  atomicAdd((unsigned long long*)&nd.msgSent[node[i]], (unsigned long long)msgs[i]);
+  atomicAdd((unsigned long long*)&nd.bytesSent[node[i]], (unsigned long long)bytes[i]);
+}
+__global__ void k_set_nout(Globals* g, uint32_t n) { g->nOut = n; }
+
+// Push host-staged envelopes (in push order) through the same append pipeline the device uses.
+void Engine::flush_staged() {
+  if (staged.empty() && pendingSent.empty()) return;
+  ensure_device();
+  sync_globals_to_device();
+  for (auto& sc : stagedChains) {
+    if (sc.slot >= dev.chainSlots) throw WgError(WG_ENOMEM, "chain_slots");
+    for (size_t j = 0; j < sc.words.size(); j++) {
+      size_t idx = (sc.c.destOff + j) % dev.chainDests;
+      WG_HIP(hipMemcpy(dev.dests + idx, &sc.words[j], 4, hipMemcpyHostToDevice));
+    }
+    WG_HIP(hipMemcpy(dev.chains + sc.slot, &sc.c, sizeof(Chain), hipMemcpyHostToDevice));
+  }
+  stagedChains.clear();
+  if (!pendingSent.empty()) {
+    // Node.msgSent / bytesSent for host-side sends (C/Network.java:476-477)
+    std::vector<int32_t> nodes;
+    std::vector<long long> msgs, bytes;
+    for (auto& p : pendingSent) {
+      nodes.push_back(p.node);
+      msgs.push_back(p.msgs);
+      bytes.push_back(p.msgs * (long long)proto->host_msg_size(p.msg));
+    }
+    int n = (int)nodes.size();
+    int32_t* dn;
+    long long *dm, *db;
+    WG_HIP(hipMalloc((void**)&dn, 4 * n));
+    WG_HIP(hipMalloc((void**)&dm, 8 * n));
+    WG_HIP(hipMalloc((void**)&db, 8 * n));
+    WG_HIP(hipMemcpy(dn, nodes.data(), 4 * n, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(dm, msgs.data(), 8 * n, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(db, bytes.data(), 8 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_apply_sent, dim3((n + 255) / 256), dim3(256), 0, stream, dev.nodes, n, dn, dm, db);
+    WG_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(dn);
+    (void)hipFree(dm);
+    (void)hipFree(db);
+    pendingSent.clear();
+  }
+  size_t done = 0;
+  while (done < staged.size()) {
+    size_t n = std::min<size_t>(staged.size() - done, dev.maxOut);
+    std::vector<Rec> recs(n);
+    std::vector<int32_t> arr(n);
+    for (size_t i = 0; i < n; i++) {
+      recs[i] = staged[done + i].rec;
+      arr[i] = staged[done + i].arrival;
+      if (arr[i] - time >= dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms too small for an envelope arriving at " + std::to_string(arr[i]));
+    }
+    WG_HIP(hipMemcpyAsync(dev.fin, recs.data(), sizeof(Rec) * n, hipMemcpyHostToDevice, stream));
+    WG_HIP(hipMemcpyAsync(dev.arr, arr.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, (uint32_t)n);
+    append_phase(time);
+    hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, 0u);
+    WG_HIP(hipStreamSynchronize(stream));
+    done += n;
+  }
+  staged.clear();
+  sync_globals_to_host();
+  check_device_errors();
+}
+
+void Engine::check_device_errors() {
+  uint32_t e = gh.err;
+  if (!e) return;
+  std::string m;
+  int32_t code = WG_ENOMEM;
+  if (e & ERR_BUCKET_POOL) m += "bucket page pool exhausted (raise wg_config.bucket_pool_records); ";
+  if (e & ERR_BUCKET_PAGES) m += "one ms bucket exceeded the per-bucket page table; ";
+  if (e & ERR_OUTBOX) m += "more records emitted in one ms than wg_config.outbox_records; ";
+  if (e & ERR_EVENTS) m += "more events in one ms than wg_config.outbox_records; ";
+  if (e & ERR_HORIZON) m += "arrival beyond wg_config.horizon_ms; ";
+  if (e & ERR_CHAIN_SLOTS) m += "wg_config.chain_slots exhausted; ";
+  if (e & ERR_CHAIN_DESTS) m += "wg_config.chain_dests ring overrun; ";
+  if (e & ERR_PAYLOAD) m += "wg_config.payload_words ring overrun; ";
+  if (e & ERR_QUEUE_CAP) m += "Handel toVerifyAgg exceeded wg_config.queue_cap; ";
+  if (e & ERR_PENDING) m += "Handel pending-verification table full; ";
+  if (e & ERR_MULTI_TOO_BIG) {
+    m += "device-side multi-destination send with more than 64 destinations; ";
+    code = WG_EUNSUPPORTED;
+  }
+  if (e & ERR_SAME_MS) {
+    m += "an action() registered an envelope for the millisecond being drained; ";
+    code = WG_EUNSUPPORTED;
+  }
+  if (e & ERR_ARRIVAL_PAST) {
+    m += "Arriving in the past; ";
+    code = WG_ESTATE;
+  }
+  if (e & ERR_PROTOCOL) {
+    m += "protocol invariant violated (reference IllegalStateException site); ";
+    code = WG_ESTATE;
+  }
+  throw WgError(code, m);
+}
+
+void Engine::load_protocol(int32_t id, const void* params, const void* initState) {
+  if (proto) throw WgError(WG_ESTATE, "a protocol is already resident");
+  if (id == WG_PROTO_PINGPONG) {
+    ensure_device();
+    proto = make_pingpong_host(*this);
+  } else if (id == WG_PROTO_HANDEL) {
+    if (!params || !initState) throw WgError(WG_EINVAL, "Handel needs wg_handel_params and wg_handel_init_state");
+    proto = make_handel_host(*this, *(const wg_handel_params*)params, *(const wg_handel_init_state*)initState);
+  } else {
+    throw WgError(WG_EINVAL, "unknown protocol id");
+  }
+}
+
+// Network.runMs (C/Network.java:318-338) + receiveUntil/nextMessage as a time-stepped loop.
+void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
+  if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
+  if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
+  int32_t endAt = (int32_t)((uint32_t)time + (uint32_t)ms);
+  if (endAt <= 0) throw WgError(WG_ESTATE, "Maximum time reached!");
+  ensure_device();
+  flush_staged();
+  // (time == 0: Node.start() on non-down nodes only re-asserts down == false, :323-329)
+  Globals before = gh;
+  gh.epoch++;  // a new receiveUntil() starts with a fresh nextMessage() call
+  gh.anyEvent = 0;
+  globalsDirty = true;
+  sync_globals_to_device();
+  auto t0 = std::chrono::steady_clock::now();
+  const bool cond = proto->has_cond();
+  for (int32_t t = time; t <= endAt; t++) {
+    if (cond && t > time) {  // time++ edge -> t: conditional tasks (:543-566)
+      proto->launch_cond(*this, t, endAt);
+      append_phase(t);
+      end_phase(t, false);
+    }
+    scan(ExpandF{dev, t});
+    scan(NodesF{dev});
+    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, dev);
+    proto->launch_deliver(*this, t);
+    scan(RecsF{dev});
+    hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev, t);
+    append_phase(t);
+    end_phase(t, true);
+  }
+  if (cond) {  // the edge to until+1 still runs tasks with minStartTime <= until
+    proto->launch_cond(*this, endAt + 1, endAt);
+    append_phase(endAt + 1);
+    end_phase(endAt + 1, false);
+  }
+  WG_HIP(hipStreamSynchronize(stream));
+  auto t1 = std::chrono::steady_clock::now();
+  sync_globals_to_host();
+  time = endAt;
+  if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;
+  if (stats) {
+    stats->delivered = (int64_t)(gh.delivered - before.delivered);
+    stats->tasks = (int64_t)(gh.tasks - before.tasks);
+    stats->events = (int64_t)(gh.events - before.events);
+    stats->draws = (int64_t)(gh.draws - before.draws);
+    stats->simulated_ms = ms;
+    stats->wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    stats->payload_bytes = (int64_t)(gh.payloadBytes - before.payloadBytes);
+  }
+  check_device_errors();
+}
+
+int64_t Engine::queue_size() {  // msgs.size(): number of envelopes (a multi-dest envelope counts once)
+  if (!allocated) return (int64_t)staged.size();
+  flush_staged();
+  std::vector<uint32_t> c(dev.horizon);
+  WG_HIP(hipMemcpy(c.data(), dev.bcnt, sizeof(uint32_t) * dev.horizon, hipMemcpyDeviceToHost));
+  int64_t s = 0;
+  for (uint32_t v : c) s += v;
+  return s;
+}
+int64_t Engine::queue_size_at(int32_t t) {
+  if (t < time) return 0;
+  if (!allocated) {
+    int64_t s = 0;
+    for (auto& st : staged) s += st.arrival == t;
+    return s;
+  }
+  flush_staged();
+  if (t - time >= dev.horizon) return 0;
+  uint32_t c;
+  WG_HIP(hipMemcpy(&c, dev.bcnt + ((uint32_t)t & (dev.horizon - 1)), 4, hipMemcpyDeviceToHost));
+  return c;
+}
+
+void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
+  if (n != (int32_t)hx.size()) throw WgError(WG_EINVAL, "n must equal the node count");
+  ensure_device();
+  flush_staged();
+  auto rd64 = [&](const long long* src) { WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n, hipMemcpyDeviceToHost)); };
+  switch (field) {
+    case WG_F_DONE_AT: return rd64(dev.nodes.doneAt);
+    case WG_F_MSG_RECEIVED: return rd64(dev.nodes.msgReceived);
+    case WG_F_MSG_SENT: return rd64(dev.nodes.msgSent);
+    case WG_F_BYTES_SENT: return rd64(dev.nodes.bytesSent);
+    case WG_F_BYTES_RECEIVED: return rd64(dev.nodes.bytesReceived);
+    case WG_F_DOWN:
+      for (int i = 0; i < n; i++) dst[i] = hdown[i];
+      return;
+    case WG_F_X:
+      for (int i = 0; i < n; i++) dst[i] = hx[i];
+      return;
+    case WG_F_Y:
+      for (int i = 0; i < n; i++) dst[i] = hy[i];
+      return;
+    case WG_F_EXTRA_LATENCY:
+      for (int i = 0; i < n; i++) dst[i] = hextra[i];
+      return;
+    default:
+      if (proto && proto->read_i64(*this, field, dst, n)) return;
+      throw WgError(WG_EINVAL, "unknown field for the resident protocol");
+  }
+}
+
+}  // namespace wg
+
+// ================================================================================================
+// Handel resident protocol: host side (allocation, upload of init() state, kernel launches, read-back)
+#include "proto_handel.hip.h"
+
+namespace wg {
+
+template void Engine::scan<CondF>(const CondF&);
+
+__global__ void k_handel_init(HandelState s, const uint8_t* down) {
+  int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.N) return;
+  // HLevel() for level 0 (:413-421): own signature everywhere, outgoingFinished = true
+  size_t w = (size_t)node * s.W + (node >> 6);
+  uint64_t bit = 1ULL << (node & 63);
+  s.TI[w] |= bit;
+  s.LA[w] |= bit;
+  s.VI[w] |= bit;
+  size_t i0 = (size_t)node * s.L;
+  s.cTI[i0] = 1;
+  s.cLA[i0] = 1;
+  s.cVI[i0] = 1;
+  s.outFin[i0] = 1;
+  s.window[node] = s.p.windowInitial;
+  s.addedCycle[node] = s.p.extraCycle;
+  // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
+  s.ctMinStart[node] = down[node] ? INT32_MAX : s.startAt[node] + 1;
+}
+
+struct HandelHost : ProtoHost {
+  HandelState st{};
+  Engine& eng;
+  HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
+    const int32_t N = p.nodeCount;
+    if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
+    if (N < 2 || (N & (N - 1))) throw WgError(WG_EINVAL, "We support only power of two nodes in this simulation");
+    if (!init.startAt || !init.nodePairingTime || !init.receptionRanks || !init.peers)
+      throw WgError(WG_EINVAL, "wg_handel_init_state has NULL members");
+    int L = 1;
+    while ((1 << L) <= N) L++;  // levels 0..log2(N)
+    if (L > MAX_LEVELS) throw WgError(WG_EINVAL, "too many levels");
+    const int W = N >= 64 ? N / 64 : 1;
+    const int Q = e.cfg.queue_cap > 0 ? e.cfg.queue_cap : 32;
+    if (Q > 64) throw WgError(WG_EINVAL, "queue_cap must be <= 64");
+    // payload ring: everything sent within one horizon must fit (see EngineDev::payloadHeadAt).
+    // One dissemination of one node writes at most W + L words; fast-path sends add at most the same.
+    if (e.cfg.payload_words == 0 && !e.allocated) {
+      int32_t maxPair = 1;
+      for (int i = 0; i < N; i++) maxPair = std::max(maxPair, init.nodePairingTime[i]);
+      // horizon is decided in ensure_device(); be conservative: assume 512 ms unless configured
+      int64_t horizon = e.cfg.horizon_ms > 0 ? e.cfg.horizon_ms : 512;
+      int64_t bursts = horizon / std::max(1, p.disseminationPeriodMs) + 2;
+      e.cfg.payload_words = std::max<int64_t>(1 << 20, (int64_t)N * (W + L) * (bursts + 2));
+    }
+    e.ensure_device();
+    if (p.disseminationPeriodMs >= e.dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms <= dissemination period");
+    st.p = p;
+    st.N = N;
+    st.L = L;
+    st.W = W;
+    st.Q = Q;
+    const size_t rows = (size_t)N * W;
+    st.TI = e.dalloc<uint64_t>(rows);
+    st.LA = e.dalloc<uint64_t>(rows);
+    st.VI = e.dalloc<uint64_t>(rows);
+    st.TV = e.dalloc<uint64_t>(rows);
+    st.FP = e.dalloc<uint64_t>(rows);
+    st.ranks = e.dalloc<int32_t>((size_t)N * N, false);
+    st.peers = e.dalloc<int32_t>((size_t)N * (N - 1), false);
+    st.startAt = e.dalloc<int32_t>(N);
+    st.pairing = e.dalloc<int32_t>(N);
+    st.window = e.dalloc<int32_t>(N);
+    st.addedCycle = e.dalloc<int32_t>(N);
+    st.sigsChecked = e.dalloc<int32_t>(N);
+    st.sigQueueSize = e.dalloc<int32_t>(N);
+    st.msgFiltered = e.dalloc<int32_t>(N);
+    st.ctMinStart = e.dalloc<int32_t>(N);
+    st.ctEpoch = e.dalloc<uint32_t>(N);
+    const size_t NL = (size_t)N * L;
+    st.pos = e.dalloc<int32_t>(NL);
+    st.cTI = e.dalloc<int32_t>(NL);
+    st.cLA = e.dalloc<int32_t>(NL);
+    st.cVI = e.dalloc<int32_t>(NL);
+    st.outFin = e.dalloc<uint8_t>(NL);
+    st.qlen = e.dalloc<uint8_t>(NL);
+    st.qorder = e.dalloc<uint8_t>(NL * 64);
+    st.qused = e.dalloc<unsigned long long>(NL);
+    st.qfrom = e.dalloc<int32_t>(NL * Q, false);
+    st.qrank = e.dalloc<int32_t>(NL * Q, false);
+    unsigned long long off = 0;
+    for (int l = 0; l < L; l++) {
+      st.qsigOff[l] = off;
+      int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
+      off += (unsigned long long)N * Q * nw;
+    }
+    st.qsig = e.dalloc<uint64_t>(off, false);
+    st.pend = e.dalloc<uint32_t>((size_t)N * H_PEND);
+    st.pendFrom = e.dalloc<int32_t>((size_t)N * H_PEND);
+    st.candCnt = e.dalloc<uint8_t>(N);
+    st.candLevel = e.dalloc<uint8_t>(NL);
+    st.candSlot = e.dalloc<uint8_t>(NL);
+    st.condOrd = e.dalloc<uint32_t>(N);
+    st.condList = e.dalloc<uint32_t>(N);
+    st.drawVal = e.dalloc<int32_t>(N);
+    WG_HIP(hipMemcpy(st.startAt, init.startAt, 4 * (size_t)N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.pairing, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.ranks, init.receptionRanks, 4 * (size_t)N * N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * (N - 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_handel_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down);
+    WG_HIP(hipStreamSynchronize(e.stream));
+  }
+  bool has_cond() const override { return true; }
+  int levels() const override { return st.L; }
+  int host_msg_size(uint32_t msg) const override {
+    int l = (int)(msg & 31u);
+    return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 192;
+  }
+  void launch_cond(Engine& e, int32_t t, int32_t until) override {
+    hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t, until);
+    e.scan(CondF{e.dev, st});
+    hipLaunchKernelGGL(k_handel_cond_draw, dim3(128), dim3(256), 0, e.stream, e.dev, st);
+    hipLaunchKernelGGL(k_handel_cond_fix, dim3(1), dim3(1), 0, e.stream, e.dev, st);
+    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128), dim3(256), 0, e.stream, e.dev, st, t);
+  }
+  void launch_deliver(Engine& e, int32_t t) override {
+    hipLaunchKernelGGL(k_deliver_handel, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t);
+  }
+  bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
+    const int32_t* src = nullptr;
+    switch (field) {
+      case WG_F_SIGS_CHECKED: src = st.sigsChecked; break;
+      case WG_F_SIG_QUEUE_SIZE: src = st.sigQueueSize; break;
+      case WG_F_MSG_FILTERED: src = st.msgFiltered; break;
+      case WG_F_CURR_WINDOW_SIZE: src = st.window; break;
+      case WG_F_ADDED_CYCLE: src = st.addedCycle; break;
+      case WG_F_START_AT: src = st.startAt; break;
+      case WG_F_NODE_PAIRING_TIME: src = st.pairing; break;
+      default: return false;
+    }
+    std::vector<int32_t> h(n);
+    WG_HIP(hipMemcpy(h.data(), src, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) dst[i] = h[i];
+    return true;
+  }
+  bool read_level_i32(Engine&, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
+    if (n != st.N || L != st.L) throw WgError(WG_EINVAL, "shape must be [nodeCount][levels]");
+    const size_t NL = (size_t)n * L;
+    if (field == WG_LF_POS_IN_LEVEL) {
+      WG_HIP(hipMemcpy(dst, st.pos, 4 * NL, hipMemcpyDeviceToHost));
+      return true;
+    }
+    const uint8_t* src = field == WG_LF_OUTGOING_FINISHED ? st.outFin : field == WG_LF_QUEUE_LEN ? st.qlen : nullptr;
+    if (!src) return false;
+    std::vector<uint8_t> h(NL);
+    WG_HIP(hipMemcpy(h.data(), src, NL, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < NL; i++) dst[i] = h[i];
+    return true;
+  }
+  bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {
+    if (n != st.N || w != st.W) throw WgError(WG_EINVAL, "shape must be [nodeCount][max(1, nodeCount/64)]");
+    const uint64_t* src = nullptr;
+    switch (field) {
+      case WG_B_TOTAL_INCOMING: src = st.TI; break;
+      case WG_B_LAST_AGG_VERIFIED: src = st.LA; break;
+      case WG_B_VERIFIED_IND: src = st.VI; break;
+      case WG_B_TO_VERIFY_IND: src = st.TV; break;
+      case WG_B_FINISHED_PEERS: src = st.FP; break;
+      default: return false;
+    }
+    WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
+    return true;
+  }
+};
+
+ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st) {
+  return new HandelHost(e, p, st);
+}
+
+}  // namespace wg

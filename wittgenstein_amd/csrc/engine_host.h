@@ -1,0 +1,143 @@
+// Host-side runtime of the engine: owns device memory and the HIP stream, enqueues the per-ms
+// kernel sequence, mirrors the pieces of core.Network state that init() code paths touch from the
+// host (time, rd, node flags, staged envelopes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/wittgpu.h"
+#include "engine.h"
+
+namespace wg {
+
+struct WgError : std::runtime_error {
+  int32_t code;
+  WgError(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define WG_HIP(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      throw ::wg::WgError(WG_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+class Engine;
+
+// A resident protocol: device state + the kernels that run its action()/conditional tasks.
+struct ProtoHost {
+  virtual ~ProtoHost() {}
+  virtual bool has_cond() const { return false; }
+  // conditional-task phase at the time++ edge -> t (C/Network.java:543-566); emits into the ordered
+  // outbox (fin/arr, g->nOut) and g->nDraws. Only called when has_cond().
+  virtual void launch_cond(Engine&, int32_t /*t*/, int32_t /*until*/) {}
+  virtual void launch_deliver(Engine&, int32_t t) = 0;
+  virtual bool read_i64(Engine&, int32_t /*field*/, int64_t* /*dst*/, int32_t /*n*/) { return false; }
+  virtual bool read_level_i32(Engine&, int32_t, int32_t*, int32_t, int32_t) { return false; }
+  virtual bool read_bits(Engine&, int32_t, uint64_t*, int32_t, int32_t) { return false; }
+  virtual int levels() const { return 0; }
+  virtual int host_msg_size(uint32_t /*msg*/) const { return 1; }  // Message.size() of a host-side send
+  virtual bool delivered_by_level(Engine&, int64_t* /*dst32*/) { return false; }
+};
+
+class Engine {
+ public:
+  explicit Engine(const wg_config& cfg);
+  ~Engine();
+
+  // topology
+  void add_nodes(int32_t n, const int32_t* x, const int32_t* y, const int32_t* extra, const uint8_t* down,
+                 const uint8_t* byz, const double* speed);
+  void set_latency(int32_t kind, const int32_t* params, int32_t nparams);
+  void set_latency_by_name(const char* name);
+  void set_partitions(const int32_t* cuts, int32_t k);
+  void set_node_down(int32_t id, bool down);
+  void latency_probe(int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta, int32_t* out);
+
+  // host-side Network API used by init() code
+  void send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+            int32_t delayBetween);
+  void register_task(uint32_t task, uint32_t arg, int32_t startAt, int32_t node);
+  void register_periodic_task(uint32_t task, int32_t startAt, int32_t period, int32_t node);
+
+  void load_protocol(int32_t id, const void* params, const void* initState);
+  void run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
+  int64_t queue_size();
+  int64_t queue_size_at(int32_t t);
+  void read_i64(int32_t field, int64_t* dst, int32_t n);
+
+  // used by protocol hosts
+  void ensure_device();          // allocate device state once the node count is known
+  void sync_globals_to_host();
+  void sync_globals_to_device();
+  void append_phase(int32_t t);  // multisplit of the ordered outbox into the buckets
+  void end_phase(int32_t t, bool drained);
+  template <class F>
+  void scan(const F& f);
+  void flush_staged();
+  int32_t host_latency(int32_t from, int32_t to, int32_t seed) const;
+  int32_t part_of(int32_t x) const;
+  void check_device_errors();
+
+  wg_config cfg;
+  std::string lastError;
+  hipStream_t stream = nullptr;
+  EngineDev dev{};               // device pointers (passed by value to kernels)
+  Globals gh{};                  // host shadow of the device globals (valid between runs)
+  bool globalsDirty = true;
+  bool allocated = false;
+  int32_t time = 0;              // Network.time
+  int32_t discardTime = INT32_MAX;
+  int32_t binBits = 0;
+  uint32_t maxTiles = 0;
+  // host copies of node fields (send-time decisions of host-side sends)
+  std::vector<int32_t> hx, hy, hextra;
+  std::vector<uint8_t> hdown, hbyz;
+  std::vector<double> hspeed;
+  std::vector<int32_t> cuts;
+  // latency model (host tables mirrored on device)
+  int32_t latKind = LAT_IC3;     // C/Network.java:43 default
+  int32_t latParam = 0;
+  std::vector<uint8_t> lutDist;
+  std::vector<int32_t> tabDelta, tabDist;
+  void* dLut = nullptr;
+  void* dTabDelta = nullptr;
+  void* dTabDist = nullptr;
+  // envelopes pushed from the host and not yet on the device, in push order
+  struct Staged {
+    int32_t arrival;
+    Rec rec;
+  };
+  std::vector<Staged> staged;
+  struct StagedChain {
+    uint32_t slot;
+    Chain c;
+    std::vector<int32_t> words;  // dest ids (+ explicit arrivals)
+  };
+  std::vector<StagedChain> stagedChains;
+  struct PendingSent {  // Node.msgSent/bytesSent of host-side sends, applied at flush
+    int32_t node;
+    long long msgs;
+    uint32_t msg;
+  };
+  std::vector<PendingSent> pendingSent;
+  ProtoHost* proto = nullptr;
+  std::vector<void*> allocs;     // everything to hipFree
+
+  template <class T>
+  T* dalloc(size_t count, bool zero = true) {
+    void* p = nullptr;
+    WG_HIP(hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+    if (zero) WG_HIP(hipMemsetAsync(p, 0, count * sizeof(T), stream));
+    allocs.push_back(p);
+    return (T*)p;
+  }
+  void upload_latency();
+  void rebuild_partitions();
+};
+
+ProtoHost* make_pingpong_host(Engine& e);
+ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st);
+
+}  // namespace wg

@@ -1,0 +1,699 @@
+// Generic (protocol-independent) CDNA4 kernels of the time-stepped engine. gfx950 only: 64-wide
+// wavefronts are hard-coded (ballot masks are 64-bit, one simulated node per wavefront in the
+// delivery kernels, lanes = 64-bit words of that node's bitsets).
+//
+// One simulated millisecond t (C/Network.java:533-637) =
+//   [conditional-task phase — protocol kernels, see proto_handel.hip.h]
+//   expand   bucket t in LIFO order, MultipleDestEnvelope runs unrolled        -> events[0..E)
+//   group    events by destination node (count, scan, fill)                     -> per-node inbox
+//   deliver  one wavefront per node with >=1 event applies them in event order  -> unordered outbox
+//   order    scan of per-event record/draw counts                               -> global push order + draw index
+//   resolve  seed = rd.nextInt() by LCG jump-ahead, latency, arrival, drops     -> ordered outbox
+//   append   stable multisplit of the ordered outbox by arrival-ms (LDS histogram per 1024-record
+//            tile, wave-ballot match for the in-tile rank) onto the tail of each arrival bucket
+#pragma once
+#include <hip/hip_runtime.h>
+#include "engine.h"
+
+namespace wg {
+
+#define WG_LANE (threadIdx.x & 63)
+
+__device__ __forceinline__ void set_err(Globals* g, uint32_t bit) { atomicOr(&g->err, bit); }
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+  uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int delta) {
+  uint32_t lo = __shfl_up((uint32_t)v, delta, 64), hi = __shfl_up((uint32_t)(v >> 32), delta, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint64_t u = shfl_up64(v, o);
+    if ((int)WG_LANE >= o) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t lanes_lt() { return (1ULL << WG_LANE) - 1ULL; }
+
+__device__ __forceinline__ Rec* rec_ptr(const EngineDev& d, uint32_t bucket, uint32_t i) {
+  uint32_t page = d.pagetab[(size_t)bucket * d.maxPagesPerBucket + (i >> PAGE_SHIFT)];
+  return d.pool + (((size_t)page << PAGE_SHIFT) | (i & (PAGE_RECS - 1)));
+}
+
+__device__ __forceinline__ int32_t dev_latency(const EngineDev& d, int32_t from, int32_t to, int32_t seed) {
+  const NodeArrays& n = d.nodes;
+  return latency_of(d.lat, from, to, n.x[from], n.y[from], n.extraLatency[from], n.x[to], n.y[to],
+                    n.extraLatency[to], pseudo_delta(to, seed));
+}
+
+// arrival of the j-th destination of a chain (MultipleDestEnvelope.arrivalTime C/Envelope.java:107-113,
+// MultipleDestWithDelayEnvelope.nextArrivalTime :186-188)
+__device__ __forceinline__ int32_t chain_dest(const EngineDev& d, const Chain& c, int j) {
+  return d.dests[(c.destOff + (unsigned long long)j) % d.chainDests];
+}
+__device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain& c, int j) {
+  if (c.flags & 2u) return d.dests[(c.destOff + (unsigned long long)c.ndest + j) % d.chainDests];
+  return c.sendTime + dev_latency(d, c.from, chain_dest(d, c, j), c.seed);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-wide exclusive scan of F(i), i in [0, F.count()), as two launches with no inter-block
+// communication: (1) per-block partial sums of a contiguous chunk, (2) every block re-sums the
+// partials before it, scans its chunk and calls F.write(i, exclusive_prefix). Values are uint64 so a
+// pair of 32-bit counters can be scanned at once.
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_GRID = 240;
+
+__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
+  uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+  chunk = (chunk + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
+  lo = min(n, blockIdx.x * chunk);
+  hi = min(n, lo + chunk);
+}
+
+__device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl64(v, WG_LANE ^ o);
+  int w = threadIdx.x >> 6;
+  if (WG_LANE == 0) sh[w] = v;
+  __syncthreads();
+  uint64_t t = 0;
+  for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += sh[k];
+  __syncthreads();
+  return t;
+}
+
+// exclusive scan of one uint32 per thread over a 1024-thread block; *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t* sh16, uint32_t* total) {
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t u = __shfl_up(incl, o, 64);
+    if ((int)WG_LANE >= o) incl += u;
+  }
+  int w = threadIdx.x >> 6;
+  if (WG_LANE == 63) sh16[w] = incl;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+  for (int k = 0; k < 16; k++) {
+    uint32_t x = sh16[k];
+    if (k < w) woff += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return woff + incl - v;
+}
+
+template <class F>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(F f, unsigned long long* partials) {
+  __shared__ uint64_t sh[SCAN_BLOCK / 64];
+  uint32_t n = f.count(), lo, hi;
+  scan_range(n, lo, hi);
+  uint64_t acc = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
+  uint64_t tot = block_sum64(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+template <class F>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(F f, const unsigned long long* partials) {
+  __shared__ uint64_t sh[SCAN_BLOCK / 64];
+  __shared__ uint64_t shw[SCAN_BLOCK / 64];
+  uint32_t n = f.count(), lo, hi;
+  scan_range(n, lo, hi);
+  uint64_t before = 0, all = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += SCAN_BLOCK) {
+    uint64_t p = partials[b];
+    all += p;
+    if (b < blockIdx.x) before += p;
+  }
+  uint64_t prefix = block_sum64(before, sh);
+  uint64_t total = block_sum64(all, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) f.total(total);
+  int w = threadIdx.x >> 6;
+  for (uint32_t base = lo; base < hi; base += SCAN_BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint64_t v = i < hi ? f.value(i) : 0;
+    uint64_t incl = wave_incl_scan64(v);
+    if (WG_LANE == 63) shw[w] = incl;
+    __syncthreads();
+    uint64_t woff = 0, tile = 0;
+    for (int k = 0; k < SCAN_BLOCK / 64; k++) {
+      uint64_t x = shw[k];
+      if (k < w) woff += x;
+      tile += x;
+    }
+    if (i < hi) f.write(i, prefix + woff + incl - v);
+    prefix += tile;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// expand: bucket t, LIFO, chain runs unrolled
+struct ExpandF {
+  EngineDev d;
+  int32_t t;
+  __device__ uint32_t bucket() const { return (uint32_t)t & (uint32_t)(d.horizon - 1); }
+  __device__ uint32_t count() const { return d.bcnt[bucket()]; }
+  __device__ uint32_t runlen(const Rec& r) const {
+    if (rec_kind(r) != K_CHAIN) return 1;
+    const Chain c = d.chains[r.w1];
+    uint32_t len = 1;
+    for (int j = (int)r.w2 + 1; j < c.ndest && chain_arrival(d, c, j) == t; j++) len++;
+    return len;
+  }
+  __device__ uint64_t value(uint32_t i) const { return runlen(*rec_ptr(d, bucket(), count() - 1 - i)); }
+  __device__ void total(uint64_t tot) const {
+    if (tot > d.maxEvents) {
+      set_err(d.g, ERR_EVENTS);
+      tot = 0;
+    }
+    d.g->nEvents = (uint32_t)tot;
+  }
+  __device__ void write(uint32_t i, uint64_t excl) const {
+    const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
+    uint32_t e = (uint32_t)excl;
+    if (rec_kind(r) != K_CHAIN) {
+      if (e >= d.maxEvents) return;
+      d.ev[e] = r;
+      d.evChain[e] = -1;
+      d.evCpos[e] = 0;
+      d.evLast[e] = 0;
+      atomicAdd(&d.cntN[r.w1], 1u);
+      return;
+    }
+    const Chain c = d.chains[r.w1];
+    uint32_t len = runlen(r);
+    for (uint32_t k = 0; k < len; k++, e++) {
+      if (e >= d.maxEvents) return;
+      int32_t to = chain_dest(d, c, (int)r.w2 + (int)k);
+      d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+      d.evChain[e] = (int32_t)r.w1;
+      d.evCpos[e] = (int32_t)r.w2 + (int32_t)k;
+      d.evLast[e] = (k + 1 == len);
+      atomicAdd(&d.cntN[to], 1u);
+    }
+  }
+};
+
+// group: per-node offsets + list of active nodes (pair scan: high = active flag, low = count)
+struct NodesF {
+  EngineDev d;
+  __device__ uint32_t count() const { return (uint32_t)d.nodes.n; }
+  __device__ uint64_t value(uint32_t i) const {
+    uint32_t c = d.cntN[i];
+    return ((uint64_t)(c > 0) << 32) | c;
+  }
+  __device__ void total(uint64_t tot) const { d.g->nActive = (uint32_t)(tot >> 32); }
+  __device__ void write(uint32_t i, uint64_t excl) const {
+    d.nodeOff[i] = (uint32_t)excl;
+    if (d.cntN[i] > 0) d.active[(uint32_t)(excl >> 32)] = i;
+  }
+};
+
+__global__ void __launch_bounds__(256) k_fill(EngineDev d) {
+  uint32_t n = d.g->nEvents;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    uint32_t to = d.ev[e].w1;
+    uint32_t pos = atomicAdd(&d.fillN[to], 1u);
+    d.inbox[d.nodeOff[to] + pos] = e;
+  }
+}
+
+// order: per-event (records, draws) -> offsets in the global push order / draw order
+struct RecsF {
+  EngineDev d;
+  __device__ uint32_t count() const { return d.g->nEvents; }
+  __device__ uint64_t value(uint32_t i) const { return ((uint64_t)d.evNdraw[i] << 32) | d.evNrec[i]; }
+  __device__ void total(uint64_t tot) const {
+    d.g->nOut = (uint32_t)tot;
+    d.g->nDraws = (uint32_t)(tot >> 32);
+  }
+  __device__ void write(uint32_t i, uint64_t excl) const {
+    d.evRecOff[i] = (uint32_t)excl;
+    d.evDrawOff[i] = (uint32_t)(excl >> 32);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// resolve: unordered outbox -> ordered outbox (fin, arr). One thread per record.
+// Network.send / createMessageArrival(s) (C/Network.java:369-382,418-487).
+__device__ __forceinline__ int32_t draw_next_int(const EngineDev& d, uint32_t drawIdx) {
+  uint64_t s = lcg_skip(d.g->rng, (uint64_t)drawIdx + 1);
+  return (int32_t)(int64_t)(s >> 16);
+}
+
+__device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from, int32_t to, int32_t sendTime,
+                                               int32_t seed, int32_t& arrival) {
+  const NodeArrays& n = d.nodes;
+  if (n.part[from] != n.part[to] || n.down[from] || n.down[to]) return false;
+  int32_t nt = dev_latency(d, from, to, seed);
+  if (nt >= d.discardTime) return false;
+  arrival = sendTime + nt;
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_resolve(EngineDev d, int32_t t) {
+  uint32_t n = d.g->nOutTmp;
+  if (n > d.maxOut) n = d.maxOut;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const Out o = d.outTmp[r];
+    uint32_t p = d.evRecOff[o.ev] + (o.subs & 0xFFFFu);
+    if (p >= d.maxOut) continue;
+    uint32_t kind = o.kindfrom >> 28;
+    int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
+    Rec fin = make_rec(K_MSG, from, 0, 0, 0);
+    int32_t arrival = -1;
+    switch (kind) {
+      case O_SEND: {
+        int32_t seed = draw_next_int(d, d.evDrawOff[o.ev] + (o.subs >> 16));
+        fin = make_rec(K_MSG, from, (uint32_t)o.to, o.a, o.b);
+        if (!arrival_of_send(d, from, o.to, o.t, seed, arrival)) arrival = -1;
+        break;
+      }
+      case O_MULTI: {  // delaysBetweenMessage == 0 only (device actions); stable sort by arrival (:464)
+        int32_t seed = draw_next_int(d, d.evDrawOff[o.ev] + (o.subs >> 16));
+        int nd = o.to;
+        int32_t dst[64], arv[64];
+        int m = 0;
+        for (int j = 0; j < nd && j < 64; j++) {
+          int32_t to = d.dests[(o.destOff + (unsigned long long)j) % d.chainDests];
+          int32_t a;
+          if (!arrival_of_send(d, from, to, o.t, seed, a)) continue;
+          int k = m++;
+          while (k > 0 && arv[k - 1] > a) {  // insertion keeps equal arrivals in caller order
+            arv[k] = arv[k - 1];
+            dst[k] = dst[k - 1];
+            k--;
+          }
+          arv[k] = a;
+          dst[k] = to;
+        }
+        if (m == 1) {
+          fin = make_rec(K_MSG, from, (uint32_t)dst[0], o.a, o.b);
+          arrival = arv[0];
+        } else if (m > 1) {
+          uint32_t slot = atomicAdd(&d.g->chainHead, 1u) % d.chainSlots;
+          if (d.chains[slot].flags & 1u) {
+            set_err(d.g, ERR_CHAIN_SLOTS);
+            break;
+          }
+          for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)j) % d.chainDests] = dst[j];
+          Chain c;
+          c.from = from;
+          c.seed = seed;
+          c.sendTime = o.t;
+          c.ndest = m;
+          c.destOff = o.destOff;
+          c.msg = o.a;
+          c.payload = o.b;
+          c.flags = 1u;
+          d.chains[slot] = c;
+          fin = make_rec(K_CHAIN, from, slot, 0, 0);
+          arrival = arv[0];
+        }
+        break;
+      }
+      case O_TASK:
+        fin = make_rec(K_TASK, from, (uint32_t)o.to, o.a, o.b);
+        arrival = o.t;
+        break;
+      case O_PERIODIC:
+        fin = make_rec(K_PERIODIC, from, (uint32_t)o.to, o.a, o.b);
+        arrival = o.t;
+        break;
+      default: {  // O_CHAINCONT: msgs.addMsg(m) after markRead (C/Network.java:629-632)
+        const Chain c = d.chains[o.to];
+        fin = make_rec(K_CHAIN, from, (uint32_t)o.to, o.a, 0);
+        arrival = chain_arrival(d, c, (int)o.a);
+      }
+    }
+    if (arrival >= 0) {
+      if (arrival < t) {
+        set_err(d.g, ERR_ARRIVAL_PAST);
+        arrival = -1;
+      } else if (arrival == t) {
+        set_err(d.g, ERR_SAME_MS);
+        arrival = -1;
+      } else if (arrival - t >= d.horizon) {
+        set_err(d.g, ERR_HORIZON);
+        arrival = -1;
+      }
+    }
+    d.fin[p] = fin;
+    d.arr[p] = arrival;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// append: stable multisplit of the ordered outbox by arrival bucket.
+constexpr int TILE = 1024;
+
+// in-tile stable rank of each element among equal bins: wave-level ballot match, then waves in order
+// through an LDS running count. `hist` is this block's LDS histogram [D]; must be zero on entry and
+// holds the per-bin tile totals on exit.
+__device__ __forceinline__ uint32_t tile_rank(uint32_t* hist, int bin, bool valid, int binBits) {
+  uint64_t m = __ballot(valid);
+  if (valid) {
+    for (int b = 0; b < binBits; b++) {
+      uint64_t bb = __ballot((bin >> b) & 1);
+      m &= ((bin >> b) & 1) ? bb : ~bb;
+    }
+  }
+  uint32_t rankInWave = __popcll(m & lanes_lt());
+  uint32_t group = __popcll(m);
+  uint32_t rank = 0;
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = 0; k < nw; k++) {
+    if (k == w && valid) {
+      rank = hist[bin] + rankInWave;
+    }
+    __syncthreads();
+    if (k == w && valid && rankInWave + 1 == group) hist[bin] += group;
+    __syncthreads();
+  }
+  return rank;
+}
+
+__global__ void __launch_bounds__(TILE) k_tile_hist(EngineDev d, int32_t t, int binBits) {
+  extern __shared__ uint32_t hist[];
+  uint32_t n = d.g->nOut;
+  uint32_t nTiles = (n + TILE - 1) / TILE;
+  uint32_t D = (uint32_t)d.horizon;
+  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+    __syncthreads();
+    uint32_t i = tile * TILE + threadIdx.x;
+    if (i < n) {
+      int32_t a = d.arr[i];
+      if (a >= 0) atomicAdd(&hist[(uint32_t)a & (D - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) d.tileHist[(size_t)tile * D + b] = hist[b];
+    __syncthreads();
+  }
+}
+
+// single block: per-bin exclusive prefix over tiles (in place), then reserve pages for every bucket
+// that grows (MessageStorage.ensureSize analogue) and publish each bucket's append base.
+__global__ void __launch_bounds__(1024) k_col_reserve(EngineDev d) {
+  __shared__ uint32_t shNeed[16];
+  __shared__ uint32_t shBase;
+  uint32_t n = d.g->nOut;
+  uint32_t nTiles = (n + TILE - 1) / TILE;
+  uint32_t D = (uint32_t)d.horizon;
+  for (uint32_t b0 = 0; b0 < D; b0 += 1024) {
+    uint32_t b = b0 + threadIdx.x;
+    uint32_t add = 0;
+    if (b < D) {
+      for (uint32_t tile = 0; tile < nTiles; tile++) {
+        uint32_t h = d.tileHist[(size_t)tile * D + b];
+        d.tileHist[(size_t)tile * D + b] = add;
+        add += h;
+      }
+    }
+    uint32_t have = 0, need = 0, cur = 0;
+    if (b < D) {
+      cur = d.bcnt[b];
+      have = (cur + PAGE_RECS - 1) >> PAGE_SHIFT;
+      need = ((cur + add + PAGE_RECS - 1) >> PAGE_SHIFT) - have;
+      if (have + need > (uint32_t)d.maxPagesPerBucket) {
+        set_err(d.g, ERR_BUCKET_PAGES);
+        need = 0;
+        add = 0;
+      }
+    }
+    uint32_t totalNeed;
+    uint32_t before = block_excl_scan32_1024(need, shNeed, &totalNeed);
+    if (threadIdx.x == 0) shBase = d.g->freeTop;
+    __syncthreads();
+    bool ok = totalNeed <= shBase;
+    if (!ok && threadIdx.x == 0) set_err(d.g, ERR_BUCKET_POOL);
+    if (b < D) {
+      if (ok) {
+        for (uint32_t k = 0; k < need; k++)
+          d.pagetab[(size_t)b * d.maxPagesPerBucket + have + k] = d.freeStack[shBase - 1 - (before + k)];
+        d.binBase[b] = cur;
+        d.bcnt[b] = cur + add;
+      } else {
+        d.binBase[b] = cur;  // nothing appended
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && ok) d.g->freeTop = shBase - totalNeed;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int32_t t, int binBits) {
+  extern __shared__ uint32_t hist[];
+  uint32_t n = d.g->nOut;
+  uint32_t nTiles = (n + TILE - 1) / TILE;
+  uint32_t D = (uint32_t)d.horizon;
+  if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) return;
+  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+    __syncthreads();
+    uint32_t i = tile * TILE + threadIdx.x;
+    int32_t a = i < n ? d.arr[i] : -1;
+    bool valid = a >= 0;
+    int bin = valid ? (int)((uint32_t)a & (D - 1)) : 0;
+    uint32_t rank = tile_rank(hist, bin, valid, binBits);
+    if (valid) {
+      uint32_t pos = d.binBase[bin] + d.tileHist[(size_t)tile * D + bin] + rank;
+      *rec_ptr(d, (uint32_t)bin, pos) = d.fin[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
+// release the bucket's pages and bump the nextMessage() epoch if anything was polled.
+__global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int32_t t, int drained) {
+  __shared__ uint32_t shTop;
+  Globals* g = d.g;
+  if (threadIdx.x == 0) shTop = g->freeTop;
+  __syncthreads();
+  if (drained) {
+    uint32_t b = (uint32_t)t & (uint32_t)(d.horizon - 1);
+    uint32_t cnt = d.bcnt[b];
+    uint32_t pages = (cnt + PAGE_RECS - 1) >> PAGE_SHIFT;
+    for (uint32_t k = threadIdx.x; k < pages; k += blockDim.x)
+      d.freeStack[shTop + k] = d.pagetab[(size_t)b * d.maxPagesPerBucket + k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      g->freeTop = shTop + pages;
+      d.bcnt[b] = 0;
+      if (g->nEvents > 0) {
+        g->epoch++;
+        g->anyEvent = 1;
+        g->events += g->nEvents;
+      }
+      unsigned long long oldD = d.destHeadAt[b], oldP = d.payloadHeadAt[b];
+      if (g->destHead - oldD > d.chainDests) set_err(g, ERR_CHAIN_DESTS);
+      if (g->payloadHead - oldP > d.payloadWords) set_err(g, ERR_PAYLOAD);
+      d.destHeadAt[b] = g->destHead;
+      d.payloadHeadAt[b] = g->payloadHead;
+    }
+  }
+  if (threadIdx.x == 0) {
+    g->rng = lcg_skip(g->rng, g->nDraws);
+    g->draws += g->nDraws;
+    g->nEvents = 0;
+    g->nActive = 0;
+    g->nOutTmp = 0;
+    g->nOut = 0;
+    g->nDraws = 0;
+    g->rejectSeen = 0;
+  }
+}
+
+__global__ void k_latency_probe(EngineDev d, int n, const int32_t* from, const int32_t* to, const int32_t* delta,
+                                int32_t* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const NodeArrays& nd = d.nodes;
+  int f = from[i], t = to[i];
+  out[i] = latency_of(d.lat, f, t, nd.x[f], nd.y[f], nd.extraLatency[f], nd.x[t], nd.y[t], nd.extraLatency[t],
+                      delta[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delivery context handed to protocol action() code. One wavefront per destination node; every
+// lane runs the same control flow, scalars are wave-uniform, lane 0 performs the scalar stores.
+struct Ctx {
+  const EngineDev& d;
+  int32_t t;       // network.time
+  int32_t node;    // the node whose action() runs (`to`)
+  uint32_t ev;     // event index in the global order
+  uint32_t sub;    // records emitted by this event so far
+  uint32_t draws;  // rd.nextInt() calls by this event so far
+  long long msgSent, bytesSent;  // accumulated Node counters (C/Network.java:476-477)
+
+  __device__ uint32_t alloc_out() {
+    uint32_t idx = 0;
+    if (WG_LANE == 0) {
+      idx = atomicAdd(&d.g->nOutTmp, 1u);
+      if (idx >= d.maxOut) {
+        set_err(d.g, ERR_OUTBOX);
+        idx = 0xFFFFFFFFu;
+      }
+    }
+    return idx;  // valid on lane 0 only
+  }
+  __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw) {
+    uint32_t idx = alloc_out();
+    if (WG_LANE == 0 && idx != 0xFFFFFFFFu) {
+      Out o;
+      o.ev = ev;
+      o.subs = sub | (draws << 16);
+      o.kindfrom = (kind << 28) | (uint32_t)node;
+      o.to = to;
+      o.a = a;
+      o.b = b;
+      o.t = tt;
+      o.destOff = destOff;
+      d.outTmp[idx] = o;
+    }
+    sub++;
+    if (draw) draws++;
+  }
+  // Network.send(m, this, to): sendTime = time + 1, one rd.nextInt() (C/Network.java:364-382)
+  __device__ void send(int32_t to, uint32_t msg, uint32_t payload, int size) {
+    msgSent++;
+    bytesSent += size;
+    put(O_SEND, to, msg, payload, t + 1, 0, true);
+  }
+  // Network.send(m, this, dests) (:353-362): empty -> nothing, one -> single send, else multi-dest.
+  // The destination ids must already be in the dest ring at destOff (dest_reserve).
+  __device__ uint32_t dest_reserve(int n) {
+    unsigned long long off = 0;
+    if (WG_LANE == 0) off = atomicAdd(&d.g->destHead, (unsigned long long)n);
+    off = shfl64(off, 0);
+    return (uint32_t)(off % d.chainDests);
+  }
+  __device__ void dest_put(uint32_t destOff, int j, int32_t id) {
+    d.dests[(destOff + (unsigned long long)j) % d.chainDests] = id;
+  }
+  __device__ void send_list(uint32_t destOff, int n, uint32_t msg, uint32_t payload, int size) {
+    if (n == 0) return;
+    msgSent += n;
+    bytesSent += (long long)n * size;
+    if (n == 1) {
+      int32_t to = __hip_atomic_load(&d.dests[destOff % d.chainDests], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      put(O_SEND, to, msg, payload, t + 1, 0, true);
+    } else {
+      if (n > 64) {
+        if (WG_LANE == 0) set_err(d.g, ERR_MULTI_TOO_BIG);
+        n = 64;
+      }
+      put(O_MULTI, n, msg, payload, t + 1, destOff, true);
+    }
+  }
+  // Network.registerTask(r, startAt, this) (:505-508)
+  __device__ void register_task(int32_t startAt, uint32_t word, uint32_t arg) {
+    put(O_TASK, node, word, arg, startAt, 0, false);
+  }
+  // payload ring: `words` 64-bit words, returns ref (word offset)
+  __device__ uint32_t alloc_payload(int words) {
+    unsigned long long off = 0;
+    if (WG_LANE == 0) off = atomicAdd(&d.g->payloadHead, (unsigned long long)words);
+    off = shfl64(off, 0);
+    // keep an allocation contiguous: skip the tail of the ring if it does not fit
+    unsigned long long pos = off % d.payloadWords;
+    if (pos + words > d.payloadWords) {
+      if (WG_LANE == 0) off = atomicAdd(&d.g->payloadHead, (unsigned long long)words);
+      off = shfl64(off, 0);
+      pos = off % d.payloadWords;
+      if (pos + words > d.payloadWords) {
+        if (WG_LANE == 0) set_err(d.g, ERR_PAYLOAD);
+        pos = 0;
+      }
+    }
+    return (uint32_t)pos;
+  }
+};
+
+// The delivery kernel: receiveUntil's loop body (C/Network.java:594-635) for all events of ms t.
+template <class P>
+__global__ void __launch_bounds__(256) k_deliver(EngineDev d, typename P::State ps, int32_t t) {
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  for (uint32_t a = wave; a < nActive; a += nWaves) {
+    const int32_t node = (int32_t)d.active[a];
+    const uint32_t off = d.nodeOff[node], cnt = d.cntN[node];
+    // event order inside the node: rank sort of the (unordered) inbox segment by event index
+    for (uint32_t i = lane; i < cnt; i += 64) {
+      uint32_t e = d.inbox[off + i], rank = 0;
+      for (uint32_t j = 0; j < cnt; j++) rank += d.inbox[off + j] < e;
+      d.inbox2[off + rank] = e;
+    }
+    __threadfence_block();
+    Ctx c{d, t, node, 0, 0, 0, 0, 0};
+    long long nRecv = 0, bRecv = 0, nTasks = 0;
+    const bool toDown = d.nodes.down[node] != 0;
+    const uint8_t toPart = d.nodes.part[node];
+    P::node_begin(c, ps);
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t e = d.inbox2[off + k];
+      const Rec r = d.ev[e];
+      const uint32_t kind = rec_kind(r);
+      const int32_t from = rec_from(r);
+      c.ev = e;
+      c.sub = 0;
+      c.draws = 0;
+      if (!toDown && d.nodes.part[from] == toPart) {  // :606
+        if (kind == K_MSG) {
+          nRecv++;
+          bRecv += P::msg_size(ps, r.w2);
+          P::on_message(c, ps, from, r.w2, r.w3);
+        } else {
+          nTasks++;
+          P::on_task(c, ps, r.w2, r.w3);
+          if (kind == K_PERIODIC)  // PeriodicTask.action re-arm (C/messages/PeriodicTask.java:39-47)
+            c.put(O_PERIODIC, node, r.w2, r.w3, t + (int32_t)r.w3, 0, false);
+        }
+      }
+      const int32_t slot = d.evChain[e];
+      if (slot >= 0 && d.evLast[e]) {  // markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
+        const int32_t next = d.evCpos[e] + 1;
+        if (next < d.chains[slot].ndest)
+          c.put(O_CHAINCONT, slot, (uint32_t)next, 0, 0, 0, false);
+        else if (lane == 0)
+          d.chains[slot].flags = 0;  // envelope fully delivered
+      }
+      if (lane == 0) {
+        d.evNrec[e] = c.sub;
+        d.evNdraw[e] = c.draws;
+      }
+      __threadfence_block();
+    }
+    P::node_end(c, ps);
+    if (lane == 0) {
+      d.nodes.msgReceived[node] += nRecv;
+      d.nodes.bytesReceived[node] += bRecv;
+      d.nodes.msgSent[node] += c.msgSent;
+      d.nodes.bytesSent[node] += c.bytesSent;
+      d.cntN[node] = 0;
+      d.fillN[node] = 0;
+      if (nRecv) atomicAdd(&d.g->delivered, (unsigned long long)nRecv);
+      if (nTasks) atomicAdd(&d.g->tasks, (unsigned long long)nTasks);
+    }
+  }
+}
+
+}  // namespace wg

@@ -1,0 +1,290 @@
+// Host-side mirror of the reference's Protocol.init() for the resident protocols (see
+// include/wittgpu_host.h). Pure host C++ over the public C ABI: nothing here touches engine
+// internals, so the same sequence is what a Java `init()` performs through the JNI shim.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/wittgpu_host.h"
+#include "jdk_random.h"
+
+using wg::JavaRandom;
+
+static thread_local std::string g_err;
+static thread_local double g_initSeconds = 0;
+
+namespace {
+
+// RegistryNodeBuilders (C/RegistryNodeBuilders.java:28-81), RANDOM location only.
+struct Builder {
+  bool speedUniform = false;  // the registry's "GAUSSIAN" entries install UniformSpeed (:59-61)
+  double tor = 0.0;
+};
+bool parse_builder(const char* name, Builder& b) {
+  std::string s = name ? name : "";
+  if (s.empty()) return true;
+  if (s.rfind("RANDOM_SPEED=", 0) != 0) {
+    g_err = s + " not in the registry of the device engine (RANDOM builders only)";
+    return false;
+  }
+  b.speedUniform = s.find("SPEED=GAUSSIAN") != std::string::npos;
+  size_t p = s.find("_TOR=");
+  if (p == std::string::npos) {
+    g_err = s + " not in the registry";
+    return false;
+  }
+  double tor = atof(s.c_str() + p + 5);
+  if (tor > 0.001) b.tor = tor;
+  return true;
+}
+
+struct NodeSoA {
+  std::vector<int32_t> x, y, extra;
+  std::vector<uint8_t> down;
+  std::vector<double> speed;
+};
+
+// new Node(rd, nb) — C/Node.java:246-271 with NodeBuilderWithRandomPosition (C/NodeBuilder.java:77-96)
+void build_node(JavaRandom& rd, const Builder& b, NodeSoA& out) {
+  int32_t r = rd.nextInt();
+  int64_t rx = (int64_t)(r >> 16);
+  if (rx < 0) rx = -rx;
+  int64_t ry = (int64_t)(int32_t)((uint32_t)r << 16);
+  if (ry < 0) ry = -ry;
+  out.x.push_back((int32_t)(rx % 2000 + 1));
+  out.y.push_back((int32_t)(ry % 1112 + 1));
+  double speed = 1.0;
+  if (b.speedUniform) speed = rd.nextBoolean() ? (rd.nextInt(67) + 33) / 100.0 : (rd.nextInt(200) + 100) / 100.0;
+  int32_t extra = 0;
+  if (b.tor > 0) extra = rd.nextDouble() < b.tor ? 500 : 0;
+  out.speed.push_back(speed);
+  out.extra.push_back(extra);
+  out.down.push_back(0);
+}
+
+struct Cleanup {
+  wg_engine* e;
+  bool keep = false;
+  ~Cleanup() {
+    if (e && !keep) wg_destroy(e);
+  }
+};
+
+#define CK(call)                                   \
+  do {                                             \
+    int32_t _rc = (call);                          \
+    if (_rc != WG_OK) {                            \
+      g_err = wg_last_error(e);                    \
+      return _rc;                                  \
+    }                                              \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* wgh_last_error(void) { return g_err.c_str(); }
+double wgh_last_init_seconds(void) { return g_initSeconds; }
+
+int32_t wgh_jrandom_ints(int64_t seed, int32_t n, int32_t* out) {
+  JavaRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextInt();
+  return WG_OK;
+}
+int32_t wgh_jrandom_skip_ints(int64_t seed, int32_t n, int32_t* out) {
+  uint64_t s0 = wg::lcg_scramble(seed);
+  for (int i = 0; i < n; i++) out[i] = (int32_t)(int64_t)(wg::lcg_skip(s0, (uint64_t)i + 1) >> 16);
+  return WG_OK;
+}
+int32_t wgh_jrandom_bounded(int64_t seed, int32_t bound, int32_t n, int32_t* out) {
+  if (bound <= 0) return WG_EINVAL;
+  JavaRandom r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.nextInt(bound);
+  return WG_OK;
+}
+
+int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                            const wg_config* cfg, wg_engine** out) {
+  if (!out) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+  if (nodeCt <= 0) {
+    g_err = "nodeCt";
+    return WG_EINVAL;
+  }
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // PingPong ctor :52-57
+  JavaRandom rd(seed);
+  NodeSoA nodes;
+  for (int i = 0; i < nodeCt; i++) build_node(rd, b, nodes);  // init() :82-84
+  CK(wg_add_nodes(e, nodeCt, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
+                  nodes.speed.data()));
+  CK(wg_rng_set_state(e, rd.s));
+  CK(wg_protocol_load(e, WG_PROTO_PINGPONG, nullptr, nullptr));
+  // network.sendAll(new Ping(), getNodeById(0))  :86 -> send(m, time + 1, from, allNodes)
+  std::vector<int32_t> all(nodeCt);
+  for (int i = 0; i < nodeCt; i++) all[i] = i;
+  CK(wg_send(e, /*Ping*/ 0u, 0u, 1, 0, all.data(), nodeCt, 0));
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
+int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName,
+                          int64_t seed, const wg_config* cfg, wg_engine** out) {
+  if (!out || !pp) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  wg_handel_params p = *pp;
+  if (p.windowInitial == 0 && p.windowMinimum == 0 && p.windowMaximum == 0) {  // new WindowParameters() :155-157
+    p.windowInitial = 16;
+    p.windowMinimum = 1;
+    p.windowMaximum = 128;
+  }
+  const int32_t N = p.nodeCount;
+  // HandelParameters ctor checks (:113-125)
+  if (N <= 0 || p.nodesDown >= N || p.nodesDown < 0 || p.threshold > N || p.nodesDown + p.threshold > N) {
+    g_err = "nodeCount=" + std::to_string(N) + ", threshold=" + std::to_string(p.threshold);
+    return WG_EINVAL;
+  }
+  if (__builtin_popcount((unsigned)N) != 1) {
+    g_err = "We support only power of two nodes in this simulation";
+    return WG_EINVAL;
+  }
+  if (p.disseminationPeriodMs <= 0 || p.pairingTime < 0) {
+    g_err = "period/pairingTime";
+    return WG_EINVAL;
+  }
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // Handel ctor :208-212
+  JavaRandom rd(seed);
+
+  // Network.chooseBadNodes (C/Network.java:52-64)
+  std::vector<uint8_t> bad(N, 0);
+  for (int setDown = 0; setDown < p.nodesDown;) {
+    int32_t d = rd.nextInt(N);
+    if (d != 1 && !bad[d]) {
+      bad[d] = 1;
+      setDown++;
+    }
+  }
+  // node construction loop (:965-974)
+  NodeSoA nodes;
+  std::vector<int32_t> startAt(N), pairing(N);
+  for (int i = 0; i < N; i++) {
+    startAt[i] = p.desynchronizedStart == 0 ? 0 : rd.nextInt(p.desynchronizedStart);
+    build_node(rd, b, nodes);
+    double pt = p.pairingTime * nodes.speed[i];
+    pairing[i] = (int32_t)(pt > 1.0 ? pt : 1.0);  // (int) Math.max(1, pairingTime * speedRatio)  :283
+    nodes.down[i] = bad[i];
+  }
+  CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
+                  nodes.speed.data()));
+  // registerPeriodicTask(dissemination, startAt + 1, period) for live nodes, in id order (:976-984).
+  // The conditional task (checkSigs) is part of the resident protocol's state (minStartTime = startAt + 1).
+  for (int i = 0; i < N; i++)
+    if (!bad[i]) CK(wg_register_periodic_task(e, /*dissemination*/ 0u, startAt[i] + 1, p.disseminationPeriodMs, i));
+
+  // setReceivingRanks (:940-948): one list, shuffled cumulatively once per node.
+  std::vector<int32_t> ranks((size_t)N * N);
+  {
+    std::vector<int32_t> expected(N);
+    for (int i = 0; i < N; i++) expected[i] = i;
+    for (int n = 0; n < N; n++) {
+      for (int32_t i = N; i > 1; i--) std::swap(expected[i - 1], expected[rd.nextInt(i)]);  // Collections.shuffle
+      int32_t* row = ranks.data() + (size_t)n * N;
+      for (int i = 0; i < N; i++) row[expected[i]] = i;
+    }
+  }
+  // Emission lists (:991-1013, buildEmissionList :510-522). For sender s and level l the receivers are
+  // the sibling block of size 2^(l-1) in ascending id (expectedNodes :446-455); they are bucketed by
+  // receiver.receptionRanks[s], buckets walked in rank order, a bucket with >1 entries shuffled with rd.
+  const int L = 32 - __builtin_clz((unsigned)N);  // levels 0..log2(N)
+  std::vector<int32_t> peers((size_t)N * (N > 1 ? N - 1 : 1), -1);
+  {
+    // column s of `ranks` is read for every sender: transpose tile-wise first (cache friendly)
+    std::vector<int32_t> ranksT((size_t)N * N);
+    const int TB = 64;
+    for (int i0 = 0; i0 < N; i0 += TB)
+      for (int j0 = 0; j0 < N; j0 += TB)
+        for (int i = i0; i < std::min(N, i0 + TB); i++)
+          for (int j = j0; j < std::min(N, j0 + TB); j++) ranksT[(size_t)j * N + i] = ranks[(size_t)i * N + j];
+    std::vector<uint32_t> keyA, keyB;  // (rank << 32 | receiver) would need 64 bits; ranks < N <= 2^28
+    std::vector<uint64_t> a, tmp;
+    for (int s = 0; s < N; s++) {
+      if (bad[s]) continue;
+      const int32_t* col = ranksT.data() + (size_t)s * N;  // col[r] = ranks[r][s]
+      for (int l = 1; l < L; l++) {
+        const int size = 1 << (l - 1);
+        const int base = ((s >> (l - 1)) ^ 1) << (l - 1);
+        a.resize(size);
+        for (int k = 0; k < size; k++) a[k] = ((uint64_t)(uint32_t)col[base + k] << 32) | (uint32_t)(base + k);
+        // stable sort by rank: LSD radix on the rank bits (ids ascending initially => stable)
+        if (size <= 32) {
+          for (int i = 1; i < size; i++) {
+            uint64_t v = a[i];
+            int k = i;
+            while (k > 0 && (a[k - 1] >> 32) > (v >> 32)) {
+              a[k] = a[k - 1];
+              k--;
+            }
+            a[k] = v;
+          }
+        } else {
+          tmp.resize(size);
+          int bitsNeeded = 32 - __builtin_clz((unsigned)N);
+          for (int shift = 0; shift < bitsNeeded; shift += 11) {
+            uint32_t cnt[2049];
+            memset(cnt, 0, sizeof(cnt));
+            for (int k = 0; k < size; k++) cnt[((a[k] >> (32 + shift)) & 2047) + 1]++;
+            for (int k = 0; k < 2048; k++) cnt[k + 1] += cnt[k];
+            for (int k = 0; k < size; k++) tmp[cnt[(a[k] >> (32 + shift)) & 2047]++] = a[k];
+            a.swap(tmp);
+          }
+        }
+        int32_t* dst = peers.data() + (size_t)s * (N - 1) + (size - 1);
+        for (int i = 0; i < size;) {
+          int j = i;
+          while (j < size && (a[j] >> 32) == (a[i] >> 32)) j++;
+          int g = j - i;
+          if (g > 1)
+            for (int32_t k = g; k > 1; k--) std::swap(a[i + k - 1], a[i + rd.nextInt(k)]);
+          for (int k = i; k < j; k++) dst[k] = (int32_t)(uint32_t)a[k];
+          i = j;
+        }
+      }
+    }
+  }
+  CK(wg_rng_set_state(e, rd.s));
+  wg_handel_init_state st;
+  st.startAt = startAt.data();
+  st.nodePairingTime = pairing.data();
+  st.receptionRanks = ranks.data();
+  st.peers = peers.data();
+  CK(wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st));
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
+}  // extern "C"

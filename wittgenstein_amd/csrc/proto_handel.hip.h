@@ -1,0 +1,705 @@
+// Handel (P/Handel.java) as a resident device protocol. One wavefront per simulated node: scalars
+// are wave-uniform, lane k owns the 64-bit words w with (w & 63) == k of every bitset row of the
+// node, so bitset algebra (or/and/cardinality/intersects) is a coalesced pass + a wave reduction.
+//
+// State layout (struct-of-arrays, HBM):
+//   bit rows  TI,LA,VI,TV,FP : [N][W] uint64, W = N/64. Bit j = node id j. HLevel l's bitsets
+//             (totalIncoming, lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers
+//             :373-394) only ever hold ids of the level's aligned sibling block of 2^(l-1) ids
+//             (allSigsAtLevel :671-684), and the blocks of different levels are disjoint, so one row
+//             per kind holds all levels. totalOutgoing of level l is always the union of
+//             totalIncoming of levels < l (:728-731) = the node's OWN aligned block in the TI row.
+//   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] int32 emission lists (:510-522)
+//   queues    toVerifyAgg (:385): per (node, level) up to Q slots {from, rank, sig[2^(l-1) bits]} in a
+//             private slab + an order list; a slot stays allocated while a registered
+//             updateVerifiedSignatures task still references it (:833-836).
+// Honest-node paths only: byzantineSuicide / hiddenByzantine (:538-559, :840-917) are not resident.
+#pragma once
+#include "engine_kernels.hip.h"
+
+namespace wg {
+
+constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks per node
+constexpr uint32_t H_TASK_DISSEMINATION = 0;
+constexpr uint32_t H_TASK_UPDATE = 1;
+
+struct HandelState {
+  wg_handel_params p;
+  int32_t N, L, W, Q;
+  uint64_t *TI, *LA, *VI, *TV, *FP;   // [N][W]
+  int32_t* ranks;                      // [N][N]
+  int32_t* peers;                      // [N][N-1]
+  int32_t *startAt, *pairing, *window, *addedCycle, *sigsChecked, *sigQueueSize, *msgFiltered;  // [N]
+  int32_t* ctMinStart;                 // ConditionalTask.minStartTime
+  uint32_t* ctEpoch;                   // epoch in which the task left nextMessage()'s private copy
+  int32_t *pos, *cTI, *cLA, *cVI;      // [N][L]
+  uint8_t* outFin;                     // [N][L]
+  uint8_t* qlen;                       // [N][L]
+  uint8_t* qorder;                     // [N][L][64] slot ids in list order
+  unsigned long long* qused;           // [N][L] slots allocated
+  int32_t *qfrom, *qrank;              // [N][L][Q]
+  uint64_t* qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
+  unsigned long long qsigOff[MAX_LEVELS];
+  uint32_t* pend;                      // [N][H_PEND]: valid<<31 | level<<24 | slot<<18 | ... ; from in pendFrom
+  int32_t* pendFrom;                   // [N][H_PEND]
+  // conditional-task phase scratch
+  uint8_t* candCnt;                    // [N] number of levels with a candidate
+  uint8_t* candLevel;                  // [N][L]
+  uint8_t* candSlot;                   // [N][L]
+  uint32_t* condOrd;                   // [N] ordinal among drawing nodes
+  uint32_t* condList;                  // drawing nodes in id order
+  int32_t* drawVal;                    // [N]
+};
+
+// geometry of one level inside a row
+struct Lv {
+  int32_t size;   // ids in the block = expectedSigs()
+  int32_t bw;     // first 64-bit word
+  int32_t nw;     // number of words
+  uint64_t mask;  // bits of the block inside the word when nw == 1 and size < 64, else ~0
+};
+__device__ __forceinline__ Lv block_view(int32_t firstId, int32_t size) {
+  Lv v;
+  v.size = size;
+  v.bw = firstId >> 6;
+  if (size >= 64) {
+    v.nw = size >> 6;
+    v.mask = ~0ULL;
+  } else {
+    v.nw = 1;
+    v.mask = ((1ULL << size) - 1ULL) << (firstId & 63);
+  }
+  return v;
+}
+// the sibling block: ids whose signatures level l waits for (waitedSigs :424-432)
+__device__ __forceinline__ Lv sib_view(int32_t node, int l) {
+  if (l == 0) return block_view(node, 1);
+  return block_view(((node >> (l - 1)) ^ 1) << (l - 1), 1 << (l - 1));
+}
+// the node's own block: ids that totalOutgoing of level l can hold
+__device__ __forceinline__ Lv own_view(int32_t node, int l) { return block_view((node >> (l - 1)) << (l - 1), 1 << (l - 1)); }
+
+__device__ __forceinline__ int h_nw(int l) { return l == 0 ? 1 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1); }
+__device__ __forceinline__ int h_msg_size(int l) { return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 96 * 2; }  // :256-260
+
+// word j of a view is owned by lane (bw + j) & 63
+#define H_FOR_WORDS(v, j)                                                                      \
+  for (int j = (int)((WG_LANE - (v).bw) & 63); j < (v).nw; j += 64)
+
+__device__ __forceinline__ uint64_t ld_coherent(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool row_get(const uint64_t* row, int32_t id) { return (ld_coherent(row + (id >> 6)) >> (id & 63)) & 1ULL; }
+__device__ __forceinline__ void row_set(uint64_t* row, int32_t id, bool v) {
+  int w = id >> 6;
+  if ((int)WG_LANE == (w & 63)) {
+    uint64_t x = row[w];
+    row[w] = v ? (x | (1ULL << (id & 63))) : (x & ~(1ULL << (id & 63)));
+  }
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl64(v, WG_LANE ^ o);
+  return v;
+}
+
+// per-wave LDS mirror of the (node, level) scalars
+struct LevelScalars {
+  int32_t pos[MAX_LEVELS];
+  int32_t cTI[MAX_LEVELS];
+  int32_t cLA[MAX_LEVELS];
+  int32_t cVI[MAX_LEVELS];
+  int32_t qlen[MAX_LEVELS];
+  int32_t outFin[MAX_LEVELS];
+  unsigned long long qused[MAX_LEVELS];
+};
+
+struct HandelProto {
+  typedef HandelState State;
+
+  // node-scoped registers (wave-uniform) live in this struct for the duration of a node's events
+  struct NodeRegs {
+    long long doneAt;
+    int32_t addedCycle, sigQueueSize, msgFiltered, startAt;
+    uint32_t pend[H_PEND];
+    int32_t pendFrom[H_PEND];
+    LevelScalars* ls;
+  };
+
+  __device__ static int msg_size(const State&, uint32_t msg) { return h_msg_size((int)(msg & 31u)); }
+
+  __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
+    for (int l = WG_LANE; l < s.L; l += 64) {
+      size_t i = (size_t)node * s.L + l;
+      ls->pos[l] = s.pos[i];
+      ls->cTI[l] = s.cTI[i];
+      ls->cLA[l] = s.cLA[i];
+      ls->cVI[l] = s.cVI[i];
+      ls->qlen[l] = s.qlen[i];
+      ls->outFin[l] = s.outFin[i];
+      ls->qused[l] = s.qused[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
+    __builtin_amdgcn_wave_barrier();
+    for (int l = WG_LANE; l < s.L; l += 64) {
+      size_t i = (size_t)node * s.L + l;
+      s.pos[i] = ls->pos[l];
+      s.cTI[i] = ls->cTI[l];
+      s.cLA[i] = ls->cLA[l];
+      s.cVI[i] = ls->cVI[l];
+      s.qlen[i] = (uint8_t)ls->qlen[l];
+      s.outFin[i] = (uint8_t)ls->outFin[l];
+      s.qused[i] = ls->qused[l];
+    }
+  }
+
+  // ---- queue helpers ---------------------------------------------------------------------------
+  __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int l, int slot) {
+    return s.qsig + s.qsigOff[l] + ((size_t)node * s.Q + slot) * (size_t)h_nw(l);
+  }
+  __device__ static bool slot_pending(const NodeRegs& r, int l, int slot) {
+    bool p = false;
+#pragma unroll
+    for (int k = 0; k < H_PEND; k++) p |= (r.pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot));
+    return p;
+  }
+  // remove list position `at` from the order list of (node, l); lane i holds entry i
+  __device__ static void order_remove(const State& s, int32_t node, int l, int at, int len) {
+    uint8_t* ord = s.qorder + ((size_t)node * s.L + l) * 64;
+    int lane = WG_LANE;
+    int mine = lane < len ? ord[lane] : 0;
+    int next = __shfl_down(mine, 1, 64);
+    if (lane >= at && lane < len - 1) ord[lane] = (uint8_t)next;
+  }
+
+  // ---- getRemainingPeers (:486-508), wave-parallel but sequentially equivalent ------------------
+  // Scans the emission list from posInLevel, 64 peers per step. Accepted peers (not finished) are
+  // appended to the dest ring at destOff (want > 1) or returned (want == 1). Returns the count.
+  __device__ static int remaining_peers(Ctx& c, const State& s, LevelScalars* ls, int l, int want, uint32_t destOff,
+                                        int32_t* single) {
+    const int32_t node = c.node;
+    const int size = 1 << (l - 1);
+    const int32_t* peers = s.peers + (size_t)node * (s.N - 1) + (size - 1);
+    const uint64_t* fp = s.FP + (size_t)node * s.W;
+    int pos = ls->pos[l];
+    const int start = pos;
+    int got = 0;
+    bool fin = false;
+    while (want > 0 && !fin) {
+      int len = min(64, size - pos);
+      int k = WG_LANE;
+      bool in = k < len;
+      int32_t p = in ? peers[pos + k] : 0;
+      bool ok = in && !row_get(fp, p);
+      uint64_t okm = __ballot(ok);
+      // a rejected peer whose successor position is `start` finishes the level (:499-503)
+      int nextPos = pos + k + 1;
+      if (nextPos >= size) nextPos = 0;
+      uint64_t finm = __ballot(in && !ok && nextPos == start);
+      // stop index: the want-th accepted lane, or the finishing lane, whichever comes first
+      int stopAcc = 64, stopFin = finm ? __ffsll((unsigned long long)finm) - 1 : 64;
+      if (__popcll(okm) >= want) {
+        uint64_t m = okm;
+        for (int i = 1; i < want; i++) m &= m - 1;
+        stopAcc = __ffsll((unsigned long long)m) - 1;
+      }
+      int stop = min(stopAcc, stopFin);
+      int consumed = stop < 64 ? stop + 1 : len;
+      uint64_t take = okm & (consumed >= 64 ? ~0ULL : ((1ULL << consumed) - 1ULL));
+      int ntake = __popcll(take);
+      if (ok && k < consumed) {
+        int idx = got + __popcll(take & lanes_lt());
+        if (want == 1 && single && ntake >= 1 && idx == 0) *single = p;  // written by exactly one lane
+        if (destOff != 0xFFFFFFFFu) c.dest_put(destOff, idx, p);
+      }
+      got += ntake;
+      want -= ntake;
+      pos += consumed;
+      if (pos >= size) pos = 0;
+      if (stopFin < 64 && stopFin <= stopAcc && stopFin < consumed) fin = true;
+    }
+    if (WG_LANE == 0) {
+      ls->pos[l] = pos;
+      if (fin) ls->outFin[l] = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return got;
+  }
+
+  // snapshot of totalOutgoing of level l (the node's own block of the TI row) into the payload ring
+  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l) {
+    Lv v = own_view(c.node, l);
+    uint32_t ref = c.alloc_payload(v.nw);
+    const uint64_t* ti = s.TI + (size_t)c.node * s.W;
+    H_FOR_WORDS(v, j) c.d.payload[ref + j] = ti[v.bw + j] & v.mask;
+    return ref;
+  }
+
+  // ---- Message.action: SendSigs -> onNewSig (:757-790) -------------------------------------------
+  __device__ static void on_new_sig(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    const int l = (int)(msg & 31u);
+    const bool levelFinished = (msg >> 5) & 1u;
+    const int32_t node = c.node;
+    if (WG_LANE == 0) {
+      atomicAdd(&c.d.g->deliveredByLevel[l], 1ULL);
+      atomicAdd(&c.d.g->payloadBytes, (unsigned long long)h_nw(l) * 8ULL);
+    }
+    if (r.doneAt > 0) {
+      r.msgFiltered++;
+      return;
+    }
+    if (c.t < r.startAt) return;
+    LevelScalars* ls = r.ls;
+    if (levelFinished) row_set(s.FP + (size_t)node * s.W, from, true);
+    if (!row_get(s.VI + (size_t)node * s.W, from)) row_set(s.TV + (size_t)node * s.W, from, true);
+    r.sigQueueSize++;
+    // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
+    unsigned long long used = ls->qused[l];
+    unsigned long long capMask = s.Q >= 64 ? ~0ULL : ((1ULL << s.Q) - 1ULL);
+    unsigned long long freeM = ~used & capMask;
+    int len = ls->qlen[l];
+    if (freeM == 0 || len >= 64) {
+      if (WG_LANE == 0) set_err(c.d.g, ERR_QUEUE_CAP);
+      return;
+    }
+    int slot = __ffsll(freeM) - 1;
+    Lv v = sib_view(node, l);
+    uint64_t* dst = sig_ptr(s, node, l, slot);
+    H_FOR_WORDS(v, j) dst[j] = c.d.payload[payload + j];
+    if (WG_LANE == 0) {
+      size_t qi = ((size_t)node * s.L + l) * s.Q + slot;
+      s.qfrom[qi] = from;
+      s.qrank[qi] = s.ranks[(size_t)node * s.N + from];
+      s.qorder[((size_t)node * s.L + l) * 64 + len] = (uint8_t)slot;
+      ls->qused[l] = used | (1ULL << slot);
+      ls->qlen[l] = len + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- PeriodicTask: dissemination (:331-343) -> HLevel.doCycle (:474-484) ------------------------
+  __device__ static void dissemination(Ctx& c, const State& s, NodeRegs& r) {
+    if (r.doneAt > 0) {
+      if (r.addedCycle > 0)
+        r.addedCycle--;
+      else
+        return;
+    }
+    LevelScalars* ls = r.ls;
+    int cur = ls->cTI[0];  // |totalOutgoing| of level l = sum of |totalIncoming| below l
+    for (int l = 1; l < s.L; l++) {
+      const int size = 1 << (l - 1);
+      const int below = cur;
+      cur += ls->cTI[l];
+      if (ls->outFin[l]) continue;                                              // isOpen :458-472
+      if (!(c.t >= (l - 1) * s.p.levelWaitTime || below == size)) continue;
+      int32_t dest = -1;
+      int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
+      if (got > 0) {
+        dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
+        uint32_t ref = snapshot_outgoing(c, s, l);
+        bool lf = ls->cTI[l] == size;                                           // incomingComplete :524-526
+        c.send(dest, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
+      }
+    }
+  }
+
+  // ---- Task: updateVerifiedSignatures (:690-754) --------------------------------------------------
+  __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
+    const int32_t node = c.node;
+    const uint32_t pe = r.pend[arg & (H_PEND - 1)];
+    const int32_t from = r.pendFrom[arg & (H_PEND - 1)];
+    if (!(pe & 0x80000000u)) {
+      if (WG_LANE == 0) set_err(c.d.g, ERR_PROTOCOL);
+      return;
+    }
+    const int lv = (int)((pe >> 8) & 0xFF), slot = (int)(pe & 0xFF);
+    r.pend[arg & (H_PEND - 1)] = 0;
+    LevelScalars* ls = r.ls;
+    const Lv v = sib_view(node, lv);
+    uint64_t* ti = s.TI + (size_t)node * s.W;
+    uint64_t* la = s.LA + (size_t)node * s.W;
+    uint64_t* vi = s.VI + (size_t)node * s.W;
+    const uint64_t* sig = sig_ptr(s, node, lv, slot);
+    row_set(s.TV + (size_t)node * s.W, from, false);  // toVerifyInd.set(from, false)
+    // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
+    {
+      int len = ls->qlen[lv];
+      const uint8_t* ord = s.qorder + ((size_t)node * s.L + lv) * 64;
+      int mine = (int)WG_LANE < len ? ord[WG_LANE] : -1;
+      uint64_t hit = __ballot(mine == slot);
+      if (hit) {
+        int at = __ffsll((unsigned long long)hit) - 1;
+        order_remove(s, node, lv, at, len);
+        if (WG_LANE == 0) ls->qlen[lv] = len - 1;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool hadVI = row_get(vi, from);
+    const bool hadTI = row_get(ti, from);
+    row_set(vi, from, true);
+    int cVI = ls->cVI[lv] + (hadVI ? 0 : 1);
+    int cTI = ls->cTI[lv];
+    int cLA = ls->cLA[lv];
+    bool improved = false;
+    if (!hadTI) {
+      row_set(ti, from, true);
+      cTI++;
+      improved = true;
+    }
+    // all = sig | verifiedInd ; intersects(lastAgg, sig)
+    uint64_t acc = 0;
+    H_FOR_WORDS(v, j) {
+      uint64_t sg = sig[j], viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
+      acc += (uint64_t)__popcll(sg | viw) | ((uint64_t)((sg & law) != 0) << 32);
+    }
+    acc = wave_sum64(acc);
+    const int u2 = (int)(acc & 0xFFFFFFFFu);
+    const bool inter = (acc >> 32) != 0;
+    if (u2 > cVI) {
+      improved = true;
+      uint64_t cnt = 0;
+      H_FOR_WORDS(v, j) {
+        uint64_t sg = sig[j];
+        uint64_t law = la[v.bw + j], viw = vi[v.bw + j], tiw = ti[v.bw + j];
+        uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
+        uint64_t nti = nla | (viw & v.mask);
+        la[v.bw + j] = (law & ~v.mask) | nla;
+        ti[v.bw + j] = (tiw & ~v.mask) | nti;
+        cnt += (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
+      }
+      cnt = wave_sum64(cnt);
+      cLA = (int)(cnt & 0xFFFFFFFFu);
+      cTI = (int)(cnt >> 32);
+    }
+    if (WG_LANE == 0) {
+      ls->cVI[lv] = cVI;
+      ls->cTI[lv] = cTI;
+      ls->cLA[lv] = cLA;
+      // The entry was just unlisted (an entry is listed at most once), so its slot dies with this task
+      // unless another registered task still references it (checkSigs can pick the same entry twice).
+      if (!slot_pending(r, lv, slot)) ls->qused[lv] &= ~(1ULL << slot);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (!improved) return;
+    const bool justCompleted = cTI == v.size;  // incomingComplete()
+    int cur = 0;
+    for (int l = 0; l < s.L; l++) {
+      if (l > lv) {
+        // totalOutgoing(l) := cur  — implicit in the TI row
+        if (justCompleted && s.p.fastPath > 0 && !ls->outFin[l] && cur == (1 << (l - 1))) {
+          uint32_t destOff = c.dest_reserve(s.p.fastPath);
+          int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
+          if (n > 0) {
+            uint32_t ref = snapshot_outgoing(c, s, l);
+            bool lf = ls->cTI[l] == (1 << (l - 1));
+            __threadfence_block();
+            c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
+          }
+        }
+      }
+      cur += ls->cTI[l];
+    }
+    if (r.doneAt == 0 && cur >= s.p.threshold) r.doneAt = c.t;
+  }
+};
+
+// ---- delivery kernel wrapper: same loop as k_deliver, with the node registers / LDS level mirror --
+__global__ void __launch_bounds__(256) k_deliver_handel(EngineDev d, HandelState s, int32_t t) {
+  __shared__ LevelScalars shLevels[4];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
+  for (uint32_t a = wave; a < nActive; a += nWaves) {
+    const int32_t node = (int32_t)d.active[a];
+    const uint32_t off = d.nodeOff[node], cnt = d.cntN[node];
+    for (uint32_t i = lane; i < cnt; i += 64) {
+      uint32_t e = d.inbox[off + i], rank = 0;
+      for (uint32_t j = 0; j < cnt; j++) rank += d.inbox[off + j] < e;
+      d.inbox2[off + rank] = e;
+    }
+    __threadfence_block();
+    Ctx c{d, t, node, 0, 0, 0, 0, 0};
+    HandelProto::NodeRegs r;
+    r.doneAt = d.nodes.doneAt[node];
+    r.addedCycle = s.addedCycle[node];
+    r.sigQueueSize = s.sigQueueSize[node];
+    r.msgFiltered = s.msgFiltered[node];
+    r.startAt = s.startAt[node];
+#pragma unroll
+    for (int k = 0; k < H_PEND; k++) {
+      r.pend[k] = s.pend[(size_t)node * H_PEND + k];
+      r.pendFrom[k] = s.pendFrom[(size_t)node * H_PEND + k];
+    }
+    r.ls = ls;
+    HandelProto::load_levels(s, node, ls);
+    long long nRecv = 0, bRecv = 0, nTasks = 0;
+    const bool toDown = d.nodes.down[node] != 0;
+    const uint8_t toPart = d.nodes.part[node];
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t e = d.inbox2[off + k];
+      const Rec rec = d.ev[e];
+      const uint32_t kind = rec_kind(rec);
+      const int32_t from = rec_from(rec);
+      c.ev = e;
+      c.sub = 0;
+      c.draws = 0;
+      if (!toDown && d.nodes.part[from] == toPart) {
+        if (kind == K_MSG) {
+          nRecv++;
+          bRecv += HandelProto::msg_size(s, rec.w2);
+          HandelProto::on_new_sig(c, s, r, from, rec.w2, rec.w3);
+        } else {
+          nTasks++;
+          if (rec.w2 == H_TASK_DISSEMINATION)
+            HandelProto::dissemination(c, s, r);
+          else
+            HandelProto::update_verified(c, s, r, rec.w3);
+          if (kind == K_PERIODIC) c.put(O_PERIODIC, node, rec.w2, rec.w3, t + (int32_t)rec.w3, 0, false);
+        }
+      }
+      const int32_t slot = d.evChain[e];
+      if (slot >= 0 && d.evLast[e]) {
+        const int32_t next = d.evCpos[e] + 1;
+        if (next < d.chains[slot].ndest)
+          c.put(O_CHAINCONT, slot, (uint32_t)next, 0, 0, 0, false);
+        else if (lane == 0)
+          d.chains[slot].flags = 0;
+      }
+      if (lane == 0) {
+        d.evNrec[e] = c.sub;
+        d.evNdraw[e] = c.draws;
+      }
+      __threadfence_block();
+    }
+    HandelProto::store_levels(s, node, ls);
+    if (lane == 0) {
+      d.nodes.doneAt[node] = r.doneAt;
+      s.addedCycle[node] = r.addedCycle;
+      s.sigQueueSize[node] = r.sigQueueSize;
+      s.msgFiltered[node] = r.msgFiltered;
+#pragma unroll
+      for (int k = 0; k < H_PEND; k++) s.pend[(size_t)node * H_PEND + k] = r.pend[k];
+      d.nodes.msgReceived[node] += nRecv;
+      d.nodes.bytesReceived[node] += bRecv;
+      d.nodes.msgSent[node] += c.msgSent;
+      d.nodes.bytesSent[node] += c.bytesSent;
+      d.cntN[node] = 0;
+      d.fillN[node] = 0;
+      if (nRecv) atomicAdd(&d.g->delivered, (unsigned long long)nRecv);
+      if (nTasks) atomicAdd(&d.g->tasks, (unsigned long long)nTasks);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
+// A1: eligibility + bestToVerify for every level (:570-634): curates the lists, records the candidates.
+__global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState s, int32_t t, int32_t until) {
+  __shared__ LevelScalars shLevels[4];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t epoch = d.g->epoch;
+  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
+  for (int32_t node = (int32_t)wave; node < s.N; node += (int32_t)nWaves) {
+    // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
+    // at most once per call (epoch); evaluate only when minStartTime <= time.
+    bool run = false;
+    if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
+      int32_t ms = s.ctMinStart[node];
+      if (ms <= until && ms <= t) {
+        if (lane == 0) s.ctEpoch[node] = epoch;
+        run = s.sigQueueSize[node] != 0;  // startIf = hasSigToVerify (:345-347)
+      }
+    }
+    if (!run) {
+      if (lane == 0) s.candCnt[node] = 0;
+      continue;
+    }
+    if (lane == 0) s.ctMinStart[node] = t + s.pairing[node];  // minStartTime = time + duration (:557-560)
+    HandelProto::load_levels(s, node, ls);
+    const uint64_t* ti = s.TI + (size_t)node * s.W;
+    const uint64_t* la = s.LA + (size_t)node * s.W;
+    const uint64_t* vi = s.VI + (size_t)node * s.W;
+    const int window = s.window[node];
+    int sigQueueSize = s.sigQueueSize[node];
+    uint32_t pend[H_PEND];
+#pragma unroll
+    for (int k = 0; k < H_PEND; k++) pend[k] = s.pend[(size_t)node * H_PEND + k];
+    int ncand = 0;
+    for (int l = 1; l < s.L; l++) {
+      const int len = ls->qlen[l];
+      if (len == 0) continue;
+      const Lv v = sib_view(node, l);
+      uint8_t* ord = s.qorder + ((size_t)node * s.L + l) * 64;
+      const size_t qbase = ((size_t)node * s.L + l) * s.Q;
+      const int mySlot = lane < len ? ord[lane] : 0;
+      const int myRank = lane < len ? s.qrank[qbase + mySlot] : INT32_MAX;
+      int windowIndex = myRank;  // Collections.min(rank)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) windowIndex = min(windowIndex, __shfl_xor(windowIndex, o, 64));
+      const int curSize = ls->cTI[l], cLA = ls->cLA[l];
+      int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
+      uint64_t keep = 0;
+      for (int i = 0; i < len; i++) {
+        const int slot = __shfl(mySlot, i, 64);
+        const int rank = __shfl(myRank, i, 64);
+        const uint64_t* sig = HandelProto::sig_ptr(s, node, l, slot);
+        uint64_t a = 0, b = 0;
+        H_FOR_WORDS(v, j) {
+          uint64_t sg = sig[j], tiw = ti[v.bw + j] & v.mask, viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
+          a += (uint64_t)__popcll(sg | tiw | viw) | ((uint64_t)__popcll(sg | viw) << 21) | ((uint64_t)__popcll(sg) << 42);
+          b += (uint64_t)((sg & tiw) != 0) | ((uint64_t)((sg & law) != 0) << 21);
+        }
+        a = wave_sum64(a);
+        b = wave_sum64(b);
+        const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
+        const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
+        const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
+        if (sII > curSize) {
+          keep |= 1ULL << i;
+          if (rank <= windowIndex + window) {
+            int score;  // score(l, sig) :655-668
+            if (cLA >= v.size)
+              score = 0;
+            else if (!iLA)
+              score = cLA + cs;
+            else
+              score = max(0, u2 - cLA);
+            if (score > bestScore) {
+              bestScore = score;
+              bestInside = slot;
+            }
+          } else if (bestOutside < 0 || rank < bestOutsideRank) {
+            bestOutside = slot;
+            bestOutsideRank = rank;
+          }
+        }
+      }
+      const int kept = __popcll(keep);
+      if (kept != len) {  // replaceToVerifyAgg :636-646
+        int newPos = __popcll(keep & lanes_lt());
+        bool mineKept = lane < len && ((keep >> lane) & 1ULL);
+        __builtin_amdgcn_wave_barrier();
+        if (mineKept) ord[newPos] = (uint8_t)mySlot;
+        // slots of dropped entries are released unless a registered task still holds them
+        bool mineDropped = lane < len && !mineKept;
+        bool held = false;
+#pragma unroll
+        for (int k = 0; k < H_PEND; k++) held |= pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)mySlot);
+        uint64_t rel = __ballot(mineDropped && !held);
+        unsigned long long relMask = 0;
+        for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << __shfl(mySlot, __ffsll((unsigned long long)m) - 1, 64);
+        if (lane == 0) {
+          ls->qused[l] &= ~relMask;
+          ls->qlen[l] = kept;
+        }
+        sigQueueSize += kept - len;
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int cand = bestInside >= 0 ? bestInside : bestOutside;
+      if (cand >= 0) {
+        if (lane == 0) {
+          s.candLevel[(size_t)node * s.L + ncand] = (uint8_t)l;
+          s.candSlot[(size_t)node * s.L + ncand] = (uint8_t)cand;
+        }
+        ncand++;
+      }
+    }
+    HandelProto::store_levels(s, node, ls);
+    if (lane == 0) {
+      s.sigQueueSize[node] = sigQueueSize;
+      s.candCnt[node] = (uint8_t)ncand;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate)
+struct CondF {
+  EngineDev d;
+  HandelState s;
+  __device__ uint32_t count() const { return (uint32_t)s.N; }
+  __device__ uint64_t value(uint32_t i) const { return s.candCnt[i] > 0; }
+  __device__ void total(uint64_t tot) const {
+    d.g->nOut = (uint32_t)tot;  // one registerTask per drawing node
+    d.g->nDraws = (uint32_t)tot;
+  }
+  __device__ void write(uint32_t i, uint64_t excl) const {
+    s.condOrd[i] = (uint32_t)excl;
+    if (s.candCnt[i] > 0) s.condList[(uint32_t)excl] = i;
+  }
+};
+
+// chooseBestFromLevels: rd.nextInt(byLevels.size()) (:788-790). Value by jump-ahead assuming no
+// earlier nextInt(bound) rejection; a rejection anywhere triggers the serial re-walk below.
+__global__ void __launch_bounds__(256) k_handel_cond_draw(EngineDev d, HandelState s) {
+  const uint32_t n = d.g->nOut;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t node = s.condList[j];
+    uint64_t st = lcg_skip(d.g->rng, j);
+    int consumed;
+    s.drawVal[node] = lcg_next_int_bounded(st, (int32_t)s.candCnt[node], &consumed);
+    if (consumed != 1) d.g->rejectSeen = 1;
+  }
+}
+__global__ void k_handel_cond_fix(EngineDev d, HandelState s) {
+  if (!d.g->rejectSeen) return;
+  const uint32_t n = d.g->nOut;
+  uint64_t st = d.g->rng;
+  uint32_t total = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t node = s.condList[j];
+    int consumed;
+    s.drawVal[node] = lcg_next_int_bounded(st, (int32_t)s.candCnt[node], &consumed);
+    total += (uint32_t)consumed;
+  }
+  d.g->nDraws = total;
+}
+
+// A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
+__global__ void __launch_bounds__(256) k_handel_cond_a2(EngineDev d, HandelState s, int32_t t) {
+  const uint32_t n = d.g->nOut;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int32_t node = (int32_t)s.condList[j];
+    const int k = s.drawVal[node];
+    const int l = s.candLevel[(size_t)node * s.L + k];
+    const int slot = s.candSlot[(size_t)node * s.L + k];
+    const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
+    // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
+    int w = s.window[node] * 2;
+    if (w > s.p.windowMaximum) w = s.p.windowMaximum;
+    if (w < s.p.windowMinimum) w = s.p.windowMinimum;
+    s.window[node] = min(w, 1 << (l - 1));
+    // receptionRanks[best.from] += nodeCount, saturating (:825-828)
+    int32_t* rk = s.ranks + (size_t)node * s.N + from;
+    int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
+    *rk = nr < 0 ? INT32_MAX : nr;
+    s.sigsChecked[node]++;
+    int pe = -1;
+    for (int q = 0; q < H_PEND; q++)
+      if (!(s.pend[(size_t)node * H_PEND + q] & 0x80000000u)) {
+        pe = q;
+        break;
+      }
+    if (pe < 0) {
+      set_err(d.g, ERR_PENDING);
+      pe = 0;
+    }
+    s.pend[(size_t)node * H_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
+    s.pendFrom[(size_t)node * H_PEND + pe] = from;
+    // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
+    const int32_t arrival = t + s.pairing[node];
+    d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
+    d.arr[j] = (arrival - t >= d.horizon) ? -1 : arrival;
+    if (arrival - t >= d.horizon) set_err(d.g, ERR_HORIZON);
+  }
+}
+
+}  // namespace wg

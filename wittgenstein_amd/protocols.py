@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's Protocol objects (C/Protocol.java:9-22) for the resident
+protocols: same constructor arguments, copy(), init(), network()."""
+import ctypes as C
+
+from . import _lib as L
+from .core import Network, _raise
+
+
+def _config(cfg):
+    c = L.wg_config()
+    for k, v in (cfg or {}).items():
+        setattr(c, k, v)
+    return c
+
+
+class PingPongParameters:
+    """P/PingPong.java:34-50"""
+
+    def __init__(self, nodeCt=1000, nodeBuilderName=None, networkLatencyName=None):
+        self.nodeCt, self.nodeBuilderName, self.networkLatencyName = nodeCt, nodeBuilderName, networkLatencyName
+
+
+class PingPong:
+    """P/PingPong.java. `seed` is what RunMultipleTimes does with network.rd.setSeed(i) before init()."""
+
+    def __init__(self, params=None, seed=0, config=None):
+        self.params = params or PingPongParameters()
+        self.seed, self.config = seed, config
+        self._net = None
+        self.init_seconds = None
+
+    def copy(self):
+        return PingPong(self.params, self.seed, self.config)
+
+    def init(self):
+        p = self.params
+        h = C.c_void_p()
+        cfg = _config(self.config)
+        rc = L.lib().wgh_pingpong_create(p.nodeCt, p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                         p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                         C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wgh_last_error().decode())
+        self._net = Network(h)
+        self.init_seconds = L.lib().wgh_last_init_seconds()
+
+    def network(self):
+        return self._net
+
+
+class HandelParameters:
+    """P/Handel.java:97-142 (constructor argument order preserved). byzantineSuicide / hiddenByzantine must be
+    False: those attack paths are not resident on the device."""
+
+    def __init__(self, nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath,
+                 nodesDown, nodeBuilderName=None, networkLatencyName=None, desynchronizedStart=0,
+                 byzantineSuicide=False, hiddenByzantine=False, badNodes=None):
+        if byzantineSuicide and hiddenByzantine:
+            from .core import IllegalArgumentException
+            raise IllegalArgumentException("Only one attack at a time")
+        if byzantineSuicide or hiddenByzantine or badNodes is not None:
+            from .core import UnsupportedError
+            raise UnsupportedError("byzantine modes / explicit badNodes are not resident on the device")
+        self.nodeCount, self.threshold, self.pairingTime, self.levelWaitTime = nodeCount, threshold, pairingTime, levelWaitTime
+        self.extraCycle, self.disseminationPeriodMs, self.fastPath, self.nodesDown = extraCycle, disseminationPeriodMs, fastPath, nodesDown
+        self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
+        self.desynchronizedStart = desynchronizedStart
+
+
+class Handel:
+    """P/Handel.java."""
+
+    def __init__(self, params, seed=0, config=None):
+        self.params, self.seed, self.config = params, seed, config
+        self._net = None
+        self.init_seconds = None
+
+    def copy(self):
+        return Handel(self.params, self.seed, self.config)
+
+    def init(self):
+        p = self.params
+        hp = L.wg_handel_params(p.nodeCount, p.threshold, p.pairingTime, p.levelWaitTime, p.extraCycle,
+                                p.disseminationPeriodMs, p.fastPath, p.nodesDown, p.desynchronizedStart, 0, 0, 0)
+        h = C.c_void_p()
+        cfg = _config(self.config)
+        rc = L.lib().wgh_handel_create(C.byref(hp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                       p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                       C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wgh_last_error().decode())
+        self._net = Network(h)
+        self.init_seconds = L.lib().wgh_last_init_seconds()
+
+    def network(self):
+        return self._net
+
+    def cont_if(self):
+        """Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0."""
+        n = self._net
+        live = n.read("down") == 0
+        return bool(((n.read("doneAt")[live] == 0) | (n.read("addedCycle")[live] > 0)).any())
