@@ -69,6 +69,28 @@ int32_t orc_latency_bydistance(int32_t dist, int32_t delta) {
   return (int)(raw / 2);
 }
 int32_t orc_max_dist() { return Node::MAX_DIST(); }
+// NetworkLatency.getLatency(from, to, delta) of a registry model for two ad-hoc nodes
+struct ProbeNB : NodeBuilder {
+  int px, py;
+  int getX(jint) override { return px; }
+  int getY(jint) override { return py; }
+};
+int orc_latency(const char* name, int32_t x1, int32_t y1, int32_t e1, int32_t x2, int32_t y2, int32_t e2, int32_t same,
+                int32_t delta, int32_t* out) {
+  ORC_TRY auto nl = networkLatencyByName(name ? name : "");
+  JRandom rd(0);
+  ProbeNB nb;
+  nb.px = x1;
+  nb.py = y1;
+  Node a(rd, nb);
+  nb.px = x2;
+  nb.py = y2;
+  Node b(rd, nb);
+  a.extraLatency = e1;
+  b.extraLatency = e2;
+  *out = nl->getLatency(a, same ? a : b, delta);
+  ORC_CATCH
+}
 int orc_node_xy(int32_t rdInt, int32_t* x, int32_t* y) {
   NodeBuilderWithRandomPosition nb;
   *x = nb.getX(rdInt);

@@ -82,6 +82,12 @@ def latency_bydistance(dist, delta):
     return lib().orc_latency_bydistance(dist, delta)
 
 
+def latency(name, x1, y1, e1, x2, y2, e2, delta, same=False):
+    out = C.c_int32()
+    _ck(lib().orc_latency(name.encode() if name else None, x1, y1, e1, x2, y2, e2, int(same), delta, C.byref(out)))
+    return out.value
+
+
 def latency_table():
     md = lib().orc_max_dist()
     t = np.zeros((md + 1, 100), np.int32)

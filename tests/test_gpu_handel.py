@@ -1,0 +1,136 @@
+"""Handel on the MI355X vs the CPU oracle, bit-exact: every per-node counter, every HLevel bitset, the
+verification queues' lengths, posInLevel, the shared rd state and network.time (the GPU-vs-oracle analogue
+of the reference's testCopy, PT/HandelTest.java:14-34), plus size-independent properties at the
+BASELINE.json size (32 768 nodes)."""
+import numpy as np
+import pytest
+
+import parity
+import wittgenstein_amd as w
+
+pytestmark = pytest.mark.gpu
+
+
+def ratios(n, pairing=4, level_wait=50, extra=10, period=20, fast=10, dead=0.10, desync=0):
+    """HandelScenarios.defaultParams ratios (P/HandelScenarios.java:104-119), SURVEY.md §8d config 3"""
+    down = int(n * dead)
+    return (n, int(n * (1 - dead) * 0.99), pairing, level_wait, extra, period, fast, down, desync)
+
+
+def lockstep(params, step, check_every=1, max_ms=6000, **kw):
+    g, c = parity.handel_pair(params, **kw)
+    assert not parity.diff_handel(g, c), "state after init()"
+    t, k = 0, 0
+    while c.cont_if() and t < max_ms:
+        g.network().runMs(step)
+        c.run_ms(step)
+        t += step
+        k += 1
+        if k % check_every == 0:
+            d = parity.diff_handel(g, c)
+            assert not d, "t=%d: %s" % (t, d)
+    d = parity.diff_handel(g, c)
+    assert not d, "final t=%d: %s" % (t, d)
+    assert g.cont_if() == c.cont_if()
+    assert (g.network().delivered_by_level()[:c.levels] == c.stats()["deliveredByLevel"].astype(np.int64)).all()
+    return g, c
+
+
+def test_handel_test_params_every_ms():  # PT/HandelTest.java:14-49 parameters, runMs(1) lock-step
+    g, c = lockstep((64, 60, 6, 10, 5, 5, 10, 2, 100), step=1, max_ms=2000)
+    live = g.network().read("down") == 0
+    assert (g.network().read("doneAt")[live] > 0).all()
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32])
+def test_tiny_networks(n):  # single-word rows, masks inside one 64-bit word
+    lockstep((n, max(1, n - 1), 3, 20, 3, 10, 10, 0, 0), step=1, max_ms=1500)
+
+
+def test_256_every_ms():
+    lockstep(ratios(256), step=1)
+
+
+def test_1024_chunks_of_10():  # RunMultipleTimes' runMs(10) loop (C/RunMultipleTimes.java:50-64)
+    lockstep(ratios(1024), step=10)
+
+
+def test_4096_chunks_of_10():
+    lockstep(ratios(4096), step=10, check_every=10)
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 7, 1000])
+def test_chunk_size_is_observable_and_matches(chunk):  # runMs edges, conditional tasks at until+1
+    lockstep((128, 100, 1, 10, 4, 7, 10, 12, 0), step=chunk, max_ms=3000)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 77])
+def test_seeds(seed):  # rd.setSeed(i) of RunMultipleTimes (C/RunMultipleTimes.java:47)
+    lockstep(ratios(256), step=10, seed=seed)
+
+
+def test_desynchronized_start_and_fast_pairing():  # desynchronizedStart != 0, pairingTime 1 (epoch quirk)
+    lockstep((256, 200, 1, 20, 2, 5, 3, 10, 300), step=1, max_ms=3000)
+
+
+def test_no_fast_path_no_extra_cycle():
+    lockstep((256, 230, 4, 50, 0, 20, 0, 20, 0), step=10)
+
+
+@pytest.mark.parametrize("nb", ["RANDOM_SPEED=GAUSSIAN_TOR=0.00", "RANDOM_SPEED=CONSTANT_TOR=0.33",
+                                "RANDOM_SPEED=GAUSSIAN_TOR=0.10"])
+def test_node_builders_speed_and_tor(nb):  # UniformSpeed pairing times, +500 ms Tor latency (C/Node.java:151-161,233-238)
+    lockstep(ratios(256), step=10, nb=nb, max_ms=20000)
+
+
+@pytest.mark.parametrize("nl", ["NetworkFixedLatency(100)", "NetworkUniformLatency(200)", "NetworkNoLatency",
+                                "IC3NetworkLatency"])
+def test_latency_models(nl):
+    lockstep(ratios(256), step=10, nl=nl, max_ms=20000)
+
+
+def test_queue_capacity_overflow_is_loud():
+    g = w.Handel(w.HandelParameters(*ratios(256)[:8], parity.NB, parity.NL, 0), config={"queue_cap": 2})
+    g.init()
+    with pytest.raises(w.EngineCapacityError):
+        for _ in range(200):
+            g.network().runMs(10)
+
+
+def test_parameter_checks():  # HandelParameters ctor (P/Handel.java:113-125)
+    for bad in [(100, 90, 4, 50, 10, 20, 10, 5), (64, 70, 4, 50, 10, 20, 10, 0), (64, 60, 4, 50, 10, 20, 10, 10)]:
+        g = w.Handel(w.HandelParameters(*bad, parity.NB, parity.NL, 0))
+        with pytest.raises(w.IllegalArgumentException):
+            g.init()
+
+
+def test_full_size_properties_32768():
+    """BASELINE.json config 3 (Handel 32 768 nodes, 10 % dead): no oracle at this size inside the test
+    budget, so check the size-independent properties: every live node converges, totalIncoming stays inside
+    waitedSigs, message accounting closes, two copies agree (PT/HandelTest.java:14-34)."""
+    n = 32768
+    p = w.HandelParameters(*ratios(n)[:8], parity.NB, parity.NL, 0)
+    g1, g2 = w.Handel(p), w.Handel(p)
+    g1.init()
+    g2.init()
+    steps = 0
+    while g1.cont_if() and steps < 1000:
+        g1.network().runMs(10)
+        g2.network().runMs(10)
+        steps += 1
+    assert not g1.cont_if() and not g2.cont_if()
+    n1, n2 = g1.network(), g2.network()
+    live = n1.read("down") == 0
+    assert live.sum() == n - int(n * 0.1)
+    assert (n1.read("doneAt")[live] > 0).all() and (n1.read("doneAt")[~live] == 0).all()
+    for f in parity.SCALARS:
+        assert (n1.read(f) == n2.read(f)).all(), f
+    assert n1.rng_state() == n2.rng_state()
+    ti = n1.read_bits("totalIncoming")
+    assert (ti == n2.read_bits("totalIncoming")).all()
+    assert n1.read("msgReceived").sum() == n1.delivered_by_level().sum()
+    assert (n1.read("msgReceived")[~live] == 0).all() and (n1.read("msgSent")[~live] == 0).all()
+    # verifiedIndSignatures subset of totalIncoming is NOT an invariant (lastAgg replacement), but
+    # toVerifyInd and verifiedInd are disjoint per level after every update (P/Handel.java:700-704)
+    vi, tv = n1.read_bits("verifiedIndSignatures"), n1.read_bits("toVerifyInd")
+    assert ((vi & tv) == 0).all()

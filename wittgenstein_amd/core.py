@@ -75,6 +75,64 @@ class Network:
         self.msgs = MessageStorage(self)
         self.last_stats = None
 
+    # ---- raw construction: what a Java init() does through the JNI shim ------------------------
+    @classmethod
+    def create(cls, config=None):
+        """new Network<>() (C/Network.java:14-49)."""
+        cfg = L.wg_config()
+        for k, v in (config or {}).items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = L.lib().wg_create(C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wg_last_error(None).decode())
+        return cls(h)
+
+    def add_nodes(self, x, y, extraLatency=None, down=None, speedRatio=None):
+        """Network.addNode for len(x) nodes with dense ids (C/Network.java:651-659)."""
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        ex = None if extraLatency is None else np.ascontiguousarray(extraLatency, np.int32)
+        dn = None if down is None else np.ascontiguousarray(down, np.uint8)
+        sp = None if speedRatio is None else np.ascontiguousarray(speedRatio, np.float64)
+        self._ck(L.lib().wg_add_nodes(self._h, len(x), _p(x, C.c_int32), _p(y, C.c_int32),
+                                      None if ex is None else _p(ex, C.c_int32),
+                                      None if dn is None else _p(dn, C.c_uint8), None,
+                                      None if sp is None else _p(sp, C.c_double)))
+
+    def setNetworkLatency(self, name):
+        """Network.setNetworkLatency(RegistryNetworkLatencies.getByName(name))."""
+        self._ck(L.lib().wg_set_latency_by_name(self._h, name.encode() if name else None))
+
+    def setMeasuredLatency(self, longDistrib):
+        arr = np.ascontiguousarray(longDistrib, np.int32)
+        self._ck(L.lib().wg_set_latency(self._h, 4, _p(arr, C.c_int32), len(arr)))
+
+    def setMsgDiscardTime(self, ms):
+        self._ck(L.lib().wg_set_discard_time(self._h, int(ms)))
+
+    def load_protocol(self, proto_id):
+        self._ck(L.lib().wg_protocol_load(self._h, proto_id, None, None))
+
+    def set_seed(self, seed):
+        self._ck(L.lib().wg_rng_set_seed(self._h, C.c_int64(seed)))
+
+    def send(self, msg, sendTime, frm, dests, delayBetween=0, payload=0):
+        """Network.send(m, sendTime, from, dests[, delaysBetweenMessage]) (C/Network.java:369-382,418-447)."""
+        d = np.ascontiguousarray(np.atleast_1d(dests), np.int32)
+        self._ck(L.lib().wg_send(self._h, int(msg), int(payload), int(sendTime), int(frm), _p(d, C.c_int32), len(d),
+                                 int(delayBetween)))
+
+    def registerTask(self, task, startAt, node, arg=0):
+        self._ck(L.lib().wg_register_task(self._h, int(task), int(arg), int(startAt), int(node)))
+
+    def registerPeriodicTask(self, task, startAt, period, node):
+        self._ck(L.lib().wg_register_periodic_task(self._h, int(task), int(startAt), int(period), int(node)))
+
+    def set_node_down(self, node, down=True):
+        """Node.stop() / Node.start() (C/Node.java:120-131)."""
+        self._ck(L.lib().wg_set_node_down(self._h, int(node), int(bool(down))))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -489,10 +489,13 @@ __global__ void k_apply_sent(NodeArrays nd, int n, const int32_t* node, const lo
 __global__ void k_set_nout(Globals* g, uint32_t n) { g->nOut = n; }
 
 // Push host-staged envelopes (in push order) through the same append pipeline the device uses.
-void Engine::flush_staged() {
+// Envelopes arriving beyond the bucket ring's horizon stay on the host until they come into range;
+// they are injected at the start of ms (arrival - horizon + 1), before any device push of that ms can
+// target the same bucket, so the push order inside the bucket is unchanged.
+void Engine::flush_staged(int32_t t, bool inRun) {
   if (staged.empty() && pendingSent.empty()) return;
   ensure_device();
-  sync_globals_to_device();
+  if (!inRun) sync_globals_to_device();
   for (auto& sc : stagedChains) {
     if (sc.slot >= dev.chainSlots) throw WgError(WG_ENOMEM, "chain_slots");
     for (size_t j = 0; j < sc.words.size(); j++) {
@@ -527,27 +530,32 @@ void Engine::flush_staged() {
     (void)hipFree(db);
     pendingSent.clear();
   }
+  std::vector<Staged> near, far;
+  for (auto& st : staged) (st.arrival - t < dev.horizon ? near : far).push_back(st);
+  staged.swap(far);
+  stagedMin = INT32_MAX;
+  for (auto& st : staged) stagedMin = std::min(stagedMin, st.arrival);
   size_t done = 0;
-  while (done < staged.size()) {
-    size_t n = std::min<size_t>(staged.size() - done, dev.maxOut);
+  while (done < near.size()) {
+    size_t n = std::min<size_t>(near.size() - done, dev.maxOut);
     std::vector<Rec> recs(n);
     std::vector<int32_t> arr(n);
     for (size_t i = 0; i < n; i++) {
-      recs[i] = staged[done + i].rec;
-      arr[i] = staged[done + i].arrival;
-      if (arr[i] - time >= dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms too small for an envelope arriving at " + std::to_string(arr[i]));
+      recs[i] = near[done + i].rec;
+      arr[i] = near[done + i].arrival;
     }
     WG_HIP(hipMemcpyAsync(dev.fin, recs.data(), sizeof(Rec) * n, hipMemcpyHostToDevice, stream));
     WG_HIP(hipMemcpyAsync(dev.arr, arr.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, (uint32_t)n);
-    append_phase(time);
+    append_phase(t);
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, 0u);
     WG_HIP(hipStreamSynchronize(stream));
     done += n;
   }
-  staged.clear();
-  sync_globals_to_host();
-  check_device_errors();
+  if (!inRun) {
+    sync_globals_to_host();
+    check_device_errors();
+  }
 }
 
 void Engine::check_device_errors() {
@@ -604,7 +612,7 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   int32_t endAt = (int32_t)((uint32_t)time + (uint32_t)ms);
   if (endAt <= 0) throw WgError(WG_ESTATE, "Maximum time reached!");
   ensure_device();
-  flush_staged();
+  flush_staged(time, false);
   // (time == 0: Node.start() on non-down nodes only re-asserts down == false, :323-329)
   Globals before = gh;
   gh.epoch++;  // a new receiveUntil() starts with a fresh nextMessage() call
@@ -614,6 +622,10 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   auto t0 = std::chrono::steady_clock::now();
   const bool cond = proto->has_cond();
   for (int32_t t = time; t <= endAt; t++) {
+    if (t > time && stagedMin - t < dev.horizon) {
+      WG_HIP(hipStreamSynchronize(stream));
+      flush_staged(t, true);
+    }
     if (cond && t > time) {  // time++ edge -> t: conditional tasks (:543-566)
       proto->launch_cond(*this, t, endAt);
       append_phase(t);
@@ -652,22 +664,19 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
 
 int64_t Engine::queue_size() {  // msgs.size(): number of envelopes (a multi-dest envelope counts once)
   if (!allocated) return (int64_t)staged.size();
-  flush_staged();
+  flush_staged(time, false);
   std::vector<uint32_t> c(dev.horizon);
   WG_HIP(hipMemcpy(c.data(), dev.bcnt, sizeof(uint32_t) * dev.horizon, hipMemcpyDeviceToHost));
-  int64_t s = 0;
+  int64_t s = (int64_t)staged.size();
   for (uint32_t v : c) s += v;
   return s;
 }
 int64_t Engine::queue_size_at(int32_t t) {
   if (t < time) return 0;
-  if (!allocated) {
-    int64_t s = 0;
-    for (auto& st : staged) s += st.arrival == t;
-    return s;
-  }
-  flush_staged();
-  if (t - time >= dev.horizon) return 0;
+  int64_t far = 0;
+  if (allocated) flush_staged(time, false);
+  for (auto& st : staged) far += st.arrival == t;
+  if (!allocated || t - time >= dev.horizon) return far;
   uint32_t c;
   WG_HIP(hipMemcpy(&c, dev.bcnt + ((uint32_t)t & (dev.horizon - 1)), 4, hipMemcpyDeviceToHost));
   return c;
@@ -676,7 +685,7 @@ int64_t Engine::queue_size_at(int32_t t) {
 void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
   if (n != (int32_t)hx.size()) throw WgError(WG_EINVAL, "n must equal the node count");
   ensure_device();
-  flush_staged();
+  flush_staged(time, false);
   auto rd64 = [&](const long long* src) { WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n, hipMemcpyDeviceToHost)); };
   switch (field) {
     case WG_F_DONE_AT: return rd64(dev.nodes.doneAt);

@@ -75,7 +75,7 @@ class Engine {
   void end_phase(int32_t t, bool drained);
   template <class F>
   void scan(const F& f);
-  void flush_staged();
+  void flush_staged(int32_t t, bool inRun);
   int32_t host_latency(int32_t from, int32_t to, int32_t seed) const;
   int32_t part_of(int32_t x) const;
   void check_device_errors();
@@ -110,6 +110,7 @@ class Engine {
     Rec rec;
   };
   std::vector<Staged> staged;
+  int32_t stagedMin = INT32_MAX;  // earliest arrival among host-held envelopes
   struct StagedChain {
     uint32_t slot;
     Chain c;
