@@ -130,6 +130,10 @@ int32_t wg_time(wg_engine* e, int32_t* time);                   /* Network.time 
 int32_t wg_queue_size(wg_engine* e, int64_t* size);             /* msgs.size()   :204-210 */
 int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt(t) :212-220 */
 
+/* The resident protocol's continuation predicate of the RunMultipleTimes loop (C/RunMultipleTimes.java:50-64),
+ * evaluated on the device: Handel.newContIf (P/Handel.java:1044-1053). *cont = 1 while the run must go on. */
+int32_t wg_protocol_cont_if(wg_engine* e, int32_t* cont);
+
 /* ---- read-back -------------------------------------------------------------------------- */
 typedef enum {
   /* Node counters (C/Node.java:69-79) */
@@ -154,6 +158,18 @@ int32_t wg_read_bits(wg_engine* e, int32_t field, uint64_t* dst, int32_t n_nodes
 int32_t wg_levels(wg_engine* e, int32_t* levels);
 /* per-level count of SendSigs delivered so far (roofline accounting); dst[32] */
 int32_t wg_delivered_by_level(wg_engine* e, int64_t* dst32);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Per-phase device time measured with HIP events recorded on the engine's own stream around each
+ * kernel (group) of the per-ms pipeline. No reference counterpart (the reference's only timing is the
+ * wall-clock print of C/ProgressPerTime.java:68,96,111). Off by default: each span costs two event records. */
+typedef struct {
+  const char* name;   /* static string: phase and the kernel(s) it brackets */
+  int64_t spans;      /* bracketed launches (groups) since the engine was created */
+  double total_ns;    /* summed device time of those spans */
+} wg_profile_entry;
+int32_t wg_profile_enable(wg_engine* e, int32_t on);
+int32_t wg_profile_read(wg_engine* e, wg_profile_entry* dst, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,10 @@ class wg_run_stats(C.Structure):
                                          "payload_bytes")]
 
 
+class wg_profile_entry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("spans", C.c_int64), ("total_ns", C.c_double)]
+
+
 # every symbol include/wittgpu.h and include/wittgpu_host.h declare
 ABI_SYMBOLS = [
     "wg_create", "wg_destroy", "wg_last_error", "wg_add_nodes", "wg_node_count", "wg_set_latency",
@@ -34,6 +38,7 @@ ABI_SYMBOLS = [
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
+    "wg_protocol_cont_if", "wg_profile_enable", "wg_profile_read",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",
 ]

@@ -214,6 +214,16 @@ class Network:
         self._ck(L.lib().wg_delivered_by_level(self._h, _p(out, C.c_int64)))
         return out
 
+    def profile(self, on=True):
+        """bracket every kernel (group) of the per-ms pipeline with HIP events on the engine's stream"""
+        self._ck(L.lib().wg_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        arr = (L.wg_profile_entry * 16)()
+        n = C.c_int32()
+        self._ck(L.lib().wg_profile_read(self._h, arr, 16, C.byref(n)))
+        return {arr[i].name.decode(): {"spans": arr[i].spans, "total_ns": arr[i].total_ns} for i in range(n.value)}
+
     def latency_probe(self, frm, to, delta):
         frm = np.ascontiguousarray(frm, np.int32)
         to = np.ascontiguousarray(to, np.int32)

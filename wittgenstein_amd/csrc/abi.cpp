@@ -163,4 +163,33 @@ int32_t wg_delivered_by_level(wg_engine* h, int64_t* dst32) {
   WG_END
 }
 
+int32_t wg_protocol_cont_if(wg_engine* h, int32_t* cont) {
+  WG_TRY(h)
+  if (!cont) throw WgError(WG_EINVAL, "cont");
+  E.ensure_device();
+  E.flush_staged(E.time, false);
+  if (!E.proto || !E.proto->cont_if(E, cont))
+    throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+  WG_END
+}
+int32_t wg_profile_enable(wg_engine* h, int32_t on) {
+  WG_TRY(h) E.profiling = on != 0;
+  WG_END
+}
+int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_t* n) {
+  WG_TRY(h)
+  static const char* names[Engine::PC_COUNT] = {"expand(k_scan1+k_scan2<ExpandF>)", "group(k_scan<NodesF>+k_fill)",
+                                                "deliver", "order(k_scan<RecsF>)", "k_resolve",
+                                                "append(k_tile_hist+k_col_reserve+k_scatter)", "k_end_phase",
+                                                "cond_select", "cond_rest"};
+  int k = 0;
+  for (int c = 0; c < Engine::PC_COUNT && k < cap; c++, k++) {
+    dst[k].name = names[c];
+    dst[k].spans = E.profLaunches[c];
+    dst[k].total_ns = E.profNs[c];
+  }
+  if (n) *n = k;
+  WG_END
+}
+
 }  // extern "C"

@@ -68,7 +68,35 @@ Engine::~Engine() {
   if (dLut) (void)hipFree(dLut);
   if (dTabDelta) (void)hipFree(dTabDelta);
   if (dTabDist) (void)hipFree(dTabDist);
+  for (auto& sp : profSpans) {
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  for (auto ev : profFree) (void)hipEventDestroy(ev);
   if (stream) (void)hipStreamDestroy(stream);
+}
+
+hipEvent_t Engine::prof_event() {
+  if (!profFree.empty()) {
+    hipEvent_t ev = profFree.back();
+    profFree.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  WG_HIP(hipEventCreate(&ev));
+  return ev;
+}
+void Engine::prof_collect() {
+  for (auto& sp : profSpans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      profNs[sp.cls] += (double)ms * 1e6;
+      profLaunches[sp.cls]++;
+    }
+    profFree.push_back(sp.a);
+    profFree.push_back(sp.b);
+  }
+  profSpans.clear();
 }
 
 void Engine::add_nodes(int32_t n, const int32_t* x, const int32_t* y, const int32_t* extra, const uint8_t* down,
@@ -628,16 +656,39 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
     }
     if (cond && t > time) {  // time++ edge -> t: conditional tasks (:543-566)
       proto->launch_cond(*this, t, endAt);
-      append_phase(t);
+      {
+        ProfScope ps(*this, PC_APPEND);
+        append_phase(t);
+      }
+      ProfScope ps(*this, PC_END);
       end_phase(t, false);
     }
-    scan(ExpandF{dev, t});
-    scan(NodesF{dev});
-    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, dev);
-    proto->launch_deliver(*this, t);
-    scan(RecsF{dev});
-    hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev, t);
-    append_phase(t);
+    {
+      ProfScope ps(*this, PC_EXPAND);
+      scan(ExpandF{dev, t});
+    }
+    {
+      ProfScope ps(*this, PC_GROUP);
+      scan(NodesF{dev});
+      hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, dev);
+    }
+    {
+      ProfScope ps(*this, PC_DELIVER);
+      proto->launch_deliver(*this, t);
+    }
+    {
+      ProfScope ps(*this, PC_ORDER);
+      scan(RecsF{dev});
+    }
+    {
+      ProfScope ps(*this, PC_RESOLVE);
+      hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev, t);
+    }
+    {
+      ProfScope ps(*this, PC_APPEND);
+      append_phase(t);
+    }
+    ProfScope ps(*this, PC_END);
     end_phase(t, true);
   }
   if (cond) {  // the edge to until+1 still runs tasks with minStartTime <= until
@@ -647,6 +698,7 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   }
   WG_HIP(hipStreamSynchronize(stream));
   auto t1 = std::chrono::steady_clock::now();
+  if (profiling) prof_collect();
   sync_globals_to_host();
   time = endAt;
   if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;
@@ -741,9 +793,17 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down) {
   s.ctMinStart[node] = down[node] ? INT32_MAX : s.startAt[node] + 1;
 }
 
+// Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0
+__global__ void k_handel_cont_if(HandelState s, const uint8_t* down, const long long* doneAt, uint32_t* out) {
+  int node = blockIdx.x * blockDim.x + threadIdx.x;
+  bool c = node < s.N && !down[node] && (doneAt[node] == 0 || s.addedCycle[node] > 0);
+  if (__ballot(c) && WG_LANE == 0) atomicOr(out, 1u);
+}
+
 struct HandelHost : ProtoHost {
   HandelState st{};
   Engine& eng;
+  uint32_t* dCont = nullptr;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
@@ -825,12 +885,27 @@ struct HandelHost : ProtoHost {
   }
   bool has_cond() const override { return true; }
   int levels() const override { return st.L; }
+  bool cont_if(Engine& e, int32_t* out) override {
+    if (!dCont) dCont = e.dalloc<uint32_t>(1);
+    WG_HIP(hipMemsetAsync(dCont, 0, 4, e.stream));
+    hipLaunchKernelGGL(k_handel_cont_if, dim3((st.N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down,
+                       e.dev.nodes.doneAt, dCont);
+    uint32_t v = 0;
+    WG_HIP(hipMemcpyAsync(&v, dCont, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    *out = (int32_t)v;
+    return true;
+  }
   int host_msg_size(uint32_t msg) const override {
     int l = (int)(msg & 31u);
     return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 192;
   }
   void launch_cond(Engine& e, int32_t t, int32_t until) override {
-    hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t, until);
+    {
+      Engine::ProfScope ps(e, Engine::PC_COND_SELECT);
+      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t, until);
+    }
+    Engine::ProfScope ps(e, Engine::PC_COND_REST);
     e.scan(CondF{e.dev, st});
     hipLaunchKernelGGL(k_handel_cond_draw, dim3(128), dim3(256), 0, e.stream, e.dev, st);
     hipLaunchKernelGGL(k_handel_cond_fix, dim3(1), dim3(1), 0, e.stream, e.dev, st);

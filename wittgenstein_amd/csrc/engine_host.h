@@ -39,6 +39,8 @@ struct ProtoHost {
   virtual int levels() const { return 0; }
   virtual int host_msg_size(uint32_t /*msg*/) const { return 1; }  // Message.size() of a host-side send
   virtual bool delivered_by_level(Engine&, int64_t* /*dst32*/) { return false; }
+  // the protocol's RunMultipleTimes continuation predicate, evaluated on the device
+  virtual bool cont_if(Engine&, int32_t* /*out*/) { return false; }
 };
 
 class Engine {
@@ -125,6 +127,36 @@ class Engine {
   std::vector<PendingSent> pendingSent;
   ProtoHost* proto = nullptr;
   std::vector<void*> allocs;     // everything to hipFree
+
+  // optional per-kernel-class timing with HIP events recorded on the engine's stream (bench.py's
+  // roofline leg; off by default because every bracket costs two event records)
+  enum ProfClass { PC_EXPAND = 0, PC_GROUP, PC_DELIVER, PC_ORDER, PC_RESOLVE, PC_APPEND, PC_END, PC_COND_SELECT,
+                   PC_COND_REST, PC_COUNT };
+  bool profiling = false;
+  struct ProfSpan {
+    int cls;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfSpan> profSpans;         // recorded in the current run
+  std::vector<hipEvent_t> profFree;        // recycled events
+  double profNs[PC_COUNT] = {0};
+  long long profLaunches[PC_COUNT] = {0};
+  hipEvent_t prof_event();
+  void prof_collect();                     // after the stream is idle
+  struct ProfScope {
+    Engine& e;
+    size_t idx = (size_t)-1;
+    ProfScope(Engine& en, int cls) : e(en) {
+      if (!e.profiling) return;
+      ProfSpan s{cls, e.prof_event(), e.prof_event()};
+      (void)hipEventRecord(s.a, e.stream);
+      idx = e.profSpans.size();
+      e.profSpans.push_back(s);
+    }
+    ~ProfScope() {
+      if (idx != (size_t)-1) (void)hipEventRecord(e.profSpans[idx].b, e.stream);
+    }
+  };
 
   template <class T>
   T* dalloc(size_t count, bool zero = true) {

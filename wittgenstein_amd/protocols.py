@@ -97,6 +97,6 @@ class Handel:
 
     def cont_if(self):
         """Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0."""
-        n = self._net
-        live = n.read("down") == 0
-        return bool(((n.read("doneAt")[live] == 0) | (n.read("addedCycle")[live] > 0)).any())
+        v = C.c_int32()
+        self._net._ck(L.lib().wg_protocol_cont_if(self._net._h, C.byref(v)))
+        return bool(v.value)
