@@ -178,7 +178,7 @@ int32_t wg_profile_enable(wg_engine* h, int32_t on) {
 }
 int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_t* n) {
   WG_TRY(h)
-  static const char* names[Engine::PC_COUNT] = {"expand(k_scan1+k_scan2<ExpandF>)", "group(k_scan<NodesF>+k_fill)",
+  static const char* names[Engine::PC_COUNT] = {"expand(k_scan1+k_scan2<ExpandF>)", "group(unused)",
                                                 "deliver", "order(k_scan<RecsF>)", "k_resolve",
                                                 "append(k_tile_hist+k_col_reserve+k_scatter)", "k_end_phase",
                                                 "cond_select", "cond_rest"};

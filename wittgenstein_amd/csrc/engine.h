@@ -55,18 +55,36 @@ struct Chain {  // 32 bytes
 
 enum OutKind : uint32_t { O_SEND = 0, O_MULTI = 1, O_TASK = 2, O_PERIODIC = 3, O_CHAINCONT = 4 };
 
-// 32-byte unordered outbox record written by action() code; (ev, sub) is its place in the global
-// push order, drawsub its rd.nextInt() ordinal inside the event.
+// 32-byte outbox record written by action() code. It lives at outTmp[evOutBase[event] + sub]: every
+// event owns a private slice of the outbox sized by the protocol's emission bound for that kind of
+// event (assigned by the expand scan), so emitting needs no allocation and `sub` IS the push order
+// inside the event.
 struct Out {
-  uint32_t ev;
-  uint32_t subs;      // sub | drawsub << 16
   uint32_t kindfrom;  // OutKind << 28 | from
   int32_t to;         // SEND: dest | MULTI: ndest | TASK/PERIODIC: node | CHAINCONT: chain slot
   uint32_t a;         // SEND/MULTI: message word | TASK/PERIODIC: task word | CHAINCONT: pos
   uint32_t b;         // SEND/MULTI: payload | TASK: arg | PERIODIC: period
   int32_t t;          // SEND/MULTI: sendTime | TASK/PERIODIC: arrival
   uint32_t destOff;   // MULTI: offset of the (unsorted) dest list in the dest ring
+  uint32_t drawsub;   // ordinal of this record's rd.nextInt() among the event's draws
+  uint32_t pad;
 };
+
+// per-event side data written by expand (16 bytes, one store)
+struct EvAux {
+  int32_t chain;      // chain slot of a chain hop, else -1
+  int32_t cpos;       // position inside the chain | last-of-run << 31
+  uint32_t outBase;   // first outbox slot of the event
+  uint32_t outCap;    // slots owned
+};
+// per-event result written by deliver (8 bytes)
+struct EvRes {
+  uint32_t nrec;      // records emitted | EV_DELIVERED / EV_TASK_RUN flags | level << 24
+  uint32_t ndraw;     // rd draws consumed
+};
+constexpr uint32_t EV_NREC_MASK = 0xFFFFu;
+constexpr uint32_t EV_DELIVERED = 1u << 16;  // counted in msgReceived (C/Network.java:607-613)
+constexpr uint32_t EV_TASK_RUN = 1u << 17;
 
 enum LatKind : int32_t { LAT_BYDIST = 0, LAT_FIXED = 1, LAT_UNIFORM = 2, LAT_NONE = 3, LAT_MEASURED = 4, LAT_IC3 = 5, LAT_ETHSCAN = 6 };
 
@@ -92,6 +110,9 @@ struct Globals {
   uint64_t rng;            // rd's 48-bit state (C/Network.java:32)
   uint32_t epoch;          // nextMessage() call counter
   uint32_t err;
+  int32_t now;             // the ms being processed (Network.time during the drain; the time++ target
+                           // during a conditional-task phase). Advanced by k_end_phase after a drain.
+  int32_t until;           // receiveUntil's bound for the run in progress
   // cumulative statistics
   unsigned long long delivered, tasks, events, draws, payloadBytes;
   unsigned long long deliveredByLevel[32];
@@ -99,7 +120,7 @@ struct Globals {
   // per-ms scratch counters
   uint32_t nEvents;        // events in the bucket being drained (after chain-run expansion)
   uint32_t nActive;        // nodes with >= 1 event
-  uint32_t nOutTmp;        // unordered outbox fill
+  uint32_t outSlots;       // outbox slots handed out to the events of this ms
   uint32_t nOut;           // ordered outbox length
   uint32_t nDraws;         // draws in this phase
   uint32_t rejectSeen;     // a nextInt(bound) rejection happened in this phase
@@ -161,24 +182,22 @@ struct EngineDev {
   unsigned long long* payloadHeadAt;  // [D]
   // per-ms scratch
   uint32_t maxEvents;
-  Rec* ev;                  // expanded events (MSG/TASK/PERIODIC form)
-  int32_t* evChain;         // chain slot of a chain hop, else -1
-  int32_t* evCpos;          // position inside the chain
-  uint8_t* evLast;          // 1 = last event of its chain run
-  uint32_t* evNrec;         // records emitted by the event
-  uint32_t* evNdraw;
-  uint32_t* evRecOff;
+  Rec* ev;                  // expanded events (MSG/TASK/PERIODIC form) in global event order
+  EvAux* evAux;
+  EvRes* evRes;
+  uint32_t* evRecOff;       // exclusive scans of nrec / ndraw in event order
   uint32_t* evDrawOff;
-  uint32_t* cntN;           // [n] events per node this ms
-  uint32_t* fillN;
-  uint32_t* nodeOff;
-  uint32_t* active;
-  uint32_t* inbox;
-  uint32_t* inbox2;
+  int32_t* evNext;          // per-node inbox as a linked list through the events
+  int32_t* head;            // [n] newest event of the node this ms, -1 = none
+  uint32_t* active;         // nodes with >= 1 event (unordered)
   uint32_t maxOut;
-  Out* outTmp;
+  Out* outTmp;              // per-event slices (see Out)
+  uint32_t* recEv;          // event of each ordered outbox position
   Rec* fin;                 // ordered outbox
   int32_t* arr;             // arrival per ordered record, -1 = dropped at send time
+  // protocol emission bounds used by expand to size the per-event outbox slices
+  uint32_t boundMsg;        // max records a delivered message's action() can emit
+  uint32_t boundTask[4];    // ... a task's action(), by task word (words >= 3 use [3])
   // multisplit scratch
   uint32_t* tileHist;       // [maxTiles][D]
   uint32_t* binBase;        // [D] position of this phase's first record inside each bucket

@@ -14,25 +14,34 @@ struct PingPongProto {
   struct State {
     int32_t* pong;
   };
+  struct WaveShared {
+    int unused;
+  };
+  struct NodeRegs {};
   enum : uint32_t { MSG_PING = 0, MSG_PONG = 1 };
   __device__ static int msg_size(const State&, uint32_t) { return 1; }  // Message.size() default
-  __device__ static void node_begin(Ctx&, const State&) {}
-  __device__ static void node_end(Ctx&, const State&) {}
-  __device__ static void on_message(Ctx& c, const State& s, int32_t from, uint32_t msg, uint32_t) {
+  __device__ static int msg_level(uint32_t) { return 0; }
+  __device__ static void node_begin(Ctx&, const State&, NodeRegs&, WaveShared*) {}
+  __device__ static void node_end(Ctx&, const State&, NodeRegs&) {}
+  __device__ static void on_message(Ctx& c, const State& s, NodeRegs&, int32_t from, uint32_t msg, uint32_t) {
     if (msg == MSG_PING) {
       c.send(from, MSG_PONG, 0, 1);  // onPing :67-69
     } else if (WG_LANE == 0) {
       s.pong[c.node]++;  // onPong :71-73
     }
   }
-  __device__ static void on_task(Ctx&, const State&, uint32_t, uint32_t) {}
+  __device__ static void on_task(Ctx&, const State&, NodeRegs&, uint32_t, uint32_t) {}
 };
 
 struct PingPongHost : ProtoHost {
   PingPongProto::State st{};
-  explicit PingPongHost(Engine& e) { st.pong = e.dalloc<int32_t>(e.dev.nodes.n); }
-  void launch_deliver(Engine& e, int32_t t) override {
-    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512), dim3(256), 0, e.stream, e.dev, st, t);
+  explicit PingPongHost(Engine& e) {
+    st.pong = e.dalloc<int32_t>(e.dev.nodes.n);
+    e.dev.boundMsg = 1;  // a delivered Ping emits one Pong
+    for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
+  }
+  void launch_deliver(Engine& e) override {
+    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512), dim3(256), 0, e.stream, e.dev, st);
   }
   bool read_i64(Engine& e, int32_t field, int64_t* dst, int32_t n) override {
     if (field != WG_F_PONG) return false;
@@ -356,25 +365,21 @@ void Engine::ensure_device() {
 
   dev.maxEvents = maxOut;
   dev.ev = dalloc<Rec>(maxOut, false);
-  dev.evChain = dalloc<int32_t>(maxOut, false);
-  dev.evCpos = dalloc<int32_t>(maxOut, false);
-  dev.evLast = dalloc<uint8_t>(maxOut, false);
-  dev.evNrec = dalloc<uint32_t>(maxOut);
-  dev.evNdraw = dalloc<uint32_t>(maxOut);
+  dev.evAux = dalloc<EvAux>(maxOut, false);
+  dev.evRes = dalloc<EvRes>(maxOut);
   dev.evRecOff = dalloc<uint32_t>(maxOut);
   dev.evDrawOff = dalloc<uint32_t>(maxOut);
-  dev.cntN = dalloc<uint32_t>(n);
-  dev.fillN = dalloc<uint32_t>(n);
-  dev.nodeOff = dalloc<uint32_t>(n);
+  dev.evNext = dalloc<int32_t>(maxOut, false);
+  dev.head = dalloc<int32_t>(n, false);
+  WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
   dev.active = dalloc<uint32_t>(n);
-  dev.inbox = dalloc<uint32_t>(maxOut, false);
-  dev.inbox2 = dalloc<uint32_t>(maxOut, false);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false);
+  dev.recEv = dalloc<uint32_t>(maxOut, false);
   dev.fin = dalloc<Rec>(maxOut, false);
   dev.arr = dalloc<int32_t>(maxOut, false);
   maxTiles = (maxOut + TILE - 1) / TILE;
-  dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D, false);
+  dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D);
   dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID);
   allocated = true;
@@ -495,17 +500,19 @@ void Engine::scan(const F& f) {
   hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID), dim3(SCAN_BLOCK), 0, stream, f, dev.scanPartials);
 }
 template void Engine::scan<ExpandF>(const ExpandF&);
-template void Engine::scan<NodesF>(const NodesF&);
 template void Engine::scan<RecsF>(const RecsF&);
 
-void Engine::append_phase(int32_t t) {
+// multisplit of the ordered outbox (fin/arr, g->nOut) into the buckets. The per-tile histograms are
+// built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
+// host-staged envelopes need the standalone histogram kernel.
+void Engine::append_phase(bool needHist) {
   size_t lds = sizeof(uint32_t) * (size_t)dev.horizon;
-  hipLaunchKernelGGL(k_tile_hist, dim3(256), dim3(TILE), lds, stream, dev, t, binBits);
+  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(256), dim3(TILE), lds, stream, dev, binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1), dim3(1024), 0, stream, dev);
-  hipLaunchKernelGGL(k_scatter, dim3(256), dim3(TILE), lds, stream, dev, t, binBits);
+  hipLaunchKernelGGL(k_scatter, dim3(256), dim3(TILE), lds, stream, dev, binBits);
 }
-void Engine::end_phase(int32_t t, bool drained) {
-  hipLaunchKernelGGL(k_end_phase, dim3(1), dim3(256), 0, stream, dev, t, drained ? 1 : 0);
+void Engine::end_phase(bool drained) {
+  hipLaunchKernelGGL(k_end_phase, dim3(1), dim3(256), 0, stream, dev, drained ? 1 : 0);
 }
 
 __global__ void k_apply_sent(NodeArrays nd, int n, const int32_t* node, const long long* msgs, const long long* bytes) {
@@ -575,7 +582,7 @@ void Engine::flush_staged(int32_t t, bool inRun) {
     WG_HIP(hipMemcpyAsync(dev.fin, recs.data(), sizeof(Rec) * n, hipMemcpyHostToDevice, stream));
     WG_HIP(hipMemcpyAsync(dev.arr, arr.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, (uint32_t)n);
-    append_phase(t);
+    append_phase(true);
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, 0u);
     WG_HIP(hipStreamSynchronize(stream));
     done += n;
@@ -645,36 +652,24 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   Globals before = gh;
   gh.epoch++;  // a new receiveUntil() starts with a fresh nextMessage() call
   gh.anyEvent = 0;
+  gh.now = time;
+  gh.until = endAt;
   globalsDirty = true;
   sync_globals_to_device();
   auto t0 = std::chrono::steady_clock::now();
   const bool cond = proto->has_cond();
+  // One simulated ms = drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the
+  // new `now` (:543-566). runMs(ms) is ms + 1 of those: the first drain re-visits the current ms
+  // (envelopes the host registered for it), the last conditional phase is the edge to until + 1, which
+  // still runs tasks whose minStartTime <= until. Kernels read `now` from device globals.
   for (int32_t t = time; t <= endAt; t++) {
-    if (t > time && stagedMin - t < dev.horizon) {
-      WG_HIP(hipStreamSynchronize(stream));
-      flush_staged(t, true);
-    }
-    if (cond && t > time) {  // time++ edge -> t: conditional tasks (:543-566)
-      proto->launch_cond(*this, t, endAt);
-      {
-        ProfScope ps(*this, PC_APPEND);
-        append_phase(t);
-      }
-      ProfScope ps(*this, PC_END);
-      end_phase(t, false);
-    }
     {
       ProfScope ps(*this, PC_EXPAND);
-      scan(ExpandF{dev, t});
-    }
-    {
-      ProfScope ps(*this, PC_GROUP);
-      scan(NodesF{dev});
-      hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, dev);
+      scan(ExpandF{dev});
     }
     {
       ProfScope ps(*this, PC_DELIVER);
-      proto->launch_deliver(*this, t);
+      proto->launch_deliver(*this);
     }
     {
       ProfScope ps(*this, PC_ORDER);
@@ -682,19 +677,31 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
     }
     {
       ProfScope ps(*this, PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev, t);
+      hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev);
     }
     {
       ProfScope ps(*this, PC_APPEND);
-      append_phase(t);
+      append_phase(false);
     }
-    ProfScope ps(*this, PC_END);
-    end_phase(t, true);
-  }
-  if (cond) {  // the edge to until+1 still runs tasks with minStartTime <= until
-    proto->launch_cond(*this, endAt + 1, endAt);
-    append_phase(endAt + 1);
-    end_phase(endAt + 1, false);
+    {
+      ProfScope ps(*this, PC_END);
+      end_phase(true);
+    }
+    // host-held envelopes beyond the bucket ring come into range as `now` advances; they go in before
+    // any device push of the new ms can target the same bucket (push order inside the bucket unchanged)
+    if (stagedMin - (t + 1) < dev.horizon) {
+      WG_HIP(hipStreamSynchronize(stream));
+      flush_staged(t + 1, true);
+    }
+    if (cond) {
+      proto->launch_cond(*this);
+      {
+        ProfScope ps(*this, PC_APPEND);
+        append_phase(false);
+      }
+      ProfScope ps(*this, PC_END);
+      end_phase(false);
+    }
   }
   WG_HIP(hipStreamSynchronize(stream));
   auto t1 = std::chrono::steady_clock::now();
@@ -709,7 +716,10 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
     stats->draws = (int64_t)(gh.draws - before.draws);
     stats->simulated_ms = ms;
     stats->wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-    stats->payload_bytes = (int64_t)(gh.payloadBytes - before.payloadBytes);
+    int64_t pb = 0;
+    for (int l = 0; l < 32; l++)
+      pb += (int64_t)(gh.deliveredByLevel[l] - before.deliveredByLevel[l]) * proto->payload_bytes_of_level(l);
+    stats->payload_bytes = pb;
   }
   check_device_errors();
 }
@@ -816,16 +826,10 @@ struct HandelHost : ProtoHost {
     const int W = N >= 64 ? N / 64 : 1;
     const int Q = e.cfg.queue_cap > 0 ? e.cfg.queue_cap : 32;
     if (Q > 64) throw WgError(WG_EINVAL, "queue_cap must be <= 64");
-    // payload ring: everything sent within one horizon must fit (see EngineDev::payloadHeadAt).
-    // One dissemination of one node writes at most W + L words; fast-path sends add at most the same.
-    if (e.cfg.payload_words == 0 && !e.allocated) {
-      int32_t maxPair = 1;
-      for (int i = 0; i < N; i++) maxPair = std::max(maxPair, init.nodePairingTime[i]);
-      // horizon is decided in ensure_device(); be conservative: assume 512 ms unless configured
-      int64_t horizon = e.cfg.horizon_ms > 0 ? e.cfg.horizon_ms : 512;
-      int64_t bursts = horizon / std::max(1, p.disseminationPeriodMs) + 2;
-      e.cfg.payload_words = std::max<int64_t>(1 << 20, (int64_t)N * (W + L) * (bursts + 2));
-    }
+    // engine payload ring: only fast-path sends (:738-749) snapshot into it — at most one per (node, level)
+    // completion; the periodic dissemination snapshots have computed addresses (HandelState::snap).
+    if (e.cfg.payload_words == 0 && !e.allocated)
+      e.cfg.payload_words = std::max<int64_t>(1 << 20, 2 * (int64_t)N * (W + L));
     e.ensure_device();
     if (p.disseminationPeriodMs >= e.dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms <= dissemination period");
     st.p = p;
@@ -868,6 +872,23 @@ struct HandelHost : ProtoHost {
       off += (unsigned long long)N * Q * nw;
     }
     st.qsig = e.dalloc<uint64_t>(off, false);
+    {
+      uint32_t off = 0;
+      for (int l = 0; l < L; l++) {
+        st.lvlOff[l] = off;
+        off += l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
+      }
+      st.snapStride = off;
+      st.snapNb = (uint32_t)(e.dev.horizon / p.disseminationPeriodMs) + 2;  // a snapshot is read within < horizon ms
+      uint64_t words = (uint64_t)st.snapNb * N * st.snapStride;
+      if (words >= 0x80000000ull) throw WgError(WG_ENOMEM, "Handel snapshot ring exceeds 2^31 words: lower horizon_ms");
+      if ((uint64_t)e.dev.payloadWords >= 0x80000000ull) throw WgError(WG_EINVAL, "payload_words must be < 2^31");
+      st.snap = e.dalloc<uint64_t>(words, false);
+    }
+    e.dev.boundMsg = 0;            // onNewSig never sends
+    e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
+    e.dev.boundTask[1] = L - 1;    // updateVerifiedSignatures: one fast-path send per higher level
+    e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
     st.pend = e.dalloc<uint32_t>((size_t)N * H_PEND);
     st.pendFrom = e.dalloc<int32_t>((size_t)N * H_PEND);
     st.candCnt = e.dalloc<uint8_t>(N);
@@ -900,19 +921,20 @@ struct HandelHost : ProtoHost {
     int l = (int)(msg & 31u);
     return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 192;
   }
-  void launch_cond(Engine& e, int32_t t, int32_t until) override {
+  int payload_bytes_of_level(int l) const override {
+    return l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) / 8 : 8);  // 64-bit words of the level's block
+  }
+  void launch_cond(Engine& e) override {
     {
       Engine::ProfScope ps(e, Engine::PC_COND_SELECT);
-      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t, until);
+      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st);
     }
     Engine::ProfScope ps(e, Engine::PC_COND_REST);
     e.scan(CondF{e.dev, st});
-    hipLaunchKernelGGL(k_handel_cond_draw, dim3(128), dim3(256), 0, e.stream, e.dev, st);
-    hipLaunchKernelGGL(k_handel_cond_fix, dim3(1), dim3(1), 0, e.stream, e.dev, st);
-    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128), dim3(256), 0, e.stream, e.dev, st, t);
+    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128), dim3(256), 0, e.stream, e.dev, st);
   }
-  void launch_deliver(Engine& e, int32_t t) override {
-    hipLaunchKernelGGL(k_deliver_handel, dim3(2048), dim3(256), 0, e.stream, e.dev, st, t);
+  void launch_deliver(Engine& e) override {
+    hipLaunchKernelGGL(k_deliver<HandelProto>, dim3(2048), dim3(256), 0, e.stream, e.dev, st);
   }
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
     const int32_t* src = nullptr;

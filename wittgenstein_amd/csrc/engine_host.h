@@ -31,8 +31,9 @@ struct ProtoHost {
   virtual bool has_cond() const { return false; }
   // conditional-task phase at the time++ edge -> t (C/Network.java:543-566); emits into the ordered
   // outbox (fin/arr, g->nOut) and g->nDraws. Only called when has_cond().
-  virtual void launch_cond(Engine&, int32_t /*t*/, int32_t /*until*/) {}
-  virtual void launch_deliver(Engine&, int32_t t) = 0;
+  virtual void launch_cond(Engine&) {}
+  virtual void launch_deliver(Engine&) = 0;
+  virtual int payload_bytes_of_level(int /*level*/) const { return 0; }
   virtual bool read_i64(Engine&, int32_t /*field*/, int64_t* /*dst*/, int32_t /*n*/) { return false; }
   virtual bool read_level_i32(Engine&, int32_t, int32_t*, int32_t, int32_t) { return false; }
   virtual bool read_bits(Engine&, int32_t, uint64_t*, int32_t, int32_t) { return false; }
@@ -73,8 +74,8 @@ class Engine {
   void ensure_device();          // allocate device state once the node count is known
   void sync_globals_to_host();
   void sync_globals_to_device();
-  void append_phase(int32_t t);  // multisplit of the ordered outbox into the buckets
-  void end_phase(int32_t t, bool drained);
+  void append_phase(bool needHist);  // multisplit of the ordered outbox into the buckets
+  void end_phase(bool drained);
   template <class F>
   void scan(const F& f);
   void flush_staged(int32_t t, bool inRun);

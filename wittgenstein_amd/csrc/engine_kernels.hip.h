@@ -4,13 +4,17 @@
 //
 // One simulated millisecond t (C/Network.java:533-637) =
 //   [conditional-task phase — protocol kernels, see proto_handel.hip.h]
-//   expand   bucket t in LIFO order, MultipleDestEnvelope runs unrolled        -> events[0..E)
-//   group    events by destination node (count, scan, fill)                     -> per-node inbox
-//   deliver  one wavefront per node with >=1 event applies them in event order  -> unordered outbox
-//   order    scan of per-event record/draw counts                               -> global push order + draw index
-//   resolve  seed = rd.nextInt() by LCG jump-ahead, latency, arrival, drops     -> ordered outbox
-//   append   stable multisplit of the ordered outbox by arrival-ms (LDS histogram per 1024-record
-//            tile, wave-ballot match for the in-tile rank) onto the tail of each arrival bucket
+//   expand   bucket t in LIFO order, MultipleDestEnvelope runs unrolled -> events[0..E); the same scan
+//            hands every event a private outbox slice (protocol emission bound) and threads the event
+//            onto its destination node's inbox list (atomicExch on the node's head: distinct addresses)
+//   deliver  one wavefront per node with >=1 event applies them in event order  -> per-event outbox slices
+//   order    scan of per-event record/draw counts (+ statistics)               -> global push order + draw index
+//   resolve  seed = rd.nextInt() by LCG jump-ahead, latency, arrival, drops     -> ordered outbox + tile histograms
+//   append   stable multisplit of the ordered outbox by arrival-ms (per-1024-record tile histogram,
+//            wave-ballot match for the in-tile rank) onto the tail of each arrival bucket
+// No kernel of the per-ms pipeline performs a same-address atomic per event or per record: on MI355X
+// one L2 atomic unit retires ~88 same-address atomics/us, which at 10^4..10^5 events per ms was the
+// whole cost of the first version of this engine (profiles/r01a_kernel_stats.md).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "engine.h"
@@ -123,8 +127,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(F f, unsigned long long* p
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
   uint64_t tot = block_sum64(acc, sh);
   if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+  f.tally(lo, hi);
 }
 
+// f.write(i, exclusive_prefix, valid) is called by every thread of the block at the same point (valid
+// = i is in range), so write() may use wave-level collectives.
 template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(F f, const unsigned long long* partials) {
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
@@ -153,96 +160,147 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(F f, const unsigned long l
       if (k < w) woff += x;
       tile += x;
     }
-    if (i < hi) f.write(i, prefix + woff + incl - v);
+    f.write(i, prefix + woff + incl - v, i < hi);
     prefix += tile;
     __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// expand: bucket t, LIFO, chain runs unrolled
+// expand: bucket t, LIFO, chain runs unrolled. Pair scan: low = events, high = outbox slots.
 struct ExpandF {
   EngineDev d;
-  int32_t t;
-  __device__ uint32_t bucket() const { return (uint32_t)t & (uint32_t)(d.horizon - 1); }
+  __device__ int32_t now() const { return d.g->now; }
+  __device__ uint32_t bucket() const { return (uint32_t)now() & (uint32_t)(d.horizon - 1); }
   __device__ uint32_t count() const { return d.bcnt[bucket()]; }
-  __device__ uint32_t runlen(const Rec& r) const {
+  __device__ uint32_t runlen(const Rec& r, int32_t t) const {
     if (rec_kind(r) != K_CHAIN) return 1;
     const Chain c = d.chains[r.w1];
     uint32_t len = 1;
     for (int j = (int)r.w2 + 1; j < c.ndest && chain_arrival(d, c, j) == t; j++) len++;
     return len;
   }
-  __device__ uint64_t value(uint32_t i) const { return runlen(*rec_ptr(d, bucket(), count() - 1 - i)); }
-  __device__ void total(uint64_t tot) const {
-    if (tot > d.maxEvents) {
-      set_err(d.g, ERR_EVENTS);
-      tot = 0;
-    }
-    d.g->nEvents = (uint32_t)tot;
+  __device__ uint32_t task_bound(const Rec& r) const {
+    return d.boundTask[r.w2 < 3u ? r.w2 : 3u] + (rec_kind(r) == K_PERIODIC ? 1u : 0u);
   }
-  __device__ void write(uint32_t i, uint64_t excl) const {
-    const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
-    uint32_t e = (uint32_t)excl;
-    if (rec_kind(r) != K_CHAIN) {
-      if (e >= d.maxEvents) return;
-      d.ev[e] = r;
-      d.evChain[e] = -1;
-      d.evCpos[e] = 0;
-      d.evLast[e] = 0;
-      atomicAdd(&d.cntN[r.w1], 1u);
-      return;
-    }
-    const Chain c = d.chains[r.w1];
-    uint32_t len = runlen(r);
-    for (uint32_t k = 0; k < len; k++, e++) {
-      if (e >= d.maxEvents) return;
-      int32_t to = chain_dest(d, c, (int)r.w2 + (int)k);
-      d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
-      d.evChain[e] = (int32_t)r.w1;
-      d.evCpos[e] = (int32_t)r.w2 + (int32_t)k;
-      d.evLast[e] = (k + 1 == len);
-      atomicAdd(&d.cntN[to], 1u);
-    }
-  }
-};
-
-// group: per-node offsets + list of active nodes (pair scan: high = active flag, low = count)
-struct NodesF {
-  EngineDev d;
-  __device__ uint32_t count() const { return (uint32_t)d.nodes.n; }
   __device__ uint64_t value(uint32_t i) const {
-    uint32_t c = d.cntN[i];
-    return ((uint64_t)(c > 0) << 32) | c;
+    const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
+    const uint32_t k = rec_kind(r);
+    if (k == K_MSG) return ((uint64_t)d.boundMsg << 32) | 1u;
+    if (k != K_CHAIN) return ((uint64_t)task_bound(r) << 32) | 1u;
+    const uint32_t len = runlen(r, now());
+    return ((uint64_t)(len * d.boundMsg + 1u) << 32) | len;  // + the re-push after the run (:629-632)
   }
-  __device__ void total(uint64_t tot) const { d.g->nActive = (uint32_t)(tot >> 32); }
-  __device__ void write(uint32_t i, uint64_t excl) const {
-    d.nodeOff[i] = (uint32_t)excl;
-    if (d.cntN[i] > 0) d.active[(uint32_t)(excl >> 32)] = i;
+  __device__ void tally(uint32_t, uint32_t) const {}
+  __device__ void total(uint64_t tot) const {
+    uint32_t ne = (uint32_t)tot, ns = (uint32_t)(tot >> 32);
+    if (ne > d.maxEvents) {
+      set_err(d.g, ERR_EVENTS);
+      ne = 0;
+    }
+    if (ns > d.maxOut) set_err(d.g, ERR_OUTBOX);
+    d.g->nEvents = ne;
+    d.g->outSlots = ns;
+  }
+  // thread the event onto its node's inbox list; returns true if it is the node's first event
+  __device__ bool link(uint32_t e, int32_t to) const {
+    int32_t prev = atomicExch(&d.head[to], (int32_t)e);
+    d.evNext[e] = prev;
+    return prev < 0;
+  }
+  __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
+    bool first = false;
+    int32_t firstNode = 0;
+    if (valid) {
+      const int32_t t = now();
+      const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
+      uint32_t e = (uint32_t)excl, ob = (uint32_t)(excl >> 32);
+      const uint32_t k = rec_kind(r);
+      if (k != K_CHAIN) {
+        if (e < d.maxEvents) {
+          d.ev[e] = r;
+          EvAux a;
+          a.chain = -1;
+          a.cpos = 0;
+          a.outBase = ob;
+          a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
+          d.evAux[e] = a;
+          first = link(e, (int32_t)r.w1);
+          firstNode = (int32_t)r.w1;
+        }
+      } else {
+        const Chain c = d.chains[r.w1];
+        const uint32_t len = runlen(r, t);
+        for (uint32_t q = 0; q < len; q++, e++) {
+          if (e >= d.maxEvents) break;
+          const int32_t to = chain_dest(d, c, (int)r.w2 + (int)q);
+          d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+          const bool last = q + 1 == len;
+          EvAux a;
+          a.chain = (int32_t)r.w1;
+          a.cpos = (int32_t)(r.w2 + q) | (last ? (int32_t)0x80000000 : 0);
+          a.outBase = ob + q * d.boundMsg;
+          a.outCap = d.boundMsg + (last ? 1u : 0u);
+          d.evAux[e] = a;
+          if (link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+        }
+      }
+    }
+    // wave-aggregated append to the active list: one atomic per wavefront, not per node
+    const uint64_t m = __ballot(first);
+    if (m) {
+      uint32_t base = 0;
+      const int leader = __ffsll((unsigned long long)m) - 1;
+      if ((int)WG_LANE == leader) base = atomicAdd(&d.g->nActive, (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (first) d.active[base + __popcll(m & lanes_lt())] = (uint32_t)firstNode;
+    }
   }
 };
 
-__global__ void __launch_bounds__(256) k_fill(EngineDev d) {
-  uint32_t n = d.g->nEvents;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    uint32_t to = d.ev[e].w1;
-    uint32_t pos = atomicAdd(&d.fillN[to], 1u);
-    d.inbox[d.nodeOff[to] + pos] = e;
-  }
-}
-
-// order: per-event (records, draws) -> offsets in the global push order / draw order
+// order: per-event (records, draws) -> offsets in the global push order / draw order, the event of
+// every ordered outbox position, and the run statistics (block-aggregated).
 struct RecsF {
   EngineDev d;
   __device__ uint32_t count() const { return d.g->nEvents; }
-  __device__ uint64_t value(uint32_t i) const { return ((uint64_t)d.evNdraw[i] << 32) | d.evNrec[i]; }
+  __device__ uint64_t value(uint32_t i) const {
+    const EvRes r = d.evRes[i];
+    return ((uint64_t)r.ndraw << 32) | (r.nrec & EV_NREC_MASK);
+  }
+  __device__ void tally(uint32_t lo, uint32_t hi) const {
+    __shared__ uint32_t shStat[34];  // [0..31] delivered by level, [32] delivered, [33] tasks
+    for (int k = threadIdx.x; k < 34; k += SCAN_BLOCK) shStat[k] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) {
+      const uint32_t f = d.evRes[i].nrec;
+      if (f & EV_DELIVERED) {
+        atomicAdd(&shStat[(f >> 24) & 31u], 1u);
+        atomicAdd(&shStat[32], 1u);
+      }
+      if (f & EV_TASK_RUN) atomicAdd(&shStat[33], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 34 && shStat[threadIdx.x]) {
+      unsigned long long* dst = threadIdx.x < 32 ? &d.g->deliveredByLevel[threadIdx.x]
+                                                 : (threadIdx.x == 32 ? &d.g->delivered : &d.g->tasks);
+      atomicAdd(dst, (unsigned long long)shStat[threadIdx.x]);
+    }
+  }
   __device__ void total(uint64_t tot) const {
-    d.g->nOut = (uint32_t)tot;
+    uint32_t n = (uint32_t)tot;
+    if (n > d.maxOut) {
+      set_err(d.g, ERR_OUTBOX);
+      n = 0;
+    }
+    d.g->nOut = n;
     d.g->nDraws = (uint32_t)(tot >> 32);
   }
-  __device__ void write(uint32_t i, uint64_t excl) const {
-    d.evRecOff[i] = (uint32_t)excl;
+  __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
+    if (!valid) return;
+    const uint32_t off = (uint32_t)excl, n = d.evRes[i].nrec & EV_NREC_MASK;
+    d.evRecOff[i] = off;
     d.evDrawOff[i] = (uint32_t)(excl >> 32);
+    for (uint32_t k = 0; k < n && off + k < d.maxOut; k++) d.recEv[off + k] = i;
   }
 };
 
@@ -264,26 +322,28 @@ __device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_resolve(EngineDev d, int32_t t) {
-  uint32_t n = d.g->nOutTmp;
-  if (n > d.maxOut) n = d.maxOut;
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const Out o = d.outTmp[r];
-    uint32_t p = d.evRecOff[o.ev] + (o.subs & 0xFFFFu);
-    if (p >= d.maxOut) continue;
+constexpr int TILE = 1024;
+
+__global__ void __launch_bounds__(256) k_resolve(EngineDev d) {
+  const int32_t t = d.g->now;
+  const uint32_t n = d.g->nOut;
+  const uint32_t D = (uint32_t)d.horizon;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const uint32_t e = d.recEv[p];
+    const Out o = d.outTmp[d.evAux[e].outBase + (p - d.evRecOff[e])];
     uint32_t kind = o.kindfrom >> 28;
     int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
     Rec fin = make_rec(K_MSG, from, 0, 0, 0);
     int32_t arrival = -1;
     switch (kind) {
       case O_SEND: {
-        int32_t seed = draw_next_int(d, d.evDrawOff[o.ev] + (o.subs >> 16));
+        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
         fin = make_rec(K_MSG, from, (uint32_t)o.to, o.a, o.b);
         if (!arrival_of_send(d, from, o.to, o.t, seed, arrival)) arrival = -1;
         break;
       }
       case O_MULTI: {  // delaysBetweenMessage == 0 only (device actions); stable sort by arrival (:464)
-        int32_t seed = draw_next_int(d, d.evDrawOff[o.ev] + (o.subs >> 16));
+        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
         int nd = o.to;
         int32_t dst[64], arv[64];
         int m = 0;
@@ -353,12 +413,13 @@ __global__ void __launch_bounds__(256) k_resolve(EngineDev d, int32_t t) {
     }
     d.fin[p] = fin;
     d.arr[p] = arrival;
+    // per-tile arrival histogram of the multisplit (rows are zero on entry: k_scatter re-zeroes them)
+    if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // append: stable multisplit of the ordered outbox by arrival bucket.
-constexpr int TILE = 1024;
 
 // in-tile stable rank of each element among equal bins: wave-level ballot match, then waves in order
 // through an LDS running count. `hist` is this block's LDS histogram [D]; must be zero on entry and
@@ -386,7 +447,8 @@ __device__ __forceinline__ uint32_t tile_rank(uint32_t* hist, int bin, bool vali
   return rank;
 }
 
-__global__ void __launch_bounds__(TILE) k_tile_hist(EngineDev d, int32_t t, int binBits) {
+// (host-staged envelopes only: the device pipeline builds the histogram inside k_resolve / cond_a2)
+__global__ void __launch_bounds__(TILE) k_tile_hist(EngineDev d, int binBits) {
   extern __shared__ uint32_t hist[];
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
@@ -456,7 +518,7 @@ __global__ void __launch_bounds__(1024) k_col_reserve(EngineDev d) {
   }
 }
 
-__global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int32_t t, int binBits) {
+__global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int binBits) {
   extern __shared__ uint32_t hist[];
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
@@ -475,15 +537,17 @@ __global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int32_t t, int bi
       *rec_ptr(d, (uint32_t)bin, pos) = d.fin[i];
     }
     __syncthreads();
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) d.tileHist[(size_t)tile * D + b] = 0;  // for the next phase
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
 // release the bucket's pages and bump the nextMessage() epoch if anything was polled.
-__global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int32_t t, int drained) {
+__global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int drained) {
   __shared__ uint32_t shTop;
   Globals* g = d.g;
+  const int32_t t = g->now;
   if (threadIdx.x == 0) shTop = g->freeTop;
   __syncthreads();
   if (drained) {
@@ -506,6 +570,7 @@ __global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int32_t t, int d
       if (g->payloadHead - oldP > d.payloadWords) set_err(g, ERR_PAYLOAD);
       d.destHeadAt[b] = g->destHead;
       d.payloadHeadAt[b] = g->payloadHead;
+      g->now = t + 1;  // nextMessage(): time++
     }
   }
   if (threadIdx.x == 0) {
@@ -513,7 +578,7 @@ __global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int32_t t, int d
     g->draws += g->nDraws;
     g->nEvents = 0;
     g->nActive = 0;
-    g->nOutTmp = 0;
+    g->outSlots = 0;
     g->nOut = 0;
     g->nDraws = 0;
     g->rejectSeen = 0;
@@ -540,34 +605,27 @@ struct Ctx {
   uint32_t ev;     // event index in the global order
   uint32_t sub;    // records emitted by this event so far
   uint32_t draws;  // rd.nextInt() calls by this event so far
+  uint32_t outBase, outCap;      // the event's private outbox slice
   long long msgSent, bytesSent;  // accumulated Node counters (C/Network.java:476-477)
 
-  __device__ uint32_t alloc_out() {
-    uint32_t idx = 0;
+  __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw) {
     if (WG_LANE == 0) {
-      idx = atomicAdd(&d.g->nOutTmp, 1u);
-      if (idx >= d.maxOut) {
-        set_err(d.g, ERR_OUTBOX);
-        idx = 0xFFFFFFFFu;
+      if (sub < outCap && outBase + sub < d.maxOut) {
+        Out o;
+        o.kindfrom = (kind << 28) | (uint32_t)node;
+        o.to = to;
+        o.a = a;
+        o.b = b;
+        o.t = tt;
+        o.destOff = destOff;
+        o.drawsub = draws;
+        o.pad = 0;
+        d.outTmp[outBase + sub] = o;
+      } else {
+        set_err(d.g, ERR_OUTBOX);  // the protocol's emission bound (EngineDev::boundMsg/boundTask) is wrong
       }
     }
-    return idx;  // valid on lane 0 only
-  }
-  __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw) {
-    uint32_t idx = alloc_out();
-    if (WG_LANE == 0 && idx != 0xFFFFFFFFu) {
-      Out o;
-      o.ev = ev;
-      o.subs = sub | (draws << 16);
-      o.kindfrom = (kind << 28) | (uint32_t)node;
-      o.to = to;
-      o.a = a;
-      o.b = b;
-      o.t = tt;
-      o.destOff = destOff;
-      d.outTmp[idx] = o;
-    }
-    sub++;
+    if (sub < outCap) sub++;
     if (draw) draws++;
   }
   // Network.send(m, this, to): sendTime = time + 1, one rd.nextInt() (C/Network.java:364-382)
@@ -606,7 +664,7 @@ struct Ctx {
   __device__ void register_task(int32_t startAt, uint32_t word, uint32_t arg) {
     put(O_TASK, node, word, arg, startAt, 0, false);
   }
-  // payload ring: `words` 64-bit words, returns ref (word offset)
+  // engine payload ring (irregular senders): `words` 64-bit words, returns the word offset
   __device__ uint32_t alloc_payload(int words) {
     unsigned long long off = 0;
     if (WG_LANE == 0) off = atomicAdd(&d.g->payloadHead, (unsigned long long)words);
@@ -627,72 +685,116 @@ struct Ctx {
 };
 
 // The delivery kernel: receiveUntil's loop body (C/Network.java:594-635) for all events of ms t.
+// A protocol P provides:
+//   State                      device pointers of its SoA state (kernel argument)
+//   WaveShared                 per-wavefront LDS scratch
+//   NodeRegs                   wave-uniform registers holding the node's scalars between its events
+//   node_begin / node_end      load / store NodeRegs
+//   msg_size(State, word)      Message.size()
+//   msg_level(word)            statistics bucket (Handel level) 0..31
+//   on_message / on_task       Message.action()
 template <class P>
-__global__ void __launch_bounds__(256) k_deliver(EngineDev d, typename P::State ps, int32_t t) {
-  const int lane = WG_LANE;
+__device__ __forceinline__ void deliver_event(const EngineDev& d, const typename P::State& ps, Ctx& c,
+                                              typename P::NodeRegs& r, uint32_t e, bool toDown, uint8_t toPart,
+                                              long long& nRecv, long long& bRecv) {
+  const Rec rec = d.ev[e];
+  const EvAux aux = d.evAux[e];
+  const uint32_t kind = rec_kind(rec);
+  const int32_t from = rec_from(rec);
+  c.ev = e;
+  c.sub = 0;
+  c.draws = 0;
+  c.outBase = aux.outBase;
+  c.outCap = aux.outCap;
+  uint32_t flags = 0;
+  if (!toDown && d.nodes.part[from] == toPart) {  // :606
+    if (kind == K_MSG) {
+      nRecv++;
+      bRecv += P::msg_size(ps, rec.w2);
+      flags = EV_DELIVERED | ((uint32_t)P::msg_level(rec.w2) << 24);
+      P::on_message(c, ps, r, from, rec.w2, rec.w3);
+    } else {
+      flags = EV_TASK_RUN;
+      P::on_task(c, ps, r, rec.w2, rec.w3);
+      if (kind == K_PERIODIC)  // PeriodicTask.action re-arm (C/messages/PeriodicTask.java:39-47)
+        c.put(O_PERIODIC, c.node, rec.w2, rec.w3, c.t + (int32_t)rec.w3, 0, false);
+    }
+  }
+  if (aux.chain >= 0 && aux.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
+    const int32_t next = (aux.cpos & 0x7FFFFFFF) + 1;
+    if (next < d.chains[aux.chain].ndest)
+      c.put(O_CHAINCONT, aux.chain, (uint32_t)next, 0, 0, 0, false);
+    else if (WG_LANE == 0)
+      d.chains[aux.chain].flags = 0;  // envelope fully delivered
+  }
+  if (WG_LANE == 0) {
+    EvRes res;
+    res.nrec = c.sub | flags;
+    res.ndraw = c.draws;
+    d.evRes[e] = res;
+  }
+  __threadfence_block();  // the node's next event reads what this one wrote (other lanes, same wavefront)
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_deliver(EngineDev d, typename P::State ps) {
+  __shared__ typename P::WaveShared shP[4];
+  __shared__ uint32_t shSort[4][64];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nActive; a += nWaves) {
     const int32_t node = (int32_t)d.active[a];
-    const uint32_t off = d.nodeOff[node], cnt = d.cntN[node];
-    // event order inside the node: rank sort of the (unordered) inbox segment by event index
-    for (uint32_t i = lane; i < cnt; i += 64) {
-      uint32_t e = d.inbox[off + i], rank = 0;
-      for (uint32_t j = 0; j < cnt; j++) rank += d.inbox[off + j] < e;
-      d.inbox2[off + rank] = e;
+    // the node's events of this ms: walk the inbox list (newest first), then order by event index
+    int32_t cur = d.head[node];
+    uint32_t cnt = 0, mine = 0xFFFFFFFFu;
+    while (cur >= 0 && cnt < 64) {
+      if ((uint32_t)lane == cnt) mine = (uint32_t)cur;
+      cur = d.evNext[cur];
+      cnt++;
     }
-    __threadfence_block();
-    Ctx c{d, t, node, 0, 0, 0, 0, 0};
-    long long nRecv = 0, bRecv = 0, nTasks = 0;
+    const bool overflow = cur >= 0;
+    Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+    typename P::NodeRegs r;
+    long long nRecv = 0, bRecv = 0;
     const bool toDown = d.nodes.down[node] != 0;
     const uint8_t toPart = d.nodes.part[node];
-    P::node_begin(c, ps);
-    for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t e = d.inbox2[off + k];
-      const Rec r = d.ev[e];
-      const uint32_t kind = rec_kind(r);
-      const int32_t from = rec_from(r);
-      c.ev = e;
-      c.sub = 0;
-      c.draws = 0;
-      if (!toDown && d.nodes.part[from] == toPart) {  // :606
-        if (kind == K_MSG) {
-          nRecv++;
-          bRecv += P::msg_size(ps, r.w2);
-          P::on_message(c, ps, from, r.w2, r.w3);
-        } else {
-          nTasks++;
-          P::on_task(c, ps, r.w2, r.w3);
-          if (kind == K_PERIODIC)  // PeriodicTask.action re-arm (C/messages/PeriodicTask.java:39-47)
-            c.put(O_PERIODIC, node, r.w2, r.w3, t + (int32_t)r.w3, 0, false);
-        }
+    P::node_begin(c, ps, r, &shP[w]);
+    if (!overflow) {
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
+      if ((uint32_t)lane < cnt) shSort[w][rank] = mine;
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = shSort[w][k];
+        deliver_event<P>(d, ps, c, r, e, toDown, toPart, nRecv, bRecv);
       }
-      const int32_t slot = d.evChain[e];
-      if (slot >= 0 && d.evLast[e]) {  // markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
-        const int32_t next = d.evCpos[e] + 1;
-        if (next < d.chains[slot].ndest)
-          c.put(O_CHAINCONT, slot, (uint32_t)next, 0, 0, 0, false);
-        else if (lane == 0)
-          d.chains[slot].flags = 0;  // envelope fully delivered
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // more than 64 events for one node in one ms (e.g. the PingPong origin): repeated minimum search
+      bool have = false;
+      uint32_t last = 0;
+      for (;;) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (int32_t q = d.head[node]; q >= 0; q = d.evNext[q])
+          if ((!have || (uint32_t)q > last) && (uint32_t)q < best) best = (uint32_t)q;
+        if (best == 0xFFFFFFFFu) break;
+        deliver_event<P>(d, ps, c, r, best, toDown, toPart, nRecv, bRecv);
+        last = best;
+        have = true;
       }
-      if (lane == 0) {
-        d.evNrec[e] = c.sub;
-        d.evNdraw[e] = c.draws;
-      }
-      __threadfence_block();
     }
-    P::node_end(c, ps);
+    P::node_end(c, ps, r);
     if (lane == 0) {
       d.nodes.msgReceived[node] += nRecv;
       d.nodes.bytesReceived[node] += bRecv;
       d.nodes.msgSent[node] += c.msgSent;
       d.nodes.bytesSent[node] += c.bytesSent;
-      d.cntN[node] = 0;
-      d.fillN[node] = 0;
-      if (nRecv) atomicAdd(&d.g->delivered, (unsigned long long)nRecv);
-      if (nTasks) atomicAdd(&d.g->tasks, (unsigned long long)nTasks);
+      d.head[node] = -1;
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

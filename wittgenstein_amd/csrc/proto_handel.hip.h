@@ -40,7 +40,13 @@ struct HandelState {
   int32_t *qfrom, *qrank;              // [N][L][Q]
   uint64_t* qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
-  uint32_t* pend;                      // [N][H_PEND]: valid<<31 | level<<24 | slot<<18 | ... ; from in pendFrom
+  // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
+  // per aligned window of `period` ms, so its snapshots live at a computed address — no allocation:
+  //   snap[((t / period) % snapNb) * N + node][lvlOff[l] ...]      (snapStride words per node)
+  uint64_t* snap;
+  uint32_t snapNb, snapStride;
+  uint32_t lvlOff[MAX_LEVELS];
+  uint32_t* pend;                      // [N][H_PEND]: valid<<31 | level<<8 | slot ; from in pendFrom
   int32_t* pendFrom;                   // [N][H_PEND]
   // conditional-task phase scratch
   uint8_t* candCnt;                    // [N] number of levels with a candidate
@@ -114,8 +120,11 @@ struct LevelScalars {
   unsigned long long qused[MAX_LEVELS];
 };
 
+constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
+
 struct HandelProto {
   typedef HandelState State;
+  typedef LevelScalars WaveShared;
 
   // node-scoped registers (wave-uniform) live in this struct for the duration of a node's events
   struct NodeRegs {
@@ -127,6 +136,44 @@ struct HandelProto {
   };
 
   __device__ static int msg_size(const State&, uint32_t msg) { return h_msg_size((int)(msg & 31u)); }
+  __device__ static int msg_level(uint32_t msg) { return (int)(msg & 31u); }
+
+  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls) {
+    const int32_t node = c.node;
+    r.doneAt = c.d.nodes.doneAt[node];
+    r.addedCycle = s.addedCycle[node];
+    r.sigQueueSize = s.sigQueueSize[node];
+    r.msgFiltered = s.msgFiltered[node];
+    r.startAt = s.startAt[node];
+#pragma unroll
+    for (int k = 0; k < H_PEND; k++) {
+      r.pend[k] = s.pend[(size_t)node * H_PEND + k];
+      r.pendFrom[k] = s.pendFrom[(size_t)node * H_PEND + k];
+    }
+    r.ls = ls;
+    load_levels(s, node, ls);
+  }
+  __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
+    const int32_t node = c.node;
+    store_levels(s, node, r.ls);
+    if (WG_LANE == 0) {
+      c.d.nodes.doneAt[node] = r.doneAt;
+      s.addedCycle[node] = r.addedCycle;
+      s.sigQueueSize[node] = r.sigQueueSize;
+      s.msgFiltered[node] = r.msgFiltered;
+#pragma unroll
+      for (int k = 0; k < H_PEND; k++) s.pend[(size_t)node * H_PEND + k] = r.pend[k];
+    }
+  }
+  __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    on_new_sig(c, s, r, from, msg, payload);
+  }
+  __device__ static void on_task(Ctx& c, const State& s, NodeRegs& r, uint32_t word, uint32_t arg) {
+    if (word == H_TASK_DISSEMINATION)
+      dissemination(c, s, r);
+    else
+      update_verified(c, s, r, arg);
+  }
 
   __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
     for (int l = WG_LANE; l < s.L; l += 64) {
@@ -228,13 +275,20 @@ struct HandelProto {
     return got;
   }
 
-  // snapshot of totalOutgoing of level l (the node's own block of the TI row) into the payload ring
-  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l) {
+  // snapshot of totalOutgoing of level l (the node's own block of the TI row).
+  // periodic = true: the dissemination's computed slot; false (fast path, irregular): engine payload ring.
+  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l, bool periodic) {
     Lv v = own_view(c.node, l);
-    uint32_t ref = c.alloc_payload(v.nw);
     const uint64_t* ti = s.TI + (size_t)c.node * s.W;
+    if (periodic) {
+      const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
+      const uint32_t ref = (win * (uint32_t)s.N + (uint32_t)c.node) * s.snapStride + s.lvlOff[l];
+      H_FOR_WORDS(v, j) s.snap[ref + j] = ti[v.bw + j] & v.mask;
+      return ref;
+    }
+    uint32_t ref = c.alloc_payload(v.nw);
     H_FOR_WORDS(v, j) c.d.payload[ref + j] = ti[v.bw + j] & v.mask;
-    return ref;
+    return ref | H_REF_RING;
   }
 
   // ---- Message.action: SendSigs -> onNewSig (:757-790) -------------------------------------------
@@ -242,10 +296,6 @@ struct HandelProto {
     const int l = (int)(msg & 31u);
     const bool levelFinished = (msg >> 5) & 1u;
     const int32_t node = c.node;
-    if (WG_LANE == 0) {
-      atomicAdd(&c.d.g->deliveredByLevel[l], 1ULL);
-      atomicAdd(&c.d.g->payloadBytes, (unsigned long long)h_nw(l) * 8ULL);
-    }
     if (r.doneAt > 0) {
       r.msgFiltered++;
       return;
@@ -267,7 +317,8 @@ struct HandelProto {
     int slot = __ffsll(freeM) - 1;
     Lv v = sib_view(node, l);
     uint64_t* dst = sig_ptr(s, node, l, slot);
-    H_FOR_WORDS(v, j) dst[j] = c.d.payload[payload + j];
+    const uint64_t* src = (payload & H_REF_RING) ? c.d.payload + (payload & ~H_REF_RING) : s.snap + payload;
+    H_FOR_WORDS(v, j) dst[j] = src[j];
     if (WG_LANE == 0) {
       size_t qi = ((size_t)node * s.L + l) * s.Q + slot;
       s.qfrom[qi] = from;
@@ -299,7 +350,7 @@ struct HandelProto {
       int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
       if (got > 0) {
         dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
-        uint32_t ref = snapshot_outgoing(c, s, l);
+        uint32_t ref = snapshot_outgoing(c, s, l, true);
         bool lf = ls->cTI[l] == size;                                           // incomingComplete :524-526
         c.send(dest, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
       }
@@ -394,7 +445,7 @@ struct HandelProto {
           uint32_t destOff = c.dest_reserve(s.p.fastPath);
           int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
           if (n > 0) {
-            uint32_t ref = snapshot_outgoing(c, s, l);
+            uint32_t ref = snapshot_outgoing(c, s, l, false);
             bool lf = ls->cTI[l] == (1 << (l - 1));
             __threadfence_block();
             c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
@@ -407,101 +458,11 @@ struct HandelProto {
   }
 };
 
-// ---- delivery kernel wrapper: same loop as k_deliver, with the node registers / LDS level mirror --
-__global__ void __launch_bounds__(256) k_deliver_handel(EngineDev d, HandelState s, int32_t t) {
-  __shared__ LevelScalars shLevels[4];
-  const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nActive = d.g->nActive;
-  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
-  for (uint32_t a = wave; a < nActive; a += nWaves) {
-    const int32_t node = (int32_t)d.active[a];
-    const uint32_t off = d.nodeOff[node], cnt = d.cntN[node];
-    for (uint32_t i = lane; i < cnt; i += 64) {
-      uint32_t e = d.inbox[off + i], rank = 0;
-      for (uint32_t j = 0; j < cnt; j++) rank += d.inbox[off + j] < e;
-      d.inbox2[off + rank] = e;
-    }
-    __threadfence_block();
-    Ctx c{d, t, node, 0, 0, 0, 0, 0};
-    HandelProto::NodeRegs r;
-    r.doneAt = d.nodes.doneAt[node];
-    r.addedCycle = s.addedCycle[node];
-    r.sigQueueSize = s.sigQueueSize[node];
-    r.msgFiltered = s.msgFiltered[node];
-    r.startAt = s.startAt[node];
-#pragma unroll
-    for (int k = 0; k < H_PEND; k++) {
-      r.pend[k] = s.pend[(size_t)node * H_PEND + k];
-      r.pendFrom[k] = s.pendFrom[(size_t)node * H_PEND + k];
-    }
-    r.ls = ls;
-    HandelProto::load_levels(s, node, ls);
-    long long nRecv = 0, bRecv = 0, nTasks = 0;
-    const bool toDown = d.nodes.down[node] != 0;
-    const uint8_t toPart = d.nodes.part[node];
-    for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t e = d.inbox2[off + k];
-      const Rec rec = d.ev[e];
-      const uint32_t kind = rec_kind(rec);
-      const int32_t from = rec_from(rec);
-      c.ev = e;
-      c.sub = 0;
-      c.draws = 0;
-      if (!toDown && d.nodes.part[from] == toPart) {
-        if (kind == K_MSG) {
-          nRecv++;
-          bRecv += HandelProto::msg_size(s, rec.w2);
-          HandelProto::on_new_sig(c, s, r, from, rec.w2, rec.w3);
-        } else {
-          nTasks++;
-          if (rec.w2 == H_TASK_DISSEMINATION)
-            HandelProto::dissemination(c, s, r);
-          else
-            HandelProto::update_verified(c, s, r, rec.w3);
-          if (kind == K_PERIODIC) c.put(O_PERIODIC, node, rec.w2, rec.w3, t + (int32_t)rec.w3, 0, false);
-        }
-      }
-      const int32_t slot = d.evChain[e];
-      if (slot >= 0 && d.evLast[e]) {
-        const int32_t next = d.evCpos[e] + 1;
-        if (next < d.chains[slot].ndest)
-          c.put(O_CHAINCONT, slot, (uint32_t)next, 0, 0, 0, false);
-        else if (lane == 0)
-          d.chains[slot].flags = 0;
-      }
-      if (lane == 0) {
-        d.evNrec[e] = c.sub;
-        d.evNdraw[e] = c.draws;
-      }
-      __threadfence_block();
-    }
-    HandelProto::store_levels(s, node, ls);
-    if (lane == 0) {
-      d.nodes.doneAt[node] = r.doneAt;
-      s.addedCycle[node] = r.addedCycle;
-      s.sigQueueSize[node] = r.sigQueueSize;
-      s.msgFiltered[node] = r.msgFiltered;
-#pragma unroll
-      for (int k = 0; k < H_PEND; k++) s.pend[(size_t)node * H_PEND + k] = r.pend[k];
-      d.nodes.msgReceived[node] += nRecv;
-      d.nodes.bytesReceived[node] += bRecv;
-      d.nodes.msgSent[node] += c.msgSent;
-      d.nodes.bytesSent[node] += c.bytesSent;
-      d.cntN[node] = 0;
-      d.fillN[node] = 0;
-      if (nRecv) atomicAdd(&d.g->delivered, (unsigned long long)nRecv);
-      if (nTasks) atomicAdd(&d.g->tasks, (unsigned long long)nTasks);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
 // ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
 // A1: eligibility + bestToVerify for every level (:570-634): curates the lists, records the candidates.
-__global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState s, int32_t t, int32_t until) {
+__global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState s) {
   __shared__ LevelScalars shLevels[4];
+  const int32_t t = d.g->now, until = d.g->until;
   const int lane = WG_LANE;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
@@ -621,84 +582,95 @@ __global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState
   }
 }
 
-// scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate)
+// scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate),
+// and the draw itself — chooseBestFromLevels: rd.nextInt(byLevels.size()) (:788-790) — by jump-ahead
+// assuming no earlier nextInt(bound) rejection; a rejection anywhere is flagged and re-walked in A2.
 struct CondF {
   EngineDev d;
   HandelState s;
   __device__ uint32_t count() const { return (uint32_t)s.N; }
   __device__ uint64_t value(uint32_t i) const { return s.candCnt[i] > 0; }
+  __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
     d.g->nOut = (uint32_t)tot;  // one registerTask per drawing node
     d.g->nDraws = (uint32_t)tot;
   }
-  __device__ void write(uint32_t i, uint64_t excl) const {
-    s.condOrd[i] = (uint32_t)excl;
-    if (s.candCnt[i] > 0) s.condList[(uint32_t)excl] = i;
+  __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
+    if (!valid || s.candCnt[i] == 0) return;
+    s.condList[(uint32_t)excl] = i;
+    uint64_t st = lcg_skip(d.g->rng, excl);
+    int consumed;
+    s.drawVal[i] = lcg_next_int_bounded(st, (int32_t)s.candCnt[i], &consumed);
+    if (consumed != 1) d.g->rejectSeen = 1;
   }
 };
 
-// chooseBestFromLevels: rd.nextInt(byLevels.size()) (:788-790). Value by jump-ahead assuming no
-// earlier nextInt(bound) rejection; a rejection anywhere triggers the serial re-walk below.
-__global__ void __launch_bounds__(256) k_handel_cond_draw(EngineDev d, HandelState s) {
-  const uint32_t n = d.g->nOut;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const uint32_t node = s.condList[j];
-    uint64_t st = lcg_skip(d.g->rng, j);
-    int consumed;
-    s.drawVal[node] = lcg_next_int_bounded(st, (int32_t)s.candCnt[node], &consumed);
-    if (consumed != 1) d.g->rejectSeen = 1;
-  }
-}
-__global__ void k_handel_cond_fix(EngineDev d, HandelState s) {
-  if (!d.g->rejectSeen) return;
-  const uint32_t n = d.g->nOut;
-  uint64_t st = d.g->rng;
-  uint32_t total = 0;
-  for (uint32_t j = 0; j < n; j++) {
-    const uint32_t node = s.condList[j];
-    int consumed;
-    s.drawVal[node] = lcg_next_int_bounded(st, (int32_t)s.candCnt[node], &consumed);
-    total += (uint32_t)consumed;
-  }
-  d.g->nDraws = total;
-}
-
 // A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
-__global__ void __launch_bounds__(256) k_handel_cond_a2(EngineDev d, HandelState s, int32_t t) {
+__global__ void __launch_bounds__(256) k_handel_cond_a2(EngineDev d, HandelState s) {
   const uint32_t n = d.g->nOut;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int32_t node = (int32_t)s.condList[j];
-    const int k = s.drawVal[node];
-    const int l = s.candLevel[(size_t)node * s.L + k];
-    const int slot = s.candSlot[(size_t)node * s.L + k];
-    const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
-    // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
-    int w = s.window[node] * 2;
-    if (w > s.p.windowMaximum) w = s.p.windowMaximum;
-    if (w < s.p.windowMinimum) w = s.p.windowMinimum;
-    s.window[node] = min(w, 1 << (l - 1));
-    // receptionRanks[best.from] += nodeCount, saturating (:825-828)
-    int32_t* rk = s.ranks + (size_t)node * s.N + from;
-    int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
-    *rk = nr < 0 ? INT32_MAX : nr;
-    s.sigsChecked[node]++;
-    int pe = -1;
-    for (int q = 0; q < H_PEND; q++)
-      if (!(s.pend[(size_t)node * H_PEND + q] & 0x80000000u)) {
-        pe = q;
-        break;
+  const int32_t t = d.g->now;
+  const bool rejected = d.g->rejectSeen != 0;
+  const uint32_t D = (uint32_t)d.horizon;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+    const uint32_t j = j0 + threadIdx.x;
+    uint32_t histKey = 0xFFFFFFFFu;
+    if (j < n) {
+      const int32_t node = (int32_t)s.condList[j];
+      int k = s.drawVal[node];
+      if (rejected) {  // a nextInt(bound) rejection shifted the stream: walk it serially up to this draw (rare)
+        uint64_t st = d.g->rng;
+        uint32_t total = 0;
+        for (uint32_t q = 0; q <= j; q++) {
+          int consumed;
+          k = lcg_next_int_bounded(st, (int32_t)s.candCnt[s.condList[q]], &consumed);
+          total += (uint32_t)consumed;
+        }
+        if (j + 1 == n) d.g->nDraws = total;
       }
-    if (pe < 0) {
-      set_err(d.g, ERR_PENDING);
-      pe = 0;
+      const int l = s.candLevel[(size_t)node * s.L + k];
+      const int slot = s.candSlot[(size_t)node * s.L + k];
+      const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
+      // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
+      int w = s.window[node] * 2;
+      if (w > s.p.windowMaximum) w = s.p.windowMaximum;
+      if (w < s.p.windowMinimum) w = s.p.windowMinimum;
+      s.window[node] = min(w, 1 << (l - 1));
+      // receptionRanks[best.from] += nodeCount, saturating (:825-828)
+      int32_t* rk = s.ranks + (size_t)node * s.N + from;
+      int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
+      *rk = nr < 0 ? INT32_MAX : nr;
+      s.sigsChecked[node]++;
+      int pe = -1;
+      for (int q = 0; q < H_PEND; q++)
+        if (!(s.pend[(size_t)node * H_PEND + q] & 0x80000000u)) {
+          pe = q;
+          break;
+        }
+      if (pe < 0) {
+        set_err(d.g, ERR_PENDING);
+        pe = 0;
+      }
+      s.pend[(size_t)node * H_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
+      s.pendFrom[(size_t)node * H_PEND + pe] = from;
+      // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
+      const int32_t arrival = t + s.pairing[node];
+      d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
+      const bool ok = arrival - t < d.horizon;
+      d.arr[j] = ok ? arrival : -1;
+      if (!ok) set_err(d.g, ERR_HORIZON);
+      if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
     }
-    s.pend[(size_t)node * H_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
-    s.pendFrom[(size_t)node * H_PEND + pe] = from;
-    // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
-    const int32_t arrival = t + s.pairing[node];
-    d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
-    d.arr[j] = (arrival - t >= d.horizon) ? -1 : arrival;
-    if (arrival - t >= d.horizon) set_err(d.g, ERR_HORIZON);
+    // per-tile arrival histogram of the multisplit; pairing times are nearly uniform, so aggregate equal
+    // keys inside the wavefront before touching memory
+    uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);
+    while (todo) {
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const uint32_t key = __shfl(histKey, leader, 64);
+      const uint64_t m = __ballot(histKey == key) & todo;
+      if ((int)WG_LANE == leader) atomicAdd(&d.tileHist[key], (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
   }
 }
 
