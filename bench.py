@@ -3,17 +3,18 @@
 
 Workload (BASELINE.json metric): Handel aggregation, 32 768 nodes, 10 % dead,
 threshold 0.99 of the live nodes, pairing 4 ms, levelWait 50 ms, period 20 ms, fastPath 10, node builder
-RANDOM/constant speed, NetworkLatencyByDistanceWJitter, run as the reference's RunMultipleTimes loop does
-(runMs(10) while Handel.newContIf, C/RunMultipleTimes.java:50-64).
+RANDOM/constant speed, NetworkLatencyByDistanceWJitter, run exactly as the reference runs simulations:
+C/RunMultipleTimes.java:44-64 — for each of runCount copies rd.setSeed(i); init(); runMs(10) while
+Handel.newContIf holds.
 
-A "step" is ONE complete simulation (seed i, as rd.setSeed(i) of C/RunMultipleTimes.java:47) from the
-state Protocol.init() leaves to the stop predicate. init() is host work outside the hot path and is done
-for all steps before the timed region (the engines sit in HBM: ~17 GB each at 32 768 nodes). Delivered
-messages = sum of Node.msgReceived increments (C/Network.java:607-613), simulated ms = network.time.
+A "step" is ONE RunMultipleTimes pass over R = --replicas independent 32 768-node simulations (seeds
+distinct), advanced in lock-step by a wg_batch (one launch sequence per simulated ms for all R, each copy
+stopping at its own predicate). init() is host work outside the hot path: every copy of every step is
+initialised before the timed region and sits resident in HBM (~15 GB per copy). Delivered messages = sum
+of Node.msgReceived increments (C/Network.java:607-613), simulated ms = sum over copies of network.time.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): the path's natural parallelism is independent
-simulations (RunMultipleTimes seeds), so every rank runs its own K simulations (seeds disjoint across
-ranks), no data-path collective, "scaling": "weak".
+Multi-GPU (--gpus N, launched by torch.distributed.run): the copies shard across ranks with no data-path
+collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak".
 
 One JSON line on stdout (rank 0). Everything else goes to stderr.
 """
@@ -22,6 +23,7 @@ import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -59,18 +61,11 @@ def make_sim(w, n, seed, device):
     return g
 
 
-def run_sim(g, chunk=10, max_ms=20000):
-    """RunMultipleTimes inner loop (C/RunMultipleTimes.java:50-64). returns (delivered, simulated_ms, device_wall_ns)"""
-    net = g.network()
-    delivered = ms = wall = launches = 0
-    while g.cont_if() and ms < max_ms:
-        net.runMs(chunk)
-        st = net.last_stats
-        delivered += st["delivered"]
-        wall += st["wall_ns"]
-        ms += chunk
-        launches += chunk + 1
-    return delivered, ms, wall
+def make_batch(w, n, seeds, device, threads):
+    """Protocol.copy() + rd.setSeed(i) + init() for every copy (host work; ctypes releases the GIL)."""
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        sims = list(ex.map(lambda s: make_sim(w, n, s, device), seeds))
+    return sims, w.Batch([g.network() for g in sims])
 
 
 def cpu_baseline(n_sample):
@@ -95,12 +90,13 @@ def cpu_baseline(n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
+    ap.add_argument("--replicas", type=int, default=8, help="independent simulations per step and per GPU")
+    ap.add_argument("--init-threads", type=int, default=4)
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -126,30 +122,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    K, W, n = args.steps, args.warmup, args.nodes
+    K, W, n, R = args.steps, args.warmup, args.nodes, args.replicas
+    # host init() of one copy holds ~3 N^2 int32 (ranks, their transpose, emission lists): cap the init
+    # threads by the host memory actually available
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+        per = 3.5 * 4 * n * n + (1 << 30)
+        args.init_threads = max(1, min(args.init_threads, int(0.6 * avail / per)))
+    except Exception:
+        pass
+    seed0 = rank * (K + W) * R
+    prof_phase = None
+    # ---- warmup steps: same shape as a timed step; every phase is bracketed with HIP events here so the
+    # phase breakdown costs the timed region nothing. Freed before the timed copies are initialised.
     t_init = time.perf_counter()
-    sims = [make_sim(w, n, rank * (K + W) + i, local) for i in range(K + W)]
-    init_s = (time.perf_counter() - t_init) / max(1, K + W)
-    log("[rank %d] init(): %.1f s per simulation (host, outside the timed region)" % (rank, init_s))
+    inits = 0
+    for i in range(W):
+        sims, batch = make_batch(w, n, range(seed0 + i * R, seed0 + (i + 1) * R), local, args.init_threads)
+        inits += R
+        sims[0].network().profile(1)
+        batch.run_multiple_times(chunk=10, max_ms=20000)
+        prof_phase = sims[0].network().profile_read()
+        del batch, sims
+    timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads)
+             for i in range(K)]
+    inits += K * R
+    init_s = (time.perf_counter() - t_init) / max(1, inits)
+    log("[rank %d] init(): %.1f s per simulation amortised over %d host threads (outside the timed region)"
+        % (rank, init_s, args.init_threads))
+    for sims, _ in timed:
+        sims[0].network().profile(2)  # HIP events around the delivery kernel only, inside the timed region
 
-    for g in sims[:W]:
-        run_sim(g)
     barrier()
     t0 = time.perf_counter()
     delivered = sim_ms = 0
-    by_level = None
-    for g in sims[W:]:
-        d, ms, _ = run_sim(g)
-        delivered += d
-        sim_ms += ms
-        bl = g.network().delivered_by_level()
-        by_level = bl if by_level is None else by_level + bl
+    for sims, batch in timed:
+        d, ms = batch.run_multiple_times(chunk=10, max_ms=20000)
+        delivered += sum(d)
+        sim_ms += sum(ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    for g in sims[W:]:
-        assert not g.cont_if()
-    check = int(sims[-1].network().read("msgReceived").sum())
-    del sims
+
+    by_level = None
+    dk_spans = dk_ns = 0
+    for sims, batch in timed:
+        assert not any(batch.cont_if())
+        pr = sims[0].network().profile_read()["deliver"]
+        dk_spans += pr["spans"]
+        dk_ns += pr["total_ns"]
+        for g in sims:
+            bl = g.network().delivered_by_level()
+            by_level = bl if by_level is None else by_level + bl
+    check = int(sum(int(g.network().read("msgReceived").sum()) for g in timed[-1][0]))
+    del timed
 
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -170,38 +195,37 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "simulated_ms_per_s": sim_ms / elapsed,
         "config": {"workload": "Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, "
-                               "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; runMs(10) until "
-                               "Handel.newContIf is false; one simulation per step, seeds 0..K-1 per rank" % n,
-                   "nodes": n, "simulations_per_rank": K, "parallelism": "independent simulations (replicas) per GPU",
-                   "delivered_per_step": delivered // max(1, K * world), "init_s_per_simulation": init_s},
+                               "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
+                               "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
+                               "copy's Handel.newContIf is false" % (n, R),
+                   "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch",
+                   "delivered_per_simulation": delivered // max(1, K * R * world),
+                   "init_s_per_simulation": init_s},
     }
-
-    # ---- roofline of the dominant kernel: HIP events on the engine's stream around every kernel of the
-    # per-ms pipeline, over one more simulation of seed 0 (same launches as timed step 0).
-    if not args.no_profile:
-        g = make_sim(w, n, 0, local)
-        g.network().profile(True)
-        d, ms, _ = run_sim(g)
-        prof = g.network().profile_read()
-        bl = g.network().delivered_by_level()
-        del g
-        alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(bl)))
-        dk = prof["deliver"]
-        per_launch_bytes = alg_bytes / max(1, dk["spans"])
-        avg_ns = dk["total_ns"] / max(1, dk["spans"])
-        achieved = per_launch_bytes / avg_ns  # bytes/ns == GB/s
-        total_ns = sum(v["total_ns"] for v in prof.values())
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_deliver_handel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0,
-            "launches": dk["spans"], "bytes_per_delivered_message": alg_bytes / max(1, d),
-            "whole_pipeline_achieved_GBs": alg_bytes / total_ns,
-            "phase_device_ms": {k: round(v["total_ns"] / 1e6, 3) for k, v in prof.items()},
-        }
+    # ---- roofline of the dominant kernel (k_deliver<HandelProto>): algorithmic bytes of everything delivered
+    # in the timed region / its launches, over its average duration measured with HIP events in the timed region
+    alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
+    per_launch_bytes = alg_bytes / max(1, dk_spans)
+    avg_ns = dk_ns / max(1, dk_spans)
+    achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the rocprofv3 PMC passes
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("replicas") == R and tj.get("nodes") == n:
+            traffic = tj.get("hbm_bytes_per_launch")
+    out["roofline"] = {
+        "bound": "hbm", "kernel": "k_deliver<HandelProto>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
+        "bytes_per_delivered_message": alg_bytes / max(1, delivered if world == 1 else int(by_level.sum())),
+        "whole_run_achieved_GBs": alg_bytes / (elapsed * 1e9),
+    }
+    if prof_phase:
+        out["roofline"]["warmup_phase_device_ms"] = {k: round(v["total_ns"] / 1e6, 3) for k, v in prof_phase.items()}
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes)
-    log("msgReceived sum of the last simulation: %d" % check)
+    log("msgReceived sum of the last step's copies: %d" % check)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -134,6 +134,22 @@ int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt
  * evaluated on the device: Handel.newContIf (P/Handel.java:1044-1053). *cont = 1 while the run must go on. */
 int32_t wg_protocol_cont_if(wg_engine* e, int32_t* cont);
 
+/* ---- batches: RunMultipleTimes on the device ------------------------------------------------ */
+/* The reference's way to run many simulations is C/RunMultipleTimes.java:44-64: for each of runCount
+ * copies, rd.setSeed(i); init(); runMs(10) while the continuation predicate holds. A wg_batch advances n
+ * such independent engines in lock-step with ONE launch sequence per simulated ms (gridDim.y = member),
+ * which is how a 288 GB MI355X is kept busy by a latency-bound event loop. Members must share device,
+ * resident protocol, node count and horizon_ms; each keeps its own state, rd stream and clock, and every
+ * per-engine call (wg_read_*, wg_time, ...) stays valid. The batch does not own its members. */
+typedef struct wg_batch wg_batch;
+int32_t wg_batch_create(wg_engine** engines, int32_t n, wg_batch** out);
+void wg_batch_destroy(wg_batch* b);
+const char* wg_batch_last_error(wg_batch* b);       /* b may be NULL: error of a failed wg_batch_create */
+/* Network.runMs(ms) on every member with active[i] != 0 (NULL = all); the others are not advanced
+ * (a copy whose predicate turned false stops, C/RunMultipleTimes.java:56-61). didSomething / stats: [n] or NULL. */
+int32_t wg_batch_run_ms(wg_batch* b, int32_t ms, const uint8_t* active, uint8_t* didSomething, wg_run_stats* stats);
+int32_t wg_batch_cont_if(wg_batch* b, int32_t* cont); /* wg_protocol_cont_if for every member, one launch; cont[n] */
+
 /* ---- read-back -------------------------------------------------------------------------- */
 typedef enum {
   /* Node counters (C/Node.java:69-79) */
@@ -168,7 +184,9 @@ typedef struct {
   int64_t spans;      /* bracketed launches (groups) since the engine was created */
   double total_ns;    /* summed device time of those spans */
 } wg_profile_entry;
-int32_t wg_profile_enable(wg_engine* e, int32_t on);
+/* mode 0 = off, 1 = every phase, 2 = the delivery kernel only (cheap enough to leave on in a timed run).
+ * Resets the accumulated spans. In a batch the spans are recorded on the first member. */
+int32_t wg_profile_enable(wg_engine* e, int32_t mode);
 int32_t wg_profile_read(wg_engine* e, wg_profile_entry* dst, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus

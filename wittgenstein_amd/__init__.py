@@ -3,9 +3,9 @@
 The compute path is libwittgpu.so (hand-written HIP for gfx950, C ABI in include/wittgpu.h); this
 package is the thin host-side mirror of the reference's Java surface used by tests and bench.py.
 """
-from .core import (EngineCapacityError, HipError, IllegalArgumentException, IllegalStateException, Network,
+from .core import (Batch, EngineCapacityError, HipError, IllegalArgumentException, IllegalStateException, Network,
                    UnsupportedError)
 from .protocols import Handel, HandelParameters, PingPong, PingPongParameters
 
-__all__ = ["Network", "PingPong", "PingPongParameters", "Handel", "HandelParameters", "IllegalArgumentException",
+__all__ = ["Network", "Batch", "PingPong", "PingPongParameters", "Handel", "HandelParameters", "IllegalArgumentException",
            "IllegalStateException", "EngineCapacityError", "HipError", "UnsupportedError"]

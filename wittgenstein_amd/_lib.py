@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
-    "wg_protocol_cont_if", "wg_profile_enable", "wg_profile_read",
+    "wg_protocol_cont_if", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
+    "wg_batch_run_ms", "wg_batch_cont_if", "wg_profile_enable", "wg_profile_read",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",
 ]
@@ -62,5 +63,9 @@ def lib():
         l.wgh_last_init_seconds.restype = C.c_double
         l.wg_destroy.restype = None
         l.wg_destroy.argtypes = [C.c_void_p]
+        l.wg_batch_last_error.restype = C.c_char_p
+        l.wg_batch_last_error.argtypes = [C.c_void_p]
+        l.wg_batch_destroy.restype = None
+        l.wg_batch_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib

@@ -214,9 +214,10 @@ class Network:
         self._ck(L.lib().wg_delivered_by_level(self._h, _p(out, C.c_int64)))
         return out
 
-    def profile(self, on=True):
-        """bracket every kernel (group) of the per-ms pipeline with HIP events on the engine's stream"""
-        self._ck(L.lib().wg_profile_enable(self._h, int(bool(on))))
+    def profile(self, mode=1):
+        """HIP events on the engine's stream around the kernels of the per-ms pipeline: 0 off, 1 every phase,
+        2 the delivery kernel only. Resets the accumulated spans."""
+        self._ck(L.lib().wg_profile_enable(self._h, int(mode)))
 
     def profile_read(self):
         arr = (L.wg_profile_entry * 16)()
@@ -232,3 +233,64 @@ class Network:
         self._ck(L.lib().wg_latency_probe(self._h, len(frm), _p(frm, C.c_int32), _p(to, C.c_int32),
                                           _p(delta, C.c_int32), _p(out, C.c_int32)))
         return out
+
+
+class Batch:
+    """A batch of independent simulations advanced in lock-step on one MI355X (wg_batch_*): the device
+    form of RunMultipleTimes' loop over copies (C/RunMultipleTimes.java:44-64)."""
+
+    def __init__(self, networks):
+        self.networks = list(networks)
+        n = len(self.networks)
+        arr = (C.c_void_p * n)(*[net._h for net in self.networks])
+        h = C.c_void_p()
+        rc = L.lib().wg_batch_create(arr, n, C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wg_batch_last_error(None).decode())
+        self._h = h
+        self.last_stats = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().wg_batch_destroy(h)
+
+    def _ck(self, rc):
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wg_batch_last_error(self._h).decode())
+
+    def runMs(self, ms, active=None):
+        """Network.runMs(ms) on every member with active[i] (None = all); returns didSomething per member."""
+        n = len(self.networks)
+        did = (C.c_uint8 * n)()
+        st = (L.wg_run_stats * n)()
+        act = None if active is None else (C.c_uint8 * n)(*[1 if a else 0 for a in active])
+        self._ck(L.lib().wg_batch_run_ms(self._h, int(ms), act, did, st))
+        self.last_stats = [{f: getattr(st[i], f) for f, _ in L.wg_run_stats._fields_} for i in range(n)]
+        for net, s in zip(self.networks, self.last_stats):
+            net.last_stats = s
+        return [bool(d) for d in did]
+
+    def cont_if(self):
+        n = len(self.networks)
+        out = (C.c_int32 * n)()
+        self._ck(L.lib().wg_batch_cont_if(self._h, out))
+        return [bool(v) for v in out]
+
+    def run_multiple_times(self, chunk=10, max_ms=None):
+        """RunMultipleTimes.run's inner loop for all members: runMs(chunk) while a member's continuation
+        predicate holds; a member whose predicate turned false is no longer advanced. Returns per-member
+        (delivered, simulated_ms)."""
+        n = len(self.networks)
+        delivered, sim_ms = [0] * n, [0] * n
+        active = self.cont_if()
+        while any(active):
+            self.runMs(chunk, active)
+            for i in range(n):
+                if active[i]:
+                    delivered[i] += self.last_stats[i]["delivered"]
+                    sim_ms[i] += chunk
+            active = self.cont_if()
+            if max_ms is not None:
+                active = [a and sim_ms[i] < max_ms for i, a in enumerate(active)]
+        return delivered, sim_ms

@@ -13,6 +13,7 @@ static thread_local std::string g_createError;
 #define WG_TRY(h)                       \
   if (!(h)) return WG_EINVAL;           \
   Engine& E = *(h)->e;                  \
+  (void)hipSetDevice(E.cfg.device);     \
   try {
 #define WG_END                          \
   }                                     \
@@ -172,8 +173,63 @@ int32_t wg_protocol_cont_if(wg_engine* h, int32_t* cont) {
     throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
   WG_END
 }
+// ---- batches (RunMultipleTimes on the device)
+struct wg_batch {
+  Batch* b;
+};
+static thread_local std::string g_batchError;
+#define WGB_TRY try {
+#define WGB_END(h)                                       \
+  }                                                      \
+  catch (const WgError& x) {                             \
+    ((h) ? (h)->b->lastError : g_batchError) = x.what(); \
+    return x.code;                                       \
+  }                                                      \
+  catch (const std::exception& x) {                      \
+    ((h) ? (h)->b->lastError : g_batchError) = x.what(); \
+    return WG_ESTATE;                                    \
+  }                                                      \
+  return WG_OK;
+
+int32_t wg_batch_create(wg_engine** engines, int32_t n, wg_batch** out) {
+  if (!out) return WG_EINVAL;
+  *out = nullptr;
+  wg_batch* none = nullptr;
+  WGB_TRY
+  if (!engines || n <= 0) throw WgError(WG_EINVAL, "empty batch");
+  std::vector<Engine*> es;
+  for (int i = 0; i < n; i++) {
+    if (!engines[i]) throw WgError(WG_EINVAL, "NULL engine in batch");
+    es.push_back(engines[i]->e);
+  }
+  *out = new wg_batch{new Batch(es.data(), n)};
+  WGB_END(none)
+}
+void wg_batch_destroy(wg_batch* b) {
+  if (!b) return;
+  delete b->b;
+  delete b;
+}
+const char* wg_batch_last_error(wg_batch* b) { return b ? b->b->lastError.c_str() : g_batchError.c_str(); }
+int32_t wg_batch_run_ms(wg_batch* b, int32_t ms, const uint8_t* active, uint8_t* didSomething, wg_run_stats* stats) {
+  if (!b) return WG_EINVAL;
+  WGB_TRY b->b->run_ms(ms, active, didSomething, stats);
+  WGB_END(b)
+}
+int32_t wg_batch_cont_if(wg_batch* b, int32_t* cont) {
+  if (!b || !cont) return WG_EINVAL;
+  WGB_TRY b->b->cont_if(cont);
+  WGB_END(b)
+}
+
 int32_t wg_profile_enable(wg_engine* h, int32_t on) {
-  WG_TRY(h) E.profiling = on != 0;
+  WG_TRY(h)
+  if (on < 0 || on > 2) throw WgError(WG_EINVAL, "mode");
+  E.profiling = on;
+  for (int c = 0; c < Engine::PC_COUNT; c++) {
+    E.profNs[c] = 0;
+    E.profLaunches[c] = 0;
+  }
   WG_END
 }
 int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_t* n) {

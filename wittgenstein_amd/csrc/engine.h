@@ -155,6 +155,8 @@ struct NodeArrays {
 
 // Everything a kernel needs, passed by value.
 struct EngineDev {
+  uint32_t halted;          // batch member that is not advanced by the current run (RunMultipleTimes: its
+                            // continuation predicate turned false); every kernel returns at once for it
   Globals* g;
   NodeArrays nodes;
   LatencyModel lat;

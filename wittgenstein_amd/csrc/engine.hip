@@ -40,9 +40,12 @@ struct PingPongHost : ProtoHost {
     e.dev.boundMsg = 1;  // a delivered Ping emits one Pong
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
   }
-  void launch_deliver(Engine& e) override {
-    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512), dim3(256), 0, e.stream, e.dev, st);
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512, g.R), dim3(256), 0, g.stream, g.tab,
+                       (const PingPongProto::State*)g.stab);
   }
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
   bool read_i64(Engine& e, int32_t field, int64_t* dst, int32_t n) override {
     if (field != WG_F_PONG) return false;
     std::vector<int32_t> h(n);
@@ -413,7 +416,8 @@ void Engine::latency_probe(int32_t n, const int32_t* from, const int32_t* to, co
   WG_HIP(hipMemcpy(df, from, 4 * n, hipMemcpyHostToDevice));
   WG_HIP(hipMemcpy(dt, to, 4 * n, hipMemcpyHostToDevice));
   WG_HIP(hipMemcpy(dd, delta, 4 * n, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_latency_probe, dim3((n + 255) / 256), dim3(256), 0, stream, dev, n, df, dt, dd, dout);
+  Group g = self();
+  hipLaunchKernelGGL(k_latency_probe, dim3((n + 255) / 256), dim3(256), 0, stream, g.tab, n, df, dt, dd, dout);
   WG_HIP(hipStreamSynchronize(stream));
   WG_HIP(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
   (void)hipFree(df);
@@ -495,24 +499,56 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 }
 
 template <class F>
-void Engine::scan(const F& f) {
-  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID), dim3(SCAN_BLOCK), 0, stream, f, dev.scanPartials);
-  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID), dim3(SCAN_BLOCK), 0, stream, f, dev.scanPartials);
+void Engine::scan(const Group& g, const typename F::Aux* atab) {
+  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
-template void Engine::scan<ExpandF>(const ExpandF&);
-template void Engine::scan<RecsF>(const RecsF&);
+template void Engine::scan<ExpandF>(const Group&, const int*);
+template void Engine::scan<RecsF>(const Group&, const int*);
 
 // multisplit of the ordered outbox (fin/arr, g->nOut) into the buckets. The per-tile histograms are
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
-void Engine::append_phase(bool needHist) {
-  size_t lds = sizeof(uint32_t) * (size_t)dev.horizon;
-  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(256), dim3(TILE), lds, stream, dev, binBits);
-  hipLaunchKernelGGL(k_col_reserve, dim3(1), dim3(1024), 0, stream, dev);
-  hipLaunchKernelGGL(k_scatter, dim3(256), dim3(TILE), lds, stream, dev, binBits);
+void Engine::append_phase(const Group& g, bool needHist) {
+  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(256, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
+  hipLaunchKernelGGL(k_scatter, dim3(256, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
 }
-void Engine::end_phase(bool drained) {
-  hipLaunchKernelGGL(k_end_phase, dim3(1), dim3(256), 0, stream, dev, drained ? 1 : 0);
+void Engine::end_phase(const Group& g, bool drained) {
+  hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
+}
+
+Group Engine::self() {
+  ensure_device();
+  dev.halted = 0;
+  bool sync = false;
+  if (!dTab || memcmp(&tabShadow, &dev, sizeof(EngineDev)) != 0) {
+    if (!dTab) dTab = dalloc<EngineDev>(1);
+    WG_HIP(hipMemcpyAsync(dTab, &dev, sizeof(EngineDev), hipMemcpyHostToDevice, stream));
+    tabShadow = dev;
+    sync = true;
+  }
+  if (proto) {
+    const size_t sz = proto->state_size();
+    if (!dStab || stabShadow.size() != sz || memcmp(stabShadow.data(), proto->state_host(), sz) != 0) {
+      if (!dStab) {
+        WG_HIP(hipMalloc(&dStab, sz));
+        allocs.push_back(dStab);
+      }
+      WG_HIP(hipMemcpyAsync(dStab, proto->state_host(), sz, hipMemcpyHostToDevice, stream));
+      stabShadow.assign((const char*)proto->state_host(), (const char*)proto->state_host() + sz);
+      sync = true;
+    }
+  }
+  if (sync) WG_HIP(hipStreamSynchronize(stream));
+  Group g;
+  g.tab = dTab;
+  g.stab = dStab;
+  g.R = 1;
+  g.stream = stream;
+  g.binBits = binBits;
+  g.histLds = sizeof(uint32_t) * (size_t)dev.horizon;
+  return g;
 }
 
 __global__ void k_apply_sent(NodeArrays nd, int n, const int32_t* node, const long long* msgs, const long long* bytes) {
@@ -582,7 +618,7 @@ void Engine::flush_staged(int32_t t, bool inRun) {
     WG_HIP(hipMemcpyAsync(dev.fin, recs.data(), sizeof(Rec) * n, hipMemcpyHostToDevice, stream));
     WG_HIP(hipMemcpyAsync(dev.arr, arr.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, (uint32_t)n);
-    append_phase(true);
+    append_phase(self(), true);
     hipLaunchKernelGGL(k_set_nout, dim3(1), dim3(1), 0, stream, dev.g, 0u);
     WG_HIP(hipStreamSynchronize(stream));
     done += n;
@@ -641,7 +677,7 @@ void Engine::load_protocol(int32_t id, const void* params, const void* initState
 }
 
 // Network.runMs (C/Network.java:318-338) + receiveUntil/nextMessage as a time-stepped loop.
-void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
+void Engine::begin_run(int32_t ms, int32_t* endAtOut) {
   if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
   if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
   int32_t endAt = (int32_t)((uint32_t)time + (uint32_t)ms);
@@ -649,79 +685,219 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   ensure_device();
   flush_staged(time, false);
   // (time == 0: Node.start() on non-down nodes only re-asserts down == false, :323-329)
-  Globals before = gh;
   gh.epoch++;  // a new receiveUntil() starts with a fresh nextMessage() call
   gh.anyEvent = 0;
   gh.now = time;
   gh.until = endAt;
   globalsDirty = true;
   sync_globals_to_device();
+  *endAtOut = endAt;
+}
+
+void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
+  if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
+  if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
+  Engine* me = this;
+  Group g = self();
+  run_group(&me, 1, nullptr, g, ms, didSomething, stats);
+}
+
+// One simulated ms = drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the
+// new `now` (:543-566). runMs(ms) is ms + 1 of those: the first drain re-visits the current ms
+// (envelopes the host registered for it), the last conditional phase is the edge to until + 1, which
+// still runs tasks whose minStartTime <= until. Kernels read `now` from device globals,
+// so the launch sequence does not depend on the time and serves every member of the group at once.
+void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g, int32_t ms, uint8_t* did,
+                       wg_run_stats* stats) {
+  Engine& lead = *es[0];
+  std::vector<Globals> before(R);
+  std::vector<int32_t> endAt(R, 0);
+  std::vector<uint8_t> on(R, 1);
+  for (int r = 0; r < R; r++) {
+    on[r] = !active || active[r];
+    if (on[r]) {
+      before[r] = es[r]->gh;  // statistics deltas are taken against the state before begin_run
+      es[r]->begin_run(ms, &endAt[r]);
+    }
+  }
   auto t0 = std::chrono::steady_clock::now();
+  ProtoHost* proto = lead.proto;
   const bool cond = proto->has_cond();
-  // One simulated ms = drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the
-  // new `now` (:543-566). runMs(ms) is ms + 1 of those: the first drain re-visits the current ms
-  // (envelopes the host registered for it), the last conditional phase is the edge to until + 1, which
-  // still runs tasks whose minStartTime <= until. Kernels read `now` from device globals.
-  for (int32_t t = time; t <= endAt; t++) {
+  for (int32_t k = 0; k <= ms; k++) {
+    // Host-held envelopes beyond the bucket ring come into range as `now` advances (arrival - t <
+    // horizon). They must precede every device push into their bucket: drain(t - 1) reaches at most
+    // t + horizon - 2 and the conditional-task phase of the edge to t is held to the same bound
+    // (ERR_HORIZON at horizon - 1), so injecting before drain(t) keeps the bucket's push order.
+    if (k > 0)
+      for (int r = 0; r < R; r++) {
+        Engine& e = *es[r];
+        const int32_t t = e.time + k;
+        if (on[r] && e.stagedMin - t < e.dev.horizon) {
+          WG_HIP(hipStreamSynchronize(g.stream));
+          e.flush_staged(t, true);
+        }
+      }
     {
-      ProfScope ps(*this, PC_EXPAND);
-      scan(ExpandF{dev});
+      ProfScope ps(lead, PC_EXPAND);
+      scan<ExpandF>(g, nullptr);
     }
     {
-      ProfScope ps(*this, PC_DELIVER);
-      proto->launch_deliver(*this);
+      ProfScope ps(lead, PC_DELIVER);
+      proto->launch_deliver(g);
     }
     {
-      ProfScope ps(*this, PC_ORDER);
-      scan(RecsF{dev});
+      ProfScope ps(lead, PC_ORDER);
+      scan<RecsF>(g, nullptr);
     }
     {
-      ProfScope ps(*this, PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(512), dim3(256), 0, stream, dev);
+      ProfScope ps(lead, PC_RESOLVE);
+      hipLaunchKernelGGL(k_resolve, dim3(512, g.R), dim3(256), 0, g.stream, g.tab);
     }
     {
-      ProfScope ps(*this, PC_APPEND);
-      append_phase(false);
+      ProfScope ps(lead, PC_APPEND);
+      append_phase(g, false);
     }
     {
-      ProfScope ps(*this, PC_END);
-      end_phase(true);
-    }
-    // host-held envelopes beyond the bucket ring come into range as `now` advances; they go in before
-    // any device push of the new ms can target the same bucket (push order inside the bucket unchanged)
-    if (stagedMin - (t + 1) < dev.horizon) {
-      WG_HIP(hipStreamSynchronize(stream));
-      flush_staged(t + 1, true);
+      ProfScope ps(lead, PC_END);
+      end_phase(g, true);
     }
     if (cond) {
-      proto->launch_cond(*this);
+      proto->launch_cond(lead, g);
       {
-        ProfScope ps(*this, PC_APPEND);
-        append_phase(false);
+        ProfScope ps(lead, PC_APPEND);
+        append_phase(g, false);
       }
-      ProfScope ps(*this, PC_END);
-      end_phase(false);
+      ProfScope ps(lead, PC_END);
+      end_phase(g, false);
     }
   }
-  WG_HIP(hipStreamSynchronize(stream));
+  WG_HIP(hipStreamSynchronize(g.stream));
   auto t1 = std::chrono::steady_clock::now();
-  if (profiling) prof_collect();
-  sync_globals_to_host();
-  time = endAt;
-  if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;
-  if (stats) {
-    stats->delivered = (int64_t)(gh.delivered - before.delivered);
-    stats->tasks = (int64_t)(gh.tasks - before.tasks);
-    stats->events = (int64_t)(gh.events - before.events);
-    stats->draws = (int64_t)(gh.draws - before.draws);
-    stats->simulated_ms = ms;
-    stats->wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-    int64_t pb = 0;
-    for (int l = 0; l < 32; l++)
-      pb += (int64_t)(gh.deliveredByLevel[l] - before.deliveredByLevel[l]) * proto->payload_bytes_of_level(l);
-    stats->payload_bytes = pb;
+  if (lead.profiling) lead.prof_collect();
+  const int64_t wall = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+  std::string firstErr;
+  int32_t firstCode = WG_OK;
+  for (int r = 0; r < R; r++) {
+    if (!on[r]) {
+      if (did) did[r] = 0;
+      if (stats) memset(&stats[r], 0, sizeof(wg_run_stats));
+      continue;
+    }
+    Engine& e = *es[r];
+    e.sync_globals_to_host();
+    e.time = endAt[r];
+    if (did) did[r] = e.gh.anyEvent ? 1 : 0;
+    if (stats) {
+      wg_run_stats& st = stats[r];
+      st.delivered = (int64_t)(e.gh.delivered - before[r].delivered);
+      st.tasks = (int64_t)(e.gh.tasks - before[r].tasks);
+      st.events = (int64_t)(e.gh.events - before[r].events);
+      st.draws = (int64_t)(e.gh.draws - before[r].draws);
+      st.simulated_ms = ms;
+      st.wall_ns = wall;
+      int64_t pb = 0;
+      for (int l = 0; l < 32; l++)
+        pb += (int64_t)(e.gh.deliveredByLevel[l] - before[r].deliveredByLevel[l]) * e.proto->payload_bytes_of_level(l);
+      st.payload_bytes = pb;
+    }
+    try {
+      e.check_device_errors();
+    } catch (const WgError& x) {
+      e.lastError = x.what();
+      if (firstCode == WG_OK) {
+        firstCode = x.code;
+        firstErr = x.what();
+      }
+    }
   }
-  check_device_errors();
+  if (firstCode != WG_OK) throw WgError(firstCode, firstErr);
+}
+
+// ---- batches
+Batch::Batch(Engine** es, int n) {
+  if (n <= 0 || !es) throw WgError(WG_EINVAL, "empty batch");
+  for (int i = 0; i < n; i++) {
+    Engine* e = es[i];
+    if (!e || !e->proto) throw WgError(WG_ESTATE, "every batch member needs a resident protocol");
+    e->ensure_device();
+    Engine* l = es[0];
+    if (e->cfg.device != l->cfg.device || e->dev.horizon != l->dev.horizon || e->dev.nodes.n != l->dev.nodes.n ||
+        e->proto->state_size() != l->proto->state_size() || e->proto->has_cond() != l->proto->has_cond() ||
+        e->proto->levels() != l->proto->levels())
+      throw WgError(WG_EINVAL, "batch members must share device, protocol, node count and horizon_ms");
+    for (int j = 0; j < i; j++)
+      if (es[j] == e) throw WgError(WG_EINVAL, "an engine appears twice in the batch");
+    members.push_back(e);
+  }
+  Engine& l = *members[0];
+  WG_HIP(hipSetDevice(l.cfg.device));
+  WG_HIP(hipMalloc((void**)&dTab, sizeof(EngineDev) * (size_t)n));
+  WG_HIP(hipMalloc(&dStab, l.proto->state_size() * (size_t)n));
+  WG_HIP(hipMalloc((void**)&dCont, sizeof(uint32_t) * (size_t)n));
+}
+Batch::~Batch() {
+  if (dTab) (void)hipFree(dTab);
+  if (dStab) (void)hipFree(dStab);
+  if (dCont) (void)hipFree(dCont);
+}
+Group Batch::prepare(const uint8_t* active) {
+  Engine& l = *members[0];
+  const int n = (int)members.size();
+  const size_t sz = l.proto->state_size();
+  std::vector<EngineDev> tab(n);
+  std::vector<char> stab(sz * n);
+  for (int r = 0; r < n; r++) {
+    tab[r] = members[r]->dev;
+    tab[r].halted = (active && !active[r]) ? 1u : 0u;
+    memcpy(stab.data() + sz * r, members[r]->proto->state_host(), sz);
+  }
+  bool sync = false;
+  if (hTab.size() != tab.size() || memcmp(hTab.data(), tab.data(), sizeof(EngineDev) * n) != 0) {
+    hTab = tab;
+    WG_HIP(hipMemcpyAsync(dTab, hTab.data(), sizeof(EngineDev) * n, hipMemcpyHostToDevice, l.stream));
+    sync = true;
+  }
+  if (hStab != stab) {
+    hStab = stab;
+    WG_HIP(hipMemcpyAsync(dStab, hStab.data(), hStab.size(), hipMemcpyHostToDevice, l.stream));
+    sync = true;
+  }
+  if (sync) WG_HIP(hipStreamSynchronize(l.stream));
+  Group g;
+  g.tab = dTab;
+  g.stab = dStab;
+  g.R = n;
+  g.stream = l.stream;
+  g.binBits = l.binBits;
+  g.histLds = sizeof(uint32_t) * (size_t)l.dev.horizon;
+  return g;
+}
+void Batch::run_ms(int32_t ms, const uint8_t* active, uint8_t* did, wg_run_stats* stats) {
+  if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
+  bool any = false;
+  for (size_t r = 0; r < members.size(); r++) any |= !active || active[r];
+  if (!any) {
+    if (did) memset(did, 0, members.size());
+    if (stats) memset(stats, 0, sizeof(wg_run_stats) * members.size());
+    return;
+  }
+  WG_HIP(hipSetDevice(members[0]->cfg.device));
+  Group g = prepare(active);
+  Engine::run_group(members.data(), (int)members.size(), active, g, ms, did, stats);
+}
+void Batch::cont_if(int32_t* out) {
+  Engine& l = *members[0];
+  WG_HIP(hipSetDevice(l.cfg.device));
+  for (Engine* e : members) e->flush_staged(e->time, false);
+  Group g = prepare(nullptr);
+  const int n = (int)members.size();
+  WG_HIP(hipMemsetAsync(dCont, 0, sizeof(uint32_t) * n, l.stream));
+  if (!l.proto->launch_cont_if(g, dCont))
+    throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+  std::vector<uint32_t> v(n);
+  WG_HIP(hipMemcpyAsync(v.data(), dCont, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, l.stream));
+  WG_HIP(hipStreamSynchronize(l.stream));
+  for (int r = 0; r < n; r++) out[r] = (int32_t)v[r];
 }
 
 int64_t Engine::queue_size() {  // msgs.size(): number of envelopes (a multi-dest envelope counts once)
@@ -781,7 +957,7 @@ void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
 
 namespace wg {
 
-template void Engine::scan<CondF>(const CondF&);
+template void Engine::scan<CondF>(const Group&, const HandelState*);
 
 __global__ void k_handel_init(HandelState s, const uint8_t* down) {
   int node = blockIdx.x * blockDim.x + threadIdx.x;
@@ -804,10 +980,12 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down) {
 }
 
 // Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0
-__global__ void k_handel_cont_if(HandelState s, const uint8_t* down, const long long* doneAt, uint32_t* out) {
+__global__ void k_handel_cont_if(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab, uint32_t* out) {
+  const EngineDev& d = tab[blockIdx.y];
+  const HandelState& s = stab[blockIdx.y];
   int node = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = node < s.N && !down[node] && (doneAt[node] == 0 || s.addedCycle[node] > 0);
-  if (__ballot(c) && WG_LANE == 0) atomicOr(out, 1u);
+  bool c = node < s.N && !d.nodes.down[node] && (d.nodes.doneAt[node] == 0 || s.addedCycle[node] > 0);
+  if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
 }
 
 struct HandelHost : ProtoHost {
@@ -908,9 +1086,9 @@ struct HandelHost : ProtoHost {
   int levels() const override { return st.L; }
   bool cont_if(Engine& e, int32_t* out) override {
     if (!dCont) dCont = e.dalloc<uint32_t>(1);
+    Group g = e.self();
     WG_HIP(hipMemsetAsync(dCont, 0, 4, e.stream));
-    hipLaunchKernelGGL(k_handel_cont_if, dim3((st.N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down,
-                       e.dev.nodes.doneAt, dCont);
+    launch_cont_if(g, dCont);
     uint32_t v = 0;
     WG_HIP(hipMemcpyAsync(&v, dCont, 4, hipMemcpyDeviceToHost, e.stream));
     WG_HIP(hipStreamSynchronize(e.stream));
@@ -924,17 +1102,26 @@ struct HandelHost : ProtoHost {
   int payload_bytes_of_level(int l) const override {
     return l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) / 8 : 8);  // 64-bit words of the level's block
   }
-  void launch_cond(Engine& e) override {
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
+  void launch_cond(Engine& profOwner, const Group& g) override {
+    const HandelState* stab = (const HandelState*)g.stab;
     {
-      Engine::ProfScope ps(e, Engine::PC_COND_SELECT);
-      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048), dim3(256), 0, e.stream, e.dev, st);
+      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
+      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
-    Engine::ProfScope ps(e, Engine::PC_COND_REST);
-    e.scan(CondF{e.dev, st});
-    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128), dim3(256), 0, e.stream, e.dev, st);
+    Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
+    Engine::scan<CondF>(g, stab);
+    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
-  void launch_deliver(Engine& e) override {
-    hipLaunchKernelGGL(k_deliver<HandelProto>, dim3(2048), dim3(256), 0, e.stream, e.dev, st);
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL(k_deliver<HandelProto>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab,
+                       (const HandelState*)g.stab);
+  }
+  bool launch_cont_if(const Group& g, uint32_t* dOut) override {
+    hipLaunchKernelGGL(k_handel_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,
+                       (const HandelState*)g.stab, dOut);
+    return true;
   }
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
     const int32_t* src = nullptr;

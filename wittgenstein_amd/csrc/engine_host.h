@@ -25,14 +25,30 @@ struct WgError : std::runtime_error {
 
 class Engine;
 
+// What a launch addresses: a device table of R engines (blockIdx.y) + the matching table of protocol
+// State structs, on one stream. A stand-alone engine is a group of one; a batch (wg_batch_*) is the
+// device-side form of the reference's RunMultipleTimes loop over independent copies.
+struct Group {
+  const EngineDev* tab = nullptr;
+  const void* stab = nullptr;
+  int R = 1;
+  hipStream_t stream = nullptr;
+  int binBits = 0;
+  size_t histLds = 0;  // dynamic LDS of the multisplit kernels: horizon words
+};
+
 // A resident protocol: device state + the kernels that run its action()/conditional tasks.
 struct ProtoHost {
   virtual ~ProtoHost() {}
   virtual bool has_cond() const { return false; }
   // conditional-task phase at the time++ edge -> t (C/Network.java:543-566); emits into the ordered
   // outbox (fin/arr, g->nOut) and g->nDraws. Only called when has_cond().
-  virtual void launch_cond(Engine&) {}
-  virtual void launch_deliver(Engine&) = 0;
+  virtual void launch_cond(Engine& profOwner, const Group&) {}
+  virtual void launch_deliver(const Group&) = 0;
+  virtual size_t state_size() const = 0;        // sizeof the device State struct ...
+  virtual const void* state_host() const = 0;   // ... and its host copy (what a Group's stab holds)
+  // continuation predicate for every member of the group: out[R] on the device
+  virtual bool launch_cont_if(const Group&, uint32_t* /*dOut*/) { return false; }
   virtual int payload_bytes_of_level(int /*level*/) const { return 0; }
   virtual bool read_i64(Engine&, int32_t /*field*/, int64_t* /*dst*/, int32_t /*n*/) { return false; }
   virtual bool read_level_i32(Engine&, int32_t, int32_t*, int32_t, int32_t) { return false; }
@@ -74,10 +90,19 @@ class Engine {
   void ensure_device();          // allocate device state once the node count is known
   void sync_globals_to_host();
   void sync_globals_to_device();
-  void append_phase(bool needHist);  // multisplit of the ordered outbox into the buckets
-  void end_phase(bool drained);
+  static void append_phase(const Group& g, bool needHist);  // multisplit of the ordered outbox into the buckets
+  static void end_phase(const Group& g, bool drained);
   template <class F>
-  void scan(const F& f);
+  static void scan(const Group& g, const typename F::Aux* atab);
+  Group self();                  // this engine as a group of one (refreshes its device table entry)
+  // Network.runMs for every active member of a group in lock-step (one launch sequence for all)
+  static void run_group(Engine** es, int R, const uint8_t* active, const Group& g, int32_t ms, uint8_t* did,
+                        wg_run_stats* stats);
+  void begin_run(int32_t ms, int32_t* endAt);
+  EngineDev* dTab = nullptr;     // device copy of `dev` (table of one)
+  void* dStab = nullptr;         // device copy of the protocol State struct
+  EngineDev tabShadow{};         // what dTab / dStab currently hold (skip the upload when unchanged)
+  std::vector<char> stabShadow;
   void flush_staged(int32_t t, bool inRun);
   int32_t host_latency(int32_t from, int32_t to, int32_t seed) const;
   int32_t part_of(int32_t x) const;
@@ -133,7 +158,7 @@ class Engine {
   // roofline leg; off by default because every bracket costs two event records)
   enum ProfClass { PC_EXPAND = 0, PC_GROUP, PC_DELIVER, PC_ORDER, PC_RESOLVE, PC_APPEND, PC_END, PC_COND_SELECT,
                    PC_COND_REST, PC_COUNT };
-  bool profiling = false;
+  int profiling = 0;                       // 0 off, 1 every phase, 2 the delivery kernel only
   struct ProfSpan {
     int cls;
     hipEvent_t a, b;
@@ -148,7 +173,7 @@ class Engine {
     Engine& e;
     size_t idx = (size_t)-1;
     ProfScope(Engine& en, int cls) : e(en) {
-      if (!e.profiling) return;
+      if (!(e.profiling == 1 || (e.profiling == 2 && cls == PC_DELIVER))) return;
       ProfSpan s{cls, e.prof_event(), e.prof_event()};
       (void)hipEventRecord(s.a, e.stream);
       idx = e.profSpans.size();
@@ -169,6 +194,26 @@ class Engine {
   }
   void upload_latency();
   void rebuild_partitions();
+};
+
+// A batch of engines advanced in lock-step by one launch sequence (gridDim.y = members): the device
+// form of RunMultipleTimes' loop over independent copies (C/RunMultipleTimes.java:44-64).
+class Batch {
+ public:
+  Batch(Engine** es, int n);
+  ~Batch();
+  void run_ms(int32_t ms, const uint8_t* active, uint8_t* did, wg_run_stats* stats);
+  void cont_if(int32_t* out);
+  std::vector<Engine*> members;
+  std::string lastError;
+
+ private:
+  Group prepare(const uint8_t* active);
+  EngineDev* dTab = nullptr;
+  void* dStab = nullptr;
+  uint32_t* dCont = nullptr;
+  std::vector<EngineDev> hTab;
+  std::vector<char> hStab;
 };
 
 ProtoHost* make_pingpong_host(Engine& e);

@@ -118,8 +118,18 @@ __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t*
   return woff + incl - v;
 }
 
+// Every kernel of the pipeline is launched over a TABLE of engines, blockIdx.y selecting the engine:
+// a batch of independent simulations (the reference's RunMultipleTimes copies, C/RunMultipleTimes.java:
+// 44-48) advances one simulated ms per launch. A stand-alone engine is a table of one.
+#define WG_ENGINE(tab)                         \
+  const EngineDev& d = (tab)[blockIdx.y];      \
+  if (d.halted) return
+
 template <class F>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(F f, unsigned long long* partials) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
+  WG_ENGINE(tab);
+  const F f(d, atab ? atab + blockIdx.y : nullptr);
+  unsigned long long* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
   scan_range(n, lo, hi);
@@ -133,7 +143,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(F f, unsigned long long* p
 // f.write(i, exclusive_prefix, valid) is called by every thread of the block at the same point (valid
 // = i is in range), so write() may use wave-level collectives.
 template <class F>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(F f, const unsigned long long* partials) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
+  WG_ENGINE(tab);
+  const F f(d, atab ? atab + blockIdx.y : nullptr);
+  const unsigned long long* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   __shared__ uint64_t shw[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
@@ -169,7 +182,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(F f, const unsigned long l
 // ------------------------------------------------------------------------------------------------
 // expand: bucket t, LIFO, chain runs unrolled. Pair scan: low = events, high = outbox slots.
 struct ExpandF {
-  EngineDev d;
+  typedef int Aux;
+  const EngineDev& d;
+  __device__ ExpandF(const EngineDev& d_, const Aux*) : d(d_) {}
   __device__ int32_t now() const { return d.g->now; }
   __device__ uint32_t bucket() const { return (uint32_t)now() & (uint32_t)(d.horizon - 1); }
   __device__ uint32_t count() const { return d.bcnt[bucket()]; }
@@ -261,7 +276,9 @@ struct ExpandF {
 // order: per-event (records, draws) -> offsets in the global push order / draw order, the event of
 // every ordered outbox position, and the run statistics (block-aggregated).
 struct RecsF {
-  EngineDev d;
+  typedef int Aux;
+  const EngineDev& d;
+  __device__ RecsF(const EngineDev& d_, const Aux*) : d(d_) {}
   __device__ uint32_t count() const { return d.g->nEvents; }
   __device__ uint64_t value(uint32_t i) const {
     const EvRes r = d.evRes[i];
@@ -324,7 +341,8 @@ __device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from
 
 constexpr int TILE = 1024;
 
-__global__ void __launch_bounds__(256) k_resolve(EngineDev d) {
+__global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
   const uint32_t D = (uint32_t)d.horizon;
@@ -448,7 +466,8 @@ __device__ __forceinline__ uint32_t tile_rank(uint32_t* hist, int bin, bool vali
 }
 
 // (host-staged envelopes only: the device pipeline builds the histogram inside k_resolve / cond_a2)
-__global__ void __launch_bounds__(TILE) k_tile_hist(EngineDev d, int binBits) {
+__global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict__ tab, int binBits) {
+  WG_ENGINE(tab);
   extern __shared__ uint32_t hist[];
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
@@ -469,7 +488,8 @@ __global__ void __launch_bounds__(TILE) k_tile_hist(EngineDev d, int binBits) {
 
 // single block: per-bin exclusive prefix over tiles (in place), then reserve pages for every bucket
 // that grows (MessageStorage.ensureSize analogue) and publish each bucket's append base.
-__global__ void __launch_bounds__(1024) k_col_reserve(EngineDev d) {
+__global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
   __shared__ uint32_t shNeed[16];
   __shared__ uint32_t shBase;
   uint32_t n = d.g->nOut;
@@ -518,7 +538,8 @@ __global__ void __launch_bounds__(1024) k_col_reserve(EngineDev d) {
   }
 }
 
-__global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int binBits) {
+__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits) {
+  WG_ENGINE(tab);
   extern __shared__ uint32_t hist[];
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
@@ -544,7 +565,8 @@ __global__ void __launch_bounds__(TILE) k_scatter(EngineDev d, int binBits) {
 // ------------------------------------------------------------------------------------------------
 // end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
 // release the bucket's pages and bump the nextMessage() epoch if anything was polled.
-__global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int drained) {
+__global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
+  WG_ENGINE(tab);
   __shared__ uint32_t shTop;
   Globals* g = d.g;
   const int32_t t = g->now;
@@ -585,8 +607,9 @@ __global__ void __launch_bounds__(256) k_end_phase(EngineDev d, int drained) {
   }
 }
 
-__global__ void k_latency_probe(EngineDev d, int n, const int32_t* from, const int32_t* to, const int32_t* delta,
+__global__ void k_latency_probe(const EngineDev* __restrict__ tab, int n, const int32_t* from, const int32_t* to, const int32_t* delta,
                                 int32_t* out) {
+  const EngineDev& d = tab[0];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const NodeArrays& nd = d.nodes;
@@ -737,7 +760,10 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) k_deliver(EngineDev d, typename P::State ps) {
+__global__ void __launch_bounds__(256) k_deliver(const EngineDev* __restrict__ tab,
+                                                 const typename P::State* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const typename P::State& ps = stab[blockIdx.y];
   __shared__ typename P::WaveShared shP[4];
   __shared__ uint32_t shSort[4][64];
   const int lane = WG_LANE, w = threadIdx.x >> 6;

@@ -460,7 +460,10 @@ struct HandelProto {
 
 // ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
 // A1: eligibility + bestToVerify for every level (:570-634): curates the lists, records the candidates.
-__global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState s) {
+__global__ void __launch_bounds__(256) k_handel_cond_a1(const EngineDev* __restrict__ tab,
+                                                        const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
   __shared__ LevelScalars shLevels[4];
   const int32_t t = d.g->now, until = d.g->until;
   const int lane = WG_LANE;
@@ -586,8 +589,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_a1(EngineDev d, HandelState
 // and the draw itself — chooseBestFromLevels: rd.nextInt(byLevels.size()) (:788-790) — by jump-ahead
 // assuming no earlier nextInt(bound) rejection; a rejection anywhere is flagged and re-walked in A2.
 struct CondF {
-  EngineDev d;
-  HandelState s;
+  typedef HandelState Aux;
+  const EngineDev& d;
+  const HandelState& s;
+  __device__ CondF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
   __device__ uint32_t count() const { return (uint32_t)s.N; }
   __device__ uint64_t value(uint32_t i) const { return s.candCnt[i] > 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
@@ -606,7 +611,10 @@ struct CondF {
 };
 
 // A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
-__global__ void __launch_bounds__(256) k_handel_cond_a2(EngineDev d, HandelState s) {
+__global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restrict__ tab,
+                                                        const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
   const uint32_t n = d.g->nOut;
   const int32_t t = d.g->now;
   const bool rejected = d.g->rejectSeen != 0;
@@ -656,7 +664,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(EngineDev d, HandelState
       // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
       const int32_t arrival = t + s.pairing[node];
       d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
-      const bool ok = arrival - t < d.horizon;
+      const bool ok = arrival - t < d.horizon - 1;  // see Engine::run_ms on host-held envelopes
       d.arr[j] = ok ? arrival : -1;
       if (!ok) set_err(d.g, ERR_HORIZON);
       if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
