@@ -41,7 +41,7 @@ struct PingPongHost : ProtoHost {
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL(k_deliver<PingPongProto>, dim3(512, g.R), dim3(256), 0, g.stream, g.tab,
+    hipLaunchKernelGGL((k_deliver<PingPongProto, 4>), dim3(512, g.R), dim3(256), 0, g.stream, g.tab,
                        (const PingPongProto::State*)g.stab);
   }
   size_t state_size() const override { return sizeof(st); }
@@ -992,6 +992,10 @@ struct HandelHost : ProtoHost {
   HandelState st{};
   Engine& eng;
   uint32_t* dCont = nullptr;
+  // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
+  // tuning knobs, see DESIGN.md "Occupancy"
+  int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 3;
+  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
@@ -1069,6 +1073,8 @@ struct HandelHost : ProtoHost {
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
     st.pend = e.dalloc<uint32_t>((size_t)N * H_PEND);
     st.pendFrom = e.dalloc<int32_t>((size_t)N * H_PEND);
+    st.runList = e.dalloc<uint32_t>(N);
+    st.runCount = e.dalloc<uint32_t>(1);
     st.candCnt = e.dalloc<uint8_t>(N);
     st.candLevel = e.dalloc<uint8_t>(NL);
     st.candSlot = e.dalloc<uint8_t>(NL);
@@ -1108,15 +1114,27 @@ struct HandelHost : ProtoHost {
     const HandelState* stab = (const HandelState*)g.stab;
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
-      hipLaunchKernelGGL(k_handel_cond_a1, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      switch (wavesCond) {
+        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      }
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
     hipLaunchKernelGGL(k_handel_cond_a2, dim3(128, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL(k_deliver<HandelProto>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab,
-                       (const HandelState*)g.stab);
+    const HandelState* stab = (const HandelState*)g.stab;
+    switch (wavesDeliver) {
+      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_handel_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,

@@ -759,9 +759,9 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
   __threadfence_block();  // the node's next event reads what this one wrote (other lanes, same wavefront)
 }
 
-template <class P>
-__global__ void __launch_bounds__(256) k_deliver(const EngineDev* __restrict__ tab,
-                                                 const typename P::State* __restrict__ stab) {
+template <class P, int WPE>  // WPE: waves per SIMD the register allocation must admit
+__global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
+                                                      const typename P::State* __restrict__ stab) {
   WG_ENGINE(tab);
   const typename P::State& ps = stab[blockIdx.y];
   __shared__ typename P::WaveShared shP[4];

@@ -49,6 +49,8 @@ struct HandelState {
   uint32_t* pend;                      // [N][H_PEND]: valid<<31 | level<<8 | slot ; from in pendFrom
   int32_t* pendFrom;                   // [N][H_PEND]
   // conditional-task phase scratch
+  uint32_t* runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
+  uint32_t* runCount;                  // [1]
   uint8_t* candCnt;                    // [N] number of levels with a candidate
   uint8_t* candLevel;                  // [N][L]
   uint8_t* candSlot;                   // [N][L]
@@ -459,34 +461,59 @@ struct HandelProto {
 };
 
 // ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
-// A1: eligibility + bestToVerify for every level (:570-634): curates the lists, records the candidates.
-__global__ void __launch_bounds__(256) k_handel_cond_a1(const EngineDev* __restrict__ tab,
-                                                        const HandelState* __restrict__ stab) {
+// PRE: which conditional tasks run at this edge — one lane per node, coalesced reads of the four words
+// that decide it; the runners go to a compact list (one atomic per wavefront) so the expensive part
+// below is launched over runners only, not over all N nodes.
+__global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __restrict__ tab,
+                                                         const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  __shared__ LevelScalars shLevels[4];
   const int32_t t = d.g->now, until = d.g->until;
-  const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t epoch = d.g->epoch;
-  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
-  for (int32_t node = (int32_t)wave; node < s.N; node += (int32_t)nWaves) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t n0 = blockIdx.x * blockDim.x; n0 < (uint32_t)s.N; n0 += stride) {
+    const uint32_t node = n0 + threadIdx.x;
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
-    if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
-      int32_t ms = s.ctMinStart[node];
-      if (ms <= until && ms <= t) {
-        if (lane == 0) s.ctEpoch[node] = epoch;
-        run = s.sigQueueSize[node] != 0;  // startIf = hasSigToVerify (:345-347)
+    if (node < (uint32_t)s.N) {
+      if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
+        const int32_t ms = s.ctMinStart[node];
+        if (ms <= until && ms <= t) {
+          s.ctEpoch[node] = epoch;
+          run = s.sigQueueSize[node] != 0;  // startIf = hasSigToVerify (:345-347)
+        }
       }
+      if (run)
+        s.ctMinStart[node] = t + s.pairing[node];  // minStartTime = time + duration (:557-560)
+      else
+        s.candCnt[node] = 0;
     }
-    if (!run) {
-      if (lane == 0) s.candCnt[node] = 0;
-      continue;
+    const uint64_t m = __ballot(run);
+    if (m) {
+      uint32_t base = 0;
+      const int leader = __ffsll((unsigned long long)m) - 1;
+      if ((int)WG_LANE == leader) base = atomicAdd(s.runCount, (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
     }
-    if (lane == 0) s.ctMinStart[node] = t + s.pairing[node];  // minStartTime = time + duration (:557-560)
+  }
+}
+
+// A1: bestToVerify for every level (:570-634) of every runner: curates the lists, records the candidates.
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __restrict__ tab,
+                                                             const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  __shared__ LevelScalars shLevels[4];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nRun = *s.runCount;
+  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
+  for (uint32_t q = wave; q < nRun; q += nWaves) {
+    const int32_t node = (int32_t)s.runList[q];
     HandelProto::load_levels(s, node, ls);
     const uint64_t* ti = s.TI + (size_t)node * s.W;
     const uint64_t* la = s.LA + (size_t)node * s.W;
@@ -511,6 +538,35 @@ __global__ void __launch_bounds__(256) k_handel_cond_a1(const EngineDev* __restr
       const int curSize = ls->cTI[l], cLA = ls->cLA[l];
       int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
       uint64_t keep = 0;
+      if (v.nw == 1) {
+        // the level's block fits one 64-bit word (levels <= 7): one lane per queue entry, no reductions.
+        // Same selection as the sequential walk below: best inside = FIRST entry with the strictly
+        // greatest positive score, best outside = FIRST entry with the smallest rank.
+        const bool mineIn = lane < len;
+        const uint64_t sg = mineIn ? *HandelProto::sig_ptr(s, node, l, mySlot) : 0ULL;
+        const uint64_t tiw = ti[v.bw] & v.mask, viw = vi[v.bw] & v.mask, law = la[v.bw] & v.mask;
+        const int u1 = __popcll(sg | tiw | viw), u2 = __popcll(sg | viw), cs = __popcll(sg);
+        const bool iTI = (sg & tiw) != 0, iLA = (sg & law) != 0;
+        const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
+        const bool kept1 = mineIn && sII > curSize;
+        const bool inside = kept1 && myRank <= windowIndex + window;
+        const bool outside = kept1 && !inside;
+        int score = 0;  // score(l, sig) :655-668
+        if (inside) score = cLA >= v.size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));
+        keep = __ballot(kept1);
+        int maxScore = score, minRank = outside ? myRank : INT32_MAX;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          maxScore = max(maxScore, __shfl_xor(maxScore, o, 64));
+          minRank = min(minRank, __shfl_xor(minRank, o, 64));
+        }
+        if (maxScore > 0) {
+          const uint64_t mm = __ballot(inside && score == maxScore);
+          bestInside = __shfl(mySlot, __ffsll((unsigned long long)mm) - 1, 64);
+        }
+        const uint64_t om = __ballot(outside && myRank == minRank);
+        if (om) bestOutside = __shfl(mySlot, __ffsll((unsigned long long)om) - 1, 64);
+      } else
       for (int i = 0; i < len; i++) {
         const int slot = __shfl(mySlot, i, 64);
         const int rank = __shfl(myRank, i, 64);
@@ -620,6 +676,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
   const bool rejected = d.g->rejectSeen != 0;
   const uint32_t D = (uint32_t)d.horizon;
   const uint32_t stride = gridDim.x * blockDim.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *s.runCount = 0;  // for the next edge's k_handel_cond_pre
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
     const uint32_t j = j0 + threadIdx.x;
     uint32_t histKey = 0xFFFFFFFFu;
