@@ -141,7 +141,7 @@ def main():
         sims, batch = make_batch(w, n, range(seed0 + i * R, seed0 + (i + 1) * R), local, args.init_threads)
         inits += R
         sims[0].network().profile(1)
-        batch.run_multiple_times(chunk=10, max_ms=20000)
+        batch.run_multiple_times(chunk=10, maxTime=20000)
         prof_phase = sims[0].network().profile_read()
         del batch, sims
     timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads)
@@ -157,7 +157,7 @@ def main():
     t0 = time.perf_counter()
     delivered = sim_ms = 0
     for sims, batch in timed:
-        d, ms = batch.run_multiple_times(chunk=10, max_ms=20000)
+        d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
         delivered += sum(d)
         sim_ms += sum(ms)
     barrier()

@@ -277,20 +277,20 @@ class Batch:
         self._ck(L.lib().wg_batch_cont_if(self._h, out))
         return [bool(v) for v in out]
 
-    def run_multiple_times(self, chunk=10, max_ms=None):
-        """RunMultipleTimes.run's inner loop for all members: runMs(chunk) while a member's continuation
-        predicate holds; a member whose predicate turned false is no longer advanced. Returns per-member
-        (delivered, simulated_ms)."""
+    def run_multiple_times(self, chunk=10, maxTime=0):
+        """RunMultipleTimes.run's inner loop (C/RunMultipleTimes.java:50-64) for all members at once:
+            do { didSomething = runMs(10); }
+            while ((maxTime == 0 || time < maxTime) && (!didSomething || contIf.test(c)));
+        A member whose loop ended is no longer advanced. Returns per-member (delivered, simulated_ms)."""
         n = len(self.networks)
         delivered, sim_ms = [0] * n, [0] * n
-        active = self.cont_if()
+        active = [True] * n
         while any(active):
-            self.runMs(chunk, active)
+            did = self.runMs(chunk, active)
+            cont = self.cont_if()
             for i in range(n):
                 if active[i]:
                     delivered[i] += self.last_stats[i]["delivered"]
                     sim_ms[i] += chunk
-            active = self.cont_if()
-            if max_ms is not None:
-                active = [a and sim_ms[i] < max_ms for i, a in enumerate(active)]
+                    active[i] = (maxTime == 0 or self.networks[i].time < maxTime) and (not did[i] or cont[i])
         return delivered, sim_ms
