@@ -161,6 +161,7 @@ struct EngineDev {
   NodeArrays nodes;
   LatencyModel lat;
   int32_t discardTime;
+  uint32_t nparts;          // number of partition cuts (C/Network.java:639-649); 0 = the lookup is skipped
   // buckets
   int32_t horizon;          // D (power of two)
   int32_t maxPagesPerBucket;

@@ -268,6 +268,7 @@ int32_t Engine::part_of(int32_t x) const {  // partitionId  C/Network.java:639-6
 }
 
 void Engine::rebuild_partitions() {
+  dev.nparts = (uint32_t)cuts.size();
   if (!allocated) return;
   std::vector<uint8_t> part(hx.size());
   for (size_t i = 0; i < hx.size(); i++) part[i] = (uint8_t)part_of(hx[i]);
@@ -994,7 +995,7 @@ struct HandelHost : ProtoHost {
   uint32_t* dCont = nullptr;
   // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
   // tuning knobs, see DESIGN.md "Occupancy"
-  int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 3;
+  int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
   int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const int32_t N = p.nodeCount;
@@ -1043,10 +1044,9 @@ struct HandelHost : ProtoHost {
     st.cVI = e.dalloc<int32_t>(NL);
     st.outFin = e.dalloc<uint8_t>(NL);
     st.qlen = e.dalloc<uint8_t>(NL);
-    st.qorder = e.dalloc<uint8_t>(NL * 64);
+    st.qent = e.dalloc<uint64_t>(NL * 64);
     st.qused = e.dalloc<unsigned long long>(NL);
     st.qfrom = e.dalloc<int32_t>(NL * Q, false);
-    st.qrank = e.dalloc<int32_t>(NL * Q, false);
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
       st.qsigOff[l] = off;

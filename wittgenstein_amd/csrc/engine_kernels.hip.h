@@ -718,10 +718,9 @@ struct Ctx {
 //   on_message / on_task       Message.action()
 template <class P>
 __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename P::State& ps, Ctx& c,
-                                              typename P::NodeRegs& r, uint32_t e, bool toDown, uint8_t toPart,
-                                              long long& nRecv, long long& bRecv) {
-  const Rec rec = d.ev[e];
-  const EvAux aux = d.evAux[e];
+                                              typename P::NodeRegs& r, uint32_t e, const Rec rec, const EvAux aux,
+                                              bool toDown, uint8_t toPart, bool moreEvents, long long& nRecv,
+                                              long long& bRecv) {
   const uint32_t kind = rec_kind(rec);
   const int32_t from = rec_from(rec);
   c.ev = e;
@@ -730,7 +729,8 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
   c.outBase = aux.outBase;
   c.outCap = aux.outCap;
   uint32_t flags = 0;
-  if (!toDown && d.nodes.part[from] == toPart) {  // :606
+  // :606 — partitions are rare: without cuts every node is in partition 0 and the lookup is skipped
+  if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {
     if (kind == K_MSG) {
       nRecv++;
       bRecv += P::msg_size(ps, rec.w2);
@@ -756,9 +756,16 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
     res.ndraw = c.draws;
     d.evRes[e] = res;
   }
-  __threadfence_block();  // the node's next event reads what this one wrote (other lanes, same wavefront)
+  // the node's next event reads what this one wrote (other lanes, same wavefront)
+  if (moreEvents) __threadfence_block();
 }
 
+// A node visit is a chain of dependent HBM round trips and the kernel is bound by that latency
+// (DESIGN.md §3.1), so the loop is written to keep the chain short:
+//   1. active[a]                                  -> node
+//   2. head[node] + everything node_begin loads   -> newest event e0, node registers
+//   3. evNext[e0] + ev[e0] + evAux[e0]            -> (usually) "e0 is the only event" and the event itself
+//   4. whatever action() loads (hoisted inside P) -> stores; counters by no-return atomics
 template <class P, int WPE>  // WPE: waves per SIMD the register allocation must admit
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
                                                       const typename P::State* __restrict__ stab) {
@@ -773,51 +780,76 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nActive; a += nWaves) {
     const int32_t node = (int32_t)d.active[a];
-    // the node's events of this ms: walk the inbox list (newest first), then order by event index
-    int32_t cur = d.head[node];
-    uint32_t cnt = 0, mine = 0xFFFFFFFFu;
-    while (cur >= 0 && cnt < 64) {
-      if ((uint32_t)lane == cnt) mine = (uint32_t)cur;
-      cur = d.evNext[cur];
-      cnt++;
-    }
-    const bool overflow = cur >= 0;
+    const int32_t e0 = d.head[node];  // newest event of the node (always >= 0 for a listed node)
+    const bool toDown = d.nodes.down[node] != 0;
+    const uint8_t toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
     typename P::NodeRegs r;
     long long nRecv = 0, bRecv = 0;
-    const bool toDown = d.nodes.down[node] != 0;
-    const uint8_t toPart = d.nodes.part[node];
     P::node_begin(c, ps, r, &shP[w]);
-    if (!overflow) {
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
-      if ((uint32_t)lane < cnt) shSort[w][rank] = mine;
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e = shSort[w][k];
-        deliver_event<P>(d, ps, c, r, e, toDown, toPart, nRecv, bRecv);
+    const int32_t next0 = d.evNext[e0];
+    const Rec rec0 = d.ev[e0];
+    const EvAux aux0 = d.evAux[e0];
+    // mode 0: e0 is the only event (usual); 1: <= 64 events, sorted into shSort; 2: more (the PingPong
+    // origin): repeated minimum search over the list. One call site of deliver_event for all three.
+    int mode = 0;
+    uint32_t cnt = 1;
+    if (next0 >= 0) {
+      int32_t cur = e0;
+      uint32_t mine = 0xFFFFFFFFu;
+      cnt = 0;
+      while (cur >= 0 && cnt < 64) {
+        if ((uint32_t)lane == cnt) mine = (uint32_t)cur;
+        cur = d.evNext[cur];
+        cnt++;
       }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      // more than 64 events for one node in one ms (e.g. the PingPong origin): repeated minimum search
-      bool have = false;
-      uint32_t last = 0;
-      for (;;) {
+      if (cur < 0) {
+        mode = 1;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
+        if ((uint32_t)lane < cnt) shSort[w][rank] = mine;
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        mode = 2;
+        cnt = 0xFFFFFFFFu;
+      }
+    }
+    bool have = false;
+    uint32_t last = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+      uint32_t e = (uint32_t)e0;
+      if (mode == 1) {
+        e = shSort[w][k];
+      } else if (mode == 2) {
         uint32_t best = 0xFFFFFFFFu;
-        for (int32_t q = d.head[node]; q >= 0; q = d.evNext[q])
+        for (int32_t q = e0; q >= 0; q = d.evNext[q])
           if ((!have || (uint32_t)q > last) && (uint32_t)q < best) best = (uint32_t)q;
         if (best == 0xFFFFFFFFu) break;
-        deliver_event<P>(d, ps, c, r, best, toDown, toPart, nRecv, bRecv);
+        e = best;
         last = best;
         have = true;
       }
+      Rec rec = rec0;
+      EvAux aux = aux0;
+      if (mode != 0) {
+        rec = d.ev[e];
+        aux = d.evAux[e];
+      }
+      deliver_event<P>(d, ps, c, r, e, rec, aux, toDown, toPart, mode == 2 || k + 1 < cnt, nRecv, bRecv);
     }
+    __builtin_amdgcn_wave_barrier();
     P::node_end(c, ps, r);
     if (lane == 0) {
-      d.nodes.msgReceived[node] += nRecv;
-      d.nodes.bytesReceived[node] += bRecv;
-      d.nodes.msgSent[node] += c.msgSent;
-      d.nodes.bytesSent[node] += c.bytesSent;
+      // Node counters (C/Node.java:69-79): this wavefront is the node's only writer in this launch;
+      // atomics without a return value do not stall the wave the way a load-add-store would
+      if (nRecv) {
+        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      }
+      if (c.msgSent) {
+        atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+        atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+      }
       d.head[node] = -1;
     }
     __builtin_amdgcn_wave_barrier();

@@ -35,9 +35,9 @@ struct HandelState {
   int32_t *pos, *cTI, *cLA, *cVI;      // [N][L]
   uint8_t* outFin;                     // [N][L]
   uint8_t* qlen;                       // [N][L]
-  uint8_t* qorder;                     // [N][L][64] slot ids in list order
+  uint64_t* qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
   unsigned long long* qused;           // [N][L] slots allocated
-  int32_t *qfrom, *qrank;              // [N][L][Q]
+  int32_t* qfrom;                      // [N][L][Q]
   uint64_t* qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
   // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
@@ -214,15 +214,6 @@ struct HandelProto {
     for (int k = 0; k < H_PEND; k++) p |= (r.pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot));
     return p;
   }
-  // remove list position `at` from the order list of (node, l); lane i holds entry i
-  __device__ static void order_remove(const State& s, int32_t node, int l, int at, int len) {
-    uint8_t* ord = s.qorder + ((size_t)node * s.L + l) * 64;
-    int lane = WG_LANE;
-    int mine = lane < len ? ord[lane] : 0;
-    int next = __shfl_down(mine, 1, 64);
-    if (lane >= at && lane < len - 1) ord[lane] = (uint8_t)next;
-  }
-
   // ---- getRemainingPeers (:486-508), wave-parallel but sequentially equivalent ------------------
   // Scans the emission list from posInLevel, 64 peers per step. Accepted peers (not finished) are
   // appended to the dest ring at destOff (want > 1) or returned (want == 1). Returns the count.
@@ -304,8 +295,24 @@ struct HandelProto {
     }
     if (c.t < r.startAt) return;
     LevelScalars* ls = r.ls;
-    if (levelFinished) row_set(s.FP + (size_t)node * s.W, from, true);
-    if (!row_get(s.VI + (size_t)node * s.W, from)) row_set(s.TV + (size_t)node * s.W, from, true);
+    // Everything this event reads from HBM depends only on (node, from, payload): issue it all before the
+    // first use so the event costs ONE memory round trip (the path is latency-bound).
+    const int w = from >> 6;
+    const uint64_t bit = 1ULL << (from & 63);
+    uint64_t* fpp = s.FP + (size_t)node * s.W + w;
+    uint64_t* vip = s.VI + (size_t)node * s.W + w;
+    uint64_t* tvp = s.TV + (size_t)node * s.W + w;
+    const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
+    const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+    const Lv v = sib_view(node, l);
+    const uint64_t* src = (payload & H_REF_RING) ? c.d.payload + (payload & ~H_REF_RING) : s.snap + payload;
+    const int j0 = (int)((WG_LANE - v.bw) & 63);
+    const bool has0 = j0 < v.nw;
+    uint64_t pw0 = 0;
+    if (has0) pw0 = src[j0];
+    const bool owner = (int)WG_LANE == (w & 63);
+    if (levelFinished && owner) *fpp = fpv | bit;                 // finishedPeers.set(from)
+    if (!(viv & bit) && owner) *tvp = tvv | bit;                  // toVerifyInd.set(from) unless verified
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
     unsigned long long used = ls->qused[l];
@@ -317,15 +324,12 @@ struct HandelProto {
       return;
     }
     int slot = __ffsll(freeM) - 1;
-    Lv v = sib_view(node, l);
     uint64_t* dst = sig_ptr(s, node, l, slot);
-    const uint64_t* src = (payload & H_REF_RING) ? c.d.payload + (payload & ~H_REF_RING) : s.snap + payload;
-    H_FOR_WORDS(v, j) dst[j] = src[j];
+    if (has0) dst[j0] = pw0;
+    for (int j = j0 + 64; j < v.nw; j += 64) dst[j] = src[j];
     if (WG_LANE == 0) {
-      size_t qi = ((size_t)node * s.L + l) * s.Q + slot;
-      s.qfrom[qi] = from;
-      s.qrank[qi] = s.ranks[(size_t)node * s.N + from];
-      s.qorder[((size_t)node * s.L + l) * 64 + len] = (uint8_t)slot;
+      s.qfrom[((size_t)node * s.L + l) * s.Q + slot] = from;
+      s.qent[((size_t)node * s.L + l) * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
       ls->qused[l] = used | (1ULL << slot);
       ls->qlen[l] = len + 1;
     }
@@ -362,10 +366,11 @@ struct HandelProto {
   // ---- Task: updateVerifiedSignatures (:690-754) --------------------------------------------------
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int32_t node = c.node;
+    const int lane = WG_LANE;
     const uint32_t pe = r.pend[arg & (H_PEND - 1)];
     const int32_t from = r.pendFrom[arg & (H_PEND - 1)];
     if (!(pe & 0x80000000u)) {
-      if (WG_LANE == 0) set_err(c.d.g, ERR_PROTOCOL);
+      if (lane == 0) set_err(c.d.g, ERR_PROTOCOL);
       return;
     }
     const int lv = (int)((pe >> 8) & 0xFF), slot = (int)(pe & 0xFF);
@@ -376,36 +381,59 @@ struct HandelProto {
     uint64_t* la = s.LA + (size_t)node * s.W;
     uint64_t* vi = s.VI + (size_t)node * s.W;
     const uint64_t* sig = sig_ptr(s, node, lv, slot);
-    row_set(s.TV + (size_t)node * s.W, from, false);  // toVerifyInd.set(from, false)
+    // ---- every load of the event, issued before the first use (one memory round trip)
+    const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block
+    const uint64_t bit = 1ULL << (from & 63);
+    uint64_t* tvp = s.TV + (size_t)node * s.W + wF;
+    const uint64_t tvv = ld_coherent(tvp), viF = ld_coherent(vi + wF), tiF = ld_coherent(ti + wF);
+    uint64_t* ent = s.qent + ((size_t)node * s.L + lv) * 64;
+    const int len = ls->qlen[lv];
+    const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
+    const int j0 = (int)((lane - v.bw) & 63);
+    const bool has0 = j0 < v.nw;
+    uint64_t sg0 = 0, vi0 = 0, la0 = 0, ti0 = 0;
+    if (has0) {
+      sg0 = sig[j0];
+      vi0 = vi[v.bw + j0];
+      la0 = la[v.bw + j0];
+      ti0 = ti[v.bw + j0];
+    }
+    const bool owner = lane == (wF & 63);
+    if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     {
-      int len = ls->qlen[lv];
-      const uint8_t* ord = s.qorder + ((size_t)node * s.L + lv) * 64;
-      int mine = (int)WG_LANE < len ? ord[WG_LANE] : -1;
-      uint64_t hit = __ballot(mine == slot);
+      const uint64_t hit = __ballot(lane < len && (int)(myEnt & 0xFF) == slot);
       if (hit) {
-        int at = __ffsll((unsigned long long)hit) - 1;
-        order_remove(s, node, lv, at, len);
-        if (WG_LANE == 0) ls->qlen[lv] = len - 1;
+        const int at = __ffsll((unsigned long long)hit) - 1;
+        const uint64_t next = shfl64(myEnt, (lane + 1) & 63);
+        if (lane >= at && lane < len - 1) ent[lane] = next;
+        if (lane == 0) ls->qlen[lv] = len - 1;
       }
-      __builtin_amdgcn_wave_barrier();
     }
-    const bool hadVI = row_get(vi, from);
-    const bool hadTI = row_get(ti, from);
-    row_set(vi, from, true);
+    const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
+    // verifiedIndSignatures.set(from); totalIncoming.set(from) if new — applied to the register copies of
+    // the words and written back by the owning lane
+    if (owner) {
+      if (!hadVI) vi[wF] = viF | bit;
+    }
     int cVI = ls->cVI[lv] + (hadVI ? 0 : 1);
     int cTI = ls->cTI[lv];
     int cLA = ls->cLA[lv];
     bool improved = false;
     if (!hadTI) {
-      row_set(ti, from, true);
       cTI++;
       improved = true;
     }
+    if (has0 && j0 == jF) {
+      vi0 |= bit;
+      if (!hadTI) ti0 |= bit;
+    }
     // all = sig | verifiedInd ; intersects(lastAgg, sig)
     uint64_t acc = 0;
-    H_FOR_WORDS(v, j) {
+    if (has0) acc = (uint64_t)__popcll(sg0 | (vi0 & v.mask)) | ((uint64_t)((sg0 & la0 & v.mask) != 0) << 32);
+    for (int j = j0 + 64; j < v.nw; j += 64) {
       uint64_t sg = sig[j], viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
+      if (j == jF) viw |= bit;
       acc += (uint64_t)__popcll(sg | viw) | ((uint64_t)((sg & law) != 0) << 32);
     }
     acc = wave_sum64(acc);
@@ -414,9 +442,17 @@ struct HandelProto {
     if (u2 > cVI) {
       improved = true;
       uint64_t cnt = 0;
-      H_FOR_WORDS(v, j) {
+      if (has0) {
+        uint64_t nla = (inter ? 0ULL : (la0 & v.mask)) | sg0;
+        uint64_t nti = nla | (vi0 & v.mask);
+        la[v.bw + j0] = (la0 & ~v.mask) | nla;
+        ti[v.bw + j0] = (ti0 & ~v.mask) | nti;
+        cnt = (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
+      }
+      for (int j = j0 + 64; j < v.nw; j += 64) {
         uint64_t sg = sig[j];
         uint64_t law = la[v.bw + j], viw = vi[v.bw + j], tiw = ti[v.bw + j];
+        if (j == jF) viw |= bit;  // (this lane stored it above; same-lane order makes the reload see it anyway)
         uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
         uint64_t nti = nla | (viw & v.mask);
         la[v.bw + j] = (law & ~v.mask) | nla;
@@ -426,8 +462,10 @@ struct HandelProto {
       cnt = wave_sum64(cnt);
       cLA = (int)(cnt & 0xFFFFFFFFu);
       cTI = (int)(cnt >> 32);
+    } else if (!hadTI && owner) {
+      ti[wF] = tiF | bit;
     }
-    if (WG_LANE == 0) {
+    if (lane == 0) {
       ls->cVI[lv] = cVI;
       ls->cTI[lv] = cTI;
       ls->cLA[lv] = cLA;
@@ -436,7 +474,6 @@ struct HandelProto {
       if (!slot_pending(r, lv, slot)) ls->qused[lv] &= ~(1ULL << slot);
     }
     __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
     if (!improved) return;
     const bool justCompleted = cTI == v.size;  // incomingComplete()
     int cur = 0;
@@ -444,6 +481,7 @@ struct HandelProto {
       if (l > lv) {
         // totalOutgoing(l) := cur  — implicit in the TI row
         if (justCompleted && s.p.fastPath > 0 && !ls->outFin[l] && cur == (1 << (l - 1))) {
+          __threadfence_block();  // the snapshot below reads the totalIncoming words stored above
           uint32_t destOff = c.dest_reserve(s.p.fastPath);
           int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
           if (n > 0) {
@@ -524,14 +562,29 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
 #pragma unroll
     for (int k = 0; k < H_PEND; k++) pend[k] = s.pend[(size_t)node * H_PEND + k];
     int ncand = 0;
-    for (int l = 1; l < s.L; l++) {
+    // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
+    uint32_t lvMask = 0;
+    for (int l = 1; l < s.L; l++)
+      if (ls->qlen[l] > 0) lvMask |= 1u << l;
+    uint64_t entNext = ~0ULL;
+    if (lvMask) {
+      const int l0 = __ffs(lvMask) - 1;
+      if (lane < ls->qlen[l0]) entNext = s.qent[((size_t)node * s.L + l0) * 64 + lane];
+    }
+    while (lvMask) {
+      const int l = __ffs(lvMask) - 1;
+      lvMask &= lvMask - 1;
       const int len = ls->qlen[l];
-      if (len == 0) continue;
       const Lv v = sib_view(node, l);
-      uint8_t* ord = s.qorder + ((size_t)node * s.L + l) * 64;
-      const size_t qbase = ((size_t)node * s.L + l) * s.Q;
-      const int mySlot = lane < len ? ord[lane] : 0;
-      const int myRank = lane < len ? s.qrank[qbase + mySlot] : INT32_MAX;
+      uint64_t* ent = s.qent + ((size_t)node * s.L + l) * 64;
+      const uint64_t myEnt = entNext;
+      entNext = ~0ULL;
+      if (lvMask) {
+        const int ln = __ffs(lvMask) - 1;
+        if (lane < ls->qlen[ln]) entNext = s.qent[((size_t)node * s.L + ln) * 64 + lane];
+      }
+      const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
+      const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
       int windowIndex = myRank;  // Collections.min(rank)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) windowIndex = min(windowIndex, __shfl_xor(windowIndex, o, 64));
@@ -606,8 +659,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       if (kept != len) {  // replaceToVerifyAgg :636-646
         int newPos = __popcll(keep & lanes_lt());
         bool mineKept = lane < len && ((keep >> lane) & 1ULL);
-        __builtin_amdgcn_wave_barrier();
-        if (mineKept) ord[newPos] = (uint8_t)mySlot;
+        if (mineKept) ent[newPos] = myEnt;
         // slots of dropped entries are released unless a registered task still holds them
         bool mineDropped = lane < len && !mineKept;
         bool held = false;
