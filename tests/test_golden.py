@@ -49,7 +49,9 @@ def test_gpu_handel_golden(key):
     import wittgenstein_amd as w
     g0 = GOLD[key]
     n, thr, pair, lw, ec, per, fp, down, desync = g0["params"]
-    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync), seed=g0["seed"])
+    # (the HandelTest parameters queue up to 39 entries per level with runMs(10) chunks: raise the default cap of 32)
+    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync), seed=g0["seed"],
+                 config={"queue_cap": 64})
     g.init()
     net = g.network()
     delivered = 0
