@@ -21,6 +21,18 @@ constexpr int PAGE_RECS = 1 << PAGE_SHIFT;
 constexpr int MAX_CUTS = 8;
 constexpr int MAX_LEVELS = 24;
 
+// Launch widths of the grid-stride kernels (blocks; every one of them loops, so results never depend
+// on these). 2048 blocks x 4 waves = 8 waves per SIMD of a 256-CU MI355X. WG_GRID_DIV exists for
+// tests/emu, which builds these kernels for a CPU wave emulator and wants tiny grids.
+#ifndef WG_GRID_DIV
+#define WG_GRID_DIV 1
+#endif
+constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node visit (deliver, cond_a1)
+constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
+constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;
+constexpr int GRID_TILES = 256 / WG_GRID_DIV;
+constexpr int GRID_COND_TAIL = 128 / WG_GRID_DIV;
+
 enum RecKind : uint32_t { K_MSG = 0, K_TASK = 1, K_PERIODIC = 2, K_CHAIN = 3 };
 
 // 16-byte envelope record (SingleDestEnvelope C/Envelope.java:230-234 is {from,to,arrival,message};

@@ -41,7 +41,7 @@ struct PingPongHost : ProtoHost {
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL((k_deliver<PingPongProto, 4>), dim3(512, g.R), dim3(256), 0, g.stream, g.tab,
+    hipLaunchKernelGGL((k_deliver<PingPongProto, 4>), dim3(GRID_DELIVER_SMALL, g.R), dim3(256), 0, g.stream, g.tab,
                        (const PingPongProto::State*)g.stab);
   }
   size_t state_size() const override { return sizeof(st); }
@@ -511,9 +511,9 @@ template void Engine::scan<RecsF>(const Group&, const int*);
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
 void Engine::append_phase(const Group& g, bool needHist) {
-  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(256, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
-  hipLaunchKernelGGL(k_scatter, dim3(256, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
 }
 void Engine::end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
@@ -752,7 +752,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
     }
     {
       ProfScope ps(lead, PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(512, g.R), dim3(256), 0, g.stream, g.tab);
+      hipLaunchKernelGGL(k_resolve, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
     }
     {
       ProfScope ps(lead, PC_APPEND);
@@ -1116,24 +1116,24 @@ struct HandelHost : ProtoHost {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
       switch (wavesCond) {
-        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
+        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
       }
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
-    hipLaunchKernelGGL(k_handel_cond_a2, dim3(128, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(2048, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {

@@ -23,6 +23,12 @@ namespace wg {
 
 #define WG_LANE (threadIdx.x & 63)
 
+// dynamic LDS of a kernel (a macro so that tests/emu, which builds these kernels for its CPU wave
+// emulator, can bind the name to its own buffer)
+#ifndef WG_DYN_LDS
+#define WG_DYN_LDS(T, name) extern __shared__ T name[]
+#endif
+
 __device__ __forceinline__ void set_err(Globals* g, uint32_t bit) { atomicOr(&g->err, bit); }
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
@@ -75,7 +81,7 @@ __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain
 // partials before it, scans its chunk and calls F.write(i, exclusive_prefix). Values are uint64 so a
 // pair of 32-bit counters can be scanned at once.
 constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_GRID = 240;
+constexpr int SCAN_GRID = 240 / WG_GRID_DIV;
 
 __device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
@@ -468,7 +474,7 @@ __device__ __forceinline__ uint32_t tile_rank(uint32_t* hist, int bin, bool vali
 // (host-staged envelopes only: the device pipeline builds the histogram inside k_resolve / cond_a2)
 __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict__ tab, int binBits) {
   WG_ENGINE(tab);
-  extern __shared__ uint32_t hist[];
+  WG_DYN_LDS(uint32_t, hist);
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
@@ -540,7 +546,7 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
 
 __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits) {
   WG_ENGINE(tab);
-  extern __shared__ uint32_t hist[];
+  WG_DYN_LDS(uint32_t, hist);
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;

@@ -327,6 +327,7 @@ struct HandelProto {
     uint64_t* dst = sig_ptr(s, node, l, slot);
     if (has0) dst[j0] = pw0;
     for (int j = j0 + 64; j < v.nw; j += 64) dst[j] = src[j];
+    __builtin_amdgcn_wave_barrier();  // every lane has read qused/qlen before lane 0 replaces them
     if (WG_LANE == 0) {
       s.qfrom[((size_t)node * s.L + l) * s.Q + slot] = from;
       s.qent[((size_t)node * s.L + l) * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
