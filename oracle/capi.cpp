@@ -4,6 +4,7 @@
 // (-1 IllegalArgumentException, -2 IllegalStateException, -3 other); orc_last_error() has the text.
 #include <cstring>
 #include <chrono>
+#include "gsf.hpp"
 #include "handel.hpp"
 #include "pingpong.hpp"
 
@@ -292,6 +293,146 @@ int orc_handel_stats(void* h, uint64_t* deliveredByLevel32, int32_t* queueMax32)
   auto& p = *((OrcHandel*)h)->p;
   memcpy(deliveredByLevel32, p.statDeliveredByLevel, sizeof(uint64_t) * 32);
   memcpy(queueMax32, p.statQueueMax, sizeof(int32_t) * 32);
+  return 0;
+}
+
+// ---- GSFSignature
+struct OrcGsf {
+  std::unique_ptr<GSFSignature> p;
+  double initSeconds = 0;
+};
+// iparams: nodeCount, threshold, pairingTime, timeoutPerLevelMs, periodDurationMs, acceleratedCallsCount,
+//          nodesDown   (P/GSFSignature.java:59-68 ctor order, ints only)
+int orc_gsf_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY GSFSignature::GSFSignatureParameters pr(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], nb ? nb : "",
+                                                  nl ? nl : "");
+  auto* h = new OrcGsf();
+  h->p = std::make_unique<GSFSignature>(pr);
+  h->p->network().rd.setSeed(seed);
+  auto t0 = std::chrono::steady_clock::now();
+  h->p->init();
+  h->initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
+  ORC_CATCH
+}
+void orc_gsf_destroy(void* h) { delete (OrcGsf*)h; }
+int orc_gsf_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcGsf*)h)->p->network().runMs(ms);
+  ORC_CATCH
+}
+void orc_gsf_set_copy_on_delivery(void* h, int on) { ((OrcGsf*)h)->p->copyOnDelivery = on != 0; }
+int orc_gsf_cont_if(void* h) { return ((OrcGsf*)h)->p->contIf(); }
+int orc_gsf_levels(void* h) {
+  auto& p = *((OrcGsf*)h)->p;
+  for (auto& n : p.nodes)
+    if (!n->levels.empty()) return (int)n->levels.size();
+  return 0;
+}
+// per-node scalar fields: 0 doneAt 1 msgReceived 2 msgSent 3 bytesSent 4 bytesReceived 5 sigChecked
+// 6 sigQueueSize 7 toVerify.size 8 verifiedSignatures.cardinality 10 down 11 x 12 y 14 nodePairingTime
+// 15 extraLatency
+int orc_gsf_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcGsf*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.doneAt; break;
+      case 1: v = n.msgReceived; break;
+      case 2: v = n.msgSent; break;
+      case 3: v = n.bytesSent; break;
+      case 4: v = n.bytesReceived; break;
+      case 5: v = n.sigChecked; break;
+      case 6: v = n.sigQueueSize; break;
+      case 7: v = (int64_t)n.toVerify.size(); break;
+      case 8: v = n.verifiedSignatures.cardinality(); break;
+      case 10: v = n.down; break;
+      case 11: v = n.x; break;
+      case 12: v = n.y; break;
+      case 14: v = n.nodePairingTime; break;
+      case 15: v = n.extraLatency; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+// per (node, level) ints, row-major [node][level]: 0 posInLevel 1 remainingCalls
+int orc_gsf_read_level(void* h, int field, int32_t* out) {
+  ORC_TRY auto& p = *((OrcGsf*)h)->p;
+  int L = orc_gsf_levels(h);
+  for (size_t i = 0; i < p.nodes.size(); i++)
+    for (int l = 0; l < L; l++) {
+      auto& n = *p.nodes[i];
+      int v = 0;
+      if (!n.levels.empty()) {
+        auto& lv = *n.levels[l];
+        switch (field) {
+          case 0: v = lv.posInLevel; break;
+          case 1: v = lv.remainingCalls; break;
+          default: throw IllegalArgumentException("field");
+        }
+      }
+      out[i * L + l] = v;
+    }
+  ORC_CATCH
+}
+// One nodeCount-bit row per node (words = nodeCount/64 rounded up), bit j = node id j.
+// which: 0 GSFNode.verifiedSignatures; union over levels of 1 SFLevel.verifiedSignatures
+//        2 individualSignatures 3 indivVerifiedSig 4 waitedSigs
+int orc_gsf_read_bits(void* h, int which, uint64_t* out) {
+  ORC_TRY auto& p = *((OrcGsf*)h)->p;
+  int N = p.params.nodeCount;
+  int W = (N + 63) / 64;
+  memset(out, 0, sizeof(uint64_t) * (size_t)W * p.nodes.size());
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    uint64_t* row = out + i * W;
+    if (which == 0) {
+      for (int w = 0; w < W; w++) row[w] = n.verifiedSignatures.wordAt(w);
+      continue;
+    }
+    for (size_t l = 0; l < n.levels.size(); l++) {
+      auto& lv = *n.levels[l];
+      const BitSet* b = nullptr;
+      switch (which) {
+        case 1: b = &lv.verifiedSignatures; break;
+        case 2: b = &lv.individualSignatures; break;
+        case 3: b = &lv.indivVerifiedSig; break;
+        case 4: b = &lv.waitedSigs; break;
+        default: throw IllegalArgumentException("which");
+      }
+      for (int w = 0; w < W; w++) row[w] |= b->wordAt(w);
+    }
+  }
+  ORC_CATCH
+}
+int orc_gsf_read_peers(void* h, int node, int level, int32_t* out, int32_t* cnt) {
+  auto& n = *((OrcGsf*)h)->p->node(node);
+  if (n.levels.empty()) {
+    *cnt = 0;
+    return 0;
+  }
+  auto& lv = *n.levels[level];
+  *cnt = (int)lv.peers.size();
+  for (size_t i = 0; i < lv.peers.size(); i++) out[i] = lv.peers[i]->nodeId;
+  return 0;
+}
+int orc_gsf_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered, uint64_t* tasks,
+                 int32_t* queueMax, double* initSeconds) {
+  auto& p = *((OrcGsf*)h)->p;
+  *time = p.network().time;
+  if (queueSize) *queueSize = p.network().msgs.size();
+  *rngState = p.network().rd.rawState();
+  *delivered = p.network().statDelivered;
+  *tasks = p.network().statTasks;
+  *queueMax = p.statQueueMax;
+  *initSeconds = ((OrcGsf*)h)->initSeconds;
+  return 0;
+}
+uint64_t orc_gsf_shape_violations(void* h) { return ((OrcGsf*)h)->p->statShapeViolations; }
+int orc_gsf_stats(void* h, uint64_t* deliveredByLevel32) {
+  memcpy(deliveredByLevel32, ((OrcGsf*)h)->p->statDeliveredByLevel, sizeof(uint64_t) * 32);
   return 0;
 }
 

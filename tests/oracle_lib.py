@@ -26,6 +26,7 @@ def lib():
         _LIB = C.CDLL(path)
         _LIB.orc_last_error.restype = C.c_char_p
         _LIB.orc_handel_init_seconds.restype = C.c_double
+        _LIB.orc_gsf_shape_violations.restype = C.c_uint64
     return _LIB
 
 
@@ -206,3 +207,74 @@ class Handel:
         qm = np.zeros(32, np.int32)
         lib().orc_handel_stats(self.h, _p(dl, C.c_uint64), _p(qm, C.c_int32))
         return {"deliveredByLevel": dl[:self.levels].copy(), "queueMax": qm[:self.levels].copy()}
+
+
+class GSFSignature:
+    FIELDS = {"doneAt": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesReceived": 4, "sigChecked": 5,
+              "sigQueueSize": 6, "toVerifySize": 7, "verifiedCardinality": 8, "down": 10, "x": 11, "y": 12,
+              "nodePairingTime": 14, "extraLatency": 15}
+    LEVEL_FIELDS = {"posInLevel": 0, "remainingCalls": 1}
+    BITS = {"verifiedSignatures": 0, "levelVerified": 1, "individualSignatures": 2, "indivVerifiedSig": 3,
+            "waitedSigs": 4}
+
+    def __init__(self, node_count, threshold, pairing_time, timeout_per_level, period, accelerated_calls,
+                 nodes_down, nb=None, nl=None, seed=0):
+        ip = (C.c_int32 * 7)(node_count, threshold, pairing_time, timeout_per_level, period, accelerated_calls,
+                             nodes_down)
+        self.h = C.c_void_p()
+        self.n = node_count
+        _ck(lib().orc_gsf_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                 C.byref(self.h)))
+        self.levels = lib().orc_gsf_levels(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_gsf_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_gsf_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def set_copy_on_delivery(self, on=True):
+        lib().orc_gsf_set_copy_on_delivery(self.h, int(on))
+
+    def cont_if(self):
+        return bool(lib().orc_gsf_cont_if(self.h))
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_gsf_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def read_level(self, field):
+        out = np.zeros((self.n, self.levels), np.int32)
+        _ck(lib().orc_gsf_read_level(self.h, self.LEVEL_FIELDS[field], _p(out, C.c_int32)))
+        return out
+
+    def read_bits(self, which):
+        w = (self.n + 63) // 64
+        out = np.zeros((self.n, w), np.uint64)
+        _ck(lib().orc_gsf_read_bits(self.h, self.BITS[which], _p(out, C.c_uint64)))
+        return out
+
+    def read_peers(self, node, level):
+        out = np.zeros(self.n, np.int32)
+        cnt = C.c_int32()
+        lib().orc_gsf_read_peers(self.h, node, level, _p(out, C.c_int32), C.byref(cnt))
+        return out[:cnt.value].copy()
+
+    def info(self, with_queue=True):
+        t, q, r, d, k, qm = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        s = C.c_double()
+        lib().orc_gsf_info(self.h, C.byref(t), C.byref(q) if with_queue else None, C.byref(r), C.byref(d),
+                           C.byref(k), C.byref(qm), C.byref(s))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value,
+                "queueMax": qm.value, "init_s": s.value}
+
+    def stats(self):
+        dl = np.zeros(32, np.uint64)
+        lib().orc_gsf_stats(self.h, _p(dl, C.c_uint64))
+        return {"deliveredByLevel": dl[:self.levels].copy(),
+                "shapeViolations": int(lib().orc_gsf_shape_violations(self.h))}
