@@ -41,7 +41,8 @@ typedef struct {
   int64_t outbox_records;       /* max records emitted within one simulated ms */
   int64_t chain_dests;          /* total destination ids held by in-flight multi-destination envelopes */
   int32_t chain_slots;          /* in-flight multi-destination envelopes (C/Envelope.java:57) */
-  int32_t queue_cap;            /* Handel: per (node, level) toVerifyAgg capacity (P/Handel.java:385), <= 64 */
+  int32_t queue_cap;            /* Handel: per (node, level) toVerifyAgg capacity (P/Handel.java:385), <= 64;
+                                   GSFSignature: per node toVerify capacity (P/GSFSignature.java:167), <= 512 */
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -91,7 +92,7 @@ int32_t wg_register_task(wg_engine* e, uint32_t task, uint32_t arg, int32_t star
 int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, int32_t period, int32_t node);
 
 /* ---- resident protocols ----------------------------------------------------------------- */
-typedef enum { WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2 } wg_proto_id;
+typedef enum { WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3 } wg_proto_id;
 
 /* Handel parameters: HandelParameters ctor order (P/Handel.java:97-142) + WindowParameters (:147-174) */
 typedef struct {
@@ -112,6 +113,21 @@ typedef struct {
   const int32_t* peers;
 } wg_handel_init_state;
 
+/* GSFSignature parameters: GSFSignatureParameters ctor order (P/GSFSignature.java:59-84) */
+typedef struct {
+  int32_t nodeCount, threshold, pairingTime, timeoutPerLevelMs, periodDurationMs, acceleratedCallsCount, nodesDown;
+} wg_gsf_params;
+
+/* Per-node state produced by GSFSignature.init() (P/GSFSignature.java:611-635), uploaded once:
+ *   nodePairingTime[n]   GSFNode.nodePairingTime (:170)
+ *   peers[n*(n-1)]       row i = concatenation over levels 1..L-1 of SFLevel.peers (randomSubset's shuffle of the
+ *                        level's waitedSigs, :278, :462-476); level l occupies [2^(l-1)-1, 2^l-1). Ignored for
+ *                        down nodes (they never get levels, :627-634). */
+typedef struct {
+  const int32_t* nodePairingTime;
+  const int32_t* peers;
+} wg_gsf_init_state;
+
 int32_t wg_protocol_load(wg_engine* e, int32_t proto_id, const void* params, const void* init_state);
 
 /* ---- run -------------------------------------------------------------------------------- */
@@ -131,7 +147,8 @@ int32_t wg_queue_size(wg_engine* e, int64_t* size);             /* msgs.size()  
 int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt(t) :212-220 */
 
 /* The resident protocol's continuation predicate of the RunMultipleTimes loop (C/RunMultipleTimes.java:50-64),
- * evaluated on the device: Handel.newContIf (P/Handel.java:1044-1053). *cont = 1 while the run must go on. */
+ * evaluated on the device: Handel.newContIf (P/Handel.java:1044-1053), GSFSignature.newConfIf
+ * (P/GSFSignature.java:670-683). *cont = 1 while the run must go on. */
 int32_t wg_protocol_cont_if(wg_engine* e, int32_t* cont);
 
 /* ---- batches: RunMultipleTimes on the device ------------------------------------------------ */
@@ -159,16 +176,24 @@ typedef enum {
   WG_F_PONG = 16,
   /* Handel HNode (P/Handel.java:280-299) */
   WG_F_SIGS_CHECKED = 32, WG_F_SIG_QUEUE_SIZE = 33, WG_F_MSG_FILTERED = 34, WG_F_CURR_WINDOW_SIZE = 35,
-  WG_F_ADDED_CYCLE = 36, WG_F_START_AT = 37, WG_F_NODE_PAIRING_TIME = 38
+  WG_F_ADDED_CYCLE = 36, WG_F_START_AT = 37, WG_F_NODE_PAIRING_TIME = 38,
+  /* GSFSignature GSFNode (P/GSFSignature.java:166-175): sigChecked, sigQueueSize, toVerify.size(),
+   * verifiedSignatures.cardinality() */
+  WG_F_GSF_SIG_CHECKED = 48, WG_F_GSF_SIG_QUEUE_SIZE = 49, WG_F_GSF_TO_VERIFY_SIZE = 50,
+  WG_F_GSF_VERIFIED_CARDINALITY = 51
 } wg_field;
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */
-  WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2
+  WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2,
+  WG_LF_REMAINING_CALLS = 3 /* GSF SFLevel.remainingCalls (P/GSFSignature.java:257) */
 } wg_level_field;
 int32_t wg_read_level_i32(wg_engine* e, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels);
 typedef enum { /* Handel HLevel bitsets (P/Handel.java:373-394) as one nodeCount-bit row per node, bit j = node j */
   WG_B_TOTAL_INCOMING = 0, WG_B_LAST_AGG_VERIFIED = 1, WG_B_VERIFIED_IND = 2, WG_B_TO_VERIFY_IND = 3,
-  WG_B_FINISHED_PEERS = 4
+  WG_B_FINISHED_PEERS = 4,
+  /* GSFSignature: GSFNode.verifiedSignatures (= the union of SFLevel.verifiedSignatures, :171,:244) and the
+   * unions over levels of SFLevel.individualSignatures / indivVerifiedSig (:245-246) */
+  WG_B_GSF_VERIFIED = 8, WG_B_GSF_INDIVIDUAL = 9, WG_B_GSF_INDIV_VERIFIED = 10
 } wg_bits_field;
 int32_t wg_read_bits(wg_engine* e, int32_t field, uint64_t* dst, int32_t n_nodes, int32_t words_per_node);
 int32_t wg_levels(wg_engine* e, int32_t* levels);

@@ -5,6 +5,7 @@
  * with java.util.Random semantics and hands the result to the C ABI of wittgpu.h:
  *   PingPong.init()  P/PingPong.java:81-87
  *   Handel.init()    P/Handel.java:957-1014  (+ HandelParameters checks :113-125)
+ *   GSFSignature.init()  P/GSFSignature.java:611-635  (+ GSFSignatureParameters checks :69-74)
  * (P/ = protocols/src/main/java/net/consensys/wittgenstein/protocols/)
  */
 #ifndef WITTGPU_HOST_H
@@ -22,6 +23,8 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
                             const wg_config* cfg, wg_engine** out);
 int32_t wgh_handel_create(const wg_handel_params* params, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out);
+int32_t wgh_gsf_create(const wg_gsf_params* params, const char* nodeBuilderName, const char* latencyName,
+                       int64_t seed, const wg_config* cfg, wg_engine** out);
 const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);

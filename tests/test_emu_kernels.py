@@ -32,6 +32,7 @@ def emulated_kernels(oracle):
 
 import test_gpu_batch as tb  # noqa: E402
 import test_gpu_engine as te  # noqa: E402
+import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
@@ -89,3 +90,22 @@ def test_batch_every_ms():
 
 def test_batch_pingpong_active_mask():
     tb.test_pingpong_batch_and_active_mask()
+
+
+def test_gsf_reference_parameters():  # PT/GSFSignatureTest.java parameters
+    tg.test_reference_test_parameters_every_ms()
+
+
+def test_gsf_dead_nodes_and_long_lists():
+    tg.test_simple_threshold_with_dead_nodes()
+    tg.lockstep((128, 96, 6, 10, 5, 10, 25), tg.NBG, total=300, config={"queue_cap": 256})
+
+
+def test_gsf_256_to_convergence():
+    tg.test_256_chunks_of_10_to_convergence()
+
+
+def test_gsf_multiword_levels_and_overflow():
+    tg.lockstep((512, 500, 3, 50, 10, 10, 0), seed=5, step=10, total=150)
+    tg.test_queue_capacity_overflow_is_loud()
+    tg.test_unsupported_shapes_are_loud()

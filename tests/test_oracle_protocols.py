@@ -31,3 +31,82 @@ def test_handel_invariants(oracle):
     #  when a new aggregate intersects it — P/Handel.java:713-716 — so only doneAt is monotone)
     st = h.stats()
     assert st["deliveredByLevel"].sum() == h.info(False)["delivered"]
+
+
+# ---- GSFSignature: PT/GSFSignatureTest.java restated against the oracle ----------------------------------
+GSF_NB = "RANDOM_SPEED=GAUSSIAN_TOR=0.00"  # RegistryNodeBuilders.name(RANDOM, true, 0)  (PT/GSFSignatureTest.java:11)
+GSF_NL = "NetworkLatencyByDistanceWJitter"
+
+
+def test_gsf_init_and_max_sig_in_level(oracle):  # testInit :22-47, testMaxSigInLevel :49-57
+    g = o.GSFSignature(32, 1, 3, 20, 10, 10, 0, GSF_NB, GSF_NL)
+    assert g.levels == 6
+    assert [len(g.read_peers(0, l)) for l in range(6)] == [0, 1, 2, 4, 8, 16]
+    assert g.read_peers(0, 1)[0] == 1
+    lv = g.read_bits("levelVerified")
+    assert lv[0, 0] == 1  # level 0 holds the node's own signature, the other levels nothing
+    waited = g.read_bits("waitedSigs")
+    assert bin(int(waited[0, 0])).count("1") == 1 + 1 + 2 + 4 + 8 + 16  # expectedSigs 1,1,2,4,8,16
+
+
+def test_gsf_send(oracle):  # testSend :59-64: after runMs(1) every node has sent its signature to its peer
+    g = o.GSFSignature(32, 1, 3, 20, 10, 10, 0, GSF_NB, GSF_NL)
+    g.run_ms(1)
+    assert g.info()["queue"] == 64
+
+
+def test_gsf_dead_nodes(oracle):  # testDeadNodes :73-80
+    g = o.GSFSignature(32, int(0.8 * 32), 3, 20, 10, 10, int(0.1 * 32), GSF_NB, GSF_NL)
+    assert g.read("down").sum() == 3
+
+
+def test_gsf_simple_run_and_threshold(oracle):  # testSimpleRun :95-105, testSimpleThreshold :107-124
+    g = o.GSFSignature(32, 1, 3, 20, 10, 10, 0, GSF_NB, GSF_NL)
+    g.run_ms(10000)
+    assert (g.read("verifiedCardinality") == 32).all()
+    g = o.GSFSignature(64, int(.50 * 64), 3, 20, 10, 10, int(.2 * 64), GSF_NB, GSF_NL)
+    g.run_ms(10000)
+    card, down = g.read("verifiedCardinality"), g.read("down") != 0
+    assert (card[down] == 1).all()
+    assert ((card[~down] >= 32) & (card[~down] <= 64)).all()
+
+
+def _gsf_state(g):
+    return ([g.read(f) for f in ("doneAt", "msgReceived", "msgSent", "bytesSent", "sigChecked", "sigQueueSize",
+                                 "toVerifySize")] +
+            [g.read_bits(b) for b in ("verifiedSignatures", "levelVerified", "individualSignatures", "indivVerifiedSig")] +
+            [g.read_level("posInLevel"), g.read_level("remainingCalls"), g.info()["rng"], g.info()["queue"]])
+
+
+def test_gsf_copy_is_deterministic(oracle):  # testCopy :126-147 (lock-step, every ms)
+    a = o.GSFSignature(128, int(.75 * 128), 6, 10, 5, 10, int(.2 * 128), GSF_NB, GSF_NL)
+    b = o.GSFSignature(128, int(.75 * 128), 6, 10, 5, 10, int(.2 * 128), GSF_NB, GSF_NL)
+    for _ in range(400):
+        a.run_ms(1)
+        b.run_ms(1)
+        assert a.info()["queue"] == b.info()["queue"]
+        assert (a.read("doneAt") == b.read("doneAt")).all()
+        assert (a.read_bits("verifiedSignatures") == b.read_bits("verifiedSignatures")).all()
+        assert (a.read("toVerifySize") == b.read("toVerifySize")).all()
+
+
+def test_gsf_aliasing_is_unobservable(oracle):
+    """updateVerifiedSignatures ORs into the BitSet of the message object (P/GSFSignature.java:390,419), which a
+    multi-destination send shares between its receivers. The device protocol keeps a private copy per receiver;
+    that is exact because the shared objects are always whole level blocks (or larger) — shown here by running
+    the oracle with and without sharing, and by the payload-shape counter — and because GSFNode.verifiedSignatures
+    is always the union of the levels' verifiedSignatures (the device keeps one row for both)."""
+    for (n, thr, pair, to, per, acc, down, nb, seed) in [
+            (128, 96, 6, 10, 5, 10, 25, GSF_NB, 0), (512, 500, 3, 50, 10, 10, 0, "RANDOM_SPEED=CONSTANT_TOR=0.00", 3),
+            (256, 200, 2, 30, 7, 3, 20, "RANDOM_SPEED=CONSTANT_TOR=0.33", 11)]:
+        a = o.GSFSignature(n, thr, pair, to, per, acc, down, nb, GSF_NL, seed)
+        b = o.GSFSignature(n, thr, pair, to, per, acc, down, nb, GSF_NL, seed)
+        b.set_copy_on_delivery()
+        for _ in range(100):
+            a.run_ms(7)
+            b.run_ms(7)
+            for x, y in zip(_gsf_state(a), _gsf_state(b)):
+                assert np.array_equal(x, y)
+        assert a.stats()["shapeViolations"] == 0
+        live = a.read("down") == 0
+        assert np.array_equal(a.read_bits("levelVerified")[live], a.read_bits("verifiedSignatures")[live])

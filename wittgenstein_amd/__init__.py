@@ -5,7 +5,9 @@ package is the thin host-side mirror of the reference's Java surface used by tes
 """
 from .core import (Batch, EngineCapacityError, HipError, IllegalArgumentException, IllegalStateException, Network,
                    UnsupportedError)
-from .protocols import Handel, HandelParameters, PingPong, PingPongParameters
+from .protocols import (GSFSignature, GSFSignatureParameters, Handel, HandelParameters, PingPong,
+                        PingPongParameters)
 
-__all__ = ["Network", "Batch", "PingPong", "PingPongParameters", "Handel", "HandelParameters", "IllegalArgumentException",
+__all__ = ["Network", "Batch", "PingPong", "PingPongParameters", "Handel", "HandelParameters", "GSFSignature",
+           "GSFSignatureParameters", "IllegalArgumentException",
            "IllegalStateException", "EngineCapacityError", "HipError", "UnsupportedError"]

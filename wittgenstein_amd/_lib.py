@@ -22,6 +22,12 @@ class wg_handel_params(C.Structure):
         "nodesDown", "desynchronizedStart", "windowInitial", "windowMinimum", "windowMaximum")]
 
 
+class wg_gsf_params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nodeCount", "threshold", "pairingTime", "timeoutPerLevelMs", "periodDurationMs", "acceleratedCallsCount",
+        "nodesDown")]
+
+
 class wg_run_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("delivered", "tasks", "events", "draws", "simulated_ms", "wall_ns",
                                          "payload_bytes")]
@@ -40,7 +46,7 @@ ABI_SYMBOLS = [
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
     "wg_protocol_cont_if", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_profile_enable", "wg_profile_read",
-    "wgh_pingpong_create", "wgh_handel_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
+    "wgh_pingpong_create", "wgh_handel_create", "wgh_gsf_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",
 ]
 

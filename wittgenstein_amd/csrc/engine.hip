@@ -643,8 +643,8 @@ void Engine::check_device_errors() {
   if (e & ERR_CHAIN_SLOTS) m += "wg_config.chain_slots exhausted; ";
   if (e & ERR_CHAIN_DESTS) m += "wg_config.chain_dests ring overrun; ";
   if (e & ERR_PAYLOAD) m += "wg_config.payload_words ring overrun; ";
-  if (e & ERR_QUEUE_CAP) m += "Handel toVerifyAgg exceeded wg_config.queue_cap; ";
-  if (e & ERR_PENDING) m += "Handel pending-verification table full; ";
+  if (e & ERR_QUEUE_CAP) m += "toVerify list (Handel toVerifyAgg / GSFSignature toVerify) exceeded wg_config.queue_cap; ";
+  if (e & ERR_PENDING) m += "pending-verification table full; ";
   if (e & ERR_MULTI_TOO_BIG) {
     m += "device-side multi-destination send with more than 64 destinations; ";
     code = WG_EUNSUPPORTED;
@@ -672,6 +672,9 @@ void Engine::load_protocol(int32_t id, const void* params, const void* initState
   } else if (id == WG_PROTO_HANDEL) {
     if (!params || !initState) throw WgError(WG_EINVAL, "Handel needs wg_handel_params and wg_handel_init_state");
     proto = make_handel_host(*this, *(const wg_handel_params*)params, *(const wg_handel_init_state*)initState);
+  } else if (id == WG_PROTO_GSF) {
+    if (!params || !initState) throw WgError(WG_EINVAL, "GSFSignature needs wg_gsf_params and wg_gsf_init_state");
+    proto = make_gsf_host(*this, *(const wg_gsf_params*)params, *(const wg_gsf_init_state*)initState);
   } else {
     throw WgError(WG_EINVAL, "unknown protocol id");
   }
@@ -1191,5 +1194,209 @@ struct HandelHost : ProtoHost {
 ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st) {
   return new HandelHost(e, p, st);
 }
+
+}  // namespace wg
+
+// ================================================================================================
+// GSFSignature resident protocol: host side
+#include "proto_gsf.hip.h"
+
+namespace wg {
+
+template void Engine::scan<GsfCondF>(const Group&, const GsfState*);
+
+__global__ void k_gsf_init(GsfState s, const uint8_t* down) {
+  int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.N) return;
+  // GSFNode(): verifiedSignatures.set(nodeId) (:179) — for every node, also the ones stopped later;
+  // SFLevel() for level 0 (:263-270) and remainingCalls = peers.size() for the others (:282)
+  s.V[(size_t)node * s.W + (node >> 6)] |= 1ULL << (node & 63);
+  size_t i0 = (size_t)node * s.L;
+  s.cV[i0] = 1;
+  s.cU[i0] = 1;
+  for (int l = 1; l < s.L; l++) s.rem[i0 + l] = down[node] ? 0 : 1 << (l - 1);
+  // registerConditionalTask(checkSigs, 1, nodePairingTime, ...) for live nodes (:631-632)
+  s.ctMinStart[node] = down[node] ? INT32_MAX : 1;
+}
+
+// GSFSignature.newConfIf (P/GSFSignature.java:670-683): some live node holds fewer than `threshold` signatures
+__global__ void k_gsf_cont_if(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, uint32_t* out) {
+  const EngineDev& d = tab[blockIdx.y];
+  const GsfState& s = stab[blockIdx.y];
+  int node = blockIdx.x * blockDim.x + threadIdx.x;
+  bool c = false;
+  if (node < s.N && !d.nodes.down[node]) {
+    int tot = 0;
+    for (int l = 0; l < s.L; l++) tot += s.cV[(size_t)node * s.L + l];
+    c = tot < s.p.threshold;
+  }
+  if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
+}
+
+struct GsfHost : ProtoHost {
+  GsfState st{};
+  Engine& eng;
+  uint32_t* dCont = nullptr;
+  GsfHost(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& init) : eng(e) {
+    const int32_t N = p.nodeCount;
+    if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "GSFSignature nodeCount != nodes in the network");
+    if (N < 2 || (N & (N - 1)))
+      throw WgError(WG_EUNSUPPORTED, "the resident GSFSignature needs a power-of-two nodeCount");
+    if (N > (1 << 24)) throw WgError(WG_EUNSUPPORTED, "nodeCount > 2^24");
+    if (!init.nodePairingTime || !init.peers) throw WgError(WG_EINVAL, "wg_gsf_init_state has NULL members");
+    if (p.acceleratedCallsCount > 64)
+      throw WgError(WG_EUNSUPPORTED, "acceleratedCallsCount > 64 (device multi-destination sends hold <= 64 ids)");
+    if (p.periodDurationMs <= 0) throw WgError(WG_EINVAL, "periodDurationMs");
+    int L = 1;
+    while ((1 << L) <= N) L++;  // levels 0..log2(N) (:182-192)
+    if (L > MAX_LEVELS) throw WgError(WG_EINVAL, "too many levels");
+    const int W = N >= 64 ? N / 64 : 1;
+    int Q = e.cfg.queue_cap > 0 ? e.cfg.queue_cap : 128;
+    Q = (Q + 63) / 64 * 64;
+    if (Q > G_MAX_Q) throw WgError(WG_EINVAL, "queue_cap must be <= 512 for GSFSignature");
+    e.ensure_device();
+    if (p.periodDurationMs >= e.dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms <= period");
+    st.p = p;
+    st.N = N;
+    st.L = L;
+    st.W = W;
+    st.Q = Q;
+    st.SW = N >= 128 ? N / 128 : 1;
+    const size_t rows = (size_t)N * W;
+    st.V = e.dalloc<uint64_t>(rows);
+    st.IS = e.dalloc<uint64_t>(rows);
+    st.IV = e.dalloc<uint64_t>(rows);
+    st.peers = e.dalloc<int32_t>((size_t)N * (N - 1), false);
+    st.pairing = e.dalloc<int32_t>(N);
+    st.sigChecked = e.dalloc<int32_t>(N);
+    st.sigQueueSize = e.dalloc<int32_t>(N);
+    st.tvLen = e.dalloc<int32_t>(N);
+    st.ctMinStart = e.dalloc<int32_t>(N);
+    st.ctEpoch = e.dalloc<uint32_t>(N);
+    const size_t NL = (size_t)N * L;
+    st.pos = e.dalloc<int32_t>(NL);
+    st.rem = e.dalloc<int32_t>(NL);
+    st.cV = e.dalloc<int32_t>(NL);
+    st.cIV = e.dalloc<int32_t>(NL);
+    st.cU = e.dalloc<int32_t>(NL);
+    st.tvEnt = e.dalloc<uint64_t>((size_t)N * Q, false);
+    st.tvUsed = e.dalloc<uint64_t>((size_t)N * (Q / 64));
+    st.tvSig = e.dalloc<uint64_t>((size_t)N * Q * st.SW, false);
+    {
+      uint32_t off = 0;
+      for (int l = 0; l < L; l++) {
+        st.lvlOff[l] = off;
+        off += l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
+      }
+      st.snapStride = off;
+      st.snapNb = (uint32_t)(e.dev.horizon / p.periodDurationMs) + 2;  // a snapshot is read within < horizon ms
+      uint64_t words = (uint64_t)st.snapNb * N * st.snapStride;
+      if (words >= 0x100000000ull) throw WgError(WG_ENOMEM, "GSF snapshot ring exceeds 2^32 words: lower horizon_ms");
+      st.snap = e.dalloc<uint64_t>(words, false);
+    }
+    e.dev.boundMsg = 0;           // onNewSig never sends
+    e.dev.boundTask[0] = L - 1;   // doCycle: one send per level >= 1 (+1 periodic re-arm added by expand)
+    e.dev.boundTask[1] = L - 1;   // updateVerifiedSignatures: one accelerated send per higher level
+    e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
+    st.pend = e.dalloc<uint32_t>((size_t)N * G_PEND);
+    st.pendFrom = e.dalloc<int32_t>((size_t)N * G_PEND);
+    st.runList = e.dalloc<uint32_t>(N);
+    st.runCount = e.dalloc<uint32_t>(1);
+    st.candFlag = e.dalloc<uint8_t>(N);
+    st.candPend = e.dalloc<uint8_t>(N);
+    st.condList = e.dalloc<uint32_t>(N);
+    WG_HIP(hipMemcpy(st.pairing, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * (N - 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gsf_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down);
+    WG_HIP(hipStreamSynchronize(e.stream));
+  }
+  bool has_cond() const override { return true; }
+  int levels() const override { return st.L; }
+  bool cont_if(Engine& e, int32_t* out) override {
+    if (!dCont) dCont = e.dalloc<uint32_t>(1);
+    Group g = e.self();
+    WG_HIP(hipMemsetAsync(dCont, 0, 4, e.stream));
+    launch_cont_if(g, dCont);
+    uint32_t v = 0;
+    WG_HIP(hipMemcpyAsync(&v, dCont, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    *out = (int32_t)v;
+    return true;
+  }
+  int host_msg_size(uint32_t msg) const override {
+    int l = (int)(msg & 31u);
+    return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 96;
+  }
+  int payload_bytes_of_level(int l) const override {
+    return l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) / 8 : 8);
+  }
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
+  void launch_cond(Engine& profOwner, const Group& g) override {
+    const GsfState* stab = (const GsfState*)g.stab;
+    {
+      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
+      hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
+    Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
+    Engine::scan<GsfCondF>(g, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab,
+                       (const GsfState*)g.stab);
+  }
+  bool launch_cont_if(const Group& g, uint32_t* dOut) override {
+    hipLaunchKernelGGL(k_gsf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,
+                       (const GsfState*)g.stab, dOut);
+    return true;
+  }
+  bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
+    const int32_t* src = nullptr;
+    switch (field) {
+      case WG_F_GSF_SIG_CHECKED: src = st.sigChecked; break;
+      case WG_F_GSF_SIG_QUEUE_SIZE: src = st.sigQueueSize; break;
+      case WG_F_GSF_TO_VERIFY_SIZE: src = st.tvLen; break;
+      case WG_F_NODE_PAIRING_TIME: src = st.pairing; break;
+      case WG_F_GSF_VERIFIED_CARDINALITY: {
+        std::vector<int32_t> h((size_t)n * st.L);
+        WG_HIP(hipMemcpy(h.data(), st.cV, 4 * h.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) {
+          int64_t t = 0;
+          for (int l = 0; l < st.L; l++) t += h[(size_t)i * st.L + l];
+          dst[i] = t;
+        }
+        return true;
+      }
+      default: return false;
+    }
+    std::vector<int32_t> h(n);
+    WG_HIP(hipMemcpy(h.data(), src, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) dst[i] = h[i];
+    return true;
+  }
+  bool read_level_i32(Engine&, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
+    if (n != st.N || L != st.L) throw WgError(WG_EINVAL, "shape must be [nodeCount][levels]");
+    const int32_t* src = field == WG_LF_POS_IN_LEVEL ? st.pos : field == WG_LF_REMAINING_CALLS ? st.rem : nullptr;
+    if (!src) return false;
+    WG_HIP(hipMemcpy(dst, src, 4 * (size_t)n * L, hipMemcpyDeviceToHost));
+    return true;
+  }
+  bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {
+    if (n != st.N || w != st.W) throw WgError(WG_EINVAL, "shape must be [nodeCount][max(1, nodeCount/64)]");
+    const uint64_t* src = nullptr;
+    switch (field) {
+      case WG_B_GSF_VERIFIED: src = st.V; break;
+      case WG_B_GSF_INDIVIDUAL: src = st.IS; break;
+      case WG_B_GSF_INDIV_VERIFIED: src = st.IV; break;
+      default: return false;
+    }
+    WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
+    return true;
+  }
+};
+
+ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st) { return new GsfHost(e, p, st); }
 
 }  // namespace wg

@@ -218,5 +218,6 @@ class Batch {
 
 ProtoHost* make_pingpong_host(Engine& e);
 ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st);
+ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st);
 
 }  // namespace wg

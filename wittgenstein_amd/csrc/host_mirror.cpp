@@ -287,4 +287,80 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   return WG_OK;
 }
 
+int32_t wgh_gsf_create(const wg_gsf_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                       const wg_config* cfg, wg_engine** out) {
+  if (!out || !pp) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  const wg_gsf_params p = *pp;
+  const int32_t N = p.nodeCount;
+  // GSFSignatureParameters ctor checks (P/GSFSignature.java:69-74)
+  if (N <= 0 || p.nodesDown >= N || p.nodesDown < 0 || p.threshold > N || p.nodesDown + p.threshold > N) {
+    g_err = "nodeCount=" + std::to_string(N) + ", threshold=" + std::to_string(p.threshold);
+    return WG_EINVAL;
+  }
+  if (p.periodDurationMs <= 0 || p.pairingTime < 0) {
+    g_err = "period/pairingTime";
+    return WG_EINVAL;
+  }
+  if (__builtin_popcount((unsigned)N) != 1 || N < 2) {
+    g_err = "the resident GSFSignature needs a power-of-two nodeCount";
+    return WG_EUNSUPPORTED;
+  }
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // GSFSignature ctor :109-114
+  JavaRandom rd(seed);
+  // init() :611-635 — node ctors, then the nodesDown loop, then levels + tasks of the live nodes in id order
+  NodeSoA nodes;
+  std::vector<int32_t> pairing(N);
+  for (int i = 0; i < N; i++) {
+    build_node(rd, b, nodes);
+    double pt = p.pairingTime * nodes.speed[i];
+    pairing[i] = (int32_t)(pt > 1.0 ? pt : 1.0);  // (int) Math.max(1, pairingTime * speedRatio)  :170
+  }
+  for (int setDown = 0; setDown < p.nodesDown;) {
+    int32_t d = rd.nextInt(N);
+    if (!nodes.down[d] && d != 1) {
+      nodes.down[d] = 1;
+      setDown++;
+    }
+  }
+  CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
+                  nodes.speed.data()));
+  const int L = 32 - __builtin_clz((unsigned)N);  // levels 0..log2(N)
+  std::vector<int32_t> peers((size_t)N * (N - 1), -1);
+  for (int i = 0; i < N; i++) {
+    if (nodes.down[i]) continue;
+    // initLevel() :182-192 -> SFLevel(previous, allPreviousNodes) :273-283: peers = randomSubset(waitedSigs):
+    // the sibling block in ascending id, Collections.shuffle(res, rd) (:462-476)
+    for (int l = 1; l < L; l++) {
+      const int size = 1 << (l - 1);
+      const int base = ((i >> (l - 1)) ^ 1) << (l - 1);
+      int32_t* dst = peers.data() + (size_t)i * (N - 1) + (size - 1);
+      for (int k = 0; k < size; k++) dst[k] = base + k;
+      for (int32_t k = size; k > 1; k--) std::swap(dst[k - 1], dst[rd.nextInt(k)]);
+    }
+    // registerPeriodicTask(n::doCycle, 1, periodDurationMs, n) :630; the conditional task (checkSigs, :631-632)
+    // is part of the resident protocol's state (minStartTime = 1)
+    CK(wg_register_periodic_task(e, /*doCycle*/ 0u, 1, p.periodDurationMs, i));
+  }
+  CK(wg_rng_set_state(e, rd.s));
+  wg_gsf_init_state st;
+  st.nodePairingTime = pairing.data();
+  st.peers = peers.data();
+  CK(wg_protocol_load(e, WG_PROTO_GSF, &p, &st));
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,612 @@
+// GSFSignature (P/GSFSignature.java) — gossiping San Fermin — as a resident device protocol. One
+// wavefront per simulated node, lanes = 64-bit words of the node's bitset rows (as proto_handel.hip.h).
+//
+// What makes it resident in a small state (each point is checked against the oracle by tests/):
+//  * SFLevel l (l >= 1) waits for the node's aligned sibling block of 2^(l-1) ids (allSigsAtLevel minus
+//    the previous levels, :274-283, :362-375); the blocks of different levels are disjoint, so ONE row
+//    per kind holds every level: V (SFLevel.verifiedSignatures; its union over levels is exactly
+//    GSFNode.verifiedSignatures :171 — both are updated by the same two statements :423-427), IS
+//    (individualSignatures), IV (indivVerifiedSig). Bit `node` of V is level 0.
+//  * A SendSigs payload (`toSend` of doCycle :217-224, `bestToSend` of the accelerated calls :433-443) is
+//    getLastFinishedLevel() | verified(levels below l). With k = first incomplete level of the sender
+//    that is: k > l  the sender's aligned block of 2^(k-1) ids  ("OVER", strictly larger than the level)
+//             k == l the receiver's whole level block            ("FULL")
+//             k < l  the sender's verified bits of levels < l    ("PARTIAL": the only kind that needs
+//                    payload words; snapshot at send, private copy at delivery).
+//    updateVerifiedSignatures' in-place `sigs.or(...)` (:390, :419) mutates the message object that a
+//    multi-destination send shares between receivers; such messages are always FULL or OVER (accelerated
+//    calls are only made for completed levels), OR-ing subsets of the level block into them changes
+//    nothing, and every PARTIAL message has one receiver — so the aliasing is unobservable and a private
+//    copy per receiver is exact (tests/test_oracle_protocols.py::test_gsf_aliasing_is_unobservable).
+//  * toVerify (:167) is one list per node in arrival order: tvEnt[node][Q] entries
+//    {from, level, kind, slot | j}; PARTIAL entries own one of the node's Q payload slots.
+// N must be a power of two (the reference's own non-power-of-two test is disabled, PT/GSFSignatureTest.java:60-70).
+#pragma once
+#include "proto_handel.hip.h"
+
+namespace wg {
+
+constexpr int G_PEND = 4;  // outstanding updateVerifiedSignatures tasks per node
+constexpr int G_MAX_Q = 512;
+constexpr uint32_t G_TASK_DOCYCLE = 0;
+constexpr uint32_t G_TASK_UPDATE = 1;
+enum GsfKind : uint32_t { GK_PARTIAL = 0, GK_FULL = 1, GK_OVER = 2, GK_INDIV = 3 };
+
+struct GsfState {
+  wg_gsf_params p;
+  int32_t N, L, W, Q, SW;             // SW = payload slot size in 64-bit words (largest level block)
+  uint64_t *V, *IS, *IV;              // [N][W]
+  int32_t* peers;                     // [N][N-1] SFLevel.peers, level l at [2^(l-1)-1, 2^l-1)
+  int32_t *pairing, *sigChecked, *sigQueueSize, *tvLen;  // [N]
+  int32_t* ctMinStart;                // ConditionalTask.minStartTime
+  uint32_t* ctEpoch;                  // epoch in which the task left nextMessage()'s private copy
+  int32_t *pos, *rem, *cV, *cIV, *cU; // [N][L] posInLevel, remainingCalls, |V|, |IV|, |V u IV| inside the level block
+  uint64_t* tvEnt;                    // [N][Q] toVerify, list order
+  uint64_t* tvUsed;                   // [N][Q/64] payload slots in use
+  uint64_t* tvSig;                    // [N][Q][SW]
+  // doCycle snapshots (SendSigs.sigs = toSend.clone() :146): one doCycle per node and period window, so the
+  // snapshot of level l lives at snap[((t / period) % snapNb) * N + node][lvlOff[l] ...] (no allocation)
+  uint64_t* snap;
+  uint32_t snapNb, snapStride;
+  uint32_t lvlOff[MAX_LEVELS];
+  uint32_t* pend;                     // [N][G_PEND] valid<<31 | kind<<29 | level<<24 | slot or j
+  int32_t* pendFrom;                  // [N][G_PEND]
+  // conditional-task phase scratch
+  uint32_t* runList;                  // nodes whose checkSigs runs at this edge (unordered)
+  uint32_t* runCount;
+  uint8_t* candFlag;                  // [N] checkSigs found a best -> registers a task
+  uint8_t* candPend;                  // [N] its pend index
+  uint32_t* condList;                 // registering nodes in id order
+};
+
+__device__ __forceinline__ uint64_t g_ent(int32_t from, int l, uint32_t kind, uint32_t aux) {
+  return (uint64_t)(uint32_t)from | ((uint64_t)l << 24) | ((uint64_t)kind << 29) | ((uint64_t)aux << 32);
+}
+__device__ __forceinline__ int32_t g_ent_from(uint64_t e) { return (int32_t)(e & 0xFFFFFFu); }
+__device__ __forceinline__ int g_ent_level(uint64_t e) { return (int)((e >> 24) & 31u); }
+__device__ __forceinline__ uint32_t g_ent_kind(uint64_t e) { return (uint32_t)((e >> 29) & 3u); }
+__device__ __forceinline__ uint32_t g_ent_aux(uint64_t e) { return (uint32_t)(e >> 32) & 0xFFFFu; }
+__device__ __forceinline__ int g_msg_size(int l) { return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 96; }  // :150
+
+// evaluateSig's tail (:519-534) given the totals its three branches compute
+__device__ __forceinline__ int g_score(int l, int size, int newTotal, int added, bool single, bool interIV) {
+  if (added <= 0) return (single && !interIV) ? 1 : 0;
+  if (newTotal == size) return 1000000 - l * 10;
+  return 100000 - l * 100 + added;
+}
+
+// per-wave LDS mirror of the (node, level) scalars and the slot bitmap
+struct GLevels {
+  int32_t pos[MAX_LEVELS];
+  int32_t rem[MAX_LEVELS];
+  int32_t cV[MAX_LEVELS];
+  int32_t cIV[MAX_LEVELS];
+  int32_t cU[MAX_LEVELS];
+  unsigned long long used[G_MAX_Q / 64];
+};
+
+struct GsfProto {
+  typedef GsfState State;
+  typedef GLevels WaveShared;
+  struct NodeRegs {
+    long long doneAt;
+    int32_t sigQueueSize, tvLen;
+    uint32_t pend[G_PEND];
+    int32_t pendFrom[G_PEND];
+    GLevels* ls;
+  };
+
+  __device__ static int msg_size(const State&, uint32_t msg) { return g_msg_size((int)(msg & 31u)); }
+  __device__ static int msg_level(uint32_t msg) { return (int)(msg & 31u); }
+
+  __device__ static void load_levels(const State& s, int32_t node, GLevels* ls) {
+    for (int l = WG_LANE; l < s.L; l += 64) {
+      size_t i = (size_t)node * s.L + l;
+      ls->pos[l] = s.pos[i];
+      ls->rem[l] = s.rem[i];
+      ls->cV[l] = s.cV[i];
+      ls->cIV[l] = s.cIV[i];
+      ls->cU[l] = s.cU[i];
+    }
+    for (int q = WG_LANE; q < s.Q / 64; q += 64) ls->used[q] = s.tvUsed[(size_t)node * (s.Q / 64) + q];
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ static void store_levels(const State& s, int32_t node, const GLevels* ls) {
+    __builtin_amdgcn_wave_barrier();
+    for (int l = WG_LANE; l < s.L; l += 64) {
+      size_t i = (size_t)node * s.L + l;
+      s.pos[i] = ls->pos[l];
+      s.rem[i] = ls->rem[l];
+      s.cV[i] = ls->cV[l];
+      s.cIV[i] = ls->cIV[l];
+      s.cU[i] = ls->cU[l];
+    }
+    for (int q = WG_LANE; q < s.Q / 64; q += 64) s.tvUsed[(size_t)node * (s.Q / 64) + q] = ls->used[q];
+  }
+  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, GLevels* ls) {
+    const int32_t node = c.node;
+    r.doneAt = c.d.nodes.doneAt[node];
+    r.sigQueueSize = s.sigQueueSize[node];
+    r.tvLen = s.tvLen[node];
+#pragma unroll
+    for (int k = 0; k < G_PEND; k++) {
+      r.pend[k] = s.pend[(size_t)node * G_PEND + k];
+      r.pendFrom[k] = s.pendFrom[(size_t)node * G_PEND + k];
+    }
+    r.ls = ls;
+    load_levels(s, node, ls);
+  }
+  __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
+    const int32_t node = c.node;
+    store_levels(s, node, r.ls);
+    if (WG_LANE == 0) {
+      c.d.nodes.doneAt[node] = r.doneAt;
+      s.sigQueueSize[node] = r.sigQueueSize;
+      s.tvLen[node] = r.tvLen;
+#pragma unroll
+      for (int k = 0; k < G_PEND; k++) s.pend[(size_t)node * G_PEND + k] = r.pend[k];
+    }
+  }
+  __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    on_new_sig(c, s, r, from, msg, payload);
+  }
+  __device__ static void on_task(Ctx& c, const State& s, NodeRegs& r, uint32_t word, uint32_t arg) {
+    if (word == G_TASK_DOCYCLE)
+      do_cycle(c, s, r);
+    else
+      update_verified(c, s, r, arg);
+  }
+
+  __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int slot) {
+    return s.tvSig + ((size_t)node * s.Q + slot) * (size_t)s.SW;
+  }
+  // first incomplete level (levels below it form getLastFinishedLevel :194-211); L if every level is complete
+  __device__ static int first_incomplete(const State& s, const GLevels* ls) {
+    int k = 1;
+    while (k < s.L && ls->cV[k] == (1 << (k - 1))) k++;
+    return k;
+  }
+  // message word of a SendSigs built at level l while the sender's first incomplete level is k (header comment)
+  __device__ static uint32_t msg_word(int l, int k, bool levelFinished) {
+    uint32_t kind = k > l ? GK_OVER : (k == l ? GK_FULL : GK_PARTIAL);
+    return (uint32_t)l | (levelFinished ? 32u : 0u) | (kind << 6) | ((uint32_t)(k - 1) << 8);
+  }
+
+  // ---- Message.action: SendSigs -> onNewSig (:538-556) ----------------------------------------------
+  __device__ static void on_new_sig(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    const int l = (int)(msg & 31u);
+    const uint32_t kind = (msg >> 6) & 3u;
+    uint32_t aux = (msg >> 8) & 31u;
+    const int32_t node = c.node;
+    GLevels* ls = r.ls;
+    uint64_t* isRow = s.IS + (size_t)node * s.W;
+    const bool hadIS = row_get(isRow, from);
+    const int len = r.tvLen;
+    const int need = hadIS ? 1 : 2;
+    if (len + need > s.Q) {
+      if (WG_LANE == 0) set_err(c.d.g, ERR_QUEUE_CAP);
+      return;
+    }
+    if (kind == GK_PARTIAL) {
+      int slot = -1;
+      for (int q = 0; q < s.Q / 64 && slot < 0; q++) {
+        const unsigned long long u = ls->used[q];
+        if (~u) slot = q * 64 + __ffsll(~u) - 1;
+      }
+      if (slot < 0) {
+        if (WG_LANE == 0) set_err(c.d.g, ERR_QUEUE_CAP);
+        return;
+      }
+      const Lv v = sib_view(node, l);
+      const uint64_t* src = s.snap + payload;
+      uint64_t* dst = sig_ptr(s, node, slot);
+      H_FOR_WORDS(v, j) dst[j] = src[j];
+      __builtin_amdgcn_wave_barrier();  // every lane has read the slot bitmap before lane 0 changes it
+      if (WG_LANE == 0) ls->used[slot >> 6] |= 1ULL << (slot & 63);
+      aux = (uint32_t)slot;
+    }
+    if (WG_LANE == 0) {
+      uint64_t* ent = s.tvEnt + (size_t)node * s.Q;
+      ent[len] = g_ent(from, l, kind, aux);                         // toVerify.add(ssigs)
+      if (!hadIS) ent[len + 1] = g_ent(from, l, GK_INDIV, 0);       // the individual signature (:547-553)
+    }
+    if (!hadIS) row_set(isRow, from, true);
+    r.tvLen = len + need;
+    r.sigQueueSize = r.tvLen;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- PeriodicTask: doCycle (:213-225) -> SFLevel.doCycle (:317-327) -------------------------------
+  __device__ static void do_cycle(Ctx& c, const State& s, NodeRegs& r) {
+    GLevels* ls = r.ls;
+    const int32_t node = c.node;
+    const int k = first_incomplete(s, ls);
+    for (int l = 1; l < s.L; l++) {
+      const int rem = ls->rem[l], pos = ls->pos[l], cvl = ls->cV[l];
+      __builtin_amdgcn_wave_barrier();  // every lane has read the level's scalars before lane 0 replaces them
+      if (rem == 0) continue;
+      if (!(c.t >= l * s.p.timeoutPerLevelMs || k >= l)) continue;  // hasStarted :294-315
+      const int size = 1 << (l - 1);
+      const int32_t dest = s.peers[(size_t)node * (s.N - 1) + (size - 1) + pos];  // getRemainingPeers(1)
+      const uint32_t word = msg_word(l, k, cvl == size);
+      uint32_t ref = 0;
+      if (k < l) {  // PARTIAL: snapshot the verified bits of the levels below l (the node's own block)
+        const Lv v = own_view(node, l);
+        const uint64_t* vr = s.V + (size_t)node * s.W;
+        const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
+        ref = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride + s.lvlOff[l];
+        H_FOR_WORDS(v, j) s.snap[ref + j] = vr[v.bw + j] & v.mask;
+      }
+      c.send(dest, word, ref, g_msg_size(l));
+      if (WG_LANE == 0) {
+        ls->pos[l] = pos + 1 >= size ? 0 : pos + 1;
+        ls->rem[l] = rem - 1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- Task: updateVerifiedSignatures (:387-460) ------------------------------------------------------
+  __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
+    const int lane = WG_LANE;
+    const int32_t node = c.node;
+    const uint32_t pe = r.pend[arg & (G_PEND - 1)];
+    const int32_t from = r.pendFrom[arg & (G_PEND - 1)];
+    if (!(pe & 0x80000000u)) {
+      if (lane == 0) set_err(c.d.g, ERR_PROTOCOL);
+      return;
+    }
+    r.pend[arg & (G_PEND - 1)] = 0;
+    const uint32_t kind = (pe >> 29) & 3u;
+    const int l = (int)((pe >> 24) & 31u);
+    const uint32_t aux = pe & 0xFFFFu;
+    GLevels* ls = r.ls;
+    const Lv v = sib_view(node, l);
+    const int size = v.size;
+    uint64_t* vr = s.V + (size_t)node * s.W;
+    uint64_t* ivr = s.IV + (size_t)node * s.W;
+    const uint64_t* sig = kind == GK_PARTIAL ? sig_ptr(s, node, (int)aux) : nullptr;
+    const int wF = from >> 6, jF = wF - v.bw;
+    const uint64_t bitF = 1ULL << (from & 63);
+    // word j of the signature set, as held by the lane that owns row word v.bw + j
+    auto sword = [&](int j) -> uint64_t {
+      if (kind == GK_PARTIAL) return sig[j] & v.mask;
+      if (kind == GK_INDIV) return j == jF ? bitF : 0ULL;
+      return v.mask;  // FULL (and OVER after `sigs = waitedSigs.clone()` :412)
+    };
+    int cVl = ls->cV[l], cIVl = ls->cIV[l], cUl = ls->cU[l];
+    bool reset = false;
+    if (kind == GK_OVER) {
+      // the sender sent its next levels too (:397-413): every level i <= j whose block the set includes is
+      // completed outright
+      const int jTop = min((int)aux, s.L - 1);
+      uint32_t incomplete = 0;
+      for (int i = 1; i <= jTop; i++)
+        if (ls->cV[i] != (1 << (i - 1))) incomplete |= 1u << i;
+      __builtin_amdgcn_wave_barrier();  // every lane has read the counts before lane 0 replaces them
+      if (incomplete) {
+        reset = true;  // resetRemaining stays true from the first completed level on (:404-408)
+        for (int i = __ffs(incomplete) - 1; i <= jTop; i++) {
+          const int sz = 1 << (i - 1);
+          if ((incomplete >> i) & 1u) {
+            const Lv vi = sib_view(node, i);
+            H_FOR_WORDS(vi, j) vr[vi.bw + j] |= vi.mask;
+            if (lane == 0) {
+              ls->cV[i] = sz;
+              ls->cU[i] = sz;
+            }
+          }
+          if (lane == 0) ls->rem[i] = sz;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      cVl = ls->cV[l];
+      cUl = ls->cU[l];
+    } else {
+      // sigs.cardinality() == 1 -> indivVerifiedSig.set(from) (:388-390)
+      uint64_t a = 0;
+      H_FOR_WORDS(v, j) a += (uint64_t)__popcll(sword(j));
+      const int cs = (int)wave_sum64(a);
+      if (cs == 1) {
+        const uint64_t ivF = ld_coherent(ivr + wF), vF = ld_coherent(vr + wF);
+        if (!(ivF & bitF)) {
+          if (lane == (wF & 63)) ivr[wF] = ivF | bitF;
+          cIVl++;
+          if (!(vF & bitF)) cUl++;
+        }
+      }
+    }
+    // sigs |= indivVerifiedSig; merge with the level's verified set when disjoint (:390, :415-420)
+    uint64_t acc = 0, flg = 0;
+    H_FOR_WORDS(v, j) {
+      const uint64_t sg = sword(j) | (ivr[v.bw + j] & v.mask), vw = vr[v.bw + j] & v.mask;
+      acc += (uint64_t)__popcll(sg) | ((uint64_t)__popcll(sg | vw) << 24);
+      flg |= (uint64_t)((sg & vw) != 0);
+    }
+    acc = wave_sum64(acc);
+    const bool inter = __ballot(flg != 0) != 0;
+    const bool merge = cVl > 0 && !inter;
+    const int cFinal = merge ? (int)(acc >> 24) : (int)(acc & 0xFFFFFFu);
+    const bool improved = cFinal > cVl || reset;
+    if (improved) {
+      // verifiedSignatures.andNot(waitedSigs); verifiedSignatures.or(sigs) — level and node rows are one (:423-427)
+      H_FOR_WORDS(v, j) {
+        const uint64_t old = vr[v.bw + j];
+        const uint64_t nv = sword(j) | (ivr[v.bw + j] & v.mask) | (merge ? (old & v.mask) : 0ULL);
+        vr[v.bw + j] = (old & ~v.mask) | nv;
+      }
+      cVl = cFinal;
+      cUl = cFinal;  // the new set includes indivVerifiedSig
+    }
+    if (lane == 0) {
+      ls->cV[l] = cVl;
+      ls->cIV[l] = cIVl;
+      ls->cU[l] = cUl;
+      if (kind == GK_PARTIAL) ls->used[aux >> 6] &= ~(1ULL << (aux & 63));  // the message object dies with the task
+    }
+    if (improved && lane >= l && lane < s.L) ls->rem[lane] = 1 << (lane - 1);  // :421-425 (L <= 64 lanes)
+    __builtin_amdgcn_wave_barrier();
+    if (!improved) return;
+    if (s.p.acceleratedCallsCount > 0) {  // :429-444
+      const int k = first_incomplete(s, ls);
+      int cur = l;
+      while (cur <= k - 1 && cur < s.L - 1) {
+        cur++;
+        const int sz = 1 << (cur - 1);
+        const int rem = ls->rem[cur], p0 = ls->pos[cur];
+        const int n = min(s.p.acceleratedCallsCount, rem);  // getRemainingPeers(acceleratedCallsCount) :329-353
+        if (n > 0) {
+          __threadfence_block();
+          const uint32_t destOff = c.dest_reserve(n);
+          if (lane < n) c.dest_put(destOff, lane, s.peers[(size_t)node * (s.N - 1) + (sz - 1) + (p0 + lane) % sz]);
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            ls->pos[cur] = (p0 + n) % sz;
+            ls->rem[cur] = rem - n;
+          }
+          __threadfence_block();
+          c.send_list(destOff, n, msg_word(cur, k, ls->cV[cur] == sz), 0, g_msg_size(cur));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (r.doneAt == 0) {
+      int tot = 0;
+      for (int i = 0; i < s.L; i++) tot += ls->cV[i];
+      if (tot >= s.p.threshold) r.doneAt = c.t;
+    }
+  }
+};
+
+// ---- conditional-task phase (C/Network.java:543-566 driving GSFNode.checkSigs :558-584) --------------
+__global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  const int32_t t = d.g->now, until = d.g->until;
+  const uint32_t epoch = d.g->epoch;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t n0 = blockIdx.x * blockDim.x; n0 < (uint32_t)s.N; n0 += stride) {
+    const uint32_t node = n0 + threadIdx.x;
+    bool run = false;
+    if (node < (uint32_t)s.N) {
+      if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
+        const int32_t ms = s.ctMinStart[node];
+        if (ms <= until && ms <= t) {
+          s.ctEpoch[node] = epoch;
+          run = s.tvLen[node] > 0;  // startIf = !toVerify.isEmpty() (:632)
+        }
+      }
+      if (run) s.ctMinStart[node] = t + s.pairing[node];  // minStartTime = time + duration
+      s.candFlag[node] = 0;
+    }
+    const uint64_t m = __ballot(run);
+    if (m) {
+      uint32_t base = 0;
+      const int leader = __ffsll((unsigned long long)m) - 1;
+      if ((int)WG_LANE == leader) base = atomicAdd(s.runCount, (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
+    }
+  }
+}
+
+// checkSigs (:558-584) of every runner: score every toVerify entry (evaluateSig :482-535), drop the zeros,
+// take the FIRST entry with the greatest score out of the list and park it in the pend table.
+__global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  __shared__ GLevels shLevels[4];
+  __shared__ int32_t shNs[4][G_MAX_Q];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nRun = *s.runCount;
+  GLevels* ls = &shLevels[w];
+  for (uint32_t q = wave; q < nRun; q += nWaves) {
+    const int32_t node = (int32_t)s.runList[q];
+    GsfProto::load_levels(s, node, ls);
+    const uint64_t* vr = s.V + (size_t)node * s.W;
+    const uint64_t* ivr = s.IV + (size_t)node * s.W;
+    uint64_t* ent = s.tvEnt + (size_t)node * s.Q;
+    const int len = s.tvLen[node];
+    int bestScore = 0, bestIdx = -1;
+    uint64_t bestEnt = 0;
+    for (int base = 0; base < len; base += 64) {
+      const int i = base + lane;
+      const bool mine = i < len;
+      const uint64_t e = mine ? ent[i] : 0ULL;
+      const int32_t from = g_ent_from(e);
+      const int l = mine ? g_ent_level(e) : 1;
+      const uint32_t kind = g_ent_kind(e), aux = g_ent_aux(e);
+      const int size = 1 << (l - 1);
+      const int cVl = ls->cV[l];
+      const Lv v = sib_view(node, l);
+      int ns = 0;
+      bool wide = false;
+      if (mine && cVl < size) {  // :490-492
+        if (kind == GK_FULL) {
+          ns = 1000000 - l * 10;  // completes the level
+        } else if (kind == GK_OVER) {
+          ns = 100000 - l * 100 + ((1 << aux) - cVl);  // 2^j ids, a replace or a first set
+        } else if (kind == GK_INDIV) {
+          const uint64_t bit = 1ULL << (from & 63);
+          const bool vHas = (vr[from >> 6] & bit) != 0, ivHas = (ivr[from >> 6] & bit) != 0;
+          int newTotal, added;
+          if (cVl == 0) {
+            newTotal = 1;
+            added = 1;
+          } else if (vHas) {
+            newTotal = ls->cIV[l] + (ivHas ? 0 : 1);
+            added = newTotal - cVl;
+          } else {
+            newTotal = ls->cU[l] + (ivHas ? 0 : 1);
+            added = newTotal - cVl;
+          }
+          ns = g_score(l, size, newTotal, added, true, ivHas);
+        } else if (v.nw == 1) {
+          const uint64_t sg = *GsfProto::sig_ptr(s, node, (int)aux) & v.mask;
+          const uint64_t vw = vr[v.bw] & v.mask, iw = ivr[v.bw] & v.mask;
+          const int cs = __popcll(sg);
+          int newTotal;
+          if (cVl == 0)
+            newTotal = cs;
+          else if (sg & vw)
+            newTotal = __popcll(sg | iw);
+          else
+            newTotal = __popcll(sg | iw | vw);
+          ns = g_score(l, size, newTotal, cVl == 0 ? cs : newTotal - cVl, cs == 1, (sg & iw) != 0);
+        } else {
+          wide = true;
+        }
+      }
+      // PARTIAL entries of multi-word levels: the whole wavefront streams the block, one entry at a time
+      for (uint64_t m = __ballot(wide); m; m &= m - 1) {
+        const int src = __ffsll((unsigned long long)m) - 1;
+        const int el = __shfl(l, src, 64);
+        const int eslot = (int)__shfl(aux, src, 64);
+        const Lv ev = sib_view(node, el);
+        const uint64_t* sig = GsfProto::sig_ptr(s, node, eslot);
+        uint64_t a = 0, f = 0;
+        H_FOR_WORDS(ev, j) {
+          const uint64_t sg = sig[j], vw = vr[ev.bw + j], iw = ivr[ev.bw + j];
+          a += (uint64_t)__popcll(sg) | ((uint64_t)__popcll(sg | iw) << 21) | ((uint64_t)__popcll(sg | iw | vw) << 42);
+          f |= (uint64_t)((sg & vw) != 0) | ((uint64_t)((sg & iw) != 0) << 1);
+        }
+        a = wave_sum64(a);
+        const bool iV = __ballot((f & 1) != 0) != 0, iIV = __ballot((f & 2) != 0) != 0;
+        if (lane == src) {
+          const int cs = (int)(a & 0x1FFFFF), cSI = (int)((a >> 21) & 0x1FFFFF), cM = (int)((a >> 42) & 0x1FFFFF);
+          const int newTotal = cVl == 0 ? cs : (iV ? cSI : cM);
+          ns = g_score(l, size, newTotal, cVl == 0 ? cs : newTotal - cVl, cs == 1, iIV);
+        }
+      }
+      if (mine) shNs[w][i] = ns;
+      int mx = ns;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+      if (mx > bestScore) {  // `ns > score`: the first entry reaching a new maximum wins
+        bestScore = mx;
+        const int src = __ffsll((unsigned long long)__ballot(mine && ns == mx)) - 1;
+        bestIdx = base + src;
+        bestEnt = shfl64(e, src);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rewrite the list: zeros are removed (:571-573), the best leaves it (:577)
+    int newLen = 0;
+    for (int base = 0; base < len; base += 64) {
+      const int i = base + lane;
+      const bool mine = i < len;
+      const uint64_t e = mine ? ent[i] : 0ULL;
+      const int ns = mine ? shNs[w][i] : 0;
+      const bool keep = mine && ns != 0 && i != bestIdx;
+      const uint64_t km = __ballot(keep);
+      const bool freeSlot = mine && ns == 0 && g_ent_kind(e) == GK_PARTIAL;
+      for (uint64_t m = __ballot(freeSlot); m; m &= m - 1) {
+        const uint32_t sl = __shfl(g_ent_aux(e), __ffsll((unsigned long long)m) - 1, 64);
+        if (lane == 0) ls->used[sl >> 6] &= ~(1ULL << (sl & 63));
+      }
+      if (keep) ent[newLen + __popcll(km & lanes_lt())] = e;
+      newLen += __popcll(km);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < s.Q / 64; k += 64) s.tvUsed[(size_t)node * (s.Q / 64) + k] = ls->used[k];
+    if (lane == 0) {
+      s.tvLen[node] = newLen;
+      if (bestIdx >= 0) {
+        // sigChecked++; sigQueueSize = toVerify.size(); registerTask(updateVerifiedSignatures(best), ...) :576-583.
+        // The task's closure (tBest) is the pend entry; k_gsf_cond_a2 emits the task record in node order.
+        int pe = -1;
+        for (int k = 0; k < G_PEND; k++)
+          if (!(s.pend[(size_t)node * G_PEND + k] & 0x80000000u)) {
+            pe = k;
+            break;
+          }
+        if (pe < 0) {
+          set_err(d.g, ERR_PENDING);
+          pe = 0;
+        }
+        s.pend[(size_t)node * G_PEND + pe] = 0x80000000u | (g_ent_kind(bestEnt) << 29) |
+                                             ((uint32_t)g_ent_level(bestEnt) << 24) | g_ent_aux(bestEnt);
+        s.pendFrom[(size_t)node * G_PEND + pe] = g_ent_from(bestEnt);
+        s.candPend[node] = (uint8_t)pe;
+        s.sigChecked[node]++;
+        s.sigQueueSize[node] = newLen;
+        s.candFlag[node] = 1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// scan over nodes: ordinal of every node whose checkSigs registers a task (conditional tasks run in
+// registration = node id order, so that is the push order). GSF's checkSigs draws nothing from rd.
+struct GsfCondF {
+  typedef GsfState Aux;
+  const EngineDev& d;
+  const GsfState& s;
+  __device__ GsfCondF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
+  __device__ uint32_t count() const { return (uint32_t)s.N; }
+  __device__ uint64_t value(uint32_t i) const { return s.candFlag[i] != 0; }
+  __device__ void tally(uint32_t, uint32_t) const {}
+  __device__ void total(uint64_t tot) const {
+    d.g->nOut = (uint32_t)tot;
+    d.g->nDraws = 0;
+  }
+  __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
+    if (valid && s.candFlag[i]) s.condList[(uint32_t)excl] = i;
+  }
+};
+
+__global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nOut;
+  const int32_t t = d.g->now;
+  const uint32_t D = (uint32_t)d.horizon;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *s.runCount = 0;  // for the next edge's k_gsf_cond_pre
+  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+    const uint32_t j = j0 + threadIdx.x;
+    uint32_t histKey = 0xFFFFFFFFu;
+    if (j < n) {
+      const int32_t node = (int32_t)s.condList[j];
+      const int32_t arrival = t + s.pairing[node];
+      d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, G_TASK_UPDATE, (uint32_t)s.candPend[node]);
+      const bool ok = arrival - t < d.horizon - 1;
+      d.arr[j] = ok ? arrival : -1;
+      if (!ok) set_err(d.g, ERR_HORIZON);
+      if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
+    }
+    uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);
+    while (todo) {
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const uint32_t key = __shfl(histKey, leader, 64);
+      const uint64_t m = __ballot(histKey == key) & todo;
+      if ((int)WG_LANE == leader) atomicAdd(&d.tileHist[key], (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
+  }
+}
+
+}  // namespace wg

@@ -100,3 +100,62 @@ class Handel:
         v = C.c_int32()
         self._net._ck(L.lib().wg_protocol_cont_if(self._net._h, C.byref(v)))
         return bool(v.value)
+
+
+class GSFSignatureParameters:
+    """P/GSFSignature.java:26-107 (constructor argument order preserved; the ratio overload :86-106 is
+    `from_ratios`)."""
+
+    def __init__(self, nodeCount=32768 // 32, threshold=None, pairingTime=3, timeoutPerLevelMs=50, periodDurationMs=10,
+                 acceleratedCallsCount=10, nodesDown=0, nodeBuilderName=None, networkLatencyName=None):
+        if threshold is None:
+            threshold = int(nodeCount * 0.99)
+        if nodesDown >= nodeCount or nodesDown < 0 or threshold > nodeCount or nodesDown + threshold > nodeCount:
+            from .core import IllegalArgumentException
+            raise IllegalArgumentException("nodeCount=%d, threshold=%d" % (nodeCount, threshold))
+        self.nodeCount, self.threshold, self.pairingTime = nodeCount, threshold, pairingTime
+        self.timeoutPerLevelMs, self.periodDurationMs = timeoutPerLevelMs, periodDurationMs
+        self.acceleratedCallsCount, self.nodesDown = acceleratedCallsCount, nodesDown
+        self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
+
+    @classmethod
+    def from_ratios(cls, nodeCount, ratioThreshold, pairingTime, timeoutPerLevelMs, periodDurationMs,
+                    acceleratedCallsCount, ratioNodesDown, nodeBuilderName=None, networkLatencyName=None):
+        return cls(nodeCount, int(ratioThreshold * nodeCount), pairingTime, timeoutPerLevelMs, periodDurationMs,
+                   acceleratedCallsCount, int(ratioNodesDown * nodeCount), nodeBuilderName, networkLatencyName)
+
+
+class GSFSignature:
+    """P/GSFSignature.java."""
+
+    def __init__(self, params=None, seed=0, config=None):
+        self.params = params or GSFSignatureParameters()
+        self.seed, self.config = seed, config
+        self._net = None
+        self.init_seconds = None
+
+    def copy(self):
+        return GSFSignature(self.params, self.seed, self.config)
+
+    def init(self):
+        p = self.params
+        gp = L.wg_gsf_params(p.nodeCount, p.threshold, p.pairingTime, p.timeoutPerLevelMs, p.periodDurationMs,
+                             p.acceleratedCallsCount, p.nodesDown)
+        h = C.c_void_p()
+        cfg = _config(self.config)
+        rc = L.lib().wgh_gsf_create(C.byref(gp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                    p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                    C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wgh_last_error().decode())
+        self._net = Network(h)
+        self.init_seconds = L.lib().wgh_last_init_seconds()
+
+    def network(self):
+        return self._net
+
+    def cont_if(self):
+        """GSFSignature.newConfIf (P/GSFSignature.java:670-683): some live node holds < threshold signatures."""
+        v = C.c_int32()
+        self._net._ck(L.lib().wg_protocol_cont_if(self._net._h, C.byref(v)))
+        return bool(v.value)
