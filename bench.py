@@ -52,7 +52,22 @@ def b_msg(level):
     return 136 + 3 * ((bits + 7) // 8)
 
 
-def make_sim(w, n, seed, device):
+def gsf_params(n):
+    """BASELINE.json configs[1] / SURVEY.md §8d config 2: the GSFSignatureParameters() defaults
+    (P/GSFSignature.java:47-57) scaled to n nodes"""
+    return dict(nodeCount=n, threshold=int(n * 0.99), pairingTime=3, timeoutPerLevelMs=50, periodDurationMs=10,
+                acceleratedCallsCount=10, nodesDown=0)
+
+
+def make_sim(w, n, seed, device, workload="handel"):
+    if workload == "gsf":
+        gp = gsf_params(n)
+        g = w.GSFSignature(w.GSFSignatureParameters(gp["nodeCount"], gp["threshold"], gp["pairingTime"],
+                                                    gp["timeoutPerLevelMs"], gp["periodDurationMs"],
+                                                    gp["acceleratedCallsCount"], gp["nodesDown"], NB, NL),
+                           seed=seed, config={"device": device})
+        g.init()
+        return g
     hp = handel_params(n)
     p = w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                            hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0)
@@ -61,17 +76,31 @@ def make_sim(w, n, seed, device):
     return g
 
 
-def make_batch(w, n, seeds, device, threads):
+def make_batch(w, n, seeds, device, threads, workload="handel"):
     """Protocol.copy() + rd.setSeed(i) + init() for every copy (host work; ctypes releases the GIL)."""
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
-        sims = list(ex.map(lambda s: make_sim(w, n, s, device), seeds))
+        sims = list(ex.map(lambda s: make_sim(w, n, s, device, workload), seeds))
     return sims, w.Batch([g.network() for g in sims])
 
 
-def cpu_baseline(n_sample):
+def cpu_baseline(n_sample, workload="handel"):
     """the C++ oracle (event-for-event restatement of the single-threaded Java path) on one host core"""
     import oracle_lib as o
     o.build()
+    if workload == "gsf":
+        gp = gsf_params(n_sample)
+        c = o.GSFSignature(gp["nodeCount"], gp["threshold"], gp["pairingTime"], gp["timeoutPerLevelMs"],
+                           gp["periodDurationMs"], gp["acceleratedCallsCount"], gp["nodesDown"], NB, NL, seed=0)
+        t0 = time.perf_counter()
+        while c.cont_if():
+            c.run_ms(10)
+        dt = time.perf_counter() - t0
+        info = c.info(False)
+        return {"value": info["delivered"] / dt, "unit": "delivered messages/s", "cores": 1, "kind": "port",
+                "sample": "GSFSignature %d nodes (seed 0), full run to the stop predicate: %d delivered messages, %d "
+                          "simulated ms in %.2f s on one host core (C++ oracle, upper bound on the JVM path)"
+                          % (n_sample, info["delivered"], info["time"], dt),
+                "simulated_ms_per_s": info["time"] / dt}
     hp = handel_params(n_sample)
     c = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                  hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0, seed=0)
@@ -97,6 +126,9 @@ def main():
     ap.add_argument("--init-threads", type=int, default=4)
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["handel", "gsf"], default="handel",
+                    help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
+                         "(use --nodes 4096)")
     args = ap.parse_args()
 
     import torch
@@ -138,13 +170,13 @@ def main():
     t_init = time.perf_counter()
     inits = 0
     for i in range(W):
-        sims, batch = make_batch(w, n, range(seed0 + i * R, seed0 + (i + 1) * R), local, args.init_threads)
+        sims, batch = make_batch(w, n, range(seed0 + i * R, seed0 + (i + 1) * R), local, args.init_threads, args.workload)
         inits += R
         sims[0].network().profile(1)
         batch.run_multiple_times(chunk=10, maxTime=20000)
         prof_phase = sims[0].network().profile_read()
         del batch, sims
-    timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads)
+    timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads, args.workload)
              for i in range(K)]
     inits += K * R
     init_s = (time.perf_counter() - t_init) / max(1, inits)
@@ -188,16 +220,22 @@ def main():
             dist.destroy_process_group()
         return
 
+    gsf = args.workload == "gsf"
     out = {
-        "metric": "delivered messages/sec (Handel 32k nodes; simulated-ms/sec alongside)",
+        "metric": "delivered messages/sec (GSFSignature; simulated-ms/sec alongside)" if gsf else
+                  "delivered messages/sec (Handel 32k nodes; simulated-ms/sec alongside)",
         "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "simulated_ms_per_s": sim_ms / elapsed,
-        "config": {"workload": "Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, "
-                               "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
-                               "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
-                               "copy's Handel.newContIf is false" % (n, R),
+        "config": {"workload": ("GSFSignature, %d nodes, threshold 0.99, pairing 3, timeoutPerLevel 50, period 10, "
+                                "accelerated calls 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
+                                "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
+                                "copy's newConfIf is false" % (n, R)) if gsf else
+                               ("Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, "
+                                "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
+                                "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
+                                "copy's Handel.newContIf is false" % (n, R)),
                    "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch",
                    "delivered_per_simulation": delivered // max(1, K * R * world),
                    "init_s_per_simulation": init_s},
@@ -215,7 +253,7 @@ def main():
         if tj.get("replicas") == R and tj.get("nodes") == n:
             traffic = tj.get("hbm_bytes_per_launch")
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_deliver<HandelProto>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_deliver<HandelProto>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
         "bytes_per_delivered_message": alg_bytes / max(1, delivered if world == 1 else int(by_level.sum())),
@@ -224,7 +262,7 @@ def main():
     if prof_phase:
         out["roofline"]["warmup_phase_device_ms"] = {k: round(v["total_ns"] / 1e6, 3) for k, v in prof_phase.items()}
     if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes)
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes, args.workload)
     log("msgReceived sum of the last step's copies: %d" % check)
     print(json.dumps(out), flush=True)
     if world > 1:
