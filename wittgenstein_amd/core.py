@@ -74,6 +74,7 @@ class Network:
 
     def __init__(self, handle):
         self._h = handle
+        self._owner = L.lib()  # the library that created the handle destroys it
         self.msgs = MessageStorage(self)
         self.last_stats = None
 
@@ -138,7 +139,7 @@ class Network:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            L.lib().wg_destroy(h)
+            self._owner.wg_destroy(h)
 
     def _ck(self, rc):
         if rc != L.WG_OK:
@@ -250,12 +251,13 @@ class Batch:
         if rc != L.WG_OK:
             _raise(rc, L.lib().wg_batch_last_error(None).decode())
         self._h = h
+        self._owner = L.lib()
         self.last_stats = None
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            L.lib().wg_batch_destroy(h)
+            self._owner.wg_batch_destroy(h)
 
     def _ck(self, rc):
         if rc != L.WG_OK:

@@ -29,6 +29,7 @@ constexpr int MAX_LEVELS = 24;
 #endif
 constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node visit (deliver, cond_a1)
 constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
+constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_deliver_msgs)
 constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;
 constexpr int GRID_TILES = 256 / WG_GRID_DIV;
 constexpr int GRID_COND_TAIL = 128 / WG_GRID_DIV;
@@ -132,6 +133,7 @@ struct Globals {
   // per-ms scratch counters
   uint32_t nEvents;        // events in the bucket being drained (after chain-run expansion)
   uint32_t nActive;        // nodes with >= 1 event
+  uint32_t nActiveB;       // ... of which the lane-per-node message kernel left to the wave-per-node kernel
   uint32_t outSlots;       // outbox slots handed out to the events of this ms
   uint32_t nOut;           // ordered outbox length
   uint32_t nDraws;         // draws in this phase
@@ -205,6 +207,7 @@ struct EngineDev {
   int32_t* evNext;          // per-node inbox as a linked list through the events
   int32_t* head;            // [n] newest event of the node this ms, -1 = none
   uint32_t* active;         // nodes with >= 1 event (unordered)
+  uint32_t* activeB;        // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
   uint32_t maxOut;
   Out* outTmp;              // per-event slices (see Out)
   uint32_t* recEv;          // event of each ordered outbox position

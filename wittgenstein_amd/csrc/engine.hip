@@ -42,7 +42,7 @@ struct PingPongHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<PingPongProto, 4>), dim3(GRID_DELIVER_SMALL, g.R), dim3(256), 0, g.stream, g.tab,
-                       (const PingPongProto::State*)g.stab);
+                       (const PingPongProto::State*)g.stab, 0);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
@@ -377,6 +377,7 @@ void Engine::ensure_device() {
   dev.head = dalloc<int32_t>(n, false);
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
   dev.active = dalloc<uint32_t>(n);
+  dev.activeB = dalloc<uint32_t>(n);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false);
   dev.recEv = dalloc<uint32_t>(maxOut, false);
@@ -1129,14 +1130,19 @@ struct HandelHost : ProtoHost {
     Engine::scan<CondF>(g, stab);
     hipLaunchKernelGGL(k_handel_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
+  // WG_LANE_MSGS=0 keeps every node visit on the wave-per-node kernel (A/B switch for profiles)
+  int laneMsgs = getenv("WG_LANE_MSGS") ? atoi(getenv("WG_LANE_MSGS")) : 1;
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
+    const int useB = laneMsgs ? 1 : 0;
+    if (useB)
+      hipLaunchKernelGGL((k_deliver_msgs<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
@@ -1345,7 +1351,7 @@ struct GsfHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab,
-                       (const GsfState*)g.stab);
+                       (const GsfState*)g.stab, 0);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_gsf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,

@@ -606,6 +606,7 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
     g->draws += g->nDraws;
     g->nEvents = 0;
     g->nActive = 0;
+    g->nActiveB = 0;
     g->outSlots = 0;
     g->nOut = 0;
     g->nDraws = 0;
@@ -774,7 +775,7 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
 //   4. whatever action() loads (hoisted inside P) -> stores; counters by no-return atomics
 template <class P, int WPE>  // WPE: waves per SIMD the register allocation must admit
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
-                                                      const typename P::State* __restrict__ stab) {
+                                                      const typename P::State* __restrict__ stab, int useB) {
   WG_ENGINE(tab);
   const typename P::State& ps = stab[blockIdx.y];
   __shared__ typename P::WaveShared shP[4];
@@ -782,10 +783,12 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nActive = d.g->nActive;
+  // useB: k_deliver_msgs ran first and left this kernel the nodes of activeB
+  const uint32_t nActive = useB ? d.g->nActiveB : d.g->nActive;
+  const uint32_t* __restrict__ activeList = useB ? d.activeB : d.active;
   const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nActive; a += nWaves) {
-    const int32_t node = (int32_t)d.active[a];
+    const int32_t node = (int32_t)activeList[a];
     const int32_t e0 = d.head[node];  // newest event of the node (always >= 0 for a listed node)
     const bool toDown = d.nodes.down[node] != 0;
     const uint8_t toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
@@ -857,6 +860,116 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
         atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
       }
       d.head[node] = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lane-per-node delivery of message-only nodes. Most events of a Handel-class run are messages whose
+// action() only files the payload into the receiver's queue (onNewSig): a few dependent scalar accesses
+// and a copy. One wavefront per node keeps ONE such chain in flight per wave; here every lane owns a node
+// (64 chains in flight per wave) and walks its <= 4 events in event order; payloads wider than one word
+// are copied afterwards by the whole wavefront (coalesced). Nodes with a task, a chain hop or more than
+// 4 events go to activeB for k_deliver. Protocols opt in with P::LANE_MSGS and provide
+//   LaneNode, lane_begin / lane_message / lane_end     (action() of a message that emits nothing)
+struct CopyJob {
+  const uint64_t* src;
+  uint64_t* dst;
+  int32_t nw;
+  int32_t pad;
+};
+
+template <class P>
+__global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restrict__ tab,
+                                                      const typename P::State* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const typename P::State& ps = stab[blockIdx.y];
+  __shared__ CopyJob shJobs[4][256];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
+    const uint32_t a = base + lane;
+    const bool have = a < nActive;
+    const int32_t node = have ? (int32_t)d.active[a] : 0;
+    // the node's events, sorted by event index (the inbox list is in link order)
+    uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
+    bool mine = have;
+    if (have) {
+      int32_t e = d.head[node];
+      int cnt = 0;
+      while (e >= 0 && cnt < 4) {
+        uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
+        if (v < s0) { uint32_t x = s0; s0 = v; v = x; }
+        if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
+        if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
+        if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
+        if (rec_kind(d.ev[e]) != K_MSG || d.evAux[e].chain >= 0) mine = false;
+        cnt++;
+        e = d.evNext[e];
+      }
+      if (e >= 0) mine = false;  // more than 4 events
+    }
+    {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
+      const bool toB = have && !mine;
+      const uint64_t m = __ballot(toB);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(&d.g->nActiveB, (uint32_t)__popcll(m));
+        bb = __shfl(bb, leader, 64);
+        if (toB) d.activeB[bb + __popcll(m & lanes_lt())] = (uint32_t)node;
+      }
+    }
+    typename P::LaneNode r;
+    bool toDown = false;
+    uint8_t toPart = 0;
+    if (mine) {
+      toDown = d.nodes.down[node] != 0;
+      toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
+      P::lane_begin(d, ps, node, r);
+    }
+    long long nRecv = 0, bRecv = 0;
+    uint32_t nJobs = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t e = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
+      CopyJob job;
+      job.nw = 0;
+      if (mine && e != 0xFFFFFFFFu) {
+        const Rec rec = d.ev[e];
+        const int32_t from = rec_from(rec);
+        uint32_t flags = 0;
+        if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
+          nRecv++;
+          bRecv += P::msg_size(ps, rec.w2);
+          flags = EV_DELIVERED | ((uint32_t)P::msg_level(rec.w2) << 24);
+          P::lane_message(d, ps, t, node, r, from, rec.w2, rec.w3, job);
+        }
+        EvRes res;
+        res.nrec = flags;
+        res.ndraw = 0;
+        d.evRes[e] = res;
+      }
+      const uint64_t jm = __ballot(job.nw > 0);
+      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
+      nJobs += (uint32_t)__popcll(jm);
+    }
+    if (mine) {
+      P::lane_end(d, ps, node, r);
+      if (nRecv) {
+        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      }
+      d.head[node] = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = 0; j < nJobs; j++) {  // wide payloads: the whole wavefront copies, coalesced
+      const CopyJob job = shJobs[w][j];
+      for (int q = lane; q < job.nw; q += 64) job.dst[q] = job.src[q];
     }
     __builtin_amdgcn_wave_barrier();
   }

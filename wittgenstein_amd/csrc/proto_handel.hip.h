@@ -204,6 +204,73 @@ struct HandelProto {
     }
   }
 
+
+  // ---- lane-per-node form of onNewSig for k_deliver_msgs: the same statements as on_new_sig below, one
+  // lane per receiving node; payloads wider than one word are handed back as a copy job --------------------
+  struct LaneNode {
+    long long doneAt;
+    int32_t startAt, sigQueueSize, msgFiltered;
+    int32_t sigQueueSize0, msgFiltered0;
+  };
+  __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
+    r.doneAt = d.nodes.doneAt[node];
+    r.startAt = s.startAt[node];
+    r.sigQueueSize = r.sigQueueSize0 = s.sigQueueSize[node];
+    r.msgFiltered = r.msgFiltered0 = s.msgFiltered[node];
+  }
+  __device__ static void lane_end(const EngineDev&, const State& s, int32_t node, const LaneNode& r) {
+    if (r.sigQueueSize != r.sigQueueSize0) s.sigQueueSize[node] = r.sigQueueSize;
+    if (r.msgFiltered != r.msgFiltered0) s.msgFiltered[node] = r.msgFiltered;
+  }
+  __device__ static void lane_message(const EngineDev& d, const State& s, int32_t t, int32_t node, LaneNode& r,
+                                      int32_t from, uint32_t msg, uint32_t payload, CopyJob& job) {
+    const int l = (int)(msg & 31u);
+    const bool levelFinished = (msg >> 5) & 1u;
+    if (r.doneAt > 0) {  // :758-761
+      r.msgFiltered++;
+      return;
+    }
+    if (t < r.startAt) return;
+    const int w = from >> 6;
+    const uint64_t bit = 1ULL << (from & 63);
+    uint64_t* fpp = s.FP + (size_t)node * s.W + w;
+    const uint64_t* vip = s.VI + (size_t)node * s.W + w;
+    uint64_t* tvp = s.TV + (size_t)node * s.W + w;
+    const size_t nl = (size_t)node * s.L + l;
+    // every load of the event before the first use
+    const uint64_t viv = *vip;
+    const uint64_t fpv = levelFinished ? *fpp : 0ULL;
+    const uint64_t tvv = *tvp;
+    const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+    const unsigned long long used = s.qused[nl];
+    const int len = s.qlen[nl];
+    const uint64_t* src = (payload & H_REF_RING) ? d.payload + (payload & ~H_REF_RING) : s.snap + payload;
+    const int nw = h_nw(l);
+    const uint64_t pw0 = nw == 1 ? src[0] : 0ULL;
+    if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
+    if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
+    r.sigQueueSize++;
+    const unsigned long long capMask = s.Q >= 64 ? ~0ULL : ((1ULL << s.Q) - 1ULL);
+    const unsigned long long freeM = ~used & capMask;
+    if (freeM == 0 || len >= 64) {
+      set_err(d.g, ERR_QUEUE_CAP);
+      return;
+    }
+    const int slot = __ffsll(freeM) - 1;
+    uint64_t* dst = sig_ptr(s, node, l, slot);
+    s.qfrom[nl * s.Q + slot] = from;
+    s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
+    s.qused[nl] = used | (1ULL << slot);
+    s.qlen[nl] = (uint8_t)(len + 1);
+    if (nw == 1) {
+      dst[0] = pw0;
+    } else {
+      job.src = src;
+      job.dst = dst;
+      job.nw = nw;
+    }
+  }
+
   // ---- queue helpers ---------------------------------------------------------------------------
   __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int l, int slot) {
     return s.qsig + s.qsigOff[l] + ((size_t)node * s.Q + slot) * (size_t)h_nw(l);
