@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwittgpu.so")
+# WG_LIB selects an investigation build (tools/kprof.sh); the product library otherwise
+LIB_PATH = os.environ.get("WG_LIB") or os.path.join(_HERE, "libwittgpu.so")
 
 
 class wg_config(C.Structure):

@@ -244,6 +244,18 @@ int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_
     dst[k].spans = E.profLaunches[c];
     dst[k].total_ns = E.profNs[c];
   }
+#ifdef WG_KPROF
+  static const char* kn[16] = {"kprof00 visits", "kprof01 cyc desc+node_begin", "kprof02 cyc events", "kprof03 cyc node_end",
+                               "kprof04 n on_message", "kprof05 cyc on_message", "kprof06 n dissemination",
+                               "kprof07 cyc dissemination", "kprof08 cyc dissem fin-bits", "kprof09 cyc dissem snapshots",
+                               "kprof10 cyc dissem sends", "kprof11 n update", "kprof12 cyc update",
+                               "kprof13 n dissem slow levels", "kprof14", "kprof15"};
+  for (int c = 0; c < 16 && k < cap; c++, k++) {
+    dst[k].name = kn[c];
+    dst[k].spans = 1;
+    dst[k].total_ns = (double)E.gh.kprof[c];
+  }
+#endif
   if (n) *n = k;
   WG_END
 }

@@ -90,6 +90,13 @@ struct EvAux {
   uint32_t outBase;   // first outbox slot of the event
   uint32_t outCap;    // slots owned
 };
+// what a wave-per-node visit starts from, written by k_deliver_msgs for the nodes it leaves to k_deliver:
+// the node, its newest event and that event's record — one coalesced read instead of three dependent ones
+struct VisitDesc {
+  int32_t node, e0, next0, pad;
+  Rec rec0;
+  EvAux aux0;
+};
 // per-event result written by deliver (8 bytes)
 struct EvRes {
   uint32_t nrec;      // records emitted | EV_DELIVERED / EV_TASK_RUN flags | level << 24
@@ -143,6 +150,8 @@ struct Globals {
   uint32_t chainHead;      // monotone
   unsigned long long destHead;     // monotone (ring index = destHead % chainDests)
   unsigned long long payloadHead;  // monotone, in 64-bit words
+  // in-kernel cycle counters of investigation builds (-DWG_KPROF, tools/kprof.sh); untouched otherwise
+  unsigned long long kprof[32];
 };
 
 struct LatencyModel {
@@ -207,7 +216,7 @@ struct EngineDev {
   int32_t* evNext;          // per-node inbox as a linked list through the events
   int32_t* head;            // [n] newest event of the node this ms, -1 = none
   uint32_t* active;         // nodes with >= 1 event (unordered)
-  uint32_t* activeB;        // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
+  VisitDesc* activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
   uint32_t maxOut;
   Out* outTmp;              // per-event slices (see Out)
   uint32_t* recEv;          // event of each ordered outbox position

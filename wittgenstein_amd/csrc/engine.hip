@@ -377,7 +377,7 @@ void Engine::ensure_device() {
   dev.head = dalloc<int32_t>(n, false);
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
   dev.active = dalloc<uint32_t>(n);
-  dev.activeB = dalloc<uint32_t>(n);
+  dev.activeB = dalloc<VisitDesc>(n);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false);
   dev.recEv = dalloc<uint32_t>(maxOut, false);
@@ -964,24 +964,26 @@ namespace wg {
 
 template void Engine::scan<CondF>(const Group&, const HandelState*);
 
-__global__ void k_handel_init(HandelState s, const uint8_t* down) {
+__global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t* startAt, const int32_t* pairing) {
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= s.N) return;
+  uint32_t* h = h_hdr(s, node);
+  h[HH_START] = (uint32_t)startAt[node];
+  h[HH_PAIR] = (uint32_t)pairing[node];
   // HLevel() for level 0 (:413-421): own signature everywhere, outgoingFinished = true
   size_t w = (size_t)node * s.W + (node >> 6);
   uint64_t bit = 1ULL << (node & 63);
   s.TI[w] |= bit;
   s.LA[w] |= bit;
   s.VI[w] |= bit;
-  size_t i0 = (size_t)node * s.L;
-  s.cTI[i0] = 1;
-  s.cLA[i0] = 1;
-  s.cVI[i0] = 1;
-  s.outFin[i0] = 1;
-  s.window[node] = s.p.windowInitial;
-  s.addedCycle[node] = s.p.extraCycle;
+  *h_lv(s, node, HP_CTI, 0) = 1;
+  *h_lv(s, node, HP_CLA, 0) = 1;
+  *h_lv(s, node, HP_CVI, 0) = 1;
+  *h_lv(s, node, HP_OUTFIN, 0) = 1;
+  h[HH_WINDOW] = (uint32_t)s.p.windowInitial;
+  h[HH_ADDED] = (uint32_t)s.p.extraCycle;
   // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
-  s.ctMinStart[node] = down[node] ? INT32_MAX : s.startAt[node] + 1;
+  h[HH_CTMIN] = (uint32_t)(down[node] ? INT32_MAX : startAt[node] + 1);
 }
 
 // Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0
@@ -989,7 +991,7 @@ __global__ void k_handel_cont_if(const EngineDev* __restrict__ tab, const Handel
   const EngineDev& d = tab[blockIdx.y];
   const HandelState& s = stab[blockIdx.y];
   int node = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = node < s.N && !d.nodes.down[node] && (d.nodes.doneAt[node] == 0 || s.addedCycle[node] > 0);
+  bool c = node < s.N && !d.nodes.down[node] && (d.nodes.doneAt[node] == 0 || (int32_t)h_hdr(s, node)[HH_ADDED] > 0);
   if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
 }
 
@@ -1032,24 +1034,12 @@ struct HandelHost : ProtoHost {
     st.FP = e.dalloc<uint64_t>(rows);
     st.ranks = e.dalloc<int32_t>((size_t)N * N, false);
     st.peers = e.dalloc<int32_t>((size_t)N * (N - 1), false);
-    st.startAt = e.dalloc<int32_t>(N);
-    st.pairing = e.dalloc<int32_t>(N);
-    st.window = e.dalloc<int32_t>(N);
-    st.addedCycle = e.dalloc<int32_t>(N);
-    st.sigsChecked = e.dalloc<int32_t>(N);
-    st.sigQueueSize = e.dalloc<int32_t>(N);
-    st.msgFiltered = e.dalloc<int32_t>(N);
-    st.ctMinStart = e.dalloc<int32_t>(N);
-    st.ctEpoch = e.dalloc<uint32_t>(N);
+    st.LS = L <= 16 ? 16 : 32;
+    st.lsShift = L <= 16 ? 4 : 5;
+    st.hdrStride = HH_LV + HP_COUNT * st.LS;  // 160 or 288 words: whole 128-byte lines
+    st.hdr = e.dalloc<uint32_t>((size_t)N * st.hdrStride);
     const size_t NL = (size_t)N * L;
-    st.pos = e.dalloc<int32_t>(NL);
-    st.cTI = e.dalloc<int32_t>(NL);
-    st.cLA = e.dalloc<int32_t>(NL);
-    st.cVI = e.dalloc<int32_t>(NL);
-    st.outFin = e.dalloc<uint8_t>(NL);
-    st.qlen = e.dalloc<uint8_t>(NL);
     st.qent = e.dalloc<uint64_t>(NL * 64);
-    st.qused = e.dalloc<unsigned long long>(NL);
     st.qfrom = e.dalloc<int32_t>(NL * Q, false);
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
@@ -1059,12 +1049,7 @@ struct HandelHost : ProtoHost {
     }
     st.qsig = e.dalloc<uint64_t>(off, false);
     {
-      uint32_t off = 0;
-      for (int l = 0; l < L; l++) {
-        st.lvlOff[l] = off;
-        off += l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
-      }
-      st.snapStride = off;
+      st.snapStride = N >= 128 ? (uint32_t)(N / 128) : 1u;  // words of the top level's block (N/2 ids)
       st.snapNb = (uint32_t)(e.dev.horizon / p.disseminationPeriodMs) + 2;  // a snapshot is read within < horizon ms
       uint64_t words = (uint64_t)st.snapNb * N * st.snapStride;
       if (words >= 0x80000000ull) throw WgError(WG_ENOMEM, "Handel snapshot ring exceeds 2^31 words: lower horizon_ms");
@@ -1075,8 +1060,6 @@ struct HandelHost : ProtoHost {
     e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
     e.dev.boundTask[1] = L - 1;    // updateVerifiedSignatures: one fast-path send per higher level
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
-    st.pend = e.dalloc<uint32_t>((size_t)N * H_PEND);
-    st.pendFrom = e.dalloc<int32_t>((size_t)N * H_PEND);
     st.runList = e.dalloc<uint32_t>(N);
     st.runCount = e.dalloc<uint32_t>(1);
     st.candCnt = e.dalloc<uint8_t>(N);
@@ -1085,12 +1068,17 @@ struct HandelHost : ProtoHost {
     st.condOrd = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N);
     st.drawVal = e.dalloc<int32_t>(N);
-    WG_HIP(hipMemcpy(st.startAt, init.startAt, 4 * (size_t)N, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(st.pairing, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
     WG_HIP(hipMemcpy(st.ranks, init.receptionRanks, 4 * (size_t)N * N, hipMemcpyHostToDevice));
     WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * (N - 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_handel_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down);
+    int32_t *dStart = nullptr, *dPair = nullptr;
+    WG_HIP(hipMalloc((void**)&dStart, 4 * (size_t)N));
+    WG_HIP(hipMalloc((void**)&dPair, 4 * (size_t)N));
+    WG_HIP(hipMemcpy(dStart, init.startAt, 4 * (size_t)N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(dPair, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_handel_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down, dStart, dPair);
     WG_HIP(hipStreamSynchronize(e.stream));
+    (void)hipFree(dStart);
+    (void)hipFree(dPair);
   }
   bool has_cond() const override { return true; }
   int levels() const override { return st.L; }
@@ -1150,35 +1138,36 @@ struct HandelHost : ProtoHost {
                        (const HandelState*)g.stab, dOut);
     return true;
   }
+  // read-back (tests, statistics): the header records come back whole and are picked apart on the host
+  std::vector<uint32_t> read_hdr() {
+    std::vector<uint32_t> h((size_t)st.N * st.hdrStride);
+    WG_HIP(hipMemcpy(h.data(), st.hdr, 4 * h.size(), hipMemcpyDeviceToHost));
+    return h;
+  }
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
-    const int32_t* src = nullptr;
+    int off;
     switch (field) {
-      case WG_F_SIGS_CHECKED: src = st.sigsChecked; break;
-      case WG_F_SIG_QUEUE_SIZE: src = st.sigQueueSize; break;
-      case WG_F_MSG_FILTERED: src = st.msgFiltered; break;
-      case WG_F_CURR_WINDOW_SIZE: src = st.window; break;
-      case WG_F_ADDED_CYCLE: src = st.addedCycle; break;
-      case WG_F_START_AT: src = st.startAt; break;
-      case WG_F_NODE_PAIRING_TIME: src = st.pairing; break;
+      case WG_F_SIGS_CHECKED: off = HH_SIGCHK; break;
+      case WG_F_SIG_QUEUE_SIZE: off = HH_SIGQ; break;
+      case WG_F_MSG_FILTERED: off = HH_FILT; break;
+      case WG_F_CURR_WINDOW_SIZE: off = HH_WINDOW; break;
+      case WG_F_ADDED_CYCLE: off = HH_ADDED; break;
+      case WG_F_START_AT: off = HH_START; break;
+      case WG_F_NODE_PAIRING_TIME: off = HH_PAIR; break;
       default: return false;
     }
-    std::vector<int32_t> h(n);
-    WG_HIP(hipMemcpy(h.data(), src, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) dst[i] = h[i];
+    const std::vector<uint32_t> h = read_hdr();
+    for (int i = 0; i < n; i++) dst[i] = (int32_t)h[(size_t)i * st.hdrStride + off];
     return true;
   }
   bool read_level_i32(Engine&, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
     if (n != st.N || L != st.L) throw WgError(WG_EINVAL, "shape must be [nodeCount][levels]");
-    const size_t NL = (size_t)n * L;
-    if (field == WG_LF_POS_IN_LEVEL) {
-      WG_HIP(hipMemcpy(dst, st.pos, 4 * NL, hipMemcpyDeviceToHost));
-      return true;
-    }
-    const uint8_t* src = field == WG_LF_OUTGOING_FINISHED ? st.outFin : field == WG_LF_QUEUE_LEN ? st.qlen : nullptr;
-    if (!src) return false;
-    std::vector<uint8_t> h(NL);
-    WG_HIP(hipMemcpy(h.data(), src, NL, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < NL; i++) dst[i] = h[i];
+    const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN
+                      : field == WG_LF_QUEUE_LEN ? HP_QLEN : -1;
+    if (plane < 0) return false;
+    const std::vector<uint32_t> h = read_hdr();
+    for (int i = 0; i < n; i++)
+      for (int l = 0; l < L; l++) dst[(size_t)i * L + l] = (int32_t)h[(size_t)i * st.hdrStride + HH_LV + plane * st.LS + l];
     return true;
   }
   bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {

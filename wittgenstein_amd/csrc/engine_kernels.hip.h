@@ -23,6 +23,24 @@ namespace wg {
 
 #define WG_LANE (threadIdx.x & 63)
 
+// Investigation builds only (-DWG_KPROF): lane 0 of a wavefront adds the cycles since its previous mark
+// to Globals::kprof[slot]. Marks sit where the code first consumes loaded data, so a region's cycles
+// are mostly the wait for its loads.
+#ifdef WG_KPROF
+#define KPROF_DECL unsigned long long _kp = __builtin_readcyclecounter()
+#define KPROF_MARK(g, slot)                                                            \
+  do {                                                                                 \
+    const unsigned long long _n = __builtin_readcyclecounter();                        \
+    if (WG_LANE == 0) atomicAdd(&(g)->kprof[slot], _n - _kp);                          \
+    _kp = _n;                                                                          \
+  } while (0)
+#define KPROF_COUNT(g, slot) do { if (WG_LANE == 0) atomicAdd(&(g)->kprof[slot], 1ULL); } while (0)
+#else
+#define KPROF_DECL
+#define KPROF_MARK(g, slot)
+#define KPROF_COUNT(g, slot)
+#endif
+
 // dynamic LDS of a kernel (a macro so that tests/emu, which builds these kernels for its CPU wave
 // emulator, can bind the name to its own buffer)
 #ifndef WG_DYN_LDS
@@ -664,6 +682,32 @@ struct Ctx {
     bytesSent += size;
     put(O_SEND, to, msg, payload, t + 1, 0, true);
   }
+  // n single-destination Network.send calls of one action(), written by n lanes at once: lane `active` with
+  // `rank` (0..n-1, the order the reference would issue them in) writes the rank-th record; every lane
+  // calls this with the same n / bytesTotal
+  __device__ void send_many(bool active, int rank, int n, int32_t to, uint32_t msg, uint32_t payload, long long bytesTotal) {
+    if (active) {
+      const uint32_t idx = sub + (uint32_t)rank;
+      if (idx < outCap && outBase + idx < d.maxOut) {
+        Out o;
+        o.kindfrom = (O_SEND << 28) | (uint32_t)node;
+        o.to = to;
+        o.a = msg;
+        o.b = payload;
+        o.t = t + 1;
+        o.destOff = 0;
+        o.drawsub = draws + (uint32_t)rank;
+        o.pad = 0;
+        d.outTmp[outBase + idx] = o;
+      } else {
+        set_err(d.g, ERR_OUTBOX);
+      }
+    }
+    sub = min(sub + (uint32_t)n, outCap);
+    draws += (uint32_t)n;
+    msgSent += n;
+    bytesSent += bytesTotal;
+  }
   // Network.send(m, this, dests) (:353-362): empty -> nothing, one -> single send, else multi-dest.
   // The destination ids must already be in the dest ring at destOff (dest_reserve).
   __device__ uint32_t dest_reserve(int n) {
@@ -785,20 +829,33 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   // useB: k_deliver_msgs ran first and left this kernel the nodes of activeB
   const uint32_t nActive = useB ? d.g->nActiveB : d.g->nActive;
-  const uint32_t* __restrict__ activeList = useB ? d.activeB : d.active;
   const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nActive; a += nWaves) {
-    const int32_t node = (int32_t)activeList[a];
-    const int32_t e0 = d.head[node];  // newest event of the node (always >= 0 for a listed node)
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 0);
+    VisitDesc vd;
+    if (useB) {
+      vd = d.activeB[a];
+    } else {
+      vd.node = (int32_t)d.active[a];
+      vd.e0 = d.head[vd.node];  // newest event of the node (always >= 0 for a listed node)
+    }
+    const int32_t node = vd.node;
+    const int32_t e0 = vd.e0;
     const bool toDown = d.nodes.down[node] != 0;
     const uint8_t toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
     typename P::NodeRegs r;
     long long nRecv = 0, bRecv = 0;
     P::node_begin(c, ps, r, &shP[w]);
-    const int32_t next0 = d.evNext[e0];
-    const Rec rec0 = d.ev[e0];
-    const EvAux aux0 = d.evAux[e0];
+    if (!useB) {
+      vd.next0 = d.evNext[e0];
+      vd.rec0 = d.ev[e0];
+      vd.aux0 = d.evAux[e0];
+    }
+    const int32_t next0 = vd.next0;
+    const Rec rec0 = vd.rec0;
+    const EvAux aux0 = vd.aux0;
     // mode 0: e0 is the only event (usual); 1: <= 64 events, sorted into shSort; 2: more (the PingPong
     // origin): repeated minimum search over the list. One call site of deliver_event for all three.
     int mode = 0;
@@ -825,6 +882,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
     }
     bool have = false;
     uint32_t last = 0;
+    KPROF_MARK(d.g, 1);  // descriptor + node_begin (+ the inbox sort of multi-event nodes)
     for (uint32_t k = 0; k < cnt; k++) {
       uint32_t e = (uint32_t)e0;
       if (mode == 1) {
@@ -847,6 +905,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
       deliver_event<P>(d, ps, c, r, e, rec, aux, toDown, toPart, mode == 2 || k + 1 < cnt, nRecv, bRecv);
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 2);  // the events' action()s
     P::node_end(c, ps, r);
     if (lane == 0) {
       // Node counters (C/Node.java:69-79): this wavefront is the node's only writer in this launch;
@@ -862,6 +921,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
       d.head[node] = -1;
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 3);  // node_end + counters
   }
 }
 
@@ -898,8 +958,12 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     // the node's events, sorted by event index (the inbox list is in link order)
     uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
     bool mine = have;
+    VisitDesc vd;
+    vd.node = node;
+    vd.pad = 0;
     if (have) {
       int32_t e = d.head[node];
+      vd.e0 = e;
       int cnt = 0;
       while (e >= 0 && cnt < 4) {
         uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
@@ -907,9 +971,17 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
         if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
         if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
-        if (rec_kind(d.ev[e]) != K_MSG || d.evAux[e].chain >= 0) mine = false;
+        const Rec rc = d.ev[e];
+        const EvAux ax = d.evAux[e];
+        const int32_t nx = d.evNext[e];
+        if (cnt == 0) {
+          vd.rec0 = rc;
+          vd.aux0 = ax;
+          vd.next0 = nx;
+        }
+        if (rec_kind(rc) != K_MSG || ax.chain >= 0) mine = false;
         cnt++;
-        e = d.evNext[e];
+        e = nx;
       }
       if (e >= 0) mine = false;  // more than 4 events
     }
@@ -921,7 +993,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         const int leader = __ffsll((unsigned long long)m) - 1;
         if (lane == leader) bb = atomicAdd(&d.g->nActiveB, (uint32_t)__popcll(m));
         bb = __shfl(bb, leader, 64);
-        if (toB) d.activeB[bb + __popcll(m & lanes_lt())] = (uint32_t)node;
+        if (toB) d.activeB[bb + __popcll(m & lanes_lt())] = vd;
       }
     }
     typename P::LaneNode r;

@@ -29,25 +29,26 @@ struct HandelState {
   uint64_t *TI, *LA, *VI, *TV, *FP;   // [N][W]
   int32_t* ranks;                      // [N][N]
   int32_t* peers;                      // [N][N-1]
-  int32_t *startAt, *pairing, *window, *addedCycle, *sigsChecked, *sigQueueSize, *msgFiltered;  // [N]
-  int32_t* ctMinStart;                 // ConditionalTask.minStartTime
-  uint32_t* ctEpoch;                   // epoch in which the task left nextMessage()'s private copy
-  int32_t *pos, *cTI, *cLA, *cVI;      // [N][L]
-  uint8_t* outFin;                     // [N][L]
-  uint8_t* qlen;                       // [N][L]
+  // Node header: every scalar of a node and its per-level scalars in ONE record of hdrStride 32-bit words
+  // (array of structs). A node visit is one wavefront touching one node, so the record is read and written
+  // back as a few consecutive cache lines of one page, instead of twenty 64-byte lines in twenty arrays:
+  //   [HH_ADDED .. HH_CTEPOCH]  addedCycle, sigQueueSize, msgFiltered, startAt, nodePairingTime, currWindowSize,
+  //                              sigsChecked, ConditionalTask.minStartTime, the epoch it last left nextMessage()'s copy
+  //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
+  //   [HH_LV + plane*LS + l]     planes posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
+  //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L
+  uint32_t* hdr;
+  int32_t LS, lsShift, hdrStride;
   uint64_t* qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
-  unsigned long long* qused;           // [N][L] slots allocated
   int32_t* qfrom;                      // [N][L][Q]
   uint64_t* qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
   // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
-  // per aligned window of `period` ms, so its snapshots live at a computed address — no allocation:
-  //   snap[((t / period) % snapNb) * N + node][lvlOff[l] ...]      (snapStride words per node)
+  // per aligned window of `period` ms, so its snapshot lives at a computed address — no allocation:
+  //   snap[((t / period) % snapNb) * N + node][0 .. snapStride)   the own block of the highest open level;
+  //   the lower levels' blocks are sub-ranges of it (see dissemination)
   uint64_t* snap;
   uint32_t snapNb, snapStride;
-  uint32_t lvlOff[MAX_LEVELS];
-  uint32_t* pend;                      // [N][H_PEND]: valid<<31 | level<<8 | slot ; from in pendFrom
-  int32_t* pendFrom;                   // [N][H_PEND]
   // conditional-task phase scratch
   uint32_t* runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
   uint32_t* runCount;                  // [1]
@@ -58,6 +59,14 @@ struct HandelState {
   uint32_t* condList;                  // drawing nodes in id order
   int32_t* drawVal;                    // [N]
 };
+
+enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
+                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_PEND = 12, HH_PENDFROM = 16, HH_LV = 32 };
+enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
+__device__ __forceinline__ uint32_t* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
+__device__ __forceinline__ uint32_t* h_lv(const HandelState& s, int32_t node, int plane, int l) {
+  return s.hdr + (size_t)node * s.hdrStride + HH_LV + plane * s.LS + l;
+}
 
 // geometry of one level inside a row
 struct Lv {
@@ -112,14 +121,14 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 }
 
 // per-wave LDS mirror of the (node, level) scalars
-struct LevelScalars {
-  int32_t pos[MAX_LEVELS];
-  int32_t cTI[MAX_LEVELS];
-  int32_t cLA[MAX_LEVELS];
-  int32_t cVI[MAX_LEVELS];
-  int32_t qlen[MAX_LEVELS];
-  int32_t outFin[MAX_LEVELS];
-  unsigned long long qused[MAX_LEVELS];
+struct LevelScalars {  // the first six arrays mirror the header's planes HP_POS..HP_OUTFIN (32 words each)
+  int32_t pos[32];
+  int32_t cTI[32];
+  int32_t cLA[32];
+  int32_t cVI[32];
+  int32_t qlen[32];
+  int32_t outFin[32];
+  unsigned long long qused[32];
 };
 
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
@@ -142,15 +151,16 @@ struct HandelProto {
 
   __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls) {
     const int32_t node = c.node;
+    const uint32_t* h = h_hdr(s, node);
     r.doneAt = c.d.nodes.doneAt[node];
-    r.addedCycle = s.addedCycle[node];
-    r.sigQueueSize = s.sigQueueSize[node];
-    r.msgFiltered = s.msgFiltered[node];
-    r.startAt = s.startAt[node];
+    r.addedCycle = (int32_t)h[HH_ADDED];
+    r.sigQueueSize = (int32_t)h[HH_SIGQ];
+    r.msgFiltered = (int32_t)h[HH_FILT];
+    r.startAt = (int32_t)h[HH_START];
 #pragma unroll
     for (int k = 0; k < H_PEND; k++) {
-      r.pend[k] = s.pend[(size_t)node * H_PEND + k];
-      r.pendFrom[k] = s.pendFrom[(size_t)node * H_PEND + k];
+      r.pend[k] = h[HH_PEND + k];
+      r.pendFrom[k] = (int32_t)h[HH_PENDFROM + k];
     }
     r.ls = ls;
     load_levels(s, node, ls);
@@ -159,51 +169,54 @@ struct HandelProto {
     const int32_t node = c.node;
     store_levels(s, node, r.ls);
     if (WG_LANE == 0) {
+      uint32_t* h = h_hdr(s, node);
       c.d.nodes.doneAt[node] = r.doneAt;
-      s.addedCycle[node] = r.addedCycle;
-      s.sigQueueSize[node] = r.sigQueueSize;
-      s.msgFiltered[node] = r.msgFiltered;
+      h[HH_ADDED] = (uint32_t)r.addedCycle;
+      h[HH_SIGQ] = (uint32_t)r.sigQueueSize;
+      h[HH_FILT] = (uint32_t)r.msgFiltered;
 #pragma unroll
-      for (int k = 0; k < H_PEND; k++) s.pend[(size_t)node * H_PEND + k] = r.pend[k];
+      for (int k = 0; k < H_PEND; k++) h[HH_PEND + k] = r.pend[k];
     }
   }
   __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    KPROF_DECL;
     on_new_sig(c, s, r, from, msg, payload);
+    KPROF_COUNT(c.d.g, 4);
+    KPROF_MARK(c.d.g, 5);
   }
   __device__ static void on_task(Ctx& c, const State& s, NodeRegs& r, uint32_t word, uint32_t arg) {
-    if (word == H_TASK_DISSEMINATION)
+    KPROF_DECL;
+    if (word == H_TASK_DISSEMINATION) {
       dissemination(c, s, r);
-    else
+      KPROF_COUNT(c.d.g, 6);
+      KPROF_MARK(c.d.g, 7);
+    } else {
       update_verified(c, s, r, arg);
+      KPROF_COUNT(c.d.g, 11);
+      KPROF_MARK(c.d.g, 12);
+    }
   }
 
   __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
-    for (int l = WG_LANE; l < s.L; l += 64) {
-      size_t i = (size_t)node * s.L + l;
-      ls->pos[l] = s.pos[i];
-      ls->cTI[l] = s.cTI[i];
-      ls->cLA[l] = s.cLA[i];
-      ls->cVI[l] = s.cVI[i];
-      ls->qlen[l] = s.qlen[i];
-      ls->outFin[l] = s.outFin[i];
-      ls->qused[l] = s.qused[i];
-    }
+    const uint32_t* h = h_hdr(s, node) + HH_LV;
+    const int LS = s.LS;
+    for (int i = WG_LANE; i < 6 * LS; i += 64)  // planes HP_POS..HP_OUTFIN, consecutive words
+      ((int32_t*)ls)[((i >> s.lsShift) << 5) + (i & (LS - 1))] = (int32_t)h[i];
+    for (int l = WG_LANE; l < LS; l += 64)
+      ls->qused[l] = (unsigned long long)h[HP_QUSED_LO * LS + l] | ((unsigned long long)h[HP_QUSED_HI * LS + l] << 32);
     __builtin_amdgcn_wave_barrier();
   }
   __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
     __builtin_amdgcn_wave_barrier();
-    for (int l = WG_LANE; l < s.L; l += 64) {
-      size_t i = (size_t)node * s.L + l;
-      s.pos[i] = ls->pos[l];
-      s.cTI[i] = ls->cTI[l];
-      s.cLA[i] = ls->cLA[l];
-      s.cVI[i] = ls->cVI[l];
-      s.qlen[i] = (uint8_t)ls->qlen[l];
-      s.outFin[i] = (uint8_t)ls->outFin[l];
-      s.qused[i] = ls->qused[l];
+    uint32_t* h = h_hdr(s, node) + HH_LV;
+    const int LS = s.LS;
+    for (int i = WG_LANE; i < 6 * LS; i += 64)
+      h[i] = (uint32_t)((const int32_t*)ls)[((i >> s.lsShift) << 5) + (i & (LS - 1))];
+    for (int l = WG_LANE; l < LS; l += 64) {
+      h[HP_QUSED_LO * LS + l] = (uint32_t)ls->qused[l];
+      h[HP_QUSED_HI * LS + l] = (uint32_t)(ls->qused[l] >> 32);
     }
   }
-
 
   // ---- lane-per-node form of onNewSig for k_deliver_msgs: the same statements as on_new_sig below, one
   // lane per receiving node; payloads wider than one word are handed back as a copy job --------------------
@@ -213,14 +226,15 @@ struct HandelProto {
     int32_t sigQueueSize0, msgFiltered0;
   };
   __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
+    const uint32_t* h = h_hdr(s, node);
     r.doneAt = d.nodes.doneAt[node];
-    r.startAt = s.startAt[node];
-    r.sigQueueSize = r.sigQueueSize0 = s.sigQueueSize[node];
-    r.msgFiltered = r.msgFiltered0 = s.msgFiltered[node];
+    r.startAt = (int32_t)h[HH_START];
+    r.sigQueueSize = r.sigQueueSize0 = (int32_t)h[HH_SIGQ];
+    r.msgFiltered = r.msgFiltered0 = (int32_t)h[HH_FILT];
   }
   __device__ static void lane_end(const EngineDev&, const State& s, int32_t node, const LaneNode& r) {
-    if (r.sigQueueSize != r.sigQueueSize0) s.sigQueueSize[node] = r.sigQueueSize;
-    if (r.msgFiltered != r.msgFiltered0) s.msgFiltered[node] = r.msgFiltered;
+    if (r.sigQueueSize != r.sigQueueSize0) h_hdr(s, node)[HH_SIGQ] = (uint32_t)r.sigQueueSize;
+    if (r.msgFiltered != r.msgFiltered0) h_hdr(s, node)[HH_FILT] = (uint32_t)r.msgFiltered;
   }
   __device__ static void lane_message(const EngineDev& d, const State& s, int32_t t, int32_t node, LaneNode& r,
                                       int32_t from, uint32_t msg, uint32_t payload, CopyJob& job) {
@@ -242,11 +256,14 @@ struct HandelProto {
     const uint64_t fpv = levelFinished ? *fpp : 0ULL;
     const uint64_t tvv = *tvp;
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
-    const unsigned long long used = s.qused[nl];
-    const int len = s.qlen[nl];
+    uint32_t* qlo = h_lv(s, node, HP_QUSED_LO, l);
+    uint32_t* qhi = h_lv(s, node, HP_QUSED_HI, l);
+    uint32_t* qln = h_lv(s, node, HP_QLEN, l);
+    const unsigned long long used = (unsigned long long)*qlo | ((unsigned long long)*qhi << 32);
+    const int len = (int)*qln;
     const uint64_t* src = (payload & H_REF_RING) ? d.payload + (payload & ~H_REF_RING) : s.snap + payload;
     const int nw = h_nw(l);
-    const uint64_t pw0 = nw == 1 ? src[0] : 0ULL;
+    const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
     if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
     if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
     r.sigQueueSize++;
@@ -260,8 +277,11 @@ struct HandelProto {
     uint64_t* dst = sig_ptr(s, node, l, slot);
     s.qfrom[nl * s.Q + slot] = from;
     s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
-    s.qused[nl] = used | (1ULL << slot);
-    s.qlen[nl] = (uint8_t)(len + 1);
+    if (slot < 32)
+      *qlo = (uint32_t)used | (1u << slot);
+    else
+      *qhi = (uint32_t)(used >> 32) | (1u << (slot - 32));
+    *qln = (uint32_t)(len + 1);
     if (nw == 1) {
       dst[0] = pw0;
     } else {
@@ -335,17 +355,11 @@ struct HandelProto {
     return got;
   }
 
-  // snapshot of totalOutgoing of level l (the node's own block of the TI row).
-  // periodic = true: the dissemination's computed slot; false (fast path, irregular): engine payload ring.
-  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l, bool periodic) {
+  // snapshot of totalOutgoing of level l (the node's own block of the TI row) for a fast-path send
+  // (irregular: engine payload ring); the periodic dissemination has its own computed slot.
+  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l) {
     Lv v = own_view(c.node, l);
     const uint64_t* ti = s.TI + (size_t)c.node * s.W;
-    if (periodic) {
-      const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
-      const uint32_t ref = (win * (uint32_t)s.N + (uint32_t)c.node) * s.snapStride + s.lvlOff[l];
-      H_FOR_WORDS(v, j) s.snap[ref + j] = ti[v.bw + j] & v.mask;
-      return ref;
-    }
     uint32_t ref = c.alloc_payload(v.nw);
     H_FOR_WORDS(v, j) c.d.payload[ref + j] = ti[v.bw + j] & v.mask;
     return ref | H_REF_RING;
@@ -376,7 +390,7 @@ struct HandelProto {
     const int j0 = (int)((WG_LANE - v.bw) & 63);
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
-    if (has0) pw0 = src[j0];
+    if (has0) pw0 = src[j0] & v.mask;
     const bool owner = (int)WG_LANE == (w & 63);
     if (levelFinished && owner) *fpp = fpv | bit;                 // finishedPeers.set(from)
     if (!(viv & bit) && owner) *tvp = tvv | bit;                  // toVerifyInd.set(from) unless verified
@@ -405,6 +419,11 @@ struct HandelProto {
   }
 
   // ---- PeriodicTask: dissemination (:331-343) -> HLevel.doCycle (:474-484) ------------------------
+  // The reference walks the levels one after the other; done literally that is one chain of dependent
+  // HBM round trips per level (peer id -> its finishedPeers bit -> the snapshot's words). Here lane l
+  // resolves level l's isOpen() and first candidate peer, so all levels' lookups are two round trips in
+  // total, and the snapshots of all open levels are one flat copy. A level whose first candidate is a
+  // finished peer (the scan of getRemainingPeers :486-508 has to go on) takes the sequential path.
   __device__ static void dissemination(Ctx& c, const State& s, NodeRegs& r) {
     if (r.doneAt > 0) {
       if (r.addedCycle > 0)
@@ -413,22 +432,85 @@ struct HandelProto {
         return;
     }
     LevelScalars* ls = r.ls;
-    int cur = ls->cTI[0];  // |totalOutgoing| of level l = sum of |totalIncoming| below l
-    for (int l = 1; l < s.L; l++) {
-      const int size = 1 << (l - 1);
-      const int below = cur;
-      cur += ls->cTI[l];
-      if (ls->outFin[l]) continue;                                              // isOpen :458-472
-      if (!(c.t >= (l - 1) * s.p.levelWaitTime || below == size)) continue;
-      int32_t dest = -1;
-      int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
-      if (got > 0) {
-        dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
-        uint32_t ref = snapshot_outgoing(c, s, l, true);
-        bool lf = ls->cTI[l] == size;                                           // incomingComplete :524-526
-        c.send(dest, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
+    const int lane = WG_LANE;
+    const int32_t node = c.node;
+    // |totalOutgoing| of level l = sum of |totalIncoming| below l
+    const int cti = lane < s.L ? ls->cTI[lane] : 0;
+    int incl = cti;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int below = incl - cti;
+    bool open = false, fin = false;
+    int32_t cand = 0;
+    int myPos = 0;
+    const int mySize = (lane >= 1 && lane < s.L) ? 1 << (lane - 1) : 0;
+    if (mySize) {
+      open = !ls->outFin[lane] && (c.t >= (lane - 1) * s.p.levelWaitTime || below == mySize);  // isOpen :458-472
+      if (open) {
+        myPos = ls->pos[lane];
+        cand = s.peers[(size_t)node * (s.N - 1) + (mySize - 1) + myPos];
       }
     }
+    KPROF_DECL;
+    const uint64_t openM = __ballot(open);
+    if (!openM) return;
+    if (open) fin = (ld_coherent(s.FP + (size_t)node * s.W + (cand >> 6)) >> (cand & 63)) & 1ULL;
+    const bool lf = cti == mySize;  // incomingComplete :524-526
+    // snapshots (SendSigs.sigs = totalOutgoing.clone() :254): totalOutgoing of level l is the node's own aligned
+    // block of 2^(l-1) ids in the TI row, and those blocks are nested — so ONE copy of the highest open level's
+    // block serves every level: level l's message points at its sub-range (the receiver masks single-word
+    // blocks with its level mask). Loads first, stores after.
+    const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
+    const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
+    {
+      const uint64_t* ti = s.TI + (size_t)node * s.W + tv.bw;
+      for (int j0 = 0; j0 < tv.nw; j0 += 256) {
+        uint64_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int j = j0 + q * 64 + lane;
+          v[q] = j < tv.nw ? ti[j] & tv.mask : 0ULL;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int j = j0 + q * 64 + lane;
+          if (j < tv.nw) s.snap[refBase + j] = v[q];
+        }
+      }
+    }
+    KPROF_MARK(c.d.g, 9);   // snapshots
+    const uint64_t okM = __ballot(open && !fin);
+    KPROF_MARK(c.d.g, 8);   // candidate peers' finished bits
+    if (open && !fin) ls->pos[lane] = myPos + 1 >= mySize ? 0 : myPos + 1;  // getRemainingPeers(1) took the candidate
+    __builtin_amdgcn_wave_barrier();
+    if (okM == openM) {  // every open level took its first candidate: lane l writes level l's send
+      long long bytes = 0;
+      for (uint64_t m = openM; m; m &= m - 1) bytes += h_msg_size(__ffsll((unsigned long long)m) - 1);
+      c.send_many(open, __popcll(openM & lanes_lt()), __popcll(openM), cand, (uint32_t)lane | (lf ? 32u : 0u),
+                  refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
+      KPROF_MARK(c.d.g, 10);
+      return;
+    }
+    for (uint64_t m = openM; m; m &= m - 1) {  // sends in level order (one rd.nextInt() each, :374-382)
+      const int l = __ffsll((unsigned long long)m) - 1;
+      int32_t dest;
+      if ((okM >> l) & 1ULL) {
+        dest = __shfl(cand, l, 64);
+      } else {
+        dest = -1;
+        const int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
+        if (got <= 0) continue;
+        dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
+      }
+      const bool lfl = __shfl((int)lf, l, 64) != 0;
+      c.send(dest, (uint32_t)l | (lfl ? 32u : 0u), refBase + (uint32_t)(own_view(node, l).bw - tv.bw), h_msg_size(l));
+      if (!((okM >> l) & 1ULL)) KPROF_COUNT(c.d.g, 13);  // levels that took the sequential scan
+    }
+    KPROF_MARK(c.d.g, 10);  // sends
   }
 
   // ---- Task: updateVerifiedSignatures (:690-754) --------------------------------------------------
@@ -553,7 +635,7 @@ struct HandelProto {
           uint32_t destOff = c.dest_reserve(s.p.fastPath);
           int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
           if (n > 0) {
-            uint32_t ref = snapshot_outgoing(c, s, l, false);
+            uint32_t ref = snapshot_outgoing(c, s, l);
             bool lf = ls->cTI[l] == (1 << (l - 1));
             __threadfence_block();
             c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
@@ -583,15 +665,16 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
     if (node < (uint32_t)s.N) {
-      if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
-        const int32_t ms = s.ctMinStart[node];
+      uint32_t* h = h_hdr(s, (int32_t)node);
+      if (!d.nodes.down[node] && h[HH_CTEPOCH] != epoch) {
+        const int32_t ms = (int32_t)h[HH_CTMIN];
         if (ms <= until && ms <= t) {
-          s.ctEpoch[node] = epoch;
-          run = s.sigQueueSize[node] != 0;  // startIf = hasSigToVerify (:345-347)
+          h[HH_CTEPOCH] = epoch;
+          run = h[HH_SIGQ] != 0;  // startIf = hasSigToVerify (:345-347)
         }
       }
       if (run)
-        s.ctMinStart[node] = t + s.pairing[node];  // minStartTime = time + duration (:557-560)
+        h[HH_CTMIN] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
       else
         s.candCnt[node] = 0;
     }
@@ -624,11 +707,12 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     const uint64_t* ti = s.TI + (size_t)node * s.W;
     const uint64_t* la = s.LA + (size_t)node * s.W;
     const uint64_t* vi = s.VI + (size_t)node * s.W;
-    const int window = s.window[node];
-    int sigQueueSize = s.sigQueueSize[node];
+    uint32_t* hh = h_hdr(s, node);
+    const int window = (int)hh[HH_WINDOW];
+    int sigQueueSize = (int)hh[HH_SIGQ];
     uint32_t pend[H_PEND];
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) pend[k] = s.pend[(size_t)node * H_PEND + k];
+    for (int k = 0; k < H_PEND; k++) pend[k] = hh[HH_PEND + k];
     int ncand = 0;
     // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
     uint32_t lvMask = 0;
@@ -754,7 +838,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     }
     HandelProto::store_levels(s, node, ls);
     if (lane == 0) {
-      s.sigQueueSize[node] = sigQueueSize;
+      hh[HH_SIGQ] = (uint32_t)sigQueueSize;
       s.candCnt[node] = (uint8_t)ncand;
     }
     __builtin_amdgcn_wave_barrier();
@@ -817,18 +901,19 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       const int slot = s.candSlot[(size_t)node * s.L + k];
       const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
-      int w = s.window[node] * 2;
+      uint32_t* h = h_hdr(s, node);
+      int w = (int)h[HH_WINDOW] * 2;
       if (w > s.p.windowMaximum) w = s.p.windowMaximum;
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
-      s.window[node] = min(w, 1 << (l - 1));
+      h[HH_WINDOW] = (uint32_t)min(w, 1 << (l - 1));
       // receptionRanks[best.from] += nodeCount, saturating (:825-828)
       int32_t* rk = s.ranks + (size_t)node * s.N + from;
       int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
       *rk = nr < 0 ? INT32_MAX : nr;
-      s.sigsChecked[node]++;
+      h[HH_SIGCHK]++;
       int pe = -1;
       for (int q = 0; q < H_PEND; q++)
-        if (!(s.pend[(size_t)node * H_PEND + q] & 0x80000000u)) {
+        if (!(h[HH_PEND + q] & 0x80000000u)) {
           pe = q;
           break;
         }
@@ -836,10 +921,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         set_err(d.g, ERR_PENDING);
         pe = 0;
       }
-      s.pend[(size_t)node * H_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
-      s.pendFrom[(size_t)node * H_PEND + pe] = from;
+      h[HH_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
+      h[HH_PENDFROM + pe] = (uint32_t)from;
       // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
-      const int32_t arrival = t + s.pairing[node];
+      const int32_t arrival = t + (int32_t)h[HH_PAIR];
       d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
       const bool ok = arrival - t < d.horizon - 1;  // see Engine::run_ms on host-held envelopes
       d.arr[j] = ok ? arrival : -1;
