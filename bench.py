@@ -19,6 +19,7 @@ collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak"
 One JSON line on stdout (rank 0). Everything else goes to stderr.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -176,6 +177,7 @@ def main():
         batch.run_multiple_times(chunk=10, maxTime=20000)
         prof_phase = sims[0].network().profile_read()
         del batch, sims
+        gc.collect()  # Network <-> MessageStorage cycles hold ~15 GB of HBM per copy until collected
     timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads, args.workload)
              for i in range(K)]
     inits += K * R
@@ -207,6 +209,7 @@ def main():
             by_level = bl if by_level is None else by_level + bl
     check = int(sum(int(g.network().read("msgReceived").sum()) for g in timed[-1][0]))
     del timed
+    gc.collect()
 
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)

@@ -166,6 +166,12 @@ const char* wg_batch_last_error(wg_batch* b);       /* b may be NULL: error of a
  * (a copy whose predicate turned false stops, C/RunMultipleTimes.java:56-61). didSomething / stats: [n] or NULL. */
 int32_t wg_batch_run_ms(wg_batch* b, int32_t ms, const uint8_t* active, uint8_t* didSomething, wg_run_stats* stats);
 int32_t wg_batch_cont_if(wg_batch* b, int32_t* cont); /* wg_protocol_cont_if for every member, one launch; cont[n] */
+/* RunMultipleTimes.run's inner loop (C/RunMultipleTimes.java:50-64) for every member, evaluated on the device:
+ *   do { didSomething = runMs(chunk); } while ((maxTime == 0 || time < maxTime) && (!didSomething || contIf(p)));
+ * Chunks are enqueued back to back with no host round trip per runMs; a member whose loop ended is no longer
+ * advanced. delivered[n] / simulatedMs[n] (NULL allowed): msgReceived increments and Network.time advance. */
+int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime, int64_t* delivered,
+                                    int64_t* simulatedMs);
 
 /* ---- read-back -------------------------------------------------------------------------- */
 typedef enum {

@@ -82,3 +82,18 @@ def test_batch_rejects_mismatched_members():
         w.Batch([a.network(), b.network()])
     with pytest.raises(w.IllegalArgumentException):
         w.Batch([a.network(), a.network()])
+
+
+@pytest.mark.parametrize("n", [512])
+def test_run_multiple_times_device_loop_equals_host_loop(n):
+    """wg_batch_run_multiple_times (loop condition evaluated on the device, chunks enqueued back to back) and the
+    same loop driven from the host with one wg_batch_run_ms per chunk reach the same state, per member."""
+    seeds = [3, 4, 5]
+    res = []
+    for on_device in (True, False):
+        gs = [parity.handel_pair(ratios(n), seed=s)[0] for s in seeds]
+        batch = w.Batch([g.network() for g in gs])
+        out = batch.run_multiple_times(chunk=10, maxTime=20000, on_device=on_device)
+        res.append((out, [(g.network().time, g.network().rng_state(), g.network().read("doneAt").tolist(),
+                           g.network().read("msgReceived").tolist()) for g in gs]))
+    assert res[0] == res[1]

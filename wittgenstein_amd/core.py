@@ -281,12 +281,19 @@ class Batch:
         self._ck(L.lib().wg_batch_cont_if(self._h, out))
         return [bool(v) for v in out]
 
-    def run_multiple_times(self, chunk=10, maxTime=0):
+    def run_multiple_times(self, chunk=10, maxTime=0, on_device=True):
         """RunMultipleTimes.run's inner loop (C/RunMultipleTimes.java:50-64) for all members at once:
             do { didSomething = runMs(10); }
             while ((maxTime == 0 || time < maxTime) && (!didSomething || contIf.test(c)));
-        A member whose loop ended is no longer advanced. Returns per-member (delivered, simulated_ms)."""
+        A member whose loop ended is no longer advanced. Returns per-member (delivered, simulated_ms).
+        on_device: the loop condition is evaluated by the engine (wg_batch_run_multiple_times), chunks are
+        enqueued back to back; False drives it from here with one wg_batch_run_ms per chunk."""
         n = len(self.networks)
+        if on_device:
+            dl = (C.c_int64 * n)()
+            ms = (C.c_int64 * n)()
+            self._ck(L.lib().wg_batch_run_multiple_times(self._h, int(chunk), int(maxTime), dl, ms))
+            return [int(v) for v in dl], [int(v) for v in ms]
         delivered, sim_ms = [0] * n, [0] * n
         active = [True] * n
         while any(active):

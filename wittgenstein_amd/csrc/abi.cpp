@@ -222,6 +222,12 @@ int32_t wg_batch_cont_if(wg_batch* b, int32_t* cont) {
   WGB_END(b)
 }
 
+int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime, int64_t* delivered, int64_t* simulatedMs) {
+  if (!b) return WG_EINVAL;
+  WGB_TRY b->b->run_multiple_times(chunk, maxTime, delivered, simulatedMs);
+  WGB_END(b)
+}
+
 int32_t wg_profile_enable(wg_engine* h, int32_t on) {
   WG_TRY(h)
   if (on < 0 || on > 2) throw WgError(WG_EINVAL, "mode");

@@ -92,8 +92,13 @@ struct EvAux {
 };
 // what a wave-per-node visit starts from, written by k_deliver_msgs for the nodes it leaves to k_deliver:
 // the node, its newest event and that event's record — one coalesced read instead of three dependent ones
-struct VisitDesc {
-  int32_t node, e0, next0, pad;
+struct alignas(16) U4 {  // one 16-byte vector load / store per lane
+  uint32_t x, y, z, w;
+};
+constexpr uint32_t VD_DOWN = 1u;  // VisitDesc::flags: the node is down | partition id << 8
+struct alignas(16) VisitDesc {
+  int32_t node, e0, next0;
+  uint32_t flags;
   Rec rec0;
   EvAux aux0;
 };

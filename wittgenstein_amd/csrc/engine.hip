@@ -707,6 +707,50 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   run_group(&me, 1, nullptr, g, ms, didSomething, stats);
 }
 
+// One simulated ms: drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the new `now`.
+static void enqueue_one_ms(Engine& lead, const Group& g) {
+  ProtoHost* proto = lead.proto;
+  const bool cond = proto->has_cond();
+  typedef Engine::ProfScope ProfScope;
+    {
+      ProfScope ps(lead, Engine::PC_EXPAND);
+      Engine::scan<ExpandF>(g, nullptr);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_DELIVER);
+      proto->launch_deliver(g);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_ORDER);
+      Engine::scan<RecsF>(g, nullptr);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_RESOLVE);
+      hipLaunchKernelGGL(k_resolve, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_APPEND);
+      Engine::append_phase(g, false);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_END);
+      Engine::end_phase(g, true);
+    }
+    if (cond) {
+      proto->launch_cond(lead, g);
+      {
+        ProfScope ps(lead, Engine::PC_APPEND);
+        Engine::append_phase(g, false);
+      }
+      ProfScope ps(lead, Engine::PC_END);
+      Engine::end_phase(g, false);
+    }
+  }
+
+void Engine::enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms) {
+  for (int32_t k = 0; k <= ms; k++) enqueue_one_ms(lead, g);
+}
+
 // One simulated ms = drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the
 // new `now` (:543-566). runMs(ms) is ms + 1 of those: the first drain re-visits the current ms
 // (envelopes the host registered for it), the last conditional phase is the edge to until + 1, which
@@ -742,39 +786,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
           e.flush_staged(t, true);
         }
       }
-    {
-      ProfScope ps(lead, PC_EXPAND);
-      scan<ExpandF>(g, nullptr);
-    }
-    {
-      ProfScope ps(lead, PC_DELIVER);
-      proto->launch_deliver(g);
-    }
-    {
-      ProfScope ps(lead, PC_ORDER);
-      scan<RecsF>(g, nullptr);
-    }
-    {
-      ProfScope ps(lead, PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
-    }
-    {
-      ProfScope ps(lead, PC_APPEND);
-      append_phase(g, false);
-    }
-    {
-      ProfScope ps(lead, PC_END);
-      end_phase(g, true);
-    }
-    if (cond) {
-      proto->launch_cond(lead, g);
-      {
-        ProfScope ps(lead, PC_APPEND);
-        append_phase(g, false);
-      }
-      ProfScope ps(lead, PC_END);
-      end_phase(g, false);
-    }
+    enqueue_one_ms(lead, g);
   }
   WG_HIP(hipStreamSynchronize(g.stream));
   auto t1 = std::chrono::steady_clock::now();
@@ -903,6 +915,77 @@ void Batch::cont_if(int32_t* out) {
   WG_HIP(hipMemcpyAsync(v.data(), dCont, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, l.stream));
   WG_HIP(hipStreamSynchronize(l.stream));
   for (int r = 0; r < n; r++) out[r] = (int32_t)v[r];
+}
+
+
+// RunMultipleTimes.run's inner loop (C/RunMultipleTimes.java:50-64) for every member without a host round
+// trip per runMs: chunks are enqueued back to back (k_chunk_begin, the ms sequence, the predicate kernel,
+// k_chunk_end); the host only looks at the number of members still running every few chunks.
+void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivered, int64_t* simulatedMs) {
+  if (chunk <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(chunk));
+  const int n = (int)members.size();
+  Engine& l = *members[0];
+  WG_HIP(hipSetDevice(l.cfg.device));
+  std::vector<Globals> before(n);
+  std::vector<int32_t> t0(n);
+  bool hostLoop = false;
+  for (int r = 0; r < n; r++) {
+    Engine& e = *members[r];
+    e.flush_staged(e.time, false);
+    if (e.stagedMin != INT32_MAX) hostLoop = true;  // envelopes held on the host beyond the bucket ring
+  }
+  if (hostLoop) throw WgError(WG_EUNSUPPORTED, "host-held envelopes beyond horizon_ms: use wg_batch_run_ms per chunk");
+  for (int r = 0; r < n; r++) {
+    Engine& e = *members[r];
+    before[r] = e.gh;
+    t0[r] = e.time;
+    e.gh.until = e.time;  // k_chunk_begin reads Network.time from `until`
+    e.globalsDirty = true;
+    e.sync_globals_to_device();
+  }
+  Group g = prepare(nullptr);
+  EngineDev* tab = dTab;
+  uint32_t* dRunning = nullptr;
+  WG_HIP(hipMalloc((void**)&dRunning, sizeof(uint32_t)));
+  const int CHECK_EVERY = 4;
+  uint32_t running = (uint32_t)n;
+  while (running) {
+    for (int k = 0; k < CHECK_EVERY; k++) {
+      hipLaunchKernelGGL(k_chunk_begin, dim3(n), dim3(64), 0, g.stream, tab, chunk);
+      Engine::enqueue_ms_sequence(l, g, chunk);
+      WG_HIP(hipMemsetAsync(dCont, 0, sizeof(uint32_t) * n, g.stream));
+      if (!l.proto->launch_cont_if(g, dCont)) {
+        (void)hipFree(dRunning);
+        throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+      }
+      WG_HIP(hipMemsetAsync(dRunning, 0, sizeof(uint32_t), g.stream));
+      hipLaunchKernelGGL(k_chunk_end, dim3(n), dim3(64), 0, g.stream, tab, dCont, maxTime, dRunning);
+    }
+    WG_HIP(hipMemcpyAsync(&running, dRunning, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    WG_HIP(hipStreamSynchronize(g.stream));
+  }
+  (void)hipFree(dRunning);
+  if (l.profiling) l.prof_collect();
+  hTab.clear();  // the device table now carries halted flags the host shadow does not
+  std::string firstErr;
+  int32_t firstCode = WG_OK;
+  for (int r = 0; r < n; r++) {
+    Engine& e = *members[r];
+    e.sync_globals_to_host();
+    e.time = e.gh.until;
+    if (delivered) delivered[r] = (int64_t)(e.gh.delivered - before[r].delivered);
+    if (simulatedMs) simulatedMs[r] = (int64_t)e.time - t0[r];
+    try {
+      e.check_device_errors();
+    } catch (const WgError& x) {
+      e.lastError = x.what();
+      if (firstCode == WG_OK) {
+        firstCode = x.code;
+        firstErr = x.what();
+      }
+    }
+  }
+  if (firstCode != WG_OK) throw WgError(firstCode, firstErr);
 }
 
 int64_t Engine::queue_size() {  // msgs.size(): number of envelopes (a multi-dest envelope counts once)

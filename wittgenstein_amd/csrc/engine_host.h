@@ -98,6 +98,8 @@ class Engine {
   // Network.runMs for every active member of a group in lock-step (one launch sequence for all)
   static void run_group(Engine** es, int R, const uint8_t* active, const Group& g, int32_t ms, uint8_t* did,
                         wg_run_stats* stats);
+  // the kernel sequence of runMs(ms) for a group whose members' globals are set up (begin_run / k_chunk_begin)
+  static void enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms);
   void begin_run(int32_t ms, int32_t* endAt);
   EngineDev* dTab = nullptr;     // device copy of `dev` (table of one)
   void* dStab = nullptr;         // device copy of the protocol State struct
@@ -204,6 +206,8 @@ class Batch {
   ~Batch();
   void run_ms(int32_t ms, const uint8_t* active, uint8_t* did, wg_run_stats* stats);
   void cont_if(int32_t* out);
+  // RunMultipleTimes.run's inner loop for every member, on the device (include/wittgpu.h)
+  void run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivered, int64_t* simulatedMs);
   std::vector<Engine*> members;
   std::string lastError;
 

@@ -657,21 +657,23 @@ struct Ctx {
   long long msgSent, bytesSent;  // accumulated Node counters (C/Network.java:476-477)
 
   __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw) {
-    if (WG_LANE == 0) {
-      if (sub < outCap && outBase + sub < d.maxOut) {
-        Out o;
-        o.kindfrom = (kind << 28) | (uint32_t)node;
-        o.to = to;
-        o.a = a;
-        o.b = b;
-        o.t = tt;
-        o.destOff = destOff;
-        o.drawsub = draws;
-        o.pad = 0;
-        d.outTmp[outBase + sub] = o;
+    if (sub < outCap && outBase + sub < d.maxOut) {
+      // the 32-byte record as ONE memory instruction: lanes 0 and 1 store 16 bytes each
+      U4 q;
+      if (WG_LANE == 0) {
+        q.x = (kind << 28) | (uint32_t)node;
+        q.y = (uint32_t)to;
+        q.z = a;
+        q.w = b;
       } else {
-        set_err(d.g, ERR_OUTBOX);  // the protocol's emission bound (EngineDev::boundMsg/boundTask) is wrong
+        q.x = (uint32_t)tt;
+        q.y = destOff;
+        q.z = draws;
+        q.w = 0;
       }
+      if (WG_LANE < 2) ((U4*)&d.outTmp[outBase + sub])[WG_LANE] = q;
+    } else if (WG_LANE == 0) {
+      set_err(d.g, ERR_OUTBOX);  // the protocol's emission bound (EngineDev::boundMsg/boundTask) is wrong
     }
     if (sub < outCap) sub++;
     if (draw) draws++;
@@ -835,15 +837,30 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
     KPROF_COUNT(d.g, 0);
     VisitDesc vd;
     if (useB) {
-      vd = d.activeB[a];
+      // the 48-byte descriptor in ONE memory instruction (lanes 0..2 take 16 bytes each): the kernel is bound
+      // by the number of scattered wave-level memory instructions, not by their bytes
+      const U4 q = ((const U4*)&d.activeB[a])[lane < 3 ? lane : 0];
+      vd.node = (int32_t)__shfl(q.x, 0, 64);
+      vd.e0 = (int32_t)__shfl(q.y, 0, 64);
+      vd.next0 = (int32_t)__shfl(q.z, 0, 64);
+      vd.flags = __shfl(q.w, 0, 64);
+      vd.rec0.w0 = __shfl(q.x, 1, 64);
+      vd.rec0.w1 = __shfl(q.y, 1, 64);
+      vd.rec0.w2 = __shfl(q.z, 1, 64);
+      vd.rec0.w3 = __shfl(q.w, 1, 64);
+      vd.aux0.chain = (int32_t)__shfl(q.x, 2, 64);
+      vd.aux0.cpos = (int32_t)__shfl(q.y, 2, 64);
+      vd.aux0.outBase = __shfl(q.z, 2, 64);
+      vd.aux0.outCap = __shfl(q.w, 2, 64);
     } else {
       vd.node = (int32_t)d.active[a];
       vd.e0 = d.head[vd.node];  // newest event of the node (always >= 0 for a listed node)
+      vd.flags = (d.nodes.down[vd.node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[vd.node] << 8 : 0u);
     }
     const int32_t node = vd.node;
     const int32_t e0 = vd.e0;
-    const bool toDown = d.nodes.down[node] != 0;
-    const uint8_t toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
+    const bool toDown = (vd.flags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vd.flags >> 8);
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
     typename P::NodeRegs r;
     long long nRecv = 0, bRecv = 0;
@@ -918,7 +935,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
         atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
         atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
       }
-      d.head[node] = -1;
+      if (!useB) d.head[node] = -1;  // (k_deliver_msgs has emptied the inbox lists already)
     }
     __builtin_amdgcn_wave_barrier();
     KPROF_MARK(d.g, 3);  // node_end + counters
@@ -960,9 +977,11 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     bool mine = have;
     VisitDesc vd;
     vd.node = node;
-    vd.pad = 0;
+    vd.flags = 0;
     if (have) {
       int32_t e = d.head[node];
+      d.head[node] = -1;  // the list is consumed here (k_deliver works from the descriptor and evNext)
+      vd.flags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
       vd.e0 = e;
       int cnt = 0;
       while (e >= 0 && cnt < 4) {
@@ -997,13 +1016,9 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       }
     }
     typename P::LaneNode r;
-    bool toDown = false;
-    uint8_t toPart = 0;
-    if (mine) {
-      toDown = d.nodes.down[node] != 0;
-      toPart = d.nparts ? d.nodes.part[node] : (uint8_t)0;
-      P::lane_begin(d, ps, node, r);
-    }
+    const bool toDown = (vd.flags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vd.flags >> 8);
+    if (mine) P::lane_begin(d, ps, node, r);
     long long nRecv = 0, bRecv = 0;
     uint32_t nJobs = 0;
 #pragma unroll
@@ -1036,7 +1051,6 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
         atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
       }
-      d.head[node] = -1;
     }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = 0; j < nJobs; j++) {  // wide payloads: the whole wavefront copies, coalesced
@@ -1045,6 +1059,40 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RunMultipleTimes' inner loop (C/RunMultipleTimes.java:50-64) kept on the device, so that a batch runs
+// chunk after chunk without a host round trip per runMs:
+//   do { didSomething = runMs(chunk); } while ((maxTime == 0 || time < maxTime) && (!didSomething || contIf(p)));
+// k_chunk_begin = the head of Network.runMs (:318-338) for every member still running; k_chunk_end = the
+// loop condition (cont[] comes from the protocol's predicate kernel); a member whose loop ended gets
+// `halted` in the device table and every later kernel returns at once for it.
+__global__ void k_chunk_begin(EngineDev* tab, int32_t ms) {
+  EngineDev& d = tab[blockIdx.x];
+  if (d.halted || threadIdx.x != 0) return;
+  Globals* g = d.g;
+  const int32_t time = g->until;  // Network.time after the previous runMs
+  const int32_t endAt = (int32_t)((uint32_t)time + (uint32_t)ms);
+  if (endAt <= 0) {  // "Maximum time reached!" (:333) — stop the member; the host reports it
+    set_err(g, ERR_ARRIVAL_PAST);
+    d.halted = 1;
+    return;
+  }
+  g->epoch++;  // a new receiveUntil() starts with a fresh nextMessage() call
+  g->anyEvent = 0;
+  g->now = time;
+  g->until = endAt;
+}
+__global__ void k_chunk_end(EngineDev* tab, const uint32_t* cont, int32_t maxTime, uint32_t* running) {
+  EngineDev& d = tab[blockIdx.x];
+  if (d.halted || threadIdx.x != 0) return;
+  const Globals* g = d.g;
+  const bool goOn = (maxTime == 0 || g->until < maxTime) && (!g->anyEvent || cont[blockIdx.x] != 0) && g->err == 0;
+  if (!goOn)
+    d.halted = 1;
+  else
+    atomicAdd(running, 1u);
 }
 
 }  // namespace wg

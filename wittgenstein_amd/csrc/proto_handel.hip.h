@@ -34,6 +34,7 @@ struct HandelState {
   // back as a few consecutive cache lines of one page, instead of twenty 64-byte lines in twenty arrays:
   //   [HH_ADDED .. HH_CTEPOCH]  addedCycle, sigQueueSize, msgFiltered, startAt, nodePairingTime, currWindowSize,
   //                              sigsChecked, ConditionalTask.minStartTime, the epoch it last left nextMessage()'s copy
+  //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
   //   [HH_LV + plane*LS + l]     planes posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
   //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L
@@ -61,7 +62,8 @@ struct HandelState {
 };
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
-                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_PEND = 12, HH_PENDFROM = 16, HH_LV = 32 };
+                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_PEND = 12, HH_PENDFROM = 16,
+                       HH_LV = 32 };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t* h_lv(const HandelState& s, int32_t node, int plane, int l) {
@@ -121,15 +123,24 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 }
 
 // per-wave LDS mirror of the (node, level) scalars
-struct LevelScalars {  // the first six arrays mirror the header's planes HP_POS..HP_OUTFIN (32 words each)
+struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_QUSED_HI (32 words each), then the scalars
   int32_t pos[32];
   int32_t cTI[32];
   int32_t cLA[32];
   int32_t cVI[32];
   int32_t qlen[32];
   int32_t outFin[32];
-  unsigned long long qused[32];
+  uint32_t quLo[32];
+  uint32_t quHi[32];
+  uint32_t sc[HH_LV];
 };
+__device__ __forceinline__ unsigned long long ls_qused(const LevelScalars* ls, int l) {
+  return (unsigned long long)ls->quLo[l] | ((unsigned long long)ls->quHi[l] << 32);
+}
+__device__ __forceinline__ void ls_set_qused(LevelScalars* ls, int l, unsigned long long v) {
+  ls->quLo[l] = (uint32_t)v;
+  ls->quHi[l] = (uint32_t)(v >> 32);
+}
 
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
 
@@ -139,7 +150,7 @@ struct HandelProto {
 
   // node-scoped registers (wave-uniform) live in this struct for the duration of a node's events
   struct NodeRegs {
-    long long doneAt;
+    long long doneAt, doneAt0;
     int32_t addedCycle, sigQueueSize, msgFiltered, startAt;
     uint32_t pend[H_PEND];
     int32_t pendFrom[H_PEND];
@@ -150,9 +161,9 @@ struct HandelProto {
   __device__ static int msg_level(uint32_t msg) { return (int)(msg & 31u); }
 
   __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls) {
-    const int32_t node = c.node;
-    const uint32_t* h = h_hdr(s, node);
-    r.doneAt = c.d.nodes.doneAt[node];
+    load_levels(s, c.node, ls);  // the whole header, one memory instruction
+    const uint32_t* h = ls->sc;
+    r.doneAt = r.doneAt0 = (long long)((unsigned long long)h[HH_DONE_LO] | ((unsigned long long)h[HH_DONE_HI] << 32));
     r.addedCycle = (int32_t)h[HH_ADDED];
     r.sigQueueSize = (int32_t)h[HH_SIGQ];
     r.msgFiltered = (int32_t)h[HH_FILT];
@@ -163,20 +174,22 @@ struct HandelProto {
       r.pendFrom[k] = (int32_t)h[HH_PENDFROM + k];
     }
     r.ls = ls;
-    load_levels(s, node, ls);
   }
   __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
     const int32_t node = c.node;
-    store_levels(s, node, r.ls);
+    __builtin_amdgcn_wave_barrier();
     if (WG_LANE == 0) {
-      uint32_t* h = h_hdr(s, node);
-      c.d.nodes.doneAt[node] = r.doneAt;
+      uint32_t* h = r.ls->sc;
+      h[HH_DONE_LO] = (uint32_t)(unsigned long long)r.doneAt;
+      h[HH_DONE_HI] = (uint32_t)((unsigned long long)r.doneAt >> 32);
       h[HH_ADDED] = (uint32_t)r.addedCycle;
       h[HH_SIGQ] = (uint32_t)r.sigQueueSize;
       h[HH_FILT] = (uint32_t)r.msgFiltered;
 #pragma unroll
       for (int k = 0; k < H_PEND; k++) h[HH_PEND + k] = r.pend[k];
+      if (r.doneAt != r.doneAt0) c.d.nodes.doneAt[node] = r.doneAt;  // Node.doneAt proper (read-back, contIf)
     }
+    store_levels(s, node, r.ls);
   }
   __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
     KPROF_DECL;
@@ -197,24 +210,46 @@ struct HandelProto {
     }
   }
 
+  // header <-> LDS image, 16 bytes a lane: 640 bytes (L <= 16) are one memory instruction
   __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
-    const uint32_t* h = h_hdr(s, node) + HH_LV;
+    const U4* g = (const U4*)h_hdr(s, node);
     const int LS = s.LS;
-    for (int i = WG_LANE; i < 6 * LS; i += 64)  // planes HP_POS..HP_OUTFIN, consecutive words
-      ((int32_t*)ls)[((i >> s.lsShift) << 5) + (i & (LS - 1))] = (int32_t)h[i];
-    for (int l = WG_LANE; l < LS; l += 64)
-      ls->qused[l] = (unsigned long long)h[HP_QUSED_LO * LS + l] | ((unsigned long long)h[HP_QUSED_HI * LS + l] << 32);
+    for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) {
+      const U4 q = g[i];
+      const int w = i << 2;
+      uint32_t* dst;
+      if (w < HH_LV) {
+        dst = ls->sc + w;
+      } else {
+        const int r = w - HH_LV;
+        dst = (uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (LS - 1));
+      }
+      dst[0] = q.x;
+      dst[1] = q.y;
+      dst[2] = q.z;
+      dst[3] = q.w;
+    }
     __builtin_amdgcn_wave_barrier();
   }
   __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
     __builtin_amdgcn_wave_barrier();
-    uint32_t* h = h_hdr(s, node) + HH_LV;
+    U4* g = (U4*)h_hdr(s, node);
     const int LS = s.LS;
-    for (int i = WG_LANE; i < 6 * LS; i += 64)
-      h[i] = (uint32_t)((const int32_t*)ls)[((i >> s.lsShift) << 5) + (i & (LS - 1))];
-    for (int l = WG_LANE; l < LS; l += 64) {
-      h[HP_QUSED_LO * LS + l] = (uint32_t)ls->qused[l];
-      h[HP_QUSED_HI * LS + l] = (uint32_t)(ls->qused[l] >> 32);
+    for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) {
+      const int w = i << 2;
+      const uint32_t* src;
+      if (w < HH_LV) {
+        src = ls->sc + w;
+      } else {
+        const int r = w - HH_LV;
+        src = (const uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (LS - 1));
+      }
+      U4 q;
+      q.x = src[0];
+      q.y = src[1];
+      q.z = src[2];
+      q.w = src[3];
+      g[i] = q;
     }
   }
 
@@ -227,7 +262,7 @@ struct HandelProto {
   };
   __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
     const uint32_t* h = h_hdr(s, node);
-    r.doneAt = d.nodes.doneAt[node];
+    r.doneAt = (long long)((unsigned long long)h[HH_DONE_LO] | ((unsigned long long)h[HH_DONE_HI] << 32));
     r.startAt = (int32_t)h[HH_START];
     r.sigQueueSize = r.sigQueueSize0 = (int32_t)h[HH_SIGQ];
     r.msgFiltered = r.msgFiltered0 = (int32_t)h[HH_FILT];
@@ -396,7 +431,7 @@ struct HandelProto {
     if (!(viv & bit) && owner) *tvp = tvv | bit;                  // toVerifyInd.set(from) unless verified
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
-    unsigned long long used = ls->qused[l];
+    unsigned long long used = ls_qused(ls, l);
     unsigned long long capMask = s.Q >= 64 ? ~0ULL : ((1ULL << s.Q) - 1ULL);
     unsigned long long freeM = ~used & capMask;
     int len = ls->qlen[l];
@@ -412,7 +447,7 @@ struct HandelProto {
     if (WG_LANE == 0) {
       s.qfrom[((size_t)node * s.L + l) * s.Q + slot] = from;
       s.qent[((size_t)node * s.L + l) * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
-      ls->qused[l] = used | (1ULL << slot);
+      ls_set_qused(ls, l, used | (1ULL << slot));
       ls->qlen[l] = len + 1;
     }
     __builtin_amdgcn_wave_barrier();
@@ -487,28 +522,24 @@ struct HandelProto {
     KPROF_MARK(c.d.g, 8);   // candidate peers' finished bits
     if (open && !fin) ls->pos[lane] = myPos + 1 >= mySize ? 0 : myPos + 1;  // getRemainingPeers(1) took the candidate
     __builtin_amdgcn_wave_barrier();
-    if (okM == openM) {  // every open level took its first candidate: lane l writes level l's send
-      long long bytes = 0;
-      for (uint64_t m = openM; m; m &= m - 1) bytes += h_msg_size(__ffsll((unsigned long long)m) - 1);
-      c.send_many(open, __popcll(openM & lanes_lt()), __popcll(openM), cand, (uint32_t)lane | (lf ? 32u : 0u),
-                  refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
-      KPROF_MARK(c.d.g, 10);
-      return;
-    }
-    for (uint64_t m = openM; m; m &= m - 1) {  // sends in level order (one rd.nextInt() each, :374-382)
+    // levels whose first candidate is a finished peer: the sequential scan of getRemainingPeers, before any send
+    // (the scan does not depend on the sends; the records keep level order through their rank)
+    uint64_t sendM = okM;
+    for (uint64_t m = openM & ~okM; m; m &= m - 1) {
       const int l = __ffsll((unsigned long long)m) - 1;
-      int32_t dest;
-      if ((okM >> l) & 1ULL) {
-        dest = __shfl(cand, l, 64);
-      } else {
-        dest = -1;
-        const int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
-        if (got <= 0) continue;
-        dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
-      }
-      const bool lfl = __shfl((int)lf, l, 64) != 0;
-      c.send(dest, (uint32_t)l | (lfl ? 32u : 0u), refBase + (uint32_t)(own_view(node, l).bw - tv.bw), h_msg_size(l));
-      if (!((okM >> l) & 1ULL)) KPROF_COUNT(c.d.g, 13);  // levels that took the sequential scan
+      int32_t dest = -1;
+      const int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
+      KPROF_COUNT(c.d.g, 13);
+      if (got <= 0) continue;
+      dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
+      if (lane == l) cand = dest;
+      sendM |= 1ULL << l;
+    }
+    if (sendM) {  // one rd.nextInt() per send, in level order (:374-382): lane l writes level l's record
+      long long bytes = 0;
+      for (uint64_t m = sendM; m; m &= m - 1) bytes += h_msg_size(__ffsll((unsigned long long)m) - 1);
+      c.send_many((sendM >> lane) & 1ULL, __popcll(sendM & lanes_lt()), __popcll(sendM), cand,
+                  (uint32_t)lane | (lf ? 32u : 0u), refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
     }
     KPROF_MARK(c.d.g, 10);  // sends
   }
@@ -535,7 +566,7 @@ struct HandelProto {
     const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block
     const uint64_t bit = 1ULL << (from & 63);
     uint64_t* tvp = s.TV + (size_t)node * s.W + wF;
-    const uint64_t tvv = ld_coherent(tvp), viF = ld_coherent(vi + wF), tiF = ld_coherent(ti + wF);
+    const uint64_t tvv = ld_coherent(tvp);
     uint64_t* ent = s.qent + ((size_t)node * s.L + lv) * 64;
     const int len = ls->qlen[lv];
     const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
@@ -547,6 +578,16 @@ struct HandelProto {
       vi0 = vi[v.bw + j0];
       la0 = la[v.bw + j0];
       ti0 = ti[v.bw + j0];
+    }
+    // the VI / TI words holding `from` are among the block words just loaded (the lane owning row word wF);
+    // only beyond the first 64 words of a wide level do they cost memory instructions of their own
+    uint64_t viF, tiF;
+    if (jF < 64) {
+      viF = shfl64(vi0, wF & 63);
+      tiF = shfl64(ti0, wF & 63);
+    } else {
+      viF = ld_coherent(vi + wF);
+      tiF = ld_coherent(ti + wF);
     }
     const bool owner = lane == (wF & 63);
     if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
@@ -621,7 +662,7 @@ struct HandelProto {
       ls->cLA[lv] = cLA;
       // The entry was just unlisted (an entry is listed at most once), so its slot dies with this task
       // unless another registered task still references it (checkSigs can pick the same entry twice).
-      if (!slot_pending(r, lv, slot)) ls->qused[lv] &= ~(1ULL << slot);
+      if (!slot_pending(r, lv, slot)) ls_set_qused(ls, lv, ls_qused(ls, lv) & ~(1ULL << slot));
     }
     __builtin_amdgcn_wave_barrier();
     if (!improved) return;
@@ -707,12 +748,11 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     const uint64_t* ti = s.TI + (size_t)node * s.W;
     const uint64_t* la = s.LA + (size_t)node * s.W;
     const uint64_t* vi = s.VI + (size_t)node * s.W;
-    uint32_t* hh = h_hdr(s, node);
-    const int window = (int)hh[HH_WINDOW];
-    int sigQueueSize = (int)hh[HH_SIGQ];
+    const int window = (int)ls->sc[HH_WINDOW];
+    int sigQueueSize = (int)ls->sc[HH_SIGQ];
     uint32_t pend[H_PEND];
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) pend[k] = hh[HH_PEND + k];
+    for (int k = 0; k < H_PEND; k++) pend[k] = ls->sc[HH_PEND + k];
     int ncand = 0;
     // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
     uint32_t lvMask = 0;
@@ -821,7 +861,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         unsigned long long relMask = 0;
         for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << __shfl(mySlot, __ffsll((unsigned long long)m) - 1, 64);
         if (lane == 0) {
-          ls->qused[l] &= ~relMask;
+          ls_set_qused(ls, l, ls_qused(ls, l) & ~relMask);
           ls->qlen[l] = kept;
         }
         sigQueueSize += kept - len;
@@ -836,11 +876,12 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         ncand++;
       }
     }
-    HandelProto::store_levels(s, node, ls);
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-      hh[HH_SIGQ] = (uint32_t)sigQueueSize;
+      ls->sc[HH_SIGQ] = (uint32_t)sigQueueSize;
       s.candCnt[node] = (uint8_t)ncand;
     }
+    HandelProto::store_levels(s, node, ls);
     __builtin_amdgcn_wave_barrier();
   }
 }
