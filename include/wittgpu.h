@@ -87,12 +87,17 @@ int32_t wg_rng_set_state(wg_engine* e, uint64_t s48);
  * overload). msg = protocol message word, payload = protocol payload handle. Draws one rd.nextInt(). */
 int32_t wg_send(wg_engine* e, uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests,
                 int32_t n, int32_t delayBetween);
+/* Network.sendArriveAt (C/Network.java:384-390): no latency, no rd draw; WG_EINVAL if arriveAt <= time */
+int32_t wg_send_arrive_at(wg_engine* e, uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to);
 /* Network.registerTask / registerPeriodicTask (C/Network.java:505-519): task = protocol task word */
 int32_t wg_register_task(wg_engine* e, uint32_t task, uint32_t arg, int32_t startAt, int32_t node);
 int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, int32_t period, int32_t node);
 
 /* ---- resident protocols ----------------------------------------------------------------- */
-typedef enum { WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3 } wg_proto_id;
+typedef enum {
+  WG_PROTO_HOST = 0, /* no resident protocol: Message.action() stays with the caller (wg_next_delivery below) */
+  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3
+} wg_proto_id;
 
 /* Handel parameters: HandelParameters ctor order (P/Handel.java:97-142) + WindowParameters (:147-174) */
 typedef struct {
@@ -150,6 +155,30 @@ int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt
  * evaluated on the device: Handel.newContIf (P/Handel.java:1044-1053), GSFSignature.newConfIf
  * (P/GSFSignature.java:670-683). *cont = 1 while the run must go on. */
 int32_t wg_protocol_cont_if(wg_engine* e, int32_t* cont);
+
+/* ---- host-callback mode: any protocol, action() stays in the caller ------------------------------------ */
+/* For protocols without a resident device form (the reference's San Fermin, Paxos, Slush, Dfinity, P2P* ...): the
+ * message queue, its LIFO / chain ordering (C/Network.java:116-299, C/Envelope.java:57-301), NetworkLatency
+ * sampling and the shared rd live in the engine; the caller keeps its Node / Message objects and runs action().
+ * After wg_protocol_load(e, WG_PROTO_HOST, NULL, NULL):
+ *   wg_send / wg_register_task take caller-chosen 32-bit handles as msg / payload (task / arg);
+ *   wg_next_delivery is Network.nextMessage (C/Network.java:533-570) plus the post-action part of receiveUntil
+ *   (:625-632): it returns the next envelope to deliver in exactly the reference's order — kind 0 message, 1 task —
+ *   for the caller to apply (stats :607-613 and action() :616-626 are the caller's), or a time edge (kind 2) when
+ *   `time++` reached cond_time, the earliest ConditionalTask.minStartTime the caller holds (INT32_MAX: none), so
+ *   that it can run the conditional-task scan of :543-566 at that edge; *got = 0 once time > until.
+ *   Deliveries to a down node or across a partition are consumed silently (:606). Envelopes pushed by the caller
+ *   while a delivery is being applied land exactly where Java's msgs.addMsg would put them.
+ *   wg_set_time is the tail of Network.runMs (`time = endAt`, :336). */
+typedef struct {
+  int32_t kind;     /* 0 message, 1 task, 2 time edge */
+  int32_t time;     /* Network.time at the delivery (= arrival) / the new time of an edge */
+  int32_t from, to; /* node ids (task: from == to) */
+  uint32_t msg;     /* the handle given to wg_send / wg_register_task */
+  uint32_t payload; /* second handle word (wg_send payload / wg_register_task arg) */
+} wg_delivery;
+int32_t wg_next_delivery(wg_engine* e, int32_t until, int32_t cond_time, wg_delivery* out, int32_t* got);
+int32_t wg_set_time(wg_engine* e, int32_t time);
 
 /* ---- batches: RunMultipleTimes on the device ------------------------------------------------ */
 /* The reference's way to run many simulations is C/RunMultipleTimes.java:44-64: for each of runCount

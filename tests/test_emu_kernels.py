@@ -34,6 +34,7 @@ import test_gpu_batch as tb  # noqa: E402
 import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
+import test_gpu_hostmode as thm  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -114,3 +115,13 @@ def test_gsf_multiword_levels_and_overflow():
     tg.lockstep((512, 500, 3, 50, 10, 10, 0), seed=5, step=10, total=150)
     tg.test_queue_capacity_overflow_is_loud()
     tg.test_unsupported_shapes_are_loud()
+
+
+@pytest.mark.parametrize("name", ["test_register_task", "test_task_and_stopped_node", "test_periodic_task",
+                                  "test_conditional_task", "test_multiple_destinations_with_delay_and_lifo"])
+def test_host_callback_mode_reference_vectors(name):  # CT/NetworkTest.java through wg_next_delivery
+    getattr(thm, name)()
+
+
+def test_host_callback_mode_pingpong():
+    thm.test_pingpong_through_host_callbacks_matches_oracle(120)

@@ -110,6 +110,10 @@ int32_t wg_send(wg_engine* h, uint32_t msg, uint32_t payload, int32_t sendTime, 
   WG_TRY(h) E.send(msg, payload, sendTime, from, dests, n, delayBetween);
   WG_END
 }
+int32_t wg_send_arrive_at(wg_engine* h, uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to) {
+  WG_TRY(h) E.send_arrive_at(msg, payload, arriveAt, from, to);
+  WG_END
+}
 int32_t wg_register_task(wg_engine* h, uint32_t task, uint32_t arg, int32_t startAt, int32_t node) {
   WG_TRY(h) E.register_task(task, arg, startAt, node);
   WG_END
@@ -171,6 +175,16 @@ int32_t wg_protocol_cont_if(wg_engine* h, int32_t* cont) {
   E.flush_staged(E.time, false);
   if (!E.proto || !E.proto->cont_if(E, cont))
     throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+  WG_END
+}
+int32_t wg_next_delivery(wg_engine* h, int32_t until, int32_t cond_time, wg_delivery* out, int32_t* got) {
+  WG_TRY(h)
+  if (!out || !got) throw WgError(WG_EINVAL, "out/got");
+  *got = E.next_delivery(until, cond_time, out) ? 1 : 0;
+  WG_END
+}
+int32_t wg_set_time(wg_engine* h, int32_t time) {
+  WG_TRY(h) E.host_set_time(time);
   WG_END
 }
 // ---- batches (RunMultipleTimes on the device)

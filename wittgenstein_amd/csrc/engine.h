@@ -183,6 +183,7 @@ struct NodeArrays {
 
 // Everything a kernel needs, passed by value.
 struct EngineDev {
+  uint32_t hostMode;        // wg_next_delivery mode: events go to the host, no device inbox lists are built
   uint32_t halted;          // batch member that is not advanced by the current run (RunMultipleTimes: its
                             // continuation predicate turned false); every kernel returns at once for it
   Globals* g;

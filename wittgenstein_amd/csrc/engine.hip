@@ -464,7 +464,7 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   if (n > 1) std::stable_sort(da.begin(), da.end(), [](const Arr& a, const Arr& b) { return a.arrival < b.arrival; });
   if (da.empty()) return;
   if (da.size() == 1) {
-    staged.push_back({da[0].arrival, make_rec(K_MSG, from, (uint32_t)da[0].dest, msg, payload)});
+    hc_push(da[0].arrival, make_rec(K_MSG, from, (uint32_t)da[0].dest, msg, payload));
     return;
   }
   ensure_device();
@@ -484,18 +484,34 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   for (auto& a : da) sc.words.push_back(a.dest);
   if (delayBetween != 0)
     for (auto& a : da) sc.words.push_back(a.arrival);
-  staged.push_back({da[0].arrival, make_rec(K_CHAIN, from, sc.slot, 0, 0)});
+  if (dev.hostMode) {  // the host hands the hops out itself: keep the envelope
+    if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
+    hostChains[sc.slot].live = true;
+    hostChains[sc.slot].c = sc.c;
+    hostChains[sc.slot].words = sc.words;
+  }
+  hc_push(da[0].arrival, make_rec(K_CHAIN, from, sc.slot, 0, 0));
   stagedChains.push_back(std::move(sc));
+}
+
+void Engine::send_arrive_at(uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to) {  // :384-390
+  const int32_t N = (int32_t)hx.size();
+  if (from < 0 || from >= N || to < 0 || to >= N) throw WgError(WG_EINVAL, "node id");
+  if (arriveAt <= time)
+    throw WgError(WG_EINVAL, "wrong arrival time: arriveAt=" + std::to_string(arriveAt) + ", time=" + std::to_string(time));
+  hc_push(arriveAt, make_rec(K_MSG, from, (uint32_t)to, msg, payload));
 }
 
 void Engine::register_task(uint32_t task, uint32_t arg, int32_t startAt, int32_t node) {  // :505-508
   if (node < 0 || node >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
   if (startAt < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(startAt));  // :249-252
-  staged.push_back({startAt, make_rec(K_TASK, node, (uint32_t)node, task, arg)});
+  hc_push(startAt, make_rec(K_TASK, node, (uint32_t)node, task, arg));
 }
 void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t period, int32_t node) {  // :510-513
   if (node < 0 || node >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
   if (period <= 0) throw WgError(WG_EINVAL, "period");
+  if (dev.hostMode)
+    throw WgError(WG_EUNSUPPORTED, "host-callback mode: a PeriodicTask re-arms itself from its action() (C/messages/PeriodicTask.java:39-47)");
   if (startAt < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(startAt));
   staged.push_back({startAt, make_rec(K_PERIODIC, node, (uint32_t)node, task, (uint32_t)period)});
 }
@@ -667,7 +683,11 @@ void Engine::check_device_errors() {
 
 void Engine::load_protocol(int32_t id, const void* params, const void* initState) {
   if (proto) throw WgError(WG_ESTATE, "a protocol is already resident");
-  if (id == WG_PROTO_PINGPONG) {
+  if (id == WG_PROTO_HOST) {
+    ensure_device();
+    proto = make_host_proto(*this);
+    dev.hostMode = 1;
+  } else if (id == WG_PROTO_PINGPONG) {
     ensure_device();
     proto = make_pingpong_host(*this);
   } else if (id == WG_PROTO_HANDEL) {
@@ -702,6 +722,7 @@ void Engine::begin_run(int32_t ms, int32_t* endAtOut) {
 void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
   if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
+  if (dev.hostMode) throw WgError(WG_ESTATE, "host-callback mode: drive the run with wg_next_delivery");
   Engine* me = this;
   Group g = self();
   run_group(&me, 1, nullptr, g, ms, didSomething, stats);
@@ -828,6 +849,142 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
     }
   }
   if (firstCode != WG_OK) throw WgError(firstCode, firstErr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-callback mode (WG_PROTO_HOST): the queue, its ordering, latency sampling and rd live in the engine,
+// Message.action() stays with the caller. The device expands bucket `time` exactly as for a resident
+// protocol (LIFO, chain runs unrolled: the same k_scan<ExpandF>); the events come to the host and are
+// handed out one by one; what the caller pushes meanwhile is staged in push order and appended to the
+// buckets by the same multisplit the device pipeline uses.
+struct HostProto : ProtoHost {
+  int dummy[4] = {0, 0, 0, 0};
+  void launch_deliver(const Group&) override { throw WgError(WG_ESTATE, "host-callback mode has no device action()"); }
+  size_t state_size() const override { return sizeof(dummy); }
+  const void* state_host() const override { return dummy; }
+  int host_msg_size(uint32_t) const override { return 0; }  // Message.size() is the caller's business here
+};
+ProtoHost* make_host_proto(Engine&) { return new HostProto(); }
+
+// msgs.addMsg of a host push (C/Network.java:247-255): an envelope for the ms being handed out goes on top of
+// what is left of it (LIFO: it is the next one delivered); everything else is staged for its bucket.
+void Engine::hc_push(int32_t arrival, const Rec& rec) {
+  if (dev.hostMode && hcLoaded && arrival == time) {
+    HostEv ev;
+    ev.rec = rec;
+    ev.aux.chain = -1;
+    ev.aux.cpos = 0;
+    ev.aux.outBase = ev.aux.outCap = 0;
+    if (rec_kind(rec) == K_CHAIN) throw WgError(WG_EUNSUPPORTED, "multi-destination envelope arriving in the millisecond being delivered");
+    hcEvents.insert(hcEvents.begin() + (long)hcCursor, ev);
+    return;
+  }
+  staged.push_back({arrival, rec});
+}
+
+void Engine::host_set_time(int32_t t) {
+  if (!dev.hostMode) throw WgError(WG_ESTATE, "wg_set_time is for host-callback mode");
+  // (nextMessage leaves time at until + 1; runMs then assigns endAt = until, C/Network.java:336)
+  if (hcLoaded && hcCursor < hcEvents.size()) throw WgError(WG_ESTATE, "deliveries of the current ms are pending");
+  if (hcLoaded) hc_finish_ms();
+  time = t;
+}
+
+// m.markRead(); if (m.hasNextReader()) msgs.addMsg(m)  (C/Network.java:629-632), after the action()'s own pushes
+void Engine::hc_stage_continuation() {
+  if (hcContSlot < 0) return;
+  const StagedChainKeep& k = hostChains[hcContSlot];
+  const Chain& c = k.c;
+  const int j = hcContPos;
+  int32_t arrival;
+  if (c.flags & 2u)
+    arrival = k.words[(size_t)c.ndest + j];
+  else
+    arrival = c.sendTime + host_latency(c.from, k.words[j], c.seed);
+  const int32_t slot = hcContSlot;
+  hcContSlot = -1;
+  if (arrival < time) throw WgError(WG_ESTATE, "Arriving in the past");
+  if (arrival == time) throw WgError(WG_ESTATE, "chain run was not unrolled");  // expand unrolls same-ms hops
+  staged.push_back({arrival, make_rec(K_CHAIN, c.from, (uint32_t)slot, (uint32_t)j, 0)});
+}
+
+// the ms handed out is exhausted: append what was pushed meanwhile, release the bucket, time++
+void Engine::hc_finish_ms() {
+  flush_staged(time, false);
+  gh.now = time;
+  globalsDirty = true;
+  sync_globals_to_device();
+  end_phase(self(), true);
+  sync_globals_to_host();
+  check_device_errors();
+  hcLoaded = false;
+  hcEvents.clear();
+  hcCursor = 0;
+}
+
+bool Engine::next_delivery(int32_t until, int32_t condTime, wg_delivery* out) {
+  if (!dev.hostMode) throw WgError(WG_ESTATE, "load WG_PROTO_HOST first");
+  for (;;) {
+    hc_stage_continuation();  // owed by the delivery the caller has just applied
+    while (hcLoaded && hcCursor < hcEvents.size()) {
+      const HostEv ev = hcEvents[hcCursor++];
+      if (ev.aux.chain >= 0 && ev.aux.cpos < 0) {  // last hop of a run: the envelope is re-pushed after action()
+        const int next = (ev.aux.cpos & 0x7FFFFFFF) + 1;
+        if (next < hostChains[ev.aux.chain].c.ndest) {
+          hcContSlot = ev.aux.chain;
+          hcContPos = next;
+        } else {
+          hostChains[ev.aux.chain].live = false;
+        }
+      }
+      const int32_t from = rec_from(ev.rec), to = (int32_t)ev.rec.w1;
+      if (hdown[to] || part_of(hx[from]) != part_of(hx[to])) {  // :606 — consumed, not delivered
+        hc_stage_continuation();
+        continue;
+      }
+      out->kind = rec_kind(ev.rec) == K_MSG ? 0 : 1;
+      out->time = time;
+      out->from = from;
+      out->to = to;
+      out->msg = ev.rec.w2;
+      out->payload = ev.rec.w3;
+      return true;
+    }
+    if (hcLoaded) {  // nextMessage(): poll returned null -> time++ and the conditional-task edge
+      hc_finish_ms();
+      time++;
+      if (time >= condTime) {
+        out->kind = 2;
+        out->time = time;
+        out->from = out->to = -1;
+        out->msg = out->payload = 0;
+        return true;
+      }
+      continue;
+    }
+    if (time > until) return false;
+    // load bucket `time`
+    flush_staged(time, false);
+    gh.now = time;
+    gh.until = until;
+    globalsDirty = true;
+    sync_globals_to_device();
+    Group g = self();
+    scan<ExpandF>(g, nullptr);
+    sync_globals_to_host();
+    check_device_errors();
+    const uint32_t n = gh.nEvents;
+    hcEvents.resize(n);
+    if (n) {
+      std::vector<Rec> recs(n);
+      std::vector<EvAux> aux(n);
+      WG_HIP(hipMemcpy(recs.data(), dev.ev, sizeof(Rec) * n, hipMemcpyDeviceToHost));
+      WG_HIP(hipMemcpy(aux.data(), dev.evAux, sizeof(EvAux) * n, hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < n; i++) hcEvents[i] = {recs[i], aux[i]};
+    }
+    hcCursor = 0;
+    hcLoaded = true;
+  }
 }
 
 // ---- batches

@@ -77,6 +77,7 @@ class Engine {
   // host-side Network API used by init() code
   void send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
             int32_t delayBetween);
+  void send_arrive_at(uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to);
   void register_task(uint32_t task, uint32_t arg, int32_t startAt, int32_t node);
   void register_periodic_task(uint32_t task, int32_t startAt, int32_t period, int32_t node);
 
@@ -84,6 +85,26 @@ class Engine {
   void run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
   int64_t queue_size();
   int64_t queue_size_at(int32_t t);
+  struct StagedChainKeep {
+    bool live = false;
+    Chain c;
+    std::vector<int32_t> words;
+  };
+  // host-callback mode (WG_PROTO_HOST): Network.nextMessage + the post-action part of receiveUntil
+  bool next_delivery(int32_t until, int32_t condTime, wg_delivery* out);
+  void host_set_time(int32_t t);
+  struct HostEv {
+    Rec rec;
+    EvAux aux;
+  };
+  std::vector<HostEv> hcEvents;    // the ms being handed out, in event order
+  size_t hcCursor = 0;
+  bool hcLoaded = false;
+  int32_t hcContSlot = -1, hcContPos = 0;  // chain re-push owed after the delivery in progress (:629-632)
+  std::vector<StagedChainKeep> hostChains; // host copies of the multi-destination envelopes, by slot
+  void hc_push(int32_t arrival, const Rec& rec);
+  void hc_stage_continuation();
+  void hc_finish_ms();
   void read_i64(int32_t field, int64_t* dst, int32_t n);
 
   // used by protocol hosts
@@ -221,6 +242,7 @@ class Batch {
 };
 
 ProtoHost* make_pingpong_host(Engine& e);
+ProtoHost* make_host_proto(Engine& e);
 ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st);
 ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st);
 

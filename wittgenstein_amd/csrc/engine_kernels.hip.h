@@ -264,7 +264,7 @@ struct ExpandF {
           a.outBase = ob;
           a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
           d.evAux[e] = a;
-          first = link(e, (int32_t)r.w1);
+          if (!d.hostMode) first = link(e, (int32_t)r.w1);
           firstNode = (int32_t)r.w1;
         }
       } else {
@@ -281,7 +281,7 @@ struct ExpandF {
           a.outBase = ob + q * d.boundMsg;
           a.outCap = d.boundMsg + (last ? 1u : 0u);
           d.evAux[e] = a;
-          if (link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+          if (!d.hostMode && link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
         }
       }
     }

@@ -1,0 +1,271 @@
+"""core.Network for protocols whose Message.action() stays on the host (host-callback mode, wg_next_delivery).
+
+The message queue with its LIFO / multi-destination-chain ordering, NetworkLatency sampling and the shared
+`rd` live in libwittgpu.so on the MI355X; Node / Message / Task objects and action() stay here — the Python
+stand-in for what the reference's Java classes do (C/Network.java, C/Node.java, C/messages/*.java), so that
+any protocol written against that API runs unchanged in structure. Method names follow the Java API."""
+import ctypes as C
+
+from . import _lib as L
+from .core import IllegalArgumentException, IllegalStateException, Network as _EngineNetwork
+
+INT_MAX = 2**31 - 1
+_MASK48 = (1 << 48) - 1
+
+
+def _s32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
+class EngineRandom:
+    """network.rd (C/Network.java:32): java.util.Random whose 48-bit state is the engine's, so draws made by
+    protocol code and by send() interleave exactly as in the reference."""
+
+    def __init__(self, net):
+        self._net = net
+
+    def _next(self, bits):
+        s = (self._net._eng.rng_state() * 0x5DEECE66D + 0xB) & _MASK48
+        self._net._eng._ck(L.lib().wg_rng_set_state(self._net._eng._h, C.c_uint64(s)))
+        return _s32(s >> (48 - bits))
+
+    def setSeed(self, seed):
+        self._net._eng.set_seed(seed)
+
+    def nextInt(self, bound=None):
+        if bound is None:
+            return self._next(32)
+        if bound <= 0:
+            raise IllegalArgumentException("bound must be positive")
+        r = self._next(31)
+        m = bound - 1
+        if bound & m == 0:
+            return _s32((bound * r) >> 31)
+        u = r
+        while True:
+            r = u % bound
+            if _s32(u - r + m) >= 0:
+                return r
+            u = self._next(31)
+
+    def nextBoolean(self):
+        return self._next(1) != 0
+
+    def nextDouble(self):
+        return ((self._next(26) << 27) + self._next(27)) * (1.0 / (1 << 53))
+
+
+class Node:
+    """C/Node.java: identity, position (NodeBuilderWithRandomPosition, C/NodeBuilder.java:77-96) and counters."""
+
+    def __init__(self, net):
+        r = net.rd.nextInt()
+        rx = _s32(r >> 16)
+        ry = _s32((r << 16) & 0xFFFFFFFF)
+        self.x = abs(rx) % 2000 + 1
+        self.y = abs(ry) % 1112 + 1
+        self.nodeId = net._allocate_id()
+        self.down = False
+        self.extraLatency = 0
+        self.msgReceived = self.msgSent = self.bytesSent = self.bytesReceived = 0
+        self.doneAt = 0
+
+    def isDown(self):
+        return self.down
+
+    def start(self):
+        self.down = False
+
+    def stop(self):
+        self.down = True
+
+
+class Message:
+    """C/messages/Message.java:15-29"""
+
+    def size(self):
+        return 1
+
+    def action(self, network, frm, to):
+        raise NotImplementedError
+
+
+class Task(Message):
+    """C/messages/Task.java:8-31"""
+
+    def __init__(self, r):
+        self.r = r
+
+    def size(self):
+        return 0
+
+    def action(self, network, frm, to):
+        self.r()
+
+
+class PeriodicTask(Task):
+    """C/messages/PeriodicTask.java:10-47"""
+
+    def __init__(self, r, sender, period, cond=lambda: True):
+        super().__init__(r)
+        self.sender, self.period, self.cond = sender, period, cond
+
+    def action(self, network, frm, to):
+        self.r()
+        if self.cond():
+            network.sendArriveAt(self, network.time + self.period, self.sender, self.sender)
+
+
+class ConditionalTask:
+    """C/messages/ConditionalTask.java:6-36"""
+
+    def __init__(self, startIf, repeatIf, r, minStartTime, frm, duration):
+        self.startIf, self.repeatIf, self.r = startIf, repeatIf, r
+        self.minStartTime, self.frm, self.duration = minStartTime, frm, duration
+
+
+class HostNetwork:
+    """C/Network.java over the engine's host-callback mode."""
+
+    def __init__(self, networkLatencyName=None, config=None):
+        self._eng = _EngineNetwork.create(config)
+        self._eng.setNetworkLatency(networkLatencyName)
+        self.rd = EngineRandom(self)
+        self.allNodes = []
+        self.conditionalTasks = []
+        self._handles = {}
+        self._next_handle = 1
+        self._next_id = 0
+        self._ready = False
+        self.time = 0
+
+    # ---- nodes
+    def _allocate_id(self):  # NodeBuilder.allocateNodeId (C/NodeBuilder.java:61-63)
+        i = self._next_id
+        self._next_id += 1
+        return i
+
+    def addNode(self, node):  # :651-659
+        if self._ready:
+            raise IllegalStateException("nodes must be added before the first send / run")
+        if node.nodeId != len(self.allNodes):
+            raise IllegalArgumentException("bad node id")
+        self.allNodes.append(node)
+
+    def getNodeById(self, i):
+        return self.allNodes[i]
+
+    def _start(self):
+        if self._ready:
+            return
+        self._eng.add_nodes([n.x for n in self.allNodes], [n.y for n in self.allNodes],
+                            [n.extraLatency for n in self.allNodes], [1 if n.down else 0 for n in self.allNodes])
+        self._eng.load_protocol(0)  # WG_PROTO_HOST
+        self._ready = True
+
+    def _handle(self, obj):
+        h = self._next_handle
+        self._next_handle += 1
+        self._handles[h] = obj
+        return h
+
+    def set_down(self, node, down=True):
+        node.down = down
+        if self._ready:
+            self._eng.set_node_down(node.nodeId, down)
+
+    # ---- sends (C/Network.java:341-390, 418-447)
+    def sendAll(self, m, fromNode, sendTime=None):
+        self.send(m, fromNode, self.allNodes, self.time + 1 if sendTime is None else sendTime, _force_multi=True)
+
+    def send(self, m, fromNode, dests, sendTime=None, delayBetween=0, _force_multi=False):
+        self._start()
+        if isinstance(dests, Node):
+            dests = [dests]
+        elif not _force_multi and sendTime is None:
+            if not dests:
+                return  # the 3-argument overload returns without drawing (:354-356)
+        if sendTime is None:
+            sendTime = self.time + 1
+        ids = [d.nodeId for d in dests]
+        # createMessageArrival counts the sender's statistics for every destination, dropped or not (:476-477)
+        fromNode.msgSent += len(ids)
+        fromNode.bytesSent += len(ids) * m.size()
+        self._eng.send(self._handle(m), sendTime, fromNode.nodeId, ids, delayBetween)
+
+    def sendArriveAt(self, m, arriveAt, fromNode, toNode):
+        self._start()
+        self._eng._ck(L.lib().wg_send_arrive_at(self._eng._h, self._handle(m), 0, int(arriveAt), fromNode.nodeId,
+                                                toNode.nodeId))
+
+    def registerTask(self, task, startAt, fromNode):  # :505-508
+        self._start()
+        self._eng.registerTask(self._handle(Task(task)), startAt, fromNode.nodeId)
+
+    def registerPeriodicTask(self, task, startAt, period, fromNode, cond=lambda: True):  # :510-519
+        self._start()
+        self._eng.registerTask(self._handle(PeriodicTask(task, fromNode, period, cond)), startAt, fromNode.nodeId)
+
+    def registerConditionalTask(self, task, startAt, duration, fromNode, startIf, repeatIf):  # :521-531
+        self.conditionalTasks.append(ConditionalTask(startIf, repeatIf, task, startAt, fromNode, duration))
+
+    # ---- the loop
+    def run(self, seconds):
+        return self.runMs(seconds * 1000)
+
+    def runMs(self, ms):  # :318-338
+        if ms <= 0:
+            raise IllegalArgumentException("Should be greater than 0. ms=%d" % ms)
+        self._start()
+        if self.time == 0:
+            for n in self.allNodes:
+                if not n.isDown():
+                    n.start()
+        endAt = self.time + ms
+        did = self._receiveUntil(endAt)
+        self.time = endAt
+        self._eng._ck(L.lib().wg_set_time(self._eng._h, endAt))
+        return did
+
+    def _cond_time(self, cts, until):
+        src = self.conditionalTasks if cts is None else cts
+        t = [ct.minStartTime for ct in src if ct.minStartTime <= until and not ct.frm.isDown()]
+        return min(t) if t else INT_MAX
+
+    def _receiveUntil(self, until):  # :587-637 with nextMessage :533-570
+        lib, h = L.lib(), self._eng._h
+        d = L.wg_delivery()
+        got = C.c_int32()
+        did = False
+        cts = None  # nextMessage()'s private copy of the conditional tasks, made at the first edge of a call
+        while True:
+            self._eng._ck(lib.wg_next_delivery(h, until, self._cond_time(cts, until), C.byref(d), C.byref(got)))
+            if not got.value:
+                return did
+            self.time = d.time
+            if d.kind == 2:  # time++ edge: the conditional-task scan of :543-566
+                if cts is None:
+                    cts = list(self.conditionalTasks)
+                for ct in list(cts):
+                    if ct.minStartTime > until or ct.frm.isDown():
+                        cts.remove(ct)
+                        continue
+                    if ct.minStartTime <= self.time:
+                        cts.remove(ct)
+                        if ct.startIf():
+                            ct.r()
+                            ct.minStartTime = self.time + ct.duration
+                            if not ct.repeatIf():
+                                self.conditionalTasks.remove(ct)
+                continue
+            did = True
+            cts = None  # a delivery ends the nextMessage() call
+            m = self._handles[d.msg]
+            frm, to = self.allNodes[d.from_], self.allNodes[d.to]
+            if not isinstance(m, Task):  # :607-613 (`!(mc instanceof Task)`)
+                if m.size() == 0:
+                    raise IllegalStateException("Message size should be greater than zero: %r" % m)
+                to.msgReceived += 1
+                to.bytesReceived += m.size()
+            m.action(self, frm, to)
