@@ -164,22 +164,22 @@ def main():
         args.init_threads = max(1, min(args.init_threads, int(0.6 * avail / max(1, world) / per)))
     except Exception:
         pass
-    seed0 = rank * (K + W) * R
+    from wittgenstein_amd import replicas
+    warm_seeds, timed_seeds = replicas.seed_ranges(rank, world, K, W, R)  # disjoint across ranks
     prof_phase = None
     # ---- warmup steps: same shape as a timed step; every phase is bracketed with HIP events here so the
     # phase breakdown costs the timed region nothing. Freed before the timed copies are initialised.
     t_init = time.perf_counter()
     inits = 0
-    for i in range(W):
-        sims, batch = make_batch(w, n, range(seed0 + i * R, seed0 + (i + 1) * R), local, args.init_threads, args.workload)
+    for seeds in warm_seeds:
+        sims, batch = make_batch(w, n, seeds, local, args.init_threads, args.workload)
         inits += R
         sims[0].network().profile(1)
         batch.run_multiple_times(chunk=10, maxTime=20000)
         prof_phase = sims[0].network().profile_read()
         del batch, sims
         gc.collect()  # Network <-> MessageStorage cycles hold ~15 GB of HBM per copy until collected
-    timed = [make_batch(w, n, range(seed0 + (W + i) * R, seed0 + (W + i + 1) * R), local, args.init_threads, args.workload)
-             for i in range(K)]
+    timed = [make_batch(w, n, seeds, local, args.init_threads, args.workload) for seeds in timed_seeds]
     inits += K * R
     init_s = (time.perf_counter() - t_init) / max(1, inits)
     log("[rank %d] init(): %.1f s per simulation amortised over %d host threads (outside the timed region)"
@@ -212,12 +212,7 @@ def main():
     gc.collect()
 
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cnt = torch.tensor([delivered, sim_ms], device="cuda", dtype=torch.int64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        delivered, sim_ms = int(cnt[0].item()), int(cnt[1].item())
+        elapsed, delivered, sim_ms = replicas.reduce_job(dist, "cuda", elapsed, delivered, sim_ms)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
