@@ -27,7 +27,16 @@ constexpr int MAX_LEVELS = 24;
 #ifndef WG_GRID_DIV
 #define WG_GRID_DIV 1
 #endif
-constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node visit (deliver, cond_a1)
+constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node visit (deliver, cond_a1), per engine
+// ... of a batch of R engines: ~4 rounds of the chip's resident waves in total are enough, and every launched
+// wavefront that finds no work still costs its launch (131 072 waves per launch at R = 16 otherwise)
+inline int grid_node_waves(int R) {
+  int b = (4 * GRID_NODE_WAVES) / (R > 0 ? R : 1);
+  const int lo = GRID_NODE_WAVES / 8 > 0 ? GRID_NODE_WAVES / 8 : 1;
+  if (b < lo) b = lo;
+  if (b > GRID_NODE_WAVES) b = GRID_NODE_WAVES;
+  return b;
+}
 constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
 constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_deliver_msgs)
 constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;

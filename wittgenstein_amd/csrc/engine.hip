@@ -1348,10 +1348,10 @@ struct HandelHost : ProtoHost {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
       switch (wavesCond) {
-        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
       }
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
@@ -1366,11 +1366,11 @@ struct HandelHost : ProtoHost {
     if (useB)
       hipLaunchKernelGGL((k_deliver_msgs<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab, useB);
+      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
@@ -1572,14 +1572,14 @@ struct GsfHost : ProtoHost {
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
     hipLaunchKernelGGL(k_gsf_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(GRID_NODE_WAVES, g.R), dim3(256), 0, g.stream, g.tab,
+    hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                        (const GsfState*)g.stab, 0);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {

@@ -714,10 +714,19 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
           run = h[HH_SIGQ] != 0;  // startIf = hasSigToVerify (:345-347)
         }
       }
-      if (run)
+      if (run) {
         h[HH_CTMIN] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
-      else
-        s.candCnt[node] = 0;
+        // sigQueueSize drifts above the real queue lengths: checkSigs then runs over empty
+        // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node needs no visit
+        const U4* ql = (const U4*)(h + HH_LV + HP_QLEN * s.LS);
+        uint32_t tot = 0;
+        for (int k = 0; k < (s.LS >> 2); k++) {
+          const U4 q = ql[k];
+          tot |= q.x | q.y | q.z | q.w;
+        }
+        if (tot == 0) run = false;
+      }
+      if (!run) s.candCnt[node] = 0;
     }
     const uint64_t m = __ballot(run);
     if (m) {
