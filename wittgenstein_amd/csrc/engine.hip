@@ -1351,6 +1351,7 @@ struct HandelHost : ProtoHost {
         case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
         case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
         case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 3: hipLaunchKernelGGL(k_handel_cond_a1<3>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
         default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
       }
     }
