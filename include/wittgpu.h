@@ -32,6 +32,10 @@ typedef enum {
   WG_EUNSUPPORTED = -5 /* a reference feature the resident protocol does not cover (message says which) */
 } wg_status;
 
+/* in-place SUM of `count` int32 words at buf (device memory) across the shards of one simulation; see
+ * "node-range sharding" below */
+typedef int32_t (*wg_allreduce_fn)(void* ctx, void* buf, int64_t count);
+
 /* Engine capacities. 0 = pick a default from node count / protocol. */
 typedef struct {
   int32_t device;               /* HIP device ordinal */
@@ -43,6 +47,10 @@ typedef struct {
   int32_t chain_slots;          /* in-flight multi-destination envelopes (C/Envelope.java:57) */
   int32_t queue_cap;            /* Handel: per (node, level) toVerifyAgg capacity (P/Handel.java:385), <= 64;
                                    GSFSignature: per node toVerify capacity (P/GSFSignature.java:167), <= 512 */
+  /* node-range sharding (same effect as wg_shard_configure right after wg_create); nshards == 0: not sharded */
+  int32_t shard, nshards;
+  wg_allreduce_fn allreduce;
+  void* allreduce_ctx;
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -201,6 +209,29 @@ int32_t wg_batch_cont_if(wg_batch* b, int32_t* cont); /* wg_protocol_cont_if for
  * advanced. delivered[n] / simulatedMs[n] (NULL allowed): msgReceived increments and Network.time advance. */
 int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime, int64_t* delivered,
                                     int64_t* simulatedMs);
+
+/* ---- node-range sharding: ONE simulation over several engines (one process per GPU) --------- */
+/* The reference is single-threaded (C/Network.java:7-11); this group has no counterpart there. Every shard is a
+ * full wg_engine built by the SAME sequence of calls (nodes, latency, seed, protocol, host-side sends/tasks) in its
+ * own process; shard s of S owns the nodes [N*s/S, N*(s+1)/S). The scheduler state (per-ms buckets, multi-destination
+ * envelopes, rd, clock) is replicated and evolves identically on every shard; Message.action() runs, and node /
+ * protocol state lives, only on the owner of the destination node. Bit-exactness with the unsharded engine (global
+ * LIFO order, one shared rd stream) is kept by two sums across shards per simulated ms:
+ *   1. per-event (records emitted, rd draws) after delivery          -> every shard derives the global push order
+ *                                                                        and the rd index of every send;
+ *   2. the resolved outbox (record, arrival) after latency sampling  -> every shard appends the same records to
+ *                                                                        the same buckets.
+ * The engine calls `allreduce` (in-place SUM of count int32 words at buf, which is DEVICE memory of this engine's
+ * device) with its stream idle; the function returns once the summed values are visible to any stream. Bind it to
+ * RCCL (torch.distributed backend "nccl": wittgenstein_amd/shards.py) — over xGMI the payload is a few bytes per event,
+ * so the latency of the collective, not its bandwidth, is what a simulated ms pays.
+ * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong.
+ * wg_read_i64 on a shard returns its own nodes' values and zeros for the others (sum across shards for the whole
+ * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
+ * shard yet, batches, and host-callback mode. */
+int32_t wg_shard_configure(wg_engine* e, int32_t shard, int32_t nshards, wg_allreduce_fn allreduce, void* ctx);
+/* [lo, hi) of this shard (valid once the nodes are added); collectives / int32 words exchanged so far */
+int32_t wg_shard_info(wg_engine* e, int32_t* lo, int32_t* hi, int64_t* collectives, int64_t* words);
 
 /* ---- read-back -------------------------------------------------------------------------- */
 typedef enum {

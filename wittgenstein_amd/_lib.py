@@ -14,7 +14,12 @@ LIB_PATH = os.environ.get("WG_LIB") or os.path.join(_HERE, "libwittgpu.so")
 class wg_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("horizon_ms", C.c_int32), ("bucket_pool_records", C.c_int64),
                 ("payload_words", C.c_int64), ("outbox_records", C.c_int64), ("chain_dests", C.c_int64),
-                ("chain_slots", C.c_int32), ("queue_cap", C.c_int32)]
+                ("chain_slots", C.c_int32), ("queue_cap", C.c_int32),
+                ("shard", C.c_int32), ("nshards", C.c_int32), ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p)]
+
+
+# int32_t (*wg_allreduce_fn)(void* ctx, void* buf, int64_t count)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class wg_handel_params(C.Structure):
@@ -50,7 +55,7 @@ ABI_SYMBOLS = [
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_send_arrive_at", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
-    "wg_protocol_cont_if", "wg_next_delivery", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
+    "wg_protocol_cont_if", "wg_shard_configure", "wg_shard_info", "wg_next_delivery", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_batch_run_multiple_times", "wg_profile_enable", "wg_profile_read",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_gsf_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",

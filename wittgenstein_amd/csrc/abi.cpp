@@ -130,6 +130,20 @@ int32_t wg_run_ms(wg_engine* h, int32_t ms, uint8_t* didSomething, wg_run_stats*
   WG_TRY(h) E.run_ms(ms, didSomething, stats);
   WG_END
 }
+int32_t wg_shard_configure(wg_engine* h, int32_t shard, int32_t nshards, wg_allreduce_fn fn, void* ctx) {
+  WG_TRY(h) E.configure_shard(shard, nshards, fn, ctx);
+  WG_END
+}
+int32_t wg_shard_info(wg_engine* h, int32_t* lo, int32_t* hi, int64_t* collectives, int64_t* words) {
+  WG_TRY(h)
+  if (E.shardCount == 0) throw WgError(WG_ESTATE, "not a sharded engine");
+  const int64_t n = (int64_t)E.hx.size();
+  if (lo) *lo = (int32_t)(n * E.shardIndex / E.shardCount);
+  if (hi) *hi = (int32_t)(n * (E.shardIndex + 1) / E.shardCount);
+  if (collectives) *collectives = E.shardCollectives;
+  if (words) *words = E.shardWords;
+  WG_END
+}
 int32_t wg_time(wg_engine* h, int32_t* time) {
   WG_TRY(h)* time = E.time;
   WG_END

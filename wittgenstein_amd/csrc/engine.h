@@ -136,7 +136,8 @@ enum ErrBits : uint32_t {
   ERR_PENDING = 1u << 10,      // Handel pending-verification table full
   ERR_PROTOCOL = 1u << 11,     // a reference IllegalStateException site inside action()
   ERR_EVENTS = 1u << 12,       // events in one ms exceed scratch capacity
-  ERR_ARRIVAL_PAST = 1u << 13
+  ERR_ARRIVAL_PAST = 1u << 13,
+  ERR_SHARD_MULTI = 1u << 14   // sharded engine: an action() emitted a multi-destination envelope
 };
 
 // Device-resident engine globals (one instance).
@@ -245,7 +246,14 @@ struct EngineDev {
   uint32_t* binBase;        // [D] position of this phase's first record inside each bucket
   // scan scratch
   unsigned long long* scanPartials;
+  // node-range sharding of ONE simulation over several engines (wg_shard_configure): the scheduler state above
+  // is replicated on every shard and evolves identically; node / protocol state is touched only for the nodes
+  // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.
+  uint32_t sharded;
+  int32_t shardLo, shardHi;
+  int32_t* xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1)
 };
+WG_HD inline bool shard_owns(const EngineDev& d, int32_t node) { return node >= d.shardLo && node < d.shardHi; }
 
 WG_HD inline int32_t isqrt_floor(int32_t v) {  // (int) Math.sqrt(v), C/Node.java:281
   int32_t r = (int32_t)

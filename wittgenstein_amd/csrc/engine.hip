@@ -46,6 +46,7 @@ struct PingPongHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
+  bool supports_shards() const override { return true; }  // pong[] is touched for the visited node only
   bool read_i64(Engine& e, int32_t field, int64_t* dst, int32_t n) override {
     if (field != WG_F_PONG) return false;
     std::vector<int32_t> h(n);
@@ -72,6 +73,7 @@ Engine::Engine(const wg_config& c) : cfg(c) {
   WG_HIP(hipStreamCreate(&stream));
   gh.rng = lcg_scramble(0);  // new Random(0)  C/Network.java:32
   set_latency(WG_LAT_IC3, nullptr, 0);
+  if (cfg.nshards != 0) configure_shard(cfg.shard, cfg.nshards, cfg.allreduce, cfg.allreduce_ctx);
 }
 
 Engine::~Engine() {
@@ -387,6 +389,15 @@ void Engine::ensure_device() {
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D);
   dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID);
+  dev.sharded = shardCount > 0 ? 1u : 0u;
+  dev.shardLo = 0;
+  dev.shardHi = INT32_MAX;
+  dev.xbuf = nullptr;
+  if (shardCount > 0) {
+    dev.shardLo = (int32_t)((int64_t)n * shardIndex / shardCount);
+    dev.shardHi = (int32_t)((int64_t)n * (shardIndex + 1) / shardCount);
+    dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5);
+  }
   allocated = true;
   upload_latency();
   rebuild_partitions();
@@ -599,6 +610,7 @@ void Engine::flush_staged(int32_t t, bool inRun) {
     std::vector<int32_t> nodes;
     std::vector<long long> msgs, bytes;
     for (auto& p : pendingSent) {
+      if (!shard_owns(dev, p.node)) continue;  // sharded: Node counters live with the owner of the node
       nodes.push_back(p.node);
       msgs.push_back(p.msgs);
       bytes.push_back(p.msgs * (long long)proto->host_msg_size(p.msg));
@@ -606,6 +618,7 @@ void Engine::flush_staged(int32_t t, bool inRun) {
     int n = (int)nodes.size();
     int32_t* dn;
     long long *dm, *db;
+    if (n > 0) {
     WG_HIP(hipMalloc((void**)&dn, 4 * n));
     WG_HIP(hipMalloc((void**)&dm, 8 * n));
     WG_HIP(hipMalloc((void**)&db, 8 * n));
@@ -617,6 +630,7 @@ void Engine::flush_staged(int32_t t, bool inRun) {
     (void)hipFree(dn);
     (void)hipFree(dm);
     (void)hipFree(db);
+    }
     pendingSent.clear();
   }
   std::vector<Staged> near, far;
@@ -666,6 +680,10 @@ void Engine::check_device_errors() {
     m += "device-side multi-destination send with more than 64 destinations; ";
     code = WG_EUNSUPPORTED;
   }
+  if (e & ERR_SHARD_MULTI) {
+    m += "sharded engine: an action() emitted a multi-destination envelope (not sharded yet); ";
+    code = WG_EUNSUPPORTED;
+  }
   if (e & ERR_SAME_MS) {
     m += "an action() registered an envelope for the millisecond being drained; ";
     code = WG_EUNSUPPORTED;
@@ -684,6 +702,7 @@ void Engine::check_device_errors() {
 void Engine::load_protocol(int32_t id, const void* params, const void* initState) {
   if (proto) throw WgError(WG_ESTATE, "a protocol is already resident");
   if (id == WG_PROTO_HOST) {
+    if (shardCount > 0) throw WgError(WG_EUNSUPPORTED, "host-callback mode on a sharded engine");
     ensure_device();
     proto = make_host_proto(*this);
     dev.hostMode = 1;
@@ -723,6 +742,7 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   if (ms <= 0) throw WgError(WG_EINVAL, "Should be greater than 0. ms=" + std::to_string(ms));
   if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
   if (dev.hostMode) throw WgError(WG_ESTATE, "host-callback mode: drive the run with wg_next_delivery");
+  if (shardCount > 0) return run_ms_sharded(ms, didSomething, stats);
   Engine* me = this;
   Group g = self();
   run_group(&me, 1, nullptr, g, ms, didSomething, stats);
@@ -747,7 +767,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
+      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
@@ -849,6 +869,86 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
     }
   }
   if (firstCode != WG_OK) throw WgError(firstCode, firstErr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node-range sharding of ONE simulation (wg_shard_configure, include/wittgpu.h). Every shard runs the whole
+// per-ms pipeline on a replicated scheduler state; only the delivery (Message.action(), node and protocol state)
+// and the send resolution (rd draw -> latency -> arrival) are split, by owner of the acting node. The two places
+// where a shard needs what the others computed are summed across shards (non-owners contribute zeros):
+//   evRes[0..nEvents)   (records emitted, draws) per event  -> `order` gives every shard the global push order
+//   xbuf[0..nOut)       resolved record + arrival           -> `append` files the same records everywhere
+// The counts are replicated too, so every shard issues the same collectives without negotiating sizes.
+void Engine::configure_shard(int32_t shard, int32_t nshards, wg_allreduce_fn fn, void* ctx) {
+  if (nshards <= 0 || shard < 0 || shard >= nshards || !fn) throw WgError(WG_EINVAL, "shard / nshards / allreduce");
+  if (allocated) throw WgError(WG_ESTATE, "wg_shard_configure must precede the first call that allocates the engine");
+  shardIndex = shard;
+  shardCount = nshards;
+  xfn = fn;
+  xctx = ctx;
+}
+
+void Engine::shard_allreduce(void* buf, int64_t count) {
+  if (count <= 0) return;
+  WG_HIP(hipStreamSynchronize(stream));
+  const int32_t rc = xfn(xctx, buf, count);
+  if (rc != 0) throw WgError(WG_EHIP, "the shard all-reduce callback failed with " + std::to_string(rc));
+  shardCollectives++;
+  shardWords += count;
+}
+
+void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
+  if (!proto->supports_shards())
+    throw WgError(WG_EUNSUPPORTED, "this resident protocol does not run on a sharded engine yet (PingPong does)");
+  const Globals before = gh;
+  int32_t endAt = 0;
+  begin_run(ms, &endAt);
+  Group g = self();
+  auto t0 = std::chrono::steady_clock::now();
+  auto scratch = [&](uint32_t Globals::*field) {
+    uint32_t v = 0;
+    WG_HIP(hipStreamSynchronize(stream));
+    WG_HIP(hipMemcpy(&v, (const char*)dev.g + ((const char*)&(gh.*field) - (const char*)&gh), 4, hipMemcpyDeviceToHost));
+    return v;
+  };
+  for (int32_t k = 0; k <= ms; k++) {
+    const int32_t t = time + k;
+    if (k > 0 && stagedMin - t < dev.horizon) {  // (see run_group)
+      WG_HIP(hipStreamSynchronize(stream));
+      flush_staged(t, true);
+    }
+    scan<ExpandF>(g, nullptr);
+    proto->launch_deliver(g);
+    const uint32_t nEvents = scratch(&Globals::nEvents);
+    shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
+    scan<RecsF>(g, nullptr);
+    const uint32_t nOut = scratch(&Globals::nOut);
+    if (nOut) {
+      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+      shard_allreduce(dev.xbuf, 5 * (int64_t)nOut);
+      hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+    }
+    append_phase(g, false);
+    end_phase(g, true);
+  }
+  WG_HIP(hipStreamSynchronize(stream));
+  auto t1 = std::chrono::steady_clock::now();
+  sync_globals_to_host();
+  time = endAt;
+  if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;
+  if (stats) {
+    stats->delivered = (int64_t)(gh.delivered - before.delivered);
+    stats->tasks = (int64_t)(gh.tasks - before.tasks);
+    stats->events = (int64_t)(gh.events - before.events);
+    stats->draws = (int64_t)(gh.draws - before.draws);
+    stats->simulated_ms = ms;
+    stats->wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    int64_t pb = 0;
+    for (int l = 0; l < 32; l++)
+      pb += (int64_t)(gh.deliveredByLevel[l] - before.deliveredByLevel[l]) * proto->payload_bytes_of_level(l);
+    stats->payload_bytes = pb;
+  }
+  check_device_errors();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -993,6 +1093,7 @@ Batch::Batch(Engine** es, int n) {
   for (int i = 0; i < n; i++) {
     Engine* e = es[i];
     if (!e || !e->proto) throw WgError(WG_ESTATE, "every batch member needs a resident protocol");
+    if (e->shardCount > 0) throw WgError(WG_EUNSUPPORTED, "a sharded engine cannot be a batch member");
     e->ensure_device();
     Engine* l = es[0];
     if (e->cfg.device != l->cfg.device || e->dev.horizon != l->dev.horizon || e->dev.nodes.n != l->dev.nodes.n ||

@@ -58,6 +58,9 @@ struct ProtoHost {
   virtual bool delivered_by_level(Engine&, int64_t* /*dst32*/) { return false; }
   // the protocol's RunMultipleTimes continuation predicate, evaluated on the device
   virtual bool cont_if(Engine&, int32_t* /*out*/) { return false; }
+  // node-range sharding (wg_shard_configure): the protocol's kernels touch only the nodes the engine links into
+  // its inbox lists, its payloads are self-contained and it has no conditional-task phase
+  virtual bool supports_shards() const { return false; }
 };
 
 class Engine {
@@ -83,6 +86,14 @@ class Engine {
 
   void load_protocol(int32_t id, const void* params, const void* initState);
   void run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
+  // node-range sharding of one simulation over several engines (one process per GPU), include/wittgpu.h
+  void configure_shard(int32_t shard, int32_t nshards, wg_allreduce_fn fn, void* ctx);
+  void run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
+  void shard_allreduce(void* buf, int64_t count);
+  int32_t shardIndex = 0, shardCount = 0;  // shardCount == 0: not sharded
+  wg_allreduce_fn xfn = nullptr;
+  void* xctx = nullptr;
+  long long shardCollectives = 0, shardWords = 0;  // all-reduce calls / int32 words summed so far
   int64_t queue_size();
   int64_t queue_size_at(int32_t t);
   struct StagedChainKeep {

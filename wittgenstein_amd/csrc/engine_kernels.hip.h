@@ -243,6 +243,10 @@ struct ExpandF {
   }
   // thread the event onto its node's inbox list; returns true if it is the node's first event
   __device__ bool link(uint32_t e, int32_t to) const {
+    if (d.sharded) {  // the event list is replicated on every shard; a shard applies the events of its own nodes
+      d.evRes[e] = EvRes{0u, 0u};  // ... and reports zeros for the others (summed across shards before `order`)
+      if (!shard_owns(d, to)) return false;
+    }
     int32_t prev = atomicExch(&d.head[to], (int32_t)e);
     d.evNext[e] = prev;
     return prev < 0;
@@ -283,6 +287,8 @@ struct ExpandF {
           d.evAux[e] = a;
           if (!d.hostMode && link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
         }
+        // sharded: the envelope's slot is released by every shard (deliver_event's release runs on one shard only)
+        if (d.sharded && (int)(r.w2 + len) >= c.ndest) d.chains[r.w1].flags = 0;
       }
     }
     // wave-aggregated append to the active list: one atomic per wavefront, not per node
@@ -365,6 +371,10 @@ __device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from
 
 constexpr int TILE = 1024;
 
+// SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
+// emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
+// across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
+template <bool SH>
 __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
   const int32_t t = d.g->now;
@@ -372,6 +382,10 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
   const uint32_t D = (uint32_t)d.horizon;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     const uint32_t e = d.recEv[p];
+    if (SH && !shard_owns(d, (int32_t)d.ev[e].w1)) {
+      for (int k = 0; k < 5; k++) d.xbuf[(size_t)p * 5 + k] = 0;
+      continue;
+    }
     const Out o = d.outTmp[d.evAux[e].outBase + (p - d.evRecOff[e])];
     uint32_t kind = o.kindfrom >> 28;
     int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
@@ -385,6 +399,10 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         break;
       }
       case O_MULTI: {  // delaysBetweenMessage == 0 only (device actions); stable sort by arrival (:464)
+        if (SH) {  // the envelope (slot, sorted destinations) would have to be created on every shard
+          set_err(d.g, ERR_SHARD_MULTI);
+          break;
+        }
         int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
         int nd = o.to;
         int32_t dst[64], arv[64];
@@ -453,9 +471,37 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         arrival = -1;
       }
     }
+    if (SH) {
+      int32_t* x = d.xbuf + (size_t)p * 5;
+      x[0] = (int32_t)fin.w0;
+      x[1] = (int32_t)fin.w1;
+      x[2] = (int32_t)fin.w2;
+      x[3] = (int32_t)fin.w3;
+      x[4] = arrival + 1;  // 0 = dropped at send time
+      continue;
+    }
     d.fin[p] = fin;
     d.arr[p] = arrival;
     // per-tile arrival histogram of the multisplit (rows are zero on entry: k_scatter re-zeroes them)
+    if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
+  }
+}
+
+// sharded engine: the summed exchange image -> ordered outbox + tile histograms, identically on every shard
+__global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  const uint32_t n = d.g->nOut;
+  const uint32_t D = (uint32_t)d.horizon;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int32_t* x = d.xbuf + (size_t)p * 5;
+    Rec fin;
+    fin.w0 = (uint32_t)x[0];
+    fin.w1 = (uint32_t)x[1];
+    fin.w2 = (uint32_t)x[2];
+    fin.w3 = (uint32_t)x[3];
+    const int32_t arrival = x[4] - 1;
+    d.fin[p] = fin;
+    d.arr[p] = arrival;
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
   }
 }

@@ -1,0 +1,82 @@
+"""Node-range sharding of ONE simulation over the GPUs of a box: one process per GPU, `torch.distributed` over
+RCCL ("nccl" on ROCm) carrying the two per-ms sums the engine asks for (include/wittgpu.h, "node-range sharding";
+DESIGN.md §7). The reference has no counterpart (it is single-threaded, C/Network.java:7-11); what is kept is its
+result: every shard-count gives the same pong counts / counters / rd state as the unsharded engine.
+
+    cfg = shards.config(dist)                   # rank / world size of the default process group
+    p = PingPong(PingPongParameters(1000), config=cfg); p.init()
+    p.network().runMs(50)
+    pong = shards.gather(dist, p.network().read("pong"))   # whole-network view (SUM of the per-shard views)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class _DeviceWords:
+    """int32 words at a raw device address, for torch.as_tensor (zero copy through __cuda_array_interface__)"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def make_allreduce(dist, group=None, device_memory=True):
+    """wg_allreduce_fn over a torch.distributed process group. device_memory=False is for tests/emu only (the
+    kernel sources on the CPU wave emulator keep "device" buffers in host memory; backend gloo)."""
+    import torch
+
+    def fn(_ctx, buf, count):
+        try:
+            if device_memory:
+                t = torch.as_tensor(_DeviceWords(buf, count), device="cuda")
+                dist.all_reduce(t, group=group)
+                torch.cuda.synchronize()
+            else:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32)), shape=(int(count),))
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, group=group)
+            return 0
+        except Exception:  # an exception must not unwind through the C frames of the engine
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return L.ALLREDUCE_FN(fn)
+
+
+_KEEP = []  # the ctypes thunks must outlive every engine that holds their address
+
+
+def config(dist, group=None, device_memory=True, **capacities):
+    """wg_config fields (a dict for the `config=` argument of the protocol mirrors / Network.create) that make
+    the engine shard `rank` of `world_size`."""
+    fn = make_allreduce(dist, group, device_memory)
+    _KEEP.append(fn)
+    cfg = dict(capacities)
+    cfg.update(shard=dist.get_rank(group), nshards=dist.get_world_size(group),
+               allreduce=C.cast(fn, C.c_void_p).value)
+    return cfg
+
+
+def shard_range(net):
+    lo, hi = C.c_int32(), C.c_int32()
+    net._ck(L.lib().wg_shard_info(net._h, C.byref(lo), C.byref(hi), None, None))
+    return lo.value, hi.value
+
+
+def traffic(net):
+    """(all-reduce calls, int32 words summed) so far"""
+    c, w = C.c_int64(), C.c_int64()
+    net._ck(L.lib().wg_shard_info(net._h, None, None, C.byref(c), C.byref(w)))
+    return c.value, w.value
+
+
+def gather(dist, per_shard, group=None, device="cpu"):
+    """whole-network view of a per-node read-back: a shard reports its own nodes and zeros for the others"""
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(per_shard)).to(device)
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy()
