@@ -78,3 +78,71 @@ def test_sharded_pingpong_matches_the_oracle(oracle, tmp_path, world, n, nl):
         assert r["calls"] > 0 and r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]
     assert res[0]["pong0"] == n                      # PT/PingPongTest.java:8-19: node 0 collects every pong
     assert res[0]["delivered"] == 2 * n
+
+
+HANDEL_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+import wittgenstein_amd as w
+from wittgenstein_amd import shards
+import oracle_lib as o
+import parity
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+params = %(params)r
+g, c = parity.handel_pair(params, seed=%(seed)d, config=shards.config(dist, device_memory=False, queue_cap=64))
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad, steps, delivered = [], 0, 0
+while True:
+    g.network().runMs(%(chunk)d); c.run_ms(%(chunk)d); steps += 1
+    delivered += g.network().last_stats["delivered"]
+    if steps %% %(check_every)d == 0:
+        bad += [(steps, m) for m in parity.diff_handel(G(), c)]
+    go, want = shards.cont_if(dist, g), c.cont_if()
+    if go != want: bad.append((steps, "cont_if %%s != %%s" %% (go, want)))
+    if bad or not want or steps >= %(max_steps)d: break
+bad += [(steps, m) for m in parity.diff_handel(G(), c)]
+dl = c.stats()["deliveredByLevel"]
+if not np.array_equal(g.network().delivered_by_level()[:len(dl)].astype(np.uint64), dl): bad.append((steps, "delivered_by_level"))
+calls, words = shards.traffic(g.network())
+res = [None] * world
+dist.all_gather_object(res, {"rank": rank, "bad": [str(b) for b in bad[:6]], "steps": steps, "calls": calls, "words": words,
+                             "delivered": delivered, "expect": c.info(False)["delivered"], "done": not c.cont_if(),
+                             "doneAt": int((whole.read("doneAt") > 0).sum())})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def _run_handel(tmp_path, world, port, **kw):
+    global WORKER
+    keep, WORKER = WORKER, HANDEL_WORKER
+    try:
+        return _run(tmp_path, world, port, **kw)
+    finally:
+        WORKER = keep
+
+
+# (nodeCount, threshold, pairing, levelWait, extraCycle, period, fastPath, nodesDown, desync)
+@pytest.mark.parametrize("world,params", [
+    (2, (64, 57, 4, 50, 10, 20, 10, 6, 0)),      # PT/HandelTest's size, fast path on, dead nodes
+    (2, (128, 100, 4, 20, 5, 10, 10, 12, 100)),  # desynchronised start, wider levels
+    (4, (64, 60, 6, 10, 5, 5, 10, 2, 100)),      # PT/HandelTest.java:36-49 parameters, 4 shards
+])
+def test_sharded_handel_matches_the_oracle(oracle, tmp_path, world, params):
+    res = _run_handel(tmp_path, world, 29551 + world + params[0] % 7, params=params, seed=1, chunk=10, check_every=5,
+                      max_steps=400)
+    assert len(res) == world
+    for r in res:
+        assert r["bad"] == [], r
+        assert r["done"] and r["delivered"] == r["expect"] > 0
+        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]
+    live = params[0] - params[7]
+    assert res[0]["doneAt"] == live          # every live node reached the threshold (PT/HandelTest.java:36-49)

@@ -167,6 +167,10 @@ struct Globals {
   unsigned long long payloadHead;  // monotone, in 64-bit words
   // in-kernel cycle counters of investigation builds (-DWG_KPROF, tools/kprof.sh); untouched otherwise
   unsigned long long kprof[32];
+  // sharded engines only (0 otherwise): multi-destination envelopes created in this phase / their destinations
+  // (replicated), and this shard's private scratch-ring head for the unsorted destination lists of its action()s
+  uint32_t nMulti, nMultiDests;
+  unsigned long long localDestHead;
 };
 
 struct LatencyModel {
@@ -252,7 +256,17 @@ struct EngineDev {
   uint32_t sharded;
   int32_t shardLo, shardHi;
   int32_t* xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1)
+  int32_t* xmulti;          // [maxMulti][XM_WORDS] exchange image of the multi-destination envelopes of a phase
+  uint32_t maxMulti;
+  uint32_t* multiK;         // [maxOut] ordinal of a fresh multi-destination record / offset of its destinations
+  uint32_t* multiOff;
+  // where action() code parks the (unsorted) destination list of a multi-destination send until `resolve`:
+  // the envelope ring itself, or — sharded, where that ring is replicated state — a private scratch ring
+  int32_t* sdests;
+  unsigned long long sdestCap;
 };
+constexpr int XM_WORDS = 6 + 64;               // seed, sendTime, msg, payload, ndest, pad, dest[64]
+constexpr uint32_t MULTI_FRESH = 0xFFFFFFFFu;  // Rec::w3 of a K_CHAIN record whose envelope is yet to be created
 WG_HD inline bool shard_owns(const EngineDev& d, int32_t node) { return node >= d.shardLo && node < d.shardHi; }
 
 WG_HD inline int32_t isqrt_floor(int32_t v) {  // (int) Math.sqrt(v), C/Node.java:281

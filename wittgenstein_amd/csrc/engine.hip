@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
+#include <type_traits>
 #include "engine_host.h"
 #include "engine_kernels.hip.h"
 
@@ -393,10 +395,20 @@ void Engine::ensure_device() {
   dev.shardLo = 0;
   dev.shardHi = INT32_MAX;
   dev.xbuf = nullptr;
+  dev.xmulti = nullptr;
+  dev.maxMulti = 0;
+  dev.multiK = dev.multiOff = nullptr;
+  dev.sdests = dev.dests;
+  dev.sdestCap = dev.chainDests;
   if (shardCount > 0) {
     dev.shardLo = (int32_t)((int64_t)n * shardIndex / shardCount);
     dev.shardHi = (int32_t)((int64_t)n * (shardIndex + 1) / shardCount);
     dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5);
+    dev.maxMulti = std::max<uint32_t>(1024, maxOut / 16);
+    dev.xmulti = dalloc<int32_t>((size_t)dev.maxMulti * XM_WORDS);
+    dev.multiK = dalloc<uint32_t>(maxOut, false);
+    dev.multiOff = dalloc<uint32_t>(maxOut, false);
+    dev.sdests = dalloc<int32_t>(chainDests, false);  // private scratch for unsorted destination lists
   }
   allocated = true;
   upload_latency();
@@ -534,6 +546,7 @@ void Engine::scan(const Group& g, const typename F::Aux* atab) {
 }
 template void Engine::scan<ExpandF>(const Group&, const int*);
 template void Engine::scan<RecsF>(const Group&, const int*);
+template void Engine::scan<MultiF>(const Group&, const int*);
 
 // multisplit of the ordered outbox (fin/arr, g->nOut) into the buckets. The per-tile histograms are
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
@@ -897,9 +910,29 @@ void Engine::shard_allreduce(void* buf, int64_t count) {
   shardWords += count;
 }
 
+// the exchange image of a phase's ordered outbox (xbuf, written by the owners) -> fin / arr / tile histograms on
+// every shard, then the multi-destination envelopes among them
+void Engine::exchange_outbox(uint32_t nOut) {
+  Group g = self();
+  shard_allreduce(dev.xbuf, 5 * (int64_t)nOut);
+  hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+  if (!proto->emits_multi()) return;
+  uint32_t nMulti = 0;
+  WG_HIP(hipStreamSynchronize(stream));
+  WG_HIP(hipMemcpy(&nMulti, (const char*)dev.g + offsetof(Globals, nMulti), 4, hipMemcpyDeviceToHost));
+  if (!nMulti) return;
+  scan<MultiF>(g, nullptr);
+  nMulti = std::min(nMulti, dev.maxMulti);
+  if (getenv("WG_SHARD_DEBUG")) fprintf(stderr, "[shard %d] t=%d multi-destination envelopes: %u\n", shardIndex, time, nMulti);
+  WG_HIP(hipMemsetAsync(dev.xmulti, 0, sizeof(int32_t) * (size_t)nMulti * XM_WORDS, stream));
+  hipLaunchKernelGGL(k_shard_multi_fill, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+  shard_allreduce(dev.xmulti, (int64_t)nMulti * XM_WORDS);
+  hipLaunchKernelGGL(k_shard_multi_create, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+}
+
 void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   if (!proto->supports_shards())
-    throw WgError(WG_EUNSUPPORTED, "this resident protocol does not run on a sharded engine yet (PingPong does)");
+    throw WgError(WG_EUNSUPPORTED, "this resident protocol does not run on a sharded engine yet (PingPong and Handel do)");
   const Globals before = gh;
   int32_t endAt = 0;
   begin_run(ms, &endAt);
@@ -920,16 +953,22 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     scan<ExpandF>(g, nullptr);
     proto->launch_deliver(g);
     const uint32_t nEvents = scratch(&Globals::nEvents);
+    if (nEvents) proto->shard_post_deliver(*this, g);
     shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
     scan<RecsF>(g, nullptr);
     const uint32_t nOut = scratch(&Globals::nOut);
     if (nOut) {
       hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
-      shard_allreduce(dev.xbuf, 5 * (int64_t)nOut);
-      hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+      exchange_outbox(nOut);
     }
     append_phase(g, false);
     end_phase(g, true);
+    if (proto->has_cond()) {  // the conditional tasks of the edge to the new `now` (C/Network.java:543-566)
+      const uint32_t nCond = proto->shard_cond(*this, g);
+      if (nCond) exchange_outbox(nCond);
+      append_phase(g, false);
+      end_phase(g, false);
+    }
   }
   WG_HIP(hipStreamSynchronize(stream));
   auto t1 = std::chrono::steady_clock::now();
@@ -1304,10 +1343,11 @@ void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
 namespace wg {
 
 template void Engine::scan<CondF>(const Group&, const HandelState*);
+template void Engine::scan<SnapF>(const Group&, const HandelState*);
 
 __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t* startAt, const int32_t* pairing) {
-  int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= s.N) return;
+  int node = s.lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.hi) return;
   uint32_t* h = h_hdr(s, node);
   h[HH_START] = (uint32_t)startAt[node];
   h[HH_PAIR] = (uint32_t)pairing[node];
@@ -1331,8 +1371,9 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
 __global__ void k_handel_cont_if(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab, uint32_t* out) {
   const EngineDev& d = tab[blockIdx.y];
   const HandelState& s = stab[blockIdx.y];
-  int node = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = node < s.N && !d.nodes.down[node] && (d.nodes.doneAt[node] == 0 || (int32_t)h_hdr(s, node)[HH_ADDED] > 0);
+  int node = blockIdx.x * blockDim.x + threadIdx.x;  // (sharded: the predicate over this shard's nodes)
+  bool c = node >= s.lo && node < s.hi && !d.nodes.down[node] &&
+           (d.nodes.doneAt[node] == 0 || (int32_t)h_hdr(s, node)[HH_ADDED] > 0);
   if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
 }
 
@@ -1367,26 +1408,34 @@ struct HandelHost : ProtoHost {
     st.L = L;
     st.W = W;
     st.Q = Q;
-    const size_t rows = (size_t)N * W;
-    st.TI = e.dalloc<uint64_t>(rows);
-    st.LA = e.dalloc<uint64_t>(rows);
-    st.VI = e.dalloc<uint64_t>(rows);
-    st.TV = e.dalloc<uint64_t>(rows);
-    st.FP = e.dalloc<uint64_t>(rows);
-    st.ranks = e.dalloc<int32_t>((size_t)N * N, false);
-    st.peers = e.dalloc<int32_t>((size_t)N * (N - 1), false);
+    // Per-node rows are held for the nodes [lo, hi) this engine owns — everything when it is not sharded — behind
+    // pointers biased by -lo rows, so that the kernels keep indexing them by node id (they touch only owned nodes).
+    const int32_t lo = st.lo = e.shardCount > 0 ? e.dev.shardLo : 0;
+    const int32_t hi = st.hi = e.shardCount > 0 ? e.dev.shardHi : N;
+    const size_t nLoc = (size_t)(hi - lo);
+    auto rows = [&](auto* tag, size_t stride, bool zero) {
+      typedef std::remove_pointer_t<decltype(tag)> T;
+      return e.dalloc<T>(nLoc * stride, zero) - (size_t)lo * stride;
+    };
+    st.TI = rows((uint64_t*)nullptr, W, true);
+    st.LA = rows((uint64_t*)nullptr, W, true);
+    st.VI = rows((uint64_t*)nullptr, W, true);
+    st.TV = rows((uint64_t*)nullptr, W, true);
+    st.FP = rows((uint64_t*)nullptr, W, true);
+    st.ranks = rows((int32_t*)nullptr, N, false);
+    st.peers = rows((int32_t*)nullptr, N - 1, false);
     st.LS = L <= 16 ? 16 : 32;
     st.lsShift = L <= 16 ? 4 : 5;
     st.hdrStride = HH_LV + HP_COUNT * st.LS;  // 160 or 288 words: whole 128-byte lines
-    st.hdr = e.dalloc<uint32_t>((size_t)N * st.hdrStride);
+    st.hdr = rows((uint32_t*)nullptr, st.hdrStride, true);
     const size_t NL = (size_t)N * L;
-    st.qent = e.dalloc<uint64_t>(NL * 64);
-    st.qfrom = e.dalloc<int32_t>(NL * Q, false);
+    st.qent = rows((uint64_t*)nullptr, (size_t)L * 64, true);
+    st.qfrom = rows((int32_t*)nullptr, (size_t)L * Q, false);
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
-      st.qsigOff[l] = off;
       int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
-      off += (unsigned long long)N * Q * nw;
+      st.qsigOff[l] = off - (unsigned long long)lo * Q * nw;  // (node * Q + slot) * nw is added to it: biased like the rows
+      off += (unsigned long long)nLoc * Q * nw;
     }
     st.qsig = e.dalloc<uint64_t>(off, false);
     {
@@ -1403,20 +1452,38 @@ struct HandelHost : ProtoHost {
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
     st.runList = e.dalloc<uint32_t>(N);
     st.runCount = e.dalloc<uint32_t>(1);
-    st.candCnt = e.dalloc<uint8_t>(N);
+    st.candCnt = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
     st.candLevel = e.dalloc<uint8_t>(NL);
     st.candSlot = e.dalloc<uint8_t>(NL);
     st.condOrd = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N);
     st.drawVal = e.dalloc<int32_t>(N);
-    WG_HIP(hipMemcpy(st.ranks, init.receptionRanks, 4 * (size_t)N * N, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * (N - 1), hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.peers + (size_t)lo * (N - 1), init.peers + (size_t)lo * (N - 1), 4 * nLoc * (N - 1),
+                     hipMemcpyHostToDevice));
+    st.ones = nullptr;
+    st.snapIdx = nullptr;
+    st.nSnap = nullptr;
+    st.xsnap = nullptr;
+    st.xsnapRows = 0;
+    if (e.shardCount > 0) {
+      std::vector<uint64_t> ones((size_t)W, ~0ULL);
+      uint64_t* dOnes = e.dalloc<uint64_t>(W, false);
+      WG_HIP(hipMemcpy(dOnes, ones.data(), 8 * (size_t)W, hipMemcpyHostToDevice));
+      st.ones = dOnes;
+      st.snapIdx = e.dalloc<uint32_t>(e.dev.maxEvents, false);
+      st.nSnap = e.dalloc<uint32_t>(1);
+      // every node disseminates once per period; a desynchronised start spreads them, a synchronised one puts all
+      // of them into the same ms
+      st.xsnapRows = (uint32_t)N;
+      st.xsnap = e.dalloc<int32_t>((size_t)st.xsnapRows * st.snapStride * 2, false);
+    }
     int32_t *dStart = nullptr, *dPair = nullptr;
     WG_HIP(hipMalloc((void**)&dStart, 4 * (size_t)N));
     WG_HIP(hipMalloc((void**)&dPair, 4 * (size_t)N));
     WG_HIP(hipMemcpy(dStart, init.startAt, 4 * (size_t)N, hipMemcpyHostToDevice));
     WG_HIP(hipMemcpy(dPair, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_handel_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down, dStart, dPair);
+    hipLaunchKernelGGL(k_handel_init, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down, dStart, dPair);
     WG_HIP(hipStreamSynchronize(e.stream));
     (void)hipFree(dStart);
     (void)hipFree(dPair);
@@ -1458,7 +1525,38 @@ struct HandelHost : ProtoHost {
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
-    hipLaunchKernelGGL(k_handel_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  // ---- node-range sharding (Engine::run_ms_sharded) ----
+  bool supports_shards() const override { return true; }
+  bool emits_multi() const override { return st.p.fastPath > 1; }
+  // the dissemination snapshots written in this ms -> every shard's copy of the snapshot ring
+  void shard_post_deliver(Engine& e, const Group& g) override {
+    const HandelState* stab = (const HandelState*)g.stab;
+    Engine::scan<SnapF>(g, stab);
+    uint32_t nSnap = 0;
+    WG_HIP(hipStreamSynchronize(g.stream));
+    WG_HIP(hipMemcpy(&nSnap, st.nSnap, 4, hipMemcpyDeviceToHost));
+    if (!nSnap) return;
+    hipLaunchKernelGGL(k_handel_shard_snap<true>, dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
+    hipLaunchKernelGGL(k_handel_shard_snap<false>, dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  // checkSigs' edge (launch_cond above) with the draw order made global: the per-node candidate counts are summed
+  // across shards (a shard knows its own nodes'), after which the ordinal of every drawing node, its rd draw and the
+  // number of draws are computed identically everywhere; the task registrations go through the exchange image.
+  uint32_t shard_cond(Engine& e, const Group& g) override {
+    const HandelState* stab = (const HandelState*)g.stab;
+    hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.shard_allreduce(st.candCnt, ((int64_t)st.N + 3) / 4);
+    Engine::scan<CondF>(g, stab);
+    uint32_t nOut = 0;
+    WG_HIP(hipStreamSynchronize(g.stream));
+    WG_HIP(hipMemcpy(&nOut, (const char*)e.dev.g + offsetof(Globals, nOut), 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_handel_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    WG_HIP(hipMemsetAsync(st.candCnt, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' counts
+    return nOut;
   }
   // WG_LANE_MSGS=0 keeps every node visit on the wave-per-node kernel (A/B switch for profiles)
   int laneMsgs = getenv("WG_LANE_MSGS") ? atoi(getenv("WG_LANE_MSGS")) : 1;
@@ -1482,8 +1580,9 @@ struct HandelHost : ProtoHost {
   }
   // read-back (tests, statistics): the header records come back whole and are picked apart on the host
   std::vector<uint32_t> read_hdr() {
-    std::vector<uint32_t> h((size_t)st.N * st.hdrStride);
-    WG_HIP(hipMemcpy(h.data(), st.hdr, 4 * h.size(), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> h((size_t)st.N * st.hdrStride);  // (sharded: zeros for the nodes of other shards)
+    const size_t at = (size_t)st.lo * st.hdrStride;
+    WG_HIP(hipMemcpy(h.data() + at, st.hdr + at, 4 * (size_t)(st.hi - st.lo) * st.hdrStride, hipMemcpyDeviceToHost));
     return h;
   }
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
@@ -1523,7 +1622,8 @@ struct HandelHost : ProtoHost {
       case WG_B_FINISHED_PEERS: src = st.FP; break;
       default: return false;
     }
-    WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
+    memset(dst, 0, 8 * (size_t)n * w);
+    WG_HIP(hipMemcpy(dst + (size_t)st.lo * w, src + (size_t)st.lo * w, 8 * (size_t)(st.hi - st.lo) * w, hipMemcpyDeviceToHost));
     return true;
   }
 };

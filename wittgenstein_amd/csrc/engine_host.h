@@ -61,6 +61,12 @@ struct ProtoHost {
   // node-range sharding (wg_shard_configure): the protocol's kernels touch only the nodes the engine links into
   // its inbox lists, its payloads are self-contained and it has no conditional-task phase
   virtual bool supports_shards() const { return false; }
+  virtual bool emits_multi() const { return false; }   // its action()s issue multi-destination sends
+  // after the delivery kernels of a ms: payloads written by this shard's action()s that other shards will read
+  virtual void shard_post_deliver(Engine&, const Group&) {}
+  // the conditional-task phase on a sharded engine: leaves the task records of this shard's nodes in the exchange
+  // image (EngineDev::xbuf) and returns the (replicated) number of records; only called when has_cond()
+  virtual uint32_t shard_cond(Engine&, const Group&) { return 0; }
 };
 
 class Engine {
@@ -90,6 +96,7 @@ class Engine {
   void configure_shard(int32_t shard, int32_t nshards, wg_allreduce_fn fn, void* ctx);
   void run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
   void shard_allreduce(void* buf, int64_t count);
+  void exchange_outbox(uint32_t nOut);
   int32_t shardIndex = 0, shardCount = 0;  // shardCount == 0: not sharded
   wg_allreduce_fn xfn = nullptr;
   void* xctx = nullptr;

@@ -371,6 +371,28 @@ __device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from
 
 constexpr int TILE = 1024;
 
+// createMessageArrivals of a device-side multi-destination send (delaysBetweenMessage == 0): arrivals of the
+// destinations that are reachable, stable-sorted by arrival (C/Network.java:449-467). Returns their number.
+__device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t* dst,
+                                             int32_t* arv) {
+  const int nd = o.to;
+  int m = 0;
+  for (int j = 0; j < nd && j < 64; j++) {
+    int32_t to = d.sdests[(o.destOff + (unsigned long long)j) % d.sdestCap];
+    int32_t a;
+    if (!arrival_of_send(d, from, to, o.t, seed, a)) continue;
+    int k = m++;
+    while (k > 0 && arv[k - 1] > a) {  // insertion keeps equal arrivals in caller order
+      arv[k] = arv[k - 1];
+      dst[k] = dst[k - 1];
+      k--;
+    }
+    arv[k] = a;
+    dst[k] = to;
+  }
+  return m;
+}
+
 // SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
 // emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
@@ -399,29 +421,16 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         break;
       }
       case O_MULTI: {  // delaysBetweenMessage == 0 only (device actions); stable sort by arrival (:464)
-        if (SH) {  // the envelope (slot, sorted destinations) would have to be created on every shard
-          set_err(d.g, ERR_SHARD_MULTI);
-          break;
-        }
         int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
-        int nd = o.to;
         int32_t dst[64], arv[64];
-        int m = 0;
-        for (int j = 0; j < nd && j < 64; j++) {
-          int32_t to = d.dests[(o.destOff + (unsigned long long)j) % d.chainDests];
-          int32_t a;
-          if (!arrival_of_send(d, from, to, o.t, seed, a)) continue;
-          int k = m++;
-          while (k > 0 && arv[k - 1] > a) {  // insertion keeps equal arrivals in caller order
-            arv[k] = arv[k - 1];
-            dst[k] = dst[k - 1];
-            k--;
-          }
-          arv[k] = a;
-          dst[k] = to;
-        }
+        const int m = resolve_multi(d, o, from, seed, dst, arv);
         if (m == 1) {
           fin = make_rec(K_MSG, from, (uint32_t)dst[0], o.a, o.b);
+          arrival = arv[0];
+        } else if (m > 1 && SH) {
+          // the envelope (slot, sorted destinations) is replicated state: it is created on every shard from the
+          // exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push order
+          fin = make_rec(K_CHAIN, from, (uint32_t)m, 0, MULTI_FRESH);
           arrival = arv[0];
         } else if (m > 1) {
           uint32_t slot = atomicAdd(&d.g->chainHead, 1u) % d.chainSlots;
@@ -503,6 +512,87 @@ __global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restric
     d.fin[p] = fin;
     d.arr[p] = arrival;
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
+    if (arrival >= 0 && rec_kind(fin) == K_CHAIN && fin.w3 == MULTI_FRESH) atomicAdd(&d.g->nMulti, 1u);  // rare
+  }
+}
+
+// sharded engine, multi-destination envelopes emitted in this phase (Network.send(m, from, dests) inside an
+// action(), C/Network.java:418-447). MultiF numbers them in push order; the owner of the sender writes the
+// envelope's image {seed, sendTime, msg, payload, ndest, destinations sorted by arrival}; after the sum across
+// shards every shard creates the same envelope in the same slot of its (replicated) envelope table.
+struct MultiF {
+  typedef int Aux;
+  const EngineDev& d;
+  __device__ MultiF(const EngineDev& d_, const Aux*) : d(d_) {}
+  __device__ uint32_t count() const { return d.g->nOut; }
+  __device__ bool fresh(uint32_t p) const {
+    const Rec r = d.fin[p];
+    return d.arr[p] >= 0 && rec_kind(r) == K_CHAIN && r.w3 == MULTI_FRESH;
+  }
+  __device__ uint64_t value(uint32_t p) const { return fresh(p) ? (((uint64_t)d.fin[p].w1 << 32) | 1u) : 0; }
+  __device__ void tally(uint32_t, uint32_t) const {}
+  __device__ void total(uint64_t tot) const {
+    if ((uint32_t)tot > d.maxMulti) set_err(d.g, ERR_CHAIN_SLOTS);
+    d.g->nMulti = min((uint32_t)tot, d.maxMulti);
+    d.g->nMultiDests = (uint32_t)(tot >> 32);
+  }
+  __device__ void write(uint32_t p, uint64_t excl, bool valid) const {
+    if (!valid) return;
+    d.multiK[p] = (uint32_t)excl;
+    d.multiOff[p] = (uint32_t)(excl >> 32);
+  }
+};
+
+__global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  const uint32_t n = d.g->nOut;
+  const MultiF f(d, nullptr);
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    if (!f.fresh(p) || d.multiK[p] >= d.maxMulti) continue;
+    const uint32_t e = d.recEv[p];
+    if (!shard_owns(d, (int32_t)d.ev[e].w1)) continue;  // (the image is zero on entry)
+    const Out o = d.outTmp[d.evAux[e].outBase + (p - d.evRecOff[e])];
+    const int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
+    const int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
+    int32_t dst[64], arv[64];
+    const int m = resolve_multi(d, o, from, seed, dst, arv);
+    int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
+    x[0] = seed;
+    x[1] = o.t;
+    x[2] = (int32_t)o.a;
+    x[3] = (int32_t)o.b;
+    x[4] = m;
+    for (int j = 0; j < m; j++) x[6 + j] = dst[j];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  const uint32_t n = d.g->nOut;
+  const MultiF f(d, nullptr);
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    if (!f.fresh(p) || d.multiK[p] >= d.maxMulti) continue;
+    const int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
+    const Rec r = d.fin[p];
+    const uint32_t slot = (d.g->chainHead + d.multiK[p]) % d.chainSlots;
+    if (d.chains[slot].flags & 1u) {
+      set_err(d.g, ERR_CHAIN_SLOTS);
+      continue;
+    }
+    const unsigned long long off = (d.g->destHead + d.multiOff[p]) % d.chainDests;
+    const int m = x[4];
+    for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)j) % d.chainDests] = x[6 + j];
+    Chain c;
+    c.from = rec_from(r);
+    c.seed = x[0];
+    c.sendTime = x[1];
+    c.ndest = m;
+    c.destOff = (uint32_t)off;
+    c.msg = (uint32_t)x[2];
+    c.payload = (uint32_t)x[3];
+    c.flags = 1u;
+    d.chains[slot] = c;
+    d.fin[p] = make_rec(K_CHAIN, c.from, slot, 0, 0);
   }
 }
 
@@ -640,7 +730,13 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
   __shared__ uint32_t shTop;
   Globals* g = d.g;
   const int32_t t = g->now;
-  if (threadIdx.x == 0) shTop = g->freeTop;
+  if (threadIdx.x == 0) {
+    shTop = g->freeTop;
+    g->chainHead += g->nMulti;  // (sharded engines only: envelopes created by k_shard_multi_create; 0 otherwise)
+    g->destHead += g->nMultiDests;
+    g->nMulti = 0;
+    g->nMultiDests = 0;
+  }
   __syncthreads();
   if (drained) {
     uint32_t b = (uint32_t)t & (uint32_t)(d.horizon - 1);
@@ -760,19 +856,19 @@ struct Ctx {
   // The destination ids must already be in the dest ring at destOff (dest_reserve).
   __device__ uint32_t dest_reserve(int n) {
     unsigned long long off = 0;
-    if (WG_LANE == 0) off = atomicAdd(&d.g->destHead, (unsigned long long)n);
+    if (WG_LANE == 0) off = atomicAdd(d.sharded ? &d.g->localDestHead : &d.g->destHead, (unsigned long long)n);
     off = shfl64(off, 0);
-    return (uint32_t)(off % d.chainDests);
+    return (uint32_t)(off % d.sdestCap);
   }
   __device__ void dest_put(uint32_t destOff, int j, int32_t id) {
-    d.dests[(destOff + (unsigned long long)j) % d.chainDests] = id;
+    d.sdests[(destOff + (unsigned long long)j) % d.sdestCap] = id;
   }
   __device__ void send_list(uint32_t destOff, int n, uint32_t msg, uint32_t payload, int size) {
     if (n == 0) return;
     msgSent += n;
     bytesSent += (long long)n * size;
     if (n == 1) {
-      int32_t to = __hip_atomic_load(&d.dests[destOff % d.chainDests], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int32_t to = __hip_atomic_load(&d.sdests[destOff % d.sdestCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       put(O_SEND, to, msg, payload, t + 1, 0, true);
     } else {
       if (n > 64) {

@@ -59,6 +59,14 @@ struct HandelState {
   uint32_t* condOrd;                   // [N] ordinal among drawing nodes
   uint32_t* condList;                  // drawing nodes in id order
   int32_t* drawVal;                    // [N]
+  // node-range sharding (wg_shard_configure): this engine holds the per-node rows above only for the nodes
+  // [lo, hi) (the row pointers are biased so that they are still indexed by node id); 0 / N when not sharded
+  int32_t lo, hi;
+  const uint64_t* ones;                // [W] all-ones words: the payload of a sharded fast-path send (see snapshot_outgoing)
+  uint32_t* snapIdx;                   // [maxEvents] row of a dissemination event in the snapshot exchange image
+  uint32_t* nSnap;                     // [1]
+  int32_t* xsnap;                      // [xsnapRows][snapStride * 2] exchange image of this ms's dissemination snapshots
+  uint32_t xsnapRows;
 };
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
@@ -143,6 +151,11 @@ __device__ __forceinline__ void ls_set_qused(LevelScalars* ls, int l, unsigned l
 }
 
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
+constexpr uint32_t H_REF_ONES = 0xFFFFFFFFu;  // payload ref: the all-ones block (fast-path sends of a sharded engine)
+__device__ __forceinline__ const uint64_t* h_payload(const EngineDev& d, const HandelState& s, uint32_t payload) {
+  if (payload & H_REF_RING) return payload == H_REF_ONES ? s.ones : d.payload + (payload & ~H_REF_RING);
+  return s.snap + payload;
+}
 
 struct HandelProto {
   typedef HandelState State;
@@ -296,7 +309,7 @@ struct HandelProto {
     uint32_t* qln = h_lv(s, node, HP_QLEN, l);
     const unsigned long long used = (unsigned long long)*qlo | ((unsigned long long)*qhi << 32);
     const int len = (int)*qln;
-    const uint64_t* src = (payload & H_REF_RING) ? d.payload + (payload & ~H_REF_RING) : s.snap + payload;
+    const uint64_t* src = h_payload(d, s, payload);
     const int nw = h_nw(l);
     const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
     if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
@@ -393,6 +406,10 @@ struct HandelProto {
   // snapshot of totalOutgoing of level l (the node's own block of the TI row) for a fast-path send
   // (irregular: engine payload ring); the periodic dissemination has its own computed slot.
   __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l) {
+    // A fast-path send happens when totalOutgoing of level l is complete (cur == 2^(l-1), :738-741): its snapshot
+    // is the node's whole own block, i.e. all ones under the receiver's level mask. A sharded engine, whose payload
+    // ring is private to the shard, sends that constant instead of a copy.
+    if (c.d.sharded) return H_REF_ONES;
     Lv v = own_view(c.node, l);
     const uint64_t* ti = s.TI + (size_t)c.node * s.W;
     uint32_t ref = c.alloc_payload(v.nw);
@@ -421,7 +438,7 @@ struct HandelProto {
     const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
     const Lv v = sib_view(node, l);
-    const uint64_t* src = (payload & H_REF_RING) ? c.d.payload + (payload & ~H_REF_RING) : s.snap + payload;
+    const uint64_t* src = h_payload(c.d, s, payload);
     const int j0 = (int)((WG_LANE - v.bw) & 63);
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
@@ -700,12 +717,12 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   const int32_t t = d.g->now, until = d.g->until;
   const uint32_t epoch = d.g->epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t n0 = blockIdx.x * blockDim.x; n0 < (uint32_t)s.N; n0 += stride) {
+  for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
-    if (node < (uint32_t)s.N) {
+    if (node < (uint32_t)s.hi) {
       uint32_t* h = h_hdr(s, (int32_t)node);
       if (!d.nodes.down[node] && h[HH_CTEPOCH] != epoch) {
         const int32_t ms = (int32_t)h[HH_CTMIN];
@@ -921,6 +938,8 @@ struct CondF {
 };
 
 // A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
+// SH (sharded engine): a drawing node is handled by its owner, the task record goes to the exchange image.
+template <bool SH>
 __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restrict__ tab,
                                                         const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -937,7 +956,8 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
     if (j < n) {
       const int32_t node = (int32_t)s.condList[j];
       int k = s.drawVal[node];
-      if (rejected) {  // a nextInt(bound) rejection shifted the stream: walk it serially up to this draw (rare)
+      const bool owned = !SH || shard_owns(d, node);
+      if (rejected && (owned || j + 1 == n)) {  // a nextInt(bound) rejection shifted the stream: walk it serially up to this draw (rare)
         uint64_t st = d.g->rng;
         uint32_t total = 0;
         for (uint32_t q = 0; q <= j; q++) {
@@ -946,6 +966,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
           total += (uint32_t)consumed;
         }
         if (j + 1 == n) d.g->nDraws = total;
+      }
+      if (!owned) {
+        for (int q = 0; q < 5; q++) d.xbuf[(size_t)j * 5 + q] = 0;
+        continue;
       }
       const int l = s.candLevel[(size_t)node * s.L + k];
       const int slot = s.candSlot[(size_t)node * s.L + k];
@@ -975,12 +999,23 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       h[HH_PENDFROM + pe] = (uint32_t)from;
       // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
       const int32_t arrival = t + (int32_t)h[HH_PAIR];
-      d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
+      const Rec fin = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
       const bool ok = arrival - t < d.horizon - 1;  // see Engine::run_ms on host-held envelopes
-      d.arr[j] = ok ? arrival : -1;
       if (!ok) set_err(d.g, ERR_HORIZON);
+      if (SH) {
+        int32_t* x = d.xbuf + (size_t)j * 5;
+        x[0] = (int32_t)fin.w0;
+        x[1] = (int32_t)fin.w1;
+        x[2] = (int32_t)fin.w2;
+        x[3] = (int32_t)fin.w3;
+        x[4] = ok ? arrival + 1 : 0;
+        continue;
+      }
+      d.fin[j] = fin;
+      d.arr[j] = ok ? arrival : -1;
       if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
     }
+    if (SH) continue;  // (k_shard_unpack builds the tile histograms from the summed image)
     // per-tile arrival histogram of the multisplit; pairing times are nearly uniform, so aggregate equal
     // keys inside the wavefront before touching memory
     uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);
@@ -990,6 +1025,55 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       const uint64_t m = __ballot(histKey == key) & todo;
       if ((int)WG_LANE == leader) atomicAdd(&d.tileHist[key], (uint32_t)__popcll(m));
       todo &= ~m;
+    }
+  }
+}
+
+// ---- sharded engine: the dissemination snapshots of this ms (SendSigs.sigs, :254) reach the other shards -----
+// A snapshot is read at delivery by the receiver's shard at the address the message carries, so every shard keeps
+// the whole snapshot ring and the rows written in this ms are summed across shards (zeros from non-owners). The
+// rows are those of the dissemination events of the (replicated) event list, numbered in event order by SnapF.
+__device__ __forceinline__ bool h_is_dissemination(const EngineDev& d, uint32_t e) {
+  const Rec r = d.ev[e];
+  return rec_kind(r) == K_PERIODIC && r.w2 == H_TASK_DISSEMINATION;
+}
+struct SnapF {
+  typedef HandelState Aux;
+  const EngineDev& d;
+  const HandelState& s;
+  __device__ SnapF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
+  __device__ uint32_t count() const { return d.g->nEvents; }
+  __device__ uint64_t value(uint32_t e) const { return h_is_dissemination(d, e); }
+  __device__ void tally(uint32_t, uint32_t) const {}
+  __device__ void total(uint64_t tot) const {
+    if ((uint32_t)tot > s.xsnapRows) set_err(d.g, ERR_PAYLOAD);
+    *s.nSnap = min((uint32_t)tot, s.xsnapRows);
+  }
+  __device__ void write(uint32_t e, uint64_t excl, bool valid) const {
+    if (valid) s.snapIdx[e] = (uint32_t)excl;
+  }
+};
+// one wavefront per dissemination event: pack = owner's ring row -> image (zeros elsewhere); unpack = summed
+// image -> ring row on the shards that do not own the node
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_handel_shard_snap(const EngineDev* __restrict__ tab,
+                                                           const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nEv = d.g->nEvents;
+  const uint32_t win = ((uint32_t)d.g->now / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
+  for (uint32_t e = wave; e < nEv; e += nWaves) {
+    if (!h_is_dissemination(d, e) || s.snapIdx[e] >= s.xsnapRows) continue;
+    const int32_t node = (int32_t)d.ev[e].w1;
+    const bool owned = shard_owns(d, node);
+    uint64_t* row = s.snap + (size_t)(win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    uint64_t* img = (uint64_t*)s.xsnap + (size_t)s.snapIdx[e] * s.snapStride;
+    for (uint32_t j = WG_LANE; j < s.snapStride; j += 64) {
+      if (PACK)
+        img[j] = owned ? row[j] : 0ULL;
+      else if (!owned)
+        row[j] = img[j];
     }
   }
 }

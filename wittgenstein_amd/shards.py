@@ -80,3 +80,55 @@ def gather(dist, per_shard, group=None, device="cpu"):
     t = torch.as_tensor(np.ascontiguousarray(per_shard)).to(device)
     dist.all_reduce(t, group=group)
     return t.cpu().numpy()
+
+
+def cont_if(dist, protocol, group=None):
+    """the RunMultipleTimes continuation predicate of a sharded protocol: a shard evaluates it over its own nodes
+    (Handel.newContIf, P/Handel.java:1044-1053, is an OR over live nodes)"""
+    import torch
+    t = torch.tensor([1 if protocol.cont_if() else 0], dtype=torch.int32)
+    dist.all_reduce(t, group=group)
+    return bool(t.item())
+
+
+class WholeNetwork:
+    """Whole-network read-back of a sharded Network: every per-node view is this shard's own rows plus, through a
+    SUM across shards, everybody else's. Replicated quantities (time, rd state, queue sizes) pass through."""
+
+    def __init__(self, dist, net, group=None):
+        self._dist, self._net, self._group = dist, net, group
+        self.lo, self.hi = shard_range(net)
+        self.msgs = net.msgs
+
+    def _own(self, a):
+        a = np.array(a, copy=True)
+        a[:self.lo] = 0
+        a[self.hi:] = 0
+        if a.dtype == np.uint64:  # (torch has no unsigned 64-bit all-reduce)
+            return gather(self._dist, a.view(np.int64), self._group).view(np.uint64)
+        return gather(self._dist, a, self._group)
+
+    time = property(lambda self: self._net.time)
+    node_count = property(lambda self: self._net.node_count)
+    last_stats = property(lambda self: self._net.last_stats)
+
+    def rng_state(self):
+        return self._net.rng_state()
+
+    def runMs(self, ms):
+        return self._net.runMs(ms)
+
+    def levels(self):
+        return self._net.levels()
+
+    def read(self, field):
+        return self._own(self._net.read(field))
+
+    def read_level(self, field):
+        return self._own(self._net.read_level(field))
+
+    def read_bits(self, field):
+        return self._own(self._net.read_bits(field))
+
+    def delivered_by_level(self):
+        return self._net.delivered_by_level()
