@@ -1,0 +1,317 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Pins oracle/casper.hpp against every value the reference's own Casper tests
+// hold: PT/CasperIMDTest.java:21-276 (11 tests) and PT/CasperByzantineTest.java:12-66 (2 tests), restated one for one.
+// Prints one "ok <name>" / "FAIL <name>" line per test; exit code = number of failures.
+#include <cstdio>
+#include "casper.hpp"
+
+using namespace orc;
+
+static int g_fail = 0;
+static const char* g_cur = "";
+#define CHECK(c)                                                        \
+  do {                                                                  \
+    if (!(c)) {                                                         \
+      printf("FAIL %s: %s (line %d)\n", g_cur, #c, __LINE__);           \
+      g_fail++;                                                         \
+      return;                                                           \
+    }                                                                   \
+  } while (0)
+#define CHECK_EQ(a, b)                                                                        \
+  do {                                                                                        \
+    long long _a = (long long)(a), _b = (long long)(b);                                       \
+    if (_a != _b) {                                                                           \
+      printf("FAIL %s: %s == %lld, expected %lld (line %d)\n", g_cur, #b, _b, _a, __LINE__);  \
+      g_fail++;                                                                               \
+      return;                                                                                 \
+    }                                                                                         \
+  } while (0)
+
+typedef CasperIMD::CasperBlock Blk;
+typedef std::shared_ptr<CasperIMD::Attestation> Att;
+
+// fixture of PT/CasperIMDTest.java:9-19
+struct Fx {
+  CasperIMD ci{CasperIMD::CasperParemeters(5, false, 5, 80, 1000, 1, "", "")};
+  CasperIMD::BlockProducer* bp1 = ci.make<CasperIMD::BlockProducer>();
+  CasperIMD::BlockProducer* bp2 = ci.make<CasperIMD::BlockProducer>();
+  CasperIMD::Attester* at1 = ci.make<CasperIMD::Attester>();
+  CasperIMD::Attester* at2 = ci.make<CasperIMD::Attester>();
+  Fx() { ci.network_.time = 100000; }
+  static bool hasKey(const Blk* b, int h) { return b->attestationsByHeight.count(h) != 0; }
+  static size_t sizeAt(const Blk* b, int h) { return b->attestationsByHeight.at(h).size(); }
+};
+
+static void testInit() {  // :21-41
+  Fx f;
+  f.ci.network_.time = 0;
+  f.ci.init(f.ci.make<CasperIMD::ByzBlockProducerWF>(0));
+  auto& m = f.ci.network_.msgs;
+  CHECK_EQ(5 * 80, f.ci.params.attestersCount);
+  CHECK_EQ(0, m.sizeAt(1));
+  for (int k = 1; k <= 5; k++) CHECK_EQ(1, m.sizeAt(8000 * k));
+  CHECK_EQ(0, m.sizeAt(48000));
+  for (int k = 0; k < 5; k++) CHECK_EQ(80, m.sizeAt(12000 + 8000 * k));
+  CHECK_EQ(0, m.sizeAt(52000));
+}
+
+static void testMerge() {  // :43-85
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  CHECK(b == f.bp1->head);
+  Att a1 = f.ci.newAttestation(f.at1, 1);
+  CHECK_EQ(0, a1->hs.size());
+  f.at1->onBlock(b);
+  CHECK(b == f.at1->head);
+  f.at2->onBlock(b);
+  a1 = f.ci.newAttestation(f.at1, 1);
+  CHECK_EQ(1, a1->hs.size());
+  CHECK(a1->attests(&f.ci.genesis));
+  CHECK(!a1->attests(b));
+  a1 = f.ci.newAttestation(f.at1, 2);
+  CHECK_EQ(1, a1->hs.size());
+  CHECK(a1->attests(&f.ci.genesis));
+  CHECK(!a1->attests(b));
+  f.bp1->onAttestation(a1.get());
+  CHECK(f.bp1->attestationsByHead.count(b->id));
+  CHECK_EQ(1, f.bp1->attestationsByHead[b->id].size());
+  CHECK(f.bp1->attestationsByHead[b->id].count(a1.get()));
+  b = f.bp1->buildBlock(f.bp1->head, 2);
+  CHECK(!Fx::hasKey(b, 2));
+  b = f.bp1->buildBlock(f.bp1->head, 3);
+  CHECK(Fx::hasKey(b, 2));
+  CHECK_EQ(1, Fx::sizeAt(b, 2));
+  a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  b = f.bp1->buildBlock(f.bp1->head, 3);
+  CHECK(Fx::hasKey(b, 2));
+  CHECK_EQ(2, Fx::sizeAt(b, 2));
+}
+
+static void testCompareNoAttester() {  // :87-101
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  f.bp2->onBlock(b);
+  Blk* b1 = f.bp1->buildBlock(f.bp1->head, 2);
+  Blk* b2 = f.bp2->buildBlock(f.bp2->head, 3);
+  f.bp2->onBlock(b2);
+  CHECK(b2 == f.bp2->head);
+  f.bp2->onBlock(b1);
+  CHECK(b1 != f.bp2->head);  // tie on votes: the block id separates
+}
+
+static void testCountAttestationReceived() {  // :103-118
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  f.at1->onBlock(b);
+  CHECK_EQ(0, f.bp1->countAttestations(b, &f.ci.genesis));
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  CHECK(f.bp1->attestationsByHead.count(b->id));
+  CHECK_EQ(1, f.bp1->countAttestations(b, &f.ci.genesis));
+}
+
+static void testCountAttestationInBlock() {  // :120-142
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  f.at1->onBlock(b);
+  CHECK_EQ(0, f.bp2->countAttestations(b, &f.ci.genesis));
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  CHECK(f.bp1->attestationsByHead.count(b->id));
+  b = f.bp1->buildBlock(f.bp1->head, 3);
+  CHECK(Fx::hasKey(b, 2));
+  CHECK_EQ(1, Fx::sizeAt(b, 2));
+  f.bp2->onBlock(b);
+  CHECK(b == f.bp2->head);
+  CHECK_EQ(1, f.bp2->countAttestations(b, &f.ci.genesis));
+}
+
+static void testTooFarAwayAttestation() {  // :144-164
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  f.at1->onBlock(b);
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  CHECK(f.bp1->attestationsByHead.count(b->id));
+  b = f.bp1->buildBlock(f.bp1->head, a1->height + f.ci.params.cycleLength);
+  CHECK(Fx::hasKey(b, 2));
+  b = f.bp1->buildBlock(f.bp1->head, a1->height + f.ci.params.cycleLength + 1);
+  CHECK(!Fx::hasKey(b, 2));
+}
+
+static void testOtherBranchAttestation() {  // :166-187
+  Fx f;
+  Blk* b1 = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b1);
+  f.bp2->onBlock(b1);
+  f.at1->onBlock(b1);
+  Blk* b2 = f.bp1->buildBlock(f.bp1->head, 2);
+  f.bp1->onBlock(b2);
+  f.at1->onBlock(b2);
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  CHECK(a1->hs.count(b1->id));
+  f.bp2->onAttestation(a1.get());
+  Blk* b3 = f.bp2->buildBlock(f.bp2->head, 3);
+  CHECK(b3->attestationsByHeight.at(2).empty());
+  f.bp2->onBlock(b2);
+  b3 = f.bp2->buildBlock(f.bp2->head, 3);
+  CHECK(!b3->attestationsByHeight.at(2).empty());
+}
+
+static void testCompareWithAttester() {  // :189-210
+  Fx f;
+  Blk* b1 = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b1);
+  f.bp2->onBlock(b1);
+  f.at1->onBlock(b1);
+  Blk* b2 = f.bp1->buildBlock(f.bp1->head, 2);
+  f.bp1->onBlock(b2);
+  f.at1->onBlock(b2);
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  Blk* b3 = f.bp1->buildBlock(f.bp1->head, 3);
+  CHECK_EQ(1, Fx::sizeAt(b3, 2));
+  Blk* b4 = f.bp2->buildBlock(f.bp2->head, 4);
+  f.bp2->onBlock(b4);
+  CHECK(b4 == f.bp2->head);
+  f.bp2->onBlock(b3);
+  CHECK(b3 == f.bp2->head);
+}
+
+static void testCompareWithAttesterAttestationOnAParent() {  // :212-230
+  Fx f;
+  Blk* b = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b);
+  f.bp2->onBlock(b);
+  f.at1->onBlock(b);
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  f.bp1->onAttestation(a1.get());
+  Blk* b1 = f.bp1->buildBlock(f.bp1->head, 3);
+  CHECK_EQ(1, Fx::sizeAt(b1, 2));
+  Blk* b2 = f.bp2->buildBlock(f.bp2->head, 4);
+  f.bp2->onBlock(b2);
+  CHECK(b2 == f.bp2->head);
+  f.bp2->onBlock(b1);
+  CHECK(b2 == f.bp2->head);
+}
+
+static void testRevaluation() {  // :232-255
+  Fx f;
+  Blk* b1 = f.bp1->buildBlock(f.bp1->head, 1);
+  f.bp1->onBlock(b1);
+  f.bp2->onBlock(b1);
+  Blk* b2 = f.bp1->buildBlock(f.bp1->head, 2);
+  Blk* b3 = f.bp1->buildBlock(f.bp1->head, 3);
+  f.bp2->onBlock(b2);
+  f.bp2->onBlock(b3);
+  CHECK(b3 == f.bp2->head);
+  f.at1->onBlock(b2);
+  Att a1 = f.ci.newAttestation(f.at1, 2);
+  CHECK(a1->hs.count(b1->id));
+  f.bp2->onAttestation(a1.get());
+  CHECK(f.bp2->attestationsByHead.count(b2->id));
+  CHECK_EQ(1, f.bp2->countAttestations(b2, b1));
+  f.bp2->reevaluateHead();
+  CHECK(b2 == f.bp2->head);
+}
+
+static void testCopy() {  // :257-276 — two copies agree on every node after every runMs(10) up to 20 s
+  CasperIMD p1(CasperIMD::CasperParemeters(5, false, 5, 80, 1000, 1, "", ""));
+  CasperIMD p2(p1.params);
+  p1.init();
+  p2.init();
+  while (p1.network_.time < 20000) {
+    p1.network_.runMs(10);
+    p2.network_.runMs(10);
+    for (Node* n : p1.network_.allNodes) {
+      auto* n1 = static_cast<CasperIMD::CasperNode*>(n);
+      auto* n2 = static_cast<CasperIMD::CasperNode*>(p2.network_.getNodeById(n1->nodeId));
+      CHECK(n2 != nullptr);
+      CHECK_EQ(n1->doneAt, n2->doneAt);
+      CHECK_EQ(n1->isDown(), n2->isDown());
+      CHECK_EQ(n1->head->proposalTime, n2->head->proposalTime);
+      CHECK_EQ(n1->attestationsByHead.size(), n2->attestationsByHead.size());
+      CHECK_EQ(n1->msgReceived, n2->msgReceived);
+    }
+  }
+  CHECK(p1.observer->head->height >= 1);
+}
+
+// fixture of PT/CasperByzantineTest.java:9-10
+static void testByzantineWF() {  // :12-35
+  CasperIMD ci(CasperIMD::CasperParemeters(1, false, 2, 2, 1000, 1, "", ""));
+  ci.network_.networkLatency = std::make_unique<NetworkNoLatency>();
+  auto* byz = ci.make<CasperIMD::ByzBlockProducerWF>(0);
+  ci.init(byz);
+  ci.network_.run(9);
+  CHECK(&ci.genesis == ci.observer->head);
+  ci.network_.run(1);  // 10 s: 8 for start + 1 for build time + 1 ms of network delay
+  CHECK(&ci.genesis != ci.observer->head);
+  CHECK_EQ(1, ci.observer->head->height);
+  CHECK(byz == ci.observer->head->producer);
+  ci.network_.run(8);  // 18 s
+  CHECK_EQ(2, ci.observer->head->height);
+  CHECK(byz != ci.observer->head->producer);
+  ci.network_.run(8);  // 26 s
+  CHECK_EQ(3, ci.observer->head->height);
+  CHECK(byz == ci.observer->head->producer);
+}
+
+static void testByzantineWFWithDelay() {  // :37-65
+  CasperIMD ci(CasperIMD::CasperParemeters(1, false, 2, 2, 1000, 1, "", ""));
+  ci.network_.networkLatency = std::make_unique<NetworkNoLatency>();
+  auto* byz = ci.make<CasperIMD::ByzBlockProducerWF>(-2000);
+  ci.init(byz);
+  ci.network_.run(5);
+  CHECK_EQ(0, byz->head->height);
+  ci.network_.run(1);
+  CHECK_EQ(1, byz->head->height);
+  CHECK_EQ(0, ci.observer->head->height);
+  ci.network_.run(2);
+  CHECK_EQ(1, ci.observer->head->height);
+  ci.network_.run(9);
+  CHECK_EQ(1, ci.observer->head->height);
+  ci.network_.run(1);
+  CHECK_EQ(2, byz->head->height);
+  CHECK(byz->head->producer != nullptr);
+  CHECK(byz != byz->head->producer);
+  ci.network_.run(3);
+  CHECK_EQ(2, byz->head->height);
+  ci.network_.run(1);  // 22 s: 24 - 2 seconds of delay
+  CHECK_EQ(3, byz->head->height);
+}
+
+#define RUN(t)        \
+  do {                \
+    g_cur = #t;       \
+    int b = g_fail;   \
+    try {             \
+      t();            \
+    } catch (const std::exception& x) { \
+      printf("FAIL %s: exception %s\n", #t, x.what()); \
+      g_fail++;       \
+    }                 \
+    if (g_fail == b) printf("ok %s\n", #t); \
+  } while (0)
+
+int main() {
+  RUN(testInit);
+  RUN(testMerge);
+  RUN(testCompareNoAttester);
+  RUN(testCountAttestationReceived);
+  RUN(testCountAttestationInBlock);
+  RUN(testTooFarAwayAttestation);
+  RUN(testOtherBranchAttestation);
+  RUN(testCompareWithAttester);
+  RUN(testCompareWithAttesterAttestationOnAParent);
+  RUN(testRevaluation);
+  RUN(testCopy);
+  RUN(testByzantineWF);
+  RUN(testByzantineWFWithDelay);
+  return g_fail;
+}

@@ -1,5 +1,6 @@
 """Runs oracle/test_network: the reference's engine + protocol unit tests restated against the oracle
-(CT/NetworkTest, CT/EnvelopeStorageTest, CT/NetworkLatencyTest, PT/PingPongTest, PT/HandelTest)."""
+(CT/NetworkTest, CT/EnvelopeStorageTest, CT/NetworkLatencyTest, PT/PingPongTest, PT/HandelTest), and
+oracle/test_casper: PT/CasperIMDTest (11 tests) and PT/CasperByzantineTest (2 tests) restated one for one."""
 import os
 import subprocess
 
@@ -13,3 +14,12 @@ def test_restated_reference_unit_tests(oracle):
     failed = [l for l in lines if l.startswith("FAIL")]
     assert r.returncode == 0 and not failed, r.stdout
     assert sum(l.startswith("ok ") for l in lines) >= 29
+
+
+def test_restated_casper_unit_tests(oracle):
+    exe = os.path.join(o.ORACLE_DIR, "test_casper")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    lines = r.stdout.strip().splitlines()
+    failed = [l for l in lines if l.startswith("FAIL")]
+    assert r.returncode == 0 and not failed, r.stdout
+    assert sum(l.startswith("ok ") for l in lines) == 13

@@ -1,0 +1,93 @@
+"""Node-range sharding on the MI355X (include/wittgpu.h "node-range sharding"): the sharded pipeline — owner-only
+delivery and send resolution, the exchange images, the replicated creation of multi-destination envelopes, Handel's
+snapshot exchange and global draw order — run through RCCL (torch.distributed backend "nccl") on DEVICE memory.
+The GPU box has one GPU, so the process group has one rank: every collective is the identity, every kernel of the
+sharded path runs, and the result must be the oracle's bit for bit. Shard-count invariance proper (2, 3, 4 shards)
+is covered over gloo by tests/test_shards_gloo.py.
+
+The rank runs in its own process, as it does in production (one process per GPU): torch brings its own HIP runtime,
+which has to be the first one initialised in a process — bench.py and this worker import torch before the engine
+library, the rest of the GPU suite never loads torch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json, ctypes as C
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+import wittgenstein_amd as w
+from wittgenstein_amd import shards
+import oracle_lib as o, parity
+o.build()
+out = {}
+# 1. the all-reduce thunk on device words (one rank: the sum is the value itself)
+fn = shards.make_allreduce(dist, device_memory=True)
+t = torch.arange(1000, dtype=torch.int32, device="cuda")
+out["thunk_rc"] = fn(None, C.c_void_p(t.data_ptr()), 1000)
+out["thunk_ok"] = bool((t.cpu().numpy() == np.arange(1000)).all())
+# 2. PingPong 1000 nodes (BASELINE config 1), runMs(50) x 10 in lock-step with the oracle
+p = w.PingPong(w.PingPongParameters(1000), seed=0, config=shards.config(dist)); p.init()
+c = o.PingPong(1000, seed=0)
+bad = []
+for _ in range(10):
+    p.network().runMs(50); c.run_ms(50)
+    bad += parity.diff_pingpong(p, c)
+out["pingpong_bad"] = bad[:5]
+out["pingpong_range"] = list(shards.shard_range(p.network()))
+out["pong0"] = int(p.network().read("pong")[0])
+out["pingpong_traffic"] = list(shards.traffic(p.network()))
+# 3. Handel in lock-step with the oracle to convergence
+out["handel"] = []
+for params in [(64, 57, 4, 50, 10, 20, 10, 6, 0), (256, 230, 4, 50, 10, 20, 10, 25, 100)]:
+    g, c = parity.handel_pair(params, seed=2, config=shards.config(dist, queue_cap=64))
+    bad, k = [], 0
+    while c.cont_if() and k < 400 and not bad:
+        g.network().runMs(10); c.run_ms(10); k += 1
+        if k %% 5 == 0: bad += parity.diff_handel(g, c)
+    bad += parity.diff_handel(g, c)
+    dl = c.stats()["deliveredByLevel"]
+    out["handel"].append({"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
+                          "by_level": bool((g.network().delivered_by_level()[:len(dl)].astype(np.uint64) == dl).all()),
+                          "traffic": list(shards.traffic(g.network()))})
+print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+@pytest.fixture(scope="module")
+def result(tmp_path_factory):
+    script = tmp_path_factory.mktemp("shards") / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_allreduce_thunk_sums_device_words(result):
+    assert result["thunk_rc"] == 0 and result["thunk_ok"]
+
+
+def test_sharded_pingpong_one_rank(result):
+    assert result["pingpong_bad"] == []
+    assert result["pingpong_range"] == [0, 1000] and result["pong0"] == 1000
+    calls, words = result["pingpong_traffic"]
+    assert calls > 0 and words >= 2 * 2000 + 5 * 1000     # (records, draws) per event + one record image per Pong
+
+
+def test_sharded_handel_one_rank(result):
+    assert len(result["handel"]) == 2
+    for r in result["handel"]:
+        assert r["bad"] == [] and r["done"] and r["by_level"], r
+        assert r["traffic"][0] > 0
