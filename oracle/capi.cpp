@@ -4,6 +4,7 @@
 // (-1 IllegalArgumentException, -2 IllegalStateException, -3 other); orc_last_error() has the text.
 #include <cstring>
 #include <chrono>
+#include "casper.hpp"
 #include "gsf.hpp"
 #include "handel.hpp"
 #include "pingpong.hpp"
@@ -433,6 +434,68 @@ int orc_gsf_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState,
 uint64_t orc_gsf_shape_violations(void* h) { return ((OrcGsf*)h)->p->statShapeViolations; }
 int orc_gsf_stats(void* h, uint64_t* deliveredByLevel32) {
   memcpy(deliveredByLevel32, ((OrcGsf*)h)->p->statDeliveredByLevel, sizeof(uint64_t) * 32);
+  return 0;
+}
+
+
+// ---- Casper IMD (P/CasperIMD.java)
+struct OrcCasper {
+  std::unique_ptr<CasperIMD> p;
+};
+// ip: cycleLength, randomOnTies, blockProducersCount, attestersPerRound, blockConstructionTime,
+//     attestationConstructionTime, delay of the ByzBlockProducerWF that init(badNode) starts with (:475-479 uses 0).
+// As RunMultipleTimes does (C/RunMultipleTimes.java:44-48): new CasperIMD(params) — which already builds the observer
+// node from rd (:80-87) — then rd.setSeed(seed), then init().
+int orc_casper_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY CasperIMD::CasperParemeters pr(ip[0], ip[1] != 0, ip[2], ip[3], ip[4], ip[5], nb ? nb : "", nl ? nl : "");
+  auto* h = new OrcCasper();
+  h->p = std::make_unique<CasperIMD>(pr);
+  h->p->network().rd.setSeed(seed);
+  h->p->init(h->p->make<CasperIMD::ByzBlockProducerWF>(ip[6]));
+  *out = h;
+  ORC_CATCH
+}
+void orc_casper_destroy(void* h) { delete (OrcCasper*)h; }
+int orc_casper_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcCasper*)h)->p->network().runMs(ms);
+  ORC_CATCH
+}
+int orc_casper_node_count(void* h) { return (int)((OrcCasper*)h)->p->network().allNodes.size(); }
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 head.height, 5 head.proposalTime, 6 head.id,
+//         7 attestationsByHead.size(), 8 x, 9 y, 10 blocksReceivedByBlockId.size(), 11 attestations held (all heads)
+int orc_casper_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& net = ((OrcCasper*)h)->p->network();
+  for (size_t i = 0; i < net.allNodes.size(); i++) {
+    auto& n = *static_cast<CasperIMD::CasperNode*>(net.allNodes[i]);
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.head->height; break;
+      case 5: v = n.head->proposalTime; break;
+      case 6: v = n.head->id; break;
+      case 7: v = (int64_t)n.attestationsByHead.size(); break;
+      case 8: v = n.x; break;
+      case 9: v = n.y; break;
+      case 10: v = (int64_t)n.blocksReceivedByBlockId.size(); break;
+      case 11:
+        for (auto& kv : n.attestationsByHead) v += (int64_t)kv.second.size();
+        break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_casper_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered, uint64_t* tasks) {
+  auto& p = *((OrcCasper*)h)->p;
+  *time = p.network().time;
+  if (queueSize) *queueSize = p.network().msgs.size();
+  *rngState = p.network().rd.rawState();
+  *delivered = p.network().statDelivered;
+  *tasks = p.network().statTasks;
   return 0;
 }
 

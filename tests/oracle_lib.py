@@ -278,3 +278,39 @@ class GSFSignature:
         lib().orc_gsf_stats(self.h, _p(dl, C.c_uint64))
         return {"deliveredByLevel": dl[:self.levels].copy(),
                 "shapeViolations": int(lib().orc_gsf_shape_violations(self.h))}
+
+
+class CasperIMD:
+    """oracle/casper.hpp through oracle/capi.cpp; params = (cycleLength, randomOnTies, blockProducersCount,
+    attestersPerRound, blockConstructionTime, attestationConstructionTime) — CasperParemeters' ctor order
+    (P/CasperIMD.java:52-70)."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "headHeight": 4,
+              "headProposalTime": 5, "headId": 6, "attestationsByHeadSize": 7, "x": 8, "y": 9, "blocksReceived": 10,
+              "attestationsHeld": 11}
+
+    def __init__(self, params, nb=None, nl=None, seed=0, byz_delay=0):
+        self.h = C.c_void_p()
+        ip = (C.c_int32 * 7)(params[0], int(params[1]), params[2], params[3], params[4], params[5], byz_delay)
+        _ck(lib().orc_casper_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                    C.byref(self.h)))
+        self.n = lib().orc_casper_node_count(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_casper_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_casper_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_casper_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d, k = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().orc_casper_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d), C.byref(k))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value}

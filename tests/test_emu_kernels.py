@@ -34,6 +34,7 @@ import test_gpu_batch as tb  # noqa: E402
 import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
+import test_gpu_casper as tc  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
@@ -125,3 +126,8 @@ def test_host_callback_mode_reference_vectors(name):  # CT/NetworkTest.java thro
 
 def test_host_callback_mode_pingpong():
     thm.test_pingpong_through_host_callbacks_matches_oracle(120)
+
+
+def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp
+    tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=10)
+    tc.test_byzantine_wf_timeline()
