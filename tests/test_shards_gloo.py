@@ -146,3 +146,60 @@ def test_sharded_handel_matches_the_oracle(oracle, tmp_path, world, params):
         assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]
     live = params[0] - params[7]
     assert res[0]["doneAt"] == live          # every live node reached the threshold (PT/HandelTest.java:36-49)
+
+
+GSF_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+import wittgenstein_amd as w
+from wittgenstein_amd import shards
+import oracle_lib as o
+import test_gpu_gsf as tg
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+g, c = tg.pair(%(params)r, nb=%(nb)r, seed=%(seed)d, config=shards.config(dist, device_memory=False))
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad, steps, delivered = [], 0, 0
+while True:
+    g.network().runMs(%(chunk)d); c.run_ms(%(chunk)d); steps += 1
+    delivered += g.network().last_stats["delivered"]
+    if steps %% %(check_every)d == 0:
+        bad += [(steps, m) for m in tg.diff(G(), c)]
+    go, want = shards.cont_if(dist, g), c.cont_if()
+    if go != want: bad.append((steps, "cont_if %%s != %%s" %% (go, want)))
+    if bad or not want or steps >= %(max_steps)d: break
+bad += [(steps, m) for m in tg.diff(G(), c)]
+calls, words = shards.traffic(g.network())
+res = [None] * world
+dist.all_gather_object(res, {"rank": rank, "bad": [str(b) for b in bad[:6]], "steps": steps, "calls": calls, "words": words,
+                             "delivered": delivered, "expect": c.info(False)["delivered"], "done": not c.cont_if()})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+# GSFSignatureParameters ctor order: (nodeCount, threshold, pairingTime, timeoutPerLevelMs, periodDurationMs,
+# acceleratedCallsCount, nodesDown)
+@pytest.mark.parametrize("world,params,nb", [
+    (2, (64, 63, 3, 50, 10, 10, 0), "RANDOM_SPEED=CONSTANT_TOR=0.00"),
+    (4, (128, 100, 3, 20, 10, 10, 12), "RANDOM_SPEED=GAUSSIAN_TOR=0.00"),   # dead nodes, speed ratios, 4 shards
+])
+def test_sharded_gsf_matches_the_oracle(oracle, tmp_path, world, params, nb):
+    global WORKER
+    keep, WORKER = WORKER, GSF_WORKER
+    try:
+        res = _run(tmp_path, world, 29571 + world, params=params, nb=nb, seed=4, chunk=5, check_every=4, max_steps=600)
+    finally:
+        WORKER = keep
+    assert len(res) == world
+    for r in res:
+        assert r["bad"] == [], r
+        assert r["done"] and r["delivered"] == r["expect"] > 0
+        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]

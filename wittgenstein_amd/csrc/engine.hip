@@ -932,7 +932,7 @@ void Engine::exchange_outbox(uint32_t nOut) {
 
 void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   if (!proto->supports_shards())
-    throw WgError(WG_EUNSUPPORTED, "this resident protocol does not run on a sharded engine yet (PingPong and Handel do)");
+    throw WgError(WG_EUNSUPPORTED, "this resident protocol does not run on a sharded engine yet (PingPong, Handel and GSFSignature do)");
   const Globals before = gh;
   int32_t endAt = 0;
   begin_run(ms, &endAt);
@@ -1343,7 +1343,8 @@ void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
 namespace wg {
 
 template void Engine::scan<CondF>(const Group&, const HandelState*);
-template void Engine::scan<SnapF>(const Group&, const HandelState*);
+typedef SnapF<HandelState, H_TASK_DISSEMINATION> HandelSnapF;
+template void Engine::scan<HandelSnapF>(const Group&, const HandelState*);
 
 __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t* startAt, const int32_t* pairing) {
   int node = s.lo + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1533,14 +1534,14 @@ struct HandelHost : ProtoHost {
   // the dissemination snapshots written in this ms -> every shard's copy of the snapshot ring
   void shard_post_deliver(Engine& e, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    Engine::scan<SnapF>(g, stab);
+    Engine::scan<HandelSnapF>(g, stab);
     uint32_t nSnap = 0;
     WG_HIP(hipStreamSynchronize(g.stream));
     WG_HIP(hipMemcpy(&nSnap, st.nSnap, 4, hipMemcpyDeviceToHost));
     if (!nSnap) return;
-    hipLaunchKernelGGL(k_handel_shard_snap<true>, dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
     e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
-    hipLaunchKernelGGL(k_handel_shard_snap<false>, dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
   }
   // checkSigs' edge (launch_cond above) with the draw order made global: the per-node candidate counts are summed
   // across shards (a shard knows its own nodes'), after which the ordinal of every drawing node, its rd draw and the
@@ -1641,10 +1642,12 @@ ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_hande
 namespace wg {
 
 template void Engine::scan<GsfCondF>(const Group&, const GsfState*);
+typedef SnapF<GsfState, G_TASK_DOCYCLE> GsfSnapF;
+template void Engine::scan<GsfSnapF>(const Group&, const GsfState*);
 
 __global__ void k_gsf_init(GsfState s, const uint8_t* down) {
-  int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= s.N) return;
+  int node = s.lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.hi) return;
   // GSFNode(): verifiedSignatures.set(nodeId) (:179) — for every node, also the ones stopped later;
   // SFLevel() for level 0 (:263-270) and remainingCalls = peers.size() for the others (:282)
   s.V[(size_t)node * s.W + (node >> 6)] |= 1ULL << (node & 63);
@@ -1662,7 +1665,7 @@ __global__ void k_gsf_cont_if(const EngineDev* __restrict__ tab, const GsfState*
   const GsfState& s = stab[blockIdx.y];
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   bool c = false;
-  if (node < s.N && !d.nodes.down[node]) {
+  if (node >= s.lo && node < s.hi && !d.nodes.down[node]) {  // (sharded: the predicate over this shard's nodes)
     int tot = 0;
     for (int l = 0; l < s.L; l++) tot += s.cV[(size_t)node * s.L + l];
     c = tot < s.p.threshold;
@@ -1699,11 +1702,18 @@ struct GsfHost : ProtoHost {
     st.W = W;
     st.Q = Q;
     st.SW = N >= 128 ? N / 128 : 1;
-    const size_t rows = (size_t)N * W;
-    st.V = e.dalloc<uint64_t>(rows);
-    st.IS = e.dalloc<uint64_t>(rows);
-    st.IV = e.dalloc<uint64_t>(rows);
-    st.peers = e.dalloc<int32_t>((size_t)N * (N - 1), false);
+    // the big per-node arrays are held for the owned node range only, behind biased pointers (see HandelHost)
+    const int32_t lo = st.lo = e.shardCount > 0 ? e.dev.shardLo : 0;
+    const int32_t hi = st.hi = e.shardCount > 0 ? e.dev.shardHi : N;
+    const size_t nLoc = (size_t)(hi - lo);
+    auto rows = [&](auto* tag, size_t stride, bool zero) {
+      typedef std::remove_pointer_t<decltype(tag)> T;
+      return e.dalloc<T>(nLoc * stride, zero) - (size_t)lo * stride;
+    };
+    st.V = rows((uint64_t*)nullptr, W, true);
+    st.IS = rows((uint64_t*)nullptr, W, true);
+    st.IV = rows((uint64_t*)nullptr, W, true);
+    st.peers = rows((int32_t*)nullptr, N - 1, false);
     st.pairing = e.dalloc<int32_t>(N);
     st.sigChecked = e.dalloc<int32_t>(N);
     st.sigQueueSize = e.dalloc<int32_t>(N);
@@ -1716,9 +1726,9 @@ struct GsfHost : ProtoHost {
     st.cV = e.dalloc<int32_t>(NL);
     st.cIV = e.dalloc<int32_t>(NL);
     st.cU = e.dalloc<int32_t>(NL);
-    st.tvEnt = e.dalloc<uint64_t>((size_t)N * Q, false);
-    st.tvUsed = e.dalloc<uint64_t>((size_t)N * (Q / 64));
-    st.tvSig = e.dalloc<uint64_t>((size_t)N * Q * st.SW, false);
+    st.tvEnt = rows((uint64_t*)nullptr, Q, false);
+    st.tvUsed = rows((uint64_t*)nullptr, Q / 64, true);
+    st.tvSig = rows((uint64_t*)nullptr, (size_t)Q * st.SW, false);
     {
       uint32_t off = 0;
       for (int l = 0; l < L; l++) {
@@ -1739,12 +1749,23 @@ struct GsfHost : ProtoHost {
     st.pendFrom = e.dalloc<int32_t>((size_t)N * G_PEND);
     st.runList = e.dalloc<uint32_t>(N);
     st.runCount = e.dalloc<uint32_t>(1);
-    st.candFlag = e.dalloc<uint8_t>(N);
+    st.candFlag = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
     st.candPend = e.dalloc<uint8_t>(N);
     st.condList = e.dalloc<uint32_t>(N);
     WG_HIP(hipMemcpy(st.pairing, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * (N - 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_gsf_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down);
+    WG_HIP(hipMemcpy(st.peers + (size_t)lo * (N - 1), init.peers + (size_t)lo * (N - 1), 4 * nLoc * (N - 1),
+                     hipMemcpyHostToDevice));
+    st.snapIdx = nullptr;
+    st.nSnap = nullptr;
+    st.xsnap = nullptr;
+    st.xsnapRows = 0;
+    if (e.shardCount > 0) {
+      st.snapIdx = e.dalloc<uint32_t>(e.dev.maxEvents, false);
+      st.nSnap = e.dalloc<uint32_t>(1);
+      st.xsnapRows = (uint32_t)N;
+      st.xsnap = e.dalloc<int32_t>((size_t)st.xsnapRows * st.snapStride * 2, false);
+    }
+    hipLaunchKernelGGL(k_gsf_init, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down);
     WG_HIP(hipStreamSynchronize(e.stream));
   }
   bool has_cond() const override { return true; }
@@ -1778,7 +1799,36 @@ struct GsfHost : ProtoHost {
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
-    hipLaunchKernelGGL(k_gsf_cond_a2, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
+  bool supports_shards() const override { return true; }
+  bool emits_multi() const override { return st.p.acceleratedCallsCount > 1; }
+  void shard_post_deliver(Engine& e, const Group& g) override {  // the doCycle snapshots (PARTIAL payloads) of this ms
+    const GsfState* stab = (const GsfState*)g.stab;
+    Engine::scan<GsfSnapF>(g, stab);
+    uint32_t nSnap = 0;
+    WG_HIP(hipStreamSynchronize(g.stream));
+    WG_HIP(hipMemcpy(&nSnap, st.nSnap, 4, hipMemcpyDeviceToHost));
+    if (!nSnap) return;
+    hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
+    hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  // checkSigs' edge: which nodes register a task is summed across shards, so that the registrations keep their
+  // node-id (= push) order; checkSigs draws nothing from rd
+  uint32_t shard_cond(Engine& e, const Group& g) override {
+    const GsfState* stab = (const GsfState*)g.stab;
+    hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
+    Engine::scan<GsfCondF>(g, stab);
+    uint32_t nOut = 0;
+    WG_HIP(hipStreamSynchronize(g.stream));
+    WG_HIP(hipMemcpy(&nOut, (const char*)e.dev.g + offsetof(Globals, nOut), 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_gsf_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    WG_HIP(hipMemsetAsync(st.candFlag, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' flags
+    return nOut;
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
@@ -1829,7 +1879,8 @@ struct GsfHost : ProtoHost {
       case WG_B_GSF_INDIV_VERIFIED: src = st.IV; break;
       default: return false;
     }
-    WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
+    memset(dst, 0, 8 * (size_t)n * w);  // (sharded: zeros for the nodes of other shards)
+    WG_HIP(hipMemcpy(dst + (size_t)st.lo * w, src + (size_t)st.lo * w, 8 * (size_t)(st.hi - st.lo) * w, hipMemcpyDeviceToHost));
     return true;
   }
 };

@@ -57,7 +57,15 @@ struct GsfState {
   uint8_t* candFlag;                  // [N] checkSigs found a best -> registers a task
   uint8_t* candPend;                  // [N] its pend index
   uint32_t* condList;                 // registering nodes in id order
+  // node-range sharding (wg_shard_configure): the rows V / IS / IV, peers and the toVerify storage are held for
+  // the nodes [lo, hi) only (pointers biased by -lo rows); 0 / N when not sharded. Snapshot exchange as Handel's.
+  int32_t lo, hi;
+  uint32_t* snapIdx;
+  uint32_t* nSnap;
+  int32_t* xsnap;
+  uint32_t xsnapRows;
 };
+__device__ __forceinline__ int32_t snap_period(const GsfState& s) { return s.p.periodDurationMs; }
 
 __device__ __forceinline__ uint64_t g_ent(int32_t from, int l, uint32_t kind, uint32_t aux) {
   return (uint64_t)(uint32_t)from | ((uint64_t)l << 24) | ((uint64_t)kind << 29) | ((uint64_t)aux << 32);
@@ -385,10 +393,10 @@ __global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restric
   const int32_t t = d.g->now, until = d.g->until;
   const uint32_t epoch = d.g->epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t n0 = blockIdx.x * blockDim.x; n0 < (uint32_t)s.N; n0 += stride) {
+  for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     bool run = false;
-    if (node < (uint32_t)s.N) {
+    if (node < (uint32_t)s.hi) {
       if (!d.nodes.down[node] && s.ctEpoch[node] != epoch) {
         const int32_t ms = s.ctMinStart[node];
         if (ms <= until && ms <= t) {
@@ -578,6 +586,8 @@ struct GsfCondF {
   }
 };
 
+// SH (sharded engine): a registering node is handled by its owner, the task record goes to the exchange image.
+template <bool SH>
 __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
   WG_ENGINE(tab);
   const GsfState& s = stab[blockIdx.y];
@@ -591,13 +601,28 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict
     uint32_t histKey = 0xFFFFFFFFu;
     if (j < n) {
       const int32_t node = (int32_t)s.condList[j];
+      if (SH && !shard_owns(d, node)) {
+        for (int q = 0; q < 5; q++) d.xbuf[(size_t)j * 5 + q] = 0;
+        continue;
+      }
       const int32_t arrival = t + s.pairing[node];
-      d.fin[j] = make_rec(K_TASK, node, (uint32_t)node, G_TASK_UPDATE, (uint32_t)s.candPend[node]);
+      const Rec fin = make_rec(K_TASK, node, (uint32_t)node, G_TASK_UPDATE, (uint32_t)s.candPend[node]);
       const bool ok = arrival - t < d.horizon - 1;
-      d.arr[j] = ok ? arrival : -1;
       if (!ok) set_err(d.g, ERR_HORIZON);
+      if (SH) {
+        int32_t* x = d.xbuf + (size_t)j * 5;
+        x[0] = (int32_t)fin.w0;
+        x[1] = (int32_t)fin.w1;
+        x[2] = (int32_t)fin.w2;
+        x[3] = (int32_t)fin.w3;
+        x[4] = ok ? arrival + 1 : 0;
+        continue;
+      }
+      d.fin[j] = fin;
+      d.arr[j] = ok ? arrival : -1;
       if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
     }
+    if (SH) continue;  // (k_shard_unpack builds the tile histograms from the summed image)
     uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);
     while (todo) {
       const int leader = __ffsll((unsigned long long)todo) - 1;

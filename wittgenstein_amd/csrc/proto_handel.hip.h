@@ -1029,21 +1029,26 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
   }
 }
 
-// ---- sharded engine: the dissemination snapshots of this ms (SendSigs.sigs, :254) reach the other shards -----
+// ---- sharded engine: the periodic-task snapshots of this ms (Handel SendSigs.sigs, P/Handel.java:254; GSFSignature
+// toSend.clone(), P/GSFSignature.java:146) reach the other shards -------------------------------------------------
 // A snapshot is read at delivery by the receiver's shard at the address the message carries, so every shard keeps
 // the whole snapshot ring and the rows written in this ms are summed across shards (zeros from non-owners). The
-// rows are those of the dissemination events of the (replicated) event list, numbered in event order by SnapF.
-__device__ __forceinline__ bool h_is_dissemination(const EngineDev& d, uint32_t e) {
+// rows are those of the periodic-task events (task word TASK) of the (replicated) event list, numbered in event
+// order by SnapF. S = HandelState / GsfState: snap, snapNb, snapStride, N, snapIdx, nSnap, xsnap, xsnapRows.
+__device__ __forceinline__ int32_t snap_period(const HandelState& s) { return s.p.disseminationPeriodMs; }
+template <uint32_t TASK>
+__device__ __forceinline__ bool is_snapshot_event(const EngineDev& d, uint32_t e) {
   const Rec r = d.ev[e];
-  return rec_kind(r) == K_PERIODIC && r.w2 == H_TASK_DISSEMINATION;
+  return rec_kind(r) == K_PERIODIC && r.w2 == TASK;
 }
+template <class S, uint32_t TASK>
 struct SnapF {
-  typedef HandelState Aux;
+  typedef S Aux;
   const EngineDev& d;
-  const HandelState& s;
+  const S& s;
   __device__ SnapF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
   __device__ uint32_t count() const { return d.g->nEvents; }
-  __device__ uint64_t value(uint32_t e) const { return h_is_dissemination(d, e); }
+  __device__ uint64_t value(uint32_t e) const { return is_snapshot_event<TASK>(d, e); }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
     if ((uint32_t)tot > s.xsnapRows) set_err(d.g, ERR_PAYLOAD);
@@ -1053,18 +1058,17 @@ struct SnapF {
     if (valid) s.snapIdx[e] = (uint32_t)excl;
   }
 };
-// one wavefront per dissemination event: pack = owner's ring row -> image (zeros elsewhere); unpack = summed
+// one wavefront per snapshot event: pack = owner's ring row -> image (zeros elsewhere); unpack = summed
 // image -> ring row on the shards that do not own the node
-template <bool PACK>
-__global__ void __launch_bounds__(256) k_handel_shard_snap(const EngineDev* __restrict__ tab,
-                                                           const HandelState* __restrict__ stab) {
+template <class S, uint32_t TASK, bool PACK>
+__global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict__ tab, const S* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const S& s = stab[blockIdx.y];
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nEv = d.g->nEvents;
-  const uint32_t win = ((uint32_t)d.g->now / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
+  const uint32_t win = ((uint32_t)d.g->now / (uint32_t)snap_period(s)) % s.snapNb;
   for (uint32_t e = wave; e < nEv; e += nWaves) {
-    if (!h_is_dissemination(d, e) || s.snapIdx[e] >= s.xsnapRows) continue;
+    if (!is_snapshot_event<TASK>(d, e) || s.snapIdx[e] >= s.xsnapRows) continue;
     const int32_t node = (int32_t)d.ev[e].w1;
     const bool owned = shard_owns(d, node);
     uint64_t* row = s.snap + (size_t)(win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
