@@ -1,6 +1,6 @@
 """Node-range sharding on the MI355X (include/wittgpu.h "node-range sharding"): the sharded pipeline — owner-only
-delivery and send resolution, the exchange images, the replicated creation of multi-destination envelopes, Handel's
-snapshot exchange and global draw order — run through RCCL (torch.distributed backend "nccl") on DEVICE memory.
+delivery and send resolution, the exchange images, the replicated creation of multi-destination envelopes, the
+snapshot exchanges and global draw / registration orders of Handel and GSFSignature — run through RCCL (torch.distributed backend "nccl") on DEVICE memory.
 The GPU box has one GPU, so the process group has one rank: every collective is the identity, every kernel of the
 sharded path runs, and the result must be the oracle's bit for bit. Shard-count invariance proper (2, 3, 4 shards)
 is covered over gloo by tests/test_shards_gloo.py.
@@ -60,6 +60,19 @@ for params in [(64, 57, 4, 50, 10, 20, 10, 6, 0), (256, 230, 4, 50, 10, 20, 10, 
     out["handel"].append({"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
                           "by_level": bool((g.network().delivered_by_level()[:len(dl)].astype(np.uint64) == dl).all()),
                           "traffic": list(shards.traffic(g.network()))})
+# 4. GSFSignature in lock-step with the oracle to convergence
+import test_gpu_gsf as tg
+g, c = tg.pair((256, 250, 3, 50, 10, 10, 5), seed=3, config=shards.config(dist))
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad, k = [], 0
+while c.cont_if() and k < 600 and not bad:
+    g.network().runMs(5); c.run_ms(5); k += 1
+    if k %% 4 == 0: bad += tg.diff(G(), c)
+bad += tg.diff(G(), c)
+out["gsf"] = {"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
+              "traffic": list(shards.traffic(g.network()))}
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 '''
@@ -91,3 +104,8 @@ def test_sharded_handel_one_rank(result):
     for r in result["handel"]:
         assert r["bad"] == [] and r["done"] and r["by_level"], r
         assert r["traffic"][0] > 0
+
+
+def test_sharded_gsf_one_rank(result):
+    r = result["gsf"]
+    assert r["bad"] == [] and r["done"] and r["traffic"][0] > 0, r
