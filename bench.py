@@ -16,6 +16,10 @@ of Node.msgReceived increments (C/Network.java:607-613), simulated ms = sum over
 Multi-GPU (--gpus N, launched by torch.distributed.run): the copies shard across ranks with no data-path
 collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak".
 
+--mode shard (not the default): a step is ONE simulation whose nodes are split by id range over
+the N ranks (wg_shard_configure; RCCL all-reduces per simulated ms through wittgenstein_amd/shards.py),
+"scaling": "strong". With --gpus 1 it measures what the sharded pipeline costs on one GPU.
+
 One JSON line on stdout (rank 0). Everything else goes to stderr.
 """
 import argparse
@@ -117,6 +121,83 @@ def cpu_baseline(n_sample, workload="handel"):
             "simulated_ms_per_s": info["time"] / dt}
 
 
+def main_shard(args):
+    """one simulation per step, sharded by node range over the ranks (strong scaling)"""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    import wittgenstein_amd as w
+    from wittgenstein_amd import shards
+    K, W, n = args.steps, args.warmup, args.nodes
+    hp = handel_params(n)
+    delivered = sim_ms = 0
+    elapsed = 0.0
+    dk_spans = dk_ns = 0
+    by_level = None
+    traffic = (0, 0)
+    for step in range(W + K):  # every rank builds the SAME simulation (seed = step) and owns a node range of it
+        cfg = shards.config(dist, device=local)
+        g = w.Handel(w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"],
+                                        hp["extraCycle"], hp["disseminationPeriodMs"], hp["fastPath"],
+                                        hp["nodesDown"], NB, NL, 0), seed=step, config=cfg)
+        g.init()
+        g.network().profile(2)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d, ms = shards.run_multiple_times(dist, g, chunk=10, maxTime=20000)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if step >= W:
+            delivered += d
+            sim_ms += ms
+            elapsed += dt
+            pr = g.network().profile_read()["deliver"]
+            dk_spans += pr["spans"]
+            dk_ns += pr["total_ns"]
+            bl = g.network().delivered_by_level()   # replicated: the whole network's histogram
+            by_level = bl if by_level is None else by_level + bl
+            traffic = shards.traffic(g.network())
+        del g
+        gc.collect()
+    tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    if rank == 0:
+        alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
+        avg_ns = dk_ns / max(1, dk_spans)
+        out = {
+            "metric": "delivered messages/sec (Handel 32k nodes; simulated-ms/sec alongside)",
+            "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": sim_ms / elapsed,
+            "config": {"workload": "Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, "
+                                   "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; ONE simulation "
+                                   "per step, nodes split by id range over %d rank(s), runMs(10) until Handel.newContIf is "
+                                   "false" % (n, world),
+                       "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure)",
+                       "allreduce_calls_per_simulation": traffic[0], "allreduce_int32_words_per_simulation": traffic[1]},
+            "roofline": {"bound": "hbm", "kernel": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> on rank 0's node range",
+                         "achieved": (alg_bytes / world / max(1, dk_spans)) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (alg_bytes / world / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
+                         "whole_run_achieved_GBs": alg_bytes / (elapsed * 1e9)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes, "handel")
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +211,12 @@ def main():
     ap.add_argument("--workload", choices=["handel", "gsf"], default="handel",
                     help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
                          "(use --nodes 4096)")
+    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
+                    help="replicas = independent copies per GPU (default, weak scaling); shard = one simulation per "
+                         "step, its nodes split by id range over the ranks (strong scaling)")
     args = ap.parse_args()
+    if args.mode == "shard":
+        return main_shard(args)
 
     import torch
     import torch.distributed as dist

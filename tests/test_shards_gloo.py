@@ -203,3 +203,38 @@ def test_sharded_gsf_matches_the_oracle(oracle, tmp_path, world, params, nb):
         assert r["bad"] == [], r
         assert r["done"] and r["delivered"] == r["expect"] > 0
         assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]
+
+
+RMT_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+from wittgenstein_amd import shards
+import parity
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+g, c = parity.handel_pair(%(params)r, seed=%(seed)d, config=shards.config(dist, device_memory=False, queue_cap=64))
+d, ms = shards.run_multiple_times(dist, g, chunk=10, maxTime=20000)      # what bench.py --mode shard times
+cms = 0
+while True:                                                              # C/RunMultipleTimes.java:50-64 on the oracle
+    did = c.run_ms(10); cms += 10
+    if not (c.info(False)["time"] < 20000 and (not did or c.cont_if())): break
+res = [None] * world
+dist.all_gather_object(res, {"delivered": d, "ms": ms, "expect": c.info(False)["delivered"], "expect_ms": cms})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_run_multiple_times_loop(oracle, tmp_path):
+    global WORKER
+    keep, WORKER = WORKER, RMT_WORKER
+    try:
+        res = _run(tmp_path, 2, 29591, params=(64, 57, 4, 50, 10, 20, 10, 6, 0), seed=7)
+    finally:
+        WORKER = keep
+    for r in res:
+        assert (r["delivered"], r["ms"]) == (r["expect"], r["expect_ms"]) and r["delivered"] > 0

@@ -951,7 +951,10 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
       flush_staged(t, true);
     }
     scan<ExpandF>(g, nullptr);
-    proto->launch_deliver(g);
+    {
+      ProfScope ps(*this, PC_DELIVER);
+      proto->launch_deliver(g);
+    }
     const uint32_t nEvents = scratch(&Globals::nEvents);
     if (nEvents) proto->shard_post_deliver(*this, g);
     shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
@@ -972,6 +975,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   }
   WG_HIP(hipStreamSynchronize(stream));
   auto t1 = std::chrono::steady_clock::now();
+  if (profiling) prof_collect();
   sync_globals_to_host();
   time = endAt;
   if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;

@@ -91,6 +91,20 @@ def cont_if(dist, protocol, group=None):
     return bool(t.item())
 
 
+def run_multiple_times(dist, protocol, chunk=10, maxTime=0, group=None):
+    """RunMultipleTimes.run's inner loop (C/RunMultipleTimes.java:50-64) for ONE sharded copy:
+        do { didSomething = runMs(chunk); } while ((maxTime == 0 || time < maxTime) && (!didSomething || contIf(p)));
+    Returns (delivered messages, simulated ms) of the whole network — both are replicated on every shard."""
+    net = protocol.network()
+    delivered = sim_ms = 0
+    while True:
+        did = net.runMs(chunk)
+        delivered += net.last_stats["delivered"]
+        sim_ms += chunk
+        if not ((maxTime == 0 or net.time < maxTime) and (not did or cont_if(dist, protocol, group))):
+            return delivered, sim_ms
+
+
 class WholeNetwork:
     """Whole-network read-back of a sharded Network: every per-node view is this shard's own rows plus, through a
     SUM across shards, everybody else's. Replicated quantities (time, rd state, queue sizes) pass through."""
