@@ -5,6 +5,7 @@
 #include <cstring>
 #include <chrono>
 #include "casper.hpp"
+#include "fuzz.hpp"
 #include "gsf.hpp"
 #include "handel.hpp"
 #include "pingpong.hpp"
@@ -496,6 +497,57 @@ int orc_casper_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngSta
   *rngState = p.network().rd.rawState();
   *delivered = p.network().statDelivered;
   *tasks = p.network().statTasks;
+  return 0;
+}
+
+
+// ---- Fuzz (oracle/fuzz.hpp): scheduler stress protocol, test infrastructure on both sides
+struct OrcFuzz {
+  std::unique_ptr<Fuzz> p;
+};
+int orc_fuzz_create(int n, int ttl, const char* nl, int64_t seed, void** out) {
+  ORC_TRY auto* h = new OrcFuzz();
+  h->p = std::make_unique<Fuzz>(n, ttl, nl ? nl : "");
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_fuzz_destroy(void* h) { delete (OrcFuzz*)h; }
+int orc_fuzz_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcFuzz*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// ops between chunks: 0 partition(arg/1000.f), 1 endPartition, 2 stop node arg, 3 start node arg, 4 setMsgDiscardTime(arg)
+int orc_fuzz_op(void* h, int op, int arg) {
+  ORC_TRY auto& p = *((OrcFuzz*)h)->p;
+  switch (op) {
+    case 0: p.network_.partition(arg / 1000.f); break;
+    case 1: p.network_.endPartition(); break;
+    case 2: p.node(arg)->stop(); break;
+    case 3: p.node(arg)->start(); break;
+    case 4: p.network_.setMsgDiscardTime(arg); break;
+    default: throw IllegalArgumentException("op");
+  }
+  ORC_CATCH
+}
+// fields: 0 h, 1 c, 2 msgReceived, 3 msgSent, 4 bytesSent, 5 bytesReceived
+int orc_fuzz_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcFuzz*)h)->p;
+  for (int i = 0; i < p.N; i++) {
+    auto& n = *p.nodes[i];
+    out[i] = field == 0 ? (int64_t)n.h : field == 1 ? n.c : field == 2 ? n.msgReceived : field == 3 ? n.msgSent
+             : field == 4 ? n.bytesSent : n.bytesReceived;
+  }
+  ORC_CATCH
+}
+int orc_fuzz_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered, uint64_t* tasks) {
+  auto& p = *((OrcFuzz*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  *tasks = p.network_.statTasks;
   return 0;
 }
 

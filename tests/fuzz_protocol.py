@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE — the twin of oracle/fuzz.hpp on the engine's host-callback mode (wittgenstein_amd.hostnet).
+Not a reference protocol: a deterministic stress of core.Network's scheduler semantics. Every action() derives what
+it does (single / multi-destination / delayed multi-destination sends, sendArriveAt, tasks, rd draws, message sizes)
+from a per-node hash, so any deviation of the engine's delivery order, latency sampling or rd stream from the
+oracle's diverges the hashes at once. Statement for statement the same as the C++ side."""
+from wittgenstein_amd.hostnet import HostNetwork, Message, Node
+
+M32 = 0xFFFFFFFF
+
+
+def mix(h, x):
+    return (h ^ ((x + 0x9E3779B9 + ((h << 6) & M32) + (h >> 2)) & M32)) & M32
+
+
+class FuzzNode(Node):
+    def __init__(self, net):
+        super().__init__(net)
+        self.h = (self.nodeId * 2654435761) & M32
+        self.c = 0
+
+
+class Msg(Message):
+    def __init__(self, p, v, ttl):
+        self.p, self.v, self.ttl = p, v & M32, ttl
+
+    def size(self):
+        return 1 + self.v % 5
+
+    def action(self, network, frm, to):
+        self.p.onMsg(frm, to, self)
+
+
+class Fuzz:
+    def __init__(self, n, ttl, nl=None, seed=0, config=None):
+        self.N, self.ttl0 = n, ttl
+        self.network = HostNetwork(nl, config)
+        self.network.rd.setSeed(seed)
+        self.nodes = []
+
+    def node(self, i):
+        return self.nodes[(i & M32) % self.N]
+
+    def msg(self, v, ttl):
+        return Msg(self, v, ttl)
+
+    def init(self):
+        net = self.network
+        for _ in range(self.N):
+            n = FuzzNode(net)
+            self.nodes.append(n)
+            net.addNode(n)
+        net.sendAll(self.msg(1, self.ttl0), self.node(0))
+        net.send(self.msg(2, self.ttl0), self.node(1), [self.node(2), self.node(3), self.node(2), self.node(5)], 3, 4)
+        pn = self.node(1)
+
+        def periodic():
+            pn.h = mix(pn.h, net.time)
+            net.send(self.msg(pn.h, 2), pn, self.node(pn.h >> 5))
+        net.registerPeriodicTask(periodic, 7, 13, pn, lambda: pn.c < 400)
+        cn = self.node(2)
+
+        def conditional():
+            cn.h = mix(cn.h, 0xC0DE)
+            net.send(self.msg(cn.h, 1), cn, self.node(cn.h >> 7))
+        net.registerConditionalTask(conditional, 5, 9, cn, lambda: cn.c % 3 == 0, lambda: cn.c < 300)
+
+    def onMsg(self, frm, to, m):
+        net = self.network
+        to.h = mix(mix(mix(to.h, m.v), frm.nodeId), net.time)
+        to.c += 1
+        if m.ttl <= 0:
+            return
+        r, t = to.h, m.ttl - 1
+        k = r % 8
+        if k in (0, 1):
+            return
+        if k == 2:
+            net.send(self.msg(r, t), to, self.node(r >> 3))
+        elif k == 3:
+            d = [self.node(to.nodeId + 1 + ((r >> (6 + j)) % (self.N - 1))) for j in range(2 + ((r >> 3) % 5))]
+            net.send(self.msg(r, t), to, d)
+        elif k == 4:
+            d = [self.node(r >> (5 + 2 * j)) for j in range(2 + ((r >> 3) % 4))]
+            net.send(self.msg(r, t), to, d, net.time + 1 + ((r >> 12) % 3), 1 + ((r >> 8) % 7))
+        elif k == 5:
+            n, rv = to, r
+
+            def task():
+                n.h = mix(n.h, 77)
+                if rv & 16:
+                    net.send(self.msg(n.h, t), n, self.node(n.h >> 4))
+            net.registerTask(task, net.time + 1 + ((r >> 3) % 20), to)
+        elif k == 6:
+            x = net.rd.nextInt(10)
+            net.send(self.msg(r ^ x, t), to, self.node(to.nodeId + x))
+        else:
+            net.sendArriveAt(self.msg(r, t), net.time + 1 + ((r >> 3) % 5), to, self.node(r >> 9))

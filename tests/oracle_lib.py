@@ -314,3 +314,37 @@ class CasperIMD:
         t, q, r, d, k = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         lib().orc_casper_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d), C.byref(k))
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value}
+
+
+class Fuzz:
+    """oracle/fuzz.hpp — the scheduler stress protocol (test infrastructure on both sides; tests/fuzz_protocol.py is
+    its twin on the engine's host-callback mode)."""
+    FIELDS = {"h": 0, "c": 1, "msgReceived": 2, "msgSent": 3, "bytesSent": 4, "bytesReceived": 5}
+    OPS = {"partition": 0, "endPartition": 1, "stop": 2, "start": 3, "setMsgDiscardTime": 4}
+
+    def __init__(self, n, ttl, nl=None, seed=0):
+        self.h, self.n = C.c_void_p(), n
+        _ck(lib().orc_fuzz_create(n, ttl, nl.encode() if nl else None, C.c_int64(seed), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_fuzz_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_fuzz_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def op(self, name, arg=0):
+        _ck(lib().orc_fuzz_op(self.h, self.OPS[name], int(arg)))
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_fuzz_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d, k = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().orc_fuzz_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d), C.byref(k))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value}

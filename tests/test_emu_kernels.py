@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
@@ -131,3 +132,12 @@ def test_host_callback_mode_pingpong():
 def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp
     tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=10)
     tc.test_byzantine_wf_timeline()
+
+
+@pytest.mark.parametrize("nl", [None, "NetworkNoLatency"])
+def test_scheduler_fuzz_latency(nl):  # oracle/fuzz.hpp vs tests/fuzz_protocol.py on the engine
+    tf.test_fuzz_latency_models(nl)
+
+
+def test_scheduler_fuzz_partitions_stops_discard():
+    tf.test_fuzz_partitions_stops_and_discard(2)

@@ -87,8 +87,8 @@ int32_t wg_set_node_down(wg_engine* h, int32_t id, int32_t down) {
 }
 int32_t wg_set_discard_time(wg_engine* h, int32_t ms) {
   WG_TRY(h)
-  if (E.allocated) throw WgError(WG_ESTATE, "set the discard time before the first run");
-  E.discardTime = ms;
+  E.discardTime = ms;      // (C/Network.java:103-107: a plain field, read at send time :481 — may change between runs)
+  E.dev.discardTime = ms;  // the device table entry is refreshed before the next launch (Engine::self / Batch::prepare)
   WG_END
 }
 int32_t wg_rng_set_seed(wg_engine* h, int64_t seed) {

@@ -210,6 +210,22 @@ class HostNetwork:
     def registerConditionalTask(self, task, startAt, duration, fromNode, startIf, repeatIf):  # :521-531
         self.conditionalTasks.append(ConditionalTask(startIf, repeatIf, task, startAt, fromNode, duration))
 
+    # ---- partitions, discard time, queue (C/Network.java:693-707, :103-107, :201-220): straight to the engine
+    def partition(self, part):
+        self._start()
+        self._eng.partition(part)
+
+    def endPartition(self):
+        self._eng.endPartition()
+
+    def setMsgDiscardTime(self, ms):
+        self._eng.setMsgDiscardTime(ms)
+
+    @property
+    def msgs(self):
+        self._start()
+        return self._eng.msgs
+
     # ---- the loop
     def run(self, seconds):
         return self.runMs(seconds * 1000)
