@@ -114,11 +114,31 @@ def cpu_baseline(n_sample, workload="handel"):
         c.run_ms(10)
     dt = time.perf_counter() - t0
     info = c.info(False)
-    return {"value": info["delivered"] / dt, "unit": "delivered messages/s", "cores": 1, "kind": "port",
-            "sample": "Handel %d nodes (same ratios as the GPU workload, seed 0), full run to the stop predicate: "
-                      "%d delivered messages, %d simulated ms in %.2f s on one host core (C++ oracle, upper bound "
-                      "on the JVM path)" % (n_sample, info["delivered"], info["time"], dt),
-            "simulated_ms_per_s": info["time"] / dt}
+    out = {"value": info["delivered"] / dt, "unit": "delivered messages/s", "cores": 1, "kind": "port",
+           "sample": "Handel %d nodes (same ratios as the GPU workload, seed 0), full run to the stop predicate: "
+                     "%d delivered messages, %d simulated ms in %.2f s on one host core (C++ oracle, upper bound "
+                     "on the JVM path)" % (n_sample, info["delivered"], info["time"], dt),
+           "simulated_ms_per_s": info["time"] / dt}
+    # the only parallelism the reference admits (C/RunMultipleTimes.java:44-48): independent seeds, one per core
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16, int(0.5 * avail / (16.0 * n_sample * n_sample + (1 << 28)))))
+    except Exception:
+        cores = 1
+    if cores > 1:
+        def one(seed):
+            cc = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
+                          hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0, seed=seed)
+            t1 = time.perf_counter()
+            while cc.cont_if():
+                cc.run_ms(10)
+            return cc.info(False)["delivered"], t1, time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:  # (ctypes releases the GIL inside the oracle)
+            res = list(ex.map(one, range(1, cores + 1)))
+        wall = max(r[2] for r in res) - min(r[1] for r in res)
+        out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "delivered messages/s", "cores": cores,
+                            "sample": "%d independent seeds of the same %d-node run, one per core, run loops only" % (cores, n_sample)}
+    return out
 
 
 def main_shard(args):
