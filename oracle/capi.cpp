@@ -9,6 +9,7 @@
 #include "gsf.hpp"
 #include "handel.hpp"
 #include "pingpong.hpp"
+#include "sanfermin.hpp"
 
 using namespace orc;
 
@@ -548,6 +549,77 @@ int orc_fuzz_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState
   *rngState = p.network_.rd.rawState();
   *delivered = p.network_.statDelivered;
   *tasks = p.network_.statTasks;
+  return 0;
+}
+
+
+// ---- San Fermin (P/SanFerminSignature.java)
+struct OrcSanFermin {
+  std::unique_ptr<SanFerminSignature> p;
+};
+// ip: nodeCount, threshold, pairingTime, signatureSize, replyTimeout, candidateCount (SanFerminSignatureParameters
+// ctor order :84-104; shuffledLists is read nowhere in the protocol). The constructor builds the nodes from rd (:126-131),
+// so — as RunMultipleTimes does — the seed is set on the fresh Network's rd only after them: here the seed is applied
+// BEFORE construction through `seed_before` when nonzero semantics are wanted by the caller (tests use both).
+int orc_sanfermin_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY SanFerminSignature::Params pr;
+  pr.nodeCount = ip[0];
+  pr.threshold = ip[1];
+  pr.pairingTime = ip[2];
+  pr.signatureSize = ip[3];
+  pr.replyTimeout = ip[4];
+  pr.candidateCount = ip[5];
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcSanFermin();
+  h->p = std::make_unique<SanFerminSignature>(pr);
+  h->p->network_.rd.setSeed(seed);  // rd.setSeed(i) on the copy, then init()  C/RunMultipleTimes.java:44-48
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_sanfermin_destroy(void* h) { delete (OrcSanFermin*)h; }
+int orc_sanfermin_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcSanFermin*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 aggValue, 5 currentPrefixLength, 6 doneAt,
+//         7 thresholdAt, 8 sentRequests, 9 receivedRequests, 10 done, 11 isSwapping, 12 x, 13 y
+int orc_sanfermin_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcSanFermin*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.aggValue; break;
+      case 5: v = n.currentPrefixLength; break;
+      case 6: v = n.doneAt; break;
+      case 7: v = n.thresholdAt; break;
+      case 8: v = n.sentRequests; break;
+      case 9: v = n.receivedRequests; break;
+      case 10: v = n.done; break;
+      case 11: v = n.isSwapping; break;
+      case 12: v = n.x; break;
+      case 13: v = n.y; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_sanfermin_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered, uint64_t* tasks,
+                       int32_t* finished) {
+  auto& p = *((OrcSanFermin*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  *tasks = p.network_.statTasks;
+  *finished = (int32_t)p.finishedNodes.size();
   return 0;
 }
 

@@ -1,8 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Pins oracle/casper.hpp against every value the reference's own Casper tests
-// hold: PT/CasperIMDTest.java:21-276 (11 tests) and PT/CasperByzantineTest.java:12-66 (2 tests), restated one for one.
+// hold: PT/CasperIMDTest.java:21-276 (11 tests) and PT/CasperByzantineTest.java:12-66 (2 tests), restated one for one;
+// and oracle/sanfermin.hpp against PT/SanFerminTest.java:24-60 (2 tests).
 // Prints one "ok <name>" / "FAIL <name>" line per test; exit code = number of failures.
 #include <cstdio>
 #include "casper.hpp"
+#include "sanfermin.hpp"
 
 using namespace orc;
 
@@ -286,6 +288,44 @@ static void testByzantineWFWithDelay() {  // :37-65
   CHECK_EQ(3, byz->head->height);
 }
 
+// PT/SanFerminTest.java: 8 nodes, helper of node 1
+static void testCandidateSet() {  // :24-47
+  JRandom rd(0);
+  SanFerminHelper helper(1, 8, &rd);
+  CHECK(helper.isCandidate(0, 2));
+  CHECK(helper.isCandidate(3, 1));
+  CHECK(!helper.isCandidate(0, 1));
+  CHECK(helper.isCandidate(4, 0));
+  CHECK(!helper.isCandidate(0, 0));
+  CHECK(!helper.isCandidate(3, 0));
+  SanFerminHelper helper4(4, 8, &rd);
+  CHECK(helper4.isCandidate(1, 0));
+}
+static void testPickNextNodes() {  // :49-60
+  JRandom rd(0);
+  SanFerminHelper helper(1, 8, &rd);
+  std::vector<int> set2 = helper.pickNextNodes(2, 10);
+  CHECK(std::find(set2.begin(), set2.end(), 0) != set2.end());
+  CHECK(helper.pickNextNodes(2, 10).empty());
+}
+// (no reference test runs the protocol; this one checks what the class comment and the code imply: a node that
+// finishes has swapped at every level, so with 2^n nodes it holds all n signatures; a few nodes run out of candidates
+// — "is OUT (no more nodes to pick)", :329-337 — and stay where they are)
+static void testSanFerminRuns() {
+  SanFerminSignature::Params pr;
+  pr.nodeCount = 64;
+  pr.threshold = 64;
+  SanFerminSignature p(pr);
+  p.init();
+  p.network_.run(30);
+  CHECK(p.finishedNodes.size() >= 56 && p.finishedNodes.size() <= 64);
+  for (auto* n : p.finishedNodes) {
+    CHECK_EQ(64, n->aggValue);
+    CHECK(n->doneAt > 0 && n->thresholdDone);
+  }
+  CHECK_EQ(0, p.network_.msgs.size());
+}
+
 #define RUN(t)        \
   do {                \
     g_cur = #t;       \
@@ -313,5 +353,8 @@ int main() {
   RUN(testCopy);
   RUN(testByzantineWF);
   RUN(testByzantineWFWithDelay);
+  RUN(testCandidateSet);
+  RUN(testPickNextNodes);
+  RUN(testSanFerminRuns);
   return g_fail;
 }

@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_zw_gpu_sanfermin as tsf  # noqa: E402
 import test_zy_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 
@@ -141,3 +142,8 @@ def test_scheduler_fuzz_latency(nl):  # oracle/fuzz.hpp vs tests/fuzz_protocol.p
 
 def test_scheduler_fuzz_partitions_stops_discard():
     tf.test_fuzz_partitions_stops_and_discard(2)
+
+
+def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
+    tsf.test_sanfermin_64_matches_oracle()
+    tsf.test_sanfermin_fixed_latency_short_timeout()

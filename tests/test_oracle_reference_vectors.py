@@ -1,6 +1,7 @@
 """Runs oracle/test_network: the reference's engine + protocol unit tests restated against the oracle
 (CT/NetworkTest, CT/EnvelopeStorageTest, CT/NetworkLatencyTest, PT/PingPongTest, PT/HandelTest), and
-oracle/test_casper: PT/CasperIMDTest (11 tests) and PT/CasperByzantineTest (2 tests) restated one for one."""
+oracle/test_casper: PT/CasperIMDTest (11 tests), PT/CasperByzantineTest (2 tests) and PT/SanFerminTest (2 tests)
+restated one for one."""
 import os
 import subprocess
 
@@ -22,4 +23,4 @@ def test_restated_casper_unit_tests(oracle):
     lines = r.stdout.strip().splitlines()
     failed = [l for l in lines if l.startswith("FAIL")]
     assert r.returncode == 0 and not failed, r.stdout
-    assert sum(l.startswith("ok ") for l in lines) == 13
+    assert sum(l.startswith("ok ") for l in lines) == 16
