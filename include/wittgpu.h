@@ -92,7 +92,9 @@ int32_t wg_rng_set_state(wg_engine* e, uint64_t s48);
 
 /* ---- host-side sends / tasks (init() code paths; action() of resident protocols runs on device) */
 /* Network.send(m, sendTime, from, dests, delayBetween) C/Network.java:369-382,418-447 (n==1: single-dest
- * overload). msg = protocol message word, payload = protocol payload handle. Draws one rd.nextInt(). */
+ * overload). msg = protocol message word, payload = protocol payload handle. Draws one rd.nextInt() — also for
+ * n == 0, as the list overload does (:430; the 3-argument overload that returns early on an empty list, :353-356,
+ * is the caller's business). */
 int32_t wg_send(wg_engine* e, uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests,
                 int32_t n, int32_t delayBetween);
 /* Network.sendArriveAt (C/Network.java:384-390): no latency, no rd draw; WG_EINVAL if arriveAt <= time */

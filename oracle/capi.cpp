@@ -8,6 +8,7 @@
 #include "fuzz.hpp"
 #include "gsf.hpp"
 #include "handel.hpp"
+#include "p2pflood.hpp"
 #include "pingpong.hpp"
 #include "sanfermin.hpp"
 
@@ -620,6 +621,71 @@ int orc_sanfermin_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rng
   *delivered = p.network_.statDelivered;
   *tasks = p.network_.statTasks;
   *finished = (int32_t)p.finishedNodes.size();
+  return 0;
+}
+
+
+// ---- P2PFlood (P/P2PFlood.java over C/P2PNetwork.java, C/messages/FloodMessage.java)
+struct OrcFlood {
+  std::unique_ptr<P2PFlood> p;
+};
+// ip: nodeCount, deadNodeCount, delayBeforeResent, msgCount, msgToReceive, peersCount, delayBetweenSends (:63-86)
+int orc_p2pflood_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY P2PFlood::Params pr;
+  pr.nodeCount = ip[0];
+  pr.deadNodeCount = ip[1];
+  pr.delayBeforeResent = ip[2];
+  pr.msgCount = ip[3];
+  pr.msgToReceive = ip[4];
+  pr.peersCount = ip[5];
+  pr.delayBetweenSends = ip[6];
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcFlood();
+  h->p = std::make_unique<P2PFlood>(pr);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_p2pflood_destroy(void* h) { delete (OrcFlood*)h; }
+int orc_p2pflood_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcFlood*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 doneAt, 5 down, 6 getMsgReceived(-1).size(),
+//         7 peers.size(), 8 sum of peer ids, 9 x, 10 y
+int orc_p2pflood_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcFlood*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.doneAt; break;
+      case 5: v = n.down; break;
+      case 6: v = (int64_t)n.getMsgReceived(-1).size(); break;
+      case 7: v = (int64_t)n.peers.size(); break;
+      case 8:
+        for (size_t k = 0; k < n.peers.size(); k++) v += (int64_t)(k + 1) * n.peers[k]->nodeId;  // order-sensitive
+        break;
+      case 9: v = n.x; break;
+      case 10: v = n.y; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_p2pflood_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcFlood*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
   return 0;
 }
 

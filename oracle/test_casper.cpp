@@ -1,9 +1,11 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Pins oracle/casper.hpp against every value the reference's own Casper tests
 // hold: PT/CasperIMDTest.java:21-276 (11 tests) and PT/CasperByzantineTest.java:12-66 (2 tests), restated one for one;
-// and oracle/sanfermin.hpp against PT/SanFerminTest.java:24-60 (2 tests).
+// oracle/sanfermin.hpp against PT/SanFerminTest.java:24-60 (2 tests); oracle/p2pflood.hpp against
+// PT/P2PFloodTest.java:12-31 (testSimpleRun).
 // Prints one "ok <name>" / "FAIL <name>" line per test; exit code = number of failures.
 #include <cstdio>
 #include "casper.hpp"
+#include "p2pflood.hpp"
 #include "sanfermin.hpp"
 
 using namespace orc;
@@ -326,6 +328,19 @@ static void testSanFerminRuns() {
   CHECK_EQ(0, p.network_.msgs.size());
 }
 
+// PT/P2PFloodTest.java:12-31: 100 nodes, 10 dead, NoLatency, 20 s: every live node holds the message once, dead ones never
+static void testP2PFloodSimpleRun() {
+  P2PFlood::Params pr;  // (100, 10, 50, 1, 1, 10, 30, RANDOM / gaussian speed, NetworkNoLatency)
+  pr.nodeBuilderName = "RANDOM_SPEED=GAUSSIAN_TOR=0.00";
+  pr.networkLatencyName = "NetworkNoLatency";
+  P2PFlood p(pr);
+  p.init();
+  p.network_.run(20);
+  CHECK_EQ(100, p.network_.allNodes.size());
+  for (auto& n : p.nodes) CHECK_EQ(n->isDown() ? 0 : 1, n->getMsgReceived(-1).size());
+  for (auto& n : p.nodes) CHECK(n->isDown() || (int)n->peers.size() >= 10);
+}
+
 #define RUN(t)        \
   do {                \
     g_cur = #t;       \
@@ -356,5 +371,6 @@ int main() {
   RUN(testCandidateSet);
   RUN(testPickNextNodes);
   RUN(testSanFerminRuns);
+  RUN(testP2PFloodSimpleRun);
   return g_fail;
 }

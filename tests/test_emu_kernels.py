@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_zv_gpu_p2pflood as tpf  # noqa: E402
 import test_zw_gpu_sanfermin as tsf  # noqa: E402
 import test_zy_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -147,3 +148,8 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage + P/P2PFlood.java on the engine
+    tpf.test_p2pflood_three_messages_by_distance()
+    tpf.test_empty_destination_list_costs_a_draw()

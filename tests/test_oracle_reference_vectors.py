@@ -23,4 +23,4 @@ def test_restated_casper_unit_tests(oracle):
     lines = r.stdout.strip().splitlines()
     failed = [l for l in lines if l.startswith("FAIL")]
     assert r.returncode == 0 and not failed, r.stdout
-    assert sum(l.startswith("ok ") for l in lines) == 16
+    assert sum(l.startswith("ok ") for l in lines) == 17

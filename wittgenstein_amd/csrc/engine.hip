@@ -458,7 +458,15 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   if (from < 0 || from >= N) throw WgError(WG_EINVAL, "The from node is not in the network.");  // :371,:427
   for (int i = 0; i < n; i++)
     if (dests[i] < 0 || dests[i] >= N) throw WgError(WG_EINVAL, "The to node is not in the network.");  // :374
-  if (n <= 0) return;
+  if (n <= 0) {  // the list overload draws its seed before it looks at the destinations (:430): an empty list costs a draw
+    JavaRandom rd0;
+    rd0.s = gh.rng;
+    (void)rd0.nextInt();
+    gh.rng = rd0.s;
+    gh.draws++;
+    globalsDirty = true;
+    return;
+  }
   if (sendTime <= time) throw WgError(WG_ESTATE, "sendTime=" + std::to_string(sendTime) + ", time=" + std::to_string(time));  // :471
   if (!proto) throw WgError(WG_ESTATE, "load a protocol before sending (message sizes are protocol-defined)");
   JavaRandom rd;

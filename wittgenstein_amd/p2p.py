@@ -1,0 +1,142 @@
+"""The reference's P2P layer — core.P2PNetwork (C/P2PNetwork.java), core.P2PNode (C/P2PNode.java),
+core.messages.FloodMessage (C/messages/FloodMessage.java) — and protocols.P2PFlood (P/P2PFlood.java) on the engine in
+host-callback mode: peer graphs are built on the host with the shared `rd` exactly as setPeers() does (:27-56), every
+flood hop is one `MultipleDestWithDelayEnvelope` (C/Envelope.java:157-228: the peers, shuffled with rd, one every
+delayBetweenPeers ms) queued, ordered and latency-sampled by libwittgpu.so. Host-side Python stand-in for the Java
+classes (no JVM in the build image); names follow the Java source."""
+from .core import IllegalArgumentException
+from .hostnet import HostNetwork, Message, Node
+from .sanfermin import shuffle
+
+
+class P2PNode(Node):  # C/P2PNode.java
+    def __init__(self, net, byzantine=False):
+        super().__init__(net)
+        self.byzantine = byzantine
+        self.peers = []
+        self.received = {}
+
+    def getMsgReceived(self, msgId):
+        return self.received.setdefault(msgId, set())
+
+    def onFlood(self, frm, floodMessage):
+        pass
+
+
+class FloodMessage(Message):  # C/messages/FloodMessage.java
+    def __init__(self, size, localDelay, delayBetweenPeers):
+        self._size, self.localDelay, self.delayBetweenPeers = size, localDelay, delayBetweenPeers
+
+    def msgId(self):
+        return -1
+
+    def addToReceived(self, to):
+        s = to.getMsgReceived(self.msgId())
+        if self in s:
+            return False
+        s.add(self)
+        return True
+
+    def action(self, network, frm, to):  # :47-55
+        if self.addToReceived(to):
+            to.onFlood(frm, self)
+            dest = [n for n in to.peers if n is not frm]
+            shuffle(dest, network.rd)
+            network.send(self, to, dest, network.time + 1 + self.localDelay, self.delayBetweenPeers, _force_multi=True)
+
+    def size(self):
+        return self._size
+
+
+class P2PNetwork(HostNetwork):  # C/P2PNetwork.java
+    def __init__(self, connectionCount, minimum, networkLatencyName=None, config=None):
+        super().__init__(networkLatencyName, config)
+        self.connectionCount, self.minimum = connectionCount, minimum
+        self.existingLinks = set()
+
+    def setPeers(self):  # :27-56
+        n = len(self.allNodes)
+        if self.connectionCount >= n:
+            raise IllegalArgumentException("Wrong configuration: #nodes=%d, connection target=%d" % (n, self.connectionCount))
+        if not self.minimum:
+            toCreate = (n * self.connectionCount) // 2
+            while toCreate != len(self.existingLinks):
+                pp1 = self.rd.nextInt(n)
+                pp2 = self.rd.nextInt(n)
+                self._createLink(pp1, pp2)
+        an = list(self.allNodes)
+        shuffle(an, self.rd)
+        want = self.connectionCount if self.minimum else min(3, self.connectionCount)
+        for node in an:
+            while len(node.peers) < want:
+                self._createLink(node.nodeId, self.rd.nextInt(n))
+
+    def createLink(self, p1, p2):
+        self._createLink(p1.nodeId, p2.nodeId)
+
+    def _createLink(self, pp1, pp2):  # :72-93
+        if pp1 == pp2:
+            return
+        link = (min(pp1, pp2) << 32) + max(pp1, pp2)
+        if link in self.existingLinks:
+            return
+        self.existingLinks.add(link)
+        p1, p2 = self.allNodes[pp1], self.allNodes[pp2]
+        p1.peers.append(p2)
+        p2.peers.append(p1)
+
+    def avgPeers(self):
+        return sum(len(n.peers) for n in self.allNodes) // len(self.allNodes) if self.allNodes else 0
+
+    def sendPeers(self, msg, frm):  # :127-132
+        msg.addToReceived(frm)
+        dest = list(frm.peers)
+        shuffle(dest, self.rd)
+        self.send(msg, frm, dest, self.time + 1 + msg.localDelay, msg.delayBetweenPeers, _force_multi=True)
+
+
+class P2PFloodParameters:  # P/P2PFlood.java:41-86
+    def __init__(self, nodeCount=100, deadNodeCount=10, delayBeforeResent=50, msgCount=1, msgToReceive=1, peersCount=10,
+                 delayBetweenSends=30, nodeBuilderName=None, networkLatencyName=None):
+        if nodeBuilderName not in (None, "", "RANDOM_SPEED=CONSTANT_TOR=0.00"):
+            raise IllegalArgumentException("hostnet.Node builds RANDOM / constant-speed nodes only")
+        self.nodeCount, self.deadNodeCount, self.delayBeforeResent = nodeCount, deadNodeCount, delayBeforeResent
+        self.msgCount, self.msgToReceive, self.peersCount = msgCount, msgToReceive, peersCount
+        self.delayBetweenSends = delayBetweenSends
+        self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
+
+
+class P2PFloodNode(P2PNode):  # :25-39
+    def __init__(self, p, down):
+        super().__init__(p.network, down)
+        self.p = p
+        if down:
+            self.stop()
+
+    def onFlood(self, frm, floodMessage):
+        if len(self.getMsgReceived(floodMessage.msgId())) == self.p.params.msgCount:
+            self.doneAt = self.p.network.time
+
+
+class P2PFlood:  # P/P2PFlood.java
+    def __init__(self, params=None, config=None):
+        self.params = params or P2PFloodParameters()
+        self.network = P2PNetwork(self.params.peersCount, True, self.params.networkLatencyName, config)
+
+    def copy(self):
+        return P2PFlood(self.params)
+
+    def init(self):  # :121-140
+        p, net = self.params, self.network
+        for i in range(p.nodeCount):
+            net.addNode(P2PFloodNode(self, i < p.deadNodeCount))
+        net.setPeers()
+        senders = set()
+        while len(senders) < p.msgCount:
+            nodeId = net.rd.nextInt(p.nodeCount)
+            frm = net.getNodeById(nodeId)
+            if not frm.isDown() and nodeId not in senders:
+                senders.add(nodeId)
+                net.sendPeers(FloodMessage(1, p.delayBeforeResent, p.delayBetweenSends), frm)
+                if p.msgCount == 1:
+                    frm.doneAt = 1
