@@ -931,7 +931,6 @@ void Engine::exchange_outbox(uint32_t nOut) {
   if (!nMulti) return;
   scan<MultiF>(g, nullptr);
   nMulti = std::min(nMulti, dev.maxMulti);
-  if (getenv("WG_SHARD_DEBUG")) fprintf(stderr, "[shard %d] t=%d multi-destination envelopes: %u\n", shardIndex, time, nMulti);
   WG_HIP(hipMemsetAsync(dev.xmulti, 0, sizeof(int32_t) * (size_t)nMulti * XM_WORDS, stream));
   hipLaunchKernelGGL(k_shard_multi_fill, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
   shard_allreduce(dev.xmulti, (int64_t)nMulti * XM_WORDS);
