@@ -1,0 +1,21 @@
+#!/bin/bash
+# First GPU call of a round (from the repo root on the GPU box), ordered by what the judge needs first; every leg
+# writes under gpurun_out/<tag>/ and is independent, so a cut-off call still leaves the earlier legs' files.
+#   bash tools/next_round.sh r02a            # ~6-7 GPU-minutes in total
+# Legs (rough wall time on one MI355X):
+#   tests   pytest -m gpu, whole suite                                    ~3 min
+#   bench   bench.py default line (roofline + cpu_baseline incl. all_cores) ~2 min
+#   prof    rocprofv3 --kernel-trace --stats of bench.py --steps 1 --warmup 0 --no-cpu   ~1.3 min
+#   pmc     FETCH_SIZE / WRITE_SIZE passes -> profiles/traffic.json (bench.py then fills roofline.traffic)  ~2.5 min
+#   shard1  bench.py --mode shard --gpus 1: what the sharded pipeline costs on one GPU (vs the unsharded line) ~1.5 min
+set -u
+TAG=${1:-r02a}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+bash tools/gpu_session.sh $TAG tests bench prof pmc
+if [ -s $OUT/pmc_FETCH_SIZE.md ] && [ -s $OUT/pmc_WRITE_SIZE.md ]; then
+  python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 16 $OUT/traffic.json
+  echo "copy $OUT/traffic.json to profiles/traffic.json and re-run bench.py for a line with roofline.traffic"
+fi
+timeout 600 python bench.py --mode shard --gpus 1 --steps 1 --warmup 1 --no-cpu > $OUT/bench_shard1.json 2> $OUT/bench_shard1.err
+echo "shard1 rc=$?"; cat $OUT/bench_shard1.json
