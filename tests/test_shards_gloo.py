@@ -67,7 +67,8 @@ def _run(tmp_path, world, port, **kw):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("world,n,nl", [(2, 300, None), (3, 257, "NetworkLatencyByDistanceWJitter")])
+@pytest.mark.parametrize("world,n,nl", [(2, 300, None), (3, 257, "NetworkLatencyByDistanceWJitter"),
+                                        (8, 200, "NetworkLatencyByDistanceWJitter")])
 def test_sharded_pingpong_matches_the_oracle(oracle, tmp_path, world, n, nl):
     res = _run(tmp_path, world, 29541 + world, n=n, seed=3, nl=nl, steps=8, chunk=50)
     assert len(res) == world
@@ -135,6 +136,7 @@ def _run_handel(tmp_path, world, port, **kw):
     (2, (64, 57, 4, 50, 10, 20, 10, 6, 0)),      # PT/HandelTest's size, fast path on, dead nodes
     (2, (128, 100, 4, 20, 5, 10, 10, 12, 100)),  # desynchronised start, wider levels
     (4, (64, 60, 6, 10, 5, 5, 10, 2, 100)),      # PT/HandelTest.java:36-49 parameters, 4 shards
+    (2, (64, 57, 4, 50, 10, 20, 10, 6, 600)),    # starts beyond the bucket horizon: host-held envelopes injected mid-run
 ])
 def test_sharded_handel_matches_the_oracle(oracle, tmp_path, world, params):
     res = _run_handel(tmp_path, world, 29551 + world + params[0] % 7, params=params, seed=1, chunk=10, check_every=5,
