@@ -163,20 +163,41 @@ def main_shard(args):
     dk_spans = dk_ns = 0
     by_level = None
     traffic = (0, 0)
+    kl = args.logical_shards if world == 1 else 0
+    hparams = w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"],
+                                 hp["extraCycle"], hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0)
     for step in range(W + K):  # every rank builds the SAME simulation (seed = step) and owns a node range of it
-        cfg = shards.config(dist, device=local)
-        g = w.Handel(w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"],
-                                        hp["extraCycle"], hp["disseminationPeriodMs"], hp["fastPath"],
-                                        hp["nodesDown"], NB, NL, 0), seed=step, config=cfg)
-        g.init()
-        g.network().profile(2)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        d, ms = shards.run_multiple_times(dist, g, chunk=10, maxTime=20000)
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        if kl > 0:  # k shards on this one GPU, one host thread each; RunMultipleTimes' loop driven from here
+            grp = shards.LoopbackGroup(kl)
+            sims = []
+            for sh in range(kl):
+                sims.append(w.Handel(hparams, seed=step, config=grp.config(sh, device=local)))
+                sims[-1].init()
+            g = sims[0]
+            g.network().profile(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d = ms = 0
+            while True:
+                did = grp.run(lambda sh: sims[sh].network().runMs(10))[0]
+                d += g.network().last_stats["delivered"]
+                ms += 10
+                if not (g.network().time < 20000 and (not did or any(x.cont_if() for x in sims))):
+                    break
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        else:
+            sims = None
+            g = w.Handel(hparams, seed=step, config=shards.config(dist, device=local))
+            g.init()
+            g.network().profile(2)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d, ms = shards.run_multiple_times(dist, g, chunk=10, maxTime=20000)
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
         if step >= W:
             delivered += d
             sim_ms += ms
@@ -187,7 +208,7 @@ def main_shard(args):
             bl = g.network().delivered_by_level()   # replicated: the whole network's histogram
             by_level = bl if by_level is None else by_level + bl
             traffic = shards.traffic(g.network())
-        del g
+        del g, sims
         gc.collect()
     tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -202,13 +223,13 @@ def main_shard(args):
             "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": sim_ms / elapsed,
             "config": {"workload": "Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, "
                                    "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; ONE simulation "
-                                   "per step, nodes split by id range over %d rank(s), runMs(10) until Handel.newContIf is "
-                                   "false" % (n, world),
-                       "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure)",
+                                   "per step, nodes split by id range over %d shard(s)%s, runMs(10) until Handel.newContIf is "
+                                   "false" % (n, kl if kl else world, " on one GPU (in-process loopback all-reduce)" if kl else ""),
+                       "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure)", "shards": kl if kl else world,
                        "allreduce_calls_per_simulation": traffic[0], "allreduce_int32_words_per_simulation": traffic[1]},
             "roofline": {"bound": "hbm", "kernel": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> on rank 0's node range",
-                         "achieved": (alg_bytes / world / max(1, dk_spans)) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (alg_bytes / world / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
+                         "achieved": (alg_bytes / (kl if kl else world) / max(1, dk_spans)) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (alg_bytes / (kl if kl else world) / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                          "traffic": None, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
                          "whole_run_achieved_GBs": alg_bytes / (elapsed * 1e9)},
         }
@@ -234,6 +255,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="replicas = independent copies per GPU (default, weak scaling); shard = one simulation per "
                          "step, its nodes split by id range over the ranks (strong scaling)")
+    ap.add_argument("--logical-shards", type=int, default=0,
+                    help="--mode shard on ONE GPU: k engines in this process, each owning a node range; the all-reduce "
+                         "sums their buffers in place (shards.LoopbackGroup). 0 = one shard per rank over RCCL")
     args = ap.parse_args()
     if args.mode == "shard":
         return main_shard(args)

@@ -3,6 +3,7 @@
 // calls the engine's host code makes, as plain host memory operations.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <vector>
 
@@ -193,7 +194,12 @@ static void run_block(unsigned nThreads) {
   }
 }
 
+// one launch at a time: the emulated device state (fibers, LDS, the built-in index variables, the kernels' static
+// __shared__ storage) is global, and the sharded-engine tests drive several engines from several host threads
+static std::mutex g_launchMutex;
+
 void launch(dim3 grid, dim3 block, size_t lds, Thunk t) {
+  std::lock_guard<std::mutex> guard(g_launchMutex);
   if (block.y != 1 || block.z != 1 || grid.z != 1) {
     fprintf(stderr, "emu: only 1-D blocks and 2-D grids are supported\n");
     abort();

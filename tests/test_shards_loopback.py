@@ -1,0 +1,86 @@
+"""k shards of one simulation in ONE process (wittgenstein_amd.shards.LoopbackGroup: k engines, k host threads, the
+all-reduce sums the k buffers in place) — on the CPU wave emulator here, on one MI355X in tests/test_zz_gpu_shards.py.
+Shard-count invariance against the oracle, as tests/test_shards_gloo.py checks it over processes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import wittgenstein_amd._lib as L
+import parity
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulated_kernels(oracle):
+    subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
+    saved = (L._lib, L.LIB_PATH)
+    L._lib, L.LIB_PATH = None, os.path.join(EMU_DIR, "libwittgpu_emu.so")
+    try:
+        L.lib()
+        yield
+    finally:
+        L._lib, L.LIB_PATH = saved
+
+
+def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=5):
+    """runs k shards in lock-step with the oracle; returns the list of mismatches (empty = identical)"""
+    import wittgenstein_amd as w
+    from wittgenstein_amd import shards
+    import oracle_lib as o
+    n, thr, pair, lw, ec, per, fp, down, desync = params
+    grp = shards.LoopbackGroup(k, device_memory=device_memory)
+    sims = []
+    for s in range(k):
+        g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync), seed=seed,
+                     config=grp.config(s, queue_cap=64))
+        g.init()
+        sims.append(g)
+    c = o.Handel(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync, seed=seed)
+    nets = [g.network() for g in sims]
+
+    class Whole:  # what parity.diff_handel reads, assembled from the shards' own rows
+        time = property(lambda self: nets[0].time)
+
+        def rng_state(self):
+            assert len({net.rng_state() for net in nets}) == 1
+            return nets[0].rng_state()
+
+        def read(self, f):
+            return grp.gather([net.read(f) for net in nets], nets)
+
+        def read_level(self, f):
+            return grp.gather([net.read_level(f) for net in nets], nets)
+
+        def read_bits(self, f):
+            return grp.gather([net.read_bits(f) for net in nets], nets)
+
+    class G:
+        def network(self):
+            return Whole()
+
+    bad, steps = [], 0
+    while c.cont_if() and steps < chunks_max and not bad:
+        grp.run(lambda s: nets[s].runMs(10))
+        c.run_ms(10)
+        steps += 1
+        if steps % check_every == 0:
+            bad += parity.diff_handel(G(), c)
+        if any(g.cont_if() for g in sims) != c.cont_if():
+            bad.append("cont_if")
+    bad += parity.diff_handel(G(), c)
+    dl = c.stats()["deliveredByLevel"]
+    if not np.array_equal(nets[0].delivered_by_level()[:len(dl)].astype(np.uint64), dl):
+        bad.append("delivered_by_level")
+    if c.cont_if():
+        bad.append("did not converge in %d chunks" % chunks_max)
+    return bad, [shards.traffic(net) for net in nets]
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_handel_logical_shards_match_the_oracle(k):
+    bad, traffic = handel_loopback(k, (64, 57, 4, 50, 10, 20, 10, 6, 0), seed=1, device_memory=False)
+    assert bad == []
+    assert len(set(traffic)) == 1 and traffic[0][0] > 0     # every shard issued the same collectives

@@ -3,7 +3,8 @@ delivery and send resolution, the exchange images, the replicated creation of mu
 snapshot exchanges and global draw / registration orders of Handel and GSFSignature — run through RCCL (torch.distributed backend "nccl") on DEVICE memory.
 The GPU box has one GPU, so the process group has one rank: every collective is the identity, every kernel of the
 sharded path runs, and the result must be the oracle's bit for bit. Shard-count invariance proper (2, 3, 4 shards)
-is covered over gloo by tests/test_shards_gloo.py.
+is covered over gloo by tests/test_shards_gloo.py and, on this one GPU, by k engines in one process whose
+all-reduce sums their buffers in place (wittgenstein_amd.shards.LoopbackGroup; leg 5 below).
 
 The rank runs in its own process, as it does in production (one process per GPU): torch brings its own HIP runtime,
 which has to be the first one initialised in a process — bench.py and this worker import torch before the engine
@@ -73,6 +74,13 @@ while c.cont_if() and k < 600 and not bad:
 bad += tg.diff(G(), c)
 out["gsf"] = {"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
               "traffic": list(shards.traffic(g.network()))}
+# 5. real shard-count invariance on the one GPU: k engines in this process, the all-reduce sums their buffers in place
+import test_shards_loopback as tl
+out["loopback"] = []
+for k, params in [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (256, 230, 4, 50, 10, 20, 10, 25, 100))]:
+    bad, traffic = tl.handel_loopback(k, params, seed=1, device_memory=True)
+    out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len(set(traffic)) == 1,
+                            "calls": traffic[0][0]})
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 '''
@@ -109,3 +117,9 @@ def test_sharded_handel_one_rank(result):
 def test_sharded_gsf_one_rank(result):
     r = result["gsf"]
     assert r["bad"] == [] and r["done"] and r["traffic"][0] > 0, r
+
+
+def test_logical_shards_on_one_gpu(result):   # 2 and 4 shards of one Handel simulation on the one MI355X
+    assert [r["k"] for r in result["loopback"]] == [2, 4]
+    for r in result["loopback"]:
+        assert r["bad"] == [] and r["same_collectives"] and r["calls"] > 0, r

@@ -8,6 +8,7 @@
 #   prof    rocprofv3 --kernel-trace --stats of bench.py --steps 1 --warmup 0 --no-cpu   ~1.3 min
 #   pmc     FETCH_SIZE / WRITE_SIZE passes -> profiles/traffic.json (bench.py then fills roofline.traffic)  ~2.5 min
 #   shard1  bench.py --mode shard --gpus 1: what the sharded pipeline costs on one GPU (vs the unsharded line) ~1.5 min
+#   shard4  ... --logical-shards 4: four node-range shards of one simulation on the one GPU                 ~2 min
 set -u
 TAG=${1:-r02a}
 OUT=gpurun_out/$TAG
@@ -19,3 +20,7 @@ if [ -s $OUT/pmc_FETCH_SIZE.md ] && [ -s $OUT/pmc_WRITE_SIZE.md ]; then
 fi
 timeout 600 python bench.py --mode shard --gpus 1 --steps 1 --warmup 1 --no-cpu > $OUT/bench_shard1.json 2> $OUT/bench_shard1.err
 echo "shard1 rc=$?"; cat $OUT/bench_shard1.json
+# the same simulation as 4 node-range shards on this one GPU (in-process loopback all-reduce): the exchange volumes and
+# the owner split at full size, without xGMI
+timeout 600 python bench.py --mode shard --gpus 1 --logical-shards 4 --steps 1 --warmup 0 --no-cpu > $OUT/bench_shard4_logical.json 2> $OUT/bench_shard4_logical.err
+echo "shard4-logical rc=$?"; cat $OUT/bench_shard4_logical.json

@@ -146,3 +146,94 @@ class WholeNetwork:
 
     def delivered_by_level(self):
         return self._net.delivered_by_level()
+
+
+class LoopbackGroup:
+    """k shards of one simulation on ONE device in one process: every shard is its own wg_engine (own stream, own
+    state for its node range), the shards' runMs calls run on k host threads and meet in the all-reduce, which sums the
+    k buffers in place on the device. What a one-GPU box can measure of the sharded pipeline (exchange volumes, the
+    owner split, shard-count invariance on the hardware); xGMI and RCCL are not involved.
+
+        grp = LoopbackGroup(4)
+        sims = [Handel(params, seed=0, config=grp.config(s)) for s in range(4)]; [g.init() for g in sims]
+        grp.run(lambda s: sims[s].network().runMs(10))
+    """
+
+    def __init__(self, k, device_memory=True):
+        import threading
+        self.k, self.device_memory = k, device_memory
+        self._barrier = threading.Barrier(k)
+        self._bufs = [None] * k
+        self._thunks = []
+
+    def _allreduce(self, shard, buf, count):
+        import threading
+        try:
+            self._bufs[shard] = (buf, int(count))
+            leader = self._barrier.wait() == 0
+            if leader:
+                if len({c for _, c in self._bufs}) != 1:
+                    raise RuntimeError("shards disagree on the size of a collective: %r" % [c for _, c in self._bufs])
+                if self.device_memory:
+                    import torch
+                    ts = [torch.as_tensor(_DeviceWords(b, c), device="cuda") for b, c in self._bufs]
+                    total = torch.stack(ts).sum(0, dtype=torch.int32)
+                    for t in ts:
+                        t.copy_(total)
+                    torch.cuda.synchronize()
+                else:
+                    arrs = [np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_int32)), shape=(c,)) for b, c in self._bufs]
+                    total = np.sum(arrs, axis=0, dtype=np.int32)
+                    for a in arrs:
+                        a[:] = total
+            self._barrier.wait()
+            return 0
+        except threading.BrokenBarrierError:
+            return 2
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            self._barrier.abort()
+            return 1
+
+    def config(self, shard, **capacities):
+        """wg_config fields that make an engine shard `shard` of this group"""
+        fn = L.ALLREDUCE_FN(lambda _ctx, buf, count, s=shard: self._allreduce(s, buf, count))
+        self._thunks.append(fn)
+        _KEEP.append(fn)
+        cfg = dict(capacities)
+        cfg.update(shard=shard, nshards=self.k, allreduce=C.cast(fn, C.c_void_p).value)
+        return cfg
+
+    def run(self, fn):
+        """fn(shard) on k threads at once (the shards meet in their collectives); returns the k results"""
+        import threading
+        out, err = [None] * self.k, [None] * self.k
+
+        def work(s):
+            try:
+                out[s] = fn(s)
+            except BaseException as e:  # noqa: B036 — re-raised below, after every thread has been released
+                err[s] = e
+                self._barrier.abort()
+        ts = [threading.Thread(target=work, args=(s,)) for s in range(self.k)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        self._barrier.reset()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def gather(self, per_shard_views, nets):
+        """whole-network view: every shard's own rows (a shard reports zeros / stale rows for the others)"""
+        total = None
+        for a, net in zip(per_shard_views, nets):
+            lo, hi = shard_range(net)
+            a = np.array(a, copy=True)
+            a[:lo] = 0
+            a[hi:] = 0
+            total = a if total is None else total + a
+        return total
