@@ -132,7 +132,7 @@ def test_host_callback_mode_pingpong():
 
 
 def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp
-    tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=10)
+    tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=6)
     tc.test_byzantine_wf_timeline()
 
 

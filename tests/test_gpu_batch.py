@@ -88,7 +88,7 @@ def test_batch_rejects_mismatched_members():
 def test_run_multiple_times_device_loop_equals_host_loop(n):
     """wg_batch_run_multiple_times (loop condition evaluated on the device, chunks enqueued back to back) and the
     same loop driven from the host with one wg_batch_run_ms per chunk reach the same state, per member."""
-    seeds = [3, 4, 5]
+    seeds = [3, 4, 5] if n > 64 else [3, 4]
     res = []
     for on_device in (True, False):
         gs = [parity.handel_pair(ratios(n), seed=s)[0] for s in seeds]

@@ -79,8 +79,8 @@ def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=
     return bad, [shards.traffic(net) for net in nets]
 
 
-@pytest.mark.parametrize("k", [2, 4])
-def test_handel_logical_shards_match_the_oracle(k):
-    bad, traffic = handel_loopback(k, (64, 57, 4, 50, 10, 20, 10, 6, 0), seed=1, device_memory=False)
+@pytest.mark.parametrize("k,params", [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (32, 28, 4, 20, 5, 10, 10, 2, 0))])
+def test_handel_logical_shards_match_the_oracle(k, params):
+    bad, traffic = handel_loopback(k, params, seed=1, device_memory=False)
     assert bad == []
     assert len(set(traffic)) == 1 and traffic[0][0] > 0     # every shard issued the same collectives
