@@ -84,3 +84,50 @@ def test_handel_logical_shards_match_the_oracle(k, params):
     bad, traffic = handel_loopback(k, params, seed=1, device_memory=False)
     assert bad == []
     assert len(set(traffic)) == 1 and traffic[0][0] > 0     # every shard issued the same collectives
+
+
+def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_cap=64):
+    """k logical shards against the UNSHARDED engine (no oracle: usable at sizes the oracle cannot reach in a test).
+    Both run RunMultipleTimes' loop; compared at the end: every per-node scalar, the per-level scalars, all five bitset
+    rows, time, rd state, delivered count. Returns the list of mismatches."""
+    import wittgenstein_amd as w
+    from wittgenstein_amd import shards
+    n, thr, pair, lw, ec, per, fp, down, desync = params
+    hp = w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync)
+    ref = w.Handel(hp, seed=seed, config={"queue_cap": queue_cap})
+    ref.init()
+    rd_, rms = w.Batch([ref.network()]).run_multiple_times(chunk=chunk, maxTime=20000)
+    grp = shards.LoopbackGroup(k, device_memory=device_memory)
+    sims = []
+    for s in range(k):
+        sims.append(w.Handel(hp, seed=seed, config=grp.config(s, queue_cap=queue_cap)))
+        sims[-1].init()
+    nets = [g.network() for g in sims]
+    delivered = ms = 0
+    while True:
+        did = grp.run(lambda s: nets[s].runMs(chunk))[0]
+        delivered += nets[0].last_stats["delivered"]
+        ms += chunk
+        if not (nets[0].time < 20000 and (not did or any(g.cont_if() for g in sims))):
+            break
+    bad = []
+    if (delivered, ms) != (rd_[0], rms[0]):
+        bad.append("delivered / simulated ms: shards %r unsharded %r" % ((delivered, ms), (rd_[0], rms[0])))
+    rnet = ref.network()
+    if (nets[0].time, nets[0].rng_state()) != (rnet.time, rnet.rng_state()):
+        bad.append("time / rd state")
+    for f in parity.SCALARS:
+        if not np.array_equal(grp.gather([net.read(f) for net in nets], nets), rnet.read(f)):
+            bad.append(f)
+    for f in parity.LEVELS:
+        if not np.array_equal(grp.gather([net.read_level(f) for net in nets], nets), rnet.read_level(f)):
+            bad.append(f)
+    for f in parity.BITS:
+        if not np.array_equal(grp.gather([net.read_bits(f) for net in nets], nets), rnet.read_bits(f)):
+            bad.append(f)
+    return bad, int((rnet.read("doneAt") > 0).sum()), delivered
+
+
+def test_logical_shards_equal_the_unsharded_engine():
+    bad, done, delivered = handel_shards_vs_unsharded(2, (64, 57, 4, 50, 10, 20, 10, 6, 0), seed=3, device_memory=False)
+    assert bad == [] and done == 58 and delivered > 0

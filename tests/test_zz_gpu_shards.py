@@ -81,6 +81,9 @@ for k, params in [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (256, 230, 4, 50, 
     bad, traffic = tl.handel_loopback(k, params, seed=1, device_memory=True)
     out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len(set(traffic)) == 1,
                             "calls": traffic[0][0]})
+# 6. at a size the oracle cannot reach inside a test: 4 logical shards == the unsharded engine, bit for bit
+bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
+out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 '''
@@ -123,3 +126,8 @@ def test_logical_shards_on_one_gpu(result):   # 2 and 4 shards of one Handel sim
     assert [r["k"] for r in result["loopback"]] == [2, 4]
     for r in result["loopback"]:
         assert r["bad"] == [] and r["same_collectives"] and r["calls"] > 0, r
+
+
+def test_four_logical_shards_equal_the_unsharded_engine_at_8192_nodes(result):
+    r = result["vs_unsharded_8192"]
+    assert r["bad"] == [] and r["done"] == 8192 - 819 and r["delivered"] > 1000000, r
