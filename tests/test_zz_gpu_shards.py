@@ -30,60 +30,73 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 import wittgenstein_amd as w
 from wittgenstein_amd import shards
 import oracle_lib as o, parity
+import test_shards_loopback as tl
 o.build()
 out = {}
-# 1. the all-reduce thunk on device words (one rank: the sum is the value itself)
-fn = shards.make_allreduce(dist, device_memory=True)
-t = torch.arange(1000, dtype=torch.int32, device="cuda")
-out["thunk_rc"] = fn(None, C.c_void_p(t.data_ptr()), 1000)
-out["thunk_ok"] = bool((t.cpu().numpy() == np.arange(1000)).all())
-# 2. PingPong 1000 nodes (BASELINE config 1), runMs(50) x 10 in lock-step with the oracle
-p = w.PingPong(w.PingPongParameters(1000), seed=0, config=shards.config(dist)); p.init()
-c = o.PingPong(1000, seed=0)
-bad = []
-for _ in range(10):
-    p.network().runMs(50); c.run_ms(50)
-    bad += parity.diff_pingpong(p, c)
-out["pingpong_bad"] = bad[:5]
-out["pingpong_range"] = list(shards.shard_range(p.network()))
-out["pong0"] = int(p.network().read("pong")[0])
-out["pingpong_traffic"] = list(shards.traffic(p.network()))
-# 3. Handel in lock-step with the oracle to convergence
-out["handel"] = []
-for params in [(64, 57, 4, 50, 10, 20, 10, 6, 0), (256, 230, 4, 50, 10, 20, 10, 25, 100)]:
-    g, c = parity.handel_pair(params, seed=2, config=shards.config(dist, queue_cap=64))
+def leg1():
+    # 1. the all-reduce thunk on device words (one rank: the sum is the value itself)
+    fn = shards.make_allreduce(dist, device_memory=True)
+    t = torch.arange(1000, dtype=torch.int32, device="cuda")
+    out["thunk_rc"] = fn(None, C.c_void_p(t.data_ptr()), 1000)
+    out["thunk_ok"] = bool((t.cpu().numpy() == np.arange(1000)).all())
+def leg2():
+    # 2. PingPong 1000 nodes (BASELINE config 1), runMs(50) x 10 in lock-step with the oracle
+    p = w.PingPong(w.PingPongParameters(1000), seed=0, config=shards.config(dist)); p.init()
+    c = o.PingPong(1000, seed=0)
+    bad = []
+    for _ in range(10):
+        p.network().runMs(50); c.run_ms(50)
+        bad += parity.diff_pingpong(p, c)
+    out["pingpong_bad"] = bad[:5]
+    out["pingpong_range"] = list(shards.shard_range(p.network()))
+    out["pong0"] = int(p.network().read("pong")[0])
+    out["pingpong_traffic"] = list(shards.traffic(p.network()))
+def leg3():
+    # 3. Handel in lock-step with the oracle to convergence
+    out["handel"] = []
+    for params in [(64, 57, 4, 50, 10, 20, 10, 6, 0), (256, 230, 4, 50, 10, 20, 10, 25, 100)]:
+        g, c = parity.handel_pair(params, seed=2, config=shards.config(dist, queue_cap=64))
+        bad, k = [], 0
+        while c.cont_if() and k < 400 and not bad:
+            g.network().runMs(10); c.run_ms(10); k += 1
+            if k %% 5 == 0: bad += parity.diff_handel(g, c)
+        bad += parity.diff_handel(g, c)
+        dl = c.stats()["deliveredByLevel"]
+        out["handel"].append({"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
+                              "by_level": bool((g.network().delivered_by_level()[:len(dl)].astype(np.uint64) == dl).all()),
+                              "traffic": list(shards.traffic(g.network()))})
+def leg4():
+    # 4. GSFSignature in lock-step with the oracle to convergence
+    import test_gpu_gsf as tg
+    g, c = tg.pair((256, 250, 3, 50, 10, 10, 5), seed=3, config=shards.config(dist))
+    whole = shards.WholeNetwork(dist, g.network())
+    class G:
+        def network(self): return whole
     bad, k = [], 0
-    while c.cont_if() and k < 400 and not bad:
-        g.network().runMs(10); c.run_ms(10); k += 1
-        if k %% 5 == 0: bad += parity.diff_handel(g, c)
-    bad += parity.diff_handel(g, c)
-    dl = c.stats()["deliveredByLevel"]
-    out["handel"].append({"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
-                          "by_level": bool((g.network().delivered_by_level()[:len(dl)].astype(np.uint64) == dl).all()),
-                          "traffic": list(shards.traffic(g.network()))})
-# 4. GSFSignature in lock-step with the oracle to convergence
-import test_gpu_gsf as tg
-g, c = tg.pair((256, 250, 3, 50, 10, 10, 5), seed=3, config=shards.config(dist))
-whole = shards.WholeNetwork(dist, g.network())
-class G:
-    def network(self): return whole
-bad, k = [], 0
-while c.cont_if() and k < 600 and not bad:
-    g.network().runMs(5); c.run_ms(5); k += 1
-    if k %% 4 == 0: bad += tg.diff(G(), c)
-bad += tg.diff(G(), c)
-out["gsf"] = {"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
-              "traffic": list(shards.traffic(g.network()))}
-# 5. real shard-count invariance on the one GPU: k engines in this process, the all-reduce sums their buffers in place
-import test_shards_loopback as tl
-out["loopback"] = []
-for k, params in [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (256, 230, 4, 50, 10, 20, 10, 25, 100))]:
-    bad, traffic = tl.handel_loopback(k, params, seed=1, device_memory=True)
-    out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len(set(traffic)) == 1,
-                            "calls": traffic[0][0]})
-# 6. at a size the oracle cannot reach inside a test: 4 logical shards == the unsharded engine, bit for bit
-bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
-out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
+    while c.cont_if() and k < 600 and not bad:
+        g.network().runMs(5); c.run_ms(5); k += 1
+        if k %% 4 == 0: bad += tg.diff(G(), c)
+    bad += tg.diff(G(), c)
+    out["gsf"] = {"bad": bad[:5], "done": (not c.cont_if()) and (not g.cont_if()), "chunks": k,
+                  "traffic": list(shards.traffic(g.network()))}
+def leg5():
+    # 5. real shard-count invariance on the one GPU: k engines in this process, the all-reduce sums their buffers in place
+    out["loopback"] = []
+    for k, params in [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (256, 230, 4, 50, 10, 20, 10, 25, 100))]:
+        bad, traffic = tl.handel_loopback(k, params, seed=1, device_memory=True)
+        out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len(set(traffic)) == 1,
+                                "calls": traffic[0][0]})
+def leg6():
+    # 6. at a size the oracle cannot reach inside a test: 4 logical shards == the unsharded engine, bit for bit
+    bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
+    out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
+import traceback
+out["errors"] = {}
+for _name, _fn in [(k, v) for k, v in sorted(globals().items()) if k.startswith('leg') and callable(v)]:
+    try:
+        _fn()
+    except Exception:
+        out["errors"][_name] = traceback.format_exc()[-1500:]
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 '''
@@ -100,10 +113,12 @@ def result(tmp_path_factory):
 
 
 def test_allreduce_thunk_sums_device_words(result):
+    assert "leg1" not in result["errors"], result["errors"]["leg1"]
     assert result["thunk_rc"] == 0 and result["thunk_ok"]
 
 
 def test_sharded_pingpong_one_rank(result):
+    assert "leg2" not in result["errors"], result["errors"]["leg2"]
     assert result["pingpong_bad"] == []
     assert result["pingpong_range"] == [0, 1000] and result["pong0"] == 1000
     calls, words = result["pingpong_traffic"]
@@ -111,6 +126,7 @@ def test_sharded_pingpong_one_rank(result):
 
 
 def test_sharded_handel_one_rank(result):
+    assert "leg3" not in result["errors"], result["errors"]["leg3"]
     assert len(result["handel"]) == 2
     for r in result["handel"]:
         assert r["bad"] == [] and r["done"] and r["by_level"], r
@@ -118,16 +134,19 @@ def test_sharded_handel_one_rank(result):
 
 
 def test_sharded_gsf_one_rank(result):
+    assert "leg4" not in result["errors"], result["errors"]["leg4"]
     r = result["gsf"]
     assert r["bad"] == [] and r["done"] and r["traffic"][0] > 0, r
 
 
 def test_logical_shards_on_one_gpu(result):   # 2 and 4 shards of one Handel simulation on the one MI355X
+    assert "leg5" not in result["errors"], result["errors"]["leg5"]
     assert [r["k"] for r in result["loopback"]] == [2, 4]
     for r in result["loopback"]:
         assert r["bad"] == [] and r["same_collectives"] and r["calls"] > 0, r
 
 
 def test_four_logical_shards_equal_the_unsharded_engine_at_8192_nodes(result):
+    assert "leg6" not in result["errors"], result["errors"]["leg6"]
     r = result["vs_unsharded_8192"]
     assert r["bad"] == [] and r["done"] == 8192 - 819 and r["delivered"] > 1000000, r
