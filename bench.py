@@ -309,7 +309,27 @@ def main():
         prof_phase = sims[0].network().profile_read()
         del batch, sims
         gc.collect()  # Network <-> MessageStorage cycles hold ~15 GB of HBM per copy until collected
-    timed = [make_batch(w, n, seeds, local, args.init_threads, args.workload) for seeds in timed_seeds]
+    # Every copy of every timed step is resident in HBM before the timed region (init() is host work outside the hot
+    # path), so K steps of R copies must fit: measure what one step takes and, if K of them do not fit, run the timed
+    # steps with fewer copies per step rather than overrun the device (the JSON states the number used).
+    free0 = torch.cuda.mem_get_info()[0]
+    timed = [make_batch(w, n, timed_seeds[0], local, args.init_threads, args.workload)] if K > 0 else []
+    torch.cuda.synchronize()
+    per_copy = max(1, (free0 - torch.cuda.mem_get_info()[0]) // max(1, R))
+    fit = int(0.92 * free0 / per_copy) // max(1, K)
+    if K > 1 and fit < R:
+        if fit < 1:
+            raise SystemExit("bench.py: %d steps of one %d-node simulation (%.1f GB each) do not fit this GPU's %.0f GB; "
+                             "lower --steps" % (K, n, per_copy / 1e9, free0 / 1e9))
+        log("[rank %d] %d steps x %d copies x %.1f GB exceed the %.0f GB free: %d copies per timed step instead"
+            % (rank, K, R, per_copy / 1e9, free0 / 1e9, fit))
+        del timed
+        gc.collect()
+        R = fit
+        base = timed_seeds[0][0]
+        timed_seeds = [range(base + i * R, base + (i + 1) * R) for i in range(K)]
+        timed = [make_batch(w, n, timed_seeds[0], local, args.init_threads, args.workload)]
+    timed += [make_batch(w, n, seeds, local, args.init_threads, args.workload) for seeds in timed_seeds[1:]]
     inits += K * R
     init_s = (time.perf_counter() - t_init) / max(1, inits)
     log("[rank %d] init(): %.1f s per simulation amortised over %d host threads (outside the timed region)"
