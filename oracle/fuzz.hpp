@@ -64,6 +64,8 @@ class Fuzz {
     const int t = m.ttl - 1;
     switch (r % 8u) {
       case 0:
+        if (((r >> 20) % 16u) == 0) net.sendAll(msg(r, t > 2 ? 2 : t), to);  // a mid-run sendAll: N destinations, no delays
+        break;
       case 1: break;
       case 2: net.send(msg(r, t), to, node(r >> 3)); break;
       case 3: {

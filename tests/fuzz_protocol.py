@@ -72,7 +72,11 @@ class Fuzz:
             return
         r, t = to.h, m.ttl - 1
         k = r % 8
-        if k in (0, 1):
+        if k == 0:
+            if (r >> 20) % 16 == 0:
+                net.sendAll(self.msg(r, 2 if t > 2 else t), to)  # a mid-run sendAll: N destinations, no delays
+            return
+        if k == 1:
             return
         if k == 2:
             net.send(self.msg(r, t), to, self.node(r >> 3))

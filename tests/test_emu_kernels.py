@@ -153,3 +153,7 @@ def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the
 def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage + P/P2PFlood.java on the engine
     tpf.test_p2pflood_three_messages_by_distance()
     tpf.test_empty_destination_list_costs_a_draw()
+
+
+def test_sendall_expanded_on_the_device():
+    te.test_sendall_expanded_on_the_device_many_tiles()

@@ -475,6 +475,7 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   gh.rng = rd.s;
   gh.draws++;
   globalsDirty = true;
+  if (n >= sendExpandMin && delayBetween == 0 && shardCount == 0) return send_expanded(msg, payload, sendTime, from, dests, n, seed);
   // sender statistics are applied on the device at flush time; host keeps them in staged counters
   struct Arr {
     int32_t dest, arrival;
@@ -523,6 +524,88 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   }
   hc_push(da[0].arrival, make_rec(K_CHAIN, from, sc.slot, 0, 0));
   stagedChains.push_back(std::move(sc));
+}
+
+// A list send with many destinations (a protocol's sendAll): latencies, drops and the stable sort by arrival on the
+// device (k_send_expand_*), straight into the envelope's slice of the destination ring. The seed has been drawn.
+void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+                           int32_t seed) {
+  ensure_device();
+  if (!allocated || (unsigned long long)n > dev.chainDests)
+    throw WgError(WG_ENOMEM, "chain_dests too small for this multi-destination send");
+  pendingSent.push_back({from, (long long)n, msg});
+  Group g = self();
+  const uint32_t D = (uint32_t)dev.horizon;
+  const uint32_t nTiles = ((uint32_t)n + TILE - 1) / TILE;
+  if (expCap < (size_t)n) {  // scratch grows with the largest send seen
+    expCap = (size_t)n;
+    expIn = dalloc<int32_t>(expCap, false);
+    expLat = dalloc<int32_t>(expCap, false);
+    expHist = dalloc<uint32_t>((size_t)((expCap + TILE - 1) / TILE) * D, false);
+    if (!expResult) expResult = dalloc<int32_t>(2);
+  }
+  SendExpand x;
+  x.in = expIn;
+  x.lat = expLat;
+  x.hist = expHist;
+  x.result = expResult;
+  x.n = n;
+  x.from = from;
+  x.seed = seed;
+  x.destOff = gh.destHead % dev.chainDests;
+  WG_HIP(hipMemcpyAsync(expIn, dests, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+  const size_t lds = sizeof(uint32_t) * (size_t)D;
+  hipLaunchKernelGGL(k_send_expand_lat, dim3(std::min<uint32_t>(nTiles, GRID_TILES)), dim3(TILE), lds, stream, g.tab, x);
+  hipLaunchKernelGGL(k_send_expand_scan, dim3(1), dim3(1024), 0, stream, g.tab, x);
+  hipLaunchKernelGGL(k_send_expand_scatter, dim3(std::min<uint32_t>(nTiles, GRID_TILES)), dim3(TILE), lds, stream, g.tab, x, binBits);
+  int32_t res[2] = {0, 0};
+  WG_HIP(hipMemcpyAsync(res, expResult, sizeof(res), hipMemcpyDeviceToHost, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+  {  // (ERR_HORIZON from a latency beyond the bucket ring)
+    uint32_t err = 0;
+    WG_HIP(hipMemcpy(&err, (const char*)dev.g + offsetof(Globals, err), 4, hipMemcpyDeviceToHost));
+    if (err) {
+      gh.err |= err;
+      check_device_errors();
+    }
+  }
+  const int32_t m = res[0];
+  if (m <= 0) return;
+  if (sendTime <= time) throw WgError(WG_ESTATE, "sendTime=" + std::to_string(sendTime) + ", time=" + std::to_string(time));  // :471
+  const int32_t firstArrival = sendTime + res[1];
+  const bool needIds = m == 1 || dev.hostMode;
+  std::vector<int32_t> sorted;
+  if (needIds) {  // the host hands the hops out itself (host-callback mode), or the envelope degenerates to one destination
+    sorted.resize((size_t)m);
+    const unsigned long long off = x.destOff;
+    const size_t first = (size_t)std::min<unsigned long long>((unsigned long long)m, dev.chainDests - off);
+    WG_HIP(hipMemcpy(sorted.data(), dev.dests + off, 4 * first, hipMemcpyDeviceToHost));
+    if (first < (size_t)m) WG_HIP(hipMemcpy(sorted.data() + first, dev.dests, 4 * ((size_t)m - first), hipMemcpyDeviceToHost));
+  }
+  if (m == 1) {
+    hc_push(firstArrival, make_rec(K_MSG, from, (uint32_t)sorted[0], msg, payload));
+    return;
+  }
+  StagedChain sc;
+  sc.slot = gh.chainHead++ % dev.chainSlots;
+  sc.c.from = from;
+  sc.c.seed = seed;
+  sc.c.sendTime = sendTime;
+  sc.c.ndest = m;
+  sc.c.destOff = (uint32_t)x.destOff;
+  gh.destHead += (unsigned long long)m;
+  sc.c.msg = msg;
+  sc.c.payload = payload;
+  sc.c.flags = 1u;
+  globalsDirty = true;
+  if (dev.hostMode) {
+    if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
+    hostChains[sc.slot].live = true;
+    hostChains[sc.slot].c = sc.c;
+    hostChains[sc.slot].words = sorted;
+  }
+  hc_push(firstArrival, make_rec(K_CHAIN, from, sc.slot, 0, 0));
+  stagedChains.push_back(std::move(sc));  // (no words: the destinations are in the ring already)
 }
 
 void Engine::send_arrive_at(uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to) {  // :384-390

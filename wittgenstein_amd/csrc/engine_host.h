@@ -3,6 +3,7 @@
 // host (time, rd, node flags, staged envelopes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -87,6 +88,13 @@ class Engine {
   void send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
             int32_t delayBetween);
   void send_arrive_at(uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to);
+  // list sends with >= sendExpandMin destinations are resolved on the device (k_send_expand_*); WG_SEND_EXPAND_MIN
+  void send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+                     int32_t seed);
+  int32_t sendExpandMin = getenv("WG_SEND_EXPAND_MIN") ? atoi(getenv("WG_SEND_EXPAND_MIN")) : 64;
+  int32_t *expIn = nullptr, *expLat = nullptr, *expResult = nullptr;
+  uint32_t* expHist = nullptr;
+  size_t expCap = 0;
   void register_task(uint32_t task, uint32_t arg, int32_t startAt, int32_t node);
   void register_periodic_task(uint32_t task, int32_t startAt, int32_t period, int32_t node);
 

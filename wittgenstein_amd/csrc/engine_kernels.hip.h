@@ -723,6 +723,106 @@ __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// send expand: createMessageArrivals + its stable sort (C/Network.java:449-467) and the destination array of the
+// MultipleDestEnvelope (C/Envelope.java:66-81) for ONE host-issued multi-destination send (sendAll of a protocol's
+// init(), or any list send in host-callback mode) with many destinations: latency per destination (drops for
+// partitions / down nodes / msgDiscardTime as createMessageArrival :469-487), then a stable counting sort by
+// latency — the same tile histogram + wave-ballot rank multisplit as `append`, aimed at the envelope's slice of the
+// destination ring instead of the buckets. Equal arrivals keep the caller's order, as Java's stable sort does.
+struct SendExpand {
+  const int32_t* in;   // [n] destination ids in caller order
+  int32_t* lat;        // [n] scratch: latency, -1 = dropped
+  uint32_t* hist;      // [tiles][D] scratch
+  int32_t* result;     // [2]: reachable destinations m, smallest latency
+  int32_t n, from, seed;
+  unsigned long long destOff;
+};
+__global__ void __launch_bounds__(TILE) k_send_expand_lat(const EngineDev* __restrict__ tab, SendExpand x) {
+  const EngineDev& d = tab[0];
+  WG_DYN_LDS(uint32_t, hist);
+  const uint32_t D = (uint32_t)d.horizon;
+  const uint32_t nTiles = ((uint32_t)x.n + TILE - 1) / TILE;
+  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+    __syncthreads();
+    const uint32_t j = tile * TILE + threadIdx.x;
+    if (j < (uint32_t)x.n) {
+      const int32_t to = x.in[j];
+      int32_t nt = -1;
+      const NodeArrays& n = d.nodes;
+      if (n.part[x.from] == n.part[to] && !n.down[x.from] && !n.down[to]) {
+        nt = dev_latency(d, x.from, to, x.seed);
+        if (nt >= d.discardTime) nt = -1;
+      }
+      if (nt >= (int32_t)D) {  // (a hop that far ahead cannot be filed in the bucket ring either)
+        set_err(d.g, ERR_HORIZON);
+        nt = -1;
+      }
+      x.lat[j] = nt;
+      if (nt >= 0) atomicAdd(&hist[nt], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) x.hist[(size_t)tile * D + b] = hist[b];
+    __syncthreads();
+  }
+}
+// single block: per latency value the exclusive prefix over tiles, then over latency values
+__global__ void __launch_bounds__(1024) k_send_expand_scan(const EngineDev* __restrict__ tab, SendExpand x) {
+  const EngineDev& d = tab[0];
+  __shared__ uint32_t sh16[16];
+  __shared__ uint32_t shCarry;
+  __shared__ int32_t shMin;
+  const uint32_t D = (uint32_t)d.horizon;
+  const uint32_t nTiles = ((uint32_t)x.n + TILE - 1) / TILE;
+  if (threadIdx.x == 0) {
+    shCarry = 0;
+    shMin = INT32_MAX;
+  }
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < D; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    uint32_t tot = 0;
+    if (b < D)
+      for (uint32_t t = 0; t < nTiles; t++) {
+        const uint32_t h = x.hist[(size_t)t * D + b];
+        x.hist[(size_t)t * D + b] = tot;
+        tot += h;
+      }
+    uint32_t all;
+    const uint32_t before = block_excl_scan32_1024(tot, sh16, &all);
+    const uint32_t carry = shCarry;
+    if (b < D) {
+      for (uint32_t t = 0; t < nTiles; t++) x.hist[(size_t)t * D + b] += carry + before;
+      if (tot) atomicMin(&shMin, (int32_t)b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) shCarry = carry + all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    x.result[0] = (int32_t)shCarry;
+    x.result[1] = shMin;
+  }
+}
+__global__ void __launch_bounds__(TILE) k_send_expand_scatter(const EngineDev* __restrict__ tab, SendExpand x, int binBits) {
+  const EngineDev& d = tab[0];
+  WG_DYN_LDS(uint32_t, hist);
+  const uint32_t D = (uint32_t)d.horizon;
+  const uint32_t nTiles = ((uint32_t)x.n + TILE - 1) / TILE;
+  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+    __syncthreads();
+    const uint32_t j = tile * TILE + threadIdx.x;
+    const int32_t nt = j < (uint32_t)x.n ? x.lat[j] : -1;
+    const bool valid = nt >= 0;
+    const int bin = valid ? nt : 0;
+    const uint32_t rank = tile_rank(hist, bin, valid, binBits);
+    if (valid) d.dests[(x.destOff + x.hist[(size_t)tile * D + bin] + rank) % d.chainDests] = x.in[j];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
 // release the bucket's pages and bump the nextMessage() epoch if anything was polled.
 __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
