@@ -475,7 +475,7 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   gh.rng = rd.s;
   gh.draws++;
   globalsDirty = true;
-  if (n >= sendExpandMin && delayBetween == 0 && shardCount == 0) return send_expanded(msg, payload, sendTime, from, dests, n, seed);
+  if (n >= sendExpandMin && delayBetween == 0) return send_expanded(msg, payload, sendTime, from, dests, n, seed);
   // sender statistics are applied on the device at flush time; host keeps them in staged counters
   struct Arr {
     int32_t dest, arrival;
