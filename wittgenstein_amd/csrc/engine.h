@@ -255,7 +255,9 @@ struct EngineDev {
   // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.
   uint32_t sharded;
   int32_t shardLo, shardHi;
-  int32_t* xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1)
+  int32_t* xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1); preceded by
+                            // XB_HEAD header words (xbuf[-XB_HEAD] = multi-destination envelopes among the records),
+                            // which travel in the same all-reduce
   int32_t* xmulti;          // [maxMulti][XM_WORDS] exchange image of the multi-destination envelopes of a phase
   uint32_t maxMulti;
   uint32_t* multiK;         // [maxOut] ordinal of a fresh multi-destination record / offset of its destinations
@@ -265,6 +267,7 @@ struct EngineDev {
   int32_t* sdests;
   unsigned long long sdestCap;
 };
+constexpr int XB_HEAD = 4;                    // header words in front of EngineDev::xbuf (16-byte alignment kept)
 constexpr int XM_WORDS = 6 + 64;               // seed, sendTime, msg, payload, ndest, pad, dest[64]
 constexpr uint32_t MULTI_FRESH = 0xFFFFFFFFu;  // Rec::w3 of a K_CHAIN record whose envelope is yet to be created
 WG_HD inline bool shard_owns(const EngineDev& d, int32_t node) { return node >= d.shardLo && node < d.shardHi; }

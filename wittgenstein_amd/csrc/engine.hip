@@ -403,7 +403,7 @@ void Engine::ensure_device() {
   if (shardCount > 0) {
     dev.shardLo = (int32_t)((int64_t)n * shardIndex / shardCount);
     dev.shardHi = (int32_t)((int64_t)n * (shardIndex + 1) / shardCount);
-    dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5);
+    dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5 + XB_HEAD) + XB_HEAD;
     dev.maxMulti = std::max<uint32_t>(1024, maxOut / 16);
     dev.xmulti = dalloc<int32_t>((size_t)dev.maxMulti * XM_WORDS);
     dev.multiK = dalloc<uint32_t>(maxOut, false);
@@ -1005,12 +1005,13 @@ void Engine::shard_allreduce(void* buf, int64_t count) {
 // every shard, then the multi-destination envelopes among them
 void Engine::exchange_outbox(uint32_t nOut) {
   Group g = self();
-  shard_allreduce(dev.xbuf, 5 * (int64_t)nOut);
-  hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
-  if (!proto->emits_multi()) return;
+  shard_allreduce(dev.xbuf - XB_HEAD, XB_HEAD + 5 * (int64_t)nOut);
+  // the header word arrived with the records: how many of them are multi-destination envelopes still to be created
+  // (the collective has synchronised; no further stream synchronisation is needed to read it)
   uint32_t nMulti = 0;
-  WG_HIP(hipStreamSynchronize(stream));
-  WG_HIP(hipMemcpy(&nMulti, (const char*)dev.g + offsetof(Globals, nMulti), 4, hipMemcpyDeviceToHost));
+  WG_HIP(hipMemcpy(&nMulti, dev.xbuf - XB_HEAD, 4, hipMemcpyDeviceToHost));
+  WG_HIP(hipMemsetAsync(dev.xbuf - XB_HEAD, 0, sizeof(int32_t) * XB_HEAD, stream));  // for the next phase's producers
+  hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
   if (!nMulti) return;
   scan<MultiF>(g, nullptr);
   nMulti = std::min(nMulti, dev.maxMulti);
@@ -1045,8 +1046,13 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
       ProfScope ps(*this, PC_DELIVER);
       proto->launch_deliver(g);
     }
+    uint32_t* dSnap = proto->shard_snap_enqueue(g);  // (numbers this ms's payload rows; its count is read with nEvents)
     const uint32_t nEvents = scratch(&Globals::nEvents);
-    if (nEvents) proto->shard_post_deliver(*this, g);
+    if (dSnap && nEvents) {
+      uint32_t nSnap = 0;
+      WG_HIP(hipMemcpy(&nSnap, dSnap, 4, hipMemcpyDeviceToHost));
+      if (nSnap) proto->shard_snap_exchange(*this, g, nSnap);
+    }
     shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
     scan<RecsF>(g, nullptr);
     const uint32_t nOut = scratch(&Globals::nOut);
@@ -1624,15 +1630,13 @@ struct HandelHost : ProtoHost {
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
-  bool emits_multi() const override { return st.p.fastPath > 1; }
   // the dissemination snapshots written in this ms -> every shard's copy of the snapshot ring
-  void shard_post_deliver(Engine& e, const Group& g) override {
+  uint32_t* shard_snap_enqueue(const Group& g) override {
+    Engine::scan<HandelSnapF>(g, (const HandelState*)g.stab);
+    return st.nSnap;
+  }
+  void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    Engine::scan<HandelSnapF>(g, stab);
-    uint32_t nSnap = 0;
-    WG_HIP(hipStreamSynchronize(g.stream));
-    WG_HIP(hipMemcpy(&nSnap, st.nSnap, 4, hipMemcpyDeviceToHost));
-    if (!nSnap) return;
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
     e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
@@ -1897,14 +1901,12 @@ struct GsfHost : ProtoHost {
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
-  bool emits_multi() const override { return st.p.acceleratedCallsCount > 1; }
-  void shard_post_deliver(Engine& e, const Group& g) override {  // the doCycle snapshots (PARTIAL payloads) of this ms
+  uint32_t* shard_snap_enqueue(const Group& g) override {  // the doCycle snapshots (PARTIAL payloads) of this ms
+    Engine::scan<GsfSnapF>(g, (const GsfState*)g.stab);
+    return st.nSnap;
+  }
+  void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
     const GsfState* stab = (const GsfState*)g.stab;
-    Engine::scan<GsfSnapF>(g, stab);
-    uint32_t nSnap = 0;
-    WG_HIP(hipStreamSynchronize(g.stream));
-    WG_HIP(hipMemcpy(&nSnap, st.nSnap, 4, hipMemcpyDeviceToHost));
-    if (!nSnap) return;
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
     e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);

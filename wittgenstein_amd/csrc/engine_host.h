@@ -62,9 +62,11 @@ struct ProtoHost {
   // node-range sharding (wg_shard_configure): the protocol's kernels touch only the nodes the engine links into
   // its inbox lists, its payloads are self-contained and it has no conditional-task phase
   virtual bool supports_shards() const { return false; }
-  virtual bool emits_multi() const { return false; }   // its action()s issue multi-destination sends
-  // after the delivery kernels of a ms: payloads written by this shard's action()s that other shards will read
-  virtual void shard_post_deliver(Engine&, const Group&) {}
+  // after the delivery kernels of a ms: payloads written by this shard's action()s that other shards will read.
+  // enqueue numbers the rows on the device and returns where their count will be (NULL: the protocol has none);
+  // exchange ships `nSnap` rows (called only when there are any)
+  virtual uint32_t* shard_snap_enqueue(const Group&) { return nullptr; }
+  virtual void shard_snap_exchange(Engine&, const Group&, uint32_t /*nSnap*/) {}
   // the conditional-task phase on a sharded engine: leaves the task records of this shard's nodes in the exchange
   // image (EngineDev::xbuf) and returns the (replicated) number of records; only called when has_cond()
   virtual uint32_t shard_cond(Engine&, const Group&) { return 0; }

@@ -432,6 +432,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           // exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push order
           fin = make_rec(K_CHAIN, from, (uint32_t)m, 0, MULTI_FRESH);
           arrival = arv[0];
+          atomicAdd(&d.xbuf[-XB_HEAD], 1);  // header word of the exchange image: envelopes to create (rare)
         } else if (m > 1) {
           uint32_t slot = atomicAdd(&d.g->chainHead, 1u) % d.chainSlots;
           if (d.chains[slot].flags & 1u) {
@@ -512,7 +513,6 @@ __global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restric
     d.fin[p] = fin;
     d.arr[p] = arrival;
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
-    if (arrival >= 0 && rec_kind(fin) == K_CHAIN && fin.w3 == MULTI_FRESH) atomicAdd(&d.g->nMulti, 1u);  // rare
   }
 }
 
