@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <mutex>
+#include <functional>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #if !defined(__x86_64__)
@@ -244,12 +246,57 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
   memmove(dst, src, n);
   return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, n, k); }
+// ---- stream capture / graphs (see hip_runtime.h)
+struct emuGraph {
+  std::vector<std::function<void()>> ops;
+};
+static emuGraph* g_capture = nullptr;
+namespace emu {
+bool capturing() { return g_capture != nullptr; }
+void record(std::function<void()> f) { g_capture->ops.push_back(std::move(f)); }
+}  // namespace emu
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+  if (g_capture) return hipErrorInvalidValue;
+  g_capture = new emuGraph();
+  return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+  *g = g_capture;
+  g_capture = nullptr;
+  return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+  *e = new emuGraph(*g);
+  return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  if (getenv("EMU_TRACE_GRAPH")) fprintf(stderr, "emu: hipGraphLaunch of %zu recorded operations\n", e->ops.size());
+  for (auto& f : e->ops) f();
+  return hipSuccess;
+}
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) {
+  delete e;
+  return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) {
+  delete g;
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t) {
+  if (g_capture) return hipErrorInvalidValue;  // (the engine captures no copies)
+  return hipMemcpy(dst, src, n, k);
+}
 hipError_t hipMemset(void* dst, int v, size_t n) {
   memset(dst, v, n);
   return hipSuccess;
 }
-hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { return hipMemset(dst, v, n); }
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) {
+  if (g_capture) {
+    g_capture->ops.push_back([=]() { memset(dst, v, n); });
+    return hipSuccess;
+  }
+  return hipMemset(dst, v, n);
+}
 hipError_t hipStreamCreate(hipStream_t* s) {
   *s = new emuStream();
   return hipSuccess;

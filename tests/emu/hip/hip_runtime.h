@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <type_traits>
 #include <utility>
+#include <functional>
+#include <tuple>
 
 #define WG_EMU 1
 
@@ -69,6 +71,17 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipMemGetInfo(size_t* freeB, size_t* totalB);
+// stream capture / graphs: while a stream is capturing, launches and async memsets are recorded instead of executed;
+// hipGraphLaunch replays the record (what the engine's WG_GRAPH=1 path relies on)
+typedef struct emuGraph* hipGraph_t;
+typedef struct emuGraph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t);
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
+hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+hipError_t hipGraphDestroy(hipGraph_t g);
 
 namespace emu {
 struct Idx3 {
@@ -218,8 +231,24 @@ inline typename std::common_type<A, B>::type max(A a, B b) {
 
 // ---- launch
 namespace emu {
+bool capturing();
+void record(std::function<void()> f);
 template <class... KArgs, class... Args>
-inline void launch_kernel(void (*k)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t, Args&&... args) {
+inline void launch_kernel(void (*k)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+  if (capturing()) {  // copy the arguments: the record outlives this call
+    std::tuple<std::decay_t<KArgs>...> copy(static_cast<KArgs>(args)...);
+    record([=]() {
+      std::apply([&](auto&... a) {
+        auto call = [&]() { k(a...); };
+        typedef decltype(call) L;
+        Thunk t;
+        t.fn = [](void* c) { (*(L*)c)(); };
+        t.ctx = &call;
+        launch(grid, block, lds, t);
+      }, const_cast<std::tuple<std::decay_t<KArgs>...>&>(copy));
+    });
+    return;
+  }
   auto call = [&]() { k(static_cast<KArgs>(args)...); };
   typedef decltype(call) L;
   Thunk t;

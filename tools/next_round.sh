@@ -20,6 +20,11 @@ if [ -s $OUT/pmc_FETCH_SIZE.md ] && [ -s $OUT/pmc_WRITE_SIZE.md ]; then
 fi
 timeout 600 python bench.py --mode shard --gpus 1 --steps 1 --warmup 1 --no-cpu > $OUT/bench_shard1.json 2> $OUT/bench_shard1.err
 echo "shard1 rc=$?"; cat $OUT/bench_shard1.json
+# hipGraph A/B (value only: the HIP-event roofline bracket is off under WG_GRAPH) on the launch-bound GSFSignature config
+for gr in 0 1; do
+  WG_GRAPH=$gr timeout 300 python bench.py --workload gsf --nodes 4096 --replicas 16 --no-cpu > $OUT/bench_gsf_graph$gr.json 2> $OUT/bench_gsf_graph$gr.err
+  echo "gsf graph=$gr rc=$?"; cat $OUT/bench_gsf_graph$gr.json
+done
 # the same simulation as 4 node-range shards on this one GPU (in-process loopback all-reduce): the exchange volumes and
 # the owner split at full size, without xGMI
 timeout 600 python bench.py --mode shard --gpus 1 --logical-shards 4 --steps 1 --warmup 0 --no-cpu > $OUT/bench_shard4_logical.json 2> $OUT/bench_shard4_logical.err

@@ -1346,21 +1346,52 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
   WG_HIP(hipMalloc((void**)&dRunning, sizeof(uint32_t)));
   const int CHECK_EVERY = 4;
   uint32_t running = (uint32_t)n;
-  while (running) {
-    for (int k = 0; k < CHECK_EVERY; k++) {
-      hipLaunchKernelGGL(k_chunk_begin, dim3(n), dim3(64), 0, g.stream, tab, chunk);
-      Engine::enqueue_ms_sequence(l, g, chunk);
-      WG_HIP(hipMemsetAsync(dCont, 0, sizeof(uint32_t) * n, g.stream));
-      if (!l.proto->launch_cont_if(g, dCont)) {
-        (void)hipFree(dRunning);
-        throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+  // one runMs(chunk) of every member: the same launch sequence every time (the kernels read the clock and the loop
+  // state from device memory), which is what makes it a graph
+  auto enqueue_chunk = [&]() {
+    hipLaunchKernelGGL(k_chunk_begin, dim3(n), dim3(64), 0, g.stream, tab, chunk);
+    Engine::enqueue_ms_sequence(l, g, chunk);
+    WG_HIP(hipMemsetAsync(dCont, 0, sizeof(uint32_t) * n, g.stream));
+    if (!l.proto->launch_cont_if(g, dCont))
+      throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
+    WG_HIP(hipMemsetAsync(dRunning, 0, sizeof(uint32_t), g.stream));
+    hipLaunchKernelGGL(k_chunk_end, dim3(n), dim3(64), 0, g.stream, tab, dCont, maxTime, dRunning);
+  };
+  // WG_GRAPH=1: the chunk is captured once into a hipGraph and replayed — one graph launch instead of ~30 kernel
+  // launches per simulated ms (off by default; not with the HIP-event profiler, whose events would be re-recorded)
+  static const bool wantGraph = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  try {
+    if (wantGraph && !l.profiling) {
+      WG_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeRelaxed));
+      try {
+        enqueue_chunk();
+      } catch (...) {
+        (void)hipStreamEndCapture(g.stream, &graph);
+        throw;
       }
-      WG_HIP(hipMemsetAsync(dRunning, 0, sizeof(uint32_t), g.stream));
-      hipLaunchKernelGGL(k_chunk_end, dim3(n), dim3(64), 0, g.stream, tab, dCont, maxTime, dRunning);
+      WG_HIP(hipStreamEndCapture(g.stream, &graph));
+      WG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     }
-    WG_HIP(hipMemcpyAsync(&running, dRunning, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-    WG_HIP(hipStreamSynchronize(g.stream));
+    while (running) {
+      for (int k = 0; k < CHECK_EVERY; k++) {
+        if (exec)
+          WG_HIP(hipGraphLaunch(exec, g.stream));
+        else
+          enqueue_chunk();
+      }
+      WG_HIP(hipMemcpyAsync(&running, dRunning, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+      WG_HIP(hipStreamSynchronize(g.stream));
+    }
+  } catch (...) {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipFree(dRunning);
+    throw;
   }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
   (void)hipFree(dRunning);
   if (l.profiling) l.prof_collect();
   hTab.clear();  // the device table now carries halted flags the host shadow does not
