@@ -106,8 +106,16 @@ int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, 
 /* ---- resident protocols ----------------------------------------------------------------- */
 typedef enum {
   WG_PROTO_HOST = 0, /* no resident protocol: Message.action() stays with the caller (wg_next_delivery below) */
-  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3
+  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3, WG_PROTO_SANFERMIN = 4
 } wg_proto_id;
+
+/* San Fermin parameters: SanFerminSignatureParameters ctor order (P/SanFerminSignature.java:84-104; shuffledLists is
+ * read nowhere in the protocol). nodeCount must be a power of two (toBinaryID, P/SanFerminHelper.java:158-171).
+ * No init state: the nodes' swap state starts from constants (:202-219); init() registers goNextLevel at t = 1 for
+ * every node (:139-141) = wg_register_task(e, 0, 0, 1, node) in id order. */
+typedef struct {
+  int32_t nodeCount, threshold, pairingTime, signatureSize, replyTimeout, candidateCount;
+} wg_sanfermin_params;
 
 /* Handel parameters: HandelParameters ctor order (P/Handel.java:97-142) + WindowParameters (:147-174) */
 typedef struct {
@@ -248,7 +256,11 @@ typedef enum {
   /* GSFSignature GSFNode (P/GSFSignature.java:166-175): sigChecked, sigQueueSize, toVerify.size(),
    * verifiedSignatures.cardinality() */
   WG_F_GSF_SIG_CHECKED = 48, WG_F_GSF_SIG_QUEUE_SIZE = 49, WG_F_GSF_TO_VERIFY_SIZE = 50,
-  WG_F_GSF_VERIFIED_CARDINALITY = 51
+  WG_F_GSF_VERIFIED_CARDINALITY = 51,
+  /* San Fermin SanFerminNode (P/SanFerminSignature.java:149-221): aggValue, currentPrefixLength, done |
+   * thresholdDone << 1 | isSwapping << 2, sentRequests, receivedRequests, thresholdAt */
+  WG_F_SF_AGG_VALUE = 64, WG_F_SF_PREFIX_LENGTH = 65, WG_F_SF_FLAGS = 66, WG_F_SF_SENT_REQUESTS = 67,
+  WG_F_SF_RECEIVED_REQUESTS = 68, WG_F_SF_THRESHOLD_AT = 69
 } wg_field;
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */

@@ -6,6 +6,7 @@
  *   PingPong.init()  P/PingPong.java:81-87
  *   Handel.init()    P/Handel.java:957-1014  (+ HandelParameters checks :113-125)
  *   GSFSignature.init()  P/GSFSignature.java:611-635  (+ GSFSignatureParameters checks :69-74)
+ *   SanFerminSignature ctor + init()  P/SanFerminSignature.java:113-141
  * (P/ = protocols/src/main/java/net/consensys/wittgenstein/protocols/)
  */
 #ifndef WITTGPU_HOST_H
@@ -25,6 +26,10 @@ int32_t wgh_handel_create(const wg_handel_params* params, const char* nodeBuilde
                           int64_t seed, const wg_config* cfg, wg_engine** out);
 int32_t wgh_gsf_create(const wg_gsf_params* params, const char* nodeBuilderName, const char* latencyName,
                        int64_t seed, const wg_config* cfg, wg_engine** out);
+/* new SanFerminSignature(params) — which builds the nodes from the fresh Network's rd, new Random(0) (:126-131) —
+ * then, as RunMultipleTimes does, rd.setSeed(seed) and init() (P/SanFerminSignature.java:113-141) */
+int32_t wgh_sanfermin_create(const wg_sanfermin_params* params, const char* nodeBuilderName, const char* latencyName,
+                             int64_t seed, const wg_config* cfg, wg_engine** out);
 const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);

@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_zt_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_zv_gpu_p2pflood as tpf  # noqa: E402
 import test_zw_gpu_sanfermin as tsf  # noqa: E402
 import test_zy_gpu_fuzz as tf  # noqa: E402
@@ -157,3 +158,17 @@ def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage 
 
 def test_sendall_expanded_on_the_device():
     te.test_sendall_expanded_on_the_device_many_tiles()
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_sanfermin_resident_tiny(n):  # P/SanFerminSignature.java resident on the device vs oracle/sanfermin.hpp
+    tsr.test_tiny_networks(n)
+
+
+@pytest.mark.parametrize("cand", [1, 3])
+def test_sanfermin_resident_candidates(cand):
+    tsr.test_candidate_counts_shuffle_draws(cand)
+
+
+def test_sanfermin_resident_fixed_latency():
+    tsr.test_fixed_latency_short_timeout_and_threshold()

@@ -88,9 +88,10 @@ struct Out {
   uint32_t b;         // SEND/MULTI: payload | TASK: arg | PERIODIC: period
   int32_t t;          // SEND/MULTI: sendTime | TASK/PERIODIC: arrival
   uint32_t destOff;   // MULTI: offset of the (unsorted) dest list in the dest ring
-  uint32_t drawsub;   // ordinal of this record's rd.nextInt() among the event's draws
-  uint32_t pad;
+  uint32_t drawsub;   // ordinal of this record's first rd draw among the event's draws
+  uint32_t pad;       // flags: OUT_SHUFFLE
 };
+constexpr uint32_t OUT_SHUFFLE = 1u;  // MULTI: Collections.shuffle(dests, rd) precedes the send (n - 1 draws, then the seed)
 
 // per-event side data written by expand (16 bytes, one store)
 struct EvAux {

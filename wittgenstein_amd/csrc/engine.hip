@@ -312,7 +312,7 @@ void Engine::ensure_device() {
     case LAT_ETHSCAN: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 4 * maxExtra; break;
     case LAT_IC3: maxLat = 175 + 2 * maxExtra; break;
   }
-  uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms : next_pow2((uint32_t)std::max(256, maxLat + 8));
+  uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms : next_pow2((uint32_t)std::max({256, maxLat + 8, horizonFloor}));
   if ((D & (D - 1)) != 0 || D > 32768) throw WgError(WG_EINVAL, "horizon_ms must be a power of two <= 32768");
   binBits = 0;
   while ((1u << binBits) < D) binBits++;
@@ -819,6 +819,9 @@ void Engine::load_protocol(int32_t id, const void* params, const void* initState
   } else if (id == WG_PROTO_GSF) {
     if (!params || !initState) throw WgError(WG_EINVAL, "GSFSignature needs wg_gsf_params and wg_gsf_init_state");
     proto = make_gsf_host(*this, *(const wg_gsf_params*)params, *(const wg_gsf_init_state*)initState);
+  } else if (id == WG_PROTO_SANFERMIN) {
+    if (!params) throw WgError(WG_EINVAL, "San Fermin needs wg_sanfermin_params");
+    proto = make_sanfermin_host(*this, *(const wg_sanfermin_params*)params);
   } else {
     throw WgError(WG_EINVAL, "unknown protocol id");
   }
@@ -2013,5 +2016,94 @@ struct GsfHost : ProtoHost {
 };
 
 ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st) { return new GsfHost(e, p, st); }
+
+}  // namespace wg
+
+// ================================================================================================
+// San Fermin resident protocol: host side
+#include "proto_sanfermin.hip.h"
+
+namespace wg {
+
+struct SfHost : ProtoHost {
+  SfState st{};
+  Engine& eng;
+  uint32_t* dCont = nullptr;
+  SfHost(Engine& e, const wg_sanfermin_params& p) : eng(e) {
+    const int32_t N = p.nodeCount;
+    if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "San Fermin nodeCount != nodes in the network");
+    if (N < 2 || (N & (N - 1)))
+      throw WgError(WG_EUNSUPPORTED, "San Fermin needs a power-of-two nodeCount (toBinaryID, P/SanFerminHelper.java:158-171)");
+    if (p.candidateCount < 0 || p.candidateCount > 62)
+      throw WgError(WG_EUNSUPPORTED, "candidateCount > 62 (device multi-destination sends hold <= 64 ids)");
+    if (p.pairingTime <= 0 || p.replyTimeout <= 0) throw WgError(WG_EINVAL, "pairingTime / replyTimeout");
+    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "San Fermin does not run on a sharded engine yet");
+    int P = 0;
+    while ((1 << (P + 1)) <= N) P++;
+    if (!e.allocated) e.horizonFloor = std::max(e.horizonFloor, std::max(p.replyTimeout, p.pairingTime) + 8);  // its tasks' delays
+    e.ensure_device();
+    if (p.replyTimeout >= e.dev.horizon - 1 || p.pairingTime >= e.dev.horizon - 1)
+      throw WgError(WG_ENOMEM, "horizon_ms <= replyTimeout: raise wg_config.horizon_ms");
+    st.p = p;
+    st.N = N;
+    st.P = P;
+    st.W = N >= 64 ? N / 64 : 1;
+    st.cpl = e.dalloc<int32_t>(N);
+    st.agg = e.dalloc<int32_t>(N);
+    st.sentReq = e.dalloc<int32_t>(N);
+    st.recvReq = e.dalloc<int32_t>(N);
+    st.thresholdAt = e.dalloc<int32_t>(N);
+    st.flags = e.dalloc<uint32_t>(N);
+    st.cacheMask = e.dalloc<uint32_t>(N);
+    st.cache = e.dalloc<int32_t>((size_t)N * (P + 1));
+    st.used = e.dalloc<uint64_t>((size_t)N * st.W);
+    st.pending = e.dalloc<uint64_t>((size_t)N * st.W);
+    e.dev.boundMsg = 2;  // a reply | a transition task | a request (one multi-destination send) + its timeout task
+    for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 2;
+    hipLaunchKernelGGL(k_sf_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st);
+    WG_HIP(hipStreamSynchronize(e.stream));
+  }
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL((k_deliver<SfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                       (const SfState*)g.stab, 0);
+  }
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
+  int host_msg_size(uint32_t) const override { return 4 + st.p.signatureSize; }
+  int levels() const override { return st.P; }
+  bool launch_cont_if(const Group& g, uint32_t* dOut) override {
+    hipLaunchKernelGGL(k_sf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, (const SfState*)g.stab, dOut);
+    return true;
+  }
+  bool cont_if(Engine& e, int32_t* out) override {
+    if (!dCont) dCont = e.dalloc<uint32_t>(1);
+    Group g = e.self();
+    WG_HIP(hipMemsetAsync(dCont, 0, 4, e.stream));
+    launch_cont_if(g, dCont);
+    uint32_t v = 0;
+    WG_HIP(hipMemcpyAsync(&v, dCont, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    *out = (int32_t)v;
+    return true;
+  }
+  bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
+    const void* src = nullptr;
+    switch (field) {
+      case WG_F_SF_AGG_VALUE: src = st.agg; break;
+      case WG_F_SF_PREFIX_LENGTH: src = st.cpl; break;
+      case WG_F_SF_FLAGS: src = st.flags; break;
+      case WG_F_SF_SENT_REQUESTS: src = st.sentReq; break;
+      case WG_F_SF_RECEIVED_REQUESTS: src = st.recvReq; break;
+      case WG_F_SF_THRESHOLD_AT: src = st.thresholdAt; break;
+      default: return false;
+    }
+    std::vector<int32_t> h(n);
+    WG_HIP(hipMemcpy(h.data(), src, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) dst[i] = h[i];
+    return true;
+  }
+};
+
+ProtoHost* make_sanfermin_host(Engine& e, const wg_sanfermin_params& p) { return new SfHost(e, p); }
 
 }  // namespace wg

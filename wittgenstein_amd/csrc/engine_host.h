@@ -169,6 +169,7 @@ class Engine {
   int32_t time = 0;              // Network.time
   int32_t discardTime = INT32_MAX;
   int32_t binBits = 0;
+  int32_t horizonFloor = 0;      // a resident protocol's longest task delay (default horizon_ms only)
   uint32_t maxTiles = 0;
   // host copies of node fields (send-time decisions of host-side sends)
   std::vector<int32_t> hx, hy, hextra;
@@ -273,5 +274,6 @@ ProtoHost* make_pingpong_host(Engine& e);
 ProtoHost* make_host_proto(Engine& e);
 ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st);
 ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st);
+ProtoHost* make_sanfermin_host(Engine& e, const wg_sanfermin_params& p);
 
 }  // namespace wg

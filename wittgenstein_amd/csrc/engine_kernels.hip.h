@@ -393,6 +393,28 @@ __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, i
   return m;
 }
 
+// A multi-destination send whose action() shuffled the list with the shared rd just before sending
+// (Collections.shuffle(newList, rd) — P/SanFerminHelper.java:144, C/messages/FloodMessage.java:52): the permutation
+// only decides the order of the destinations, so it is deferred to here, where the rd index of the event's draws is
+// known: for (i = n; i > 1; i--) swap(list, i-1, rd.nextInt(i)), in the scratch ring, then the seed draw. Returns the
+// draws consumed (n - 1). A nextInt(bound) rejection (bound not a power of two, p < 2^-30 per draw) would shift every
+// later draw of the ms: flagged, the run fails loudly rather than diverge.
+__device__ __forceinline__ uint32_t shuffle_dests(const EngineDev& d, const Out& o, uint32_t drawIdx) {
+  const int n = o.to < 64 ? o.to : 64;
+  uint64_t st = lcg_skip(d.g->rng, (uint64_t)drawIdx);
+  for (int i = n; i > 1; i--) {
+    int consumed;
+    const int32_t j = lcg_next_int_bounded(st, i, &consumed);
+    if (consumed != 1) set_err(d.g, ERR_PROTOCOL);
+    const unsigned long long a = (o.destOff + (unsigned long long)(i - 1)) % d.sdestCap;
+    const unsigned long long b = (o.destOff + (unsigned long long)j) % d.sdestCap;
+    const int32_t x = d.sdests[a];
+    d.sdests[a] = d.sdests[b];
+    d.sdests[b] = x;
+  }
+  return n > 1 ? (uint32_t)(n - 1) : 0u;
+}
+
 // SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
 // emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
@@ -421,7 +443,9 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         break;
       }
       case O_MULTI: {  // delaysBetweenMessage == 0 only (device actions); stable sort by arrival (:464)
-        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
+        uint32_t drawIdx = d.evDrawOff[e] + o.drawsub;
+        if (o.pad & OUT_SHUFFLE) drawIdx += shuffle_dests(d, o, drawIdx);  // Collections.shuffle(dests, rd) first
+        int32_t seed = draw_next_int(d, drawIdx);
         int32_t dst[64], arv[64];
         const int m = resolve_multi(d, o, from, seed, dst, arv);
         if (m == 1) {
@@ -553,7 +577,9 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
     if (!shard_owns(d, (int32_t)d.ev[e].w1)) continue;  // (the image is zero on entry)
     const Out o = d.outTmp[d.evAux[e].outBase + (p - d.evRecOff[e])];
     const int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
-    const int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
+    // (a shuffled list was permuted in the scratch ring by k_resolve<true> already; its draws precede the seed)
+    const uint32_t shuffled = (o.pad & OUT_SHUFFLE) && o.to > 1 ? (uint32_t)((o.to < 64 ? o.to : 64) - 1) : 0u;
+    const int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub + shuffled);
     int32_t dst[64], arv[64];
     const int m = resolve_multi(d, o, from, seed, dst, arv);
     int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
@@ -898,7 +924,8 @@ struct Ctx {
   uint32_t outBase, outCap;      // the event's private outbox slice
   long long msgSent, bytesSent;  // accumulated Node counters (C/Network.java:476-477)
 
-  __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw) {
+  __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw,
+                      uint32_t pad = 0, uint32_t extraDraws = 0) {
     if (sub < outCap && outBase + sub < d.maxOut) {
       // the 32-byte record as ONE memory instruction: lanes 0 and 1 store 16 bytes each
       U4 q;
@@ -911,14 +938,14 @@ struct Ctx {
         q.x = (uint32_t)tt;
         q.y = destOff;
         q.z = draws;
-        q.w = 0;
+        q.w = pad;
       }
       if (WG_LANE < 2) ((U4*)&d.outTmp[outBase + sub])[WG_LANE] = q;
     } else if (WG_LANE == 0) {
       set_err(d.g, ERR_OUTBOX);  // the protocol's emission bound (EngineDev::boundMsg/boundTask) is wrong
     }
     if (sub < outCap) sub++;
-    if (draw) draws++;
+    if (draw) draws += 1 + extraDraws;
   }
   // Network.send(m, this, to): sendTime = time + 1, one rd.nextInt() (C/Network.java:364-382)
   __device__ void send(int32_t to, uint32_t msg, uint32_t payload, int size) {
@@ -977,6 +1004,23 @@ struct Ctx {
       }
       put(O_MULTI, n, msg, payload, t + 1, destOff, true);
     }
+  }
+  // Collections.shuffle(dests, rd); network.send(m, this, dests): the shuffle's n - 1 draws and the permutation are
+  // deferred to `resolve` (shuffle_dests); the list at destOff is in the order the action built it
+  __device__ void send_list_shuffled(uint32_t destOff, int n, uint32_t msg, uint32_t payload, int size) {
+    if (n == 0) return;
+    msgSent += n;
+    bytesSent += (long long)n * size;
+    if (n == 1) {
+      int32_t to = __hip_atomic_load(&d.sdests[destOff % d.sdestCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      put(O_SEND, to, msg, payload, t + 1, 0, true);
+      return;
+    }
+    if (n > 64) {
+      if (WG_LANE == 0) set_err(d.g, ERR_MULTI_TOO_BIG);
+      n = 64;
+    }
+    put(O_MULTI, n, msg, payload, t + 1, destOff, true, OUT_SHUFFLE, (uint32_t)(n - 1));
   }
   // Network.registerTask(r, startAt, this) (:505-508)
   __device__ void register_task(int32_t startAt, uint32_t word, uint32_t arg) {

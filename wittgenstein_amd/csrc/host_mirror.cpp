@@ -287,6 +287,41 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   return WG_OK;
 }
 
+int32_t wgh_sanfermin_create(const wg_sanfermin_params* pp, const char* nodeBuilderName, const char* latencyName,
+                             int64_t seed, const wg_config* cfg, wg_engine** out) {
+  if (!out || !pp) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  const wg_sanfermin_params p = *pp;
+  const int32_t N = p.nodeCount;
+  if (N < 2 || __builtin_popcount((unsigned)N) != 1) {
+    g_err = "San Fermin needs a power-of-two nodeCount (toBinaryID, P/SanFerminHelper.java:158-171)";
+    return WG_EUNSUPPORTED;
+  }
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // ctor :113-120
+  JavaRandom rd(0);                            // the ctor builds the nodes from the fresh Network's rd (:126-131) ...
+  NodeSoA nodes;
+  for (int i = 0; i < N; i++) build_node(rd, b, nodes);
+  CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
+                  nodes.speed.data()));
+  CK(wg_rng_set_seed(e, seed));                // ... rd.setSeed(i) comes after it (C/RunMultipleTimes.java:44-48)
+  CK(wg_protocol_load(e, WG_PROTO_SANFERMIN, &p, nullptr));
+  for (int i = 0; i < N; i++) CK(wg_register_task(e, /*goNextLevel*/ 0u, 0u, 1, i));  // init() :139-141
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
 int32_t wgh_gsf_create(const wg_gsf_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
                        const wg_config* cfg, wg_engine** out) {
   if (!out || !pp) return WG_EINVAL;
