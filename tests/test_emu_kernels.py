@@ -157,7 +157,8 @@ def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage 
 
 
 def test_sendall_expanded_on_the_device():
-    te.test_sendall_expanded_on_the_device_many_tiles()
+    import test_zs_gpu_send_expand as tse
+    tse.test_sendall_expanded_on_the_device_many_tiles()
 
 
 @pytest.mark.parametrize("n", [2, 8])

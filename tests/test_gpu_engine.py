@@ -254,17 +254,3 @@ def test_pingpong_chunking_and_seeds(chunk):
             t += chunk
         assert not parity.diff_pingpong(g, c)
 
-
-@pytest.mark.gpu
-def test_sendall_expanded_on_the_device_many_tiles():
-    """a sendAll of 5000 destinations — createMessageArrivals + its stable sort on the device (k_send_expand_*: five
-    tiles of the counting sort) — against the oracle; drops at send time (partitions, stopped nodes, discard time) go
-    through the same kernels in tests/test_zy_gpu_fuzz.py"""
-    g = w.PingPong(w.PingPongParameters(5000, parity.NB, parity.NL), seed=4)
-    g.init()
-    c = o.PingPong(5000, parity.NB, parity.NL, seed=4)
-    for _ in range(8):
-        g.network().runMs(60)
-        c.run_ms(60)
-        assert not parity.diff_pingpong(g, c)
-    assert g.network().read("pong")[0] > 4000

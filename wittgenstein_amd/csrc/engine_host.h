@@ -91,9 +91,10 @@ class Engine {
             int32_t delayBetween);
   void send_arrive_at(uint32_t msg, uint32_t payload, int32_t arriveAt, int32_t from, int32_t to);
   // list sends with >= sendExpandMin destinations are resolved on the device (k_send_expand_*); WG_SEND_EXPAND_MIN
+  // (below it the host's latency loop + stable sort is as fast as three launches and a read-back)
   void send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
                      int32_t seed);
-  int32_t sendExpandMin = getenv("WG_SEND_EXPAND_MIN") ? atoi(getenv("WG_SEND_EXPAND_MIN")) : 64;
+  int32_t sendExpandMin = getenv("WG_SEND_EXPAND_MIN") ? atoi(getenv("WG_SEND_EXPAND_MIN")) : 4096;
   int32_t *expIn = nullptr, *expLat = nullptr, *expResult = nullptr;
   uint32_t* expHist = nullptr;
   size_t expCap = 0;
