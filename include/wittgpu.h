@@ -106,8 +106,20 @@ int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, 
 /* ---- resident protocols ----------------------------------------------------------------- */
 typedef enum {
   WG_PROTO_HOST = 0, /* no resident protocol: Message.action() stays with the caller (wg_next_delivery below) */
-  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3, WG_PROTO_SANFERMIN = 4
+  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3, WG_PROTO_SANFERMIN = 4, WG_PROTO_CASPER = 5
 } wg_proto_id;
+
+/* Casper IMD parameters: CasperParemeters ctor order (sic, P/CasperIMD.java:52-70), then the delay of the
+ * ByzBlockProducerWF that init(badNode) starts with (:475-479 uses 0) and a capacity: the run may reach slot maxSlots
+ * (a slot is 8000 ms; attestation and block tables are sized by it). Nodes: 0 the observer, 1 the byzantine producer,
+ * 2..blockProducersCount the other producers, then cycleLength * attestersPerRound attesters (:481-509).
+ * randomOnTies != 0 is WG_EUNSUPPORTED (the tie's rd.nextBoolean() decides a head inside action()). init() =
+ * wg_register_periodic_task per node in the reference's order: task words 2 (byzantine producer), 0 (producer), 1 (attester). */
+typedef struct {
+  int32_t cycleLength, randomOnTies, blockProducersCount, attestersPerRound, blockConstructionTime,
+      attestationConstructionTime;
+  int32_t byzDelay, maxSlots;
+} wg_casper_params;
 
 /* San Fermin parameters: SanFerminSignatureParameters ctor order (P/SanFerminSignature.java:84-104; shuffledLists is
  * read nowhere in the protocol). nodeCount must be a power of two (toBinaryID, P/SanFerminHelper.java:158-171).
@@ -260,7 +272,11 @@ typedef enum {
   /* San Fermin SanFerminNode (P/SanFerminSignature.java:149-221): aggValue, currentPrefixLength, done |
    * thresholdDone << 1 | isSwapping << 2, sentRequests, receivedRequests, thresholdAt */
   WG_F_SF_AGG_VALUE = 64, WG_F_SF_PREFIX_LENGTH = 65, WG_F_SF_FLAGS = 66, WG_F_SF_SENT_REQUESTS = 67,
-  WG_F_SF_RECEIVED_REQUESTS = 68, WG_F_SF_THRESHOLD_AT = 69
+  WG_F_SF_RECEIVED_REQUESTS = 68, WG_F_SF_THRESHOLD_AT = 69,
+  /* Casper IMD CasperNode (P/CasperIMD.java:177-368): head.height, head.proposalTime, head.id (creation order, genesis 0),
+   * attestationsByHead.size(), blocksReceivedByBlockId.size(), attestations held (all heads) */
+  WG_F_CASPER_HEAD_HEIGHT = 80, WG_F_CASPER_HEAD_TIME = 81, WG_F_CASPER_HEAD_ID = 82, WG_F_CASPER_HEADS_ATTESTED = 83,
+  WG_F_CASPER_BLOCKS_RECEIVED = 84, WG_F_CASPER_ATTESTATIONS_HELD = 85
 } wg_field;
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */

@@ -30,6 +30,10 @@ int32_t wgh_gsf_create(const wg_gsf_params* params, const char* nodeBuilderName,
  * then, as RunMultipleTimes does, rd.setSeed(seed) and init() (P/SanFerminSignature.java:113-141) */
 int32_t wgh_sanfermin_create(const wg_sanfermin_params* params, const char* nodeBuilderName, const char* latencyName,
                              int64_t seed, const wg_config* cfg, wg_engine** out);
+/* new CasperIMD(params) — which builds the observer from new Random(0) (:80-87) — rd.setSeed(seed), init(new
+ * ByzBlockProducerWF(params->byzDelay)) (P/CasperIMD.java:481-509) */
+int32_t wgh_casper_create(const wg_casper_params* params, const char* nodeBuilderName, const char* latencyName,
+                          int64_t seed, const wg_config* cfg, wg_engine** out);
 const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);

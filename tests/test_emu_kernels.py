@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_zr_gpu_casper_resident as tcr  # noqa: E402
 import test_zt_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_zv_gpu_p2pflood as tpf  # noqa: E402
 import test_zw_gpu_sanfermin as tsf  # noqa: E402
@@ -173,3 +174,8 @@ def test_sanfermin_resident_candidates(cand):
 
 def test_sanfermin_resident_fixed_latency():
     tsr.test_fixed_latency_short_timeout_and_threshold()
+
+
+def test_casper_resident():  # P/CasperIMD.java resident on the device vs oracle/casper.hpp (two blocks, one WF far task)
+    tcr.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=1500, chunks=18)
+    tcr.test_random_on_ties_is_refused()

@@ -1,0 +1,79 @@
+"""Casper IMD (P/CasperIMD.java) RESIDENT on the device (wittgenstein_amd/csrc/proto_casper.hip.h: attestation sets as
+bitsets over an attestation index, sendAll resolved by k_sendall_*, 8-second periodic tasks through the far buffer) vs
+the CPU oracle (oracle/casper.hpp, pinned against PT/CasperIMDTest / PT/CasperByzantineTest). After every chunk, per node:
+msgReceived / msgSent / bytesSent / bytesReceived, head (height, proposalTime, id), attestationsByHead.size(), blocks
+received, attestations held — the observables of PT/CasperIMDTest.java:263-274 — plus network.time and the rd state."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from wittgenstein_amd import protocols as P
+from wittgenstein_amd.core import UnsupportedError
+
+FIELDS = ["msgReceived", "msgSent", "bytesSent", "bytesReceived", "headHeight", "headProposalTime", "headId",
+          "attestationsByHeadSize", "blocksReceived", "attestationsHeld", "x", "y"]
+
+
+def diff(g, c):
+    net, out = g.network(), []
+    for f in FIELDS:
+        a, b = net.read(f), c.read(f)
+        bad = np.nonzero(a != b)[0]
+        if len(bad):
+            out.append("%s: %d nodes differ, first node %d: device %d oracle %d" % (f, len(bad), bad[0], a[bad[0]], b[bad[0]]))
+    i = c.info()
+    if (net.time, net.rng_state()) != (i["time"], i["rng"]):
+        out.append("time / rd: device %r oracle %r" % ((net.time, net.rng_state()), i))
+    return out
+
+
+def lockstep(params, seed, chunk, chunks, byz_delay=0, nl=None, max_slots=16):
+    """params = CasperParemeters ctor order: (cycleLength, randomOnTies, blockProducersCount, attestersPerRound,
+    blockConstructionTime, attestationConstructionTime)"""
+    g = P.CasperIMD(P.CasperParemeters(*params, None, nl), seed=seed, byz_delay=byz_delay, max_slots=max_slots)
+    g.init()
+    c = o.CasperIMD(params, None, nl, seed=seed, byz_delay=byz_delay)
+    assert not diff(g, c), "after init()"
+    for k in range(chunks):
+        g.network().runMs(chunk)
+        c.run_ms(chunk)
+        d = diff(g, c)
+        assert not d, "t=%d: %s" % (g.network().time, d)
+    return g, c
+
+
+@pytest.mark.gpu
+def test_casper_small():
+    g, c = lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=25)
+    assert c.read("headHeight")[0] >= 5 and c.info()["delivered"] > 400
+
+
+@pytest.mark.gpu
+def test_casper_byzantine_delay():  # ByzBlockProducerWF(-2000), PT/CasperByzantineTest.java:41
+    lockstep((3, False, 3, 8, 1000, 1), seed=9, chunk=1000, chunks=60, byz_delay=-2000)
+
+
+@pytest.mark.gpu
+def test_casper_reference_test_parameters():  # PT/CasperIMDTest.java:10-11: 5 producers, 5 x 80 attesters
+    g, c = lockstep((5, False, 5, 80, 1000, 1), seed=0, chunk=4000, chunks=12)
+    assert g.network().node_count == 406 and c.info()["delivered"] > 150000
+    assert g.network().read("headHeight")[0] == 5
+
+
+@pytest.mark.gpu
+def test_casper_4096_attesters_a_slot_runs():  # one round of BASELINE config 5's attesters per slot, 2 cycles of 2 slots
+    g = P.CasperIMD(P.CasperParemeters(2, False, 2, 4096, 1000, 1), seed=1, max_slots=8)
+    g.init()
+    net = g.network()
+    net.runMs(22000)
+    n = net.node_count
+    assert n == 1 + 2 + 8192
+    assert net.read("headHeight")[0] == 2                      # the observer follows the chain
+    assert int(net.read("attestationsHeld").min()) >= 4096     # every node holds the first round's attestations
+    assert net.last_stats["delivered"] > 2 * 4096 * n * 0.9    # two rounds of sendAll, minus what is still in flight
+
+
+@pytest.mark.gpu
+def test_random_on_ties_is_refused():
+    with pytest.raises(UnsupportedError):
+        P.CasperIMD(P.CasperParemeters(2, True, 2, 6, 1000, 1)).init()

@@ -75,7 +75,7 @@ struct Chain {  // 32 bytes
   uint32_t flags;     // bit0: busy, bit1: explicit arrivals (MultipleDestWithDelayEnvelope :157-228)
 };
 
-enum OutKind : uint32_t { O_SEND = 0, O_MULTI = 1, O_TASK = 2, O_PERIODIC = 3, O_CHAINCONT = 4 };
+enum OutKind : uint32_t { O_SEND = 0, O_MULTI = 1, O_TASK = 2, O_PERIODIC = 3, O_CHAINCONT = 4, O_SENDALL = 5 };
 
 // 32-byte outbox record written by action() code. It lives at outTmp[evOutBase[event] + sub]: every
 // event owns a private slice of the outbox sized by the protocol's emission bound for that kind of
@@ -172,6 +172,8 @@ struct Globals {
   // (replicated), and this shard's private scratch-ring head for the unsorted destination lists of its action()s
   uint32_t nMulti, nMultiDests;
   unsigned long long localDestHead;
+  uint32_t nSendAll;       // Network.sendAll calls made by action()s in this phase (k_sendall_*), reset by k_end_phase
+  uint32_t nFar;           // records parked in EngineDev::farBuf since the host last collected them
 };
 
 struct LatencyModel {
@@ -267,6 +269,32 @@ struct EngineDev {
   // the envelope ring itself, or — sharded, where that ring is replicated state — a private scratch ring
   int32_t* sdests;
   unsigned long long sdestCap;
+  // Network.sendAll issued by an action() (O_SENDALL): every node is a destination, so the envelope is resolved by
+  // k_sendall_* after `resolve` (one descriptor per call, latency scratch and tile histograms per descriptor);
+  // maxSendAll == 0: the resident protocol never calls it
+  struct SendAllDesc* saDesc;
+  int32_t* saLat;           // [maxSendAll][n]
+  uint32_t* saHist;         // [maxSendAll][tiles(n)][D]
+  uint32_t maxSendAll;
+  struct FarRec* farBuf;    // NULL: arrivals beyond the ring are an error
+  uint32_t farCap;
+};
+// An envelope an action() registered for a time beyond the bucket ring (a task seconds ahead: Casper's 8 s slots): parked
+// here, collected by the host every `horizon` ms of simulated time and staged like a host-side registration — it is
+// injected before any device push can reach its bucket, so the bucket's push order is what the reference's would be
+// provided arrival - time >= 2 * horizon (else ERR_HORIZON, as without the buffer).
+struct FarRec {  // 32 bytes
+  int32_t ms;              // Network.time when it was pushed
+  uint32_t p;              // its position in that ms's ordered outbox
+  Rec rec;
+  int32_t arrival;
+  uint32_t pad;
+};
+struct SendAllDesc {  // 32 bytes
+  uint32_t p;               // position in the ordered outbox
+  int32_t from, seed, sendTime;
+  uint32_t slot, msg, payload, pad;
+  unsigned long long destOff;
 };
 constexpr int XB_HEAD = 4;                    // header words in front of EngineDev::xbuf (16-byte alignment kept)
 constexpr int XM_WORDS = 6 + 64;               // seed, sendTime, msg, payload, ndest, pad, dest[64]

@@ -312,7 +312,8 @@ void Engine::ensure_device() {
     case LAT_ETHSCAN: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 4 * maxExtra; break;
     case LAT_IC3: maxLat = 175 + 2 * maxExtra; break;
   }
-  uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms : next_pow2((uint32_t)std::max({256, maxLat + 8, horizonFloor}));
+  uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms
+                                  : next_pow2((uint32_t)std::max({256, maxLat + 8 + horizonExtra, horizonFloor}));
   if ((D & (D - 1)) != 0 || D > 32768) throw WgError(WG_EINVAL, "horizon_ms must be a power of two <= 32768");
   binBits = 0;
   while ((1u << binBits) < D) binBits++;
@@ -391,6 +392,22 @@ void Engine::ensure_device() {
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D);
   dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID);
+  dev.farBuf = nullptr;
+  dev.farCap = 0;
+  if (farCapacity > 0) {
+    dev.farCap = (uint32_t)farCapacity;
+    dev.farBuf = dalloc<FarRec>(dev.farCap, false);
+  }
+  dev.saDesc = nullptr;
+  dev.saLat = nullptr;
+  dev.saHist = nullptr;
+  dev.maxSendAll = 0;
+  if (sendAllCapacity > 0) {  // (a resident protocol whose action()s call Network.sendAll asked for it)
+    dev.maxSendAll = (uint32_t)sendAllCapacity;
+    dev.saDesc = dalloc<SendAllDesc>(dev.maxSendAll);
+    dev.saLat = dalloc<int32_t>((size_t)dev.maxSendAll * n, false);
+    dev.saHist = dalloc<uint32_t>((size_t)dev.maxSendAll * ((n + TILE - 1) / TILE) * D, false);
+  }
   dev.sharded = shardCount > 0 ? 1u : 0u;
   dev.shardLo = 0;
   dev.shardHi = INT32_MAX;
@@ -822,6 +839,9 @@ void Engine::load_protocol(int32_t id, const void* params, const void* initState
   } else if (id == WG_PROTO_SANFERMIN) {
     if (!params) throw WgError(WG_EINVAL, "San Fermin needs wg_sanfermin_params");
     proto = make_sanfermin_host(*this, *(const wg_sanfermin_params*)params);
+  } else if (id == WG_PROTO_CASPER) {
+    if (!params) throw WgError(WG_EINVAL, "Casper IMD needs wg_casper_params");
+    proto = make_casper_host(*this, *(const wg_casper_params*)params);
   } else {
     throw WgError(WG_EINVAL, "unknown protocol id");
   }
@@ -855,6 +875,26 @@ void Engine::run_ms(int32_t ms, uint8_t* didSomething, wg_run_stats* stats) {
   run_group(&me, 1, nullptr, g, ms, didSomething, stats);
 }
 
+// Envelopes the device parked beyond the bucket ring (FarRec) become host-held envelopes, in push order (ms, then
+// position in that ms's ordered outbox); flush_staged injects them when their bucket comes into range.
+void Engine::collect_far() {
+  if (!dev.farBuf) return;
+  WG_HIP(hipStreamSynchronize(stream));
+  uint32_t n = 0;
+  WG_HIP(hipMemcpy(&n, (const char*)dev.g + offsetof(Globals, nFar), 4, hipMemcpyDeviceToHost));
+  if (!n) return;
+  if (n > dev.farCap) throw WgError(WG_ENOMEM, "more envelopes registered beyond horizon_ms than the far buffer holds");
+  std::vector<FarRec> recs(n);
+  WG_HIP(hipMemcpy(recs.data(), dev.farBuf, sizeof(FarRec) * n, hipMemcpyDeviceToHost));
+  const uint32_t zero = 0;
+  WG_HIP(hipMemcpy((char*)dev.g + offsetof(Globals, nFar), &zero, 4, hipMemcpyHostToDevice));
+  std::sort(recs.begin(), recs.end(), [](const FarRec& a, const FarRec& b) { return a.ms != b.ms ? a.ms < b.ms : a.p < b.p; });
+  for (const FarRec& r : recs) {
+    staged.push_back({r.arrival, r.rec});
+    stagedMin = std::min(stagedMin, r.arrival);
+  }
+}
+
 // One simulated ms: drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the new `now`.
 static void enqueue_one_ms(Engine& lead, const Group& g) {
   ProtoHost* proto = lead.proto;
@@ -875,6 +915,12 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
       hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
+    }
+    if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
+      ProfScope ps(lead, Engine::PC_RESOLVE);
+      hipLaunchKernelGGL(k_sendall_lat, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab);
+      hipLaunchKernelGGL(k_sendall_scan, dim3(GRID_DELIVER_SMALL / 8 > 0 ? GRID_DELIVER_SMALL / 8 : 1, g.R), dim3(1024), 0, g.stream, g.tab);
+      hipLaunchKernelGGL(k_sendall_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
@@ -929,6 +975,8 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
       for (int r = 0; r < R; r++) {
         Engine& e = *es[r];
         const int32_t t = e.time + k;
+        // (a parked envelope is >= 2 * horizon ms ahead of its push: collecting every horizon ms is early enough)
+        if (on[r] && e.dev.farBuf && (t % e.dev.horizon) == 0) e.collect_far();
         if (on[r] && e.stagedMin - t < e.dev.horizon) {
           WG_HIP(hipStreamSynchronize(g.stream));
           e.flush_staged(t, true);
@@ -949,6 +997,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
       continue;
     }
     Engine& e = *es[r];
+    e.collect_far();
     e.sync_globals_to_host();
     e.time = endAt[r];
     if (did) did[r] = e.gh.anyEvent ? 1 : 0;
@@ -1334,6 +1383,8 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
     e.flush_staged(e.time, false);
     if (e.stagedMin != INT32_MAX) hostLoop = true;  // envelopes held on the host beyond the bucket ring
   }
+  for (int r = 0; r < n; r++)
+    if (members[r]->dev.farBuf) hostLoop = true;  // its far envelopes are collected by the host between milliseconds
   if (hostLoop) throw WgError(WG_EUNSUPPORTED, "host-held envelopes beyond horizon_ms: use wg_batch_run_ms per chunk");
   for (int r = 0; r < n; r++) {
     Engine& e = *members[r];
@@ -2105,5 +2156,109 @@ struct SfHost : ProtoHost {
 };
 
 ProtoHost* make_sanfermin_host(Engine& e, const wg_sanfermin_params& p) { return new SfHost(e, p); }
+
+}  // namespace wg
+
+// ================================================================================================
+// Casper IMD resident protocol: host side
+#include "proto_casper.hip.h"
+
+namespace wg {
+
+struct CasperHost : ProtoHost {
+  CasperState st{};
+  Engine& eng;
+  CasperHost(Engine& e, const wg_casper_params& p) : eng(e) {
+    const int32_t N = 1 + p.blockProducersCount + p.cycleLength * p.attestersPerRound;
+    if ((int32_t)e.hx.size() != N)
+      throw WgError(WG_EINVAL, "Casper IMD: the network must hold 1 observer + blockProducersCount + cycleLength * attestersPerRound nodes");
+    if (p.cycleLength <= 0 || p.blockProducersCount <= 0 || p.attestersPerRound <= 0 || p.maxSlots <= 0)
+      throw WgError(WG_EINVAL, "Casper IMD parameters");
+    if (p.randomOnTies)
+      throw WgError(WG_EUNSUPPORTED, "randomOnTies: the tie's rd.nextBoolean() decides a head inside action() (not resident)");
+    if (p.blockConstructionTime <= 0 || p.attestationConstructionTime <= 0)
+      throw WgError(WG_EUNSUPPORTED, "construction times must be >= 1 ms (a sendAll for the current ms would have to be delivered in it)");
+    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "Casper IMD does not run on a sharded engine yet");
+    if (!e.allocated) {
+      e.sendAllCapacity = p.attestersPerRound + 2;  // one round of attesters votes in the same ms (+ a block)
+      // every in-flight sendAll holds N destinations until its last hop: one slot's worth of them is in flight at most
+      const int64_t need = (int64_t)(p.attestersPerRound + 4) * N * 2;
+      if (e.cfg.chain_dests == 0) e.cfg.chain_dests = std::max<int64_t>(1 << 20, need);
+      if (e.cfg.outbox_records == 0)  // chain runs: every in-flight envelope delivers ~N / latency-spread hops per ms
+        e.cfg.outbox_records = std::max<int64_t>(1 << 16, (int64_t)(p.attestersPerRound + 4) * N / 8 + 4 * (int64_t)N);
+      if (e.cfg.chain_slots == 0) e.cfg.chain_slots = std::max(4096, 64 * (p.attestersPerRound + 4));
+      // a sendAll's first hop arrives construction time + latency ahead: the bucket ring must reach that far; the
+      // periodic re-arms (>= 8 s) and the byzantine producer's delayed build go through the far buffer
+      e.horizonExtra = std::max(e.horizonExtra, std::max(p.blockConstructionTime, p.attestationConstructionTime) + 1);
+      e.farCapacity = std::max(e.farCapacity, 4 * N + 1024);
+    }
+    e.ensure_device();
+    if (e.dev.maxSendAll == 0) throw WgError(WG_ESTATE, "load the Casper protocol before the engine allocates");
+    st.p = p;
+    st.N = N;
+    st.B = p.maxSlots + 8;
+    st.A = p.maxSlots * p.attestersPerRound;
+    st.Aw = (st.A + 63) / 64;
+    st.Bw = (st.B + 63) / 64;
+    st.head = e.dalloc<int32_t>(N);
+    st.recv = e.dalloc<uint64_t>((size_t)N * st.Aw);
+    st.blkRecv = e.dalloc<uint64_t>((size_t)N * st.Bw);
+    st.reeval = e.dalloc<uint64_t>((size_t)N * st.Bw);
+    st.headsAtt = e.dalloc<uint64_t>((size_t)N * st.Bw);
+    st.wf = e.dalloc<int32_t>(4);
+    st.bHeight = e.dalloc<int32_t>(st.B);
+    st.bParent = e.dalloc<int32_t>(st.B);
+    st.bProducer = e.dalloc<int32_t>(st.B);
+    st.bTime = e.dalloc<int32_t>(st.B);
+    st.nBlocks = e.dalloc<uint32_t>(1);
+    st.lastBlockMs = e.dalloc<int32_t>(1);
+    st.blockAtt = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
+    st.headMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
+    st.attestsMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
+    st.attHead = e.dalloc<int32_t>(st.A);
+    e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
+    for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
+    hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st);
+    WG_HIP(hipStreamSynchronize(e.stream));
+  }
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                       (const CasperState*)g.stab, 0);
+  }
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
+  bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
+    if (field < WG_F_CASPER_HEAD_HEIGHT || field > WG_F_CASPER_ATTESTATIONS_HELD) return false;
+    std::vector<int32_t> head(n), bh(st.B), bt(st.B);
+    WG_HIP(hipMemcpy(head.data(), st.head, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(bh.data(), st.bHeight, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(bt.data(), st.bTime, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
+    auto popcounts = [&](const uint64_t* rows, int words) {
+      std::vector<uint64_t> h((size_t)n * words);
+      WG_HIP(hipMemcpy(h.data(), rows, 8 * h.size(), hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) {
+        int64_t t = 0;
+        for (int w = 0; w < words; w++) t += __builtin_popcountll(h[(size_t)i * words + w]);
+        dst[i] = t;
+      }
+    };
+    switch (field) {
+      case WG_F_CASPER_HEAD_HEIGHT:
+        for (int i = 0; i < n; i++) dst[i] = bh[head[i]];
+        return true;
+      case WG_F_CASPER_HEAD_TIME:
+        for (int i = 0; i < n; i++) dst[i] = bt[head[i]];
+        return true;
+      case WG_F_CASPER_HEAD_ID:
+        for (int i = 0; i < n; i++) dst[i] = head[i];
+        return true;
+      case WG_F_CASPER_HEADS_ATTESTED: popcounts(st.headsAtt, st.Bw); return true;
+      case WG_F_CASPER_BLOCKS_RECEIVED: popcounts(st.blkRecv, st.Bw); return true;
+      default: popcounts(st.recv, st.Aw); return true;
+    }
+  }
+};
+
+ProtoHost* make_casper_host(Engine& e, const wg_casper_params& p) { return new CasperHost(e, p); }
 
 }  // namespace wg

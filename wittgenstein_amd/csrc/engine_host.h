@@ -170,6 +170,10 @@ class Engine {
   int32_t time = 0;              // Network.time
   int32_t discardTime = INT32_MAX;
   int32_t binBits = 0;
+  int32_t farCapacity = 0;       // > 0: envelopes registered beyond the bucket ring are parked for the host (FarRec)
+  int32_t horizonExtra = 0;      // the longest sendTime - time a resident protocol's sends use (added to the latency bound)
+  void collect_far();            // FarRec -> staged (host-held) envelopes
+  int32_t sendAllCapacity = 0;   // Network.sendAll calls per simulated ms a resident protocol's action()s may make
   int32_t horizonFloor = 0;      // a resident protocol's longest task delay (default horizon_ms only)
   uint32_t maxTiles = 0;
   // host copies of node fields (send-time decisions of host-side sends)
@@ -276,5 +280,6 @@ ProtoHost* make_host_proto(Engine& e);
 ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_handel_init_state& st);
 ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st);
 ProtoHost* make_sanfermin_host(Engine& e, const wg_sanfermin_params& p);
+ProtoHost* make_casper_host(Engine& e, const wg_casper_params& p);
 
 }  // namespace wg

@@ -487,6 +487,37 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         fin = make_rec(K_PERIODIC, from, (uint32_t)o.to, o.a, o.b);
         arrival = o.t;
         break;
+      case O_SENDALL: {  // Network.sendAll(m, sendTime, from) inside an action(): N destinations, resolved by k_sendall_*
+        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
+        if (SH || d.maxSendAll == 0) {
+          set_err(d.g, ERR_MULTI_TOO_BIG);
+          break;
+        }
+        const uint32_t k = atomicAdd(&d.g->nSendAll, 1u);
+        if (k >= d.maxSendAll) {
+          set_err(d.g, ERR_MULTI_TOO_BIG);
+          break;
+        }
+        const uint32_t slot = atomicAdd(&d.g->chainHead, 1u) % d.chainSlots;
+        if (d.chains[slot].flags & 1u) {
+          set_err(d.g, ERR_CHAIN_SLOTS);
+          break;
+        }
+        SendAllDesc sd;
+        sd.p = p;
+        sd.from = from;
+        sd.seed = seed;
+        sd.sendTime = o.t;
+        sd.slot = slot;
+        sd.msg = o.a;
+        sd.payload = o.b;
+        sd.pad = 0;
+        sd.destOff = atomicAdd(&d.g->destHead, (unsigned long long)d.nodes.n) % d.chainDests;
+        d.saDesc[k] = sd;
+        d.fin[p] = make_rec(K_CHAIN, from, slot, 0, 0);
+        d.arr[p] = -1;  // k_sendall_scan files the arrival of the first hop (and the histogram entry)
+        continue;
+      }
       default: {  // O_CHAINCONT: msgs.addMsg(m) after markRead (C/Network.java:629-632)
         const Chain c = d.chains[o.to];
         fin = make_rec(K_CHAIN, from, (uint32_t)o.to, o.a, 0);
@@ -495,13 +526,28 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
     }
     if (arrival >= 0) {
       if (arrival < t) {
+#ifdef WG_EMU
+        if (getenv("WG_DEBUG_PAST")) fprintf(stderr, "PAST: p=%u kind=%u from=%d to=%d a=%u b=%u o.t=%d arrival=%d t=%d\n", p, kind, from, o.to, o.a, o.b, o.t, arrival, t);
+#endif
         set_err(d.g, ERR_ARRIVAL_PAST);
         arrival = -1;
       } else if (arrival == t) {
         set_err(d.g, ERR_SAME_MS);
         arrival = -1;
       } else if (arrival - t >= d.horizon) {
-        set_err(d.g, ERR_HORIZON);
+        uint32_t k = 0xFFFFFFFFu;
+        if (!SH && d.farBuf && arrival - t >= 2 * d.horizon) k = atomicAdd(&d.g->nFar, 1u);
+        if (k < d.farCap) {  // parked for the host (FarRec): not filed in a bucket now
+          FarRec fr;
+          fr.ms = t;
+          fr.p = p;
+          fr.rec = fin;
+          fr.arrival = arrival;
+          fr.pad = 0;
+          d.farBuf[k] = fr;
+        } else {
+          set_err(d.g, ERR_HORIZON);
+        }
         arrival = -1;
       }
     }
@@ -848,6 +894,130 @@ __global__ void __launch_bounds__(TILE) k_send_expand_scatter(const EngineDev* _
   }
 }
 
+// The same three steps for the Network.sendAll calls an action() made in this phase (O_SENDALL): destinations are all
+// nodes in id order (C/Network.java:341-347); one descriptor per call, blockIdx.y strides over the descriptors. The scan
+// step also creates the envelope and files the arrival of its first hop in the ordered outbox (+ tile histogram).
+__global__ void __launch_bounds__(TILE) k_sendall_lat(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  WG_DYN_LDS(uint32_t, hist);
+  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
+  for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
+    const uint32_t k = wi / nTiles, tile = wi % nTiles;
+    const SendAllDesc sd = d.saDesc[k];
+    {
+      for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+      __syncthreads();
+      const uint32_t to = tile * TILE + threadIdx.x;
+      if (to < N) {
+        int32_t nt = -1;
+        const NodeArrays& n = d.nodes;
+        if (n.part[sd.from] == n.part[to] && !n.down[sd.from] && !n.down[to]) {
+          nt = dev_latency(d, sd.from, (int32_t)to, sd.seed);
+          if (nt >= d.discardTime) nt = -1;
+        }
+        if (nt >= (int32_t)D) {
+          set_err(d.g, ERR_HORIZON);
+          nt = -1;
+        }
+        d.saLat[(size_t)k * N + to] = nt;
+        if (nt >= 0) atomicAdd(&hist[nt], 1u);
+      }
+      __syncthreads();
+      for (uint32_t b = threadIdx.x; b < D; b += TILE) d.saHist[((size_t)k * nTiles + tile) * D + b] = hist[b];
+      __syncthreads();
+    }
+  }
+}
+__global__ void __launch_bounds__(1024) k_sendall_scan(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  __shared__ uint32_t sh16[16];
+  __shared__ uint32_t shCarry;
+  __shared__ int32_t shMin;
+  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
+  const int32_t t = d.g->now;
+  for (uint32_t k = blockIdx.x; k < nSA; k += gridDim.x) {
+    const SendAllDesc sd = d.saDesc[k];
+    uint32_t* H = d.saHist + (size_t)k * nTiles * D;
+    if (threadIdx.x == 0) {
+      shCarry = 0;
+      shMin = INT32_MAX;
+    }
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < D; b0 += 1024) {
+      const uint32_t b = b0 + threadIdx.x;
+      uint32_t tot = 0;
+      if (b < D)
+        for (uint32_t tl = 0; tl < nTiles; tl++) {
+          const uint32_t h = H[(size_t)tl * D + b];
+          H[(size_t)tl * D + b] = tot;
+          tot += h;
+        }
+      uint32_t all;
+      const uint32_t before = block_excl_scan32_1024(tot, sh16, &all);
+      const uint32_t carry = shCarry;
+      if (b < D) {
+        for (uint32_t tl = 0; tl < nTiles; tl++) H[(size_t)tl * D + b] += carry + before;
+        if (tot) atomicMin(&shMin, (int32_t)b);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) shCarry = carry + all;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const int32_t m = (int32_t)shCarry;
+      int32_t arrival = -1;
+      if (m > 0) {
+        arrival = sd.sendTime + shMin;
+        if (arrival <= t) {  // (sendAll(m, sendTime, from) with sendTime <= time throws in the reference, :471)
+          set_err(d.g, arrival == t ? ERR_SAME_MS : ERR_ARRIVAL_PAST);
+          arrival = -1;
+        } else if (arrival - t >= d.horizon) {
+          set_err(d.g, ERR_HORIZON);
+          arrival = -1;
+        }
+      }
+      if (arrival >= 0) {
+        Chain c;
+        c.from = sd.from;
+        c.seed = sd.seed;
+        c.sendTime = sd.sendTime;
+        c.ndest = m;
+        c.destOff = (uint32_t)sd.destOff;
+        c.msg = sd.msg;
+        c.payload = sd.payload;
+        c.flags = 1u;
+        d.chains[sd.slot] = c;  // (a single reachable destination stays a one-hop envelope: same delivery)
+        d.arr[sd.p] = arrival;
+        atomicAdd(&d.tileHist[(size_t)(sd.p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __restrict__ tab, int binBits) {
+  WG_ENGINE(tab);
+  WG_DYN_LDS(uint32_t, hist);
+  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
+  for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
+    const uint32_t k = wi / nTiles, tile = wi % nTiles;
+    const SendAllDesc sd = d.saDesc[k];
+    {
+      for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
+      __syncthreads();
+      const uint32_t to = tile * TILE + threadIdx.x;
+      const int32_t nt = to < N ? d.saLat[(size_t)k * N + to] : -1;
+      const bool valid = nt >= 0;
+      const int bin = valid ? nt : 0;
+      const uint32_t rank = tile_rank(hist, bin, valid, binBits);
+      if (valid) d.dests[(sd.destOff + d.saHist[((size_t)k * nTiles + tile) * D + bin] + rank) % d.chainDests] = (int32_t)to;
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
 // release the bucket's pages and bump the nextMessage() epoch if anything was polled.
@@ -862,6 +1032,7 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
     g->destHead += g->nMultiDests;
     g->nMulti = 0;
     g->nMultiDests = 0;
+    g->nSendAll = 0;
   }
   __syncthreads();
   if (drained) {
@@ -1021,6 +1192,12 @@ struct Ctx {
       n = 64;
     }
     put(O_MULTI, n, msg, payload, t + 1, destOff, true, OUT_SHUFFLE, (uint32_t)(n - 1));
+  }
+  // Network.sendAll(m, sendTime, this) (:341-347): every node of the network is a destination, one rd draw
+  __device__ void send_all(uint32_t msg, uint32_t payload, int32_t sendTime, int size) {
+    msgSent += d.nodes.n;
+    bytesSent += (long long)d.nodes.n * size;
+    put(O_SENDALL, d.nodes.n, msg, payload, sendTime, 0, true);
   }
   // Network.registerTask(r, startAt, this) (:505-508)
   __device__ void register_task(int32_t startAt, uint32_t word, uint32_t arg) {

@@ -322,6 +322,50 @@ int32_t wgh_sanfermin_create(const wg_sanfermin_params* pp, const char* nodeBuil
   return WG_OK;
 }
 
+int32_t wgh_casper_create(const wg_casper_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                          const wg_config* cfg, wg_engine** out) {
+  if (!out || !pp) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  const wg_casper_params p = *pp;
+  if (p.cycleLength <= 0 || p.blockProducersCount <= 0 || p.attestersPerRound <= 0) {
+    g_err = "Casper IMD parameters";
+    return WG_EINVAL;
+  }
+  const int32_t attesters = p.cycleLength * p.attestersPerRound, N = 1 + p.blockProducersCount + attesters;
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // ctor :80-87
+  NodeSoA nodes;
+  JavaRandom rd(0);
+  build_node(rd, b, nodes);                    // network.addObserver(new CasperNode(false, genesis) {}) — from new Random(0)
+  rd.setSeed(seed);                            // rd.setSeed(i) on the copy  C/RunMultipleTimes.java:44-48
+  for (int i = 1; i < N; i++) build_node(rd, b, nodes);  // init(): the byzantine producer, the producers, the attesters
+  CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
+                  nodes.speed.data()));
+  CK(wg_rng_set_state(e, rd.s));
+  CK(wg_protocol_load(e, WG_PROTO_CASPER, &p, nullptr));
+  const int32_t SD = 8000;  // SLOT_DURATION
+  // registerPeriodicTask calls of init(badNode) :481-509, in its order (= push order of the task envelopes)
+  CK(wg_register_periodic_task(e, /*ByzBlockProducerWF*/ 2u, SD + p.byzDelay, SD * p.blockProducersCount, 1));
+  for (int i = 1; i < p.blockProducersCount; i++)
+    CK(wg_register_periodic_task(e, /*BlockProducer*/ 0u, SD * (i + 1), SD * p.blockProducersCount, 1 + i));
+  for (int i = 0; i < attesters; i++)
+    CK(wg_register_periodic_task(e, /*Attester*/ 1u, SD * (1 + i % p.cycleLength) + 4000, SD * p.cycleLength,
+                                 1 + p.blockProducersCount + i));
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
 int32_t wgh_gsf_create(const wg_gsf_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
                        const wg_config* cfg, wg_engine** out) {
   if (!out || !pp) return WG_EINVAL;

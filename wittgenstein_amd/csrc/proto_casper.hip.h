@@ -1,0 +1,277 @@
+// Casper IMD (P/CasperIMD.java over C/Block.java, C/BlockChainNode.java, C/BlockChainNetwork.java) as a resident device
+// protocol. One wavefront per simulated node; lanes split the words of the attestation bitsets.
+//
+// The reference keeps per node a Map<Long, Set<Attestation>> (attestationsByHead) and per block a
+// Map<Integer, Set<Attestation>>, and its fork choice (best / countAttestations :186-266) and block building (:389-434)
+// are set algebra over them. Here every Attestation has an index a = height * attestersPerRound + (attester ordinal /
+// cycleLength) — an attester votes once per cycle, in the slot (1 + ordinal % cycleLength) of it (:501-507), so the index
+// is unique and the attestations of one height are a contiguous index range — and every set is a bitset over that index:
+//   recv[node]        the attestations the node has received (the union of its attestationsByHead sets)
+//   headMask[b]       attestations whose head is block b          (attestationsByHead.get(b) = recv & headMask[b])
+//   attestsMask[b]    attestations a with b in a.hs               (Attestation.attests :113-115)
+//   blockAtt[b]       the attestations block b carries            (its attestationsByHeight, all heights)
+// so countAttestations / buildBlock are OR / AND / popcount passes over words. Blocks are rows of a table, ids in creation
+// order as the reference's Block.blockId (at most one block is created per simulated ms, checked).
+// Not resident: randomOnTies (the tie's rd.nextBoolean() decides the node's head inside action(): its value cannot be
+// deferred) and the byzantine producers other than the ByzBlockProducerWF that init() installs (:475-479).
+#pragma once
+#include "engine_kernels.hip.h"
+
+namespace wg {
+
+constexpr int32_t C_SLOT = 8000;  // SLOT_DURATION :19
+constexpr uint32_t C_TASK_PRODUCER = 0, C_TASK_ATTESTER = 1, C_TASK_WF = 2, C_TASK_WF_BUILD = 3;
+constexpr uint32_t C_MSG_BLOCK = 0, C_MSG_ATTESTATION = 1;
+
+struct CasperState {
+  wg_casper_params p;
+  int32_t N, B, A, Aw, Bw;
+  int32_t* head;        // [N] block index
+  uint64_t* recv;       // [N][Aw]
+  uint64_t* blkRecv;    // [N][Bw] blocksReceivedByBlockId
+  uint64_t* reeval;     // [N][Bw] blocksToReevaluate
+  uint64_t* headsAtt;   // [N][Bw] keys of attestationsByHead
+  int32_t* wf;          // ByzBlockProducerWF (node 1): toSend, late, onTime
+  int32_t *bHeight, *bParent, *bProducer, *bTime;  // [B]
+  uint32_t* nBlocks;    // [1]
+  int32_t* lastBlockMs; // [1]
+  uint64_t *blockAtt, *headMask, *attestsMask;     // [B][Aw]
+  int32_t* attHead;     // [A]
+};
+
+struct CasperProto {
+  typedef CasperState State;
+  struct WaveShared {
+    int unused;
+  };
+  struct NodeRegs {
+    int32_t head;
+  };
+  __device__ static int msg_size(const State&, uint32_t) { return 1; }  // Message.size() default
+  __device__ static int msg_level(uint32_t) { return 0; }
+  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, WaveShared*) { r.head = s.head[c.node]; }
+  __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
+    if (WG_LANE == 0) s.head[c.node] = r.head;
+  }
+
+  __device__ static uint64_t ldc(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ static int32_t ldi(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ static bool bit(const uint64_t* row, int32_t i) { return (ldc(row + (i >> 6)) >> (i & 63)) & 1ULL; }
+  __device__ static void set_bit(uint64_t* row, int32_t i) {  // one lane
+    row[i >> 6] |= 1ULL << (i & 63);
+  }
+  // bits [lo, hi) of word w
+  __device__ static uint64_t range_mask(int w, int64_t lo, int64_t hi) {
+    const int64_t b0 = (int64_t)w << 6, b1 = b0 + 64;
+    if (hi <= b0 || lo >= b1 || hi <= lo) return 0ULL;
+    uint64_t m = ~0ULL;
+    if (lo > b0) m &= ~0ULL << (lo - b0);
+    if (hi < b1) m &= (1ULL << (hi - b0)) - 1ULL;
+    return m;
+  }
+  __device__ static bool has_direct_link(const State& s, int32_t a, int32_t b) {  // C/Block.java:86-99
+    if (a == b) return true;
+    const int32_t ha = ldi(s.bHeight + a), hb = ldi(s.bHeight + b);
+    if (ha == hb) return false;
+    int32_t older = ha > hb ? a : b, young = ha > hb ? b : a;
+    const int32_t hy = ldi(s.bHeight + young);
+    while (ldi(s.bHeight + older) > hy) older = ldi(s.bParent + older);
+    return older == young;
+  }
+  // countAttestations(start, h) :241-266
+  __device__ static int count_attestations(Ctx& c, const State& s, int32_t start, int32_t h) {
+    const uint64_t* rv = s.recv + (size_t)c.node * s.Aw;
+    const int32_t hh = ldi(s.bHeight + h);
+    const int64_t pr = s.p.attestersPerRound;
+    int cnt = 0;
+    for (int w = WG_LANE; w < s.Aw; w += 64) {
+      uint64_t x = 0;
+      for (int32_t cur = start; cur != h; cur = ldi(s.bParent + cur)) {
+        const int32_t ch = ldi(s.bHeight + cur);
+        x |= ldc(s.blockAtt + (size_t)cur * s.Aw + w) & range_mask(w, ((int64_t)hh + 1) * pr, (int64_t)ch * pr);
+        x |= ldc(rv + w) & ldc(s.headMask + (size_t)cur * s.Aw + w);
+      }
+      cnt += __popcll(x & ldc(s.attestsMask + (size_t)h * s.Aw + w));
+    }
+    return wave_sum(cnt);
+  }
+  __device__ static int32_t best(Ctx& c, const State& s, int32_t o1, int32_t o2) {  // :186-236
+    if (o1 == o2) return o1;
+    const int32_t h1 = ldi(s.bHeight + o1), h2 = ldi(s.bHeight + o2);
+    if (h1 == h2) {
+      if (WG_LANE == 0) set_err(c.d.g, ERR_PROTOCOL);  // "Someone sent two blocks for the same height": IllegalStateException
+      return o1;
+    }
+    if (has_direct_link(s, o1, o2)) return h1 < h2 ? o2 : o1;
+    int32_t b1 = o1, b2 = o2;
+    while (ldi(s.bParent + b1) != ldi(s.bParent + b2)) {
+      if (ldi(s.bHeight + ldi(s.bParent + b1)) > ldi(s.bHeight + ldi(s.bParent + b2)))
+        b1 = ldi(s.bParent + b1);
+      else
+        b2 = ldi(s.bParent + b2);
+    }
+    const int32_t h = ldi(s.bParent + b1);
+    const int v1 = count_attestations(c, s, o1, h), v2 = count_attestations(c, s, o2, h);
+    if (v1 > v2) return o1;
+    if (v1 < v2) return o2;
+    return b1 >= b2 ? o1 : o2;  // (randomOnTies is refused at load time)
+  }
+  __device__ static void reevaluate_head(Ctx& c, const State& s, NodeRegs& r) {  // :349-356, ascending block id
+    uint64_t* re = s.reeval + (size_t)c.node * s.Bw;
+    for (int w = 0; w < s.Bw; w++) {
+      uint64_t m = ldc(re + w);
+      while (m) {
+        const int32_t b = (w << 6) + (__ffsll((unsigned long long)m) - 1);
+        m &= m - 1;
+        r.head = best(c, s, r.head, b);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int w = WG_LANE; w < s.Bw; w += 64) re[w] = 0;
+    __threadfence_block();
+  }
+  // buildBlock(base, height) :389-434 -> the new block's index
+  __device__ static int32_t build_block(Ctx& c, const State& s, int32_t base, int32_t height) {
+    int32_t idx = 0;
+    if (WG_LANE == 0) {
+      idx = (int32_t)atomicAdd(s.nBlocks, 1u);
+      if (atomicExch(s.lastBlockMs, c.t) == c.t || idx >= s.B || height <= 0 || c.t < ldi(s.bTime + base) ||
+          ldi(s.bHeight + base) >= height)
+        set_err(c.d.g, idx >= s.B ? ERR_PAYLOAD : ERR_PROTOCOL);  // two blocks in one ms / table full / Block's ctor checks :36-47
+      if (idx >= s.B) idx = s.B - 1;
+      s.bHeight[idx] = height;
+      s.bParent[idx] = base;
+      s.bProducer[idx] = c.node;
+      s.bTime[idx] = c.t;
+    }
+    idx = __shfl(idx, 0, 64);
+    const int cl = s.p.cycleLength;
+    const uint64_t* rv = s.recv + (size_t)c.node * s.Aw;
+    for (int w = WG_LANE; w < s.Aw; w += 64) {
+      uint64_t all = 0, res = 0;
+      for (int32_t cur = base; cur != 0 && ldi(s.bHeight + cur) >= height - cl; cur = ldi(s.bParent + cur))
+        all |= ldc(s.blockAtt + (size_t)cur * s.Aw + w);  // phase 1: what the parents' blocks already carry
+      for (int32_t cur = base; cur >= 0 && ldi(s.bHeight + cur) >= height - cl; cur = ldi(s.bParent + cur))
+        res |= ldc(rv + w) & ldc(s.headMask + (size_t)cur * s.Aw + w);  // phase 2: attestationsByHead of the branch
+      res &= range_mask(w, 0, (int64_t)height * s.p.attestersPerRound) & ~all;  // a.height < height, not yet included
+      s.blockAtt[(size_t)idx * s.Aw + w] = res;
+    }
+    __threadfence_block();
+    return idx;
+  }
+  __device__ static void send_block(Ctx& c, const State& s, int32_t b) {  // sendAll(new SendBlock<>(head), time + blockConstructionTime, this)
+    c.send_all(C_MSG_BLOCK, (uint32_t)b, c.t + s.p.blockConstructionTime, 1);
+  }
+  __device__ static void create_and_send_block(Ctx& c, const State& s, NodeRegs& r, int32_t height) {  // :436-442
+    r.head = build_block(c, s, r.head, height);
+    send_block(c, s, r.head);
+  }
+  __device__ static void vote(Ctx& c, const State& s, NodeRegs& r, int32_t height) {  // :453-466 + Attestation() :107-121
+    reevaluate_head(c, s, r);
+    const int32_t ordinal = c.node - (s.p.blockProducersCount + 1);
+    const int64_t a = (int64_t)height * s.p.attestersPerRound + ordinal / s.p.cycleLength;
+    if (a >= s.A) {
+      if (WG_LANE == 0) set_err(c.d.g, ERR_PAYLOAD);  // wg_casper_params.maxSlots
+      return;
+    }
+    if (WG_LANE == 0) {
+      s.attHead[a] = r.head;
+      atomicOr((unsigned long long*)(s.headMask + (size_t)r.head * s.Aw + (a >> 6)), 1ULL << (a & 63));
+      const int32_t hh = ldi(s.bHeight + r.head);
+      for (int32_t cur = ldi(s.bParent + r.head); cur >= 0 && ldi(s.bHeight + cur) >= hh - s.p.cycleLength; cur = ldi(s.bParent + cur))
+        atomicOr((unsigned long long*)(s.attestsMask + (size_t)cur * s.Aw + (a >> 6)), 1ULL << (a & 63));
+    }
+    c.send_all(C_MSG_ATTESTATION, (uint32_t)a, c.t + s.p.attestationConstructionTime, 1);
+  }
+  // BlockChainNode.onBlock :29-47 under CasperNode.onBlock :276-292 (delta >= 0 always: the formula adds the slot time)
+  __device__ static bool on_block(Ctx& c, const State& s, NodeRegs& r, int32_t b) {
+    uint64_t* re = s.reeval + (size_t)c.node * s.Bw;
+    uint64_t* br = s.blkRecv + (size_t)c.node * s.Bw;
+    const bool known = bit(br, b);
+    __builtin_amdgcn_wave_barrier();
+    if (WG_LANE == 0) {
+      set_bit(re, r.head);
+      set_bit(re, b);
+      if (!known) set_bit(br, b);
+    }
+    __threadfence_block();
+    if (known) return false;
+    r.head = best(c, s, r.head, b);
+    return true;
+  }
+  __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t, uint32_t msg, uint32_t payload) {
+    if (msg == C_MSG_ATTESTATION) {  // onAttestation :294-337
+      const int32_t a = (int32_t)payload;
+      const int32_t h = ldi(s.attHead + a);
+      const bool haveBlock = bit(s.blkRecv + (size_t)c.node * s.Bw, h);
+      __builtin_amdgcn_wave_barrier();
+      if (WG_LANE == 0) {
+        set_bit(s.recv + (size_t)c.node * s.Aw, a);
+        set_bit(s.headsAtt + (size_t)c.node * s.Bw, h);
+        if (haveBlock) set_bit(s.reeval + (size_t)c.node * s.Bw, h);
+      }
+      __threadfence_block();
+      return;
+    }
+    const int32_t b = (int32_t)payload;
+    if (!on_block(c, s, r, b)) return;
+    if (c.node != 1) return;
+    // ByzBlockProducerWF.onBlock :651-683
+    const int32_t toSend = ldi(s.wf + 0);
+    const int32_t bh = ldi(s.bHeight + b);
+    __builtin_amdgcn_wave_barrier();  // every lane has read toSend before lane 0 replaces it
+    if (bh != toSend - 1) return;
+    const int32_t perfectDate = C_SLOT * toSend + s.p.byzDelay;
+    if (WG_LANE == 0) s.wf[0] = toSend + s.p.blockProducersCount;
+    if (c.t >= perfectDate) {
+      r.head = build_block(c, s, b, toSend);
+      send_block(c, s, r.head);
+      if (WG_LANE == 0) s.wf[1]++;
+    } else {
+      c.register_task(perfectDate, C_TASK_WF_BUILD, (uint32_t)b);
+      if (WG_LANE == 0) s.wf[2]++;
+    }
+    __threadfence_block();
+  }
+  __device__ static void on_task(Ctx& c, const State& s, NodeRegs& r, uint32_t word, uint32_t arg) {
+    if (word == C_TASK_PRODUCER) {  // BlockProducer.periodicTask :381-386
+      reevaluate_head(c, s, r);
+      create_and_send_block(c, s, r, c.t / C_SLOT);
+    } else if (word == C_TASK_ATTESTER) {
+      vote(c, s, r, c.t / C_SLOT);
+    } else if (word == C_TASK_WF) {  // ByzBlockProducerWF.periodicTask :640-649
+      const int32_t toSend = ldi(s.wf + 0);
+      __builtin_amdgcn_wave_barrier();
+      if (r.head == 0 && toSend == 1) {
+        reevaluate_head(c, s, r);  // reevaluateH :529-543
+        while (ldi(s.bHeight + r.head) >= toSend) r.head = ldi(s.bParent + r.head);
+        const int32_t h = (c.t - s.p.byzDelay) / C_SLOT;
+        if (h != toSend) {
+          if (WG_LANE == 0) set_err(c.d.g, ERR_PROTOCOL);
+          return;
+        }
+        create_and_send_block(c, s, r, h);
+        if (WG_LANE == 0) s.wf[0] = toSend + s.p.blockProducersCount;
+        __threadfence_block();
+      }
+    } else {  // the Runnable of ByzBlockProducerWF.onBlock :657-669
+      const int32_t b = (int32_t)arg;
+      r.head = build_block(c, s, b, ldi(s.bHeight + b) + 1);
+      send_block(c, s, r.head);
+    }
+  }
+};
+
+__global__ void k_casper_init(CasperState s) {
+  int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.N) return;
+  s.blkRecv[(size_t)node * s.Bw] = 1ULL;  // blocksReceivedByBlockId.put(genesis.id, genesis)  C/BlockChainNode.java:21-26
+  if (node == 0) {
+    s.bParent[0] = -1;  // genesis: Block(0)  C/Block.java:22-30
+    *s.nBlocks = 1;
+    *s.lastBlockMs = -1;
+    s.wf[0] = 1;  // toSend = 1 :512
+  }
+}
+
+}  // namespace wg

@@ -207,3 +207,47 @@ class SanFerminSignature:
         v = C.c_int32()
         self._net._ck(L.lib().wg_protocol_cont_if(self._net._h, C.byref(v)))
         return bool(v.value)
+
+
+class CasperParemeters:
+    """(sic) P/CasperIMD.java:18-70, constructor argument order preserved."""
+
+    def __init__(self, cycleLength=4, randomOnTies=True, blockProducersCount=2, attestersPerRound=20,
+                 blockConstructionTime=1000, attestationConstructionTime=1, nodeBuilderName=None,
+                 networkLatencyName=None):
+        self.cycleLength, self.randomOnTies, self.blockProducersCount = cycleLength, randomOnTies, blockProducersCount
+        self.attestersPerRound, self.attestersCount = attestersPerRound, attestersPerRound * cycleLength
+        self.blockConstructionTime, self.attestationConstructionTime = blockConstructionTime, attestationConstructionTime
+        self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
+
+
+class CasperIMD:
+    """P/CasperIMD.java resident on the device (wittgenstein_amd/csrc/proto_casper.hip.h): init() as the reference's,
+    with ByzBlockProducerWF(byzDelay). max_slots sizes the attestation / block tables (a slot is 8 s). `seed` is
+    RunMultipleTimes' rd.setSeed(i) on the copy (the constructor has built the observer from new Random(0) before)."""
+
+    def __init__(self, params=None, seed=0, config=None, byz_delay=0, max_slots=64):
+        self.params = params or CasperParemeters()
+        self.seed, self.config, self.byz_delay, self.max_slots = seed, config, byz_delay, max_slots
+        self._net = None
+        self.init_seconds = None
+
+    def copy(self):
+        return CasperIMD(self.params, self.seed, self.config, self.byz_delay, self.max_slots)
+
+    def init(self):
+        p = self.params
+        cp = L.wg_casper_params(p.cycleLength, int(bool(p.randomOnTies)), p.blockProducersCount, p.attestersPerRound,
+                                p.blockConstructionTime, p.attestationConstructionTime, self.byz_delay, self.max_slots)
+        h = C.c_void_p()
+        cfg = _config(self.config)
+        rc = L.lib().wgh_casper_create(C.byref(cp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                       p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                       C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wgh_last_error().decode())
+        self._net = Network(h)
+        self.init_seconds = L.lib().wgh_last_init_seconds()
+
+    def network(self):
+        return self._net
