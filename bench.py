@@ -141,6 +141,72 @@ def cpu_baseline(n_sample, workload="handel"):
     return out
 
 
+def main_casper(args):
+    """BASELINE configs[4]'s protocol at a size the resident form delivers today: Casper IMD, cycleLength 2, 2 block
+    producers, --attesters-per-round attesters voting per slot (every vote and block is a sendAll to all N nodes). A step
+    is one simulation of --casper-ms simulated ms. Not the BASELINE metric's workload (that is Handel): a second line."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload casper is a one-GPU line")
+    from wittgenstein_amd import protocols as P
+    K, W, per, T = args.steps, args.warmup, args.attesters_per_round, args.casper_ms
+    cl, bp = 2, 2
+    params = (cl, False, bp, per, 1000, 1)
+    n = 1 + bp + cl * per
+    delivered = 0
+    elapsed = dk_ns = 0.0
+    dk_spans = 0
+    for step in range(W + K):
+        g = P.CasperIMD(P.CasperParemeters(*params, NB, NL), seed=step, max_slots=T // 8000 + 2)
+        g.init()
+        net = g.network()
+        net.profile(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net.runMs(T)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if step >= W:
+            delivered += net.last_stats["delivered"]
+            elapsed += dt
+            pr = net.profile_read()["deliver"]
+            dk_spans += pr["spans"]
+            dk_ns += pr["total_ns"]
+        del g, net
+        gc.collect()
+    bmsg = 104 + 24 + 8  # SURVEY.md §8d fixed part + the attestation's three bit-sets (8-byte RMW each) + attHead read
+    alg = float(delivered) * bmsg
+    avg_ns = dk_ns / max(1, dk_spans)
+    out = {
+        "metric": "delivered messages/sec (Casper IMD; simulated-ms/sec alongside)",
+        "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": K * T / elapsed,
+        "config": {"workload": "Casper IMD, %d nodes (1 observer, %d block producers, %d x %d attesters), randomOnTies false, "
+                               "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
+                               "%d simulated ms per step" % (n, bp, cl, per, T), "nodes": n},
+        "roofline": {"bound": "hbm", "kernel": "k_deliver<CasperProto>", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
+                     "launches": dk_spans, "bytes_per_delivered_message": bmsg, "whole_run_achieved_GBs": alg / (elapsed * 1e9)},
+    }
+    if not args.no_cpu:
+        import oracle_lib as o
+        o.build()
+        sample = min(per, 512)  # the oracle keeps every attestation in every node's HashSet: bounded sample
+        c = o.CasperIMD((cl, False, bp, sample, 1000, 1), NB, NL, seed=0)
+        t0 = time.perf_counter()
+        c.run_ms(T)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c.info()["delivered"] / dt, "unit": "delivered messages/s", "cores": 1, "kind": "port",
+                               "sample": "Casper IMD with %d attesters per round (%d nodes), %d simulated ms: %d delivered "
+                                         "messages in %.2f s on one host core (C++ oracle)" % (sample, 1 + bp + cl * sample, T, c.info()["delivered"], dt)}
+    print(json.dumps(out), flush=True)
+
+
 def main_shard(args):
     """one simulation per step, sharded by node range over the ranks (strong scaling)"""
     import torch
@@ -249,7 +315,9 @@ def main():
     ap.add_argument("--init-threads", type=int, default=6)
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", choices=["handel", "gsf"], default="handel",
+    ap.add_argument("--attesters-per-round", type=int, default=4096, help="--workload casper: attesters voting per slot")
+    ap.add_argument("--casper-ms", type=int, default=40000, help="--workload casper: simulated ms per step")
+    ap.add_argument("--workload", choices=["handel", "gsf", "casper"], default="handel",
                     help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
                          "(use --nodes 4096)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
@@ -259,6 +327,8 @@ def main():
                     help="--mode shard on ONE GPU: k engines in this process, each owning a node range; the all-reduce "
                          "sums their buffers in place (shards.LoopbackGroup). 0 = one shard per rank over RCCL")
     args = ap.parse_args()
+    if args.workload == "casper":
+        return main_casper(args)
     if args.mode == "shard":
         return main_shard(args)
 

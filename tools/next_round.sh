@@ -20,6 +20,9 @@ if [ -s $OUT/pmc_FETCH_SIZE.md ] && [ -s $OUT/pmc_WRITE_SIZE.md ]; then
 fi
 timeout 600 python bench.py --mode shard --gpus 1 --steps 1 --warmup 1 --no-cpu > $OUT/bench_shard1.json 2> $OUT/bench_shard1.err
 echo "shard1 rc=$?"; cat $OUT/bench_shard1.json
+# Casper IMD resident (4096 attesters voting per slot, 8195 nodes): deliveries are three bit-sets and two counters each
+timeout 600 python bench.py --workload casper --steps 1 --warmup 1 > $OUT/bench_casper.json 2> $OUT/bench_casper.err
+echo "casper rc=$?"; cat $OUT/bench_casper.json
 # hipGraph A/B (value only: the HIP-event roofline bracket is off under WG_GRAPH) on the launch-bound GSFSignature config
 for gr in 0 1; do
   WG_GRAPH=$gr timeout 300 python bench.py --workload gsf --nodes 4096 --replicas 16 --no-cpu > $OUT/bench_gsf_graph$gr.json 2> $OUT/bench_gsf_graph$gr.err
