@@ -2216,14 +2216,20 @@ struct CasperHost : ProtoHost {
     st.headMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
     st.attestsMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
     st.attHead = e.dalloc<int32_t>(st.A);
+    st.mixed = e.dalloc<uint8_t>(N);
+    st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
     hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st);
     WG_HIP(hipStreamSynchronize(e.stream));
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
-                       (const CasperState*)g.stab, 0);
+    const CasperState* stab = (const CasperState*)g.stab;
+    if (st.laneEvents) {  // attestation-only nodes: one lane per event (see k_casper_attestations)
+      hipLaunchKernelGGL(k_casper_classify, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_casper_attestations, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }

@@ -1282,6 +1282,19 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
 //   2. head[node] + everything node_begin loads   -> newest event e0, node registers
 //   3. evNext[e0] + ev[e0] + evAux[e0]            -> (usually) "e0 is the only event" and the event itself
 //   4. whatever action() loads (hoisted inside P) -> stores; counters by no-return atomics
+// A protocol may deliver some nodes' events itself before this kernel runs (Casper: nodes whose events of the ms are
+// all attestations, applied one lane per event with atomics — they commute); P::visit_skip(d, ps, node) then tells the
+// visit to leave the node alone (its events already have their EvRes). Detected at compile time: nothing changes for
+// the protocols without the hook.
+template <class P, class = void>
+struct HasVisitSkip {
+  static constexpr bool value = false;
+};
+template <class P>
+struct HasVisitSkip<P, decltype((void)&P::visit_skip)> {
+  static constexpr bool value = true;
+};
+
 template <class P, int WPE>  // WPE: waves per SIMD the register allocation must admit
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
                                                       const typename P::State* __restrict__ stab, int useB) {
@@ -1322,6 +1335,12 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
     }
     const int32_t node = vd.node;
     const int32_t e0 = vd.e0;
+    if constexpr (HasVisitSkip<P>::value) {
+      if (P::visit_skip(d, ps, node)) {
+        if (lane == 0 && !useB) d.head[node] = -1;
+        continue;
+      }
+    }
     const bool toDown = (vd.flags & VD_DOWN) != 0;
     const uint8_t toPart = (uint8_t)(vd.flags >> 8);
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};

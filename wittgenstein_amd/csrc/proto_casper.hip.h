@@ -37,6 +37,8 @@ struct CasperState {
   int32_t* lastBlockMs; // [1]
   uint64_t *blockAtt, *headMask, *attestsMask;     // [B][Aw]
   int32_t* attHead;     // [A]
+  uint8_t* mixed;       // [N] this ms the node has an event that is not an attestation (block, task): ordered visit
+  uint32_t laneEvents;  // 1: attestation-only nodes are delivered one lane per event (k_casper_attestations)
 };
 
 struct CasperProto {
@@ -54,6 +56,14 @@ struct CasperProto {
     if (WG_LANE == 0) s.head[c.node] = r.head;
   }
 
+  // k_deliver leaves a node to k_casper_attestations unless the node has a block or a task this ms (and resets the flag)
+  __device__ static bool visit_skip(const EngineDev&, const State& s, int32_t node) {
+    if (!s.laneEvents) return false;
+    const bool mixed = __hip_atomic_load(s.mixed + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    __builtin_amdgcn_wave_barrier();
+    if (mixed && WG_LANE == 0) s.mixed[node] = 0;
+    return !mixed;
+  }
   __device__ static uint64_t ldc(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   __device__ static int32_t ldi(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   __device__ static bool bit(const uint64_t* row, int32_t i) { return (ldc(row + (i >> 6)) >> (i & 63)) & 1ULL; }
@@ -261,6 +271,67 @@ struct CasperProto {
     }
   }
 };
+
+// An attestation delivery (onAttestation :294-337) is three bit-sets and two counters, and it commutes with the node's
+// other attestation deliveries — and with a block delivery of the same ms (whichever comes first, the head's bit ends up
+// in blocksToReevaluate: onBlock adds the block itself). Only relative to the node's own tasks does the order show (what
+// a vote or a block built in that ms includes). So: nodes with a block or a task this ms are flagged and visited in event
+// order by k_deliver; for all the others one lane per EVENT applies the delivery with atomics — at 4096 attesters per
+// slot a node receives a dozen attestations per ms, which one wavefront per node would apply one after the other.
+__device__ __forceinline__ bool casper_is_attestation(const Rec& r) { return rec_kind(r) == K_MSG && r.w2 == C_MSG_ATTESTATION; }
+__global__ void __launch_bounds__(256) k_casper_classify(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nEvents;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const Rec r = d.ev[e];
+    if (!casper_is_attestation(r)) s.mixed[r.w1] = 1;
+  }
+}
+__global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nEvents;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const Rec r = d.ev[e];
+    if (!casper_is_attestation(r)) continue;
+    const int32_t to = (int32_t)r.w1, from = rec_from(r);
+    if (s.mixed[to]) continue;  // k_deliver applies this node's events in order
+    const EvAux aux = d.evAux[e];
+    EvRes res;
+    res.nrec = 0;
+    res.ndraw = 0;
+    if (!d.nodes.down[to] && (d.nparts == 0 || d.nodes.part[from] == d.nodes.part[to])) {  // C/Network.java:606
+      const int32_t a = (int32_t)r.w3, h = s.attHead[a];
+      atomicAdd((unsigned long long*)&d.nodes.msgReceived[to], 1ULL);
+      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[to], 1ULL);
+      atomicOr((unsigned long long*)(s.recv + (size_t)to * s.Aw + (a >> 6)), 1ULL << (a & 63));
+      atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
+      if ((s.blkRecv[(size_t)to * s.Bw + (h >> 6)] >> (h & 63)) & 1ULL)
+        atomicOr((unsigned long long*)(s.reeval + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
+      res.nrec = EV_DELIVERED;
+    }
+    if (aux.chain >= 0 && aux.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
+      const int32_t next = (aux.cpos & 0x7FFFFFFF) + 1;
+      if (next < d.chains[aux.chain].ndest) {
+        Out o;
+        o.kindfrom = (O_CHAINCONT << 28) | (uint32_t)to;
+        o.to = aux.chain;
+        o.a = (uint32_t)next;
+        o.b = 0;
+        o.t = 0;
+        o.destOff = 0;
+        o.drawsub = 0;
+        o.pad = 0;
+        d.outTmp[aux.outBase] = o;
+        res.nrec |= 1u;
+      } else {
+        d.chains[aux.chain].flags = 0;
+      }
+    }
+    d.evRes[e] = res;
+  }
+}
 
 __global__ void k_casper_init(CasperState s) {
   int node = blockIdx.x * blockDim.x + threadIdx.x;
