@@ -38,7 +38,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests")
 import oracle_lib as o
 o.build()
 import test_gpu_engine as te, test_zy_gpu_fuzz as tf
-te.test_pingpong_reference_run()
+te.test_pingpong_chunking_and_seeds(7)
 tf.test_fuzz_partitions_stops_and_discard(2)
 tf.run(64, 12, "NetworkNoLatency", seed=11, chunk=5, chunks=40)
 print("EXPAND OK")

@@ -17,7 +17,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests")
 import oracle_lib as o
 o.build()
 import test_gpu_batch as tb
-tb.test_handel_batch_matches_oracle_per_seed(%(n)d, [0, 1, 2])
+tb.test_handel_batch_matches_oracle_per_seed(%(n)d, [0, 1])
 import wittgenstein_amd as w, test_gpu_gsf as tg
 seeds = [5, 6]
 gs = [tg.pair((64, 63, 3, 50, 10, 10, 0), seed=s)[0] for s in seeds]
