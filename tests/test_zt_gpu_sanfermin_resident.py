@@ -73,3 +73,25 @@ def test_sanfermin_default_size():  # the no-arg parameters (:69-81): 1024 nodes
 def test_fixed_latency_short_timeout_and_threshold():
     g, c = lockstep((128, 100, 3, 48, 40, 2), seed=8, chunk=10, chunks=120, nl="NetworkFixedLatency(25)")
     assert (c.read("thresholdAt") > 0).sum() > 100
+
+
+@pytest.mark.gpu
+def test_sanfermin_batch_run_multiple_times():
+    """RunMultipleTimes over San Fermin copies (wg_batch_run_multiple_times: the loop on the device): nodes that run out of
+    candidates never finish, so the loop ends at maxTime (C/RunMultipleTimes.java:50-64)"""
+    import wittgenstein_amd as w
+    params, seeds = (64, 64, 2, 48, 300, 1), [1, 2, 3]
+    gs = []
+    for sd in seeds:
+        g = P.SanFerminSignature(P.SanFerminSignatureParameters(*params), seed=sd)
+        g.init()
+        gs.append(g)
+    delivered, ms = w.Batch([g.network() for g in gs]).run_multiple_times(chunk=10, maxTime=3000)
+    for g, sd, d in zip(gs, seeds, delivered):
+        c = o.SanFerminSignature(params, seed=sd)
+        while True:
+            did = c.run_ms(10)
+            if not (c.info()["time"] < 3000 and (not did or int((c.read("done") == 0).sum()) > 0)):
+                break
+        assert not diff(g, c), diff(g, c)
+        assert d == c.info()["delivered"]
