@@ -2,7 +2,8 @@
 bitsets over an attestation index, sendAll resolved by k_sendall_*, 8-second periodic tasks through the far buffer) vs
 the CPU oracle (oracle/casper.hpp, pinned against PT/CasperIMDTest / PT/CasperByzantineTest). After every chunk, per node:
 msgReceived / msgSent / bytesSent / bytesReceived, head (height, proposalTime, id), attestationsByHead.size(), blocks
-received, attestations held — the observables of PT/CasperIMDTest.java:263-274 — plus network.time and the rd state."""
+received, attestations held — the observables of PT/CasperIMDTest.java:263-274 — plus network.time, msgs.size() (far
+envelopes included) and the rd state."""
 import numpy as np
 import pytest
 
@@ -22,8 +23,9 @@ def diff(g, c):
         if len(bad):
             out.append("%s: %d nodes differ, first node %d: device %d oracle %d" % (f, len(bad), bad[0], a[bad[0]], b[bad[0]]))
     i = c.info()
-    if (net.time, net.rng_state()) != (i["time"], i["rng"]):
-        out.append("time / rd: device %r oracle %r" % ((net.time, net.rng_state()), i))
+    mine = (net.time, net.rng_state(), net.msgs.size())
+    if mine != (i["time"], i["rng"], i["queue"]):
+        out.append("time / rd / msgs.size(): device %r oracle %r" % (mine, i))
     return out
 
 
