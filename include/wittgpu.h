@@ -247,7 +247,7 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * device) with its stream idle; the function returns once the summed values are visible to any stream. Bind it to
  * RCCL (torch.distributed backend "nccl": wittgenstein_amd/shards.py) — over xGMI the payload is a few bytes per event,
  * so the latency of the collective, not its bandwidth, is what a simulated ms pays.
- * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong, Handel, GSFSignature.
+ * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong, Handel, GSFSignature, San Fermin.
  * wg_read_i64 on a shard returns its own nodes' values and zeros for the others (sum across shards for the whole
  * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
  * shard yet, batches, and host-callback mode. */

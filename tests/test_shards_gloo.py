@@ -239,3 +239,51 @@ def test_sharded_run_multiple_times_loop(oracle, tmp_path):
         WORKER = keep
     for r in res:
         assert (r["delivered"], r["ms"]) == (r["expect"], r["expect_ms"]) and r["delivered"] > 0
+
+
+SF_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+from wittgenstein_amd import shards, protocols as P
+import oracle_lib as o
+import test_zt_gpu_sanfermin_resident as ts
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+params = %(params)r
+g = P.SanFerminSignature(P.SanFerminSignatureParameters(*params), seed=%(seed)d, config=shards.config(dist, device_memory=False))
+g.init()
+c = o.SanFerminSignature(params, seed=%(seed)d)
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad = []
+for k in range(%(chunks)d):
+    g.network().runMs(%(chunk)d); c.run_ms(%(chunk)d)
+    bad += [(k, m) for m in ts.diff(G(), c)]
+    if bad: break
+if shards.cont_if(dist, g) != (int((c.read("done") == 0).sum()) > 0): bad.append("cont_if")
+calls, words = shards.traffic(g.network())
+res = [None] * world
+dist.all_gather_object(res, {"rank": rank, "bad": [str(b) for b in bad[:6]], "calls": calls, "words": words,
+                             "finished": c.info()["finished"]})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,params", [(2, (64, 64, 2, 48, 300, 1)), (4, (128, 128, 2, 48, 300, 3))])
+def test_sharded_sanfermin_matches_the_oracle(oracle, tmp_path, world, params):  # shuffled multi-destination requests
+    global WORKER
+    keep, WORKER = WORKER, SF_WORKER
+    try:
+        res = _run(tmp_path, world, 29601 + world, params=params, seed=3, chunk=50, chunks=30)
+    finally:
+        WORKER = keep
+    for r in res:
+        assert r["bad"] == [], r
+        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["finished"] > params[0] * 0.8

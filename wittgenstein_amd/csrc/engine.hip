@@ -2088,7 +2088,6 @@ struct SfHost : ProtoHost {
     if (p.candidateCount < 0 || p.candidateCount > 62)
       throw WgError(WG_EUNSUPPORTED, "candidateCount > 62 (device multi-destination sends hold <= 64 ids)");
     if (p.pairingTime <= 0 || p.replyTimeout <= 0) throw WgError(WG_EINVAL, "pairingTime / replyTimeout");
-    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "San Fermin does not run on a sharded engine yet");
     int P = 0;
     while ((1 << (P + 1)) <= N) P++;
     if (!e.allocated) e.horizonFloor = std::max(e.horizonFloor, std::max(p.replyTimeout, p.pairingTime) + 8);  // its tasks' delays
@@ -2122,6 +2121,9 @@ struct SfHost : ProtoHost {
   const void* state_host() const override { return &st; }
   int host_msg_size(uint32_t) const override { return 4 + st.p.signatureSize; }
   int levels() const override { return st.P; }
+  // node-range sharding: a visit touches the visited node's rows only, payloads are message words, no conditional tasks;
+  // the (shuffled) multi-destination requests go through the replicated envelope creation (k_shard_multi_*)
+  bool supports_shards() const override { return true; }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_sf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, (const SfState*)g.stab, dOut);
     return true;
