@@ -106,8 +106,24 @@ int32_t wg_register_periodic_task(wg_engine* e, uint32_t task, int32_t startAt, 
 /* ---- resident protocols ----------------------------------------------------------------- */
 typedef enum {
   WG_PROTO_HOST = 0, /* no resident protocol: Message.action() stays with the caller (wg_next_delivery below) */
-  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3, WG_PROTO_SANFERMIN = 4, WG_PROTO_CASPER = 5
+  WG_PROTO_PINGPONG = 1, WG_PROTO_HANDEL = 2, WG_PROTO_GSF = 3, WG_PROTO_SANFERMIN = 4, WG_PROTO_CASPER = 5,
+  WG_PROTO_P2PFLOOD = 6
 } wg_proto_id;
+
+/* P2PFlood parameters: P2PFloodParameters ctor order (P/P2PFlood.java:63-86); msgCount <= 64 on the device.
+ * Init state produced by P2PFlood.init() (:121-140) on the host: the peer lists P2PNetwork.setPeers built (row i =
+ * node i's peers in list order, peerCount[i] of them, rows maxPeers <= 64 wide) and the sender of each message
+ * (sendPeers' addToReceived and `doneAt = 1` are applied on the device; the sends themselves are wg_send calls with
+ * delaysBetweenMessage). */
+typedef struct {
+  int32_t nodeCount, deadNodeCount, delayBeforeResent, msgCount, msgToReceive, peersCount, delayBetweenSends;
+} wg_p2pflood_params;
+typedef struct {
+  const int32_t* peers;      /* [nodeCount][maxPeers] */
+  const int32_t* peerCount;  /* [nodeCount] */
+  int32_t maxPeers;
+  const int32_t* senders;    /* [msgCount] */
+} wg_p2pflood_init_state;
 
 /* Casper IMD parameters: CasperParemeters ctor order (sic, P/CasperIMD.java:52-70), then the delay of the
  * ByzBlockProducerWF that init(badNode) starts with (:475-479 uses 0) and a capacity: the run may reach slot maxSlots
@@ -276,7 +292,9 @@ typedef enum {
   /* Casper IMD CasperNode (P/CasperIMD.java:177-368): head.height, head.proposalTime, head.id (creation order, genesis 0),
    * attestationsByHead.size(), blocksReceivedByBlockId.size(), attestations held (all heads) */
   WG_F_CASPER_HEAD_HEIGHT = 80, WG_F_CASPER_HEAD_TIME = 81, WG_F_CASPER_HEAD_ID = 82, WG_F_CASPER_HEADS_ATTESTED = 83,
-  WG_F_CASPER_BLOCKS_RECEIVED = 84, WG_F_CASPER_ATTESTATIONS_HELD = 85
+  WG_F_CASPER_BLOCKS_RECEIVED = 84, WG_F_CASPER_ATTESTATIONS_HELD = 85,
+  /* P2PFlood P2PNode (C/P2PNode.java): getMsgReceived(-1).size(), peers.size() */
+  WG_F_FLOOD_RECEIVED = 96, WG_F_FLOOD_PEER_COUNT = 97
 } wg_field;
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */

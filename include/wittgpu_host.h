@@ -34,6 +34,10 @@ int32_t wgh_sanfermin_create(const wg_sanfermin_params* params, const char* node
  * ByzBlockProducerWF(params->byzDelay)) (P/CasperIMD.java:481-509) */
 int32_t wgh_casper_create(const wg_casper_params* params, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out);
+/* new P2PFlood(params), rd.setSeed(seed), init(): nodes (the first deadNodeCount stopped), P2PNetwork.setPeers, one
+ * sendPeers per message from a random live node (P/P2PFlood.java:88-140, C/P2PNetwork.java:27-56,127-132) */
+int32_t wgh_p2pflood_create(const wg_p2pflood_params* params, const char* nodeBuilderName, const char* latencyName,
+                            int64_t seed, const wg_config* cfg, wg_engine** out);
 const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);

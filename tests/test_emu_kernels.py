@@ -35,6 +35,7 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
+import test_zq_gpu_p2pflood_resident as tfr  # noqa: E402
 import test_zr_gpu_casper_resident as tcr  # noqa: E402
 import test_zt_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_zv_gpu_p2pflood as tpf  # noqa: E402
@@ -178,3 +179,8 @@ def test_casper_resident():  # P/CasperIMD.java resident on the device vs oracle
     # (block construction 100 ms + a fixed latency keep the bucket ring at 256 ms: the emulator pays per simulated ms)
     tcr.lockstep((2, False, 2, 6, 100, 1), seed=5, chunk=1500, chunks=18, nl="NetworkFixedLatency(20)")
     tcr.test_random_on_ties_is_refused()
+
+
+def test_p2pflood_resident():  # P/P2PFlood.java resident on the device vs oracle/p2pflood.hpp
+    tfr.test_three_messages_by_distance()
+    tfr.lockstep((64, 0, 5, 2, 1, 12, 1), "NetworkFixedLatency(7)", seed=9, chunk=1, chunks=150)

@@ -45,6 +45,11 @@ class wg_casper_params(C.Structure):
         "attestationConstructionTime", "byzDelay", "maxSlots")]
 
 
+class wg_p2pflood_params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nodeCount", "deadNodeCount", "delayBeforeResent", "msgCount", "msgToReceive", "peersCount", "delayBetweenSends")]
+
+
 class wg_delivery(C.Structure):
     _fields_ = [("kind", C.c_int32), ("time", C.c_int32), ("from_", C.c_int32), ("to", C.c_int32),
                 ("msg", C.c_uint32), ("payload", C.c_uint32)]
@@ -68,7 +73,7 @@ ABI_SYMBOLS = [
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
     "wg_protocol_cont_if", "wg_shard_configure", "wg_shard_info", "wg_next_delivery", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_batch_run_multiple_times", "wg_profile_enable", "wg_profile_read",
-    "wgh_pingpong_create", "wgh_handel_create", "wgh_gsf_create", "wgh_sanfermin_create", "wgh_casper_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
+    "wgh_pingpong_create", "wgh_handel_create", "wgh_gsf_create", "wgh_sanfermin_create", "wgh_casper_create", "wgh_p2pflood_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",
 ]
 

@@ -92,6 +92,8 @@ struct Out {
   uint32_t pad;       // flags: OUT_SHUFFLE
 };
 constexpr uint32_t OUT_SHUFFLE = 1u;  // MULTI: Collections.shuffle(dests, rd) precedes the send (n - 1 draws, then the seed)
+constexpr uint32_t OUT_DELAYED = 2u;  // MULTI: send(m, sendTime, from, dests, delaysBetweenMessage) with the delay in pad >> 8:
+                                      // a MultipleDestWithDelayEnvelope (C/Envelope.java:157-228), explicit arrivals
 
 // per-event side data written by expand (16 bytes, one store)
 struct EvAux {

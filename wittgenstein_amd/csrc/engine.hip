@@ -842,6 +842,9 @@ void Engine::load_protocol(int32_t id, const void* params, const void* initState
   } else if (id == WG_PROTO_CASPER) {
     if (!params) throw WgError(WG_EINVAL, "Casper IMD needs wg_casper_params");
     proto = make_casper_host(*this, *(const wg_casper_params*)params);
+  } else if (id == WG_PROTO_P2PFLOOD) {
+    if (!params || !initState) throw WgError(WG_EINVAL, "P2PFlood needs wg_p2pflood_params and wg_p2pflood_init_state");
+    proto = make_p2pflood_host(*this, *(const wg_p2pflood_params*)params, *(const wg_p2pflood_init_state*)initState);
   } else {
     throw WgError(WG_EINVAL, "unknown protocol id");
   }
@@ -2268,5 +2271,71 @@ struct CasperHost : ProtoHost {
 };
 
 ProtoHost* make_casper_host(Engine& e, const wg_casper_params& p) { return new CasperHost(e, p); }
+
+}  // namespace wg
+
+// ================================================================================================
+// P2PFlood resident protocol: host side
+#include "proto_p2pflood.hip.h"
+
+namespace wg {
+
+struct FloodHost : ProtoHost {
+  FloodState st{};
+  FloodHost(Engine& e, const wg_p2pflood_params& p, const wg_p2pflood_init_state& init) {
+    const int32_t N = p.nodeCount;
+    if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "P2PFlood nodeCount != nodes in the network");
+    if (!init.peers || !init.peerCount || !init.senders) throw WgError(WG_EINVAL, "wg_p2pflood_init_state has NULL members");
+    if (p.msgCount < 1 || p.msgCount > 64) throw WgError(WG_EUNSUPPORTED, "msgCount must be 1..64 on the device");
+    if (init.maxPeers < 1 || init.maxPeers > 64)
+      throw WgError(WG_EUNSUPPORTED, "a node with more than 64 peers (device multi-destination sends hold <= 64 ids)");
+    if (p.delayBetweenSends < 0 || p.delayBetweenSends >= (1 << 20) || p.delayBeforeResent < 0) throw WgError(WG_EINVAL, "delays");
+    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "P2PFlood does not run on a sharded engine yet");
+    if (!e.allocated)  // a hop arrives delayBeforeResent + up to 64 * (delayBetweenSends + 1) + latency ahead
+      e.horizonExtra = std::max(e.horizonExtra, p.delayBeforeResent + 1 + init.maxPeers * (p.delayBetweenSends + 1));
+    e.ensure_device();
+    st.p = p;
+    st.N = N;
+    st.maxPeers = init.maxPeers;
+    st.peers = e.dalloc<int32_t>((size_t)N * st.maxPeers, false);
+    st.peerCnt = e.dalloc<int32_t>(N, false);
+    st.received = e.dalloc<uint64_t>(N);
+    WG_HIP(hipMemcpy(st.peers, init.peers, 4 * (size_t)N * st.maxPeers, hipMemcpyHostToDevice));
+    WG_HIP(hipMemcpy(st.peerCnt, init.peerCount, 4 * (size_t)N, hipMemcpyHostToDevice));
+    int32_t* dS = nullptr;
+    WG_HIP(hipMalloc((void**)&dS, 4 * (size_t)p.msgCount));
+    WG_HIP(hipMemcpy(dS, init.senders, 4 * (size_t)p.msgCount, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_flood_init, dim3(1), dim3(64), 0, e.stream, st, e.dev.nodes, dS, p.msgCount);
+    WG_HIP(hipStreamSynchronize(e.stream));
+    (void)hipFree(dS);
+    e.dev.boundMsg = 1;  // one (delayed, shuffled) multi-destination send per first receipt
+    for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
+  }
+  void launch_deliver(const Group& g) override {
+    hipLaunchKernelGGL((k_deliver<FloodProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                       (const FloodState*)g.stab, 0);
+  }
+  size_t state_size() const override { return sizeof(st); }
+  const void* state_host() const override { return &st; }
+  bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
+    if (field == WG_F_FLOOD_RECEIVED) {
+      std::vector<uint64_t> h(n);
+      WG_HIP(hipMemcpy(h.data(), st.received, 8 * (size_t)n, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) dst[i] = __builtin_popcountll(h[i]);
+      return true;
+    }
+    if (field == WG_F_FLOOD_PEER_COUNT) {
+      std::vector<int32_t> h(n);
+      WG_HIP(hipMemcpy(h.data(), st.peerCnt, 4 * (size_t)n, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) dst[i] = h[i];
+      return true;
+    }
+    return false;
+  }
+};
+
+ProtoHost* make_p2pflood_host(Engine& e, const wg_p2pflood_params& p, const wg_p2pflood_init_state& st) {
+  return new FloodHost(e, p, st);
+}
 
 }  // namespace wg

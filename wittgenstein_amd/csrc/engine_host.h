@@ -281,5 +281,6 @@ ProtoHost* make_handel_host(Engine& e, const wg_handel_params& p, const wg_hande
 ProtoHost* make_gsf_host(Engine& e, const wg_gsf_params& p, const wg_gsf_init_state& st);
 ProtoHost* make_sanfermin_host(Engine& e, const wg_sanfermin_params& p);
 ProtoHost* make_casper_host(Engine& e, const wg_casper_params& p);
+ProtoHost* make_p2pflood_host(Engine& e, const wg_p2pflood_params& p, const wg_p2pflood_init_state& st);
 
 }  // namespace wg

@@ -376,11 +376,12 @@ constexpr int TILE = 1024;
 __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t* dst,
                                              int32_t* arv) {
   const int nd = o.to;
+  const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;  // sendTime += delay + 1 per destination (:459)
   int m = 0;
   for (int j = 0; j < nd && j < 64; j++) {
     int32_t to = d.sdests[(o.destOff + (unsigned long long)j) % d.sdestCap];
     int32_t a;
-    if (!arrival_of_send(d, from, to, o.t, seed, a)) continue;
+    if (!arrival_of_send(d, from, to, o.t + j * step, seed, a)) continue;
     int k = m++;
     while (k > 0 && arv[k - 1] > a) {  // insertion keeps equal arrivals in caller order
       arv[k] = arv[k - 1];
@@ -451,6 +452,8 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         if (m == 1) {
           fin = make_rec(K_MSG, from, (uint32_t)dst[0], o.a, o.b);
           arrival = arv[0];
+        } else if (m > 1 && SH && (o.pad & OUT_DELAYED)) {
+          set_err(d.g, ERR_SHARD_MULTI);  // (the exchanged envelope image carries no explicit arrivals yet)
         } else if (m > 1 && SH) {
           // the envelope (slot, sorted destinations) is replicated state: it is created on every shard from the
           // exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push order
@@ -464,6 +467,8 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
             break;
           }
           for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)j) % d.chainDests] = dst[j];
+          if (o.pad & OUT_DELAYED)  // explicit arrivals follow the destinations (the action reserved 2 n entries)
+            for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)(m + j)) % d.chainDests] = arv[j];
           Chain c;
           c.from = from;
           c.seed = seed;
@@ -472,7 +477,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           c.destOff = o.destOff;
           c.msg = o.a;
           c.payload = o.b;
-          c.flags = 1u;
+          c.flags = 1u | ((o.pad & OUT_DELAYED) ? 2u : 0u);
           d.chains[slot] = c;
           fin = make_rec(K_CHAIN, from, slot, 0, 0);
           arrival = arv[0];
@@ -1192,6 +1197,20 @@ struct Ctx {
       n = 64;
     }
     put(O_MULTI, n, msg, payload, t + 1, destOff, true, OUT_SHUFFLE, (uint32_t)(n - 1));
+  }
+  // Collections.shuffle(dests, rd); network.send(m, sendTime, this, dests, delaysBetweenMessage) (:418-447, FloodMessage
+  // :52-54): the list overload — it draws its seed even for an empty or one-element list; the list at destOff must have
+  // been reserved with 2 n entries (destinations, then their explicit arrivals)
+  __device__ void send_list_delayed_shuffled(uint32_t destOff, int n, uint32_t msg, uint32_t payload, int32_t sendTime,
+                                             int delay, int size) {
+    msgSent += n;
+    bytesSent += (long long)n * size;
+    if (n > 64) {
+      if (WG_LANE == 0) set_err(d.g, ERR_MULTI_TOO_BIG);
+      n = 64;
+    }
+    put(O_MULTI, n, msg, payload, sendTime, destOff, true, OUT_SHUFFLE | OUT_DELAYED | ((uint32_t)delay << 8),
+        n > 1 ? (uint32_t)(n - 1) : 0u);
   }
   // Network.sendAll(m, sendTime, this) (:341-347): every node of the network is a destination, one rd draw
   __device__ void send_all(uint32_t msg, uint32_t payload, int32_t sendTime, int size) {

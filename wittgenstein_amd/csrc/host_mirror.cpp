@@ -3,6 +3,7 @@
 // internals, so the same sequence is what a Java `init()` performs through the JNI shim.
 #include <algorithm>
 #include <chrono>
+#include <set>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -360,6 +361,105 @@ int32_t wgh_casper_create(const wg_casper_params* pp, const char* nodeBuilderNam
   for (int i = 0; i < attesters; i++)
     CK(wg_register_periodic_task(e, /*Attester*/ 1u, SD * (1 + i % p.cycleLength) + 4000, SD * p.cycleLength,
                                  1 + p.blockProducersCount + i));
+  g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  guard.keep = true;
+  *out = e;
+  return WG_OK;
+}
+
+int32_t wgh_p2pflood_create(const wg_p2pflood_params* pp, const char* nodeBuilderName, const char* latencyName,
+                            int64_t seed, const wg_config* cfg, wg_engine** out) {
+  if (!out || !pp) return WG_EINVAL;
+  *out = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  const wg_p2pflood_params p = *pp;
+  const int32_t N = p.nodeCount;
+  if (N <= 0 || p.deadNodeCount < 0 || p.deadNodeCount >= N || p.msgCount < 1) {
+    g_err = "P2PFlood parameters";
+    return WG_EINVAL;
+  }
+  if (p.peersCount >= N) {  // P2PNetwork.setPeers :28-35
+    g_err = "Wrong configuration: #nodes=" + std::to_string(N) + ", connection target=" + std::to_string(p.peersCount);
+    return WG_EINVAL;
+  }
+  Builder b;
+  if (!parse_builder(nodeBuilderName, b)) return WG_EINVAL;
+  wg_engine* e = nullptr;
+  int32_t rc = wg_create(cfg, &e);
+  if (rc != WG_OK) {
+    g_err = wg_last_error(nullptr);
+    return rc;
+  }
+  Cleanup guard{e};
+  CK(wg_set_latency_by_name(e, latencyName));  // ctor :88-94
+  JavaRandom rd(seed);
+  NodeSoA nodes;
+  for (int i = 0; i < N; i++) {  // init(): new P2PFloodNode(nb, i < deadNodeCount) :122-124 (its stop() when down :27-31)
+    build_node(rd, b, nodes);
+    if (i < p.deadNodeCount) nodes.down[i] = 1;
+  }
+  // P2PNetwork.setPeers with minimum == true (:27-56): nodes in a Collections.shuffle'd order, links drawn until
+  // every node has connectionCount peers; createLink :72-93
+  std::vector<std::vector<int32_t>> peers(N);
+  std::set<int64_t> links;
+  auto createLink = [&](int32_t a, int32_t c) {
+    if (a == c) return;
+    const int64_t link = ((int64_t)std::min(a, c) << 32) + (int64_t)std::max(a, c);
+    if (!links.insert(link).second) return;
+    peers[a].push_back(c);
+    peers[c].push_back(a);
+  };
+  std::vector<int32_t> an(N);
+  for (int i = 0; i < N; i++) an[i] = i;
+  for (int32_t k = N; k > 1; k--) std::swap(an[k - 1], an[rd.nextInt(k)]);
+  for (int32_t n : an)
+    while ((int32_t)peers[n].size() < p.peersCount) createLink(n, rd.nextInt(N));
+  int32_t maxPeers = 1;
+  for (auto& v : peers) maxPeers = std::max(maxPeers, (int32_t)v.size());
+  if (maxPeers > 64) {
+    g_err = "a node has more than 64 peers (device multi-destination sends hold <= 64 ids)";
+    return WG_EUNSUPPORTED;
+  }
+  CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nodes.down.data(),
+                  nodes.speed.data()));
+  std::vector<int32_t> flat((size_t)N * maxPeers, -1), cnt(N);
+  for (int i = 0; i < N; i++) {
+    cnt[i] = (int32_t)peers[i].size();
+    for (size_t k = 0; k < peers[i].size(); k++) flat[(size_t)i * maxPeers + k] = peers[i][k];
+  }
+  // the senders loop :126-139 interleaves three uses of rd: the sender's id, sendPeers' shuffle of its peers
+  // (C/P2PNetwork.java:127-132) and the seed Network.send draws (:430). The protocol has to be loaded (with the senders)
+  // before the first wg_send, so the loop runs twice: on a copy of rd to learn the senders, then for real.
+  std::vector<int32_t> senders;
+  {
+    JavaRandom probe = rd;
+    std::set<int32_t> seen;
+    while ((int32_t)senders.size() < p.msgCount) {
+      const int32_t nodeId = probe.nextInt(N);
+      if (nodes.down[nodeId] || !seen.insert(nodeId).second) continue;
+      for (int32_t k = (int32_t)peers[nodeId].size(); k > 1; k--) (void)probe.nextInt(k);
+      (void)probe.nextInt();
+      senders.push_back(nodeId);
+    }
+  }
+  wg_p2pflood_init_state st{flat.data(), cnt.data(), maxPeers, senders.data()};
+  CK(wg_rng_set_state(e, rd.s));
+  CK(wg_protocol_load(e, WG_PROTO_P2PFLOOD, &p, &st));
+  {
+    std::set<int32_t> seen;
+    int32_t k = 0;
+    while (k < p.msgCount) {
+      const int32_t nodeId = rd.nextInt(N);
+      if (nodes.down[nodeId] || !seen.insert(nodeId).second) continue;
+      std::vector<int32_t> dest(peers[nodeId]);
+      for (int32_t q = (int32_t)dest.size(); q > 1; q--) std::swap(dest[q - 1], dest[rd.nextInt(q)]);
+      CK(wg_rng_set_state(e, rd.s));  // the engine's rd is the Java rd: wg_send draws the seed from it
+      CK(wg_send(e, (uint32_t)k, 0u, 1 + p.delayBeforeResent, nodeId, dest.data(), (int32_t)dest.size(), p.delayBetweenSends));
+      (void)rd.nextInt();
+      k++;
+    }
+    CK(wg_rng_set_state(e, rd.s));
+  }
   g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   guard.keep = true;
   *out = e;

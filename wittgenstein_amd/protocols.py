@@ -251,3 +251,45 @@ class CasperIMD:
 
     def network(self):
         return self._net
+
+
+class P2PFloodParameters:
+    """P/P2PFlood.java:41-86, constructor argument order preserved."""
+
+    def __init__(self, nodeCount=100, deadNodeCount=10, delayBeforeResent=50, msgCount=1, msgToReceive=1, peersCount=10,
+                 delayBetweenSends=30, nodeBuilderName=None, networkLatencyName=None):
+        self.nodeCount, self.deadNodeCount, self.delayBeforeResent = nodeCount, deadNodeCount, delayBeforeResent
+        self.msgCount, self.msgToReceive, self.peersCount = msgCount, msgToReceive, peersCount
+        self.delayBetweenSends = delayBetweenSends
+        self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
+
+
+class P2PFlood:
+    """P/P2PFlood.java resident on the device (wittgenstein_amd/csrc/proto_p2pflood.hip.h); the peer graph is built on
+    the host as P2PNetwork.setPeers does."""
+
+    def __init__(self, params=None, seed=0, config=None):
+        self.params = params or P2PFloodParameters()
+        self.seed, self.config = seed, config
+        self._net = None
+        self.init_seconds = None
+
+    def copy(self):
+        return P2PFlood(self.params, self.seed, self.config)
+
+    def init(self):
+        p = self.params
+        fp = L.wg_p2pflood_params(p.nodeCount, p.deadNodeCount, p.delayBeforeResent, p.msgCount, p.msgToReceive,
+                                  p.peersCount, p.delayBetweenSends)
+        h = C.c_void_p()
+        cfg = _config(self.config)
+        rc = L.lib().wgh_p2pflood_create(C.byref(fp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                         p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                         C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        if rc != L.WG_OK:
+            _raise(rc, L.lib().wgh_last_error().decode())
+        self._net = Network(h)
+        self.init_seconds = L.lib().wgh_last_init_seconds()
+
+    def network(self):
+        return self._net
