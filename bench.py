@@ -88,6 +88,13 @@ def make_batch(w, n, seeds, device, threads, workload="handel"):
     return sims, w.Batch([g.network() for g in sims])
 
 
+def split_batches(w, sims, k):
+    """the copies of one step as k batches (contiguous slices), each led by its first member's stream"""
+    k = max(1, min(k, len(sims)))
+    per = (len(sims) + k - 1) // k
+    return [w.Batch([g.network() for g in sims[i:i + per]]) for i in range(0, len(sims), per)]
+
+
 def cpu_baseline(n_sample, workload="handel"):
     """the C++ oracle (event-for-event restatement of the single-threaded Java path) on one host core"""
     import oracle_lib as o
@@ -153,7 +160,7 @@ def main_casper(args):
         raise SystemExit("--workload casper is a one-GPU line")
     from wittgenstein_amd import protocols as P
     K, W, per, T = args.steps, args.warmup, args.attesters_per_round, args.casper_ms
-    cl, bp = 2, 2
+    cl, bp = args.casper_cycle_length, args.casper_producers
     params = (cl, False, bp, per, 1000, 1)
     n = 1 + bp + cl * per
     delivered = 0
@@ -312,10 +319,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
     ap.add_argument("--replicas", type=int, default=16, help="independent simulations per step and per GPU")
+    ap.add_argument("--batches", type=int, default=1,
+                    help="split a step's copies into this many concurrently running batches (one HIP stream each)")
     ap.add_argument("--init-threads", type=int, default=6)
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--attesters-per-round", type=int, default=4096, help="--workload casper: attesters voting per slot")
+    ap.add_argument("--casper-cycle-length", type=int, default=2, help="--workload casper: slots per cycle (BASELINE config 5: 64)")
+    ap.add_argument("--casper-producers", type=int, default=2, help="--workload casper: block producers (BASELINE config 5: 5)")
     ap.add_argument("--casper-ms", type=int, default=40000, help="--workload casper: simulated ms per step")
     ap.add_argument("--workload", choices=["handel", "gsf", "casper"], default="handel",
                     help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
@@ -414,9 +425,20 @@ def main():
     t0 = time.perf_counter()
     delivered = sim_ms = 0
     for sims, batch in timed:
-        d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
-        delivered += sum(d)
-        sim_ms += sum(ms)
+        if args.batches > 1:
+            # the step's copies as `--batches` smaller batches, each on its own HIP stream and host thread: while one
+            # batch sits in a kernel's low-occupancy tail the other batches' kernels fill the chip
+            subs = split_batches(w, sims, args.batches)
+            with ThreadPoolExecutor(max_workers=len(subs)) as ex:
+                res = list(ex.map(lambda b: b.run_multiple_times(chunk=10, maxTime=20000), subs))
+            for d, ms in res:
+                delivered += sum(d)
+                sim_ms += sum(ms)
+            del subs
+        else:
+            d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
+            delivered += sum(d)
+            sim_ms += sum(ms)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -457,7 +479,8 @@ def main():
                                 "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
                                 "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
                                 "copy's Handel.newContIf is false" % (n, R)),
-                   "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch",
+                   "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch" +
+                   ("" if args.batches <= 1 else ", %d concurrent batches (one HIP stream each)" % args.batches),
                    "delivered_per_simulation": delivered // max(1, K * R * world),
                    "init_s_per_simulation": init_s},
     }
@@ -465,6 +488,8 @@ def main():
     # in the timed region / its launches, over its average duration measured with HIP events in the timed region
     alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
     per_launch_bytes = alg_bytes / max(1, dk_spans)
+    if args.batches > 1:  # the HIP events bracket the first batch's launches only: its share of the bytes
+        per_launch_bytes /= min(args.batches, R)
     avg_ns = dk_ns / max(1, dk_spans)
     achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
     traffic = None

@@ -11,7 +11,7 @@ REPO=$(pwd)
 for w in $WHAT; do
 case $w in
 tests)
-  timeout 900 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log ;;
+  timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu ${PYTEST_X--x} -q --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log ;;
 bench)
   timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json ;;
 prof)

@@ -3,8 +3,16 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch. MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE =
 TCC_EA0_RDREQ x 64 B and undercounts 128-byte requests by half (calibrated on wide coalesced reads); other widths and
-WRITE_SIZE are uncalibrated. The delivery kernels issue mostly scattered 64-byte accesses, so both readings are kept:
-`hbm_bytes_per_launch` applies the guide's x2 to the reads (an upper bound), `..._uncorrected` does not.
+WRITE_SIZE are "uncalibrated: calibrate on a known byte count in your own access pattern". That calibration is
+tools/micro/pmc_calib.hip (profiles/r02b_pmc_calib.txt), for the access shapes of the delivery kernels:
+  reads   one 64-byte line per request (8 lanes x 8 B, or 4 lanes x 16 B): FETCH_SIZE == bytes (x1.00);
+          a lane alone in its line (8 or 16 B used): 64 B counted per lane (the line is fetched);
+          wide coalesced 16 B/lane streams: x0.50 (the guide's case)
+  writes  full lines: WRITE_SIZE == bytes (x1.00, also for the coalesced stream);
+          a lane alone in its line (8 or 16 B): 32 B counted per lane (32-byte write granules)
+So for these kernels (scattered lines and lane-scattered words, no wide streams) the counters are the memory-side
+bytes as they stand: `hbm_bytes_per_launch` = FETCH_SIZE + WRITE_SIZE; `..._reads_doubled` keeps the guide's x2 on
+the reads as the upper bound (it would apply only to the part of the reads that are 128-byte requests).
 usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json>"""
 import json
 import sys
@@ -31,10 +39,13 @@ def main():
     json.dump({"nodes": nodes, "replicas": replicas,
                "kernels": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (one launch of each per simulated ms)",
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
-               "hbm_bytes_per_launch": 2.0 * rd + wr, "hbm_bytes_per_launch_uncorrected": rd + wr,
+               "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,
                "per_kernel_KB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; reads doubled per the guide's gfx950 "
-                       "correction (upper bound for 64-byte scattered reads); per dispatch means over the run"},
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per dispatch means over the run; "
+                       "calibrated on known byte counts in these access shapes (profiles/r02b_pmc_calib.txt): scattered "
+                       "64-byte-line reads and full-line writes count x1.00, a lane alone in its line counts the 64-byte "
+                       "line (read) / a 32-byte granule (write); the guide's x2 (128-byte requests) is kept as "
+                       "..._reads_doubled, an upper bound"},
               open(out, "w"), indent=1)
     print(open(out).read())
 

@@ -74,10 +74,21 @@ def traffic(net):
     return c.value, w.value
 
 
-def gather(dist, per_shard, group=None, device="cpu"):
+def _host_device(dist, group=None):
+    """where a host-side value has to live to be reduced over this group: RCCL ("nccl") only moves device tensors,
+    gloo only host tensors"""
+    import torch
+    try:
+        nccl = "nccl" in str(dist.get_backend(group)).lower()
+    except Exception:  # LoopbackGroup and other in-process stand-ins: host tensors
+        nccl = False
+    return torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+
+
+def gather(dist, per_shard, group=None, device=None):
     """whole-network view of a per-node read-back: a shard reports its own nodes and zeros for the others"""
     import torch
-    t = torch.as_tensor(np.ascontiguousarray(per_shard)).to(device)
+    t = torch.as_tensor(np.ascontiguousarray(per_shard)).to(device or _host_device(dist, group))
     dist.all_reduce(t, group=group)
     return t.cpu().numpy()
 
@@ -86,7 +97,7 @@ def cont_if(dist, protocol, group=None):
     """the RunMultipleTimes continuation predicate of a sharded protocol: a shard evaluates it over its own nodes
     (Handel.newContIf, P/Handel.java:1044-1053, is an OR over live nodes)"""
     import torch
-    t = torch.tensor([1 if protocol.cont_if() else 0], dtype=torch.int32)
+    t = torch.tensor([1 if protocol.cont_if() else 0], dtype=torch.int32, device=_host_device(dist, group))
     dist.all_reduce(t, group=group)
     return bool(t.item())
 
