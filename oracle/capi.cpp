@@ -463,6 +463,17 @@ int orc_casper_run_ms(void* h, int ms, int* didSomething) {
   ORC_TRY* didSomething = ((OrcCasper*)h)->p->network().runMs(ms);
   ORC_CATCH
 }
+// BASELINE config 5's "+10 % Byzantine" has no counterpart in the reference (init() installs exactly one
+// ByzBlockProducerWF, P/CasperIMD.java:473-476); SURVEY.md §8d defines it as attesters stop()ped after init(),
+// identically in the oracle and the engine: Node.stop() (C/Node.java:120-123) on the listed nodes.
+int orc_casper_stop(void* h, const int32_t* ids, int n) {
+  ORC_TRY auto& net = ((OrcCasper*)h)->p->network();
+  for (int i = 0; i < n; i++) {
+    if (ids[i] < 0 || ids[i] >= (int)net.allNodes.size()) throw IllegalArgumentException("node id");
+    net.allNodes[ids[i]]->stop();
+  }
+  ORC_CATCH
+}
 int orc_casper_node_count(void* h) { return (int)((OrcCasper*)h)->p->network().allNodes.size(); }
 // fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 head.height, 5 head.proposalTime, 6 head.id,
 //         7 attestationsByHead.size(), 8 x, 9 y, 10 blocksReceivedByBlockId.size(), 11 attestations held (all heads)

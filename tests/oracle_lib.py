@@ -300,6 +300,11 @@ class CasperIMD:
             lib().orc_casper_destroy(self.h)
             self.h = None
 
+    def stop(self, ids):
+        """Node.stop() on the listed nodes (SURVEY.md §8d's definition of config 5's stopped attesters)"""
+        a = np.ascontiguousarray(ids, np.int32)
+        _ck(lib().orc_casper_stop(self.h, _p(a, C.c_int32), len(a)))
+
     def run_ms(self, ms):
         d = C.c_int()
         _ck(lib().orc_casper_run_ms(self.h, ms, C.byref(d)))

@@ -181,6 +181,10 @@ def test_casper_resident():  # P/CasperIMD.java resident on the device vs oracle
     tcr.test_random_on_ties_is_refused()
 
 
+def test_casper_resident_stopped_attesters():  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
+    tcr.lockstep((2, False, 2, 10, 100, 1), seed=7, chunk=1500, chunks=12, nl="NetworkFixedLatency(20)", stopped=2)
+
+
 def test_p2pflood_resident():  # P/P2PFlood.java resident on the device vs oracle/p2pflood.hpp
     tfr.test_three_messages_by_distance()
     tfr.lockstep((64, 0, 5, 2, 1, 12, 1), "NetworkFixedLatency(7)", seed=9, chunk=1, chunks=150)

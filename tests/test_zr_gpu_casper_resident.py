@@ -29,12 +29,18 @@ def diff(g, c):
     return out
 
 
-def lockstep(params, seed, chunk, chunks, byz_delay=0, nl=None, max_slots=16):
+def lockstep(params, seed, chunk, chunks, byz_delay=0, nl=None, max_slots=16, stopped=0):
     """params = CasperParemeters ctor order: (cycleLength, randomOnTies, blockProducersCount, attestersPerRound,
-    blockConstructionTime, attestationConstructionTime)"""
+    blockConstructionTime, attestationConstructionTime); stopped = attesters stop()ped after init() (BASELINE config
+    5's "+10 % Byzantine" as SURVEY.md §8d defines it), the same nodes on both sides"""
     g = P.CasperIMD(P.CasperParemeters(*params, None, nl), seed=seed, byz_delay=byz_delay, max_slots=max_slots)
     g.init()
     c = o.CasperIMD(params, None, nl, seed=seed, byz_delay=byz_delay)
+    if stopped:
+        ids = g.stop_attesters(stopped, seed=seed + 1)
+        assert len(set(ids)) == stopped and all(i in g.attester_ids() for i in ids)
+        c.stop(ids)
+        g.stopped_ids = ids
     assert not diff(g, c), "after init()"
     for k in range(chunks):
         g.network().runMs(chunk)
@@ -60,6 +66,23 @@ def test_casper_reference_test_parameters():  # PT/CasperIMDTest.java:10-11: 5 p
     g, c = lockstep((5, False, 5, 80, 1000, 1), seed=0, chunk=4000, chunks=12)
     assert g.network().node_count == 406 and c.info()["delivered"] > 150000
     assert g.network().read("headHeight")[0] == 5
+
+
+@pytest.mark.gpu
+def test_casper_ten_percent_attesters_stopped():  # BASELINE config 5's "+10 %": 40 of 400 attesters stop()ped
+    g, c = lockstep((5, False, 5, 80, 1000, 1), seed=3, chunk=4000, chunks=12, stopped=40)
+    held = g.network().read("attestationsHeld")
+    ids = g.stopped_ids
+    assert ids == P.choose_attesters(g.attester_ids(), 40, seed=4)
+    assert int(g.network().read("msgReceived")[ids].sum()) == 0   # a stopped node receives nothing ...
+    assert int(g.network().read("msgSent")[ids].sum()) == 0       # ... and its attester task never runs
+    live = np.setdiff1d(np.arange(1, g.network().node_count), ids)
+    assert int(held[live].min()) > 0 and int(held[ids].max()) == 0
+
+
+@pytest.mark.gpu
+def test_casper_stopped_attesters_byzantine_delay():
+    lockstep((3, False, 3, 8, 1000, 1), seed=9, chunk=1000, chunks=40, byz_delay=-2000, stopped=3)
 
 
 @pytest.mark.gpu

@@ -252,6 +252,61 @@ class CasperIMD:
     def network(self):
         return self._net
 
+    def attester_ids(self):
+        p = self.params
+        first = 1 + p.blockProducersCount
+        return range(first, first + p.cycleLength * p.attestersPerRound)
+
+    def stop_attesters(self, count, seed=0):
+        """BASELINE config 5's "+10 % Byzantine": the reference has no such population (init() installs exactly one
+        ByzBlockProducerWF, P/CasperIMD.java:473-476), so it is defined as `count` attesters stop()ped
+        (C/Node.java:120-123) after init(), chosen the way Network.chooseBadNodes picks (C/Network.java:52-64: draw
+        until `count` distinct ones) from a java.util.Random(seed) of their own — the simulation's rd is not touched.
+        Returns the node ids, so that a checker can stop the same nodes."""
+        ids = choose_attesters(self.attester_ids(), count, seed)
+        for i in ids:
+            self._net.set_node_down(i, True)
+        return ids
+
+
+class _JavaRandom:
+    """java.util.Random's nextInt(bound) (JDK javadoc algorithm) for host-side choices that need no engine"""
+
+    def __init__(self, seed):
+        self.s = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+
+    def _next(self, bits):
+        self.s = (self.s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.s >> (48 - bits)
+        return v - (1 << 32) if v >= (1 << 31) else v  # (int) of the shifted seed
+
+    def nextInt(self, bound):
+        if bound <= 0:
+            raise ValueError("bound must be positive")
+        r = self._next(31)
+        m = bound - 1
+        if (bound & m) == 0:
+            return (bound * r) >> 31
+        u = r
+        while True:
+            r = u % bound
+            if u - r + m < (1 << 31):
+                return r
+            u = self._next(31)
+
+
+def choose_attesters(attester_ids, count, seed=0):
+    ids = list(attester_ids)
+    if not 0 <= count < len(ids):
+        raise ValueError("count must be in [0, attesters)")
+    rd, bad, out = _JavaRandom(seed), set(), []
+    while len(out) < count:
+        k = rd.nextInt(len(ids))
+        if k not in bad:
+            bad.add(k)
+            out.append(ids[k])
+    return out
+
 
 class P2PFloodParameters:
     """P/P2PFlood.java:41-86, constructor argument order preserved."""
