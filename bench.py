@@ -149,9 +149,10 @@ def cpu_baseline(n_sample, workload="handel"):
 
 
 def main_casper(args):
-    """BASELINE configs[4]'s protocol at a size the resident form delivers today: Casper IMD, cycleLength 2, 2 block
-    producers, --attesters-per-round attesters voting per slot (every vote and block is a sendAll to all N nodes). A step
-    is one simulation of --casper-ms simulated ms. Not the BASELINE metric's workload (that is Handel): a second line."""
+    """BASELINE configs[4]'s protocol at its node count, on one GPU: Casper IMD, cycleLength 64, 5 block producers,
+    --attesters-per-round (4096) attesters voting per slot = 262 150 nodes (every vote and block is a sendAll to all N
+    nodes); --casper-stopped 0.1 stops 10 % of the attesters after init(). A step is one simulation of --casper-ms
+    simulated ms. Not the BASELINE metric's workload (that is Handel): a second line."""
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
@@ -170,6 +171,8 @@ def main_casper(args):
         g = P.CasperIMD(P.CasperParemeters(*params, NB, NL), seed=step, max_slots=T // 8000 + 2)
         g.init()
         net = g.network()
+        if args.casper_stopped > 0:  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
+            g.stop_attesters(int(args.casper_stopped * cl * per), seed=step)
         net.profile(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -194,7 +197,9 @@ def main_casper(args):
         "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": K * T / elapsed,
         "config": {"workload": "Casper IMD, %d nodes (1 observer, %d block producers, %d x %d attesters), randomOnTies false, "
                                "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
-                               "%d simulated ms per step" % (n, bp, cl, per, T), "nodes": n},
+                               "%d simulated ms per step%s" % (n, bp, cl, per, T, "" if args.casper_stopped <= 0 else
+                                                               ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
+                   "nodes": n},
         "roofline": {"bound": "hbm", "kernel": "k_deliver<CasperProto>", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
@@ -203,8 +208,11 @@ def main_casper(args):
     if not args.no_cpu:
         import oracle_lib as o
         o.build()
-        sample = min(per, 512)  # the oracle keeps every attestation in every node's HashSet: bounded sample
+        # the oracle keeps every attestation in every node's HashSet: a bounded sample (about 10 s of one core)
+        sample = min(per, 512, max(16, 16384 // cl))
         c = o.CasperIMD((cl, False, bp, sample, 1000, 1), NB, NL, seed=0)
+        if args.casper_stopped > 0:
+            c.stop(P.choose_attesters(range(1 + bp, 1 + bp + cl * sample), int(args.casper_stopped * cl * sample), seed=0))
         t0 = time.perf_counter()
         c.run_ms(T)
         dt = time.perf_counter() - t0
@@ -325,9 +333,11 @@ def main():
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--attesters-per-round", type=int, default=4096, help="--workload casper: attesters voting per slot")
-    ap.add_argument("--casper-cycle-length", type=int, default=2, help="--workload casper: slots per cycle (BASELINE config 5: 64)")
-    ap.add_argument("--casper-producers", type=int, default=2, help="--workload casper: block producers (BASELINE config 5: 5)")
-    ap.add_argument("--casper-ms", type=int, default=40000, help="--workload casper: simulated ms per step")
+    ap.add_argument("--casper-cycle-length", type=int, default=64, help="--workload casper: slots per cycle (BASELINE config 5: 64)")
+    ap.add_argument("--casper-producers", type=int, default=5, help="--workload casper: block producers (BASELINE config 5: 5)")
+    ap.add_argument("--casper-stopped", type=float, default=0.0,
+                    help="--workload casper: fraction of the attesters stop()ped after init() (config 5's '+10 %%': 0.1)")
+    ap.add_argument("--casper-ms", type=int, default=24000, help="--workload casper: simulated ms per step")
     ap.add_argument("--workload", choices=["handel", "gsf", "casper"], default="handel",
                     help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
                          "(use --nodes 4096)")

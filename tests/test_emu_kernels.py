@@ -185,6 +185,12 @@ def test_casper_resident_stopped_attesters():  # config 5's "+10 %" (SURVEY.md Â
     tcr.lockstep((2, False, 2, 10, 100, 1), seed=7, chunk=1500, chunks=12, nl="NetworkFixedLatency(20)", stopped=2)
 
 
+def test_long_chain_runs_one_wavefront_each(monkeypatch):  # k_expand_runs, forced on networks this small
+    monkeypatch.setenv("WG_RUN_MIN", "2")
+    tcr.lockstep((2, False, 2, 10, 100, 1), seed=3, chunk=1500, chunks=8, nl="NetworkFixedLatency(20)", stopped=1)
+    th.lockstep(th.ratios(128), step=10)  # Handel fast-path envelopes (<= 64 destinations) through the same path
+
+
 def test_p2pflood_resident():  # P/P2PFlood.java resident on the device vs oracle/p2pflood.hpp
     tfr.test_three_messages_by_distance()
     tfr.lockstep((64, 0, 5, 2, 1, 12, 1), "NetworkFixedLatency(7)", seed=9, chunk=1, chunks=150)

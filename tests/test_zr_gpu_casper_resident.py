@@ -86,6 +86,16 @@ def test_casper_stopped_attesters_byzantine_delay():
 
 
 @pytest.mark.gpu
+def test_casper_long_chain_runs_one_wavefront_each(monkeypatch):
+    """k_expand_runs: chain runs of >= runMin hops (64 for this protocol: a sendAll to N nodes has runs of ~N/300) are
+    unrolled one wavefront per run instead of in place by the scanning lane; WG_RUN_MIN=2 sends every run of 2+ hops of
+    these small networks through it — same events, same order, same everything as the oracle"""
+    monkeypatch.setenv("WG_RUN_MIN", "2")
+    lockstep((5, False, 5, 80, 1000, 1), seed=1, chunk=4000, chunks=8, stopped=17)
+    lockstep((3, False, 3, 8, 1000, 1), seed=2, chunk=500, chunks=40, byz_delay=-2000)
+
+
+@pytest.mark.gpu
 def test_casper_4096_attesters_a_slot_runs():  # one round of BASELINE config 5's attesters per slot, 2 cycles of 2 slots
     g = P.CasperIMD(P.CasperParemeters(2, False, 2, 4096, 1000, 1), seed=1, max_slots=8)
     g.init()

@@ -41,6 +41,7 @@ constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
 constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_deliver_msgs)
 constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;
 constexpr int GRID_TILES = 256 / WG_GRID_DIV;
+constexpr int GRID_EXPAND_RUNS = 1024 / WG_GRID_DIV;  // x 4 wavefronts: one per long chain run
 constexpr int GRID_COND_TAIL = 128 / WG_GRID_DIV;
 
 enum RecKind : uint32_t { K_MSG = 0, K_TASK = 1, K_PERIODIC = 2, K_CHAIN = 3 };
@@ -176,6 +177,7 @@ struct Globals {
   unsigned long long localDestHead;
   uint32_t nSendAll;       // Network.sendAll calls made by action()s in this phase (k_sendall_*), reset by k_end_phase
   uint32_t nFar;           // records parked in EngineDev::farBuf since the host last collected them
+  uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
 };
 
 struct LatencyModel {
@@ -280,6 +282,17 @@ struct EngineDev {
   uint32_t maxSendAll;
   struct FarRec* farBuf;    // NULL: arrivals beyond the ring are an error
   uint32_t farCap;
+  // chain runs (consecutive hops of one multi-destination envelope arriving in the same ms) of >= runMin hops are
+  // not unrolled by the lane that scans their bucket record but listed here and unrolled one wavefront per run by
+  // k_expand_runs (a sendAll to N nodes has runs of ~N/300 hops: Casper). runMin == 0: every run is unrolled in place
+  struct RunDesc* runs;
+  uint32_t maxRuns;
+  uint32_t runMin;
+};
+struct RunDesc {  // 32 bytes
+  uint32_t chain, pos;      // envelope slot, first hop of the run
+  uint32_t e, ob;           // its first event index / first outbox slot (the expand scan's exclusive prefix)
+  uint32_t len, pad0, pad1, pad2;
 };
 // An envelope an action() registered for a time beyond the bucket ring (a task seconds ahead: Casper's 8 s slots): parked
 // here, collected by the host every `horizon` ms of simulated time and staged like a host-side registration — it is

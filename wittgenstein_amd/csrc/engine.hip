@@ -408,6 +408,16 @@ void Engine::ensure_device() {
     dev.saLat = dalloc<int32_t>((size_t)dev.maxSendAll * n, false);
     dev.saHist = dalloc<uint32_t>((size_t)dev.maxSendAll * ((n + TILE - 1) / TILE) * D, false);
   }
+  // long chain runs (EngineDev::runs): worth a wavefront each where envelopes reach every node — the resident
+  // protocols that call Network.sendAll (WG_RUN_MIN=<hops> overrides, 0 = unroll every run in place)
+  dev.runs = nullptr;
+  dev.maxRuns = 0;
+  dev.runMin = sendAllCapacity > 0 ? 64u : 0u;
+  if (const char* rm = getenv("WG_RUN_MIN")) dev.runMin = (uint32_t)std::max(0, atoi(rm));
+  if (dev.runMin) {
+    dev.maxRuns = dev.chainSlots;
+    dev.runs = dalloc<RunDesc>(dev.maxRuns, false);
+  }
   dev.sharded = shardCount > 0 ? 1u : 0u;
   dev.shardLo = 0;
   dev.shardHi = INT32_MAX;
@@ -653,6 +663,11 @@ void Engine::scan(const Group& g, const typename F::Aux* atab) {
   hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
 template void Engine::scan<ExpandF>(const Group&, const int*);
+// expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
+void Engine::expand(const Group& g) {
+  scan<ExpandF>(g, nullptr);
+  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(GRID_EXPAND_RUNS, g.R), dim3(256), 0, g.stream, g.tab);
+}
 template void Engine::scan<RecsF>(const Group&, const int*);
 template void Engine::scan<MultiF>(const Group&, const int*);
 
@@ -905,7 +920,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
   typedef Engine::ProfScope ProfScope;
     {
       ProfScope ps(lead, Engine::PC_EXPAND);
-      Engine::scan<ExpandF>(g, nullptr);
+      lead.expand(g);
     }
     {
       ProfScope ps(lead, Engine::PC_DELIVER);
@@ -1096,7 +1111,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
       WG_HIP(hipStreamSynchronize(stream));
       flush_staged(t, true);
     }
-    scan<ExpandF>(g, nullptr);
+    expand(g);
     {
       ProfScope ps(*this, PC_DELIVER);
       proto->launch_deliver(g);
@@ -1264,7 +1279,7 @@ bool Engine::next_delivery(int32_t until, int32_t condTime, wg_delivery* out) {
     globalsDirty = true;
     sync_globals_to_device();
     Group g = self();
-    scan<ExpandF>(g, nullptr);
+    expand(g);
     sync_globals_to_host();
     check_device_errors();
     const uint32_t n = gh.nEvents;

@@ -215,9 +215,30 @@ struct ExpandF {
   __device__ uint32_t runlen(const Rec& r, int32_t t) const {
     if (rec_kind(r) != K_CHAIN) return 1;
     const Chain c = d.chains[r.w1];
-    uint32_t len = 1;
-    for (int j = (int)r.w2 + 1; j < c.ndest && chain_arrival(d, c, j) == t; j++) len++;
-    return len;
+    // The destinations of an envelope are sorted by arrival when it is created (C/Network.java:464), so arrivals
+    // never decrease along the chain and the run of hops arriving in t, which starts at r.w2, ends before the first
+    // hop arriving later: gallop to bracket that hop, then bisect. One probe for the usual run of one hop (as the
+    // plain walk), ~2 log2(len) for the N/300-hop runs of a sendAll.
+    const int p = (int)r.w2, n = c.ndest;
+    int lo = p + 1, hi = n, step = 1;  // arrival(j) == t for p <= j < lo; arrival(hi) > t or hi == n
+    while (lo < n) {
+      const int probe = min(lo + step - 1, n - 1);
+      if (chain_arrival(d, c, probe) == t) {
+        lo = probe + 1;
+        step <<= 1;
+      } else {
+        hi = probe;
+        break;
+      }
+    }
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (chain_arrival(d, c, mid) == t)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return (uint32_t)(lo - p);
   }
   __device__ uint32_t task_bound(const Rec& r) const {
     return d.boundTask[r.w2 < 3u ? r.w2 : 3u] + (rec_kind(r) == K_PERIODIC ? 1u : 0u);
@@ -274,6 +295,21 @@ struct ExpandF {
       } else {
         const Chain c = d.chains[r.w1];
         const uint32_t len = runlen(r, t);
+        if (d.runMin && len >= d.runMin) {  // a long run: one wavefront unrolls it (k_expand_runs)
+          const uint32_t k = atomicAdd(&d.g->nRuns, 1u);
+          if (k < d.maxRuns) {
+            RunDesc rd;
+            rd.chain = r.w1;
+            rd.pos = r.w2;
+            rd.e = e;
+            rd.ob = ob;
+            rd.len = len;
+            rd.pad0 = rd.pad1 = rd.pad2 = 0;
+            d.runs[k] = rd;
+          } else {
+            set_err(d.g, ERR_EVENTS);
+          }
+        } else
         for (uint32_t q = 0; q < len; q++, e++) {
           if (e >= d.maxEvents) break;
           const int32_t to = chain_dest(d, c, (int)r.w2 + (int)q);
@@ -302,6 +338,47 @@ struct ExpandF {
     }
   }
 };
+
+// The long chain runs ExpandF::write listed (EngineDev::runs): one wavefront per run, a lane per hop — destination ids
+// read and events written coalesced, the inbox links and the active-list append as in ExpandF::write. Event indices
+// and outbox slices are the scan's, so the result is what the in-place unrolling would have written.
+__global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  const uint32_t nRuns = min(d.g->nRuns, d.maxRuns);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t lane = WG_LANE;
+  const ExpandF f(d, nullptr);
+  for (uint32_t k = wave; k < nRuns; k += nWaves) {
+    const RunDesc rd = d.runs[k];
+    const Chain c = d.chains[rd.chain];
+    for (uint32_t q0 = 0; q0 < rd.len; q0 += 64) {
+      const uint32_t q = q0 + lane, e = rd.e + q;
+      bool first = false;
+      int32_t to = 0;
+      if (q < rd.len && e < d.maxEvents) {
+        to = chain_dest(d, c, (int)(rd.pos + q));
+        d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+        const bool last = q + 1 == rd.len;
+        EvAux a;
+        a.chain = (int32_t)rd.chain;
+        a.cpos = (int32_t)(rd.pos + q) | (last ? (int32_t)0x80000000 : 0);
+        a.outBase = rd.ob + q * d.boundMsg;
+        a.outCap = d.boundMsg + (last ? 1u : 0u);
+        d.evAux[e] = a;
+        if (!d.hostMode) first = f.link(e, to);
+      }
+      const uint64_t m = __ballot(first);
+      if (m) {
+        uint32_t base = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if ((int)lane == leader) base = atomicAdd(&d.g->nActive, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (first) d.active[base + __popcll(m & lanes_lt())] = (uint32_t)to;
+      }
+    }
+  }
+}
 
 // order: per-event (records, draws) -> offsets in the global push order / draw order, the event of
 // every ordered outbox position, and the run statistics (block-aggregated).
@@ -1038,6 +1115,7 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
     g->nMulti = 0;
     g->nMultiDests = 0;
     g->nSendAll = 0;
+    g->nRuns = 0;
   }
   __syncthreads();
   if (drained) {
