@@ -984,24 +984,60 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
   auto t0 = std::chrono::steady_clock::now();
   ProtoHost* proto = lead.proto;
   const bool cond = proto->has_cond();
-  for (int32_t k = 0; k <= ms; k++) {
-    // Host-held envelopes beyond the bucket ring come into range as `now` advances (arrival - t <
-    // horizon). They must precede every device push into their bucket: drain(t - 1) reaches at most
-    // t + horizon - 2 and the conditional-task phase of the edge to t is held to the same bound
-    // (ERR_HORIZON at horizon - 1), so injecting before drain(t) keeps the bucket's push order.
-    if (k > 0)
-      for (int r = 0; r < R; r++) {
-        Engine& e = *es[r];
-        const int32_t t = e.time + k;
-        // (a parked envelope is >= 2 * horizon ms ahead of its push: collecting every horizon ms is early enough)
-        if (on[r] && e.dev.farBuf && (t % e.dev.horizon) == 0) e.collect_far();
-        if (on[r] && e.stagedMin - t < e.dev.horizon) {
-          WG_HIP(hipStreamSynchronize(g.stream));
-          e.flush_staged(t, true);
+  // Host-held envelopes beyond the bucket ring come into range as `now` advances (arrival - t <
+  // horizon). They must precede every device push into their bucket: drain(t - 1) reaches at most
+  // t + horizon - 2 and the conditional-task phase of the edge to t is held to the same bound
+  // (ERR_HORIZON at horizon - 1), so injecting before drain(t) keeps the bucket's push order.
+  auto host_envelopes = [&](int32_t k) {
+    for (int r = 0; r < R; r++) {
+      Engine& e = *es[r];
+      const int32_t t = e.time + k;
+      // (a parked envelope is >= 2 * horizon ms ahead of its push: collecting every horizon ms is early enough)
+      if (on[r] && e.dev.farBuf && (t % e.dev.horizon) == 0) e.collect_far();
+      if (on[r] && e.stagedMin - t < e.dev.horizon) {
+        WG_HIP(hipStreamSynchronize(g.stream));
+        e.flush_staged(t, true);
+      }
+    }
+  };
+  // Idle stretches are skipped instead of enqueued (k_next_busy / k_skip_idle) where an empty ms does nothing: no
+  // conditional tasks. Every SKIP_EVERY ms the host asks how far the first non-empty bucket is; the skip stops at
+  // the next multiple of horizon (far collection), at the run's last ms, and cannot pass a host-held envelope (those
+  // are >= horizon ahead after host_envelopes(k)). WG_SKIP_IDLE=0 enqueues every ms.
+  static const bool skipIdle = !(getenv("WG_SKIP_IDLE") && atoi(getenv("WG_SKIP_IDLE")) == 0);
+  const bool canSkip = skipIdle && !cond && !lead.dev.hostMode;
+  const int32_t SKIP_EVERY = 16;
+  int32_t* dNb = nullptr;
+  std::vector<int32_t> hNb((size_t)R);
+  if (canSkip && ms > SKIP_EVERY) WG_HIP(hipMalloc((void**)&dNb, sizeof(int32_t) * (size_t)R));
+  int32_t sinceCheck = 0;
+  try {
+    for (int32_t k = 0; k <= ms; k++) {
+      if (k > 0) host_envelopes(k);
+      if (dNb && k > 0 && k < ms && ++sinceCheck >= SKIP_EVERY) {
+        sinceCheck = 0;
+        hipLaunchKernelGGL(k_next_busy, dim3(1, R), dim3(256), 0, g.stream, g.tab, dNb);
+        WG_HIP(hipMemcpyAsync(hNb.data(), dNb, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, g.stream));
+        WG_HIP(hipStreamSynchronize(g.stream));
+        int32_t n = ms - k;
+        for (int r = 0; r < R; r++)
+          if (on[r]) {
+            const int32_t D = es[r]->dev.horizon, t = es[r]->time + k;
+            n = std::min(n, std::min(hNb[r], D - (int32_t)((uint32_t)t & (uint32_t)(D - 1))));
+          }
+        if (n > 0) {
+          hipLaunchKernelGGL(k_skip_idle, dim3(1, R), dim3(256), 0, g.stream, g.tab, n);
+          k += n;
+          host_envelopes(k);
         }
       }
-    enqueue_one_ms(lead, g);
+      enqueue_one_ms(lead, g);
+    }
+  } catch (...) {
+    if (dNb) (void)hipFree(dNb);
+    throw;
   }
+  if (dNb) (void)hipFree(dNb);
   WG_HIP(hipStreamSynchronize(g.stream));
   auto t1 = std::chrono::steady_clock::now();
   if (lead.profiling) lead.prof_collect();

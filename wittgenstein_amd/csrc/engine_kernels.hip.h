@@ -1154,6 +1154,41 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
   }
 }
 
+// Idle stretches (protocols without conditional tasks): an empty bucket's ms does nothing (nextMessage just moves the
+// clock, C/Network.java:533-570), yet its launch sequence costs the host ~15 launches. k_next_busy reports how many ms
+// from `now` the first non-empty bucket is (horizon if none); k_skip_idle moves the clock over n empty ms, leaving the
+// per-ms ring bookkeeping as their k_end_phase would have.
+__global__ void __launch_bounds__(256) k_next_busy(const EngineDev* __restrict__ tab, int32_t* __restrict__ out) {
+  const EngineDev& d = tab[blockIdx.y];
+  __shared__ uint32_t shMin;
+  if (threadIdx.x == 0) shMin = d.halted ? 0x7FFFFFFFu : (uint32_t)d.horizon;
+  __syncthreads();
+  if (!d.halted) {
+    const uint32_t D = (uint32_t)d.horizon, now = (uint32_t)d.g->now;
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      if (d.bcnt[(now + k) & (D - 1)] != 0) {
+        atomicMin(&shMin, k);
+        break;
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.y] = (int32_t)shMin;
+}
+__global__ void __launch_bounds__(256) k_skip_idle(const EngineDev* __restrict__ tab, int32_t n) {
+  WG_ENGINE(tab);
+  Globals* g = d.g;
+  const uint32_t D = (uint32_t)d.horizon;
+  const int32_t t = g->now;
+  const unsigned long long dh = g->destHead, ph = g->payloadHead;
+  for (int32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t b = (uint32_t)(t + k) & (D - 1);
+    d.destHeadAt[b] = dh;
+    d.payloadHeadAt[b] = ph;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) g->now = t + n;
+}
+
 __global__ void k_latency_probe(const EngineDev* __restrict__ tab, int n, const int32_t* from, const int32_t* to, const int32_t* delta,
                                 int32_t* out) {
   const EngineDev& d = tab[0];
