@@ -204,7 +204,7 @@ def casper_line(args):
                                "%d simulated ms per step%s" % (n, bp, cl, per, T, "" if args.casper_stopped <= 0 else
                                                                ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
                    "nodes": n},
-        "roofline": {"bound": "hbm", "kernel": "k_deliver<CasperProto>", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
+        "roofline": {"bound": "hbm", "kernel": "the delivery pass: k_casper_classify + k_casper_attestations + k_deliver<CasperProto> (one launch of each per simulated ms that is not skipped)", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
                      "launches": dk_spans, "bytes_per_delivered_message": bmsg, "whole_run_achieved_GBs": alg / (elapsed * 1e9)},

@@ -149,6 +149,17 @@ __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t*
   const EngineDev& d = (tab)[blockIdx.y];      \
   if (d.halted) return
 
+// k_scan2 re-evaluates F::value(i); a functor whose value is expensive may take a `first` flag and reuse what the
+// first evaluation (k_scan1) left behind (ExpandF: chain run lengths)
+template <class F>
+__device__ __forceinline__ auto scan_value_again(const F& f, uint32_t i) -> decltype(f.value(i, false)) {
+  return f.value(i, false);
+}
+template <class F, class... X>
+__device__ __forceinline__ uint64_t scan_value_again(const F& f, uint32_t i, X...) {
+  return f.value(i);
+}
+
 template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
@@ -187,7 +198,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restric
   int w = threadIdx.x >> 6;
   for (uint32_t base = lo; base < hi; base += SCAN_BLOCK) {
     uint32_t i = base + threadIdx.x;
-    uint64_t v = i < hi ? f.value(i) : 0;
+    uint64_t v = i < hi ? scan_value_again(f, i) : 0;
     uint64_t incl = wave_incl_scan64(v);
     if (WG_LANE == 63) shw[w] = incl;
     __syncthreads();
@@ -243,12 +254,20 @@ struct ExpandF {
   __device__ uint32_t task_bound(const Rec& r) const {
     return d.boundTask[r.w2 < 3u ? r.w2 : 3u] + (rec_kind(r) == K_PERIODIC ? 1u : 0u);
   }
-  __device__ uint64_t value(uint32_t i) const {
+  // The run length of chain record i is needed three times (k_scan1's sum, k_scan2's scan and its write): the
+  // first evaluation parks it in recEv[i] — scratch of the later `order` phase, idle during expand — for the other two.
+  __device__ uint32_t runlen_first(uint32_t i, const Rec& r) const {
+    const uint32_t len = runlen(r, now());
+    if (i < d.maxOut) d.recEv[i] = len;
+    return len;
+  }
+  __device__ uint32_t runlen_again(uint32_t i, const Rec& r) const { return i < d.maxOut ? d.recEv[i] : runlen(r, now()); }
+  __device__ uint64_t value(uint32_t i, bool first = true) const {
     const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
     const uint32_t k = rec_kind(r);
     if (k == K_MSG) return ((uint64_t)d.boundMsg << 32) | 1u;
     if (k != K_CHAIN) return ((uint64_t)task_bound(r) << 32) | 1u;
-    const uint32_t len = runlen(r, now());
+    const uint32_t len = first ? runlen_first(i, r) : runlen_again(i, r);
     return ((uint64_t)(len * d.boundMsg + 1u) << 32) | len;  // + the re-push after the run (:629-632)
   }
   __device__ void tally(uint32_t, uint32_t) const {}
@@ -276,7 +295,6 @@ struct ExpandF {
     bool first = false;
     int32_t firstNode = 0;
     if (valid) {
-      const int32_t t = now();
       const Rec r = *rec_ptr(d, bucket(), count() - 1 - i);
       uint32_t e = (uint32_t)excl, ob = (uint32_t)(excl >> 32);
       const uint32_t k = rec_kind(r);
@@ -294,7 +312,7 @@ struct ExpandF {
         }
       } else {
         const Chain c = d.chains[r.w1];
-        const uint32_t len = runlen(r, t);
+        const uint32_t len = runlen_again(i, r);
         if (d.runMin && len >= d.runMin) {  // a long run: one wavefront unrolls it (k_expand_runs)
           const uint32_t k = atomicAdd(&d.g->nRuns, 1u);
           if (k < d.maxRuns) {
