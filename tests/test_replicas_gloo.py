@@ -9,6 +9,13 @@ import sys
 
 import pytest
 
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -67,7 +74,7 @@ def test_two_ranks_over_gloo(oracle, tmp_path):
     script.write_text(WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     import json

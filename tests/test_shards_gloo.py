@@ -54,7 +54,16 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port():
+    """a port nobody listens on right now (the CPU suite runs on several xdist workers: fixed ports would collide)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _run(tmp_path, world, port, **kw):
+    port = _free_port()
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(kw, root=ROOT))

@@ -1,0 +1,13 @@
+#!/bin/bash
+# sendAll latency-bin histograms + runMin 8: tests, Casper bench, kernel stats
+set -u
+OUT=gpurun_out/r02j; mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$(pwd)
+timeout 900 python -m pytest tests/test_zr_gpu_casper_resident.py tests/test_gpu_engine.py tests/test_zs_gpu_send_expand.py tests/test_gpu_batch.py -m gpu -q > $OUT/pytest.log 2>&1; echo "tests rc=$?"; tail -4 $OUT/pytest.log
+timeout 900 python bench.py --workload casper --steps 2 --warmup 1 --no-cpu > $OUT/bench_casper.json 2> $OUT/bench_casper.err
+echo "casper rc=$?"; cat $OUT/bench_casper.json; tail -2 $OUT/bench_casper.err
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof_casper -o k --output-format csv -- \
+   python $REPO/bench.py --workload casper --steps 1 --warmup 0 --no-cpu > $REPO/$OUT/prof_casper.json 2> $REPO/$OUT/prof_casper.err)
+python tools/prof_summary.py stats $OUT/prof_casper $OUT/casper_kernel_stats.md && rm -rf $OUT/prof_casper
+head -16 $OUT/casper_kernel_stats.md

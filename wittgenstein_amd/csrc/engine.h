@@ -280,6 +280,7 @@ struct EngineDev {
   int32_t* saLat;           // [maxSendAll][n]
   uint32_t* saHist;         // [maxSendAll][tiles(n)][D]
   uint32_t maxSendAll;
+  uint32_t saBins;          // latency bins of saHist (<= horizon): max latency of the model + 1, rounded up to 64
   struct FarRec* farBuf;    // NULL: arrivals beyond the ring are an error
   uint32_t farCap;
   // chain runs (consecutive hops of one multi-destination envelope arriving in the same ms) of >= runMin hops are

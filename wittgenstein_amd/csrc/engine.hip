@@ -211,7 +211,10 @@ void Engine::set_latency(int32_t kind, const int32_t* params, int32_t nparams) {
     default: throw WgError(WG_EINVAL, "unknown latency kind");
   }
   latKind = kind;
-  if (allocated) upload_latency();
+  if (allocated) {
+    upload_latency();
+    dev.saBins = sendall_bins();
+  }
 }
 
 void Engine::set_latency_by_name(const char* name) {  // C/RegistryNetworkLatencies.java:42-58
@@ -295,11 +298,8 @@ void Engine::set_node_down(int32_t id, bool down) {
   }
 }
 
-// ---- device allocation
-void Engine::ensure_device() {
-  if (allocated) return;
-  const int32_t n = (int32_t)hx.size();
-  if (n == 0) throw WgError(WG_ESTATE, "no nodes in the network");
+// the largest latency the current model can return for these nodes (sizes the bucket ring and the sendAll histograms)
+int32_t Engine::max_latency() const {
   int32_t maxExtra = 0;
   for (int v : hextra) maxExtra = std::max(maxExtra, v);
   int32_t maxLat = 1;
@@ -312,6 +312,20 @@ void Engine::ensure_device() {
     case LAT_ETHSCAN: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 4 * maxExtra; break;
     case LAT_IC3: maxLat = 175 + 2 * maxExtra; break;
   }
+  return maxLat;
+}
+// latency bins of the sendAll histograms: every latency the model can return, not the whole bucket ring
+uint32_t Engine::sendall_bins() const {
+  const uint32_t want = ((uint32_t)std::max(1, max_latency()) + 1u + 63u) & ~63u;
+  return std::min<uint32_t>((uint32_t)dev.horizon, want);
+}
+
+// ---- device allocation
+void Engine::ensure_device() {
+  if (allocated) return;
+  const int32_t n = (int32_t)hx.size();
+  if (n == 0) throw WgError(WG_ESTATE, "no nodes in the network");
+  const int32_t maxLat = max_latency();
   uint32_t D = cfg.horizon_ms > 0 ? (uint32_t)cfg.horizon_ms
                                   : next_pow2((uint32_t)std::max({256, maxLat + 8 + horizonExtra, horizonFloor}));
   if ((D & (D - 1)) != 0 || D > 32768) throw WgError(WG_EINVAL, "horizon_ms must be a power of two <= 32768");
@@ -408,11 +422,12 @@ void Engine::ensure_device() {
     dev.saLat = dalloc<int32_t>((size_t)dev.maxSendAll * n, false);
     dev.saHist = dalloc<uint32_t>((size_t)dev.maxSendAll * ((n + TILE - 1) / TILE) * D, false);
   }
+  dev.saBins = sendall_bins();
   // long chain runs (EngineDev::runs): worth a wavefront each where envelopes reach every node — the resident
-  // protocols that call Network.sendAll (WG_RUN_MIN=<hops> overrides, 0 = unroll every run in place)
+  // protocols that call Network.sendAll, from 8 hops on (WG_RUN_MIN=<hops> overrides, 0 = unroll every run in place)
   dev.runs = nullptr;
   dev.maxRuns = 0;
-  dev.runMin = sendAllCapacity > 0 ? 64u : 0u;
+  dev.runMin = sendAllCapacity > 0 ? 8u : 0u;  // (profiles/r02i_sweep_run_min_casper.txt: 4..16 within 2 %, 64 is 12 % slower)
   if (const char* rm = getenv("WG_RUN_MIN")) dev.runMin = (uint32_t)std::max(0, atoi(rm));
   if (dev.runMin) {
     dev.maxRuns = dev.chainSlots;

@@ -145,6 +145,8 @@ class Engine {
   template <class F>
   static void scan(const Group& g, const typename F::Aux* atab);
   void expand(const Group& g);  // scan<ExpandF> + k_expand_runs
+  int32_t max_latency() const;
+  uint32_t sendall_bins() const;
   Group self();                  // this engine as a group of one (refreshes its device table entry)
   // Network.runMs for every active member of a group in lock-step (one launch sequence for all)
   static void run_group(Engine** es, int R, const uint8_t* active, const Group& g, int32_t ms, uint8_t* did,

@@ -1000,7 +1000,8 @@ __global__ void __launch_bounds__(TILE) k_send_expand_scatter(const EngineDev* _
 __global__ void __launch_bounds__(TILE) k_sendall_lat(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
-  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  // D: the histograms span the latencies the model can return (saBins <= horizon), not the whole bucket ring
+  const uint32_t D = d.saBins, N = (uint32_t)d.nodes.n;
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
   for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
     const uint32_t k = wi / nTiles, tile = wi % nTiles;
@@ -1016,7 +1017,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_lat(const EngineDev* __restric
           nt = dev_latency(d, sd.from, (int32_t)to, sd.seed);
           if (nt >= d.discardTime) nt = -1;
         }
-        if (nt >= (int32_t)D) {
+        if (nt >= (int32_t)D) {  // (beyond the model's own bound or the ring: loud)
           set_err(d.g, ERR_HORIZON);
           nt = -1;
         }
@@ -1034,7 +1035,8 @@ __global__ void __launch_bounds__(1024) k_sendall_scan(const EngineDev* __restri
   __shared__ uint32_t sh16[16];
   __shared__ uint32_t shCarry;
   __shared__ int32_t shMin;
-  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  const uint32_t D = d.saBins, N = (uint32_t)d.nodes.n;  // latency bins (k_sendall_lat)
+  const uint32_t RING = (uint32_t)d.horizon;
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
   const int32_t t = d.g->now;
   for (uint32_t k = blockIdx.x; k < nSA; k += gridDim.x) {
@@ -1090,7 +1092,7 @@ __global__ void __launch_bounds__(1024) k_sendall_scan(const EngineDev* __restri
         c.flags = 1u;
         d.chains[sd.slot] = c;  // (a single reachable destination stays a one-hop envelope: same delivery)
         d.arr[sd.p] = arrival;
-        atomicAdd(&d.tileHist[(size_t)(sd.p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
+        atomicAdd(&d.tileHist[(size_t)(sd.p / TILE) * RING + ((uint32_t)arrival & (RING - 1))], 1u);
       }
     }
     __syncthreads();
@@ -1099,7 +1101,7 @@ __global__ void __launch_bounds__(1024) k_sendall_scan(const EngineDev* __restri
 __global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __restrict__ tab, int binBits) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
-  const uint32_t D = (uint32_t)d.horizon, N = (uint32_t)d.nodes.n;
+  const uint32_t D = d.saBins, N = (uint32_t)d.nodes.n;  // latency bins (k_sendall_lat)
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
   for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
     const uint32_t k = wi / nTiles, tile = wi % nTiles;
