@@ -681,7 +681,8 @@ template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
 void Engine::expand(const Group& g) {
   scan<ExpandF>(g, nullptr);
-  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(GRID_EXPAND_RUNS, g.R), dim3(256), 0, g.stream, g.tab);
+  static const int runGrid = getenv("WG_EXPAND_RUNS_GRID") ? std::max(1, atoi(getenv("WG_EXPAND_RUNS_GRID"))) : GRID_EXPAND_RUNS;
+  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(runGrid, g.R), dim3(256), 0, g.stream, g.tab);
 }
 template void Engine::scan<RecsF>(const Group&, const int*);
 template void Engine::scan<MultiF>(const Group&, const int*);
@@ -2298,7 +2299,9 @@ struct CasperHost : ProtoHost {
     const CasperState* stab = (const CasperState*)g.stab;
     if (st.laneEvents) {  // attestation-only nodes: one lane per event (see k_casper_attestations)
       hipLaunchKernelGGL(k_casper_classify, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      hipLaunchKernelGGL(k_casper_attestations, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      // (a latency-bound pass of scattered atomics: as many wavefronts in flight as the chip holds)
+      static const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;
+      hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
   }
