@@ -1,6 +1,7 @@
 """The oracle's (and the product's) java.util.Random against published JDK known answers.
 The reference's own tests pin no RNG-dependent value, so these anchor the stream."""
 import numpy as np
+import pytest
 
 import oracle_lib as o
 
@@ -53,3 +54,18 @@ def test_latency_table_shape(oracle):
     assert t.shape == (1145, 100)
     assert t.min() == 2 and t.max() == 217
     assert (np.diff(t, axis=1) >= 0).all() and (np.diff(t, axis=0) >= 0).all()
+
+
+def test_host_side_java_random_of_the_package_matches(oracle):
+    """wittgenstein_amd.protocols._JavaRandom (used by CasperIMD.stop_attesters to pick the stopped attesters) is
+    java.util.Random.nextInt(bound): same stream as the oracle's restatement, power-of-two and rejection bounds"""
+    from wittgenstein_amd.protocols import _JavaRandom, choose_attesters
+    for seed in (0, 42, -7, 1 << 40):
+        for bound in (1, 7, 64, 100, 1 << 30, (1 << 30) + 12345, (1 << 31) - 1):
+            r = _JavaRandom(seed)
+            assert [r.nextInt(bound) for _ in range(300)] == [int(v) for v in oracle.jrandom_bounded(seed, bound, 300)]
+    ids = choose_attesters(range(6, 406), 40, seed=4)
+    assert len(ids) == len(set(ids)) == 40 and all(6 <= i < 406 for i in ids)
+    assert ids == choose_attesters(range(6, 406), 40, seed=4) and ids != choose_attesters(range(6, 406), 40, seed=5)
+    with pytest.raises(ValueError):
+        choose_attesters(range(6, 406), 400)
