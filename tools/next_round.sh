@@ -20,9 +20,15 @@ if [ -s $OUT/pmc_FETCH_SIZE.md ] && [ -s $OUT/pmc_WRITE_SIZE.md ]; then
 fi
 timeout 600 python bench.py --mode shard --gpus 1 --steps 1 --warmup 1 --no-cpu > $OUT/bench_shard1.json 2> $OUT/bench_shard1.err
 echo "shard1 rc=$?"; cat $OUT/bench_shard1.json
-# Casper IMD resident (4096 attesters voting per slot, 8195 nodes): deliveries are three bit-sets and two counters each
-timeout 600 python bench.py --workload casper --steps 1 --warmup 1 > $OUT/bench_casper.json 2> $OUT/bench_casper.err
+# Casper IMD resident at BASELINE config 5's node count (262 150 nodes; the default of --workload casper), + kernel stats
+timeout 600 python bench.py --workload casper --steps 2 --warmup 1 > $OUT/bench_casper.json 2> $OUT/bench_casper.err
 echo "casper rc=$?"; cat $OUT/bench_casper.json
+(cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof_casper -o k --output-format csv -- \
+   python $OLDPWD/bench.py --workload casper --steps 1 --warmup 0 --no-cpu > $OLDPWD/$OUT/prof_casper.json 2> $OLDPWD/$OUT/prof_casper.err)
+python tools/prof_summary.py stats $OUT/prof_casper $OUT/casper_kernel_stats.md && rm -rf $OUT/prof_casper
+# shard-count invariance at full size (one simulation as 4 logical shards vs the unsharded engine, every row and counter)
+timeout 900 python tools/shard_invariance.py 32768 4 0 > $OUT/shard_invariance_32768_k4.json 2> $OUT/shard_invariance_32768_k4.err
+echo "shard invariance rc=$?"; cat $OUT/shard_invariance_32768_k4.json
 # hipGraph A/B (value only: the HIP-event roofline bracket is off under WG_GRAPH) on the launch-bound GSFSignature config
 for gr in 0 1; do
   WG_GRAPH=$gr timeout 300 python bench.py --workload gsf --nodes 4096 --replicas 16 --no-cpu > $OUT/bench_gsf_graph$gr.json 2> $OUT/bench_gsf_graph$gr.err
