@@ -175,8 +175,9 @@ def casper_line(args):
         g = P.CasperIMD(P.CasperParemeters(*params, NB, NL), seed=step, max_slots=T // 8000 + 2)
         g.init()
         net = g.network()
+        stopped_ids = []
         if args.casper_stopped > 0:  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
-            g.stop_attesters(int(args.casper_stopped * cl * per), seed=step)
+            stopped_ids = g.stop_attesters(int(args.casper_stopped * cl * per), seed=step)
         net.profile(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -187,7 +188,10 @@ def casper_line(args):
             delivered += net.last_stats["delivered"]
             elapsed += dt
             heights = net.read("headHeight")  # (outside the timed region) the observables of PT/CasperIMDTest.java:263-274
-            observer_height, min_height = int(heights[0]), int(heights[1:].min())
+            import numpy as np
+            live = np.ones(len(heights), bool)
+            live[stopped_ids] = False  # (a stopped node receives nothing: its head stays the genesis block)
+            observer_height, min_height = int(heights[0]), int(heights[live].min())
             pr = net.profile_read()["deliver"]
             dk_spans += pr["spans"]
             dk_ns += pr["total_ns"]
@@ -205,7 +209,7 @@ def casper_line(args):
                                "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
                                "%d simulated ms per step%s" % (n, bp, cl, per, T, "" if args.casper_stopped <= 0 else
                                                                ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
-                   "nodes": n, "observer_head_height_at_end": observer_height, "lowest_head_height_of_a_node_at_end": min_height},
+                   "nodes": n, "observer_head_height_at_end": observer_height, "lowest_head_height_of_a_live_node_at_end": min_height},
         "roofline": {"bound": "hbm", "kernel": "the delivery pass: k_casper_classify + k_casper_attestations + k_deliver<CasperProto> (one launch of each per simulated ms that is not skipped)", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
