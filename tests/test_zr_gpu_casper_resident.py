@@ -109,6 +109,37 @@ def test_casper_4096_attesters_a_slot_runs():  # one round of BASELINE config 5'
 
 
 @pytest.mark.gpu
+def test_config5_size_fast_paths_equal_the_plain_ones(monkeypatch):
+    """BASELINE config 5's node count (262 150 nodes, 10 % of the attesters stopped) is beyond the oracle; the
+    size-independent property instead: the paths added for this size — chain runs unrolled one wavefront per run
+    (k_expand_runs), idle stretches skipped (k_skip_idle) — give exactly what the plain paths give (in-place runs, every
+    ms enqueued), which are the ones the small lock-step cases pin against the oracle. Two and a half slots: two rounds
+    of 4096 votes and two blocks, every one a sendAll to all nodes."""
+    def run(run_min, skip):
+        monkeypatch.setenv("WG_RUN_MIN", run_min)
+        monkeypatch.setenv("WG_SKIP_IDLE", skip)
+        g = P.CasperIMD(P.CasperParemeters(64, False, 5, 4096, 1000, 1), seed=2, max_slots=5)
+        g.init()
+        ids = g.stop_attesters(26214, seed=3)
+        net = g.network()
+        net.runMs(20500)
+        out = {f: net.read(f) for f in FIELDS}
+        out["state"] = (net.time, net.rng_state(), net.msgs.size(), net.last_stats["delivered"])
+        return out, ids
+    plain, ids = run("0", "0")
+    fast, ids2 = run("8", "1")
+    assert ids == ids2 and plain["state"] == fast["state"], (plain["state"], fast["state"])
+    for f in FIELDS:
+        assert np.array_equal(plain[f], fast[f]), f
+    n = 1 + 5 + 64 * 4096
+    live = np.ones(n, bool)
+    live[ids] = False
+    assert plain["state"][3] > 2 * (4096 * 0.85) * (n - 26214) * 0.95  # two rounds of votes from the live voters of those slots
+    assert int(fast["headHeight"][0]) == 2 and int(fast["headHeight"][live].min()) == 2   # everybody follows the chain
+    assert int(fast["msgReceived"][ids].sum()) == 0 and int(fast["attestationsHeld"][live].min()) > 4096
+
+
+@pytest.mark.gpu
 def test_random_on_ties_is_refused():
     with pytest.raises(UnsupportedError):
         P.CasperIMD(P.CasperParemeters(2, True, 2, 6, 1000, 1)).init()

@@ -1020,7 +1020,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
   // conditional tasks. Every SKIP_EVERY ms the host asks how far the first non-empty bucket is; the skip stops at
   // the next multiple of horizon (far collection), at the run's last ms, and cannot pass a host-held envelope (those
   // are >= horizon ahead after host_envelopes(k)). WG_SKIP_IDLE=0 enqueues every ms.
-  static const bool skipIdle = !(getenv("WG_SKIP_IDLE") && atoi(getenv("WG_SKIP_IDLE")) == 0);
+  const bool skipIdle = !(getenv("WG_SKIP_IDLE") && atoi(getenv("WG_SKIP_IDLE")) == 0);  // (read per run: tests toggle it)
   const bool canSkip = skipIdle && !cond && !lead.dev.hostMode;
   const int32_t SKIP_EVERY = 16;
   int32_t* dNb = nullptr;
