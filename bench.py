@@ -20,7 +20,10 @@ collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak"
 the N ranks (wg_shard_configure; RCCL all-reduces per simulated ms through wittgenstein_amd/shards.py),
 "scaling": "strong". With --gpus 1 it measures what the sharded pipeline costs on one GPU.
 
-One JSON line on stdout (rank 0). Everything else goes to stderr.
+One JSON line on stdout (rank 0). Everything else goes to stderr. At --gpus 1 the line also carries a
+"second_workload" object, outside `value` and outside the timed region: BASELINE configs[4]'s protocol at its node
+count — Casper IMD resident, 262 150 nodes, 10 % of the attesters stopped, 24 simulated seconds per step — with its
+own metric / roofline / cpu_baseline fields (--workload casper prints that object alone; --no-second skips it).
 """
 import argparse
 import gc
