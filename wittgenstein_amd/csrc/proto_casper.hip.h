@@ -306,7 +306,10 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
       atomicAdd((unsigned long long*)&d.nodes.msgReceived[to], 1ULL);
       atomicAdd((unsigned long long*)&d.nodes.bytesReceived[to], 1ULL);
       atomicOr((unsigned long long*)(s.recv + (size_t)to * s.Aw + (a >> 6)), 1ULL << (a & 63));
-      atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
+      // (the votes of a slot mostly share their head: after a node's first one the bit is set, and a plain load leaves
+      // the line clean — the atomics' dirty lines are what this kernel pays for, profiles/r02p_casper_pmc_WRITE_SIZE.md)
+      if (!((CasperProto::ldc(s.headsAtt + (size_t)to * s.Bw + (h >> 6)) >> (h & 63)) & 1ULL))
+        atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
       if ((s.blkRecv[(size_t)to * s.Bw + (h >> 6)] >> (h & 63)) & 1ULL)
         atomicOr((unsigned long long*)(s.reeval + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
       res.nrec = EV_DELIVERED;
