@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
       // the line clean — the atomics' dirty lines are what this kernel pays for, profiles/r02p_casper_pmc_WRITE_SIZE.md)
       if (!((CasperProto::ldc(s.headsAtt + (size_t)to * s.Bw + (h >> 6)) >> (h & 63)) & 1ULL))
         atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
-      if ((s.blkRecv[(size_t)to * s.Bw + (h >> 6)] >> (h & 63)) & 1ULL)
+      if (((s.blkRecv[(size_t)to * s.Bw + (h >> 6)] >> (h & 63)) & 1ULL) &&
+          !((CasperProto::ldc(s.reeval + (size_t)to * s.Bw + (h >> 6)) >> (h & 63)) & 1ULL))  // (as headsAtt: set once, then clean)
         atomicOr((unsigned long long*)(s.reeval + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
       res.nrec = EV_DELIVERED;
     }
