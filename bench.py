@@ -9,9 +9,14 @@ Handel.newContIf holds.
 
 A "step" is ONE RunMultipleTimes pass over R = --replicas independent 32 768-node simulations (seeds
 distinct), advanced in lock-step by a wg_batch (one launch sequence per simulated ms for all R, each copy
-stopping at its own predicate). init() is host work outside the hot path: every copy of every step is
-initialised before the timed region and sits resident in HBM (~15 GB per copy). Delivered messages = sum
-of Node.msgReceived increments (C/Network.java:607-613), simulated ms = sum over copies of network.time.
+stopping at its own predicate). init() is host work outside the hot path: every copy is initialised ONCE
+before the first step, its init() image kept on the device (wg_snapshot), and every step starts from the
+restored image (wg_restore — the same R seeds every step), so `--steps 20 --warmup 5` costs 25 runs and R
+init()s, not 25 R. Each step's pass is timed on its own (barrier + synchronize on both sides) and the K
+brackets are summed; the restores sit between the brackets. If R copies (+ images) do not fit the free HBM
+the batch is lowered to what fits and the line says so — a size check never aborts the run. Delivered
+messages = sum of Node.msgReceived increments (C/Network.java:607-613), simulated ms = sum over copies of
+network.time.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run): the copies shard across ranks with no data-path
 collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak".
@@ -34,9 +39,18 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _oracle():
+    """the CPU oracle's binding (tests/oracle_lib.py): cpu_baseline legs only — the product path never loads it"""
+    t = os.path.join(ROOT, "tests")
+    if t not in sys.path:
+        sys.path.append(t)
+    import oracle_lib
+    oracle_lib.build()
+    return oracle_lib
 
 NB = "RANDOM_SPEED=CONSTANT_TOR=0.00"
 NL = "NetworkLatencyByDistanceWJitter"
@@ -100,8 +114,7 @@ def split_batches(w, sims, k):
 
 def cpu_baseline(n_sample, workload="handel"):
     """the C++ oracle (event-for-event restatement of the single-threaded Java path) on one host core"""
-    import oracle_lib as o
-    o.build()
+    o = _oracle()
     if workload == "gsf":
         gp = gsf_params(n_sample)
         c = o.GSFSignature(gp["nodeCount"], gp["threshold"], gp["pairingTime"], gp["timeoutPerLevelMs"],
@@ -219,8 +232,7 @@ def casper_line(args):
                      "launches": dk_spans, "bytes_per_delivered_message": bmsg, "whole_run_achieved_GBs": alg / (elapsed * 1e9)},
     }
     if not args.no_cpu:
-        import oracle_lib as o
-        o.build()
+        o = _oracle()
         # the oracle keeps every attestation in every node's HashSet: a bounded sample (about 10 s of one core)
         sample = min(per, 512, max(16, 16384 // cl))
         c = o.CasperIMD((cl, False, bp, sample, 1000, 1), NB, NL, seed=0)
@@ -342,7 +354,8 @@ def main():
     ap.add_argument("--replicas", type=int, default=16, help="independent simulations per step and per GPU")
     ap.add_argument("--batches", type=int, default=1,
                     help="split a step's copies into this many concurrently running batches (one HIP stream each)")
-    ap.add_argument("--init-threads", type=int, default=6)
+    ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
+                    "bounded by the box's cores and host memory)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second", action="store_true", help="skip the second_workload object (Casper IMD, config 5's node count)")
@@ -390,94 +403,123 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    K, W, n, R = args.steps, args.warmup, args.nodes, args.replicas
-    # host init() of one copy holds ~3 N^2 int32 (ranks, their transpose, emission lists): cap the init
-    # threads by the host memory actually available
+    K, W, n, R_req = args.steps, args.warmup, args.nodes, args.replicas
+    from wittgenstein_amd import replicas
+    # ---- init(), ONCE per copy. RunMultipleTimes re-creates and re-initialises the protocol for every run
+    # (`p.copy(); rd.setSeed(i); init()`, C/RunMultipleTimes.java:44-48); init() is sequential host work outside the hot
+    # path ("wall time covers runMs only"), so every copy is initialised once, its init() image kept on
+    # the device (wg_snapshot) and every step — warm-up or timed — starts from the restored image (wg_restore): the same
+    # R seeds are re-run each step. Copies are created one wave of host threads at a time; the first copy measures what
+    # a copy (plus its image) takes and the batch is lowered to what fits the free HBM (never an error).
+    t_init = time.perf_counter()
+    free0 = torch.cuda.mem_get_info()[0]
+    seeds = list(replicas.rank_seeds(rank, world, R_req))
+    first = make_sim(w, n, seeds[0], local, args.workload)
+    first.network().snapshot()
+    torch.cuda.synchronize()
+    per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
+    R = replicas.plan_replicas(R_req, free0, per_copy)
+    if world > 1:  # every rank runs the same batch size (weak scaling: fixed work per GPU)
+        rt = torch.tensor([R], device="cuda", dtype=torch.int64)
+        dist.all_reduce(rt, op=dist.ReduceOp.MIN)
+        R = int(rt.item())
+    if R < R_req:
+        log("[rank %d] %d copies x %.1f GB (with init() image) exceed the %.0f GB free: %d copies per step instead"
+            % (rank, R_req, per_copy / 1e9, free0 / 1e9, R))
+    seeds = list(replicas.rank_seeds(rank, world, R))
     try:
         avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
-        per = 3.5 * 4 * n * n + (1 << 30)
-        args.init_threads = max(1, min(args.init_threads, int(0.6 * avail / max(1, world) / per)))
     except Exception:
-        pass
-    from wittgenstein_amd import replicas
-    warm_seeds, timed_seeds = replicas.seed_ranges(rank, world, K, W, R)  # disjoint across ranks
-    prof_phase = None
-    # ---- warmup steps: same shape as a timed step; every phase is bracketed with HIP events here so the
-    # phase breakdown costs the timed region nothing. Freed before the timed copies are initialised.
-    t_init = time.perf_counter()
-    inits = 0
-    for seeds in warm_seeds:
-        sims, batch = make_batch(w, n, seeds, local, args.init_threads, args.workload)
-        inits += R
-        if os.environ.get("WG_GRAPH", "0") in ("", "0"):
-            sims[0].network().profile(1)
-        batch.run_multiple_times(chunk=10, maxTime=20000)
-        prof_phase = sims[0].network().profile_read() if os.environ.get("WG_GRAPH", "0") in ("", "0") else None
-        del batch, sims
-        gc.collect()  # Network <-> MessageStorage cycles hold ~15 GB of HBM per copy until collected
-    # Every copy of every timed step is resident in HBM before the timed region (init() is host work outside the hot
-    # path), so K steps of R copies must fit: measure what one step takes and, if K of them do not fit, run the timed
-    # steps with fewer copies per step rather than overrun the device (the JSON states the number used).
-    free0 = torch.cuda.mem_get_info()[0]
-    timed = [make_batch(w, n, timed_seeds[0], local, args.init_threads, args.workload)] if K > 0 else []
-    torch.cuda.synchronize()
-    per_copy = max(1, (free0 - torch.cuda.mem_get_info()[0]) // max(1, R))
-    fit = int(0.92 * free0 / per_copy) // max(1, K)
-    if K > 1 and fit < R:
-        if fit < 1:
-            raise SystemExit("bench.py: %d steps of one %d-node simulation (%.1f GB each) do not fit this GPU's %.0f GB; "
-                             "lower --steps" % (K, n, per_copy / 1e9, free0 / 1e9))
-        log("[rank %d] %d steps x %d copies x %.1f GB exceed the %.0f GB free: %d copies per timed step instead"
-            % (rank, K, R, per_copy / 1e9, free0 / 1e9, fit))
-        del timed
-        gc.collect()
-        R = fit
-        base = timed_seeds[0][0]
-        timed_seeds = [range(base + i * R, base + (i + 1) * R) for i in range(K)]
-        timed = [make_batch(w, n, timed_seeds[0], local, args.init_threads, args.workload)]
-    timed += [make_batch(w, n, seeds, local, args.init_threads, args.workload) for seeds in timed_seeds[1:]]
-    inits += K * R
-    init_s = (time.perf_counter() - t_init) / max(1, inits)
-    log("[rank %d] init(): %.1f s per simulation amortised over %d host threads (outside the timed region)"
-        % (rank, init_s, args.init_threads))
-    graph_mode = os.environ.get("WG_GRAPH", "0") not in ("", "0")  # the device loop replayed as a hipGraph: no HIP events
-    for sims, _ in timed:
-        if not graph_mode:
-            sims[0].network().profile(2)  # HIP events around the delivery kernel only, inside the timed region
+        avail = 0
+    # host init() of one copy holds ~3 N^2 int32 (ranks, their transpose, emission lists)
+    threads = replicas.init_threads(args.init_threads, max(1, R - 1), avail, 3.5 * 4 * n * n + (1 << 30),
+                                    len(os.sched_getaffinity(0)), world)
 
-    barrier()
-    t0 = time.perf_counter()
-    delivered = sim_ms = 0
-    for sims, batch in timed:
+    def init_one(s):
+        g = make_sim(w, n, s, local, args.workload)
+        g.network().snapshot()
+        return g
+    sims = [first]
+    if R > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            sims += list(ex.map(init_one, seeds[1:]))
+    batch = w.Batch([g.network() for g in sims])
+    init_wall = time.perf_counter() - t_init
+    init_s = init_wall / R
+    log("[rank %d] init(): %d copies in %.1f s (%.1f s per simulation amortised over %d host threads; outside the timed "
+        "region); %.2f GB per copy incl. its init() image" % (rank, R, init_wall, init_s, threads, per_copy / 1e9))
+    graph_mode = os.environ.get("WG_GRAPH", "0") not in ("", "0")  # the device loop replayed as a hipGraph: no HIP events
+
+    def restore_all():
+        for g in sims:
+            g.network().restore()
+        torch.cuda.synchronize()
+
+    def run_step():
         if args.batches > 1:
-            # the step's copies as `--batches` smaller batches, each on its own HIP stream and host thread: while one
-            # batch sits in a kernel's low-occupancy tail the other batches' kernels fill the chip
+            # the step's copies as `--batches` smaller batches, each on its own HIP stream and host thread
             subs = split_batches(w, sims, args.batches)
             with ThreadPoolExecutor(max_workers=len(subs)) as ex:
                 res = list(ex.map(lambda b: b.run_multiple_times(chunk=10, maxTime=20000), subs))
-            for d, ms in res:
-                delivered += sum(d)
-                sim_ms += sum(ms)
-            del subs
-        else:
-            d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
-            delivered += sum(d)
-            sim_ms += sum(ms)
-    barrier()
-    elapsed = time.perf_counter() - t0
+            return sum(sum(d) for d, _ in res), sum(sum(ms) for _, ms in res)
+        d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
+        return sum(d), sum(ms)
 
+    # ---- warm-up steps: same shape as a timed step; the first one brackets every phase with HIP events (the phase
+    # breakdown costs the timed region nothing)
+    prof_phase = None
+    restore_s = 0.0
+    restores = 0
+    first_step = True
+    for i in range(W):
+        if not first_step:
+            t_r = time.perf_counter()
+            restore_all()
+            restore_s += time.perf_counter() - t_r
+            restores += 1
+        first_step = False
+        if i == 0 and not graph_mode:
+            sims[0].network().profile(1)
+        run_step()
+        if i == 0 and not graph_mode:
+            prof_phase = sims[0].network().profile_read()
+            sims[0].network().profile(0)
+    # ---- K timed steps: each step's RunMultipleTimes pass is bracketed by barrier + synchronize on both sides and the
+    # brackets are summed; between steps (outside the brackets) the copies go back to their init() image
+    delivered = sim_ms = 0
+    elapsed = 0.0
+    step_s = []
     by_level = None
     dk_spans = dk_ns = 0
-    for sims, batch in timed:
+    t_wall0 = time.perf_counter()
+    for i in range(K):
+        if not first_step:
+            t_r = time.perf_counter()
+            restore_all()
+            restore_s += time.perf_counter() - t_r
+            restores += 1
+        first_step = False
+        if not graph_mode:
+            sims[0].network().profile(2)  # HIP events around the delivery kernels only, inside the timed region
+        barrier()
+        t0 = time.perf_counter()
+        d, ms = run_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        elapsed += dt
+        step_s.append(dt)
+        delivered += d
+        sim_ms += ms
         assert not any(batch.cont_if())
         pr = sims[0].network().profile_read()["deliver"]
         dk_spans += pr["spans"]
         dk_ns += pr["total_ns"]
         for g in sims:
-            bl = g.network().delivered_by_level()
+            bl = g.network().delivered_by_level()  # (cumulative since the restored image: this step's)
             by_level = bl if by_level is None else by_level + bl
-    check = int(sum(int(g.network().read("msgReceived").sum()) for g in timed[-1][0]))
-    del timed
+    wall_timed_loop = time.perf_counter() - t_wall0
+    check = int(sum(int(g.network().read("msgReceived").sum()) for g in sims)) if K > 0 else 0
+    del batch, sims, first
     gc.collect()
 
     if world > 1:
@@ -491,10 +533,10 @@ def main():
     out = {
         "metric": "delivered messages/sec (GSFSignature; simulated-ms/sec alongside)" if gsf else
                   "delivered messages/sec (Handel 32k nodes; simulated-ms/sec alongside)",
-        "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": delivered / max(elapsed, 1e-9), "unit": "delivered messages/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed * 1000.0 / max(1, K), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "simulated_ms_per_s": sim_ms / elapsed,
+        "simulated_ms_per_s": sim_ms / max(elapsed, 1e-9),
         "config": {"workload": ("GSFSignature, %d nodes, threshold 0.99, pairing 3, timeoutPerLevel 50, period 10, "
                                 "accelerated calls 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: "
                                 "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
@@ -505,11 +547,23 @@ def main():
                                 "copy's Handel.newContIf is false" % (n, R)),
                    "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch" +
                    ("" if args.batches <= 1 else ", %d concurrent batches (one HIP stream each)" % args.batches),
+                   "replicas_requested": R_req, "hbm_bytes_per_copy_incl_init_image": int(per_copy),
                    "delivered_per_simulation": delivered // max(1, K * R * world),
-                   "init_s_per_simulation": init_s},
+                   "timing": "sum over the K steps of each step's RunMultipleTimes pass (barrier + synchronize on both "
+                             "sides of every step); between steps the copies are put back to their init() image "
+                             "(wg_restore, device-to-device) outside the brackets: the same R seeds every step",
+                   "step_s_min_max": [min(step_s), max(step_s)] if step_s else None,
+                   "restore_ms_per_step": 1000.0 * restore_s / max(1, restores),
+                   "timed_loop_wall_s_incl_restores": wall_timed_loop,
+                   "init_s_per_simulation": init_s, "init_wall_s": init_wall, "init_threads": threads,
+                   "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes),
+                   "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WG_")}},
     }
     # ---- roofline of the dominant kernel (k_deliver<HandelProto>): algorithmic bytes of everything delivered
     # in the timed region / its launches, over its average duration measured with HIP events in the timed region
+    if by_level is None:
+        import numpy as np
+        by_level = np.zeros(32, np.int64)
     alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
     per_launch_bytes = alg_bytes / max(1, dk_spans)
     if args.batches > 1:  # the HIP events bracket the first batch's launches only: its share of the bytes
@@ -523,14 +577,14 @@ def main():
         if tj.get("replicas") == R and tj.get("nodes") == n:
             traffic = tj.get("hbm_bytes_per_launch")
     if graph_mode:  # no per-launch timing: the whole-run figure stands in, and says so
-        achieved = alg_bytes / (elapsed * 1e9)
+        achieved = alg_bytes / (max(elapsed, 1e-9) * 1e9)
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (the delivery pass: "
                                                               "one launch of each per simulated ms)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
         "bytes_per_delivered_message": alg_bytes / max(1, delivered if world == 1 else int(by_level.sum())),
-        "whole_run_achieved_GBs": alg_bytes / (elapsed * 1e9),
+        "whole_run_achieved_GBs": alg_bytes / (max(elapsed, 1e-9) * 1e9),
     }
     if graph_mode:
         out["roofline"]["note"] = "WG_GRAPH=1: the chunk is replayed as a hipGraph, no per-launch HIP events; achieved = whole-run algorithmic bytes / wall time"

@@ -202,6 +202,21 @@ int32_t wg_queue_size_at(wg_engine* e, int32_t t, int64_t* size); /* msgs.sizeAt
  * (P/GSFSignature.java:670-683). *cont = 1 while the run must go on. */
 int32_t wg_protocol_cont_if(wg_engine* e, int32_t* cont);
 
+/* ---- init() image: RunMultipleTimes without re-running init() ---------------------------------------- */
+/* C/RunMultipleTimes.java:44-48 builds every run from scratch: `p.copy(); rd.setSeed(i); init()`. init() is sequential
+ * host work (Handel: nodeCount cumulative Collections.shuffle calls, P/Handel.java:940-948) that depends only on the
+ * parameters and the seed, so for a seed that is run more than once the engine can keep what init() produced:
+ *   wg_snapshot  after init() (nodes, protocol state, host-side sends / task registrations) and before the first
+ *                event is polled (WG_ESTATE otherwise): keeps an image of the engine in device memory —
+ *                Network.time, rd, node flags, the queued envelopes, the resident protocol's state;
+ *   wg_restore   puts the engine back to that image (device-to-device; what the protocol can recompute in place is
+ *                recomputed: Handel's receptionRanks, whose only mutation is `+= nodeCount`, P/Handel.java:825-828).
+ * Every observable after a restore + run equals a fresh engine's after init() + run (tests/test_snapshot_*.py).
+ * wg_snapshot_bytes: size of the image (0 without one). Not for host-callback mode (WG_EUNSUPPORTED). */
+int32_t wg_snapshot(wg_engine* e);
+int32_t wg_restore(wg_engine* e);
+int32_t wg_snapshot_bytes(wg_engine* e, int64_t* bytes);
+
 /* ---- host-callback mode: any protocol, action() stays in the caller ------------------------------------ */
 /* For protocols without a resident device form (the reference's San Fermin, Paxos, Slush, Dfinity, P2P* ...): the
  * message queue, its LIFO / chain ordering (C/Network.java:116-299, C/Envelope.java:57-301), NetworkLatency

@@ -48,8 +48,55 @@ def handel(params, seed, chunk=10):
             "deliveredByLevel": [int(v) for v in h.stats()["deliveredByLevel"]]}
 
 
+SCALARS = ["doneAt", "msgReceived", "msgSent", "bytesSent", "bytesReceived", "sigsChecked", "sigQueueSize",
+           "msgFiltered", "currWindowSize", "addedCycle"]
+LEVELS = ["posInLevel", "outgoingFinished", "queueLen"]
+BITS = ["totalIncoming", "lastAggVerified", "verifiedIndSignatures", "toVerifyInd", "finishedPeers"]
+
+
+def handel_full(params, seed, chunk=10, marks=()):
+    """BASELINE config 3 at full size: the run loop of C/RunMultipleTimes.java:50-64 to the stop
+    predicate (P/Handel.java:1044-1053), with a digest of EVERY observable tests/parity.py compares in lock-step —
+    per-node scalars, per-(node, level) scalars, the five bitset rows (P/Handel.java:349-352, 373-394) — at the end
+    and, for `marks` (simulated times), on the way. ~7.5 min and ~17 GB on one core at 32 768 nodes."""
+    n, thr, pair, lw, ec, per, fp, down, desync = params
+    h = o.Handel(n, thr, pair, lw, ec, per, fp, down, NB, NL, desync, seed=seed)
+
+    def snap():
+        i = h.info(False)
+        d = {"time": i["time"], "delivered": i["delivered"], "rng": i["rng"]}
+        for f in SCALARS:
+            d[f] = digest(h.read(f))
+        for f in LEVELS:
+            d[f] = digest(h.read_level(f))
+        for f in BITS:
+            d[f] = digest(h.read_bits(f))
+        return d
+    at = {}
+    while True:
+        did = h.run_ms(chunk)
+        t = h.info(False)["time"]
+        if t in marks:
+            at[str(t)] = snap()
+        if did and not h.cont_if():
+            break
+    out = {"protocol": "Handel", "params": list(params), "seed": seed, "chunk": chunk, "init_s": h.init_seconds(),
+           "final": snap(), "marks": at, "deliveredByLevel": [int(v) for v in h.stats()["deliveredByLevel"]],
+           "done_nodes": int((h.read("doneAt") > 0).sum())}
+    return out
+
+
 if __name__ == "__main__":
     o.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "config3":
+        # separate file: tests/golden/handel_config3_32768.json (regenerating the small traces takes seconds, this 8 min)
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+        down = int(n * 0.10)
+        res = handel_full((n, int(n * 0.9 * 0.99), 4, 50, 10, 20, 10, down, 0), 0, marks=(200, 600, 1000))
+        with open(os.path.join(HERE, "handel_config3_%d.json" % n), "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        print("wrote config 3 trace at", n, "nodes: time", res["final"]["time"], "delivered", res["final"]["delivered"])
+        sys.exit(0)
     out = {"pingpong_1000_seed0": pingpong(1000, 0), "pingpong_1000_seed3": pingpong(1000, 3),
            "handel_64_handeltest": handel((64, 60, 6, 10, 5, 5, 10, 2, 100), 0),
            "handel_256_seed0": handel((256, 228, 4, 50, 10, 20, 10, 25, 0), 0),

@@ -1,0 +1,100 @@
+"""bench.py's host logic without a GPU: the replica / thread planning arithmetic (wittgenstein_amd/replicas.py) and the
+whole main loop — init once, wg_snapshot, per-step wg_restore + RunMultipleTimes pass, JSON line — driven with the
+DRIVER'S literal argv (`--gpus 1 --steps 20 --warmup 5`) on a tiny network, the product's kernel sources on the CPU wave
+emulator (tests/emu) and torch.cuda's four calls stubbed. Round 1's bench line died on exactly this argv."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from wittgenstein_amd import replicas
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_replicas_degrades_and_never_fails():
+    GB = 1 << 30
+    assert replicas.plan_replicas(16, 288 * GB, 10 * GB) == 16
+    assert replicas.plan_replicas(32, 288 * GB, 10 * GB) == 26          # int(0.92 * 288 / 10)
+    assert replicas.plan_replicas(16, 288 * GB, 16 * GB) == 16
+    assert replicas.plan_replicas(16, 288 * GB, 17 * GB) == 15
+    assert replicas.plan_replicas(16, 288 * GB, 400 * GB) == 1          # does not fit at all: still one copy, no error
+    assert replicas.plan_replicas(4, 0, 0) == 4                         # nothing measured: the request stands
+    # the number of steps plays no part (round 1: `fit // K` turned --steps 20 into rc=1)
+    with pytest.raises(ValueError):
+        replicas.plan_replicas(0, GB, GB)
+
+
+def test_init_threads_bounds():
+    GB = 1 << 30
+    assert replicas.init_threads(0, 15, 3000 * GB, 16 * GB, 256) == 15      # one per copy
+    assert replicas.init_threads(0, 31, 3000 * GB, 16 * GB, 16) == 16       # cores
+    assert replicas.init_threads(0, 31, 62 * GB, 16 * GB, 256) == 2         # host memory
+    assert replicas.init_threads(6, 31, 3000 * GB, 16 * GB, 256) == 6       # the request
+    assert replicas.init_threads(0, 31, 3000 * GB, 16 * GB, 256, world=8) == 14  # this rank's share
+    assert replicas.init_threads(0, 1, 0, 16 * GB, 1) == 1
+
+
+def test_rank_seeds_disjoint():
+    seen = set()
+    for rank in range(4):
+        s = set(replicas.rank_seeds(rank, 4, 5))
+        assert len(s) == 5 and not (s & seen)
+        seen |= s
+    with pytest.raises(ValueError):
+        replicas.rank_seeds(4, 4, 1)
+
+
+DRIVER = r'''
+import os, sys, types, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join({root!r}, "tests", "emu", "libwittgpu_emu.so"); L._lib = None
+import torch
+free = [int({free})]
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a: None
+def mem_get_info(*a):
+    import wittgenstein_amd  # every snapshot()ed copy "takes" 100 units of the pretend device
+    free[0] -= 100
+    return (free[0], int({free}))
+torch.cuda.mem_get_info = mem_get_info
+import bench
+sys.argv = ["bench.py"] + {argv!r}
+bench.main()
+'''
+
+
+def run_bench(argv, free=10**6):
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
+    p = subprocess.run([sys.executable, "-c", DRIVER.format(root=ROOT, argv=argv, free=free)], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout  # ONE JSON line on stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_main_with_the_drivers_argv():
+    out, _ = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--nodes", "16", "--replicas", "2", "--no-cpu",
+                        "--no-second"])
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1
+    assert out["config"]["replicas_per_gpu"] == 2 and out["config"]["nodes"] == 16
+    assert out["value"] > 0 and out["unit"] == "delivered messages/s" and out["vs_baseline"] is None
+    # the same 2 seeds are re-run from their init() image every step: 20 identical steps
+    total = round(out["value"] * out["ms_per_step"] * 20 / 1000.0)
+    assert total % 20 == 0 and total // 40 == out["config"]["delivered_per_simulation"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches"] > 0 and 0 < r["frac"] < 1
+    assert out["config"]["workload"].startswith("Handel aggregation, 16 nodes")
+
+
+def test_bench_lowers_the_batch_instead_of_failing():
+    # a pretend device on which one copy (100 units) fits 4 times into 92 % of the free memory: 8 requested -> 4 run
+    out, err = run_bench(["--steps", "2", "--warmup", "1", "--nodes", "16", "--replicas", "8", "--no-cpu", "--no-second"],
+                         free=600)
+    assert out["config"]["replicas_requested"] == 8 and out["config"]["replicas_per_gpu"] == 4
+    assert "copies per step instead" in err

@@ -42,6 +42,7 @@ import test_zv_gpu_p2pflood as tpf  # noqa: E402
 import test_zw_gpu_sanfermin as tsf  # noqa: E402
 import test_zy_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
+import test_gpu_snapshot as tsn  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -194,3 +195,9 @@ def test_long_chain_runs_one_wavefront_each(monkeypatch):  # k_expand_runs, forc
 def test_p2pflood_resident():  # P/P2PFlood.java resident on the device vs oracle/p2pflood.hpp
     tfr.test_three_messages_by_distance()
     tfr.lockstep((64, 0, 5, 2, 1, 12, 1), "NetworkFixedLatency(7)", seed=9, chunk=1, chunks=150)
+
+
+@pytest.mark.parametrize("name", ["test_handel_restore_equals_fresh_init", "test_snapshot_only_before_the_first_event",
+                                  "test_batch_restore_and_run_multiple_times_again", "test_pingpong_and_gsf_restore"])
+def test_snapshot_restore(name):  # wg_snapshot / wg_restore: the init() image
+    getattr(tsn, name)()

@@ -220,6 +220,22 @@ class Network:
         self._ck(L.lib().wg_delivered_by_level(self._h, _p(out, C.c_int64)))
         return out
 
+    def snapshot(self):
+        """wg_snapshot: keep the engine as init() left it (device-resident image); valid before the first event.
+        restore() then replaces RunMultipleTimes' `p.copy(); rd.setSeed(i); init()` for the same seed
+        (C/RunMultipleTimes.java:44-48). Returns the image size in bytes."""
+        self._ck(L.lib().wg_snapshot(self._h))
+        self._snap_cuts = list(getattr(self, "_cuts", []))
+        v = C.c_int64()
+        self._ck(L.lib().wg_snapshot_bytes(self._h, C.byref(v)))
+        return v.value
+
+    def restore(self):
+        """wg_restore: back to the image of snapshot()."""
+        self._ck(L.lib().wg_restore(self._h))
+        self.last_stats = None
+        self._cuts = getattr(self, "_snap_cuts", getattr(self, "_cuts", []))
+
     def profile(self, mode=1):
         """HIP events on the engine's stream around the kernels of the per-ms pipeline: 0 off, 1 every phase,
         2 the delivery kernel only. Resets the accumulated spans."""

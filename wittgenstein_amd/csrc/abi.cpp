@@ -191,6 +191,20 @@ int32_t wg_protocol_cont_if(wg_engine* h, int32_t* cont) {
     throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
   WG_END
 }
+int32_t wg_snapshot(wg_engine* h) {
+  WG_TRY(h) E.snapshot();
+  WG_END
+}
+int32_t wg_restore(wg_engine* h) {
+  WG_TRY(h) E.restore();
+  WG_END
+}
+int32_t wg_snapshot_bytes(wg_engine* h, int64_t* bytes) {
+  WG_TRY(h)
+  if (!bytes) throw WgError(WG_EINVAL, "bytes");
+  *bytes = E.snapshot_bytes();
+  WG_END
+}
 int32_t wg_next_delivery(wg_engine* h, int32_t until, int32_t cond_time, wg_delivery* out, int32_t* got) {
   WG_TRY(h)
   if (!out || !got) throw WgError(WG_EINVAL, "out/got");

@@ -178,7 +178,9 @@ struct Globals {
   uint32_t nSendAll;       // Network.sendAll calls made by action()s in this phase (k_sendall_*), reset by k_end_phase
   uint32_t nFar;           // records parked in EngineDev::farBuf since the host last collected them
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
+  uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
 };
+constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)
 
 struct LatencyModel {
   int32_t kind;

@@ -80,6 +80,10 @@ Engine::Engine(const wg_config& c) : cfg(c) {
 
 Engine::~Engine() {
   delete proto;
+  if (snap) {
+    if (snap->arena) (void)hipFree(snap->arena);
+    delete snap;
+  }
   for (void* p : allocs) (void)hipFree(p);
   if (dLut) (void)hipFree(dLut);
   if (dTabDelta) (void)hipFree(dTabDelta);
@@ -387,21 +391,21 @@ void Engine::ensure_device() {
   dev.payloadHeadAt = dalloc<unsigned long long>(D);
 
   dev.maxEvents = maxOut;
-  dev.ev = dalloc<Rec>(maxOut, false);
-  dev.evAux = dalloc<EvAux>(maxOut, false);
+  dev.ev = dalloc<Rec>(maxOut, false, AC_SCRATCH);
+  dev.evAux = dalloc<EvAux>(maxOut, false, AC_SCRATCH);
   dev.evRes = dalloc<EvRes>(maxOut);
   dev.evRecOff = dalloc<uint32_t>(maxOut);
   dev.evDrawOff = dalloc<uint32_t>(maxOut);
-  dev.evNext = dalloc<int32_t>(maxOut, false);
+  dev.evNext = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
   dev.head = dalloc<int32_t>(n, false);
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
   dev.active = dalloc<uint32_t>(n);
   dev.activeB = dalloc<VisitDesc>(n);
   dev.maxOut = maxOut;
-  dev.outTmp = dalloc<Out>(maxOut, false);
-  dev.recEv = dalloc<uint32_t>(maxOut, false);
-  dev.fin = dalloc<Rec>(maxOut, false);
-  dev.arr = dalloc<int32_t>(maxOut, false);
+  dev.outTmp = dalloc<Out>(maxOut, false, AC_SCRATCH);
+  dev.recEv = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
+  dev.fin = dalloc<Rec>(maxOut, false, AC_SCRATCH);
+  dev.arr = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
   maxTiles = (maxOut + TILE - 1) / TILE;
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D);
@@ -468,6 +472,87 @@ void Engine::sync_globals_to_device() {
 void Engine::sync_globals_to_host() {
   WG_HIP(hipMemcpyAsync(&gh, dev.g, sizeof(Globals), hipMemcpyDeviceToHost, stream));
   WG_HIP(hipStreamSynchronize(stream));
+}
+
+// ---- wg_snapshot / wg_restore: the engine as init() left it, kept on the device --------------------------------
+// RunMultipleTimes re-creates and re-initialises the protocol for every run (`p.copy(); rd.setSeed(i); init()`,
+// C/RunMultipleTimes.java:44-48); init() is sequential host work (Handel: N cumulative shuffles, P/Handel.java:940-948).
+// For a seed that was initialised once, restoring the image is the same state at the cost of a device-to-device copy.
+// Valid between init() and the first event (nothing polled yet): the protocol hosts rely on that to leave their
+// queues / snapshot rings / payload slabs — empty at that point — out of the image (AC_SCRATCH).
+void Engine::snapshot() {
+  if (!proto) throw WgError(WG_ESTATE, "no resident protocol loaded");
+  if (dev.hostMode) throw WgError(WG_EUNSUPPORTED, "host-callback mode keeps its envelopes with the caller");
+  ensure_device();
+  flush_staged(time, false);
+  sync_globals_to_device();
+  WG_HIP(hipStreamSynchronize(stream));
+  sync_globals_to_host();
+  if (gh.events != 0 || gh.delivered != 0 || gh.tasks != 0)
+    throw WgError(WG_ESTATE, "wg_snapshot is taken after init() and before the first event is polled");
+  if (!stagedChains.empty() || !pendingSent.empty()) throw WgError(WG_ESTATE, "host-staged sends left after a flush");
+  if (snap) {
+    if (snap->arena) (void)hipFree(snap->arena);
+    delete snap;
+    snap = nullptr;
+  }
+  Snapshot* sn = new Snapshot();
+  sn->nAllocs = allocs.size();
+  sn->offs.assign(allocs.size(), (size_t)-1);
+  size_t total = 0;
+  for (size_t i = 0; i < allocs.size(); i++) {
+    if (allocInfo[i].cls != AC_STATE) continue;
+    if (allocs[i] == (void*)dev.payload && gh.payloadHead == 0) continue;  // nothing allocated in the ring yet
+    sn->offs[i] = total;
+    total += (allocInfo[i].bytes + 255) & ~(size_t)255;
+  }
+  sn->bytes = total;
+  if (hipMalloc((void**)&sn->arena, total > 0 ? total : 16) != hipSuccess) {
+    delete sn;
+    throw WgError(WG_ENOMEM, "wg_snapshot: no device memory for the image (" + std::to_string(total >> 20) + " MiB)");
+  }
+  for (size_t i = 0; i < allocs.size(); i++)
+    if (sn->offs[i] != (size_t)-1)
+      WG_HIP(hipMemcpyAsync(sn->arena + sn->offs[i], allocs[i], allocInfo[i].bytes, hipMemcpyDeviceToDevice, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+  sn->gh = gh;
+  sn->time = time;
+  sn->discardTime = discardTime;
+  sn->stagedMin = stagedMin;
+  sn->hdown = hdown;
+  sn->cuts = cuts;
+  sn->staged = staged;
+  snap = sn;
+}
+
+void Engine::restore() {
+  if (!snap) throw WgError(WG_ESTATE, "wg_restore without a wg_snapshot");
+  Snapshot& sn = *snap;
+  WG_HIP(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < sn.nAllocs; i++)
+    if (sn.offs[i] != (size_t)-1)
+      WG_HIP(hipMemcpyAsync(allocs[i], sn.arena + sn.offs[i], allocInfo[i].bytes, hipMemcpyDeviceToDevice, stream));
+  const uint32_t notes = gh.notes;  // (what the run being undone left: the protocol's on_restore may need it)
+  gh = sn.gh;
+  gh.notes = notes;
+  time = sn.time;
+  discardTime = sn.discardTime;
+  dev.discardTime = sn.discardTime;
+  stagedMin = sn.stagedMin;
+  hdown = sn.hdown;
+  if (cuts != sn.cuts) {
+    cuts = sn.cuts;
+    rebuild_partitions();
+  }
+  staged = sn.staged;
+  stagedChains.clear();
+  pendingSent.clear();
+  dev.halted = 0;
+  if (proto) proto->on_restore(*this);
+  gh.notes = sn.gh.notes;
+  globalsDirty = true;
+  sync_globals_to_device();
+  lastError.clear();
 }
 
 void Engine::latency_probe(int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta, int32_t* out) {
@@ -715,6 +800,7 @@ Group Engine::self() {
       if (!dStab) {
         WG_HIP(hipMalloc(&dStab, sz));
         allocs.push_back(dStab);
+        allocInfo.push_back({sz, AC_STATE});
       }
       WG_HIP(hipMemcpyAsync(dStab, proto->state_host(), sz, hipMemcpyHostToDevice, stream));
       stabShadow.assign((const char*)proto->state_host(), (const char*)proto->state_host() + sz);
@@ -1633,6 +1719,37 @@ __global__ void k_handel_cont_if(const EngineDev* __restrict__ tab, const Handel
   if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
 }
 
+// wg_restore: receptionRanks as init() left them. The only writer is checkSigs' `receptionRanks[from] += nodeCount`
+// (k_handel_cond_a2, P/Handel.java:825-828) on values that start in [0, nodeCount), nodeCount a power of two: the low
+// bits are the initial rank (a saturated entry would not be: NOTE_RANKS_SATURATED refuses the restore).
+__global__ void __launch_bounds__(256) k_handel_ranks_reset(HandelState s) {
+  const size_t n4 = ((size_t)(s.hi - s.lo) * (size_t)s.N) >> 2;  // (N >= 4 here: rows are whole 16-byte vectors)
+  U4* r = (U4*)(s.ranks + (size_t)s.lo * s.N);
+  const uint32_t m = (uint32_t)s.N - 1u;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    U4 q = r[i];
+    if ((q.x | q.y | q.z | q.w) & ~m) {
+      q.x &= m;
+      q.y &= m;
+      q.z &= m;
+      q.w &= m;
+      r[i] = q;
+    }
+  }
+}
+
+// HLevel() for level 0 (P/Handel.java:413-421): the node's own signature in totalIncoming / lastAggVerified /
+// verifiedIndSignatures; everything else of the five rows is empty after init()
+__global__ void k_handel_own_bits(HandelState s) {
+  int node = s.lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= s.hi) return;
+  size_t w = (size_t)node * s.W + (node >> 6);
+  uint64_t bit = 1ULL << (node & 63);
+  s.TI[w] = bit;
+  s.LA[w] = bit;
+  s.VI[w] = bit;
+}
+
 struct HandelHost : ProtoHost {
   HandelState st{};
   Engine& eng;
@@ -1669,38 +1786,43 @@ struct HandelHost : ProtoHost {
     const int32_t lo = st.lo = e.shardCount > 0 ? e.dev.shardLo : 0;
     const int32_t hi = st.hi = e.shardCount > 0 ? e.dev.shardHi : N;
     const size_t nLoc = (size_t)(hi - lo);
-    auto rows = [&](auto* tag, size_t stride, bool zero) {
+    auto rows = [&](auto* tag, size_t stride, bool zero, int cls = Engine::AC_STATE) {
       typedef std::remove_pointer_t<decltype(tag)> T;
-      return e.dalloc<T>(nLoc * stride, zero) - (size_t)lo * stride;
+      return e.dalloc<T>(nLoc * stride, zero, cls) - (size_t)lo * stride;
     };
-    st.TI = rows((uint64_t*)nullptr, W, true);
-    st.LA = rows((uint64_t*)nullptr, W, true);
-    st.VI = rows((uint64_t*)nullptr, W, true);
-    st.TV = rows((uint64_t*)nullptr, W, true);
-    st.FP = rows((uint64_t*)nullptr, W, true);
-    st.ranks = rows((int32_t*)nullptr, N, false);
-    st.peers = rows((int32_t*)nullptr, N - 1, false);
+    // (wg_restore re-creates the five bit rows — zero but for the node's own signature, k_handel_own_bits — instead of
+    // keeping a copy: AC_SCRATCH)
+    st.TI = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    st.LA = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    st.VI = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    st.TV = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    st.FP = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    // wg_snapshot / wg_restore: the emission lists are never written; receptionRanks only by `+= nodeCount`
+    // (k_handel_cond_a2), which on_restore undoes in place; the verification queues, the dissemination snapshots and the
+    // scratch of the conditional-task phase hold nothing before the first event
+    st.ranks = rows((int32_t*)nullptr, N, false, Engine::AC_SCRATCH);
+    st.peers = rows((int32_t*)nullptr, N - 1, false, Engine::AC_CONST);
     st.LS = L <= 16 ? 16 : 32;
     st.lsShift = L <= 16 ? 4 : 5;
     st.hdrStride = HH_LV + HP_COUNT * st.LS;  // 160 or 288 words: whole 128-byte lines
     st.hdr = rows((uint32_t*)nullptr, st.hdrStride, true);
     const size_t NL = (size_t)N * L;
-    st.qent = rows((uint64_t*)nullptr, (size_t)L * 64, true);
-    st.qfrom = rows((int32_t*)nullptr, (size_t)L * Q, false);
+    st.qent = rows((uint64_t*)nullptr, (size_t)L * 64, true, Engine::AC_SCRATCH);
+    st.qfrom = rows((int32_t*)nullptr, (size_t)L * Q, false, Engine::AC_SCRATCH);
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
       int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
       st.qsigOff[l] = off - (unsigned long long)lo * Q * nw;  // (node * Q + slot) * nw is added to it: biased like the rows
       off += (unsigned long long)nLoc * Q * nw;
     }
-    st.qsig = e.dalloc<uint64_t>(off, false);
+    st.qsig = e.dalloc<uint64_t>(off, false, Engine::AC_SCRATCH);
     {
       st.snapStride = N >= 128 ? (uint32_t)(N / 128) : 1u;  // words of the top level's block (N/2 ids)
       st.snapNb = (uint32_t)(e.dev.horizon / p.disseminationPeriodMs) + 2;  // a snapshot is read within < horizon ms
       uint64_t words = (uint64_t)st.snapNb * N * st.snapStride;
       if (words >= 0x80000000ull) throw WgError(WG_ENOMEM, "Handel snapshot ring exceeds 2^31 words: lower horizon_ms");
       if ((uint64_t)e.dev.payloadWords >= 0x80000000ull) throw WgError(WG_EINVAL, "payload_words must be < 2^31");
-      st.snap = e.dalloc<uint64_t>(words, false);
+      st.snap = e.dalloc<uint64_t>(words, false, Engine::AC_SCRATCH);
     }
     e.dev.boundMsg = 0;            // onNewSig never sends
     e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
@@ -1746,6 +1868,25 @@ struct HandelHost : ProtoHost {
   }
   bool has_cond() const override { return true; }
   int levels() const override { return st.L; }
+  void on_restore(Engine& e) override {
+    if (e.gh.notes & NOTE_RANKS_SATURATED)
+      throw WgError(WG_EUNSUPPORTED, "wg_restore: a receptionRanks entry saturated at Integer.MAX_VALUE in the last run; "
+                                     "the initial ranks cannot be recomputed in place — re-run init()");
+    reset_rows(e);
+    if (st.N < 4) {  // (rows shorter than a vector: the few words by plain copy of what init() uploaded is not kept; mask on the host)
+      std::vector<int32_t> r((size_t)(st.hi - st.lo) * st.N);
+      WG_HIP(hipMemcpy(r.data(), st.ranks + (size_t)st.lo * st.N, 4 * r.size(), hipMemcpyDeviceToHost));
+      for (auto& v : r) v &= st.N - 1;
+      WG_HIP(hipMemcpy(st.ranks + (size_t)st.lo * st.N, r.data(), 4 * r.size(), hipMemcpyHostToDevice));
+      return;
+    }
+    hipLaunchKernelGGL(k_handel_ranks_reset, dim3(2048 / WG_GRID_DIV), dim3(256), 0, e.stream, st);
+  }
+  void reset_rows(Engine& e) {
+    const size_t nLoc = (size_t)(st.hi - st.lo), at = (size_t)st.lo * st.W;
+    for (uint64_t* row : {st.TI, st.LA, st.VI, st.TV, st.FP}) WG_HIP(hipMemsetAsync(row + at, 0, 8 * nLoc * st.W, e.stream));
+    hipLaunchKernelGGL(k_handel_own_bits, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st);
+  }
   bool cont_if(Engine& e, int32_t* out) override {
     if (!dCont) dCont = e.dalloc<uint32_t>(1);
     Group g = e.self();

@@ -70,6 +70,9 @@ struct ProtoHost {
   // the conditional-task phase on a sharded engine: leaves the task records of this shard's nodes in the exchange
   // image (EngineDev::xbuf) and returns the (replicated) number of records; only called when has_cond()
   virtual uint32_t shard_cond(Engine&, const Group&) { return 0; }
+  // wg_restore: whatever of the protocol's state is cheaper to recompute than to copy (enqueued on the engine's stream
+  // after the STATE allocations are back); throws if the state cannot be brought back
+  virtual void on_restore(Engine&) {}
 };
 
 class Engine {
@@ -213,6 +216,32 @@ class Engine {
   std::vector<PendingSent> pendingSent;
   ProtoHost* proto = nullptr;
   std::vector<void*> allocs;     // everything to hipFree
+  // What wg_snapshot / wg_restore do with an allocation (parallel to `allocs`): STATE is copied, SCRATCH holds
+  // nothing that outlives a simulated ms (or nothing before the first event), CONST is never written by a kernel.
+  enum AllocClass : int { AC_STATE = 0, AC_SCRATCH = 1, AC_CONST = 2 };
+  struct AllocInfo {
+    size_t bytes;
+    int cls;
+  };
+  std::vector<AllocInfo> allocInfo;
+  // The image of the engine right after init() (wg_snapshot): device copies of every STATE allocation in one arena +
+  // the host-side pieces of Network state; wg_restore puts the engine back there — the cheap form of
+  // RunMultipleTimes' `p.copy(); rd.setSeed(i); init()` for a seed that was initialised once (C/RunMultipleTimes.java:44-48).
+  struct Snapshot {
+    char* arena = nullptr;
+    size_t bytes = 0;
+    std::vector<size_t> offs;    // per allocation: offset in the arena, (size_t)-1 = not copied
+    Globals gh;
+    int32_t time = 0, discardTime = 0, stagedMin = 0;
+    std::vector<uint8_t> hdown;
+    std::vector<int32_t> cuts;
+    std::vector<Staged> staged;  // envelopes still held on the host (beyond the bucket ring)
+    size_t nAllocs = 0;
+  };
+  Snapshot* snap = nullptr;
+  void snapshot();
+  void restore();
+  int64_t snapshot_bytes() const { return snap ? (int64_t)snap->bytes : 0; }
 
   // optional per-kernel-class timing with HIP events recorded on the engine's stream (bench.py's
   // roofline leg; off by default because every bracket costs two event records)
@@ -245,11 +274,12 @@ class Engine {
   };
 
   template <class T>
-  T* dalloc(size_t count, bool zero = true) {
+  T* dalloc(size_t count, bool zero = true, int cls = AC_STATE) {
     void* p = nullptr;
     WG_HIP(hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
     if (zero) WG_HIP(hipMemsetAsync(p, 0, count * sizeof(T), stream));
     allocs.push_back(p);
+    allocInfo.push_back({count * sizeof(T), cls});
     return (T*)p;
   }
   void upload_latency();

@@ -984,6 +984,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       int32_t* rk = s.ranks + (size_t)node * s.N + from;
       int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
       *rk = nr < 0 ? INT32_MAX : nr;
+      if (nr < 0) atomicOr(&d.g->notes, NOTE_RANKS_SATURATED);
       h[HH_SIGCHK]++;
       int pe = -1;
       for (int q = 0; q < H_PEND; q++)

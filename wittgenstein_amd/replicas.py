@@ -23,3 +23,34 @@ def reduce_job(dist, device, elapsed, delivered, sim_ms):
     cnt = torch.tensor([delivered, sim_ms], device=device, dtype=torch.int64)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     return float(tt.item()), int(cnt[0].item()), int(cnt[1].item())
+
+
+def rank_seeds(rank, world, replicas):
+    """the seeds of `rank`'s copies when every step re-runs the SAME copies from their init() image (wg_snapshot /
+    wg_restore): `replicas` consecutive seeds per rank, disjoint across ranks — rd.setSeed(i) of
+    C/RunMultipleTimes.java:47 with i = rank * replicas + k."""
+    if not (0 <= rank < world) or replicas <= 0:
+        raise ValueError("rank/world/replicas")
+    return range(rank * replicas, (rank + 1) * replicas)
+
+
+def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.92):
+    """How many resident copies a step runs on one GPU: the request, lowered to what fits `headroom` of the free HBM
+    (per_copy_bytes = one copy incl. its init() image, measured on the first copy). Never below 1 and never an
+    error: a step that cannot hold the requested batch runs a smaller one and the bench line says so
+    (config.replicas_per_gpu / config.replicas_requested)."""
+    if requested <= 0:
+        raise ValueError("replicas")
+    if per_copy_bytes <= 0 or free_bytes <= 0:
+        return requested
+    fit = int(headroom * free_bytes) // int(per_copy_bytes)
+    return max(1, min(requested, fit))
+
+
+def init_threads(requested, copies, host_avail_bytes, per_init_bytes, cores, world=1):
+    """host threads for the copies' init() (sequential host work per copy, C/RunMultipleTimes.java:44-48): one per copy,
+    bounded by the cores of this rank's share of the box and by host memory (per_init_bytes per running init())."""
+    by_mem = int(0.6 * host_avail_bytes / max(1, world) / max(1, per_init_bytes)) if host_avail_bytes > 0 else 1
+    by_cpu = max(1, cores // max(1, world))
+    want = requested if requested > 0 else copies
+    return max(1, min(want, copies, by_mem, by_cpu))
