@@ -3,6 +3,9 @@
 
   prof_summary.py stats <dir> <out.md>      kernel_stats.csv  -> per-kernel calls / total / average / share
   prof_summary.py pmc   <dir> <out.md>      counter_collection.csv -> per-kernel, per-counter sum and per-dispatch mean
+  prof_summary.py phases <dir> <out.md> [period]   kernel_trace.csv of a bench.py run (device-side RunMultipleTimes loop,
+                                            runMs(10) chunks) -> per kernel, mean duration by simulated ms modulo the
+                                            dissemination period (Handel: every node disseminates in the same ms)
 """
 import csv
 import glob
@@ -48,5 +51,39 @@ def pmc(d, out):
             o.write("| %s | %s | %d | %.1f | %.3f |\n" % (short(k), c, n, s, s / max(1, n)))
 
 
+def phases(d, out, period=20, chunk=10):
+    rows = []
+    for f in find(d, "kernel_trace.csv"):
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ch, j = -1, -1
+    agg = defaultdict(lambda: [[0, 0.0] for _ in range(period)])
+    tot = defaultdict(float)
+    for r in rows:
+        n = short(r["Kernel_Name"]).split("(")[0]
+        if "k_chunk_begin" in n:
+            ch, j = ch + 1, -1
+        if ch < 0:
+            continue
+        if "k_scan1<" in n and "ExpandF" in n:
+            j += 1
+        t = chunk * ch + max(j, 0)
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg[n][t % period]
+        a[0] += 1
+        a[1] += dur
+        tot[n] += dur
+    with open(out, "w") as o:
+        o.write("mean us per launch by (simulated ms mod %d); last column: total ms\n\n" % period)
+        o.write("| kernel | " + " | ".join(str(p) for p in range(period)) + " | total ms |\n|---|" + "---|" * (period + 1) + "\n")
+        for n in sorted(tot, key=lambda k: -tot[k]):
+            o.write("| %s | " % n + " | ".join("%.0f" % (a[1] / max(1, a[0]) / 1e3) for a in agg[n]) + " | %.1f |\n" % (tot[n] / 1e6))
+        o.write("| ALL | " + " | ".join("%.0f" % (sum(agg[n][p][1] for n in agg) / max(1, max(agg[n][p][0] for n in agg)) / 1e3)
+                                        for p in range(period)) + " | %.1f |\n" % (sum(tot.values()) / 1e6))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "phases":
+        phases(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 20)
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -1111,9 +1111,15 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
   const int32_t SKIP_EVERY = 16;
   int32_t* dNb = nullptr;
   std::vector<int32_t> hNb((size_t)R);
-  if (canSkip && ms > SKIP_EVERY) WG_HIP(hipMalloc((void**)&dNb, sizeof(int32_t) * (size_t)R));
+  if (canSkip && ms > SKIP_EVERY) {  // (kept by the lead engine: no allocation on the per-chunk path)
+    if (lead.skipCap < R) {
+      lead.skipBuf = lead.dalloc<int32_t>((size_t)R);
+      lead.skipCap = R;
+    }
+    dNb = lead.skipBuf;
+  }
   int32_t sinceCheck = 0;
-  try {
+  {
     for (int32_t k = 0; k <= ms; k++) {
       if (k > 0) host_envelopes(k);
       if (dNb && k > 0 && k < ms && ++sinceCheck >= SKIP_EVERY) {
@@ -1135,11 +1141,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
       }
       enqueue_one_ms(lead, g);
     }
-  } catch (...) {
-    if (dNb) (void)hipFree(dNb);
-    throw;
   }
-  if (dNb) (void)hipFree(dNb);
   WG_HIP(hipStreamSynchronize(g.stream));
   auto t1 = std::chrono::steady_clock::now();
   if (lead.profiling) lead.prof_collect();

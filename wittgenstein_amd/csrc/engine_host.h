@@ -179,6 +179,8 @@ class Engine {
   int32_t farCapacity = 0;       // > 0: envelopes registered beyond the bucket ring are parked for the host (FarRec)
   int32_t horizonExtra = 0;      // the longest sendTime - time a resident protocol's sends use (added to the latency bound)
   void collect_far();            // FarRec -> staged (host-held) envelopes
+  int32_t* skipBuf = nullptr;    // k_next_busy's result, one word per member of the group this engine leads
+  int skipCap = 0;
   int32_t sendAllCapacity = 0;   // Network.sendAll calls per simulated ms a resident protocol's action()s may make
   int32_t horizonFloor = 0;      // a resident protocol's longest task delay (default horizon_ms only)
   uint32_t maxTiles = 0;

@@ -277,7 +277,10 @@ struct ExpandF {
       set_err(d.g, ERR_EVENTS);
       ne = 0;
     }
-    if (ns > d.maxOut) set_err(d.g, ERR_OUTBOX);
+    if (ns > d.maxOut) {  // no delivery kernel may see outbox slices beyond the outbox: the ms is dropped, loudly
+      set_err(d.g, ERR_OUTBOX);
+      ne = 0;
+    }
     d.g->nEvents = ne;
     d.g->outSlots = ns;
   }
@@ -626,9 +629,6 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
     }
     if (arrival >= 0) {
       if (arrival < t) {
-#ifdef WG_EMU
-        if (getenv("WG_DEBUG_PAST")) fprintf(stderr, "PAST: p=%u kind=%u from=%d to=%d a=%u b=%u o.t=%d arrival=%d t=%d\n", p, kind, from, o.to, o.a, o.b, o.t, arrival, t);
-#endif
         set_err(d.g, ERR_ARRIVAL_PAST);
         arrival = -1;
       } else if (arrival == t) {

@@ -327,8 +327,12 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
         o.destOff = 0;
         o.drawsub = 0;
         o.pad = 0;
-        d.outTmp[aux.outBase] = o;
-        res.nrec |= 1u;
+        if (aux.outCap && aux.outBase < d.maxOut) {  // (as Ctx::put: an over-subscribed ms must not write past the outbox)
+          d.outTmp[aux.outBase] = o;
+          res.nrec |= 1u;
+        } else {
+          set_err(d.g, ERR_OUTBOX);
+        }
       } else {
         d.chains[aux.chain].flags = 0;
       }
