@@ -145,6 +145,9 @@ inline void wave_barrier(void* site) { (void)wave_collective(OP_BARRIER, 0, 0, 6
 #define __shfl(...) ::emu::shfl(EMU_SITE, __VA_ARGS__)
 #define __shfl_up(...) ::emu::shfl_up(EMU_SITE, __VA_ARGS__)
 #define __shfl_xor(...) ::emu::shfl_xor(EMU_SITE, __VA_ARGS__)
+// the product's SGPR hints: lane l's value / the (wave-uniform) value every lane holds
+#define WG_READLANE(v, l) ((uint32_t)::emu::shfl(EMU_SITE, (uint32_t)(v), (l), 64))
+#define WG_READFIRST(v) ((uint32_t)(v))
 #define __builtin_amdgcn_wave_barrier() ::emu::wave_barrier(EMU_SITE)
 #define __threadfence_block() ::emu::wave_barrier(EMU_SITE)
 inline void __threadfence() {}

@@ -1915,11 +1915,11 @@ struct HandelHost : ProtoHost {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
       switch (wavesCond) {
-        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 3: hipLaunchKernelGGL(k_handel_cond_a1<3>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        case 3: hipLaunchKernelGGL(k_handel_cond_a1<3>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
       }
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
@@ -1945,7 +1945,7 @@ struct HandelHost : ProtoHost {
   uint32_t shard_cond(Engine& e, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(node_grid(1), 1), dim3(256), 0, g.stream, g.tab, stab);
     e.shard_allreduce(st.candCnt, ((int64_t)st.N + 3) / 4);
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
@@ -1957,17 +1957,37 @@ struct HandelHost : ProtoHost {
   }
   // WG_LANE_MSGS=0 keeps every node visit on the wave-per-node kernel (A/B switch for profiles)
   int laneMsgs = getenv("WG_LANE_MSGS") ? atoi(getenv("WG_LANE_MSGS")) : 1;
+  int pipeDeliver = getenv("WG_DELIVER_PIPE") ? atoi(getenv("WG_DELIVER_PIPE")) : 1;
+  // blocks per engine of the wave-per-node kernels. The pipelined loops want SEVERAL visits per wavefront (the next
+  // visit's header is fetched during the current one), so their grid is about twice the chip's resident waves over the
+  // whole batch (the factor lets the blocks of members whose run has ended — they return at once — leave their share to the
+  // others); WG_NODE_GRID=<blocks per engine> overrides
+  int nodeGridEnv = getenv("WG_NODE_GRID") ? atoi(getenv("WG_NODE_GRID")) : 0;
+  int node_grid(int R) const {
+    if (nodeGridEnv > 0) return nodeGridEnv;
+    if (!pipeDeliver) return grid_node_waves(R);
+    int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
+    return b < 16 ? 16 : b;
+  }
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     const int useB = laneMsgs ? 1 : 0;
     if (useB)
       hipLaunchKernelGGL((k_deliver_msgs<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    // WG_DELIVER_PIPE=0: the plain loop (one dependent chain of round trips per visit) instead of the pipelined one
+    const dim3 grid(node_grid(g.R), g.R);
+    if (useB && pipeDeliver) {
+      switch (wavesDeliver) {
+        case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
+        case 3: hipLaunchKernelGGL((k_deliver<HandelProto, 3, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
+        default: hipLaunchKernelGGL((k_deliver<HandelProto, 4, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB);
+      }
+      return;
+    }
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_deliver<HandelProto, 8>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 6: hipLaunchKernelGGL((k_deliver<HandelProto, 6>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 4: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      default: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, useB);
+      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      case 3: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
+      default: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), grid, dim3(256), 0, g.stream, g.tab, stab, useB);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {

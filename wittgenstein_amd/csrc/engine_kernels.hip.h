@@ -1447,7 +1447,129 @@ struct HasVisitSkip<P, decltype((void)&P::visit_skip)> {
   static constexpr bool value = true;
 };
 
-template <class P, int WPE>  // WPE: waves per SIMD the register allocation must admit
+// A protocol whose node header is one record can have it fetched ahead of the visit (P::Pre, P::prefetch,
+// P::node_begin_pre): the loop below then overlaps the descriptor and header loads of the NEXT visit with the memory
+// round trip of the current visit's action(), instead of paying them as two more dependent round trips per visit.
+template <class P, class = void>
+struct HasPrefetch {
+  static constexpr bool value = false;
+};
+template <class P>
+struct HasPrefetch<P, decltype((void)&P::prefetch)> {
+  static constexpr bool value = true;
+};
+
+// the 48-byte visit descriptor in ONE memory instruction (lanes 0..2 take 16 bytes each): the kernel is bound
+// by the number of scattered wave-level memory instructions, not by their bytes
+__device__ __forceinline__ U4 load_desc_raw(const EngineDev& d, uint32_t a) {
+  return ((const U4*)&d.activeB[a])[WG_LANE < 3 ? WG_LANE : 0];
+}
+#ifndef WG_READLANE
+#define WG_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))  // wave-uniform result (an SGPR)
+#define WG_READFIRST(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+#endif
+__device__ __forceinline__ VisitDesc unpack_desc(const U4 q) {
+  VisitDesc vd;
+  vd.node = (int32_t)WG_READLANE(q.x, 0);
+  vd.e0 = (int32_t)WG_READLANE(q.y, 0);
+  vd.next0 = (int32_t)WG_READLANE(q.z, 0);
+  vd.flags = WG_READLANE(q.w, 0);
+  vd.rec0.w0 = WG_READLANE(q.x, 1);
+  vd.rec0.w1 = WG_READLANE(q.y, 1);
+  vd.rec0.w2 = WG_READLANE(q.z, 1);
+  vd.rec0.w3 = WG_READLANE(q.w, 1);
+  vd.aux0.chain = (int32_t)WG_READLANE(q.x, 2);
+  vd.aux0.cpos = (int32_t)WG_READLANE(q.y, 2);
+  vd.aux0.outBase = WG_READLANE(q.z, 2);
+  vd.aux0.outCap = WG_READLANE(q.w, 2);
+  return vd;
+}
+
+// One node visit: receiveUntil's body for the node's events of this ms, in event order. The node registers are loaded
+// (P::node_begin / node_begin_pre) by the caller.
+template <class P>
+__device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename P::State& ps, Ctx& c,
+                                              typename P::NodeRegs& r, const VisitDesc& vd, uint32_t* shSortW, bool useB) {
+  const int lane = WG_LANE;
+  const int32_t node = vd.node;
+  const int32_t e0 = vd.e0;
+  const bool toDown = (vd.flags & VD_DOWN) != 0;
+  const uint8_t toPart = (uint8_t)(vd.flags >> 8);
+  long long nRecv = 0, bRecv = 0;
+  const int32_t next0 = vd.next0;
+  const Rec rec0 = vd.rec0;
+  const EvAux aux0 = vd.aux0;
+  // mode 0: e0 is the only event (usual); 1: <= 64 events, sorted into shSort; 2: more (the PingPong
+  // origin): repeated minimum search over the list. One call site of deliver_event for all three.
+  int mode = 0;
+  uint32_t cnt = 1;
+  if (next0 >= 0) {
+    int32_t cur = e0;
+    uint32_t mine = 0xFFFFFFFFu;
+    cnt = 0;
+    while (cur >= 0 && cnt < 64) {
+      if ((uint32_t)lane == cnt) mine = (uint32_t)cur;
+      cur = d.evNext[cur];
+      cnt++;
+    }
+    if (cur < 0) {
+      mode = 1;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
+      if ((uint32_t)lane < cnt) shSortW[rank] = mine;
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      mode = 2;
+      cnt = 0xFFFFFFFFu;
+    }
+  }
+  bool have = false;
+  uint32_t last = 0;
+  KPROF_DECL;
+  KPROF_MARK(d.g, 1);  // descriptor + node_begin (+ the inbox sort of multi-event nodes)
+  for (uint32_t k = 0; k < cnt; k++) {
+    uint32_t e = (uint32_t)e0;
+    if (mode == 1) {
+      e = shSortW[k];
+    } else if (mode == 2) {
+      uint32_t best = 0xFFFFFFFFu;
+      for (int32_t q = e0; q >= 0; q = d.evNext[q])
+        if ((!have || (uint32_t)q > last) && (uint32_t)q < best) best = (uint32_t)q;
+      if (best == 0xFFFFFFFFu) break;
+      e = best;
+      last = best;
+      have = true;
+    }
+    Rec rec = rec0;
+    EvAux aux = aux0;
+    if (mode != 0) {
+      rec = d.ev[e];
+      aux = d.evAux[e];
+    }
+    deliver_event<P>(d, ps, c, r, e, rec, aux, toDown, toPart, mode == 2 || k + 1 < cnt, nRecv, bRecv);
+  }
+  __builtin_amdgcn_wave_barrier();
+  KPROF_MARK(d.g, 2);  // the events' action()s
+  P::node_end(c, ps, r);
+  if (lane == 0) {
+    // Node counters (C/Node.java:69-79): this wavefront is the node's only writer in this launch;
+    // atomics without a return value do not stall the wave the way a load-add-store would
+    if (nRecv) {
+      atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+    }
+    if (c.msgSent) {
+      atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+      atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+    }
+    if (!useB) d.head[node] = -1;  // (k_deliver_msgs has emptied the inbox lists already)
+  }
+  __builtin_amdgcn_wave_barrier();
+  KPROF_MARK(d.g, 3);  // node_end + counters
+}
+
+// WPE: waves per SIMD the register allocation must admit; PIPE: the software-pipelined loop (needs useB and P::prefetch)
+template <class P, int WPE, bool PIPE = false>
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
                                                       const typename P::State* __restrict__ stab, int useB) {
   WG_ENGINE(tab);
@@ -1460,119 +1582,71 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   // useB: k_deliver_msgs ran first and left this kernel the nodes of activeB
   const uint32_t nActive = useB ? d.g->nActiveB : d.g->nActive;
   const int32_t t = d.g->now;
+  if constexpr (PIPE && HasPrefetch<P>::value) {
+    {
+      // Software-pipelined visits: while visit a runs, the header of visit a + nWaves and the descriptor of visit
+      // a + 2 nWaves are in flight. A visit writes no other node's header (effects on other nodes travel as
+      // envelopes, at least one ms later), so fetching the next header early reads what the visit itself would.
+      uint32_t a = wave;
+      if (a >= nActive) return;
+      U4 descCur = load_desc_raw(d, a);
+      typename P::Pre hdrCur = P::prefetch(ps, (int32_t)WG_READLANE(descCur.x, 0));
+      U4 descNext = descCur;
+      if (a + nWaves < nActive) descNext = load_desc_raw(d, a + nWaves);
+      for (;;) {
+        KPROF_DECL;
+        KPROF_COUNT(d.g, 0);
+        const uint32_t an = a + nWaves;
+        const bool haveNext = an < nActive;
+        typename P::Pre hdrNext = hdrCur;
+        U4 descNext2 = descNext;
+        if (haveNext) {
+          hdrNext = P::prefetch(ps, (int32_t)WG_READLANE(descNext.x, 0));
+          if (an + nWaves < nActive) descNext2 = load_desc_raw(d, an + nWaves);
+        }
+        {
+          const VisitDesc vd = unpack_desc(descCur);
+          Ctx c{d, t, vd.node, 0, 0, 0, 0, 0, 0, 0};
+          typename P::NodeRegs r;
+          P::node_begin_pre(c, ps, r, &shP[w], hdrCur);
+          deliver_visit<P>(d, ps, c, r, vd, shSort[w], true);
+        }
+        if (!haveNext) break;
+        a = an;
+        descCur = descNext;
+        hdrCur = hdrNext;
+        descNext = descNext2;
+      }
+      return;
+    }
+  }
   for (uint32_t a = wave; a < nActive; a += nWaves) {
     KPROF_DECL;
     KPROF_COUNT(d.g, 0);
     VisitDesc vd;
     if (useB) {
-      // the 48-byte descriptor in ONE memory instruction (lanes 0..2 take 16 bytes each): the kernel is bound
-      // by the number of scattered wave-level memory instructions, not by their bytes
-      const U4 q = ((const U4*)&d.activeB[a])[lane < 3 ? lane : 0];
-      vd.node = (int32_t)__shfl(q.x, 0, 64);
-      vd.e0 = (int32_t)__shfl(q.y, 0, 64);
-      vd.next0 = (int32_t)__shfl(q.z, 0, 64);
-      vd.flags = __shfl(q.w, 0, 64);
-      vd.rec0.w0 = __shfl(q.x, 1, 64);
-      vd.rec0.w1 = __shfl(q.y, 1, 64);
-      vd.rec0.w2 = __shfl(q.z, 1, 64);
-      vd.rec0.w3 = __shfl(q.w, 1, 64);
-      vd.aux0.chain = (int32_t)__shfl(q.x, 2, 64);
-      vd.aux0.cpos = (int32_t)__shfl(q.y, 2, 64);
-      vd.aux0.outBase = __shfl(q.z, 2, 64);
-      vd.aux0.outCap = __shfl(q.w, 2, 64);
+      vd = unpack_desc(load_desc_raw(d, a));
     } else {
       vd.node = (int32_t)d.active[a];
       vd.e0 = d.head[vd.node];  // newest event of the node (always >= 0 for a listed node)
       vd.flags = (d.nodes.down[vd.node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[vd.node] << 8 : 0u);
     }
     const int32_t node = vd.node;
-    const int32_t e0 = vd.e0;
     if constexpr (HasVisitSkip<P>::value) {
       if (P::visit_skip(d, ps, node)) {
         if (lane == 0 && !useB) d.head[node] = -1;
         continue;
       }
     }
-    const bool toDown = (vd.flags & VD_DOWN) != 0;
-    const uint8_t toPart = (uint8_t)(vd.flags >> 8);
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
     typename P::NodeRegs r;
-    long long nRecv = 0, bRecv = 0;
     P::node_begin(c, ps, r, &shP[w]);
     if (!useB) {
-      vd.next0 = d.evNext[e0];
-      vd.rec0 = d.ev[e0];
-      vd.aux0 = d.evAux[e0];
+      vd.next0 = d.evNext[vd.e0];
+      vd.rec0 = d.ev[vd.e0];
+      vd.aux0 = d.evAux[vd.e0];
     }
-    const int32_t next0 = vd.next0;
-    const Rec rec0 = vd.rec0;
-    const EvAux aux0 = vd.aux0;
-    // mode 0: e0 is the only event (usual); 1: <= 64 events, sorted into shSort; 2: more (the PingPong
-    // origin): repeated minimum search over the list. One call site of deliver_event for all three.
-    int mode = 0;
-    uint32_t cnt = 1;
-    if (next0 >= 0) {
-      int32_t cur = e0;
-      uint32_t mine = 0xFFFFFFFFu;
-      cnt = 0;
-      while (cur >= 0 && cnt < 64) {
-        if ((uint32_t)lane == cnt) mine = (uint32_t)cur;
-        cur = d.evNext[cur];
-        cnt++;
-      }
-      if (cur < 0) {
-        mode = 1;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
-        if ((uint32_t)lane < cnt) shSort[w][rank] = mine;
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        mode = 2;
-        cnt = 0xFFFFFFFFu;
-      }
-    }
-    bool have = false;
-    uint32_t last = 0;
-    KPROF_MARK(d.g, 1);  // descriptor + node_begin (+ the inbox sort of multi-event nodes)
-    for (uint32_t k = 0; k < cnt; k++) {
-      uint32_t e = (uint32_t)e0;
-      if (mode == 1) {
-        e = shSort[w][k];
-      } else if (mode == 2) {
-        uint32_t best = 0xFFFFFFFFu;
-        for (int32_t q = e0; q >= 0; q = d.evNext[q])
-          if ((!have || (uint32_t)q > last) && (uint32_t)q < best) best = (uint32_t)q;
-        if (best == 0xFFFFFFFFu) break;
-        e = best;
-        last = best;
-        have = true;
-      }
-      Rec rec = rec0;
-      EvAux aux = aux0;
-      if (mode != 0) {
-        rec = d.ev[e];
-        aux = d.evAux[e];
-      }
-      deliver_event<P>(d, ps, c, r, e, rec, aux, toDown, toPart, mode == 2 || k + 1 < cnt, nRecv, bRecv);
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_MARK(d.g, 2);  // the events' action()s
-    P::node_end(c, ps, r);
-    if (lane == 0) {
-      // Node counters (C/Node.java:69-79): this wavefront is the node's only writer in this launch;
-      // atomics without a return value do not stall the wave the way a load-add-store would
-      if (nRecv) {
-        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
-        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
-      }
-      if (c.msgSent) {
-        atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
-        atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
-      }
-      if (!useB) d.head[node] = -1;  // (k_deliver_msgs has emptied the inbox lists already)
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_MARK(d.g, 3);  // node_end + counters
+    deliver_visit<P>(d, ps, c, r, vd, shSort[w], useB != 0);
   }
 }
 
@@ -1687,9 +1761,44 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       }
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = 0; j < nJobs; j++) {  // wide payloads: the whole wavefront copies, coalesced
-      const CopyJob job = shJobs[w][j];
-      for (int q = lane; q < job.nw; q += 64) job.dst[q] = job.src[q];
+    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
+    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
+    // after the other, and up to a few dozen jobs a wavefront.
+    uint32_t totalWords = 0;
+    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
+      const uint32_t j = base0 + (uint32_t)lane;
+      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
+      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
+      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
+      totalWords += __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 < totalWords; i0 += 256) {
+      uint64_t v[4];
+      uint64_t* dp[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
+        dp[u] = nullptr;
+        v[u] = 0;
+        if (idx < totalWords) {
+          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)shJobs[w][mid].pad <= idx)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          const CopyJob job = shJobs[w][lo];
+          const uint32_t off = idx - (uint32_t)job.pad;
+          v[u] = job.src[off];
+          dp[u] = job.dst + off;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (dp[u]) *dp[u] = v[u];
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -175,16 +175,54 @@ struct HandelProto {
 
   __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls) {
     load_levels(s, c.node, ls);  // the whole header, one memory instruction
+    regs_from_image(r, ls);
+  }
+  // the header fetched ahead of the visit (k_deliver's pipelined loop): 16 bytes a lane, two rounds when L > 16
+  struct Pre {
+    U4 q0;
+  };
+  __device__ static Pre prefetch(const State& s, int32_t node) {
+    const U4* g = (const U4*)h_hdr(s, node);
+    const int n4 = s.hdrStride >> 2;
+    Pre p;
+    p.q0 = g[(int)WG_LANE < n4 ? (int)WG_LANE : 0];
+    return p;
+  }
+  __device__ static void scatter_levels(const State& s, LevelScalars* ls, int i, const U4 q) {
+    const int w = i << 2;
+    uint32_t* dst;
+    if (w < HH_LV) {
+      dst = ls->sc + w;
+    } else {
+      const int r = w - HH_LV;
+      dst = (uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (s.LS - 1));
+    }
+    dst[0] = q.x;
+    dst[1] = q.y;
+    dst[2] = q.z;
+    dst[3] = q.w;
+  }
+  __device__ static void node_begin_pre(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls, const Pre& p) {
+    const int n4 = s.hdrStride >> 2;
+    __builtin_amdgcn_wave_barrier();  // the previous visit's store_levels has read the image
+    if ((int)WG_LANE < n4) scatter_levels(s, ls, (int)WG_LANE, p.q0);
+    if ((int)WG_LANE + 64 < n4)  // (L > 16: the record's tail is fetched here, not ahead)
+      scatter_levels(s, ls, (int)WG_LANE + 64, ((const U4*)h_hdr(s, c.node))[(int)WG_LANE + 64]);
+    __builtin_amdgcn_wave_barrier();
+    regs_from_image(r, ls);
+  }
+  __device__ static void regs_from_image(NodeRegs& r, LevelScalars* ls) {
+    // (every lane reads the same LDS words: readfirstlane tells the compiler the values are wave-uniform — SGPRs)
     const uint32_t* h = ls->sc;
-    r.doneAt = r.doneAt0 = (long long)((unsigned long long)h[HH_DONE_LO] | ((unsigned long long)h[HH_DONE_HI] << 32));
-    r.addedCycle = (int32_t)h[HH_ADDED];
-    r.sigQueueSize = (int32_t)h[HH_SIGQ];
-    r.msgFiltered = (int32_t)h[HH_FILT];
-    r.startAt = (int32_t)h[HH_START];
+    r.doneAt = r.doneAt0 = (long long)((unsigned long long)WG_READFIRST(h[HH_DONE_LO]) | ((unsigned long long)WG_READFIRST(h[HH_DONE_HI]) << 32));
+    r.addedCycle = (int32_t)WG_READFIRST(h[HH_ADDED]);
+    r.sigQueueSize = (int32_t)WG_READFIRST(h[HH_SIGQ]);
+    r.msgFiltered = (int32_t)WG_READFIRST(h[HH_FILT]);
+    r.startAt = (int32_t)WG_READFIRST(h[HH_START]);
 #pragma unroll
     for (int k = 0; k < H_PEND; k++) {
-      r.pend[k] = h[HH_PEND + k];
-      r.pendFrom[k] = (int32_t)h[HH_PENDFROM + k];
+      r.pend[k] = WG_READFIRST(h[HH_PEND + k]);
+      r.pendFrom[k] = (int32_t)WG_READFIRST(h[HH_PENDFROM + k]);
     }
     r.ls = ls;
   }
@@ -768,17 +806,39 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nRun = *s.runCount;
   LevelScalars* ls = &shLevels[threadIdx.x >> 6];
+  // Software-pipelined over the runners of this wavefront: while runner q is worked on, the header of runner
+  // q + nWaves and the id of runner q + 2 nWaves are in flight (a runner's checkSigs touches its own node only).
+  if (wave >= nRun) return;
+  int32_t nodeCur = (int32_t)s.runList[wave];
+  HandelProto::Pre hdrCur = HandelProto::prefetch(s, nodeCur);
+  int32_t nodeNext = wave + nWaves < nRun ? (int32_t)s.runList[wave + nWaves] : 0;
   for (uint32_t q = wave; q < nRun; q += nWaves) {
-    const int32_t node = (int32_t)s.runList[q];
-    HandelProto::load_levels(s, node, ls);
+    const int32_t node = nodeCur;
+    const bool haveNext = q + nWaves < nRun;
+    HandelProto::Pre hdrNext = hdrCur;
+    int32_t nodeNext2 = 0;
+    if (haveNext) {
+      hdrNext = HandelProto::prefetch(s, nodeNext);
+      if (q + 2 * nWaves < nRun) nodeNext2 = (int32_t)s.runList[q + 2 * nWaves];
+    }
+    {
+      const int n4 = s.hdrStride >> 2;
+      __builtin_amdgcn_wave_barrier();  // the previous runner's store_levels has read the image
+      if (lane < n4) HandelProto::scatter_levels(s, ls, lane, hdrCur.q0);
+      if (lane + 64 < n4) HandelProto::scatter_levels(s, ls, lane + 64, ((const U4*)h_hdr(s, node))[lane + 64]);
+      __builtin_amdgcn_wave_barrier();
+    }
+    nodeCur = nodeNext;
+    nodeNext = nodeNext2;
+    hdrCur = hdrNext;
     const uint64_t* ti = s.TI + (size_t)node * s.W;
     const uint64_t* la = s.LA + (size_t)node * s.W;
     const uint64_t* vi = s.VI + (size_t)node * s.W;
-    const int window = (int)ls->sc[HH_WINDOW];
-    int sigQueueSize = (int)ls->sc[HH_SIGQ];
+    const int window = (int)WG_READFIRST(ls->sc[HH_WINDOW]);
+    int sigQueueSize = (int)WG_READFIRST(ls->sc[HH_SIGQ]);
     uint32_t pend[H_PEND];
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) pend[k] = ls->sc[HH_PEND + k];
+    for (int k = 0; k < H_PEND; k++) pend[k] = WG_READFIRST(ls->sc[HH_PEND + k]);
     int ncand = 0;
     // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
     uint32_t lvMask = 0;
@@ -837,12 +897,29 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         }
         const uint64_t om = __ballot(outside && myRank == minRank);
         if (om) bestOutside = __shfl(mySlot, __ffsll((unsigned long long)om) - 1, 64);
-      } else
+      } else {
+      // blocks of up to 64 words (levels <= 13): the level's three row words of this lane are loaded once, not once
+      // per queue entry
+      const int jh = (int)((lane - v.bw) & 63);
+      const bool oneRound = v.nw <= 64;
+      uint64_t tih = 0, vih = 0, lah = 0;
+      if (oneRound && jh < v.nw) {
+        tih = ti[v.bw + jh];
+        vih = vi[v.bw + jh];
+        lah = la[v.bw + jh];
+      }
       for (int i = 0; i < len; i++) {
         const int slot = __shfl(mySlot, i, 64);
         const int rank = __shfl(myRank, i, 64);
         const uint64_t* sig = HandelProto::sig_ptr(s, node, l, slot);
         uint64_t a = 0, b = 0;
+        if (oneRound) {
+          if (jh < v.nw) {
+            const uint64_t sg = sig[jh];
+            a = (uint64_t)__popcll(sg | tih | vih) | ((uint64_t)__popcll(sg | vih) << 21) | ((uint64_t)__popcll(sg) << 42);
+            b = (uint64_t)((sg & tih) != 0) | ((uint64_t)((sg & lah) != 0) << 21);
+          }
+        } else
         H_FOR_WORDS(v, j) {
           uint64_t sg = sig[j], tiw = ti[v.bw + j] & v.mask, viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
           a += (uint64_t)__popcll(sg | tiw | viw) | ((uint64_t)__popcll(sg | viw) << 21) | ((uint64_t)__popcll(sg) << 42);
@@ -872,6 +949,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
             bestOutsideRank = rank;
           }
         }
+      }
       }
       const int kept = __popcll(keep);
       if (kept != len) {  // replaceToVerifyAgg :636-646
