@@ -1,17 +1,18 @@
 #!/bin/bash
-# Investigation build: in-kernel cycle counters (KPROF_MARK) of the wave-per-node delivery kernel.
-# Builds wittgenstein_amd/libwittgpu_kprof.so (-DWG_KPROF) and runs one un-timed bench step with it.
+# Investigation build: in-kernel cycle counters (KPROF_MARK) of the Handel node-visit kernels.
+# Builds wittgenstein_amd/libwittgpu_kprof.so (-DWG_KPROF) and runs one un-timed RunMultipleTimes pass with it; the
+# counters are those of the batch's FIRST member (s_memtime units, summed over its wavefronts).
 OUT=gpurun_out/${1:-kprof}; mkdir -p $OUT
-bash wittgenstein_amd/csrc/build.sh -DWG_KPROF -o $(pwd)/wittgenstein_amd/libwittgpu_kprof.so 2>&1 | grep -E "error" 
+bash wittgenstein_amd/csrc/build.sh -DWG_KPROF -o $(pwd)/wittgenstein_amd/libwittgpu_kprof.so 2>&1 | grep -E "error"
 WG_LIB=$(pwd)/wittgenstein_amd/libwittgpu_kprof.so python - <<'PY' | tee $OUT/kprof.txt
 import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+sys.path.insert(0, os.getcwd())
 import bench, wittgenstein_amd as w
-R = int(os.environ.get("KPROF_R", "8")); n = int(os.environ.get("KPROF_N", "32768"))
-sims, batch = bench.make_batch(w, n, range(R), 0, 4)
+R = int(os.environ.get("KPROF_R", "16")); n = int(os.environ.get("KPROF_N", "32768"))
+sims, batch = bench.make_batch(w, n, range(R), 0, R)
 sims[0].network().profile(1)
 batch.run_multiple_times(chunk=10, maxTime=20000)
 pr = sims[0].network().profile_read()
 for k, v in pr.items():
-    print("%-40s %14.0f" % (k, v["total_ns"]))
+    print("%-44s %16.0f" % (k, v["total_ns"]))
 PY

@@ -242,9 +242,9 @@ class Network:
         self._ck(L.lib().wg_profile_enable(self._h, int(mode)))
 
     def profile_read(self):
-        arr = (L.wg_profile_entry * 32)()
+        arr = (L.wg_profile_entry * 64)()
         n = C.c_int32()
-        self._ck(L.lib().wg_profile_read(self._h, arr, 32, C.byref(n)))
+        self._ck(L.lib().wg_profile_read(self._h, arr, 64, C.byref(n)))
         return {arr[i].name.decode(): {"spans": arr[i].spans, "total_ns": arr[i].total_ns} for i in range(n.value)}
 
     def latency_probe(self, frm, to, delta):

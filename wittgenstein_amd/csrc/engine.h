@@ -171,6 +171,7 @@ struct Globals {
   unsigned long long payloadHead;  // monotone, in 64-bit words
   // in-kernel cycle counters of investigation builds (-DWG_KPROF, tools/kprof.sh); untouched otherwise
   unsigned long long kprof[32];
+  unsigned long long* kprofBuf;  // [KPROF_WAVES][32] per-wavefront rows the marks add to (summed into kprof[] by the host)
   // sharded engines only (0 otherwise): multi-destination envelopes created in this phase / their destinations
   // (replicated), and this shard's private scratch-ring head for the unsorted destination lists of its action()s
   uint32_t nMulti, nMultiDests;
@@ -180,6 +181,7 @@ struct Globals {
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
 };
+constexpr uint32_t KPROF_WAVES = 16384;
 constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)
 
 struct LatencyModel {

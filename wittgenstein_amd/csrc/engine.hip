@@ -345,6 +345,9 @@ void Engine::ensure_device() {
   uint64_t payloadWords = cfg.payload_words > 0 ? (uint64_t)cfg.payload_words : (1u << 16);
 
   dev.g = dalloc<Globals>(1);
+#ifdef WG_KPROF
+  gh.kprofBuf = dalloc<unsigned long long>((size_t)KPROF_WAVES * 32);
+#endif
   NodeArrays& nd = dev.nodes;
   nd.n = n;
   nd.x = dalloc<int16_t>(n);
@@ -470,6 +473,14 @@ void Engine::sync_globals_to_device() {
   globalsDirty = false;
 }
 void Engine::sync_globals_to_host() {
+#ifdef WG_KPROF
+  if (gh.kprofBuf) {
+    std::vector<unsigned long long> rows((size_t)KPROF_WAVES * 32);
+    WG_HIP(hipMemcpy(rows.data(), gh.kprofBuf, 8 * rows.size(), hipMemcpyDeviceToHost));
+    WG_HIP(hipMemset(gh.kprofBuf, 0, 8 * rows.size()));
+    for (size_t i = 0; i < rows.size(); i++) kprofSum[i & 31] += rows[i];
+  }
+#endif
   WG_HIP(hipMemcpyAsync(&gh, dev.g, sizeof(Globals), hipMemcpyDeviceToHost, stream));
   WG_HIP(hipStreamSynchronize(stream));
 }
@@ -2025,7 +2036,7 @@ struct HandelHost : ProtoHost {
     if (plane < 0) return false;
     const std::vector<uint32_t> h = read_hdr();
     for (int i = 0; i < n; i++)
-      for (int l = 0; l < L; l++) dst[(size_t)i * L + l] = (int32_t)h[(size_t)i * st.hdrStride + HH_LV + plane * st.LS + l];
+      for (int l = 0; l < L; l++) dst[(size_t)i * L + l] = (int32_t)h[(size_t)i * st.hdrStride + HH_LV + l * HP_COUNT + plane];
     return true;
   }
   bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {

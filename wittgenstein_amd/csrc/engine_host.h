@@ -171,6 +171,7 @@ class Engine {
   hipStream_t stream = nullptr;
   EngineDev dev{};               // device pointers (passed by value to kernels)
   Globals gh{};                  // host shadow of the device globals (valid between runs)
+  unsigned long long kprofSum[32] = {0};  // -DWG_KPROF builds: the in-kernel marks, summed over wavefronts and runs
   bool globalsDirty = true;
   bool allocated = false;
   int32_t time = 0;              // Network.time

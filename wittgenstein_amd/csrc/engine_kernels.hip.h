@@ -27,18 +27,23 @@ namespace wg {
 // to Globals::kprof[slot]. Marks sit where the code first consumes loaded data, so a region's cycles
 // are mostly the wait for its loads.
 #ifdef WG_KPROF
+// (per-wavefront rows of Globals::kprofBuf — distinct addresses, no-return atomics: a same-address counter would make
+// the instrumentation the run time, one L2 atomic unit retires ~88 same-address atomics/us)
+#define KPROF_WAVE ((((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (KPROF_WAVES - 1)) * 32)
 #define KPROF_DECL unsigned long long _kp = __builtin_readcyclecounter()
 #define KPROF_MARK(g, slot)                                                            \
   do {                                                                                 \
     const unsigned long long _n = __builtin_readcyclecounter();                        \
-    if (WG_LANE == 0) atomicAdd(&(g)->kprof[slot], _n - _kp);                          \
+    if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], _n - _kp);        \
     _kp = _n;                                                                          \
   } while (0)
-#define KPROF_COUNT(g, slot) do { if (WG_LANE == 0) atomicAdd(&(g)->kprof[slot], 1ULL); } while (0)
+#define KPROF_COUNT(g, slot) do { if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], 1ULL); } while (0)
+#define KPROF_ADD(g, slot, v) do { if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], (unsigned long long)(v)); } while (0)
 #else
 #define KPROF_DECL
 #define KPROF_MARK(g, slot)
 #define KPROF_COUNT(g, slot)
+#define KPROF_ADD(g, slot, v)
 #endif
 
 // dynamic LDS of a kernel (a macro so that tests/emu, which builds these kernels for its CPU wave
@@ -1677,6 +1682,8 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
   for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 24);
     const uint32_t a = base + lane;
     const bool have = a < nActive;
     const int32_t node = have ? (int32_t)d.active[a] : 0;
@@ -1726,6 +1733,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     typename P::LaneNode r;
     const bool toDown = (vd.flags & VD_DOWN) != 0;
     const uint8_t toPart = (uint8_t)(vd.flags >> 8);
+    KPROF_MARK(d.g, 25);  // inbox walk + classification
     if (mine) P::lane_begin(d, ps, node, r);
     long long nRecv = 0, bRecv = 0;
     uint32_t nJobs = 0;
@@ -1761,6 +1769,8 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       }
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 26);  // the lanes' messages
+    KPROF_ADD(d.g, 28, nJobs);
     // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
     // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
     // after the other, and up to a few dozen jobs a wavefront.
@@ -1801,6 +1811,8 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         if (dp[u]) *dp[u] = v[u];
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_ADD(d.g, 29, totalWords);
+    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
   }
 }
 

@@ -36,8 +36,12 @@ struct HandelState {
   //                              sigsChecked, ConditionalTask.minStartTime, the epoch it last left nextMessage()'s copy
   //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
-  //   [HH_LV + plane*LS + l]     planes posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
-  //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L
+  //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
+  //   [HH_LV + l*8 + plane]      level-major: the eight scalars of HLevel l side by side (32 bytes, two levels a 64-byte
+  //                              line) — posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
+  //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L levels.
+  //                              An event works on ONE level: the record goes back as the few 16-byte pieces that
+  //                              changed (store_levels), i.e. the scalars' line and the level's, not all ten lines
   uint32_t* hdr;
   int32_t LS, lsShift, hdrStride;
   uint64_t* qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
@@ -70,12 +74,12 @@ struct HandelState {
 };
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
-                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_PEND = 12, HH_PENDFROM = 16,
-                       HH_LV = 32 };
+                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
+                       HH_PENDFROM = 16, HH_LV = 32 };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t* h_lv(const HandelState& s, int32_t node, int plane, int l) {
-  return s.hdr + (size_t)node * s.hdrStride + HH_LV + plane * s.LS + l;
+  return s.hdr + (size_t)node * s.hdrStride + HH_LV + l * HP_COUNT + plane;
 }
 
 // geometry of one level inside a row
@@ -141,6 +145,7 @@ struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_QUSE
   uint32_t quLo[32];
   uint32_t quHi[32];
   uint32_t sc[HH_LV];
+  U4 orig[(HH_LV + 8 * 32) / 4];  // the record as it was loaded, 16-byte pieces: store_levels writes back what differs
 };
 __device__ __forceinline__ unsigned long long ls_qused(const LevelScalars* ls, int l) {
   return (unsigned long long)ls->quLo[l] | ((unsigned long long)ls->quHi[l] << 32);
@@ -188,19 +193,44 @@ struct HandelProto {
     p.q0 = g[(int)WG_LANE < n4 ? (int)WG_LANE : 0];
     return p;
   }
-  __device__ static void scatter_levels(const State& s, LevelScalars* ls, int i, const U4 q) {
+  // piece i of the record (16 bytes) <-> the LDS image: scalars as they are; a level's two pieces are the planes
+  // 0..3 / 4..7 of that level (the image keeps one array per plane: ls->cTI[l], ...)
+  __device__ static void scatter_levels(const State&, LevelScalars* ls, int i, const U4 q) {
     const int w = i << 2;
-    uint32_t* dst;
+    ls->orig[i] = q;
     if (w < HH_LV) {
-      dst = ls->sc + w;
+      uint32_t* dst = ls->sc + w;
+      dst[0] = q.x;
+      dst[1] = q.y;
+      dst[2] = q.z;
+      dst[3] = q.w;
     } else {
       const int r = w - HH_LV;
-      dst = (uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (s.LS - 1));
+      uint32_t* dst = (uint32_t*)ls + (((r >> 2) & 1) << 7) + (r >> 3);  // plane (0 or 4) * 32 + level
+      dst[0] = q.x;
+      dst[32] = q.y;
+      dst[64] = q.z;
+      dst[96] = q.w;
     }
-    dst[0] = q.x;
-    dst[1] = q.y;
-    dst[2] = q.z;
-    dst[3] = q.w;
+  }
+  __device__ static U4 gather_levels(const LevelScalars* ls, int i) {
+    const int w = i << 2;
+    U4 q;
+    if (w < HH_LV) {
+      const uint32_t* src = ls->sc + w;
+      q.x = src[0];
+      q.y = src[1];
+      q.z = src[2];
+      q.w = src[3];
+    } else {
+      const int r = w - HH_LV;
+      const uint32_t* src = (const uint32_t*)ls + (((r >> 2) & 1) << 7) + (r >> 3);
+      q.x = src[0];
+      q.y = src[32];
+      q.z = src[64];
+      q.w = src[96];
+    }
+    return q;
   }
   __device__ static void node_begin_pre(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls, const Pre& p) {
     const int n4 = s.hdrStride >> 2;
@@ -264,43 +294,18 @@ struct HandelProto {
   // header <-> LDS image, 16 bytes a lane: 640 bytes (L <= 16) are one memory instruction
   __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
     const U4* g = (const U4*)h_hdr(s, node);
-    const int LS = s.LS;
-    for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) {
-      const U4 q = g[i];
-      const int w = i << 2;
-      uint32_t* dst;
-      if (w < HH_LV) {
-        dst = ls->sc + w;
-      } else {
-        const int r = w - HH_LV;
-        dst = (uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (LS - 1));
-      }
-      dst[0] = q.x;
-      dst[1] = q.y;
-      dst[2] = q.z;
-      dst[3] = q.w;
-    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) scatter_levels(s, ls, i, g[i]);
     __builtin_amdgcn_wave_barrier();
   }
+  // ... and back: only the 16-byte pieces that differ from what was loaded (an event changes the scalars' line and
+  // its level's: the other lines of the record stay clean in L2 and are never written back to HBM)
   __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
     __builtin_amdgcn_wave_barrier();
     U4* g = (U4*)h_hdr(s, node);
-    const int LS = s.LS;
     for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) {
-      const int w = i << 2;
-      const uint32_t* src;
-      if (w < HH_LV) {
-        src = ls->sc + w;
-      } else {
-        const int r = w - HH_LV;
-        src = (const uint32_t*)ls + ((r >> s.lsShift) << 5) + (r & (LS - 1));
-      }
-      U4 q;
-      q.x = src[0];
-      q.y = src[1];
-      q.z = src[2];
-      q.w = src[3];
-      g[i] = q;
+      const U4 q = gather_levels(ls, i), o = ls->orig[i];
+      if (q.x != o.x || q.y != o.y || q.z != o.z || q.w != o.w) g[i] = q;
     }
   }
 
@@ -310,6 +315,7 @@ struct HandelProto {
     long long doneAt;
     int32_t startAt, sigQueueSize, msgFiltered;
     int32_t sigQueueSize0, msgFiltered0;
+    uint32_t qmask, qmask0;
   };
   __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
     const uint32_t* h = h_hdr(s, node);
@@ -317,10 +323,12 @@ struct HandelProto {
     r.startAt = (int32_t)h[HH_START];
     r.sigQueueSize = r.sigQueueSize0 = (int32_t)h[HH_SIGQ];
     r.msgFiltered = r.msgFiltered0 = (int32_t)h[HH_FILT];
+    r.qmask = r.qmask0 = h[HH_QMASK];
   }
   __device__ static void lane_end(const EngineDev&, const State& s, int32_t node, const LaneNode& r) {
     if (r.sigQueueSize != r.sigQueueSize0) h_hdr(s, node)[HH_SIGQ] = (uint32_t)r.sigQueueSize;
     if (r.msgFiltered != r.msgFiltered0) h_hdr(s, node)[HH_FILT] = (uint32_t)r.msgFiltered;
+    if (r.qmask != r.qmask0) h_hdr(s, node)[HH_QMASK] = r.qmask;
   }
   __device__ static void lane_message(const EngineDev& d, const State& s, int32_t t, int32_t node, LaneNode& r,
                                       int32_t from, uint32_t msg, uint32_t payload, CopyJob& job) {
@@ -368,6 +376,7 @@ struct HandelProto {
     else
       *qhi = (uint32_t)(used >> 32) | (1u << (slot - 32));
     *qln = (uint32_t)(len + 1);
+    r.qmask |= 1u << l;
     if (nw == 1) {
       dst[0] = pw0;
     } else {
@@ -504,6 +513,7 @@ struct HandelProto {
       s.qent[((size_t)node * s.L + l) * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
       ls_set_qused(ls, l, used | (1ULL << slot));
       ls->qlen[l] = len + 1;
+      ls->sc[HH_QMASK] |= 1u << l;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -653,7 +663,10 @@ struct HandelProto {
         const int at = __ffsll((unsigned long long)hit) - 1;
         const uint64_t next = shfl64(myEnt, (lane + 1) & 63);
         if (lane >= at && lane < len - 1) ent[lane] = next;
-        if (lane == 0) ls->qlen[lv] = len - 1;
+        if (lane == 0) {
+          ls->qlen[lv] = len - 1;
+          if (len == 1) ls->sc[HH_QMASK] &= ~(1u << lv);
+        }
       }
     }
     const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
@@ -670,6 +683,7 @@ struct HandelProto {
       cTI++;
       improved = true;
     }
+    const uint64_t ti0m = ti0;  // the word as it is in memory
     if (has0 && j0 == jF) {
       vi0 |= bit;
       if (!hadTI) ti0 |= bit;
@@ -688,11 +702,13 @@ struct HandelProto {
     if (u2 > cVI) {
       improved = true;
       uint64_t cnt = 0;
+      // (only the words that change are written: a verified aggregate usually adds a few bits to a block whose other
+      // words — up to 2 KB of them — would otherwise be dirtied in L2 and written back to HBM for nothing)
       if (has0) {
         uint64_t nla = (inter ? 0ULL : (la0 & v.mask)) | sg0;
         uint64_t nti = nla | (vi0 & v.mask);
-        la[v.bw + j0] = (la0 & ~v.mask) | nla;
-        ti[v.bw + j0] = (ti0 & ~v.mask) | nti;
+        if (nla != (la0 & v.mask)) la[v.bw + j0] = (la0 & ~v.mask) | nla;
+        if (nti != (ti0m & v.mask)) ti[v.bw + j0] = (ti0m & ~v.mask) | nti;
         cnt = (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
       }
       for (int j = j0 + 64; j < v.nw; j += 64) {
@@ -701,8 +717,8 @@ struct HandelProto {
         if (j == jF) viw |= bit;  // (this lane stored it above; same-lane order makes the reload see it anyway)
         uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
         uint64_t nti = nla | (viw & v.mask);
-        la[v.bw + j] = (law & ~v.mask) | nla;
-        ti[v.bw + j] = (tiw & ~v.mask) | nti;
+        if (nla != (law & v.mask)) la[v.bw + j] = (law & ~v.mask) | nla;
+        if (nti != (tiw & v.mask)) ti[v.bw + j] = (tiw & ~v.mask) | nti;
         cnt += (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
       }
       cnt = wave_sum64(cnt);
@@ -773,13 +789,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
         h[HH_CTMIN] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
         // sigQueueSize drifts above the real queue lengths: checkSigs then runs over empty
         // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node needs no visit
-        const U4* ql = (const U4*)(h + HH_LV + HP_QLEN * s.LS);
-        uint32_t tot = 0;
-        for (int k = 0; k < (s.LS >> 2); k++) {
-          const U4 q = ql[k];
-          tot |= q.x | q.y | q.z | q.w;
-        }
-        if (tot == 0) run = false;
+        if (h[HH_QMASK] == 0) run = false;
       }
       if (!run) s.candCnt[node] = 0;
     }
@@ -813,6 +823,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
   HandelProto::Pre hdrCur = HandelProto::prefetch(s, nodeCur);
   int32_t nodeNext = wave + nWaves < nRun ? (int32_t)s.runList[wave + nWaves] : 0;
   for (uint32_t q = wave; q < nRun; q += nWaves) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 16);
     const int32_t node = nodeCur;
     const bool haveNext = q + nWaves < nRun;
     HandelProto::Pre hdrNext = hdrCur;
@@ -831,6 +843,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     nodeCur = nodeNext;
     nodeNext = nodeNext2;
     hdrCur = hdrNext;
+    KPROF_MARK(d.g, 17);  // header image (prefetched a runner ahead)
     const uint64_t* ti = s.TI + (size_t)node * s.W;
     const uint64_t* la = s.LA + (size_t)node * s.W;
     const uint64_t* vi = s.VI + (size_t)node * s.W;
@@ -863,6 +876,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       }
       const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
       const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+      KPROF_COUNT(d.g, 18);
+      KPROF_MARK(d.g, 19);  // the level's list entries
       int windowIndex = myRank;  // Collections.min(rank)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) windowIndex = min(windowIndex, __shfl_xor(windowIndex, o, 64));
@@ -897,6 +912,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         }
         const uint64_t om = __ballot(outside && myRank == minRank);
         if (om) bestOutside = __shfl(mySlot, __ffsll((unsigned long long)om) - 1, 64);
+        KPROF_MARK(d.g, 20);  // a single-word level
       } else {
       // blocks of up to 64 words (levels <= 13): the level's three row words of this lane are loaded once, not once
       // per queue entry
@@ -950,6 +966,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
           }
         }
       }
+      KPROF_ADD(d.g, 21, len);
+      KPROF_MARK(d.g, 22);  // a multi-word level (kprof21: its entries)
       }
       const int kept = __popcll(keep);
       if (kept != len) {  // replaceToVerifyAgg :636-646
@@ -967,6 +985,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         if (lane == 0) {
           ls_set_qused(ls, l, ls_qused(ls, l) & ~relMask);
           ls->qlen[l] = kept;
+          if (kept == 0) ls->sc[HH_QMASK] &= ~(1u << l);
         }
         sigQueueSize += kept - len;
         __builtin_amdgcn_wave_barrier();
@@ -987,6 +1006,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     }
     HandelProto::store_levels(s, node, ls);
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 23);  // list curation, candidates, header store
   }
 }
 
