@@ -28,6 +28,38 @@ __global__ void __launch_bounds__(256) probe(const uint64_t* base, uint64_t line
   }
   if (lane == 0) out[wave] = acc;
 }
+// A round = one dependent load, then (ST = 1) one 64-byte store to another random line. On gfx9-family ISAs loads and
+// stores share the vmcnt counter, which retires in order: waiting for the NEXT round's load also waits for this round's
+// store to be acknowledged. ST = 2: the store goes to the line that was just loaded (already in L2).
+template <int ST>
+__global__ void __launch_bounds__(256) probe_st(uint64_t* base, uint64_t lines, int rounds, uint64_t* out) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t acc = mix(wave * 0x9E3779B97F4A7C15ULL + 1);
+  for (int s = 0; s < rounds; s++) {
+    const uint64_t r = mix(acc) & (lines - 1);
+    const uint64_t got = lane < 8 ? base[r * 8 + lane] : 0;
+    acc += __shfl(got & 1, 0, 64) + 1;
+    if (ST) {
+      const uint64_t w = ST == 2 ? r : (mix(acc + 77) & (lines - 1));
+      if (lane < 8) base[w * 8 + lane] = got | 1;
+    }
+  }
+  if (lane == 0) out[wave] = acc;
+}
+template <int ST>
+int run_st(uint64_t* buf, uint64_t lines, uint64_t* out, int blocks) {
+  const int rounds = 256;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(probe_st<ST>, dim3(blocks), dim3(256), 0, 0, buf, lines, 8, out);
+  CK(hipEventRecord(a));
+  hipLaunchKernelGGL(probe_st<ST>, dim3(blocks), dim3(256), 0, 0, buf, lines, rounds, out);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  printf("%8d  store=%d | %9.3f us/round\n", blocks * 4, ST, ms * 1e3 / rounds);
+  return 0;
+}
 template <int PAR>
 int run(const uint64_t* buf, uint64_t lines, uint64_t* out, int blocks) {
   const int rounds = 256;
@@ -58,6 +90,12 @@ int main() {
     if (run<4>(buf, lines, out, blocks)) return 1;
     if (run<8>(buf, lines, out, blocks)) return 1;
     if (run<16>(buf, lines, out, blocks)) return 1;
+  }
+  printf("dependent load (+ store) per round\n");
+  for (int blocks : {64, 1024, 2048}) {
+    if (run_st<0>(buf, lines, out, blocks)) return 1;
+    if (run_st<1>(buf, lines, out, blocks)) return 1;
+    if (run_st<2>(buf, lines, out, blocks)) return 1;
   }
   return 0;
 }

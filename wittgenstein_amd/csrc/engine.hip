@@ -1844,8 +1844,6 @@ struct HandelHost : ProtoHost {
     st.runList = e.dalloc<uint32_t>(N);
     st.runCount = e.dalloc<uint32_t>(1);
     st.candCnt = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
-    st.candLevel = e.dalloc<uint8_t>(NL);
-    st.candSlot = e.dalloc<uint8_t>(NL);
     st.condOrd = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N);
     st.drawVal = e.dalloc<int32_t>(N);

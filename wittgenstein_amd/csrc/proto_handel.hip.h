@@ -36,6 +36,8 @@ struct HandelState {
   //                              sigsChecked, ConditionalTask.minStartTime, the epoch it last left nextMessage()'s copy
   //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
+  //   [HH_CAND +12]              checkSigs' candidates of this edge, in level order: 16 bits each, level << 8 | slot (written by
+  //                              k_handel_cond_a1 with the rest of the record, read by k_handel_cond_a2 in the same phase)
   //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
   //   [HH_LV + l*8 + plane]      level-major: the eight scalars of HLevel l side by side (32 bytes, two levels a 64-byte
   //                              line) — posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
@@ -58,8 +60,6 @@ struct HandelState {
   uint32_t* runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
   uint32_t* runCount;                  // [1]
   uint8_t* candCnt;                    // [N] number of levels with a candidate
-  uint8_t* candLevel;                  // [N][L]
-  uint8_t* candSlot;                   // [N][L]
   uint32_t* condOrd;                   // [N] ordinal among drawing nodes
   uint32_t* condList;                  // drawing nodes in id order
   int32_t* drawVal;                    // [N]
@@ -75,7 +75,7 @@ struct HandelState {
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
-                       HH_PENDFROM = 16, HH_LV = 32 };
+                       HH_PENDFROM = 16, HH_CAND = 20, HH_LV = 32 };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t* h_lv(const HandelState& s, int32_t node, int plane, int l) {
@@ -822,6 +822,15 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
   int32_t nodeCur = (int32_t)s.runList[wave];
   HandelProto::Pre hdrCur = HandelProto::prefetch(s, nodeCur);
   int32_t nodeNext = wave + nWaves < nRun ? (int32_t)s.runList[wave + nWaves] : 0;
+  // list entries of the lowest level with a queue, from a record still in registers: lane l's piece is words 4l..4l+3
+  auto first_entries = [&](const HandelProto::Pre& h, int32_t nd) -> uint64_t {
+    const uint32_t qm = WG_READLANE(h.q0.w, 2) & ~1u;  // HH_QMASK = word 11
+    if (!qm) return ~0ULL;
+    const int l0 = __ffs(qm) - 1;
+    const int len0 = (int)WG_READLANE(h.q0.x, (HH_LV + l0 * HP_COUNT + HP_QLEN) >> 2);
+    return lane < len0 ? s.qent[((size_t)nd * s.L + l0) * 64 + lane] : ~0ULL;
+  };
+  uint64_t entFirst = first_entries(hdrCur, nodeCur);
   for (uint32_t q = wave; q < nRun; q += nWaves) {
     KPROF_DECL;
     KPROF_COUNT(d.g, 16);
@@ -857,11 +866,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     uint32_t lvMask = 0;
     for (int l = 1; l < s.L; l++)
       if (ls->qlen[l] > 0) lvMask |= 1u << l;
-    uint64_t entNext = ~0ULL;
-    if (lvMask) {
-      const int l0 = __ffs(lvMask) - 1;
-      if (lane < ls->qlen[l0]) entNext = s.qent[((size_t)node * s.L + l0) * 64 + lane];
-    }
+    // (the first level's list entries were requested at the end of the previous runner — before ITS stores: loads and
+    // stores retire through one in-order counter on this ISA, so a load issued after stores waits for their acknowledgement)
+    uint64_t entNext = entFirst;
     while (lvMask) {
       const int l = __ffs(lvMask) - 1;
       lvMask &= lvMask - 1;
@@ -992,14 +999,16 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       }
       const int cand = bestInside >= 0 ? bestInside : bestOutside;
       if (cand >= 0) {
-        if (lane == 0) {
-          s.candLevel[(size_t)node * s.L + ncand] = (uint8_t)l;
-          s.candSlot[(size_t)node * s.L + ncand] = (uint8_t)cand;
+        if (lane == 0) {  // (into the record's image: stored with it at the end of the runner, no memory traffic here)
+          uint32_t* cw = ls->sc + HH_CAND + (ncand >> 1);
+          const uint32_t e16 = ((uint32_t)l << 8) | (uint32_t)cand;
+          *cw = (ncand & 1) ? ((*cw & 0xFFFFu) | (e16 << 16)) : ((*cw & 0xFFFF0000u) | e16);
         }
         ncand++;
       }
     }
     __builtin_amdgcn_wave_barrier();
+    entFirst = q + nWaves < nRun ? first_entries(hdrCur, nodeCur) : ~0ULL;  // (hdrCur / nodeCur: the next runner's by now)
     if (lane == 0) {
       ls->sc[HH_SIGQ] = (uint32_t)sigQueueSize;
       s.candCnt[node] = (uint8_t)ncand;
@@ -1069,11 +1078,12 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         for (int q = 0; q < 5; q++) d.xbuf[(size_t)j * 5 + q] = 0;
         continue;
       }
-      const int l = s.candLevel[(size_t)node * s.L + k];
-      const int slot = s.candSlot[(size_t)node * s.L + k];
+      uint32_t* h = h_hdr(s, node);
+      const uint32_t e16 = (h[HH_CAND + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
+      const int l = (int)(e16 >> 8);
+      const int slot = (int)(e16 & 0xFFu);
       const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
-      uint32_t* h = h_hdr(s, node);
       int w = (int)h[HH_WINDOW] * 2;
       if (w > s.p.windowMaximum) w = s.p.windowMaximum;
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
