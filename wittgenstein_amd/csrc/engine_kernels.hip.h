@@ -62,11 +62,75 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int delta) {
   uint32_t lo = __shfl_up((uint32_t)v, delta, 64), hi = __shfl_up((uint32_t)(v >> 32), delta, 64);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
+// ---- wave-wide reductions and scans on the DPP path ------------------------------------------------------------
+// `__shfl*` lowers to ds_bpermute_b32: every step of a 6-step butterfly is an LDS-crossbar round trip (~100 cycles) the
+// next step depends on — with four wavefronts a SIMD that latency is the cost of a node visit's reductions (DESIGN.md
+// §3.1). The DPP row operations move data between lanes inside the VALU (quad_perm / row_ror inside a row of 16,
+// row_bcast:15 / :31 across rows — gfx9-family encodings), a few cycles a step; the total is read from lane 63 with
+// v_readlane, i.e. it lands in an SGPR. tests/emu (no DPP) takes the generic branch.
+#if defined(__HIPCC__) && !defined(WG_NO_DPP)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint64_t dpp_mov64(uint64_t old, uint64_t v) {
+  const uint32_t lo = dpp_mov<CTRL, ROWMASK>((uint32_t)old, (uint32_t)v);
+  const uint32_t hi = dpp_mov<CTRL, ROWMASK>((uint32_t)(old >> 32), (uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// OP(a, b) with identity ID; the result is wave-uniform
+#define WG_DPP_REDUCE(T, MOV, v, OP, ID)                                             \
+  do {                                                                               \
+    v = OP(v, (T)MOV<0xb1, 0xf>((T)(ID), v));  /* quad_perm [1,0,3,2] */             \
+    v = OP(v, (T)MOV<0x4e, 0xf>((T)(ID), v));  /* quad_perm [2,3,0,1] */             \
+    v = OP(v, (T)MOV<0x124, 0xf>((T)(ID), v)); /* row_ror:4 */                       \
+    v = OP(v, (T)MOV<0x128, 0xf>((T)(ID), v)); /* row_ror:8: every lane holds its row's total */ \
+    v = OP(v, (T)MOV<0x142, 0xa>((T)(ID), v)); /* row_bcast:15 into rows 1 and 3 */  \
+    v = OP(v, (T)MOV<0x143, 0xc>((T)(ID), v)); /* row_bcast:31 into rows 2 and 3 */  \
+  } while (0)
+#define WG_OP_ADD(a, b) ((a) + (b))
+#define WG_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define WG_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+__device__ __forceinline__ uint32_t wave_reduce_add32(uint32_t v) {
+  WG_DPP_REDUCE(uint32_t, dpp_mov, v, WG_OP_ADD, 0u);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
+  WG_DPP_REDUCE(uint64_t, dpp_mov64, v, WG_OP_ADD, 0ull);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int32_t wave_reduce_min_i32(int32_t v) {
+  uint32_t u = (uint32_t)v ^ 0x80000000u;  // order-preserving map to unsigned
+  WG_DPP_REDUCE(uint32_t, dpp_mov, u, WG_OP_MIN, 0xFFFFFFFFu);
+  return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
+}
+__device__ __forceinline__ int32_t wave_reduce_max_i32(int32_t v) {
+  uint32_t u = (uint32_t)v ^ 0x80000000u;
+  WG_DPP_REDUCE(uint32_t, dpp_mov, u, WG_OP_MAX, 0u);
+  return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
+}
+#else
+__device__ __forceinline__ uint32_t wave_reduce_add32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += shfl64(v, WG_LANE ^ o);
+  return v;
+}
+__device__ __forceinline__ int32_t wave_reduce_min_i32(int32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int32_t wave_reduce_max_i32(int32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif
+__device__ __forceinline__ int wave_sum(int v) { return (int)wave_reduce_add32((uint32_t)v); }
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -114,8 +178,7 @@ __device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& h
 }
 
 __device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t* sh) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl64(v, WG_LANE ^ o);
+  v = wave_reduce_add64(v);
   int w = threadIdx.x >> 6;
   if (WG_LANE == 0) sh[w] = v;
   __syncthreads();

@@ -128,11 +128,7 @@ __device__ __forceinline__ void row_set(uint64_t* row, int32_t id, bool v) {
     row[w] = v ? (x | (1ULL << (id & 63))) : (x & ~(1ULL << (id & 63)));
   }
 }
-__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl64(v, WG_LANE ^ o);
-  return v;
-}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) { return wave_reduce_add64(v); }
 
 // per-wave LDS mirror of the (node, level) scalars
 struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_QUSED_HI (32 words each), then the scalars
@@ -885,9 +881,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
       KPROF_COUNT(d.g, 18);
       KPROF_MARK(d.g, 19);  // the level's list entries
-      int windowIndex = myRank;  // Collections.min(rank)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) windowIndex = min(windowIndex, __shfl_xor(windowIndex, o, 64));
+      const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
       const int curSize = ls->cTI[l], cLA = ls->cLA[l];
       int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
       uint64_t keep = 0;
@@ -907,12 +901,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         int score = 0;  // score(l, sig) :655-668
         if (inside) score = cLA >= v.size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));
         keep = __ballot(kept1);
-        int maxScore = score, minRank = outside ? myRank : INT32_MAX;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          maxScore = max(maxScore, __shfl_xor(maxScore, o, 64));
-          minRank = min(minRank, __shfl_xor(minRank, o, 64));
-        }
+        const int maxScore = wave_reduce_max_i32(score), minRank = wave_reduce_min_i32(outside ? myRank : INT32_MAX);
         if (maxScore > 0) {
           const uint64_t mm = __ballot(inside && score == maxScore);
           bestInside = __shfl(mySlot, __ffsll((unsigned long long)mm) - 1, 64);
