@@ -4,6 +4,9 @@
 set -u
 TAG=${1:-perf}; shift || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$(pwd)
+for f in wittgenstein_amd/csrc/*; do  # a failed local build must not be measured as if it were the new code
+  if [ "$f" -nt wittgenstein_amd/libwittgpu.so ]; then echo "STALE libwittgpu.so: $f is newer"; exit 1; fi
+done
 timeout 600 python -m pytest tests/test_gpu_handel.py tests/test_golden.py tests/test_gpu_snapshot.py tests/test_gpu_batch.py -m gpu -x -q > $OUT/pytest_handel.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_handel.log
 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu --no-second "$@" > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -2 $OUT/bench.err
 python - $OUT/bench.json <<'PY'

@@ -79,38 +79,48 @@ __device__ __forceinline__ uint64_t dpp_mov64(uint64_t old, uint64_t v) {
   const uint32_t hi = dpp_mov<CTRL, ROWMASK>((uint32_t)(old >> 32), (uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
-// OP(a, b) with identity ID; the result is wave-uniform
-#define WG_DPP_REDUCE(T, MOV, v, OP, ID)                                             \
-  do {                                                                               \
-    v = OP(v, (T)MOV<0xb1, 0xf>((T)(ID), v));  /* quad_perm [1,0,3,2] */             \
-    v = OP(v, (T)MOV<0x4e, 0xf>((T)(ID), v));  /* quad_perm [2,3,0,1] */             \
-    v = OP(v, (T)MOV<0x124, 0xf>((T)(ID), v)); /* row_ror:4 */                       \
-    v = OP(v, (T)MOV<0x128, 0xf>((T)(ID), v)); /* row_ror:8: every lane holds its row's total */ \
-    v = OP(v, (T)MOV<0x142, 0xa>((T)(ID), v)); /* row_bcast:15 into rows 1 and 3 */  \
-    v = OP(v, (T)MOV<0x143, 0xc>((T)(ID), v)); /* row_bcast:31 into rows 2 and 3 */  \
-  } while (0)
-#define WG_OP_ADD(a, b) ((a) + (b))
-#define WG_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
-#define WG_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
-__device__ __forceinline__ uint32_t wave_reduce_add32(uint32_t v) {
-  WG_DPP_REDUCE(uint32_t, dpp_mov, v, WG_OP_ADD, 0u);
+// the six steps: pairs, quads, row_ror:4, row_ror:8 (every lane then holds its row's total), row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3 — lane 63 ends with the wave's total. `id` is the operation's identity (what a lane
+// without a source contributes).
+struct OpAdd {
+  template <class T>
+  __device__ static T f(T a, T b) { return a + b; }
+};
+struct OpMin {
+  template <class T>
+  __device__ static T f(T a, T b) { return a < b ? a : b; }
+};
+struct OpMax {
+  template <class T>
+  __device__ static T f(T a, T b) { return a > b ? a : b; }
+};
+template <class OP>
+__device__ __forceinline__ uint32_t dpp_reduce32(uint32_t v, uint32_t id) {
+  v = OP::f(v, dpp_mov<0xb1, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x4e, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x124, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x128, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x142, 0xa>(id, v));
+  v = OP::f(v, dpp_mov<0x143, 0xc>(id, v));
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wave_reduce_add32(uint32_t v) { return dpp_reduce32<OpAdd>(v, 0u); }
 __device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
-  WG_DPP_REDUCE(uint64_t, dpp_mov64, v, WG_OP_ADD, 0ull);
+  v = v + dpp_mov64<0xb1, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x4e, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x124, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x128, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x142, 0xa>(0ull, v);
+  v = v + dpp_mov64<0x143, 0xc>(0ull, v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ int32_t wave_reduce_min_i32(int32_t v) {
-  uint32_t u = (uint32_t)v ^ 0x80000000u;  // order-preserving map to unsigned
-  WG_DPP_REDUCE(uint32_t, dpp_mov, u, WG_OP_MIN, 0xFFFFFFFFu);
-  return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
+__device__ __forceinline__ int32_t wave_reduce_min_i32(int32_t v) {  // (order-preserving map to unsigned)
+  return (int32_t)(dpp_reduce32<OpMin>((uint32_t)v ^ 0x80000000u, 0xFFFFFFFFu) ^ 0x80000000u);
 }
 __device__ __forceinline__ int32_t wave_reduce_max_i32(int32_t v) {
-  uint32_t u = (uint32_t)v ^ 0x80000000u;
-  WG_DPP_REDUCE(uint32_t, dpp_mov, u, WG_OP_MAX, 0u);
-  return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
+  return (int32_t)(dpp_reduce32<OpMax>((uint32_t)v ^ 0x80000000u, 0u) ^ 0x80000000u);
 }
 #else
 __device__ __forceinline__ uint32_t wave_reduce_add32(uint32_t v) {
