@@ -17,6 +17,7 @@
 // whole cost of the first version of this engine (profiles/r01a_kernel_stats.md).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "engine.h"
 
 namespace wg {
@@ -50,6 +51,11 @@ namespace wg {
 // emulator, can bind the name to its own buffer)
 #ifndef WG_DYN_LDS
 #define WG_DYN_LDS(T, name) extern __shared__ T name[]
+#endif
+
+#ifndef WG_READLANE
+#define WG_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))  // wave-uniform result (an SGPR)
+#define WG_READFIRST(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #endif
 
 __device__ __forceinline__ void set_err(Globals* g, uint32_t bit) { atomicOr(&g->err, bit); }
@@ -141,14 +147,56 @@ __device__ __forceinline__ int32_t wave_reduce_max_i32(int32_t v) {
 }
 #endif
 __device__ __forceinline__ int wave_sum(int v) { return (int)wave_reduce_add32((uint32_t)v); }
+// the value lane `src` holds, src wave-uniform: v_readlane (an SGPR) instead of a ds_bpermute broadcast
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return WG_READLANE(v, src); }
+__device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src) {
+  return ((uint64_t)WG_READLANE((uint32_t)(v >> 32), src) << 32) | WG_READLANE((uint32_t)v, src);
+}
+// inclusive prefix sums over the 64 lanes: Hillis-Steele inside each row of 16 with row_shr (zero fill), then the row
+// totals carried over with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+#if defined(__HIPCC__) && !defined(WG_NO_DPP)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {  // lanes without a source read 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) {
+  v += dpp_mov0<0x111, 0xf>(v);
+  v += dpp_mov0<0x112, 0xf>(v);
+  v += dpp_mov0<0x114, 0xf>(v);
+  v += dpp_mov0<0x118, 0xf>(v);
+  v += dpp_mov<0x142, 0xa>(0u, v);
+  v += dpp_mov<0x143, 0xc>(0u, v);
+  return v;
+}
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
-#pragma unroll
+  auto mv0 = [](uint64_t x, auto tag) {
+    constexpr int C = decltype(tag)::value;
+    return ((uint64_t)dpp_mov0<C, 0xf>((uint32_t)(x >> 32)) << 32) | dpp_mov0<C, 0xf>((uint32_t)x);
+  };
+  v += mv0(v, std::integral_constant<int, 0x111>());
+  v += mv0(v, std::integral_constant<int, 0x112>());
+  v += mv0(v, std::integral_constant<int, 0x114>());
+  v += mv0(v, std::integral_constant<int, 0x118>());
+  v += dpp_mov64<0x142, 0xa>(0ull, v);
+  v += dpp_mov64<0x143, 0xc>(0ull, v);
+  return v;
+}
+#else
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) {
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t u = __shfl_up(v, o, 64);
+    if ((int)WG_LANE >= o) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
   for (int o = 1; o < 64; o <<= 1) {
     uint64_t u = shfl_up64(v, o);
     if ((int)WG_LANE >= o) v += u;
   }
   return v;
 }
+#endif
 __device__ __forceinline__ uint64_t lanes_lt() { return (1ULL << WG_LANE) - 1ULL; }
 
 __device__ __forceinline__ Rec* rec_ptr(const EngineDev& d, uint32_t bucket, uint32_t i) {
@@ -200,12 +248,7 @@ __device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t* sh) {
 
 // exclusive scan of one uint32 per thread over a 1024-thread block; *total = block sum
 __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t* sh16, uint32_t* total) {
-  uint32_t incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t u = __shfl_up(incl, o, 64);
-    if ((int)WG_LANE >= o) incl += u;
-  }
+  const uint32_t incl = wave_incl_scan32(v);
   int w = threadIdx.x >> 6;
   if (WG_LANE == 63) sh16[w] = incl;
   __syncthreads();
@@ -432,7 +475,7 @@ struct ExpandF {
       uint32_t base = 0;
       const int leader = __ffsll((unsigned long long)m) - 1;
       if ((int)WG_LANE == leader) base = atomicAdd(&d.g->nActive, (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
+      base = lane_bcast(base, leader);
       if (first) d.active[base + __popcll(m & lanes_lt())] = (uint32_t)firstNode;
     }
   }
@@ -472,7 +515,7 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         uint32_t base = 0;
         const int leader = __ffsll((unsigned long long)m) - 1;
         if ((int)lane == leader) base = atomicAdd(&d.g->nActive, (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
+        base = lane_bcast(base, leader);
         if (first) d.active[base + __popcll(m & lanes_lt())] = (uint32_t)to;
       }
     }
@@ -1371,7 +1414,7 @@ struct Ctx {
   __device__ uint32_t dest_reserve(int n) {
     unsigned long long off = 0;
     if (WG_LANE == 0) off = atomicAdd(d.sharded ? &d.g->localDestHead : &d.g->destHead, (unsigned long long)n);
-    off = shfl64(off, 0);
+    off = lane_bcast64(off, 0);
     return (uint32_t)(off % d.sdestCap);
   }
   __device__ void dest_put(uint32_t destOff, int j, int32_t id) {
@@ -1437,12 +1480,12 @@ struct Ctx {
   __device__ uint32_t alloc_payload(int words) {
     unsigned long long off = 0;
     if (WG_LANE == 0) off = atomicAdd(&d.g->payloadHead, (unsigned long long)words);
-    off = shfl64(off, 0);
+    off = lane_bcast64(off, 0);
     // keep an allocation contiguous: skip the tail of the ring if it does not fit
     unsigned long long pos = off % d.payloadWords;
     if (pos + words > d.payloadWords) {
       if (WG_LANE == 0) off = atomicAdd(&d.g->payloadHead, (unsigned long long)words);
-      off = shfl64(off, 0);
+      off = lane_bcast64(off, 0);
       pos = off % d.payloadWords;
       if (pos + words > d.payloadWords) {
         if (WG_LANE == 0) set_err(d.g, ERR_PAYLOAD);
@@ -1542,10 +1585,6 @@ struct HasPrefetch<P, decltype((void)&P::prefetch)> {
 __device__ __forceinline__ U4 load_desc_raw(const EngineDev& d, uint32_t a) {
   return ((const U4*)&d.activeB[a])[WG_LANE < 3 ? WG_LANE : 0];
 }
-#ifndef WG_READLANE
-#define WG_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))  // wave-uniform result (an SGPR)
-#define WG_READFIRST(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
-#endif
 __device__ __forceinline__ VisitDesc unpack_desc(const U4 q) {
   VisitDesc vd;
   vd.node = (int32_t)WG_READLANE(q.x, 0);
@@ -1593,7 +1632,7 @@ __device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename
     if (cur < 0) {
       mode = 1;
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < cnt; j++) rank += __shfl(mine, (int)j, 64) < mine;
+      for (uint32_t j = 0; j < cnt; j++) rank += lane_bcast(mine, (int)j) < mine;
       if ((uint32_t)lane < cnt) shSortW[rank] = mine;
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1799,7 +1838,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         uint32_t bb = 0;
         const int leader = __ffsll((unsigned long long)m) - 1;
         if (lane == leader) bb = atomicAdd(&d.g->nActiveB, (uint32_t)__popcll(m));
-        bb = __shfl(bb, leader, 64);
+        bb = lane_bcast(bb, leader);
         if (toB) d.activeB[bb + __popcll(m & lanes_lt())] = vd;
       }
     }
@@ -1853,7 +1892,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
       const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
       if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
-      totalWords += __shfl(incl, 63, 64);
+      totalWords += lane_bcast(incl, 63);
     }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i0 = 0; i0 < totalWords; i0 += 256) {

@@ -532,12 +532,7 @@ struct HandelProto {
     const int32_t node = c.node;
     // |totalOutgoing| of level l = sum of |totalIncoming| below l
     const int cti = lane < s.L ? ls->cTI[lane] : 0;
-    int incl = cti;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
+    const int incl = (int)wave_incl_scan32((uint32_t)cti);
     const int below = incl - cti;
     bool open = false, fin = false;
     int32_t cand = 0;
@@ -592,7 +587,7 @@ struct HandelProto {
       const int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
       KPROF_COUNT(c.d.g, 13);
       if (got <= 0) continue;
-      dest = __shfl(dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1, 64);
+      dest = (int32_t)lane_bcast((uint32_t)dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1);
       if (lane == l) cand = dest;
       sendM |= 1ULL << l;
     }
@@ -644,8 +639,8 @@ struct HandelProto {
     // only beyond the first 64 words of a wide level do they cost memory instructions of their own
     uint64_t viF, tiF;
     if (jF < 64) {
-      viF = shfl64(vi0, wF & 63);
-      tiF = shfl64(ti0, wF & 63);
+      viF = lane_bcast64(vi0, wF & 63);
+      tiF = lane_bcast64(ti0, wF & 63);
     } else {
       viF = ld_coherent(vi + wF);
       tiF = ld_coherent(ti + wF);
@@ -794,7 +789,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
       uint32_t base = 0;
       const int leader = __ffsll((unsigned long long)m) - 1;
       if ((int)WG_LANE == leader) base = atomicAdd(s.runCount, (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
+      base = lane_bcast(base, leader);
       if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
     }
   }
@@ -904,10 +899,10 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         const int maxScore = wave_reduce_max_i32(score), minRank = wave_reduce_min_i32(outside ? myRank : INT32_MAX);
         if (maxScore > 0) {
           const uint64_t mm = __ballot(inside && score == maxScore);
-          bestInside = __shfl(mySlot, __ffsll((unsigned long long)mm) - 1, 64);
+          bestInside = (int)lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)mm) - 1);
         }
         const uint64_t om = __ballot(outside && myRank == minRank);
-        if (om) bestOutside = __shfl(mySlot, __ffsll((unsigned long long)om) - 1, 64);
+        if (om) bestOutside = (int)lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)om) - 1);
         KPROF_MARK(d.g, 20);  // a single-word level
       } else {
       // blocks of up to 64 words (levels <= 13): the level's three row words of this lane are loaded once, not once
@@ -921,8 +916,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         lah = la[v.bw + jh];
       }
       for (int i = 0; i < len; i++) {
-        const int slot = __shfl(mySlot, i, 64);
-        const int rank = __shfl(myRank, i, 64);
+        const int slot = (int)lane_bcast((uint32_t)mySlot, i);
+        const int rank = (int)lane_bcast((uint32_t)myRank, i);
         const uint64_t* sig = HandelProto::sig_ptr(s, node, l, slot);
         uint64_t a = 0, b = 0;
         if (oneRound) {
@@ -977,7 +972,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         for (int k = 0; k < H_PEND; k++) held |= pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)mySlot);
         uint64_t rel = __ballot(mineDropped && !held);
         unsigned long long relMask = 0;
-        for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << __shfl(mySlot, __ffsll((unsigned long long)m) - 1, 64);
+        for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
         if (lane == 0) {
           ls_set_qused(ls, l, ls_qused(ls, l) & ~relMask);
           ls->qlen[l] = kept;
@@ -1119,7 +1114,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
     uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);
     while (todo) {
       const int leader = __ffsll((unsigned long long)todo) - 1;
-      const uint32_t key = __shfl(histKey, leader, 64);
+      const uint32_t key = lane_bcast(histKey, leader);
       const uint64_t m = __ballot(histKey == key) & todo;
       if ((int)WG_LANE == leader) atomicAdd(&d.tileHist[key], (uint32_t)__popcll(m));
       todo &= ~m;
