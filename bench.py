@@ -294,7 +294,10 @@ def main_shard(args):
             dt = time.perf_counter() - t0
         else:
             sims = None
-            g = w.Handel(hparams, seed=step, config=shards.config(dist, device=local))
+            # the engine's own RCCL communicator (wg_shard_configure_rccl): the unique id comes from rank 0's engine
+            # library and travels once over torch.distributed; --shard-callback keeps the caller-supplied collective
+            scfg = shards.config(dist, device=local) if args.shard_callback else shards.config_rccl(dist, device=local)
+            g = w.Handel(hparams, seed=step, config=scfg)
             g.init()
             g.network().profile(2)
             dist.barrier()
@@ -331,7 +334,7 @@ def main_shard(args):
                                    "period 20, fastPath 10, RANDOM nodes, NetworkLatencyByDistanceWJitter; ONE simulation "
                                    "per step, nodes split by id range over %d shard(s)%s, runMs(10) until Handel.newContIf is "
                                    "false" % (n, kl if kl else world, " on one GPU (in-process loopback all-reduce)" if kl else ""),
-                       "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure)", "shards": kl if kl else world,
+                       "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure%s)" % ("" if (kl or args.shard_callback) else "_rccl: engine-owned RCCL communicator"), "shards": kl if kl else world,
                        "allreduce_calls_per_simulation": traffic[0], "allreduce_int32_words_per_simulation": traffic[1]},
             "roofline": {"bound": "hbm", "kernel": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> on rank 0's node range",
                          "achieved": (alg_bytes / (kl if kl else world) / max(1, dk_spans)) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS,
@@ -371,6 +374,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="replicas = independent copies per GPU (default, weak scaling); shard = one simulation per "
                          "step, its nodes split by id range over the ranks (strong scaling)")
+    ap.add_argument("--shard-callback", action="store_true",
+                    help="--mode shard: the per-ms sums through the caller-supplied torch.distributed all-reduce "
+                         "(wg_allreduce_fn) instead of the engine's own RCCL communicator")
     ap.add_argument("--logical-shards", type=int, default=0,
                     help="--mode shard on ONE GPU: k engines in this process, each owning a node range; the all-reduce "
                          "sums their buffers in place (shards.LoopbackGroup). 0 = one shard per rank over RCCL")

@@ -51,6 +51,9 @@ typedef struct {
   int32_t shard, nshards;
   wg_allreduce_fn allreduce;
   void* allreduce_ctx;
+  /* ... or, with allreduce == NULL, the 128-byte RCCL unique id of wg_rccl_unique_id: the engine creates and owns the
+   * communicator (same effect as wg_shard_configure_rccl right after wg_create) */
+  const uint8_t* rccl_id;
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -283,6 +286,15 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
  * shard yet, batches, and host-callback mode. */
 int32_t wg_shard_configure(wg_engine* e, int32_t shard, int32_t nshards, wg_allreduce_fn allreduce, void* ctx);
+/* The same with the collective OWNED BY THE ENGINE: an RCCL communicator over the box's GPUs (xGMI), created from a
+ * unique id that shard 0's process obtains with wg_rccl_unique_id and hands to the other processes by whatever channel
+ * the host application has (the Java host: its own launcher; wittgenstein_amd/shards.py: one torch.distributed
+ * broadcast at start-up). The per-ms sums are then ncclAllReduce calls enqueued on the engine's own HIP stream — no
+ * callback into the caller, no host synchronisation per collective. librccl.so.1 of the ROCm installation libwittgpu.so
+ * was built against is loaded on first use (WG_EHIP if absent). Call before the engine allocates. */
+#define WG_RCCL_UNIQUE_ID_BYTES 128
+int32_t wg_rccl_unique_id(uint8_t* id128);
+int32_t wg_shard_configure_rccl(wg_engine* e, int32_t shard, int32_t nshards, const uint8_t* id128);
 /* [lo, hi) of this shard (valid once the nodes are added); collectives / int32 words exchanged so far */
 int32_t wg_shard_info(wg_engine* e, int32_t* lo, int32_t* hi, int64_t* collectives, int64_t* words);
 
@@ -326,6 +338,9 @@ typedef enum { /* Handel HLevel bitsets (P/Handel.java:373-394) as one nodeCount
 } wg_bits_field;
 int32_t wg_read_bits(wg_engine* e, int32_t field, uint64_t* dst, int32_t n_nodes, int32_t words_per_node);
 int32_t wg_levels(wg_engine* e, int32_t* levels);
+/* bytes of device memory the engine holds (every allocation of the engine and its resident protocol; a sharded
+ * engine: this shard's) — capacity planning for configurations that need several GPUs */
+int32_t wg_device_bytes(wg_engine* e, int64_t* bytes);
 /* per-level count of SendSigs delivered so far (roofline accounting); dst[32] */
 int32_t wg_delivered_by_level(wg_engine* e, int64_t* dst32);
 

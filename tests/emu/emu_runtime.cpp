@@ -335,6 +335,9 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;
 }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipMemGetInfo(size_t* freeB, size_t* totalB) {
   *freeB = *totalB = (size_t)32 << 30;
   return hipSuccess;

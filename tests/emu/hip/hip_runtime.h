@@ -44,6 +44,7 @@ struct dim3 {
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorInvalidValue = 1;
+constexpr hipError_t hipErrorNotReady = 600;
 typedef struct emuStream* hipStream_t;
 typedef struct emuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -71,6 +72,10 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipMemGetInfo(size_t* freeB, size_t* totalB);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipStreamQuery(hipStream_t s);
+inline void __threadfence_system() {}
 // stream capture / graphs: while a stream is capturing, launches and async memsets are recorded instead of executed;
 // hipGraphLaunch replays the record (what the engine's WG_GRAPH=1 path relies on)
 typedef struct emuGraph* hipGraph_t;

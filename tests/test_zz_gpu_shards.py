@@ -90,6 +90,40 @@ def leg6():
     # 6. at a size the oracle cannot reach inside a test: 4 logical shards == the unsharded engine, bit for bit
     bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
     out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
+def leg7():
+    # 7. BASELINE config 3's size (Handel 32 768 nodes, 10 % dead, seed 0) as 8 logical shards — what each GPU of config
+    # 4's box runs, one eighth of the rows each — against the ORACLE's golden trace of that run
+    # (tests/golden/handel_config3_32768.json): every per-node scalar, per-level scalar and bitset row, rd, clock.
+    import hashlib, time
+    from concurrent.futures import ThreadPoolExecutor
+    gold = json.load(open(os.path.join(%(root)r, "tests", "golden", "handel_config3_32768.json")))
+    n, thr, pair, lw, ec, per, fp, down, desync = gold["params"]
+    hp = w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync)
+    K = 8
+    grp = shards.LoopbackGroup(K, device_memory=True)
+    sims = [w.Handel(hp, seed=gold["seed"], config=grp.config(s)) for s in range(K)]
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=K) as ex:  # (init() is host work: ctypes releases the GIL)
+        list(ex.map(lambda g: g.init(), sims))
+    t_init = time.time() - t0
+    nets = [g.network() for g in sims]
+    delivered = 0
+    while True:  # C/RunMultipleTimes.java:50-64
+        did = grp.run(lambda s: nets[s].runMs(gold["chunk"]))[0]
+        delivered += nets[0].last_stats["delivered"]
+        if did and not any(g.cont_if() for g in sims):
+            break
+        if nets[0].time > 5000: break
+    dig = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    got = {"time": nets[0].time, "rng": nets[0].rng_state(), "delivered": delivered}
+    for f in parity.SCALARS: got[f] = dig(grp.gather([net.read(f) for net in nets], nets))
+    for f in parity.LEVELS: got[f] = dig(grp.gather([net.read_level(f) for net in nets], nets))
+    for f in parity.BITS: got[f] = dig(grp.gather([net.read_bits(f) for net in nets], nets))
+    bad = {k: (got.get(k), v) for k, v in gold["final"].items() if got.get(k) != v}
+    per_shard = [net.device_bytes() for net in nets]
+    out["config3_as_8_shards"] = {"bad": {k: [str(x) for x in v] for k, v in bad.items()}, "init_s": t_init,
+                                  "run_s": time.time() - t0 - t_init, "device_bytes_per_shard": per_shard,
+                                  "same_rng": len({net.rng_state() for net in nets}) == 1}
 import traceback
 out["errors"] = {}
 for _name, _fn in [(k, v) for k, v in sorted(globals().items()) if k.startswith('leg') and callable(v)]:
@@ -106,7 +140,7 @@ dist.destroy_process_group()
 def result(tmp_path_factory):
     script = tmp_path_factory.mktemp("shards") / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0]
     return json.loads(line[len("RESULT "):])
@@ -150,3 +184,29 @@ def test_four_logical_shards_equal_the_unsharded_engine_at_8192_nodes(result):
     assert "leg6" not in result["errors"], result["errors"]["leg6"]
     r = result["vs_unsharded_8192"]
     assert r["bad"] == [] and r["done"] == 8192 - 819 and r["delivered"] > 1000000, r
+
+
+def handel_shard_bytes_model(n, k, horizon=256, q=32):
+    """device bytes of one of k node-range shards of an n-node Handel simulation: what wittgenstein_amd/csrc/engine.hip
+    (ensure_device, HandelHost) allocates — per-node rows for the owned n/k nodes, the scheduler replicated"""
+    L = n.bit_length()          # levels 0..log2(n)
+    W = max(1, n // 64)
+    own = n // k
+    rows = own * (5 * W * 8 + n * 4 + (n - 1) * 4 + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * 64 * 8 + L * q * 4)
+    qsig = sum(own * q * (max(1, (1 << (l - 1)) // 64)) * 8 for l in range(1, L))
+    snap = (horizon // 20 + 2) * n * max(1, n // 128) * 8           # dissemination snapshots: replicated ring
+    maxout = 24 * n
+    sched = (max(1 << 20, 256 * n) + horizon * 1024) * 16 + maxout * (16 + 16 + 8 + 4 + 4 + 4 + 32 + 4 + 16 + 4) \
+        + 16 * n * 32 + 2 * max(1 << 20, 256 * n) * 4 + max(1 << 20, 2 * n * (W + L)) * 8 + maxout * 5 * 4 + maxout * 8
+    return rows + qsig + snap + sched + own * 8 * max(1, n // 128) * 2
+
+
+def test_config3_as_8_logical_shards_equals_the_oracle_trace(result):
+    assert "leg7" not in result["errors"], result["errors"]["leg7"]
+    r = result["config3_as_8_shards"]
+    assert r["bad"] == {} and r["same_rng"], r
+    # the capacity model reproduces what a shard of this run actually holds (within 10 %) ...
+    measured = max(r["device_bytes_per_shard"])
+    assert abs(handel_shard_bytes_model(32768, 8) - measured) < 0.10 * measured, (handel_shard_bytes_model(32768, 8), measured)
+    # ... and says that BASELINE config 4 (Handel 131 072 nodes over the 8 GPUs of one box) fits an MI355X per shard
+    assert handel_shard_bytes_model(131072, 8) < 0.92 * 288 * (1 << 30)

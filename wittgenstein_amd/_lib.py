@@ -15,7 +15,19 @@ class wg_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("horizon_ms", C.c_int32), ("bucket_pool_records", C.c_int64),
                 ("payload_words", C.c_int64), ("outbox_records", C.c_int64), ("chain_dests", C.c_int64),
                 ("chain_slots", C.c_int32), ("queue_cap", C.c_int32),
-                ("shard", C.c_int32), ("nshards", C.c_int32), ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p)]
+                ("shard", C.c_int32), ("nshards", C.c_int32), ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p),
+                ("rccl_id", C.c_void_p)]
+
+
+def make_config(cfg):
+    """wg_config from a dict of its fields; `rccl_id` may be the 128 bytes of shards.rccl_unique_id()"""
+    c = wg_config()
+    for k, v in (cfg or {}).items():
+        if k == "rccl_id" and isinstance(v, (bytes, bytearray)):
+            c._rccl_keep = (C.c_uint8 * 128).from_buffer_copy(bytes(v))  # must outlive the wg_create call
+            v = C.addressof(c._rccl_keep)
+        setattr(c, k, v)
+    return c
 
 
 # int32_t (*wg_allreduce_fn)(void* ctx, void* buf, int64_t count)
@@ -70,8 +82,8 @@ ABI_SYMBOLS = [
     "wg_set_latency_by_name", "wg_latency_probe", "wg_set_partitions", "wg_set_node_down", "wg_set_discard_time",
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_send_arrive_at", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
-    "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_delivered_by_level",
-    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_info", "wg_next_delivery", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
+    "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_device_bytes", "wg_delivered_by_level",
+    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_configure_rccl", "wg_rccl_unique_id", "wg_shard_info", "wg_next_delivery", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_batch_run_multiple_times", "wg_profile_enable", "wg_profile_read",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_gsf_create", "wgh_sanfermin_create", "wgh_casper_create", "wgh_p2pflood_create", "wgh_last_error", "wgh_last_init_seconds", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",

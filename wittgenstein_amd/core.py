@@ -85,9 +85,7 @@ class Network:
     @classmethod
     def create(cls, config=None):
         """new Network<>() (C/Network.java:14-49)."""
-        cfg = L.wg_config()
-        for k, v in (config or {}).items():
-            setattr(cfg, k, v)
+        cfg = L.make_config(config)
         h = C.c_void_p()
         rc = L.lib().wg_create(C.byref(cfg), C.byref(h))
         if rc != L.WG_OK:
@@ -214,6 +212,12 @@ class Network:
         out = np.zeros((n, w), np.uint64)
         self._ck(L.lib().wg_read_bits(self._h, BITS[field], _p(out, C.c_uint64), n, w))
         return out
+
+    def device_bytes(self):
+        """device memory held by the engine and its resident protocol (a sharded engine: this shard's)"""
+        v = C.c_int64()
+        self._ck(L.lib().wg_device_bytes(self._h, C.byref(v)))
+        return v.value
 
     def delivered_by_level(self):
         out = np.zeros(32, np.int64)

@@ -134,6 +134,20 @@ int32_t wg_shard_configure(wg_engine* h, int32_t shard, int32_t nshards, wg_allr
   WG_TRY(h) E.configure_shard(shard, nshards, fn, ctx);
   WG_END
 }
+int32_t wg_shard_configure_rccl(wg_engine* h, int32_t shard, int32_t nshards, const uint8_t* id128) {
+  WG_TRY(h) E.configure_shard_rccl(shard, nshards, id128);
+  WG_END
+}
+int32_t wg_rccl_unique_id(uint8_t* id128) {
+  if (!id128) return WG_EINVAL;
+  try {
+    wg::rccl_unique_id(id128);
+  } catch (const WgError& x) {
+    g_createError = x.what();
+    return x.code;
+  }
+  return WG_OK;
+}
 int32_t wg_shard_info(wg_engine* h, int32_t* lo, int32_t* hi, int64_t* collectives, int64_t* words) {
   WG_TRY(h)
   if (E.shardCount == 0) throw WgError(WG_ESTATE, "not a sharded engine");
@@ -174,6 +188,14 @@ int32_t wg_read_bits(wg_engine* h, int32_t field, uint64_t* dst, int32_t n_nodes
 }
 int32_t wg_levels(wg_engine* h, int32_t* levels) {
   WG_TRY(h)* levels = E.proto ? E.proto->levels() : 0;
+  WG_END
+}
+int32_t wg_device_bytes(wg_engine* h, int64_t* bytes) {
+  WG_TRY(h)
+  if (!bytes) throw WgError(WG_EINVAL, "bytes");
+  int64_t b = 0;
+  for (const auto& a : E.allocInfo) b += (int64_t)a.bytes;
+  *bytes = b + E.snapshot_bytes();
   WG_END
 }
 int32_t wg_delivered_by_level(wg_engine* h, int64_t* dst32) {

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <dlfcn.h>
 #include <type_traits>
 #include "engine_host.h"
 #include "engine_kernels.hip.h"
@@ -66,6 +67,63 @@ static uint32_t next_pow2(uint32_t v) {
   return p;
 }
 
+// ---- the engine's own RCCL communicator --------------------------------------------------------------------------
+// librccl is loaded at run time (dlopen), from the ROCm installation this library was built against first: the
+// collective must run on the HIP runtime that owns the engine's stream and buffers, and a host process may carry a
+// second RCCL (PyTorch bundles one). Only the five entry points used are bound; the types are RCCL's ABI
+// (rccl.h: ncclUniqueId = 128 opaque bytes, ncclInt32 = 2, ncclSum = 0, ncclSuccess = 0).
+namespace {
+struct NcclUniqueId {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl& rccl() {
+  static Rccl r;
+  if (r.lib || !r.err.empty()) return r;
+  std::vector<std::string> names;
+  if (const char* p = getenv("WG_RCCL_LIB")) names.push_back(p);
+  if (const char* p = getenv("ROCM_PATH")) names.push_back(std::string(p) + "/lib/librccl.so.1");
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  names.push_back("librccl.so.1");
+  for (const std::string& n : names) {
+    r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) {
+    r.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    return r;
+  }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.err = "librccl.so.1 lacks the nccl* entry points";
+  return r;
+}
+void rccl_check(int rc, const char* what) {
+  if (rc == 0) return;
+  Rccl& r = rccl();
+  throw WgError(WG_EHIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+void rccl_unique_id(uint8_t* id128) {
+  Rccl& r = rccl();
+  if (!r.err.empty()) throw WgError(WG_EHIP, r.err);
+  NcclUniqueId id;
+  rccl_check(r.GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(id128, id.internal, 128);
+}
+
 Engine::Engine(const wg_config& c) : cfg(c) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -75,11 +133,19 @@ Engine::Engine(const wg_config& c) : cfg(c) {
   WG_HIP(hipStreamCreate(&stream));
   gh.rng = lcg_scramble(0);  // new Random(0)  C/Network.java:32
   set_latency(WG_LAT_IC3, nullptr, 0);
-  if (cfg.nshards != 0) configure_shard(cfg.shard, cfg.nshards, cfg.allreduce, cfg.allreduce_ctx);
+  if (cfg.nshards != 0) {
+    if (!cfg.allreduce && cfg.rccl_id)
+      configure_shard_rccl(cfg.shard, cfg.nshards, cfg.rccl_id);
+    else
+      configure_shard(cfg.shard, cfg.nshards, cfg.allreduce, cfg.allreduce_ctx);
+    cfg.rccl_id = nullptr;  // (the caller's buffer is not kept)
+  }
 }
 
 Engine::~Engine() {
   delete proto;
+  if (rcclComm) (void)rccl().CommDestroy(rcclComm);
+  if (mailbox) (void)hipHostFree((void*)mailbox);
   if (snap) {
     if (snap->arena) (void)hipFree(snap->arena);
     delete snap;
@@ -1213,11 +1279,57 @@ void Engine::configure_shard(int32_t shard, int32_t nshards, wg_allreduce_fn fn,
   xctx = ctx;
 }
 
+void Engine::configure_shard_rccl(int32_t shard, int32_t nshards, const uint8_t* id128) {
+  if (nshards <= 0 || shard < 0 || shard >= nshards || !id128) throw WgError(WG_EINVAL, "shard / nshards / unique id");
+  if (allocated) throw WgError(WG_ESTATE, "wg_shard_configure_rccl must precede the first call that allocates the engine");
+  Rccl& r = rccl();
+  if (!r.err.empty()) throw WgError(WG_EHIP, r.err);
+  NcclUniqueId id;
+  memcpy(id.internal, id128, 128);
+  WG_HIP(hipSetDevice(cfg.device));
+  rccl_check(r.CommInitRank(&rcclComm, nshards, id, shard), "ncclCommInitRank");
+  shardIndex = shard;
+  shardCount = nshards;
+  xfn = nullptr;
+  xctx = nullptr;
+}
+
+// counts the host needs to size the next collective: published into pinned host memory in stream order, awaited by
+// polling (a few microseconds instead of a stream synchronisation and a blocking copy per count)
+__global__ void k_publish(const uint32_t* a, const uint32_t* b, Engine::Mailbox* mb, uint32_t seq) {
+  mb->v[0] = a ? *a : 0u;
+  mb->v[1] = b ? *b : 0u;
+  __threadfence_system();
+  mb->seq = seq;
+}
+void Engine::await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb) {
+  if (!mailbox) {
+    WG_HIP(hipHostMalloc((void**)&mailbox, sizeof(Mailbox), 0));
+    memset((void*)mailbox, 0, sizeof(Mailbox));
+  }
+  const uint32_t seq = ++mailSeq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, a, b, mailbox, seq);
+  uint64_t spins = 0;
+  while (mailbox->seq != seq) {
+    if ((++spins & 0xFFFFF) == 0) {  // a failed launch would never publish: ask the runtime now and then
+      const hipError_t q = hipStreamQuery(stream);
+      if (q != hipSuccess && q != hipErrorNotReady) WG_HIP(q);
+      if (q == hipSuccess && mailbox->seq != seq) throw WgError(WG_EHIP, "the count mailbox was not written");
+    }
+  }
+  if (va) *va = mailbox->v[0];
+  if (vb) *vb = mailbox->v[1];
+}
+
 void Engine::shard_allreduce(void* buf, int64_t count) {
   if (count <= 0) return;
-  WG_HIP(hipStreamSynchronize(stream));
-  const int32_t rc = xfn(xctx, buf, count);
-  if (rc != 0) throw WgError(WG_EHIP, "the shard all-reduce callback failed with " + std::to_string(rc));
+  if (rcclComm) {  // in stream order with the producers and consumers of `buf`: nothing to wait for on the host
+    rccl_check(rccl().AllReduce(buf, buf, (size_t)count, /*ncclInt32*/ 2, /*ncclSum*/ 0, rcclComm, stream), "ncclAllReduce");
+  } else {
+    WG_HIP(hipStreamSynchronize(stream));
+    const int32_t rc = xfn(xctx, buf, count);
+    if (rc != 0) throw WgError(WG_EHIP, "the shard all-reduce callback failed with " + std::to_string(rc));
+  }
   shardCollectives++;
   shardWords += count;
 }
@@ -1230,7 +1342,7 @@ void Engine::exchange_outbox(uint32_t nOut) {
   // the header word arrived with the records: how many of them are multi-destination envelopes still to be created
   // (the collective has synchronised; no further stream synchronisation is needed to read it)
   uint32_t nMulti = 0;
-  WG_HIP(hipMemcpy(&nMulti, dev.xbuf - XB_HEAD, 4, hipMemcpyDeviceToHost));
+  await_counts((const uint32_t*)(dev.xbuf - XB_HEAD), nullptr, &nMulti, nullptr);
   WG_HIP(hipMemsetAsync(dev.xbuf - XB_HEAD, 0, sizeof(int32_t) * XB_HEAD, stream));  // for the next phase's producers
   hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
   if (!nMulti) return;
@@ -1250,11 +1362,8 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   begin_run(ms, &endAt);
   Group g = self();
   auto t0 = std::chrono::steady_clock::now();
-  auto scratch = [&](uint32_t Globals::*field) {
-    uint32_t v = 0;
-    WG_HIP(hipStreamSynchronize(stream));
-    WG_HIP(hipMemcpy(&v, (const char*)dev.g + ((const char*)&(gh.*field) - (const char*)&gh), 4, hipMemcpyDeviceToHost));
-    return v;
+  auto gfield = [&](uint32_t Globals::*field) {
+    return (const uint32_t*)((const char*)dev.g + ((const char*)&(gh.*field) - (const char*)&gh));
   };
   for (int32_t k = 0; k <= ms; k++) {
     const int32_t t = time + k;
@@ -1268,15 +1377,13 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
       proto->launch_deliver(g);
     }
     uint32_t* dSnap = proto->shard_snap_enqueue(g);  // (numbers this ms's payload rows; its count is read with nEvents)
-    const uint32_t nEvents = scratch(&Globals::nEvents);
-    if (dSnap && nEvents) {
-      uint32_t nSnap = 0;
-      WG_HIP(hipMemcpy(&nSnap, dSnap, 4, hipMemcpyDeviceToHost));
-      if (nSnap) proto->shard_snap_exchange(*this, g, nSnap);
-    }
+    uint32_t nEvents = 0, nSnap = 0;
+    await_counts(gfield(&Globals::nEvents), dSnap, &nEvents, &nSnap);
+    if (dSnap && nEvents && nSnap) proto->shard_snap_exchange(*this, g, nSnap);
     shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
     scan<RecsF>(g, nullptr);
-    const uint32_t nOut = scratch(&Globals::nOut);
+    uint32_t nOut = 0;
+    await_counts(gfield(&Globals::nOut), nullptr, &nOut, nullptr);
     if (nOut) {
       hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
       exchange_outbox(nOut);
@@ -1958,8 +2065,7 @@ struct HandelHost : ProtoHost {
     e.shard_allreduce(st.candCnt, ((int64_t)st.N + 3) / 4);
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
-    WG_HIP(hipStreamSynchronize(g.stream));
-    WG_HIP(hipMemcpy(&nOut, (const char*)e.dev.g + offsetof(Globals, nOut), 4, hipMemcpyDeviceToHost));
+    e.await_counts((const uint32_t*)((const char*)e.dev.g + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
     hipLaunchKernelGGL(k_handel_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
     WG_HIP(hipMemsetAsync(st.candCnt, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' counts
     return nOut;
@@ -2247,8 +2353,7 @@ struct GsfHost : ProtoHost {
     e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
     Engine::scan<GsfCondF>(g, stab);
     uint32_t nOut = 0;
-    WG_HIP(hipStreamSynchronize(g.stream));
-    WG_HIP(hipMemcpy(&nOut, (const char*)e.dev.g + offsetof(Globals, nOut), 4, hipMemcpyDeviceToHost));
+    e.await_counts((const uint32_t*)((const char*)e.dev.g + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
     hipLaunchKernelGGL(k_gsf_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
     WG_HIP(hipMemsetAsync(st.candFlag, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' flags
     return nOut;

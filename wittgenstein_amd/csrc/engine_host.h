@@ -112,8 +112,20 @@ class Engine {
   void shard_allreduce(void* buf, int64_t count);
   void exchange_outbox(uint32_t nOut);
   int32_t shardIndex = 0, shardCount = 0;  // shardCount == 0: not sharded
-  wg_allreduce_fn xfn = nullptr;
+  wg_allreduce_fn xfn = nullptr;          // caller-supplied collective (tests: gloo / in-process loopback) ...
   void* xctx = nullptr;
+  void* rcclComm = nullptr;               // ... or the engine's own RCCL communicator (wg_shard_configure_rccl):
+                                          // ncclAllReduce enqueued on the engine's stream, no host round trip
+  void configure_shard_rccl(int32_t shard, int32_t nshards, const uint8_t* uniqueId128);
+  // per-phase counts the host needs to size the next collective, published by the device into pinned host memory
+  // (k_publish) and awaited by polling — not a stream synchronisation plus a copy per count
+  struct Mailbox {
+    volatile uint32_t seq;
+    uint32_t v[7];
+  };
+  Mailbox* mailbox = nullptr;             // pinned host memory (hipHostMalloc), device-visible
+  uint32_t mailSeq = 0;
+  void await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb);  // device words -> host
   long long shardCollectives = 0, shardWords = 0;  // all-reduce calls / int32 words summed so far
   int64_t queue_size();
   int64_t queue_size_at(int32_t t);
@@ -310,6 +322,8 @@ class Batch {
   std::vector<EngineDev> hTab;
   std::vector<char> hStab;
 };
+
+void rccl_unique_id(uint8_t* id128);  // ncclGetUniqueId of the dynamically loaded librccl
 
 ProtoHost* make_pingpong_host(Engine& e);
 ProtoHost* make_host_proto(Engine& e);

@@ -6,11 +6,7 @@ from . import _lib as L
 from .core import Network, _raise
 
 
-def _config(cfg):
-    c = L.wg_config()
-    for k, v in (cfg or {}).items():
-        setattr(c, k, v)
-    return c
+_config = L.make_config
 
 
 class PingPongParameters:

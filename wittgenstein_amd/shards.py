@@ -61,6 +61,33 @@ def config(dist, group=None, device_memory=True, **capacities):
     return cfg
 
 
+def rccl_unique_id():
+    """wg_rccl_unique_id: 128 opaque bytes from which every shard's engine builds the shared RCCL communicator; taken by
+    shard 0's process and handed to the others (here: one torch.distributed object broadcast)."""
+    buf = (C.c_uint8 * 128)()
+    rc = L.lib().wg_rccl_unique_id(buf)
+    if rc != L.WG_OK:
+        raise RuntimeError("wg_rccl_unique_id: %s" % L.lib().wg_last_error(None).decode())
+    return bytes(buf)
+
+
+def config_rccl(dist=None, rank=0, world=1, group=None, **capacities):
+    """wg_config fields for a shard whose per-ms sums travel over the ENGINE'S OWN RCCL communicator
+    (wg_shard_configure_rccl): no callback, no host synchronisation per collective. With a torch.distributed process
+    group the unique id is broadcast from rank 0; without one (`dist=None`) this is a single-process group of `world`
+    = 1 (tests, `bench.py --mode shard --gpus 1`)."""
+    if dist is not None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = box[0]
+    else:
+        uid = rccl_unique_id()
+    cfg = dict(capacities)
+    cfg.update(shard=rank, nshards=world, rccl_id=uid)
+    return cfg
+
+
 def shard_range(net):
     lo, hi = C.c_int32(), C.c_int32()
     net._ck(L.lib().wg_shard_info(net._h, C.byref(lo), C.byref(hi), None, None))
