@@ -41,6 +41,10 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# stdout carries exactly one JSON line: native libraries print there too (RCCL's version banner at the first
+# communicator), so file descriptor 1 points at stderr for the whole run and the line goes to a saved copy
+_REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
 
 
 def _oracle():
@@ -165,7 +169,7 @@ def cpu_baseline(n_sample, workload="handel"):
 
 
 def main_casper(args):
-    print(json.dumps(casper_line(args)), flush=True)
+    emit(casper_line(args))
 
 
 def casper_line(args):
@@ -344,8 +348,13 @@ def main_shard(args):
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes, "handel")
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.destroy_process_group()
+
+
+def emit(obj):
+    """the ONE JSON line, on the process's real stdout"""
+    os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
 
 
 def main():
@@ -609,7 +618,7 @@ def main():
             out["second_workload"] = casper_line(ca)
         except Exception as x:  # the Handel line stands on its own
             out["second_workload"] = {"error": "%s: %s" % (type(x).__name__, x)}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if world > 1:
         dist.destroy_process_group()
 

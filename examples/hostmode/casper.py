@@ -10,8 +10,8 @@ and method names follow the Java source so that it reads side by side with it. `
 blocksToReevaluate)` (:352-356) iterates a HashSet in identity-hash order, which the JDK leaves unspecified; like the
 oracle (oracle/casper.hpp) this iterates in ascending block id. ByzBlockProducerSF / NS (:583-633) are not mirrored
 (unused by init() and by every reference test)."""
-from .core import IllegalArgumentException, IllegalStateException
-from .hostnet import HostNetwork, Message, Node
+from wittgenstein_amd.core import IllegalArgumentException, IllegalStateException
+from wittgenstein_amd.hostnet import HostNetwork, Message, Node
 
 SLOT_DURATION = 8000  # :19
 

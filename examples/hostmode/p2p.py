@@ -4,8 +4,8 @@ host-callback mode: peer graphs are built on the host with the shared `rd` exact
 flood hop is one `MultipleDestWithDelayEnvelope` (C/Envelope.java:157-228: the peers, shuffled with rd, one every
 delayBetweenPeers ms) queued, ordered and latency-sampled by libwittgpu.so. Host-side Python stand-in for the Java
 classes (no JVM in the build image); names follow the Java source."""
-from .core import IllegalArgumentException
-from .hostnet import HostNetwork, Message, Node
+from wittgenstein_amd.core import IllegalArgumentException
+from wittgenstein_amd.hostnet import HostNetwork, Message, Node
 from .sanfermin import shuffle
 
 

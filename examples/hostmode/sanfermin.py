@@ -5,8 +5,8 @@ SanFerminHelper.pickNextNodes shuffles with, :144) live in libwittgpu.so on the 
 host objects as in the reference. Host-side Python stand-in for the Java classes (no JVM in the build image,
 INTEGRATION.md); class, field and method names follow the Java source. As in the reference, node counts must be powers
 of two (toBinaryID's padding throws otherwise, P/SanFerminHelper.java:158-171)."""
-from .core import IllegalArgumentException, IllegalStateException
-from .hostnet import HostNetwork, Message, Node
+from wittgenstein_amd.core import IllegalArgumentException, IllegalStateException
+from wittgenstein_amd.hostnet import HostNetwork, Message, Node
 
 OK, NO = 0, 1  # enum Status :520-523
 

@@ -79,6 +79,19 @@ typedef enum {
 } wg_latency_kind;
 /* Network.setNetworkLatency (C/Network.java:666-678): WG_ESTATE if messages are in flight. */
 int32_t wg_set_latency(wg_engine* e, int32_t kind, const int32_t* params, int32_t nparams);
+/* The city-based models (C/NetworkLatency.java:86-233). Their inputs are the caller's: Node.cityName as an index per
+ * node into the caller's own city list (city_of_node[node_count]; the nodes must have been added) and, for that list,
+ *   WG_CITY_AWS              tab[C*C] = latencies[min][max] / 2 both ways (:113-133), jitter[100] = gpd.inverseF(delta / 100.0)
+ *                            of NetworkLatencyByDistanceWJitter (:53-65); same region -> 1
+ *   WG_CITY_BY_CITY          tab[C*C] = max(1, Math.round(0.5f * ping)) with CSVLatencyReader's matrix (T/CSVLatencyReader.java:
+ *                            303-312: 30 inside a city, the to->from fallback of :187-197); ping, jitter unused (NULL)
+ *   WG_CITY_BY_CITY_WJITTER  ping[C*C] (float, both ways), jitter[100] (double) of GeneralizedParetoDistribution(1.4, -0.3, 0.35)
+ * — the FP of these models that depends on (from, to, delta) jointly (:228-231) is evaluated on the device in IEEE double,
+ * as the JVM does. Node.extraLatency, `from == to -> 1` and max(1, ...) are NetworkLatency.getLatency's (:27-34), as for
+ * every model. */
+typedef enum { WG_CITY_AWS = 0, WG_CITY_BY_CITY = 1, WG_CITY_BY_CITY_WJITTER = 2 } wg_city_latency_mode;
+int32_t wg_set_latency_city(wg_engine* e, int32_t mode, int32_t n_cities, const int32_t* city_of_node,
+                            const int32_t* tab, const float* ping, const double* jitter100);
 /* RegistryNetworkLatencies.getByName (C/RegistryNetworkLatencies.java:42-58); NULL = ByDistanceWJitter */
 int32_t wg_set_latency_by_name(wg_engine* e, const char* name);
 /* getLatency(from, to, delta) of the installed model, evaluated by the device kernel (tests, estimateLatency) */

@@ -38,6 +38,18 @@ int32_t wgh_casper_create(const wg_casper_params* params, const char* nodeBuilde
  * sendPeers per message from a random live node (P/P2PFlood.java:88-140, C/P2PNetwork.java:27-56,127-132) */
 int32_t wgh_p2pflood_create(const wg_p2pflood_params* params, const char* nodeBuilderName, const char* latencyName,
                             int64_t seed, const wg_config* cfg, wg_engine** out);
+/* City node builders and city latency models (C/RegistryNodeBuilders.java:44-58, C/NetworkLatency.java:86-233). The
+ * reference computes them from its resource files (cities.csv, the wondernetwork ping CSVs); here the caller hands the
+ * computed tables over once per process, and the creators above then accept the registry names "AWS_SPEED=..._TOR=..." /
+ * "CITIES_SPEED=..._TOR=..." and the registered latency names (e.g. "NetworkLatencyByCityWJitter"):
+ *   site "AWS" | "CITIES": NodeBuilderWithCity's citiesInfo in ITS entrySet() order (a java.util.HashMap: the order
+ *   decides which city a draw falls into, C/NodeBuilder.java:128-139) — cumulativeProbability, mercX, mercY per city,
+ *   and cities.size() of the list the builder was given. A node's city is its row in this table;
+ *   latency tables indexed by those rows: see wg_set_latency_city for the three modes. */
+int32_t wgh_register_city_builder(const char* site, int32_t n, const float* cumulativeProbability, const int32_t* mercX,
+                                  const int32_t* mercY, int32_t listSize);
+int32_t wgh_register_city_latency(const char* latencyName, int32_t mode, int32_t nCities, const int32_t* tab,
+                                  const float* ping, const double* jitter100);
 const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);

@@ -96,6 +96,95 @@ int orc_latency(const char* name, int32_t x1, int32_t y1, int32_t e1, int32_t x2
   *out = nl->getLatency(a, same ? a : b, delta);
   ORC_CATCH
 }
+// ---- city data, city node builders, city latency models (geo.hpp)
+// text: lines "D\t<dir>" (CSVLatencyReader's list, in order), "P\t<dir index>\t<other city>\t<average ms>",
+// "C\t<name>\t<Lat>\t<Long>\t<Population>" (cities.csv rows, in order) — tests/golden/city_data.json flattened
+int orc_city_data_load(const char* text) {
+  ORC_TRY CityData d;
+  std::string line;
+  auto fields = [](const std::string& l) {
+    std::vector<std::string> f;
+    size_t a = 0;
+    for (;;) {
+      size_t b = l.find('\t', a);
+      f.push_back(l.substr(a, b == std::string::npos ? std::string::npos : b - a));
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+    return f;
+  };
+  for (const char* p = text;; p++) {
+    if (*p == '\n' || *p == 0) {
+      if (!line.empty()) {
+        auto f = fields(line);
+        if (f[0] == "D" && f.size() == 2) {
+          d.dirs.push_back(f[1]);
+          d.ping.emplace_back();
+        } else if (f[0] == "P" && f.size() == 4) {
+          d.ping.at((size_t)atoi(f[1].c_str()))[f[2]] = f[3];
+        } else if (f[0] == "C" && f.size() == 5) {
+          d.cityRows.push_back({f[1], f[2], f[3], f[4]});
+        } else {
+          throw IllegalArgumentException("bad city data line: " + line);
+        }
+      }
+      line.clear();
+      if (*p == 0) break;
+    } else {
+      line.push_back(*p);
+    }
+  }
+  cityData() = d;
+  ORC_CATCH
+}
+// the table a NodeBuilderWithCity works from, in its citiesInfo.entrySet() order: kind 0 = AWS, 1 = CITIES.
+// names: '\n'-joined into buf (cap bytes); returns the count in *n, cities.size() of the builder's LIST in *listSize
+int orc_city_builder_table(int32_t kind, int32_t cap, char* buf, int32_t* mercX, int32_t* mercY, float* cum, int32_t* n,
+                           int32_t* listSize) {
+  ORC_TRY std::unique_ptr<NodeBuilder> nb = nodeBuilderByName(kind == 0 ? "AWS_SPEED=CONSTANT_TOR=0.00" : "CITIES_SPEED=CONSTANT_TOR=0.00");
+  const CityChooser& c = static_cast<NodeBuilderWithCity*>(nb.get())->chooser;
+  std::string names;
+  for (size_t i = 0; i < c.name.size(); i++) {
+    names += c.name[i];
+    names += '\n';
+    mercX[i] = c.info[i].mercX;
+    mercY[i] = c.info[i].mercY;
+    cum[i] = c.info[i].cumulativeProbability;
+  }
+  if ((int32_t)names.size() + 1 > cap) throw IllegalArgumentException("buffer too small");
+  memcpy(buf, names.c_str(), names.size() + 1);
+  *n = (int32_t)c.name.size();
+  *listSize = c.listSize;
+  ORC_CATCH
+}
+int orc_city_choose(int32_t kind, int32_t rdInt, int32_t* idx) {
+  ORC_TRY static std::unique_ptr<NodeBuilder> nbs[2];
+  if (!nbs[kind & 1]) nbs[kind & 1] = nodeBuilderByName(kind == 0 ? "AWS_SPEED=CONSTANT_TOR=0.00" : "CITIES_SPEED=CONSTANT_TOR=0.00");
+  *idx = static_cast<NodeBuilderWithCity*>(nbs[kind & 1].get())->chooser.choose(rdInt);
+  ORC_CATCH
+}
+// NetworkLatency.getLatency(from, to, delta) of a named model between nodes placed in two named cities
+struct OrcLatencyModel {
+  std::unique_ptr<NetworkLatency> nl;
+};
+int orc_latency_model_create(const char* name, void** out) {
+  ORC_TRY* out = new OrcLatencyModel{networkLatencyByName(name)};
+  ORC_CATCH
+}
+void orc_latency_model_destroy(void* h) { delete (OrcLatencyModel*)h; }
+int orc_latency_model_city(void* h, const char* cityFrom, const char* cityTo, int32_t e1, int32_t e2, int32_t same,
+                           int32_t delta, int32_t* out) {
+  ORC_TRY JRandom rd(0);
+  ProbeNB nb;
+  nb.px = nb.py = 1;
+  Node a(rd, nb), b(rd, nb);
+  a.cityName = cityFrom;
+  b.cityName = cityTo;
+  a.extraLatency = e1;
+  b.extraLatency = e2;
+  *out = ((OrcLatencyModel*)h)->nl->getLatency(a, same ? a : b, delta);
+  ORC_CATCH
+}
 int orc_node_xy(int32_t rdInt, int32_t* x, int32_t* y) {
   NodeBuilderWithRandomPosition nb;
   *x = nb.getX(rdInt);

@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include "jdk.hpp"
+#include "geo.hpp"
 
 namespace orc {
 
@@ -43,6 +44,7 @@ struct GeneralizedParetoDistribution {  // C/utils/GeneralizedParetoDistribution
 // ---------------------------------------------------------------- NodeBuilder
 struct NodeBuilder {  // C/NodeBuilder.java:19-75
   int nodeIds = 0;
+  virtual std::string getCityName(jint) { return "world"; }  // Node.DEFAULT_CITY (C/Node.java:20, C/NodeBuilder.java:64-66)
   // aspects (C/Node.java:145-243): only the two the RANDOM registry entries can add
   bool speedUniform = false;  // SpeedRatioAspect(UniformSpeed)  (C/RegistryNodeBuilders.java:59-61)
   double torRatio = 0.0;      // ExtraLatencyAspect(tor) when tor > 0.001 (:62-64)
@@ -65,13 +67,38 @@ struct NodeBuilderWithRandomPosition : NodeBuilder {  // C/NodeBuilder.java:77-9
   }
 };
 
-// RegistryNodeBuilders.getByName for the RANDOM location entries (C/RegistryNodeBuilders.java:28-81).
-// Names look like "RANDOM_SPEED=CONSTANT_TOR=0.00". Null/empty -> RANDOM, constant, tor 0.
+struct NodeBuilderWithCity : NodeBuilder {  // C/NodeBuilder.java:98-147 (oracle/geo.hpp)
+  CityChooser chooser;
+  NodeBuilderWithCity(const std::vector<std::string>& cities, const JHashMap<CityInfo>& geo) : chooser(cities, geo) {}
+  int city(jint rdInt) const {
+    const int c = chooser.choose(rdInt);
+    if (c < 0) throw IllegalStateException("NullPointerException: no city for this draw (C/NodeBuilder.java:121-124)");
+    return c;
+  }
+  std::string getCityName(jint rdInt) override { return chooser.name[city(rdInt)]; }
+  int getX(jint rdInt) override { return chooser.info[city(rdInt)].mercX; }
+  int getY(jint rdInt) override { return chooser.info[city(rdInt)].mercY; }
+};
+
+inline std::vector<std::string> awsCitiesSorted() {  // AwsRegionNetworkLatency.cities() (C/NetworkLatency.java:104-109)
+  std::vector<std::string> c = awsRegions();
+  std::sort(c.begin(), c.end());
+  return c;
+}
+
+// RegistryNodeBuilders.getByName (C/RegistryNodeBuilders.java:28-81).
+// Names look like "RANDOM_SPEED=CONSTANT_TOR=0.00" (also AWS_..., CITIES_...). Null/empty -> RANDOM, constant, tor 0.
 inline std::unique_ptr<NodeBuilder> nodeBuilderByName(const std::string& name) {
-  auto nb = std::make_unique<NodeBuilderWithRandomPosition>();
+  std::unique_ptr<NodeBuilder> nb;
+  if (name.rfind("AWS_SPEED=", 0) == 0)
+    nb = std::make_unique<NodeBuilderWithCity>(awsCitiesSorted(), geoAwsPosition());
+  else if (name.rfind("CITIES_SPEED=", 0) == 0)
+    nb = std::make_unique<NodeBuilderWithCity>(CSVLatencyReader().cities(), geoAllCitiesPosition());
+  else
+    nb = std::make_unique<NodeBuilderWithRandomPosition>();
   if (name.empty()) return nb;
-  if (name.rfind("RANDOM_SPEED=", 0) != 0)
-    throw IllegalArgumentException(name + " not in the oracle's registry (RANDOM builders only)");
+  if (name.rfind("RANDOM_SPEED=", 0) != 0 && name.rfind("AWS_SPEED=", 0) != 0 && name.rfind("CITIES_SPEED=", 0) != 0)
+    throw IllegalArgumentException(name + " not in the registry");
   nb->speedUniform = name.find("SPEED=GAUSSIAN") != std::string::npos;
   size_t p = name.find("_TOR=");
   if (p == std::string::npos) throw IllegalArgumentException(name);
@@ -89,6 +116,7 @@ class Node {  // C/Node.java
   }
   int nodeId;
   int x, y;
+  std::string cityName;
   int extraLatency = 0;
   bool byzantine;
   double speedRatio = 1.0;
@@ -99,6 +127,7 @@ class Node {  // C/Node.java
   Node(JRandom& rd, NodeBuilder& nb, bool byz = false) : byzantine(byz) {  // :246-271
     nodeId = nb.allocateNodeId();
     jint rdNode = rd.nextInt();
+    cityName = nb.getCityName(rdNode);
     x = nb.getX(rdNode);
     y = nb.getY(rdNode);
     if (x <= 0 || x > MAX_X) throw IllegalArgumentException("bad x");
@@ -219,8 +248,68 @@ struct IC3NetworkLatency : NetworkLatency {  // :399-417
   }
 };
 
+struct AwsRegionNetworkLatency : NetworkLatency {  // C/NetworkLatency.java:86-157
+  NetworkLatencyByDistanceWJitter var;
+  static int region(const std::string& city) {
+    const auto& r = awsRegions();
+    for (size_t i = 0; i < r.size(); i++)
+      if (r[i] == city) return (int)i;
+    return -1;
+  }
+  static int ping(int a, int b) {  // :113-133 (upper triangle; that's ping time)
+    static const int L[10][11] = {{0, 81, 216, 126, 165, 138, 97, 64, 164, 131, 141}, {0, 0, 182, 181, 232, 195, 167, 13, 88, 80, 75},
+                                  {0, 0, 0, 152, 62, 223, 123, 194, 111, 122, 113},  {0, 0, 0, 0, 97, 133, 35, 184, 259, 254, 264},
+                                  {0, 0, 0, 0, 0, 169, 69, 218, 162, 174, 171},      {0, 0, 0, 0, 0, 0, 105, 210, 282, 269, 271},
+                                  {0, 0, 0, 0, 0, 0, 0, 156, 235, 222, 234},         {0, 0, 0, 0, 0, 0, 0, 0, 101, 78, 87},
+                                  {0, 0, 0, 0, 0, 0, 0, 0, 0, 24, 13},               {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 12}};
+    return L[a][b];
+  }
+  int getExtendedLatency(const Node& from, const Node& to, int delta) const override {
+    const int reg1 = region(from.cityName), reg2 = region(to.cityName);
+    if (reg1 < 0 || reg2 < 0) throw IllegalArgumentException("not in our aws cities list");
+    if (reg1 == reg2) return 1;
+    const int minReg = std::min(reg1, reg2), maxReg = std::max(reg1, reg2);
+    return std::max(1, ping(minReg, maxReg) / 2 + (int)var.getJitter(delta));
+  }
+};
+
+struct NetworkLatencyByCity : NetworkLatency {  // C/NetworkLatency.java:159-198
+  CSVLatencyReader reader;
+  float cityLatency(const std::string& cityFrom, const std::string& cityTo) const {  // getLatency(String, String) :187-197
+    const JHashMap<float>* from = reader.latencyMatrix.get(cityFrom);
+    if (!from) throw IllegalArgumentException("Can't find latencies for " + cityFrom);
+    const float* res = from->get(cityTo);
+    if (!res) res = reader.latencyMatrix.get(cityTo)->get(cityFrom);
+    return *res;
+  }
+  int getExtendedLatency(const Node& from, const Node& to, int) const override {
+    if (from.nodeId == to.nodeId) return 1;
+    if (from.cityName == "world" || to.cityName == "world")
+      throw IllegalStateException("Can't use NetworkLatencyByCity model with default city location");
+    return std::max(1, jround_f(0.5f * cityLatency(from.cityName, to.cityName)));
+  }
+};
+
+struct NetworkLatencyByCityWJitter : NetworkLatencyByCity {  // C/NetworkLatency.java:200-233
+  GeneralizedParetoDistribution gpd{1.4, -0.3, 0.35};
+  int getExtendedLatency(const Node& from, const Node& to, int delta) const override {
+    if (from.nodeId == to.nodeId) return 1;
+    if (from.cityName == "world" || to.cityName == "world")
+      throw IllegalStateException("Can't use NetworkLatencyByCity model with default city location");
+    double raw = gpd.inverseF(delta / 100.0);
+    if (from.cityName == to.cityName)
+      raw += 10;
+    else
+      raw += cityLatency(from.cityName, to.cityName);
+    return std::max(1, (int)jround(0.5 * raw));
+  }
+};
+
 // RegistryNetworkLatencies.getByName (C/RegistryNetworkLatencies.java:26-58)
 inline std::unique_ptr<NetworkLatency> networkLatencyByName(const std::string& name) {
+  if (name == "AwsRegionNetworkLatency") return std::make_unique<AwsRegionNetworkLatency>();
+  if (name == "NetworkLatencyByCity") return std::make_unique<NetworkLatencyByCity>();
+  if (name == "NetworkLatencyByCityWJitter") return std::make_unique<NetworkLatencyByCityWJitter>();
   if (name.empty() || name == "NetworkLatencyByDistanceWJitter")
     return std::make_unique<NetworkLatencyByDistanceWJitter>();
   if (name.rfind("NetworkFixedLatency(", 0) == 0)

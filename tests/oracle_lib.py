@@ -421,3 +421,63 @@ class P2PFlood:
         t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
         lib().orc_p2pflood_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
+# ---- city topology / latency (oracle/geo.hpp): data from tests/golden/city_data.json
+_CITY_LOADED = False
+
+
+def load_city_data(path=None):
+    global _CITY_LOADED
+    if _CITY_LOADED:
+        return
+    import json
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "city_data.json")
+    d = json.load(open(path))
+    lines = ["D\t%s" % c for c in d["dirs"]]
+    for i, m in enumerate(d["ping"]):
+        lines += ["P\t%d\t%s\t%s" % (i, k, v) for k, v in m.items()]
+    lines += ["C\t%s\t%s\t%s\t%s" % tuple(r) for r in d["cities"]]
+    _ck(lib().orc_city_data_load("\n".join(lines).encode()))
+    _CITY_LOADED = True
+
+
+def city_builder_table(kind):
+    """NodeBuilderWithCity's citiesInfo in entrySet() order: kind "AWS" | "CITIES" -> (names, mercX, mercY, cumulative
+    probability (float32), size of the city LIST the builder was given)"""
+    load_city_data()
+    cap = 1 << 16
+    buf = C.create_string_buffer(cap)
+    x, y, cum = np.zeros(512, np.int32), np.zeros(512, np.int32), np.zeros(512, np.float32)
+    n, ls = C.c_int32(), C.c_int32()
+    _ck(lib().orc_city_builder_table(0 if kind == "AWS" else 1, cap, buf, _p(x, C.c_int32), _p(y, C.c_int32),
+                                     _p(cum, C.c_float), C.byref(n), C.byref(ls)))
+    names = buf.value.decode().split("\n")[:n.value]
+    return names, x[:n.value].copy(), y[:n.value].copy(), cum[:n.value].copy(), ls.value
+
+
+def city_choose(kind, rd_int):
+    load_city_data()
+    idx = C.c_int32()
+    _ck(lib().orc_city_choose(0 if kind == "AWS" else 1, C.c_int32(rd_int), C.byref(idx)))
+    return idx.value
+
+
+class LatencyModel:
+    """a named NetworkLatency of the registry (C/RegistryNetworkLatencies.java), probed between two cities"""
+
+    def __init__(self, name):
+        load_city_data()
+        self.h = C.c_void_p()
+        _ck(lib().orc_latency_model_create(name.encode(), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_latency_model_destroy(self.h)
+            self.h = None
+
+    def city(self, city_from, city_to, delta, same=False, e1=0, e2=0):
+        out = C.c_int32()
+        _ck(lib().orc_latency_model_city(self.h, city_from.encode(), city_to.encode(), e1, e2, int(same), delta,
+                                         C.byref(out)))
+        return out.value

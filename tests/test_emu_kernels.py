@@ -43,6 +43,7 @@ import test_zw_gpu_sanfermin as tsf  # noqa: E402
 import test_zy_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 import test_gpu_snapshot as tsn  # noqa: E402
+import test_gpu_city as tcy  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -201,3 +202,11 @@ def test_p2pflood_resident():  # P/P2PFlood.java resident on the device vs oracl
                                   "test_batch_restore_and_run_multiple_times_again", "test_pingpong_and_gsf_restore"])
 def test_snapshot_restore(name):  # wg_snapshot / wg_restore: the init() image
     getattr(tsn, name)()
+
+
+def test_city_latency_models_and_builders():  # C/NetworkLatency.java:86-233, C/NodeBuilder.java:98-147 on the engine
+    for m in ["AwsRegionNetworkLatency", "NetworkLatencyByCity", "NetworkLatencyByCityWJitter"]:
+        tcy.test_city_latency_probe_matches_the_oracle(m)
+    tcy.test_pingpong_on_city_nodes("CITIES_SPEED=CONSTANT_TOR=0.00", "NetworkLatencyByCityWJitter")
+    tcy.test_pingpong_on_city_nodes("AWS_SPEED=CONSTANT_TOR=0.00", "AwsRegionNetworkLatency")
+    tcy.test_city_latency_needs_city_nodes()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from wittgenstein_amd import casper
+from examples.hostmode import casper
 
 FIELDS = {
     "msgReceived": lambda n: n.msgReceived, "msgSent": lambda n: n.msgSent, "bytesSent": lambda n: n.bytesSent,

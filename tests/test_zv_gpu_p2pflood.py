@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from wittgenstein_amd import p2p
+from examples.hostmode import p2p
 
 GET = {"msgReceived": lambda n: n.msgReceived, "msgSent": lambda n: n.msgSent, "bytesSent": lambda n: n.bytesSent,
        "bytesReceived": lambda n: n.bytesReceived, "doneAt": lambda n: n.doneAt, "down": lambda n: int(n.down),

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from wittgenstein_amd import sanfermin as sf
+from examples.hostmode import sanfermin as sf
 
 GET = {"msgReceived": lambda n: n.msgReceived, "msgSent": lambda n: n.msgSent, "bytesSent": lambda n: n.bytesSent,
        "bytesReceived": lambda n: n.bytesReceived, "aggValue": lambda n: n.aggValue,

@@ -91,7 +91,7 @@ def leg6():
     bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
     out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
 def leg7():
-    # 7. BASELINE config 3's size (Handel 32 768 nodes, 10 % dead, seed 0) as 8 logical shards — what each GPU of config
+    # 7. BASELINE config 3's size (Handel 32 768 nodes, 10 percent dead, seed 0) as 8 logical shards — what each GPU of config
     # 4's box runs, one eighth of the rows each — against the ORACLE's golden trace of that run
     # (tests/golden/handel_config3_32768.json): every per-node scalar, per-level scalar and bitset row, rd, clock.
     import hashlib, time

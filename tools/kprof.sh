@@ -4,7 +4,7 @@
 # counters are those of the batch's FIRST member (s_memtime units, summed over its wavefronts).
 OUT=gpurun_out/${1:-kprof}; mkdir -p $OUT
 bash wittgenstein_amd/csrc/build.sh -DWG_KPROF -o $(pwd)/wittgenstein_amd/libwittgpu_kprof.so 2>&1 | grep -E "error"
-WG_LIB=$(pwd)/wittgenstein_amd/libwittgpu_kprof.so python - <<'PY' | tee $OUT/kprof.txt
+WG_LIB=$(pwd)/wittgenstein_amd/libwittgpu_kprof.so python - <<'PY' 2>&1 | tee $OUT/kprof.txt
 import sys, os
 sys.path.insert(0, os.getcwd())
 import bench, wittgenstein_amd as w

@@ -112,6 +112,19 @@ class Network:
         arr = np.ascontiguousarray(longDistrib, np.int32)
         self._ck(L.lib().wg_set_latency(self._h, 4, _p(arr, C.c_int32), len(arr)))
 
+    def setCityLatency(self, mode, city_of_node, tab=None, ping=None, jitter=None):
+        """wg_set_latency_city: AwsRegionNetworkLatency (mode 0), NetworkLatencyByCity (1), NetworkLatencyByCityWJitter (2)
+        over the caller's city list — the tables of wittgenstein_amd.geo (C/NetworkLatency.java:86-233)."""
+        c = np.ascontiguousarray(city_of_node, np.int32)
+        nc = (np.asarray(tab if tab is not None else ping)).shape[0]
+        t = None if tab is None else np.ascontiguousarray(tab, np.int32)
+        pg = None if ping is None else np.ascontiguousarray(ping, np.float32)
+        j = None if jitter is None else np.ascontiguousarray(jitter, np.float64)
+        self._ck(L.lib().wg_set_latency_city(self._h, int(mode), int(nc), _p(c, C.c_int32),
+                                             None if t is None else _p(t, C.c_int32),
+                                             None if pg is None else _p(pg, C.c_float),
+                                             None if j is None else _p(j, C.c_double)))
+
     def setMsgDiscardTime(self, ms):
         self._ck(L.lib().wg_set_discard_time(self._h, int(ms)))
 

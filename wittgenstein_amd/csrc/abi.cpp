@@ -68,6 +68,11 @@ int32_t wg_set_latency(wg_engine* h, int32_t kind, const int32_t* params, int32_
   WG_TRY(h) E.set_latency(kind, params, nparams);
   WG_END
 }
+int32_t wg_set_latency_city(wg_engine* h, int32_t mode, int32_t n_cities, const int32_t* city_of_node, const int32_t* tab,
+                            const float* ping, const double* jitter100) {
+  WG_TRY(h) E.set_latency_city(mode, n_cities, city_of_node, tab, ping, jitter100);
+  WG_END
+}
 int32_t wg_set_latency_by_name(wg_engine* h, const char* name) {
   WG_TRY(h) E.set_latency_by_name(name);
   WG_END

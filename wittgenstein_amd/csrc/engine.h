@@ -124,7 +124,7 @@ constexpr uint32_t EV_NREC_MASK = 0xFFFFu;
 constexpr uint32_t EV_DELIVERED = 1u << 16;  // counted in msgReceived (C/Network.java:607-613)
 constexpr uint32_t EV_TASK_RUN = 1u << 17;
 
-enum LatKind : int32_t { LAT_BYDIST = 0, LAT_FIXED = 1, LAT_UNIFORM = 2, LAT_NONE = 3, LAT_MEASURED = 4, LAT_IC3 = 5, LAT_ETHSCAN = 6 };
+enum LatKind : int32_t { LAT_BYDIST = 0, LAT_FIXED = 1, LAT_UNIFORM = 2, LAT_NONE = 3, LAT_MEASURED = 4, LAT_IC3 = 5, LAT_ETHSCAN = 6, LAT_CITY = 7 };
 
 enum ErrBits : uint32_t {
   ERR_BUCKET_POOL = 1u << 0,   // out of bucket pages
@@ -190,6 +190,12 @@ struct LatencyModel {
   const uint8_t* lutDist;   // BYDIST: [1145][100]
   const int32_t* tabDelta;  // MEASURED/ETHSCAN/UNIFORM: [100]
   const int32_t* tabDist;   // IC3: [1145]
+  // LAT_CITY — the city-based models (C/NetworkLatency.java:86-233); param = wg_city_latency_mode, C = nCities:
+  const uint16_t* city;     // [n] the node's city (Node.cityName as an index into the caller's city list)
+  const int32_t* cityTab;   // [C][C] AWS: ping / 2; BY_CITY: max(1, round(0.5f * ping)), the whole answer
+  const float* cityPing;    // [C][C] BY_CITY_WJITTER: the measured round trip (float, as CSVLatencyReader parsed it)
+  const double* cityJit;    // [100]  AWS / BY_CITY_WJITTER: gpd.inverseF(delta / 100.0)
+  int32_t nCities;
 };
 
 struct NodeArrays {
@@ -354,6 +360,22 @@ WG_HD inline int32_t latency_of(const LatencyModel& m, int32_t from, int32_t to,
     case LAT_UNIFORM:
     case LAT_MEASURED: ext = m.tabDelta[delta]; break;
     case LAT_IC3: ext = m.tabDist[node_dist(x1, y1, x2, y2)]; break;
+    case LAT_CITY: {
+      const int32_t c1 = m.city[from], c2 = m.city[to];
+      if (m.param == 0) {  // AwsRegionNetworkLatency.getLatency :135-145: same datacenter 1, else ping / 2 + (int) jitter
+        ext = c1 == c2 ? 1 : m.cityTab[c1 * m.nCities + c2] + (int32_t)m.cityJit[delta];
+        if (ext < 1) ext = 1;
+      } else if (m.param == 1) {  // NetworkLatencyByCity :168-185 (the table holds max(1, Math.round(0.5f * ping)))
+        ext = m.cityTab[c1 * m.nCities + c2];
+      } else {  // NetworkLatencyByCityWJitter :212-232: max(1, (int) Math.round(0.5 * (jitter + (same city ? 10 : ping))))
+        const double raw = m.cityJit[delta] + (c1 == c2 ? 10.0 : (double)m.cityPing[c1 * m.nCities + c2]);
+        const double h = 0.5 * raw + 0.5;  // Math.round(double) = floor(x + 1/2)
+        long long r = (long long)h;
+        if ((double)r > h) r--;
+        ext = r < 1 ? 1 : (int32_t)r;
+      }
+      break;
+    }
     default: {  // LAT_ETHSCAN delegates to an inner MeasuredNetworkLatency.getLatency (:366-384)
       int32_t inner = base + m.tabDelta[delta];
       ext = inner > 1 ? inner : 1;

@@ -154,6 +154,8 @@ Engine::~Engine() {
   if (dLut) (void)hipFree(dLut);
   if (dTabDelta) (void)hipFree(dTabDelta);
   if (dTabDist) (void)hipFree(dTabDist);
+  for (void* p : {dCity, dCityTab, dCityPing, dCityJit})
+    if (p) (void)hipFree(p);
   for (auto& sp : profSpans) {
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);
@@ -287,6 +289,35 @@ void Engine::set_latency(int32_t kind, const int32_t* params, int32_t nparams) {
   }
 }
 
+void Engine::set_latency_city(int32_t mode, int32_t nC, const int32_t* cityOfNode, const int32_t* tab, const float* ping,
+                              const double* jit) {
+  if (queue_size() != 0) throw WgError(WG_ESTATE, "You can't change the latency while the system as on going messages");
+  const size_t n = hx.size();
+  if (mode < 0 || mode > 2 || nC <= 0 || nC > 65535 || !cityOfNode || n == 0)
+    throw WgError(WG_EINVAL, "wg_set_latency_city: mode / n_cities / city_of_node (add the nodes first)");
+  if ((mode != WG_CITY_BY_CITY_WJITTER && !tab) || (mode == WG_CITY_BY_CITY_WJITTER && !ping) || (mode != WG_CITY_BY_CITY && !jit))
+    throw WgError(WG_EINVAL, "wg_set_latency_city: a table this mode needs is NULL");
+  cityOf.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    if (cityOfNode[i] < 0 || cityOfNode[i] >= nC) throw WgError(WG_EINVAL, "wg_set_latency_city: city index out of range");
+    cityOf[i] = (uint16_t)cityOfNode[i];
+  }
+  const size_t cc = (size_t)nC * nC;
+  cityTab.assign(tab ? tab : nullptr, tab ? tab + cc : nullptr);
+  cityPing.assign(ping ? ping : nullptr, ping ? ping + cc : nullptr);
+  cityJit.assign(jit ? jit : nullptr, jit ? jit + 100 : nullptr);
+  nCities = nC;
+  lutDist.clear();
+  tabDelta.clear();
+  tabDist.clear();
+  latKind = LAT_CITY;
+  latParam = mode;
+  if (allocated) {
+    upload_latency();
+    dev.saBins = sendall_bins();
+  }
+}
+
 void Engine::set_latency_by_name(const char* name) {  // C/RegistryNetworkLatencies.java:42-58
   std::string s = name ? name : "";
   int32_t p;
@@ -323,6 +354,15 @@ void Engine::upload_latency() {
   dev.lat.lutDist = (const uint8_t*)dLut;
   dev.lat.tabDelta = (const int32_t*)dTabDelta;
   dev.lat.tabDist = (const int32_t*)dTabDist;
+  up(dCity, cityOf.data(), cityOf.size() * sizeof(uint16_t));
+  up(dCityTab, cityTab.data(), cityTab.size() * sizeof(int32_t));
+  up(dCityPing, cityPing.data(), cityPing.size() * sizeof(float));
+  up(dCityJit, cityJit.data(), cityJit.size() * sizeof(double));
+  dev.lat.city = (const uint16_t*)dCity;
+  dev.lat.cityTab = (const int32_t*)dCityTab;
+  dev.lat.cityPing = (const float*)dCityPing;
+  dev.lat.cityJit = (const double*)dCityJit;
+  dev.lat.nCities = nCities;
 }
 
 int32_t Engine::host_latency(int32_t from, int32_t to, int32_t seed) const {
@@ -332,6 +372,11 @@ int32_t Engine::host_latency(int32_t from, int32_t to, int32_t seed) const {
   m.lutDist = lutDist.data();
   m.tabDelta = tabDelta.data();
   m.tabDist = tabDist.data();
+  m.city = cityOf.data();
+  m.cityTab = cityTab.data();
+  m.cityPing = cityPing.data();
+  m.cityJit = cityJit.data();
+  m.nCities = nCities;
   return latency_of(m, from, to, hx[from], hy[from], hextra[from], hx[to], hy[to], hextra[to], pseudo_delta(to, seed));
 }
 
@@ -381,6 +426,16 @@ int32_t Engine::max_latency() const {
     case LAT_MEASURED: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 2 * maxExtra; break;
     case LAT_ETHSCAN: maxLat = *std::max_element(tabDelta.begin(), tabDelta.end()) + 4 * maxExtra; break;
     case LAT_IC3: maxLat = 175 + 2 * maxExtra; break;
+    case LAT_CITY: {  // the largest table entry (+ the largest jitter where the mode adds one)
+      double jmax = 0;
+      for (double j : cityJit) jmax = std::max(jmax, j);
+      double m = 1;
+      for (int32_t v : cityTab) m = std::max(m, (double)v + (latParam == 0 ? jmax : 0.0));
+      for (float v : cityPing) m = std::max(m, 0.5 * ((double)v + jmax) + 1.0);
+      if (latParam == 2) m = std::max(m, 0.5 * (10.0 + jmax) + 1.0);
+      maxLat = (int32_t)std::ceil(m) + 2 * maxExtra;
+      break;
+    }
   }
   return maxLat;
 }

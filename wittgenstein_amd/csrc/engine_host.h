@@ -85,6 +85,14 @@ class Engine {
                  const uint8_t* byz, const double* speed);
   void set_latency(int32_t kind, const int32_t* params, int32_t nparams);
   void set_latency_by_name(const char* name);
+  void set_latency_city(int32_t mode, int32_t nCities, const int32_t* cityOfNode, const int32_t* tab, const float* ping,
+                        const double* jit);
+  std::vector<uint16_t> cityOf;   // LAT_CITY host tables (mirrored on the device by upload_latency)
+  std::vector<int32_t> cityTab;
+  std::vector<float> cityPing;
+  std::vector<double> cityJit;
+  int32_t nCities = 0;
+  void *dCity = nullptr, *dCityTab = nullptr, *dCityPing = nullptr, *dCityJit = nullptr;
   void set_partitions(const int32_t* cuts, int32_t k);
   void set_node_down(int32_t id, bool down);
   void latency_probe(int32_t n, const int32_t* from, const int32_t* to, const int32_t* delta, int32_t* out);

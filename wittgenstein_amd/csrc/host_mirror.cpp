@@ -3,7 +3,9 @@
 // internals, so the same sequence is what a Java `init()` performs through the JNI shim.
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <set>
+#include <stdexcept>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,16 +19,49 @@ static thread_local double g_initSeconds = 0;
 
 namespace {
 
-// RegistryNodeBuilders (C/RegistryNodeBuilders.java:28-81), RANDOM location only.
+// City builders / city latency models: their inputs are data of the caller (the reference reads cities.csv and the
+// wondernetwork ping files, C/geoinfo/GeoAllCities.java, T/CSVLatencyReader.java) registered once per process with
+// wgh_register_city_builder / wgh_register_city_latency (include/wittgpu_host.h); the mirrors then restate what
+// NodeBuilderWithCity does with them per node (C/NodeBuilder.java:98-147).
+struct CityTable {
+  std::vector<float> cum;            // CityInfo.cumulativeProbability, in citiesInfo.entrySet() order
+  std::vector<int32_t> mercX, mercY;
+  int32_t listSize = 0;              // cities.size() of the builder's list
+};
+struct CityLatency {
+  int32_t mode = 0, nCities = 0;
+  std::vector<int32_t> tab;
+  std::vector<float> ping;
+  std::vector<double> jit;
+};
+std::map<std::string, CityTable>& city_tables() {
+  static std::map<std::string, CityTable> m;
+  return m;
+}
+std::map<std::string, CityLatency>& city_latencies() {
+  static std::map<std::string, CityLatency> m;
+  return m;
+}
+
+// RegistryNodeBuilders (C/RegistryNodeBuilders.java:28-81): RANDOM, and AWS / CITIES once their tables are registered.
 struct Builder {
   bool speedUniform = false;  // the registry's "GAUSSIAN" entries install UniformSpeed (:59-61)
   double tor = 0.0;
+  const CityTable* city = nullptr;
 };
 bool parse_builder(const char* name, Builder& b) {
   std::string s = name ? name : "";
   if (s.empty()) return true;
-  if (s.rfind("RANDOM_SPEED=", 0) != 0) {
-    g_err = s + " not in the registry of the device engine (RANDOM builders only)";
+  const std::string site = s.substr(0, s.find("_SPEED="));
+  if (site == "AWS" || site == "CITIES") {
+    auto it = city_tables().find(site);
+    if (it == city_tables().end()) {
+      g_err = s + ": register the " + site + " city table first (wgh_register_city_builder)";
+      return false;
+    }
+    b.city = &it->second;
+  } else if (s.rfind("RANDOM_SPEED=", 0) != 0) {
+    g_err = s + " not in the registry";
     return false;
   }
   b.speedUniform = s.find("SPEED=GAUSSIAN") != std::string::npos;
@@ -41,7 +76,8 @@ bool parse_builder(const char* name, Builder& b) {
 }
 
 struct NodeSoA {
-  std::vector<int32_t> x, y, extra;
+  std::vector<int32_t> x, y, extra, city;
+  bool bad = false;  // a draw fell past the last city's cumulative probability
   std::vector<uint8_t> down;
   std::vector<double> speed;
 };
@@ -49,12 +85,32 @@ struct NodeSoA {
 // new Node(rd, nb) — C/Node.java:246-271 with NodeBuilderWithRandomPosition (C/NodeBuilder.java:77-96)
 void build_node(JavaRandom& rd, const Builder& b, NodeSoA& out) {
   int32_t r = rd.nextInt();
+  if (b.city) {  // NodeBuilderWithCity.getRandomCityInfo / getPos (C/NodeBuilder.java:119-139)
+    const CityTable& t = *b.city;
+    const int32_t a = r == INT32_MIN ? r : (r < 0 ? -r : r);  // Math.abs(int)
+    const int32_t rand = a % t.listSize;
+    const float p = (float)rand / (float)t.listSize;
+    int32_t c = -1;
+    for (size_t i = 0; i < t.cum.size(); i++)
+      if (p <= t.cum[i]) {
+        c = (int32_t)i;
+        break;
+      }
+    if (c < 0) {  // (the reference dies with a NullPointerException in getPos, C/NodeBuilder.java:121-124)
+      out.bad = true;
+      c = 0;
+    }
+    out.city.push_back(c);
+    out.x.push_back(t.mercX[c]);
+    out.y.push_back(t.mercY[c]);
+  } else {
   int64_t rx = (int64_t)(r >> 16);
   if (rx < 0) rx = -rx;
   int64_t ry = (int64_t)(int32_t)((uint32_t)r << 16);
   if (ry < 0) ry = -ry;
   out.x.push_back((int32_t)(rx % 2000 + 1));
   out.y.push_back((int32_t)(ry % 1112 + 1));
+  }
   double speed = 1.0;
   if (b.speedUniform) speed = rd.nextBoolean() ? (rd.nextInt(67) + 33) / 100.0 : (rd.nextInt(200) + 100) / 100.0;
   int32_t extra = 0;
@@ -72,11 +128,35 @@ struct Cleanup {
   }
 };
 
+// Network.setNetworkLatency(RegistryNetworkLatencies.getByName(name)): the table-ised models by name before the nodes
+// exist (as the reference's constructors do), a registered city model once the nodes — and their cities — are there
+int32_t set_latency_early(wg_engine* e, const char* name) {
+  if (name && city_latencies().count(name)) return WG_OK;
+  return wg_set_latency_by_name(e, name);
+}
+int32_t set_latency_late(wg_engine* e, const char* name, const NodeSoA& nodes) {
+  if (nodes.bad) {
+    g_err = "NullPointerException: a node's draw is past the last city's cumulative probability (C/NodeBuilder.java:121-139)";
+    return WG_ESTATE;
+  }
+  if (!name) return WG_OK;
+  auto it = city_latencies().find(name);
+  if (it == city_latencies().end()) return WG_OK;
+  if (nodes.city.size() != nodes.x.size()) {
+    g_err = std::string(name) + " needs a city node builder (IllegalStateException: default city location, C/NetworkLatency.java:175-178)";
+    return WG_ESTATE;
+  }
+  const CityLatency& l = it->second;
+  return wg_set_latency_city(e, l.mode, l.nCities, nodes.city.data(), l.tab.empty() ? nullptr : l.tab.data(),
+                             l.ping.empty() ? nullptr : l.ping.data(), l.jit.empty() ? nullptr : l.jit.data());
+}
+
 #define CK(call)                                   \
   do {                                             \
     int32_t _rc = (call);                          \
     if (_rc != WG_OK) {                            \
-      g_err = wg_last_error(e);                    \
+      const char* _m = wg_last_error(e);           \
+      if (_m && *_m) g_err = _m;                   \
       return _rc;                                  \
     }                                              \
   } while (0)
@@ -86,6 +166,38 @@ struct Cleanup {
 extern "C" {
 
 const char* wgh_last_error(void) { return g_err.c_str(); }
+
+int32_t wgh_register_city_builder(const char* site, int32_t n, const float* cum, const int32_t* mercX, const int32_t* mercY,
+                                  int32_t listSize) {
+  const std::string s = site ? site : "";
+  if ((s != "AWS" && s != "CITIES") || n <= 0 || !cum || !mercX || !mercY || listSize <= 0) {
+    g_err = "wgh_register_city_builder: site is AWS or CITIES, the tables have n > 0 rows";
+    return WG_EINVAL;
+  }
+  CityTable t;
+  t.cum.assign(cum, cum + n);
+  t.mercX.assign(mercX, mercX + n);
+  t.mercY.assign(mercY, mercY + n);
+  t.listSize = listSize;
+  city_tables()[s] = t;
+  return WG_OK;
+}
+int32_t wgh_register_city_latency(const char* latencyName, int32_t mode, int32_t nCities, const int32_t* tab, const float* ping,
+                                  const double* jitter100) {
+  if (!latencyName || nCities <= 0 || mode < 0 || mode > 2) {
+    g_err = "wgh_register_city_latency: name / mode / nCities";
+    return WG_EINVAL;
+  }
+  CityLatency l;
+  l.mode = mode;
+  l.nCities = nCities;
+  const size_t cc = (size_t)nCities * nCities;
+  if (tab) l.tab.assign(tab, tab + cc);
+  if (ping) l.ping.assign(ping, ping + cc);
+  if (jitter100) l.jit.assign(jitter100, jitter100 + 100);
+  city_latencies()[latencyName] = l;
+  return WG_OK;
+}
 double wgh_last_init_seconds(void) { return g_initSeconds; }
 
 int32_t wgh_jrandom_ints(int64_t seed, int32_t n, int32_t* out) {
@@ -123,12 +235,13 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // PingPong ctor :52-57
+  CK(set_latency_early(e, latencyName));  // PingPong ctor :52-57
   JavaRandom rd(seed);
   NodeSoA nodes;
   for (int i = 0; i < nodeCt; i++) build_node(rd, b, nodes);  // init() :82-84
   CK(wg_add_nodes(e, nodeCt, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   CK(wg_rng_set_state(e, rd.s));
   CK(wg_protocol_load(e, WG_PROTO_PINGPONG, nullptr, nullptr));
   // network.sendAll(new Ping(), getNodeById(0))  :86 -> send(m, time + 1, from, allNodes)
@@ -176,7 +289,7 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // Handel ctor :208-212
+  CK(set_latency_early(e, latencyName));  // Handel ctor :208-212
   JavaRandom rd(seed);
 
   // Network.chooseBadNodes (C/Network.java:52-64)
@@ -200,6 +313,7 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   }
   CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   // registerPeriodicTask(dissemination, startAt + 1, period) for live nodes, in id order (:976-984).
   // The conditional task (checkSigs) is part of the resident protocol's state (minStartTime = startAt + 1).
   for (int i = 0; i < N; i++)
@@ -308,12 +422,13 @@ int32_t wgh_sanfermin_create(const wg_sanfermin_params* pp, const char* nodeBuil
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // ctor :113-120
+  CK(set_latency_early(e, latencyName));  // ctor :113-120
   JavaRandom rd(0);                            // the ctor builds the nodes from the fresh Network's rd (:126-131) ...
   NodeSoA nodes;
   for (int i = 0; i < N; i++) build_node(rd, b, nodes);
   CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   CK(wg_rng_set_seed(e, seed));                // ... rd.setSeed(i) comes after it (C/RunMultipleTimes.java:44-48)
   CK(wg_protocol_load(e, WG_PROTO_SANFERMIN, &p, nullptr));
   for (int i = 0; i < N; i++) CK(wg_register_task(e, /*goNextLevel*/ 0u, 0u, 1, i));  // init() :139-141
@@ -343,7 +458,7 @@ int32_t wgh_casper_create(const wg_casper_params* pp, const char* nodeBuilderNam
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // ctor :80-87
+  CK(set_latency_early(e, latencyName));  // ctor :80-87
   NodeSoA nodes;
   JavaRandom rd(0);
   build_node(rd, b, nodes);                    // network.addObserver(new CasperNode(false, genesis) {}) — from new Random(0)
@@ -351,6 +466,7 @@ int32_t wgh_casper_create(const wg_casper_params* pp, const char* nodeBuilderNam
   for (int i = 1; i < N; i++) build_node(rd, b, nodes);  // init(): the byzantine producer, the producers, the attesters
   CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   CK(wg_rng_set_state(e, rd.s));
   CK(wg_protocol_load(e, WG_PROTO_CASPER, &p, nullptr));
   const int32_t SD = 8000;  // SLOT_DURATION
@@ -391,7 +507,7 @@ int32_t wgh_p2pflood_create(const wg_p2pflood_params* pp, const char* nodeBuilde
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // ctor :88-94
+  CK(set_latency_early(e, latencyName));  // ctor :88-94
   JavaRandom rd(seed);
   NodeSoA nodes;
   for (int i = 0; i < N; i++) {  // init(): new P2PFloodNode(nb, i < deadNodeCount) :122-124 (its stop() when down :27-31)
@@ -422,6 +538,7 @@ int32_t wgh_p2pflood_create(const wg_p2pflood_params* pp, const char* nodeBuilde
   }
   CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nodes.down.data(),
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   std::vector<int32_t> flat((size_t)N * maxPeers, -1), cnt(N);
   for (int i = 0; i < N; i++) {
     cnt[i] = (int32_t)peers[i].size();
@@ -495,7 +612,7 @@ int32_t wgh_gsf_create(const wg_gsf_params* pp, const char* nodeBuilderName, con
     return rc;
   }
   Cleanup guard{e};
-  CK(wg_set_latency_by_name(e, latencyName));  // GSFSignature ctor :109-114
+  CK(set_latency_early(e, latencyName));  // GSFSignature ctor :109-114
   JavaRandom rd(seed);
   // init() :611-635 — node ctors, then the nodesDown loop, then levels + tasks of the live nodes in id order
   NodeSoA nodes;
@@ -514,6 +631,7 @@ int32_t wgh_gsf_create(const wg_gsf_params* pp, const char* nodeBuilderName, con
   }
   CK(wg_add_nodes(e, N, nodes.x.data(), nodes.y.data(), nodes.extra.data(), nodes.down.data(), nullptr,
                   nodes.speed.data()));
+  CK(set_latency_late(e, latencyName, nodes));
   const int L = 32 - __builtin_clz((unsigned)N);  // levels 0..log2(N)
   std::vector<int32_t> peers((size_t)N * (N - 1), -1);
   for (int i = 0; i < N; i++) {
