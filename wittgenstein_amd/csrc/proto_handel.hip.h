@@ -729,23 +729,24 @@ struct HandelProto {
     __builtin_amdgcn_wave_barrier();
     if (!improved) return;
     const bool justCompleted = cTI == v.size;  // incomingComplete()
-    int cur = 0;
-    for (int l = 0; l < s.L; l++) {
-      if (l > lv) {
-        // totalOutgoing(l) := cur  — implicit in the TI row
-        if (justCompleted && s.p.fastPath > 0 && !ls->outFin[l] && cur == (1 << (l - 1))) {
-          __threadfence_block();  // the snapshot below reads the totalIncoming words stored above
-          uint32_t destOff = c.dest_reserve(s.p.fastPath);
-          int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
-          if (n > 0) {
-            uint32_t ref = snapshot_outgoing(c, s, l);
-            bool lf = ls->cTI[l] == (1 << (l - 1));
-            __threadfence_block();
-            c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
-          }
-        }
+    // totalOutgoing(l) = the sum of |totalIncoming| below l (:728-731): lane l takes level l, one prefix scan over the
+    // lanes instead of a loop of dependent LDS reads; the fast path (:738-749) is rare, its levels come from a ballot
+    const int myCTI = lane < s.L ? ls->cTI[lane] : 0;
+    const int incl = (int)wave_incl_scan32((uint32_t)myCTI);
+    const int cur = (int)lane_bcast((uint32_t)incl, 63);
+    const bool fp = justCompleted && s.p.fastPath > 0 && lane > lv && lane < s.L && !ls->outFin[lane] &&
+                    incl - myCTI == (1 << (lane - 1));
+    for (uint64_t fpM = __ballot(fp); fpM; fpM &= fpM - 1) {
+      const int l = __ffsll((unsigned long long)fpM) - 1;
+      __threadfence_block();  // the snapshot below reads the totalIncoming words stored above
+      uint32_t destOff = c.dest_reserve(s.p.fastPath);
+      int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
+      if (n > 0) {
+        uint32_t ref = snapshot_outgoing(c, s, l);
+        bool lf = ls->cTI[l] == (1 << (l - 1));
+        __threadfence_block();
+        c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
       }
-      cur += ls->cTI[l];
     }
     if (r.doneAt == 0 && cur >= s.p.threshold) r.doneAt = c.t;
   }
@@ -854,9 +855,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     for (int k = 0; k < H_PEND; k++) pend[k] = WG_READFIRST(ls->sc[HH_PEND + k]);
     int ncand = 0;
     // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
-    uint32_t lvMask = 0;
-    for (int l = 1; l < s.L; l++)
-      if (ls->qlen[l] > 0) lvMask |= 1u << l;
+    uint32_t lvMask = WG_READFIRST(ls->sc[HH_QMASK]) & ~1u;  // (bit l <=> qlen[l] > 0, kept by every writer of qlen)
     // (the first level's list entries were requested at the end of the previous runner — before ITS stores: loads and
     // stores retire through one in-order counter on this ISA, so a load issued after stores waits for their acknowledgement)
     uint64_t entNext = entFirst;
