@@ -364,8 +364,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
     ap.add_argument("--replicas", type=int, default=16, help="independent simulations per step and per GPU")
-    ap.add_argument("--batches", type=int, default=1,
-                    help="split a step's copies into this many concurrently running batches (one HIP stream each)")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
+                         "thread each); 0 = 2 when the step has at least 4 copies (profiles/r03d_sweep_batches.txt: the "
+                         "per-ms kernels are chains of dependent latencies that leave the chip mostly idle — two "
+                         "half-batches overlap them; three and more lose to their smaller launches), else 1")
     ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
                     "bounded by the box's cores and host memory)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
@@ -470,10 +473,14 @@ def main():
             g.network().restore()
         torch.cuda.synchronize()
 
-    def run_step():
-        if args.batches > 1:
-            # the step's copies as `--batches` smaller batches, each on its own HIP stream and host thread
-            subs = split_batches(w, sims, args.batches)
+    nb = args.batches if args.batches > 0 else (2 if R >= 4 else 1)
+    nb = max(1, min(nb, R))
+    # the step's copies as `nb` smaller batches, each on its own HIP stream and host thread
+    subs = split_batches(w, sims, nb) if nb > 1 else [batch]
+    n_first = (R + nb - 1) // nb  # copies of the first sub-batch: the one whose stream carries the HIP events
+
+    def run_step(single=False):
+        if nb > 1 and not single:
             with ThreadPoolExecutor(max_workers=len(subs)) as ex:
                 res = list(ex.map(lambda b: b.run_multiple_times(chunk=10, maxTime=20000), subs))
             return sum(sum(d) for d, _ in res), sum(sum(ms) for _, ms in res)
@@ -495,7 +502,7 @@ def main():
         first_step = False
         if i == 0 and not graph_mode:
             sims[0].network().profile(1)
-        run_step()
+        run_step(single=(i == 0))  # (the first warm-up step as ONE batch on one stream: a clean per-phase breakdown)
         if i == 0 and not graph_mode:
             prof_phase = sims[0].network().profile_read()
             sims[0].network().profile(0)
@@ -504,7 +511,7 @@ def main():
     delivered = sim_ms = 0
     elapsed = 0.0
     step_s = []
-    by_level = None
+    by_level = by_level_first = None
     dk_spans = dk_ns = 0
     t_wall0 = time.perf_counter()
     for i in range(K):
@@ -529,12 +536,14 @@ def main():
         pr = sims[0].network().profile_read()["deliver"]
         dk_spans += pr["spans"]
         dk_ns += pr["total_ns"]
-        for g in sims:
+        for k, g in enumerate(sims):
             bl = g.network().delivered_by_level()  # (cumulative since the restored image: this step's)
             by_level = bl if by_level is None else by_level + bl
+            if k < n_first:
+                by_level_first = bl if by_level_first is None else by_level_first + bl
     wall_timed_loop = time.perf_counter() - t_wall0
     check = int(sum(int(g.network().read("msgReceived").sum()) for g in sims)) if K > 0 else 0
-    del batch, sims, first
+    del subs, batch, sims, first
     gc.collect()
 
     if world > 1:
@@ -561,7 +570,8 @@ def main():
                                 "%d independent copies per step and per GPU (seeds distinct), runMs(10) until each "
                                 "copy's Handel.newContIf is false" % (n, R)),
                    "nodes": n, "replicas_per_gpu": R, "parallelism": "independent simulations batched per launch" +
-                   ("" if args.batches <= 1 else ", %d concurrent batches (one HIP stream each)" % args.batches),
+                   ("" if nb <= 1 else ", as %d concurrent batches (one HIP stream each)" % nb),
+                   "concurrent_batches": nb,
                    "replicas_requested": R_req, "hbm_bytes_per_copy_incl_init_image": int(per_copy),
                    "delivered_per_simulation": delivered // max(1, K * R * world),
                    "timing": "sum over the K steps of each step's RunMultipleTimes pass (barrier + synchronize on both "
@@ -579,18 +589,19 @@ def main():
     if by_level is None:
         import numpy as np
         by_level = np.zeros(32, np.int64)
+    if by_level_first is None:
+        by_level_first = by_level
     alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
-    per_launch_bytes = alg_bytes / max(1, dk_spans)
-    if args.batches > 1:  # the HIP events bracket the first batch's launches only: its share of the bytes
-        per_launch_bytes /= min(args.batches, R)
+    # the HIP events bracket the FIRST sub-batch's launches (its stream): its copies' bytes, its launches
+    per_launch_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level_first))) / max(1, dk_spans)
     avg_ns = dk_ns / max(1, dk_spans)
     achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the rocprofv3 PMC passes
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("replicas") == R and tj.get("nodes") == n:
-            traffic = tj.get("hbm_bytes_per_launch")
+        if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
+            traffic = tj.get("hbm_bytes_per_launch") * n_first / R
     if graph_mode:  # no per-launch timing: the whole-run figure stands in, and says so
         achieved = alg_bytes / (max(elapsed, 1e-9) * 1e9)
     out["roofline"] = {
@@ -603,8 +614,18 @@ def main():
     }
     if graph_mode:
         out["roofline"]["note"] = "WG_GRAPH=1: the chunk is replayed as a hipGraph, no per-launch HIP events; achieved = whole-run algorithmic bytes / wall time"
+    if nb > 1:
+        out["roofline"]["note"] = out["roofline"].get("note", "") + ("%d batches run concurrently: the bracketed launches are the first batch's (%d of the %d "
+                                   "copies) and share the chip with the other batches' kernels while they run"
+                                   % (nb, n_first, R))
     if prof_phase:
         out["roofline"]["warmup_phase_device_ms"] = {k: round(v["total_ns"] / 1e6, 3) for k, v in prof_phase.items()}
+        dp = prof_phase.get("deliver")
+        if dp and dp["spans"] and K > 0:  # the same pass alone on the chip (first warm-up step, all copies in one batch)
+            one = alg_bytes / K / dp["spans"] / max(1.0, dp["total_ns"] / dp["spans"])
+            out["roofline"]["single_stream"] = {"achieved": one, "frac": one / HBM_PEAK_GBS,
+                                                "avg_launch_us": dp["total_ns"] / dp["spans"] / 1000.0,
+                                                "launches": dp["spans"]}
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes, args.workload)
     log("msgReceived sum of the last step's copies: %d" % check)
