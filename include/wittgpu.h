@@ -54,6 +54,9 @@ typedef struct {
   /* ... or, with allreduce == NULL, the 128-byte RCCL unique id of wg_rccl_unique_id: the engine creates and owns the
    * communicator (same effect as wg_shard_configure_rccl right after wg_create) */
   const uint8_t* rccl_id;
+  int32_t queue_cap_wide;       /* Handel: toVerifyAgg capacity of the levels whose block is >= 16 words (>= 1024 ids), whose
+                                   queues stay short and whose slots are large; 0 = min(queue_cap, 16). Overflow is loud
+                                   (WG_ENOMEM), as for queue_cap */
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */

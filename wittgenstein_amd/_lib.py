@@ -16,7 +16,7 @@ class wg_config(C.Structure):
                 ("payload_words", C.c_int64), ("outbox_records", C.c_int64), ("chain_dests", C.c_int64),
                 ("chain_slots", C.c_int32), ("queue_cap", C.c_int32),
                 ("shard", C.c_int32), ("nshards", C.c_int32), ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p),
-                ("rccl_id", C.c_void_p)]
+                ("rccl_id", C.c_void_p), ("queue_cap_wide", C.c_int32)]
 
 
 def make_config(cfg):

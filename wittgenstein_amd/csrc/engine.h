@@ -141,7 +141,8 @@ enum ErrBits : uint32_t {
   ERR_PROTOCOL = 1u << 11,     // a reference IllegalStateException site inside action()
   ERR_EVENTS = 1u << 12,       // events in one ms exceed scratch capacity
   ERR_ARRIVAL_PAST = 1u << 13,
-  ERR_SHARD_MULTI = 1u << 14   // sharded engine: an action() emitted a multi-destination envelope
+  ERR_SHARD_MULTI = 1u << 14,  // sharded engine: an action() emitted a multi-destination envelope
+  ERR_SAME_MS_BLOCKS = 1u << 15  // Casper resident: two blocks created in one simulated ms (block-id order across wavefronts)
 };
 
 // Device-resident engine globals (one instance).

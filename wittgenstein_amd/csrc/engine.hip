@@ -1044,7 +1044,7 @@ void Engine::check_device_errors() {
   if (e & ERR_CHAIN_SLOTS) m += "wg_config.chain_slots exhausted; ";
   if (e & ERR_CHAIN_DESTS) m += "wg_config.chain_dests ring overrun; ";
   if (e & ERR_PAYLOAD) m += "wg_config.payload_words ring overrun; ";
-  if (e & ERR_QUEUE_CAP) m += "toVerify list (Handel toVerifyAgg / GSFSignature toVerify) exceeded wg_config.queue_cap; ";
+  if (e & ERR_QUEUE_CAP) m += "toVerify list (Handel toVerifyAgg / GSFSignature toVerify) exceeded wg_config.queue_cap (Handel levels of 1024 ids and more: queue_cap_wide); ";
   if (e & ERR_PENDING) m += "pending-verification table full; ";
   if (e & ERR_MULTI_TOO_BIG) {
     m += "device-side multi-destination send with more than 64 destinations; ";
@@ -1062,6 +1062,9 @@ void Engine::check_device_errors() {
     m += "Arriving in the past; ";
     code = WG_ESTATE;
   }
+  if (e & ERR_SAME_MS_BLOCKS)
+    throw WgError(WG_EUNSUPPORTED, "Casper IMD resident: two blocks were created in one simulated ms (the reference allows it; "
+                                   "block-id order across concurrent wavefronts is not resident) — run it on the host-callback mode");
   if (e & ERR_PROTOCOL) {
     m += "protocol invariant violated (reference IllegalStateException site); ";
     code = WG_ESTATE;
@@ -1956,6 +1959,8 @@ struct HandelHost : ProtoHost {
     st.L = L;
     st.W = W;
     st.Q = Q;
+    st.Qw = e.cfg.queue_cap_wide > 0 ? e.cfg.queue_cap_wide : std::min(Q, 16);
+    if (st.Qw > Q) throw WgError(WG_EINVAL, "queue_cap_wide must be <= queue_cap");
     // Per-node rows are held for the nodes [lo, hi) this engine owns — everything when it is not sharded — behind
     // pointers biased by -lo rows, so that the kernels keep indexing them by node id (they touch only owned nodes).
     const int32_t lo = st.lo = e.shardCount > 0 ? e.dev.shardLo : 0;
@@ -1976,7 +1981,11 @@ struct HandelHost : ProtoHost {
     // (k_handel_cond_a2), which on_restore undoes in place; the verification queues, the dissemination snapshots and the
     // scratch of the conditional-task phase hold nothing before the first event
     st.ranks = rows((int32_t*)nullptr, N, false, Engine::AC_SCRATCH);
-    st.peers = rows((int32_t*)nullptr, N - 1, false, Engine::AC_CONST);
+    const bool peers16 = N <= 65536;
+    uint16_t* dPeers16 = peers16 ? rows((uint16_t*)nullptr, N - 1, false, Engine::AC_CONST) : nullptr;
+    int32_t* dPeers32 = peers16 ? nullptr : rows((int32_t*)nullptr, N - 1, false, Engine::AC_CONST);
+    st.peers16 = dPeers16;
+    st.peers32 = dPeers32;
     st.LS = L <= 16 ? 16 : 32;
     st.lsShift = L <= 16 ? 4 : 5;
     st.hdrStride = HH_LV + HP_COUNT * st.LS;  // 160 or 288 words: whole 128-byte lines
@@ -1987,8 +1996,9 @@ struct HandelHost : ProtoHost {
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
       int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
-      st.qsigOff[l] = off - (unsigned long long)lo * Q * nw;  // (node * Q + slot) * nw is added to it: biased like the rows
-      off += (unsigned long long)nLoc * Q * nw;
+      const int ql = nw >= 16 ? st.Qw : Q;  // (h_qcap)
+      st.qsigOff[l] = off - (unsigned long long)lo * ql * nw;  // (node * ql + slot) * nw is added to it: biased like the rows
+      off += (unsigned long long)nLoc * ql * nw;
     }
     st.qsig = e.dalloc<uint64_t>(off, false, Engine::AC_SCRATCH);
     {
@@ -2010,8 +2020,19 @@ struct HandelHost : ProtoHost {
     st.condList = e.dalloc<uint32_t>(N);
     st.drawVal = e.dalloc<int32_t>(N);
     WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(st.peers + (size_t)lo * (N - 1), init.peers + (size_t)lo * (N - 1), 4 * nLoc * (N - 1),
-                     hipMemcpyHostToDevice));
+    if (peers16) {  // (narrowed on the host, a slice at a time)
+      const size_t total = nLoc * (size_t)(N - 1), step = (size_t)1 << 26;
+      std::vector<uint16_t> tmp(std::min(total, step));
+      const int32_t* src = init.peers + (size_t)lo * (N - 1);
+      for (size_t at = 0; at < total; at += step) {
+        const size_t k = std::min(step, total - at);
+        for (size_t i = 0; i < k; i++) tmp[i] = (uint16_t)src[at + i];
+        WG_HIP(hipMemcpy(dPeers16 + (size_t)lo * (N - 1) + at, tmp.data(), 2 * k, hipMemcpyHostToDevice));
+      }
+    } else {
+      WG_HIP(hipMemcpy(dPeers32 + (size_t)lo * (N - 1), init.peers + (size_t)lo * (N - 1), 4 * nLoc * (N - 1),
+                       hipMemcpyHostToDevice));
+    }
     st.ones = nullptr;
     st.snapIdx = nullptr;
     st.nSnap = nullptr;

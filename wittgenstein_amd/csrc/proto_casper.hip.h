@@ -145,9 +145,11 @@ struct CasperProto {
     int32_t idx = 0;
     if (WG_LANE == 0) {
       idx = (int32_t)atomicAdd(s.nBlocks, 1u);
-      if (atomicExch(s.lastBlockMs, c.t) == c.t || idx >= s.B || height <= 0 || c.t < ldi(s.bTime + base) ||
-          ldi(s.bHeight + base) >= height)
-        set_err(c.d.g, idx >= s.B ? ERR_PAYLOAD : ERR_PROTOCOL);  // two blocks in one ms / table full / Block's ctor checks :36-47
+      // two blocks in one ms: valid in the reference (e.g. a delayed byzantine build landing on another producer's slot),
+      // not resident — block ids are creation order and two wavefronts of one launch have none: its own error
+      if (atomicExch(s.lastBlockMs, c.t) == c.t) set_err(c.d.g, ERR_SAME_MS_BLOCKS);
+      if (idx >= s.B || height <= 0 || c.t < ldi(s.bTime + base) || ldi(s.bHeight + base) >= height)
+        set_err(c.d.g, idx >= s.B ? ERR_PAYLOAD : ERR_PROTOCOL);  // table full / Block's ctor checks :36-47
       if (idx >= s.B) idx = s.B - 1;
       s.bHeight[idx] = height;
       s.bParent[idx] = base;

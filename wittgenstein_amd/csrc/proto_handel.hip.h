@@ -28,7 +28,14 @@ struct HandelState {
   int32_t N, L, W, Q;
   uint64_t *TI, *LA, *VI, *TV, *FP;   // [N][W]
   int32_t* ranks;                      // [N][N]
-  int32_t* peers;                      // [N][N-1]
+  // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
+  // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
+  const uint16_t* peers16;
+  const int32_t* peers32;
+  // toVerifyAgg slots per (node, level): Q for the levels whose block is below 16 words, Qw (wg_config.queue_cap_wide)
+  // for the wide ones — their queues stay short (a few entries: one sender per period and level) while a slot is up to
+  // 2 KB, so a flat capacity spent gigabytes on slots that are never used
+  int32_t Qw;
   // Node header: every scalar of a node and its per-level scalars in ONE record of hdrStride 32-bit words
   // (array of structs). A node visit is one wavefront touching one node, so the record is read and written
   // back as a few consecutive cache lines of one page, instead of twenty 64-byte lines in twenty arrays:
@@ -110,7 +117,11 @@ __device__ __forceinline__ Lv sib_view(int32_t node, int l) {
 // the node's own block: ids that totalOutgoing of level l can hold
 __device__ __forceinline__ Lv own_view(int32_t node, int l) { return block_view((node >> (l - 1)) << (l - 1), 1 << (l - 1)); }
 
+__device__ __forceinline__ int32_t h_peer(const HandelState& s, size_t idx) {
+  return s.peers16 ? (int32_t)s.peers16[idx] : s.peers32[idx];
+}
 __device__ __forceinline__ int h_nw(int l) { return l == 0 ? 1 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1); }
+__device__ __forceinline__ int h_qcap(const HandelState& s, int l) { return h_nw(l) >= 16 ? s.Qw : s.Q; }
 __device__ __forceinline__ int h_msg_size(int l) { return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 96 * 2; }  // :256-260
 
 // word j of a view is owned by lane (bw + j) & 63
@@ -357,7 +368,8 @@ struct HandelProto {
     if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
     if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
     r.sigQueueSize++;
-    const unsigned long long capMask = s.Q >= 64 ? ~0ULL : ((1ULL << s.Q) - 1ULL);
+    const int qc = h_qcap(s, l);
+    const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
     const unsigned long long freeM = ~used & capMask;
     if (freeM == 0 || len >= 64) {
       set_err(d.g, ERR_QUEUE_CAP);
@@ -384,7 +396,7 @@ struct HandelProto {
 
   // ---- queue helpers ---------------------------------------------------------------------------
   __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int l, int slot) {
-    return s.qsig + s.qsigOff[l] + ((size_t)node * s.Q + slot) * (size_t)h_nw(l);
+    return s.qsig + s.qsigOff[l] + ((size_t)node * h_qcap(s, l) + slot) * (size_t)h_nw(l);
   }
   __device__ static bool slot_pending(const NodeRegs& r, int l, int slot) {
     bool p = false;
@@ -399,7 +411,7 @@ struct HandelProto {
                                         int32_t* single) {
     const int32_t node = c.node;
     const int size = 1 << (l - 1);
-    const int32_t* peers = s.peers + (size_t)node * (s.N - 1) + (size - 1);
+    const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
     const uint64_t* fp = s.FP + (size_t)node * s.W;
     int pos = ls->pos[l];
     const int start = pos;
@@ -409,7 +421,7 @@ struct HandelProto {
       int len = min(64, size - pos);
       int k = WG_LANE;
       bool in = k < len;
-      int32_t p = in ? peers[pos + k] : 0;
+      int32_t p = in ? h_peer(s, peers0 + pos + k) : 0;
       bool ok = in && !row_get(fp, p);
       uint64_t okm = __ballot(ok);
       // a rejected peer whose successor position is `start` finishes the level (:499-503)
@@ -492,7 +504,8 @@ struct HandelProto {
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
     unsigned long long used = ls_qused(ls, l);
-    unsigned long long capMask = s.Q >= 64 ? ~0ULL : ((1ULL << s.Q) - 1ULL);
+    const int qc = h_qcap(s, l);
+    unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
     unsigned long long freeM = ~used & capMask;
     int len = ls->qlen[l];
     if (freeM == 0 || len >= 64) {
@@ -542,7 +555,7 @@ struct HandelProto {
       open = !ls->outFin[lane] && (c.t >= (lane - 1) * s.p.levelWaitTime || below == mySize);  // isOpen :458-472
       if (open) {
         myPos = ls->pos[lane];
-        cand = s.peers[(size_t)node * (s.N - 1) + (mySize - 1) + myPos];
+        cand = h_peer(s, (size_t)node * (s.N - 1) + (mySize - 1) + myPos);
       }
     }
     KPROF_DECL;
