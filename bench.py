@@ -363,7 +363,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
-    ap.add_argument("--replicas", type=int, default=16, help="independent simulations per step and per GPU")
+    ap.add_argument("--replicas", type=int, default=24, help="independent simulations per step and per GPU (lowered to what fits the free HBM)")
     ap.add_argument("--batches", type=int, default=0,
                     help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
                          "thread each); 0 = 2 when the step has at least 4 copies (profiles/r03d_sweep_batches.txt: the "

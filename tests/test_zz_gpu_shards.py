@@ -192,8 +192,10 @@ def handel_shard_bytes_model(n, k, horizon=256, q=32):
     L = n.bit_length()          # levels 0..log2(n)
     W = max(1, n // 64)
     own = n // k
-    rows = own * (5 * W * 8 + n * 4 + (n - 1) * 4 + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * 64 * 8 + L * q * 4)
-    qsig = sum(own * q * (max(1, (1 << (l - 1)) // 64)) * 8 for l in range(1, L))
+    peer = 2 if n <= 65536 else 4   # emission lists: 16-bit ids up to 65 536 nodes
+    rows = own * (5 * W * 8 + n * 4 + (n - 1) * peer + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * 64 * 8 + L * q * 4)
+    nw = lambda l: max(1, (1 << (l - 1)) // 64)
+    qsig = sum(own * (min(q, 16) if nw(l) >= 16 else q) * nw(l) * 8 for l in range(1, L))   # queue_cap_wide
     snap = (horizon // 20 + 2) * n * max(1, n // 128) * 8           # dissemination snapshots: replicated ring
     maxout = 24 * n
     sched = (max(1 << 20, 256 * n) + horizon * 1024) * 16 + maxout * (16 + 16 + 8 + 4 + 4 + 4 + 32 + 4 + 16 + 4) \
