@@ -23,7 +23,7 @@ prof)
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $REPO/$OUT/pmc_$c -o k --output-format csv -- \
-       python $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-second --nodes ${PMC_NODES:-32768} > $REPO/$OUT/pmc_$c.json 2> $REPO/$OUT/pmc_$c.err)
+       python $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-second --batches 1 --nodes ${PMC_NODES:-32768} > $REPO/$OUT/pmc_$c.json 2> $REPO/$OUT/pmc_$c.err)
     echo "pmc $c rc=$?"
     python tools/prof_summary.py pmc $OUT/pmc_$c $OUT/pmc_$c.md && rm -rf $OUT/pmc_$c
     head -12 $OUT/pmc_$c.md
