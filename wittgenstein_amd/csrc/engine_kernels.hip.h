@@ -952,7 +952,21 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
     uint32_t b = b0 + threadIdx.x;
     uint32_t add = 0;
     if (b < D) {
-      for (uint32_t tile = 0; tile < nTiles; tile++) {
+      // in-place exclusive prefix over the tiles of this bin, eight tiles a round: the loads of a round are issued
+      // together (one at a time, each iteration waited a memory round trip — the millisecond in which every node
+      // disseminates has hundreds of tiles, and this is a one-block kernel)
+      uint32_t tile = 0;
+      for (; tile + 8 <= nTiles; tile += 8) {
+        uint32_t h[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) h[q] = d.tileHist[(size_t)(tile + q) * D + b];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          d.tileHist[(size_t)(tile + q) * D + b] = add;
+          add += h[q];
+        }
+      }
+      for (; tile < nTiles; tile++) {
         uint32_t h = d.tileHist[(size_t)tile * D + b];
         d.tileHist[(size_t)tile * D + b] = add;
         add += h;
