@@ -373,6 +373,13 @@ typedef struct {
  * Resets the accumulated spans. In a batch the spans are recorded on the first member. */
 int32_t wg_profile_enable(wg_engine* e, int32_t mode);
 int32_t wg_profile_read(wg_engine* e, wg_profile_entry* dst, int32_t cap, int32_t* n);
+/* Spans on a common time axis. wg_profile_set_reference(e, ref) makes e keep, for every span it brackets from now on, start and
+ * end in ns since a reference event of engine `ref` (NULL: e's own; recorded once, on ref's stream). Engines of concurrently
+ * running batches given the same reference can have their spans merged — e.g. the union of the intervals in which a delivery
+ * kernel of ANY batch runs. wg_profile_read_spans copies the spans of phase `cls` (the index of its wg_profile_read entry: 2 =
+ * deliver) recorded since the last full read; *n = how many there are (call with cap 0 to ask). */
+int32_t wg_profile_set_reference(wg_engine* e, wg_engine* ref);
+int32_t wg_profile_read_spans(wg_engine* e, int32_t cls, double* start_ns, double* end_ns, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,13 @@ def test_init_threads_bounds():
     assert replicas.init_threads(0, 1, 0, 16 * GB, 1) == 1
 
 
+def test_union_of_launch_intervals():
+    u = replicas.union_ns
+    assert u([]) == 0 and u([(0, 10)]) == 10
+    assert u([(0, 10), (5, 15), (20, 30)]) == 25      # two overlapping launches of different streams count once
+    assert u([(0, 5), (1, 2)]) == 5 and u([(3, 4), (0, 1)]) == 2
+
+
 def test_rank_seeds_disjoint():
     seen = set()
     for rank in range(4):
@@ -79,8 +86,8 @@ def run_bench(argv, free=10**6):
 
 
 def test_bench_main_with_the_drivers_argv():
-    out, _ = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--nodes", "16", "--replicas", "2", "--no-cpu",
-                        "--no-second"])
+    out, _ = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--nodes", "16", "--replicas", "2", "--batches", "2",
+                        "--no-cpu", "--no-second"])
     assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1
     assert out["config"]["replicas_per_gpu"] == 2 and out["config"]["nodes"] == 16
     assert out["value"] > 0 and out["unit"] == "delivered messages/s" and out["vs_baseline"] is None
@@ -90,6 +97,10 @@ def test_bench_main_with_the_drivers_argv():
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches"] > 0 and 0 < r["frac"] < 1
     assert out["config"]["workload"].startswith("Handel aggregation, 16 nodes")
+    assert out["config"]["concurrent_batches"] == 2           # the two copies as two concurrent batches
+    a = r["all_streams"]                                      # ... whose delivery launches are merged on one time axis
+    assert a["launches"] > r["launches"]                      # (the other seed converges at its own time)
+    assert 0 < a["union_ms"] <= a["sum_of_launch_ms"] * 1.0001
 
 
 def test_bench_lowers_the_batch_instead_of_failing():

@@ -264,6 +264,19 @@ class Network:
         self._ck(L.lib().wg_profile_read(self._h, arr, 64, C.byref(n)))
         return {arr[i].name.decode(): {"spans": arr[i].spans, "total_ns": arr[i].total_ns} for i in range(n.value)}
 
+    def profile_reference(self, ref=None):
+        """wg_profile_set_reference: keep the spans' start / end relative to `ref`'s (default: this engine's) reference event"""
+        self._ck(L.lib().wg_profile_set_reference(self._h, None if ref is None else ref._h))
+
+    def profile_spans(self, cls=2):
+        """(start_ns, end_ns) arrays of the spans of phase `cls` (2 = deliver) since the last read, on the reference's time axis"""
+        n = C.c_int32()
+        self._ck(L.lib().wg_profile_read_spans(self._h, int(cls), None, None, 0, C.byref(n)))
+        a, b = np.zeros(n.value, np.float64), np.zeros(n.value, np.float64)
+        if n.value:
+            self._ck(L.lib().wg_profile_read_spans(self._h, int(cls), _p(a, C.c_double), _p(b, C.c_double), n.value, C.byref(n)))
+        return a, b
+
     def latency_probe(self, frm, to, delta):
         frm = np.ascontiguousarray(frm, np.int32)
         to = np.ascontiguousarray(to, np.int32)

@@ -307,6 +307,32 @@ int32_t wg_profile_enable(wg_engine* h, int32_t on) {
   }
   WG_END
 }
+int32_t wg_profile_set_reference(wg_engine* h, wg_engine* ref) {
+  WG_TRY(h)
+  Engine& R = ref ? *ref->e : E;
+  if (!R.profOwnRef) {
+    (void)hipSetDevice(R.cfg.device);
+    WG_HIP(hipEventCreate(&R.profOwnRef));
+    WG_HIP(hipEventRecord(R.profOwnRef, R.stream));
+    WG_HIP(hipEventSynchronize(R.profOwnRef));
+  }
+  E.profRef = R.profOwnRef;
+  for (int c = 0; c < Engine::PC_COUNT; c++) E.profTimes[c].clear();
+  WG_END
+}
+int32_t wg_profile_read_spans(wg_engine* h, int32_t cls, double* start_ns, double* end_ns, int32_t cap, int32_t* n) {
+  WG_TRY(h)
+  if (cls < 0 || cls >= Engine::PC_COUNT || !n) throw WgError(WG_EINVAL, "class / n");
+  auto& v = E.profTimes[cls];
+  const int32_t k = std::min<int32_t>((int32_t)v.size(), cap < 0 ? 0 : cap);
+  for (int32_t i = 0; i < k; i++) {
+    if (start_ns) start_ns[i] = v[i].first;
+    if (end_ns) end_ns[i] = v[i].second;
+  }
+  *n = (int32_t)v.size();
+  if (k == (int32_t)v.size()) v.clear();  // (read in full: start afresh)
+  WG_END
+}
 int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_t* n) {
   WG_TRY(h)
   static const char* names[Engine::PC_COUNT] = {"expand(k_scan1+k_scan2<ExpandF>)", "group(unused)",

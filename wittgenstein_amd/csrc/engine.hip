@@ -161,6 +161,7 @@ Engine::~Engine() {
     (void)hipEventDestroy(sp.b);
   }
   for (auto ev : profFree) (void)hipEventDestroy(ev);
+  if (profOwnRef) (void)hipEventDestroy(profOwnRef);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -180,6 +181,9 @@ void Engine::prof_collect() {
     if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
       profNs[sp.cls] += (double)ms * 1e6;
       profLaunches[sp.cls]++;
+      float t0 = 0;
+      if (profRef && hipEventElapsedTime(&t0, profRef, sp.a) == hipSuccess)
+        profTimes[sp.cls].push_back({(double)t0 * 1e6, ((double)t0 + (double)ms) * 1e6});
     }
     profFree.push_back(sp.a);
     profFree.push_back(sp.b);

@@ -281,6 +281,12 @@ class Engine {
   long long profLaunches[PC_COUNT] = {0};
   hipEvent_t prof_event();
   void prof_collect();                     // after the stream is idle
+  // spans with their place in time (wg_profile_set_reference / wg_profile_read_spans): start / end of every bracketed span
+  // in ns since a reference event — this engine's own or ANOTHER engine's, so that spans recorded on different streams
+  // (concurrent batches) can be laid on one time axis and their union measured
+  hipEvent_t profOwnRef = nullptr;         // recorded on this engine's stream by wg_profile_enable
+  hipEvent_t profRef = nullptr;            // the reference in use (may belong to another engine)
+  std::vector<std::pair<double, double>> profTimes[PC_COUNT];
   struct ProfScope {
     Engine& e;
     size_t idx = (size_t)-1;

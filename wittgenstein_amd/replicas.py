@@ -54,3 +54,19 @@ def init_threads(requested, copies, host_avail_bytes, per_init_bytes, cores, wor
     by_cpu = max(1, cores // max(1, world))
     want = requested if requested > 0 else copies
     return max(1, min(want, copies, by_mem, by_cpu))
+
+
+def union_ns(intervals):
+    """total length of the union of [start, end) intervals (ns): the time during which AT LEAST ONE of them runs — the
+    delivery kernels of concurrently running batches laid on one time axis (wg_profile_read_spans)"""
+    total, cur_a, cur_b = 0.0, None, None
+    for a, b in sorted(intervals):
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                total += cur_b - cur_a
+            cur_a, cur_b = a, b
+        elif b > cur_b:
+            cur_b = b
+    if cur_b is not None:
+        total += cur_b - cur_a
+    return total
