@@ -177,9 +177,7 @@ struct HandelProto {
   struct NodeRegs {
     long long doneAt, doneAt0;
     int32_t addedCycle, sigQueueSize, msgFiltered, startAt;
-    uint32_t pend[H_PEND];
-    int32_t pendFrom[H_PEND];
-    LevelScalars* ls;
+    LevelScalars* ls;  // (the outstanding updateVerifiedSignatures tasks stay in the LDS image: sc[HH_PEND ..], sc[HH_PENDFROM ..])
   };
 
   __device__ static int msg_size(const State&, uint32_t msg) { return h_msg_size((int)(msg & 31u)); }
@@ -256,11 +254,6 @@ struct HandelProto {
     r.sigQueueSize = (int32_t)WG_READFIRST(h[HH_SIGQ]);
     r.msgFiltered = (int32_t)WG_READFIRST(h[HH_FILT]);
     r.startAt = (int32_t)WG_READFIRST(h[HH_START]);
-#pragma unroll
-    for (int k = 0; k < H_PEND; k++) {
-      r.pend[k] = WG_READFIRST(h[HH_PEND + k]);
-      r.pendFrom[k] = (int32_t)WG_READFIRST(h[HH_PENDFROM + k]);
-    }
     r.ls = ls;
   }
   __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
@@ -273,8 +266,6 @@ struct HandelProto {
       h[HH_ADDED] = (uint32_t)r.addedCycle;
       h[HH_SIGQ] = (uint32_t)r.sigQueueSize;
       h[HH_FILT] = (uint32_t)r.msgFiltered;
-#pragma unroll
-      for (int k = 0; k < H_PEND; k++) h[HH_PEND + k] = r.pend[k];
       if (r.doneAt != r.doneAt0) c.d.nodes.doneAt[node] = r.doneAt;  // Node.doneAt proper (read-back, contIf)
     }
     store_levels(s, node, r.ls);
@@ -401,7 +392,7 @@ struct HandelProto {
   __device__ static bool slot_pending(const NodeRegs& r, int l, int slot) {
     bool p = false;
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) p |= (r.pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot));
+    for (int k = 0; k < H_PEND; k++) p |= (r.ls->sc[HH_PEND + k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot));
     return p;
   }
   // ---- getRemainingPeers (:486-508), wave-parallel but sequentially equivalent ------------------
@@ -617,15 +608,19 @@ struct HandelProto {
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int32_t node = c.node;
     const int lane = WG_LANE;
-    const uint32_t pe = r.pend[arg & (H_PEND - 1)];
-    const int32_t from = r.pendFrom[arg & (H_PEND - 1)];
+    // (the task's record is read from the node's LDS image, indexed at run time there: a register array indexed at run
+    // time would put the whole NodeRegs in scratch memory — every access to any of its fields a memory round trip)
+    LevelScalars* ls = r.ls;
+    const int pk = (int)(arg & (H_PEND - 1));
+    const uint32_t pe = WG_READFIRST(ls->sc[HH_PEND + pk]);
+    const int32_t from = (int32_t)WG_READFIRST(ls->sc[HH_PENDFROM + pk]);
     if (!(pe & 0x80000000u)) {
       if (lane == 0) set_err(c.d.g, ERR_PROTOCOL);
       return;
     }
     const int lv = (int)((pe >> 8) & 0xFF), slot = (int)(pe & 0xFF);
-    r.pend[arg & (H_PEND - 1)] = 0;
-    LevelScalars* ls = r.ls;
+    __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
+    if (lane == 0) ls->sc[HH_PEND + pk] = 0;
     const Lv v = sib_view(node, lv);
     uint64_t* ti = s.TI + (size_t)node * s.W;
     uint64_t* la = s.LA + (size_t)node * s.W;
