@@ -12,9 +12,44 @@
 //   per-ms scratch: events (expanded bucket), per-node inbox, unordered outbox, ordered outbox.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "jdk_random.h"
 
 namespace wg {
+
+// ---- device pointers in the GLOBAL address space -----------------------------------------------------------------
+// Every pointer the kernels follow is loaded from a table in memory (EngineDev, the protocol's State), and a pointer
+// loaded from memory is a generic ("flat") pointer to the compiler: it emits flat_load / flat_store, and while a FLAT
+// operation is pending the gfx9-family wait-count logic can only wait for ALL outstanding memory operations
+// (s_waitcnt vmcnt(0) lgkmcnt(0)) — the first use of any loaded value then also waits for every load issued after it,
+// which serialises exactly the loads the node-visit kernels issue ahead of time (the next visit's header, the next
+// level's list). GP<T> stores the plain pointer (host code allocates, copies and biases it as before) and hands device
+// code a pointer qualified with address space 1: global_load / global_store / global_atomic, s_waitcnt vmcnt(N).
+// Device code keeps the qualifier on everything it derives (`const uint64_t WG_G* row = s.TI + ...`), loads and stores
+// whole records with gld / gst, and casts to a generic pointer (F) only at the call of an atomic builtin.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WG_G __attribute__((address_space(1)))
+#else
+#define WG_G
+#endif
+template <class T>
+struct GP {
+  T* raw;
+  GP() = default;
+  WG_HD GP(T* p) : raw(p) {}
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (host functions are parsed in the device pass too: they take the template; the built-in [] and + of device code find
+  // only the address-space-1 conversion)
+  template <class U, class = std::enable_if_t<std::is_convertible<T*, U*>::value>>
+  __host__ operator U*() const { return raw; }
+  __device__ operator WG_G T*() const { return (WG_G T*)raw; }
+  __host__ T* operator->() const { return raw; }
+  __device__ WG_G T* operator->() const { return (WG_G T*)raw; }
+#else
+  WG_HD operator T*() const { return raw; }
+  WG_HD T* operator->() const { return raw; }
+#endif
+};
 
 constexpr int PAGE_SHIFT = 10;
 constexpr int PAGE_RECS = 1 << PAGE_SHIFT;
@@ -172,7 +207,7 @@ struct Globals {
   unsigned long long payloadHead;  // monotone, in 64-bit words
   // in-kernel cycle counters of investigation builds (-DWG_KPROF, tools/kprof.sh); untouched otherwise
   unsigned long long kprof[32];
-  unsigned long long* kprofBuf;  // [KPROF_WAVES][32] per-wavefront rows the marks add to (summed into kprof[] by the host)
+  GP<unsigned long long> kprofBuf;  // [KPROF_WAVES][32] per-wavefront rows the marks add to (summed into kprof[] by the host)
   // sharded engines only (0 otherwise): multi-destination envelopes created in this phase / their destinations
   // (replicated), and this shard's private scratch-ring head for the unsorted destination lists of its action()s
   uint32_t nMulti, nMultiDests;
@@ -188,37 +223,40 @@ constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry
 struct LatencyModel {
   int32_t kind;
   int32_t param;            // FIXED: latency, UNIFORM: maxLatency
-  const uint8_t* lutDist;   // BYDIST: [1145][100]
-  const int32_t* tabDelta;  // MEASURED/ETHSCAN/UNIFORM: [100]
-  const int32_t* tabDist;   // IC3: [1145]
+  GP<const uint8_t> lutDist;   // BYDIST: [1145][100]
+  GP<const int32_t> tabDelta;  // MEASURED/ETHSCAN/UNIFORM: [100]
+  GP<const int32_t> tabDist;   // IC3: [1145]
   // LAT_CITY — the city-based models (C/NetworkLatency.java:86-233); param = wg_city_latency_mode, C = nCities:
-  const uint16_t* city;     // [n] the node's city (Node.cityName as an index into the caller's city list)
-  const int32_t* cityTab;   // [C][C] AWS: ping / 2; BY_CITY: max(1, round(0.5f * ping)), the whole answer
-  const float* cityPing;    // [C][C] BY_CITY_WJITTER: the measured round trip (float, as CSVLatencyReader parsed it)
-  const double* cityJit;    // [100]  AWS / BY_CITY_WJITTER: gpd.inverseF(delta / 100.0)
+  GP<const uint16_t> city;     // [n] the node's city (Node.cityName as an index into the caller's city list)
+  GP<const int32_t> cityTab;   // [C][C] AWS: ping / 2; BY_CITY: max(1, round(0.5f * ping)), the whole answer
+  GP<const float> cityPing;    // [C][C] BY_CITY_WJITTER: the measured round trip (float, as CSVLatencyReader parsed it)
+  GP<const double> cityJit;    // [100]  AWS / BY_CITY_WJITTER: gpd.inverseF(delta / 100.0)
   int32_t nCities;
 };
 
 struct NodeArrays {
   int32_t n;
-  int16_t* x;
-  int16_t* y;
-  int32_t* extraLatency;
-  uint8_t* down;
-  uint8_t* part;            // partitionId (C/Network.java:639-649), recomputed on partition()
-  long long* msgReceived;
-  long long* msgSent;
-  long long* bytesSent;
-  long long* bytesReceived;
-  long long* doneAt;
+  GP<int16_t> x;
+  GP<int16_t> y;
+  GP<int32_t> extraLatency;
+  GP<uint8_t> down;
+  GP<uint8_t> part;            // partitionId (C/Network.java:639-649), recomputed on partition()
+  GP<long long> msgReceived;
+  GP<long long> msgSent;
+  GP<long long> bytesSent;
+  GP<long long> bytesReceived;
+  GP<long long> doneAt;
 };
 
+struct SendAllDesc;
+struct FarRec;
+struct RunDesc;
 // Everything a kernel needs, passed by value.
 struct EngineDev {
   uint32_t hostMode;        // wg_next_delivery mode: events go to the host, no device inbox lists are built
   uint32_t halted;          // batch member that is not advanced by the current run (RunMultipleTimes: its
                             // continuation predicate turned false); every kernel returns at once for it
-  Globals* g;
+  GP<Globals> g;
   NodeArrays nodes;
   LatencyModel lat;
   int32_t discardTime;
@@ -227,77 +265,77 @@ struct EngineDev {
   int32_t horizon;          // D (power of two)
   int32_t maxPagesPerBucket;
   uint32_t nPages;
-  Rec* pool;
-  uint32_t* freeStack;
-  uint32_t* pagetab;        // [D][maxPagesPerBucket]
-  uint32_t* bcnt;           // [D]
+  GP<Rec> pool;
+  GP<uint32_t> freeStack;
+  GP<uint32_t> pagetab;        // [D][maxPagesPerBucket]
+  GP<uint32_t> bcnt;           // [D]
   // chains
-  Chain* chains;
+  GP<Chain> chains;
   uint32_t chainSlots;
-  int32_t* dests;
+  GP<int32_t> dests;
   unsigned long long chainDests;
   // payload ring
-  uint64_t* payload;
+  GP<uint64_t> payload;
   unsigned long long payloadWords;
   // ring-safety bookkeeping: allocator heads at the end of each of the last `horizon` ms. Everything
   // allocated at ms s is dead by s + horizon (arrival - time < horizon is enforced), so a ring is
   // safe iff head(t) - head(t - horizon) <= capacity.
-  unsigned long long* destHeadAt;     // [D]
-  unsigned long long* payloadHeadAt;  // [D]
+  GP<unsigned long long> destHeadAt;     // [D]
+  GP<unsigned long long> payloadHeadAt;  // [D]
   // per-ms scratch
   uint32_t maxEvents;
-  Rec* ev;                  // expanded events (MSG/TASK/PERIODIC form) in global event order
-  EvAux* evAux;
-  EvRes* evRes;
-  uint32_t* evRecOff;       // exclusive scans of nrec / ndraw in event order
-  uint32_t* evDrawOff;
-  int32_t* evNext;          // per-node inbox as a linked list through the events
-  int32_t* head;            // [n] newest event of the node this ms, -1 = none
-  uint32_t* active;         // nodes with >= 1 event (unordered)
-  VisitDesc* activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
+  GP<Rec> ev;                  // expanded events (MSG/TASK/PERIODIC form) in global event order
+  GP<EvAux> evAux;
+  GP<EvRes> evRes;
+  GP<uint32_t> evRecOff;       // exclusive scans of nrec / ndraw in event order
+  GP<uint32_t> evDrawOff;
+  GP<int32_t> evNext;          // per-node inbox as a linked list through the events
+  GP<int32_t> head;            // [n] newest event of the node this ms, -1 = none
+  GP<uint32_t> active;         // nodes with >= 1 event (unordered)
+  GP<VisitDesc> activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
   uint32_t maxOut;
-  Out* outTmp;              // per-event slices (see Out)
-  uint32_t* recEv;          // event of each ordered outbox position
-  Rec* fin;                 // ordered outbox
-  int32_t* arr;             // arrival per ordered record, -1 = dropped at send time
+  GP<Out> outTmp;              // per-event slices (see Out)
+  GP<uint32_t> recEv;          // event of each ordered outbox position
+  GP<Rec> fin;                 // ordered outbox
+  GP<int32_t> arr;             // arrival per ordered record, -1 = dropped at send time
   // protocol emission bounds used by expand to size the per-event outbox slices
   uint32_t boundMsg;        // max records a delivered message's action() can emit
   uint32_t boundTask[4];    // ... a task's action(), by task word (words >= 3 use [3])
   // multisplit scratch
-  uint32_t* tileHist;       // [maxTiles][D]
-  uint32_t* binBase;        // [D] position of this phase's first record inside each bucket
+  GP<uint32_t> tileHist;       // [maxTiles][D]
+  GP<uint32_t> binBase;        // [D] position of this phase's first record inside each bucket
   // scan scratch
-  unsigned long long* scanPartials;
+  GP<unsigned long long> scanPartials;
   // node-range sharding of ONE simulation over several engines (wg_shard_configure): the scheduler state above
   // is replicated on every shard and evolves identically; node / protocol state is touched only for the nodes
   // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.
   uint32_t sharded;
   int32_t shardLo, shardHi;
-  int32_t* xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1); preceded by
+  GP<int32_t> xbuf;            // [maxOut][5] exchange image of the ordered outbox: Rec words + (arrival + 1); preceded by
                             // XB_HEAD header words (xbuf[-XB_HEAD] = multi-destination envelopes among the records),
                             // which travel in the same all-reduce
-  int32_t* xmulti;          // [maxMulti][XM_WORDS] exchange image of the multi-destination envelopes of a phase
+  GP<int32_t> xmulti;          // [maxMulti][XM_WORDS] exchange image of the multi-destination envelopes of a phase
   uint32_t maxMulti;
-  uint32_t* multiK;         // [maxOut] ordinal of a fresh multi-destination record / offset of its destinations
-  uint32_t* multiOff;
+  GP<uint32_t> multiK;         // [maxOut] ordinal of a fresh multi-destination record / offset of its destinations
+  GP<uint32_t> multiOff;
   // where action() code parks the (unsorted) destination list of a multi-destination send until `resolve`:
   // the envelope ring itself, or — sharded, where that ring is replicated state — a private scratch ring
-  int32_t* sdests;
+  GP<int32_t> sdests;
   unsigned long long sdestCap;
   // Network.sendAll issued by an action() (O_SENDALL): every node is a destination, so the envelope is resolved by
   // k_sendall_* after `resolve` (one descriptor per call, latency scratch and tile histograms per descriptor);
   // maxSendAll == 0: the resident protocol never calls it
-  struct SendAllDesc* saDesc;
-  int32_t* saLat;           // [maxSendAll][n]
-  uint32_t* saHist;         // [maxSendAll][tiles(n)][D]
+  GP<SendAllDesc> saDesc;
+  GP<int32_t> saLat;           // [maxSendAll][n]
+  GP<uint32_t> saHist;         // [maxSendAll][tiles(n)][D]
   uint32_t maxSendAll;
   uint32_t saBins;          // latency bins of saHist (<= horizon): max latency of the model + 1, rounded up to 64
-  struct FarRec* farBuf;    // NULL: arrivals beyond the ring are an error
+  GP<FarRec> farBuf;    // NULL: arrivals beyond the ring are an error
   uint32_t farCap;
   // chain runs (consecutive hops of one multi-destination envelope arriving in the same ms) of >= runMin hops are
   // not unrolled by the lane that scans their bucket record but listed here and unrolled one wavefront per run by
   // k_expand_runs (a sendAll to N nodes has runs of ~N/300 hops: Casper). runMin == 0: every run is unrolled in place
-  struct RunDesc* runs;
+  GP<RunDesc> runs;
   uint32_t maxRuns;
   uint32_t runMin;
 };

@@ -15,7 +15,7 @@ namespace wg {
 // PingPong (P/PingPong.java:20-32,60-74): Ping -> send(Pong) to the sender; Pong -> pong++.
 struct PingPongProto {
   struct State {
-    int32_t* pong;
+    GP<int32_t> pong;
   };
   struct WaveShared {
     int unused;
@@ -826,7 +826,7 @@ void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int
   WG_HIP(hipStreamSynchronize(stream));
   {  // (ERR_HORIZON from a latency beyond the bucket ring)
     uint32_t err = 0;
-    WG_HIP(hipMemcpy(&err, (const char*)dev.g + offsetof(Globals, err), 4, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(&err, (const char*)dev.g.raw + offsetof(Globals, err), 4, hipMemcpyDeviceToHost));
     if (err) {
       gh.err |= err;
       check_device_errors();
@@ -1140,13 +1140,13 @@ void Engine::collect_far() {
   if (!dev.farBuf) return;
   WG_HIP(hipStreamSynchronize(stream));
   uint32_t n = 0;
-  WG_HIP(hipMemcpy(&n, (const char*)dev.g + offsetof(Globals, nFar), 4, hipMemcpyDeviceToHost));
+  WG_HIP(hipMemcpy(&n, (const char*)dev.g.raw + offsetof(Globals, nFar), 4, hipMemcpyDeviceToHost));
   if (!n) return;
   if (n > dev.farCap) throw WgError(WG_ENOMEM, "more envelopes registered beyond horizon_ms than the far buffer holds");
   std::vector<FarRec> recs(n);
   WG_HIP(hipMemcpy(recs.data(), dev.farBuf, sizeof(FarRec) * n, hipMemcpyDeviceToHost));
   const uint32_t zero = 0;
-  WG_HIP(hipMemcpy((char*)dev.g + offsetof(Globals, nFar), &zero, 4, hipMemcpyHostToDevice));
+  WG_HIP(hipMemcpy((char*)dev.g.raw + offsetof(Globals, nFar), &zero, 4, hipMemcpyHostToDevice));
   std::sort(recs.begin(), recs.end(), [](const FarRec& a, const FarRec& b) { return a.ms != b.ms ? a.ms < b.ms : a.p < b.p; });
   for (const FarRec& r : recs) {
     staged.push_back({r.arrival, r.rec});
@@ -1425,7 +1425,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   Group g = self();
   auto t0 = std::chrono::steady_clock::now();
   auto gfield = [&](uint32_t Globals::*field) {
-    return (const uint32_t*)((const char*)dev.g + ((const char*)&(gh.*field) - (const char*)&gh));
+    return (const uint32_t*)((const char*)dev.g.raw + ((const char*)&(gh.*field) - (const char*)&gh));
   };
   for (int32_t k = 0; k <= ms; k++) {
     const int32_t t = time + k;
@@ -2145,7 +2145,7 @@ struct HandelHost : ProtoHost {
     e.shard_allreduce(st.candCnt, ((int64_t)st.N + 3) / 4);
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
-    e.await_counts((const uint32_t*)((const char*)e.dev.g + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
+    e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
     hipLaunchKernelGGL(k_handel_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
     WG_HIP(hipMemsetAsync(st.candCnt, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' counts
     return nOut;
@@ -2433,7 +2433,7 @@ struct GsfHost : ProtoHost {
     e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
     Engine::scan<GsfCondF>(g, stab);
     uint32_t nOut = 0;
-    e.await_counts((const uint32_t*)((const char*)e.dev.g + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
+    e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
     hipLaunchKernelGGL(k_gsf_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
     WG_HIP(hipMemsetAsync(st.candFlag, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' flags
     return nOut;

@@ -58,7 +58,25 @@ namespace wg {
 #define WG_READFIRST(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #endif
 
-__device__ __forceinline__ void set_err(Globals* g, uint32_t bit) { atomicOr(&g->err, bit); }
+// whole records to / from global memory (a struct's copy constructor takes a generic reference: the copy goes through
+// memcpy, which the compiler turns into the widest global_load / global_store the alignment allows)
+template <class T>
+__device__ __forceinline__ T gld(const T WG_G* p) {
+  T v;
+  __builtin_memcpy(&v, p, sizeof(T));
+  return v;
+}
+template <class T>
+__device__ __forceinline__ void gst(T WG_G* p, const T& v) {
+  __builtin_memcpy(p, &v, sizeof(T));
+}
+// generic view of a global pointer, for the atomic builtins (the compiler still sees where it came from: global_atomic_*)
+template <class T>
+__device__ __forceinline__ T* F(T WG_G* p) {
+  return (T*)p;
+}
+
+__device__ __forceinline__ void set_err(Globals WG_G* g, uint32_t bit) { atomicOr(F(&g->err), bit); }
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
   uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
@@ -285,7 +303,7 @@ template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
   const F f(d, atab ? atab + blockIdx.y : nullptr);
-  unsigned long long* partials = d.scanPartials;
+  unsigned long long WG_G* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
   scan_range(n, lo, hi);
@@ -302,7 +320,7 @@ template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
   const F f(d, atab ? atab + blockIdx.y : nullptr);
-  const unsigned long long* partials = d.scanPartials;
+  const unsigned long long WG_G* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   __shared__ uint64_t shw[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
@@ -1261,7 +1279,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __res
 __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
   WG_ENGINE(tab);
   __shared__ uint32_t shTop;
-  Globals* g = d.g;
+  Globals WG_G* g = d.g;
   const int32_t t = g->now;
   if (threadIdx.x == 0) {
     shTop = g->freeTop;
@@ -1331,7 +1349,7 @@ __global__ void __launch_bounds__(256) k_next_busy(const EngineDev* __restrict__
 }
 __global__ void __launch_bounds__(256) k_skip_idle(const EngineDev* __restrict__ tab, int32_t n) {
   WG_ENGINE(tab);
-  Globals* g = d.g;
+  Globals WG_G* g = d.g;
   const uint32_t D = (uint32_t)d.horizon;
   const int32_t t = g->now;
   const unsigned long long dh = g->destHead, ph = g->payloadHead;
@@ -1790,8 +1808,8 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
 // 4 events go to activeB for k_deliver. Protocols opt in with P::LANE_MSGS and provide
 //   LaneNode, lane_begin / lane_message / lane_end     (action() of a message that emits nothing)
 struct CopyJob {
-  const uint64_t* src;
-  uint64_t* dst;
+  const uint64_t WG_G* src;
+  uint64_t WG_G* dst;
   int32_t nw;
   int32_t pad;
 };
@@ -1816,14 +1834,20 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     // the node's events, sorted by event index (the inbox list is in link order)
     uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
     bool mine = have;
-    VisitDesc vd;
-    vd.node = node;
-    vd.flags = 0;
+    // (the first event's record as plain locals: a VisitDesc filled piecemeal inside the loop would live in scratch memory)
+    uint32_t vflags = 0;
+    int32_t e0 = -1, next0 = -1;
+    Rec rec0 = make_rec(K_MSG, 0, 0, 0, 0);
+    EvAux aux0;
+    aux0.chain = -1;
+    aux0.cpos = 0;
+    aux0.outBase = 0;
+    aux0.outCap = 0;
     if (have) {
       int32_t e = d.head[node];
       d.head[node] = -1;  // the list is consumed here (k_deliver works from the descriptor and evNext)
-      vd.flags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
-      vd.e0 = e;
+      vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
+      e0 = e;
       int cnt = 0;
       while (e >= 0 && cnt < 4) {
         uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
@@ -1831,13 +1855,13 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
         if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
         if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
-        const Rec rc = d.ev[e];
-        const EvAux ax = d.evAux[e];
+        const Rec rc = gld(d.ev + e);
+        const EvAux ax = gld(d.evAux + e);
         const int32_t nx = d.evNext[e];
         if (cnt == 0) {
-          vd.rec0 = rc;
-          vd.aux0 = ax;
-          vd.next0 = nx;
+          rec0 = rc;
+          aux0 = ax;
+          next0 = nx;
         }
         if (rec_kind(rc) != K_MSG || ax.chain >= 0) mine = false;
         cnt++;
@@ -1851,14 +1875,23 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       if (m) {
         uint32_t bb = 0;
         const int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane == leader) bb = atomicAdd(&d.g->nActiveB, (uint32_t)__popcll(m));
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
         bb = lane_bcast(bb, leader);
-        if (toB) d.activeB[bb + __popcll(m & lanes_lt())] = vd;
+        if (toB) {
+          VisitDesc vd;
+          vd.node = node;
+          vd.e0 = e0;
+          vd.next0 = next0;
+          vd.flags = vflags;
+          vd.rec0 = rec0;
+          vd.aux0 = aux0;
+          gst(d.activeB + (bb + __popcll(m & lanes_lt())), vd);
+        }
       }
     }
     typename P::LaneNode r;
-    const bool toDown = (vd.flags & VD_DOWN) != 0;
-    const uint8_t toPart = (uint8_t)(vd.flags >> 8);
+    const bool toDown = (vflags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vflags >> 8);
     KPROF_MARK(d.g, 25);  // inbox walk + classification
     if (mine) P::lane_begin(d, ps, node, r);
     long long nRecv = 0, bRecv = 0;
@@ -1911,7 +1944,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i0 = 0; i0 < totalWords; i0 += 256) {
       uint64_t v[4];
-      uint64_t* dp[4];
+      uint64_t WG_G* dp[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
@@ -1952,7 +1985,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
 __global__ void k_chunk_begin(EngineDev* tab, int32_t ms) {
   EngineDev& d = tab[blockIdx.x];
   if (d.halted || threadIdx.x != 0) return;
-  Globals* g = d.g;
+  Globals WG_G* g = d.g;
   const int32_t time = g->until;  // Network.time after the previous runMs
   const int32_t endAt = (int32_t)((uint32_t)time + (uint32_t)ms);
   if (endAt <= 0) {  // "Maximum time reached!" (:333) — stop the member; the host reports it
@@ -1968,7 +2001,7 @@ __global__ void k_chunk_begin(EngineDev* tab, int32_t ms) {
 __global__ void k_chunk_end(EngineDev* tab, const uint32_t* cont, int32_t maxTime, uint32_t* running) {
   EngineDev& d = tab[blockIdx.x];
   if (d.halted || threadIdx.x != 0) return;
-  const Globals* g = d.g;
+  const Globals WG_G* g = d.g;
   const bool goOn = (maxTime == 0 || g->until < maxTime) && (!g->anyEvent || cont[blockIdx.x] != 0) && g->err == 0;
   if (!goOn)
     d.halted = 1;

@@ -26,18 +26,18 @@ constexpr uint32_t C_MSG_BLOCK = 0, C_MSG_ATTESTATION = 1;
 struct CasperState {
   wg_casper_params p;
   int32_t N, B, A, Aw, Bw;
-  int32_t* head;        // [N] block index
-  uint64_t* recv;       // [N][Aw]
-  uint64_t* blkRecv;    // [N][Bw] blocksReceivedByBlockId
-  uint64_t* reeval;     // [N][Bw] blocksToReevaluate
-  uint64_t* headsAtt;   // [N][Bw] keys of attestationsByHead
-  int32_t* wf;          // ByzBlockProducerWF (node 1): toSend, late, onTime
-  int32_t *bHeight, *bParent, *bProducer, *bTime;  // [B]
-  uint32_t* nBlocks;    // [1]
-  int32_t* lastBlockMs; // [1]
-  uint64_t *blockAtt, *headMask, *attestsMask;     // [B][Aw]
-  int32_t* attHead;     // [A]
-  uint8_t* mixed;       // [N] this ms the node has an event that is not an attestation (block, task): ordered visit
+  GP<int32_t> head;        // [N] block index
+  GP<uint64_t> recv;       // [N][Aw]
+  GP<uint64_t> blkRecv;    // [N][Bw] blocksReceivedByBlockId
+  GP<uint64_t> reeval;     // [N][Bw] blocksToReevaluate
+  GP<uint64_t> headsAtt;   // [N][Bw] keys of attestationsByHead
+  GP<int32_t> wf;          // ByzBlockProducerWF (node 1): toSend, late, onTime
+  GP<int32_t> bHeight, bParent, bProducer, bTime;  // [B]
+  GP<uint32_t> nBlocks;    // [1]
+  GP<int32_t> lastBlockMs; // [1]
+  GP<uint64_t> blockAtt, headMask, attestsMask;     // [B][Aw]
+  GP<int32_t> attHead;     // [A]
+  GP<uint8_t> mixed;       // [N] this ms the node has an event that is not an attestation (block, task): ordered visit
   uint32_t laneEvents;  // 1: attestation-only nodes are delivered one lane per event (k_casper_attestations)
 };
 
@@ -64,10 +64,10 @@ struct CasperProto {
     if (mixed && WG_LANE == 0) s.mixed[node] = 0;
     return !mixed;
   }
-  __device__ static uint64_t ldc(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ static int32_t ldi(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ static bool bit(const uint64_t* row, int32_t i) { return (ldc(row + (i >> 6)) >> (i & 63)) & 1ULL; }
-  __device__ static void set_bit(uint64_t* row, int32_t i) {  // one lane
+  __device__ static uint64_t ldc(const uint64_t WG_G* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ static int32_t ldi(const int32_t WG_G* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ static bool bit(const uint64_t WG_G* row, int32_t i) { return (ldc(row + (i >> 6)) >> (i & 63)) & 1ULL; }
+  __device__ static void set_bit(uint64_t WG_G* row, int32_t i) {  // one lane
     row[i >> 6] |= 1ULL << (i & 63);
   }
   // bits [lo, hi) of word w
@@ -90,7 +90,7 @@ struct CasperProto {
   }
   // countAttestations(start, h) :241-266
   __device__ static int count_attestations(Ctx& c, const State& s, int32_t start, int32_t h) {
-    const uint64_t* rv = s.recv + (size_t)c.node * s.Aw;
+    const uint64_t WG_G* rv = s.recv + (size_t)c.node * s.Aw;
     const int32_t hh = ldi(s.bHeight + h);
     const int64_t pr = s.p.attestersPerRound;
     int cnt = 0;
@@ -127,7 +127,7 @@ struct CasperProto {
     return b1 >= b2 ? o1 : o2;  // (randomOnTies is refused at load time)
   }
   __device__ static void reevaluate_head(Ctx& c, const State& s, NodeRegs& r) {  // :349-356, ascending block id
-    uint64_t* re = s.reeval + (size_t)c.node * s.Bw;
+    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.Bw;
     for (int w = 0; w < s.Bw; w++) {
       uint64_t m = ldc(re + w);
       while (m) {
@@ -144,10 +144,10 @@ struct CasperProto {
   __device__ static int32_t build_block(Ctx& c, const State& s, int32_t base, int32_t height) {
     int32_t idx = 0;
     if (WG_LANE == 0) {
-      idx = (int32_t)atomicAdd(s.nBlocks, 1u);
+      idx = (int32_t)atomicAdd(F(s.nBlocks + 0), 1u);
       // two blocks in one ms: valid in the reference (e.g. a delayed byzantine build landing on another producer's slot),
       // not resident — block ids are creation order and two wavefronts of one launch have none: its own error
-      if (atomicExch(s.lastBlockMs, c.t) == c.t) set_err(c.d.g, ERR_SAME_MS_BLOCKS);
+      if (atomicExch(F(s.lastBlockMs + 0), c.t) == c.t) set_err(c.d.g, ERR_SAME_MS_BLOCKS);
       if (idx >= s.B || height <= 0 || c.t < ldi(s.bTime + base) || ldi(s.bHeight + base) >= height)
         set_err(c.d.g, idx >= s.B ? ERR_PAYLOAD : ERR_PROTOCOL);  // table full / Block's ctor checks :36-47
       if (idx >= s.B) idx = s.B - 1;
@@ -158,7 +158,7 @@ struct CasperProto {
     }
     idx = __shfl(idx, 0, 64);
     const int cl = s.p.cycleLength;
-    const uint64_t* rv = s.recv + (size_t)c.node * s.Aw;
+    const uint64_t WG_G* rv = s.recv + (size_t)c.node * s.Aw;
     for (int w = WG_LANE; w < s.Aw; w += 64) {
       uint64_t all = 0, res = 0;
       for (int32_t cur = base; cur != 0 && ldi(s.bHeight + cur) >= height - cl; cur = ldi(s.bParent + cur))
@@ -197,8 +197,8 @@ struct CasperProto {
   }
   // BlockChainNode.onBlock :29-47 under CasperNode.onBlock :276-292 (delta >= 0 always: the formula adds the slot time)
   __device__ static bool on_block(Ctx& c, const State& s, NodeRegs& r, int32_t b) {
-    uint64_t* re = s.reeval + (size_t)c.node * s.Bw;
-    uint64_t* br = s.blkRecv + (size_t)c.node * s.Bw;
+    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.Bw;
+    uint64_t WG_G* br = s.blkRecv + (size_t)c.node * s.Bw;
     const bool known = bit(br, b);
     __builtin_amdgcn_wave_barrier();
     if (WG_LANE == 0) {

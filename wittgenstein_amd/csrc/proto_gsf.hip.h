@@ -35,34 +35,34 @@ enum GsfKind : uint32_t { GK_PARTIAL = 0, GK_FULL = 1, GK_OVER = 2, GK_INDIV = 3
 struct GsfState {
   wg_gsf_params p;
   int32_t N, L, W, Q, SW;             // SW = payload slot size in 64-bit words (largest level block)
-  uint64_t *V, *IS, *IV;              // [N][W]
-  int32_t* peers;                     // [N][N-1] SFLevel.peers, level l at [2^(l-1)-1, 2^l-1)
-  int32_t *pairing, *sigChecked, *sigQueueSize, *tvLen;  // [N]
-  int32_t* ctMinStart;                // ConditionalTask.minStartTime
-  uint32_t* ctEpoch;                  // epoch in which the task left nextMessage()'s private copy
-  int32_t *pos, *rem, *cV, *cIV, *cU; // [N][L] posInLevel, remainingCalls, |V|, |IV|, |V u IV| inside the level block
-  uint64_t* tvEnt;                    // [N][Q] toVerify, list order
-  uint64_t* tvUsed;                   // [N][Q/64] payload slots in use
-  uint64_t* tvSig;                    // [N][Q][SW]
+  GP<uint64_t> V, IS, IV;              // [N][W]
+  GP<int32_t> peers;                     // [N][N-1] SFLevel.peers, level l at [2^(l-1)-1, 2^l-1)
+  GP<int32_t> pairing, sigChecked, sigQueueSize, tvLen;  // [N]
+  GP<int32_t> ctMinStart;                // ConditionalTask.minStartTime
+  GP<uint32_t> ctEpoch;                  // epoch in which the task left nextMessage()'s private copy
+  GP<int32_t> pos, rem, cV, cIV, cU; // [N][L] posInLevel, remainingCalls, |V|, |IV|, |V u IV| inside the level block
+  GP<uint64_t> tvEnt;                    // [N][Q] toVerify, list order
+  GP<uint64_t> tvUsed;                   // [N][Q/64] payload slots in use
+  GP<uint64_t> tvSig;                    // [N][Q][SW]
   // doCycle snapshots (SendSigs.sigs = toSend.clone() :146): one doCycle per node and period window, so the
   // snapshot of level l lives at snap[((t / period) % snapNb) * N + node][lvlOff[l] ...] (no allocation)
-  uint64_t* snap;
+  GP<uint64_t> snap;
   uint32_t snapNb, snapStride;
   uint32_t lvlOff[MAX_LEVELS];
-  uint32_t* pend;                     // [N][G_PEND] valid<<31 | kind<<29 | level<<24 | slot or j
-  int32_t* pendFrom;                  // [N][G_PEND]
+  GP<uint32_t> pend;                     // [N][G_PEND] valid<<31 | kind<<29 | level<<24 | slot or j
+  GP<int32_t> pendFrom;                  // [N][G_PEND]
   // conditional-task phase scratch
-  uint32_t* runList;                  // nodes whose checkSigs runs at this edge (unordered)
-  uint32_t* runCount;
-  uint8_t* candFlag;                  // [N] checkSigs found a best -> registers a task
-  uint8_t* candPend;                  // [N] its pend index
-  uint32_t* condList;                 // registering nodes in id order
+  GP<uint32_t> runList;                  // nodes whose checkSigs runs at this edge (unordered)
+  GP<uint32_t> runCount;
+  GP<uint8_t> candFlag;                  // [N] checkSigs found a best -> registers a task
+  GP<uint8_t> candPend;                  // [N] its pend index
+  GP<uint32_t> condList;                 // registering nodes in id order
   // node-range sharding (wg_shard_configure): the rows V / IS / IV, peers and the toVerify storage are held for
   // the nodes [lo, hi) only (pointers biased by -lo rows); 0 / N when not sharded. Snapshot exchange as Handel's.
   int32_t lo, hi;
-  uint32_t* snapIdx;
-  uint32_t* nSnap;
-  int32_t* xsnap;
+  GP<uint32_t> snapIdx;
+  GP<uint32_t> nSnap;
+  GP<int32_t> xsnap;
   uint32_t xsnapRows;
 };
 __device__ __forceinline__ int32_t snap_period(const GsfState& s) { return s.p.periodDurationMs; }
@@ -165,7 +165,7 @@ struct GsfProto {
       update_verified(c, s, r, arg);
   }
 
-  __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int slot) {
+  __device__ static uint64_t WG_G* sig_ptr(const State& s, int32_t node, int slot) {
     return s.tvSig + ((size_t)node * s.Q + slot) * (size_t)s.SW;
   }
   // first incomplete level (levels below it form getLastFinishedLevel :194-211); L if every level is complete
@@ -187,7 +187,7 @@ struct GsfProto {
     uint32_t aux = (msg >> 8) & 31u;
     const int32_t node = c.node;
     GLevels* ls = r.ls;
-    uint64_t* isRow = s.IS + (size_t)node * s.W;
+    uint64_t WG_G* isRow = s.IS + (size_t)node * s.W;
     const bool hadIS = row_get(isRow, from);
     const int len = r.tvLen;
     const int need = hadIS ? 1 : 2;
@@ -206,15 +206,15 @@ struct GsfProto {
         return;
       }
       const Lv v = sib_view(node, l);
-      const uint64_t* src = s.snap + payload;
-      uint64_t* dst = sig_ptr(s, node, slot);
+      const uint64_t WG_G* src = s.snap + payload;
+      uint64_t WG_G* dst = sig_ptr(s, node, slot);
       H_FOR_WORDS(v, j) dst[j] = src[j];
       __builtin_amdgcn_wave_barrier();  // every lane has read the slot bitmap before lane 0 changes it
       if (WG_LANE == 0) ls->used[slot >> 6] |= 1ULL << (slot & 63);
       aux = (uint32_t)slot;
     }
     if (WG_LANE == 0) {
-      uint64_t* ent = s.tvEnt + (size_t)node * s.Q;
+      uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
       ent[len] = g_ent(from, l, kind, aux);                         // toVerify.add(ssigs)
       if (!hadIS) ent[len + 1] = g_ent(from, l, GK_INDIV, 0);       // the individual signature (:547-553)
     }
@@ -240,7 +240,7 @@ struct GsfProto {
       uint32_t ref = 0;
       if (k < l) {  // PARTIAL: snapshot the verified bits of the levels below l (the node's own block)
         const Lv v = own_view(node, l);
-        const uint64_t* vr = s.V + (size_t)node * s.W;
+        const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
         const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
         ref = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride + s.lvlOff[l];
         H_FOR_WORDS(v, j) s.snap[ref + j] = vr[v.bw + j] & v.mask;
@@ -258,22 +258,31 @@ struct GsfProto {
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int lane = WG_LANE;
     const int32_t node = c.node;
-    const uint32_t pe = r.pend[arg & (G_PEND - 1)];
-    const int32_t from = r.pendFrom[arg & (G_PEND - 1)];
+    // (selects, not r.pend[arg & 3]: a register array indexed at run time puts the whole NodeRegs — and the LDS pointer in
+    // it — in scratch memory; every access to a node scalar is then a memory round trip and every LDS access a FLAT one)
+    const int pk = (int)(arg & (G_PEND - 1));
+    uint32_t pe = r.pend[0];
+    int32_t from = r.pendFrom[0];
+#pragma unroll
+    for (int k = 1; k < G_PEND; k++) {
+      pe = pk == k ? r.pend[k] : pe;
+      from = pk == k ? r.pendFrom[k] : from;
+    }
     if (!(pe & 0x80000000u)) {
       if (lane == 0) set_err(c.d.g, ERR_PROTOCOL);
       return;
     }
-    r.pend[arg & (G_PEND - 1)] = 0;
+#pragma unroll
+    for (int k = 0; k < G_PEND; k++) r.pend[k] = pk == k ? 0u : r.pend[k];
     const uint32_t kind = (pe >> 29) & 3u;
     const int l = (int)((pe >> 24) & 31u);
     const uint32_t aux = pe & 0xFFFFu;
     GLevels* ls = r.ls;
     const Lv v = sib_view(node, l);
     const int size = v.size;
-    uint64_t* vr = s.V + (size_t)node * s.W;
-    uint64_t* ivr = s.IV + (size_t)node * s.W;
-    const uint64_t* sig = kind == GK_PARTIAL ? sig_ptr(s, node, (int)aux) : nullptr;
+    uint64_t WG_G* vr = s.V + (size_t)node * s.W;
+    uint64_t WG_G* ivr = s.IV + (size_t)node * s.W;
+    const uint64_t WG_G* sig = kind == GK_PARTIAL ? sig_ptr(s, node, (int)aux) : nullptr;
     const int wF = from >> 6, jF = wF - v.bw;
     const uint64_t bitF = 1ULL << (from & 63);
     // word j of the signature set, as held by the lane that owns row word v.bw + j
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restric
     if (m) {
       uint32_t base = 0;
       const int leader = __ffsll((unsigned long long)m) - 1;
-      if ((int)WG_LANE == leader) base = atomicAdd(s.runCount, (uint32_t)__popcll(m));
+      if ((int)WG_LANE == leader) base = atomicAdd(F(s.runCount + 0), (uint32_t)__popcll(m));
       base = __shfl(base, leader, 64);
       if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
     }
@@ -433,9 +442,9 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
   for (uint32_t q = wave; q < nRun; q += nWaves) {
     const int32_t node = (int32_t)s.runList[q];
     GsfProto::load_levels(s, node, ls);
-    const uint64_t* vr = s.V + (size_t)node * s.W;
-    const uint64_t* ivr = s.IV + (size_t)node * s.W;
-    uint64_t* ent = s.tvEnt + (size_t)node * s.Q;
+    const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
+    const uint64_t WG_G* ivr = s.IV + (size_t)node * s.W;
+    uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
     const int len = s.tvLen[node];
     int bestScore = 0, bestIdx = -1;
     uint64_t bestEnt = 0;
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
         const int el = __shfl(l, src, 64);
         const int eslot = (int)__shfl(aux, src, 64);
         const Lv ev = sib_view(node, el);
-        const uint64_t* sig = GsfProto::sig_ptr(s, node, eslot);
+        const uint64_t WG_G* sig = GsfProto::sig_ptr(s, node, eslot);
         uint64_t a = 0, f = 0;
         H_FOR_WORDS(ev, j) {
           const uint64_t sg = sig[j], vw = vr[ev.bw + j], iw = ivr[ev.bw + j];
@@ -610,7 +619,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict
       const bool ok = arrival - t < d.horizon - 1;
       if (!ok) set_err(d.g, ERR_HORIZON);
       if (SH) {
-        int32_t* x = d.xbuf + (size_t)j * 5;
+        int32_t WG_G* x = d.xbuf + (size_t)j * 5;
         x[0] = (int32_t)fin.w0;
         x[1] = (int32_t)fin.w1;
         x[2] = (int32_t)fin.w2;

@@ -26,12 +26,12 @@ constexpr uint32_t H_TASK_UPDATE = 1;
 struct HandelState {
   wg_handel_params p;
   int32_t N, L, W, Q;
-  uint64_t *TI, *LA, *VI, *TV, *FP;   // [N][W]
-  int32_t* ranks;                      // [N][N]
+  GP<uint64_t> TI, LA, VI, TV, FP;   // [N][W]
+  GP<int32_t> ranks;                      // [N][N]
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
-  const uint16_t* peers16;
-  const int32_t* peers32;
+  GP<const uint16_t> peers16;
+  GP<const int32_t> peers32;
   // toVerifyAgg slots per (node, level): Q for the levels whose block is below 16 words, Qw (wg_config.queue_cap_wide)
   // for the wide ones — their queues stay short (a few entries: one sender per period and level) while a slot is up to
   // 2 KB, so a flat capacity spent gigabytes on slots that are never used
@@ -51,32 +51,32 @@ struct HandelState {
   //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L levels.
   //                              An event works on ONE level: the record goes back as the few 16-byte pieces that
   //                              changed (store_levels), i.e. the scalars' line and the level's, not all ten lines
-  uint32_t* hdr;
+  GP<uint32_t> hdr;
   int32_t LS, lsShift, hdrStride;
-  uint64_t* qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
-  int32_t* qfrom;                      // [N][L][Q]
-  uint64_t* qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
+  GP<uint64_t> qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
+  GP<int32_t> qfrom;                      // [N][L][Q]
+  GP<uint64_t> qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
   // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
   // per aligned window of `period` ms, so its snapshot lives at a computed address — no allocation:
   //   snap[((t / period) % snapNb) * N + node][0 .. snapStride)   the own block of the highest open level;
   //   the lower levels' blocks are sub-ranges of it (see dissemination)
-  uint64_t* snap;
+  GP<uint64_t> snap;
   uint32_t snapNb, snapStride;
   // conditional-task phase scratch
-  uint32_t* runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
-  uint32_t* runCount;                  // [1]
-  uint8_t* candCnt;                    // [N] number of levels with a candidate
-  uint32_t* condOrd;                   // [N] ordinal among drawing nodes
-  uint32_t* condList;                  // drawing nodes in id order
-  int32_t* drawVal;                    // [N]
+  GP<uint32_t> runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
+  GP<uint32_t> runCount;                  // [1]
+  GP<uint8_t> candCnt;                    // [N] number of levels with a candidate
+  GP<uint32_t> condOrd;                   // [N] ordinal among drawing nodes
+  GP<uint32_t> condList;                  // drawing nodes in id order
+  GP<int32_t> drawVal;                    // [N]
   // node-range sharding (wg_shard_configure): this engine holds the per-node rows above only for the nodes
   // [lo, hi) (the row pointers are biased so that they are still indexed by node id); 0 / N when not sharded
   int32_t lo, hi;
-  const uint64_t* ones;                // [W] all-ones words: the payload of a sharded fast-path send (see snapshot_outgoing)
-  uint32_t* snapIdx;                   // [maxEvents] row of a dissemination event in the snapshot exchange image
-  uint32_t* nSnap;                     // [1]
-  int32_t* xsnap;                      // [xsnapRows][snapStride * 2] exchange image of this ms's dissemination snapshots
+  GP<const uint64_t> ones;                // [W] all-ones words: the payload of a sharded fast-path send (see snapshot_outgoing)
+  GP<uint32_t> snapIdx;                   // [maxEvents] row of a dissemination event in the snapshot exchange image
+  GP<uint32_t> nSnap;                     // [1]
+  GP<int32_t> xsnap;                      // [xsnapRows][snapStride * 2] exchange image of this ms's dissemination snapshots
   uint32_t xsnapRows;
 };
 
@@ -84,8 +84,8 @@ enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_
                        HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
                        HH_PENDFROM = 16, HH_CAND = 20, HH_LV = 32 };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
-__device__ __forceinline__ uint32_t* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
-__device__ __forceinline__ uint32_t* h_lv(const HandelState& s, int32_t node, int plane, int l) {
+__device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
+__device__ __forceinline__ uint32_t WG_G* h_lv(const HandelState& s, int32_t node, int plane, int l) {
   return s.hdr + (size_t)node * s.hdrStride + HH_LV + l * HP_COUNT + plane;
 }
 
@@ -128,11 +128,11 @@ __device__ __forceinline__ int h_msg_size(int l) { return 1 + ((l == 0 ? 1 : (1 
 #define H_FOR_WORDS(v, j)                                                                      \
   for (int j = (int)((WG_LANE - (v).bw) & 63); j < (v).nw; j += 64)
 
-__device__ __forceinline__ uint64_t ld_coherent(const uint64_t* p) {
+__device__ __forceinline__ uint64_t ld_coherent(const uint64_t WG_G* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool row_get(const uint64_t* row, int32_t id) { return (ld_coherent(row + (id >> 6)) >> (id & 63)) & 1ULL; }
-__device__ __forceinline__ void row_set(uint64_t* row, int32_t id, bool v) {
+__device__ __forceinline__ bool row_get(const uint64_t WG_G* row, int32_t id) { return (ld_coherent(row + (id >> 6)) >> (id & 63)) & 1ULL; }
+__device__ __forceinline__ void row_set(uint64_t WG_G* row, int32_t id, bool v) {
   int w = id >> 6;
   if ((int)WG_LANE == (w & 63)) {
     uint64_t x = row[w];
@@ -164,7 +164,7 @@ __device__ __forceinline__ void ls_set_qused(LevelScalars* ls, int l, unsigned l
 
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
 constexpr uint32_t H_REF_ONES = 0xFFFFFFFFu;  // payload ref: the all-ones block (fast-path sends of a sharded engine)
-__device__ __forceinline__ const uint64_t* h_payload(const EngineDev& d, const HandelState& s, uint32_t payload) {
+__device__ __forceinline__ const uint64_t WG_G* h_payload(const EngineDev& d, const HandelState& s, uint32_t payload) {
   if (payload & H_REF_RING) return payload == H_REF_ONES ? s.ones : d.payload + (payload & ~H_REF_RING);
   return s.snap + payload;
 }
@@ -192,7 +192,7 @@ struct HandelProto {
     U4 q0;
   };
   __device__ static Pre prefetch(const State& s, int32_t node) {
-    const U4* g = (const U4*)h_hdr(s, node);
+    const U4 WG_G* g = (const U4 WG_G*)h_hdr(s, node);
     const int n4 = s.hdrStride >> 2;
     Pre p;
     p.q0 = g[(int)WG_LANE < n4 ? (int)WG_LANE : 0];
@@ -291,7 +291,7 @@ struct HandelProto {
 
   // header <-> LDS image, 16 bytes a lane: 640 bytes (L <= 16) are one memory instruction
   __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
-    const U4* g = (const U4*)h_hdr(s, node);
+    const U4 WG_G* g = (const U4 WG_G*)h_hdr(s, node);
     __builtin_amdgcn_wave_barrier();
     for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) scatter_levels(s, ls, i, g[i]);
     __builtin_amdgcn_wave_barrier();
@@ -300,7 +300,7 @@ struct HandelProto {
   // its level's: the other lines of the record stay clean in L2 and are never written back to HBM)
   __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
     __builtin_amdgcn_wave_barrier();
-    U4* g = (U4*)h_hdr(s, node);
+    U4 WG_G* g = (U4 WG_G*)h_hdr(s, node);
     for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) {
       const U4 q = gather_levels(ls, i), o = ls->orig[i];
       if (q.x != o.x || q.y != o.y || q.z != o.z || q.w != o.w) g[i] = q;
@@ -316,7 +316,7 @@ struct HandelProto {
     uint32_t qmask, qmask0;
   };
   __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
-    const uint32_t* h = h_hdr(s, node);
+    const uint32_t WG_G* h = h_hdr(s, node);
     r.doneAt = (long long)((unsigned long long)h[HH_DONE_LO] | ((unsigned long long)h[HH_DONE_HI] << 32));
     r.startAt = (int32_t)h[HH_START];
     r.sigQueueSize = r.sigQueueSize0 = (int32_t)h[HH_SIGQ];
@@ -339,21 +339,21 @@ struct HandelProto {
     if (t < r.startAt) return;
     const int w = from >> 6;
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t* fpp = s.FP + (size_t)node * s.W + w;
-    const uint64_t* vip = s.VI + (size_t)node * s.W + w;
-    uint64_t* tvp = s.TV + (size_t)node * s.W + w;
+    uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
+    const uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
+    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
     const size_t nl = (size_t)node * s.L + l;
     // every load of the event before the first use
     const uint64_t viv = *vip;
     const uint64_t fpv = levelFinished ? *fpp : 0ULL;
     const uint64_t tvv = *tvp;
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
-    uint32_t* qlo = h_lv(s, node, HP_QUSED_LO, l);
-    uint32_t* qhi = h_lv(s, node, HP_QUSED_HI, l);
-    uint32_t* qln = h_lv(s, node, HP_QLEN, l);
+    uint32_t WG_G* qlo = h_lv(s, node, HP_QUSED_LO, l);
+    uint32_t WG_G* qhi = h_lv(s, node, HP_QUSED_HI, l);
+    uint32_t WG_G* qln = h_lv(s, node, HP_QLEN, l);
     const unsigned long long used = (unsigned long long)*qlo | ((unsigned long long)*qhi << 32);
     const int len = (int)*qln;
-    const uint64_t* src = h_payload(d, s, payload);
+    const uint64_t WG_G* src = h_payload(d, s, payload);
     const int nw = h_nw(l);
     const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
     if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
@@ -367,7 +367,7 @@ struct HandelProto {
       return;
     }
     const int slot = __ffsll(freeM) - 1;
-    uint64_t* dst = sig_ptr(s, node, l, slot);
+    uint64_t WG_G* dst = sig_ptr(s, node, l, slot);
     s.qfrom[nl * s.Q + slot] = from;
     s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
     if (slot < 32)
@@ -386,7 +386,7 @@ struct HandelProto {
   }
 
   // ---- queue helpers ---------------------------------------------------------------------------
-  __device__ static uint64_t* sig_ptr(const State& s, int32_t node, int l, int slot) {
+  __device__ static uint64_t WG_G* sig_ptr(const State& s, int32_t node, int l, int slot) {
     return s.qsig + s.qsigOff[l] + ((size_t)node * h_qcap(s, l) + slot) * (size_t)h_nw(l);
   }
   __device__ static bool slot_pending(const NodeRegs& r, int l, int slot) {
@@ -403,7 +403,7 @@ struct HandelProto {
     const int32_t node = c.node;
     const int size = 1 << (l - 1);
     const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
-    const uint64_t* fp = s.FP + (size_t)node * s.W;
+    const uint64_t WG_G* fp = s.FP + (size_t)node * s.W;
     int pos = ls->pos[l];
     const int start = pos;
     int got = 0;
@@ -457,7 +457,7 @@ struct HandelProto {
     // ring is private to the shard, sends that constant instead of a copy.
     if (c.d.sharded) return H_REF_ONES;
     Lv v = own_view(c.node, l);
-    const uint64_t* ti = s.TI + (size_t)c.node * s.W;
+    const uint64_t WG_G* ti = s.TI + (size_t)c.node * s.W;
     uint32_t ref = c.alloc_payload(v.nw);
     H_FOR_WORDS(v, j) c.d.payload[ref + j] = ti[v.bw + j] & v.mask;
     return ref | H_REF_RING;
@@ -478,13 +478,13 @@ struct HandelProto {
     // first use so the event costs ONE memory round trip (the path is latency-bound).
     const int w = from >> 6;
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t* fpp = s.FP + (size_t)node * s.W + w;
-    uint64_t* vip = s.VI + (size_t)node * s.W + w;
-    uint64_t* tvp = s.TV + (size_t)node * s.W + w;
+    uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
+    uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
+    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
     const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
     const Lv v = sib_view(node, l);
-    const uint64_t* src = h_payload(c.d, s, payload);
+    const uint64_t WG_G* src = h_payload(c.d, s, payload);
     const int j0 = (int)((WG_LANE - v.bw) & 63);
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
@@ -504,7 +504,7 @@ struct HandelProto {
       return;
     }
     int slot = __ffsll(freeM) - 1;
-    uint64_t* dst = sig_ptr(s, node, l, slot);
+    uint64_t WG_G* dst = sig_ptr(s, node, l, slot);
     if (has0) dst[j0] = pw0;
     for (int j = j0 + 64; j < v.nw; j += 64) dst[j] = src[j];
     __builtin_amdgcn_wave_barrier();  // every lane has read qused/qlen before lane 0 replaces them
@@ -562,7 +562,7 @@ struct HandelProto {
     const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
     const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
     {
-      const uint64_t* ti = s.TI + (size_t)node * s.W + tv.bw;
+      const uint64_t WG_G* ti = s.TI + (size_t)node * s.W + tv.bw;
       for (int j0 = 0; j0 < tv.nw; j0 += 256) {
         uint64_t v[4];
 #pragma unroll
@@ -622,16 +622,16 @@ struct HandelProto {
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
     const Lv v = sib_view(node, lv);
-    uint64_t* ti = s.TI + (size_t)node * s.W;
-    uint64_t* la = s.LA + (size_t)node * s.W;
-    uint64_t* vi = s.VI + (size_t)node * s.W;
-    const uint64_t* sig = sig_ptr(s, node, lv, slot);
+    uint64_t WG_G* ti = s.TI + (size_t)node * s.W;
+    uint64_t WG_G* la = s.LA + (size_t)node * s.W;
+    uint64_t WG_G* vi = s.VI + (size_t)node * s.W;
+    const uint64_t WG_G* sig = sig_ptr(s, node, lv, slot);
     // ---- every load of the event, issued before the first use (one memory round trip)
     const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t* tvp = s.TV + (size_t)node * s.W + wF;
+    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + wF;
     const uint64_t tvv = ld_coherent(tvp);
-    uint64_t* ent = s.qent + ((size_t)node * s.L + lv) * 64;
+    uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
     const int len = ls->qlen[lv];
     const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
     const int j0 = (int)((lane - v.bw) & 63);
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
     if (node < (uint32_t)s.hi) {
-      uint32_t* h = h_hdr(s, (int32_t)node);
+      uint32_t WG_G* h = h_hdr(s, (int32_t)node);
       if (!d.nodes.down[node] && h[HH_CTEPOCH] != epoch) {
         const int32_t ms = (int32_t)h[HH_CTMIN];
         if (ms <= until && ms <= t) {
@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     if (m) {
       uint32_t base = 0;
       const int leader = __ffsll((unsigned long long)m) - 1;
-      if ((int)WG_LANE == leader) base = atomicAdd(s.runCount, (uint32_t)__popcll(m));
+      if ((int)WG_LANE == leader) base = atomicAdd(F(s.runCount + 0), (uint32_t)__popcll(m));
       base = lane_bcast(base, leader);
       if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
     }
@@ -853,9 +853,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
     nodeNext = nodeNext2;
     hdrCur = hdrNext;
     KPROF_MARK(d.g, 17);  // header image (prefetched a runner ahead)
-    const uint64_t* ti = s.TI + (size_t)node * s.W;
-    const uint64_t* la = s.LA + (size_t)node * s.W;
-    const uint64_t* vi = s.VI + (size_t)node * s.W;
+    const uint64_t WG_G* ti = s.TI + (size_t)node * s.W;
+    const uint64_t WG_G* la = s.LA + (size_t)node * s.W;
+    const uint64_t WG_G* vi = s.VI + (size_t)node * s.W;
     const int window = (int)WG_READFIRST(ls->sc[HH_WINDOW]);
     int sigQueueSize = (int)WG_READFIRST(ls->sc[HH_SIGQ]);
     uint32_t pend[H_PEND];
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       lvMask &= lvMask - 1;
       const int len = ls->qlen[l];
       const Lv v = sib_view(node, l);
-      uint64_t* ent = s.qent + ((size_t)node * s.L + l) * 64;
+      uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
       const uint64_t myEnt = entNext;
       entNext = ~0ULL;
       if (lvMask) {
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
       for (int i = 0; i < len; i++) {
         const int slot = (int)lane_bcast((uint32_t)mySlot, i);
         const int rank = (int)lane_bcast((uint32_t)myRank, i);
-        const uint64_t* sig = HandelProto::sig_ptr(s, node, l, slot);
+        const uint64_t WG_G* sig = HandelProto::sig_ptr(s, node, l, slot);
         uint64_t a = 0, b = 0;
         if (oneRound) {
           if (jh < v.nw) {
@@ -1069,7 +1069,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         for (int q = 0; q < 5; q++) d.xbuf[(size_t)j * 5 + q] = 0;
         continue;
       }
-      uint32_t* h = h_hdr(s, node);
+      uint32_t WG_G* h = h_hdr(s, node);
       const uint32_t e16 = (h[HH_CAND + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
       const int l = (int)(e16 >> 8);
       const int slot = (int)(e16 & 0xFFu);
@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
       h[HH_WINDOW] = (uint32_t)min(w, 1 << (l - 1));
       // receptionRanks[best.from] += nodeCount, saturating (:825-828)
-      int32_t* rk = s.ranks + (size_t)node * s.N + from;
+      int32_t WG_G* rk = s.ranks + (size_t)node * s.N + from;
       int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
       *rk = nr < 0 ? INT32_MAX : nr;
       if (nr < 0) atomicOr(&d.g->notes, NOTE_RANKS_SATURATED);
@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       const bool ok = arrival - t < d.horizon - 1;  // see Engine::run_ms on host-held envelopes
       if (!ok) set_err(d.g, ERR_HORIZON);
       if (SH) {
-        int32_t* x = d.xbuf + (size_t)j * 5;
+        int32_t WG_G* x = d.xbuf + (size_t)j * 5;
         x[0] = (int32_t)fin.w0;
         x[1] = (int32_t)fin.w1;
         x[2] = (int32_t)fin.w2;
@@ -1171,8 +1171,8 @@ __global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict_
     if (!is_snapshot_event<TASK>(d, e) || s.snapIdx[e] >= s.xsnapRows) continue;
     const int32_t node = (int32_t)d.ev[e].w1;
     const bool owned = shard_owns(d, node);
-    uint64_t* row = s.snap + (size_t)(win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
-    uint64_t* img = (uint64_t*)s.xsnap + (size_t)s.snapIdx[e] * s.snapStride;
+    uint64_t WG_G* row = s.snap + (size_t)(win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    uint64_t WG_G* img = (uint64_t WG_G*)(int32_t WG_G*)s.xsnap + (size_t)s.snapIdx[e] * s.snapStride;
     for (uint32_t j = WG_LANE; j < s.snapStride; j += 64) {
       if (PACK)
         img[j] = owned ? row[j] : 0ULL;

@@ -12,9 +12,9 @@ namespace wg {
 struct FloodState {
   wg_p2pflood_params p;
   int32_t N, maxPeers;
-  int32_t* peers;      // [N][maxPeers] P2PNode.peers in list order
-  int32_t* peerCnt;    // [N]
-  uint64_t* received;  // [N] getMsgReceived(-1) as a bit per message
+  GP<int32_t> peers;      // [N][maxPeers] P2PNode.peers in list order
+  GP<int32_t> peerCnt;    // [N]
+  GP<uint64_t> received;  // [N] getMsgReceived(-1) as a bit per message
 };
 
 struct FloodProto {

@@ -25,11 +25,11 @@ enum SfFlags : uint32_t { SF_DONE = 1, SF_THRESHOLD_DONE = 2, SF_SWAPPING = 4 };
 struct SfState {
   wg_sanfermin_params p;
   int32_t N, P, W;        // W = 64-bit words of an N-bit row
-  int32_t *cpl, *agg, *sentReq, *recvReq, *thresholdAt;
-  uint32_t *flags, *cacheMask;
-  int32_t* cache;         // [N][P + 1]
-  uint64_t* used;         // [N][W]
-  uint64_t* pending;      // [N][W]  (only the first S bits of the current level are meaningful)
+  GP<int32_t> cpl, agg, sentReq, recvReq, thresholdAt;
+  GP<uint32_t> flags, cacheMask;
+  GP<int32_t> cache;         // [N][P + 1]
+  GP<uint64_t> used;         // [N][W]
+  GP<uint64_t> pending;      // [N][W]  (only the first S bits of the current level are meaningful)
 };
 
 struct SfProto {
@@ -86,14 +86,14 @@ struct SfProto {
     const int32_t S = block_size(s, level), cb = own_base(s, self, level) ^ S;
     return other >= cb && other < cb + S;
   }
-  __device__ static bool row_bit(const uint64_t* row, int64_t bit) {
+  __device__ static bool row_bit(const uint64_t WG_G* row, int64_t bit) {
     return (__hip_atomic_load(row + (bit >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 63)) & 1ULL;
   }
-  __device__ static void row_set_bit(uint64_t* row, int64_t bit) {  // (called by one lane)
+  __device__ static void row_set_bit(uint64_t WG_G* row, int64_t bit) {  // (called by one lane)
     row[bit >> 6] |= 1ULL << (bit & 63);
   }
   // first index i in [0, len) with bit (off + i) of `row` clear, or len; wave-parallel over the words
-  __device__ static int32_t first_clear(const uint64_t* row, int64_t off, int32_t len) {
+  __device__ static int32_t first_clear(const uint64_t WG_G* row, int64_t off, int32_t len) {
     const int64_t lo = off, hi = off + len;
     int32_t best = len;
     for (int64_t w0 = (lo >> 6); w0 <= ((hi - 1) >> 6) && best == len; w0 += 64) {
@@ -115,7 +115,7 @@ struct SfProto {
   __device__ static int pick_next_nodes(Ctx& c, const State& s, NodeRegs& r, int level, int howMany) {
     const int32_t node = c.node;
     const int32_t S = block_size(s, level), ob = own_base(s, node, level), cb = ob ^ S, idx = node - ob;
-    uint64_t* used = s.used + (size_t)node * s.W;
+    uint64_t WG_G* used = s.used + (size_t)node * s.W;
     const int64_t off = (int64_t)s.N - 2 * (int64_t)S;
     int n = 0;
     const bool first = !row_bit(used, off + idx);
@@ -155,7 +155,7 @@ struct SfProto {
     if (n == 0) return;
     const int32_t node = c.node;
     const int32_t S = block_size(s, r.cpl), cb = own_base(s, node, r.cpl) ^ S;
-    uint64_t* pend = s.pending + (size_t)node * s.W;
+    uint64_t WG_G* pend = s.pending + (size_t)node * s.W;
     const uint32_t destOff = c.dest_reserve(n);
     if ((int)WG_LANE < n) c.dest_put(destOff, (int)WG_LANE, r.sh->list[WG_LANE]);
     if (WG_LANE == 0)
@@ -181,7 +181,7 @@ struct SfProto {
     r.cacheMask |= 1u << r.cpl;
     r.flags &= ~SF_SWAPPING;
     {  // pendingNodes = new HashSet<>()
-      uint64_t* pend = s.pending + (size_t)c.node * s.W;
+      uint64_t WG_G* pend = s.pending + (size_t)c.node * s.W;
       const int32_t words = (block_size(s, r.cpl) + 63) >> 6;
       for (int w = WG_LANE; w < words; w += 64) pend[w] = 0;
       __threadfence_block();
