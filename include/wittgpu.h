@@ -259,6 +259,32 @@ typedef struct {
 } wg_delivery;
 int32_t wg_next_delivery(wg_engine* e, int32_t until, int32_t cond_time, wg_delivery* out, int32_t* got);
 int32_t wg_set_time(wg_engine* e, int32_t time);
+/* The same, a millisecond at a time (SURVEY.md 8(b) wg_step_begin / wg_step_end): one call hands out every deliverable
+ * envelope left in the current ms (at most cap; *n = 0 once time > until; a time edge is a batch of one kind-2 entry), the
+ * caller applies them in order, and ONE call takes back what their action()s pushed — the shape of
+ * External.receive(EnvelopeInfo) -> List<SendMessage> (C/Network.java:616-623): two FFI crossings per simulated ms instead
+ * of one per delivered message. Every op names the delivery that issued it (`after`, index into the batch; ops ordered by
+ * it), so the engine files the pushes exactly where Java's msgs.addMsg would have: delivery i's, then the re-push of i's
+ * multi-destination envelope (:629-632). The shared rd is the CALLER's while a step is open (wg_rng_get_state at
+ * wg_step_begin, wg_rng_set_state before wg_step_end): Network.send's seed draw (:377, :430) happens inside the
+ * caller's action(), in order with the action()'s own draws, and travels in the op. Node up / down and partition changes
+ * made by an action() apply from the next step on; a task registered for the ms being delivered is accepted only from
+ * the step's last delivery (WG_EUNSUPPORTED otherwise: use cap = 1 or wg_next_delivery for such a protocol). */
+typedef enum { WG_OP_SEND = 0, WG_OP_SEND_ARRIVE_AT = 1, WG_OP_TASK = 2 } wg_step_op_kind;
+typedef struct {
+  int32_t after;     /* the delivery (index in wg_step_begin's batch) whose action() issued it */
+  int32_t kind;      /* wg_step_op_kind */
+  uint32_t msg;      /* message / task handle */
+  uint32_t payload;  /* second handle word (task: arg) */
+  int32_t time;      /* SEND: sendTime, SEND_ARRIVE_AT: arriveAt, TASK: startAt */
+  int32_t from;      /* sender (TASK: the node) */
+  int32_t to;        /* n == 1: the destination; n > 1: offset of the n destinations in `dests` */
+  int32_t n;         /* SEND: number of destinations (an empty list is not an op: its draw is the caller's) */
+  int32_t delay;     /* SEND: delaysBetweenMessage */
+  int32_t seed;      /* SEND: the rd.nextInt() Network.send drew */
+} wg_step_op;
+int32_t wg_step_begin(wg_engine* e, int32_t until, int32_t cond_time, wg_delivery* out, int32_t cap, int32_t* n);
+int32_t wg_step_end(wg_engine* e, const wg_step_op* ops, int32_t nops, const int32_t* dests);
 
 /* ---- batches: RunMultipleTimes on the device ------------------------------------------------ */
 /* The reference's way to run many simulations is C/RunMultipleTimes.java:44-64: for each of runCount

@@ -131,6 +131,23 @@ def test_host_callback_mode_reference_vectors(name):  # CT/NetworkTest.java thro
     getattr(thm, name)()
 
 
+@pytest.mark.parametrize("name", thm.BATCHED)
+def test_batched_steps_reference_vectors(name, monkeypatch):  # ... and through wg_step_begin / wg_step_end
+    monkeypatch.setenv("WG_HOST_BATCH", "1")
+    getattr(thm, name)()
+
+
+def test_batched_steps_protocols(monkeypatch):
+    monkeypatch.setenv("WG_HOST_BATCH", "1")
+    thm.test_pingpong_through_host_callbacks_matches_oracle(120)
+    tsf.test_sanfermin_64_matches_oracle()
+    tpf.test_p2pflood_three_messages_by_distance()
+    tpf.test_empty_destination_list_costs_a_draw()
+    tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
+    tf.test_fuzz_partitions_stops_and_discard(2)
+    thm.test_batched_step_errors_are_loud()
+
+
 def test_host_callback_mode_pingpong():
     thm.test_pingpong_through_host_callbacks_matches_oracle(120)
 

@@ -161,3 +161,64 @@ def test_pingpong_through_host_callbacks_matches_oracle(n):
         assert net._eng.rng_state() == c.info()["rng"]
         assert net.time == c.info()["time"]
     assert 0 < nodes[0].pong <= n
+
+
+# ---- the batched form of the same boundary: wg_step_begin / wg_step_end (a ms of deliveries per call, their pushes back in
+# one call, include/wittgpu.h) must hand out and file everything exactly as wg_next_delivery does
+BATCHED = ["test_register_task", "test_task_and_stopped_node", "test_periodic_task", "test_conditional_task",
+           "test_multiple_destinations_with_delay_and_lifo"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BATCHED)
+def test_batched_steps_reference_vectors(name, monkeypatch):
+    monkeypatch.setenv("WG_HOST_BATCH", "1")
+    globals()[name]()
+
+
+@pytest.mark.gpu
+def test_batched_steps_pingpong_matches_oracle(monkeypatch):
+    monkeypatch.setenv("WG_HOST_BATCH", "1")
+    test_pingpong_through_host_callbacks_matches_oracle(300)
+
+
+@pytest.mark.gpu
+def test_batched_steps_protocols_match_oracle(monkeypatch):
+    """San Fermin (rd draws inside action(): the shuffle), P2PFlood (multi-destination envelopes with delays, an empty
+    list's draw), Casper IMD (sendAll, far tasks) and the scheduler fuzz (partitions, stops, discard) on batched steps"""
+    monkeypatch.setenv("WG_HOST_BATCH", "1")
+    import test_gpu_casper as tc
+    import test_zv_gpu_p2pflood as tpf
+    import test_zw_gpu_sanfermin as tsf
+    import test_zy_gpu_fuzz as tf
+    tsf.test_sanfermin_64_matches_oracle()
+    tsf.test_sanfermin_fixed_latency_short_timeout()
+    tpf.test_p2pflood_three_messages_by_distance()
+    tpf.test_empty_destination_list_costs_a_draw()
+    tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
+    tf.test_fuzz_latency_models(None)
+    tf.test_fuzz_partitions_stops_and_discard(2)
+
+
+@pytest.mark.gpu
+def test_batched_step_errors_are_loud():
+    import ctypes as C
+    from wittgenstein_amd import _lib as L
+    net = hn.HostNetwork(None, batched=True)
+    nodes = [hn.Node(net) for _ in range(4)]
+    for n in nodes:
+        net.addNode(n)
+    net._start()
+    lib, h = L.lib(), net._eng._h
+    assert lib.wg_step_end(h, None, 0, None) == L.WG_ESTATE  # no step open
+    net.registerTask(lambda: None, 5, nodes[0])
+    arr = (L.wg_delivery * 8)()
+    n = C.c_int32()
+    assert lib.wg_step_begin(h, 10, hn.INT_MAX, arr, 8, C.byref(n)) == 0 and n.value == 1 and arr[0].kind == 1
+    assert lib.wg_step_begin(h, 10, hn.INT_MAX, arr, 8, C.byref(n)) == L.WG_ESTATE  # the step is still open
+    d = L.wg_delivery()
+    got = C.c_int32()
+    assert lib.wg_next_delivery(h, 10, hn.INT_MAX, C.byref(d), C.byref(got)) == L.WG_ESTATE
+    op = (L.wg_step_op * 1)()
+    op[0].after, op[0].kind, op[0].msg, op[0].time, op[0].from_ = 3, 2, 99, 7, 1  # a delivery the step did not hand out
+    assert lib.wg_step_end(h, op, 1, None) == L.WG_EINVAL

@@ -238,6 +238,16 @@ int32_t wg_next_delivery(wg_engine* h, int32_t until, int32_t cond_time, wg_deli
   *got = E.next_delivery(until, cond_time, out) ? 1 : 0;
   WG_END
 }
+int32_t wg_step_begin(wg_engine* h, int32_t until, int32_t cond_time, wg_delivery* out, int32_t cap, int32_t* n) {
+  WG_TRY(h)
+  if (!out || !n) throw WgError(WG_EINVAL, "out/n");
+  *n = E.step_begin(until, cond_time, out, cap);
+  WG_END
+}
+int32_t wg_step_end(wg_engine* h, const wg_step_op* ops, int32_t nops, const int32_t* dests) {
+  WG_TRY(h) E.step_end(ops, nops, dests);
+  WG_END
+}
 int32_t wg_set_time(wg_engine* h, int32_t time) {
   WG_TRY(h) E.host_set_time(time);
   WG_END

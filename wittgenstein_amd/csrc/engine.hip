@@ -738,6 +738,20 @@ void Engine::send(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from
   gh.rng = rd.s;
   gh.draws++;
   globalsDirty = true;
+  send_seeded(msg, payload, sendTime, from, dests, n, delayBetween, seed);
+}
+
+// ... with the seed already drawn (by send() above, or by the caller of a batched step, who holds rd while it applies the
+// step's deliveries: wg_step_end)
+void Engine::send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+                         int32_t delayBetween, int32_t seed) {
+  const int32_t N = (int32_t)hx.size();
+  if (from < 0 || from >= N) throw WgError(WG_EINVAL, "The from node is not in the network.");
+  for (int i = 0; i < n; i++)
+    if (dests[i] < 0 || dests[i] >= N) throw WgError(WG_EINVAL, "The to node is not in the network.");
+  if (n <= 0) return;
+  if (sendTime <= time) throw WgError(WG_ESTATE, "sendTime=" + std::to_string(sendTime) + ", time=" + std::to_string(time));  // :471
+  if (!proto) throw WgError(WG_ESTATE, "load a protocol before sending (message sizes are protocol-defined)");
   if (n >= sendExpandMin && delayBetween == 0) return send_expanded(msg, payload, sendTime, from, dests, n, seed);
   // sender statistics are applied on the device at flush time; host keeps them in staged counters
   struct Arr {
@@ -1553,6 +1567,7 @@ void Engine::hc_finish_ms() {
 
 bool Engine::next_delivery(int32_t until, int32_t condTime, wg_delivery* out) {
   if (!dev.hostMode) throw WgError(WG_ESTATE, "load WG_PROTO_HOST first");
+  if (hcStepOpen) throw WgError(WG_ESTATE, "a batched step is open (wg_step_end)");
   for (;;) {
     hc_stage_continuation();  // owed by the delivery the caller has just applied
     while (hcLoaded && hcCursor < hcEvents.size()) {
@@ -1592,28 +1607,141 @@ bool Engine::next_delivery(int32_t until, int32_t condTime, wg_delivery* out) {
       continue;
     }
     if (time > until) return false;
-    // load bucket `time`
-    flush_staged(time, false);
-    gh.now = time;
-    gh.until = until;
-    globalsDirty = true;
-    sync_globals_to_device();
-    Group g = self();
-    expand(g);
-    sync_globals_to_host();
-    check_device_errors();
-    const uint32_t n = gh.nEvents;
-    hcEvents.resize(n);
-    if (n) {
-      std::vector<Rec> recs(n);
-      std::vector<EvAux> aux(n);
-      WG_HIP(hipMemcpy(recs.data(), dev.ev, sizeof(Rec) * n, hipMemcpyDeviceToHost));
-      WG_HIP(hipMemcpy(aux.data(), dev.evAux, sizeof(EvAux) * n, hipMemcpyDeviceToHost));
-      for (uint32_t i = 0; i < n; i++) hcEvents[i] = {recs[i], aux[i]};
-    }
-    hcCursor = 0;
-    hcLoaded = true;
+    hc_load_ms(until);
   }
+}
+
+// bucket `time` -> the host: expanded on the device as for a resident protocol, copied in two transfers
+void Engine::hc_load_ms(int32_t until) {
+  flush_staged(time, false);
+  gh.now = time;
+  gh.until = until;
+  globalsDirty = true;
+  sync_globals_to_device();
+  Group g = self();
+  expand(g);
+  sync_globals_to_host();
+  check_device_errors();
+  const uint32_t n = gh.nEvents;
+  hcEvents.resize(n);
+  if (n) {
+    std::vector<Rec> recs(n);
+    std::vector<EvAux> aux(n);
+    WG_HIP(hipMemcpy(recs.data(), dev.ev, sizeof(Rec) * n, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(aux.data(), dev.evAux, sizeof(EvAux) * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) hcEvents[i] = {recs[i], aux[i]};
+  }
+  hcCursor = 0;
+  hcLoaded = true;
+}
+
+// ---- batched host-callback steps (wg_step_begin / wg_step_end) ---------------------------------------------------
+// The same walk as next_delivery, but every deliverable envelope of the ms goes out in ONE call, and what the
+// caller's action()s pushed comes back in ONE call, tagged with the delivery that issued it — the shape of
+// External.receive(ei) -> List<SendMessage> (C/Network.java:616-623). step_end replays the pushes in the order the
+// reference would have made them: delivery i's pushes, then the re-push of i's multi-destination envelope
+// (markRead / hasNextReader / addMsg :629-632), then whatever an undeliverable envelope between i and i + 1 owes.
+int32_t Engine::step_begin(int32_t until, int32_t condTime, wg_delivery* out, int32_t cap) {
+  if (!dev.hostMode) throw WgError(WG_ESTATE, "load WG_PROTO_HOST first");
+  if (hcStepOpen) throw WgError(WG_ESTATE, "wg_step_end has not closed the previous step");
+  if (cap <= 0) throw WgError(WG_EINVAL, "cap");
+  hcPlan.clear();
+  for (;;) {
+    hc_stage_continuation();  // (owed by a wg_next_delivery the caller mixed in)
+    int32_t nOut = 0;
+    while (hcLoaded && hcCursor < hcEvents.size() && nOut < cap) {
+      const HostEv ev = hcEvents[hcCursor++];
+      StepPlan pl{-1, -1, 0};
+      if (ev.aux.chain >= 0 && ev.aux.cpos < 0) {  // last hop of a run: the envelope is re-pushed after action()
+        const int next = (ev.aux.cpos & 0x7FFFFFFF) + 1;
+        if (next < hostChains[ev.aux.chain].c.ndest) {
+          pl.contSlot = ev.aux.chain;
+          pl.contPos = next;
+        } else {
+          hostChains[ev.aux.chain].live = false;
+        }
+      }
+      const int32_t from = rec_from(ev.rec), to = (int32_t)ev.rec.w1;
+      if (!(hdown[to] || part_of(hx[from]) != part_of(hx[to]))) {  // :606
+        wg_delivery& o = out[nOut];
+        o.kind = rec_kind(ev.rec) == K_MSG ? 0 : 1;
+        o.time = time;
+        o.from = from;
+        o.to = to;
+        o.msg = ev.rec.w2;
+        o.payload = ev.rec.w3;
+        pl.outIdx = nOut++;
+      }
+      if (pl.outIdx >= 0 || pl.contSlot >= 0) hcPlan.push_back(pl);
+    }
+    if (nOut > 0) {
+      hcStepOpen = true;
+      return nOut;
+    }
+    if (!hcPlan.empty()) {  // only undeliverable envelopes were left in the ms: their re-pushes are filed here
+      hcStepOpen = true;
+      step_end(nullptr, 0, nullptr);
+      continue;
+    }
+    if (hcLoaded) {  // nextMessage(): poll returned null -> time++ and the conditional-task edge
+      hc_finish_ms();
+      time++;
+      if (time >= condTime) {
+        out[0].kind = 2;
+        out[0].time = time;
+        out[0].from = out[0].to = -1;
+        out[0].msg = out[0].payload = 0;
+        hcStepOpen = true;  // (an edge is closed by wg_step_end too: the conditional tasks' pushes are its ops, after = 0)
+        hcPlan.push_back({0, -1, 0});
+        return 1;
+      }
+      continue;
+    }
+    if (time > until) return 0;
+    hc_load_ms(until);
+  }
+}
+
+void Engine::step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests) {
+  if (!hcStepOpen) throw WgError(WG_ESTATE, "no step is open (wg_step_begin)");
+  if (nops < 0 || (nops > 0 && !ops)) throw WgError(WG_EINVAL, "ops");
+  hcStepOpen = false;
+  int32_t k = 0;
+  for (size_t pi = 0; pi < hcPlan.size(); pi++) {
+    const StepPlan pl = hcPlan[pi];
+    if (pl.outIdx >= 0) {
+      if (k < nops && ops[k].after < pl.outIdx) throw WgError(WG_EINVAL, "wg_step_end: ops must be ordered by `after`");
+      for (; k < nops && ops[k].after == pl.outIdx; k++) {
+        const wg_step_op& op = ops[k];
+        // an envelope for the ms being handed out is the NEXT one delivered (LIFO, hc_push): exact only behind the step's last delivery
+        const bool last = pi + 1 == hcPlan.size();
+        switch (op.kind) {
+          case WG_OP_SEND: {
+            const int32_t* dd = op.n == 1 ? &op.to : dests + op.to;
+            if (op.n > 1 && !dests) throw WgError(WG_EINVAL, "dests");
+            gh.draws++;  // (the caller drew the seed from the rd it holds during the step)
+            globalsDirty = true;
+            send_seeded(op.msg, op.payload, op.time, op.from, dd, op.n, op.delay, op.seed);
+            break;
+          }
+          case WG_OP_SEND_ARRIVE_AT: send_arrive_at(op.msg, op.payload, op.time, op.from, op.to); break;
+          case WG_OP_TASK:
+            if (op.time == time && hcLoaded && !last)
+              throw WgError(WG_EUNSUPPORTED, "a task registered for the millisecond being delivered, from inside a batched step: deliver this ms with wg_next_delivery or cap = 1");
+            register_task(op.msg, op.payload, op.time, op.from);
+            break;
+          default: throw WgError(WG_EINVAL, "wg_step_op.kind");
+        }
+      }
+    }
+    if (pl.contSlot >= 0) {
+      hcContSlot = pl.contSlot;
+      hcContPos = pl.contPos;
+      hc_stage_continuation();
+    }
+  }
+  if (k != nops) throw WgError(WG_EINVAL, "wg_step_end: an op refers to a delivery the step did not hand out");
+  hcPlan.clear();
 }
 
 // ---- batches

@@ -145,6 +145,16 @@ class Engine {
   // host-callback mode (WG_PROTO_HOST): Network.nextMessage + the post-action part of receiveUntil
   bool next_delivery(int32_t until, int32_t condTime, wg_delivery* out);
   void host_set_time(int32_t t);
+  // ... and its batched form (wg_step_begin / wg_step_end): the deliveries of a ms in one call, the caller's pushes in one call
+  struct StepPlan {
+    int32_t outIdx;             // index in the caller's batch, -1: consumed undelivered (:606), only its re-push is owed
+    int32_t contSlot, contPos;  // multi-destination envelope to re-push after it (-1: none)
+  };
+  std::vector<StepPlan> hcPlan;
+  bool hcStepOpen = false;
+  int32_t step_begin(int32_t until, int32_t condTime, wg_delivery* out, int32_t cap);
+  void step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests);
+  void hc_load_ms(int32_t until);
   struct HostEv {
     Rec rec;
     EvAux aux;
@@ -155,6 +165,8 @@ class Engine {
   int32_t hcContSlot = -1, hcContPos = 0;  // chain re-push owed after the delivery in progress (:629-632)
   std::vector<StagedChainKeep> hostChains; // host copies of the multi-destination envelopes, by slot
   void hc_push(int32_t arrival, const Rec& rec);
+  void send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32_t from, const int32_t* dests, int32_t n,
+                   int32_t delayBetween, int32_t seed);
   void hc_stage_continuation();
   void hc_finish_ms();
   void read_i64(int32_t field, int64_t* dst, int32_t n);

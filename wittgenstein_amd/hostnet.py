@@ -5,6 +5,7 @@ The message queue with its LIFO / multi-destination-chain ordering, NetworkLaten
 stand-in for what the reference's Java classes do (C/Network.java, C/Node.java, C/messages/*.java), so that
 any protocol written against that API runs unchanged in structure. Method names follow the Java API."""
 import ctypes as C
+import os
 
 from . import _lib as L
 from .core import IllegalArgumentException, IllegalStateException, Network as _EngineNetwork
@@ -26,8 +27,12 @@ class EngineRandom:
         self._net = net
 
     def _next(self, bits):
-        s = (self._net._eng.rng_state() * 0x5DEECE66D + 0xB) & _MASK48
-        self._net._eng._ck(L.lib().wg_rng_set_state(self._net._eng._h, C.c_uint64(s)))
+        net = self._net
+        if net._rd_held is not None:  # a batched step is open: rd is the caller's until wg_step_end
+            s = net._rd_held = (net._rd_held * 0x5DEECE66D + 0xB) & _MASK48
+            return _s32(s >> (48 - bits))
+        s = (net._eng.rng_state() * 0x5DEECE66D + 0xB) & _MASK48
+        net._eng._ck(L.lib().wg_rng_set_state(net._eng._h, C.c_uint64(s)))
         return _s32(s >> (48 - bits))
 
     def setSeed(self, seed):
@@ -128,7 +133,15 @@ class ConditionalTask:
 class HostNetwork:
     """C/Network.java over the engine's host-callback mode."""
 
-    def __init__(self, networkLatencyName=None, config=None):
+    def __init__(self, networkLatencyName=None, config=None, batched=None, batch_cap=4096):
+        if batched is None:
+            batched = os.environ.get("WG_HOST_BATCH", "0") not in ("", "0")
+        # batched: a simulated ms travels as ONE wg_step_begin / wg_step_end pair instead of one wg_next_delivery per
+        # delivered message (include/wittgpu.h); same results, two FFI crossings per ms
+        self._batched, self._batch_cap = bool(batched), int(batch_cap)
+        self._rd_held = None    # rd's state while a batched step is open
+        self._ops = None        # the step's pushes: (after, kind, handle, payload, time, from, dests, delay, seed)
+        self._cur = 0
         self._eng = _EngineNetwork.create(config)
         self._eng.setNetworkLatency(networkLatencyName)
         self.rd = EngineRandom(self)
@@ -192,20 +205,35 @@ class HostNetwork:
         # createMessageArrival counts the sender's statistics for every destination, dropped or not (:476-477)
         fromNode.msgSent += len(ids)
         fromNode.bytesSent += len(ids) * m.size()
+        if self._ops is not None:  # inside a batched step: the seed draw (:377 / :430) is made here, in action() order
+            seed = self.rd.nextInt()
+            if ids:
+                self._ops.append((self._cur, 0, self._handle(m), 0, sendTime, fromNode.nodeId, ids, delayBetween, seed))
+            return
         self._eng.send(self._handle(m), sendTime, fromNode.nodeId, ids, delayBetween)
 
     def sendArriveAt(self, m, arriveAt, fromNode, toNode):
         self._start()
+        if self._ops is not None:
+            if arriveAt <= self.time:
+                raise IllegalArgumentException("wrong arrival time: arriveAt=%d, time=%d" % (arriveAt, self.time))
+            self._ops.append((self._cur, 1, self._handle(m), 0, int(arriveAt), fromNode.nodeId, [toNode.nodeId], 0, 0))
+            return
         self._eng._ck(L.lib().wg_send_arrive_at(self._eng._h, self._handle(m), 0, int(arriveAt), fromNode.nodeId,
                                                 toNode.nodeId))
 
-    def registerTask(self, task, startAt, fromNode):  # :505-508
+    def _register(self, obj, startAt, fromNode):
         self._start()
-        self._eng.registerTask(self._handle(Task(task)), startAt, fromNode.nodeId)
+        if self._ops is not None:
+            self._ops.append((self._cur, 2, self._handle(obj), 0, int(startAt), fromNode.nodeId, [], 0, 0))
+            return
+        self._eng.registerTask(self._handle(obj), startAt, fromNode.nodeId)
+
+    def registerTask(self, task, startAt, fromNode):  # :505-508
+        self._register(Task(task), startAt, fromNode)
 
     def registerPeriodicTask(self, task, startAt, period, fromNode, cond=lambda: True):  # :510-519
-        self._start()
-        self._eng.registerTask(self._handle(PeriodicTask(task, fromNode, period, cond)), startAt, fromNode.nodeId)
+        self._register(PeriodicTask(task, fromNode, period, cond), startAt, fromNode)
 
     def registerConditionalTask(self, task, startAt, duration, fromNode, startIf, repeatIf):  # :521-531
         self.conditionalTasks.append(ConditionalTask(startIf, repeatIf, task, startAt, fromNode, duration))
@@ -250,6 +278,8 @@ class HostNetwork:
         return min(t) if t else INT_MAX
 
     def _receiveUntil(self, until):  # :587-637 with nextMessage :533-570
+        if self._batched:
+            return self._receiveUntil_batched(until)
         lib, h = L.lib(), self._eng._h
         d = L.wg_delivery()
         got = C.c_int32()
@@ -261,27 +291,80 @@ class HostNetwork:
                 return did
             self.time = d.time
             if d.kind == 2:  # time++ edge: the conditional-task scan of :543-566
-                if cts is None:
-                    cts = list(self.conditionalTasks)
-                for ct in list(cts):
-                    if ct.minStartTime > until or ct.frm.isDown():
-                        cts.remove(ct)
-                        continue
-                    if ct.minStartTime <= self.time:
-                        cts.remove(ct)
-                        if ct.startIf():
-                            ct.r()
-                            ct.minStartTime = self.time + ct.duration
-                            if not ct.repeatIf():
-                                self.conditionalTasks.remove(ct)
+                cts = self._edge(cts, until)
                 continue
             did = True
             cts = None  # a delivery ends the nextMessage() call
-            m = self._handles[d.msg]
-            frm, to = self.allNodes[d.from_], self.allNodes[d.to]
-            if not isinstance(m, Task):  # :607-613 (`!(mc instanceof Task)`)
-                if m.size() == 0:
-                    raise IllegalStateException("Message size should be greater than zero: %r" % m)
-                to.msgReceived += 1
-                to.bytesReceived += m.size()
-            m.action(self, frm, to)
+            self._deliver(d)
+
+    def _edge(self, cts, until):
+        if cts is None:
+            cts = list(self.conditionalTasks)
+        for ct in list(cts):
+            if ct.minStartTime > until or ct.frm.isDown():
+                cts.remove(ct)
+                continue
+            if ct.minStartTime <= self.time:
+                cts.remove(ct)
+                if ct.startIf():
+                    ct.r()
+                    ct.minStartTime = self.time + ct.duration
+                    if not ct.repeatIf():
+                        self.conditionalTasks.remove(ct)
+        return cts
+
+    def _deliver(self, d):
+        m = self._handles[d.msg]
+        frm, to = self.allNodes[d.from_], self.allNodes[d.to]
+        if not isinstance(m, Task):  # :607-613 (`!(mc instanceof Task)`)
+            if m.size() == 0:
+                raise IllegalStateException("Message size should be greater than zero: %r" % m)
+            to.msgReceived += 1
+            to.bytesReceived += m.size()
+        m.action(self, frm, to)
+
+    def _receiveUntil_batched(self, until):
+        """the same loop over wg_step_begin / wg_step_end: a ms of deliveries per call, their pushes back in one call"""
+        lib, eng = L.lib(), self._eng
+        h = eng._h
+        cap = self._batch_cap
+        arr = (L.wg_delivery * cap)()
+        n = C.c_int32()
+        did = False
+        cts = None
+        while True:
+            eng._ck(lib.wg_step_begin(h, until, self._cond_time(cts, until), arr, cap, C.byref(n)))
+            if not n.value:
+                return did
+            self._rd_held = eng.rng_state()
+            self._ops = []
+            try:
+                for i in range(n.value):
+                    d = arr[i]
+                    self._cur = i
+                    self.time = d.time
+                    if d.kind == 2:
+                        cts = self._edge(cts, until)
+                        continue
+                    did = True
+                    cts = None
+                    if self.allNodes[d.to].isDown():  # stopped by an earlier action() of this very step (:606)
+                        continue
+                    self._deliver(d)
+            finally:
+                ops, self._ops = self._ops, None
+                eng._ck(lib.wg_rng_set_state(h, C.c_uint64(self._rd_held)))
+                self._rd_held = None
+            oa = (L.wg_step_op * max(1, len(ops)))()
+            dests = []
+            for k, (after, kind, handle, payload, t, frm, ids, delay, seed) in enumerate(ops):
+                o = oa[k]
+                o.after, o.kind, o.msg, o.payload, o.time, o.from_ = after, kind, handle, payload, t, frm
+                o.n, o.delay, o.seed = len(ids), delay, seed
+                if len(ids) == 1:
+                    o.to = ids[0]
+                elif ids:
+                    o.to = len(dests)
+                    dests.extend(ids)
+            da = (C.c_int32 * max(1, len(dests)))(*dests)
+            eng._ck(lib.wg_step_end(h, oa, len(ops), da))
