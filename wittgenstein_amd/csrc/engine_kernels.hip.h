@@ -35,11 +35,11 @@ namespace wg {
 #define KPROF_MARK(g, slot)                                                            \
   do {                                                                                 \
     const unsigned long long _n = __builtin_readcyclecounter();                        \
-    if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], _n - _kp);        \
+    if (WG_LANE == 0) atomicAdd(F(&(g)->kprofBuf[KPROF_WAVE + (slot)]), _n - _kp);        \
     _kp = _n;                                                                          \
   } while (0)
-#define KPROF_COUNT(g, slot) do { if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], 1ULL); } while (0)
-#define KPROF_ADD(g, slot, v) do { if (WG_LANE == 0) atomicAdd(&(g)->kprofBuf[KPROF_WAVE + (slot)], (unsigned long long)(v)); } while (0)
+#define KPROF_COUNT(g, slot) do { if (WG_LANE == 0) atomicAdd(F(&(g)->kprofBuf[KPROF_WAVE + (slot)]), 1ULL); } while (0)
+#define KPROF_ADD(g, slot, v) do { if (WG_LANE == 0) atomicAdd(F(&(g)->kprofBuf[KPROF_WAVE + (slot)]), (unsigned long long)(v)); } while (0)
 #else
 #define KPROF_DECL
 #define KPROF_MARK(g, slot)
@@ -1550,8 +1550,10 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
   c.outBase = aux.outBase;
   c.outCap = aux.outCap;
   uint32_t flags = 0;
+  KPROF_DECL;
   // :606 — partitions are rare: without cuts every node is in partition 0 and the lookup is skipped
   if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {
+    KPROF_MARK(d.g, 14);  // event prologue
     if (kind == K_MSG) {
       nRecv++;
       bRecv += P::msg_size(ps, rec.w2);
@@ -1571,14 +1573,16 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
     else if (WG_LANE == 0)
       d.chains[aux.chain].flags = 0;  // envelope fully delivered
   }
+  KPROF_MARK(d.g, 30);  // the action() (+ a periodic task's re-arm, a chain's continuation)
   if (WG_LANE == 0) {
     EvRes res;
     res.nrec = c.sub | flags;
     res.ndraw = c.draws;
-    d.evRes[e] = res;
+    gst(d.evRes + e, res);
   }
   // the node's next event reads what this one wrote (other lanes, same wavefront)
   if (moreEvents) __threadfence_block();
+  KPROF_MARK(d.g, 15);  // event epilogue (result record, fence)
 }
 
 // A node visit is a chain of dependent HBM round trips and the kernel is bound by that latency
@@ -1758,6 +1762,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
           Ctx c{d, t, vd.node, 0, 0, 0, 0, 0, 0, 0};
           typename P::NodeRegs r;
           P::node_begin_pre(c, ps, r, &shP[w], hdrCur);
+          KPROF_MARK(d.g, 31);  // the next visit's prefetches issued, this visit's descriptor + header arrived
           deliver_visit<P>(d, ps, c, r, vd, shSort[w], true);
         }
         if (!haveNext) break;
