@@ -366,9 +366,11 @@ def main():
     ap.add_argument("--replicas", type=int, default=24, help="independent simulations per step and per GPU (lowered to what fits the free HBM)")
     ap.add_argument("--batches", type=int, default=0,
                     help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
-                         "thread each); 0 = 2 when the step has at least 4 copies (profiles/r03d_sweep_batches.txt: the "
-                         "per-ms kernels are chains of dependent latencies that leave the chip mostly idle — two "
-                         "half-batches overlap them; three and more lose to their smaller launches), else 1")
+                         "thread each); 0 = 1: the whole step as one batch on one stream, so that a launch of the delivery kernels "
+                         "has the chip to itself and its HIP-event / rocprofv3 duration is the kernel's own (the roofline "
+                         "figure). --batches 2 overlaps two half-batches' chains of dependent latencies: +6 % delivered "
+                         "messages/s (profiles/r04d_sweep_graph_batches.txt), at the price of launch durations inflated by "
+                         "the sharing; three and more lose to their smaller launches")
     ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
                     "bounded by the box's cores and host memory)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
@@ -473,7 +475,7 @@ def main():
             g.network().restore()
         torch.cuda.synchronize()
 
-    nb = args.batches if args.batches > 0 else (2 if R >= 4 else 1)
+    nb = args.batches if args.batches > 0 else 1
     nb = max(1, min(nb, R))
     # the step's copies as `nb` smaller batches, each on its own HIP stream and host thread
     subs = split_batches(w, sims, nb) if nb > 1 else [batch]

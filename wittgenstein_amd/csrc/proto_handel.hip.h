@@ -922,14 +922,23 @@ __global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __
         vih = vi[v.bw + jh];
         lah = la[v.bw + jh];
       }
+      // (the entries' signatures are independent of each other: entry i + 1's word is in flight while entry i is reduced)
+      uint64_t sgAhead = 0;
+      {
+        const int slot0 = (int)lane_bcast((uint32_t)mySlot, 0);
+        if (oneRound && jh < v.nw && len > 0) sgAhead = HandelProto::sig_ptr(s, node, l, slot0)[jh];
+      }
       for (int i = 0; i < len; i++) {
         const int slot = (int)lane_bcast((uint32_t)mySlot, i);
         const int rank = (int)lane_bcast((uint32_t)myRank, i);
         const uint64_t WG_G* sig = HandelProto::sig_ptr(s, node, l, slot);
         uint64_t a = 0, b = 0;
         if (oneRound) {
+          const uint64_t sgCur = sgAhead;
+          const int slotN = (int)lane_bcast((uint32_t)mySlot, i + 1 < len ? i + 1 : i);
+          if (i + 1 < len && jh < v.nw) sgAhead = HandelProto::sig_ptr(s, node, l, slotN)[jh];
           if (jh < v.nw) {
-            const uint64_t sg = sig[jh];
+            const uint64_t sg = sgCur;
             a = (uint64_t)__popcll(sg | tih | vih) | ((uint64_t)__popcll(sg | vih) << 21) | ((uint64_t)__popcll(sg) << 42);
             b = (uint64_t)((sg & tih) != 0) | ((uint64_t)((sg & lah) != 0) << 21);
           }
