@@ -250,9 +250,16 @@ struct OrcHandel {
 };
 // iparams: nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs,
 //          fastPath, nodesDown, desynchronizedStart   (P/Handel.java:97-111 ctor order, ints only)
+int orc_handel_create_byz(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzSuicide, int hiddenByz,
+                          void** out);
 int orc_handel_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  return orc_handel_create_byz(ip, nb, nl, seed, 0, 0, out);
+}
+// ... with the attack scenarios of the parameters (P/Handel.java:108-109): byzantineSuicide, hiddenByzantine
+int orc_handel_create_byz(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzSuicide, int hiddenByz,
+                          void** out) {
   ORC_TRY Handel::HandelParameters pr(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], nb ? nb : "",
-                                      nl ? nl : "", ip[8], false, false, nullptr);
+                                      nl ? nl : "", ip[8], byzSuicide != 0, hiddenByz != 0, nullptr);
   auto* h = new OrcHandel();
   h->p = std::make_unique<Handel>(pr);
   h->p->network().rd.setSeed(seed);
@@ -301,7 +308,7 @@ int orc_handel_read(void* h, int field, int64_t* out) {
   }
   ORC_CATCH
 }
-// per (node, level) ints, row-major [node][level]: 0 posInLevel 1 outgoingFinished 2 toVerifyAgg.size
+// per (node, level) ints, row-major [node][level]: 0 posInLevel 1 outgoingFinished 2 toVerifyAgg.size 3 suicideBizAfter
 int orc_handel_read_level(void* h, int field, int32_t* out) {
   ORC_TRY auto& p = *((OrcHandel*)h)->p;
   int L = (int)p.node(0)->levels.size();
@@ -318,6 +325,7 @@ int orc_handel_read_level(void* h, int field, int32_t* out) {
         case 0: v = lv.posInLevel; break;
         case 1: v = lv.outgoingFinished; break;
         case 2: v = (int)lv.toVerifyAgg.size(); break;
+        case 3: v = lv.suicideBizAfter; break;
         default: throw IllegalArgumentException("field");
       }
       out[i * L + l] = v;
@@ -327,7 +335,7 @@ int orc_handel_read_level(void* h, int field, int32_t* out) {
 // Bitsets in "natural layout": one nodeCount-bit row per node (words = nodeCount/64 rounded up),
 // bit j = node id j, union over levels (level blocks are disjoint, P/Handel.java:671-684).
 // which: 0 totalIncoming 1 lastAggVerified 2 verifiedIndSignatures 3 toVerifyInd 4 finishedPeers
-//        5 totalOutgoing of the LAST level only 6 waitedSigs
+//        5 totalOutgoing of the LAST level only 6 waitedSigs 7 the node's blacklist (:287)
 int orc_handel_read_bits(void* h, int which, uint64_t* out) {
   ORC_TRY auto& p = *((OrcHandel*)h)->p;
   int N = p.params.nodeCount;
@@ -336,6 +344,10 @@ int orc_handel_read_bits(void* h, int which, uint64_t* out) {
   for (size_t i = 0; i < p.nodes.size(); i++) {
     auto& n = *p.nodes[i];
     uint64_t* row = out + i * W;
+    if (which == 7) {
+      for (int w = 0; w < W; w++) row[w] = n.blacklist.wordAt(w);
+      continue;
+    }
     for (size_t l = 0; l < n.levels.size(); l++) {
       auto& lv = *n.levels[l];
       const BitSet* b = nullptr;

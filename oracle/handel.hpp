@@ -1,6 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see jdk.hpp header).
-// Restatement of protocols.Handel (P/Handel.java:18-1054), honest-node paths only:
-// byzantineSuicide / hiddenByzantine (P/Handel.java:538-559, 840-917) are rejected.
+// Restatement of protocols.Handel (P/Handel.java:18-1054), including the two attack scenarios of its parameters:
+// byzantineSuicide (:64-69, 406, 538-559, 577-584, 688-694) and hiddenByzantine (:70-71, 303, 813-817, 840-917).
+// The reference holds no test of either (PT/HandelTest runs honest parameters only): they are pinned by construction
+// and by the invariants tests/test_oracle_protocols.py checks (blacklists only hold down nodes, the run still converges).
 #pragma once
 #include "network.hpp"
 
@@ -37,7 +39,6 @@ class Handel {
       if (__builtin_popcount((unsigned)nodeCount) != 1)
         throw IllegalArgumentException("We support only power of two nodes in this simulation");
       if (byzantineSuicide && hiddenByzantine) throw IllegalArgumentException("Only one attack at a time");
-      if (byzantineSuicide || hiddenByzantine) throw IllegalArgumentException("oracle: byzantine modes not restated");
     }
   };
 
@@ -71,14 +72,17 @@ class Handel {
     std::vector<SigP> toVerifyAgg;
     bool outgoingFinished = false;
     int posInLevel = 0;
+    int suicideBizAfter;  // :406 a cache for the first suicidal byz node in our list (if any)
 
     explicit HLevel(HNode& node) : n(node), level(0), size(1) {  // :413-421
+      suicideBizAfter = n.h.params.byzantineSuicide ? 0 : -1;
       outgoingFinished = true;
       lastAggVerified.set(n.nodeId);
       verifiedIndSignatures.set(n.nodeId);
       totalIncoming.set(n.nodeId);
     }
     HLevel(HNode& node, const HLevel& previous, const BitSet& allPreviousNodes) : n(node) {  // :424-435
+      suicideBizAfter = n.h.params.byzantineSuicide ? 0 : -1;
       level = previous.level + 1;
       waitedSigs.or_(n.allSigsAtLevel(level));
       waitedSigs.andNot(allPreviousNodes);
@@ -129,11 +133,42 @@ class Handel {
       c.or_(verifiedIndSignatures);
       return c.cardinality();
     }
+    SigP createSuicideByzantineSig(int maxRank) {  // :538-559
+      bool reset = false;
+      for (int i = suicideBizAfter; i < (int)peers.size(); i++) {
+        HNode* p = peers[i];
+        if (p->isDown() && !n.blacklist.get(p->nodeId)) {
+          if (!reset) {
+            suicideBizAfter = i;
+            reset = true;
+          }
+          if (n.receptionRanks[p->nodeId] < maxRank) {
+            auto b = std::make_shared<SigToVerify>();
+            b->from = p->nodeId;
+            b->level = level;
+            b->rank = n.receptionRanks[p->nodeId];
+            b->sig = waitedSigs;
+            b->badSig = true;
+            return b;
+          }
+        }
+      }
+      if (!reset) suicideBizAfter = -1;  // no byzantine nodes left in this level
+      return nullptr;
+    }
     SigP bestToVerify() {  // :570-634
       if (toVerifyAgg.empty()) return nullptr;
       if (n.currWindowSize < 1) throw IllegalStateException("currWindowSize");
       int windowIndex = toVerifyAgg[0]->rank;  // Collections.min(..., comparingInt(rank)).rank
       for (auto& s : toVerifyAgg) windowIndex = std::min(windowIndex, s->rank);
+      if (suicideBizAfter >= 0) {  // :577-584
+        SigP bSig = createSuicideByzantineSig(windowIndex + n.currWindowSize);
+        if (bSig) {
+          toVerifyAgg.push_back(bSig);
+          n.sigQueueSize++;
+          return bSig;
+        }
+      }
       int curSignatureSize = totalIncoming.cardinality();
       SigP bestOutside, bestInside;
       int bestScoreInside = 0;
@@ -176,6 +211,53 @@ class Handel {
     int nodePairingTime;
     std::vector<int> receptionRanks;
     BitSet blacklist;
+    struct HiddenByzantine {  // :840-917
+      bool noByzantinePeers = false;
+      SigP last;
+      HNode* firstByzantine(HNode& t, HLevel& l) {  // :844-858
+        HNode* best = nullptr;
+        int bestRank = INT32_MAX;
+        for (HNode* p : l.peers) {
+          if (p->isDown() && t.receptionRanks[p->nodeId] < bestRank && !l.totalIncoming.get(p->nodeId)) {
+            bestRank = t.receptionRanks[p->nodeId];
+            best = p;
+            if (bestRank == 0) return p;
+          }
+        }
+        return best;  // can be null if this node has no byzantine peer
+      }
+      SigP attack(HNode& target, const SigP& currentBest) {  // :861-916
+        if (noByzantinePeers) return currentBest;
+        if (last == currentBest) {  // a previous attack finally worked
+          last = nullptr;
+          return currentBest;
+        }
+        HLevel& l = *target.levels[currentBest->level];
+        if (last) {
+          if (std::find(l.toVerifyAgg.begin(), l.toVerifyAgg.end(), last) != l.toVerifyAgg.end()) return currentBest;
+          if (!l.totalIncoming.get(last->from)) throw IllegalStateException("byz signature pruned!");
+          last = nullptr;
+        }
+        HNode* fb = firstByzantine(target, l);
+        if (!fb) {
+          noByzantinePeers = true;
+          return currentBest;
+        }
+        if (target.receptionRanks[fb->nodeId] >= currentBest->rank) return currentBest;  // we can't improve it, we're too far
+        auto bad = std::make_shared<SigToVerify>();
+        bad->from = fb->nodeId;
+        bad->level = l.level;
+        bad->rank = target.receptionRanks[fb->nodeId];
+        bad->sig.set(fb->nodeId);
+        bad->badSig = false;
+        l.toVerifyAgg.push_back(bad);
+        target.sigQueueSize++;
+        SigP newBest = l.bestToVerify();
+        if (newBest != bad) last = bad;
+        return newBest;
+      }
+    };
+    std::unique_ptr<HiddenByzantine> hiddenByzantine;  // :293, :303
     int currWindowSize;
     int addedCycle;
     bool done = false;
@@ -187,6 +269,7 @@ class Handel {
       receptionRanks.assign(h.params.nodeCount, 0);
       currWindowSize = h.params.window.initial;
       addedCycle = h.params.extraCycle;
+      if (h.params.hiddenByzantine && !byz) hiddenByzantine = std::make_unique<HiddenByzantine>();
     }
     void initLevel() {  // :319-329
       int rounded = roundPow2(h.params.nodeCount);
@@ -230,7 +313,11 @@ class Handel {
       return res;
     }
     void updateVerifiedSignatures(const SigP& vs) {  // :690-754
-      if (vs->badSig) throw IllegalStateException("We should not have invalid signatures in this scenario");
+      if (vs->badSig) {  // :688-694
+        blacklist.set(vs->from);
+        if (!h.params.byzantineSuicide) throw IllegalStateException("We should not have invalid signatures in this scenario");
+        return;
+      }
       HLevel& vsl = *levels[vs->level];
       if (!bitsetInclude(vsl.waitedSigs, vs->sig)) throw IllegalStateException("bad signature received");
       vsl.toVerifyInd.clear(vs->from);
@@ -303,6 +390,9 @@ class Handel {
       }
       if (byLevels.empty()) return;
       SigP best = byLevels[h.network_.rd.nextInt((jint)byLevels.size())];  // :788-790
+      // trying to add a nearly useless signature in the list so that signatures with a lower rank are not retained (:813-817)
+      if (hiddenByzantine && best->level == (int)levels.size() - 1) best = hiddenByzantine->attack(*this, best);
+      if (!best) throw IllegalStateException("checkSigs: attack() left no signature to check");  // (Java would NPE at :819)
       HLevel& l = *levels[best->level];
       int newSize = h.params.window.newSize(currWindowSize, !best->badSig);
       currWindowSize = std::min(newSize, l.size);

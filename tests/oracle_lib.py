@@ -139,18 +139,18 @@ class Handel:
     FIELDS = {"doneAt": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesReceived": 4, "sigsChecked": 5,
               "sigQueueSize": 6, "msgFiltered": 7, "currWindowSize": 8, "addedCycle": 9, "down": 10, "x": 11,
               "y": 12, "startAt": 13, "nodePairingTime": 14, "extraLatency": 15}
-    LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2}
+    LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2, "suicideBizAfter": 3}
     BITS = {"totalIncoming": 0, "lastAggVerified": 1, "verifiedIndSignatures": 2, "toVerifyInd": 3,
-            "finishedPeers": 4, "totalOutgoingLast": 5, "waitedSigs": 6}
+            "finishedPeers": 4, "totalOutgoingLast": 5, "waitedSigs": 6, "blacklist": 7}
 
     def __init__(self, node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
-                 nodes_down, nb=None, nl=None, desync=0, seed=0):
+                 nodes_down, nb=None, nl=None, desync=0, seed=0, byzantine_suicide=False, hidden_byzantine=False):
         ip = (C.c_int32 * 9)(node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
                              nodes_down, desync)
         self.h = C.c_void_p()
         self.n = node_count
-        _ck(lib().orc_handel_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
-                                    C.byref(self.h)))
+        _ck(lib().orc_handel_create_byz(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                        int(byzantine_suicide), int(hidden_byzantine), C.byref(self.h)))
         self.levels = lib().orc_handel_levels(self.h)
 
     def __del__(self):

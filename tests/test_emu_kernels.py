@@ -44,6 +44,7 @@ import test_zy_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 import test_gpu_snapshot as tsn  # noqa: E402
 import test_gpu_city as tcy  # noqa: E402
+import test_zx_gpu_handel_hostmode as thh  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -146,6 +147,12 @@ def test_batched_steps_protocols(monkeypatch):
     tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
     tf.test_fuzz_partitions_stops_and_discard(2)
     thm.test_batched_step_errors_are_loud()
+
+
+def test_handel_attack_scenarios_through_host_callbacks():  # P/Handel.java byzantineSuicide / hiddenByzantine vs the oracle
+    thh.test_byzantine_suicide()
+    thh.test_hidden_byzantine()
+    thh.test_byzantine_suicide_desynchronized_on_batched_steps()
 
 
 def test_host_callback_mode_pingpong():

@@ -38,6 +38,34 @@ GSF_NB = "RANDOM_SPEED=GAUSSIAN_TOR=0.00"  # RegistryNodeBuilders.name(RANDOM, t
 GSF_NL = "NetworkLatencyByDistanceWJitter"
 
 
+def _run_handel(**mode):
+    n, down = 256, 25
+    h = o.Handel(n, int(n * 0.9 * 0.99), 4, 50, 10, 20, 10, down, seed=3, **mode)
+    while h.cont_if() and h.info(False)["time"] < 20000:
+        h.run_ms(10)
+    return h
+
+
+def test_handel_attack_scenarios(oracle):
+    """P/Handel.java's byzantineSuicide (:538-559, 577-584, 688-694) and hiddenByzantine (:813-817, 840-917). The
+    reference has no test of either (PT/HandelTest is honest); what the code itself guarantees is checked: only down
+    nodes are ever blacklisted, suicide signatures cost verifications, the hidden attack blacklists nobody, and both runs
+    still reach the threshold on every live node."""
+    honest, suicide, hidden = _run_handel(), _run_handel(byzantine_suicide=True), _run_handel(hidden_byzantine=True)
+    for h in (honest, suicide, hidden):
+        assert not h.cont_if() and (h.read("doneAt")[h.read("down") == 0] > 0).all()
+    down = suicide.read("down") != 0
+    bl = suicide.read_bits("blacklist")
+    ids = [i for i in range(256) if (bl[:, i // 64] >> np.uint64(i % 64) & np.uint64(1)).any()]
+    assert ids and all(down[i] for i in ids)
+    assert not bl[down].any()  # a down node runs nothing
+    assert suicide.read("sigsChecked").sum() > honest.read("sigsChecked").sum()
+    assert (suicide.read_level("suicideBizAfter")[~down] >= -1).all() and (honest.read_level("suicideBizAfter") == -1).all()
+    assert not hidden.read_bits("blacklist").any() and not honest.read_bits("blacklist").any()
+    # the same seed draws the same topology and bad nodes in all three (init() does not depend on the scenario)
+    assert (honest.read("x") == suicide.read("x")).all() and (honest.read("down") == hidden.read("down")).all()
+
+
 def test_gsf_init_and_max_sig_in_level(oracle):  # testInit :22-47, testMaxSigInLevel :49-57
     g = o.GSFSignature(32, 1, 3, 20, 10, 10, 0, GSF_NB, GSF_NL)
     assert g.levels == 6

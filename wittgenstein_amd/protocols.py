@@ -46,7 +46,8 @@ class PingPong:
 
 class HandelParameters:
     """P/Handel.java:97-142 (constructor argument order preserved). byzantineSuicide / hiddenByzantine must be
-    False: those attack paths are not resident on the device."""
+    False here: those attack paths are not resident on the device — they run in host-callback mode
+    (examples/hostmode/handel.py on wittgenstein_amd.hostnet, checked against the oracle)."""
 
     def __init__(self, nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath,
                  nodesDown, nodeBuilderName=None, networkLatencyName=None, desynchronizedStart=0,
@@ -56,7 +57,8 @@ class HandelParameters:
             raise IllegalArgumentException("Only one attack at a time")
         if byzantineSuicide or hiddenByzantine or badNodes is not None:
             from .core import UnsupportedError
-            raise UnsupportedError("byzantine modes / explicit badNodes are not resident on the device")
+            raise UnsupportedError("byzantine modes / explicit badNodes are not resident on the device: run them in "
+                                   "host-callback mode (examples/hostmode/handel.py)")
         self.nodeCount, self.threshold, self.pairingTime, self.levelWaitTime = nodeCount, threshold, pairingTime, levelWaitTime
         self.extraCycle, self.disseminationPeriodMs, self.fastPath, self.nodesDown = extraCycle, disseminationPeriodMs, fastPath, nodesDown
         self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
