@@ -11,6 +11,7 @@
 #include "p2pflood.hpp"
 #include "pingpong.hpp"
 #include "sanfermin.hpp"
+#include "sanfermin_cappos.hpp"
 
 using namespace orc;
 
@@ -736,6 +737,74 @@ int orc_sanfermin_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rng
   return 0;
 }
 
+// ---- San Fermin, Cappos' variant (P/SanFerminCappos.java)
+struct OrcCappos {
+  std::unique_ptr<SanFerminCappos> p;
+};
+// ip: nodeCount, threshold, pairingTime, signatureSize, timeout, candidateCount (SanFerminParameters ctor order :87-106)
+int orc_cappos_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY SanFerminCappos::Params pr;
+  pr.nodeCount = ip[0];
+  pr.threshold = ip[1];
+  pr.pairingTime = ip[2];
+  pr.signatureSize = ip[3];
+  pr.timeout = ip[4];
+  pr.candidateCount = ip[5];
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcCappos();
+  h->p = std::make_unique<SanFerminCappos>(pr);
+  h->p->network_.rd.setSeed(seed);  // rd.setSeed(i) on the copy, then init() — which builds the nodes here (:121-126)
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_cappos_destroy(void* h) { delete (OrcCappos*)h; }
+int orc_cappos_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcCappos*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 totalNumberOfSigs(-1), 5 currentPrefixLength, 6 doneAt,
+//         7 thresholdAt, 8 cached levels, 9 cached values, 10 done, 11 isSwapping, 12 x, 13 y
+int orc_cappos_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcCappos*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.totalNumberOfSigs(-1); break;
+      case 5: v = n.currentPrefixLength; break;
+      case 6: v = n.doneAt; break;
+      case 7: v = n.thresholdAt; break;
+      case 8: v = (int64_t)n.signatureCache.size(); break;
+      case 9:
+        for (auto& e : n.signatureCache) v += (int64_t)e.second.size();
+        break;
+      case 10: v = n.done; break;
+      case 11: v = n.isSwapping; break;
+      case 12: v = n.x; break;
+      case 13: v = n.y; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_cappos_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered, uint64_t* tasks,
+                    int32_t* finished) {
+  auto& p = *((OrcCappos*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  *tasks = p.network_.statTasks;
+  *finished = (int32_t)p.finishedNodes.size();
+  return 0;
+}
 
 // ---- P2PFlood (P/P2PFlood.java over C/P2PNetwork.java, C/messages/FloodMessage.java)
 struct OrcFlood {

@@ -390,6 +390,41 @@ class SanFerminSignature:
                 "finished": f.value}
 
 
+class SanFerminCappos:
+    """oracle/sanfermin_cappos.hpp; params = (nodeCount, threshold, pairingTime, signatureSize, timeout, candidateCount) —
+    SanFerminParameters' ctor order (P/SanFerminCappos.java:87-106)."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "totalNumberOfSigs": 4,
+              "currentPrefixLength": 5, "doneAt": 6, "thresholdAt": 7, "cachedLevels": 8, "cachedValues": 9,
+              "done": 10, "isSwapping": 11, "x": 12, "y": 13}
+
+    def __init__(self, params, nb=None, nl=None, seed=0):
+        self.h, self.n = C.c_void_p(), params[0]
+        ip = (C.c_int32 * 6)(*params)
+        _ck(lib().orc_cappos_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                    C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_cappos_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_cappos_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_cappos_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d, k, f = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        lib().orc_cappos_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d), C.byref(k), C.byref(f))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value, "tasks": k.value,
+                "finished": f.value}
+
+
 class P2PFlood:
     """oracle/p2pflood.hpp; params = P2PFloodParameters' ctor order (P/P2PFlood.java:63-86): (nodeCount, deadNodeCount,
     delayBeforeResent, msgCount, msgToReceive, peersCount, delayBetweenSends)."""

@@ -45,6 +45,7 @@ import test_gpu_hostmode as thm  # noqa: E402
 import test_gpu_snapshot as tsn  # noqa: E402
 import test_gpu_city as tcy  # noqa: E402
 import test_zx_gpu_handel_hostmode as thh  # noqa: E402
+import test_zx_gpu_sanfermin_cappos as tsc  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -153,6 +154,11 @@ def test_handel_attack_scenarios_through_host_callbacks():  # P/Handel.java byza
     thh.test_byzantine_suicide()
     thh.test_hidden_byzantine()
     thh.test_byzantine_suicide_desynchronized_on_batched_steps()
+
+
+def test_sanfermin_cappos_through_host_callbacks():  # P/SanFerminCappos.java on the engine vs oracle/sanfermin_cappos.hpp
+    tsc.test_cappos_64_matches_oracle()
+    tsc.test_cappos_many_candidates_short_timeout_on_batched_steps()
 
 
 def test_host_callback_mode_pingpong():

@@ -66,6 +66,21 @@ def test_handel_attack_scenarios(oracle):
     assert (honest.read("x") == suicide.read("x")).all() and (honest.read("down") == hidden.read("down")).all()
 
 
+def test_sanfermin_cappos_aggregates_everything(oracle):
+    """P/SanFerminCappos.java has no test in the reference; what the protocol promises: a node that finishes holds the
+    whole set (its own signature + the best cached value of every level), thresholdAt precedes doneAt, and with a
+    generous timeout and every candidate tried nearly everybody finishes."""
+    c = o.SanFerminCappos((256, 128, 2, 48, 150, 8), seed=1)
+    for _ in range(80):
+        c.run_ms(50)
+    done = c.read("done") != 0
+    assert done.sum() >= 240 and c.info()["finished"] == done.sum()
+    assert (c.read("totalNumberOfSigs")[done] == 256).all() and (c.read("currentPrefixLength")[done] == 0).all()
+    th, da = c.read("thresholdAt"), c.read("doneAt")
+    assert (th[done] > 0).all() and (th[done] <= da[done]).all()
+    assert (c.read("msgSent") > 0).all() and c.read("msgReceived").sum() == c.info()["delivered"]
+
+
 def test_gsf_init_and_max_sig_in_level(oracle):  # testInit :22-47, testMaxSigInLevel :49-57
     g = o.GSFSignature(32, 1, 3, 20, 10, 10, 0, GSF_NB, GSF_NL)
     assert g.levels == 6
