@@ -2016,7 +2016,7 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
   h[HH_WINDOW] = (uint32_t)s.p.windowInitial;
   h[HH_ADDED] = (uint32_t)s.p.extraCycle;
   // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
-  h[HH_CTMIN] = (uint32_t)(down[node] ? INT32_MAX : startAt[node] + 1);
+  s.ct[2 * (size_t)node] = (uint32_t)(down[node] ? INT32_MAX : startAt[node] + 1);
 }
 
 // Handel.newContIf (P/Handel.java:1044-1053): some live node has doneAt == 0 or addedCycle > 0
@@ -2122,6 +2122,7 @@ struct HandelHost : ProtoHost {
     st.lsShift = L <= 16 ? 4 : 5;
     st.hdrStride = HH_LV + HP_COUNT * st.LS;  // 160 or 288 words: whole 128-byte lines
     st.hdr = rows((uint32_t*)nullptr, st.hdrStride, true);
+    st.ct = rows((uint32_t*)nullptr, 2, true);
     const size_t NL = (size_t)N * L;
     st.qent = rows((uint64_t*)nullptr, (size_t)L * 64, true, Engine::AC_SCRATCH);
     st.qfrom = rows((int32_t*)nullptr, (size_t)L * Q, false, Engine::AC_SCRATCH);

@@ -53,6 +53,10 @@ struct HandelState {
   //                              changed (store_levels), i.e. the scalars' line and the level's, not all ten lines
   GP<uint32_t> hdr;
   int32_t LS, lsShift, hdrStride;
+  // ConditionalTask.minStartTime and the epoch in which the task last left nextMessage()'s copy, two words a node, dense:
+  // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a 64-byte line of the record
+  // per node; only the nodes whose task is due touch their record (HH_CTMIN / HH_CTEPOCH of the record are unused)
+  GP<uint32_t> ct;
   GP<uint64_t> qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
   GP<int32_t> qfrom;                      // [N][L][Q]
   GP<uint64_t> qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
@@ -777,16 +781,18 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
     if (node < (uint32_t)s.hi) {
+      uint32_t WG_G* ct = s.ct + 2 * (size_t)node;
       uint32_t WG_G* h = h_hdr(s, (int32_t)node);
-      if (!d.nodes.down[node] && h[HH_CTEPOCH] != epoch) {
-        const int32_t ms = (int32_t)h[HH_CTMIN];
+      const uint32_t ctMin = ct[0], ctEpoch = ct[1];
+      if (!d.nodes.down[node] && ctEpoch != epoch) {
+        const int32_t ms = (int32_t)ctMin;
         if (ms <= until && ms <= t) {
-          h[HH_CTEPOCH] = epoch;
+          ct[1] = epoch;
           run = h[HH_SIGQ] != 0;  // startIf = hasSigToVerify (:345-347)
         }
       }
       if (run) {
-        h[HH_CTMIN] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
+        ct[0] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
         // sigQueueSize drifts above the real queue lengths: checkSigs then runs over empty
         // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node needs no visit
         if (h[HH_QMASK] == 0) run = false;
