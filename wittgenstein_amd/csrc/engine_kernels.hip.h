@@ -1812,6 +1812,9 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
 // are copied afterwards by the whole wavefront (coalesced). Nodes with a task, a chain hop or more than
 // 4 events go to activeB for k_deliver. Protocols opt in with P::LANE_MSGS and provide
 //   LaneNode, lane_begin / lane_message / lane_end     (action() of a message that emits nothing)
+#ifndef WG_COPY_UNROLL
+#define WG_COPY_UNROLL 4  // words a lane has in flight per round of the wide-payload copy
+#endif
 struct CopyJob {
   const uint64_t WG_G* src;
   uint64_t WG_G* dst;
@@ -1947,11 +1950,11 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
       totalWords += lane_bcast(incl, 63);
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < totalWords; i0 += 256) {
-      uint64_t v[4];
-      uint64_t WG_G* dp[4];
+    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
+      uint64_t v[WG_COPY_UNROLL];
+      uint64_t WG_G* dp[WG_COPY_UNROLL];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < WG_COPY_UNROLL; u++) {
         const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
         dp[u] = nullptr;
         v[u] = 0;
@@ -1971,7 +1974,7 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < WG_COPY_UNROLL; u++)
         if (dp[u]) *dp[u] = v[u];
     }
     __builtin_amdgcn_wave_barrier();
