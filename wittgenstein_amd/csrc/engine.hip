@@ -1966,7 +1966,8 @@ void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
     case WG_F_MSG_RECEIVED: return rd64(dev.nodes.msgReceived);
     case WG_F_MSG_SENT: return rd64(dev.nodes.msgSent);
     case WG_F_BYTES_SENT: return rd64(dev.nodes.bytesSent);
-    case WG_F_BYTES_RECEIVED: return rd64(dev.nodes.bytesReceived);
+    case WG_F_BYTES_RECEIVED:  // (a protocol whose messages all have size() 1 keeps the two counters as one)
+      return rd64(proto && proto->unit_message_size() ? dev.nodes.msgReceived : dev.nodes.bytesReceived);
     case WG_F_DOWN:
       for (int i = 0; i < n; i++) dst[i] = hdown[i];
       return;
@@ -2760,9 +2761,14 @@ struct CasperHost : ProtoHost {
     st.Bw = (st.B + 63) / 64;
     st.head = e.dalloc<int32_t>(N);
     st.recv = e.dalloc<uint64_t>((size_t)N * st.Aw);
-    st.blkRecv = e.dalloc<uint64_t>((size_t)N * st.Bw);
-    st.reeval = e.dalloc<uint64_t>((size_t)N * st.Bw);
-    st.headsAtt = e.dalloc<uint64_t>((size_t)N * st.Bw);
+    st.BS = 4;
+    while (st.BS < 3 * st.Bw) st.BS *= 2;
+    {
+      uint64_t* rec = e.dalloc<uint64_t>((size_t)N * st.BS);  // per node: blkRecv[Bw] | reeval[Bw] | headsAtt[Bw] | pad
+      st.blkRecv = rec;
+      st.reeval = rec + st.Bw;
+      st.headsAtt = rec + 2 * st.Bw;
+    }
     st.wf = e.dalloc<int32_t>(4);
     st.bHeight = e.dalloc<int32_t>(st.B);
     st.bParent = e.dalloc<int32_t>(st.B);
@@ -2793,18 +2799,20 @@ struct CasperHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
+  bool unit_message_size() const override { return true; }  // blocks and attestations: Message.size() default 1
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
     if (field < WG_F_CASPER_HEAD_HEIGHT || field > WG_F_CASPER_ATTESTATIONS_HELD) return false;
     std::vector<int32_t> head(n), bh(st.B), bt(st.B);
     WG_HIP(hipMemcpy(head.data(), st.head, 4 * (size_t)n, hipMemcpyDeviceToHost));
     WG_HIP(hipMemcpy(bh.data(), st.bHeight, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
     WG_HIP(hipMemcpy(bt.data(), st.bTime, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
-    auto popcounts = [&](const uint64_t* rows, int words) {
-      std::vector<uint64_t> h((size_t)n * words);
+    auto popcounts = [&](const uint64_t* rows, int words, int stride = 0) {  // (stride: words between two nodes' rows)
+      if (stride == 0) stride = words;
+      std::vector<uint64_t> h((size_t)(n - 1) * stride + words);
       WG_HIP(hipMemcpy(h.data(), rows, 8 * h.size(), hipMemcpyDeviceToHost));
       for (int i = 0; i < n; i++) {
         int64_t t = 0;
-        for (int w = 0; w < words; w++) t += __builtin_popcountll(h[(size_t)i * words + w]);
+        for (int w = 0; w < words; w++) t += __builtin_popcountll(h[(size_t)i * stride + w]);
         dst[i] = t;
       }
     };
@@ -2818,8 +2826,8 @@ struct CasperHost : ProtoHost {
       case WG_F_CASPER_HEAD_ID:
         for (int i = 0; i < n; i++) dst[i] = head[i];
         return true;
-      case WG_F_CASPER_HEADS_ATTESTED: popcounts(st.headsAtt, st.Bw); return true;
-      case WG_F_CASPER_BLOCKS_RECEIVED: popcounts(st.blkRecv, st.Bw); return true;
+      case WG_F_CASPER_HEADS_ATTESTED: popcounts(st.headsAtt, st.Bw, st.BS); return true;
+      case WG_F_CASPER_BLOCKS_RECEIVED: popcounts(st.blkRecv, st.Bw, st.BS); return true;
       default: popcounts(st.recv, st.Aw); return true;
     }
   }

@@ -56,6 +56,9 @@ struct ProtoHost {
   virtual bool read_bits(Engine&, int32_t, uint64_t*, int32_t, int32_t) { return false; }
   virtual int levels() const { return 0; }
   virtual int host_msg_size(uint32_t /*msg*/) const { return 1; }  // Message.size() of a host-side send
+  // every message of the protocol has size() 1: Node.bytesReceived == Node.msgReceived, its lane-per-event delivery kernel
+  // counts once and the read-back serves both fields from msgReceived
+  virtual bool unit_message_size() const { return false; }
   virtual bool delivered_by_level(Engine&, int64_t* /*dst32*/) { return false; }
   // the protocol's RunMultipleTimes continuation predicate, evaluated on the device
   virtual bool cont_if(Engine&, int32_t* /*out*/) { return false; }

@@ -26,6 +26,8 @@ constexpr uint32_t C_MSG_BLOCK = 0, C_MSG_ATTESTATION = 1;
 struct CasperState {
   wg_casper_params p;
   int32_t N, B, A, Aw, Bw;
+  int32_t BS;           // words of a node's block record: blkRecv | reeval | headsAtt side by side (3 Bw rounded up to a power of two), so an
+                        // attestation's look-ups of the three land in ONE cache line of its receiver instead of three
   GP<int32_t> head;        // [N] block index
   GP<uint64_t> recv;       // [N][Aw]
   GP<uint64_t> blkRecv;    // [N][Bw] blocksReceivedByBlockId
@@ -127,7 +129,7 @@ struct CasperProto {
     return b1 >= b2 ? o1 : o2;  // (randomOnTies is refused at load time)
   }
   __device__ static void reevaluate_head(Ctx& c, const State& s, NodeRegs& r) {  // :349-356, ascending block id
-    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.Bw;
+    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.BS;
     for (int w = 0; w < s.Bw; w++) {
       uint64_t m = ldc(re + w);
       while (m) {
@@ -197,8 +199,8 @@ struct CasperProto {
   }
   // BlockChainNode.onBlock :29-47 under CasperNode.onBlock :276-292 (delta >= 0 always: the formula adds the slot time)
   __device__ static bool on_block(Ctx& c, const State& s, NodeRegs& r, int32_t b) {
-    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.Bw;
-    uint64_t WG_G* br = s.blkRecv + (size_t)c.node * s.Bw;
+    uint64_t WG_G* re = s.reeval + (size_t)c.node * s.BS;
+    uint64_t WG_G* br = s.blkRecv + (size_t)c.node * s.BS;
     const bool known = bit(br, b);
     __builtin_amdgcn_wave_barrier();
     if (WG_LANE == 0) {
@@ -215,12 +217,12 @@ struct CasperProto {
     if (msg == C_MSG_ATTESTATION) {  // onAttestation :294-337
       const int32_t a = (int32_t)payload;
       const int32_t h = ldi(s.attHead + a);
-      const bool haveBlock = bit(s.blkRecv + (size_t)c.node * s.Bw, h);
+      const bool haveBlock = bit(s.blkRecv + (size_t)c.node * s.BS, h);
       __builtin_amdgcn_wave_barrier();
       if (WG_LANE == 0) {
         set_bit(s.recv + (size_t)c.node * s.Aw, a);
-        set_bit(s.headsAtt + (size_t)c.node * s.Bw, h);
-        if (haveBlock) set_bit(s.reeval + (size_t)c.node * s.Bw, h);
+        set_bit(s.headsAtt + (size_t)c.node * s.BS, h);
+        if (haveBlock) set_bit(s.reeval + (size_t)c.node * s.BS, h);
       }
       __threadfence_block();
       return;
@@ -305,16 +307,17 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
     res.ndraw = 0;
     if (!d.nodes.down[to] && (d.nparts == 0 || d.nodes.part[from] == d.nodes.part[to])) {  // C/Network.java:606
       const int32_t a = (int32_t)r.w3, h = s.attHead[a];
+      // (every Casper message has size() 1, C/messages/Message.java:19: bytesReceived == msgReceived for every node — kept
+      // once; the host reads msgReceived for both, CasperHost::unit_message_size)
       atomicAdd((unsigned long long*)&d.nodes.msgReceived[to], 1ULL);
-      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[to], 1ULL);
       atomicOr((unsigned long long*)(s.recv + (size_t)to * s.Aw + (a >> 6)), 1ULL << (a & 63));
       // (the votes of a slot mostly share their head: after a node's first one the bit is set, and a plain load leaves
       // the line clean — the atomics' dirty lines are what this kernel pays for, profiles/r02p_casper_pmc_WRITE_SIZE.md)
-      if (!((CasperProto::ldc(s.headsAtt + (size_t)to * s.Bw + (h >> 6)) >> (h & 63)) & 1ULL))
-        atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
-      if (((s.blkRecv[(size_t)to * s.Bw + (h >> 6)] >> (h & 63)) & 1ULL) &&
-          !((CasperProto::ldc(s.reeval + (size_t)to * s.Bw + (h >> 6)) >> (h & 63)) & 1ULL))  // (as headsAtt: set once, then clean)
-        atomicOr((unsigned long long*)(s.reeval + (size_t)to * s.Bw + (h >> 6)), 1ULL << (h & 63));
+      if (!((CasperProto::ldc(s.headsAtt + (size_t)to * s.BS + (h >> 6)) >> (h & 63)) & 1ULL))
+        atomicOr((unsigned long long*)(s.headsAtt + (size_t)to * s.BS + (h >> 6)), 1ULL << (h & 63));
+      if (((s.blkRecv[(size_t)to * s.BS + (h >> 6)] >> (h & 63)) & 1ULL) &&
+          !((CasperProto::ldc(s.reeval + (size_t)to * s.BS + (h >> 6)) >> (h & 63)) & 1ULL))  // (as headsAtt: set once, then clean)
+        atomicOr((unsigned long long*)(s.reeval + (size_t)to * s.BS + (h >> 6)), 1ULL << (h & 63));
       res.nrec = EV_DELIVERED;
     }
     if (aux.chain >= 0 && aux.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
 __global__ void k_casper_init(CasperState s) {
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= s.N) return;
-  s.blkRecv[(size_t)node * s.Bw] = 1ULL;  // blocksReceivedByBlockId.put(genesis.id, genesis)  C/BlockChainNode.java:21-26
+  s.blkRecv[(size_t)node * s.BS] = 1ULL;  // blocksReceivedByBlockId.put(genesis.id, genesis)  C/BlockChainNode.java:21-26
   if (node == 0) {
     s.bParent[0] = -1;  // genesis: Block(0)  C/Block.java:22-30
     *s.nBlocks = 1;
