@@ -338,6 +338,9 @@ struct EngineDev {
   GP<RunDesc> runs;
   uint32_t maxRuns;
   uint32_t runMin;
+  // message word + 1 of the K_MSG events the resident protocol delivers one lane per event, without inbox lists
+  // (ExpandF::lane_only); 0: every event is threaded onto its node's list
+  uint32_t laneMsgPlus1;
 };
 struct RunDesc {  // 32 bytes
   uint32_t chain, pos;      // envelope slot, first hop of the run

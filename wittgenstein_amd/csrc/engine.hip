@@ -2782,6 +2782,7 @@ struct CasperHost : ProtoHost {
     st.attHead = e.dalloc<int32_t>(st.A);
     st.mixed = e.dalloc<uint8_t>(N);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
+    e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
     hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st);

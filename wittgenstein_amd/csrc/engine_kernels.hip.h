@@ -423,6 +423,11 @@ struct ExpandF {
     d.g->nEvents = ne;
     d.g->outSlots = ns;
   }
+  // A protocol that delivers one kind of message one lane per EVENT (Casper's attestations, k_casper_attestations) has no
+  // use for those events' inbox lists: they are not threaded at expand (EngineDev::laneMsgPlus1) — one L2 atomic and one
+  // store less per event, and a node that only receives such messages never becomes a node visit. The protocol's kernel
+  // threads the few that fall to a node k_deliver visits after all (a node with another kind of event in the same ms).
+  __device__ bool lane_only(uint32_t msgWord) const { return d.laneMsgPlus1 != 0 && msgWord + 1u == d.laneMsgPlus1; }
   // thread the event onto its node's inbox list; returns true if it is the node's first event
   __device__ bool link(uint32_t e, int32_t to) const {
     if (d.sharded) {  // the event list is replicated on every shard; a shard applies the events of its own nodes
@@ -449,7 +454,7 @@ struct ExpandF {
           a.outBase = ob;
           a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
           d.evAux[e] = a;
-          if (!d.hostMode) first = link(e, (int32_t)r.w1);
+          if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1);
           firstNode = (int32_t)r.w1;
         }
       } else {
@@ -481,7 +486,7 @@ struct ExpandF {
           a.outBase = ob + q * d.boundMsg;
           a.outCap = d.boundMsg + (last ? 1u : 0u);
           d.evAux[e] = a;
-          if (!d.hostMode && link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+          if (!d.hostMode && !lane_only(c.msg) && link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
         }
         // sharded: the envelope's slot is released by every shard (deliver_event's release runs on one shard only)
         if (d.sharded && (int)(r.w2 + len) >= c.ndest) d.chains[r.w1].flags = 0;
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         a.outBase = rd.ob + q * d.boundMsg;
         a.outCap = d.boundMsg + (last ? 1u : 0u);
         d.evAux[e] = a;
-        if (!d.hostMode) first = f.link(e, to);
+        if (!d.hostMode && !f.lane_only(c.msg)) first = f.link(e, to);
       }
       const uint64_t m = __ballot(first);
       if (m) {

@@ -300,8 +300,14 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
     const Rec r = d.ev[e];
     if (!casper_is_attestation(r)) continue;
     const int32_t to = (int32_t)r.w1, from = rec_from(r);
-    if (s.mixed[to]) continue;  // k_deliver applies this node's events in order
-    const EvAux aux = d.evAux[e];
+    if (s.mixed[to]) {  // k_deliver applies this node's events in order: the attestation joins the node's inbox list now
+      // (expand did not thread it, ExpandF::lane_only; the node is on the active list through its other event)
+      const int32_t prev = atomicExch(F(&d.head[to]), (int32_t)e);
+      d.evNext[e] = prev;
+      if (prev < 0) set_err(d.g, ERR_PROTOCOL);
+      continue;
+    }
+    const EvAux aux = gld(d.evAux + e);
     EvRes res;
     res.nrec = 0;
     res.ndraw = 0;
