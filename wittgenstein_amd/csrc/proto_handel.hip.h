@@ -543,20 +543,38 @@ struct HandelProto {
     const int incl = (int)wave_incl_scan32((uint32_t)cti);
     const int below = incl - cti;
     bool open = false, fin = false;
-    int32_t cand = 0;
+    int32_t cand = 0, cand2 = 0;
     int myPos = 0;
+    bool two = false, fin2 = true;
     const int mySize = (lane >= 1 && lane < s.L) ? 1 << (lane - 1) : 0;
     if (mySize) {
       open = !ls->outFin[lane] && (c.t >= (lane - 1) * s.p.levelWaitTime || below == mySize);  // isOpen :458-472
       if (open) {
         myPos = ls->pos[lane];
-        cand = h_peer(s, (size_t)node * (s.N - 1) + (mySize - 1) + myPos);
+        const size_t at = (size_t)node * (s.N - 1) + (mySize - 1) + myPos;
+        cand = h_peer(s, at);
+        // ... and the peer after it, in the same round trip: when the first candidate is a finished peer the scan of
+        // getRemainingPeers usually ends at the next one. Only where neither a wrap of posInLevel nor the end-of-scan test
+        // (`posInLevel == start`, :499-503) can fall between the two: a level of more than two peers, not at its last position
+        two = mySize > 2 && myPos + 1 < mySize;
+        if (two) cand2 = h_peer(s, at + 1);
       }
     }
     KPROF_DECL;
     const uint64_t openM = __ballot(open);
     if (!openM) return;
-    if (open) fin = (ld_coherent(s.FP + (size_t)node * s.W + (cand >> 6)) >> (cand & 63)) & 1ULL;
+    if (open) {
+      const uint64_t WG_G* fpRow = s.FP + (size_t)node * s.W;
+      const uint64_t w1 = ld_coherent(fpRow + (cand >> 6));
+      const uint64_t w2 = two ? ld_coherent(fpRow + (cand2 >> 6)) : ~0ULL;
+      fin = (w1 >> (cand & 63)) & 1ULL;
+      fin2 = (w2 >> (cand2 & 63)) & 1ULL;
+      if (fin && two && !fin2) {  // the first candidate is rejected (no effect but posInLevel++), the second one is taken
+        cand = cand2;
+        myPos++;
+        fin = false;
+      }
+    }
     const bool lf = cti == mySize;  // incomingComplete :524-526
     // snapshots (SendSigs.sigs = totalOutgoing.clone() :254): totalOutgoing of level l is the node's own aligned
     // block of 2^(l-1) ids in the TI row, and those blocks are nested — so ONE copy of the highest open level's
