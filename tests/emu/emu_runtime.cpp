@@ -322,6 +322,8 @@ hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new emuEvent();
   return hipSuccess;
 }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) {
   delete e;
   return hipSuccess;

@@ -150,6 +150,12 @@ struct alignas(16) VisitDesc {
   Rec rec0;
   EvAux aux0;
 };
+// what k_msgs_classify hands k_msgs_apply for a message-only node: its (up to four) events sorted by event index
+struct alignas(16) MineDesc {
+  int32_t node;
+  uint32_t flags;  // VD_DOWN | partition id << 8
+  uint32_t s0, s1, s2, s3, pad0, pad1;
+};
 // per-event result written by deliver (8 bytes)
 struct EvRes {
   uint32_t nrec;      // records emitted | EV_DELIVERED / EV_TASK_RUN flags | level << 24
@@ -196,6 +202,7 @@ struct Globals {
   uint32_t nEvents;        // events in the bucket being drained (after chain-run expansion)
   uint32_t nActive;        // nodes with >= 1 event
   uint32_t nActiveB;       // ... of which the lane-per-node message kernel left to the wave-per-node kernel
+  uint32_t nActiveM;       // ... and the message-only ones k_msgs_classify listed for k_msgs_apply
   uint32_t outSlots;       // outbox slots handed out to the events of this ms
   uint32_t nOut;           // ordered outbox length
   uint32_t nDraws;         // draws in this phase
@@ -293,6 +300,7 @@ struct EngineDev {
   GP<int32_t> head;            // [n] newest event of the node this ms, -1 = none
   GP<uint32_t> active;         // nodes with >= 1 event (unordered)
   GP<VisitDesc> activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
+  GP<MineDesc> activeM;        // the ones it does, when the kernel runs as k_msgs_classify + k_msgs_apply
   uint32_t maxOut;
   GP<Out> outTmp;              // per-event slices (see Out)
   GP<uint32_t> recEv;          // event of each ordered outbox position

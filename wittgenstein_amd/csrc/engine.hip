@@ -529,6 +529,7 @@ void Engine::ensure_device() {
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
   dev.active = dalloc<uint32_t>(n);
   dev.activeB = dalloc<VisitDesc>(n);
+  dev.activeM = dalloc<MineDesc>(n, false, AC_SCRATCH);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false, AC_SCRATCH);
   dev.recEv = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
@@ -2294,11 +2295,44 @@ struct HandelHost : ProtoHost {
     int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
     return b < 16 ? 16 : b;
   }
+  // The lane-per-node message kernel in two halves (WG_MSGS_SPLIT=0: the fused k_deliver_msgs): k_msgs_classify walks the
+  // inbox lists and hands the mixed nodes to k_deliver (activeB) and the message-only ones to k_msgs_apply (activeM), which
+  // then runs on a second stream BESIDE k_deliver — disjoint nodes, no emissions, no draws. k_msgs_apply is a few thousand
+  // wavefronts of long dependent chains (most of the chip idles while it runs alone), k_deliver has the wavefronts to fill
+  // the chip: side by side the pass costs little more than k_deliver. Not under stream capture (WG_GRAPH).
+  int msgsSplit = getenv("WG_MSGS_SPLIT") ? atoi(getenv("WG_MSGS_SPLIT")) : 1;
+  bool graphMode = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
+  hipStream_t auxStream = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  ~HandelHost() override {
+    if (evFork) (void)hipEventDestroy(evFork);
+    if (evJoin) (void)hipEventDestroy(evJoin);
+    if (auxStream) (void)hipStreamDestroy(auxStream);
+  }
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     const int useB = laneMsgs ? 1 : 0;
-    if (useB)
+    const bool split = useB && msgsSplit && !graphMode;
+    if (split) {
+      if (!auxStream) {
+        WG_HIP(hipStreamCreate(&auxStream));
+        WG_HIP(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+        WG_HIP(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+      }
+      hipLaunchKernelGGL((k_msgs_classify<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      WG_HIP(hipEventRecord(evFork, g.stream));
+      WG_HIP(hipStreamWaitEvent(auxStream, evFork, 0));
+      hipLaunchKernelGGL((k_msgs_apply<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, auxStream, g.tab, stab);
+      WG_HIP(hipEventRecord(evJoin, auxStream));
+    } else if (useB)
       hipLaunchKernelGGL((k_deliver_msgs<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    struct Join {  // the pass ends when both halves have: whatever is enqueued next on the engine's stream waits for k_msgs_apply
+      hipStream_t s;
+      hipEvent_t e;
+      ~Join() {
+        if (e) (void)hipStreamWaitEvent(s, e, 0);
+      }
+    } join{g.stream, split ? evJoin : nullptr};
     // WG_DELIVER_PIPE=0: the plain loop (one dependent chain of round trips per visit) instead of the pipelined one
     const dim3 grid(node_grid(g.R), g.R);
     if (useB && pipeDeliver) {

@@ -1325,6 +1325,7 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
     g->nEvents = 0;
     g->nActive = 0;
     g->nActiveB = 0;
+    g->nActiveM = 0;
     g->outSlots = 0;
     g->nOut = 0;
     g->nDraws = 0;
@@ -1906,6 +1907,216 @@ __global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restric
     const bool toDown = (vflags & VD_DOWN) != 0;
     const uint8_t toPart = (uint8_t)(vflags >> 8);
     KPROF_MARK(d.g, 25);  // inbox walk + classification
+    if (mine) P::lane_begin(d, ps, node, r);
+    long long nRecv = 0, bRecv = 0;
+    uint32_t nJobs = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t e = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
+      CopyJob job;
+      job.nw = 0;
+      if (mine && e != 0xFFFFFFFFu) {
+        const Rec rec = d.ev[e];
+        const int32_t from = rec_from(rec);
+        uint32_t flags = 0;
+        if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
+          nRecv++;
+          bRecv += P::msg_size(ps, rec.w2);
+          flags = EV_DELIVERED | ((uint32_t)P::msg_level(rec.w2) << 24);
+          P::lane_message(d, ps, t, node, r, from, rec.w2, rec.w3, job);
+        }
+        EvRes res;
+        res.nrec = flags;
+        res.ndraw = 0;
+        d.evRes[e] = res;
+      }
+      const uint64_t jm = __ballot(job.nw > 0);
+      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
+      nJobs += (uint32_t)__popcll(jm);
+    }
+    if (mine) {
+      P::lane_end(d, ps, node, r);
+      if (nRecv) {
+        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 26);  // the lanes' messages
+    KPROF_ADD(d.g, 28, nJobs);
+    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
+    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
+    // after the other, and up to a few dozen jobs a wavefront.
+    uint32_t totalWords = 0;
+    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
+      const uint32_t j = base0 + (uint32_t)lane;
+      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
+      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
+      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
+      totalWords += lane_bcast(incl, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
+      uint64_t v[WG_COPY_UNROLL];
+      uint64_t WG_G* dp[WG_COPY_UNROLL];
+#pragma unroll
+      for (int u = 0; u < WG_COPY_UNROLL; u++) {
+        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
+        dp[u] = nullptr;
+        v[u] = 0;
+        if (idx < totalWords) {
+          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)shJobs[w][mid].pad <= idx)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          const CopyJob job = shJobs[w][lo];
+          const uint32_t off = idx - (uint32_t)job.pad;
+          v[u] = job.src[off];
+          dp[u] = job.dst + off;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WG_COPY_UNROLL; u++)
+        if (dp[u]) *dp[u] = v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    KPROF_ADD(d.g, 29, totalWords);
+    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
+  }
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_msgs_classify(const EngineDev* __restrict__ tab,
+                                                      const typename P::State* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const typename P::State& ps = stab[blockIdx.y];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 24);
+    const uint32_t a = base + lane;
+    const bool have = a < nActive;
+    const int32_t node = have ? (int32_t)d.active[a] : 0;
+    // the node's events, sorted by event index (the inbox list is in link order)
+    uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
+    bool mine = have;
+    // (the first event's record as plain locals: a VisitDesc filled piecemeal inside the loop would live in scratch memory)
+    uint32_t vflags = 0;
+    int32_t e0 = -1, next0 = -1;
+    Rec rec0 = make_rec(K_MSG, 0, 0, 0, 0);
+    EvAux aux0;
+    aux0.chain = -1;
+    aux0.cpos = 0;
+    aux0.outBase = 0;
+    aux0.outCap = 0;
+    if (have) {
+      int32_t e = d.head[node];
+      d.head[node] = -1;  // the list is consumed here (k_deliver works from the descriptor and evNext)
+      vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
+      e0 = e;
+      int cnt = 0;
+      while (e >= 0 && cnt < 4) {
+        uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
+        if (v < s0) { uint32_t x = s0; s0 = v; v = x; }
+        if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
+        if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
+        if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
+        const Rec rc = gld(d.ev + e);
+        const EvAux ax = gld(d.evAux + e);
+        const int32_t nx = d.evNext[e];
+        if (cnt == 0) {
+          rec0 = rc;
+          aux0 = ax;
+          next0 = nx;
+        }
+        if (rec_kind(rc) != K_MSG || ax.chain >= 0) mine = false;
+        cnt++;
+        e = nx;
+      }
+      if (e >= 0) mine = false;  // more than 4 events
+    }
+    {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
+      const bool toB = have && !mine;
+      const uint64_t m = __ballot(toB);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (toB) {
+          VisitDesc vd;
+          vd.node = node;
+          vd.e0 = e0;
+          vd.next0 = next0;
+          vd.flags = vflags;
+          vd.rec0 = rec0;
+          vd.aux0 = aux0;
+          gst(d.activeB + (bb + __popcll(m & lanes_lt())), vd);
+        }
+      }
+    }
+    {  // the nodes whose events are all plain messages: their sorted events go to k_msgs_apply
+      const uint64_t m = __ballot(mine);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveM), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (mine) {
+          MineDesc md;
+          md.node = node;
+          md.flags = vflags;
+          md.s0 = s0;
+          md.s1 = s1;
+          md.s2 = s2;
+          md.s3 = s3;
+          md.pad0 = md.pad1 = 0;
+          gst(d.activeM + (bb + __popcll(m & lanes_lt())), md);
+        }
+      }
+    }
+    KPROF_MARK(d.g, 25);  // inbox walk + classification
+  }
+}
+
+// ... the second half of k_deliver_msgs as a kernel of its own: the nodes k_msgs_classify listed (MineDesc), one lane each.
+// It touches no node k_deliver visits (those went to activeB), emits nothing and draws nothing, so the two run side by
+// side on two streams (HandelHost::launch_deliver): this kernel has a few thousand wavefronts of long dependent chains
+// and leaves the chip mostly idle, k_deliver has the wavefronts to fill it.
+template <class P>
+__global__ void __launch_bounds__(256) k_msgs_apply(const EngineDev* __restrict__ tab,
+                                                    const typename P::State* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const typename P::State& ps = stab[blockIdx.y];
+  __shared__ CopyJob shJobs[4][256];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nMine = d.g->nActiveM;
+  const int32_t t = d.g->now;
+  for (uint32_t base = wave * 64; base < nMine; base += nWaves * 64) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 24);
+    const uint32_t a = base + lane;
+    const bool mine = a < nMine;
+    MineDesc md;
+    md.node = 0;
+    md.flags = 0;
+    md.s0 = md.s1 = md.s2 = md.s3 = 0xFFFFFFFFu;
+    if (mine) md = gld(d.activeM + a);
+    const int32_t node = md.node;
+    const uint32_t vflags = md.flags, s0 = md.s0, s1 = md.s1, s2 = md.s2, s3 = md.s3;
+    typename P::LaneNode r;
+    const bool toDown = (vflags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vflags >> 8);
     if (mine) P::lane_begin(d, ps, node, r);
     long long nRecv = 0, bRecv = 0;
     uint32_t nJobs = 0;
