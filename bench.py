@@ -468,7 +468,10 @@ def main():
     init_s = init_wall / R
     log("[rank %d] init(): %d copies in %.1f s (%.1f s per simulation amortised over %d host threads; outside the timed "
         "region); %.2f GB per copy incl. its init() image" % (rank, R, init_wall, init_s, threads, per_copy / 1e9))
-    graph_mode = os.environ.get("WG_GRAPH", "0") not in ("", "0")  # the device loop replayed as a hipGraph: no HIP events
+    # WG_GRAPH=1: the device loop replayed as a hipGraph. The delivery pass is then bracketed by device clock stamps (one-lane
+    # kernels on the engine's stream writing s_memrealtime, Engine::ProfScope / k_prof_stamp) instead of HIP events, which a
+    # replayed graph would re-record; the spans-on-one-axis machinery of --batches > 1 (event based) is off there
+    graph_mode = os.environ.get("WG_GRAPH", "0") not in ("", "0")
 
     def restore_all():
         for g in sims:
@@ -502,10 +505,10 @@ def main():
             restore_s += time.perf_counter() - t_r
             restores += 1
         first_step = False
-        if i == 0 and not graph_mode:
+        if i == 0:
             sims[0].network().profile(1)
         run_step(single=(i == 0))  # (the first warm-up step as ONE batch on one stream: a clean per-phase breakdown)
-        if i == 0 and not graph_mode:
+        if i == 0:
             prof_phase = sims[0].network().profile_read()
             sims[0].network().profile(0)
     # ---- K timed steps: each step's RunMultipleTimes pass is bracketed by barrier + synchronize on both sides and the
@@ -526,9 +529,9 @@ def main():
             restore_s += time.perf_counter() - t_r
             restores += 1
         first_step = False
-        if not graph_mode:
-            for q in leads:  # HIP events around the delivery kernels only, inside the timed region; every concurrent
-                sims[q].network().profile(2)  # batch's lead, on one time axis (the first lead's reference event)
+        for q in leads:  # HIP events around the delivery kernels only, inside the timed region; every concurrent
+            sims[q].network().profile(2)  # batch's lead, on one time axis (the first lead's reference event)
+            if not graph_mode:
                 sims[q].network().profile_reference(sims[0].network())
         barrier()
         t0 = time.perf_counter()
@@ -617,8 +620,6 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
             traffic = tj.get("hbm_bytes_per_launch") * n_first / R
-    if graph_mode:  # no per-launch timing: the whole-run figure stands in, and says so
-        achieved = alg_bytes / (max(elapsed, 1e-9) * 1e9)
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (the delivery pass: "
                                                               "one launch of each per simulated ms)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -628,7 +629,9 @@ def main():
         "whole_run_achieved_GBs": alg_bytes / (max(elapsed, 1e-9) * 1e9),
     }
     if graph_mode:
-        out["roofline"]["note"] = "WG_GRAPH=1: the chunk is replayed as a hipGraph, no per-launch HIP events; achieved = whole-run algorithmic bytes / wall time"
+        out["roofline"]["note"] = ("WG_GRAPH=1: runMs(chunk) of the batch is captured once and replayed as a hipGraph; the delivery pass is "
+                                   "bracketed by device clock stamps (one-lane kernels on the engine's stream writing s_memrealtime before "
+                                   "and after the pass) — a HIP event inside a replayed graph keeps its last replay only. ")
     if nb > 1 and chip_union_ns > 0:
         # the delivery pass on the CHIP: all batches' delivery launches on one time axis; bytes of all copies over the time
         # during which at least one of them runs (their union) — the per-stream figure above counts the chip's sharing twice

@@ -14,6 +14,7 @@
 // run in lock-step between collectives (lane 0 runs until it blocks, then lane 1, ...), so code that
 // relies on lock-step without a wave barrier fails here — stricter than the hardware, on purpose.
 #pragma once
+#include <chrono>
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
@@ -79,6 +80,15 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
 hipError_t hipStreamQuery(hipStream_t s);
 inline void __threadfence_system() {}
+// the constant-rate device clock (s_memrealtime) the engine's graph-mode profiler stamps with, and its rate in kHz
+inline unsigned long long wall_clock64() {
+  return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+  *v = 100000;
+  return hipSuccess;
+}
 // stream capture / graphs: while a stream is capturing, launches and async memsets are recorded instead of executed;
 // hipGraphLaunch replays the record (what the engine's WG_GRAPH=1 path relies on)
 typedef struct emuGraph* hipGraph_t;

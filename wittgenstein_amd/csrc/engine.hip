@@ -162,6 +162,8 @@ Engine::~Engine() {
   }
   for (auto ev : profFree) (void)hipEventDestroy(ev);
   if (profOwnRef) (void)hipEventDestroy(profOwnRef);
+  if (dStamps) (void)hipFree(dStamps);
+  if (dStampCnt) (void)hipFree(dStampCnt);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -175,7 +177,38 @@ hipEvent_t Engine::prof_event() {
   WG_HIP(hipEventCreate(&ev));
   return ev;
 }
+__global__ void k_prof_stamp(uint64_t* __restrict__ ring, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t tag) {
+  const uint32_t i = atomicAdd(cnt, 1u) % cap;
+  ring[2 * (size_t)i] = tag;
+  ring[2 * (size_t)i + 1] = wall_clock64();
+}
+void Engine::prof_stamp(int tag) {
+  if (!dStamps) {
+    WG_HIP(hipMalloc((void**)&dStamps, sizeof(uint64_t) * 2 * PROF_STAMP_CAP));
+    WG_HIP(hipMalloc((void**)&dStampCnt, sizeof(uint32_t)));
+    WG_HIP(hipMemset(dStampCnt, 0, sizeof(uint32_t)));
+  }
+  hipLaunchKernelGGL(k_prof_stamp, dim3(1), dim3(1), 0, stream, dStamps, dStampCnt, PROF_STAMP_CAP, (uint32_t)tag);
+}
 void Engine::prof_collect() {
+  if (dStampCnt) {  // the records of the replayed graphs: a begin stamp of a class, then its end stamp
+    uint32_t n = 0;
+    WG_HIP(hipMemcpy(&n, dStampCnt, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n > PROF_STAMP_CAP) n = PROF_STAMP_CAP;  // (the ring wrapped: the oldest records are gone, the rest still pair up)
+    std::vector<uint64_t> h(2 * (size_t)n);
+    if (n) WG_HIP(hipMemcpy(h.data(), dStamps, sizeof(uint64_t) * 2 * n, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemset(dStampCnt, 0, sizeof(uint32_t)));
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg.device);
+    const double nsPerTick = 1e6 / (double)(khz > 0 ? khz : 100000);
+    for (uint32_t i = 0; i + 1 < n; i++) {
+      const uint64_t a = h[2 * (size_t)i], b = h[2 * (size_t)i + 2];
+      if ((a & 1) || b != a + 1 || a / 2 >= PC_COUNT) continue;
+      profNs[a / 2] += (double)(h[2 * (size_t)i + 3] - h[2 * (size_t)i + 1]) * nsPerTick;
+      profLaunches[a / 2]++;
+      i++;
+    }
+  }
   for (auto& sp : profSpans) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
@@ -1444,7 +1477,9 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   };
   for (int32_t k = 0; k <= ms; k++) {
     const int32_t t = time + k;
-    if (k > 0 && stagedMin - t < dev.horizon) {  // (see run_group)
+    // (see run_group) — the far envelopes were parked by k_shard_unpack on every shard alike, so every shard stages the same
+    if (dev.farBuf && (t % dev.horizon) == 0) collect_far();
+    if (k > 0 && stagedMin - t < dev.horizon) {
       WG_HIP(hipStreamSynchronize(stream));
       flush_staged(t, true);
     }
@@ -1464,6 +1499,11 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     if (nOut) {
       hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
       exchange_outbox(nOut);
+      if (dev.maxSendAll) {  // the Network.sendAll calls among them: destinations, envelopes, first arrivals — on every shard
+        hipLaunchKernelGGL(k_sendall_lat, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab);
+        hipLaunchKernelGGL(k_sendall_scan, dim3(GRID_DELIVER_SMALL / 8 > 0 ? GRID_DELIVER_SMALL / 8 : 1, 1), dim3(1024), 0, stream, g.tab);
+        hipLaunchKernelGGL(k_sendall_scatter, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab, g.binBits);
+      }
     }
     append_phase(g, false);
     end_phase(g, true);
@@ -1477,6 +1517,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   WG_HIP(hipStreamSynchronize(stream));
   auto t1 = std::chrono::steady_clock::now();
   if (profiling) prof_collect();
+  collect_far();  // (as run_group: what the last ms parked counts in msgs.size() from now on)
   sync_globals_to_host();
   time = endAt;
   if (didSomething) *didSomething = gh.anyEvent ? 1 : 0;
@@ -1879,19 +1920,25 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
     hipLaunchKernelGGL(k_chunk_end, dim3(n), dim3(64), 0, g.stream, tab, dCont, maxTime, dRunning);
   };
   // WG_GRAPH=1: the chunk is captured once into a hipGraph and replayed — one graph launch instead of ~30 kernel
-  // launches per simulated ms (off by default; not with the HIP-event profiler, whose events would be re-recorded)
+  // launches per simulated ms. The profiler's brackets are device clock stamps there (ProfScope / k_prof_stamp: a HIP
+  // event captured into the graph would keep its last replay only).
   static const bool wantGraph = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   try {
-    if (wantGraph && !l.profiling) {
+    if (wantGraph) {
+      if (l.profiling) l.prof_stamp(2 * Engine::PC_COUNT);  // (allocates the ring outside the capture; an unpaired tag)
+      WG_HIP(hipStreamSynchronize(g.stream));
       WG_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeRelaxed));
+      l.profStamping = true;
       try {
         enqueue_chunk();
       } catch (...) {
+        l.profStamping = false;
         (void)hipStreamEndCapture(g.stream, &graph);
         throw;
       }
+      l.profStamping = false;
       WG_HIP(hipStreamEndCapture(g.stream, &graph));
       WG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     }
@@ -2295,12 +2342,13 @@ struct HandelHost : ProtoHost {
     int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
     return b < 16 ? 16 : b;
   }
-  // The lane-per-node message kernel in two halves (WG_MSGS_SPLIT=0: the fused k_deliver_msgs): k_msgs_classify walks the
-  // inbox lists and hands the mixed nodes to k_deliver (activeB) and the message-only ones to k_msgs_apply (activeM), which
-  // then runs on a second stream BESIDE k_deliver — disjoint nodes, no emissions, no draws. k_msgs_apply is a few thousand
-  // wavefronts of long dependent chains (most of the chip idles while it runs alone), k_deliver has the wavefronts to fill
-  // the chip: side by side the pass costs little more than k_deliver. Not under stream capture (WG_GRAPH).
-  int msgsSplit = getenv("WG_MSGS_SPLIT") ? atoi(getenv("WG_MSGS_SPLIT")) : 1;
+  // WG_MSGS_SPLIT=1: the lane-per-node message kernel in two halves — k_msgs_classify walks the inbox lists and hands the
+  // mixed nodes to k_deliver (activeB) and the message-only ones to k_msgs_apply (activeM), which then runs on a second
+  // stream BESIDE k_deliver (disjoint nodes, no emissions, no draws). Measured (profiles/r05j_*): side by side both halves
+  // slow down by what the other takes from the chip (k_deliver 211 -> 272 us, the message half 83 -> 202 us per ms), the
+  // pass is no shorter and the step 6 % longer (309.9 vs 329.0 M msgs/s) — so the fused k_deliver_msgs on the engine's own
+  // stream is the default. Not under stream capture (WG_GRAPH).
+  int msgsSplit = getenv("WG_MSGS_SPLIT") ? atoi(getenv("WG_MSGS_SPLIT")) : 0;
   bool graphMode = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
   hipStream_t auxStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -2771,7 +2819,6 @@ struct CasperHost : ProtoHost {
       throw WgError(WG_EUNSUPPORTED, "randomOnTies: the tie's rd.nextBoolean() decides a head inside action() (not resident)");
     if (p.blockConstructionTime <= 0 || p.attestationConstructionTime <= 0)
       throw WgError(WG_EUNSUPPORTED, "construction times must be >= 1 ms (a sendAll for the current ms would have to be delivered in it)");
-    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "Casper IMD does not run on a sharded engine yet");
     if (!e.allocated) {
       e.sendAllCapacity = p.attestersPerRound + 2;  // one round of attesters votes in the same ms (+ a block)
       // every in-flight sendAll holds N destinations until its last hop: one slot's worth of them is in flight at most
@@ -2793,15 +2840,25 @@ struct CasperHost : ProtoHost {
     st.A = p.maxSlots * p.attestersPerRound;
     st.Aw = (st.A + 63) / 64;
     st.Bw = (st.B + 63) / 64;
-    st.head = e.dalloc<int32_t>(N);
-    st.recv = e.dalloc<uint64_t>((size_t)N * st.Aw);
+    // Per-node rows are held for the nodes [lo, hi) this engine owns — everything when it is not sharded — behind pointers
+    // offset so that kernels keep indexing by node id (as HandelHost does); the block / attestation tables are replicated.
+    lo = e.shardCount > 0 ? e.dev.shardLo : 0;
+    hi = e.shardCount > 0 ? e.dev.shardHi : N;
+    const size_t own = (size_t)(hi - lo);
+    st.head = e.dalloc<int32_t>(own) - lo;
+    st.recv = e.dalloc<uint64_t>(own * st.Aw) - (size_t)lo * st.Aw;
     st.BS = 4;
     while (st.BS < 3 * st.Bw) st.BS *= 2;
     {
-      uint64_t* rec = e.dalloc<uint64_t>((size_t)N * st.BS);  // per node: blkRecv[Bw] | reeval[Bw] | headsAtt[Bw] | pad
+      uint64_t* rec = e.dalloc<uint64_t>(own * st.BS) - (size_t)lo * st.BS;  // per node: blkRecv[Bw] | reeval[Bw] | headsAtt[Bw] | pad
       st.blkRecv = rec;
       st.reeval = rec + st.Bw;
       st.headsAtt = rec + 2 * st.Bw;
+    }
+    if (e.shardCount > 0) {
+      xtabWords = XT_HEAD + 2 * st.Aw + p.attestersPerRound;
+      st.xtab = e.dalloc<int32_t>((size_t)xtabWords);
+      st.anyTask = e.dalloc<uint32_t>(1);
     }
     st.wf = e.dalloc<int32_t>(4);
     st.bHeight = e.dalloc<int32_t>(st.B);
@@ -2819,8 +2876,19 @@ struct CasperHost : ProtoHost {
     e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
-    hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st);
+    hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, lo, hi);
     WG_HIP(hipStreamSynchronize(e.stream));
+  }
+  int32_t lo = 0, hi = 0, xtabWords = 0;
+  // ---- node-range sharding (Engine::run_ms_sharded): a delivery touches the receiver's rows only; sendAll goes through the
+  // replicated envelope creation (k_shard_multi_*, k_sendall_*); what the ms's action()s added to the replicated block /
+  // attestation tables is exchanged after the delivery pass (CasperState::xtab, k_casper_shard_apply) — in the ms that hold
+  // a block or a task at all, which every shard sees from the replicated event list (anyTask)
+  bool supports_shards() const override { return true; }
+  uint32_t* shard_snap_enqueue(const Group&) override { return st.anyTask; }
+  void shard_snap_exchange(Engine& e, const Group& g, uint32_t) override {
+    e.shard_allreduce(st.xtab, xtabWords);
+    hipLaunchKernelGGL(k_casper_shard_apply, dim3(1, 1), dim3(256), 0, g.stream, g.tab, (const CasperState*)g.stab);
   }
   void launch_deliver(const Group& g) override {
     const CasperState* stab = (const CasperState*)g.stab;
@@ -2837,29 +2905,32 @@ struct CasperHost : ProtoHost {
   bool unit_message_size() const override { return true; }  // blocks and attestations: Message.size() default 1
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
     if (field < WG_F_CASPER_HEAD_HEIGHT || field > WG_F_CASPER_ATTESTATIONS_HELD) return false;
+    if (n != st.N) throw WgError(WG_EINVAL, "n must be the node count");
+    for (int i = 0; i < n; i++) dst[i] = 0;  // (sharded: zeros for the nodes of other shards)
     std::vector<int32_t> head(n), bh(st.B), bt(st.B);
-    WG_HIP(hipMemcpy(head.data(), st.head, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(head.data() + lo, st.head + lo, 4 * (size_t)(hi - lo), hipMemcpyDeviceToHost));
     WG_HIP(hipMemcpy(bh.data(), st.bHeight, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
     WG_HIP(hipMemcpy(bt.data(), st.bTime, 4 * (size_t)st.B, hipMemcpyDeviceToHost));
     auto popcounts = [&](const uint64_t* rows, int words, int stride = 0) {  // (stride: words between two nodes' rows)
       if (stride == 0) stride = words;
-      std::vector<uint64_t> h((size_t)(n - 1) * stride + words);
-      WG_HIP(hipMemcpy(h.data(), rows, 8 * h.size(), hipMemcpyDeviceToHost));
-      for (int i = 0; i < n; i++) {
+      if (hi <= lo) return;
+      std::vector<uint64_t> h((size_t)(hi - lo - 1) * stride + words);
+      WG_HIP(hipMemcpy(h.data(), rows + (size_t)lo * stride, 8 * h.size(), hipMemcpyDeviceToHost));
+      for (int i = lo; i < hi; i++) {
         int64_t t = 0;
-        for (int w = 0; w < words; w++) t += __builtin_popcountll(h[(size_t)i * stride + w]);
+        for (int w = 0; w < words; w++) t += __builtin_popcountll(h[(size_t)(i - lo) * stride + w]);
         dst[i] = t;
       }
     };
     switch (field) {
       case WG_F_CASPER_HEAD_HEIGHT:
-        for (int i = 0; i < n; i++) dst[i] = bh[head[i]];
+        for (int i = lo; i < hi; i++) dst[i] = bh[head[i]];
         return true;
       case WG_F_CASPER_HEAD_TIME:
-        for (int i = 0; i < n; i++) dst[i] = bt[head[i]];
+        for (int i = lo; i < hi; i++) dst[i] = bt[head[i]];
         return true;
       case WG_F_CASPER_HEAD_ID:
-        for (int i = 0; i < n; i++) dst[i] = head[i];
+        for (int i = lo; i < hi; i++) dst[i] = head[i];
         return true;
       case WG_F_CASPER_HEADS_ATTESTED: popcounts(st.headsAtt, st.Bw, st.BS); return true;
       case WG_F_CASPER_BLOCKS_RECEIVED: popcounts(st.blkRecv, st.Bw, st.BS); return true;

@@ -302,17 +302,32 @@ class Engine {
   hipEvent_t profOwnRef = nullptr;         // recorded on this engine's stream by wg_profile_enable
   hipEvent_t profRef = nullptr;            // the reference in use (may belong to another engine)
   std::vector<std::pair<double, double>> profTimes[PC_COUNT];
+  // Under stream capture (the device loop replayed as a hipGraph) a HIP event would be re-recorded by every replay and keep
+  // the last one only: there the bracket is a pair of one-lane kernels that append (tag, s_memrealtime) records to a device
+  // ring (k_prof_stamp) — the same span, on the same stream, read back by prof_collect().
+  bool profStamping = false;               // set while the chunk is being captured
+  uint64_t* dStamps = nullptr;             // [PROF_STAMP_CAP][2]: tag (class * 2 + end), clock
+  uint32_t* dStampCnt = nullptr;
+  static constexpr uint32_t PROF_STAMP_CAP = 1u << 18;
+  void prof_stamp(int tag);
   struct ProfScope {
     Engine& e;
     size_t idx = (size_t)-1;
+    int stamped = -1;
     ProfScope(Engine& en, int cls) : e(en) {
       if (!(e.profiling == 1 || (e.profiling == 2 && cls == PC_DELIVER))) return;
+      if (e.profStamping) {
+        e.prof_stamp(cls * 2);
+        stamped = cls;
+        return;
+      }
       ProfSpan s{cls, e.prof_event(), e.prof_event()};
       (void)hipEventRecord(s.a, e.stream);
       idx = e.profSpans.size();
       e.profSpans.push_back(s);
     }
     ~ProfScope() {
+      if (stamped >= 0) e.prof_stamp(stamped * 2 + 1);
       if (idx != (size_t)-1) (void)hipEventRecord(e.profSpans[idx].b, e.stream);
     }
   };

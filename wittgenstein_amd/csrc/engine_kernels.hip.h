@@ -542,6 +542,8 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         if (first) d.active[base + __popcll(m & lanes_lt())] = (uint32_t)to;
       }
     }
+    // sharded: the envelope's slot is released by every shard (as ExpandF::write does for the runs it unrolls in place)
+    if (d.sharded && lane == 0 && (int)(rd.pos + rd.len) >= c.ndest) d.chains[rd.chain].flags = 0;
   }
 }
 
@@ -658,6 +660,22 @@ __device__ __forceinline__ uint32_t shuffle_dests(const EngineDev& d, const Out&
   return n > 1 ? (uint32_t)(n - 1) : 0u;
 }
 
+// an arrival beyond the bucket ring: parked for the host (FarRec, Engine::collect_far) if the engine keeps a far buffer and
+// the arrival is at least two rings ahead; false = it cannot be held (ERR_HORIZON)
+__device__ __forceinline__ bool park_far(const EngineDev& d, int32_t t, uint32_t p, const Rec& fin, int32_t arrival) {
+  uint32_t k = 0xFFFFFFFFu;
+  if (d.farBuf && arrival - t >= 2 * d.horizon) k = atomicAdd(&d.g->nFar, 1u);
+  if (k >= d.farCap) return false;
+  FarRec fr;
+  fr.ms = t;
+  fr.p = p;
+  fr.rec = fin;
+  fr.arrival = arrival;
+  fr.pad = 0;
+  d.farBuf[k] = fr;
+  return true;
+}
+
 // SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
 // emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
@@ -735,11 +753,21 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         arrival = o.t;
         break;
       case O_SENDALL: {  // Network.sendAll(m, sendTime, from) inside an action(): N destinations, resolved by k_sendall_*
-        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
-        if (SH || d.maxSendAll == 0) {
+        if (d.maxSendAll == 0) {
           set_err(d.g, ERR_MULTI_TOO_BIG);
           break;
         }
+        if (SH) {
+          // sharded: the envelope (slot, destination slice, descriptor) is replicated state — every shard creates it from
+          // the exchanged image (k_shard_multi_fill / k_shard_multi_create, numbered in push order by MultiF) and then
+          // resolves the destinations itself (k_sendall_*: a pure function of (from, seed)); here only its place in the
+          // push order. No arrival yet: k_sendall_scan files the first hop's.
+          fin = make_rec(K_CHAIN, from, (uint32_t)d.nodes.n, 0, SENDALL_FRESH);
+          arrival = -1;
+          atomicAdd(&d.xbuf[-XB_HEAD], 1);
+          break;
+        }
+        int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
         const uint32_t k = atomicAdd(&d.g->nSendAll, 1u);
         if (k >= d.maxSendAll) {
           set_err(d.g, ERR_MULTI_TOO_BIG);
@@ -778,20 +806,8 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
       } else if (arrival == t) {
         set_err(d.g, ERR_SAME_MS);
         arrival = -1;
-      } else if (arrival - t >= d.horizon) {
-        uint32_t k = 0xFFFFFFFFu;
-        if (!SH && d.farBuf && arrival - t >= 2 * d.horizon) k = atomicAdd(&d.g->nFar, 1u);
-        if (k < d.farCap) {  // parked for the host (FarRec): not filed in a bucket now
-          FarRec fr;
-          fr.ms = t;
-          fr.p = p;
-          fr.rec = fin;
-          fr.arrival = arrival;
-          fr.pad = 0;
-          d.farBuf[k] = fr;
-        } else {
-          set_err(d.g, ERR_HORIZON);
-        }
+      } else if (!SH && arrival - t >= d.horizon) {  // (sharded: k_shard_unpack parks it, on every shard alike)
+        if (!park_far(d, t, p, fin, arrival)) set_err(d.g, ERR_HORIZON);
         arrival = -1;
       }
     }
@@ -814,6 +830,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
 // sharded engine: the summed exchange image -> ordered outbox + tile histograms, identically on every shard
 __global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
+  const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
   const uint32_t D = (uint32_t)d.horizon;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
@@ -823,7 +840,11 @@ __global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restric
     fin.w1 = (uint32_t)x[1];
     fin.w2 = (uint32_t)x[2];
     fin.w3 = (uint32_t)x[3];
-    const int32_t arrival = x[4] - 1;
+    int32_t arrival = x[4] - 1;
+    if (arrival >= 0 && arrival - t >= d.horizon) {  // every shard holds the same far envelopes (the scheduler is replicated)
+      if (!park_far(d, t, p, fin, arrival)) set_err(d.g, ERR_HORIZON);
+      arrival = -1;
+    }
     d.fin[p] = fin;
     d.arr[p] = arrival;
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
@@ -841,7 +862,8 @@ struct MultiF {
   __device__ uint32_t count() const { return d.g->nOut; }
   __device__ bool fresh(uint32_t p) const {
     const Rec r = d.fin[p];
-    return d.arr[p] >= 0 && rec_kind(r) == K_CHAIN && r.w3 == MULTI_FRESH;
+    if (rec_kind(r) != K_CHAIN) return false;
+    return (d.arr[p] >= 0 && r.w3 == MULTI_FRESH) || (d.arr[p] < 0 && r.w3 == SENDALL_FRESH);
   }
   __device__ uint64_t value(uint32_t p) const { return fresh(p) ? (((uint64_t)d.fin[p].w1 << 32) | 1u) : 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
@@ -867,6 +889,15 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
     if (!shard_owns(d, (int32_t)d.ev[e].w1)) continue;  // (the image is zero on entry)
     const Out o = d.outTmp[d.evAux[e].outBase + (p - d.evRecOff[e])];
     const int32_t from = (int32_t)(o.kindfrom & 0x0FFFFFFFu);
+    if ((o.kindfrom >> 28) == O_SENDALL) {  // Network.sendAll: the descriptor; destinations are resolved on every shard
+      int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
+      x[0] = draw_next_int(d, d.evDrawOff[e] + o.drawsub);
+      x[1] = o.t;
+      x[2] = (int32_t)o.a;
+      x[3] = (int32_t)o.b;
+      x[4] = -1;
+      continue;
+    }
     // (a shuffled list was permuted in the scratch ring by k_resolve<true> already; its draws precede the seed)
     const uint32_t shuffled = (o.pad & OUT_SHUFFLE) && o.to > 1 ? (uint32_t)((o.to < 64 ? o.to : 64) - 1) : 0u;
     const int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub + shuffled);
@@ -897,6 +928,26 @@ __global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __r
     }
     const unsigned long long off = (d.g->destHead + d.multiOff[p]) % d.chainDests;
     const int m = x[4];
+    if (m < 0) {  // a Network.sendAll: descriptor for k_sendall_* (which create the envelope and file its first arrival)
+      const uint32_t k = atomicAdd(&d.g->nSendAll, 1u);
+      if (k >= d.maxSendAll) {
+        set_err(d.g, ERR_MULTI_TOO_BIG);
+        continue;
+      }
+      SendAllDesc sd;
+      sd.p = p;
+      sd.from = rec_from(r);
+      sd.seed = x[0];
+      sd.sendTime = x[1];
+      sd.slot = slot;
+      sd.msg = (uint32_t)x[2];
+      sd.payload = (uint32_t)x[3];
+      sd.pad = 0;
+      sd.destOff = off;
+      d.saDesc[k] = sd;
+      d.fin[p] = make_rec(K_CHAIN, sd.from, slot, 0, 0);
+      continue;
+    }
     for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)j) % d.chainDests] = x[6 + j];
     Chain c;
     c.from = rec_from(r);

@@ -41,7 +41,17 @@ struct CasperState {
   GP<int32_t> attHead;     // [A]
   GP<uint8_t> mixed;       // [N] this ms the node has an event that is not an attestation (block, task): ordered visit
   uint32_t laneEvents;  // 1: attestation-only nodes are delivered one lane per event (k_casper_attestations)
+  // Node-range sharding (Engine::run_ms_sharded): per-node rows are touched by the node's owner only; the block and
+  // attestation tables are replicated and filled by exchange — what the action()s of this ms added to them (at most one
+  // block, the votes of one height) goes into `xtab`, is summed across shards and applied by k_casper_shard_apply on the
+  // shards that did not create it. A table entry written in ms t is first read in a later ms (a block or an attestation
+  // is known to a node only once delivered), so an exchange at the end of the ms's delivery pass is early enough.
+  //   xtab: [0] blocks created, [1] height, [2] parent, [3] producer, [4] time, [XT_HEAD + 2 w + {0,1}] halves of
+  //         blockAtt word w, [XT_HEAD + 2 Aw + j] head + 1 of the vote with attestation index height * attestersPerRound + j
+  GP<int32_t> xtab;
+  GP<uint32_t> anyTask;    // [1] this ms holds an event that is not an attestation (replicated: the exchange is due)
 };
+constexpr int XT_HEAD = 8;
 
 struct CasperProto {
   typedef CasperState State;
@@ -169,6 +179,17 @@ struct CasperProto {
         res |= ldc(rv + w) & ldc(s.headMask + (size_t)cur * s.Aw + w);  // phase 2: attestationsByHead of the branch
       res &= range_mask(w, 0, (int64_t)height * s.p.attestersPerRound) & ~all;  // a.height < height, not yet included
       s.blockAtt[(size_t)idx * s.Aw + w] = res;
+      if (c.d.sharded) {
+        s.xtab[XT_HEAD + 2 * w] = (int32_t)(uint32_t)res;
+        s.xtab[XT_HEAD + 2 * w + 1] = (int32_t)(uint32_t)(res >> 32);
+      }
+    }
+    if (c.d.sharded && WG_LANE == 0) {
+      atomicAdd(F(s.xtab + 0), 1);
+      s.xtab[1] = height;
+      s.xtab[2] = base;
+      s.xtab[3] = c.node;
+      s.xtab[4] = c.t;
     }
     __threadfence_block();
     return idx;
@@ -190,6 +211,7 @@ struct CasperProto {
     }
     if (WG_LANE == 0) {
       s.attHead[a] = r.head;
+      if (c.d.sharded) s.xtab[XT_HEAD + 2 * s.Aw + ordinal / s.p.cycleLength] = r.head + 1;
       atomicOr((unsigned long long*)(s.headMask + (size_t)r.head * s.Aw + (a >> 6)), 1ULL << (a & 63));
       const int32_t hh = ldi(s.bHeight + r.head);
       for (int32_t cur = ldi(s.bParent + r.head); cur >= 0 && ldi(s.bHeight + cur) >= hh - s.p.cycleLength; cur = ldi(s.bParent + cur))
@@ -289,7 +311,12 @@ __global__ void __launch_bounds__(256) k_casper_classify(const EngineDev* __rest
   const uint32_t n = d.g->nEvents;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const Rec r = d.ev[e];
-    if (!casper_is_attestation(r)) s.mixed[r.w1] = 1;
+    if (casper_is_attestation(r)) continue;
+    if (d.sharded) {  // (the event list is replicated: every shard sees that the table exchange is due; flags for its own nodes)
+      *s.anyTask = 1;
+      if (!shard_owns(d, (int32_t)r.w1)) continue;
+    }
+    s.mixed[r.w1] = 1;
   }
 }
 __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
@@ -300,6 +327,10 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
     const Rec r = d.ev[e];
     if (!casper_is_attestation(r)) continue;
     const int32_t to = (int32_t)r.w1, from = rec_from(r);
+    if (d.sharded && !shard_owns(d, to)) {  // another shard's node: zeros (summed across shards before `order`)
+      d.evRes[e] = EvRes{0u, 0u};
+      continue;
+    }
     if (s.mixed[to]) {  // k_deliver applies this node's events in order: the attestation joins the node's inbox list now
       // (expand did not thread it, ExpandF::lane_only; the node is on the active list through its other event)
       const int32_t prev = atomicExch(F(&d.head[to]), (int32_t)e);
@@ -352,10 +383,56 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
   }
 }
 
-__global__ void k_casper_init(CasperState s) {
+// sharded engine: the summed table image of this ms (CasperState::xtab) -> the block and the votes the other shards'
+// nodes created, on every shard; the image is left zeroed for the next ms
+__global__ void __launch_bounds__(256) k_casper_shard_apply(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const int32_t t = d.g->now;
+  const int32_t made = s.xtab[0], height = s.xtab[1], parent = s.xtab[2], producer = s.xtab[3], when = s.xtab[4];
+  const bool mine = made == 1 && shard_owns(d, producer);
+  const int32_t idx = made == 1 ? (int32_t)*s.nBlocks - (mine ? 1 : 0) : 0;  // (the creator's shard has counted it already)
+  __syncthreads();
+  if (made > 1 && threadIdx.x == 0) set_err(d.g, ERR_SAME_MS_BLOCKS);  // two shards built a block in this ms
+  if (made == 1 && !mine) {
+    if (idx >= s.B) {
+      if (threadIdx.x == 0) set_err(d.g, ERR_PAYLOAD);
+    } else {
+      for (int w = threadIdx.x; w < s.Aw; w += blockDim.x)
+        s.blockAtt[(size_t)idx * s.Aw + w] = (uint64_t)(uint32_t)s.xtab[XT_HEAD + 2 * w] | ((uint64_t)(uint32_t)s.xtab[XT_HEAD + 2 * w + 1] << 32);
+      if (threadIdx.x == 0) {
+        s.bHeight[idx] = height;
+        s.bParent[idx] = parent;
+        s.bProducer[idx] = producer;
+        s.bTime[idx] = when;
+        *s.nBlocks = (uint32_t)idx + 1u;
+        *s.lastBlockMs = t;
+      }
+    }
+  }
+  const int32_t pr = s.p.attestersPerRound, slot = t / C_SLOT;
+  for (int j = threadIdx.x; j < pr; j += blockDim.x) {
+    const int32_t v = s.xtab[XT_HEAD + 2 * s.Aw + j];
+    if (!v) continue;
+    const int32_t head = v - 1;
+    const int64_t a = (int64_t)slot * pr + j;
+    // (Attestation() :107-121 as in CasperProto::vote; idempotent on the voter's own shard)
+    s.attHead[a] = head;
+    atomicOr((unsigned long long*)(s.headMask + (size_t)head * s.Aw + (a >> 6)), 1ULL << (a & 63));
+    const int32_t hh = s.bHeight[head];
+    for (int32_t cur = s.bParent[head]; cur >= 0 && s.bHeight[cur] >= hh - s.p.cycleLength; cur = s.bParent[cur])
+      atomicOr((unsigned long long*)(s.attestsMask + (size_t)cur * s.Aw + (a >> 6)), 1ULL << (a & 63));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < XT_HEAD + 2 * s.Aw + pr; k += blockDim.x) s.xtab[k] = 0;
+  if (threadIdx.x == 0) *s.anyTask = 0;
+}
+
+__global__ void k_casper_init(CasperState s, int32_t lo, int32_t hi) {  // [lo, hi): the nodes whose rows this engine holds
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= s.N) return;
-  s.blkRecv[(size_t)node * s.BS] = 1ULL;  // blocksReceivedByBlockId.put(genesis.id, genesis)  C/BlockChainNode.java:21-26
+  if (node >= lo && node < hi)
+    s.blkRecv[(size_t)node * s.BS] = 1ULL;  // blocksReceivedByBlockId.put(genesis.id, genesis)  C/BlockChainNode.java:21-26
   if (node == 0) {
     s.bParent[0] = -1;  // genesis: Block(0)  C/Block.java:22-30
     *s.nBlocks = 1;
