@@ -296,3 +296,60 @@ def test_sharded_sanfermin_matches_the_oracle(oracle, tmp_path, world, params): 
     for r in res:
         assert r["bad"] == [], r
         assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["finished"] > params[0] * 0.8
+
+
+CASPER_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+from wittgenstein_amd import shards, protocols as P
+import oracle_lib as o
+import test_zr_gpu_casper_resident as tcr
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+params = %(params)r
+g = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=%(seed)d, byz_delay=%(byz)d, max_slots=16,
+                config=shards.config(dist, device_memory=False))
+g.init()
+c = o.CasperIMD(params, None, None, seed=%(seed)d, byz_delay=%(byz)d)
+if %(stopped)d:
+    ids = g.stop_attesters(%(stopped)d, seed=%(seed)d + 1)   # (every shard stops the same nodes: `down` is replicated)
+    c.stop(ids)
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad = [("init", m) for m in tcr.diff(G(), c)]
+for k in range(%(chunks)d):
+    if bad: break
+    g.network().runMs(%(chunk)d); c.run_ms(%(chunk)d)
+    bad += [(k, m) for m in tcr.diff(G(), c)]
+calls, words = shards.traffic(g.network())
+res = [None] * world
+dist.all_gather_object(res, {"rank": rank, "bad": [str(b) for b in bad[:6]], "calls": calls, "words": words,
+                             "delivered": c.info()["delivered"], "height": int(c.read("headHeight")[0])})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,params,byz,stopped,chunk,chunks", [
+    (2, (5, False, 5, 80, 1000, 1), 0, 40, 4000, 7),       # PT/CasperIMDTest.java:10-11's network, 10 % of the attesters stop()ped
+    (4, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 30)])   # ByzBlockProducerWF(-2000), PT/CasperByzantineTest.java:41
+def test_sharded_casper_matches_the_oracle(oracle, tmp_path, world, params, byz, stopped, chunk, chunks):
+    """Casper IMD resident on node-range shards (per-node rows by owner, block / attestation tables replicated and filled by
+    exchange, sendAll resolved on every shard, periodic tasks through every shard's far buffer): every observable of
+    tests/test_zr_gpu_casper_resident.py::diff after every chunk, over gloo ranks"""
+    global WORKER
+    keep, WORKER = WORKER, CASPER_WORKER
+    try:
+        res = _run(tmp_path, world, 29701 + world, params=params, seed=3, byz=byz, stopped=stopped, chunk=chunk, chunks=chunks)
+    finally:
+        WORKER = keep
+    for r in res:
+        assert r["bad"] == [], r
+        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["height"] >= 2
+    assert res[0]["delivered"] > (50000 if world == 2 else 300)

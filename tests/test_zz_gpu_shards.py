@@ -124,6 +124,39 @@ def leg7():
     out["config3_as_8_shards"] = {"bad": {k: [str(x) for x in v] for k, v in bad.items()}, "init_s": t_init,
                                   "run_s": time.time() - t0 - t_init, "device_bytes_per_shard": per_shard,
                                   "same_rng": len({net.rng_state() for net in nets}) == 1}
+def leg8():
+    # 8. Casper IMD on logical shards of the one GPU: PT/CasperIMDTest.java:10-11's network (406 nodes) with 40 attesters
+    # stop()ped as 4 shards, and ByzBlockProducerWF(-2000) as 3, both in lock-step with the oracle after every chunk
+    import test_shards_casper as tc
+    out["casper"] = []
+    for k, params, byz, stopped, chunk, chunks in [(4, (5, False, 5, 80, 1000, 1), 0, 40, 4000, 12),
+                                                   (3, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 40)]:
+        c, traffic = tc.casper_loopback(k, params, seed=3, chunk=chunk, chunks=chunks, byz_delay=byz, stopped=stopped,
+                                        device_memory=True)
+        out["casper"].append({"k": k, "delivered": int(c.info()["delivered"]), "height": int(c.read("headHeight")[0]),
+                              "same_collectives": len(set(traffic)) == 1, "calls": traffic[0][0]})
+def leg9():
+    # 9. Casper IMD, 2 x 1024 attesters (2 051 nodes, every vote a sendAll to all of them): 4 logical shards == the
+    # unsharded engine after every chunk — a size the oracle does not reach inside a test
+    from wittgenstein_amd import protocols as P
+    import test_zr_gpu_casper_resident as tcr
+    params = (2, False, 2, 1024, 1000, 1)
+    ref = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=1, max_slots=8); ref.init()
+    K = 4
+    grp = shards.LoopbackGroup(K, device_memory=True)
+    sims = [P.CasperIMD(P.CasperParemeters(*params, None, None), seed=1, max_slots=8, config=grp.config(s)) for s in range(K)]
+    for g in sims: g.init()
+    nets = [g.network() for g in sims]
+    bad = []
+    for step in range(6):
+        grp.run(lambda s: nets[s].runMs(4000)); ref.network().runMs(4000)
+        for f in tcr.FIELDS:
+            a = nets[0].read(f) if f in ("x", "y") else grp.gather([net.read(f) for net in nets], nets)
+            if not np.array_equal(a, ref.network().read(f)): bad.append((step, f))
+        if (nets[0].time, nets[0].rng_state(), nets[0].msgs.size()) != (ref.network().time, ref.network().rng_state(), ref.network().msgs.size()):
+            bad.append((step, "time / rd / msgs.size()"))
+    out["casper_vs_unsharded"] = {"bad": [str(b) for b in bad[:6]], "delivered": int(ref.network().read("msgReceived").sum()),
+                                  "height": int(ref.network().read("headHeight")[0])}
 import traceback
 out["errors"] = {}
 for _name, _fn in [(k, v) for k, v in sorted(globals().items()) if k.startswith('leg') and callable(v)]:
@@ -212,3 +245,17 @@ def test_config3_as_8_logical_shards_equals_the_oracle_trace(result):
     assert abs(handel_shard_bytes_model(32768, 8) - measured) < 0.10 * measured, (handel_shard_bytes_model(32768, 8), measured)
     # ... and says that BASELINE config 4 (Handel 131 072 nodes over the 8 GPUs of one box) fits an MI355X per shard
     assert handel_shard_bytes_model(131072, 8) < 0.92 * 288 * (1 << 30)
+
+
+def test_casper_logical_shards_match_the_oracle(result):   # per-node rows by owner, tables by exchange, sendAll on every shard
+    assert "leg8" not in result["errors"], result["errors"]["leg8"]
+    assert [r["k"] for r in result["casper"]] == [4, 3]
+    for r in result["casper"]:
+        assert r["same_collectives"] and r["calls"] > 0 and r["height"] >= 3, r
+    assert result["casper"][0]["delivered"] > 100000
+
+
+def test_casper_four_logical_shards_equal_the_unsharded_engine_at_2051_nodes(result):
+    assert "leg9" not in result["errors"], result["errors"]["leg9"]
+    r = result["casper_vs_unsharded"]
+    assert r["bad"] == [] and r["height"] >= 1 and r["delivered"] > 1024 * 2051 * 0.9, r

@@ -66,6 +66,23 @@ def test_gsf_through_the_engines_own_communicator():
     assert not g.cont_if()
 
 
+def test_casper_through_the_engines_own_communicator():  # sendAll + far envelopes + the table exchange through ncclAllReduce
+    import test_zr_gpu_casper_resident as tcr
+    from wittgenstein_amd import protocols as P
+    params = (5, False, 5, 80, 1000, 1)
+    g = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=3, max_slots=16, config=shards.config_rccl())
+    g.init()
+    c = o.CasperIMD(params, None, None, seed=3)
+    ids = g.stop_attesters(40, seed=4)
+    c.stop(ids)
+    for _ in range(12):
+        g.network().runMs(4000)
+        c.run_ms(4000)
+        d = tcr.diff(g, c)
+        assert not d, (g.network().time, d)
+    assert c.info()["delivered"] > 100000 and shards.traffic(g.network())[0] > 0
+
+
 def test_configure_after_allocation_is_refused():
     net = w.Network.create({})
     net.add_nodes([1, 2], [1, 2])

@@ -1475,13 +1475,38 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
   auto gfield = [&](uint32_t Globals::*field) {
     return (const uint32_t*)((const char*)dev.g.raw + ((const char*)&(gh.*field) - (const char*)&gh));
   };
-  for (int32_t k = 0; k <= ms; k++) {
+  // host-held envelopes (see run_group) — the far ones were parked by k_shard_unpack on every shard alike, so every shard
+  // stages the same
+  auto host_envelopes = [&](int32_t k) {
     const int32_t t = time + k;
-    // (see run_group) — the far envelopes were parked by k_shard_unpack on every shard alike, so every shard stages the same
     if (dev.farBuf && (t % dev.horizon) == 0) collect_far();
     if (k > 0 && stagedMin - t < dev.horizon) {
       WG_HIP(hipStreamSynchronize(stream));
       flush_staged(t, true);
+    }
+  };
+  // Idle stretches are skipped as run_group skips them (k_next_busy / k_skip_idle: the bucket counts are replicated, every
+  // shard skips alike) — asked after a ms that held no event, so a protocol that is busy every ms never pays the question
+  const bool canSkip = !(getenv("WG_SKIP_IDLE") && atoi(getenv("WG_SKIP_IDLE")) == 0) && !proto->has_cond();
+  if (canSkip && skipCap < 1) {
+    skipBuf = dalloc<int32_t>(1);
+    skipCap = 1;
+  }
+  bool idlePrev = false;
+  for (int32_t k = 0; k <= ms; k++) {
+    host_envelopes(k);
+    if (canSkip && idlePrev && k > 0 && k < ms) {
+      int32_t nb = 0;
+      hipLaunchKernelGGL(k_next_busy, dim3(1, 1), dim3(256), 0, stream, g.tab, skipBuf);
+      WG_HIP(hipMemcpyAsync(&nb, skipBuf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+      WG_HIP(hipStreamSynchronize(stream));
+      const int32_t D = dev.horizon, t = time + k;
+      const int32_t n = std::min(ms - k, std::min(nb, D - (int32_t)((uint32_t)t & (uint32_t)(D - 1))));
+      if (n > 0) {
+        hipLaunchKernelGGL(k_skip_idle, dim3(1, 1), dim3(256), 0, stream, g.tab, n);
+        k += n;
+        host_envelopes(k);
+      }
     }
     expand(g);
     {
@@ -1491,6 +1516,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     uint32_t* dSnap = proto->shard_snap_enqueue(g);  // (numbers this ms's payload rows; its count is read with nEvents)
     uint32_t nEvents = 0, nSnap = 0;
     await_counts(gfield(&Globals::nEvents), dSnap, &nEvents, &nSnap);
+    idlePrev = nEvents == 0;
     if (dSnap && nEvents && nSnap) proto->shard_snap_exchange(*this, g, nSnap);
     shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
     scan<RecsF>(g, nullptr);
