@@ -191,23 +191,37 @@ def casper_line(args):
     delivered = 0
     elapsed = dk_ns = 0.0
     dk_spans = 0
+    ks = getattr(args, "casper_shards", 0)
+    shard_traffic = None
     for step in range(W + K):
-        g = P.CasperIMD(P.CasperParemeters(*params, NB, NL), seed=step, max_slots=T // 8000 + 2)
-        g.init()
-        net = g.network()
+        from wittgenstein_amd import shards
+        grp = shards.LoopbackGroup(ks) if ks > 1 else None
+        cfgs = [grp.config(sh) for sh in range(ks)] if grp else [shards.config_rccl() if ks == 1 else None]
+        sims = []
         stopped_ids = []
-        if args.casper_stopped > 0:  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
-            stopped_ids = g.stop_attesters(int(args.casper_stopped * cl * per), seed=step)
+        for cfg in cfgs:  # (k logical shards: k engines, each holding the rows of its node range; the same simulation)
+            g = P.CasperIMD(P.CasperParemeters(*params, NB, NL), seed=step, max_slots=T // 8000 + 2, config=cfg)
+            g.init()
+            if args.casper_stopped > 0:  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
+                stopped_ids = g.stop_attesters(int(args.casper_stopped * cl * per), seed=step)
+            sims.append(g)
+        net = sims[0].network()
         net.profile(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        net.runMs(T)
+        if grp:
+            grp.run(lambda sh: sims[sh].network().runMs(T))
+        else:
+            net.runMs(T)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if step >= W:
             delivered += net.last_stats["delivered"]
             elapsed += dt
-            heights = net.read("headHeight")  # (outside the timed region) the observables of PT/CasperIMDTest.java:263-274
+            # (outside the timed region) the observables of PT/CasperIMDTest.java:263-274; sharded: a shard reports its own rows
+            heights = sum(x.network().read("headHeight") for x in sims)
+            if ks:
+                shard_traffic = shards.traffic(net)
             import numpy as np
             live = np.ones(len(heights), bool)
             live[stopped_ids] = False  # (a stopped node receives nothing: its head stays the genesis block)
@@ -215,7 +229,7 @@ def casper_line(args):
             pr = net.profile_read()["deliver"]
             dk_spans += pr["spans"]
             dk_ns += pr["total_ns"]
-        del g, net
+        del g, net, sims, grp
         gc.collect()
     bmsg = 104 + 24 + 8  # SURVEY.md §8d fixed part + the attestation's three bit-sets (8-byte RMW each) + attHead read
     alg = float(delivered) * bmsg
@@ -229,7 +243,12 @@ def casper_line(args):
                                "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
                                "%d simulated ms per step%s" % (n, bp, cl, per, T, "" if args.casper_stopped <= 0 else
                                                                ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
-                   "nodes": n, "observer_head_height_at_end": observer_height, "lowest_head_height_of_a_live_node_at_end": min_height},
+                   "nodes": n, "observer_head_height_at_end": observer_height, "lowest_head_height_of_a_live_node_at_end": min_height,
+                   "parallelism": "one simulation, unsharded" if not ks else
+                                  ("one simulation on the node-range sharded pipeline: one rank through the engine's own RCCL communicator"
+                                   if ks == 1 else "one simulation as %d logical node-range shards on this GPU (in-process loopback "
+                                                   "all-reduce; the delivery-pass bracket is shard 0's)" % ks),
+                   "allreduce_calls_and_int32_words_per_simulation": shard_traffic},
         "roofline": {"bound": "hbm", "kernel": "the delivery pass: k_casper_classify + k_casper_attestations + k_deliver<CasperProto> (one launch of each per simulated ms that is not skipped)", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
@@ -382,6 +401,10 @@ def main():
     ap.add_argument("--casper-stopped", type=float, default=0.0,
                     help="--workload casper: fraction of the attesters stop()ped after init() (config 5's '+10 %%': 0.1)")
     ap.add_argument("--casper-ms", type=int, default=24000, help="--workload casper: simulated ms per step")
+    ap.add_argument("--casper-shards", type=int, default=0,
+                    help="--workload casper: the step's ONE simulation on the node-range sharded pipeline — 1 = one rank through the "
+                         "engine's own RCCL communicator, k > 1 = k logical shards on this GPU (in-process loopback all-reduce); "
+                         "0 = unsharded (default)")
     ap.add_argument("--workload", choices=["handel", "gsf", "casper"], default="handel",
                     help="handel = the BASELINE metric's workload (default); gsf = BASELINE configs[1], GSFSignature "
                          "(use --nodes 4096)")
