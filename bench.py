@@ -186,7 +186,8 @@ def casper_line(args):
     from wittgenstein_amd import protocols as P
     K, W, per, T = args.steps, args.warmup, args.attesters_per_round, args.casper_ms
     cl, bp = args.casper_cycle_length, args.casper_producers
-    params = (cl, False, bp, per, 1000, 1)
+    rot = bool(getattr(args, "casper_random_on_ties", False))
+    params = (cl, rot, bp, per, 1000, 1)
     n = 1 + bp + cl * per
     delivered = 0
     elapsed = dk_ns = 0.0
@@ -239,10 +240,12 @@ def casper_line(args):
         "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": K * T / elapsed,
-        "config": {"workload": "Casper IMD, %d nodes (1 observer, %d block producers, %d x %d attesters), randomOnTies false, "
-                               "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
-                               "%d simulated ms per step%s" % (n, bp, cl, per, T, "" if args.casper_stopped <= 0 else
-                                                               ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
+        "config": {"workload": ("Casper IMD, %d nodes (1 observer, %d block producers, %d x %d attesters), randomOnTies %s, "
+                                "block / attestation construction 1000 / 1 ms, RANDOM nodes, NetworkLatencyByDistanceWJitter, "
+                                "%d simulated ms per step%s") % (
+                       n, bp, cl, per, "true (the events that can call best() are delivered by one wavefront in global event order, "
+                                       "k_casper_seq)" if rot else "false", T,
+                       "" if args.casper_stopped <= 0 else ", %d attesters stop()ped after init()" % int(args.casper_stopped * cl * per)),
                    "nodes": n, "observer_head_height_at_end": observer_height, "lowest_head_height_of_a_live_node_at_end": min_height,
                    "parallelism": "one simulation, unsharded" if not ks else
                                   ("one simulation on the node-range sharded pipeline: one rank through the engine's own RCCL communicator"
@@ -401,6 +404,8 @@ def main():
     ap.add_argument("--casper-stopped", type=float, default=0.0,
                     help="--workload casper: fraction of the attesters stop()ped after init() (config 5's '+10 %%': 0.1)")
     ap.add_argument("--casper-ms", type=int, default=24000, help="--workload casper: simulated ms per step")
+    ap.add_argument("--casper-random-on-ties", action="store_true",
+                    help="--workload casper: CasperParemeters.randomOnTies = true (the reference's default): exact, through k_casper_seq")
     ap.add_argument("--casper-shards", type=int, default=0,
                     help="--workload casper: the step's ONE simulation on the node-range sharded pipeline — 1 = one rank through the "
                          "engine's own RCCL communicator, k > 1 = k logical shards on this GPU (in-process loopback all-reduce); "

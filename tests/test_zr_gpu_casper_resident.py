@@ -139,7 +139,33 @@ def test_config5_size_fast_paths_equal_the_plain_ones(monkeypatch):
     assert int(fast["msgReceived"][ids].sum()) == 0 and int(fast["attestationsHeld"][live].min()) > 4096
 
 
+def random_on_ties_cases(long=True):
+    """randomOnTies (P/CasperIMD.java:250-253, the CasperParemeters() default) resident: a tie's rd.nextBoolean() takes its
+    place in the rd sequence from the draws of every earlier event of the ms, so the events that can call best() are
+    delivered by one wavefront in global event order (k_casper_seq). ByzBlockProducerWF(+7000) forks the chain with equal
+    votes on both branches — ties do draw (checked: the rd state differs from the randomOnTies == false run of the oracle) —
+    and (-2000) / no delay are the reference's own byzantine / plain configurations, where no tie arises."""
+    cases = [((3, True, 3, 8, 1000, 1), 1, 1000, 80, 7000, 0, True), ((2, True, 2, 6, 1000, 1), 3, 500, 160, 7000, 2, True)]
+    if long:
+        cases += [((3, True, 3, 8, 1000, 1), 9, 1000, 60, -2000, 0, False), ((5, True, 5, 80, 1000, 1), 1, 4000, 10, -2000, 17, False)]
+    for params, seed, chunk, chunks, byz, stopped, ties in cases:
+        g, c = lockstep(params, seed=seed, chunk=chunk, chunks=chunks, byz_delay=byz, stopped=stopped)
+        plain = o.CasperIMD((params[0], False) + params[2:], None, None, seed=seed, byz_delay=byz)
+        if stopped:
+            plain.stop(g.stopped_ids)
+        plain.run_ms(chunk * chunks)
+        assert (c.info()["rng"] != plain.info()["rng"]) == ties, (params, byz)
+        assert c.read("headHeight")[0] >= 4
+
+
 @pytest.mark.gpu
-def test_random_on_ties_is_refused():
+def test_random_on_ties_resident():
+    random_on_ties_cases()
+
+
+@pytest.mark.gpu
+def test_random_on_ties_is_refused_on_a_sharded_engine():
+    from wittgenstein_amd import shards
+    grp = shards.LoopbackGroup(2, device_memory=False)
     with pytest.raises(UnsupportedError):
-        P.CasperIMD(P.CasperParemeters(2, True, 2, 6, 1000, 1)).init()
+        P.CasperIMD(P.CasperParemeters(2, True, 2, 6, 1000, 1), config=grp.config(0)).init()

@@ -2841,8 +2841,9 @@ struct CasperHost : ProtoHost {
       throw WgError(WG_EINVAL, "Casper IMD: the network must hold 1 observer + blockProducersCount + cycleLength * attestersPerRound nodes");
     if (p.cycleLength <= 0 || p.blockProducersCount <= 0 || p.attestersPerRound <= 0 || p.maxSlots <= 0)
       throw WgError(WG_EINVAL, "Casper IMD parameters");
-    if (p.randomOnTies)
-      throw WgError(WG_EUNSUPPORTED, "randomOnTies: the tie's rd.nextBoolean() decides a head inside action() (not resident)");
+    if (p.randomOnTies && e.shardCount > 0)
+      throw WgError(WG_EUNSUPPORTED, "randomOnTies on a sharded engine: a tie's rd.nextBoolean() takes its place in the rd sequence "
+                                     "from the draws of every earlier event of the ms, network-wide (one wavefront, k_casper_seq)");
     if (p.blockConstructionTime <= 0 || p.attestationConstructionTime <= 0)
       throw WgError(WG_EUNSUPPORTED, "construction times must be >= 1 ms (a sendAll for the current ms would have to be delivered in it)");
     if (!e.allocated) {
@@ -2898,6 +2899,7 @@ struct CasperHost : ProtoHost {
     st.attestsMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
     st.attHead = e.dalloc<int32_t>(st.A);
     st.mixed = e.dalloc<uint8_t>(N);
+    if (p.randomOnTies) st.seqBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
     e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
@@ -2923,6 +2925,11 @@ struct CasperHost : ProtoHost {
       // (a latency-bound pass of scattered atomics: as many wavefronts in flight as the chip holds)
       static const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;
       hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
+    if (st.p.randomOnTies) {  // a tie's nextBoolean() needs the global event order: one wavefront (see proto_casper.hip.h)
+      hipLaunchKernelGGL(k_casper_mark, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_casper_seq, dim3(1, g.R), dim3(64), 0, g.stream, g.tab, stab);
+      return;
     }
     hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
   }

@@ -12,8 +12,14 @@
 //   blockAtt[b]       the attestations block b carries            (its attestationsByHeight, all heights)
 // so countAttestations / buildBlock are OR / AND / popcount passes over words. Blocks are rows of a table, ids in creation
 // order as the reference's Block.blockId (at most one block is created per simulated ms, checked).
-// Not resident: randomOnTies (the tie's rd.nextBoolean() decides the node's head inside action(): its value cannot be
-// deferred) and the byzantine producers other than the ByzBlockProducerWF that init() installs (:475-479).
+// randomOnTies (:250-253, the CasperParemeters() default): the tie's rd.nextBoolean() decides the node's head INSIDE action(),
+// so its value cannot be deferred to `resolve` as a send's seed is — and its place in the rd sequence is the number of draws
+// of every earlier event of the ms, network-wide. Such a configuration delivers the events of its "mixed" nodes (those
+// with a block or a task in the ms — the only events that call best()) by ONE wavefront in global event order
+// (k_casper_seq), which knows that number as it goes; attestation-only nodes keep the lane-per-event kernel (an
+// attestation draws nothing and commutes). Exact, and as slow as one wavefront is: the parallel k_deliver stays the path of
+// randomOnTies == false.
+// Not resident: the byzantine producers other than the ByzBlockProducerWF that init() installs (:475-479).
 #pragma once
 #include "engine_kernels.hip.h"
 
@@ -50,6 +56,7 @@ struct CasperState {
   //         blockAtt word w, [XT_HEAD + 2 Aw + j] head + 1 of the vote with attestation index height * attestersPerRound + j
   GP<int32_t> xtab;
   GP<uint32_t> anyTask;    // [1] this ms holds an event that is not an attestation (replicated: the exchange is due)
+  GP<uint64_t> seqBits;    // randomOnTies: [maxEvents / 64] bit e = event e belongs to a mixed node (k_casper_mark -> k_casper_seq)
 };
 constexpr int XT_HEAD = 8;
 
@@ -60,10 +67,14 @@ struct CasperProto {
   };
   struct NodeRegs {
     int32_t head;
+    uint32_t drawBase;  // randomOnTies: rd draws of the ms's earlier events, network-wide (k_casper_seq)
   };
   __device__ static int msg_size(const State&, uint32_t) { return 1; }  // Message.size() default
   __device__ static int msg_level(uint32_t) { return 0; }
-  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, WaveShared*) { r.head = s.head[c.node]; }
+  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, WaveShared*) {
+    r.head = s.head[c.node];
+    r.drawBase = 0;
+  }
   __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
     if (WG_LANE == 0) s.head[c.node] = r.head;
   }
@@ -117,7 +128,7 @@ struct CasperProto {
     }
     return wave_sum(cnt);
   }
-  __device__ static int32_t best(Ctx& c, const State& s, int32_t o1, int32_t o2) {  // :186-236
+  __device__ static int32_t best(Ctx& c, const State& s, const NodeRegs& r, int32_t o1, int32_t o2) {  // :186-236
     if (o1 == o2) return o1;
     const int32_t h1 = ldi(s.bHeight + o1), h2 = ldi(s.bHeight + o2);
     if (h1 == h2) {
@@ -136,7 +147,13 @@ struct CasperProto {
     const int v1 = count_attestations(c, s, o1, h), v2 = count_attestations(c, s, o2, h);
     if (v1 > v2) return o1;
     if (v1 < v2) return o2;
-    return b1 >= b2 ? o1 : o2;  // (randomOnTies is refused at load time)
+    if (s.p.randomOnTies) {  // network.rd.nextBoolean() ? o1 : o2  (:250-253) — only ever reached from k_casper_seq
+      // java.util.Random.nextBoolean() = next(1) != 0: the top bit of the 48-bit state after one more step
+      const uint64_t st = lcg_skip(c.d.g->rng, (uint64_t)(r.drawBase + c.draws) + 1);
+      c.draws++;
+      return ((st >> 47) & 1ULL) ? o1 : o2;
+    }
+    return b1 >= b2 ? o1 : o2;
   }
   __device__ static void reevaluate_head(Ctx& c, const State& s, NodeRegs& r) {  // :349-356, ascending block id
     uint64_t WG_G* re = s.reeval + (size_t)c.node * s.BS;
@@ -145,7 +162,7 @@ struct CasperProto {
       while (m) {
         const int32_t b = (w << 6) + (__ffsll((unsigned long long)m) - 1);
         m &= m - 1;
-        r.head = best(c, s, r.head, b);
+        r.head = best(c, s, r, r.head, b);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -232,7 +249,7 @@ struct CasperProto {
     }
     __threadfence_block();
     if (known) return false;
-    r.head = best(c, s, r.head, b);
+    r.head = best(c, s, r, r.head, b);
     return true;
   }
   __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t, uint32_t msg, uint32_t payload) {
@@ -380,6 +397,73 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
       }
     }
     d.evRes[e] = res;
+  }
+}
+
+// randomOnTies (see the header): which events belong to a mixed node, one bit per event (64 consecutive events per
+// wavefront: one ballot, one store), then ONE wavefront delivers exactly those in global event order — receiveUntil's
+// own order (C/Network.java:594-635) — carrying the number of rd draws made so far in the ms, which is the index of a
+// tie's nextBoolean() in the rd sequence. Results, counters and records as k_deliver leaves them.
+__global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nEvents;
+  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+    const uint32_t e = e0 + WG_LANE;
+    bool mix = false;
+    if (e < n) {
+      const Rec r = d.ev[e];
+      mix = !s.laneEvents || !casper_is_attestation(r) || s.mixed[r.w1] != 0;
+    }
+    const uint64_t m = __ballot(mix);
+    if (WG_LANE == 0) s.seqBits[e0 >> 6] = m;
+  }
+}
+__global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  __shared__ CasperProto::WaveShared shP;
+  const uint32_t n = d.g->nEvents;
+  const int32_t t = d.g->now;
+  const int lane = WG_LANE;
+  uint32_t drawBase = 0;
+  for (uint32_t w0 = 0; w0 * 64 < n; w0 += 64) {  // 64 words = 4096 events per round
+    const uint32_t wi = w0 + (uint32_t)lane;
+    const uint64_t mine = (uint64_t)wi * 64 < n ? s.seqBits[wi] : 0ULL;
+    uint64_t any = __ballot(mine != 0);
+    while (any) {
+      const int k = __ffsll((unsigned long long)any) - 1;
+      any &= any - 1;
+      uint64_t bits = lane_bcast64(mine, k);
+      while (bits) {
+        const uint32_t e = (w0 + (uint32_t)k) * 64 + (uint32_t)(__ffsll((unsigned long long)bits) - 1);
+        bits &= bits - 1;
+        const Rec rec = d.ev[e];
+        const EvAux aux = d.evAux[e];
+        const int32_t node = (int32_t)rec.w1;
+        Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+        CasperProto::NodeRegs r;
+        CasperProto::node_begin(c, s, r, &shP);
+        r.drawBase = drawBase;
+        long long nRecv = 0, bRecv = 0;
+        deliver_event<CasperProto>(d, s, c, r, e, rec, aux, d.nodes.down[node] != 0, d.nparts ? d.nodes.part[node] : (uint8_t)0,
+                                   true, nRecv, bRecv);
+        __builtin_amdgcn_wave_barrier();
+        CasperProto::node_end(c, s, r);
+        if (lane == 0) {
+          if (nRecv) atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);  // (unit_message_size)
+          if (c.msgSent) {
+            atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+            atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+          }
+          d.head[node] = -1;   // (its inbox list, threaded by expand / k_casper_attestations, is not used here)
+          s.mixed[node] = 0;
+        }
+        drawBase += c.draws;
+        __threadfence_block();  // the node's next event (another round of this loop) reads what this one wrote
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
   }
 }
 
