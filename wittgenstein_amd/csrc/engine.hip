@@ -2900,7 +2900,9 @@ struct CasperHost : ProtoHost {
     st.attHead = e.dalloc<int32_t>(st.A);
     st.mixed = e.dalloc<uint8_t>(N);
     if (p.randomOnTies) st.seqBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
+    st.forked = e.dalloc<uint32_t>(1);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
+    if (p.randomOnTies) st.laneEvents = 1u;  // (k_casper_seq hands k_deliver an empty set through the mixed flags)
     e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
@@ -2926,10 +2928,11 @@ struct CasperHost : ProtoHost {
       static const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;
       hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
-    if (st.p.randomOnTies) {  // a tie's nextBoolean() needs the global event order: one wavefront (see proto_casper.hip.h)
+    if (st.p.randomOnTies) {  // a tie's nextBoolean() needs the global event order: one wavefront — once the chain has forked
+      // (CasperState::forked, read on the device: both return at once before that and k_deliver below does the visits;
+      // after it k_casper_seq has cleared every mixed flag and k_deliver's visit_skip admits no node)
       hipLaunchKernelGGL(k_casper_mark, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
       hipLaunchKernelGGL(k_casper_seq, dim3(1, g.R), dim3(64), 0, g.stream, g.tab, stab);
-      return;
     }
     hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
   }

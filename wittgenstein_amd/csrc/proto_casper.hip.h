@@ -17,8 +17,11 @@
 // of every earlier event of the ms, network-wide. Such a configuration delivers the events of its "mixed" nodes (those
 // with a block or a task in the ms — the only events that call best()) by ONE wavefront in global event order
 // (k_casper_seq), which knows that number as it goes; attestation-only nodes keep the lane-per-event kernel (an
-// attestation draws nothing and commutes). Exact, and as slow as one wavefront is: the parallel k_deliver stays the path of
-// randomOnTies == false.
+// attestation draws nothing and commutes). Exact, and as slow as one wavefront is — so only once it can matter: best() reaches
+// its tie-break only between two branches, and until some block has a second child (CasperState::forked, set by build_block;
+// never, without a byzantine delay) no event can draw in best(): the parallel k_deliver is exact and stays in charge. Both
+// paths are enqueued every ms and the flag, on the device, decides which one finds work (k_casper_seq leaves no mixed node
+// for k_deliver's visit_skip to admit).
 // Not resident: the byzantine producers other than the ByzBlockProducerWF that init() installs (:475-479).
 #pragma once
 #include "engine_kernels.hip.h"
@@ -57,6 +60,9 @@ struct CasperState {
   GP<int32_t> xtab;
   GP<uint32_t> anyTask;    // [1] this ms holds an event that is not an attestation (replicated: the exchange is due)
   GP<uint64_t> seqBits;    // randomOnTies: [maxEvents / 64] bit e = event e belongs to a mixed node (k_casper_mark -> k_casper_seq)
+  GP<uint32_t> forked;     // randomOnTies: [1] some block has two children. best() can reach its tie-break only between two
+                           // branches, i.e. never before that: until then the parallel k_deliver is exact (no draw to order),
+                           // from the next ms on k_casper_seq takes the mixed nodes
 };
 constexpr int XT_HEAD = 8;
 
@@ -73,7 +79,7 @@ struct CasperProto {
   __device__ static int msg_level(uint32_t) { return 0; }
   __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, WaveShared*) {
     r.head = s.head[c.node];
-    r.drawBase = 0;
+    r.drawBase = 0xFFFFFFFFu;  // (k_casper_seq sets the real one)
   }
   __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
     if (WG_LANE == 0) s.head[c.node] = r.head;
@@ -148,6 +154,9 @@ struct CasperProto {
     if (v1 > v2) return o1;
     if (v1 < v2) return o2;
     if (s.p.randomOnTies) {  // network.rd.nextBoolean() ? o1 : o2  (:250-253) — only ever reached from k_casper_seq
+      // (the parallel k_deliver carries no draw count: it only runs before the chain forks, where no tie can arise — except
+      // for the forking producer's own later events in the very ms of its fork: loud, not guessed)
+      if (r.drawBase == 0xFFFFFFFFu && WG_LANE == 0) set_err(c.d.g, ERR_PROTOCOL);
       // java.util.Random.nextBoolean() = next(1) != 0: the top bit of the 48-bit state after one more step
       const uint64_t st = lcg_skip(c.d.g->rng, (uint64_t)(r.drawBase + c.draws) + 1);
       c.draws++;
@@ -186,6 +195,11 @@ struct CasperProto {
       s.bTime[idx] = c.t;
     }
     idx = __shfl(idx, 0, 64);
+    if (s.p.randomOnTies) {  // a second child of `base`: from now on two branches exist (CasperState::forked)
+      bool sib = false;
+      for (int32_t b = 1 + WG_LANE; b < idx; b += 64) sib |= ldi(s.bParent + b) == base;
+      if (__ballot(sib) && WG_LANE == 0) *s.forked = 1u;
+    }
     const int cl = s.p.cycleLength;
     const uint64_t WG_G* rv = s.recv + (size_t)c.node * s.Aw;
     for (int w = WG_LANE; w < s.Aw; w += 64) {
@@ -407,6 +421,7 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
 __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
   const CasperState& s = stab[blockIdx.y];
+  if (!*s.forked) return;  // one chain so far: no tie-break can be reached, k_deliver takes the mixed nodes in parallel
   const uint32_t n = d.g->nEvents;
   for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
     const uint32_t e = e0 + WG_LANE;
@@ -422,6 +437,7 @@ __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict
 __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
   const CasperState& s = stab[blockIdx.y];
+  if (!*s.forked) return;
   __shared__ CasperProto::WaveShared shP;
   const uint32_t n = d.g->nEvents;
   const int32_t t = d.g->now;
