@@ -950,8 +950,9 @@ template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
 void Engine::expand(const Group& g) {
   scan<ExpandF>(g, nullptr);
-  static const int runGrid = getenv("WG_EXPAND_RUNS_GRID") ? std::max(1, atoi(getenv("WG_EXPAND_RUNS_GRID"))) : GRID_EXPAND_RUNS;
-  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(runGrid, g.R), dim3(256), 0, g.stream, g.tab);
+  if (expandRunsGrid < 0)  // (tuning variables are read once per ENGINE, at its first use of them: an in-process A/B builds a new engine)
+    expandRunsGrid = getenv("WG_EXPAND_RUNS_GRID") ? std::max(1, atoi(getenv("WG_EXPAND_RUNS_GRID"))) : GRID_EXPAND_RUNS;
+  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(expandRunsGrid, g.R), dim3(256), 0, g.stream, g.tab);
 }
 template void Engine::scan<RecsF>(const Group&, const int*);
 template void Engine::scan<MultiF>(const Group&, const int*);
@@ -1948,7 +1949,7 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
   // WG_GRAPH=1: the chunk is captured once into a hipGraph and replayed — one graph launch instead of ~30 kernel
   // launches per simulated ms. The profiler's brackets are device clock stamps there (ProfScope / k_prof_stamp: a HIP
   // event captured into the graph would keep its last replay only).
-  static const bool wantGraph = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
+  const bool wantGraph = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;  // (read per call)
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   try {
@@ -2910,6 +2911,7 @@ struct CasperHost : ProtoHost {
     WG_HIP(hipStreamSynchronize(e.stream));
   }
   int32_t lo = 0, hi = 0, xtabWords = 0;
+  const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;  // (per engine)
   // ---- node-range sharding (Engine::run_ms_sharded): a delivery touches the receiver's rows only; sendAll goes through the
   // replicated envelope creation (k_shard_multi_*, k_sendall_*); what the ms's action()s added to the replicated block /
   // attestation tables is exchanged after the delivery pass (CasperState::xtab, k_casper_shard_apply) — in the ms that hold
@@ -2925,7 +2927,6 @@ struct CasperHost : ProtoHost {
     if (st.laneEvents) {  // attestation-only nodes: one lane per event (see k_casper_attestations)
       hipLaunchKernelGGL(k_casper_classify, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
       // (a latency-bound pass of scattered atomics: as many wavefronts in flight as the chip holds)
-      static const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;
       hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     if (st.p.randomOnTies) {  // a tie's nextBoolean() needs the global event order: one wavefront — once the chain has forked
