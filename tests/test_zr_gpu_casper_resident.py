@@ -139,6 +139,17 @@ def test_config5_size_fast_paths_equal_the_plain_ones(monkeypatch):
     assert int(fast["msgReceived"][ids].sum()) == 0 and int(fast["attestationsHeld"][live].min()) > 4096
 
 
+@pytest.mark.gpu
+def test_casper_16390_nodes_ten_percent_stopped_against_the_oracle():
+    """BASELINE config 5's shape at the largest size the oracle runs inside a test (it keeps every attestation in every
+    node's HashSet): cycleLength 64, 5 producers, 256 attesters per slot = 16 390 nodes, 10 % of the attesters stop()ped,
+    24 simulated seconds = 8.4 M deliveries, three slots of votes (each a sendAll to all 16 390) — every node's counters,
+    head, attestation and block sets, the queue size and the rd state after every 8-second chunk"""
+    g, c = lockstep((64, False, 5, 256, 1000, 1), seed=0, chunk=8000, chunks=3, max_slots=5, stopped=1638)
+    assert g.network().node_count == 16390 and c.info()["delivered"] > 6000000
+    assert int(g.network().read("headHeight")[0]) == 2
+
+
 def random_on_ties_cases(long=True):
     """randomOnTies (P/CasperIMD.java:250-253, the CasperParemeters() default) resident: a tie's rd.nextBoolean() takes its
     place in the rd sequence from the draws of every earlier event of the ms, so the events that can call best() are

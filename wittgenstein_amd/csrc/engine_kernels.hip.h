@@ -244,7 +244,8 @@ __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain
 // partials before it, scans its chunk and calls F.write(i, exclusive_prefix). Values are uint64 so a
 // pair of 32-bit counters can be scanned at once.
 constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_GRID = 240 / WG_GRID_DIV;
+constexpr int SCAN_GRID = 240 / WG_GRID_DIV;  // blocks per ENGINE (grid.x; a batch multiplies it by its members in grid.y): a multiple of
+                                               // the 8 XCDs that keeps a block's chunk of a typical ms's events at a few SCAN_BLOCK rounds
 
 __device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
