@@ -13,6 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # (wittgenstein_amd.protocols.choose_attesters, pure Python)
 import oracle_lib as o  # noqa: E402
 
 NB, NL = "RANDOM_SPEED=CONSTANT_TOR=0.00", "NetworkLatencyByDistanceWJitter"
@@ -86,8 +87,45 @@ def handel_full(params, seed, chunk=10, marks=()):
     return out
 
 
+CASPER_FIELDS = ["msgReceived", "msgSent", "bytesSent", "bytesReceived", "headHeight", "headProposalTime", "headId",
+                 "attestationsByHeadSize", "blocksReceived", "attestationsHeld"]
+
+
+def casper_config5_shape(per, stopped_frac=0.10, seed=0, chunk=8000, chunks=3):
+    """BASELINE config 5's shape (cycleLength 64, 5 block producers, `per` attesters voting per slot, every vote and block a
+    sendAll to all nodes; stopped_frac of the attesters stop()ped after init(): SURVEY.md §8d's "+10 %") for chunks x chunk
+    simulated ms: digests of every observable tests/test_zr_gpu_casper_resident.py::diff compares, after every chunk.
+    per = 1024 (65 542 nodes, 134 M deliveries): ~8 min on one core. The oracle keeps every attestation in every node's
+    HashSet, so config 5's own 4096 per slot (16 x the events) is out of a fixture's reach."""
+    from wittgenstein_amd import protocols as P  # (choose_attesters: pure Python, java.util.Random restated)
+    params = (64, False, 5, per, 1000, 1)
+    c = o.CasperIMD(params, None, None, seed=seed)
+    first = 1 + params[2]
+    ids = P.choose_attesters(range(first, first + params[0] * per), int(stopped_frac * params[0] * per), seed=seed + 1)
+    if ids:
+        c.stop(ids)
+    marks = []
+    for _ in range(chunks):
+        c.run_ms(chunk)
+        i = c.info()
+        d = {"time": i["time"], "rng": i["rng"], "queue": i["queue"], "delivered": i["delivered"]}
+        for f in CASPER_FIELDS:
+            d[f] = digest(c.read(f))
+        marks.append(d)
+    return {"protocol": "CasperIMD", "params": list(params), "seed": seed, "chunk": chunk, "stopped": len(ids),
+            "stop_seed": seed + 1, "nodes": 1 + params[2] + params[0] * per, "marks": marks,
+            "observer_head_height": int(c.read("headHeight")[0])}
+
+
 if __name__ == "__main__":
     o.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "casper":
+        per = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+        res = casper_config5_shape(per)
+        with open(os.path.join(HERE, "casper_config5_shape_%d.json" % res["nodes"]), "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        print("wrote Casper trace at", res["nodes"], "nodes:", res["marks"][-1]["delivered"], "deliveries")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "config3":
         # separate file: tests/golden/handel_config3_32768.json (regenerating the small traces takes seconds, this 8 min)
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768

@@ -104,6 +104,24 @@ def test_batch_run_multiple_times_on_device():  # wg_batch_run_multiple_times: t
     tb.test_run_multiple_times_device_loop_equals_host_loop(64)  # (per-seed oracle runs: tests/test_zu_gpu_graph.py)
 
 
+def test_graph_replay_keeps_the_profiler(monkeypatch):
+    """WG_GRAPH=1: runMs(chunk) of a batch captured once and replayed; the profiler's brackets are then device clock stamps
+    (Engine::ProfScope / k_prof_stamp) instead of HIP events — one span per simulated ms for the delivery pass, the same
+    delivered count as the enqueued loop"""
+    import wittgenstein_amd as w
+    import parity
+    res = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("WG_GRAPH", graph)
+        sims = [parity.handel_pair((64, 57, 4, 50, 10, 20, 10, 6, 0), seed=s)[0] for s in (0, 1)]
+        sims[0].network().profile(2)
+        d, ms = w.Batch([g.network() for g in sims]).run_multiple_times(chunk=10, maxTime=20000)
+        pr = sims[0].network().profile_read()["deliver"]
+        res[graph] = (list(d), list(ms), pr["spans"])
+        assert pr["spans"] >= max(ms) and pr["total_ns"] > 0, pr
+    assert res["0"][:2] == res["1"][:2]
+
+
 def test_batch_pingpong_active_mask():
     tb.test_pingpong_batch_and_active_mask()
 

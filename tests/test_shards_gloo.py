@@ -353,3 +353,49 @@ def test_sharded_casper_matches_the_oracle(oracle, tmp_path, world, params, byz,
         assert r["bad"] == [], r
         assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["height"] >= 2
     assert res[0]["delivered"] > (50000 if world == 2 else 300)
+
+
+FLOOD_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
+from wittgenstein_amd import shards, protocols as P
+import oracle_lib as o
+import test_zq_gpu_p2pflood_resident as tf
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+params = %(params)r
+g = P.P2PFlood(P.P2PFloodParameters(*params, None, %(nl)r), seed=%(seed)d, config=shards.config(dist, device_memory=False))
+g.init()
+c = o.P2PFlood(params, None, %(nl)r, seed=%(seed)d)
+whole = shards.WholeNetwork(dist, g.network())
+class G:
+    def network(self): return whole
+bad = [("init", m) for m in tf.diff(G(), c)]
+for k in range(%(chunks)d):
+    if bad: break
+    g.network().runMs(%(chunk)d); c.run_ms(%(chunk)d)
+    bad += [(k, m) for m in tf.diff(G(), c)]
+calls, words = shards.traffic(g.network())
+res = [None] * world
+dist.all_gather_object(res, {"rank": rank, "bad": [str(b) for b in bad[:6]], "calls": calls, "words": words,
+                             "delivered": c.info()["delivered"]})
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_p2pflood_matches_the_oracle(oracle, tmp_path):  # shuffled envelopes with explicit arrivals, over 2 gloo ranks
+    global WORKER
+    keep, WORKER = WORKER, FLOOD_WORKER
+    try:
+        res = _run(tmp_path, 2, 29801, params=(300, 20, 20, 3, 1, 6, 10), nl=None, seed=4, chunk=100, chunks=40)
+    finally:
+        WORKER = keep
+    for r in res:
+        assert r["bad"] == [], r
+        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["delivered"] > 4000

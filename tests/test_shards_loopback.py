@@ -131,3 +131,49 @@ def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_c
 def test_logical_shards_equal_the_unsharded_engine():
     bad, done, delivered = handel_shards_vs_unsharded(2, (64, 57, 4, 50, 10, 20, 10, 6, 0), seed=3, device_memory=False)
     assert bad == [] and done == 58 and delivered > 0
+
+
+def p2pflood_loopback(k, params, nl, seed, chunk, chunks, device_memory=False):
+    """P2PFlood (P/P2PFlood.java) resident on k logical shards in lock-step with the oracle: every first receipt's shuffled
+    MultipleDestWithDelayEnvelope — destinations AND explicit arrivals — goes through the replicated envelope creation
+    (k_shard_multi_fill / k_shard_multi_create); every observable of tests/test_zq_gpu_p2pflood_resident.py::diff"""
+    import oracle_lib as o
+    from wittgenstein_amd import protocols as P, shards
+    import test_zq_gpu_p2pflood_resident as tf
+    grp = shards.LoopbackGroup(k, device_memory=device_memory)
+    sims = []
+    for s in range(k):
+        sims.append(P.P2PFlood(P.P2PFloodParameters(*params, None, nl), seed=seed, config=grp.config(s)))
+        sims[-1].init()
+    c = o.P2PFlood(params, None, nl, seed=seed)
+    nets = [g.network() for g in sims]
+
+    class Whole:
+        time = property(lambda self: nets[0].time)
+        msgs = property(lambda self: nets[0].msgs)
+
+        def rng_state(self):
+            assert len({net.rng_state() for net in nets}) == 1
+            return nets[0].rng_state()
+
+        def read(self, f):
+            return grp.gather([net.read(f) for net in nets], nets)
+
+    class G:
+        def network(self):
+            return Whole()
+
+    assert not tf.diff(G(), c), "after init()"
+    for _ in range(chunks):
+        grp.run(lambda s: nets[s].runMs(chunk))
+        c.run_ms(chunk)
+        d = tf.diff(G(), c)
+        assert not d, "t=%d: %s" % (nets[0].time, d)
+    return c, [shards.traffic(net) for net in nets]
+
+
+def test_p2pflood_logical_shards_match_the_oracle():
+    c, traffic = p2pflood_loopback(2, (100, 10, 50, 1, 1, 10, 30), "NetworkNoLatency", seed=0, chunk=1000, chunks=20)
+    assert c.info()["delivered"] > 800 and len(set(traffic)) == 1 and traffic[0][0] > 0
+    c, _ = p2pflood_loopback(3, (300, 20, 20, 3, 1, 6, 10), None, seed=4, chunk=100, chunks=40)
+    assert c.info()["delivered"] > 4000

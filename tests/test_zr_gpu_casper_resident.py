@@ -150,6 +150,35 @@ def test_casper_16390_nodes_ten_percent_stopped_against_the_oracle():
     assert int(g.network().read("headHeight")[0]) == 2
 
 
+@pytest.mark.gpu
+def test_casper_65542_nodes_against_the_oracle_trace():
+    """BASELINE config 5's shape at a quarter of its size — cycleLength 64, 5 producers, 1024 attesters voting per slot =
+    65 542 nodes, 10 % of the attesters stop()ped, 24 simulated seconds = 121 M deliveries — against the ORACLE's run of the
+    same configuration (tests/golden/casper_config5_shape_65542.json, tests/golden/make_golden.py casper: 8 minutes on one
+    core, so a committed fixture rather than a lock-step partner): a digest of every observable `diff` compares, the
+    queue size, the rd state and the delivered count after every 8-second chunk."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "casper_config5_shape_65542.json")))
+    params = tuple(gold["params"])
+    g = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=gold["seed"], max_slots=5)
+    g.init()
+    ids = g.stop_attesters(gold["stopped"], seed=gold["stop_seed"])
+    assert len(ids) == gold["stopped"] and g.network().node_count == gold["nodes"] == 65542
+    net = g.network()
+    delivered = 0
+    for want in gold["marks"]:
+        net.runMs(gold["chunk"])
+        delivered += net.last_stats["delivered"]
+        got = {"time": net.time, "rng": net.rng_state(), "queue": net.msgs.size(), "delivered": delivered}
+        for f in FIELDS[:10]:
+            got[f] = hashlib.sha256(np.ascontiguousarray(net.read(f), dtype=np.int64).tobytes()).hexdigest()[:16]
+        bad = {k: (got.get(k), v) for k, v in want.items() if got.get(k) != v}
+        assert not bad, "t=%d: %s" % (net.time, bad)
+    assert int(net.read("headHeight")[0]) == gold["observer_head_height"] == 2
+
+
 def random_on_ties_cases(long=True):
     """randomOnTies (P/CasperIMD.java:250-253, the CasperParemeters() default) resident: a tie's rd.nextBoolean() takes its
     place in the rd sequence from the draws of every earlier event of the ms, so the events that can call best() are

@@ -157,6 +157,14 @@ def leg9():
             bad.append((step, "time / rd / msgs.size()"))
     out["casper_vs_unsharded"] = {"bad": [str(b) for b in bad[:6]], "delivered": int(ref.network().read("msgReceived").sum()),
                                   "height": int(ref.network().read("headHeight")[0])}
+def leg10():
+    # 10. P2PFlood on logical shards of the one GPU (shuffled MultipleDestWithDelayEnvelopes with explicit arrivals through the
+    # replicated envelope creation), in lock-step with the oracle
+    out["p2pflood"] = []
+    for k, params, nl, seed, chunk, chunks in [(2, (100, 10, 50, 1, 1, 10, 30), "NetworkNoLatency", 0, 1000, 20),
+                                               (4, (2000, 10, 50, 1, 1, 10, 30), None, 0, 250, 8)]:
+        c, traffic = tl.p2pflood_loopback(k, params, nl, seed, chunk, chunks, device_memory=True)
+        out["p2pflood"].append({"k": k, "delivered": int(c.info()["delivered"]), "same_collectives": len(set(traffic)) == 1})
 import traceback
 out["errors"] = {}
 for _name, _fn in [(k, v) for k, v in sorted(globals().items()) if k.startswith('leg') and callable(v)]:
@@ -259,3 +267,9 @@ def test_casper_four_logical_shards_equal_the_unsharded_engine_at_2051_nodes(res
     assert "leg9" not in result["errors"], result["errors"]["leg9"]
     r = result["casper_vs_unsharded"]
     assert r["bad"] == [] and r["height"] >= 1 and r["delivered"] > 1024 * 2051 * 0.9, r
+
+
+def test_p2pflood_logical_shards_match_the_oracle(result):
+    assert "leg10" not in result["errors"], result["errors"]["leg10"]
+    assert [r["k"] for r in result["p2pflood"]] == [2, 4]
+    assert all(r["same_collectives"] for r in result["p2pflood"]) and result["p2pflood"][1]["delivered"] > 10000

@@ -83,6 +83,21 @@ def test_casper_through_the_engines_own_communicator():  # sendAll + far envelop
     assert c.info()["delivered"] > 100000 and shards.traffic(g.network())[0] > 0
 
 
+def test_p2pflood_through_the_engines_own_communicator():
+    import test_zq_gpu_p2pflood_resident as tf
+    from wittgenstein_amd import protocols as P
+    params = (300, 20, 20, 3, 1, 6, 10)
+    g = P.P2PFlood(P.P2PFloodParameters(*params, None, None), seed=4, config=shards.config_rccl())
+    g.init()
+    c = o.P2PFlood(params, None, None, seed=4)
+    for _ in range(40):
+        g.network().runMs(100)
+        c.run_ms(100)
+        d = tf.diff(g, c)
+        assert not d, (g.network().time, d)
+    assert c.info()["delivered"] > 4000 and shards.traffic(g.network())[0] > 0
+
+
 def test_configure_after_allocation_is_refused():
     net = w.Network.create({})
     net.add_nodes([1, 2], [1, 2])

@@ -373,7 +373,7 @@ struct SendAllDesc {  // 32 bytes
   unsigned long long destOff;
 };
 constexpr int XB_HEAD = 4;                    // header words in front of EngineDev::xbuf (16-byte alignment kept)
-constexpr int XM_WORDS = 6 + 64;               // seed, sendTime, msg, payload, ndest, pad, dest[64]
+constexpr int XM_WORDS = 6 + 128;              // seed, sendTime, msg, payload, ndest, explicit arrivals?, dest[64], arrival[64]
 constexpr uint32_t MULTI_FRESH = 0xFFFFFFFFu;  // Rec::w3 of a K_CHAIN record whose envelope is yet to be created
 constexpr uint32_t SENDALL_FRESH = 0xFFFFFFFEu;  // ... of a Network.sendAll an action() made on a sharded engine (w1 = node count)
 WG_HD inline bool shard_owns(const EngineDev& d, int32_t node) { return node >= d.shardLo && node < d.shardHi; }

@@ -2996,7 +2996,6 @@ struct FloodHost : ProtoHost {
     if (init.maxPeers < 1 || init.maxPeers > 64)
       throw WgError(WG_EUNSUPPORTED, "a node with more than 64 peers (device multi-destination sends hold <= 64 ids)");
     if (p.delayBetweenSends < 0 || p.delayBetweenSends >= (1 << 20) || p.delayBeforeResent < 0) throw WgError(WG_EINVAL, "delays");
-    if (e.shardCount > 0) throw WgError(WG_EUNSUPPORTED, "P2PFlood does not run on a sharded engine yet");
     if (!e.allocated)  // a hop arrives delayBeforeResent + up to 64 * (delayBetweenSends + 1) + latency ahead
       e.horizonExtra = std::max(e.horizonExtra, p.delayBeforeResent + 1 + init.maxPeers * (p.delayBetweenSends + 1));
     e.ensure_device();
@@ -3017,6 +3016,9 @@ struct FloodHost : ProtoHost {
     e.dev.boundMsg = 1;  // one (delayed, shuffled) multi-destination send per first receipt
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 0;
   }
+  // node-range sharding: a visit touches the visited node's `received` word only; its one (shuffled, delayed) multi-
+  // destination send goes through the replicated envelope creation with explicit arrivals (k_shard_multi_*)
+  bool supports_shards() const override { return true; }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<FloodProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                        (const FloodState*)g.stab, 0);

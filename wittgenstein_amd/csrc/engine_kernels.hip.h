@@ -713,12 +713,11 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         if (m == 1) {
           fin = make_rec(K_MSG, from, (uint32_t)dst[0], o.a, o.b);
           arrival = arv[0];
-        } else if (m > 1 && SH && (o.pad & OUT_DELAYED)) {
-          set_err(d.g, ERR_SHARD_MULTI);  // (the exchanged envelope image carries no explicit arrivals yet)
         } else if (m > 1 && SH) {
-          // the envelope (slot, sorted destinations) is replicated state: it is created on every shard from the
-          // exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push order
-          fin = make_rec(K_CHAIN, from, (uint32_t)m, 0, MULTI_FRESH);
+          // the envelope (slot, sorted destinations, explicit arrivals if any) is replicated state: it is created on every
+          // shard from the exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push
+          // order (w1 = the entries it takes in the destination ring: MultiF sums them)
+          fin = make_rec(K_CHAIN, from, (uint32_t)((o.pad & OUT_DELAYED) ? 2 * m : m), 0, MULTI_FRESH);
           arrival = arv[0];
           atomicAdd(&d.xbuf[-XB_HEAD], 1);  // header word of the exchange image: envelopes to create (rare)
         } else if (m > 1) {
@@ -910,7 +909,10 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
     x[2] = (int32_t)o.a;
     x[3] = (int32_t)o.b;
     x[4] = m;
+    x[5] = (o.pad & OUT_DELAYED) ? 1 : 0;
     for (int j = 0; j < m; j++) x[6 + j] = dst[j];
+    if (o.pad & OUT_DELAYED)  // MultipleDestWithDelayEnvelope: explicit arrivals (C/Network.java:449-467)
+      for (int j = 0; j < m; j++) x[6 + 64 + j] = arv[j];
   }
 }
 
@@ -950,6 +952,8 @@ __global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __r
       continue;
     }
     for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)j) % d.chainDests] = x[6 + j];
+    if (x[5])  // explicit arrivals follow the destinations (as k_resolve<false> lays them out; Chain::flags bit 1)
+      for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)(m + j)) % d.chainDests] = x[6 + 64 + j];
     Chain c;
     c.from = rec_from(r);
     c.seed = x[0];
@@ -958,7 +962,7 @@ __global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __r
     c.destOff = (uint32_t)off;
     c.msg = (uint32_t)x[2];
     c.payload = (uint32_t)x[3];
-    c.flags = 1u;
+    c.flags = 1u | (x[5] ? 2u : 0u);
     d.chains[slot] = c;
     d.fin[p] = make_rec(K_CHAIN, c.from, slot, 0, 0);
   }
