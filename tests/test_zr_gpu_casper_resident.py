@@ -153,7 +153,7 @@ def test_casper_16390_nodes_ten_percent_stopped_against_the_oracle():
 @pytest.mark.gpu
 def test_casper_65542_nodes_against_the_oracle_trace():
     """BASELINE config 5's shape at a quarter of its size — cycleLength 64, 5 producers, 1024 attesters voting per slot =
-    65 542 nodes, 10 % of the attesters stop()ped, 24 simulated seconds = 121 M deliveries — against the ORACLE's run of the
+    65 542 nodes, 10 % of the attesters stop()ped, 24 simulated seconds = 108.9 M deliveries — against the ORACLE's run of the
     same configuration (tests/golden/casper_config5_shape_65542.json, tests/golden/make_golden.py casper: 8 minutes on one
     core, so a committed fixture rather than a lock-step partner): a digest of every observable `diff` compares, the
     queue size, the rd state and the delivered count after every 8-second chunk."""
