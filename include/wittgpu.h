@@ -148,7 +148,9 @@ typedef struct {
  * ByzBlockProducerWF that init(badNode) starts with (:475-479 uses 0) and a capacity: the run may reach slot maxSlots
  * (a slot is 8000 ms; attestation and block tables are sized by it). Nodes: 0 the observer, 1 the byzantine producer,
  * 2..blockProducersCount the other producers, then cycleLength * attestersPerRound attesters (:481-509).
- * randomOnTies != 0 is WG_EUNSUPPORTED (the tie's rd.nextBoolean() decides a head inside action()). init() =
+ * randomOnTies (:250-253; the reference's default is true) is honoured: the tie's rd.nextBoolean() decides a head inside
+ * action(), so once the chain has forked the events that can call best() are delivered by one wavefront in global event
+ * order (exact; the parallel path until then) — WG_EUNSUPPORTED only together with node-range sharding. init() =
  * wg_register_periodic_task per node in the reference's order: task words 2 (byzantine producer), 0 (producer), 1 (attester). */
 typedef struct {
   int32_t cycleLength, randomOnTies, blockProducersCount, attestersPerRound, blockConstructionTime,
@@ -323,7 +325,8 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * device) with its stream idle; the function returns once the summed values are visible to any stream. Bind it to
  * RCCL (torch.distributed backend "nccl": wittgenstein_amd/shards.py) — over xGMI the payload is a few bytes per event,
  * so the latency of the collective, not its bandwidth, is what a simulated ms pays.
- * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong, Handel, GSFSignature, San Fermin.
+ * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong, Handel, GSFSignature, San Fermin,
+ * P2PFlood, Casper IMD (randomOnTies == 0).
  * wg_read_i64 on a shard returns its own nodes' values and zeros for the others (sum across shards for the whole
  * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
  * shard yet, batches, and host-callback mode. */
