@@ -88,3 +88,12 @@ def test_casper_reference_test_parameters_four_shards_ten_percent_stopped():
     config 5's "+10 %" as SURVEY.md §8d defines it — on 4 shards: three slots, 80 votes (each a sendAll to all 406) per slot"""
     c, _ = casper_loopback(4, (5, False, 5, 80, 1000, 1), seed=3, chunk=4000, chunks=7, stopped=40)
     assert c.info()["delivered"] > 50000
+
+
+def test_casper_shards_with_chain_runs_one_wavefront_each(monkeypatch):
+    """k_expand_runs on a sharded engine (a sendAll's runs of consecutive same-ms hops unrolled one wavefront per run: the
+    attestation events are not threaded, every shard releases the envelope's slot): WG_RUN_MIN=2 sends every run of 2+
+    hops of these small networks through it"""
+    monkeypatch.setenv("WG_RUN_MIN", "2")
+    casper_loopback(2, (5, False, 5, 80, 1000, 1), seed=1, chunk=4000, chunks=5, stopped=17)
+    casper_loopback(3, (3, False, 3, 8, 1000, 1), seed=2, chunk=500, chunks=40, byz_delay=-2000)
