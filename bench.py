@@ -232,6 +232,12 @@ def casper_line(args):
             dk_ns += pr["total_ns"]
         del g, net, sims, grp
         gc.collect()
+    ctraffic = None
+    ctpath = os.path.join(ROOT, "profiles", "traffic_casper.json")  # per-launch HBM bytes of the delivery pass (rocprofv3 PMC passes)
+    if os.path.exists(ctpath) and not ks:
+        tj = json.load(open(ctpath))
+        if tj.get("nodes") == n and tj.get("stopped_fraction", 0.0) == args.casper_stopped:
+            ctraffic = tj.get("hbm_bytes_per_launch")
     bmsg = 104 + 24 + 8  # SURVEY.md §8d fixed part + the attestation's three bit-sets (8-byte RMW each) + attHead read
     alg = float(delivered) * bmsg
     avg_ns = dk_ns / max(1, dk_spans)
@@ -254,7 +260,7 @@ def casper_line(args):
                    "allreduce_calls_and_int32_words_per_simulation": shard_traffic},
         "roofline": {"bound": "hbm", "kernel": "the delivery pass: k_casper_classify + k_casper_attestations + k_deliver<CasperProto> (one launch of each per simulated ms that is not skipped)", "achieved": (alg / max(1, dk_spans)) / max(1.0, avg_ns),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
+                     "traffic": ctraffic, "algorithmic_bytes_per_launch": alg / max(1, dk_spans), "avg_launch_us": avg_ns / 1000.0,
                      "launches": dk_spans, "bytes_per_delivered_message": bmsg, "whole_run_achieved_GBs": alg / (elapsed * 1e9)},
     }
     if not args.no_cpu:

@@ -13,7 +13,8 @@ tools/micro/pmc_calib.hip (profiles/r02b_pmc_calib.txt), for the access shapes o
 So for these kernels (scattered lines and lane-scattered words, no wide streams) the counters are the memory-side
 bytes as they stand: `hbm_bytes_per_launch` = FETCH_SIZE + WRITE_SIZE; `..._reads_doubled` keeps the guide's x2 on
 the reads as the upper bound (it would apply only to the part of the reads that are 128-byte requests).
-usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json>"""
+usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json> [kernel patterns, comma-separated]
+(default patterns: Handel's delivery pass; Casper's: "k_casper_classify,k_casper_attestations,k_deliver<CasperProto")"""
 import json
 import sys
 
@@ -31,13 +32,14 @@ def per_dispatch(path, counter, kernels):
 
 def main():
     fetch, write, nodes, replicas, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    kernels = ["k_deliver_msgs<", "k_deliver<"]
+    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_deliver_msgs<", "k_deliver<"]
     f = per_dispatch(fetch, "FETCH_SIZE", kernels)
     w = per_dispatch(write, "WRITE_SIZE", kernels)
     rd = sum(f.values()) * 1024.0
     wr = sum(w.values()) * 1024.0
     json.dump({"nodes": nodes, "replicas": replicas,
-               "kernels": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (one launch of each per simulated ms)",
+               "kernels": ("k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (one launch of each per simulated ms)"
+                           if len(sys.argv) <= 6 else " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)"),
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
                "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,
                "per_kernel_KB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
