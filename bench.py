@@ -18,8 +18,9 @@ the batch is lowered to what fits and the line says so — a size check never ab
 messages = sum of Node.msgReceived increments (C/Network.java:607-613), simulated ms = sum over copies of
 network.time.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): the copies shard across ranks with no data-path
-collective (every rank runs its own R copies, seeds disjoint), "scaling": "weak".
+Multi-GPU (--gpus N): the copies shard across ranks with no data-path collective (every rank runs its own R copies,
+seeds disjoint), "scaling": "weak". Under a launcher (torch.distributed.run: WORLD_SIZE set) every process is one rank;
+a bare `python bench.py --gpus N` starts the N ranks itself (launch_ranks) and rank 0 prints the line with n_gpus = N.
 
 --mode shard (not the default): a step is ONE simulation whose nodes are split by id range over
 the N ranks (wg_shard_configure; RCCL all-reduces per simulated ms through wittgenstein_amd/shards.py),
@@ -380,6 +381,36 @@ def main_shard(args):
     dist.destroy_process_group()
 
 
+def dist_backend():
+    """"nccl" (= RCCL on ROCm) on the GPUs; WG_BENCH_BACKEND=gloo is the CPU test hook of tests/test_bench_cpu.py (the
+    timing contract's barrier and reductions over gloo, the engine's kernels on the wave emulator)"""
+    return os.environ.get("WG_BENCH_BACKEND", "nccl")
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no torchrun environment around it: start the N ranks ourselves — one process per
+    GPU through torch.distributed.run on 127.0.0.1, the same command line — and hand their one JSON line (rank 0's)
+    through. Under a launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    if dist_backend() == "nccl":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box" % (n, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without a launcher: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc = subprocess.run(cmd, stdout=_REAL_STDOUT, env=env).returncode
+    sys.exit(rc)
+
+
 def emit(obj):
     """the ONE JSON line, on the process's real stdout"""
     os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
@@ -429,6 +460,11 @@ def main():
                     help="--mode shard on ONE GPU: k engines in this process, each owning a node range; the all-reduce "
                          "sums their buffers in place (shards.LoopbackGroup). 0 = one shard per rank over RCCL")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.logical_shards and not (args.workload == "casper"):
+        return launch_ranks(args.gpus)  # (the driver's `python bench.py --gpus N`: N ranks, one per GPU; never returns)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        log("[bench] --gpus %d but the launcher started %s ranks: the launcher's count stands (n_gpus in the line)"
+            % (args.gpus, os.environ["WORLD_SIZE"]))
     if args.workload == "casper":
         return main_casper(args)
     if args.mode == "shard":
@@ -442,9 +478,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local)
+    rdev = "cuda" if dist_backend() == "nccl" else "cpu"  # where the contract's reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rdev == "cuda":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(dist_backend())
 
     import __graft_entry__
     from wittgenstein_amd import _lib
@@ -474,7 +514,7 @@ def main():
     per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
     R = replicas.plan_replicas(R_req, free0, per_copy)
     if world > 1:  # every rank runs the same batch size (weak scaling: fixed work per GPU)
-        rt = torch.tensor([R], device="cuda", dtype=torch.int64)
+        rt = torch.tensor([R], device=rdev, dtype=torch.int64)
         dist.all_reduce(rt, op=dist.ReduceOp.MIN)
         R = int(rt.item())
     if R < R_req:
@@ -599,7 +639,7 @@ def main():
     gc.collect()
 
     if world > 1:
-        elapsed, delivered, sim_ms = replicas.reduce_job(dist, "cuda", elapsed, delivered, sim_ms)
+        elapsed, delivered, sim_ms = replicas.reduce_job(dist, rdev, elapsed, delivered, sim_ms)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -307,13 +307,25 @@ hipError_t hipStreamDestroy(hipStream_t s) {
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+// WG_EMU_DEVICES=<k>: the emulator answers as a box of k devices (they all are this process's memory) — multi-rank
+// host logic that pins rank r to device r (bench.py --gpus N over gloo) runs unchanged
+static int emu_devices() {
+  const char* v = getenv("WG_EMU_DEVICES");
+  const int k = v ? atoi(v) : 1;
+  return k > 0 ? k : 1;
+}
+static thread_local int emuCurDevice = 0;
+hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= emu_devices()) return hipErrorInvalidValue;
+  emuCurDevice = d;
+  return hipSuccess;
+}
 hipError_t hipGetDevice(int* d) {
-  *d = 0;
+  *d = emuCurDevice;
   return hipSuccess;
 }
 hipError_t hipGetDeviceCount(int* n) {
-  *n = 1;
+  *n = emu_devices();
   return hipSuccess;
 }
 hipError_t hipGetLastError() { return hipSuccess; }

@@ -55,3 +55,24 @@ def test_product_random_matches_oracle_and_jump_ahead(lib, oracle):
         a = np.zeros(500, np.int32)
         lib.wgh_jrandom_bounded(C.c_int64(5), bound, 500, a.ctypes.data_as(C.POINTER(C.c_int32)))
         assert (a == o.jrandom_bounded(5, bound, 500)).all()
+
+
+def test_rccl_that_cannot_be_loaded_is_a_status_not_a_crash():
+    """wg_rccl_unique_id on a box whose librccl cannot be dlopen'ed returns WG_EHIP with dlopen's message (include/wittgpu.h);
+    it used to build that message from two dlerror() calls — the second returns NULL — and crash the host process. Run in
+    a child process: the loader's outcome is cached per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from wittgenstein_amd import _lib\n"
+            "l = _lib.lib()\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = l.wg_rccl_unique_id(buf)\n"
+            "msg = l.wg_last_error(None).decode()\n"
+            "assert rc == _lib.WG_EHIP, rc\n"
+            "assert 'could not be loaded' in msg and '/nonexistent/librccl.so.1' in msg, msg\n"
+            "print('ok')\n" % ROOT)
+    env = dict(os.environ, WG_RCCL_LIB="/nonexistent/librccl.so.1", ROCM_PATH="")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -109,3 +109,60 @@ def test_bench_lowers_the_batch_instead_of_failing():
                          free=600)
     assert out["config"]["replicas_requested"] == 8 and out["config"]["replicas_per_gpu"] == 4
     assert "copies per step instead" in err
+
+
+SITE = r'''
+# test infrastructure (tests/test_bench_cpu.py): every python process of the bench job — the parent, torch.distributed.run
+# and its ranks — runs the engine's kernel sources on the CPU wave emulator and sees a pretend torch.cuda
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import wittgenstein_amd._lib as L
+L.LIB_PATH = os.path.join({root!r}, "tests", "emu", "libwittgpu_emu.so"); L._lib = None
+import torch
+free = [10**6]
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a: None
+def mem_get_info(*a):
+    free[0] -= 100
+    return (free[0], 10**6)
+torch.cuda.mem_get_info = mem_get_info
+'''
+
+
+def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
+    """the driver's `python bench.py --gpus 2 ...` with no launcher around it: bench.py starts the two ranks itself
+    (torch.distributed.run on 127.0.0.1), rank 0 prints ONE line with n_gpus == 2, the ranks ran disjoint seeds — here over
+    gloo on the wave emulator (WG_BENCH_BACKEND=gloo, WG_EMU_DEVICES=2), the timing contract's barrier and reductions real"""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
+    (tmp_path / "sitecustomize.py").write_text(SITE.format(root=ROOT))
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""), WG_BENCH_BACKEND="gloo",
+               WG_EMU_DEVICES="2")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "16", "--replicas", "2", "--no-cpu", "--no-second"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["replicas_per_gpu"] == 2
+    # one rank alone, same argv: seeds 0, 1; the two-rank job ran seeds 0..3 — twice the simulations per step
+    one, _ = run_bench(["--gpus", "1"] + argv[2:])
+    total2 = round(out["value"] * out["ms_per_step"] * 2 / 1000.0)
+    total1 = round(one["value"] * one["ms_per_step"] * 2 / 1000.0)
+    assert total2 > total1 and total2 % 2 == 0
+    import oracle_lib as o
+    import bench
+    hp = bench.handel_params(16)
+    want = 0
+    for seed in range(4):  # what the oracle delivers for those four seeds (RunMultipleTimes loop, C/RunMultipleTimes.java:50-64)
+        c = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
+                     hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], bench.NB, bench.NL, 0, seed=seed)
+        while True:
+            did = c.run_ms(10)
+            if c.info()["time"] >= 20000 or (did and not c.cont_if()):
+                break
+        want += c.info()["delivered"]
+    assert total2 == 2 * want

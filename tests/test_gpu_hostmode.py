@@ -222,3 +222,46 @@ def test_batched_step_errors_are_loud():
     op = (L.wg_step_op * 1)()
     op[0].after, op[0].kind, op[0].msg, op[0].time, op[0].from_ = 3, 2, 99, 7, 1  # a delivery the step did not hand out
     assert lib.wg_step_end(h, op, 1, None) == L.WG_EINVAL
+    # a refused step applies NOTHING and stays open (the ms has been handed out: the caller resubmits)
+    ops = (L.wg_step_op * 2)()
+    ops[0].after, ops[0].kind, ops[0].msg, ops[0].time, ops[0].from_, ops[0].to, ops[0].n = 0, 1, 7, 9, 1, 2, 1  # sendArriveAt: fine
+    ops[1].after, ops[1].kind, ops[1].msg, ops[1].time, ops[1].from_, ops[1].to, ops[1].n = 0, 0, 7, 5, 1, 99, 1  # send to node 99
+    q0 = C.c_int64()
+    assert lib.wg_queue_size(h, C.byref(q0)) == 0
+    assert lib.wg_step_end(h, ops, 2, None) == L.WG_EINVAL
+    q1 = C.c_int64()
+    assert lib.wg_step_begin(h, 10, hn.INT_MAX, arr, 8, C.byref(n)) == L.WG_ESTATE  # still open
+    ops[1].to = 3
+    ops[1].time = 5  # sendTime == time: IllegalStateException site :471
+    assert lib.wg_step_end(h, ops, 2, None) == L.WG_ESTATE
+    ops[1].time = 6
+    assert lib.wg_step_end(h, ops, 2, None) == 0  # accepted as a whole
+    assert lib.wg_queue_size(h, C.byref(q1)) == 0 and q1.value == q0.value + 2
+
+
+@pytest.mark.gpu
+def test_batched_step_is_closed_when_an_action_raises():
+    """an exception out of a protocol's action() must not leave the engine in 'step open': the step is closed with the pushes
+    made so far (their multi-destination envelopes' re-pushes included) and the exception reaches the caller"""
+    net = hn.HostNetwork(None, batched=True)
+    nodes = [hn.Node(net) for _ in range(3)]
+    for nd in nodes:
+        net.addNode(nd)
+    net._start()
+
+    class Boom(Exception):
+        pass
+
+    ran = []
+
+    def bad():
+        ran.append(net.time)
+        raise Boom()
+
+    net.registerTask(bad, 5, nodes[0])
+    net.registerTask(lambda: ran.append(-net.time), 8, nodes[1])
+    with pytest.raises(Boom):
+        net.runMs(10)
+    assert ran == [5]
+    net.runMs(10)  # the engine is usable: the later task still runs
+    assert ran == [5, -8]

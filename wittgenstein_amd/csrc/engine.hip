@@ -88,17 +88,25 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r;
   if (r.lib || !r.err.empty()) return r;
+  // WG_RCCL_LIB names THE library to load (no fallback: a host that pins its RCCL must not silently get another one)
   std::vector<std::string> names;
-  if (const char* p = getenv("WG_RCCL_LIB")) names.push_back(p);
-  if (const char* p = getenv("ROCM_PATH")) names.push_back(std::string(p) + "/lib/librccl.so.1");
-  names.push_back("/opt/rocm/lib/librccl.so.1");
-  names.push_back("librccl.so.1");
+  if (const char* p = getenv("WG_RCCL_LIB")) {
+    names.push_back(p);
+  } else {
+    if (const char* p = getenv("ROCM_PATH"))
+      if (*p) names.push_back(std::string(p) + "/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
+  }
+  std::string why;
   for (const std::string& n : names) {
     r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (r.lib) break;
+    const char* m = dlerror();  // (one call per failure: dlerror() clears the message it returns)
+    why += (why.empty() ? "" : "; ") + n + ": " + (m ? m : "?");
   }
   if (!r.lib) {
-    r.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    r.err = "librccl.so.1 could not be loaded: " + why;
     return r;
   }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
@@ -554,14 +562,15 @@ void Engine::ensure_device() {
   dev.maxEvents = maxOut;
   dev.ev = dalloc<Rec>(maxOut, false, AC_SCRATCH);
   dev.evAux = dalloc<EvAux>(maxOut, false, AC_SCRATCH);
-  dev.evRes = dalloc<EvRes>(maxOut);
-  dev.evRecOff = dalloc<uint32_t>(maxOut);
-  dev.evDrawOff = dalloc<uint32_t>(maxOut);
+  dev.evRes = dalloc<EvRes>(maxOut, true, AC_SCRATCH);   // (per-ms scratch holds nothing between milliseconds:
+  dev.evRecOff = dalloc<uint32_t>(maxOut, true, AC_SCRATCH);  //  not part of the init() image, wg_snapshot_bytes)
+
+  dev.evDrawOff = dalloc<uint32_t>(maxOut, true, AC_SCRATCH);
   dev.evNext = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
   dev.head = dalloc<int32_t>(n, false);
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
-  dev.active = dalloc<uint32_t>(n);
-  dev.activeB = dalloc<VisitDesc>(n);
+  dev.active = dalloc<uint32_t>(n, true, AC_SCRATCH);
+  dev.activeB = dalloc<VisitDesc>(n, true, AC_SCRATCH);
   dev.activeM = dalloc<MineDesc>(n, false, AC_SCRATCH);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false, AC_SCRATCH);
@@ -570,8 +579,8 @@ void Engine::ensure_device() {
   dev.arr = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
   maxTiles = (maxOut + TILE - 1) / TILE;
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
-  dev.binBase = dalloc<uint32_t>(D);
-  dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID);
+  dev.binBase = dalloc<uint32_t>(D, true, AC_SCRATCH);
+  dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID, true, AC_SCRATCH);
   dev.farBuf = nullptr;
   dev.farCap = 0;
   if (farCapacity > 0) {
@@ -584,9 +593,9 @@ void Engine::ensure_device() {
   dev.maxSendAll = 0;
   if (sendAllCapacity > 0) {  // (a resident protocol whose action()s call Network.sendAll asked for it)
     dev.maxSendAll = (uint32_t)sendAllCapacity;
-    dev.saDesc = dalloc<SendAllDesc>(dev.maxSendAll);
-    dev.saLat = dalloc<int32_t>((size_t)dev.maxSendAll * n, false);
-    dev.saHist = dalloc<uint32_t>((size_t)dev.maxSendAll * ((n + TILE - 1) / TILE) * D, false);
+    dev.saDesc = dalloc<SendAllDesc>(dev.maxSendAll, true, AC_SCRATCH);
+    dev.saLat = dalloc<int32_t>((size_t)dev.maxSendAll * n, false, AC_SCRATCH);
+    dev.saHist = dalloc<uint32_t>((size_t)dev.maxSendAll * ((n + TILE - 1) / TILE) * D, false, AC_SCRATCH);
   }
   dev.saBins = sendall_bins();
   // long chain runs (EngineDev::runs): worth a wavefront each where envelopes reach every node — the resident
@@ -597,7 +606,7 @@ void Engine::ensure_device() {
   if (const char* rm = getenv("WG_RUN_MIN")) dev.runMin = (uint32_t)std::max(0, atoi(rm));
   if (dev.runMin) {
     dev.maxRuns = dev.chainSlots;
-    dev.runs = dalloc<RunDesc>(dev.maxRuns, false);
+    dev.runs = dalloc<RunDesc>(dev.maxRuns, false, AC_SCRATCH);
   }
   dev.sharded = shardCount > 0 ? 1u : 0u;
   dev.shardLo = 0;
@@ -614,8 +623,8 @@ void Engine::ensure_device() {
     dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5 + XB_HEAD) + XB_HEAD;
     dev.maxMulti = std::max<uint32_t>(1024, maxOut / 16);
     dev.xmulti = dalloc<int32_t>((size_t)dev.maxMulti * XM_WORDS);
-    dev.multiK = dalloc<uint32_t>(maxOut, false);
-    dev.multiOff = dalloc<uint32_t>(maxOut, false);
+    dev.multiK = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
+    dev.multiOff = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
     dev.sdests = dalloc<int32_t>(chainDests, false);  // private scratch for unsorted destination lists
   }
   allocated = true;
@@ -1420,16 +1429,22 @@ void Engine::await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, ui
   }
   const uint32_t seq = ++mailSeq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, a, b, mailbox, seq);
+  // acquire on the sequence word: the counts the device wrote before it are read after it, whatever the compiler would
+  // like to hoist; the spin yields its pipeline slots (a host thread per shard polls two or three times per simulated ms)
   uint64_t spins = 0;
-  while (mailbox->seq != seq) {
-    if ((++spins & 0xFFFFF) == 0) {  // a failed launch would never publish: ask the runtime now and then
+  while (__atomic_load_n(&mailbox->seq, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 0xFFFF) == 0) {  // a failed launch would never publish: ask the runtime now and then
       const hipError_t q = hipStreamQuery(stream);
       if (q != hipSuccess && q != hipErrorNotReady) WG_HIP(q);
-      if (q == hipSuccess && mailbox->seq != seq) throw WgError(WG_EHIP, "the count mailbox was not written");
+      if (q == hipSuccess && __atomic_load_n(&mailbox->seq, __ATOMIC_ACQUIRE) != seq)
+        throw WgError(WG_EHIP, "the count mailbox was not written");
     }
   }
-  if (va) *va = mailbox->v[0];
-  if (vb) *vb = mailbox->v[1];
+  if (va) *va = __atomic_load_n(&mailbox->v[0], __ATOMIC_RELAXED);
+  if (vb) *vb = __atomic_load_n(&mailbox->v[1], __ATOMIC_RELAXED);
 }
 
 void Engine::shard_allreduce(void* buf, int64_t count) {
@@ -1774,32 +1789,73 @@ int32_t Engine::step_begin(int32_t until, int32_t condTime, wg_delivery* out, in
 void Engine::step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests) {
   if (!hcStepOpen) throw WgError(WG_ESTATE, "no step is open (wg_step_begin)");
   if (nops < 0 || (nops > 0 && !ops)) throw WgError(WG_EINVAL, "ops");
-  hcStepOpen = false;
-  int32_t k = 0;
-  for (size_t pi = 0; pi < hcPlan.size(); pi++) {
-    const StepPlan pl = hcPlan[pi];
-    if (pl.outIdx >= 0) {
+  // First pass: everything that can refuse an op is checked BEFORE anything is applied, and the step stays open when
+  // it does — the ms has been handed out already, so a half-applied step (earlier ops staged, the multi-destination
+  // envelopes' owed re-pushes dropped with the plan) could not be repaired by the caller. After a refusal the caller
+  // resubmits (corrected ops, or none: the deliveries' own pushes are then lost, the envelopes' re-pushes are not).
+  {
+    const int32_t N = (int32_t)hx.size();
+    int32_t k = 0;
+    for (size_t pi = 0; pi < hcPlan.size(); pi++) {
+      const StepPlan& pl = hcPlan[pi];
+      if (pl.outIdx < 0) continue;
       if (k < nops && ops[k].after < pl.outIdx) throw WgError(WG_EINVAL, "wg_step_end: ops must be ordered by `after`");
+      const bool last = pi + 1 == hcPlan.size();
       for (; k < nops && ops[k].after == pl.outIdx; k++) {
         const wg_step_op& op = ops[k];
-        // an envelope for the ms being handed out is the NEXT one delivered (LIFO, hc_push): exact only behind the step's last delivery
-        const bool last = pi + 1 == hcPlan.size();
+        switch (op.kind) {
+          case WG_OP_SEND: {
+            if (op.n < 0) throw WgError(WG_EINVAL, "wg_step_op.n");
+            if (op.n > 1 && !dests) throw WgError(WG_EINVAL, "dests");
+            if (op.n > 1 && op.to < 0) throw WgError(WG_EINVAL, "wg_step_op.to (offset into dests)");
+            if (op.from < 0 || op.from >= N) throw WgError(WG_EINVAL, "The from node is not in the network.");
+            const int32_t* dd = op.n == 1 ? &op.to : dests + op.to;
+            for (int i = 0; i < op.n; i++)
+              if (dd[i] < 0 || dd[i] >= N) throw WgError(WG_EINVAL, "The to node is not in the network.");
+            if (op.n > 0 && op.time <= time)
+              throw WgError(WG_ESTATE, "sendTime=" + std::to_string(op.time) + ", time=" + std::to_string(time));  // :471
+            break;
+          }
+          case WG_OP_SEND_ARRIVE_AT:
+            if (op.from < 0 || op.from >= N || op.to < 0 || op.to >= N) throw WgError(WG_EINVAL, "node id");
+            if (op.time <= time)
+              throw WgError(WG_EINVAL, "wrong arrival time: arriveAt=" + std::to_string(op.time) + ", time=" + std::to_string(time));
+            break;
+          case WG_OP_TASK:
+            if (op.from < 0 || op.from >= N) throw WgError(WG_EINVAL, "node id");
+            if (op.time < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(op.time));
+            // an envelope for the ms being handed out is the NEXT one delivered (LIFO, hc_push): exact only behind the step's last delivery
+            if (op.time == time && hcLoaded && !last)
+              throw WgError(WG_EUNSUPPORTED, "a task registered for the millisecond being delivered, from inside a batched step: "
+                                             "resubmit this step without it and deliver such a protocol with wg_next_delivery or cap = 1");
+            break;
+          default: throw WgError(WG_EINVAL, "wg_step_op.kind");
+        }
+      }
+    }
+    if (k != nops) throw WgError(WG_EINVAL, "wg_step_end: an op refers to a delivery the step did not hand out");
+    if (nops > 0 && !proto) throw WgError(WG_ESTATE, "load a protocol before sending (message sizes are protocol-defined)");
+  }
+  // Second pass: apply, in the reference's order (delivery i's pushes, then the re-push of i's envelope :629-632).
+  hcStepOpen = false;
+  const std::vector<StepPlan> plan = std::move(hcPlan);
+  hcPlan.clear();
+  int32_t k = 0;
+  for (size_t pi = 0; pi < plan.size(); pi++) {
+    const StepPlan pl = plan[pi];
+    if (pl.outIdx >= 0) {
+      for (; k < nops && ops[k].after == pl.outIdx; k++) {
+        const wg_step_op& op = ops[k];
         switch (op.kind) {
           case WG_OP_SEND: {
             const int32_t* dd = op.n == 1 ? &op.to : dests + op.to;
-            if (op.n > 1 && !dests) throw WgError(WG_EINVAL, "dests");
             gh.draws++;  // (the caller drew the seed from the rd it holds during the step)
             globalsDirty = true;
             send_seeded(op.msg, op.payload, op.time, op.from, dd, op.n, op.delay, op.seed);
             break;
           }
           case WG_OP_SEND_ARRIVE_AT: send_arrive_at(op.msg, op.payload, op.time, op.from, op.to); break;
-          case WG_OP_TASK:
-            if (op.time == time && hcLoaded && !last)
-              throw WgError(WG_EUNSUPPORTED, "a task registered for the millisecond being delivered, from inside a batched step: deliver this ms with wg_next_delivery or cap = 1");
-            register_task(op.msg, op.payload, op.time, op.from);
-            break;
-          default: throw WgError(WG_EINVAL, "wg_step_op.kind");
+          default: register_task(op.msg, op.payload, op.time, op.from);
         }
       }
     }
@@ -1809,8 +1865,6 @@ void Engine::step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests)
       hc_stage_continuation();
     }
   }
-  if (k != nops) throw WgError(WG_EINVAL, "wg_step_end: an op refers to a delivery the step did not hand out");
-  hcPlan.clear();
 }
 
 // ---- batches
@@ -2222,12 +2276,12 @@ struct HandelHost : ProtoHost {
     e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
     e.dev.boundTask[1] = L - 1;    // updateVerifiedSignatures: one fast-path send per higher level
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
-    st.runList = e.dalloc<uint32_t>(N);
+    st.runList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.runCount = e.dalloc<uint32_t>(1);
     st.candCnt = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
-    st.condOrd = e.dalloc<uint32_t>(N);
-    st.condList = e.dalloc<uint32_t>(N);
-    st.drawVal = e.dalloc<int32_t>(N);
+    st.condOrd = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
+    st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
+    st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
     WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
     if (peers16) {  // (narrowed on the host, a slice at a time)
       const size_t total = nLoc * (size_t)(N - 1), step = (size_t)1 << 26;
@@ -2904,6 +2958,9 @@ struct CasperHost : ProtoHost {
     st.forked = e.dalloc<uint32_t>(1);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
     if (p.randomOnTies) st.laneEvents = 1u;  // (k_casper_seq hands k_deliver an empty set through the mixed flags)
+    // sharded: the block / attestation table exchange and the two-blocks-in-one-ms check hang on k_casper_classify's
+    // anyTask flag, which only the lane-per-event path launches — the A/B switch does not apply to a sharded engine
+    if (e.shardCount > 0) st.laneEvents = 1u;
     e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)

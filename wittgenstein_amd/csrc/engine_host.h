@@ -131,7 +131,7 @@ class Engine {
   // per-phase counts the host needs to size the next collective, published by the device into pinned host memory
   // (k_publish) and awaited by polling — not a stream synchronisation plus a copy per count
   struct Mailbox {
-    volatile uint32_t seq;
+    uint32_t seq;   // written last by k_publish; the host reads it with acquire semantics (await_counts)
     uint32_t v[7];
   };
   Mailbox* mailbox = nullptr;             // pinned host memory (hipHostMalloc), device-visible

@@ -338,6 +338,7 @@ class HostNetwork:
                 return did
             self._rd_held = eng.rng_state()
             self._ops = []
+            failed = None
             try:
                 for i in range(n.value):
                     d = arr[i]
@@ -351,6 +352,8 @@ class HostNetwork:
                     if self.allNodes[d.to].isDown():  # stopped by an earlier action() of this very step (:606)
                         continue
                     self._deliver(d)
+            except BaseException as x:  # an action() raised: the step is still closed below, with the pushes made so far
+                failed = x
             finally:
                 ops, self._ops = self._ops, None
                 eng._ck(lib.wg_rng_set_state(h, C.c_uint64(self._rd_held)))
@@ -367,4 +370,14 @@ class HostNetwork:
                     o.to = len(dests)
                     dests.extend(ids)
             da = (C.c_int32 * max(1, len(dests)))(*dests)
-            eng._ck(lib.wg_step_end(h, oa, len(ops), da))
+            rc = lib.wg_step_end(h, oa, len(ops), da)
+            if rc != L.WG_OK:
+                # wg_step_end refuses a step as a whole and leaves it open (nothing applied): close it without the
+                # actions' pushes — the multi-destination envelopes' owed re-pushes are kept — and report the refusal
+                msg = lib.wg_last_error(h).decode()
+                lib.wg_step_end(h, oa, 0, da)
+                if failed is None:
+                    from .core import _raise
+                    _raise(rc, msg)
+            if failed is not None:
+                raise failed
