@@ -2,6 +2,7 @@
 // Fibers (hand-rolled x86-64 context switch), the wavefront/block scheduler, and the few HIP runtime
 // calls the engine's host code makes, as plain host memory operations.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <chrono>
 #include <mutex>
 #include <functional>
@@ -115,6 +116,24 @@ void block_barrier() {
 // every lane of wave [lo, hi) that waits in a wave collective gets its result; lanes at the same call
 // site form one group
 static void complete_wave(unsigned lo, unsigned hi) {
+  if (getenv("WG_EMU_TRACE_GROUPS")) {  // debugging aid: report a wavefront whose waiting lanes stand at different call sites
+    void* first = nullptr;
+    bool split = false;
+    for (unsigned i = lo; i < hi; i++) {
+      const Fiber& f = g_fibers[i];
+      if (f.state != ST_WAIT_WAVE) continue;
+      if (!first) first = f.site;
+      else if (f.site != first) split = true;
+    }
+    if (split) {
+      Dl_info di;
+      if (dladdr(first, &di)) fprintf(stderr, "emu: base %p ", di.dli_fbase);
+      fprintf(stderr, "emu: split collective:");
+      for (unsigned i = lo; i < hi; i++)
+        if (g_fibers[i].state == ST_WAIT_WAVE) fprintf(stderr, " %u:%p/%d", i - lo, g_fibers[i].site, g_fibers[i].op);
+      fprintf(stderr, "\n");
+    }
+  }
   for (unsigned i = lo; i < hi; i++) {
     Fiber& f = g_fibers[i];
     if (f.state != ST_WAIT_WAVE) continue;

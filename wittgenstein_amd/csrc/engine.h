@@ -156,6 +156,20 @@ struct alignas(16) MineDesc {
   uint32_t flags;  // VD_DOWN | partition id << 8
   uint32_t s0, s1, s2, s3, pad0, pad1;
 };
+// A node's inbox as ONE 64-byte line (EngineDev::inbox, protocols that ask for it: Engine::wantInbox): the first
+// INBOX_SLOTS events of the ms that go to the node, written by expand in whatever order the lanes arrive (the consumer
+// sorts the <= 4 by event index) — a node visit reads its events with one coalesced load instead of chasing
+// head[to] -> evNext[e] -> ev[e] through three dependent scattered reads per event (the reference applies a ms's
+// envelopes to `to` one after the other, C/Network.java:603-626: this is the per-destination grouping of that loop).
+// Events beyond the line's four go onto the node's overflow list (head / evNext, as for protocols without lines).
+constexpr int INBOX_SLOTS = 4;
+constexpr uint32_t INBOX_CHAIN = 1u << 31;  // InboxEntry::w0: the event is a hop of a multi-destination envelope (its EvAux matters)
+struct alignas(16) InboxEntry {
+  uint32_t e;    // event index in the global order of the ms
+  uint32_t w0;   // Rec::w0 (kind << 28 | from) | INBOX_CHAIN
+  uint32_t w2;   // Rec::w2: message word / task word
+  uint32_t w3;   // Rec::w3: payload ref / task argument / period
+};
 // per-event result written by deliver (8 bytes)
 struct EvRes {
   uint32_t nrec;      // records emitted | EV_DELIVERED / EV_TASK_RUN flags | level << 24
@@ -298,6 +312,8 @@ struct EngineDev {
   GP<uint32_t> evDrawOff;
   GP<int32_t> evNext;          // per-node inbox as a linked list through the events
   GP<int32_t> head;            // [n] newest event of the node this ms, -1 = none
+  GP<InboxEntry> inbox;        // [n][INBOX_SLOTS] the node's first events of this ms (NULL: lists only)
+  GP<uint32_t> icnt;           // [n] events of the node this ms (inbox lines only); reset by the delivery pass
   GP<uint32_t> active;         // nodes with >= 1 event (unordered)
   GP<VisitDesc> activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
   GP<MineDesc> activeM;        // the ones it does, when the kernel runs as k_msgs_classify + k_msgs_apply

@@ -569,6 +569,12 @@ void Engine::ensure_device() {
   dev.evNext = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
   dev.head = dalloc<int32_t>(n, false);
   WG_HIP(hipMemsetAsync(dev.head, 0xFF, sizeof(int32_t) * (size_t)n, stream));
+  dev.inbox = nullptr;
+  dev.icnt = nullptr;
+  if (wantInbox) {  // (per-ms scratch: empty between milliseconds — the delivery pass resets the counts it consumes)
+    dev.inbox = dalloc<InboxEntry>((size_t)n * INBOX_SLOTS, false, AC_SCRATCH);
+    dev.icnt = dalloc<uint32_t>(n, true);
+  }
   dev.active = dalloc<uint32_t>(n, true, AC_SCRATCH);
   dev.activeB = dalloc<VisitDesc>(n, true, AC_SCRATCH);
   dev.activeM = dalloc<MineDesc>(n, false, AC_SCRATCH);
@@ -2143,6 +2149,7 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
   *h_lv(s, node, HP_CLA, 0) = 1;
   *h_lv(s, node, HP_CVI, 0) = 1;
   *h_lv(s, node, HP_OUTFIN, 0) = 1;
+  h[HH_TOTAL] = 1;  // the sum of |totalIncoming| over the levels: the own signature
   h[HH_WINDOW] = (uint32_t)s.p.windowInitial;
   h[HH_ADDED] = (uint32_t)s.p.extraCycle;
   // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
@@ -2214,7 +2221,11 @@ struct HandelHost : ProtoHost {
     // completion; the periodic dissemination snapshots have computed addresses (HandelState::snap).
     if (e.cfg.payload_words == 0 && !e.allocated)
       e.cfg.payload_words = std::max<int64_t>(1 << 20, 2 * (int64_t)N * (W + L));
+    if (N > (1 << 19)) throw WgError(WG_EINVAL, "Handel resident: at most 2^19 nodes (the signer's id travels in the task word)");
+    if (e.allocated && !e.dev.inbox) throw WgError(WG_ESTATE, "load Handel before the first call that allocates the engine");
+    e.wantInbox = true;  // a node's events of the ms are read from its inbox line (k_handel_lane / k_handel_wave)
     e.ensure_device();
+    if (e.dev.maxOut >= (1u << 28)) throw WgError(WG_EINVAL, "outbox_records must be below 2^28 (an inbox entry carries a task's outbox slot in 28 bits)");
     if (p.disseminationPeriodMs >= e.dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms <= dissemination period");
     st.p = p;
     st.N = N;
@@ -2276,10 +2287,11 @@ struct HandelHost : ProtoHost {
     e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
     e.dev.boundTask[1] = L - 1;    // updateVerifiedSignatures: one fast-path send per higher level
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;
-    st.runList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
-    st.runCount = e.dalloc<uint32_t>(1);
-    st.candCnt = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
-    st.condOrd = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
+    // the conditional-task phase's scratch: (node, level) items of the edge, candidate levels per node, the draws
+    st.itemsLane = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
+    st.itemsWave = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
+    st.itemCount = e.dalloc<uint32_t>(2);
+    st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
     WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
@@ -2364,18 +2376,25 @@ struct HandelHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
+  template <int W>
+  void launch_a1(const Group& g, const HandelState* stab, int R) {
+    hipLaunchKernelGGL(k_handel_a1<W>, dim3(node_grid(R), R), dim3(256), 0, g.stream, g.tab, stab);
+  }
+  void launch_a1(const Group& g, const HandelState* stab, int R) {
+    switch (wavesCond) {
+      case 8: launch_a1<8>(g, stab, R); break;
+      case 6: launch_a1<6>(g, stab, R); break;
+      case 5: launch_a1<5>(g, stab, R); break;
+      case 3: launch_a1<3>(g, stab, R); break;
+      default: launch_a1<4>(g, stab, R);
+    }
+  }
   void launch_cond(Engine& profOwner, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      switch (wavesCond) {
-        case 8: hipLaunchKernelGGL(k_handel_cond_a1<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 6: hipLaunchKernelGGL(k_handel_cond_a1<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 5: hipLaunchKernelGGL(k_handel_cond_a1<5>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        case 3: hipLaunchKernelGGL(k_handel_cond_a1<3>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-        default: hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
-      }
+      launch_a1(g, stab, g.R);
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
@@ -2400,82 +2419,37 @@ struct HandelHost : ProtoHost {
   uint32_t shard_cond(Engine& e, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_handel_cond_a1<4>, dim3(node_grid(1), 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.candCnt, ((int64_t)st.N + 3) / 4);
+    launch_a1(g, stab, 1);
+    e.shard_allreduce(st.candMask, (int64_t)st.N);  // (a node's candidate levels: its owner's bits, zeros elsewhere)
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
     e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
     hipLaunchKernelGGL(k_handel_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    WG_HIP(hipMemsetAsync(st.candCnt, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' counts
+    WG_HIP(hipMemsetAsync(st.candMask, 0, 4 * (size_t)st.N, g.stream));  // the other shards' masks
     return nOut;
   }
-  // WG_LANE_MSGS=0 keeps every node visit on the wave-per-node kernel (A/B switch for profiles)
-  int laneMsgs = getenv("WG_LANE_MSGS") ? atoi(getenv("WG_LANE_MSGS")) : 1;
-  int pipeDeliver = getenv("WG_DELIVER_PIPE") ? atoi(getenv("WG_DELIVER_PIPE")) : 1;
-  // blocks per engine of the wave-per-node kernels. The pipelined loops want SEVERAL visits per wavefront (the next
-  // visit's header is fetched during the current one), so their grid is about twice the chip's resident waves over the
+  // blocks per engine of the wave-per-item kernels. Their pipelined loops want SEVERAL items per wavefront (the next
+  // item's header is fetched during the current one), so the grid is about twice the chip's resident waves over the
   // whole batch (the factor lets the blocks of members whose run has ended — they return at once — leave their share to the
   // others); WG_NODE_GRID=<blocks per engine> overrides
   int nodeGridEnv = getenv("WG_NODE_GRID") ? atoi(getenv("WG_NODE_GRID")) : 0;
   int node_grid(int R) const {
     if (nodeGridEnv > 0) return nodeGridEnv;
-    if (!pipeDeliver) return grid_node_waves(R);
     int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
     return b < 16 ? 16 : b;
   }
-  // WG_MSGS_SPLIT=1: the lane-per-node message kernel in two halves — k_msgs_classify walks the inbox lists and hands the
-  // mixed nodes to k_deliver (activeB) and the message-only ones to k_msgs_apply (activeM), which then runs on a second
-  // stream BESIDE k_deliver (disjoint nodes, no emissions, no draws). Measured (profiles/r05j_*): side by side both halves
-  // slow down by what the other takes from the chip (k_deliver 211 -> 272 us, the message half 83 -> 202 us per ms), the
-  // pass is no shorter and the step 6 % longer (309.9 vs 329.0 M msgs/s) — so the fused k_deliver_msgs on the engine's own
-  // stream is the default. Not under stream capture (WG_GRAPH).
-  int msgsSplit = getenv("WG_MSGS_SPLIT") ? atoi(getenv("WG_MSGS_SPLIT")) : 0;
-  bool graphMode = getenv("WG_GRAPH") && atoi(getenv("WG_GRAPH")) != 0;
-  hipStream_t auxStream = nullptr;
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
-  ~HandelHost() override {
-    if (evFork) (void)hipEventDestroy(evFork);
-    if (evJoin) (void)hipEventDestroy(evJoin);
-    if (auxStream) (void)hipStreamDestroy(auxStream);
-  }
+  // the delivery pass: k_handel_lane (one lane per node: SendSigs deliveries, narrow updateVerifiedSignatures; sorts the
+  // other nodes into the next kernel's list), then k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    const int useB = laneMsgs ? 1 : 0;
-    const bool split = useB && msgsSplit && !graphMode;
-    if (split) {
-      if (!auxStream) {
-        WG_HIP(hipStreamCreate(&auxStream));
-        WG_HIP(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
-        WG_HIP(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
-      }
-      hipLaunchKernelGGL((k_msgs_classify<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      WG_HIP(hipEventRecord(evFork, g.stream));
-      WG_HIP(hipStreamWaitEvent(auxStream, evFork, 0));
-      hipLaunchKernelGGL((k_msgs_apply<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, auxStream, g.tab, stab);
-      WG_HIP(hipEventRecord(evJoin, auxStream));
-    } else if (useB)
-      hipLaunchKernelGGL((k_deliver_msgs<HandelProto>), dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
-    struct Join {  // the pass ends when both halves have: whatever is enqueued next on the engine's stream waits for k_msgs_apply
-      hipStream_t s;
-      hipEvent_t e;
-      ~Join() {
-        if (e) (void)hipStreamWaitEvent(s, e, 0);
-      }
-    } join{g.stream, split ? evJoin : nullptr};
-    // WG_DELIVER_PIPE=0: the plain loop (one dependent chain of round trips per visit) instead of the pipelined one
+    hipLaunchKernelGGL(k_handel_lane, dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
     const dim3 grid(node_grid(g.R), g.R);
-    if (useB && pipeDeliver) {
-      switch (wavesDeliver) {
-        case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
-        case 3: hipLaunchKernelGGL((k_deliver<HandelProto, 3, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
-        default: hipLaunchKernelGGL((k_deliver<HandelProto, 4, true>), grid, dim3(256), 0, g.stream, g.tab, stab, useB);
-      }
-      return;
-    }
     switch (wavesDeliver) {
-      case 5: hipLaunchKernelGGL((k_deliver<HandelProto, 5>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      case 3: hipLaunchKernelGGL((k_deliver<HandelProto, 3>), grid, dim3(256), 0, g.stream, g.tab, stab, useB); break;
-      default: hipLaunchKernelGGL((k_deliver<HandelProto, 4>), grid, dim3(256), 0, g.stream, g.tab, stab, useB);
+      case 8: hipLaunchKernelGGL(k_handel_wave<8>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 6: hipLaunchKernelGGL(k_handel_wave<6>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 5: hipLaunchKernelGGL(k_handel_wave<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 3: hipLaunchKernelGGL(k_handel_wave<3>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      default: hipLaunchKernelGGL(k_handel_wave<4>, grid, dim3(256), 0, g.stream, g.tab, stab);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {

@@ -430,10 +430,26 @@ struct ExpandF {
   // threads the few that fall to a node k_deliver visits after all (a node with another kind of event in the same ms).
   __device__ bool lane_only(uint32_t msgWord) const { return d.laneMsgPlus1 != 0 && msgWord + 1u == d.laneMsgPlus1; }
   // thread the event onto its node's inbox list; returns true if it is the node's first event
-  __device__ bool link(uint32_t e, int32_t to) const {
+  __device__ bool link(uint32_t e, int32_t to, const Rec& r, bool chainHop, uint32_t ob) const {
     if (d.sharded) {  // the event list is replicated on every shard; a shard applies the events of its own nodes
       d.evRes[e] = EvRes{0u, 0u};  // ... and reports zeros for the others (summed across shards before `order`)
       if (!shard_owns(d, to)) return false;
+    }
+    if (d.inbox) {  // the node's inbox line: the event itself lands in the node's 64 bytes, no list to chase at delivery
+      const uint32_t k = atomicAdd(&d.icnt[to], 1u);
+      if (k < (uint32_t)INBOX_SLOTS) {
+        // (a task's `from` is the node itself: its w0 carries the event's first outbox slot instead, so that a visit
+        // needs no EvAux read for it; a message's action() gets its slice from EvAux only when boundMsg > 0 or it is a hop)
+        InboxEntry ie;
+        ie.e = e;
+        ie.w0 = rec_kind(r) == K_MSG ? (r.w0 | (chainHop ? INBOX_CHAIN : 0u)) : ((r.w0 & 0xF0000000u) | ob);
+        ie.w2 = r.w2;
+        ie.w3 = r.w3;
+        gst(d.inbox + ((size_t)to * INBOX_SLOTS + k), ie);
+      } else {  // beyond the line: the overflow list
+        d.evNext[e] = atomicExch(&d.head[to], (int32_t)e);
+      }
+      return k == 0;
     }
     int32_t prev = atomicExch(&d.head[to], (int32_t)e);
     d.evNext[e] = prev;
@@ -455,7 +471,7 @@ struct ExpandF {
           a.outBase = ob;
           a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
           d.evAux[e] = a;
-          if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1);
+          if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1, r, false, ob);
           firstNode = (int32_t)r.w1;
         }
       } else {
@@ -479,7 +495,8 @@ struct ExpandF {
         for (uint32_t q = 0; q < len; q++, e++) {
           if (e >= d.maxEvents) break;
           const int32_t to = chain_dest(d, c, (int)r.w2 + (int)q);
-          d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+          const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+          d.ev[e] = hop;
           const bool last = q + 1 == len;
           EvAux a;
           a.chain = (int32_t)r.w1;
@@ -487,7 +504,7 @@ struct ExpandF {
           a.outBase = ob + q * d.boundMsg;
           a.outCap = d.boundMsg + (last ? 1u : 0u);
           d.evAux[e] = a;
-          if (!d.hostMode && !lane_only(c.msg) && link(e, to)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+          if (!d.hostMode && !lane_only(c.msg) && link(e, to, hop, true, ob + q * d.boundMsg)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
         }
         // sharded: the envelope's slot is released by every shard (deliver_event's release runs on one shard only)
         if (d.sharded && (int)(r.w2 + len) >= c.ndest) d.chains[r.w1].flags = 0;
@@ -524,7 +541,8 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
       int32_t to = 0;
       if (q < rd.len && e < d.maxEvents) {
         to = chain_dest(d, c, (int)(rd.pos + q));
-        d.ev[e] = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+        const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+        d.ev[e] = hop;
         const bool last = q + 1 == rd.len;
         EvAux a;
         a.chain = (int32_t)rd.chain;
@@ -532,7 +550,7 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         a.outBase = rd.ob + q * d.boundMsg;
         a.outCap = d.boundMsg + (last ? 1u : 0u);
         d.evAux[e] = a;
-        if (!d.hostMode && !f.lane_only(c.msg)) first = f.link(e, to);
+        if (!d.hostMode && !f.lane_only(c.msg)) first = f.link(e, to, hop, true, rd.ob + q * d.boundMsg);
       }
       const uint64_t m = __ballot(first);
       if (m) {
@@ -1781,6 +1799,88 @@ __device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename
   }
   __builtin_amdgcn_wave_barrier();
   KPROF_MARK(d.g, 3);  // node_end + counters
+}
+
+// ... the same visit for a protocol whose nodes keep their events in inbox lines (EngineDev::inbox): lane k < INBOX_SLOTS
+// of the wavefront holds entry k of the node's line (`mine`; beyond `cnt` it is not looked at), the events beyond the
+// line hang on the node's overflow list. The usual node has 1..4 events: they are ranked by event index among the four
+// lanes and handed to deliver_event straight from the registers — no event record, no EvAux (a task's outbox slice is
+// in its entry) and no list is read from memory. `skip`: the node's first events (in event order) that another kernel
+// has applied already (a lane-per-node kernel that handed the rest of the visit over).
+template <class P>
+__device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const typename P::State& ps, Ctx& c,
+                                                    typename P::NodeRegs& r, int32_t node, uint32_t cnt, uint32_t vflags,
+                                                    const InboxEntry& mine, uint32_t skip) {
+  const int lane = WG_LANE;
+  const bool toDown = (vflags & VD_DOWN) != 0;
+  const uint8_t toPart = (uint8_t)(vflags >> 8);
+  long long nRecv = 0, bRecv = 0;
+  if (cnt <= (uint32_t)INBOX_SLOTS) {
+    const uint32_t myE = (uint32_t)lane < cnt ? mine.e : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int j = 0; j < INBOX_SLOTS; j++) rank += lane_bcast(myE, j) < myE;
+    for (uint32_t k = skip; k < cnt; k++) {
+      const int src = __ffsll((unsigned long long)__ballot((uint32_t)lane < cnt && rank == k)) - 1;
+      const uint32_t e = lane_bcast(mine.e, src), w0 = lane_bcast(mine.w0, src);
+      const uint32_t w2 = lane_bcast(mine.w2, src), w3 = lane_bcast(mine.w3, src);
+      const uint32_t kind = (w0 >> 28) & 3u;
+      Rec rec;
+      EvAux aux;
+      aux.chain = -1;
+      aux.cpos = 0;
+      if (kind == K_MSG) {
+        rec = make_rec(K_MSG, (int32_t)(w0 & 0x0FFFFFFFu), (uint32_t)node, w2, w3);
+        aux.outBase = 0;
+        aux.outCap = 0;
+        if ((w0 & INBOX_CHAIN) || d.boundMsg) aux = gld(d.evAux + e);
+      } else {
+        rec = make_rec(kind, node, (uint32_t)node, w2, w3);
+        aux.outBase = w0 & 0x0FFFFFFFu;
+        aux.outCap = d.boundTask[w2 < 3u ? w2 : 3u] + (kind == K_PERIODIC ? 1u : 0u);
+      }
+      deliver_event<P>(d, ps, c, r, e, rec, aux, toDown, toPart, k + 1 < cnt, nRecv, bRecv);
+    }
+  } else {
+    // more events than the line holds: the line's four and the overflow list, in event order — by repeated minimum
+    // search (the list is unordered; such nodes are rare: a PingPong-style origin), records from the event arrays
+    const uint32_t l0 = lane_bcast(mine.e, 0), l1 = lane_bcast(mine.e, 1), l2 = lane_bcast(mine.e, 2), l3 = lane_bcast(mine.e, 3);
+    const int32_t listHead = d.head[node];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) d.head[node] = -1;
+    bool have = false;
+    uint32_t last = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+      uint32_t best = 0xFFFFFFFFu;
+      auto consider = [&](uint32_t q) {
+        if ((!have || q > last) && q < best) best = q;
+      };
+      consider(l0);
+      consider(l1);
+      consider(l2);
+      consider(l3);
+      for (int32_t q = listHead; q >= 0; q = d.evNext[q]) consider((uint32_t)q);
+      if (best == 0xFFFFFFFFu) break;
+      last = best;
+      have = true;
+      const Rec rec = d.ev[best];
+      const EvAux aux = d.evAux[best];
+      deliver_event<P>(d, ps, c, r, best, rec, aux, toDown, toPart, true, nRecv, bRecv);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  P::node_end(c, ps, r);
+  if (lane == 0) {
+    if (nRecv) {
+      atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+    }
+    if (c.msgSent) {
+      atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+      atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 // WPE: waves per SIMD the register allocation must admit; PIPE: the software-pipelined loop (needs useB and P::prefetch)

@@ -1,18 +1,29 @@
-// Handel (P/Handel.java) as a resident device protocol. One wavefront per simulated node: scalars
-// are wave-uniform, lane k owns the 64-bit words w with (w & 63) == k of every bitset row of the
-// node, so bitset algebra (or/and/cardinality/intersects) is a coalesced pass + a wave reduction.
+// Handel (P/Handel.java) as a resident device protocol.
 //
-// State layout (struct-of-arrays, HBM):
+// State layout (HBM):
 //   bit rows  TI,LA,VI,TV,FP : [N][W] uint64, W = N/64. Bit j = node id j. HLevel l's bitsets
 //             (totalIncoming, lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers
 //             :373-394) only ever hold ids of the level's aligned sibling block of 2^(l-1) ids
 //             (allSigsAtLevel :671-684), and the blocks of different levels are disjoint, so one row
 //             per kind holds all levels. totalOutgoing of level l is always the union of
 //             totalIncoming of levels < l (:728-731) = the node's OWN aligned block in the TI row.
-//   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] int32 emission lists (:510-522)
+//   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] emission lists (:510-522)
 //   queues    toVerifyAgg (:385): per (node, level) up to Q slots {from, rank, sig[2^(l-1) bits]} in a
 //             private slab + an order list; a slot stays allocated while a registered
 //             updateVerifiedSignatures task still references it (:833-836).
+//
+// Who runs what (a node visit is a chain of dependent memory round trips — the kernels' throughput is
+// the number of visits IN FLIGHT over the length of that chain, so the work is cut by how many lanes a visit can use):
+//   k_handel_lane   one LANE per node: the nodes whose events of the ms (<= 4, read from the node's inbox line) are
+//                   SendSigs messages (onNewSig :757-790; payloads wider than one word are copied afterwards by the whole
+//                   wavefront) and at most one updateVerifiedSignatures task (:690-754) of a level whose block is <= 4
+//                   words — 64 visits in flight per wavefront. It also sorts every other node into the next kernel's list.
+//   k_handel_wave   one WAVEFRONT per node, lanes = 64-bit words of the level block: dissemination (:331-343), the
+//                   wide levels' updateVerifiedSignatures, nodes with a chain hop or more than four events — and the
+//                   fast-path sends (:738-749) the lane kernel deferred (remaining_peers is a wave-parallel scan).
+//   checkSigs (:796-837) runs per (node, LEVEL) item — bestToVerify of one level is independent of the other levels:
+//   k_handel_cond_pre lists the items, k_handel_a1 curates a level's list and records its candidate (one lane per item
+//   for blocks <= 4 words, one wavefront per item beyond), the scan + k_handel_cond_a2 draw among a node's candidates.
 // Honest-node paths only: byzantineSuicide / hiddenByzantine (:538-559, :840-917) are not resident.
 #pragma once
 #include "engine_kernels.hip.h"
@@ -22,6 +33,18 @@ namespace wg {
 constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks per node
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
+constexpr int H_LANE_NW = 4;       // level blocks of up to this many 64-bit words are worked on by ONE lane (levels <= 9)
+
+// The argument word of an updateVerifiedSignatures task (Rec::w3): everything the task needs to issue its loads —
+// the pending-table entry it owns, the level, the queue slot and the signer (SigToVerify.from) — so that the visit does
+// not wait for the node's header before it can address the level's rows. N <= 2^19.
+__device__ __forceinline__ uint32_t h_update_arg(int pk, int lv, int slot, int32_t from) {
+  return (uint32_t)pk | ((uint32_t)lv << 2) | ((uint32_t)slot << 7) | ((uint32_t)from << 13);
+}
+#define H_ARG_PK(a) ((int)((a) & 3u))
+#define H_ARG_LV(a) ((int)(((a) >> 2) & 31u))
+#define H_ARG_SLOT(a) ((int)(((a) >> 7) & 63u))
+#define H_ARG_FROM(a) ((int32_t)((a) >> 13))
 
 struct HandelState {
   wg_handel_params p;
@@ -37,25 +60,22 @@ struct HandelState {
   // 2 KB, so a flat capacity spent gigabytes on slots that are never used
   int32_t Qw;
   // Node header: every scalar of a node and its per-level scalars in ONE record of hdrStride 32-bit words
-  // (array of structs). A node visit is one wavefront touching one node, so the record is read and written
-  // back as a few consecutive cache lines of one page, instead of twenty 64-byte lines in twenty arrays:
-  //   [HH_ADDED .. HH_CTEPOCH]  addedCycle, sigQueueSize, msgFiltered, startAt, nodePairingTime, currWindowSize,
-  //                              sigsChecked, ConditionalTask.minStartTime, the epoch it last left nextMessage()'s copy
+  // (array of structs). A wave-per-node visit reads it as one 16-byte-per-lane instruction; a lane-per-node visit
+  // reads the two or three 16-byte pieces it needs:
+  //   [HH_ADDED .. HH_SIGCHK]    addedCycle, sigQueueSize, msgFiltered, startAt, nodePairingTime, currWindowSize, sigsChecked
+  //   [HH_TOTAL]                 sum over the levels of |totalIncoming| (what `cur.cardinality()` of :745 is after the loop)
   //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
-  //   [HH_CAND +12]              checkSigs' candidates of this edge, in level order: 16 bits each, level << 8 | slot (written by
-  //                              k_handel_cond_a1 with the rest of the record, read by k_handel_cond_a2 in the same phase)
+  //   [HH_CAND +12]              checkSigs' candidate of this edge per level, one BYTE a level: its queue slot (valid where
+  //                              candMask[node] has the level's bit; written by k_handel_a1, read by k_handel_cond_a2)
   //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
   //   [HH_LV + l*8 + plane]      level-major: the eight scalars of HLevel l side by side (32 bytes, two levels a 64-byte
   //                              line) — posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
   //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L levels.
-  //                              An event works on ONE level: the record goes back as the few 16-byte pieces that
-  //                              changed (store_levels), i.e. the scalars' line and the level's, not all ten lines
   GP<uint32_t> hdr;
   int32_t LS, lsShift, hdrStride;
   // ConditionalTask.minStartTime and the epoch in which the task last left nextMessage()'s copy, two words a node, dense:
-  // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a 64-byte line of the record
-  // per node; only the nodes whose task is due touch their record (HH_CTMIN / HH_CTEPOCH of the record are unused)
+  // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a line of the record
   GP<uint32_t> ct;
   GP<uint64_t> qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
   GP<int32_t> qfrom;                      // [N][L][Q]
@@ -67,11 +87,10 @@ struct HandelState {
   //   the lower levels' blocks are sub-ranges of it (see dissemination)
   GP<uint64_t> snap;
   uint32_t snapNb, snapStride;
-  // conditional-task phase scratch
-  GP<uint32_t> runList;                   // [N] nodes whose checkSigs runs at this edge (unordered)
-  GP<uint32_t> runCount;                  // [1]
-  GP<uint8_t> candCnt;                    // [N] number of levels with a candidate
-  GP<uint32_t> condOrd;                   // [N] ordinal among drawing nodes
+  // conditional-task phase scratch: the (node, level) items of this edge — node | level << 24 — by the lanes an item uses
+  GP<uint32_t> itemsLane, itemsWave;      // [N * L] each
+  GP<uint32_t> itemCount;                 // [2] lane items, wave items (reset by k_handel_cond_a2)
+  GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
   // node-range sharding (wg_shard_configure): this engine holds the per-node rows above only for the nodes
@@ -85,7 +104,7 @@ struct HandelState {
 };
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
-                       HH_CTMIN = 7, HH_CTEPOCH = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
+                       HH_TOTAL = 7, HH_SPARE = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
                        HH_PENDFROM = 16, HH_CAND = 20, HH_LV = 32 };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
@@ -172,6 +191,10 @@ __device__ __forceinline__ const uint64_t WG_G* h_payload(const EngineDev& d, co
   if (payload & H_REF_RING) return payload == H_REF_ONES ? s.ones : d.payload + (payload & ~H_REF_RING);
   return s.snap + payload;
 }
+__device__ __forceinline__ uint64_t WG_G* h_sig_ptr(const HandelState& s, int32_t node, int l, int slot) {
+  return s.qsig + s.qsigOff[l] + ((size_t)node * h_qcap(s, l) + slot) * (size_t)h_nw(l);
+}
+__device__ __forceinline__ uint32_t h_pend_word(int l, int slot) { return 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot; }
 
 struct HandelProto {
   typedef HandelState State;
@@ -187,11 +210,7 @@ struct HandelProto {
   __device__ static int msg_size(const State&, uint32_t msg) { return h_msg_size((int)(msg & 31u)); }
   __device__ static int msg_level(uint32_t msg) { return (int)(msg & 31u); }
 
-  __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, LevelScalars* ls) {
-    load_levels(s, c.node, ls);  // the whole header, one memory instruction
-    regs_from_image(r, ls);
-  }
-  // the header fetched ahead of the visit (k_deliver's pipelined loop): 16 bytes a lane, two rounds when L > 16
+  // the header fetched ahead of the visit (the pipelined loop of k_handel_wave): 16 bytes a lane, two rounds when L > 16
   struct Pre {
     U4 q0;
   };
@@ -246,7 +265,7 @@ struct HandelProto {
     __builtin_amdgcn_wave_barrier();  // the previous visit's store_levels has read the image
     if ((int)WG_LANE < n4) scatter_levels(s, ls, (int)WG_LANE, p.q0);
     if ((int)WG_LANE + 64 < n4)  // (L > 16: the record's tail is fetched here, not ahead)
-      scatter_levels(s, ls, (int)WG_LANE + 64, ((const U4*)h_hdr(s, c.node))[(int)WG_LANE + 64]);
+      scatter_levels(s, ls, (int)WG_LANE + 64, ((const U4 WG_G*)h_hdr(s, c.node))[(int)WG_LANE + 64]);
     __builtin_amdgcn_wave_barrier();
     regs_from_image(r, ls);
   }
@@ -293,15 +312,8 @@ struct HandelProto {
     }
   }
 
-  // header <-> LDS image, 16 bytes a lane: 640 bytes (L <= 16) are one memory instruction
-  __device__ static void load_levels(const State& s, int32_t node, LevelScalars* ls) {
-    const U4 WG_G* g = (const U4 WG_G*)h_hdr(s, node);
-    __builtin_amdgcn_wave_barrier();
-    for (int i = WG_LANE; i < (s.hdrStride >> 2); i += 64) scatter_levels(s, ls, i, g[i]);
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ... and back: only the 16-byte pieces that differ from what was loaded (an event changes the scalars' line and
-  // its level's: the other lines of the record stay clean in L2 and are never written back to HBM)
+  // the header back to memory: only the 16-byte pieces that differ from what was loaded (an event changes the scalars'
+  // line and its level's: the other lines of the record stay clean in L2 and are never written back to HBM)
   __device__ static void store_levels(const State& s, int32_t node, const LevelScalars* ls) {
     __builtin_amdgcn_wave_barrier();
     U4 WG_G* g = (U4 WG_G*)h_hdr(s, node);
@@ -311,92 +323,12 @@ struct HandelProto {
     }
   }
 
-  // ---- lane-per-node form of onNewSig for k_deliver_msgs: the same statements as on_new_sig below, one
-  // lane per receiving node; payloads wider than one word are handed back as a copy job --------------------
-  struct LaneNode {
-    long long doneAt;
-    int32_t startAt, sigQueueSize, msgFiltered;
-    int32_t sigQueueSize0, msgFiltered0;
-    uint32_t qmask, qmask0;
-  };
-  __device__ static void lane_begin(const EngineDev& d, const State& s, int32_t node, LaneNode& r) {
-    const uint32_t WG_G* h = h_hdr(s, node);
-    r.doneAt = (long long)((unsigned long long)h[HH_DONE_LO] | ((unsigned long long)h[HH_DONE_HI] << 32));
-    r.startAt = (int32_t)h[HH_START];
-    r.sigQueueSize = r.sigQueueSize0 = (int32_t)h[HH_SIGQ];
-    r.msgFiltered = r.msgFiltered0 = (int32_t)h[HH_FILT];
-    r.qmask = r.qmask0 = h[HH_QMASK];
-  }
-  __device__ static void lane_end(const EngineDev&, const State& s, int32_t node, const LaneNode& r) {
-    if (r.sigQueueSize != r.sigQueueSize0) h_hdr(s, node)[HH_SIGQ] = (uint32_t)r.sigQueueSize;
-    if (r.msgFiltered != r.msgFiltered0) h_hdr(s, node)[HH_FILT] = (uint32_t)r.msgFiltered;
-    if (r.qmask != r.qmask0) h_hdr(s, node)[HH_QMASK] = r.qmask;
-  }
-  __device__ static void lane_message(const EngineDev& d, const State& s, int32_t t, int32_t node, LaneNode& r,
-                                      int32_t from, uint32_t msg, uint32_t payload, CopyJob& job) {
-    const int l = (int)(msg & 31u);
-    const bool levelFinished = (msg >> 5) & 1u;
-    if (r.doneAt > 0) {  // :758-761
-      r.msgFiltered++;
-      return;
-    }
-    if (t < r.startAt) return;
-    const int w = from >> 6;
-    const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
-    const uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
-    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
-    const size_t nl = (size_t)node * s.L + l;
-    // every load of the event before the first use
-    const uint64_t viv = *vip;
-    const uint64_t fpv = levelFinished ? *fpp : 0ULL;
-    const uint64_t tvv = *tvp;
-    const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
-    uint32_t WG_G* qlo = h_lv(s, node, HP_QUSED_LO, l);
-    uint32_t WG_G* qhi = h_lv(s, node, HP_QUSED_HI, l);
-    uint32_t WG_G* qln = h_lv(s, node, HP_QLEN, l);
-    const unsigned long long used = (unsigned long long)*qlo | ((unsigned long long)*qhi << 32);
-    const int len = (int)*qln;
-    const uint64_t WG_G* src = h_payload(d, s, payload);
-    const int nw = h_nw(l);
-    const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
-    if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
-    if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
-    r.sigQueueSize++;
-    const int qc = h_qcap(s, l);
-    const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
-    const unsigned long long freeM = ~used & capMask;
-    if (freeM == 0 || len >= 64) {
-      set_err(d.g, ERR_QUEUE_CAP);
-      return;
-    }
-    const int slot = __ffsll(freeM) - 1;
-    uint64_t WG_G* dst = sig_ptr(s, node, l, slot);
-    s.qfrom[nl * s.Q + slot] = from;
-    s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
-    if (slot < 32)
-      *qlo = (uint32_t)used | (1u << slot);
-    else
-      *qhi = (uint32_t)(used >> 32) | (1u << (slot - 32));
-    *qln = (uint32_t)(len + 1);
-    r.qmask |= 1u << l;
-    if (nw == 1) {
-      dst[0] = pw0;
-    } else {
-      job.src = src;
-      job.dst = dst;
-      job.nw = nw;
-    }
-  }
-
   // ---- queue helpers ---------------------------------------------------------------------------
-  __device__ static uint64_t WG_G* sig_ptr(const State& s, int32_t node, int l, int slot) {
-    return s.qsig + s.qsigOff[l] + ((size_t)node * h_qcap(s, l) + slot) * (size_t)h_nw(l);
-  }
+  __device__ static uint64_t WG_G* sig_ptr(const State& s, int32_t node, int l, int slot) { return h_sig_ptr(s, node, l, slot); }
   __device__ static bool slot_pending(const NodeRegs& r, int l, int slot) {
     bool p = false;
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) p |= (r.ls->sc[HH_PEND + k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot));
+    for (int k = 0; k < H_PEND; k++) p |= (r.ls->sc[HH_PEND + k] == h_pend_word(l, slot));
     return p;
   }
   // ---- getRemainingPeers (:486-508), wave-parallel but sequentially equivalent ------------------
@@ -467,7 +399,7 @@ struct HandelProto {
     return ref | H_REF_RING;
   }
 
-  // ---- Message.action: SendSigs -> onNewSig (:757-790) -------------------------------------------
+  // ---- Message.action: SendSigs -> onNewSig (:757-790), one wavefront per node ------------------------------
   __device__ static void on_new_sig(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
     const int l = (int)(msg & 31u);
     const bool levelFinished = (msg >> 5) & 1u;
@@ -626,21 +558,44 @@ struct HandelProto {
     KPROF_MARK(c.d.g, 10);  // sends
   }
 
-  // ---- Task: updateVerifiedSignatures (:690-754) --------------------------------------------------
+  // the fast path of updateVerifiedSignatures (:738-749) for the levels above `lv` that just got a complete
+  // totalOutgoing: getRemainingPeers(fastPath) + one multi-destination send each. Run right after the update by the
+  // wave-per-node visit, or later in the same pass for an update a lane applied (k_handel_lane defers it: the scan of the
+  // emission list is wave-parallel work) — nothing between the two moments touches what it reads (the node's other
+  // events of the ms are SendSigs deliveries: they change neither |totalIncoming| nor posInLevel / outgoingFinished).
+  __device__ static void fast_path(Ctx& c, const State& s, LevelScalars* ls, int lv) {
+    const int lane = WG_LANE;
+    // totalOutgoing(l) = the sum of |totalIncoming| below l (:728-731): lane l takes level l, one prefix scan over the lanes
+    const int myCTI = lane < s.L ? ls->cTI[lane] : 0;
+    const int incl = (int)wave_incl_scan32((uint32_t)myCTI);
+    const bool fp = s.p.fastPath > 0 && lane > lv && lane < s.L && !ls->outFin[lane] && incl - myCTI == (1 << (lane - 1));
+    for (uint64_t fpM = __ballot(fp); fpM; fpM &= fpM - 1) {
+      const int l = __ffsll((unsigned long long)fpM) - 1;
+      __threadfence_block();  // the snapshot below reads the totalIncoming words stored above
+      uint32_t destOff = c.dest_reserve(s.p.fastPath);
+      int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
+      if (n > 0) {
+        uint32_t ref = snapshot_outgoing(c, s, l);
+        bool lf = ls->cTI[l] == (1 << (l - 1));
+        __threadfence_block();
+        c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
+      }
+    }
+  }
+
+  // ---- Task: updateVerifiedSignatures (:690-754), one wavefront per node ----------------------------------
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int32_t node = c.node;
     const int lane = WG_LANE;
-    // (the task's record is read from the node's LDS image, indexed at run time there: a register array indexed at run
-    // time would put the whole NodeRegs in scratch memory — every access to any of its fields a memory round trip)
     LevelScalars* ls = r.ls;
-    const int pk = (int)(arg & (H_PEND - 1));
+    const int pk = H_ARG_PK(arg), lv = H_ARG_LV(arg), slot = H_ARG_SLOT(arg);
+    const int32_t from = H_ARG_FROM(arg);
     const uint32_t pe = WG_READFIRST(ls->sc[HH_PEND + pk]);
-    const int32_t from = (int32_t)WG_READFIRST(ls->sc[HH_PENDFROM + pk]);
-    if (!(pe & 0x80000000u)) {
+    if (pe != h_pend_word(lv, slot) || (int32_t)WG_READFIRST(ls->sc[HH_PENDFROM + pk]) != from) {
       if (lane == 0) set_err(c.d.g, ERR_PROTOCOL);
       return;
     }
-    const int lv = (int)((pe >> 8) & 0xFF), slot = (int)(pe & 0xFF);
+    const int total0 = (int)WG_READFIRST(ls->sc[HH_TOTAL]);  // the sum of |totalIncoming| over the levels, before this task
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
     const Lv v = sib_view(node, lv);
@@ -697,7 +652,8 @@ struct HandelProto {
       if (!hadVI) vi[wF] = viF | bit;
     }
     int cVI = ls->cVI[lv] + (hadVI ? 0 : 1);
-    int cTI = ls->cTI[lv];
+    const int cTI0 = ls->cTI[lv];
+    int cTI = cTI0;
     int cLA = ls->cLA[lv];
     bool improved = false;
     if (!hadTI) {
@@ -748,44 +704,547 @@ struct HandelProto {
     } else if (!hadTI && owner) {
       ti[wF] = tiF | bit;
     }
+    const int cur = total0 + (cTI - cTI0);  // `cur.cardinality()` of :745 after the loop over the levels
     if (lane == 0) {
       ls->cVI[lv] = cVI;
       ls->cTI[lv] = cTI;
       ls->cLA[lv] = cLA;
+      ls->sc[HH_TOTAL] = (uint32_t)cur;
       // The entry was just unlisted (an entry is listed at most once), so its slot dies with this task
       // unless another registered task still references it (checkSigs can pick the same entry twice).
       if (!slot_pending(r, lv, slot)) ls_set_qused(ls, lv, ls_qused(ls, lv) & ~(1ULL << slot));
     }
     __builtin_amdgcn_wave_barrier();
     if (!improved) return;
-    const bool justCompleted = cTI == v.size;  // incomingComplete()
-    // totalOutgoing(l) = the sum of |totalIncoming| below l (:728-731): lane l takes level l, one prefix scan over the
-    // lanes instead of a loop of dependent LDS reads; the fast path (:738-749) is rare, its levels come from a ballot
-    const int myCTI = lane < s.L ? ls->cTI[lane] : 0;
-    const int incl = (int)wave_incl_scan32((uint32_t)myCTI);
-    const int cur = (int)lane_bcast((uint32_t)incl, 63);
-    const bool fp = justCompleted && s.p.fastPath > 0 && lane > lv && lane < s.L && !ls->outFin[lane] &&
-                    incl - myCTI == (1 << (lane - 1));
-    for (uint64_t fpM = __ballot(fp); fpM; fpM &= fpM - 1) {
-      const int l = __ffsll((unsigned long long)fpM) - 1;
-      __threadfence_block();  // the snapshot below reads the totalIncoming words stored above
-      uint32_t destOff = c.dest_reserve(s.p.fastPath);
-      int n = remaining_peers(c, s, ls, l, s.p.fastPath, destOff, nullptr);
-      if (n > 0) {
-        uint32_t ref = snapshot_outgoing(c, s, l);
-        bool lf = ls->cTI[l] == (1 << (l - 1));
-        __threadfence_block();
-        c.send_list(destOff, n, (uint32_t)l | (lf ? 32u : 0u), ref, h_msg_size(l));
-      }
-    }
+    if (cTI == v.size) fast_path(c, s, ls, lv);  // justCompleted = incomingComplete()
     if (r.doneAt == 0 && cur >= s.p.threshold) r.doneAt = c.t;
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The delivery pass, first kernel: one LANE per node with events (the reference applies an envelope to its `to` node,
+// C/Network.java:594-635; a lane applies its node's <= 4 events of the ms in event order).
+struct HLaneNode {
+  long long doneAt, doneAt0;
+  int32_t startAt, sigQueueSize, sigQueueSize0, msgFiltered, msgFiltered0;
+  uint32_t qmask, qmask0;
+  int32_t total, total0;
+};
+// work descriptor of the wave-per-node kernel (16 bytes): a node visit {node, vflags << 8, events, events the lane kernel
+// applied already} or a fast-path item {node, 1 | vflags << 8, event, level} the lane kernel deferred
+constexpr uint32_t HW_VISIT = 0u, HW_FASTPATH = 1u;
+
+// onNewSig (:757-790) by one lane; a payload wider than one word is handed back as a copy job
+__device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelState& s, int32_t t, int32_t node, HLaneNode& r,
+                                               int32_t from, uint32_t msg, uint32_t payload, CopyJob& job) {
+  const int l = (int)(msg & 31u);
+  const bool levelFinished = (msg >> 5) & 1u;
+  if (r.doneAt > 0) {  // :758-761
+    r.msgFiltered++;
+    return;
+  }
+  if (t < r.startAt) return;
+  const int w = from >> 6;
+  const uint64_t bit = 1ULL << (from & 63);
+  uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
+  const uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
+  uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
+  const size_t nl = (size_t)node * s.L + l;
+  // every load of the event before the first use
+  const uint64_t viv = *vip;
+  const uint64_t fpv = levelFinished ? *fpp : 0ULL;
+  const uint64_t tvv = *tvp;
+  const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+  U4 WG_G* lvp = (U4 WG_G*)h_lv(s, node, HP_QLEN, l);      // {qlen, outgoingFinished, slots in use lo / hi}
+  const U4 lq = gld(lvp);
+  const unsigned long long used = (unsigned long long)lq.z | ((unsigned long long)lq.w << 32);
+  const int len = (int)lq.x;
+  const uint64_t WG_G* src = h_payload(d, s, payload);
+  const int nw = h_nw(l);
+  const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
+  if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
+  if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
+  r.sigQueueSize++;
+  const int qc = h_qcap(s, l);
+  const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
+  const unsigned long long freeM = ~used & capMask;
+  if (freeM == 0 || len >= 64) {
+    set_err(d.g, ERR_QUEUE_CAP);
+    return;
+  }
+  const int slot = __ffsll(freeM) - 1;
+  uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
+  s.qfrom[nl * s.Q + slot] = from;
+  s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
+  U4 nq = lq;
+  nq.x = (uint32_t)(len + 1);
+  if (slot < 32)
+    nq.z |= 1u << slot;
+  else
+    nq.w |= 1u << (slot - 32);
+  gst(lvp, nq);
+  r.qmask |= 1u << l;
+  if (nw == 1) {
+    dst[0] = pw0;
+  } else {
+    job.src = src;
+    job.dst = dst;
+    job.nw = nw;
+  }
+}
+
+// updateVerifiedSignatures (:690-754) of a level whose block is <= H_LANE_NW words, by one lane.
+//   H_UPD_DONE   applied, nothing follows
+//   H_UPD_DEFER  applied; the level just became complete and a fast path may follow (:738-749): the caller hands that
+//                part to k_handel_wave. Only when the task is the node's LAST event of the ms: the scan of the emission
+//                lists reads finishedPeers, which a later SendSigs of the same ms would have changed by then
+//   H_UPD_BAIL   nothing applied: the level would become complete and the node has later events — the rest of the visit
+//                (from this event on) goes to k_handel_wave, which runs the fast path in its place
+enum : int { H_UPD_DONE = 0, H_UPD_DEFER = 1, H_UPD_BAIL = 2 };
+__device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelState& s, int32_t t, int32_t node, HLaneNode& r,
+                                             uint32_t arg, bool hasLater) {
+  const int pk = H_ARG_PK(arg), lv = H_ARG_LV(arg), slot = H_ARG_SLOT(arg);
+  const int32_t from = H_ARG_FROM(arg);
+  uint32_t WG_G* hdr = h_hdr(s, node);
+  const Lv v = sib_view(node, lv);
+  uint64_t WG_G* ti = s.TI + (size_t)node * s.W + v.bw;
+  uint64_t WG_G* la = s.LA + (size_t)node * s.W + v.bw;
+  uint64_t WG_G* vi = s.VI + (size_t)node * s.W + v.bw;
+  const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
+  const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block: 0 <= jF < nw
+  const uint64_t bit = 1ULL << (from & 63);
+  uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + wF;
+  uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
+  // ---- every load of the event (they depend on the task's argument only), before the first use
+  const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+  const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
+  U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);   // {posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|}
+  U4 WG_G* lvB = (U4 WG_G*)h_lv(s, node, HP_QLEN, lv);  // {queue length, outgoingFinished, slots in use lo / hi}
+  U4 a = gld(lvA), b = gld(lvB);
+  const uint64_t tvv = *tvp;
+  uint64_t sg[H_LANE_NW], tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
+#pragma unroll
+  for (int j = 0; j < H_LANE_NW; j++) {
+    const bool in = j < v.nw;
+    sg[j] = in ? sig[j] : 0ULL;
+    tiw[j] = in ? ti[j] : 0ULL;
+    law[j] = in ? la[j] : 0ULL;
+    viw[j] = in ? vi[j] : 0ULL;
+  }
+  uint64_t e8[8];  // the head of the level's list (a line); longer lists are walked in memory below
+#pragma unroll
+  for (int i = 0; i < 8; i++) e8[i] = ent[i];
+  // ---- the pending-table entry this task owns
+  const uint32_t pe = pk == 0 ? pend.x : pk == 1 ? pend.y : pk == 2 ? pend.z : pend.w;
+  const uint32_t pf = pk == 0 ? pfrom.x : pk == 1 ? pfrom.y : pk == 2 ? pfrom.z : pfrom.w;
+  if (pe != h_pend_word(lv, slot) || (int32_t)pf != from) {
+    set_err(d.g, ERR_PROTOCOL);
+    return H_UPD_DONE;
+  }
+  // ---- what the task will do to the level's sets, before anything is stored (H_UPD_BAIL leaves the node untouched)
+  bool hadVI = false, hadTI = false;
+#pragma unroll
+  for (int j = 0; j < H_LANE_NW; j++) {
+    hadVI |= j == jF && (viw[j] & bit) != 0;
+    hadTI |= j == jF && (tiw[j] & bit) != 0;
+  }
+  int cVI = (int)a.w + (hadVI ? 0 : 1);
+  const int cTI0 = (int)a.y;
+  int cTI = cTI0, cLA = (int)a.z;
+  bool improved = false;
+  if (!hadTI) {
+    cTI++;
+    improved = true;
+  }
+  uint64_t viN[H_LANE_NW];  // verifiedIndSignatures with `from` set
+#pragma unroll
+  for (int j = 0; j < H_LANE_NW; j++) viN[j] = viw[j] | (j == jF ? bit : 0ULL);
+  int u2 = 0;
+  bool inter = false;
+#pragma unroll
+  for (int j = 0; j < H_LANE_NW; j++) {
+    u2 += __popcll(sg[j] | (viN[j] & v.mask));
+    inter |= (sg[j] & law[j] & v.mask) != 0;
+  }
+  const bool replace = u2 > cVI;  // all.cardinality() > verifiedIndSignatures.cardinality(): the aggregate replaces / extends lastAggVerified
+  uint64_t nla[H_LANE_NW], nti[H_LANE_NW];
+  if (replace) {
+    improved = true;
+    cLA = 0;
+    cTI = 0;
+#pragma unroll
+    for (int j = 0; j < H_LANE_NW; j++) {
+      nla[j] = j < v.nw ? ((inter ? 0ULL : (law[j] & v.mask)) | sg[j]) : 0ULL;
+      nti[j] = j < v.nw ? (nla[j] | (viN[j] & v.mask)) : 0ULL;
+      cLA += __popcll(nla[j]);
+      cTI += __popcll(nti[j]);
+    }
+  }
+  const bool fastPathMayFollow = improved && cTI == v.size && s.p.fastPath > 0 && lv + 1 < s.L;  // justCompleted
+  if (fastPathMayFollow && hasLater) return H_UPD_BAIL;
+  // ---- apply
+  hdr[HH_PEND + pk] = 0;
+  *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
+  // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
+  const int len = (int)b.x;
+  {
+    // (static indices throughout: a register array indexed at run time would live in scratch memory)
+    int at = -1;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (i < len && at < 0 && (int)(e8[i] & 0xFF) == slot) at = i;
+    for (int i = 8; i < len && at < 0; i++)
+      if ((int)(ent[i] & 0xFF) == slot) at = i;
+    if (at >= 0) {
+#pragma unroll
+      for (int i = 0; i < 7; i++)
+        if (i >= at && i + 1 < len) ent[i] = e8[i + 1];
+      for (int i = at > 7 ? at : 7; i + 1 < len; i++) ent[i] = ent[i + 1];
+      b.x = (uint32_t)(len - 1);
+      if (len == 1) r.qmask &= ~(1u << lv);
+    }
+  }
+  if (replace) {
+#pragma unroll
+    for (int j = 0; j < H_LANE_NW; j++) {
+      if (j < v.nw) {
+        if (nla[j] != (law[j] & v.mask)) la[j] = (law[j] & ~v.mask) | nla[j];
+        if (nti[j] != (tiw[j] & v.mask)) ti[j] = (tiw[j] & ~v.mask) | nti[j];
+      }
+    }
+  } else if (!hadTI) {
+#pragma unroll
+    for (int j = 0; j < H_LANE_NW; j++)
+      if (j == jF) ti[j] = tiw[j] | bit;
+  }
+  if (!hadVI) {
+#pragma unroll
+    for (int j = 0; j < H_LANE_NW; j++)
+      if (j == jF) vi[j] = viN[j];
+  }
+  a.y = (uint32_t)cTI;
+  a.z = (uint32_t)cLA;
+  a.w = (uint32_t)cVI;
+  gst(lvA, a);
+  // The entry was just unlisted (an entry is listed at most once), so its slot dies with this task unless another
+  // registered task still references it (checkSigs can pick the same entry twice).
+  const uint32_t key = h_pend_word(lv, slot);
+  const bool held = (pk != 0 && pend.x == key) || (pk != 1 && pend.y == key) || (pk != 2 && pend.z == key) || (pk != 3 && pend.w == key);
+  if (!held) {
+    if (slot < 32)
+      b.z &= ~(1u << slot);
+    else
+      b.w &= ~(1u << (slot - 32));
+  }
+  gst(lvB, b);
+  r.total += cTI - cTI0;
+  if (!improved) return H_UPD_DONE;
+  if (r.doneAt == 0 && r.total >= s.p.threshold) r.doneAt = t;
+  return fastPathMayFollow ? H_UPD_DEFER : H_UPD_DONE;
+}
+
+__global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  __shared__ CopyJob shJobs[4][256];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;  // the wave-per-node kernel's list
+  for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 24);
+    const uint32_t a = base + lane;
+    const bool have = a < nActive;
+    const int32_t node = have ? (int32_t)d.active[a] : 0;
+    uint32_t cnt = 0, vflags = 0;
+    InboxEntry E[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) E[k].e = 0xFFFFFFFFu, E[k].w0 = 0, E[k].w2 = 0, E[k].w3 = 0;
+    U4 h0, h2;  // header words 0..3 {addedCycle, sigQueueSize, msgFiltered, startAt} and 8..11 {-, doneAt lo, hi, queue mask}
+    h0.x = h0.y = h0.z = h0.w = 0;
+    h2 = h0;
+    uint32_t total = 0;
+    if (have) {
+      cnt = d.icnt[node];
+      d.icnt[node] = 0;  // the line is consumed by this pass (its entries stay readable for the wave-per-node kernel)
+#pragma unroll
+      for (int k = 0; k < INBOX_SLOTS; k++) E[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+      vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
+      const uint32_t WG_G* hdr = h_hdr(s, node);
+      h0 = gld((const U4 WG_G*)hdr);
+      h2 = gld((const U4 WG_G*)(hdr + 8));
+      total = hdr[HH_TOTAL];
+    }
+    // ---- which kernel applies the node's events: this lane, if they are <= 4 SendSigs deliveries and at most one
+    // updateVerifiedSignatures of a narrow level; else a wavefront of k_handel_wave
+    bool mine = have && cnt <= (uint32_t)INBOX_SLOTS;
+    int nUpd = 0;
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      if ((uint32_t)k < cnt) {
+        const uint32_t kind = (E[k].w0 >> 28) & 3u;
+        if (kind == K_MSG) {
+          if (E[k].w0 & INBOX_CHAIN) mine = false;  // a hop of a fast-path envelope: its re-push belongs to the visit
+        } else if (kind == K_TASK && E[k].w2 == H_TASK_UPDATE && h_nw(H_ARG_LV(E[k].w3)) <= H_LANE_NW) {
+          nUpd++;
+        } else {
+          mine = false;
+        }
+      } else {
+        E[k].e = 0xFFFFFFFFu;
+      }
+    }
+    if (nUpd > 1) mine = false;
+    {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
+      const bool toB = have && !mine;
+      const uint64_t m = __ballot(toB);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (toB) {
+          U4 q;
+          q.x = (uint32_t)node;
+          q.y = HW_VISIT | (vflags << 8);
+          q.z = cnt;
+          q.w = 0;  // (events to skip: none)
+          gst(work + (bb + __popcll(m & lanes_lt())), q);
+        }
+      }
+    }
+    // the node's events in event order (the line is in arrival order of the expand lanes)
+#define H_CSWAP(A, B)                  \
+  if (E[B].e < E[A].e) {               \
+    const InboxEntry x = E[A];         \
+    E[A] = E[B];                       \
+    E[B] = x;                          \
+  }
+    H_CSWAP(0, 1) H_CSWAP(2, 3) H_CSWAP(0, 2) H_CSWAP(1, 3) H_CSWAP(1, 2)
+#undef H_CSWAP
+    HLaneNode r;
+    r.doneAt = r.doneAt0 = (long long)((unsigned long long)h2.y | ((unsigned long long)h2.z << 32));
+    r.startAt = (int32_t)h0.w;
+    r.sigQueueSize = r.sigQueueSize0 = (int32_t)h0.y;
+    r.msgFiltered = r.msgFiltered0 = (int32_t)h0.z;
+    r.qmask = r.qmask0 = h2.w;
+    r.total = r.total0 = (int32_t)total;
+    const bool toDown = (vflags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vflags >> 8);
+    KPROF_MARK(d.g, 25);  // inbox line + header + classification
+    long long nRecv = 0, bRecv = 0;
+    uint32_t nJobs = 0;
+    bool fpDefer = false;            // the node hands k_handel_wave an item: a deferred fast path, or (bailAt >= 0) the
+    uint32_t fpEvent = 0, fpLevel = 0;  // rest of its visit from event bailAt on
+    int bailAt = -1;
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      CopyJob job;
+      job.nw = 0;
+      if (mine && bailAt < 0 && E[k].e != 0xFFFFFFFFu) {
+        const uint32_t e = E[k].e;
+        EvRes res;
+        res.nrec = 0;
+        res.ndraw = 0;
+        bool deferred = false;
+        if (((E[k].w0 >> 28) & 3u) == K_MSG) {
+          const int32_t from = (int32_t)(E[k].w0 & 0x0FFFFFFFu);
+          if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
+            nRecv++;
+            bRecv += h_msg_size((int)(E[k].w2 & 31u));
+            res.nrec = EV_DELIVERED | ((E[k].w2 & 31u) << 24);
+            h_lane_message(d, s, t, node, r, from, E[k].w2, E[k].w3, job);
+          }
+        } else if (!toDown) {
+          res.nrec = EV_TASK_RUN;
+          const int st = h_lane_update(d, s, t, node, r, E[k].w3, (uint32_t)(k + 1) < cnt);
+          if (st != H_UPD_DONE) {
+            deferred = fpDefer = true;  // the item writes the event's result (the fast path's sends are the event's records)
+            fpEvent = e;
+            fpLevel = (uint32_t)H_ARG_LV(E[k].w3);
+            if (st == H_UPD_BAIL) bailAt = k;
+          }
+        }
+        if (!deferred) gst(d.evRes + e, res);
+      }
+      const uint64_t jm = __ballot(job.nw > 0);
+      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
+      nJobs += (uint32_t)__popcll(jm);
+    }
+    if (mine) {
+      uint32_t WG_G* hdr = h_hdr(s, node);
+      if (r.sigQueueSize != r.sigQueueSize0) hdr[HH_SIGQ] = (uint32_t)r.sigQueueSize;
+      if (r.msgFiltered != r.msgFiltered0) hdr[HH_FILT] = (uint32_t)r.msgFiltered;
+      if (r.qmask != r.qmask0) hdr[HH_QMASK] = r.qmask;
+      if (r.total != r.total0) hdr[HH_TOTAL] = (uint32_t)r.total;
+      if (r.doneAt != r.doneAt0) {
+        hdr[HH_DONE_LO] = (uint32_t)(unsigned long long)r.doneAt;
+        hdr[HH_DONE_HI] = (uint32_t)((unsigned long long)r.doneAt >> 32);
+        d.nodes.doneAt[node] = r.doneAt;
+      }
+      if (nRecv) {
+        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      }
+    }
+    {  // deferred fast paths: items of the wave-per-node kernel, behind the node visits
+      const uint64_t m = __ballot(fpDefer);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (fpDefer) {
+          U4 q;
+          q.x = (uint32_t)node;
+          if (bailAt >= 0) {  // the visit's events from the bailAt-th (in event order) on
+            q.y = HW_VISIT | (vflags << 8);
+            q.z = cnt;
+            q.w = (uint32_t)bailAt;
+          } else {
+            q.y = HW_FASTPATH | (vflags << 8);
+            q.z = fpEvent;
+            q.w = fpLevel;
+          }
+          gst(work + (bb + __popcll(m & lanes_lt())), q);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 26);  // the lanes' events
+    KPROF_ADD(d.g, 28, nJobs);
+    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
+    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
+    // after the other, and up to a few dozen jobs a wavefront.
+    uint32_t totalWords = 0;
+    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
+      const uint32_t j = base0 + (uint32_t)lane;
+      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
+      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
+      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
+      totalWords += lane_bcast(incl, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
+      uint64_t v[WG_COPY_UNROLL];
+      uint64_t WG_G* dp[WG_COPY_UNROLL];
+#pragma unroll
+      for (int u = 0; u < WG_COPY_UNROLL; u++) {
+        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
+        dp[u] = nullptr;
+        v[u] = 0;
+        if (idx < totalWords) {
+          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)shJobs[w][mid].pad <= idx)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          const CopyJob job = shJobs[w][lo];
+          const uint32_t off = idx - (uint32_t)job.pad;
+          v[u] = job.src[off];
+          dp[u] = job.dst + off;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WG_COPY_UNROLL; u++)
+        if (dp[u]) *dp[u] = v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    KPROF_ADD(d.g, 29, totalWords);
+    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
+  }
+}
+
+// The delivery pass, second kernel: one WAVEFRONT per work item of the list k_handel_lane wrote — a node visit
+// (receiveUntil's body for the node's events in event order, from its inbox line) or a deferred fast path.
+// Software-pipelined: while item a runs, the header and the inbox line of item a + nWaves and the descriptor of item
+// a + 2 nWaves are in flight. A visit writes no other node's header (effects on other nodes travel as envelopes, at
+// least one ms later), so fetching the next header early reads what the visit itself would.
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  __shared__ LevelScalars shP[4];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nWork = d.g->nActiveB;
+  const int32_t t = d.g->now;
+  const U4 WG_G* work = (const U4 WG_G*)(const VisitDesc WG_G*)d.activeB;
+  uint32_t a = wave;
+  if (a >= nWork) return;
+  auto inbox_of = [&](const U4& desc) -> InboxEntry {  // lane k < 4: entry k of the node's line
+    return gld(d.inbox + ((size_t)WG_READFIRST(desc.x) * INBOX_SLOTS + (lane < INBOX_SLOTS ? lane : 0)));
+  };
+  U4 descCur = gld(work + a);
+  HandelProto::Pre hdrCur = HandelProto::prefetch(s, (int32_t)WG_READFIRST(descCur.x));
+  InboxEntry inCur = inbox_of(descCur);
+  U4 descNext = descCur;
+  if (a + nWaves < nWork) descNext = gld(work + (a + nWaves));
+  for (;;) {
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 0);
+    const uint32_t an = a + nWaves;
+    const bool haveNext = an < nWork;
+    HandelProto::Pre hdrNext = hdrCur;
+    InboxEntry inNext = inCur;
+    U4 descNext2 = descNext;
+    if (haveNext) {
+      hdrNext = HandelProto::prefetch(s, (int32_t)WG_READFIRST(descNext.x));
+      inNext = inbox_of(descNext);
+      if (an + nWaves < nWork) descNext2 = gld(work + (an + nWaves));
+    }
+    {
+      const int32_t node = (int32_t)WG_READFIRST(descCur.x);
+      const uint32_t kf = WG_READFIRST(descCur.y);
+      Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+      HandelProto::NodeRegs r;
+      HandelProto::node_begin_pre(c, s, r, &shP[w], hdrCur);
+      KPROF_MARK(d.g, 31);  // the next item's prefetches issued, this item's descriptor + header arrived
+      if ((kf & 0xFFu) == HW_VISIT) {
+        deliver_visit_inbox<HandelProto>(d, s, c, r, node, WG_READFIRST(descCur.z), kf >> 8, inCur, WG_READFIRST(descCur.w));
+      } else {
+        // the fast path of an updateVerifiedSignatures a lane applied (h_lane_update): its sends are that event's records
+        const uint32_t e = WG_READFIRST(descCur.z);
+        const EvAux aux = gld(d.evAux + e);
+        c.ev = e;
+        c.outBase = aux.outBase;
+        c.outCap = aux.outCap;
+        HandelProto::fast_path(c, s, r.ls, (int)WG_READFIRST(descCur.w));
+        if (lane == 0) {
+          EvRes res;
+          res.nrec = c.sub | EV_TASK_RUN;
+          res.ndraw = c.draws;
+          gst(d.evRes + e, res);
+          if (c.msgSent) {
+            atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+            atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+          }
+        }
+        HandelProto::store_levels(s, node, r.ls);  // posInLevel / outgoingFinished of the levels it sent for
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!haveNext) break;
+    a = an;
+    descCur = descNext;
+    hdrCur = hdrNext;
+    inCur = inNext;
+    descNext = descNext2;
+  }
+}
+
 // ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
-// PRE: which conditional tasks run at this edge — one lane per node, coalesced reads of the four words
-// that decide it; the runners go to a compact list (one atomic per wavefront) so the expensive part
-// below is launched over runners only, not over all N nodes.
+// PRE: which conditional tasks run at this edge — one lane per node, coalesced reads of the two dense words that
+// decide it. checkSigs looks at every level with a queue, and bestToVerify of one level (:570-634) depends on nothing
+// of the others: every (runner, level with a non-empty queue) becomes an ITEM of k_handel_a1, in one of two lists by
+// the lanes its block needs.
 __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __restrict__ tab,
                                                          const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -793,11 +1252,13 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   const int32_t t = d.g->now, until = d.g->until;
   const uint32_t epoch = d.g->epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
+  const int lane = WG_LANE;
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
+    uint32_t qm = 0;
     if (node < (uint32_t)s.hi) {
       uint32_t WG_G* ct = s.ct + 2 * (size_t)node;
       uint32_t WG_G* h = h_hdr(s, (int32_t)node);
@@ -812,234 +1273,288 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
       if (run) {
         ct[0] = (uint32_t)(t + (int32_t)h[HH_PAIR]);  // minStartTime = time + duration (:557-560)
         // sigQueueSize drifts above the real queue lengths: checkSigs then runs over empty
-        // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node needs no visit
-        if (h[HH_QMASK] == 0) run = false;
+        // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node has no item
+        qm = h[HH_QMASK] & ~1u;
       }
-      if (!run) s.candCnt[node] = 0;
+      s.candMask[node] = 0;
     }
-    const uint64_t m = __ballot(run);
-    if (m) {
-      uint32_t base = 0;
-      const int leader = __ffsll((unsigned long long)m) - 1;
-      if ((int)WG_LANE == leader) base = atomicAdd(F(s.runCount + 0), (uint32_t)__popcll(m));
-      base = lane_bcast(base, leader);
-      if (run) s.runList[base + __popcll(m & lanes_lt())] = node;
+    // the node's items: one per level with a queue, appended wave-aggregated (one atomic per list and wavefront)
+    uint32_t mLane = 0, mWave = 0;
+    for (uint32_t m = qm; m; m &= m - 1) {
+      const int l = __ffs(m) - 1;
+      if (h_nw(l) <= H_LANE_NW)
+        mLane |= 1u << l;
+      else
+        mWave |= 1u << l;
+    }
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+      const uint32_t mm = which == 0 ? mLane : mWave;
+      const uint32_t mine = (uint32_t)__popc(mm);
+      const uint32_t incl = wave_incl_scan32(mine);
+      const uint32_t tot = lane_bcast(incl, 63);
+      if (tot) {
+        uint32_t base = 0;
+        if (lane == 63) base = atomicAdd(F(s.itemCount + which), tot);
+        base = lane_bcast(base, 63) + incl - mine;
+        uint32_t WG_G* list = which == 0 ? (uint32_t WG_G*)s.itemsLane : (uint32_t WG_G*)s.itemsWave;
+        for (uint32_t m = mm; m; m &= m - 1) list[base++] = node | ((uint32_t)(__ffs(m) - 1) << 24);
+      }
     }
   }
 }
 
-// A1: bestToVerify for every level (:570-634) of every runner: curates the lists, records the candidates.
+// score / curation of ONE queue entry against the level's state: what bestToVerify (:570-634) needs of it
+struct HEntryEval {
+  bool keep, inside;
+  int score;
+};
+__device__ __forceinline__ HEntryEval h_eval_entry(int u1, int u2, int cs, bool iTI, bool iLA, int curSize, int cLA, int size,
+                                                   int rank, int windowIndex, int window) {
+  HEntryEval ev;
+  const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
+  ev.keep = sII > curSize;
+  ev.inside = ev.keep && rank <= windowIndex + window;
+  ev.score = 0;  // score(l, sig) :655-668
+  if (ev.inside) ev.score = cLA >= size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));
+  return ev;
+}
+
+// the end of an item: the curated list's bookkeeping and the level's candidate. `relMask`: queue slots of dropped
+// entries no registered task holds; several items of one node run concurrently (other levels), so the node's shared
+// words are updated with atomics and the level's own 16-byte piece is stored whole.
+__device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node, int l, U4 lvB, int len, int kept,
+                                              unsigned long long relMask, int cand) {
+  uint32_t WG_G* hdr = h_hdr(s, node);
+  if (kept != len) {  // replaceToVerifyAgg :636-646
+    lvB.x = (uint32_t)kept;
+    lvB.z &= ~(uint32_t)relMask;
+    lvB.w &= ~(uint32_t)(relMask >> 32);
+    gst((U4 WG_G*)h_lv(s, node, HP_QLEN, l), lvB);
+    atomicAdd(F(hdr + HH_SIGQ), (uint32_t)(kept - len));  // sigQueueSize -= dropped
+    if (kept == 0) atomicAnd(F(hdr + HH_QMASK), ~(1u << l));
+  }
+  if (cand >= 0) {
+    ((uint8_t WG_G*)(hdr + HH_CAND))[l] = (uint8_t)cand;
+    atomicOr(F(s.candMask + node), 1u << l);
+  }
+}
+
+// A1: bestToVerify (:570-634) of one (runner, level) item: curates the level's list, records its candidate.
+// Blocks [0, gridDim.x / 4) take the items of the narrow levels one LANE each, the others the wide levels' items one
+// WAVEFRONT each — one launch, both kinds of chains in flight together.
 template <int WPE>
-__global__ void __launch_bounds__(256, WPE) k_handel_cond_a1(const EngineDev* __restrict__ tab,
-                                                             const HandelState* __restrict__ stab) {
+__global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  __shared__ LevelScalars shLevels[4];
   const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nRun = *s.runCount;
-  LevelScalars* ls = &shLevels[threadIdx.x >> 6];
-  // Software-pipelined over the runners of this wavefront: while runner q is worked on, the header of runner
-  // q + nWaves and the id of runner q + 2 nWaves are in flight (a runner's checkSigs touches its own node only).
-  if (wave >= nRun) return;
-  int32_t nodeCur = (int32_t)s.runList[wave];
-  HandelProto::Pre hdrCur = HandelProto::prefetch(s, nodeCur);
-  int32_t nodeNext = wave + nWaves < nRun ? (int32_t)s.runList[wave + nWaves] : 0;
-  // list entries of the lowest level with a queue, from a record still in registers: lane l's piece is words 4l..4l+3
-  auto first_entries = [&](const HandelProto::Pre& h, int32_t nd) -> uint64_t {
-    const uint32_t qm = WG_READLANE(h.q0.w, 2) & ~1u;  // HH_QMASK = word 11
-    if (!qm) return ~0ULL;
-    const int l0 = __ffs(qm) - 1;
-    const int len0 = (int)WG_READLANE(h.q0.x, (HH_LV + l0 * HP_COUNT + HP_QLEN) >> 2);
-    return lane < len0 ? s.qent[((size_t)nd * s.L + l0) * 64 + lane] : ~0ULL;
-  };
-  uint64_t entFirst = first_entries(hdrCur, nodeCur);
-  for (uint32_t q = wave; q < nRun; q += nWaves) {
+  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x / 4 : 1;
+  if (blockIdx.x < laneBlocks) {
+    // ---------------- one lane per item: blocks of <= H_LANE_NW words ----------------
+    const uint32_t nItems = s.itemCount[0];
+    const uint32_t stride = laneBlocks * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nItems; q += stride) {
+      const uint32_t it = s.itemsLane[q];
+      const int32_t node = (int32_t)(it & 0x00FFFFFFu);
+      const int l = (int)(it >> 24);
+      const uint32_t WG_G* hdr = h_hdr(s, node);
+      const Lv v = sib_view(node, l);
+      const uint64_t WG_G* ti = s.TI + (size_t)node * s.W + v.bw;
+      const uint64_t WG_G* la = s.LA + (size_t)node * s.W + v.bw;
+      const uint64_t WG_G* vi = s.VI + (size_t)node * s.W + v.bw;
+      uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
+      // ---- everything the item's address alone decides, before the first use
+      const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+      const int window = (int)hdr[HH_WINDOW];
+      const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
+      const U4 lvB = gld((const U4 WG_G*)h_lv(s, node, HP_QLEN, l));
+      uint64_t tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
+#pragma unroll
+      for (int j = 0; j < H_LANE_NW; j++) {
+        const bool in = j < v.nw;
+        tiw[j] = in ? ti[j] & v.mask : 0ULL;
+        law[j] = in ? la[j] & v.mask : 0ULL;
+        viw[j] = in ? vi[j] & v.mask : 0ULL;
+      }
+      uint64_t e4[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) e4[i] = ent[i];
+      const int len = (int)lvB.x, curSize = (int)lvA.y, cLA = (int)lvA.z;
+      int windowIndex = INT32_MAX;  // Collections.min(rank)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
+      for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
+      int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
+      unsigned long long keep = 0;
+      for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signatures in flight at a time
+        uint64_t x[4], sg[4][H_LANE_NW];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u;
+          x[u] = i < len ? (i0 == 0 ? e4[u] : ent[i]) : 0ULL;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, (int)(x[u] & 0xFF));
+#pragma unroll
+          for (int j = 0; j < H_LANE_NW; j++) sg[u][j] = (i0 + u < len && j < v.nw) ? sig[j] : 0ULL;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u;
+          if (i >= len) break;
+          int u1 = 0, u2 = 0, cs = 0;
+          bool iTI = false, iLA = false;
+#pragma unroll
+          for (int j = 0; j < H_LANE_NW; j++) {
+            u1 += __popcll(sg[u][j] | tiw[j] | viw[j]);
+            u2 += __popcll(sg[u][j] | viw[j]);
+            cs += __popcll(sg[u][j]);
+            iTI |= (sg[u][j] & tiw[j]) != 0;
+            iLA |= (sg[u][j] & law[j]) != 0;
+          }
+          const int slot = (int)(x[u] & 0xFF), rank = (int)(uint32_t)(x[u] >> 32);
+          const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rank, windowIndex, window);
+          if (ev.keep) {
+            keep |= 1ULL << i;
+            if (ev.inside) {  // best inside = FIRST entry with the strictly greatest positive score
+              if (ev.score > bestScore) {
+                bestScore = ev.score;
+                bestInside = slot;
+              }
+            } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
+              bestOutside = slot;
+              bestOutsideRank = rank;
+            }
+          }
+        }
+      }
+      const int kept = __popcll(keep);
+      unsigned long long relMask = 0;
+      if (kept != len) {
+        int pos = 0;
+        auto curate = [&](int i, uint64_t x) {
+          if ((keep >> i) & 1ULL) {
+            if (pos != i) ent[pos] = x;
+            pos++;
+          } else {  // the slot of a dropped entry is released unless a registered task still holds it
+            const uint32_t key = h_pend_word(l, (int)(x & 0xFF));
+            if (!(pend.x == key || pend.y == key || pend.z == key || pend.w == key)) relMask |= 1ULL << (x & 0xFF);
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i < len) curate(i, e4[i]);
+        for (int i = 4; i < len; i++) curate(i, ent[i]);
+      }
+      h_item_finish(s, node, l, lvB, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+    }
+    return;
+  }
+  // ---------------- one wavefront per item: lanes = 64-bit words of the level's block ----------------
+  const uint32_t wave = ((blockIdx.x - laneBlocks) * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = ((gridDim.x - laneBlocks) * blockDim.x) >> 6;
+  const uint32_t nItems = s.itemCount[1];
+  if (nWaves == 0) return;
+  for (uint32_t q = wave; q < nItems; q += nWaves) {
     KPROF_DECL;
     KPROF_COUNT(d.g, 16);
-    const int32_t node = nodeCur;
-    const bool haveNext = q + nWaves < nRun;
-    HandelProto::Pre hdrNext = hdrCur;
-    int32_t nodeNext2 = 0;
-    if (haveNext) {
-      hdrNext = HandelProto::prefetch(s, nodeNext);
-      if (q + 2 * nWaves < nRun) nodeNext2 = (int32_t)s.runList[q + 2 * nWaves];
-    }
-    {
-      const int n4 = s.hdrStride >> 2;
-      __builtin_amdgcn_wave_barrier();  // the previous runner's store_levels has read the image
-      if (lane < n4) HandelProto::scatter_levels(s, ls, lane, hdrCur.q0);
-      if (lane + 64 < n4) HandelProto::scatter_levels(s, ls, lane + 64, ((const U4*)h_hdr(s, node))[lane + 64]);
-      __builtin_amdgcn_wave_barrier();
-    }
-    nodeCur = nodeNext;
-    nodeNext = nodeNext2;
-    hdrCur = hdrNext;
-    KPROF_MARK(d.g, 17);  // header image (prefetched a runner ahead)
+    const uint32_t it = s.itemsWave[q];
+    const int32_t node = (int32_t)(it & 0x00FFFFFFu);
+    const int l = (int)(it >> 24);
+    const uint32_t WG_G* hdr = h_hdr(s, node);
+    const Lv v = sib_view(node, l);
     const uint64_t WG_G* ti = s.TI + (size_t)node * s.W;
     const uint64_t WG_G* la = s.LA + (size_t)node * s.W;
     const uint64_t WG_G* vi = s.VI + (size_t)node * s.W;
-    const int window = (int)WG_READFIRST(ls->sc[HH_WINDOW]);
-    int sigQueueSize = (int)WG_READFIRST(ls->sc[HH_SIGQ]);
-    uint32_t pend[H_PEND];
+    uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
+    // ---- everything the item's address alone decides, before the first use: header pieces (every lane the same
+    // address), the whole list (lane i = entry i) and this lane's word of the three rows
+    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+    const int window = (int)hdr[HH_WINDOW];
+    const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
+    const U4 lvB = gld((const U4 WG_G*)h_lv(s, node, HP_QLEN, l));
+    const uint64_t entAll = ent[lane];
+    const int jh = (int)((lane - v.bw) & 63);
+    const bool oneRound = v.nw <= 64;
+    uint64_t tih = 0, vih = 0, lah = 0;
+    if (oneRound && jh < v.nw) {
+      tih = ti[v.bw + jh];
+      vih = vi[v.bw + jh];
+      lah = la[v.bw + jh];
+    }
+    const int len = (int)WG_READFIRST(lvB.x), curSize = (int)WG_READFIRST(lvA.y), cLA = (int)WG_READFIRST(lvA.z);
+    const uint64_t myEnt = lane < len ? entAll : ~0ULL;
+    const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
+    const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+    KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
+    const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
+    int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
+    uint64_t keep = 0;
+    for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signature words in flight at a time
+      uint64_t sg[4];
+      int slotU[4], rankU[4];
 #pragma unroll
-    for (int k = 0; k < H_PEND; k++) pend[k] = WG_READFIRST(ls->sc[HH_PEND + k]);
-    int ncand = 0;
-    // levels with a non-empty queue; the next level's list entries are fetched while this one is worked on
-    uint32_t lvMask = WG_READFIRST(ls->sc[HH_QMASK]) & ~1u;  // (bit l <=> qlen[l] > 0, kept by every writer of qlen)
-    // (the first level's list entries were requested at the end of the previous runner — before ITS stores: loads and
-    // stores retire through one in-order counter on this ISA, so a load issued after stores waits for their acknowledgement)
-    uint64_t entNext = entFirst;
-    while (lvMask) {
-      const int l = __ffs(lvMask) - 1;
-      lvMask &= lvMask - 1;
-      const int len = ls->qlen[l];
-      const Lv v = sib_view(node, l);
-      uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
-      const uint64_t myEnt = entNext;
-      entNext = ~0ULL;
-      if (lvMask) {
-        const int ln = __ffs(lvMask) - 1;
-        if (lane < ls->qlen[ln]) entNext = s.qent[((size_t)node * s.L + ln) * 64 + lane];
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u < len ? i0 + u : len - 1;
+        slotU[u] = (int)lane_bcast((uint32_t)mySlot, i);
+        rankU[u] = (int)lane_bcast((uint32_t)myRank, i);
+        sg[u] = (oneRound && jh < v.nw && i0 + u < len) ? h_sig_ptr(s, node, l, slotU[u])[jh] : 0ULL;
       }
-      const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
-      const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
-      KPROF_COUNT(d.g, 18);
-      KPROF_MARK(d.g, 19);  // the level's list entries
-      const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
-      const int curSize = ls->cTI[l], cLA = ls->cLA[l];
-      int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
-      uint64_t keep = 0;
-      if (v.nw == 1) {
-        // the level's block fits one 64-bit word (levels <= 7): one lane per queue entry, no reductions.
-        // Same selection as the sequential walk below: best inside = FIRST entry with the strictly
-        // greatest positive score, best outside = FIRST entry with the smallest rank.
-        const bool mineIn = lane < len;
-        const uint64_t sg = mineIn ? *HandelProto::sig_ptr(s, node, l, mySlot) : 0ULL;
-        const uint64_t tiw = ti[v.bw] & v.mask, viw = vi[v.bw] & v.mask, law = la[v.bw] & v.mask;
-        const int u1 = __popcll(sg | tiw | viw), u2 = __popcll(sg | viw), cs = __popcll(sg);
-        const bool iTI = (sg & tiw) != 0, iLA = (sg & law) != 0;
-        const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
-        const bool kept1 = mineIn && sII > curSize;
-        const bool inside = kept1 && myRank <= windowIndex + window;
-        const bool outside = kept1 && !inside;
-        int score = 0;  // score(l, sig) :655-668
-        if (inside) score = cLA >= v.size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));
-        keep = __ballot(kept1);
-        const int maxScore = wave_reduce_max_i32(score), minRank = wave_reduce_min_i32(outside ? myRank : INT32_MAX);
-        if (maxScore > 0) {
-          const uint64_t mm = __ballot(inside && score == maxScore);
-          bestInside = (int)lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)mm) - 1);
-        }
-        const uint64_t om = __ballot(outside && myRank == minRank);
-        if (om) bestOutside = (int)lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)om) - 1);
-        KPROF_MARK(d.g, 20);  // a single-word level
-      } else {
-      // blocks of up to 64 words (levels <= 13): the level's three row words of this lane are loaded once, not once
-      // per queue entry
-      const int jh = (int)((lane - v.bw) & 63);
-      const bool oneRound = v.nw <= 64;
-      uint64_t tih = 0, vih = 0, lah = 0;
-      if (oneRound && jh < v.nw) {
-        tih = ti[v.bw + jh];
-        vih = vi[v.bw + jh];
-        lah = la[v.bw + jh];
-      }
-      // (the entries' signatures are independent of each other: entry i + 1's word is in flight while entry i is reduced)
-      uint64_t sgAhead = 0;
-      {
-        const int slot0 = (int)lane_bcast((uint32_t)mySlot, 0);
-        if (oneRound && jh < v.nw && len > 0) sgAhead = HandelProto::sig_ptr(s, node, l, slot0)[jh];
-      }
-      for (int i = 0; i < len; i++) {
-        const int slot = (int)lane_bcast((uint32_t)mySlot, i);
-        const int rank = (int)lane_bcast((uint32_t)myRank, i);
-        const uint64_t WG_G* sig = HandelProto::sig_ptr(s, node, l, slot);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u;
+        if (i >= len) break;
         uint64_t a = 0, b = 0;
         if (oneRound) {
-          const uint64_t sgCur = sgAhead;
-          const int slotN = (int)lane_bcast((uint32_t)mySlot, i + 1 < len ? i + 1 : i);
-          if (i + 1 < len && jh < v.nw) sgAhead = HandelProto::sig_ptr(s, node, l, slotN)[jh];
           if (jh < v.nw) {
-            const uint64_t sg = sgCur;
-            a = (uint64_t)__popcll(sg | tih | vih) | ((uint64_t)__popcll(sg | vih) << 21) | ((uint64_t)__popcll(sg) << 42);
-            b = (uint64_t)((sg & tih) != 0) | ((uint64_t)((sg & lah) != 0) << 21);
+            a = (uint64_t)__popcll(sg[u] | tih | vih) | ((uint64_t)__popcll(sg[u] | vih) << 21) | ((uint64_t)__popcll(sg[u]) << 42);
+            b = (uint64_t)((sg[u] & tih) != 0) | ((uint64_t)((sg[u] & lah) != 0) << 21);
           }
-        } else
-        H_FOR_WORDS(v, j) {
-          uint64_t sg = sig[j], tiw = ti[v.bw + j] & v.mask, viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
-          a += (uint64_t)__popcll(sg | tiw | viw) | ((uint64_t)__popcll(sg | viw) << 21) | ((uint64_t)__popcll(sg) << 42);
-          b += (uint64_t)((sg & tiw) != 0) | ((uint64_t)((sg & law) != 0) << 21);
+        } else {
+          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[u]);
+          H_FOR_WORDS(v, j) {
+            const uint64_t sgw = sig[j], tiw = ti[v.bw + j], viw = vi[v.bw + j], law = la[v.bw + j];
+            a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
+            b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
+          }
         }
         a = wave_sum64(a);
         b = wave_sum64(b);
         const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
         const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-        const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
-        if (sII > curSize) {
+        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[u], windowIndex, window);
+        if (ev.keep) {
           keep |= 1ULL << i;
-          if (rank <= windowIndex + window) {
-            int score;  // score(l, sig) :655-668
-            if (cLA >= v.size)
-              score = 0;
-            else if (!iLA)
-              score = cLA + cs;
-            else
-              score = max(0, u2 - cLA);
-            if (score > bestScore) {
-              bestScore = score;
-              bestInside = slot;
+          if (ev.inside) {
+            if (ev.score > bestScore) {
+              bestScore = ev.score;
+              bestInside = slotU[u];
             }
-          } else if (bestOutside < 0 || rank < bestOutsideRank) {
-            bestOutside = slot;
-            bestOutsideRank = rank;
+          } else if (bestOutside < 0 || rankU[u] < bestOutsideRank) {
+            bestOutside = slotU[u];
+            bestOutsideRank = rankU[u];
           }
         }
       }
-      KPROF_ADD(d.g, 21, len);
-      KPROF_MARK(d.g, 22);  // a multi-word level (kprof21: its entries)
-      }
-      const int kept = __popcll(keep);
-      if (kept != len) {  // replaceToVerifyAgg :636-646
-        int newPos = __popcll(keep & lanes_lt());
-        bool mineKept = lane < len && ((keep >> lane) & 1ULL);
-        if (mineKept) ent[newPos] = myEnt;
-        // slots of dropped entries are released unless a registered task still holds them
-        bool mineDropped = lane < len && !mineKept;
-        bool held = false;
-#pragma unroll
-        for (int k = 0; k < H_PEND; k++) held |= pend[k] == (0x80000000u | ((uint32_t)l << 8) | (uint32_t)mySlot);
-        uint64_t rel = __ballot(mineDropped && !held);
-        unsigned long long relMask = 0;
-        for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
-        if (lane == 0) {
-          ls_set_qused(ls, l, ls_qused(ls, l) & ~relMask);
-          ls->qlen[l] = kept;
-          if (kept == 0) ls->sc[HH_QMASK] &= ~(1u << l);
-        }
-        sigQueueSize += kept - len;
-        __builtin_amdgcn_wave_barrier();
-      }
-      const int cand = bestInside >= 0 ? bestInside : bestOutside;
-      if (cand >= 0) {
-        if (lane == 0) {  // (into the record's image: stored with it at the end of the runner, no memory traffic here)
-          uint32_t* cw = ls->sc + HH_CAND + (ncand >> 1);
-          const uint32_t e16 = ((uint32_t)l << 8) | (uint32_t)cand;
-          *cw = (ncand & 1) ? ((*cw & 0xFFFFu) | (e16 << 16)) : ((*cw & 0xFFFF0000u) | e16);
-        }
-        ncand++;
-      }
+    }
+    KPROF_ADD(d.g, 21, len);
+    KPROF_MARK(d.g, 22);  // the entries (kprof21: how many)
+    const int kept = __popcll(keep);
+    unsigned long long relMask = 0;
+    if (kept != len) {  // replaceToVerifyAgg :636-646
+      const int newPos = __popcll(keep & lanes_lt());
+      const bool mineKept = lane < len && ((keep >> lane) & 1ULL);
+      if (mineKept && newPos != lane) ent[newPos] = myEnt;
+      const uint32_t key = h_pend_word(l, mySlot);
+      const bool held = pend.x == key || pend.y == key || pend.z == key || pend.w == key;
+      const uint64_t rel = __ballot(lane < len && !mineKept && !held);
+      for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
     }
     __builtin_amdgcn_wave_barrier();
-    entFirst = q + nWaves < nRun ? first_entries(hdrCur, nodeCur) : ~0ULL;  // (hdrCur / nodeCur: the next runner's by now)
-    if (lane == 0) {
-      ls->sc[HH_SIGQ] = (uint32_t)sigQueueSize;
-      s.candCnt[node] = (uint8_t)ncand;
-    }
-    HandelProto::store_levels(s, node, ls);
-    __builtin_amdgcn_wave_barrier();
-    KPROF_MARK(d.g, 23);  // list curation, candidates, header store
+    if (lane == 0) h_item_finish(s, node, l, lvB, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+    KPROF_MARK(d.g, 23);  // list curation, candidate
   }
 }
 
@@ -1052,18 +1567,18 @@ struct CondF {
   const HandelState& s;
   __device__ CondF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
   __device__ uint32_t count() const { return (uint32_t)s.N; }
-  __device__ uint64_t value(uint32_t i) const { return s.candCnt[i] > 0; }
+  __device__ uint64_t value(uint32_t i) const { return s.candMask[i] != 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
     d.g->nOut = (uint32_t)tot;  // one registerTask per drawing node
     d.g->nDraws = (uint32_t)tot;
   }
   __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
-    if (!valid || s.candCnt[i] == 0) return;
+    if (!valid || s.candMask[i] == 0) return;
     s.condList[(uint32_t)excl] = i;
     uint64_t st = lcg_skip(d.g->rng, excl);
     int consumed;
-    s.drawVal[i] = lcg_next_int_bounded(st, (int32_t)s.candCnt[i], &consumed);
+    s.drawVal[i] = lcg_next_int_bounded(st, (int32_t)__popc(s.candMask[i]), &consumed);
     if (consumed != 1) d.g->rejectSeen = 1;
   }
 };
@@ -1080,7 +1595,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
   const bool rejected = d.g->rejectSeen != 0;
   const uint32_t D = (uint32_t)d.horizon;
   const uint32_t stride = gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *s.runCount = 0;  // for the next edge's k_handel_cond_pre
+  if (blockIdx.x == 0 && threadIdx.x < 2) s.itemCount[threadIdx.x] = 0;  // for the next edge's k_handel_cond_pre
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
     const uint32_t j = j0 + threadIdx.x;
     uint32_t histKey = 0xFFFFFFFFu;
@@ -1093,7 +1608,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         uint32_t total = 0;
         for (uint32_t q = 0; q <= j; q++) {
           int consumed;
-          k = lcg_next_int_bounded(st, (int32_t)s.candCnt[s.condList[q]], &consumed);
+          k = lcg_next_int_bounded(st, (int32_t)__popc(s.candMask[s.condList[q]]), &consumed);
           total += (uint32_t)consumed;
         }
         if (j + 1 == n) d.g->nDraws = total;
@@ -1103,9 +1618,11 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         continue;
       }
       uint32_t WG_G* h = h_hdr(s, node);
-      const uint32_t e16 = (h[HH_CAND + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
-      const int l = (int)(e16 >> 8);
-      const int slot = (int)(e16 & 0xFFu);
+      // byLevels is in level order: the k-th level with a candidate, its candidate's queue slot
+      uint32_t cm = s.candMask[node];
+      for (int q = 0; q < k; q++) cm &= cm - 1;
+      const int l = __ffs(cm) - 1;
+      const int slot = (int)((const uint8_t WG_G*)(h + HH_CAND))[l];
       const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
       int w = (int)h[HH_WINDOW] * 2;
@@ -1128,11 +1645,11 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         set_err(d.g, ERR_PENDING);
         pe = 0;
       }
-      h[HH_PEND + pe] = 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot;
+      h[HH_PEND + pe] = h_pend_word(l, slot);
       h[HH_PENDFROM + pe] = (uint32_t)from;
       // registerTask(updateVerifiedSignatures(best), time + nodePairingTime, this)
       const int32_t arrival = t + (int32_t)h[HH_PAIR];
-      const Rec fin = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, (uint32_t)pe);
+      const Rec fin = make_rec(K_TASK, node, (uint32_t)node, H_TASK_UPDATE, h_update_arg(pe, l, slot, from));
       const bool ok = arrival - t < d.horizon - 1;  // see Engine::run_ms on host-held envelopes
       if (!ok) set_err(d.g, ERR_HORIZON);
       if (SH) {
