@@ -73,7 +73,7 @@ inline int grid_node_waves(int R) {
   return b;
 }
 constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
-constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_deliver_msgs)
+constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_handel_lane)
 constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;
 constexpr int GRID_TILES = 256 / WG_GRID_DIV;
 constexpr int GRID_EXPAND_RUNS = 1024 / WG_GRID_DIV;  // x 4 wavefronts: one per long chain run
@@ -138,8 +138,7 @@ struct EvAux {
   uint32_t outBase;   // first outbox slot of the event
   uint32_t outCap;    // slots owned
 };
-// what a wave-per-node visit starts from, written by k_deliver_msgs for the nodes it leaves to k_deliver:
-// the node, its newest event and that event's record — one coalesced read instead of three dependent ones
+// what a wave-per-node visit of a list-based inbox starts from: the node, its newest event and that event's record
 struct alignas(16) U4 {  // one 16-byte vector load / store per lane
   uint32_t x, y, z, w;
 };
@@ -149,12 +148,6 @@ struct alignas(16) VisitDesc {
   uint32_t flags;
   Rec rec0;
   EvAux aux0;
-};
-// what k_msgs_classify hands k_msgs_apply for a message-only node: its (up to four) events sorted by event index
-struct alignas(16) MineDesc {
-  int32_t node;
-  uint32_t flags;  // VD_DOWN | partition id << 8
-  uint32_t s0, s1, s2, s3, pad0, pad1;
 };
 // A node's inbox as ONE 64-byte line (EngineDev::inbox, protocols that ask for it: Engine::wantInbox): the first
 // INBOX_SLOTS events of the ms that go to the node, written by expand in whatever order the lanes arrive (the consumer
@@ -215,8 +208,7 @@ struct Globals {
   // per-ms scratch counters
   uint32_t nEvents;        // events in the bucket being drained (after chain-run expansion)
   uint32_t nActive;        // nodes with >= 1 event
-  uint32_t nActiveB;       // ... of which the lane-per-node message kernel left to the wave-per-node kernel
-  uint32_t nActiveM;       // ... and the message-only ones k_msgs_classify listed for k_msgs_apply
+  uint32_t nActiveB;       // items in activeB
   uint32_t outSlots;       // outbox slots handed out to the events of this ms
   uint32_t nOut;           // ordered outbox length
   uint32_t nDraws;         // draws in this phase
@@ -237,6 +229,14 @@ struct Globals {
   uint32_t nFar;           // records parked in EngineDev::farBuf since the host last collected them
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
+};
+// Launch bookkeeping that lives on the device only (never mirrored by the host's Globals shadow, untouched by wg_restore):
+struct DevCtl {
+  // device-wide scan (k_scan): the sequence number the blocks tag their chunk sums with, and the blocks that have left
+  uint32_t scanSeq, scanDone;
+  // blocks of a kernel that have finished, for the kernels whose last block does the work of a follow-up single-block
+  // kernel (k_resolve / the protocol's cond tail: page reservation; k_scatter: the end of the phase)
+  uint32_t tailDone, scatterDone;
 };
 constexpr uint32_t KPROF_WAVES = 16384;
 constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)
@@ -278,6 +278,7 @@ struct EngineDev {
   uint32_t halted;          // batch member that is not advanced by the current run (RunMultipleTimes: its
                             // continuation predicate turned false); every kernel returns at once for it
   GP<Globals> g;
+  GP<DevCtl> ctl;
   NodeArrays nodes;
   LatencyModel lat;
   int32_t discardTime;
@@ -315,8 +316,7 @@ struct EngineDev {
   GP<InboxEntry> inbox;        // [n][INBOX_SLOTS] the node's first events of this ms (NULL: lists only)
   GP<uint32_t> icnt;           // [n] events of the node this ms (inbox lines only); reset by the delivery pass
   GP<uint32_t> active;         // nodes with >= 1 event (unordered)
-  GP<VisitDesc> activeB;       // the ones k_deliver_msgs does not take (tasks, chain hops, > 4 events)
-  GP<MineDesc> activeM;        // the ones it does, when the kernel runs as k_msgs_classify + k_msgs_apply
+  GP<VisitDesc> activeB;       // work list of a protocol's second delivery kernel (Handel: the items k_handel_lane leaves to k_handel_wave, 16 bytes each)
   uint32_t maxOut;
   GP<Out> outTmp;              // per-event slices (see Out)
   GP<uint32_t> recEv;          // event of each ordered outbox position
@@ -329,7 +329,8 @@ struct EngineDev {
   GP<uint32_t> tileHist;       // [maxTiles][D]
   GP<uint32_t> binBase;        // [D] position of this phase's first record inside each bucket
   // scan scratch
-  GP<unsigned long long> scanPartials;
+  GP<unsigned long long> scanPartials;  // [SCAN_GRID] chunk sums of the running scan
+  GP<uint32_t> scanFlags;               // [SCAN_GRID] Globals::scanSeq of the launch that wrote the chunk sum
   // node-range sharding of ONE simulation over several engines (wg_shard_configure): the scheduler state above
   // is replicated on every shard and evolves identically; node / protocol state is touched only for the nodes
   // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.

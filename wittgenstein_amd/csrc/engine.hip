@@ -45,7 +45,7 @@ struct PingPongHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<PingPongProto, 4>), dim3(GRID_DELIVER_SMALL, g.R), dim3(256), 0, g.stream, g.tab,
-                       (const PingPongProto::State*)g.stab, 0);
+                       (const PingPongProto::State*)g.stab);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
@@ -511,6 +511,7 @@ void Engine::ensure_device() {
   uint64_t payloadWords = cfg.payload_words > 0 ? (uint64_t)cfg.payload_words : (1u << 16);
 
   dev.g = dalloc<Globals>(1);
+  dev.ctl = dalloc<DevCtl>(1, true, AC_SCRATCH);
 #ifdef WG_KPROF
   gh.kprofBuf = dalloc<unsigned long long>((size_t)KPROF_WAVES * 32);
 #endif
@@ -577,7 +578,6 @@ void Engine::ensure_device() {
   }
   dev.active = dalloc<uint32_t>(n, true, AC_SCRATCH);
   dev.activeB = dalloc<VisitDesc>(n, true, AC_SCRATCH);
-  dev.activeM = dalloc<MineDesc>(n, false, AC_SCRATCH);
   dev.maxOut = maxOut;
   dev.outTmp = dalloc<Out>(maxOut, false, AC_SCRATCH);
   dev.recEv = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
@@ -587,6 +587,7 @@ void Engine::ensure_device() {
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D, true, AC_SCRATCH);
   dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID, true, AC_SCRATCH);
+  dev.scanFlags = dalloc<uint32_t>(SCAN_GRID, true, AC_SCRATCH);
   dev.farBuf = nullptr;
   dev.farCap = 0;
   if (farCapacity > 0) {
@@ -958,8 +959,7 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 
 template <class F>
 void Engine::scan(const Group& g, const typename F::Aux* atab) {
-  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
-  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  hipLaunchKernelGGL(k_scan<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
 template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
@@ -975,10 +975,12 @@ template void Engine::scan<MultiF>(const Group&, const int*);
 // multisplit of the ordered outbox (fin/arr, g->nOut) into the buckets. The per-tile histograms are
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
-void Engine::append_phase(const Group& g, bool needHist) {
+void Engine::append_phase(const Group& g, bool needHist, bool reserved, int endMode) {
   if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
-  hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
-  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  // (reserved: the producer of the ordered outbox has reserved the buckets' pages in its last block already)
+  if (!reserved) hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
+  // endMode 1 / 2: k_scatter's last block also ends the drain / the conditional-task phase (end_phase_body)
+  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, endMode);
 }
 void Engine::end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
@@ -1235,9 +1237,11 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
       ProfScope ps(lead, Engine::PC_ORDER);
       Engine::scan<RecsF>(g, nullptr);
     }
+    // where nothing adds to the tile histograms after `resolve`, its last block reserves the buckets' pages itself
+    const bool fuseReserve = lead.dev.maxSendAll == 0;
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
+      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, fuseReserve ? 1 : 0);
     }
     if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
       ProfScope ps(lead, Engine::PC_RESOLVE);
@@ -1247,20 +1251,12 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
-      Engine::append_phase(g, false);
-    }
-    {
-      ProfScope ps(lead, Engine::PC_END);
-      Engine::end_phase(g, true);
+      Engine::append_phase(g, false, fuseReserve, 1);  // ... and k_scatter's last block ends the drain: now++
     }
     if (cond) {
-      proto->launch_cond(lead, g);
-      {
-        ProfScope ps(lead, Engine::PC_APPEND);
-        Engine::append_phase(g, false);
-      }
-      ProfScope ps(lead, Engine::PC_END);
-      Engine::end_phase(g, false);
+      const bool reserved = proto->launch_cond(lead, g);
+      ProfScope ps(lead, Engine::PC_APPEND);
+      Engine::append_phase(g, false, reserved, 2);
     }
   }
 
@@ -1545,7 +1541,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     uint32_t nOut = 0;
     await_counts(gfield(&Globals::nOut), nullptr, &nOut, nullptr);
     if (nOut) {
-      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab, 0);
       exchange_outbox(nOut);
       if (dev.maxSendAll) {  // the Network.sendAll calls among them: destinations, envelopes, first arrivals — on every shard
         hipLaunchKernelGGL(k_sendall_lat, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab);
@@ -2389,7 +2385,7 @@ struct HandelHost : ProtoHost {
       default: launch_a1<4>(g, stab, R);
     }
   }
-  void launch_cond(Engine& profOwner, const Group& g) override {
+  bool launch_cond(Engine& profOwner, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
@@ -2399,6 +2395,7 @@ struct HandelHost : ProtoHost {
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
     hipLaunchKernelGGL(k_handel_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    return true;  // (k_handel_cond_a2<false>'s last block: col_reserve_body)
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
@@ -2668,7 +2665,7 @@ struct GsfHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
-  void launch_cond(Engine& profOwner, const Group& g) override {
+  bool launch_cond(Engine& profOwner, const Group& g) override {
     const GsfState* stab = (const GsfState*)g.stab;
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
@@ -2678,6 +2675,7 @@ struct GsfHost : ProtoHost {
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
     hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    return false;
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
@@ -2707,7 +2705,7 @@ struct GsfHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
-                       (const GsfState*)g.stab, 0);
+                       (const GsfState*)g.stab);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_gsf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,
@@ -2809,7 +2807,7 @@ struct SfHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<SfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
-                       (const SfState*)g.stab, 0);
+                       (const SfState*)g.stab);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
@@ -2966,7 +2964,7 @@ struct CasperHost : ProtoHost {
       hipLaunchKernelGGL(k_casper_mark, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
       hipLaunchKernelGGL(k_casper_seq, dim3(1, g.R), dim3(64), 0, g.stream, g.tab, stab);
     }
-    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
@@ -3052,7 +3050,7 @@ struct FloodHost : ProtoHost {
   bool supports_shards() const override { return true; }
   void launch_deliver(const Group& g) override {
     hipLaunchKernelGGL((k_deliver<FloodProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
-                       (const FloodState*)g.stab, 0);
+                       (const FloodState*)g.stab);
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }

@@ -44,7 +44,9 @@ struct ProtoHost {
   virtual bool has_cond() const { return false; }
   // conditional-task phase at the time++ edge -> t (C/Network.java:543-566); emits into the ordered
   // outbox (fin/arr, g->nOut) and g->nDraws. Only called when has_cond().
-  virtual void launch_cond(Engine& profOwner, const Group&) {}
+  // the conditional-task phase of the edge; true = its last kernel reserved the arrival buckets' pages (col_reserve_body in its
+  // last block), so the append needs no k_col_reserve launch
+  virtual bool launch_cond(Engine& profOwner, const Group&) { return false; }
   virtual void launch_deliver(const Group&) = 0;
   virtual size_t state_size() const = 0;        // sizeof the device State struct ...
   virtual const void* state_host() const = 0;   // ... and its host copy (what a Group's stab holds)
@@ -178,7 +180,7 @@ class Engine {
   void ensure_device();          // allocate device state once the node count is known
   void sync_globals_to_host();
   void sync_globals_to_device();
-  static void append_phase(const Group& g, bool needHist);  // multisplit of the ordered outbox into the buckets
+  static void append_phase(const Group& g, bool needHist, bool reserved = false, int endMode = 0);  // multisplit of the ordered outbox into the buckets
   static void end_phase(const Group& g, bool drained);
   template <class F>
   static void scan(const Group& g, const typename F::Aux* atab);

@@ -239,10 +239,8 @@ __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain
 }
 
 // ------------------------------------------------------------------------------------------------
-// Device-wide exclusive scan of F(i), i in [0, F.count()), as two launches with no inter-block
-// communication: (1) per-block partial sums of a contiguous chunk, (2) every block re-sums the
-// partials before it, scans its chunk and calls F.write(i, exclusive_prefix). Values are uint64 so a
-// pair of 32-bit counters can be scanned at once.
+// Device-wide exclusive scan of F(i), i in [0, F.count()): every block owns a contiguous chunk. Values are uint64 so
+// a pair of 32-bit counters can be scanned at once.
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_GRID = 240 / WG_GRID_DIV;  // blocks per ENGINE (grid.x; a batch multiplies it by its members in grid.y): a multiple of
                                                // the 8 XCDs that keeps a block's chunk of a typical ms's events at a few SCAN_BLOCK rounds
@@ -265,14 +263,14 @@ __device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t* sh) {
   return t;
 }
 
-// exclusive scan of one uint32 per thread over a 1024-thread block; *total = block sum
+// exclusive scan of one uint32 per thread over a block of up to 1024 threads (sh16: 16 words); *total = block sum
 __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t* sh16, uint32_t* total) {
   const uint32_t incl = wave_incl_scan32(v);
   int w = threadIdx.x >> 6;
   if (WG_LANE == 63) sh16[w] = incl;
   __syncthreads();
   uint32_t woff = 0, tot = 0;
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
     uint32_t x = sh16[k];
     if (k < w) woff += x;
     tot += x;
@@ -289,8 +287,8 @@ __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t*
   const EngineDev& d = (tab)[blockIdx.y];      \
   if (d.halted) return
 
-// k_scan2 re-evaluates F::value(i); a functor whose value is expensive may take a `first` flag and reuse what the
-// first evaluation (k_scan1) left behind (ExpandF: chain run lengths)
+// the scan evaluates F::value(i) twice (chunk sum, then the scan proper); a functor whose value is expensive may take a
+// `first` flag and reuse what the first evaluation left behind (ExpandF: chain run lengths)
 template <class F>
 __device__ __forceinline__ auto scan_value_again(const F& f, uint32_t i) -> decltype(f.value(i, false)) {
   return f.value(i, false);
@@ -300,41 +298,46 @@ __device__ __forceinline__ uint64_t scan_value_again(const F& f, uint32_t i, X..
   return f.value(i);
 }
 
+// One launch: every block (1) sums its chunk and publishes the sum tagged with the launch's sequence number, (2) waits
+// for the sums of the blocks before it — they have lower workgroup ids, so they were dispatched earlier and are running
+// or done: the wait cannot deadlock — and (3) scans its chunk from that prefix, calling F.write(i, exclusive_prefix).
+// The tag (DevCtl::scanSeq, bumped by the last block to leave) makes stale sums of earlier launches unreadable, so
+// nothing is reset between launches. (As two launches — sums, then scan — each device-wide scan cost a kernel
+// boundary more: three of them per simulated ms.)
 template <class F>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
   const F f(d, atab ? atab + blockIdx.y : nullptr);
   unsigned long long WG_G* partials = d.scanPartials;
+  uint32_t WG_G* flags = d.scanFlags;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
+  __shared__ uint64_t shw[SCAN_BLOCK / 64];
+  __shared__ uint32_t shSeq;
+  if (threadIdx.x == 0) shSeq = __hip_atomic_load(&d.ctl->scanSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  __syncthreads();
+  const uint32_t seq = shSeq;
   uint32_t n = f.count(), lo, hi;
   scan_range(n, lo, hi);
   uint64_t acc = 0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
-  uint64_t tot = block_sum64(acc, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+  const uint64_t tot = block_sum64(acc, sh);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   f.tally(lo, hi);
-}
-
-// f.write(i, exclusive_prefix, valid) is called by every thread of the block at the same point (valid
-// = i is in range), so write() may use wave-level collectives.
-template <class F>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
-  WG_ENGINE(tab);
-  const F f(d, atab ? atab + blockIdx.y : nullptr);
-  const unsigned long long WG_G* partials = d.scanPartials;
-  __shared__ uint64_t sh[SCAN_BLOCK / 64];
-  __shared__ uint64_t shw[SCAN_BLOCK / 64];
-  uint32_t n = f.count(), lo, hi;
-  scan_range(n, lo, hi);
-  uint64_t before = 0, all = 0;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += SCAN_BLOCK) {
-    uint64_t p = partials[b];
-    all += p;
-    if (b < blockIdx.x) before += p;
+  uint64_t before = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_BLOCK) {
+    while (__hip_atomic_load(&flags[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+    before += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   uint64_t prefix = block_sum64(before, sh);
-  uint64_t total = block_sum64(all, sh);
-  if (blockIdx.x == 0 && threadIdx.x == 0) f.total(total);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) f.total(prefix + tot);
   int w = threadIdx.x >> 6;
   for (uint32_t base = lo; base < hi; base += SCAN_BLOCK) {
     uint32_t i = base + threadIdx.x;
@@ -351,6 +354,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restric
     f.write(i, prefix + woff + incl - v, i < hi);
     prefix += tile;
     __syncthreads();
+  }
+  // the last block to leave opens the next launch's sequence number
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd((uint32_t*)&d.ctl->scanDone, 1u) == gridDim.x - 1) {  // (`F` is the functor here, not the cast helper)
+      d.ctl->scanDone = 0;
+      __hip_atomic_store(&d.ctl->scanSeq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -394,7 +406,7 @@ struct ExpandF {
   __device__ uint32_t task_bound(const Rec& r) const {
     return d.boundTask[r.w2 < 3u ? r.w2 : 3u] + (rec_kind(r) == K_PERIODIC ? 1u : 0u);
   }
-  // The run length of chain record i is needed three times (k_scan1's sum, k_scan2's scan and its write): the
+  // The run length of chain record i is needed three times (the chunk sum, the scan and its write): the
   // first evaluation parks it in recEv[i] — scratch of the later `order` phase, idle during expand — for the other two.
   __device__ uint32_t runlen_first(uint32_t i, const Rec& r) const {
     const uint32_t len = runlen(r, now());
@@ -614,6 +626,9 @@ struct RecsF {
   }
 };
 
+__device__ __forceinline__ bool tail_is_mine(uint32_t WG_G* counter);
+__device__ __forceinline__ void col_reserve_body(const EngineDev& d);
+
 // ------------------------------------------------------------------------------------------------
 // resolve: unordered outbox -> ordered outbox (fin, arr). One thread per record.
 // Network.send / createMessageArrival(s) (C/Network.java:369-382,418-487).
@@ -698,8 +713,10 @@ __device__ __forceinline__ bool park_far(const EngineDev& d, int32_t t, uint32_t
 // SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
 // emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
+// reserve: the block that finishes last also reserves the arrival buckets' pages (col_reserve_body) — not where a
+// later kernel still adds to the tile histograms (the sendAll resolution) and not on a sharded engine
 template <bool SH>
-__global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab) {
+__global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab, int reserve) {
   WG_ENGINE(tab);
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
@@ -843,6 +860,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
     // per-tile arrival histogram of the multisplit (rows are zero on entry: k_scatter re-zeroes them)
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
   }
+  if (!SH && reserve && tail_is_mine(&d.ctl->tailDone)) col_reserve_body(d);
 }
 
 // sharded engine: the summed exchange image -> ordered outbox + tile histograms, identically on every shard
@@ -1036,27 +1054,27 @@ __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict_
   }
 }
 
-// single block: per-bin exclusive prefix over tiles (in place), then reserve pages for every bucket
-// that grows (MessageStorage.ensureSize analogue) and publish each bucket's append base.
-__global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restrict__ tab) {
-  WG_ENGINE(tab);
+// One block: per-bin exclusive prefix over tiles (in place), then reserve pages for every bucket that grows
+// (MessageStorage.ensureSize analogue) and publish each bucket's append base. Run by a block of its own (k_col_reserve)
+// or by the LAST block of the kernel that built the tile histograms (tail_is_mine): a kernel boundary less per phase.
+__device__ __forceinline__ void col_reserve_body(const EngineDev& d) {
   __shared__ uint32_t shNeed[16];
   __shared__ uint32_t shBase;
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
-  for (uint32_t b0 = 0; b0 < D; b0 += 1024) {
+  for (uint32_t b0 = 0; b0 < D; b0 += blockDim.x) {
     uint32_t b = b0 + threadIdx.x;
     uint32_t add = 0;
     if (b < D) {
       // in-place exclusive prefix over the tiles of this bin, eight tiles a round: the loads of a round are issued
       // together (one at a time, each iteration waited a memory round trip — the millisecond in which every node
-      // disseminates has hundreds of tiles, and this is a one-block kernel)
+      // disseminates has hundreds of tiles, and this is one block)
       uint32_t tile = 0;
       for (; tile + 8 <= nTiles; tile += 8) {
         uint32_t h[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) h[q] = d.tileHist[(size_t)(tile + q) * D + b];
+        for (int q = 0; q < 8; q++) h[q] = __hip_atomic_load(&d.tileHist[(size_t)(tile + q) * D + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           d.tileHist[(size_t)(tile + q) * D + b] = add;
@@ -1064,7 +1082,7 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
         }
       }
       for (; tile < nTiles; tile++) {
-        uint32_t h = d.tileHist[(size_t)tile * D + b];
+        uint32_t h = __hip_atomic_load(&d.tileHist[(size_t)tile * D + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         d.tileHist[(size_t)tile * D + b] = add;
         add += h;
       }
@@ -1101,14 +1119,37 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  col_reserve_body(d);
+}
+// true for exactly one block of the launch (per engine): the last one to get here. Every block calls it once, after
+// its own work; the caller's block then sees what all the others wrote before their call.
+__device__ __forceinline__ bool tail_is_mine(uint32_t WG_G* counter) {
+  __shared__ uint32_t shLast;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const uint32_t k = atomicAdd(F(counter), 1u);
+    shLast = k == gridDim.x - 1;
+    if (shLast) *counter = 0;  // (the next launch that counts starts after this one has ended)
+  }
+  __syncthreads();
+  const bool last = shLast != 0;
+  if (last) __threadfence();
+  return last;
+}
 
-__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits) {
+// endMode: 0 = the append alone (host-staged envelopes); 1 / 2 = the block that finishes last also ends the phase
+// (end_phase_body: after a drain / after a conditional-task phase) — what k_end_phase did as a launch of its own
+__device__ __forceinline__ void end_phase_body(const EngineDev& d, int drained);
+__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits, int endMode) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
   uint32_t n = d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
-  if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) return;
+  if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) nTiles = 0;
   for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
     for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
     __syncthreads();
@@ -1124,6 +1165,7 @@ __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ 
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < D; b += TILE) d.tileHist[(size_t)tile * D + b] = 0;  // for the next phase
   }
+  if (endMode && tail_is_mine(&d.ctl->scatterDone)) end_phase_body(d, endMode == 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1355,8 +1397,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __res
 // ------------------------------------------------------------------------------------------------
 // end of a phase: advance rd by the draws consumed, reset scratch counters; after a drain also
 // release the bucket's pages and bump the nextMessage() epoch if anything was polled.
-__global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
-  WG_ENGINE(tab);
+__device__ __forceinline__ void end_phase_body(const EngineDev& d, int drained) {
   __shared__ uint32_t shTop;
   Globals WG_G* g = d.g;
   const int32_t t = g->now;
@@ -1399,12 +1440,15 @@ __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__
     g->nEvents = 0;
     g->nActive = 0;
     g->nActiveB = 0;
-    g->nActiveM = 0;
     g->outSlots = 0;
     g->nOut = 0;
     g->nDraws = 0;
     g->rejectSeen = 0;
   }
+}
+__global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
+  WG_ENGINE(tab);
+  end_phase_body(d, drained);
 }
 
 // Idle stretches (protocols without conditional tasks): an empty bucket's ms does nothing (nextMessage just moves the
@@ -1684,45 +1728,11 @@ struct HasVisitSkip<P, decltype((void)&P::visit_skip)> {
   static constexpr bool value = true;
 };
 
-// A protocol whose node header is one record can have it fetched ahead of the visit (P::Pre, P::prefetch,
-// P::node_begin_pre): the loop below then overlaps the descriptor and header loads of the NEXT visit with the memory
-// round trip of the current visit's action(), instead of paying them as two more dependent round trips per visit.
-template <class P, class = void>
-struct HasPrefetch {
-  static constexpr bool value = false;
-};
-template <class P>
-struct HasPrefetch<P, decltype((void)&P::prefetch)> {
-  static constexpr bool value = true;
-};
-
-// the 48-byte visit descriptor in ONE memory instruction (lanes 0..2 take 16 bytes each): the kernel is bound
-// by the number of scattered wave-level memory instructions, not by their bytes
-__device__ __forceinline__ U4 load_desc_raw(const EngineDev& d, uint32_t a) {
-  return ((const U4*)&d.activeB[a])[WG_LANE < 3 ? WG_LANE : 0];
-}
-__device__ __forceinline__ VisitDesc unpack_desc(const U4 q) {
-  VisitDesc vd;
-  vd.node = (int32_t)WG_READLANE(q.x, 0);
-  vd.e0 = (int32_t)WG_READLANE(q.y, 0);
-  vd.next0 = (int32_t)WG_READLANE(q.z, 0);
-  vd.flags = WG_READLANE(q.w, 0);
-  vd.rec0.w0 = WG_READLANE(q.x, 1);
-  vd.rec0.w1 = WG_READLANE(q.y, 1);
-  vd.rec0.w2 = WG_READLANE(q.z, 1);
-  vd.rec0.w3 = WG_READLANE(q.w, 1);
-  vd.aux0.chain = (int32_t)WG_READLANE(q.x, 2);
-  vd.aux0.cpos = (int32_t)WG_READLANE(q.y, 2);
-  vd.aux0.outBase = WG_READLANE(q.z, 2);
-  vd.aux0.outCap = WG_READLANE(q.w, 2);
-  return vd;
-}
-
 // One node visit: receiveUntil's body for the node's events of this ms, in event order. The node registers are loaded
 // (P::node_begin / node_begin_pre) by the caller.
 template <class P>
 __device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename P::State& ps, Ctx& c,
-                                              typename P::NodeRegs& r, const VisitDesc& vd, uint32_t* shSortW, bool useB) {
+                                              typename P::NodeRegs& r, const VisitDesc& vd, uint32_t* shSortW) {
   const int lane = WG_LANE;
   const int32_t node = vd.node;
   const int32_t e0 = vd.e0;
@@ -1795,7 +1805,7 @@ __device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename
       atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
       atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
     }
-    if (!useB) d.head[node] = -1;  // (k_deliver_msgs has emptied the inbox lists already)
+    d.head[node] = -1;
   }
   __builtin_amdgcn_wave_barrier();
   KPROF_MARK(d.g, 3);  // node_end + counters
@@ -1883,10 +1893,10 @@ __device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const ty
   __builtin_amdgcn_wave_barrier();
 }
 
-// WPE: waves per SIMD the register allocation must admit; PIPE: the software-pipelined loop (needs useB and P::prefetch)
-template <class P, int WPE, bool PIPE = false>
+// WPE: waves per SIMD the register allocation must admit
+template <class P, int WPE>
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
-                                                      const typename P::State* __restrict__ stab, int useB) {
+                                                      const typename P::State* __restrict__ stab) {
   WG_ENGINE(tab);
   const typename P::State& ps = stab[blockIdx.y];
   __shared__ typename P::WaveShared shP[4];
@@ -1894,86 +1904,35 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  // useB: k_deliver_msgs ran first and left this kernel the nodes of activeB
-  const uint32_t nActive = useB ? d.g->nActiveB : d.g->nActive;
+  const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
-  if constexpr (PIPE && HasPrefetch<P>::value) {
-    {
-      // Software-pipelined visits: while visit a runs, the header of visit a + nWaves and the descriptor of visit
-      // a + 2 nWaves are in flight. A visit writes no other node's header (effects on other nodes travel as
-      // envelopes, at least one ms later), so fetching the next header early reads what the visit itself would.
-      uint32_t a = wave;
-      if (a >= nActive) return;
-      U4 descCur = load_desc_raw(d, a);
-      typename P::Pre hdrCur = P::prefetch(ps, (int32_t)WG_READLANE(descCur.x, 0));
-      U4 descNext = descCur;
-      if (a + nWaves < nActive) descNext = load_desc_raw(d, a + nWaves);
-      for (;;) {
-        KPROF_DECL;
-        KPROF_COUNT(d.g, 0);
-        const uint32_t an = a + nWaves;
-        const bool haveNext = an < nActive;
-        typename P::Pre hdrNext = hdrCur;
-        U4 descNext2 = descNext;
-        if (haveNext) {
-          hdrNext = P::prefetch(ps, (int32_t)WG_READLANE(descNext.x, 0));
-          if (an + nWaves < nActive) descNext2 = load_desc_raw(d, an + nWaves);
-        }
-        {
-          const VisitDesc vd = unpack_desc(descCur);
-          Ctx c{d, t, vd.node, 0, 0, 0, 0, 0, 0, 0};
-          typename P::NodeRegs r;
-          P::node_begin_pre(c, ps, r, &shP[w], hdrCur);
-          KPROF_MARK(d.g, 31);  // the next visit's prefetches issued, this visit's descriptor + header arrived
-          deliver_visit<P>(d, ps, c, r, vd, shSort[w], true);
-        }
-        if (!haveNext) break;
-        a = an;
-        descCur = descNext;
-        hdrCur = hdrNext;
-        descNext = descNext2;
-      }
-      return;
-    }
-  }
   for (uint32_t a = wave; a < nActive; a += nWaves) {
     KPROF_DECL;
     KPROF_COUNT(d.g, 0);
     VisitDesc vd;
-    if (useB) {
-      vd = unpack_desc(load_desc_raw(d, a));
-    } else {
-      vd.node = (int32_t)d.active[a];
-      vd.e0 = d.head[vd.node];  // newest event of the node (always >= 0 for a listed node)
-      vd.flags = (d.nodes.down[vd.node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[vd.node] << 8 : 0u);
-    }
+    vd.node = (int32_t)d.active[a];
+    vd.e0 = d.head[vd.node];  // newest event of the node (always >= 0 for a listed node)
+    vd.flags = (d.nodes.down[vd.node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[vd.node] << 8 : 0u);
     const int32_t node = vd.node;
     if constexpr (HasVisitSkip<P>::value) {
       if (P::visit_skip(d, ps, node)) {
-        if (lane == 0 && !useB) d.head[node] = -1;
+        if (lane == 0) d.head[node] = -1;
         continue;
       }
     }
     Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
     typename P::NodeRegs r;
     P::node_begin(c, ps, r, &shP[w]);
-    if (!useB) {
-      vd.next0 = d.evNext[vd.e0];
-      vd.rec0 = d.ev[vd.e0];
-      vd.aux0 = d.evAux[vd.e0];
-    }
-    deliver_visit<P>(d, ps, c, r, vd, shSort[w], useB != 0);
+    vd.next0 = d.evNext[vd.e0];
+    vd.rec0 = d.ev[vd.e0];
+    vd.aux0 = d.evAux[vd.e0];
+    deliver_visit<P>(d, ps, c, r, vd, shSort[w]);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-per-node delivery of message-only nodes. Most events of a Handel-class run are messages whose
-// action() only files the payload into the receiver's queue (onNewSig): a few dependent scalar accesses
-// and a copy. One wavefront per node keeps ONE such chain in flight per wave; here every lane owns a node
-// (64 chains in flight per wave) and walks its <= 4 events in event order; payloads wider than one word
-// are copied afterwards by the whole wavefront (coalesced). Nodes with a task, a chain hop or more than
-// 4 events go to activeB for k_deliver. Protocols opt in with P::LANE_MSGS and provide
-//   LaneNode, lane_begin / lane_message / lane_end     (action() of a message that emits nothing)
+// A payload copy a lane-per-node kernel hands to its whole wavefront (k_handel_lane: SendSigs payloads wider than one
+// word are copied coalesced after the lanes' scalar work).
 #ifndef WG_COPY_UNROLL
 #define WG_COPY_UNROLL 4  // words a lane has in flight per round of the wide-payload copy
 #endif
@@ -1983,377 +1942,6 @@ struct CopyJob {
   int32_t nw;
   int32_t pad;
 };
-
-template <class P>
-__global__ void __launch_bounds__(256) k_deliver_msgs(const EngineDev* __restrict__ tab,
-                                                      const typename P::State* __restrict__ stab) {
-  WG_ENGINE(tab);
-  const typename P::State& ps = stab[blockIdx.y];
-  __shared__ CopyJob shJobs[4][256];
-  const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nActive = d.g->nActive;
-  const int32_t t = d.g->now;
-  for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
-    KPROF_DECL;
-    KPROF_COUNT(d.g, 24);
-    const uint32_t a = base + lane;
-    const bool have = a < nActive;
-    const int32_t node = have ? (int32_t)d.active[a] : 0;
-    // the node's events, sorted by event index (the inbox list is in link order)
-    uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-    bool mine = have;
-    // (the first event's record as plain locals: a VisitDesc filled piecemeal inside the loop would live in scratch memory)
-    uint32_t vflags = 0;
-    int32_t e0 = -1, next0 = -1;
-    Rec rec0 = make_rec(K_MSG, 0, 0, 0, 0);
-    EvAux aux0;
-    aux0.chain = -1;
-    aux0.cpos = 0;
-    aux0.outBase = 0;
-    aux0.outCap = 0;
-    if (have) {
-      int32_t e = d.head[node];
-      d.head[node] = -1;  // the list is consumed here (k_deliver works from the descriptor and evNext)
-      vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
-      e0 = e;
-      int cnt = 0;
-      while (e >= 0 && cnt < 4) {
-        uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
-        if (v < s0) { uint32_t x = s0; s0 = v; v = x; }
-        if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
-        if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
-        if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
-        const Rec rc = gld(d.ev + e);
-        const EvAux ax = gld(d.evAux + e);
-        const int32_t nx = d.evNext[e];
-        if (cnt == 0) {
-          rec0 = rc;
-          aux0 = ax;
-          next0 = nx;
-        }
-        if (rec_kind(rc) != K_MSG || ax.chain >= 0) mine = false;
-        cnt++;
-        e = nx;
-      }
-      if (e >= 0) mine = false;  // more than 4 events
-    }
-    {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
-      const bool toB = have && !mine;
-      const uint64_t m = __ballot(toB);
-      if (m) {
-        uint32_t bb = 0;
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
-        bb = lane_bcast(bb, leader);
-        if (toB) {
-          VisitDesc vd;
-          vd.node = node;
-          vd.e0 = e0;
-          vd.next0 = next0;
-          vd.flags = vflags;
-          vd.rec0 = rec0;
-          vd.aux0 = aux0;
-          gst(d.activeB + (bb + __popcll(m & lanes_lt())), vd);
-        }
-      }
-    }
-    typename P::LaneNode r;
-    const bool toDown = (vflags & VD_DOWN) != 0;
-    const uint8_t toPart = (uint8_t)(vflags >> 8);
-    KPROF_MARK(d.g, 25);  // inbox walk + classification
-    if (mine) P::lane_begin(d, ps, node, r);
-    long long nRecv = 0, bRecv = 0;
-    uint32_t nJobs = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t e = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
-      CopyJob job;
-      job.nw = 0;
-      if (mine && e != 0xFFFFFFFFu) {
-        const Rec rec = d.ev[e];
-        const int32_t from = rec_from(rec);
-        uint32_t flags = 0;
-        if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
-          nRecv++;
-          bRecv += P::msg_size(ps, rec.w2);
-          flags = EV_DELIVERED | ((uint32_t)P::msg_level(rec.w2) << 24);
-          P::lane_message(d, ps, t, node, r, from, rec.w2, rec.w3, job);
-        }
-        EvRes res;
-        res.nrec = flags;
-        res.ndraw = 0;
-        d.evRes[e] = res;
-      }
-      const uint64_t jm = __ballot(job.nw > 0);
-      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
-      nJobs += (uint32_t)__popcll(jm);
-    }
-    if (mine) {
-      P::lane_end(d, ps, node, r);
-      if (nRecv) {
-        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
-        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_MARK(d.g, 26);  // the lanes' messages
-    KPROF_ADD(d.g, 28, nJobs);
-    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
-    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
-    // after the other, and up to a few dozen jobs a wavefront.
-    uint32_t totalWords = 0;
-    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
-      const uint32_t j = base0 + (uint32_t)lane;
-      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
-      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
-      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
-      totalWords += lane_bcast(incl, 63);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
-      uint64_t v[WG_COPY_UNROLL];
-      uint64_t WG_G* dp[WG_COPY_UNROLL];
-#pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++) {
-        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
-        dp[u] = nullptr;
-        v[u] = 0;
-        if (idx < totalWords) {
-          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
-          while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)shJobs[w][mid].pad <= idx)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          const CopyJob job = shJobs[w][lo];
-          const uint32_t off = idx - (uint32_t)job.pad;
-          v[u] = job.src[off];
-          dp[u] = job.dst + off;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++)
-        if (dp[u]) *dp[u] = v[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_ADD(d.g, 29, totalWords);
-    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
-  }
-}
-
-template <class P>
-__global__ void __launch_bounds__(256) k_msgs_classify(const EngineDev* __restrict__ tab,
-                                                      const typename P::State* __restrict__ stab) {
-  WG_ENGINE(tab);
-  const typename P::State& ps = stab[blockIdx.y];
-  const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nActive = d.g->nActive;
-  const int32_t t = d.g->now;
-  for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
-    KPROF_DECL;
-    KPROF_COUNT(d.g, 24);
-    const uint32_t a = base + lane;
-    const bool have = a < nActive;
-    const int32_t node = have ? (int32_t)d.active[a] : 0;
-    // the node's events, sorted by event index (the inbox list is in link order)
-    uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-    bool mine = have;
-    // (the first event's record as plain locals: a VisitDesc filled piecemeal inside the loop would live in scratch memory)
-    uint32_t vflags = 0;
-    int32_t e0 = -1, next0 = -1;
-    Rec rec0 = make_rec(K_MSG, 0, 0, 0, 0);
-    EvAux aux0;
-    aux0.chain = -1;
-    aux0.cpos = 0;
-    aux0.outBase = 0;
-    aux0.outCap = 0;
-    if (have) {
-      int32_t e = d.head[node];
-      d.head[node] = -1;  // the list is consumed here (k_deliver works from the descriptor and evNext)
-      vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
-      e0 = e;
-      int cnt = 0;
-      while (e >= 0 && cnt < 4) {
-        uint32_t v = (uint32_t)e;  // insert into the sorted quadruple
-        if (v < s0) { uint32_t x = s0; s0 = v; v = x; }
-        if (v < s1) { uint32_t x = s1; s1 = v; v = x; }
-        if (v < s2) { uint32_t x = s2; s2 = v; v = x; }
-        if (v < s3) { uint32_t x = s3; s3 = v; v = x; }
-        const Rec rc = gld(d.ev + e);
-        const EvAux ax = gld(d.evAux + e);
-        const int32_t nx = d.evNext[e];
-        if (cnt == 0) {
-          rec0 = rc;
-          aux0 = ax;
-          next0 = nx;
-        }
-        if (rec_kind(rc) != K_MSG || ax.chain >= 0) mine = false;
-        cnt++;
-        e = nx;
-      }
-      if (e >= 0) mine = false;  // more than 4 events
-    }
-    {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
-      const bool toB = have && !mine;
-      const uint64_t m = __ballot(toB);
-      if (m) {
-        uint32_t bb = 0;
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
-        bb = lane_bcast(bb, leader);
-        if (toB) {
-          VisitDesc vd;
-          vd.node = node;
-          vd.e0 = e0;
-          vd.next0 = next0;
-          vd.flags = vflags;
-          vd.rec0 = rec0;
-          vd.aux0 = aux0;
-          gst(d.activeB + (bb + __popcll(m & lanes_lt())), vd);
-        }
-      }
-    }
-    {  // the nodes whose events are all plain messages: their sorted events go to k_msgs_apply
-      const uint64_t m = __ballot(mine);
-      if (m) {
-        uint32_t bb = 0;
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveM), (uint32_t)__popcll(m));
-        bb = lane_bcast(bb, leader);
-        if (mine) {
-          MineDesc md;
-          md.node = node;
-          md.flags = vflags;
-          md.s0 = s0;
-          md.s1 = s1;
-          md.s2 = s2;
-          md.s3 = s3;
-          md.pad0 = md.pad1 = 0;
-          gst(d.activeM + (bb + __popcll(m & lanes_lt())), md);
-        }
-      }
-    }
-    KPROF_MARK(d.g, 25);  // inbox walk + classification
-  }
-}
-
-// ... the second half of k_deliver_msgs as a kernel of its own: the nodes k_msgs_classify listed (MineDesc), one lane each.
-// It touches no node k_deliver visits (those went to activeB), emits nothing and draws nothing, so the two run side by
-// side on two streams (HandelHost::launch_deliver): this kernel has a few thousand wavefronts of long dependent chains
-// and leaves the chip mostly idle, k_deliver has the wavefronts to fill it.
-template <class P>
-__global__ void __launch_bounds__(256) k_msgs_apply(const EngineDev* __restrict__ tab,
-                                                    const typename P::State* __restrict__ stab) {
-  WG_ENGINE(tab);
-  const typename P::State& ps = stab[blockIdx.y];
-  __shared__ CopyJob shJobs[4][256];
-  const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nMine = d.g->nActiveM;
-  const int32_t t = d.g->now;
-  for (uint32_t base = wave * 64; base < nMine; base += nWaves * 64) {
-    KPROF_DECL;
-    KPROF_COUNT(d.g, 24);
-    const uint32_t a = base + lane;
-    const bool mine = a < nMine;
-    MineDesc md;
-    md.node = 0;
-    md.flags = 0;
-    md.s0 = md.s1 = md.s2 = md.s3 = 0xFFFFFFFFu;
-    if (mine) md = gld(d.activeM + a);
-    const int32_t node = md.node;
-    const uint32_t vflags = md.flags, s0 = md.s0, s1 = md.s1, s2 = md.s2, s3 = md.s3;
-    typename P::LaneNode r;
-    const bool toDown = (vflags & VD_DOWN) != 0;
-    const uint8_t toPart = (uint8_t)(vflags >> 8);
-    if (mine) P::lane_begin(d, ps, node, r);
-    long long nRecv = 0, bRecv = 0;
-    uint32_t nJobs = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t e = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
-      CopyJob job;
-      job.nw = 0;
-      if (mine && e != 0xFFFFFFFFu) {
-        const Rec rec = d.ev[e];
-        const int32_t from = rec_from(rec);
-        uint32_t flags = 0;
-        if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
-          nRecv++;
-          bRecv += P::msg_size(ps, rec.w2);
-          flags = EV_DELIVERED | ((uint32_t)P::msg_level(rec.w2) << 24);
-          P::lane_message(d, ps, t, node, r, from, rec.w2, rec.w3, job);
-        }
-        EvRes res;
-        res.nrec = flags;
-        res.ndraw = 0;
-        d.evRes[e] = res;
-      }
-      const uint64_t jm = __ballot(job.nw > 0);
-      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
-      nJobs += (uint32_t)__popcll(jm);
-    }
-    if (mine) {
-      P::lane_end(d, ps, node, r);
-      if (nRecv) {
-        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
-        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_MARK(d.g, 26);  // the lanes' messages
-    KPROF_ADD(d.g, 28, nJobs);
-    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
-    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
-    // after the other, and up to a few dozen jobs a wavefront.
-    uint32_t totalWords = 0;
-    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
-      const uint32_t j = base0 + (uint32_t)lane;
-      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
-      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
-      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
-      totalWords += lane_bcast(incl, 63);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
-      uint64_t v[WG_COPY_UNROLL];
-      uint64_t WG_G* dp[WG_COPY_UNROLL];
-#pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++) {
-        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
-        dp[u] = nullptr;
-        v[u] = 0;
-        if (idx < totalWords) {
-          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
-          while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)shJobs[w][mid].pad <= idx)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          const CopyJob job = shJobs[w][lo];
-          const uint32_t off = idx - (uint32_t)job.pad;
-          v[u] = job.src[off];
-          dp[u] = job.dst + off;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++)
-        if (dp[u]) *dp[u] = v[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_ADD(d.g, 29, totalWords);
-    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // RunMultipleTimes' inner loop (C/RunMultipleTimes.java:50-64) kept on the device, so that a batch runs

@@ -1677,6 +1677,8 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       todo &= ~m;
     }
   }
+  // the block that finishes last reserves the arrival buckets' pages (what k_col_reserve does as a launch of its own)
+  if (!SH && tail_is_mine(&d.ctl->tailDone)) col_reserve_body(d);
 }
 
 // ---- sharded engine: the periodic-task snapshots of this ms (Handel SendSigs.sigs, P/Handel.java:254; GSFSignature
