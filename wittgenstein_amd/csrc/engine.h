@@ -329,8 +329,7 @@ struct EngineDev {
   GP<uint32_t> tileHist;       // [maxTiles][D]
   GP<uint32_t> binBase;        // [D] position of this phase's first record inside each bucket
   // scan scratch
-  GP<unsigned long long> scanPartials;  // [SCAN_GRID] chunk sums of the running scan
-  GP<uint32_t> scanFlags;               // [SCAN_GRID] Globals::scanSeq of the launch that wrote the chunk sum
+  GP<unsigned long long> scanPartials;  // [SCAN_GRID][2] chunk sums of the running scan: DevCtl::scanSeq << 32 | half of the sum
   // node-range sharding of ONE simulation over several engines (wg_shard_configure): the scheduler state above
   // is replicated on every shard and evolves identically; node / protocol state is touched only for the nodes
   // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.

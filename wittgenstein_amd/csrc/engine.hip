@@ -586,8 +586,7 @@ void Engine::ensure_device() {
   maxTiles = (maxOut + TILE - 1) / TILE;
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D, true, AC_SCRATCH);
-  dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID, true, AC_SCRATCH);
-  dev.scanFlags = dalloc<uint32_t>(SCAN_GRID, true, AC_SCRATCH);
+  dev.scanPartials = dalloc<unsigned long long>(2 * SCAN_GRID, true, AC_SCRATCH);
   dev.farBuf = nullptr;
   dev.farCap = 0;
   if (farCapacity > 0) {
@@ -2091,7 +2090,10 @@ void Engine::read_i64(int32_t field, int64_t* dst, int32_t n) {
   if (n != (int32_t)hx.size()) throw WgError(WG_EINVAL, "n must equal the node count");
   ensure_device();
   flush_staged(time, false);
-  auto rd64 = [&](const long long* src) { WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n, hipMemcpyDeviceToHost)); };
+  auto rd64 = [&](const long long* src) {
+    WG_HIP(hipMemcpy(dst, src, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    if (proto) proto->node_counter(*this, field, dst, n);  // (a protocol may keep its share of a Node counter in its own records)
+  };
   switch (field) {
     case WG_F_DONE_AT: return rd64(dev.nodes.doneAt);
     case WG_F_MSG_RECEIVED: return rd64(dev.nodes.msgReceived);
@@ -2136,11 +2138,10 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
   h[HH_START] = (uint32_t)startAt[node];
   h[HH_PAIR] = (uint32_t)pairing[node];
   // HLevel() for level 0 (:413-421): own signature everywhere, outgoingFinished = true
-  size_t w = (size_t)node * s.W + (node >> 6);
   uint64_t bit = 1ULL << (node & 63);
-  s.TI[w] |= bit;
-  s.LA[w] |= bit;
-  s.VI[w] |= bit;
+  *h_row(s, node, HK_TI, 0) |= bit;
+  *h_row(s, node, HK_LA, 0) |= bit;
+  *h_row(s, node, HK_VI, 0) |= bit;
   *h_lv(s, node, HP_CTI, 0) = 1;
   *h_lv(s, node, HP_CLA, 0) = 1;
   *h_lv(s, node, HP_CVI, 0) = 1;
@@ -2186,11 +2187,19 @@ __global__ void __launch_bounds__(256) k_handel_ranks_reset(HandelState s) {
 __global__ void k_handel_own_bits(HandelState s) {
   int node = s.lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= s.hi) return;
-  size_t w = (size_t)node * s.W + (node >> 6);
   uint64_t bit = 1ULL << (node & 63);
-  s.TI[w] = bit;
-  s.LA[w] = bit;
-  s.VI[w] = bit;
+  *h_row(s, node, HK_TI, 0) = bit;
+  *h_row(s, node, HK_LA, 0) = bit;
+  *h_row(s, node, HK_VI, 0) = bit;
+}
+
+// read-back: kind k of every owned node as an N-bit row in id order (the layout the reference's BitSets have)
+__global__ void __launch_bounds__(256) k_handel_gather_row(HandelState s, int k, uint64_t* dst) {
+  const size_t n = (size_t)(s.hi - s.lo) * s.W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int32_t node = s.lo + (int32_t)(i / s.W);
+    dst[i] = *h_word(s, node, k, (int)(i % s.W));
+  }
 }
 
 struct HandelHost : ProtoHost {
@@ -2241,11 +2250,7 @@ struct HandelHost : ProtoHost {
     };
     // (wg_restore re-creates the five bit rows — zero but for the node's own signature, k_handel_own_bits — instead of
     // keeping a copy: AC_SCRATCH)
-    st.TI = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
-    st.LA = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
-    st.VI = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
-    st.TV = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
-    st.FP = rows((uint64_t*)nullptr, W, true, Engine::AC_SCRATCH);
+    st.rows = rows((uint64_t*)nullptr, (size_t)W * HK_COUNT, true, Engine::AC_SCRATCH);
     // wg_snapshot / wg_restore: the emission lists are never written; receptionRanks only by `+= nodeCount`
     // (k_handel_cond_a2), which on_restore undoes in place; the verification queues, the dissemination snapshots and the
     // scratch of the conditional-task phase hold nothing before the first event
@@ -2349,7 +2354,7 @@ struct HandelHost : ProtoHost {
   }
   void reset_rows(Engine& e) {
     const size_t nLoc = (size_t)(st.hi - st.lo), at = (size_t)st.lo * st.W;
-    for (uint64_t* row : {st.TI, st.LA, st.VI, st.TV, st.FP}) WG_HIP(hipMemsetAsync(row + at, 0, 8 * nLoc * st.W, e.stream));
+    WG_HIP(hipMemsetAsync(st.rows + at * HK_COUNT, 0, 8 * nLoc * st.W * HK_COUNT, e.stream));
     hipLaunchKernelGGL(k_handel_own_bits, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st);
   }
   bool cont_if(Engine& e, int32_t* out) override {
@@ -2489,17 +2494,42 @@ struct HandelHost : ProtoHost {
   }
   bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {
     if (n != st.N || w != st.W) throw WgError(WG_EINVAL, "shape must be [nodeCount][max(1, nodeCount/64)]");
-    const uint64_t* src = nullptr;
+    int k;
     switch (field) {
-      case WG_B_TOTAL_INCOMING: src = st.TI; break;
-      case WG_B_LAST_AGG_VERIFIED: src = st.LA; break;
-      case WG_B_VERIFIED_IND: src = st.VI; break;
-      case WG_B_TO_VERIFY_IND: src = st.TV; break;
-      case WG_B_FINISHED_PEERS: src = st.FP; break;
+      case WG_B_TOTAL_INCOMING: k = HK_TI; break;
+      case WG_B_LAST_AGG_VERIFIED: k = HK_LA; break;
+      case WG_B_VERIFIED_IND: k = HK_VI; break;
+      case WG_B_TO_VERIFY_IND: k = HK_TV; break;
+      case WG_B_FINISHED_PEERS: k = HK_FP; break;
       default: return false;
     }
     memset(dst, 0, 8 * (size_t)n * w);
-    WG_HIP(hipMemcpy(dst + (size_t)st.lo * w, src + (size_t)st.lo * w, 8 * (size_t)(st.hi - st.lo) * w, hipMemcpyDeviceToHost));
+    const size_t words = (size_t)(st.hi - st.lo) * w;
+    uint64_t* tmp = nullptr;  // the device keeps the five kinds level-major (h_row): gathered into id order here
+    WG_HIP(hipMalloc((void**)&tmp, 8 * words));
+    hipLaunchKernelGGL(k_handel_gather_row, dim3(1024 / WG_GRID_DIV), dim3(256), 0, eng.stream, st, k, tmp);
+    const hipError_t rc = hipMemcpy(dst + (size_t)st.lo * w, tmp, 8 * words, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    WG_HIP(rc);
+    return true;
+  }
+  // Node.msgReceived / msgSent / bytesReceived / bytesSent: what the engine's own arrays hold (host-side sends) plus what
+  // this protocol's visits counted in the header records
+  bool node_counter(Engine& e, int32_t field, int64_t* dst, int32_t n) override {
+    int off;
+    bool wide;
+    switch (field) {
+      case WG_F_MSG_RECEIVED: off = HH_NRECV, wide = false; break;
+      case WG_F_MSG_SENT: off = HH_NSENT, wide = false; break;
+      case WG_F_BYTES_RECEIVED: off = HH_BRECV, wide = true; break;
+      case WG_F_BYTES_SENT: off = HH_BSENT, wide = true; break;
+      default: return false;
+    }
+    const std::vector<uint32_t> h = read_hdr();
+    for (int i = 0; i < n; i++) {
+      const uint32_t* r = &h[(size_t)i * st.hdrStride + off];
+      dst[i] += wide ? (int64_t)((uint64_t)r[0] | ((uint64_t)r[1] << 32)) : (int64_t)r[0];
+    }
     return true;
   }
 };

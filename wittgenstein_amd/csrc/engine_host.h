@@ -44,6 +44,8 @@ struct ProtoHost {
   virtual bool has_cond() const { return false; }
   // conditional-task phase at the time++ edge -> t (C/Network.java:543-566); emits into the ordered
   // outbox (fin/arr, g->nOut) and g->nDraws. Only called when has_cond().
+  // adds the protocol's share of a Node counter (WG_F_MSG_RECEIVED ...) to dst, if it keeps one outside NodeArrays
+  virtual bool node_counter(Engine&, int32_t field, int64_t* dst, int32_t n) { return false; }
   // the conditional-task phase of the edge; true = its last kernel reserved the arrival buckets' pages (col_reserve_body in its
   // last block), so the append needs no k_col_reserve launch
   virtual bool launch_cond(Engine& profOwner, const Group&) { return false; }

@@ -301,15 +301,33 @@ __device__ __forceinline__ uint64_t scan_value_again(const F& f, uint32_t i, X..
 // One launch: every block (1) sums its chunk and publishes the sum tagged with the launch's sequence number, (2) waits
 // for the sums of the blocks before it — they have lower workgroup ids, so they were dispatched earlier and are running
 // or done: the wait cannot deadlock — and (3) scans its chunk from that prefix, calling F.write(i, exclusive_prefix).
-// The tag (DevCtl::scanSeq, bumped by the last block to leave) makes stale sums of earlier launches unreadable, so
-// nothing is reset between launches. (As two launches — sums, then scan — each device-wide scan cost a kernel
-// boundary more: three of them per simulated ms.)
+// Blocks talk through device-scope ATOMIC words only — each half of a sum travels with the tag in one 64-bit word — and
+// never through a fence: on this chip every XCD has its own L2, so a device-scope release / acquire fence means writing
+// back / invalidating that L2 (measured: hundreds of microseconds per launch with a dirty cache), while a relaxed
+// device-scope atomic is simply performed at the memory side. The tag (DevCtl::scanSeq, bumped by the last block to
+// leave) makes stale sums of earlier launches unreadable, so nothing is reset between launches. (As two launches —
+// sums, then scan — each device-wide scan cost a kernel boundary more: three of them per simulated ms.)
+__device__ __forceinline__ void scan_publish(unsigned long long WG_G* slot, uint32_t seq, uint64_t v) {
+  __hip_atomic_store(&slot[0], ((unsigned long long)seq << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&slot[1], ((unsigned long long)seq << 32) | (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t scan_await(const unsigned long long WG_G* slot, uint32_t seq) {
+  unsigned long long lo, hi;
+  for (;;) {
+    lo = __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hi = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(lo >> 32) == seq && (uint32_t)(hi >> 32) == seq) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_sleep(2);
+#endif
+  }
+  return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+}
 template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
   const F f(d, atab ? atab + blockIdx.y : nullptr);
-  unsigned long long WG_G* partials = d.scanPartials;
-  uint32_t WG_G* flags = d.scanFlags;
+  unsigned long long WG_G* partials = d.scanPartials;  // [SCAN_GRID][2]
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   __shared__ uint64_t shw[SCAN_BLOCK / 64];
   __shared__ uint32_t shSeq;
@@ -321,21 +339,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict
   uint64_t acc = 0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
   const uint64_t tot = block_sum64(acc, sh);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&partials[blockIdx.x], (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) scan_publish(partials + 2 * (size_t)blockIdx.x, seq, tot);
   f.tally(lo, hi);
   uint64_t before = 0;
-  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_BLOCK) {
-    while (__hip_atomic_load(&flags[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_s_sleep(1);
-#endif
-    }
-    before += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_BLOCK) before += scan_await(partials + 2 * (size_t)b, seq);
   uint64_t prefix = block_sum64(before, sh);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) f.total(prefix + tot);
   int w = threadIdx.x >> 6;
@@ -355,12 +362,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict
     prefix += tile;
     __syncthreads();
   }
-  // the last block to leave opens the next launch's sequence number
+  // the last block to leave opens the next launch's sequence number (every block has read the old one by then)
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     if (atomicAdd((uint32_t*)&d.ctl->scanDone, 1u) == gridDim.x - 1) {  // (`F` is the functor here, not the cast helper)
-      d.ctl->scanDone = 0;
+      __hip_atomic_store(&d.ctl->scanDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&d.ctl->scanSeq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1123,21 +1129,24 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
   WG_ENGINE(tab);
   col_reserve_body(d);
 }
-// true for exactly one block of the launch (per engine): the last one to get here. Every block calls it once, after
-// its own work; the caller's block then sees what all the others wrote before their call.
+// true for exactly one block of the launch (per engine): the last one to get here. Every block calls it once, after its
+// own work. No fence (see k_scan): what the last block may rely on of the others' work is what they did with device-scope
+// ATOMICS — the wait below makes those atomics complete before this block is counted — plus everything earlier launches
+// wrote; what it writes itself is read by later launches only.
 __device__ __forceinline__ bool tail_is_mine(uint32_t WG_G* counter) {
   __shared__ uint32_t shLast;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): this wave's memory operations, atomics included, have been acknowledged
+#endif
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     const uint32_t k = atomicAdd(F(counter), 1u);
     shLast = k == gridDim.x - 1;
-    if (shLast) *counter = 0;  // (the next launch that counts starts after this one has ended)
+    if (shLast) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next launch that counts starts after this one has ended)
   }
   __syncthreads();
-  const bool last = shLast != 0;
-  if (last) __threadfence();
-  return last;
+  return shLast != 0;
 }
 
 // endMode: 0 = the append alone (host-staged envelopes); 1 / 2 = the block that finishes last also ends the phase
@@ -1811,6 +1820,14 @@ __device__ __forceinline__ void deliver_visit(const EngineDev& d, const typename
   KPROF_MARK(d.g, 3);  // node_end + counters
 }
 
+template <class P, class = void>
+struct HasNodeCounters {
+  static constexpr bool value = false;
+};
+template <class P>
+struct HasNodeCounters<P, decltype((void)&P::node_counters)> {
+  static constexpr bool value = true;
+};
 // ... the same visit for a protocol whose nodes keep their events in inbox lines (EngineDev::inbox): lane k < INBOX_SLOTS
 // of the wavefront holds entry k of the node's line (`mine`; beyond `cnt` it is not looked at), the events beyond the
 // line hang on the node's overflow list. The usual node has 1..4 events: they are ranked by event index among the four
@@ -1879,15 +1896,20 @@ __device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const ty
     }
   }
   __builtin_amdgcn_wave_barrier();
-  P::node_end(c, ps, r);
-  if (lane == 0) {
-    if (nRecv) {
-      atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
-      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
-    }
-    if (c.msgSent) {
-      atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
-      atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+  if constexpr (HasNodeCounters<P>::value) {  // the protocol keeps the Node counters with its own per-node record
+    P::node_counters(c, ps, r, nRecv, bRecv);
+    P::node_end(c, ps, r);
+  } else {
+    P::node_end(c, ps, r);
+    if (lane == 0) {
+      if (nRecv) {
+        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
+        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      }
+      if (c.msgSent) {
+        atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+        atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();

@@ -1,12 +1,14 @@
 // Handel (P/Handel.java) as a resident device protocol.
 //
 // State layout (HBM):
-//   bit rows  TI,LA,VI,TV,FP : [N][W] uint64, W = N/64. Bit j = node id j. HLevel l's bitsets
-//             (totalIncoming, lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers
-//             :373-394) only ever hold ids of the level's aligned sibling block of 2^(l-1) ids
-//             (allSigsAtLevel :671-684), and the blocks of different levels are disjoint, so one row
-//             per kind holds all levels. totalOutgoing of level l is always the union of
-//             totalIncoming of levels < l (:728-731) = the node's OWN aligned block in the TI row.
+//   bit rows  TI,LA,VI,TV,FP : per node 5 x W uint64, W = N/64. HLevel l's bitsets (totalIncoming,
+//             lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers :373-394) only ever hold
+//             ids of the level's aligned sibling block of 2^(l-1) ids (allSigsAtLevel :671-684), and the
+//             blocks of different levels are disjoint, so W words per kind hold all levels. They are laid
+//             out LEVEL-major, kind-minor (h_row): the five bitsets of one level sit side by side — an event
+//             works on ONE level, so what it touches is one line (levels <= 9) or one contiguous run, not a
+//             line in each of five 134 MB arrays. totalOutgoing of level l is always the union of
+//             totalIncoming of levels < l (:728-731) = the node's OWN aligned block (h_word gathers it).
 //   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] emission lists (:510-522)
 //   queues    toVerifyAgg (:385): per (node, level) up to Q slots {from, rank, sig[2^(l-1) bits]} in a
 //             private slab + an order list; a slot stays allocated while a registered
@@ -49,7 +51,7 @@ __device__ __forceinline__ uint32_t h_update_arg(int pk, int lv, int slot, int32
 struct HandelState {
   wg_handel_params p;
   int32_t N, L, W, Q;
-  GP<uint64_t> TI, LA, VI, TV, FP;   // [N][W]
+  GP<uint64_t> rows;                      // [N][W][5], level-major: see h_row
   GP<int32_t> ranks;                      // [N][N]
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
@@ -66,8 +68,11 @@ struct HandelState {
   //   [HH_TOTAL]                 sum over the levels of |totalIncoming| (what `cur.cardinality()` of :745 is after the loop)
   //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
-  //   [HH_CAND +12]              checkSigs' candidate of this edge per level, one BYTE a level: its queue slot (valid where
+  //   [HH_CAND +6]               checkSigs' candidate of this edge per level, one BYTE a level: its queue slot (valid where
   //                              candMask[node] has the level's bit; written by k_handel_a1, read by k_handel_cond_a2)
+  //   [HH_NRECV .. HH_BSENT]     Node.msgReceived / msgSent (32 bits) and bytesReceived / bytesSent (64 bits) of this
+  //                              protocol's deliveries and sends (C/Network.java:476-477,611-612): they change with the words
+  //                              above, in the same line — not as four atomics into four more arrays (read back: node_counter)
   //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
   //   [HH_LV + l*8 + plane]      level-major: the eight scalars of HLevel l side by side (32 bytes, two levels a 64-byte
   //                              line) — posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
@@ -105,7 +110,9 @@ struct HandelState {
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_TOTAL = 7, HH_SPARE = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
-                       HH_PENDFROM = 16, HH_CAND = 20, HH_LV = 32 };
+                       HH_PENDFROM = 16, HH_CAND = 20, HH_NRECV = 26, HH_NSENT = 27, HH_BRECV = 28, HH_BSENT = 30, HH_LV = 32 };
+static_assert(MAX_LEVELS <= 4 * (HH_NRECV - HH_CAND), "a candidate byte per level");
+enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_TV, HK_FP, HK_COUNT };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t WG_G* h_lv(const HandelState& s, int32_t node, int plane, int l) {
@@ -145,11 +152,25 @@ __device__ __forceinline__ int32_t h_peer(const HandelState& s, size_t idx) {
 }
 __device__ __forceinline__ int h_nw(int l) { return l == 0 ? 1 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1); }
 __device__ __forceinline__ int h_qcap(const HandelState& s, int l) { return h_nw(l) >= 16 ? s.Qw : s.Q; }
+// kind k's words of level l's sibling block: h_nw(l) contiguous words. Per node the W words of a kind are split by level
+// — group 0 is the node's own 64-id word (it holds the blocks of the levels 0..6, told apart by Lv::mask), level l >= 7 is
+// its sibling block of 2^(l-7) words, and 2^(l-7) words precede it — and inside a group the five kinds follow each other.
+__device__ __forceinline__ uint64_t WG_G* h_row(const HandelState& s, int32_t node, int k, int l) {
+  const int nw = h_nw(l), before = l <= 6 ? 0 : nw;
+  return s.rows + ((size_t)node * s.W + before) * HK_COUNT + (size_t)k * nw;
+}
+// word x (index in the N-bit row of kind k, any level) of `node`: which level's block it is follows from where x
+// differs from the node's own word index
+__device__ __forceinline__ uint64_t WG_G* h_word(const HandelState& s, int32_t node, int k, int x) {
+  const uint32_t diff = (uint32_t)x ^ (uint32_t)(node >> 6);
+  if (diff == 0) return s.rows + (size_t)node * s.W * HK_COUNT + k;
+  const int nw = 1 << (31 - __clz(diff));  // the sibling block of level 7 + log2(nw)
+  return s.rows + ((size_t)node * s.W + nw) * HK_COUNT + (size_t)k * nw + (x & (nw - 1));
+}
 __device__ __forceinline__ int h_msg_size(int l) { return 1 + ((l == 0 ? 1 : (1 << (l - 1))) / 8) + 96 * 2; }  // :256-260
 
-// word j of a view is owned by lane (bw + j) & 63
-#define H_FOR_WORDS(v, j)                                                                      \
-  for (int j = (int)((WG_LANE - (v).bw) & 63); j < (v).nw; j += 64)
+// word j of a level's block is owned by lane j & 63
+#define H_FOR_WORDS(v, j) for (int j = (int)WG_LANE; j < (v).nw; j += 64)
 
 __device__ __forceinline__ uint64_t ld_coherent(const uint64_t WG_G* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -293,6 +314,21 @@ struct HandelProto {
     }
     store_levels(s, node, r.ls);
   }
+  // Node.msgReceived / bytesReceived / msgSent / bytesSent of a visit (C/Network.java:476-477,611-612) go into the
+  // header's image and are stored with it (node_end), not as atomics into the engine's four counter arrays
+  __device__ static void node_counters(Ctx& c, const State&, NodeRegs& r, long long nRecv, long long bRecv) {
+    if (WG_LANE == 0) {
+      uint32_t* h = r.ls->sc;
+      h[HH_NRECV] += (uint32_t)nRecv;
+      h[HH_NSENT] += (uint32_t)c.msgSent;
+      const unsigned long long br = ((unsigned long long)h[HH_BRECV] | ((unsigned long long)h[HH_BRECV + 1] << 32)) + (unsigned long long)bRecv;
+      const unsigned long long bs = ((unsigned long long)h[HH_BSENT] | ((unsigned long long)h[HH_BSENT + 1] << 32)) + (unsigned long long)c.bytesSent;
+      h[HH_BRECV] = (uint32_t)br;
+      h[HH_BRECV + 1] = (uint32_t)(br >> 32);
+      h[HH_BSENT] = (uint32_t)bs;
+      h[HH_BSENT + 1] = (uint32_t)(bs >> 32);
+    }
+  }
   __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
     KPROF_DECL;
     on_new_sig(c, s, r, from, msg, payload);
@@ -339,7 +375,8 @@ struct HandelProto {
     const int32_t node = c.node;
     const int size = 1 << (l - 1);
     const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
-    const uint64_t WG_G* fp = s.FP + (size_t)node * s.W;
+    const uint64_t WG_G* fp = h_row(s, node, HK_FP, l);  // the level's peers are the ids of its sibling block
+    const int fbw = sib_view(node, l).bw;
     int pos = ls->pos[l];
     const int start = pos;
     int got = 0;
@@ -349,7 +386,7 @@ struct HandelProto {
       int k = WG_LANE;
       bool in = k < len;
       int32_t p = in ? h_peer(s, peers0 + pos + k) : 0;
-      bool ok = in && !row_get(fp, p);
+      bool ok = in && !((ld_coherent(fp + ((p >> 6) - fbw)) >> (p & 63)) & 1ULL);
       uint64_t okm = __ballot(ok);
       // a rejected peer whose successor position is `start` finishes the level (:499-503)
       int nextPos = pos + k + 1;
@@ -393,9 +430,8 @@ struct HandelProto {
     // ring is private to the shard, sends that constant instead of a copy.
     if (c.d.sharded) return H_REF_ONES;
     Lv v = own_view(c.node, l);
-    const uint64_t WG_G* ti = s.TI + (size_t)c.node * s.W;
     uint32_t ref = c.alloc_payload(v.nw);
-    H_FOR_WORDS(v, j) c.d.payload[ref + j] = ti[v.bw + j] & v.mask;
+    H_FOR_WORDS(v, j) c.d.payload[ref + j] = *h_word(s, c.node, HK_TI, v.bw + j) & v.mask;
     return ref | H_REF_RING;
   }
 
@@ -412,16 +448,16 @@ struct HandelProto {
     LevelScalars* ls = r.ls;
     // Everything this event reads from HBM depends only on (node, from, payload): issue it all before the
     // first use so the event costs ONE memory round trip (the path is latency-bound).
-    const int w = from >> 6;
+    const Lv v = sib_view(node, l);
+    const int w = (from >> 6) - v.bw;  // the word of `from` inside the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
-    uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
-    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
+    uint64_t WG_G* fpp = h_row(s, node, HK_FP, l) + w;
+    uint64_t WG_G* vip = h_row(s, node, HK_VI, l) + w;
+    uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
     const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
-    const Lv v = sib_view(node, l);
     const uint64_t WG_G* src = h_payload(c.d, s, payload);
-    const int j0 = (int)((WG_LANE - v.bw) & 63);
+    const int j0 = (int)WG_LANE;
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
     if (has0) pw0 = src[j0] & v.mask;
@@ -495,10 +531,25 @@ struct HandelProto {
     KPROF_DECL;
     const uint64_t openM = __ballot(open);
     if (!openM) return;
+    // snapshots (SendSigs.sigs = totalOutgoing.clone() :254): totalOutgoing of level l is the node's own aligned
+    // block of 2^(l-1) ids, and those blocks are nested — so ONE copy of the highest open level's block serves every
+    // level: level l's message points at its sub-range (the receiver masks single-word blocks with its level mask).
+    // The block's words are requested HERE, before the candidates' finished bits are waited for: the two round trips
+    // overlap (in the millisecond in which every node disseminates this copy is most of the pass's traffic).
+    const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
+    const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
+    uint64_t sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = q * 64 + lane;
+      sv[q] = j < tv.nw ? *h_word(s, node, HK_TI, tv.bw + j) & tv.mask : 0ULL;
+    }
     if (open) {
-      const uint64_t WG_G* fpRow = s.FP + (size_t)node * s.W;
-      const uint64_t w1 = ld_coherent(fpRow + (cand >> 6));
-      const uint64_t w2 = two ? ld_coherent(fpRow + (cand2 >> 6)) : ~0ULL;
+      const uint64_t WG_G* fpRow = h_row(s, node, HK_FP, lane);  // lane = level: the level's sibling block
+      const int fbw = sib_view(node, lane).bw;
+      const uint64_t w1 = ld_coherent(fpRow + ((cand >> 6) - fbw));
+      const uint64_t w2 = two ? ld_coherent(fpRow + ((cand2 >> 6) - fbw)) : ~0ULL;
       fin = (w1 >> (cand & 63)) & 1ULL;
       fin2 = (w2 >> (cand2 & 63)) & 1ULL;
       if (fin && two && !fin2) {  // the first candidate is rejected (no effect but posInLevel++), the second one is taken
@@ -508,21 +559,18 @@ struct HandelProto {
       }
     }
     const bool lf = cti == mySize;  // incomingComplete :524-526
-    // snapshots (SendSigs.sigs = totalOutgoing.clone() :254): totalOutgoing of level l is the node's own aligned
-    // block of 2^(l-1) ids in the TI row, and those blocks are nested — so ONE copy of the highest open level's
-    // block serves every level: level l's message points at its sub-range (the receiver masks single-word
-    // blocks with its level mask). Loads first, stores after.
-    const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
-    const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
-    const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
     {
-      const uint64_t WG_G* ti = s.TI + (size_t)node * s.W + tv.bw;
-      for (int j0 = 0; j0 < tv.nw; j0 += 256) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = q * 64 + lane;
+        if (j < tv.nw) s.snap[refBase + j] = sv[q];
+      }
+      for (int j0 = 256; j0 < tv.nw; j0 += 256) {  // (beyond 16 384 ids per block: N > 32 768)
         uint64_t v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int j = j0 + q * 64 + lane;
-          v[q] = j < tv.nw ? ti[j] & tv.mask : 0ULL;
+          v[q] = j < tv.nw ? *h_word(s, node, HK_TI, tv.bw + j) & tv.mask : 0ULL;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -599,38 +647,38 @@ struct HandelProto {
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
     const Lv v = sib_view(node, lv);
-    uint64_t WG_G* ti = s.TI + (size_t)node * s.W;
-    uint64_t WG_G* la = s.LA + (size_t)node * s.W;
-    uint64_t WG_G* vi = s.VI + (size_t)node * s.W;
+    uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);  // the level's block: word j of it is [j]
+    uint64_t WG_G* la = h_row(s, node, HK_LA, lv);
+    uint64_t WG_G* vi = h_row(s, node, HK_VI, lv);
     const uint64_t WG_G* sig = sig_ptr(s, node, lv, slot);
     // ---- every load of the event, issued before the first use (one memory round trip)
-    const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block
+    const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + wF;
+    uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     const uint64_t tvv = ld_coherent(tvp);
     uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
     const int len = ls->qlen[lv];
     const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
-    const int j0 = (int)((lane - v.bw) & 63);
+    const int j0 = lane;
     const bool has0 = j0 < v.nw;
     uint64_t sg0 = 0, vi0 = 0, la0 = 0, ti0 = 0;
     if (has0) {
       sg0 = sig[j0];
-      vi0 = vi[v.bw + j0];
-      la0 = la[v.bw + j0];
-      ti0 = ti[v.bw + j0];
+      vi0 = vi[j0];
+      la0 = la[j0];
+      ti0 = ti[j0];
     }
-    // the VI / TI words holding `from` are among the block words just loaded (the lane owning row word wF);
+    // the VI / TI words holding `from` are among the block words just loaded (the lane owning block word jF);
     // only beyond the first 64 words of a wide level do they cost memory instructions of their own
     uint64_t viF, tiF;
     if (jF < 64) {
-      viF = lane_bcast64(vi0, wF & 63);
-      tiF = lane_bcast64(ti0, wF & 63);
+      viF = lane_bcast64(vi0, jF);
+      tiF = lane_bcast64(ti0, jF);
     } else {
-      viF = ld_coherent(vi + wF);
-      tiF = ld_coherent(ti + wF);
+      viF = ld_coherent(vi + jF);
+      tiF = ld_coherent(ti + jF);
     }
-    const bool owner = lane == (wF & 63);
+    const bool owner = lane == (jF & 63);
     if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     {
@@ -649,7 +697,7 @@ struct HandelProto {
     // verifiedIndSignatures.set(from); totalIncoming.set(from) if new — applied to the register copies of
     // the words and written back by the owning lane
     if (owner) {
-      if (!hadVI) vi[wF] = viF | bit;
+      if (!hadVI) vi[jF] = viF | bit;
     }
     int cVI = ls->cVI[lv] + (hadVI ? 0 : 1);
     const int cTI0 = ls->cTI[lv];
@@ -669,7 +717,7 @@ struct HandelProto {
     uint64_t acc = 0;
     if (has0) acc = (uint64_t)__popcll(sg0 | (vi0 & v.mask)) | ((uint64_t)((sg0 & la0 & v.mask) != 0) << 32);
     for (int j = j0 + 64; j < v.nw; j += 64) {
-      uint64_t sg = sig[j], viw = vi[v.bw + j] & v.mask, law = la[v.bw + j] & v.mask;
+      uint64_t sg = sig[j], viw = vi[j] & v.mask, law = la[j] & v.mask;
       if (j == jF) viw |= bit;
       acc += (uint64_t)__popcll(sg | viw) | ((uint64_t)((sg & law) != 0) << 32);
     }
@@ -684,25 +732,25 @@ struct HandelProto {
       if (has0) {
         uint64_t nla = (inter ? 0ULL : (la0 & v.mask)) | sg0;
         uint64_t nti = nla | (vi0 & v.mask);
-        if (nla != (la0 & v.mask)) la[v.bw + j0] = (la0 & ~v.mask) | nla;
-        if (nti != (ti0m & v.mask)) ti[v.bw + j0] = (ti0m & ~v.mask) | nti;
+        if (nla != (la0 & v.mask)) la[j0] = (la0 & ~v.mask) | nla;
+        if (nti != (ti0m & v.mask)) ti[j0] = (ti0m & ~v.mask) | nti;
         cnt = (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
       }
       for (int j = j0 + 64; j < v.nw; j += 64) {
         uint64_t sg = sig[j];
-        uint64_t law = la[v.bw + j], viw = vi[v.bw + j], tiw = ti[v.bw + j];
+        uint64_t law = la[j], viw = vi[j], tiw = ti[j];
         if (j == jF) viw |= bit;  // (this lane stored it above; same-lane order makes the reload see it anyway)
         uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
         uint64_t nti = nla | (viw & v.mask);
-        if (nla != (law & v.mask)) la[v.bw + j] = (law & ~v.mask) | nla;
-        if (nti != (tiw & v.mask)) ti[v.bw + j] = (tiw & ~v.mask) | nti;
+        if (nla != (law & v.mask)) la[j] = (law & ~v.mask) | nla;
+        if (nti != (tiw & v.mask)) ti[j] = (tiw & ~v.mask) | nti;
         cnt += (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
       }
       cnt = wave_sum64(cnt);
       cLA = (int)(cnt & 0xFFFFFFFFu);
       cTI = (int)(cnt >> 32);
     } else if (!hadTI && owner) {
-      ti[wF] = tiF | bit;
+      ti[jF] = tiF | bit;
     }
     const int cur = total0 + (cTI - cTI0);  // `cur.cardinality()` of :745 after the loop over the levels
     if (lane == 0) {
@@ -744,11 +792,11 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
     return;
   }
   if (t < r.startAt) return;
-  const int w = from >> 6;
+  const int w = (from >> 6) - sib_view(node, l).bw;  // the word of `from` inside the level's block
   const uint64_t bit = 1ULL << (from & 63);
-  uint64_t WG_G* fpp = s.FP + (size_t)node * s.W + w;
-  const uint64_t WG_G* vip = s.VI + (size_t)node * s.W + w;
-  uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + w;
+  uint64_t WG_G* fpp = h_row(s, node, HK_FP, l) + w;  // (the level's five bitsets side by side: one line up to level 9)
+  const uint64_t WG_G* vip = h_row(s, node, HK_VI, l) + w;
+  uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
   const size_t nl = (size_t)node * s.L + l;
   // every load of the event before the first use
   const uint64_t viv = *vip;
@@ -807,13 +855,13 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   const int32_t from = H_ARG_FROM(arg);
   uint32_t WG_G* hdr = h_hdr(s, node);
   const Lv v = sib_view(node, lv);
-  uint64_t WG_G* ti = s.TI + (size_t)node * s.W + v.bw;
-  uint64_t WG_G* la = s.LA + (size_t)node * s.W + v.bw;
-  uint64_t WG_G* vi = s.VI + (size_t)node * s.W + v.bw;
+  uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);  // (the level's five bitsets side by side: one line up to level 9)
+  uint64_t WG_G* la = h_row(s, node, HK_LA, lv);
+  uint64_t WG_G* vi = h_row(s, node, HK_VI, lv);
   const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
-  const int wF = from >> 6, jF = wF - v.bw;  // `from` lies in the level's block: 0 <= jF < nw
+  const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block: 0 <= jF < nw
   const uint64_t bit = 1ULL << (from & 63);
-  uint64_t WG_G* tvp = s.TV + (size_t)node * s.W + wF;
+  uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
   uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
   // ---- every load of the event (they depend on the task's argument only), before the first use
   const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
@@ -1085,9 +1133,9 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         hdr[HH_DONE_HI] = (uint32_t)((unsigned long long)r.doneAt >> 32);
         d.nodes.doneAt[node] = r.doneAt;
       }
-      if (nRecv) {
-        atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);
-        atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bRecv);
+      if (nRecv) {  // Node.msgReceived / bytesReceived (C/Network.java:611-612), kept in the header record
+        atomicAdd(F(hdr + HH_NRECV), (uint32_t)nRecv);
+        atomicAdd((unsigned long long*)F(hdr + HH_BRECV), (unsigned long long)bRecv);
       }
     }
     {  // deferred fast paths: items of the wave-per-node kernel, behind the node visits
@@ -1222,12 +1270,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
           res.nrec = c.sub | EV_TASK_RUN;
           res.ndraw = c.draws;
           gst(d.evRes + e, res);
-          if (c.msgSent) {
-            atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
-            atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
-          }
         }
-        HandelProto::store_levels(s, node, r.ls);  // posInLevel / outgoingFinished of the levels it sent for
+        HandelProto::node_counters(c, s, r, 0, 0);
+        HandelProto::store_levels(s, node, r.ls);  // posInLevel / outgoingFinished of the levels it sent for, the counters
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -1359,9 +1404,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       const int l = (int)(it >> 24);
       const uint32_t WG_G* hdr = h_hdr(s, node);
       const Lv v = sib_view(node, l);
-      const uint64_t WG_G* ti = s.TI + (size_t)node * s.W + v.bw;
-      const uint64_t WG_G* la = s.LA + (size_t)node * s.W + v.bw;
-      const uint64_t WG_G* vi = s.VI + (size_t)node * s.W + v.bw;
+      const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
+      const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
+      const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
       uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
       // ---- everything the item's address alone decides, before the first use
       const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
@@ -1465,9 +1510,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     const int l = (int)(it >> 24);
     const uint32_t WG_G* hdr = h_hdr(s, node);
     const Lv v = sib_view(node, l);
-    const uint64_t WG_G* ti = s.TI + (size_t)node * s.W;
-    const uint64_t WG_G* la = s.LA + (size_t)node * s.W;
-    const uint64_t WG_G* vi = s.VI + (size_t)node * s.W;
+    const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);  // the level's block: word j of it is [j]
+    const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
+    const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
     uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
     // ---- everything the item's address alone decides, before the first use: header pieces (every lane the same
     // address), the whole list (lane i = entry i) and this lane's word of the three rows
@@ -1476,13 +1521,13 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
     const U4 lvB = gld((const U4 WG_G*)h_lv(s, node, HP_QLEN, l));
     const uint64_t entAll = ent[lane];
-    const int jh = (int)((lane - v.bw) & 63);
+    const int jh = lane;
     const bool oneRound = v.nw <= 64;
     uint64_t tih = 0, vih = 0, lah = 0;
     if (oneRound && jh < v.nw) {
-      tih = ti[v.bw + jh];
-      vih = vi[v.bw + jh];
-      lah = la[v.bw + jh];
+      tih = ti[jh];
+      vih = vi[jh];
+      lah = la[jh];
     }
     const int len = (int)WG_READFIRST(lvB.x), curSize = (int)WG_READFIRST(lvA.y), cLA = (int)WG_READFIRST(lvA.z);
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
@@ -1515,7 +1560,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
         } else {
           const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[u]);
           H_FOR_WORDS(v, j) {
-            const uint64_t sgw = sig[j], tiw = ti[v.bw + j], viw = vi[v.bw + j], law = la[v.bw + j];
+            const uint64_t sgw = sig[j], tiw = ti[j], viw = vi[j], law = la[j];
             a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
             b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
           }
