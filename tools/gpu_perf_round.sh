@@ -17,4 +17,4 @@ print(d["roofline"].get("warmup_phase_device_ms"))
 PY
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/p -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second "$@" > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)
 python tools/prof_summary.py stats $OUT/p $OUT/kernel_stats.md; python tools/prof_summary.py phases $OUT/p $OUT/phases.md; rm -rf $OUT/p
-cut -d'|' -f2,3,4,5,6,12,13,23 $OUT/phases.md | head -24
+cut -d"|" -f2,3,4,5,6,12,13,23 $OUT/phases.md | head -24

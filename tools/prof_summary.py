@@ -65,7 +65,7 @@ def phases(d, out, period=20, chunk=10):
             ch, j = ch + 1, -1
         if ch < 0:
             continue
-        if "k_scan1<" in n and "ExpandF" in n:
+        if ("k_scan1<" in n or "k_scan<" in n) and "ExpandF" in n:  # the first kernel of a simulated ms
             j += 1
         t = chunk * ch + max(j, 0)
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])

@@ -230,14 +230,6 @@ struct Globals {
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
 };
-// Launch bookkeeping that lives on the device only (never mirrored by the host's Globals shadow, untouched by wg_restore):
-struct DevCtl {
-  // device-wide scan (k_scan): the sequence number the blocks tag their chunk sums with, and the blocks that have left
-  uint32_t scanSeq, scanDone;
-  // blocks of a kernel that have finished, for the kernels whose last block does the work of a follow-up single-block
-  // kernel (k_resolve / the protocol's cond tail: page reservation; k_scatter: the end of the phase)
-  uint32_t tailDone, scatterDone;
-};
 constexpr uint32_t KPROF_WAVES = 16384;
 constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)
 
@@ -278,7 +270,6 @@ struct EngineDev {
   uint32_t halted;          // batch member that is not advanced by the current run (RunMultipleTimes: its
                             // continuation predicate turned false); every kernel returns at once for it
   GP<Globals> g;
-  GP<DevCtl> ctl;
   NodeArrays nodes;
   LatencyModel lat;
   int32_t discardTime;
@@ -329,7 +320,7 @@ struct EngineDev {
   GP<uint32_t> tileHist;       // [maxTiles][D]
   GP<uint32_t> binBase;        // [D] position of this phase's first record inside each bucket
   // scan scratch
-  GP<unsigned long long> scanPartials;  // [SCAN_GRID][2] chunk sums of the running scan: DevCtl::scanSeq << 32 | half of the sum
+  GP<unsigned long long> scanPartials;
   // node-range sharding of ONE simulation over several engines (wg_shard_configure): the scheduler state above
   // is replicated on every shard and evolves identically; node / protocol state is touched only for the nodes
   // of [shardLo, shardHi). Not sharded: sharded = 0, range = everything.

@@ -152,6 +152,9 @@ Engine::Engine(const wg_config& c) : cfg(c) {
 
 Engine::~Engine() {
   delete proto;
+  if (evFork) (void)hipEventDestroy(evFork);
+  if (evJoin) (void)hipEventDestroy(evJoin);
+  if (auxStream) (void)hipStreamDestroy(auxStream);
   if (rcclComm) (void)rccl().CommDestroy(rcclComm);
   if (mailbox) (void)hipHostFree((void*)mailbox);
   if (snap) {
@@ -511,7 +514,6 @@ void Engine::ensure_device() {
   uint64_t payloadWords = cfg.payload_words > 0 ? (uint64_t)cfg.payload_words : (1u << 16);
 
   dev.g = dalloc<Globals>(1);
-  dev.ctl = dalloc<DevCtl>(1, true, AC_SCRATCH);
 #ifdef WG_KPROF
   gh.kprofBuf = dalloc<unsigned long long>((size_t)KPROF_WAVES * 32);
 #endif
@@ -586,7 +588,7 @@ void Engine::ensure_device() {
   maxTiles = (maxOut + TILE - 1) / TILE;
   dev.tileHist = dalloc<uint32_t>((size_t)maxTiles * D);  // zero between phases (k_scatter re-zeroes its rows)
   dev.binBase = dalloc<uint32_t>(D, true, AC_SCRATCH);
-  dev.scanPartials = dalloc<unsigned long long>(2 * SCAN_GRID, true, AC_SCRATCH);
+  dev.scanPartials = dalloc<unsigned long long>(SCAN_GRID, true, AC_SCRATCH);
   dev.farBuf = nullptr;
   dev.farCap = 0;
   if (farCapacity > 0) {
@@ -958,7 +960,8 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 
 template <class F>
 void Engine::scan(const Group& g, const typename F::Aux* atab) {
-  hipLaunchKernelGGL(k_scan<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
 template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
@@ -974,12 +977,10 @@ template void Engine::scan<MultiF>(const Group&, const int*);
 // multisplit of the ordered outbox (fin/arr, g->nOut) into the buckets. The per-tile histograms are
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
-void Engine::append_phase(const Group& g, bool needHist, bool reserved, int endMode) {
+void Engine::append_phase(const Group& g, bool needHist) {
   if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
-  // (reserved: the producer of the ordered outbox has reserved the buckets' pages in its last block already)
-  if (!reserved) hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
-  // endMode 1 / 2: k_scatter's last block also ends the drain / the conditional-task phase (end_phase_body)
-  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, endMode);
+  hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
+  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
 }
 void Engine::end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
@@ -1232,15 +1233,29 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
       ProfScope ps(lead, Engine::PC_DELIVER);
       proto->launch_deliver(g);
     }
+    // The first kernels of the conditional-task phase of a protocol that splits it (cond_splits) run on a second stream
+    // from here, beside order / resolve / append / end — a dozen short kernels, each a few dependent round trips long,
+    // that leave the chip idle; the two meet again before the phase's scan. (Not while every phase is being timed.)
+    if (lead.condOverlap < 0) lead.condOverlap = getenv("WG_COND_OVERLAP") ? atoi(getenv("WG_COND_OVERLAP")) : 1;
+    const bool overlap = cond && proto->cond_splits() && lead.condOverlap && lead.profiling != 1;
+    if (overlap) {
+      if (!lead.auxStream) {
+        WG_HIP(hipStreamCreate(&lead.auxStream));
+        WG_HIP(hipEventCreateWithFlags(&lead.evFork, hipEventDisableTiming));
+        WG_HIP(hipEventCreateWithFlags(&lead.evJoin, hipEventDisableTiming));
+      }
+      WG_HIP(hipEventRecord(lead.evFork, g.stream));
+      WG_HIP(hipStreamWaitEvent(lead.auxStream, lead.evFork, 0));
+      proto->launch_cond_select(g, lead.auxStream);
+      WG_HIP(hipEventRecord(lead.evJoin, lead.auxStream));
+    }
     {
       ProfScope ps(lead, Engine::PC_ORDER);
       Engine::scan<RecsF>(g, nullptr);
     }
-    // where nothing adds to the tile histograms after `resolve`, its last block reserves the buckets' pages itself
-    const bool fuseReserve = lead.dev.maxSendAll == 0;
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, fuseReserve ? 1 : 0);
+      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
     }
     if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
       ProfScope ps(lead, Engine::PC_RESOLVE);
@@ -1250,12 +1265,25 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
-      Engine::append_phase(g, false, fuseReserve, 1);  // ... and k_scatter's last block ends the drain: now++
+      Engine::append_phase(g, false);
+    }
+    {
+      ProfScope ps(lead, Engine::PC_END);
+      Engine::end_phase(g, true);
     }
     if (cond) {
-      const bool reserved = proto->launch_cond(lead, g);
-      ProfScope ps(lead, Engine::PC_APPEND);
-      Engine::append_phase(g, false, reserved, 2);
+      if (overlap) {
+        WG_HIP(hipStreamWaitEvent(g.stream, lead.evJoin, 0));
+        proto->launch_cond_rest(lead, g);
+      } else {
+        proto->launch_cond(lead, g);
+      }
+      {
+        ProfScope ps(lead, Engine::PC_APPEND);
+        Engine::append_phase(g, false);
+      }
+      ProfScope ps(lead, Engine::PC_END);
+      Engine::end_phase(g, false);
     }
   }
 
@@ -1540,7 +1568,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     uint32_t nOut = 0;
     await_counts(gfield(&Globals::nOut), nullptr, &nOut, nullptr);
     if (nOut) {
-      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab, 0);
+      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
       exchange_outbox(nOut);
       if (dev.maxSendAll) {  // the Network.sendAll calls among them: destinations, envelopes, first arrivals — on every shard
         hipLaunchKernelGGL(k_sendall_lat, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab);
@@ -2292,6 +2320,7 @@ struct HandelHost : ProtoHost {
     st.itemsLane = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemsWave = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemCount = e.dalloc<uint32_t>(2);
+    st.edge = e.dalloc<int32_t>(4);
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
@@ -2378,29 +2407,38 @@ struct HandelHost : ProtoHost {
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
   template <int W>
-  void launch_a1(const Group& g, const HandelState* stab, int R) {
-    hipLaunchKernelGGL(k_handel_a1<W>, dim3(node_grid(R), R), dim3(256), 0, g.stream, g.tab, stab);
+  void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
+    hipLaunchKernelGGL(k_handel_a1<W>, dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
   }
-  void launch_a1(const Group& g, const HandelState* stab, int R) {
+  void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
     switch (wavesCond) {
-      case 8: launch_a1<8>(g, stab, R); break;
-      case 6: launch_a1<6>(g, stab, R); break;
-      case 5: launch_a1<5>(g, stab, R); break;
-      case 3: launch_a1<3>(g, stab, R); break;
-      default: launch_a1<4>(g, stab, R);
+      case 8: launch_a1<8>(g, stab, R, s); break;
+      case 6: launch_a1<6>(g, stab, R, s); break;
+      case 5: launch_a1<5>(g, stab, R, s); break;
+      case 3: launch_a1<3>(g, stab, R, s); break;
+      default: launch_a1<4>(g, stab, R, s);
     }
   }
-  bool launch_cond(Engine& profOwner, const Group& g) override {
+  // the phase's first half — which tasks run, bestToVerify of their levels — reads only what the delivery pass left (the
+  // edge's clock values come from HandelState::edge, written by k_handel_lane): it may run beside the drain's tail
+  bool cond_splits() const override { return true; }
+  void launch_cond_select(const Group& g, hipStream_t s) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    {
-      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
-      hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      launch_a1(g, stab, g.R);
-    }
+    hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, s, g.tab, stab);
+    launch_a1(g, stab, g.R, s);
+  }
+  void launch_cond_rest(Engine& profOwner, const Group& g) override {
+    const HandelState* stab = (const HandelState*)g.stab;
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
     hipLaunchKernelGGL(k_handel_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
-    return true;  // (k_handel_cond_a2<false>'s last block: col_reserve_body)
+  }
+  void launch_cond(Engine& profOwner, const Group& g) override {
+    {
+      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
+      launch_cond_select(g, g.stream);
+    }
+    launch_cond_rest(profOwner, g);
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
@@ -2421,7 +2459,7 @@ struct HandelHost : ProtoHost {
   uint32_t shard_cond(Engine& e, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
-    launch_a1(g, stab, 1);
+    launch_a1(g, stab, 1, g.stream);
     e.shard_allreduce(st.candMask, (int64_t)st.N);  // (a node's candidate levels: its owner's bits, zeros elsewhere)
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
@@ -2695,7 +2733,7 @@ struct GsfHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
-  bool launch_cond(Engine& profOwner, const Group& g) override {
+  void launch_cond(Engine& profOwner, const Group& g) override {
     const GsfState* stab = (const GsfState*)g.stab;
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
@@ -2705,7 +2743,6 @@ struct GsfHost : ProtoHost {
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
     hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
-    return false;
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }

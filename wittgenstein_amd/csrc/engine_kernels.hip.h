@@ -287,8 +287,8 @@ __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t*
   const EngineDev& d = (tab)[blockIdx.y];      \
   if (d.halted) return
 
-// the scan evaluates F::value(i) twice (chunk sum, then the scan proper); a functor whose value is expensive may take a
-// `first` flag and reuse what the first evaluation left behind (ExpandF: chain run lengths)
+// k_scan2 re-evaluates F::value(i); a functor whose value is expensive may take a `first` flag and reuse what the
+// first evaluation (k_scan1) left behind (ExpandF: chain run lengths)
 template <class F>
 __device__ __forceinline__ auto scan_value_again(const F& f, uint32_t i) -> decltype(f.value(i, false)) {
   return f.value(i, false);
@@ -298,53 +298,45 @@ __device__ __forceinline__ uint64_t scan_value_again(const F& f, uint32_t i, X..
   return f.value(i);
 }
 
-// One launch: every block (1) sums its chunk and publishes the sum tagged with the launch's sequence number, (2) waits
-// for the sums of the blocks before it — they have lower workgroup ids, so they were dispatched earlier and are running
-// or done: the wait cannot deadlock — and (3) scans its chunk from that prefix, calling F.write(i, exclusive_prefix).
-// Blocks talk through device-scope ATOMIC words only — each half of a sum travels with the tag in one 64-bit word — and
-// never through a fence: on this chip every XCD has its own L2, so a device-scope release / acquire fence means writing
-// back / invalidating that L2 (measured: hundreds of microseconds per launch with a dirty cache), while a relaxed
-// device-scope atomic is simply performed at the memory side. The tag (DevCtl::scanSeq, bumped by the last block to
-// leave) makes stale sums of earlier launches unreadable, so nothing is reset between launches. (As two launches —
-// sums, then scan — each device-wide scan cost a kernel boundary more: three of them per simulated ms.)
-__device__ __forceinline__ void scan_publish(unsigned long long WG_G* slot, uint32_t seq, uint64_t v) {
-  __hip_atomic_store(&slot[0], ((unsigned long long)seq << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&slot[1], ((unsigned long long)seq << 32) | (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t scan_await(const unsigned long long WG_G* slot, uint32_t seq) {
-  unsigned long long lo, hi;
-  for (;;) {
-    lo = __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    hi = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(lo >> 32) == seq && (uint32_t)(hi >> 32) == seq) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_s_sleep(2);
-#endif
-  }
-  return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
-}
+// Two launches with no inter-block communication: (1) per-block sums of a contiguous chunk, (2) every block re-sums the
+// sums before it, scans its chunk and calls F.write(i, exclusive_prefix). (Measured against ONE launch whose blocks
+// wait for their predecessors' sums through device-scope atomics — profiles/r07d_*: twice the time. Launches on one
+// stream run back to back on this chip, a kernel boundary costs nothing by itself; a block that waits holds its CU.)
 template <class F>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
   const F f(d, atab ? atab + blockIdx.y : nullptr);
-  unsigned long long WG_G* partials = d.scanPartials;  // [SCAN_GRID][2]
+  unsigned long long WG_G* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
-  __shared__ uint64_t shw[SCAN_BLOCK / 64];
-  __shared__ uint32_t shSeq;
-  if (threadIdx.x == 0) shSeq = __hip_atomic_load(&d.ctl->scanSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-  __syncthreads();
-  const uint32_t seq = shSeq;
   uint32_t n = f.count(), lo, hi;
   scan_range(n, lo, hi);
   uint64_t acc = 0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
-  const uint64_t tot = block_sum64(acc, sh);
-  if (threadIdx.x == 0) scan_publish(partials + 2 * (size_t)blockIdx.x, seq, tot);
+  uint64_t tot = block_sum64(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
   f.tally(lo, hi);
-  uint64_t before = 0;
-  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_BLOCK) before += scan_await(partials + 2 * (size_t)b, seq);
+}
+
+// f.write(i, exclusive_prefix, valid) is called by every thread of the block at the same point (valid
+// = i is in range), so write() may use wave-level collectives.
+template <class F>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
+  WG_ENGINE(tab);
+  const F f(d, atab ? atab + blockIdx.y : nullptr);
+  const unsigned long long WG_G* partials = d.scanPartials;
+  __shared__ uint64_t sh[SCAN_BLOCK / 64];
+  __shared__ uint64_t shw[SCAN_BLOCK / 64];
+  uint32_t n = f.count(), lo, hi;
+  scan_range(n, lo, hi);
+  uint64_t before = 0, all = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += SCAN_BLOCK) {
+    uint64_t p = partials[b];
+    all += p;
+    if (b < blockIdx.x) before += p;
+  }
   uint64_t prefix = block_sum64(before, sh);
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) f.total(prefix + tot);
+  uint64_t total = block_sum64(all, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) f.total(total);
   int w = threadIdx.x >> 6;
   for (uint32_t base = lo; base < hi; base += SCAN_BLOCK) {
     uint32_t i = base + threadIdx.x;
@@ -361,14 +353,6 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(const EngineDev* __restrict
     f.write(i, prefix + woff + incl - v, i < hi);
     prefix += tile;
     __syncthreads();
-  }
-  // the last block to leave opens the next launch's sequence number (every block has read the old one by then)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (atomicAdd((uint32_t*)&d.ctl->scanDone, 1u) == gridDim.x - 1) {  // (`F` is the functor here, not the cast helper)
-      __hip_atomic_store(&d.ctl->scanDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d.ctl->scanSeq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
@@ -632,9 +616,6 @@ struct RecsF {
   }
 };
 
-__device__ __forceinline__ bool tail_is_mine(uint32_t WG_G* counter);
-__device__ __forceinline__ void col_reserve_body(const EngineDev& d);
-
 // ------------------------------------------------------------------------------------------------
 // resolve: unordered outbox -> ordered outbox (fin, arr). One thread per record.
 // Network.send / createMessageArrival(s) (C/Network.java:369-382,418-487).
@@ -719,10 +700,8 @@ __device__ __forceinline__ bool park_far(const EngineDev& d, int32_t t, uint32_t
 // SH (sharded engine, wg_shard_configure): a record is resolved by the shard that owns the node whose action()
 // emitted it; the result goes to the exchange image xbuf (zeros for records of other shards), which the host sums
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
-// reserve: the block that finishes last also reserves the arrival buckets' pages (col_reserve_body) — not where a
-// later kernel still adds to the tile histograms (the sendAll resolution) and not on a sharded engine
 template <bool SH>
-__global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab, int reserve) {
+__global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
@@ -866,7 +845,6 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
     // per-tile arrival histogram of the multisplit (rows are zero on entry: k_scatter re-zeroes them)
     if (arrival >= 0) atomicAdd(&d.tileHist[(size_t)(p / TILE) * D + ((uint32_t)arrival & (D - 1))], 1u);
   }
-  if (!SH && reserve && tail_is_mine(&d.ctl->tailDone)) col_reserve_body(d);
 }
 
 // sharded engine: the summed exchange image -> ordered outbox + tile histograms, identically on every shard
@@ -1061,8 +1039,7 @@ __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict_
 }
 
 // One block: per-bin exclusive prefix over tiles (in place), then reserve pages for every bucket that grows
-// (MessageStorage.ensureSize analogue) and publish each bucket's append base. Run by a block of its own (k_col_reserve)
-// or by the LAST block of the kernel that built the tile histograms (tail_is_mine): a kernel boundary less per phase.
+// (MessageStorage.ensureSize analogue) and publish each bucket's append base.
 __device__ __forceinline__ void col_reserve_body(const EngineDev& d) {
   __shared__ uint32_t shNeed[16];
   __shared__ uint32_t shBase;
@@ -1080,7 +1057,7 @@ __device__ __forceinline__ void col_reserve_body(const EngineDev& d) {
       for (; tile + 8 <= nTiles; tile += 8) {
         uint32_t h[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) h[q] = __hip_atomic_load(&d.tileHist[(size_t)(tile + q) * D + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 8; q++) h[q] = d.tileHist[(size_t)(tile + q) * D + b];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           d.tileHist[(size_t)(tile + q) * D + b] = add;
@@ -1088,7 +1065,7 @@ __device__ __forceinline__ void col_reserve_body(const EngineDev& d) {
         }
       }
       for (; tile < nTiles; tile++) {
-        uint32_t h = __hip_atomic_load(&d.tileHist[(size_t)tile * D + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t h = d.tileHist[(size_t)tile * D + b];
         d.tileHist[(size_t)tile * D + b] = add;
         add += h;
       }
@@ -1129,30 +1106,7 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
   WG_ENGINE(tab);
   col_reserve_body(d);
 }
-// true for exactly one block of the launch (per engine): the last one to get here. Every block calls it once, after its
-// own work. No fence (see k_scan): what the last block may rely on of the others' work is what they did with device-scope
-// ATOMICS — the wait below makes those atomics complete before this block is counted — plus everything earlier launches
-// wrote; what it writes itself is read by later launches only.
-__device__ __forceinline__ bool tail_is_mine(uint32_t WG_G* counter) {
-  __shared__ uint32_t shLast;
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): this wave's memory operations, atomics included, have been acknowledged
-#endif
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t k = atomicAdd(F(counter), 1u);
-    shLast = k == gridDim.x - 1;
-    if (shLast) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next launch that counts starts after this one has ended)
-  }
-  __syncthreads();
-  return shLast != 0;
-}
-
-// endMode: 0 = the append alone (host-staged envelopes); 1 / 2 = the block that finishes last also ends the phase
-// (end_phase_body: after a drain / after a conditional-task phase) — what k_end_phase did as a launch of its own
-__device__ __forceinline__ void end_phase_body(const EngineDev& d, int drained);
-__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits, int endMode) {
+__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
   uint32_t n = d.g->nOut;
@@ -1174,7 +1128,6 @@ __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ 
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < D; b += TILE) d.tileHist[(size_t)tile * D + b] = 0;  // for the next phase
   }
-  if (endMode && tail_is_mine(&d.ctl->scatterDone)) end_phase_body(d, endMode == 1);
 }
 
 // ------------------------------------------------------------------------------------------------

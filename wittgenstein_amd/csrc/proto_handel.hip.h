@@ -95,6 +95,9 @@ struct HandelState {
   // conditional-task phase scratch: the (node, level) items of this edge — node | level << 24 — by the lanes an item uses
   GP<uint32_t> itemsLane, itemsWave;      // [N * L] each
   GP<uint32_t> itemCount;                 // [2] lane items, wave items (reset by k_handel_cond_a2)
+  // the clock values of the edge that follows the drain in progress — {time the edge leads to, until, nextMessage() epoch}
+  // — written by k_handel_lane for k_handel_cond_pre, which may run while the drain's k_end_phase is updating the globals
+  GP<int32_t> edge;
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
@@ -109,9 +112,11 @@ struct HandelState {
 };
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
-                       HH_TOTAL = 7, HH_SPARE = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_PEND = 12,
-                       HH_PENDFROM = 16, HH_CAND = 20, HH_NRECV = 26, HH_NSENT = 27, HH_BRECV = 28, HH_BSENT = 30, HH_LV = 32 };
-static_assert(MAX_LEVELS <= 4 * (HH_NRECV - HH_CAND), "a candidate byte per level");
+                       HH_TOTAL = 7, HH_NRECV = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_BRECV = 12, HH_NSENT = 14,
+                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_CAND = 24, HH_BSENT = 30, HH_LV = 32 };
+// (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
+// updateVerifiedSignatures add to that)
+static_assert(MAX_LEVELS <= 4 * (HH_BSENT - HH_CAND), "a candidate byte per level");
 enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_TV, HK_FP, HK_COUNT };
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
@@ -1000,6 +1005,11 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what k_end_phase will make of the clock (see HandelState::edge)
+    s.edge[0] = t + 1;
+    s.edge[1] = d.g->until;
+    s.edge[2] = (int32_t)(d.g->epoch + (d.g->nEvents > 0 ? 1u : 0u));
+  }
   U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;  // the wave-per-node kernel's list
   for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
     KPROF_DECL;
@@ -1011,7 +1021,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     InboxEntry E[INBOX_SLOTS];
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) E[k].e = 0xFFFFFFFFu, E[k].w0 = 0, E[k].w2 = 0, E[k].w3 = 0;
-    U4 h0, h2;  // header words 0..3 {addedCycle, sigQueueSize, msgFiltered, startAt} and 8..11 {-, doneAt lo, hi, queue mask}
+    U4 h0, h2;  // header words 0..3 {addedCycle, sigQueueSize, msgFiltered, startAt} and 8..11 {msgReceived, doneAt lo, hi, queue mask}
     h0.x = h0.y = h0.z = h0.w = 0;
     h2 = h0;
     uint32_t total = 0;
@@ -1024,7 +1034,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       const uint32_t WG_G* hdr = h_hdr(s, node);
       h0 = gld((const U4 WG_G*)hdr);
       h2 = gld((const U4 WG_G*)(hdr + 8));
-      total = hdr[HH_TOTAL];
+      total = gld((const U4 WG_G*)(hdr + 4)).w;  // HH_TOTAL (the three pieces are one 64-byte line)
     }
     // ---- which kernel applies the node's events: this lane, if they are <= 4 SendSigs deliveries and at most one
     // updateVerifiedSignatures of a narrow level; else a wavefront of k_handel_wave
@@ -1294,8 +1304,8 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
                                                          const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  const int32_t t = d.g->now, until = d.g->until;
-  const uint32_t epoch = d.g->epoch;
+  const int32_t t = s.edge[0], until = s.edge[1];
+  const uint32_t epoch = (uint32_t)s.edge[2];
   const uint32_t stride = gridDim.x * blockDim.x;
   const int lane = WG_LANE;
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
@@ -1722,8 +1732,6 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       todo &= ~m;
     }
   }
-  // the block that finishes last reserves the arrival buckets' pages (what k_col_reserve does as a launch of its own)
-  if (!SH && tail_is_mine(&d.ctl->tailDone)) col_reserve_body(d);
 }
 
 // ---- sharded engine: the periodic-task snapshots of this ms (Handel SendSigs.sigs, P/Handel.java:254; GSFSignature
