@@ -152,9 +152,6 @@ Engine::Engine(const wg_config& c) : cfg(c) {
 
 Engine::~Engine() {
   delete proto;
-  if (evFork) (void)hipEventDestroy(evFork);
-  if (evJoin) (void)hipEventDestroy(evJoin);
-  if (auxStream) (void)hipStreamDestroy(auxStream);
   if (rcclComm) (void)rccl().CommDestroy(rcclComm);
   if (mailbox) (void)hipHostFree((void*)mailbox);
   if (snap) {
@@ -1233,22 +1230,6 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
       ProfScope ps(lead, Engine::PC_DELIVER);
       proto->launch_deliver(g);
     }
-    // The first kernels of the conditional-task phase of a protocol that splits it (cond_splits) run on a second stream
-    // from here, beside order / resolve / append / end — a dozen short kernels, each a few dependent round trips long,
-    // that leave the chip idle; the two meet again before the phase's scan. (Not while every phase is being timed.)
-    if (lead.condOverlap < 0) lead.condOverlap = getenv("WG_COND_OVERLAP") ? atoi(getenv("WG_COND_OVERLAP")) : 1;
-    const bool overlap = cond && proto->cond_splits() && lead.condOverlap && lead.profiling != 1;
-    if (overlap) {
-      if (!lead.auxStream) {
-        WG_HIP(hipStreamCreate(&lead.auxStream));
-        WG_HIP(hipEventCreateWithFlags(&lead.evFork, hipEventDisableTiming));
-        WG_HIP(hipEventCreateWithFlags(&lead.evJoin, hipEventDisableTiming));
-      }
-      WG_HIP(hipEventRecord(lead.evFork, g.stream));
-      WG_HIP(hipStreamWaitEvent(lead.auxStream, lead.evFork, 0));
-      proto->launch_cond_select(g, lead.auxStream);
-      WG_HIP(hipEventRecord(lead.evJoin, lead.auxStream));
-    }
     {
       ProfScope ps(lead, Engine::PC_ORDER);
       Engine::scan<RecsF>(g, nullptr);
@@ -1272,12 +1253,9 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
       Engine::end_phase(g, true);
     }
     if (cond) {
-      if (overlap) {
-        WG_HIP(hipStreamWaitEvent(g.stream, lead.evJoin, 0));
-        proto->launch_cond_rest(lead, g);
-      } else {
-        proto->launch_cond(lead, g);
-      }
+      // (running the phase's first kernels on a second stream beside the drain's tail was measured: no gain — the short
+      // kernels' latency doubles under the other stream's memory load, profiles/r07e_*)
+      proto->launch_cond(lead, g);
       {
         ProfScope ps(lead, Engine::PC_APPEND);
         Engine::append_phase(g, false);
@@ -2221,6 +2199,12 @@ __global__ void k_handel_own_bits(HandelState s) {
   *h_row(s, node, HK_VI, 0) = bit;
 }
 
+// read-back: toVerifyAgg.size() of every (owned node, level)
+__global__ void __launch_bounds__(256) k_handel_gather_qlen(HandelState s, int32_t* dst) {
+  const size_t n = (size_t)(s.hi - s.lo) * s.L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (int32_t)h_qrec(s, s.lo + (int32_t)(i / s.L), (int)(i % s.L))[0];
+}
 // read-back: kind k of every owned node as an N-bit row in id order (the layout the reference's BitSets have)
 __global__ void __launch_bounds__(256) k_handel_gather_row(HandelState s, int k, uint64_t* dst) {
   const size_t n = (size_t)(s.hi - s.lo) * s.W;
@@ -2294,8 +2278,7 @@ struct HandelHost : ProtoHost {
     st.hdr = rows((uint32_t*)nullptr, st.hdrStride, true);
     st.ct = rows((uint32_t*)nullptr, 2, true);
     const size_t NL = (size_t)N * L;
-    st.qent = rows((uint64_t*)nullptr, (size_t)L * 64, true, Engine::AC_SCRATCH);
-    st.qfrom = rows((int32_t*)nullptr, (size_t)L * Q, false, Engine::AC_SCRATCH);
+    st.qrec = rows((uint64_t*)nullptr, (size_t)L * H_QREC, true, Engine::AC_SCRATCH);
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
       int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);
@@ -2320,7 +2303,6 @@ struct HandelHost : ProtoHost {
     st.itemsLane = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemsWave = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemCount = e.dalloc<uint32_t>(2);
-    st.edge = e.dalloc<int32_t>(4);
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
@@ -2419,26 +2401,16 @@ struct HandelHost : ProtoHost {
       default: launch_a1<4>(g, stab, R, s);
     }
   }
-  // the phase's first half — which tasks run, bestToVerify of their levels — reads only what the delivery pass left (the
-  // edge's clock values come from HandelState::edge, written by k_handel_lane): it may run beside the drain's tail
-  bool cond_splits() const override { return true; }
-  void launch_cond_select(const Group& g, hipStream_t s) override {
+  void launch_cond(Engine& profOwner, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, s, g.tab, stab);
-    launch_a1(g, stab, g.R, s);
-  }
-  void launch_cond_rest(Engine& profOwner, const Group& g) override {
-    const HandelState* stab = (const HandelState*)g.stab;
+    {
+      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
+      hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      launch_a1(g, stab, g.R, g.stream);
+    }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
     hipLaunchKernelGGL(k_handel_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
-  }
-  void launch_cond(Engine& profOwner, const Group& g) override {
-    {
-      Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
-      launch_cond_select(g, g.stream);
-    }
-    launch_cond_rest(profOwner, g);
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
@@ -2520,10 +2492,20 @@ struct HandelHost : ProtoHost {
     for (int i = 0; i < n; i++) dst[i] = (int32_t)h[(size_t)i * st.hdrStride + off];
     return true;
   }
-  bool read_level_i32(Engine&, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
+  bool read_level_i32(Engine& e, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
     if (n != st.N || L != st.L) throw WgError(WG_EINVAL, "shape must be [nodeCount][levels]");
-    const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN
-                      : field == WG_LF_QUEUE_LEN ? HP_QLEN : -1;
+    if (field == WG_LF_QUEUE_LEN) {  // toVerifyAgg.size(): the head word of every queue record
+      memset(dst, 0, 4 * (size_t)n * L);
+      const size_t cnt = (size_t)(st.hi - st.lo) * L;
+      int32_t* tmp = nullptr;
+      WG_HIP(hipMalloc((void**)&tmp, 4 * cnt));
+      hipLaunchKernelGGL(k_handel_gather_qlen, dim3(256 / WG_GRID_DIV > 0 ? 256 / WG_GRID_DIV : 1), dim3(256), 0, e.stream, st, tmp);
+      const hipError_t rc = hipMemcpy(dst + (size_t)st.lo * L, tmp, 4 * cnt, hipMemcpyDeviceToHost);
+      (void)hipFree(tmp);
+      WG_HIP(rc);
+      return true;
+    }
+    const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN : -1;
     if (plane < 0) return false;
     const std::vector<uint32_t> h = read_hdr();
     for (int i = 0; i < n; i++)

@@ -47,12 +47,6 @@ struct ProtoHost {
   // adds the protocol's share of a Node counter (WG_F_MSG_RECEIVED ...) to dst, if it keeps one outside NodeArrays
   virtual bool node_counter(Engine&, int32_t field, int64_t* dst, int32_t n) { return false; }
   virtual void launch_cond(Engine& profOwner, const Group&) {}
-  // A protocol whose conditional-task phase starts with kernels that need nothing but the delivery pass's results
-  // (launch_cond_select on any stream) lets the engine run them BESIDE the drain's tail (order / resolve / append / end:
-  // a chain of short latency-bound kernels that leaves the chip idle); launch_cond_rest follows on the engine's stream.
-  virtual bool cond_splits() const { return false; }
-  virtual void launch_cond_select(const Group&, hipStream_t) {}
-  virtual void launch_cond_rest(Engine& profOwner, const Group&) {}
   virtual void launch_deliver(const Group&) = 0;
   virtual size_t state_size() const = 0;        // sizeof the device State struct ...
   virtual const void* state_host() const = 0;   // ... and its host copy (what a Group's stab holds)
@@ -295,10 +289,6 @@ class Engine {
   // roofline leg; off by default because every bracket costs two event records)
   enum ProfClass { PC_EXPAND = 0, PC_GROUP, PC_DELIVER, PC_ORDER, PC_RESOLVE, PC_APPEND, PC_END, PC_COND_SELECT,
                    PC_COND_REST, PC_COUNT };
-  // the second stream of enqueue_one_ms's fork (cond_splits): created at first use; WG_COND_OVERLAP=0 keeps everything on one stream
-  hipStream_t auxStream = nullptr;
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
-  int condOverlap = -1;
   int profiling = 0;                       // 0 off, 1 every phase, 2 the delivery kernel only
   struct ProfSpan {
     int cls;

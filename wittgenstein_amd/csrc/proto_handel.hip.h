@@ -10,8 +10,9 @@
 //             line in each of five 134 MB arrays. totalOutgoing of level l is always the union of
 //             totalIncoming of levels < l (:728-731) = the node's OWN aligned block (h_word gathers it).
 //   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] emission lists (:510-522)
-//   queues    toVerifyAgg (:385): per (node, level) up to Q slots {from, rank, sig[2^(l-1) bits]} in a
-//             private slab + an order list; a slot stays allocated while a registered
+//   queues    toVerifyAgg (:385): per (node, level) one queue record (h_qrec: length, slots in use, the list
+//             in list order — rank, signer, slot per entry — in ONE line for the usual short list) and up to
+//             Q signature slots sig[2^(l-1) bits] in a private slab; a slot stays allocated while a registered
 //             updateVerifiedSignatures task still references it (:833-836).
 //
 // Who runs what (a node visit is a chain of dependent memory round trips — the kernels' throughput is
@@ -35,6 +36,7 @@ namespace wg {
 constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks per node
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
+constexpr int H_QREC = 72;         // 64-bit words of a queue record: 2 + 64 entries, padded to whole 64-byte lines
 constexpr int H_LANE_NW = 4;       // level blocks of up to this many 64-bit words are worked on by ONE lane (levels <= 9)
 
 // The argument word of an updateVerifiedSignatures task (Rec::w3): everything the task needs to issue its loads —
@@ -68,22 +70,23 @@ struct HandelState {
   //   [HH_TOTAL]                 sum over the levels of |totalIncoming| (what `cur.cardinality()` of :745 is after the loop)
   //   [HH_DONE_LO, HH_DONE_HI]   Node.doneAt, mirrored from NodeArrays::doneAt (written through when it changes)
   //   [HH_PEND +4] [HH_PENDFROM +4]  outstanding updateVerifiedSignatures tasks: valid<<31 | level<<8 | slot ; from
-  //   [HH_CAND +6]               checkSigs' candidate of this edge per level, one BYTE a level: its queue slot (valid where
-  //                              candMask[node] has the level's bit; written by k_handel_a1, read by k_handel_cond_a2)
   //   [HH_NRECV .. HH_BSENT]     Node.msgReceived / msgSent (32 bits) and bytesReceived / bytesSent (64 bits) of this
   //                              protocol's deliveries and sends (C/Network.java:476-477,611-612): they change with the words
   //                              above, in the same line — not as four atomics into four more arrays (read back: node_counter)
   //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
-  //   [HH_LV + l*8 + plane]      level-major: the eight scalars of HLevel l side by side (32 bytes, two levels a 64-byte
-  //                              line) — posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, queue length,
-  //                              outgoingFinished, queue slots in use (low / high word); LS = 16 or 32 >= L levels.
+  //   [HH_LV + l*8 + plane]      level-major: the scalars of HLevel l side by side (32 bytes, two levels a 64-byte line) —
+  //                              posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, checkSigs' candidate of this
+  //                              edge (signer << 8 | queue slot; valid where candMask[node] has the level's bit: written by
+  //                              k_handel_a1, read by k_handel_cond_a2), outgoingFinished; LS = 16 or 32 >= L levels.
   GP<uint32_t> hdr;
   int32_t LS, lsShift, hdrStride;
   // ConditionalTask.minStartTime and the epoch in which the task last left nextMessage()'s copy, two words a node, dense:
   // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a line of the record
   GP<uint32_t> ct;
-  GP<uint64_t> qent;                      // [N][L][64] list entries in list order: rank << 32 | slot
-  GP<int32_t> qfrom;                      // [N][L][Q]
+  // toVerifyAgg of (node, level): a queue record of H_QREC 64-bit words — [0] list length, [1] signature slots in use,
+  // [2 + i] entry i in list order: rank << 32 | signer << 8 | slot. Length, slots and the first six entries are ONE
+  // 64-byte line: what a delivery appends to and checkSigs walks (it used to be a line in each of three arrays)
+  GP<uint64_t> qrec;                      // [N][L][H_QREC]
   GP<uint64_t> qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
   // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
@@ -95,9 +98,6 @@ struct HandelState {
   // conditional-task phase scratch: the (node, level) items of this edge — node | level << 24 — by the lanes an item uses
   GP<uint32_t> itemsLane, itemsWave;      // [N * L] each
   GP<uint32_t> itemCount;                 // [2] lane items, wave items (reset by k_handel_cond_a2)
-  // the clock values of the edge that follows the drain in progress — {time the edge leads to, until, nextMessage() epoch}
-  // — written by k_handel_lane for k_handel_cond_pre, which may run while the drain's k_end_phase is updating the globals
-  GP<int32_t> edge;
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
@@ -113,12 +113,11 @@ struct HandelState {
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_TOTAL = 7, HH_NRECV = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_BRECV = 12, HH_NSENT = 14,
-                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_CAND = 24, HH_BSENT = 30, HH_LV = 32 };
+                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_BSENT = 30, HH_LV = 32 };
 // (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
 // updateVerifiedSignatures add to that)
-static_assert(MAX_LEVELS <= 4 * (HH_BSENT - HH_CAND), "a candidate byte per level");
 enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_TV, HK_FP, HK_COUNT };
-enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_QLEN, HP_OUTFIN, HP_QUSED_LO, HP_QUSED_HI, HP_COUNT };
+enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_CAND, HP_OUTFIN, HP_SPARE0, HP_SPARE1, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t WG_G* h_lv(const HandelState& s, int32_t node, int plane, int l) {
   return s.hdr + (size_t)node * s.hdrStride + HH_LV + l * HP_COUNT + plane;
@@ -191,26 +190,18 @@ __device__ __forceinline__ void row_set(uint64_t WG_G* row, int32_t id, bool v) 
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) { return wave_reduce_add64(v); }
 
 // per-wave LDS mirror of the (node, level) scalars
-struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_QUSED_HI (32 words each), then the scalars
+struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_SPARE1 (32 words each), then the scalars
   int32_t pos[32];
   int32_t cTI[32];
   int32_t cLA[32];
   int32_t cVI[32];
-  int32_t qlen[32];
+  uint32_t cand[32];
   int32_t outFin[32];
-  uint32_t quLo[32];
-  uint32_t quHi[32];
+  uint32_t spare0[32];
+  uint32_t spare1[32];
   uint32_t sc[HH_LV];
   U4 orig[(HH_LV + 8 * 32) / 4];  // the record as it was loaded, 16-byte pieces: store_levels writes back what differs
 };
-__device__ __forceinline__ unsigned long long ls_qused(const LevelScalars* ls, int l) {
-  return (unsigned long long)ls->quLo[l] | ((unsigned long long)ls->quHi[l] << 32);
-}
-__device__ __forceinline__ void ls_set_qused(LevelScalars* ls, int l, unsigned long long v) {
-  ls->quLo[l] = (uint32_t)v;
-  ls->quHi[l] = (uint32_t)(v >> 32);
-}
-
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
 constexpr uint32_t H_REF_ONES = 0xFFFFFFFFu;  // payload ref: the all-ones block (fast-path sends of a sharded engine)
 __device__ __forceinline__ const uint64_t WG_G* h_payload(const EngineDev& d, const HandelState& s, uint32_t payload) {
@@ -221,6 +212,16 @@ __device__ __forceinline__ uint64_t WG_G* h_sig_ptr(const HandelState& s, int32_
   return s.qsig + s.qsigOff[l] + ((size_t)node * h_qcap(s, l) + slot) * (size_t)h_nw(l);
 }
 __device__ __forceinline__ uint32_t h_pend_word(int l, int slot) { return 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot; }
+__device__ __forceinline__ uint64_t WG_G* h_qrec(const HandelState& s, int32_t node, int l) {
+  return s.qrec + ((size_t)node * s.L + l) * H_QREC;
+}
+__device__ __forceinline__ uint64_t h_entry(int32_t rank, int32_t from, int slot) {
+  return ((uint64_t)(uint32_t)rank << 32) | ((uint64_t)(uint32_t)from << 8) | (uint32_t)slot;
+}
+// a record's head: {length, slots in use} as one 16-byte access
+struct alignas(16) HQHead {
+  uint64_t len, used;
+};
 
 struct HandelProto {
   typedef HandelState State;
@@ -461,6 +462,8 @@ struct HandelProto {
     uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
     const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+    uint64_t WG_G* qr = h_qrec(s, node, l);
+    const HQHead qh = gld((const HQHead WG_G*)qr);
     const uint64_t WG_G* src = h_payload(c.d, s, payload);
     const int j0 = (int)WG_LANE;
     const bool has0 = j0 < v.nw;
@@ -471,11 +474,11 @@ struct HandelProto {
     if (!(viv & bit) && owner) *tvp = tvv | bit;                  // toVerifyInd.set(from) unless verified
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
-    unsigned long long used = ls_qused(ls, l);
+    const unsigned long long used = qh.used;
     const int qc = h_qcap(s, l);
     unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
     unsigned long long freeM = ~used & capMask;
-    int len = ls->qlen[l];
+    const int len = (int)qh.len;
     if (freeM == 0 || len >= 64) {
       if (WG_LANE == 0) set_err(c.d.g, ERR_QUEUE_CAP);
       return;
@@ -484,12 +487,13 @@ struct HandelProto {
     uint64_t WG_G* dst = sig_ptr(s, node, l, slot);
     if (has0) dst[j0] = pw0;
     for (int j = j0 + 64; j < v.nw; j += 64) dst[j] = src[j];
-    __builtin_amdgcn_wave_barrier();  // every lane has read qused/qlen before lane 0 replaces them
+    __builtin_amdgcn_wave_barrier();  // every lane has read the record's head before lane 0 replaces it
     if (WG_LANE == 0) {
-      s.qfrom[((size_t)node * s.L + l) * s.Q + slot] = from;
-      s.qent[((size_t)node * s.L + l) * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
-      ls_set_qused(ls, l, used | (1ULL << slot));
-      ls->qlen[l] = len + 1;
+      qr[2 + len] = h_entry(rank, from, slot);
+      HQHead nh;
+      nh.len = (uint64_t)(len + 1);
+      nh.used = used | (1ULL << slot);
+      gst((HQHead WG_G*)qr, nh);
       ls->sc[HH_QMASK] |= 1u << l;
     }
     __builtin_amdgcn_wave_barrier();
@@ -661,9 +665,10 @@ struct HandelProto {
     const uint64_t bit = 1ULL << (from & 63);
     uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     const uint64_t tvv = ld_coherent(tvp);
-    uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
-    const int len = ls->qlen[lv];
-    const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
+    uint64_t WG_G* qr = h_qrec(s, node, lv);
+    uint64_t WG_G* ent = qr + 2;
+    const HQHead qh = gld((const HQHead WG_G*)qr);
+    const uint64_t entAll = ent[lane];  // (the whole list, before its length is known)
     const int j0 = lane;
     const bool has0 = j0 < v.nw;
     uint64_t sg0 = 0, vi0 = 0, la0 = 0, ti0 = 0;
@@ -686,16 +691,17 @@ struct HandelProto {
     const bool owner = lane == (jF & 63);
     if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
+    const int len = (int)qh.len;
+    const uint64_t myEnt = lane < len ? entAll : ~0ULL;
+    int newLen = len;
     {
       const uint64_t hit = __ballot(lane < len && (int)(myEnt & 0xFF) == slot);
       if (hit) {
         const int at = __ffsll((unsigned long long)hit) - 1;
         const uint64_t next = shfl64(myEnt, (lane + 1) & 63);
         if (lane >= at && lane < len - 1) ent[lane] = next;
-        if (lane == 0) {
-          ls->qlen[lv] = len - 1;
-          if (len == 1) ls->sc[HH_QMASK] &= ~(1u << lv);
-        }
+        newLen = len - 1;
+        if (lane == 0 && len == 1) ls->sc[HH_QMASK] &= ~(1u << lv);
       }
     }
     const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
@@ -765,7 +771,10 @@ struct HandelProto {
       ls->sc[HH_TOTAL] = (uint32_t)cur;
       // The entry was just unlisted (an entry is listed at most once), so its slot dies with this task
       // unless another registered task still references it (checkSigs can pick the same entry twice).
-      if (!slot_pending(r, lv, slot)) ls_set_qused(ls, lv, ls_qused(ls, lv) & ~(1ULL << slot));
+      HQHead nh;
+      nh.len = (uint64_t)newLen;
+      nh.used = slot_pending(r, lv, slot) ? qh.used : (qh.used & ~(1ULL << slot));
+      if (nh.len != qh.len || nh.used != qh.used) gst((HQHead WG_G*)qr, nh);
     }
     __builtin_amdgcn_wave_barrier();
     if (!improved) return;
@@ -802,16 +811,15 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   uint64_t WG_G* fpp = h_row(s, node, HK_FP, l) + w;  // (the level's five bitsets side by side: one line up to level 9)
   const uint64_t WG_G* vip = h_row(s, node, HK_VI, l) + w;
   uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
-  const size_t nl = (size_t)node * s.L + l;
   // every load of the event before the first use
   const uint64_t viv = *vip;
   const uint64_t fpv = levelFinished ? *fpp : 0ULL;
   const uint64_t tvv = *tvp;
   const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
-  U4 WG_G* lvp = (U4 WG_G*)h_lv(s, node, HP_QLEN, l);      // {qlen, outgoingFinished, slots in use lo / hi}
-  const U4 lq = gld(lvp);
-  const unsigned long long used = (unsigned long long)lq.z | ((unsigned long long)lq.w << 32);
-  const int len = (int)lq.x;
+  uint64_t WG_G* qr = h_qrec(s, node, l);
+  const HQHead qh = gld((const HQHead WG_G*)qr);
+  const unsigned long long used = qh.used;
+  const int len = (int)qh.len;
   const uint64_t WG_G* src = h_payload(d, s, payload);
   const int nw = h_nw(l);
   const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
@@ -827,15 +835,11 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   }
   const int slot = __ffsll(freeM) - 1;
   uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
-  s.qfrom[nl * s.Q + slot] = from;
-  s.qent[nl * 64 + len] = ((uint64_t)(uint32_t)rank << 32) | (uint32_t)slot;
-  U4 nq = lq;
-  nq.x = (uint32_t)(len + 1);
-  if (slot < 32)
-    nq.z |= 1u << slot;
-  else
-    nq.w |= 1u << (slot - 32);
-  gst(lvp, nq);
+  qr[2 + len] = h_entry(rank, from, slot);  // (lists of up to six entries: the same line as the head)
+  HQHead nh;
+  nh.len = (uint64_t)(len + 1);
+  nh.used = used | (1ULL << slot);
+  gst((HQHead WG_G*)qr, nh);
   r.qmask |= 1u << l;
   if (nw == 1) {
     dst[0] = pw0;
@@ -867,13 +871,14 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block: 0 <= jF < nw
   const uint64_t bit = 1ULL << (from & 63);
   uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
-  uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + lv) * 64;
+  uint64_t WG_G* qr = h_qrec(s, node, lv);
+  uint64_t WG_G* ent = qr + 2;
   // ---- every load of the event (they depend on the task's argument only), before the first use
   const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
   const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
   U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);   // {posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|}
-  U4 WG_G* lvB = (U4 WG_G*)h_lv(s, node, HP_QLEN, lv);  // {queue length, outgoingFinished, slots in use lo / hi}
-  U4 a = gld(lvA), b = gld(lvB);
+  U4 a = gld(lvA);
+  const HQHead qh = gld((const HQHead WG_G*)qr);
   const uint64_t tvv = *tvp;
   uint64_t sg[H_LANE_NW], tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
 #pragma unroll
@@ -939,7 +944,8 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   hdr[HH_PEND + pk] = 0;
   *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
   // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
-  const int len = (int)b.x;
+  const int len = (int)qh.len;
+  HQHead nh = qh;
   {
     // (static indices throughout: a register array indexed at run time would live in scratch memory)
     int at = -1;
@@ -953,7 +959,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
       for (int i = 0; i < 7; i++)
         if (i >= at && i + 1 < len) ent[i] = e8[i + 1];
       for (int i = at > 7 ? at : 7; i + 1 < len; i++) ent[i] = ent[i + 1];
-      b.x = (uint32_t)(len - 1);
+      nh.len = (uint64_t)(len - 1);
       if (len == 1) r.qmask &= ~(1u << lv);
     }
   }
@@ -983,13 +989,8 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   // registered task still references it (checkSigs can pick the same entry twice).
   const uint32_t key = h_pend_word(lv, slot);
   const bool held = (pk != 0 && pend.x == key) || (pk != 1 && pend.y == key) || (pk != 2 && pend.z == key) || (pk != 3 && pend.w == key);
-  if (!held) {
-    if (slot < 32)
-      b.z &= ~(1u << slot);
-    else
-      b.w &= ~(1u << (slot - 32));
-  }
-  gst(lvB, b);
+  if (!held) nh.used &= ~(1ULL << slot);
+  if (nh.len != qh.len || nh.used != qh.used) gst((HQHead WG_G*)qr, nh);
   r.total += cTI - cTI0;
   if (!improved) return H_UPD_DONE;
   if (r.doneAt == 0 && r.total >= s.p.threshold) r.doneAt = t;
@@ -1005,11 +1006,6 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what k_end_phase will make of the clock (see HandelState::edge)
-    s.edge[0] = t + 1;
-    s.edge[1] = d.g->until;
-    s.edge[2] = (int32_t)(d.g->epoch + (d.g->nEvents > 0 ? 1u : 0u));
-  }
   U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;  // the wave-per-node kernel's list
   for (uint32_t base = wave * 64; base < nActive; base += nWaves * 64) {
     KPROF_DECL;
@@ -1304,8 +1300,8 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
                                                          const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  const int32_t t = s.edge[0], until = s.edge[1];
-  const uint32_t epoch = (uint32_t)s.edge[2];
+  const int32_t t = d.g->now, until = d.g->until;
+  const uint32_t epoch = d.g->epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int lane = WG_LANE;
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
@@ -1375,22 +1371,21 @@ __device__ __forceinline__ HEntryEval h_eval_entry(int u1, int u2, int cs, bool 
   return ev;
 }
 
-// the end of an item: the curated list's bookkeeping and the level's candidate. `relMask`: queue slots of dropped
-// entries no registered task holds; several items of one node run concurrently (other levels), so the node's shared
-// words are updated with atomics and the level's own 16-byte piece is stored whole.
-__device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node, int l, U4 lvB, int len, int kept,
-                                              unsigned long long relMask, int cand) {
+// the end of an item: the curated list's bookkeeping and the level's candidate (`cand`: signer << 8 | slot of the chosen
+// entry, or -1). `relMask`: queue slots of dropped entries no registered task holds; several items of one node run
+// concurrently (other levels), so the node's shared words are updated with atomics; the record's head is the item's own.
+__device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node, int l, uint64_t WG_G* qr, HQHead qh, int len,
+                                              int kept, unsigned long long relMask, long long cand) {
   uint32_t WG_G* hdr = h_hdr(s, node);
   if (kept != len) {  // replaceToVerifyAgg :636-646
-    lvB.x = (uint32_t)kept;
-    lvB.z &= ~(uint32_t)relMask;
-    lvB.w &= ~(uint32_t)(relMask >> 32);
-    gst((U4 WG_G*)h_lv(s, node, HP_QLEN, l), lvB);
+    qh.len = (uint64_t)kept;
+    qh.used &= ~relMask;
+    gst((HQHead WG_G*)qr, qh);
     atomicAdd(F(hdr + HH_SIGQ), (uint32_t)(kept - len));  // sigQueueSize -= dropped
     if (kept == 0) atomicAnd(F(hdr + HH_QMASK), ~(1u << l));
   }
   if (cand >= 0) {
-    ((uint8_t WG_G*)(hdr + HH_CAND))[l] = (uint8_t)cand;
+    *h_lv(s, node, HP_CAND, l) = (uint32_t)cand;
     atomicOr(F(s.candMask + node), 1u << l);
   }
 }
@@ -1417,12 +1412,13 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
       const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
       const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
-      uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
+      uint64_t WG_G* qr = h_qrec(s, node, l);
+      uint64_t WG_G* ent = qr + 2;
       // ---- everything the item's address alone decides, before the first use
       const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
       const int window = (int)hdr[HH_WINDOW];
       const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
-      const U4 lvB = gld((const U4 WG_G*)h_lv(s, node, HP_QLEN, l));
+      const HQHead qh = gld((const HQHead WG_G*)qr);
       uint64_t tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
 #pragma unroll
       for (int j = 0; j < H_LANE_NW; j++) {
@@ -1434,13 +1430,14 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       uint64_t e4[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) e4[i] = ent[i];
-      const int len = (int)lvB.x, curSize = (int)lvA.y, cLA = (int)lvA.z;
+      const int len = (int)qh.len, curSize = (int)lvA.y, cLA = (int)lvA.z;
       int windowIndex = INT32_MAX;  // Collections.min(rank)
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
       for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
-      int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
+      long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
+      int bestScore = 0, bestOutsideRank = 0;
       unsigned long long keep = 0;
       for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signatures in flight at a time
         uint64_t x[4], sg[4][H_LANE_NW];
@@ -1469,17 +1466,18 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
             iTI |= (sg[u][j] & tiw[j]) != 0;
             iLA |= (sg[u][j] & law[j]) != 0;
           }
-          const int slot = (int)(x[u] & 0xFF), rank = (int)(uint32_t)(x[u] >> 32);
+          const long long who = (long long)(uint32_t)x[u];  // signer << 8 | slot
+          const int rank = (int)(uint32_t)(x[u] >> 32);
           const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rank, windowIndex, window);
           if (ev.keep) {
             keep |= 1ULL << i;
             if (ev.inside) {  // best inside = FIRST entry with the strictly greatest positive score
               if (ev.score > bestScore) {
                 bestScore = ev.score;
-                bestInside = slot;
+                bestInside = who;
               }
             } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
-              bestOutside = slot;
+              bestOutside = who;
               bestOutsideRank = rank;
             }
           }
@@ -1503,7 +1501,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
           if (i < len) curate(i, e4[i]);
         for (int i = 4; i < len; i++) curate(i, ent[i]);
       }
-      h_item_finish(s, node, l, lvB, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+      h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
     }
     return;
   }
@@ -1523,13 +1521,14 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);  // the level's block: word j of it is [j]
     const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
     const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
-    uint64_t WG_G* ent = s.qent + ((size_t)node * s.L + l) * 64;
+    uint64_t WG_G* qr = h_qrec(s, node, l);
+    uint64_t WG_G* ent = qr + 2;
     // ---- everything the item's address alone decides, before the first use: header pieces (every lane the same
     // address), the whole list (lane i = entry i) and this lane's word of the three rows
     const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
     const int window = (int)hdr[HH_WINDOW];
     const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
-    const U4 lvB = gld((const U4 WG_G*)h_lv(s, node, HP_QLEN, l));
+    const HQHead qh = gld((const HQHead WG_G*)qr);
     const uint64_t entAll = ent[lane];
     const int jh = lane;
     const bool oneRound = v.nw <= 64;
@@ -1539,21 +1538,24 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       vih = vi[jh];
       lah = la[jh];
     }
-    const int len = (int)WG_READFIRST(lvB.x), curSize = (int)WG_READFIRST(lvA.y), cLA = (int)WG_READFIRST(lvA.z);
+    const int len = (int)WG_READFIRST((uint32_t)qh.len), curSize = (int)WG_READFIRST(lvA.y), cLA = (int)WG_READFIRST(lvA.z);
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
     const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
     const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
     KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
     const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
-    int bestInside = -1, bestScore = 0, bestOutside = -1, bestOutsideRank = 0;
+    long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
+    int bestScore = 0, bestOutsideRank = 0;
     uint64_t keep = 0;
     for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signature words in flight at a time
       uint64_t sg[4];
       int slotU[4], rankU[4];
+      uint32_t whoU[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int i = i0 + u < len ? i0 + u : len - 1;
-        slotU[u] = (int)lane_bcast((uint32_t)mySlot, i);
+        whoU[u] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
+        slotU[u] = (int)(whoU[u] & 0xFFu);
         rankU[u] = (int)lane_bcast((uint32_t)myRank, i);
         sg[u] = (oneRound && jh < v.nw && i0 + u < len) ? h_sig_ptr(s, node, l, slotU[u])[jh] : 0ULL;
       }
@@ -1585,10 +1587,10 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
           if (ev.inside) {
             if (ev.score > bestScore) {
               bestScore = ev.score;
-              bestInside = slotU[u];
+              bestInside = (long long)whoU[u];
             }
           } else if (bestOutside < 0 || rankU[u] < bestOutsideRank) {
-            bestOutside = slotU[u];
+            bestOutside = (long long)whoU[u];
             bestOutsideRank = rankU[u];
           }
         }
@@ -1608,7 +1610,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) h_item_finish(s, node, l, lvB, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+    if (lane == 0) h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
     KPROF_MARK(d.g, 23);  // list curation, candidate
   }
 }
@@ -1677,8 +1679,9 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       uint32_t cm = s.candMask[node];
       for (int q = 0; q < k; q++) cm &= cm - 1;
       const int l = __ffs(cm) - 1;
-      const int slot = (int)((const uint8_t WG_G*)(h + HH_CAND))[l];
-      const int32_t from = s.qfrom[((size_t)node * s.L + l) * s.Q + slot];
+      const uint32_t who = *h_lv(s, node, HP_CAND, l);  // the level's candidate: signer << 8 | queue slot (h_item_finish)
+      const int slot = (int)(who & 0xFFu);
+      const int32_t from = (int32_t)(who >> 8);
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
       int w = (int)h[HH_WINDOW] * 2;
       if (w > s.p.windowMaximum) w = s.p.windowMaximum;
