@@ -452,10 +452,13 @@ void Engine::set_partitions(const int32_t* c, int32_t k) {
 void Engine::set_node_down(int32_t id, bool down) {
   if (id < 0 || id >= (int)hx.size()) throw WgError(WG_EINVAL, "node id");
   hdown[id] = down;
-  if (allocated) {
-    uint8_t v = down;
-    WG_HIP(hipMemcpy(dev.nodes.down + id, &v, 1, hipMemcpyHostToDevice));
-  }
+  downDirty = true;  // uploaded as one array before the next launch (a stop()ped population is thousands of calls)
+}
+void Engine::upload_down() {
+  if (!downDirty || !allocated) return;
+  WG_HIP(hipMemcpyAsync(dev.nodes.down, hdown.data(), hdown.size(), hipMemcpyHostToDevice, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+  downDirty = false;
 }
 
 // the largest latency the current model can return for these nodes (sizes the bucket ring and the sendAll histograms)
@@ -640,6 +643,7 @@ void Engine::ensure_device() {
 }
 
 void Engine::sync_globals_to_device() {
+  upload_down();
   if (!globalsDirty) return;
   WG_HIP(hipMemcpyAsync(dev.g, &gh, sizeof(Globals), hipMemcpyHostToDevice, stream));
   WG_HIP(hipStreamSynchronize(stream));
@@ -724,6 +728,7 @@ void Engine::restore() {
   dev.discardTime = sn.discardTime;
   stagedMin = sn.stagedMin;
   hdown = sn.hdown;
+  downDirty = false;  // (the device array comes back with the image)
   if (cuts != sn.cuts) {
     cuts = sn.cuts;
     rebuild_partitions();
@@ -985,6 +990,7 @@ void Engine::end_phase(const Group& g, bool drained) {
 
 Group Engine::self() {
   ensure_device();
+  upload_down();
   dev.halted = 0;
   bool sync = false;
   if (!dTab || memcmp(&tabShadow, &dev, sizeof(EngineDev)) != 0) {
@@ -1909,6 +1915,7 @@ Group Batch::prepare(const uint8_t* active) {
   std::vector<EngineDev> tab(n);
   std::vector<char> stab(sz * n);
   for (int r = 0; r < n; r++) {
+    members[r]->upload_down();
     tab[r] = members[r]->dev;
     tab[r].halted = (active && !active[r]) ? 1u : 0u;
     memcpy(stab.data() + sz * r, members[r]->proto->state_host(), sz);

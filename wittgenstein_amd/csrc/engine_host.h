@@ -227,6 +227,8 @@ class Engine {
   // host copies of node fields (send-time decisions of host-side sends)
   std::vector<int32_t> hx, hy, hextra;
   std::vector<uint8_t> hdown, hbyz;
+  bool downDirty = false;        // hdown changed since its last upload (set_node_down)
+  void upload_down();
   std::vector<double> hspeed;
   std::vector<int32_t> cuts;
   // latency model (host tables mirrored on device)
