@@ -2229,6 +2229,7 @@ struct HandelHost : ProtoHost {
   // tuning knobs, see DESIGN.md "Occupancy"
   int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
   int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;
+  int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
@@ -2310,6 +2311,10 @@ struct HandelHost : ProtoHost {
     st.itemsLane = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemsWave = e.dalloc<uint32_t>((size_t)nLoc * L, false, Engine::AC_SCRATCH);
     st.itemCount = e.dalloc<uint32_t>(2);
+    st.jobs = e.dalloc<CopyJob>(e.dev.maxEvents, false, Engine::AC_SCRATCH);
+    st.jobCount = e.dalloc<uint32_t>(1);
+    st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
+    st.updCount = e.dalloc<uint32_t>(1);
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
@@ -2458,10 +2463,17 @@ struct HandelHost : ProtoHost {
     return b < 16 ? 16 : b;
   }
   // the delivery pass: k_handel_lane (one lane per node: SendSigs deliveries, narrow updateVerifiedSignatures; sorts the
-  // other nodes into the next kernel's list), then k_handel_wave (one wavefront per listed node / deferred fast path)
+  // other nodes into the next kernel's list), k_handel_copy (the wide payloads it delivered, one wavefront each), then
+  // k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_lane, dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    switch (wavesUpdate) {
+      case 8: hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 4: hipLaunchKernelGGL(k_handel_update<4>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
     const dim3 grid(node_grid(g.R), g.R);
     switch (wavesDeliver) {
       case 8: hipLaunchKernelGGL(k_handel_wave<8>, grid, dim3(256), 0, g.stream, g.tab, stab); break;

@@ -18,9 +18,10 @@
 // Who runs what (a node visit is a chain of dependent memory round trips — the kernels' throughput is
 // the number of visits IN FLIGHT over the length of that chain, so the work is cut by how many lanes a visit can use):
 //   k_handel_lane   one LANE per node: the nodes whose events of the ms (<= 4, read from the node's inbox line) are
-//                   SendSigs messages (onNewSig :757-790; payloads wider than one word are copied afterwards by the whole
-//                   wavefront) and at most one updateVerifiedSignatures task (:690-754) of a level whose block is <= 4
-//                   words — 64 visits in flight per wavefront. It also sorts every other node into the next kernel's list.
+//                   SendSigs messages (onNewSig :757-790, the hops of fast-path envelopes included; payloads wider than
+//                   one word become jobs of k_handel_copy, one wavefront each) and at most one updateVerifiedSignatures
+//                   task (:690-754) of a level whose block is <= 4 words — 64 visits in flight per wavefront. It also
+//                   sorts every other node into the next kernel's list.
 //   k_handel_wave   one WAVEFRONT per node, lanes = 64-bit words of the level block: dissemination (:331-343), the
 //                   wide levels' updateVerifiedSignatures, nodes with a chain hop or more than four events — and the
 //                   fast-path sends (:738-749) the lane kernel deferred (remaining_peers is a wave-parallel scan).
@@ -37,7 +38,8 @@ constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
 constexpr int H_QREC = 72;         // 64-bit words of a queue record: 2 + 64 entries, padded to whole 64-byte lines
-constexpr int H_LANE_NW = 4;       // level blocks of up to this many 64-bit words are worked on by ONE lane (levels <= 9)
+constexpr int H_LANE_NW = 2;       // level blocks of up to this many 64-bit words are worked on by ONE lane (levels <= 8)
+constexpr int H_UPD_NW = 256;      // ... and up to this many by k_handel_update's four words a lane (levels <= 15); beyond: k_handel_wave
 
 // The argument word of an updateVerifiedSignatures task (Rec::w3): everything the task needs to issue its loads —
 // the pending-table entry it owns, the level, the queue slot and the signer (SigToVerify.from) — so that the visit does
@@ -98,6 +100,13 @@ struct HandelState {
   // conditional-task phase scratch: the (node, level) items of this edge — node | level << 24 — by the lanes an item uses
   GP<uint32_t> itemsLane, itemsWave;      // [N * L] each
   GP<uint32_t> itemCount;                 // [2] lane items, wave items (reset by k_handel_cond_a2)
+  // SendSigs payloads wider than one word that k_handel_lane delivered: copied by k_handel_copy, one wavefront a job
+  GP<CopyJob> jobs;                       // [maxEvents]
+  // updateVerifiedSignatures tasks of the wide levels that are their node's last event of the ms: {node, event, argument,
+  // vflags}, applied by k_handel_update one wavefront each (the node's SendSigs before them by k_handel_lane)
+  GP<U4> itemsUpd;                        // [N]
+  GP<uint32_t> updCount;                  // [1] (reset with jobCount)
+  GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
@@ -1000,8 +1009,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
 __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  __shared__ CopyJob shJobs[4][256];
-  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const int lane = WG_LANE;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
@@ -1032,23 +1040,41 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       h2 = gld((const U4 WG_G*)(hdr + 8));
       total = gld((const U4 WG_G*)(hdr + 4)).w;  // HH_TOTAL (the three pieces are one 64-byte line)
     }
+    // the node's events in event order (the line is in arrival order of the expand lanes)
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++)
+      if ((uint32_t)k >= cnt) E[k].e = 0xFFFFFFFFu;
+#define H_CSWAP(A, B)                  \
+  if (E[B].e < E[A].e) {               \
+    const InboxEntry x = E[A];         \
+    E[A] = E[B];                       \
+    E[B] = x;                          \
+  }
+    H_CSWAP(0, 1) H_CSWAP(2, 3) H_CSWAP(0, 2) H_CSWAP(1, 3) H_CSWAP(1, 2)
+#undef H_CSWAP
     // ---- which kernel applies the node's events: this lane, if they are <= 4 SendSigs deliveries and at most one
-    // updateVerifiedSignatures of a narrow level; else a wavefront of k_handel_wave
+    // updateVerifiedSignatures — of a narrow level (applied here), or of a wide level as the node's LAST event (handed to
+    // k_handel_update: the deliveries before it are this lane's); else a wavefront of k_handel_wave
     bool mine = have && cnt <= (uint32_t)INBOX_SLOTS;
-    int nUpd = 0;
+    int nUpd = 0, wideAt = -1;
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) {
       if ((uint32_t)k < cnt) {
         const uint32_t kind = (E[k].w0 >> 28) & 3u;
         if (kind == K_MSG) {
-          if (E[k].w0 & INBOX_CHAIN) mine = false;  // a hop of a fast-path envelope: its re-push belongs to the visit
-        } else if (kind == K_TASK && E[k].w2 == H_TASK_UPDATE && h_nw(H_ARG_LV(E[k].w3)) <= H_LANE_NW) {
+          // (a hop of a fast-path envelope too: its re-push after the run's last hop is one record, see below)
+        } else if (kind == K_TASK && E[k].w2 == H_TASK_UPDATE) {
           nUpd++;
+          const int unw = h_nw(H_ARG_LV(E[k].w3));
+          if (unw > H_LANE_NW) {
+            if ((uint32_t)(k + 1) == cnt && unw <= H_UPD_NW)
+              wideAt = k;
+            else
+              mine = false;
+          }
         } else {
           mine = false;
         }
-      } else {
-        E[k].e = 0xFFFFFFFFu;
       }
     }
     if (nUpd > 1) mine = false;
@@ -1070,15 +1096,6 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         }
       }
     }
-    // the node's events in event order (the line is in arrival order of the expand lanes)
-#define H_CSWAP(A, B)                  \
-  if (E[B].e < E[A].e) {               \
-    const InboxEntry x = E[A];         \
-    E[A] = E[B];                       \
-    E[B] = x;                          \
-  }
-    H_CSWAP(0, 1) H_CSWAP(2, 3) H_CSWAP(0, 2) H_CSWAP(1, 3) H_CSWAP(1, 2)
-#undef H_CSWAP
     HLaneNode r;
     r.doneAt = r.doneAt0 = (long long)((unsigned long long)h2.y | ((unsigned long long)h2.z << 32));
     r.startAt = (int32_t)h0.w;
@@ -1090,7 +1107,6 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     const uint8_t toPart = (uint8_t)(vflags >> 8);
     KPROF_MARK(d.g, 25);  // inbox line + header + classification
     long long nRecv = 0, bRecv = 0;
-    uint32_t nJobs = 0;
     bool fpDefer = false;            // the node hands k_handel_wave an item: a deferred fast path, or (bailAt >= 0) the
     uint32_t fpEvent = 0, fpLevel = 0;  // rest of its visit from event bailAt on
     int bailAt = -1;
@@ -1106,12 +1122,42 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         bool deferred = false;
         if (((E[k].w0 >> 28) & 3u) == K_MSG) {
           const int32_t from = (int32_t)(E[k].w0 & 0x0FFFFFFFu);
+          const bool hop = (E[k].w0 & INBOX_CHAIN) != 0;
+          EvAux ax;
+          ax.chain = -1;
+          ax.cpos = 0;
+          ax.outBase = ax.outCap = 0;
+          if (hop) ax = gld(d.evAux + e);  // (requested before the delivery's own loads are waited for)
           if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
             nRecv++;
             bRecv += h_msg_size((int)(E[k].w2 & 31u));
             res.nrec = EV_DELIVERED | ((E[k].w2 & 31u) << 24);
             h_lane_message(d, s, t, node, r, from, E[k].w2, E[k].w3, job);
           }
+          if (hop && ax.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  :629-632
+            const int32_t next = (ax.cpos & 0x7FFFFFFF) + 1;
+            if (next < d.chains[ax.chain].ndest) {
+              if (ax.outCap > 0 && ax.outBase < d.maxOut) {
+                Out o;  // (what Ctx::put writes for O_CHAINCONT: the event's one record)
+                o.kindfrom = (O_CHAINCONT << 28) | (uint32_t)node;
+                o.to = ax.chain;
+                o.a = (uint32_t)next;
+                o.b = 0;
+                o.t = 0;
+                o.destOff = 0;
+                o.drawsub = 0;
+                o.pad = 0;
+                gst(d.outTmp + ax.outBase, o);
+              } else {
+                set_err(d.g, ERR_OUTBOX);
+              }
+              res.nrec |= 1u;
+            } else {
+              d.chains[ax.chain].flags = 0;  // envelope fully delivered
+            }
+          }
+        } else if (!toDown && k == wideAt) {
+          deferred = true;  // k_handel_update applies it (and writes the event's result)
         } else if (!toDown) {
           res.nrec = EV_TASK_RUN;
           const int st = h_lane_update(d, s, t, node, r, E[k].w3, (uint32_t)(k + 1) < cnt);
@@ -1124,9 +1170,15 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         }
         if (!deferred) gst(d.evRes + e, res);
       }
+      // a wide payload: a job of k_handel_copy (one atomic per wavefront and event slot)
       const uint64_t jm = __ballot(job.nw > 0);
-      if (job.nw > 0) shJobs[w][nJobs + __popcll(jm & lanes_lt())] = job;
-      nJobs += (uint32_t)__popcll(jm);
+      if (jm) {
+        uint32_t jb = 0;
+        const int leader = __ffsll((unsigned long long)jm) - 1;
+        if (lane == leader) jb = atomicAdd(F(s.jobCount + 0), (uint32_t)__popcll(jm));
+        jb = lane_bcast(jb, leader);
+        if (job.nw > 0) gst(s.jobs + (jb + __popcll(jm & lanes_lt())), job);
+      }
     }
     if (mine) {
       uint32_t WG_G* hdr = h_hdr(s, node);
@@ -1142,6 +1194,32 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       if (nRecv) {  // Node.msgReceived / bytesReceived (C/Network.java:611-612), kept in the header record
         atomicAdd(F(hdr + HH_NRECV), (uint32_t)nRecv);
         atomicAdd((unsigned long long*)F(hdr + HH_BRECV), (unsigned long long)bRecv);
+      }
+    }
+    {  // the node's wide updateVerifiedSignatures: an item of k_handel_update
+      bool upd = false;
+      uint32_t ue = 0, ua = 0;
+#pragma unroll
+      for (int k = 0; k < INBOX_SLOTS; k++)
+        if (mine && !toDown && k == wideAt) {
+          upd = true;
+          ue = E[k].e;
+          ua = E[k].w3;
+        }
+      const uint64_t m = __ballot(upd);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(s.updCount + 0), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (upd) {
+          U4 q;
+          q.x = (uint32_t)node;
+          q.y = ue;
+          q.z = ua;
+          q.w = vflags;
+          gst(s.itemsUpd + (bb + __popcll(m & lanes_lt())), q);
+        }
       }
     }
     {  // deferred fast paths: items of the wave-per-node kernel, behind the node visits
@@ -1167,51 +1245,222 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
     KPROF_MARK(d.g, 26);  // the lanes' events
-    KPROF_ADD(d.g, 28, nJobs);
-    // Wide payloads: the whole wavefront copies them as ONE flat word range (job j owns the words [pad_j, pad_j + nw_j)),
-    // four independent loads a lane in flight — a job per iteration would be a load -> store round trip per job, one
-    // after the other, and up to a few dozen jobs a wavefront.
-    uint32_t totalWords = 0;
-    for (uint32_t base0 = 0; base0 < nJobs; base0 += 64) {
-      const uint32_t j = base0 + (uint32_t)lane;
-      const uint32_t nwj = j < nJobs ? (uint32_t)shJobs[w][j].nw : 0u;
-      const uint32_t incl = (uint32_t)wave_incl_scan64(nwj);
-      if (j < nJobs) shJobs[w][j].pad = (int32_t)(totalWords + incl - nwj);
-      totalWords += lane_bcast(incl, 63);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < totalWords; i0 += 64 * WG_COPY_UNROLL) {
-      uint64_t v[WG_COPY_UNROLL];
-      uint64_t WG_G* dp[WG_COPY_UNROLL];
+  }
+}
+
+// updateVerifiedSignatures (:690-754) of a WIDE level (block of 8 .. 256+ words), one wavefront per task, lanes =
+// 64-bit words of the level's block. The task touches its own level only, so it reads exactly that — two pieces of the
+// node's header, the level's four scalars, its queue record, the signature and the level's three bitsets — not the
+// node's whole record; its fast path, if one follows (:738-749), becomes an item of k_handel_wave, which runs next.
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nItems = *s.updCount;
+  const int32_t t = d.g->now;
+  if (wave >= nItems) return;
+  U4 cur = gld(s.itemsUpd + wave);
+  for (uint32_t q = wave; q < nItems; q += nWaves) {
+    U4 nxt = cur;
+    if (q + nWaves < nItems) nxt = gld(s.itemsUpd + (q + nWaves));
+    const int32_t node = (int32_t)WG_READFIRST(cur.x);
+    const uint32_t e = WG_READFIRST(cur.y), arg = WG_READFIRST(cur.z), vflags = WG_READFIRST(cur.w);
+    cur = nxt;
+    const int pk = H_ARG_PK(arg), lv = H_ARG_LV(arg), slot = H_ARG_SLOT(arg);
+    const int32_t from = H_ARG_FROM(arg);
+    uint32_t WG_G* hdr = h_hdr(s, node);
+    const Lv v = sib_view(node, lv);
+    uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);
+    uint64_t WG_G* la = h_row(s, node, HK_LA, lv);
+    uint64_t WG_G* vi = h_row(s, node, HK_VI, lv);
+    const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
+    const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block
+    const uint64_t bit = 1ULL << (from & 63);
+    uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
+    uint64_t WG_G* qr = h_qrec(s, node, lv);
+    uint64_t WG_G* ent = qr + 2;
+    // ---- every load of the task (addresses from its argument alone), before the first use
+    const U4 hT = gld((const U4 WG_G*)(hdr + 4));  // .w: the sum of |totalIncoming| over the levels
+    const U4 hD = gld((const U4 WG_G*)(hdr + 8));  // .y .z: doneAt
+    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+    const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
+    U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);
+    U4 a = gld(lvA);
+    const HQHead qh = gld((const HQHead WG_G*)qr);
+    const uint64_t entAll = ent[lane];
+    const uint64_t tvv = ld_coherent(tvp);
+    uint64_t sg[4], tiw[4], law[4], viw[4];
 #pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++) {
-        const uint32_t idx = i0 + (uint32_t)u * 64u + (uint32_t)lane;
-        dp[u] = nullptr;
-        v[u] = 0;
-        if (idx < totalWords) {
-          uint32_t lo = 0, hi = nJobs;  // the last job whose first word is <= idx
-          while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)shJobs[w][mid].pad <= idx)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          const CopyJob job = shJobs[w][lo];
-          const uint32_t off = idx - (uint32_t)job.pad;
-          v[u] = job.src[off];
-          dp[u] = job.dst + off;
+    for (int u = 0; u < 4; u++) {
+      const int j = u * 64 + lane;
+      const bool in = j < v.nw;
+      sg[u] = in ? sig[j] : 0ULL;
+      tiw[u] = in ? ti[j] : 0ULL;
+      law[u] = in ? la[j] : 0ULL;
+      viw[u] = in ? vi[j] : 0ULL;
+    }
+    EvRes res;
+    res.nrec = 0;
+    res.ndraw = 0;
+    const uint32_t pe = pk == 0 ? pend.x : pk == 1 ? pend.y : pk == 2 ? pend.z : pend.w;
+    const uint32_t pf = pk == 0 ? pfrom.x : pk == 1 ? pfrom.y : pk == 2 ? pfrom.z : pfrom.w;
+    const bool toDown = (vflags & VD_DOWN) != 0;
+    if (toDown) {  // (:606 — a stopped node's task is consumed, not run)
+      if (lane == 0) gst(d.evRes + e, res);
+      continue;
+    }
+    res.nrec = EV_TASK_RUN;
+    if (pe != h_pend_word(lv, slot) || (int32_t)pf != from || v.nw > H_UPD_NW) {
+      if (lane == 0) {
+        set_err(d.g, ERR_PROTOCOL);
+        gst(d.evRes + e, res);
+      }
+      continue;
+    }
+    // the VI / TI words holding `from`: with the lane that owns block word jF
+    uint64_t viF = 0, tiF = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if ((jF >> 6) == u) {
+        viF = lane_bcast64(viw[u], jF & 63);
+        tiF = lane_bcast64(tiw[u], jF & 63);
+      }
+    const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
+    const bool ownerLane = lane == (jF & 63);
+    int cVI = (int)a.w + (hadVI ? 0 : 1);
+    const int cTI0 = (int)a.y;
+    int cTI = cTI0, cLA = (int)a.z;
+    bool improved = false;
+    if (!hadTI) {
+      cTI++;
+      improved = true;
+    }
+    uint64_t viN[4];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      viN[u] = viw[u] | ((ownerLane && (jF >> 6) == u) ? bit : 0ULL);
+      acc += (uint64_t)__popcll(sg[u] | viN[u]) | ((uint64_t)((sg[u] & law[u]) != 0) << 32);
+    }
+    acc = wave_sum64(acc);
+    const int u2 = (int)(acc & 0xFFFFFFFFu);
+    const bool inter = (acc >> 32) != 0;
+    if (u2 > cVI) {  // all.cardinality() > verifiedIndSignatures.cardinality()
+      improved = true;
+      uint64_t cnt = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = u * 64 + lane;
+        if (j < v.nw) {
+          const uint64_t nla = (inter ? 0ULL : law[u]) | sg[u];
+          const uint64_t nti = nla | viN[u];
+          if (nla != law[u]) la[j] = nla;
+          if (nti != tiw[u]) ti[j] = nti;
+          cnt += (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
         }
       }
+      cnt = wave_sum64(cnt);
+      cLA = (int)(cnt & 0xFFFFFFFFu);
+      cTI = (int)(cnt >> 32);
+    } else if (!hadTI && ownerLane) {
 #pragma unroll
-      for (int u = 0; u < WG_COPY_UNROLL; u++)
-        if (dp[u]) *dp[u] = v[u];
+      for (int u = 0; u < 4; u++)
+        if ((jF >> 6) == u) ti[jF] = tiw[u] | bit;
     }
-    __builtin_amdgcn_wave_barrier();
-    KPROF_ADD(d.g, 29, totalWords);
-    KPROF_MARK(d.g, 27);  // wide payload copies (kprof28: jobs, kprof29: words)
+    if (!hadVI && ownerLane) {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if ((jF >> 6) == u) vi[jF] = viN[u];
+    }
+    // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
+    const int len = (int)qh.len;
+    const uint64_t myEnt = lane < len ? entAll : ~0ULL;
+    int newLen = len;
+    bool emptied = false;
+    {
+      const uint64_t hit = __ballot(lane < len && (int)(myEnt & 0xFF) == slot);
+      if (hit) {
+        const int at = __ffsll((unsigned long long)hit) - 1;
+        const uint64_t next = shfl64(myEnt, (lane + 1) & 63);
+        if (lane >= at && lane < len - 1) ent[lane] = next;
+        newLen = len - 1;
+        emptied = len == 1;
+      }
+    }
+    const int total = (int)hT.w + (cTI - cTI0);
+    long long doneAt = (long long)((unsigned long long)hD.y | ((unsigned long long)hD.z << 32));
+    const bool justDone = improved && doneAt == 0 && total >= s.p.threshold;
+    const bool fastPathFollows = improved && cTI == v.size && s.p.fastPath > 0 && lv + 1 < s.L;
+    if (lane == 0) {
+      *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
+      hdr[HH_PEND + pk] = 0;
+      a.y = (uint32_t)cTI;
+      a.z = (uint32_t)cLA;
+      a.w = (uint32_t)cVI;
+      gst(lvA, a);
+      if (total != (int)hT.w) hdr[HH_TOTAL] = (uint32_t)total;
+      if (emptied) atomicAnd(F(hdr + HH_QMASK), ~(1u << lv));
+      // the entry's slot dies with this task unless another registered task still references it
+      const uint32_t key = h_pend_word(lv, slot);
+      const bool held = (pk != 0 && pend.x == key) || (pk != 1 && pend.y == key) || (pk != 2 && pend.z == key) || (pk != 3 && pend.w == key);
+      HQHead nh;
+      nh.len = (uint64_t)newLen;
+      nh.used = held ? qh.used : (qh.used & ~(1ULL << slot));
+      if (nh.len != qh.len || nh.used != qh.used) gst((HQHead WG_G*)qr, nh);
+      if (justDone) {
+        hdr[HH_DONE_LO] = (uint32_t)t;
+        hdr[HH_DONE_HI] = 0;
+        d.nodes.doneAt[node] = (long long)t;
+      }
+      if (fastPathFollows) {  // k_handel_wave runs it (and writes the event's result: its sends are the event's records)
+        const uint32_t bb = atomicAdd(F(&d.g->nActiveB), 1u);
+        U4 qd;
+        qd.x = (uint32_t)node;
+        qd.y = HW_FASTPATH | (vflags << 8);
+        qd.z = e;
+        qd.w = (uint32_t)lv;
+        gst((U4 WG_G*)(VisitDesc WG_G*)d.activeB + bb, qd);
+      } else {
+        gst(d.evRes + e, res);
+      }
+    }
+  }
+}
+
+// ... the wide SendSigs payloads k_handel_lane delivered (:769 `sig` of the SigToVerify: the receiver's level block of
+// the sender's snapshot): one WAVEFRONT per job, lanes = consecutive 64-bit words, the next job's descriptor in flight
+// while the current one is copied. (As the tail of the lane kernel — each wavefront copying its own lanes' payloads
+// one round after the other — the copies were that kernel's longest dependent chain.)
+__global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nJobs = *s.jobCount;
+  if (wave >= nJobs) return;
+  CopyJob cur = gld(s.jobs + wave);
+  for (uint32_t q = wave; q < nJobs; q += nWaves) {
+    CopyJob nxt = cur;
+    if (q + nWaves < nJobs) nxt = gld(s.jobs + (q + nWaves));
+    for (int j0 = 0; j0 < cur.nw; j0 += 256) {
+      uint64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + u * 64 + lane;
+        v[u] = j < cur.nw ? cur.src[j] : 0ULL;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + u * 64 + lane;
+        if (j < cur.nw) cur.dst[j] = v[u];
+      }
+    }
+    cur = nxt;
   }
 }
 
@@ -1304,6 +1553,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   const uint32_t epoch = d.g->epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int lane = WG_LANE;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the delivery pass's copy jobs and wide updates have been done)
+    *s.jobCount = 0;
+    *s.updCount = 0;
+  }
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
