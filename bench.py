@@ -150,7 +150,7 @@ def cpu_baseline(n_sample, workload="handel"):
     # the only parallelism the reference admits (C/RunMultipleTimes.java:44-48): independent seeds, one per core
     try:
         avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16, int(0.5 * avail / (16.0 * n_sample * n_sample + (1 << 28)))))
+        cores = max(1, min(len(os.sched_getaffinity(0)), int(0.5 * avail / (16.0 * n_sample * n_sample + (1 << 28)))))  # every host core, memory permitting
     except Exception:
         cores = 1
     if cores > 1:
@@ -369,7 +369,7 @@ def main_shard(args):
                                    "false" % (n, kl if kl else world, " on one GPU (in-process loopback all-reduce)" if kl else ""),
                        "nodes": n, "parallelism": "node-range shards of one simulation (wg_shard_configure%s)" % ("" if (kl or args.shard_callback) else "_rccl: engine-owned RCCL communicator"), "shards": kl if kl else world,
                        "allreduce_calls_per_simulation": traffic[0], "allreduce_int32_words_per_simulation": traffic[1]},
-            "roofline": {"bound": "hbm", "kernel": "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> on rank 0's node range",
+            "roofline": {"bound": "hbm", "kernel": "k_handel_lane + k_handel_copy + k_handel_update + k_handel_wave on rank 0's node range",
                          "achieved": (alg_bytes / (kl if kl else world) / max(1, dk_spans)) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (alg_bytes / (kl if kl else world) / max(1, dk_spans)) / max(1.0, avg_ns) / HBM_PEAK_GBS,
                          "traffic": None, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
@@ -432,7 +432,8 @@ def main():
                          "the sharing; three and more lose to their smaller launches")
     ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
                     "bounded by the box's cores and host memory)")
-    ap.add_argument("--cpu-sample-nodes", type=int, default=8192)
+    ap.add_argument("--cpu-sample-nodes", type=int, default=16384,
+                    help="nodes of the cpu_baseline sample run (the oracle on host cores; 16 384 nodes: ~ 20 s of one core, half the GPU workload's node count)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second", action="store_true", help="skip the second_workload object (Casper IMD, config 5's node count)")
     ap.add_argument("--attesters-per-round", type=int, default=4096, help="--workload casper: attesters voting per slot")
@@ -676,7 +677,7 @@ def main():
                    "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes),
                    "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WG_")}},
     }
-    # ---- roofline of the dominant kernel (k_deliver<HandelProto>): algorithmic bytes of everything delivered
+    # ---- roofline of the delivery pass (Handel: k_handel_lane + _copy + _update + _wave): algorithmic bytes of everything delivered
     # in the timed region / its launches, over its average duration measured with HIP events in the timed region
     if by_level is None:
         import numpy as np
@@ -695,7 +696,7 @@ def main():
         if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
             traffic = tj.get("hbm_bytes_per_launch") * n_first / R
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (the delivery pass: "
+        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_copy + k_handel_update + k_handel_wave (the delivery pass: "
                                                               "one launch of each per simulated ms)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,

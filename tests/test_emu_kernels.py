@@ -35,17 +35,17 @@ import test_gpu_engine as te  # noqa: E402
 import test_gpu_gsf as tg  # noqa: E402
 import test_gpu_handel as th  # noqa: E402
 import test_gpu_casper as tc  # noqa: E402
-import test_zq_gpu_p2pflood_resident as tfr  # noqa: E402
-import test_zr_gpu_casper_resident as tcr  # noqa: E402
-import test_zt_gpu_sanfermin_resident as tsr  # noqa: E402
-import test_zv_gpu_p2pflood as tpf  # noqa: E402
-import test_zw_gpu_sanfermin as tsf  # noqa: E402
-import test_zy_gpu_fuzz as tf  # noqa: E402
+import test_gpu_p2pflood_resident as tfr  # noqa: E402
+import test_gpu_casper_resident as tcr  # noqa: E402
+import test_gpu_sanfermin_resident as tsr  # noqa: E402
+import test_gpu_p2pflood as tpf  # noqa: E402
+import test_gpu_sanfermin as tsf  # noqa: E402
+import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
 import test_gpu_snapshot as tsn  # noqa: E402
 import test_gpu_city as tcy  # noqa: E402
-import test_zx_gpu_handel_hostmode as thh  # noqa: E402
-import test_zx_gpu_sanfermin_cappos as tsc  # noqa: E402
+import test_gpu_handel_hostmode as thh  # noqa: E402
+import test_gpu_sanfermin_cappos as tsc  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -101,7 +101,7 @@ def test_batch_every_ms():
 
 
 def test_batch_run_multiple_times_on_device():  # wg_batch_run_multiple_times: the loop condition on the device
-    tb.test_run_multiple_times_device_loop_equals_host_loop(64)  # (per-seed oracle runs: tests/test_zu_gpu_graph.py)
+    tb.test_run_multiple_times_device_loop_equals_host_loop(64)  # (per-seed oracle runs: tests/test_gpu_graph.py)
 
 
 def test_graph_replay_keeps_the_profiler(monkeypatch):
@@ -207,7 +207,7 @@ def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage 
 
 
 def test_sendall_expanded_on_the_device():
-    import test_zs_gpu_send_expand as tse
+    import test_gpu_send_expand as tse
     tse.test_sendall_expanded_on_the_device_many_tiles()
 
 

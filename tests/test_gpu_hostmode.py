@@ -188,9 +188,9 @@ def test_batched_steps_protocols_match_oracle(monkeypatch):
     list's draw), Casper IMD (sendAll, far tasks) and the scheduler fuzz (partitions, stops, discard) on batched steps"""
     monkeypatch.setenv("WG_HOST_BATCH", "1")
     import test_gpu_casper as tc
-    import test_zv_gpu_p2pflood as tpf
-    import test_zw_gpu_sanfermin as tsf
-    import test_zy_gpu_fuzz as tf
+    import test_gpu_p2pflood as tpf
+    import test_gpu_sanfermin as tsf
+    import test_gpu_fuzz as tf
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
     tpf.test_p2pflood_three_messages_by_distance()

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_sendall_expanded_on_the_device_many_tiles():
     """a sendAll of 5000 destinations — createMessageArrivals + its stable sort on the device (k_send_expand_*: five
     tiles of the counting sort) — against the oracle; drops at send time (partitions, stopped nodes, discard time) go
-    through the same kernels in tests/test_zy_gpu_fuzz.py"""
+    through the same kernels in tests/test_gpu_fuzz.py"""
     g = w.PingPong(w.PingPongParameters(5000, parity.NB, parity.NL), seed=4)
     g.init()
     c = o.PingPong(5000, parity.NB, parity.NL, seed=4)
@@ -37,7 +37,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests")
 %(pre)s
 import oracle_lib as o
 o.build()
-import test_gpu_engine as te, test_zy_gpu_fuzz as tf
+import test_gpu_engine as te, test_gpu_fuzz as tf
 te.test_pingpong_chunking_and_seeds(7)
 tf.test_fuzz_partitions_stops_and_discard(2)
 tf.run(64, 12, "NetworkNoLatency", seed=11, chunk=5, chunks=40)

@@ -139,7 +139,7 @@ def leg9():
     # 9. Casper IMD, 2 x 1024 attesters (2 051 nodes, every vote a sendAll to all of them): 4 logical shards == the
     # unsharded engine after every chunk — a size the oracle does not reach inside a test
     from wittgenstein_amd import protocols as P
-    import test_zr_gpu_casper_resident as tcr
+    import test_gpu_casper_resident as tcr
     params = (2, False, 2, 1024, 1000, 1)
     ref = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=1, max_slots=8); ref.init()
     K = 4

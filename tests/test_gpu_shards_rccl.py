@@ -3,7 +3,7 @@ pipeline with its per-ms sums as ncclAllReduce calls on the engine's own stream 
 torch.distributed in the process at all (a Java host has neither). One GPU on the box: a one-rank communicator; every
 kernel of the sharded path and every collective runs, results against the oracle bit for bit. Shard-count invariance
 over 2/3/4 ranks is tests/test_shards_gloo.py (caller-supplied collective, gloo); 8 logical shards at BASELINE config
-3's size against the oracle's golden trace is tests/test_zz_gpu_shards.py."""
+3's size against the oracle's golden trace is tests/test_gpu_shards.py."""
 import numpy as np
 import pytest
 
@@ -67,7 +67,7 @@ def test_gsf_through_the_engines_own_communicator():
 
 
 def test_casper_through_the_engines_own_communicator():  # sendAll + far envelopes + the table exchange through ncclAllReduce
-    import test_zr_gpu_casper_resident as tcr
+    import test_gpu_casper_resident as tcr
     from wittgenstein_amd import protocols as P
     params = (5, False, 5, 80, 1000, 1)
     g = P.CasperIMD(P.CasperParemeters(*params, None, None), seed=3, max_slots=16, config=shards.config_rccl())
@@ -84,7 +84,7 @@ def test_casper_through_the_engines_own_communicator():  # sendAll + far envelop
 
 
 def test_p2pflood_through_the_engines_own_communicator():
-    import test_zq_gpu_p2pflood_resident as tf
+    import test_gpu_p2pflood_resident as tf
     from wittgenstein_amd import protocols as P
     params = (300, 20, 20, 3, 1, 6, 10)
     g = P.P2PFlood(P.P2PFloodParameters(*params, None, None), seed=4, config=shards.config_rccl())

@@ -2,9 +2,9 @@
 owner of the node, block / attestation tables replicated and filled by exchange (CasperState::xtab, k_casper_shard_apply),
 sendAll through the replicated envelope creation (k_shard_multi_*, k_sendall_* on every shard), the 8-second periodic
 tasks through the far buffer every shard keeps alike. k shards in one process (shards.LoopbackGroup) on the CPU wave
-emulator here — on one MI355X in tests/test_zz_gpu_shards.py — in lock-step with the oracle (oracle/casper.hpp, pinned
+emulator here — on one MI355X in tests/test_gpu_shards.py — in lock-step with the oracle (oracle/casper.hpp, pinned
 against PT/CasperIMDTest / PT/CasperByzantineTest): after every chunk every observable of
-tests/test_zr_gpu_casper_resident.py::diff, assembled from the shards' own rows."""
+tests/test_gpu_casper_resident.py::diff, assembled from the shards' own rows."""
 import os
 import subprocess
 
@@ -31,7 +31,7 @@ def casper_loopback(k, params, seed, chunk, chunks, byz_delay=0, max_slots=16, s
     """k logical shards in lock-step with the oracle; returns (oracle, traffic of the shards)"""
     import oracle_lib as o
     from wittgenstein_amd import protocols as P, shards
-    import test_zr_gpu_casper_resident as tcr
+    import test_gpu_casper_resident as tcr
     grp = shards.LoopbackGroup(k, device_memory=device_memory)
     sims = []
     for s in range(k):

@@ -259,7 +259,7 @@ import wittgenstein_amd._lib as L
 L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
 from wittgenstein_amd import shards, protocols as P
 import oracle_lib as o
-import test_zt_gpu_sanfermin_resident as ts
+import test_gpu_sanfermin_resident as ts
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 params = %(params)r
@@ -307,7 +307,7 @@ import wittgenstein_amd._lib as L
 L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
 from wittgenstein_amd import shards, protocols as P
 import oracle_lib as o
-import test_zr_gpu_casper_resident as tcr
+import test_gpu_casper_resident as tcr
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 params = %(params)r
@@ -342,7 +342,7 @@ dist.destroy_process_group()
 def test_sharded_casper_matches_the_oracle(oracle, tmp_path, world, params, byz, stopped, chunk, chunks):
     """Casper IMD resident on node-range shards (per-node rows by owner, block / attestation tables replicated and filled by
     exchange, sendAll resolved on every shard, periodic tasks through every shard's far buffer): every observable of
-    tests/test_zr_gpu_casper_resident.py::diff after every chunk, over gloo ranks"""
+    tests/test_gpu_casper_resident.py::diff after every chunk, over gloo ranks"""
     global WORKER
     keep, WORKER = WORKER, CASPER_WORKER
     try:
@@ -364,7 +364,7 @@ import wittgenstein_amd._lib as L
 L.LIB_PATH = os.path.join(%(root)r, "tests", "emu", "libwittgpu_emu.so")   # test infrastructure: no GPU here
 from wittgenstein_amd import shards, protocols as P
 import oracle_lib as o
-import test_zq_gpu_p2pflood_resident as tf
+import test_gpu_p2pflood_resident as tf
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 params = %(params)r

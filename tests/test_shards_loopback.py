@@ -1,5 +1,5 @@
 """k shards of one simulation in ONE process (wittgenstein_amd.shards.LoopbackGroup: k engines, k host threads, the
-all-reduce sums the k buffers in place) — on the CPU wave emulator here, on one MI355X in tests/test_zz_gpu_shards.py.
+all-reduce sums the k buffers in place) — on the CPU wave emulator here, on one MI355X in tests/test_gpu_shards.py.
 Shard-count invariance against the oracle, as tests/test_shards_gloo.py checks it over processes."""
 import os
 import subprocess
@@ -136,10 +136,10 @@ def test_logical_shards_equal_the_unsharded_engine():
 def p2pflood_loopback(k, params, nl, seed, chunk, chunks, device_memory=False):
     """P2PFlood (P/P2PFlood.java) resident on k logical shards in lock-step with the oracle: every first receipt's shuffled
     MultipleDestWithDelayEnvelope — destinations AND explicit arrivals — goes through the replicated envelope creation
-    (k_shard_multi_fill / k_shard_multi_create); every observable of tests/test_zq_gpu_p2pflood_resident.py::diff"""
+    (k_shard_multi_fill / k_shard_multi_create); every observable of tests/test_gpu_p2pflood_resident.py::diff"""
     import oracle_lib as o
     from wittgenstein_amd import protocols as P, shards
-    import test_zq_gpu_p2pflood_resident as tf
+    import test_gpu_p2pflood_resident as tf
     grp = shards.LoopbackGroup(k, device_memory=device_memory)
     sims = []
     for s in range(k):

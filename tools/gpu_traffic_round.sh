@@ -24,4 +24,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python tools/prof_summary.py pmc $OUT/p_$c $OUT/pmc_$c.md && rm -rf $OUT/p_$c
   head -14 $OUT/pmc_$c.md
 done
-python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_wave<" | head -12
+python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_copy,k_handel_update<,k_handel_wave<" | head -12
