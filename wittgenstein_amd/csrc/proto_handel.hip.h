@@ -38,7 +38,9 @@ constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
 constexpr int H_QREC = 72;         // 64-bit words of a queue record: 2 + 64 entries, padded to whole 64-byte lines
-constexpr int H_LANE_NW = 2;       // level blocks of up to this many 64-bit words are worked on by ONE lane (levels <= 8)
+constexpr int H_LANE_NW = 16;      // level blocks of up to this many 64-bit words are worked on by ONE lane, which streams
+                                   // them two words a load (levels <= 11); a wavefront per item spends ~ 25 wave-level memory
+                                   // instructions on ONE item, and that instruction rate is what bounds those kernels
 constexpr int H_UPD_NW = 256;      // ... and up to this many by k_handel_update's four words a lane (levels <= 15); beyond: k_handel_wave
 
 // The argument word of an updateVerifiedSignatures task (Rec::w3): everything the task needs to issue its loads —
@@ -792,6 +794,27 @@ struct HandelProto {
   }
 };
 
+// One lane streams a level's block: word j of up to four of the level's arrays at a time, two words a load where the
+// block has them (blocks of >= 2 words start 16-byte aligned). F(j, a, b, c, d) is called once per word.
+struct alignas(16) V2 {
+  uint64_t x, y;
+};
+template <class F>
+__device__ __forceinline__ void h_stream4(const uint64_t WG_G* pa, const uint64_t WG_G* pb, const uint64_t WG_G* pc,
+                                          const uint64_t WG_G* pd, int nw, F f) {
+  if (nw == 1) {
+    f(0, pa[0], pb[0], pc[0], pd[0]);
+    return;
+  }
+#pragma unroll 2
+  for (int j = 0; j < nw; j += 2) {
+    const V2 a = gld((const V2 WG_G*)(pa + j)), b = gld((const V2 WG_G*)(pb + j));
+    const V2 c = gld((const V2 WG_G*)(pc + j)), dd = gld((const V2 WG_G*)(pd + j));
+    f(j, a.x, b.x, c.x, dd.x);
+    f(j + 1, a.y, b.y, c.y, dd.y);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The delivery pass, first kernel: one LANE per node with events (the reference applies an envelope to its `to` node,
 // C/Network.java:594-635; a lane applies its node's <= 4 events of the ms in event order).
@@ -873,7 +896,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   const int32_t from = H_ARG_FROM(arg);
   uint32_t WG_G* hdr = h_hdr(s, node);
   const Lv v = sib_view(node, lv);
-  uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);  // (the level's five bitsets side by side: one line up to level 9)
+  uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);  // (the level's five bitsets side by side)
   uint64_t WG_G* la = h_row(s, node, HK_LA, lv);
   uint64_t WG_G* vi = h_row(s, node, HK_VI, lv);
   const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
@@ -882,25 +905,17 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
   uint64_t WG_G* qr = h_qrec(s, node, lv);
   uint64_t WG_G* ent = qr + 2;
-  // ---- every load of the event (they depend on the task's argument only), before the first use
+  // ---- the loads that depend on the task's argument only, before the first use
   const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
   const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
   U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);   // {posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|}
   U4 a = gld(lvA);
   const HQHead qh = gld((const HQHead WG_G*)qr);
   const uint64_t tvv = *tvp;
-  uint64_t sg[H_LANE_NW], tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
+  const uint64_t viF = vi[jF], tiF = ti[jF];
+  uint64_t e6[6];  // the head of the level's list (the record's first line); longer lists are walked in memory below
 #pragma unroll
-  for (int j = 0; j < H_LANE_NW; j++) {
-    const bool in = j < v.nw;
-    sg[j] = in ? sig[j] : 0ULL;
-    tiw[j] = in ? ti[j] : 0ULL;
-    law[j] = in ? la[j] : 0ULL;
-    viw[j] = in ? vi[j] : 0ULL;
-  }
-  uint64_t e8[8];  // the head of the level's list (a line); longer lists are walked in memory below
-#pragma unroll
-  for (int i = 0; i < 8; i++) e8[i] = ent[i];
+  for (int i = 0; i < 6; i++) e6[i] = ent[i];
   // ---- the pending-table entry this task owns
   const uint32_t pe = pk == 0 ? pend.x : pk == 1 ? pend.y : pk == 2 ? pend.z : pend.w;
   const uint32_t pf = pk == 0 ? pfrom.x : pk == 1 ? pfrom.y : pk == 2 ? pfrom.z : pfrom.w;
@@ -909,12 +924,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
     return H_UPD_DONE;
   }
   // ---- what the task will do to the level's sets, before anything is stored (H_UPD_BAIL leaves the node untouched)
-  bool hadVI = false, hadTI = false;
-#pragma unroll
-  for (int j = 0; j < H_LANE_NW; j++) {
-    hadVI |= j == jF && (viw[j] & bit) != 0;
-    hadTI |= j == jF && (tiw[j] & bit) != 0;
-  }
+  const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
   int cVI = (int)a.w + (hadVI ? 0 : 1);
   const int cTI0 = (int)a.y;
   int cTI = cTI0, cLA = (int)a.z;
@@ -923,32 +933,29 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
     cTI++;
     improved = true;
   }
-  uint64_t viN[H_LANE_NW];  // verifiedIndSignatures with `from` set
-#pragma unroll
-  for (int j = 0; j < H_LANE_NW; j++) viN[j] = viw[j] | (j == jF ? bit : 0ULL);
+  // all = sig | verifiedInd (with `from`) ; intersects(lastAgg, sig)
   int u2 = 0;
   bool inter = false;
-#pragma unroll
-  for (int j = 0; j < H_LANE_NW; j++) {
-    u2 += __popcll(sg[j] | (viN[j] & v.mask));
-    inter |= (sg[j] & law[j] & v.mask) != 0;
-  }
+  h_stream4(sig, vi, la, la, v.nw, [&](int j, uint64_t sg, uint64_t viw, uint64_t law, uint64_t) {
+    viw |= j == jF ? bit : 0ULL;
+    u2 += __popcll(sg | (viw & v.mask));
+    inter |= (sg & law & v.mask) != 0;
+  });
   const bool replace = u2 > cVI;  // all.cardinality() > verifiedIndSignatures.cardinality(): the aggregate replaces / extends lastAggVerified
-  uint64_t nla[H_LANE_NW], nti[H_LANE_NW];
+  const bool mayComplete = s.p.fastPath > 0 && lv + 1 < s.L;  // (a complete level lets the levels above take the fast path)
   if (replace) {
     improved = true;
-    cLA = 0;
-    cTI = 0;
-#pragma unroll
-    for (int j = 0; j < H_LANE_NW; j++) {
-      nla[j] = j < v.nw ? ((inter ? 0ULL : (law[j] & v.mask)) | sg[j]) : 0ULL;
-      nti[j] = j < v.nw ? (nla[j] | (viN[j] & v.mask)) : 0ULL;
-      cLA += __popcll(nla[j]);
-      cTI += __popcll(nti[j]);
+    if (hasLater && mayComplete) {  // would the level become complete? (counted before anything is stored)
+      int nTI = 0;
+      h_stream4(sig, vi, la, la, v.nw, [&](int j, uint64_t sg, uint64_t viw, uint64_t law, uint64_t) {
+        viw |= j == jF ? bit : 0ULL;
+        nTI += __popcll((inter ? 0ULL : (law & v.mask)) | sg | (viw & v.mask));
+      });
+      if (nTI == v.size) return H_UPD_BAIL;
     }
+  } else if (hasLater && mayComplete && improved && cTI == v.size) {
+    return H_UPD_BAIL;
   }
-  const bool fastPathMayFollow = improved && cTI == v.size && s.p.fastPath > 0 && lv + 1 < s.L;  // justCompleted
-  if (fastPathMayFollow && hasLater) return H_UPD_BAIL;
   // ---- apply
   hdr[HH_PEND + pk] = 0;
   *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
@@ -959,37 +966,35 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
     // (static indices throughout: a register array indexed at run time would live in scratch memory)
     int at = -1;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-      if (i < len && at < 0 && (int)(e8[i] & 0xFF) == slot) at = i;
-    for (int i = 8; i < len && at < 0; i++)
+    for (int i = 0; i < 6; i++)
+      if (i < len && at < 0 && (int)(e6[i] & 0xFF) == slot) at = i;
+    for (int i = 6; i < len && at < 0; i++)
       if ((int)(ent[i] & 0xFF) == slot) at = i;
     if (at >= 0) {
 #pragma unroll
-      for (int i = 0; i < 7; i++)
-        if (i >= at && i + 1 < len) ent[i] = e8[i + 1];
-      for (int i = at > 7 ? at : 7; i + 1 < len; i++) ent[i] = ent[i + 1];
+      for (int i = 0; i < 5; i++)
+        if (i >= at && i + 1 < len) ent[i] = e6[i + 1];
+      for (int i = at > 5 ? at : 5; i + 1 < len; i++) ent[i] = ent[i + 1];
       nh.len = (uint64_t)(len - 1);
       if (len == 1) r.qmask &= ~(1u << lv);
     }
   }
-  if (replace) {
-#pragma unroll
-    for (int j = 0; j < H_LANE_NW; j++) {
-      if (j < v.nw) {
-        if (nla[j] != (law[j] & v.mask)) la[j] = (law[j] & ~v.mask) | nla[j];
-        if (nti[j] != (tiw[j] & v.mask)) ti[j] = (tiw[j] & ~v.mask) | nti[j];
-      }
-    }
+  if (replace) {  // (only the words that change are written)
+    cLA = 0;
+    cTI = 0;
+    h_stream4(sig, vi, la, ti, v.nw, [&](int j, uint64_t sg, uint64_t viw, uint64_t law, uint64_t tiw) {
+      const uint64_t viN = viw | (j == jF ? bit : 0ULL);
+      const uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
+      const uint64_t nti = nla | (viN & v.mask);
+      if (nla != (law & v.mask)) la[j] = (law & ~v.mask) | nla;
+      if (nti != (tiw & v.mask)) ti[j] = (tiw & ~v.mask) | nti;
+      cLA += __popcll(nla);
+      cTI += __popcll(nti);
+    });
   } else if (!hadTI) {
-#pragma unroll
-    for (int j = 0; j < H_LANE_NW; j++)
-      if (j == jF) ti[j] = tiw[j] | bit;
+    ti[jF] = tiF | bit;
   }
-  if (!hadVI) {
-#pragma unroll
-    for (int j = 0; j < H_LANE_NW; j++)
-      if (j == jF) vi[j] = viN[j];
-  }
+  if (!hadVI) vi[jF] = viF | bit;
   a.y = (uint32_t)cTI;
   a.z = (uint32_t)cLA;
   a.w = (uint32_t)cVI;
@@ -1003,7 +1008,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   r.total += cTI - cTI0;
   if (!improved) return H_UPD_DONE;
   if (r.doneAt == 0 && r.total >= s.p.threshold) r.doneAt = t;
-  return fastPathMayFollow ? H_UPD_DEFER : H_UPD_DONE;
+  return (cTI == v.size && mayComplete) ? H_UPD_DEFER : H_UPD_DONE;  // justCompleted
 }
 
 __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
@@ -1672,14 +1677,6 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       const int window = (int)hdr[HH_WINDOW];
       const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
       const HQHead qh = gld((const HQHead WG_G*)qr);
-      uint64_t tiw[H_LANE_NW], law[H_LANE_NW], viw[H_LANE_NW];
-#pragma unroll
-      for (int j = 0; j < H_LANE_NW; j++) {
-        const bool in = j < v.nw;
-        tiw[j] = in ? ti[j] & v.mask : 0ULL;
-        law[j] = in ? la[j] & v.mask : 0ULL;
-        viw[j] = in ? vi[j] & v.mask : 0ULL;
-      }
       uint64_t e4[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) e4[i] = ent[i];
@@ -1692,50 +1689,40 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
       int bestScore = 0, bestOutsideRank = 0;
       unsigned long long keep = 0;
-      for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signatures in flight at a time
-        uint64_t x[4], sg[4][H_LANE_NW];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u;
-          x[u] = i < len ? (i0 == 0 ? e4[u] : ent[i]) : 0ULL;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, (int)(x[u] & 0xFF));
-#pragma unroll
-          for (int j = 0; j < H_LANE_NW; j++) sg[u][j] = (i0 + u < len && j < v.nw) ? sig[j] : 0ULL;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u;
-          if (i >= len) break;
-          int u1 = 0, u2 = 0, cs = 0;
-          bool iTI = false, iLA = false;
-#pragma unroll
-          for (int j = 0; j < H_LANE_NW; j++) {
-            u1 += __popcll(sg[u][j] | tiw[j] | viw[j]);
-            u2 += __popcll(sg[u][j] | viw[j]);
-            cs += __popcll(sg[u][j]);
-            iTI |= (sg[u][j] & tiw[j]) != 0;
-            iLA |= (sg[u][j] & law[j]) != 0;
-          }
-          const long long who = (long long)(uint32_t)x[u];  // signer << 8 | slot
-          const int rank = (int)(uint32_t)(x[u] >> 32);
-          const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rank, windowIndex, window);
-          if (ev.keep) {
-            keep |= 1ULL << i;
-            if (ev.inside) {  // best inside = FIRST entry with the strictly greatest positive score
-              if (ev.score > bestScore) {
-                bestScore = ev.score;
-                bestInside = who;
-              }
-            } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
-              bestOutside = who;
-              bestOutsideRank = rank;
+      // one entry after the other, its signature streamed against the level's three sets (whose lines stay in L1)
+      auto consider = [&](int i, uint64_t x) {
+        int u1 = 0, u2 = 0, cs = 0;
+        bool iTI = false, iLA = false;
+        h_stream4(h_sig_ptr(s, node, l, (int)(x & 0xFF)), ti, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
+          tiw &= v.mask;
+          viw &= v.mask;
+          law &= v.mask;
+          u1 += __popcll(sg | tiw | viw);
+          u2 += __popcll(sg | viw);
+          cs += __popcll(sg);
+          iTI |= (sg & tiw) != 0;
+          iLA |= (sg & law) != 0;
+        });
+        const long long who = (long long)(uint32_t)x;  // signer << 8 | slot
+        const int rank = (int)(uint32_t)(x >> 32);
+        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rank, windowIndex, window);
+        if (ev.keep) {
+          keep |= 1ULL << i;
+          if (ev.inside) {  // best inside = FIRST entry with the strictly greatest positive score
+            if (ev.score > bestScore) {
+              bestScore = ev.score;
+              bestInside = who;
             }
+          } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
+            bestOutside = who;
+            bestOutsideRank = rank;
           }
         }
-      }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (i < len) consider(i, e4[i]);
+      for (int i = 4; i < len; i++) consider(i, ent[i]);
       const int kept = __popcll(keep);
       unsigned long long relMask = 0;
       if (kept != len) {
