@@ -2228,7 +2228,7 @@ struct HandelHost : ProtoHost {
   // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
   // tuning knobs, see DESIGN.md "Occupancy"
   int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
-  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 5;  // (k_handel_a1 fits 96 VGPRs: five waves a SIMD without scratch)
+  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;  // (k_handel_a1: 110 VGPRs, no scratch; five waves spill)
   int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const int32_t N = p.nodeCount;

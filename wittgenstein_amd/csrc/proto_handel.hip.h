@@ -200,6 +200,27 @@ __device__ __forceinline__ void row_set(uint64_t WG_G* row, int32_t id, bool v) 
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) { return wave_reduce_add64(v); }
 
+// One lane streams a level's block: word j of up to four of the level's arrays at a time, two words a load where the
+// block has them (blocks of >= 2 words start 16-byte aligned). F(j, a, b, c, d) is called once per word.
+struct alignas(16) V2 {
+  uint64_t x, y;
+};
+template <class F>
+__device__ __forceinline__ void h_stream4(const uint64_t WG_G* pa, const uint64_t WG_G* pb, const uint64_t WG_G* pc,
+                                          const uint64_t WG_G* pd, int nw, F f) {
+  if (nw == 1) {
+    f(0, pa[0], pb[0], pc[0], pd[0]);
+    return;
+  }
+#pragma unroll 2
+  for (int j = 0; j < nw; j += 2) {
+    const V2 a = gld((const V2 WG_G*)(pa + j)), b = gld((const V2 WG_G*)(pb + j));
+    const V2 c = gld((const V2 WG_G*)(pc + j)), dd = gld((const V2 WG_G*)(pd + j));
+    f(j, a.x, b.x, c.x, dd.x);
+    f(j + 1, a.y, b.y, c.y, dd.y);
+  }
+}
+
 // per-wave LDS mirror of the (node, level) scalars
 struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_SPARE1 (32 words each), then the scalars
   int32_t pos[32];
@@ -559,11 +580,24 @@ struct HandelProto {
     const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
     const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
     const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
-    uint64_t sv[4];
+    // (two words a lane: the kernel is bound by its wave-level memory instructions. A pair of consecutive block words
+    // sits side by side in one level's group — except the pair made of the node's own word and its level-7 sibling)
+    V2 sv[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int j = q * 64 + lane;
-      sv[q] = j < tv.nw ? *h_word(s, node, HK_TI, tv.bw + j) & tv.mask : 0ULL;
+    for (int q = 0; q < 2; q++) {
+      const int j = 2 * (q * 64 + lane);
+      sv[q].x = sv[q].y = 0;
+      if (tv.nw == 1) {
+        if (q == 0 && lane == 0) sv[q].x = *h_word(s, node, HK_TI, tv.bw) & tv.mask;
+      } else if (j < tv.nw) {
+        const int x = tv.bw + j;
+        if ((x >> 1) == (node >> 7)) {
+          sv[q].x = *h_word(s, node, HK_TI, x);
+          sv[q].y = *h_word(s, node, HK_TI, x + 1);
+        } else {
+          sv[q] = gld((const V2 WG_G*)h_word(s, node, HK_TI, x));
+        }
+      }
     }
     if (open) {
       const uint64_t WG_G* fpRow = h_row(s, node, HK_FP, lane);  // lane = level: the level's sibling block
@@ -581,9 +615,13 @@ struct HandelProto {
     const bool lf = cti == mySize;  // incomingComplete :524-526
     {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int j = q * 64 + lane;
-        if (j < tv.nw) s.snap[refBase + j] = sv[q];
+      for (int q = 0; q < 2; q++) {
+        const int j = 2 * (q * 64 + lane);
+        if (tv.nw == 1) {
+          if (q == 0 && lane == 0) s.snap[refBase] = sv[q].x;
+        } else if (j < tv.nw) {
+          gst((V2 WG_G*)(s.snap + refBase + j), sv[q]);
+        }
       }
       for (int j0 = 256; j0 < tv.nw; j0 += 256) {  // (beyond 16 384 ids per block: N > 32 768)
         uint64_t v[4];
@@ -793,27 +831,6 @@ struct HandelProto {
     if (r.doneAt == 0 && cur >= s.p.threshold) r.doneAt = c.t;
   }
 };
-
-// One lane streams a level's block: word j of up to four of the level's arrays at a time, two words a load where the
-// block has them (blocks of >= 2 words start 16-byte aligned). F(j, a, b, c, d) is called once per word.
-struct alignas(16) V2 {
-  uint64_t x, y;
-};
-template <class F>
-__device__ __forceinline__ void h_stream4(const uint64_t WG_G* pa, const uint64_t WG_G* pb, const uint64_t WG_G* pc,
-                                          const uint64_t WG_G* pd, int nw, F f) {
-  if (nw == 1) {
-    f(0, pa[0], pb[0], pc[0], pd[0]);
-    return;
-  }
-#pragma unroll 2
-  for (int j = 0; j < nw; j += 2) {
-    const V2 a = gld((const V2 WG_G*)(pa + j)), b = gld((const V2 WG_G*)(pb + j));
-    const V2 c = gld((const V2 WG_G*)(pc + j)), dd = gld((const V2 WG_G*)(pd + j));
-    f(j, a.x, b.x, c.x, dd.x);
-    f(j + 1, a.y, b.y, c.y, dd.y);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // The delivery pass, first kernel: one LANE per node with events (the reference applies an envelope to its `to` node,
@@ -1288,26 +1305,42 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     uint64_t WG_G* qr = h_qrec(s, node, lv);
     uint64_t WG_G* ent = qr + 2;
-    // ---- every load of the task (addresses from its argument alone), before the first use
-    const U4 hT = gld((const U4 WG_G*)(hdr + 4));  // .w: the sum of |totalIncoming| over the levels
-    const U4 hD = gld((const U4 WG_G*)(hdr + 8));  // .y .z: doneAt
-    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
-    const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
-    U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);
-    U4 a = gld(lvA);
-    const HQHead qh = gld((const HQHead WG_G*)qr);
+    // ---- every load of the task (addresses from its argument alone), before the first use. The kernel is bound by its
+    // wave-level memory instructions: the six 16-byte pieces of the header / level / record are ONE instruction (lane k
+    // fetches piece k), the rows and the signature move two words a lane.
+    const U4 WG_G* piece = lane == 0 ? (const U4 WG_G*)(hdr + 4)             // .w: the sum of |totalIncoming| over the levels
+                           : lane == 1 ? (const U4 WG_G*)(hdr + 8)           // .y .z: doneAt
+                           : lane == 2 ? (const U4 WG_G*)(hdr + HH_PEND)
+                           : lane == 3 ? (const U4 WG_G*)(hdr + HH_PENDFROM)
+                           : lane == 4 ? (const U4 WG_G*)h_lv(s, node, HP_POS, lv) : (const U4 WG_G*)qr;
+    U4 pg;
+    pg.x = pg.y = pg.z = pg.w = 0;
+    if (lane < 6) pg = gld(piece);
     const uint64_t entAll = ent[lane];
     const uint64_t tvv = ld_coherent(tvp);
-    uint64_t sg[4], tiw[4], law[4], viw[4];
+    V2 sg[2], tiw[2], law[2], viw[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int j = u * 64 + lane;
-      const bool in = j < v.nw;
-      sg[u] = in ? sig[j] : 0ULL;
-      tiw[u] = in ? ti[j] : 0ULL;
-      law[u] = in ? la[j] : 0ULL;
-      viw[u] = in ? vi[j] : 0ULL;
+    for (int u = 0; u < 2; u++) {
+      const int j = 2 * (u * 64 + lane);
+      sg[u].x = sg[u].y = tiw[u].x = tiw[u].y = law[u].x = law[u].y = viw[u].x = viw[u].y = 0;
+      if (j < v.nw) {
+        sg[u] = gld((const V2 WG_G*)(sig + j));
+        tiw[u] = gld((const V2 WG_G*)(ti + j));
+        law[u] = gld((const V2 WG_G*)(la + j));
+        viw[u] = gld((const V2 WG_G*)(vi + j));
+      }
     }
+    auto bc = [&](uint32_t w, int l_) { return WG_READLANE(w, l_); };
+    U4 hT, hD, pend, pfrom, a;
+    hT.x = bc(pg.x, 0), hT.y = bc(pg.y, 0), hT.z = bc(pg.z, 0), hT.w = bc(pg.w, 0);
+    hD.x = bc(pg.x, 1), hD.y = bc(pg.y, 1), hD.z = bc(pg.z, 1), hD.w = bc(pg.w, 1);
+    pend.x = bc(pg.x, 2), pend.y = bc(pg.y, 2), pend.z = bc(pg.z, 2), pend.w = bc(pg.w, 2);
+    pfrom.x = bc(pg.x, 3), pfrom.y = bc(pg.y, 3), pfrom.z = bc(pg.z, 3), pfrom.w = bc(pg.w, 3);
+    a.x = bc(pg.x, 4), a.y = bc(pg.y, 4), a.z = bc(pg.z, 4), a.w = bc(pg.w, 4);
+    HQHead qh;
+    qh.len = (uint64_t)bc(pg.x, 5) | ((uint64_t)bc(pg.y, 5) << 32);
+    qh.used = (uint64_t)bc(pg.z, 5) | ((uint64_t)bc(pg.w, 5) << 32);
+    U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);
     EvRes res;
     res.nrec = 0;
     res.ndraw = 0;
@@ -1326,16 +1359,17 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
       }
       continue;
     }
-    // the VI / TI words holding `from`: with the lane that owns block word jF
+    // the VI / TI words holding `from`: with the lane (and half) that owns block word jF
+    const int fLane = (jF >> 1) & 63, fU = jF >> 7, fHalf = jF & 1;
     uint64_t viF = 0, tiF = 0;
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if ((jF >> 6) == u) {
-        viF = lane_bcast64(viw[u], jF & 63);
-        tiF = lane_bcast64(tiw[u], jF & 63);
+    for (int u = 0; u < 2; u++)
+      if (fU == u) {
+        viF = lane_bcast64(fHalf ? viw[u].y : viw[u].x, fLane);
+        tiF = lane_bcast64(fHalf ? tiw[u].y : tiw[u].x, fLane);
       }
     const bool hadVI = (viF & bit) != 0, hadTI = (tiF & bit) != 0;
-    const bool ownerLane = lane == (jF & 63);
+    const bool ownerLane = lane == fLane;
     int cVI = (int)a.w + (hadVI ? 0 : 1);
     const int cTI0 = (int)a.y;
     int cTI = cTI0, cLA = (int)a.z;
@@ -1344,12 +1378,19 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
       cTI++;
       improved = true;
     }
-    uint64_t viN[4];
+    V2 viN[2];
     uint64_t acc = 0;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      viN[u] = viw[u] | ((ownerLane && (jF >> 6) == u) ? bit : 0ULL);
-      acc += (uint64_t)__popcll(sg[u] | viN[u]) | ((uint64_t)((sg[u] & law[u]) != 0) << 32);
+    for (int u = 0; u < 2; u++) {
+      viN[u] = viw[u];
+      if (ownerLane && fU == u) {
+        if (fHalf)
+          viN[u].y |= bit;
+        else
+          viN[u].x |= bit;
+      }
+      acc += (uint64_t)(__popcll(sg[u].x | viN[u].x) + __popcll(sg[u].y | viN[u].y)) |
+             ((uint64_t)(((sg[u].x & law[u].x) | (sg[u].y & law[u].y)) != 0) << 32);
     }
     acc = wave_sum64(acc);
     const int u2 = (int)(acc & 0xFFFFFFFFu);
@@ -1358,29 +1399,26 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
       improved = true;
       uint64_t cnt = 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = u * 64 + lane;
-        if (j < v.nw) {
-          const uint64_t nla = (inter ? 0ULL : law[u]) | sg[u];
-          const uint64_t nti = nla | viN[u];
-          if (nla != law[u]) la[j] = nla;
-          if (nti != tiw[u]) ti[j] = nti;
-          cnt += (uint64_t)__popcll(nla) | ((uint64_t)__popcll(nti) << 32);
+      for (int u = 0; u < 2; u++) {
+        const int j = 2 * (u * 64 + lane);
+        if (j < v.nw) {  // (only the 16-byte pieces that change are written)
+          V2 nla, nti;
+          nla.x = (inter ? 0ULL : law[u].x) | sg[u].x;
+          nla.y = (inter ? 0ULL : law[u].y) | sg[u].y;
+          nti.x = nla.x | viN[u].x;
+          nti.y = nla.y | viN[u].y;
+          if (nla.x != law[u].x || nla.y != law[u].y) gst((V2 WG_G*)(la + j), nla);
+          if (nti.x != tiw[u].x || nti.y != tiw[u].y) gst((V2 WG_G*)(ti + j), nti);
+          cnt += (uint64_t)(__popcll(nla.x) + __popcll(nla.y)) | ((uint64_t)(__popcll(nti.x) + __popcll(nti.y)) << 32);
         }
       }
       cnt = wave_sum64(cnt);
       cLA = (int)(cnt & 0xFFFFFFFFu);
       cTI = (int)(cnt >> 32);
     } else if (!hadTI && ownerLane) {
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if ((jF >> 6) == u) ti[jF] = tiw[u] | bit;
+      ti[jF] = tiF | bit;
     }
-    if (!hadVI && ownerLane) {
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if ((jF >> 6) == u) vi[jF] = viN[u];
-    }
+    if (!hadVI && ownerLane) vi[jF] = viF | bit;
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     const int len = (int)qh.len;
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
@@ -1763,22 +1801,40 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
     uint64_t WG_G* qr = h_qrec(s, node, l);
     uint64_t WG_G* ent = qr + 2;
-    // ---- everything the item's address alone decides, before the first use: header pieces (every lane the same
-    // address), the whole list (lane i = entry i) and this lane's word of the three rows
-    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
-    const int window = (int)hdr[HH_WINDOW];
-    const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
-    const HQHead qh = gld((const HQHead WG_G*)qr);
+    // ---- everything the item's address alone decides, before the first use. These kernels are bound by the number of
+    // wave-level memory instructions, so: the four 16-byte pieces (pending table, the header words with the window, the
+    // level's scalars, the record's head) are ONE instruction — lane k fetches piece k —, the list is one (lane i = entry
+    // i), and the rows and signatures move two words a lane (blocks of <= 256 words: two instructions an array at most)
+    const U4 WG_G* piece = lane == 0 ? (const U4 WG_G*)(hdr + HH_PEND)
+                           : lane == 1 ? (const U4 WG_G*)(hdr + 4)
+                           : lane == 2 ? (const U4 WG_G*)h_lv(s, node, HP_POS, l) : (const U4 WG_G*)qr;
+    U4 pg;
+    pg.x = pg.y = pg.z = pg.w = 0;
+    if (lane < 4) pg = gld(piece);
     const uint64_t entAll = ent[lane];
-    const int jh = lane;
-    const bool oneRound = v.nw <= 64;
-    uint64_t tih = 0, vih = 0, lah = 0;
-    if (oneRound && jh < v.nw) {
-      tih = ti[jh];
-      vih = vi[jh];
-      lah = la[jh];
+    const bool wideRound = v.nw <= 256;  // (levels <= 15; beyond: the word loop below)
+    V2 ti2[2], vi2[2], la2[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = 2 * (u * 64 + lane);
+      ti2[u].x = ti2[u].y = vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
+      if (wideRound && j < v.nw) {
+        ti2[u] = gld((const V2 WG_G*)(ti + j));
+        vi2[u] = gld((const V2 WG_G*)(vi + j));
+        la2[u] = gld((const V2 WG_G*)(la + j));
+      }
     }
-    const int len = (int)WG_READFIRST((uint32_t)qh.len), curSize = (int)WG_READFIRST(lvA.y), cLA = (int)WG_READFIRST(lvA.z);
+    U4 pend;
+    pend.x = WG_READLANE(pg.x, 0);
+    pend.y = WG_READLANE(pg.y, 0);
+    pend.z = WG_READLANE(pg.z, 0);
+    pend.w = WG_READLANE(pg.w, 0);
+    const int window = (int)WG_READLANE(pg.y, 1);  // HH_WINDOW = word 5
+    const int curSize = (int)WG_READLANE(pg.y, 2), cLA = (int)WG_READLANE(pg.z, 2);
+    HQHead qh;
+    qh.len = (uint64_t)WG_READLANE(pg.x, 3) | ((uint64_t)WG_READLANE(pg.y, 3) << 32);
+    qh.used = (uint64_t)WG_READLANE(pg.z, 3) | ((uint64_t)WG_READLANE(pg.w, 3) << 32);
+    const int len = (int)qh.len;
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
     const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
     const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
@@ -1787,51 +1843,58 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
     int bestScore = 0, bestOutsideRank = 0;
     uint64_t keep = 0;
-    for (int i0 = 0; i0 < len; i0 += 4) {  // four entries' signature words in flight at a time
-      uint64_t sg[4];
-      int slotU[4], rankU[4];
-      uint32_t whoU[4];
+    for (int i0 = 0; i0 < len; i0 += 2) {  // two entries' signatures in flight at a time
+      V2 sg[2][2];
+      int slotU[2], rankU[2];
+      uint32_t whoU[2];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u < len ? i0 + u : len - 1;
-        whoU[u] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
-        slotU[u] = (int)(whoU[u] & 0xFFu);
-        rankU[u] = (int)lane_bcast((uint32_t)myRank, i);
-        sg[u] = (oneRound && jh < v.nw && i0 + u < len) ? h_sig_ptr(s, node, l, slotU[u])[jh] : 0ULL;
+      for (int e2 = 0; e2 < 2; e2++) {
+        const int i = i0 + e2 < len ? i0 + e2 : len - 1;
+        whoU[e2] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
+        slotU[e2] = (int)(whoU[e2] & 0xFFu);
+        rankU[e2] = (int)lane_bcast((uint32_t)myRank, i);
+        const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int j = 2 * (u * 64 + lane);
+          sg[e2][u].x = sg[e2][u].y = 0;
+          if (wideRound && j < v.nw && i0 + e2 < len) sg[e2][u] = gld((const V2 WG_G*)(sig + j));
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u;
+      for (int e2 = 0; e2 < 2; e2++) {
+        const int i = i0 + e2;
         if (i >= len) break;
         uint64_t a = 0, b = 0;
-        if (oneRound) {
-          if (jh < v.nw) {
-            a = (uint64_t)__popcll(sg[u] | tih | vih) | ((uint64_t)__popcll(sg[u] | vih) << 21) | ((uint64_t)__popcll(sg[u]) << 42);
-            b = (uint64_t)((sg[u] & tih) != 0) | ((uint64_t)((sg[u] & lah) != 0) << 21);
+        auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
+          a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
+          b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
+        };
+        if (wideRound) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) {  // (words beyond the block are zero in every array: they add nothing)
+            word(sg[e2][u].x, ti2[u].x, vi2[u].x, la2[u].x);
+            word(sg[e2][u].y, ti2[u].y, vi2[u].y, la2[u].y);
           }
         } else {
-          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[u]);
-          H_FOR_WORDS(v, j) {
-            const uint64_t sgw = sig[j], tiw = ti[j], viw = vi[j], law = la[j];
-            a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
-            b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
-          }
+          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
+          H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
         }
         a = wave_sum64(a);
         b = wave_sum64(b);
         const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
         const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[u], windowIndex, window);
+        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
         if (ev.keep) {
           keep |= 1ULL << i;
           if (ev.inside) {
             if (ev.score > bestScore) {
               bestScore = ev.score;
-              bestInside = (long long)whoU[u];
+              bestInside = (long long)whoU[e2];
             }
-          } else if (bestOutside < 0 || rankU[u] < bestOutsideRank) {
-            bestOutside = (long long)whoU[u];
-            bestOutsideRank = rankU[u];
+          } else if (bestOutside < 0 || rankU[e2] < bestOutsideRank) {
+            bestOutside = (long long)whoU[e2];
+            bestOutsideRank = rankU[e2];
           }
         }
       }
