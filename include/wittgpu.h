@@ -29,7 +29,10 @@ typedef enum {
   WG_ESTATE = -2,   /* IllegalStateException */
   WG_ENOMEM = -3,   /* a device pool/ring overflowed (raise the wg_config capacity named in the message) */
   WG_EHIP = -4,     /* HIP runtime error / no device */
-  WG_EUNSUPPORTED = -5 /* a reference feature the resident protocol does not cover (message says which) */
+  WG_EUNSUPPORTED = -5, /* a reference feature the resident protocol does not cover (message says which) */
+  WG_EHOSTINIT = -6     /* init() state the device was asked to build (wg_handel_init_state.peers == NULL) needs the host's
+                           sequential rd after all — a rejected nextInt(bound) draw inside a shuffle, p ~ 1e-9 per draw:
+                           build it on the host and load again */
 } wg_status;
 
 /* in-place SUM of `count` int32 words at buf (device memory) across the shards of one simulation; see
@@ -177,7 +180,12 @@ typedef struct {
  *   startAt[n], nodePairingTime[n]   HNode fields (:280-283)
  *   receptionRanks[n*n]              row i = HNode i's receptionRanks (:285, :940-948)
  *   peers[n*(n-1)]                   row i = concatenation over levels 1..L-1 of HLevel.peers (emission
- *                                    order, :510-522); level l occupies [2^(l-1)-1, 2^l-1). Ignored for down nodes. */
+ *                                    order, :510-522); level l occupies [2^(l-1)-1, 2^l-1). Ignored for down nodes.
+ *                                    NULL: the engine builds the lists on the device from receptionRanks (buildEmissionList
+ *                                    :510-522 for every live sender: sort by the receivers' rank of the sender, shuffle equal
+ *                                    ranks with rd) — rd must be where init() has it at that point (wg_rng_set_state before
+ *                                    the load) and comes back advanced by the shuffles' draws; unsharded engines of up to
+ *                                    65 536 nodes; WG_EHOSTINIT if a draw was rejected (then load again with host-built lists). */
 typedef struct {
   const int32_t* startAt;
   const int32_t* nodePairingTime;

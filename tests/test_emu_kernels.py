@@ -84,6 +84,12 @@ def test_handel_256_chunks_of_10():
     th.lockstep(th.ratios(256), step=10)
 
 
+def test_handel_emission_lists_on_the_device(monkeypatch):  # k_handel_init_sort / k_handel_init_shuffle vs the oracle's init()
+    th.test_256_every_ms()
+    th.test_emission_lists_built_on_the_device(1)
+    th.test_emission_lists_fall_back_to_the_host(monkeypatch)
+
+
 def test_handel_chunk_size_is_observable():
     th.test_chunk_size_is_observable_and_matches(7)
 

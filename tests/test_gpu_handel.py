@@ -48,7 +48,29 @@ def test_tiny_networks(n):  # single-word rows, masks inside one 64-bit word
 
 
 def test_256_every_ms():
-    lockstep(ratios(256), step=1)
+    g, _ = lockstep(ratios(256), step=1)
+    assert g.init_on_device  # the emission lists came from k_handel_init_sort / k_handel_init_shuffle
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_emission_lists_built_on_the_device(seed):
+    """init()'s buildEmissionList for every (sender, level) (P/Handel.java:991-1013, 510-522) on the device: rank sort,
+    bucket shuffles from rd's skipped-ahead state, rd left where the sequential host loop leaves it (diff_handel compares the
+    generator state); the first disseminations walk every list's head, the lock-step run the rest"""
+    g, c = lockstep(ratios(512, dead=0.2), step=5, max_ms=400, seed=seed)
+    assert g.init_on_device
+
+
+def test_emission_lists_fall_back_to_the_host(monkeypatch):
+    """a rejected nextInt(bound) draw (java.util.Random's loop, probability about bound / 2^31 per draw) makes the draw count
+    data dependent: the device reports it (WG_EHOSTINIT) and wgh_handel_create starts over with the host's sequential rd"""
+    monkeypatch.setenv("WG_FORCE_INIT_REJECT", "1")
+    g, c = lockstep(ratios(256), step=10, max_ms=200)
+    assert not g.init_on_device
+    monkeypatch.delenv("WG_FORCE_INIT_REJECT")
+    monkeypatch.setenv("WG_HOST_INIT", "1")
+    g, c = lockstep(ratios(256), step=10, max_ms=200)
+    assert not g.init_on_device
 
 
 def test_1024_chunks_of_10():  # RunMultipleTimes' runMs(10) loop (C/RunMultipleTimes.java:50-64)

@@ -32,7 +32,7 @@ class UnsupportedError(NotImplementedError):
 
 
 _EXC = {L.WG_EINVAL: IllegalArgumentException, L.WG_ESTATE: IllegalStateException, L.WG_ENOMEM: EngineCapacityError,
-        L.WG_EHIP: HipError, L.WG_EUNSUPPORTED: UnsupportedError}
+        L.WG_EHIP: HipError, L.WG_EUNSUPPORTED: UnsupportedError, L.WG_EHOSTINIT: UnsupportedError}
 
 
 def _raise(rc, msg):

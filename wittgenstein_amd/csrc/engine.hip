@@ -2234,7 +2234,7 @@ struct HandelHost : ProtoHost {
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
     if (N < 2 || (N & (N - 1))) throw WgError(WG_EINVAL, "We support only power of two nodes in this simulation");
-    if (!init.startAt || !init.nodePairingTime || !init.receptionRanks || !init.peers)
+    if (!init.startAt || !init.nodePairingTime || !init.receptionRanks)
       throw WgError(WG_EINVAL, "wg_handel_init_state has NULL members");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N)
@@ -2319,7 +2319,9 @@ struct HandelHost : ProtoHost {
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
     WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
-    if (peers16) {  // (narrowed on the host, a slice at a time)
+    if (!init.peers) {
+      build_peers(e);  // buildEmissionList on the device (k_handel_init_sort / _shuffle)
+    } else if (peers16) {  // (narrowed on the host, a slice at a time)
       const size_t total = nLoc * (size_t)(N - 1), step = (size_t)1 << 26;
       std::vector<uint16_t> tmp(std::min(total, step));
       const int32_t* src = init.peers + (size_t)lo * (N - 1);
@@ -2358,6 +2360,55 @@ struct HandelHost : ProtoHost {
     WG_HIP(hipStreamSynchronize(e.stream));
     (void)hipFree(dStart);
     (void)hipFree(dPair);
+  }
+  // The emission lists of every live sender on the device (P/Handel.java:991-1013): the sort per (sender, level), the draw
+  // counts summed on the host in the reference's order, the equal-rank shuffles from jumped rd states. Leaves the engine's
+  // rd advanced by the draws, as init() would.
+  void build_peers(Engine& e) {
+    const int32_t N = st.N;
+    if (e.shardCount > 0 || N > 65536)
+      throw WgError(WG_EINVAL, "device-built emission lists: an unsharded engine of at most 65 536 nodes (pass wg_handel_init_state.peers)");
+    const size_t NL = (size_t)N * st.L;
+    uint32_t* dCnt = nullptr;
+    unsigned long long* dOffs = nullptr;
+    uint32_t* dRej = nullptr;
+    WG_HIP(hipMalloc((void**)&dCnt, 4 * NL));
+    WG_HIP(hipMalloc((void**)&dOffs, 8 * NL));
+    WG_HIP(hipMalloc((void**)&dRej, 4));
+    struct Free {
+      void *a, *b, *c;
+      ~Free() {
+        (void)hipFree(a);
+        (void)hipFree(b);
+        (void)hipFree(c);
+      }
+    } guard{dCnt, dOffs, dRej};
+    WG_HIP(hipMemsetAsync(dRej, 0, 4, e.stream));
+    const size_t lds = sizeof(uint32_t) * (size_t)std::max(2, N / 2);
+#if !defined(WG_EMU)
+    if (lds > 48 * 1024)
+      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+    const int grid = std::max(1, std::min(N, 2048 / WG_GRID_DIV));
+    hipLaunchKernelGGL(k_handel_init_sort, dim3(grid), dim3(1024), lds, e.stream, st, e.dev.nodes.down, dCnt);
+    std::vector<uint32_t> cnt(NL);
+    WG_HIP(hipMemcpyAsync(cnt.data(), dCnt, 4 * NL, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    std::vector<unsigned long long> offs(NL);
+    unsigned long long draws = 0;
+    for (size_t i = 0; i < NL; i++) {  // (sender ascending, level ascending: the order init() walks them in)
+      offs[i] = draws;
+      draws += cnt[i];
+    }
+    WG_HIP(hipMemcpyAsync(dOffs, offs.data(), 8 * NL, hipMemcpyHostToDevice, e.stream));
+    hipLaunchKernelGGL(k_handel_init_shuffle, dim3(grid), dim3(256), 0, e.stream, st, e.dev.nodes.down, dOffs, e.gh.rng, dRej);
+    uint32_t rej = 0;
+    WG_HIP(hipMemcpyAsync(&rej, dRej, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    if (rej || (getenv("WG_FORCE_INIT_REJECT") && atoi(getenv("WG_FORCE_INIT_REJECT"))))
+      throw WgError(WG_EHOSTINIT, "a nextInt(bound) draw of an emission-list shuffle was rejected: the lists need the host's sequential rd");
+    e.gh.rng = lcg_skip(e.gh.rng, draws);
+    e.globalsDirty = true;
   }
   bool has_cond() const override { return true; }
   int levels() const override { return st.L; }

@@ -16,6 +16,7 @@ using wg::JavaRandom;
 
 static thread_local std::string g_err;
 static thread_local double g_initSeconds = 0;
+static thread_local int32_t g_initOnDevice = 0;
 
 namespace {
 
@@ -199,6 +200,7 @@ int32_t wgh_register_city_latency(const char* latencyName, int32_t mode, int32_t
   return WG_OK;
 }
 double wgh_last_init_seconds(void) { return g_initSeconds; }
+int32_t wgh_last_init_on_device(void) { return g_initOnDevice; }
 
 int32_t wgh_jrandom_ints(int64_t seed, int32_t n, int32_t* out) {
   JavaRandom r(seed);
@@ -254,9 +256,24 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
   return WG_OK;
 }
 
+static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                             const wg_config* cfg, wg_engine** out, bool devicePeers);
+// Handel.init() (P/Handel.java:957-1014). The emission lists (:991-1013) are built on the device where the engine can
+// (unsharded, 256 .. 65 536 nodes: wg_handel_init_state.peers == NULL) and on the host otherwise — or after all, when
+// the device met a rejected draw (WG_EHOSTINIT); WG_HOST_INIT=1 keeps everything on the host.
 int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out) {
   if (!out || !pp) return WG_EINVAL;
+  const bool hostOnly = getenv("WG_HOST_INIT") && atoi(getenv("WG_HOST_INIT")) != 0;
+  const bool sharded = cfg && cfg->nshards > 0;
+  if (!hostOnly && !sharded && pp->nodeCount >= 256 && pp->nodeCount <= 65536) {
+    const int32_t rc = handel_create(pp, nodeBuilderName, latencyName, seed, cfg, out, true);
+    if (rc != WG_EHOSTINIT) return rc;
+  }
+  return handel_create(pp, nodeBuilderName, latencyName, seed, cfg, out, false);
+}
+static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
+                             const wg_config* cfg, wg_engine** out, bool devicePeers) {
   *out = nullptr;
   auto t0 = std::chrono::steady_clock::now();
   wg_handel_params p = *pp;
@@ -334,8 +351,9 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   // the sibling block of size 2^(l-1) in ascending id (expectedNodes :446-455); they are bucketed by
   // receiver.receptionRanks[s], buckets walked in rank order, a bucket with >1 entries shuffled with rd.
   const int L = 32 - __builtin_clz((unsigned)N);  // levels 0..log2(N)
-  std::vector<int32_t> peers((size_t)N * (N > 1 ? N - 1 : 1), -1);
-  {
+  std::vector<int32_t> peers;
+  if (!devicePeers) {
+    peers.assign((size_t)N * (N > 1 ? N - 1 : 1), -1);
     // column s of `ranks` is read for every sender: transpose tile-wise first (cache friendly)
     std::vector<int32_t> ranksT((size_t)N * N);
     const int TB = 64;
@@ -394,9 +412,17 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   st.startAt = startAt.data();
   st.nodePairingTime = pairing.data();
   st.receptionRanks = ranks.data();
-  st.peers = peers.data();
-  CK(wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st));
+  st.peers = devicePeers ? nullptr : peers.data();  // (NULL: the engine builds them from the ranks and advances rd itself)
+  {
+    const int32_t rc = wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st);
+    if (rc == WG_EHOSTINIT) return rc;  // (the engine is destroyed by the guard; the caller starts over with host-built lists)
+    if (rc != WG_OK) {
+      g_err = wg_last_error(e);
+      return rc;
+    }
+  }
   g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  g_initOnDevice = devicePeers ? 1 : 0;
   guard.keep = true;
   *out = e;
   return WG_OK;

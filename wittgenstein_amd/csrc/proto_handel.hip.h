@@ -2040,6 +2040,123 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
   }
 }
 
+// ---- init() on the device: the emission lists (P/Handel.java:991-1013, buildEmissionList :510-522) -----------------
+// For sender s and level l the receivers are the sibling block of 2^(l-1) ids; they are bucketed by the RECEIVER's
+// receptionRanks[s], the buckets walked in rank order, a bucket of several receivers shuffled with the shared rd. The
+// shuffles are the only sequential part — rd is one stream over (sender, level, bucket) in that order — and a bucket of
+// g receivers draws exactly g - 1 times (a rejected draw, p ~ 1e-9, is flagged: the caller then builds the lists on the
+// host). So: (A) every (sender, level) sorts its block by (rank, id) — one workgroup per sender, bitonic in LDS — writes
+// the list unshuffled and counts its draws (elements - buckets); the host prefix-sums the counts in (sender, level)
+// order; (B) every bucket of several receivers shuffles itself from the rd state jumped to its first draw.
+// The receiver's rank of the sender is receptionRanks[receiver][sender]: a column of the uploaded matrix.
+__device__ __forceinline__ void h_peer_store(const HandelState& s, size_t idx, int32_t v) {
+  if (s.peers16)
+    ((uint16_t WG_G*)(const uint16_t WG_G*)s.peers16)[idx] = (uint16_t)v;
+  else
+    ((int32_t WG_G*)(const int32_t WG_G*)s.peers32)[idx] = v;
+}
+__global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const uint8_t* __restrict__ down, uint32_t* __restrict__ cnt) {
+  WG_DYN_LDS(uint32_t, key);  // [N / 2] (rank << idBits | offset in the block): unique, so any sort is the stable one
+  __shared__ uint32_t shGroups;
+  const int N = s.N, L = s.L;
+  for (int snd = blockIdx.x; snd < N; snd += gridDim.x) {
+    if (down[snd]) {  // (a stopped node gets no levels' peers; its row stays as allocated and is never read)
+      for (int l = threadIdx.x; l < L; l += blockDim.x) cnt[(size_t)snd * L + l] = 0;
+      continue;
+    }
+    if (threadIdx.x == 0) cnt[(size_t)snd * L] = 0;
+    for (int l = 1; l < L; l++) {
+      const int m = 1 << (l - 1), base = ((snd >> (l - 1)) ^ 1) << (l - 1), idBits = l - 1;
+      for (int k = threadIdx.x; k < m; k += blockDim.x)
+        key[k] = ((uint32_t)s.ranks[(size_t)(base + k) * N + snd] << idBits) | (uint32_t)k;
+      if (threadIdx.x == 0) shGroups = 0;
+      __syncthreads();
+      for (int kk = 2; kk <= m; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+          for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const uint32_t a = key[i], b = key[ixj];
+              if ((a > b) == ((i & kk) == 0)) {
+                key[i] = b;
+                key[ixj] = a;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      uint32_t mine = 0;
+      for (int pos = threadIdx.x; pos < m; pos += blockDim.x) {
+        const uint32_t kv = key[pos];
+        h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(kv & (uint32_t)(m - 1)));
+        mine += pos == 0 || (kv >> idBits) != (key[pos - 1] >> idBits);  // a bucket starts here
+      }
+      mine = wave_reduce_add32(mine);
+      if (WG_LANE == 0 && mine) atomicAdd(&shGroups, mine);
+      __syncthreads();
+      if (threadIdx.x == 0) cnt[(size_t)snd * L + l] = (uint32_t)m - shGroups;  // draws: a bucket of g draws g - 1 times
+      __syncthreads();
+    }
+  }
+}
+// (B): one thread per list position; the first position of a bucket of g >= 2 receivers runs the bucket's shuffle —
+// for (k = g; k > 1; k--) swap(a[k - 1], a[rd.nextInt(k)]) (Collections.shuffle) — from the jumped rd state
+__global__ void __launch_bounds__(256) k_handel_init_shuffle(HandelState s, const uint8_t* __restrict__ down,
+                                                             const unsigned long long* __restrict__ offs, uint64_t rng0,
+                                                             uint32_t* __restrict__ rejected) {
+  __shared__ uint32_t shW[4];
+  __shared__ uint32_t shCarry;
+  const int N = s.N, L = s.L;
+  for (int snd = blockIdx.x; snd < N; snd += gridDim.x) {
+    if (down[snd]) continue;
+    for (int l = 2; l < L; l++) {  // (level 1 is one receiver)
+      const int m = 1 << (l - 1);
+      const size_t at = (size_t)snd * (N - 1) + (m - 1);
+      const unsigned long long off = offs[(size_t)snd * L + l];
+      if (threadIdx.x == 0) shCarry = 0;
+      __syncthreads();
+      for (int p0 = 0; p0 < m; p0 += blockDim.x) {
+        const int pos = p0 + (int)threadIdx.x;
+        int32_t rk = -1, rkPrev = -2, rkNext = -3;
+        if (pos < m) {
+          rk = s.ranks[(size_t)h_peer(s, at + pos) * N + snd];
+          if (pos > 0) rkPrev = s.ranks[(size_t)h_peer(s, at + pos - 1) * N + snd];
+          if (pos + 1 < m) rkNext = s.ranks[(size_t)h_peer(s, at + pos + 1) * N + snd];
+        }
+        const bool start = pos < m && rk != rkPrev;
+        // buckets started before this position (this one included): block-wide inclusive count
+        const uint64_t bm = __ballot(start);
+        const uint32_t inWave = (uint32_t)__popcll(bm & (lanes_lt() | (1ULL << WG_LANE)));
+        if (WG_LANE == 0) shW[threadIdx.x >> 6] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t before = shCarry, total = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+          if (w < (int)(threadIdx.x >> 6)) before += shW[w];
+          total += shW[w];
+        }
+        const uint32_t q = before + inWave - 1;  // this position's bucket, counted from 0
+        __syncthreads();
+        if (threadIdx.x == 0) shCarry += total;
+        if (start && rk == rkNext) {  // a bucket of g >= 2: this is its first position
+          int g = 2;
+          while (pos + g < m && s.ranks[(size_t)h_peer(s, at + pos + g) * N + snd] == rk) g++;
+          // draws before the bucket in this list: (positions before) - (buckets before)
+          uint64_t st = lcg_skip(rng0, off + (unsigned long long)(pos - (int)q));
+          for (int k = g; k > 1; k--) {
+            int consumed;
+            const int32_t j = lcg_next_int_bounded(st, k, &consumed);
+            if (consumed != 1) atomicOr(rejected, 1u);
+            const int32_t a = h_peer(s, at + pos + k - 1), b = h_peer(s, at + pos + j);
+            h_peer_store(s, at + pos + k - 1, b);
+            h_peer_store(s, at + pos + j, a);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // ---- sharded engine: the periodic-task snapshots of this ms (Handel SendSigs.sigs, P/Handel.java:254; GSFSignature
 // toSend.clone(), P/GSFSignature.java:146) reach the other shards -------------------------------------------------
 // A snapshot is read at delivery by the receiver's shard at the address the message carries, so every shard keeps

@@ -89,6 +89,7 @@ class Handel:
             _raise(rc, L.lib().wgh_last_error().decode())
         self._net = Network(h)
         self.init_seconds = L.lib().wgh_last_init_seconds()
+        self.init_on_device = bool(L.lib().wgh_last_init_on_device())  # the emission lists (P/Handel.java:991-1013)
 
     def network(self):
         return self._net
