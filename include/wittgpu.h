@@ -179,6 +179,9 @@ typedef struct {
 /* Per-node state produced by Handel.init() (P/Handel.java:957-1014), uploaded once:
  *   startAt[n], nodePairingTime[n]   HNode fields (:280-283)
  *   receptionRanks[n*n]              row i = HNode i's receptionRanks (:285, :940-948)
+ *                                    NULL (with peers NULL): the engine runs setReceivingRanks' Collections.shuffle of the one
+ *                                    shared list once per node (:940-948, 966-989) on the device, from rd where init() has it
+ *                                    at that point; same limits and WG_EHOSTINIT as for peers.
  *   peers[n*(n-1)]                   row i = concatenation over levels 1..L-1 of HLevel.peers (emission
  *                                    order, :510-522); level l occupies [2^(l-1)-1, 2^l-1). Ignored for down nodes.
  *                                    NULL: the engine builds the lists on the device from receptionRanks (buildEmissionList
@@ -379,7 +382,9 @@ typedef enum {
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */
   WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2,
-  WG_LF_REMAINING_CALLS = 3 /* GSF SFLevel.remainingCalls (P/GSFSignature.java:257) */
+  WG_LF_REMAINING_CALLS = 3, /* GSF SFLevel.remainingCalls (P/GSFSignature.java:257) */
+  /* Handel HNode.receptionRanks (P/Handel.java:285, 825-828) as they are now: per (node, sender), n_levels = nodeCount */
+  WG_LF_RECEPTION_RANKS = 4
 } wg_level_field;
 int32_t wg_read_level_i32(wg_engine* e, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels);
 typedef enum { /* Handel HLevel bitsets (P/Handel.java:373-394) as one nodeCount-bit row per node, bit j = node j */

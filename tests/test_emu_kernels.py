@@ -90,6 +90,10 @@ def test_handel_emission_lists_on_the_device(monkeypatch):  # k_handel_init_sort
     th.test_emission_lists_fall_back_to_the_host(monkeypatch)
 
 
+def test_handel_reception_ranks_on_the_device(monkeypatch, capfd):  # k_handel_init_scan / _perm / _chain vs the oracle's init()
+    th.test_reception_ranks_shuffled_on_the_device(monkeypatch, capfd)
+
+
 def test_handel_chunk_size_is_observable():
     th.test_chunk_size_is_observable_and_matches(7)
 

@@ -61,6 +61,19 @@ def test_emission_lists_built_on_the_device(seed):
     assert g.init_on_device
 
 
+def test_reception_ranks_shuffled_on_the_device(monkeypatch, capfd):
+    """setReceivingRanks' cumulative Collections.shuffle per node (P/Handel.java:940-948, 966-989) on the device: where a node's
+    draws start in rd's stream depends on the rejected nextInt draws before it — seed 0 at 2 048 nodes has one (of 5 candidate
+    draws), and rd must come back exactly one draw further than N * (N - 1) + the lists' draws (diff_handel compares it)"""
+    monkeypatch.setenv("WG_INIT_VERBOSE", "1")
+    g, c = parity.handel_pair(ratios(2048), seed=0)
+    assert g.init_on_device
+    assert "5 candidate draws, 1 rejected" in capfd.readouterr().err
+    assert not parity.diff_handel(g, c)
+    want = np.stack([c.read_ranks(i) for i in range(2048)])
+    assert (g.network().read_ranks() == want).all()
+
+
 def test_emission_lists_fall_back_to_the_host(monkeypatch):
     """a rejected nextInt(bound) draw (java.util.Random's loop, probability about bound / 2^31 per draw) makes the draw count
     data dependent: the device reports it (WG_EHOSTINIT) and wgh_handel_create starts over with the host's sequential rd"""

@@ -219,6 +219,13 @@ class Network:
         self._ck(L.lib().wg_read_level_i32(self._h, LEVEL_FIELDS[field], _p(out, C.c_int32), n, l))
         return out
 
+    def read_ranks(self):
+        """HNode.receptionRanks of every node (P/Handel.java:285), [node][sender]"""
+        n = self.node_count
+        out = np.zeros((n, n), np.int32)
+        self._ck(L.lib().wg_read_level_i32(self._h, 4, _p(out, C.c_int32), n, n))
+        return out
+
     def read_bits(self, field):
         n = self.node_count
         w = max(1, n // 64)

@@ -2234,7 +2234,7 @@ struct HandelHost : ProtoHost {
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
     if (N < 2 || (N & (N - 1))) throw WgError(WG_EINVAL, "We support only power of two nodes in this simulation");
-    if (!init.startAt || !init.nodePairingTime || !init.receptionRanks)
+    if (!init.startAt || !init.nodePairingTime || (!init.receptionRanks && init.peers))
       throw WgError(WG_EINVAL, "wg_handel_init_state has NULL members");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N)
@@ -2318,7 +2318,10 @@ struct HandelHost : ProtoHost {
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
-    WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
+    if (init.receptionRanks)
+      WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
+    else
+      build_ranks(e);  // every node's Collections.shuffle on the device (k_handel_init_scan / _perm / _chain)
     if (!init.peers) {
       build_peers(e);  // buildEmissionList on the device (k_handel_init_sort / _shuffle)
     } else if (peers16) {  // (narrowed on the host, a slice at a time)
@@ -2360,6 +2363,83 @@ struct HandelHost : ProtoHost {
     WG_HIP(hipStreamSynchronize(e.stream));
     (void)hipFree(dStart);
     (void)hipFree(dPair);
+  }
+  // The reception ranks on the device (P/Handel.java:966-989; see k_handel_init_scan). Leaves rd after the last shuffle.
+  template <int E>
+  void launch_chain(Engine& e, int threads, size_t lds) {
+#if !defined(WG_EMU)
+    if (lds > 48 * 1024)
+      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+    hipLaunchKernelGGL(k_handel_init_chain<E>, dim3(1), dim3(threads), lds, e.stream, st);
+  }
+  void build_ranks(Engine& e) {
+    const int32_t N = st.N;
+    if (e.shardCount > 0 || N > 65536 || N < 256)
+      throw WgError(WG_EINVAL, "device-built reception ranks: an unsharded engine of 256 .. 65 536 nodes (pass wg_handel_init_state.receptionRanks)");
+    const unsigned long long total0 = (unsigned long long)N * (N - 1);
+    const unsigned long long expectRej = ((unsigned long long)N * N * N) >> 33, expectCand = ((unsigned long long)N * N * N) >> 31;
+    const unsigned long long slack = 4 * expectRej + 65536;
+    const uint32_t cap = (uint32_t)(2 * expectCand + 4096);
+    unsigned long long *dCand = nullptr, *dOffs = nullptr;
+    uint32_t* dFlags = nullptr;  // [0] candidates, [1] mismatch
+    WG_HIP(hipMalloc((void**)&dCand, 8 * (size_t)cap));
+    WG_HIP(hipMalloc((void**)&dOffs, 8 * ((size_t)N + 1)));
+    WG_HIP(hipMalloc((void**)&dFlags, 8));
+    struct Free {
+      void *a, *b, *c;
+      ~Free() {
+        (void)hipFree(a);
+        (void)hipFree(b);
+        (void)hipFree(c);
+      }
+    } guard{dCand, dOffs, dFlags};
+    WG_HIP(hipMemsetAsync(dFlags, 0, 8, e.stream));
+    hipLaunchKernelGGL(k_handel_init_scan, dim3(2048 / WG_GRID_DIV), dim3(256), 0, e.stream, e.gh.rng, total0 + slack, (uint32_t)N, dCand,
+                       dFlags, cap);
+    uint32_t nCand = 0;
+    WG_HIP(hipMemcpyAsync(&nCand, dFlags, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    if (nCand > cap) throw WgError(WG_EHOSTINIT, "reception ranks: more candidate draws than the list holds");
+    std::vector<unsigned long long> cand(nCand);
+    if (nCand) WG_HIP(hipMemcpy(cand.data(), dCand, 8 * (size_t)nCand, hipMemcpyDeviceToHost));
+    std::sort(cand.begin(), cand.end());  // (position in the high bits)
+    std::vector<unsigned long long> offs((size_t)N + 1, 0);  // [n + 1] first: rejected draws of node n
+    unsigned long long rej = 0;
+    for (unsigned long long c : cand) {
+      const unsigned long long q = (c >> 31) - rej;  // the draw this stream position belongs to
+      if (q >= total0) break;
+      const int32_t bound = N - (int32_t)(q % (unsigned long long)(N - 1));
+      const int32_t m = bound - 1, u = (int32_t)(c & 0x7fffffffULL);
+      if ((bound & m) == 0) continue;  // (a power of two: no loop, Random.nextInt)
+      if ((int32_t)((uint32_t)u - (uint32_t)(u % bound) + (uint32_t)m) < 0) {
+        rej++;
+        offs[(size_t)(q / (unsigned long long)(N - 1)) + 1]++;
+      }
+    }
+    if (getenv("WG_INIT_VERBOSE") && atoi(getenv("WG_INIT_VERBOSE")))
+      fprintf(stderr, "[wittgpu] reception ranks on the device: %u candidate draws, %llu rejected\n", nCand, rej);
+    if (rej > slack) throw WgError(WG_EHOSTINIT, "reception ranks: more rejected draws than the scanned part of rd's stream covers");
+    for (int n = 0; n < N; n++) offs[(size_t)n + 1] += offs[n] + (unsigned long long)(N - 1);
+    WG_HIP(hipMemcpyAsync(dOffs, offs.data(), 8 * offs.size(), hipMemcpyHostToDevice, e.stream));
+    hipLaunchKernelGGL(k_handel_init_perm, dim3((N + 63) / 64), dim3(64), 0, e.stream, st, dOffs, e.gh.rng, dFlags + 1);
+    const int threads = std::min(N, 1024);
+    const size_t lds = 2 * (size_t)N;
+    switch (N / threads) {
+      case 1: launch_chain<1>(e, threads, lds); break;
+      case 2: launch_chain<2>(e, threads, lds); break;
+      case 4: launch_chain<4>(e, threads, lds); break;
+      case 8: launch_chain<8>(e, threads, lds); break;
+      case 16: launch_chain<16>(e, threads, lds); break;
+      case 32: launch_chain<32>(e, threads, lds); break;
+      default: launch_chain<64>(e, threads, lds); break;
+    }
+    uint32_t bad = 0;
+    WG_HIP(hipMemcpyAsync(&bad, dFlags + 1, 4, hipMemcpyDeviceToHost, e.stream));
+    WG_HIP(hipStreamSynchronize(e.stream));
+    if (bad) throw WgError(WG_EHOSTINIT, "reception ranks: a node drew another number of times than the candidate walk gave it");
+    e.gh.rng = lcg_skip(e.gh.rng, total0 + rej);
+    e.globalsDirty = true;
   }
   // The emission lists of every live sender on the device (P/Handel.java:991-1013): the sort per (sender, level), the draw
   // counts summed on the host in the reference's order, the equal-rank shuffles from jumped rd states. Leaves the engine's
@@ -2563,6 +2643,13 @@ struct HandelHost : ProtoHost {
     return true;
   }
   bool read_level_i32(Engine& e, int32_t field, int32_t* dst, int32_t n, int32_t L) override {
+    if (field == WG_LF_RECEPTION_RANKS) {  // [node][sender], this shard's rows (zeros elsewhere)
+      if (n != st.N || L != st.N) throw WgError(WG_EINVAL, "shape must be [nodeCount][nodeCount]");
+      memset(dst, 0, 4 * (size_t)n * n);
+      WG_HIP(hipStreamSynchronize(e.stream));
+      WG_HIP(hipMemcpy(dst + (size_t)st.lo * n, st.ranks + (size_t)st.lo * n, 4 * (size_t)(st.hi - st.lo) * n, hipMemcpyDeviceToHost));
+      return true;
+    }
     if (n != st.N || L != st.L) throw WgError(WG_EINVAL, "shape must be [nodeCount][levels]");
     if (field == WG_LF_QUEUE_LEN) {  // toVerifyAgg.size(): the head word of every queue record
       memset(dst, 0, 4 * (size_t)n * L);

@@ -259,7 +259,8 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
 static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
                              const wg_config* cfg, wg_engine** out, bool devicePeers);
 // Handel.init() (P/Handel.java:957-1014). The emission lists (:991-1013) are built on the device where the engine can
-// (unsharded, 256 .. 65 536 nodes: wg_handel_init_state.peers == NULL) and on the host otherwise — or after all, when
+// (unsharded, 256 .. 65 536 nodes: wg_handel_init_state.receptionRanks and .peers == NULL) together with the rank shuffles
+// (:940-948, 966-989) and on the host otherwise — or after all, when
 // the device met a rejected draw (WG_EHOSTINIT); WG_HOST_INIT=1 keeps everything on the host.
 int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out) {
@@ -337,8 +338,10 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
     if (!bad[i]) CK(wg_register_periodic_task(e, /*dissemination*/ 0u, startAt[i] + 1, p.disseminationPeriodMs, i));
 
   // setReceivingRanks (:940-948): one list, shuffled cumulatively once per node.
-  std::vector<int32_t> ranks((size_t)N * N);
-  {
+  std::vector<int32_t> ranks;
+  const uint64_t rdBeforeRanks = rd.s;  // (the device path starts from here: wg_handel_init_state.receptionRanks == NULL)
+  if (!devicePeers) {
+    ranks.resize((size_t)N * N);
     std::vector<int32_t> expected(N);
     for (int i = 0; i < N; i++) expected[i] = i;
     for (int n = 0; n < N; n++) {
@@ -407,12 +410,13 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
       }
     }
   }
-  CK(wg_rng_set_state(e, rd.s));
+  CK(wg_rng_set_state(e, devicePeers ? rdBeforeRanks : rd.s));
   wg_handel_init_state st;
   st.startAt = startAt.data();
   st.nodePairingTime = pairing.data();
-  st.receptionRanks = ranks.data();
-  st.peers = devicePeers ? nullptr : peers.data();  // (NULL: the engine builds them from the ranks and advances rd itself)
+  // (NULL: the engine shuffles the ranks and builds the lists on the device, and advances its rd by their draws)
+  st.receptionRanks = devicePeers ? nullptr : ranks.data();
+  st.peers = devicePeers ? nullptr : peers.data();
   {
     const int32_t rc = wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st);
     if (rc == WG_EHOSTINIT) return rc;  // (the engine is destroyed by the guard; the caller starts over with host-built lists)

@@ -2040,6 +2040,97 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
   }
 }
 
+// ---- init() on the device: the reception ranks (P/Handel.java:966-989: one list of all nodes, Collections.shuffle'd
+// again for every node in id order; node n's receptionRanks[x] = the position of x in the list after its shuffle) ----
+// rd is one stream over the N * (N - 1) nextInt(i) draws, and the list carries over from node to node. Both chains are cut:
+//  * where a node's draws start depends on the rejected draws before it (java.util.Random.nextInt's loop; about N^3 / 2^33
+//    of them). A draw can only be rejected when its 31 bits are >= 2^31 - N, whatever its bound: k_handel_init_scan lists
+//    those stream positions (about N^3 / 2^31), the host walks the short list in order (position - rejections so far =
+//    the draw, hence its bound) and hands every node its start;
+//  * a shuffle moves POSITIONS: applied to the identity it gives p_n with list_n[j] = list_(n-1)[p_n[j]]. k_handel_init_perm
+//    builds p_n for all nodes at once (one lane a node, in the node's own row of `ranks`), k_handel_init_chain composes them
+//    in node order with the list in LDS and scatters row n = the inverse of list_n over p_n's row.
+__global__ void __launch_bounds__(256) k_handel_init_scan(uint64_t rng0, unsigned long long total, uint32_t N,
+                                                          unsigned long long* __restrict__ cand, uint32_t* __restrict__ candCount,
+                                                          uint32_t cap) {
+  const unsigned long long CH = 2048;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c * CH < total;
+       c += (unsigned long long)gridDim.x * blockDim.x) {
+    uint64_t st = lcg_skip(rng0, c * CH);
+    const unsigned long long end = c * CH + CH < total ? c * CH + CH : total;
+    for (unsigned long long pos = c * CH; pos < end; pos++) {
+      st = lcg_step(st);
+      const uint32_t bits = (uint32_t)(st >> 17);  // next(31)
+      if (bits >= 0x80000000u - N) {
+        const uint32_t i = atomicAdd(candCount, 1u);
+        if (i < cap) cand[i] = (pos << 31) | bits;
+      }
+    }
+  }
+}
+__global__ void __launch_bounds__(64) k_handel_init_perm(HandelState s, const unsigned long long* __restrict__ offs, uint64_t rng0,
+                                                         uint32_t* __restrict__ bad) {
+  const int N = s.N;
+  const int n0 = blockIdx.x * 64;
+  for (int r = 0; r < 64 && n0 + r < N; r++) {  // the identity, a row at a time by the whole wavefront
+    int32_t* row = s.ranks + (size_t)(n0 + r) * N;
+    for (int j = threadIdx.x; j < N; j += 64) row[j] = j;
+  }
+  __syncthreads();
+  const int n = n0 + (int)threadIdx.x;
+  if (n >= N) return;
+  int32_t* row = s.ranks + (size_t)n * N;
+  uint64_t st = lcg_skip(rng0, offs[n]);
+  unsigned long long drawn = 0;
+  for (int32_t i = N; i > 1; i--) {  // Collections.shuffle: swap(i - 1, rd.nextInt(i))
+    int consumed;
+    const int32_t j = lcg_next_int_bounded(st, i, &consumed);
+    drawn += (unsigned long long)consumed;
+    const int32_t a = row[i - 1], b = row[j];
+    row[i - 1] = b;
+    row[j] = a;
+  }
+  if (drawn != offs[n + 1] - offs[n]) atomicOr(bad, 1u);  // (the host's walk of the candidates and the draws disagree)
+}
+// one workgroup: the list (ids < 65 536) in LDS, thread t owns positions t + k * blockDim, N == E * blockDim
+template <int E>
+__global__ void __launch_bounds__(1024) k_handel_init_chain(HandelState s) {
+  WG_DYN_LDS(uint16_t, lst);  // [N]
+  const int N = s.N, T = E > 1 ? 1024 : (int)blockDim.x, t = (int)threadIdx.x;
+  constexpr bool AHEAD = E <= 16;  // (the next node's row in registers while this one is composed; more would spill)
+  uint32_t p[E], pn[AHEAD ? E : 1];
+#pragma unroll
+  for (int k = 0; k < E; k++) lst[t + k * T] = (uint16_t)(t + k * T);
+  if (AHEAD) {
+#pragma unroll
+    for (int k = 0; k < E; k++) pn[k] = (uint32_t)s.ranks[t + k * T];
+  }
+  __syncthreads();
+  for (int n = 0; n < N; n++) {
+    int32_t* row = s.ranks + (size_t)n * N;
+    if (AHEAD) {
+#pragma unroll
+      for (int k = 0; k < E; k++) p[k] = pn[k];
+      if (n + 1 < N) {
+#pragma unroll
+        for (int k = 0; k < E; k++) pn[k] = (uint32_t)row[N + t + k * T];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < E; k++) p[k] = (uint32_t)row[t + k * T];
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) p[k] = lst[p[k]];
+    __syncthreads();  // (every read of the old list and of row n is done)
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      lst[t + k * T] = (uint16_t)p[k];
+      row[p[k]] = t + k * T;  // receptionRanks[id at position j] = j
+    }
+    __syncthreads();
+  }
+}
+
 // ---- init() on the device: the emission lists (P/Handel.java:991-1013, buildEmissionList :510-522) -----------------
 // For sender s and level l the receivers are the sibling block of 2^(l-1) ids; they are bucketed by the RECEIVER's
 // receptionRanks[s], the buckets walked in rank order, a bucket of several receivers shuffled with the shared rd. The
