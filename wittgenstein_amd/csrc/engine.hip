@@ -2231,6 +2231,7 @@ struct HandelHost : ProtoHost {
   int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;  // (k_handel_a1: 110 VGPRs, no scratch; five waves spill)
   int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
+    const auto tCtor = std::chrono::steady_clock::now();
     const int32_t N = p.nodeCount;
     if ((int32_t)e.hx.size() != N) throw WgError(WG_EINVAL, "Handel nodeCount != nodes in the network");
     if (N < 2 || (N & (N - 1))) throw WgError(WG_EINVAL, "We support only power of two nodes in this simulation");
@@ -2318,12 +2319,24 @@ struct HandelHost : ProtoHost {
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
+    const bool verbose = getenv("WG_INIT_VERBOSE") && atoi(getenv("WG_INIT_VERBOSE"));
+    auto tv = tCtor;
+    auto lap = [&](const char* what) {
+      if (!verbose) return;
+      (void)hipStreamSynchronize(e.stream);
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[wittgpu] handel load: %s %.3f s\n", what, std::chrono::duration<double>(now - tv).count());
+      tv = now;
+    };
+    lap("allocations");
     if (init.receptionRanks)
       WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
     else
       build_ranks(e);  // every node's Collections.shuffle on the device (k_handel_init_scan / _perm / _chain)
+    lap("reception ranks");
     if (!init.peers) {
       build_peers(e);  // buildEmissionList on the device (k_handel_init_sort / _shuffle)
+      lap("emission lists");
     } else if (peers16) {  // (narrowed on the host, a slice at a time)
       const size_t total = nLoc * (size_t)(N - 1), step = (size_t)1 << 26;
       std::vector<uint16_t> tmp(std::min(total, step));
@@ -2361,17 +2374,24 @@ struct HandelHost : ProtoHost {
     WG_HIP(hipMemcpy(dPair, init.nodePairingTime, 4 * (size_t)N, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_handel_init, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st, e.dev.nodes.down, dStart, dPair);
     WG_HIP(hipStreamSynchronize(e.stream));
+    lap("node state");
     (void)hipFree(dStart);
     (void)hipFree(dPair);
   }
   // The reception ranks on the device (P/Handel.java:966-989; see k_handel_init_scan). Leaves rd after the last shuffle.
   template <int E>
-  void launch_chain(Engine& e, int threads, size_t lds) {
+  void launch_chain(Engine& e, int threads, size_t lds, int B, uint16_t* net, uint16_t* starts) {
 #if !defined(WG_EMU)
-    if (lds > 48 * 1024)
-      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024) {
+      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain_starts<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
 #endif
-    hipLaunchKernelGGL(k_handel_init_chain<E>, dim3(1), dim3(threads), lds, e.stream, st);
+    const int C = st.N / B;
+    hipLaunchKernelGGL((k_handel_init_chain<E, false>), dim3(C), dim3(threads), lds, e.stream, st, B, net, (const uint16_t*)starts);
+    hipLaunchKernelGGL(k_handel_init_chain_starts<E>, dim3(1), dim3(threads), lds, e.stream, st.N, C, (const uint16_t*)net, starts);
+    hipLaunchKernelGGL((k_handel_init_chain<E, true>), dim3(C), dim3(threads), lds, e.stream, st, B, net, (const uint16_t*)starts);
   }
   void build_ranks(Engine& e) {
     const int32_t N = st.N;
@@ -2425,18 +2445,25 @@ struct HandelHost : ProtoHost {
     hipLaunchKernelGGL(k_handel_init_perm, dim3((N + 63) / 64), dim3(64), 0, e.stream, st, dOffs, e.gh.rng, dFlags + 1);
     const int threads = std::min(N, 1024);
     const size_t lds = 2 * (size_t)N;
+    const int B = std::max(8, N / 256);  // nodes per chunk: 256 chunks from 2 048 nodes on
+    uint16_t* dLists = nullptr;          // [2][N / B][N]: every chunk's net move, then the list it starts from
+    WG_HIP(hipMalloc((void**)&dLists, 2 * 2 * (size_t)(N / B) * N));
+    uint16_t *net = dLists, *starts = dLists + (size_t)(N / B) * N;
     switch (N / threads) {
-      case 1: launch_chain<1>(e, threads, lds); break;
-      case 2: launch_chain<2>(e, threads, lds); break;
-      case 4: launch_chain<4>(e, threads, lds); break;
-      case 8: launch_chain<8>(e, threads, lds); break;
-      case 16: launch_chain<16>(e, threads, lds); break;
-      case 32: launch_chain<32>(e, threads, lds); break;
-      default: launch_chain<64>(e, threads, lds); break;
+      case 1: launch_chain<1>(e, threads, lds, B, net, starts); break;
+      case 2: launch_chain<2>(e, threads, lds, B, net, starts); break;
+      case 4: launch_chain<4>(e, threads, lds, B, net, starts); break;
+      case 8: launch_chain<8>(e, threads, lds, B, net, starts); break;
+      case 16: launch_chain<16>(e, threads, lds, B, net, starts); break;
+      case 32: launch_chain<32>(e, threads, lds, B, net, starts); break;
+      default: launch_chain<64>(e, threads, lds, B, net, starts); break;
     }
     uint32_t bad = 0;
-    WG_HIP(hipMemcpyAsync(&bad, dFlags + 1, 4, hipMemcpyDeviceToHost, e.stream));
-    WG_HIP(hipStreamSynchronize(e.stream));
+    const hipError_t rcBad = hipMemcpyAsync(&bad, dFlags + 1, 4, hipMemcpyDeviceToHost, e.stream);
+    const hipError_t rcSync = hipStreamSynchronize(e.stream);
+    (void)hipFree(dLists);
+    WG_HIP(rcBad);
+    WG_HIP(rcSync);
     if (bad) throw WgError(WG_EHOSTINIT, "reception ranks: a node drew another number of times than the candidate walk gave it");
     e.gh.rng = lcg_skip(e.gh.rng, total0 + rej);
     e.globalsDirty = true;

@@ -417,6 +417,10 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
   // (NULL: the engine shuffles the ranks and builds the lists on the device, and advances its rd by their draws)
   st.receptionRanks = devicePeers ? nullptr : ranks.data();
   st.peers = devicePeers ? nullptr : peers.data();
+  const bool verbose = getenv("WG_INIT_VERBOSE") && atoi(getenv("WG_INIT_VERBOSE"));
+  if (verbose)
+    fprintf(stderr, "[wittgpu] handel init(): host part before the protocol load %.3f s\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   {
     const int32_t rc = wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st);
     if (rc == WG_EHOSTINIT) return rc;  // (the engine is destroyed by the guard; the caller starts over with host-built lists)
@@ -426,6 +430,7 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
     }
   }
   g_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (verbose) fprintf(stderr, "[wittgpu] handel init(): %.3f s in all\n", g_initSeconds);
   g_initOnDevice = devicePeers ? 1 : 0;
   guard.keep = true;
   *out = e;

@@ -2049,7 +2049,8 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
 //    the draw, hence its bound) and hands every node its start;
 //  * a shuffle moves POSITIONS: applied to the identity it gives p_n with list_n[j] = list_(n-1)[p_n[j]]. k_handel_init_perm
 //    builds p_n for all nodes at once (one lane a node, in the node's own row of `ranks`), k_handel_init_chain composes them
-//    in node order with the list in LDS and scatters row n = the inverse of list_n over p_n's row.
+//    in node order with the list in LDS and scatters row n = the inverse of list_n over p_n's row — composition is
+//    associative, so the node order is cut into chunks that run side by side (see there).
 __global__ void __launch_bounds__(256) k_handel_init_scan(uint64_t rng0, unsigned long long total, uint32_t N,
                                                           unsigned long long* __restrict__ cand, uint32_t* __restrict__ candCount,
                                                           uint32_t cap) {
@@ -2092,26 +2093,32 @@ __global__ void __launch_bounds__(64) k_handel_init_perm(HandelState s, const un
   }
   if (drawn != offs[n + 1] - offs[n]) atomicOr(bad, 1u);  // (the host's walk of the candidates and the draws disagree)
 }
-// one workgroup: the list (ids < 65 536) in LDS, thread t owns positions t + k * blockDim, N == E * blockDim
-template <int E>
-__global__ void __launch_bounds__(1024) k_handel_init_chain(HandelState s) {
+// The list (ids < 65 536) in LDS, thread t owns positions t + k * blockDim, N == E * blockDim. The node order is cut
+// into chunks of B nodes, one workgroup each, in three launches:
+//   ROWS == false  compose the chunk's B shuffles from the identity: its net move q_c (list after = list before[q_c[j]])
+//   k_handel_init_chain_starts (one workgroup)  the list every chunk starts from: start_0 = identity, start_(c+1) = start_c[q_c[j]]
+//   ROWS == true   the chunk again from its start list; row n = the inverse of the list after node n, scattered over p_n
+template <int E, bool ROWS>
+__global__ void __launch_bounds__(1024) k_handel_init_chain(HandelState s, int B, uint16_t* __restrict__ net,
+                                                            const uint16_t* __restrict__ starts) {
   WG_DYN_LDS(uint16_t, lst);  // [N]
   const int N = s.N, T = E > 1 ? 1024 : (int)blockDim.x, t = (int)threadIdx.x;
   constexpr bool AHEAD = E <= 16;  // (the next node's row in registers while this one is composed; more would spill)
+  const int n0 = (int)blockIdx.x * B;
   uint32_t p[E], pn[AHEAD ? E : 1];
 #pragma unroll
-  for (int k = 0; k < E; k++) lst[t + k * T] = (uint16_t)(t + k * T);
+  for (int k = 0; k < E; k++) lst[t + k * T] = ROWS ? starts[(size_t)blockIdx.x * N + t + k * T] : (uint16_t)(t + k * T);
   if (AHEAD) {
 #pragma unroll
-    for (int k = 0; k < E; k++) pn[k] = (uint32_t)s.ranks[t + k * T];
+    for (int k = 0; k < E; k++) pn[k] = (uint32_t)s.ranks[(size_t)n0 * N + t + k * T];
   }
   __syncthreads();
-  for (int n = 0; n < N; n++) {
+  for (int n = n0; n < n0 + B; n++) {
     int32_t* row = s.ranks + (size_t)n * N;
     if (AHEAD) {
 #pragma unroll
       for (int k = 0; k < E; k++) p[k] = pn[k];
-      if (n + 1 < N) {
+      if (n + 1 < n0 + B) {
 #pragma unroll
         for (int k = 0; k < E; k++) pn[k] = (uint32_t)row[N + t + k * T];
       }
@@ -2125,8 +2132,35 @@ __global__ void __launch_bounds__(1024) k_handel_init_chain(HandelState s) {
 #pragma unroll
     for (int k = 0; k < E; k++) {
       lst[t + k * T] = (uint16_t)p[k];
-      row[p[k]] = t + k * T;  // receptionRanks[id at position j] = j
+      if (ROWS) row[p[k]] = t + k * T;  // receptionRanks[id at position j] = j
     }
+    __syncthreads();
+  }
+  if (!ROWS) {
+#pragma unroll
+    for (int k = 0; k < E; k++) net[(size_t)blockIdx.x * N + t + k * T] = lst[t + k * T];
+  }
+}
+template <int E>
+__global__ void __launch_bounds__(1024) k_handel_init_chain_starts(int N, int C, const uint16_t* __restrict__ net,
+                                                                   uint16_t* __restrict__ starts) {
+  WG_DYN_LDS(uint16_t, lst);
+  const int T = E > 1 ? 1024 : (int)blockDim.x, t = (int)threadIdx.x;
+  uint32_t p[E];
+#pragma unroll
+  for (int k = 0; k < E; k++) lst[t + k * T] = (uint16_t)(t + k * T);
+  __syncthreads();
+  for (int c = 0; c < C; c++) {
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      starts[(size_t)c * N + t + k * T] = lst[t + k * T];
+      p[k] = net[(size_t)c * N + t + k * T];
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) p[k] = lst[p[k]];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; k++) lst[t + k * T] = (uint16_t)p[k];
     __syncthreads();
   }
 }
