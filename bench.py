@@ -526,8 +526,10 @@ def main():
         avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
     except Exception:
         avail = 0
-    # host init() of one copy holds ~3 N^2 int32 (ranks, their transpose, emission lists)
-    threads = replicas.init_threads(args.init_threads, max(1, R - 1), avail, 3.5 * 4 * n * n + (1 << 30),
+    # init() of one copy on the host holds ~3 N^2 int32 (ranks, their transpose, emission lists); with the rank shuffles and
+    # the emission lists built on the device (wgh_handel_create: unsharded, 256 .. 65 536 nodes) a thread holds next to nothing
+    on_device = bool(getattr(first, "init_on_device", False))
+    threads = replicas.init_threads(args.init_threads, max(1, R - 1), avail, (1 << 28) if on_device else 3.5 * 4 * n * n + (1 << 30),
                                     len(os.sched_getaffinity(0)), world)
 
     def init_one(s):
@@ -541,8 +543,9 @@ def main():
     batch = w.Batch([g.network() for g in sims])
     init_wall = time.perf_counter() - t_init
     init_s = init_wall / R
-    log("[rank %d] init(): %d copies in %.1f s (%.1f s per simulation amortised over %d host threads; outside the timed "
-        "region); %.2f GB per copy incl. its init() image" % (rank, R, init_wall, init_s, threads, per_copy / 1e9))
+    log("[rank %d] init(): %d copies in %.1f s (%.1f s per simulation amortised over %d host threads; rank shuffles and emission "
+        "lists built on the %s; outside the timed region); %.2f GB per copy incl. its init() image"
+        % (rank, R, init_wall, init_s, threads, "device" if on_device else "host", per_copy / 1e9))
     # WG_GRAPH=1: the device loop replayed as a hipGraph. The delivery pass is then bracketed by device clock stamps (one-lane
     # kernels on the engine's stream writing s_memrealtime, Engine::ProfScope / k_prof_stamp) instead of HIP events, which a
     # replayed graph would re-record; the spans-on-one-axis machinery of --batches > 1 (event based) is off there
@@ -674,6 +677,7 @@ def main():
                    "restore_ms_per_step": 1000.0 * restore_s / max(1, restores),
                    "timed_loop_wall_s_incl_restores": wall_timed_loop,
                    "init_s_per_simulation": init_s, "init_wall_s": init_wall, "init_threads": threads,
+                   "init_on_device": on_device,
                    "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes),
                    "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WG_")}},
     }
