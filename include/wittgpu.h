@@ -174,6 +174,11 @@ typedef struct {
   int32_t nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath, nodesDown;
   int32_t desynchronizedStart;
   int32_t windowInitial, windowMinimum, windowMaximum; /* 16, 1, 128 */
+  /* HandelParameters.byzantineSuicide / hiddenByzantine (P/Handel.java:64-71, 108-109): the down nodes are byzantine and
+   * attack. byzantineSuicide (:406, 538-559, 577-584, 688-694) is resident on the device (unsharded engines; every node
+   * visit then takes the wave-per-node kernels); hiddenByzantine (:813-817, 840-917) is not: WG_EUNSUPPORTED (it runs in
+   * host-callback mode). */
+  int32_t byzantineSuicide, hiddenByzantine;
 } wg_handel_params;
 
 /* Per-node state produced by Handel.init() (P/Handel.java:957-1014), uploaded once:
@@ -384,12 +389,14 @@ typedef enum { /* per (node, level), row-major [node][level] */
   WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2,
   WG_LF_REMAINING_CALLS = 3, /* GSF SFLevel.remainingCalls (P/GSFSignature.java:257) */
   /* Handel HNode.receptionRanks (P/Handel.java:285, 825-828) as they are now: per (node, sender), n_levels = nodeCount */
-  WG_LF_RECEPTION_RANKS = 4
+  WG_LF_RECEPTION_RANKS = 4,
+  WG_LF_SUICIDE_BIZ_AFTER = 5 /* Handel HLevel.suicideBizAfter (P/Handel.java:406) */
 } wg_level_field;
 int32_t wg_read_level_i32(wg_engine* e, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels);
 typedef enum { /* Handel HLevel bitsets (P/Handel.java:373-394) as one nodeCount-bit row per node, bit j = node j */
   WG_B_TOTAL_INCOMING = 0, WG_B_LAST_AGG_VERIFIED = 1, WG_B_VERIFIED_IND = 2, WG_B_TO_VERIFY_IND = 3,
   WG_B_FINISHED_PEERS = 4,
+  WG_B_BLACKLIST = 5, /* HNode.blacklist (P/Handel.java:289; all zeros unless byzantineSuicide) */
   /* GSFSignature: GSFNode.verifiedSignatures (= the union of SFLevel.verifiedSignatures, :171,:244) and the
    * unions over levels of SFLevel.individualSignatures / indivVerifiedSig (:245-246) */
   WG_B_GSF_VERIFIED = 8, WG_B_GSF_INDIVIDUAL = 9, WG_B_GSF_INDIV_VERIFIED = 10

@@ -10,16 +10,17 @@ NL = "NetworkLatencyByDistanceWJitter"
 
 SCALARS = ["doneAt", "msgReceived", "msgSent", "bytesSent", "bytesReceived", "sigsChecked", "sigQueueSize",
            "msgFiltered", "currWindowSize", "addedCycle"]
-LEVELS = ["posInLevel", "outgoingFinished", "queueLen"]
-BITS = ["totalIncoming", "lastAggVerified", "verifiedIndSignatures", "toVerifyInd", "finishedPeers"]
+LEVELS = ["posInLevel", "outgoingFinished", "queueLen", "suicideBizAfter"]
+BITS = ["totalIncoming", "lastAggVerified", "verifiedIndSignatures", "toVerifyInd", "finishedPeers", "blacklist"]
 
 
-def handel_pair(params, nb=NB, nl=NL, seed=0, config=None):
+def handel_pair(params, nb=NB, nl=NL, seed=0, config=None, byzantine_suicide=False):
     """params = (nodeCount, threshold, pairing, levelWait, extraCycle, period, fastPath, nodesDown, desync)"""
     n, thr, pair, lw, ec, per, fp, down, desync = params
-    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync), seed=seed, config=config)
+    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, byzantineSuicide=byzantine_suicide),
+                 seed=seed, config=config)
     g.init()
-    c = o.Handel(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, seed=seed)
+    c = o.Handel(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, seed=seed, byzantine_suicide=byzantine_suicide)
     return g, c
 
 

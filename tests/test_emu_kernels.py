@@ -94,6 +94,12 @@ def test_handel_reception_ranks_on_the_device(monkeypatch, capfd):  # k_handel_i
     th.test_reception_ranks_shuffled_on_the_device(monkeypatch, capfd)
 
 
+def test_handel_byzantine_suicide_resident():  # P/Handel.java:538-559, 577-584, 688-694 on the device vs the oracle
+    th.test_byzantine_suicide_resident(64, 0)
+    th.test_byzantine_suicide_resident_hostmode_cases()
+    th.test_hidden_byzantine_is_refused_by_the_resident_engine()
+
+
 def test_handel_chunk_size_is_observable():
     th.test_chunk_size_is_observable_and_matches(7)
 

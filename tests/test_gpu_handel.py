@@ -124,6 +124,39 @@ def test_latency_models(nl):
     lockstep(ratios(256), step=10, nl=nl, max_ms=20000)
 
 
+@pytest.mark.parametrize("n,seed", [(64, 0), (256, 1)])
+def test_byzantine_suicide_resident(n, seed):
+    """HandelParameters.byzantineSuicide (P/Handel.java:64-69) resident on the device: the down nodes are byzantine; a level's
+    bestToVerify plants the bad signature of the first byzantine peer inside the window (createSuicideByzantineSig :538-559,
+    577-584), checkSigs shrinks the window for it (:821), updateVerifiedSignatures blacklists its signer (:688-694),
+    getRemainingPeers and the curation pass blacklisted ids over (:493, :592). Lock-step with the oracle, which compares
+    suicideBizAfter of every level and every node's blacklist besides the rest."""
+    g, c = lockstep(ratios(n, dead=0.25), step=1 if n <= 64 else 5, max_ms=3000, seed=seed, byzantine_suicide=True)
+    assert c.read_bits("blacklist").any()  # the attack did happen
+    assert (g.network().read_bits("blacklist") == c.read_bits("blacklist")[:, :max(1, n // 64)]).all()
+
+
+def test_byzantine_suicide_resident_hostmode_cases():
+    """the two byzantineSuicide cases tests/test_gpu_handel_hostmode.py runs through host callbacks, on the resident engine"""
+    P64 = (64, 50, 4, 50, 5, 20, 10, 6, 0)
+    g, c = lockstep(P64, step=10, max_ms=4000, seed=1, byzantine_suicide=True)
+    down = g.network().read("down") != 0
+    bl = g.network().read_bits("blacklist")[:, 0]
+    downMask = np.uint64(sum(1 << int(i) for i in np.nonzero(down)[0]))
+    assert bl.any() and not (bl & ~downMask).any()  # only byzantine nodes are blacklisted
+    assert not g.cont_if()
+    _, honest = lockstep(P64, step=10, max_ms=4000, seed=1)  # the same seed without the attack: fewer verifications were wasted
+    assert int(c.read("sigsChecked").sum()) > int(honest.read("sigsChecked").sum())
+    lockstep((32, 24, 3, 30, 4, 10, 5, 4, 40), step=10, max_ms=4000, seed=5, byzantine_suicide=True)  # desynchronized start
+
+
+def test_hidden_byzantine_is_refused_by_the_resident_engine():
+    with pytest.raises(w.UnsupportedError):
+        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, hiddenByzantine=True)
+    with pytest.raises(w.IllegalArgumentException):
+        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, byzantineSuicide=True, hiddenByzantine=True)
+
+
 def test_queue_capacity_overflow_is_loud():
     g = w.Handel(w.HandelParameters(*ratios(256)[:8], parity.NB, parity.NL, 0), config={"queue_cap": 2})
     g.init()

@@ -37,7 +37,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64)
 class wg_handel_params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nodeCount", "threshold", "pairingTime", "levelWaitTime", "extraCycle", "disseminationPeriodMs", "fastPath",
-        "nodesDown", "desynchronizedStart", "windowInitial", "windowMinimum", "windowMaximum")]
+        "nodesDown", "desynchronizedStart", "windowInitial", "windowMinimum", "windowMaximum", "byzantineSuicide",
+        "hiddenByzantine")]
 
 
 class wg_gsf_params(C.Structure):

@@ -50,9 +50,9 @@ FIELDS = {"doneAt": 0, "msgReceived": 1, "msgSent": 2, "bytesSent": 3, "bytesRec
           "aggValue": 64, "currentPrefixLength": 65, "sfFlags": 66, "sentRequests": 67, "receivedRequests": 68,
           "thresholdAt": 69, "headHeight": 80, "headProposalTime": 81, "headId": 82, "attestationsByHeadSize": 83,
           "blocksReceived": 84, "attestationsHeld": 85, "floodReceived": 96, "peerCount": 97}
-LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2, "remainingCalls": 3}
+LEVEL_FIELDS = {"posInLevel": 0, "outgoingFinished": 1, "queueLen": 2, "remainingCalls": 3, "suicideBizAfter": 5}
 BITS = {"totalIncoming": 0, "lastAggVerified": 1, "verifiedIndSignatures": 2, "toVerifyInd": 3, "finishedPeers": 4,
-        "verifiedSignatures": 8, "individualSignatures": 9, "indivVerifiedSig": 10}
+        "blacklist": 5, "verifiedSignatures": 8, "individualSignatures": 9, "indivVerifiedSig": 10}
 
 
 class MessageStorage:

@@ -1891,8 +1891,8 @@ Batch::Batch(Engine** es, int n) {
     Engine* l = es[0];
     if (e->cfg.device != l->cfg.device || e->dev.horizon != l->dev.horizon || e->dev.nodes.n != l->dev.nodes.n ||
         e->proto->state_size() != l->proto->state_size() || e->proto->has_cond() != l->proto->has_cond() ||
-        e->proto->levels() != l->proto->levels())
-      throw WgError(WG_EINVAL, "batch members must share device, protocol, node count and horizon_ms");
+        e->proto->levels() != l->proto->levels() || e->proto->variant() != l->proto->variant())
+      throw WgError(WG_EINVAL, "batch members must share device, protocol (and its attack scenario), node count and horizon_ms");
     for (int j = 0; j < i; j++)
       if (es[j] == e) throw WgError(WG_EINVAL, "an engine appears twice in the batch");
     members.push_back(e);
@@ -2162,6 +2162,7 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
   h[HH_TOTAL] = 1;  // the sum of |totalIncoming| over the levels: the own signature
   h[HH_WINDOW] = (uint32_t)s.p.windowInitial;
   h[HH_ADDED] = (uint32_t)s.p.extraCycle;
+  for (int l = 0; l < s.L; l++) *h_lv(s, node, HP_SPARE0, l) = s.atk ? 0u : 0xFFFFFFFFu;  // suicideBizAfter :406
   // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
   s.ct[2 * (size_t)node] = (uint32_t)(down[node] ? INT32_MAX : startAt[node] + 1);
 }
@@ -2204,6 +2205,12 @@ __global__ void k_handel_own_bits(HandelState s) {
   *h_row(s, node, HK_TI, 0) = bit;
   *h_row(s, node, HK_LA, 0) = bit;
   *h_row(s, node, HK_VI, 0) = bit;
+  // the verification queues are empty after init(): a run that was cut short (maxTime, an error) leaves entries behind
+  for (int l = 0; l < s.L; l++) {
+    uint64_t* qr = h_qrec(s, node, l);
+    qr[0] = qr[1] = 0;
+    qr[H_QBAD] = 0;
+  }
 }
 
 // read-back: toVerifyAgg.size() of every (owned node, level)
@@ -2237,6 +2244,11 @@ struct HandelHost : ProtoHost {
     if (N < 2 || (N & (N - 1))) throw WgError(WG_EINVAL, "We support only power of two nodes in this simulation");
     if (!init.startAt || !init.nodePairingTime || (!init.receptionRanks && init.peers))
       throw WgError(WG_EINVAL, "wg_handel_init_state has NULL members");
+    if (p.byzantineSuicide && p.hiddenByzantine) throw WgError(WG_EINVAL, "Only one attack at a time");  // :123-125
+    if (p.hiddenByzantine)
+      throw WgError(WG_EUNSUPPORTED, "Handel hiddenByzantine (P/Handel.java:840-917) is not resident on the device: run it in host-callback mode");
+    if (p.byzantineSuicide && e.shardCount > 0)
+      throw WgError(WG_EUNSUPPORTED, "Handel byzantineSuicide on a sharded engine");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N)
     if (L > MAX_LEVELS) throw WgError(WG_EINVAL, "too many levels");
@@ -2316,6 +2328,8 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
+    st.atk = p.byzantineSuicide ? 1 : 0;
+    st.blacklist = st.atk ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
@@ -2536,6 +2550,7 @@ struct HandelHost : ProtoHost {
   void reset_rows(Engine& e) {
     const size_t nLoc = (size_t)(st.hi - st.lo), at = (size_t)st.lo * st.W;
     WG_HIP(hipMemsetAsync(st.rows + at * HK_COUNT, 0, 8 * nLoc * st.W * HK_COUNT, e.stream));
+    if (st.atk) WG_HIP(hipMemsetAsync(st.blacklist, 0, 8 * (size_t)st.N * st.W, e.stream));
     hipLaunchKernelGGL(k_handel_own_bits, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st);
   }
   bool cont_if(Engine& e, int32_t* out) override {
@@ -2560,9 +2575,14 @@ struct HandelHost : ProtoHost {
   const void* state_host() const override { return &st; }
   template <int W>
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
-    hipLaunchKernelGGL(k_handel_a1<W>, dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
+    hipLaunchKernelGGL((k_handel_a1<W, false>), dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
   }
+  int variant() const override { return st.atk; }
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
+    if (st.atk) {  // byzantineSuicide: the instantiations with the attack's paths (every item a wavefront)
+      hipLaunchKernelGGL((k_handel_a1<4, true>), dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
+      return;
+    }
     switch (wavesCond) {
       case 8: launch_a1<8>(g, stab, R, s); break;
       case 6: launch_a1<6>(g, stab, R, s); break;
@@ -2580,7 +2600,10 @@ struct HandelHost : ProtoHost {
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
-    hipLaunchKernelGGL(k_handel_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    if (st.atk)
+      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    else
+      hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
@@ -2606,7 +2629,7 @@ struct HandelHost : ProtoHost {
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
     e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
-    hipLaunchKernelGGL(k_handel_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL((k_handel_cond_a2<true, false>), dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
     WG_HIP(hipMemsetAsync(st.candMask, 0, 4 * (size_t)st.N, g.stream));  // the other shards' masks
     return nOut;
   }
@@ -2633,12 +2656,16 @@ struct HandelHost : ProtoHost {
       default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     const dim3 grid(node_grid(g.R), g.R);
+    if (st.atk) {
+      hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab);
+      return;
+    }
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL(k_handel_wave<8>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 6: hipLaunchKernelGGL(k_handel_wave<6>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 5: hipLaunchKernelGGL(k_handel_wave<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 3: hipLaunchKernelGGL(k_handel_wave<3>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      default: hipLaunchKernelGGL(k_handel_wave<4>, grid, dim3(256), 0, g.stream, g.tab, stab);
+      case 8: hipLaunchKernelGGL((k_handel_wave<8, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 6: hipLaunchKernelGGL((k_handel_wave<6, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 5: hipLaunchKernelGGL((k_handel_wave<5, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      case 3: hipLaunchKernelGGL((k_handel_wave<3, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
+      default: hipLaunchKernelGGL((k_handel_wave<4, false>), grid, dim3(256), 0, g.stream, g.tab, stab);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
@@ -2689,7 +2716,8 @@ struct HandelHost : ProtoHost {
       WG_HIP(rc);
       return true;
     }
-    const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN : -1;
+    const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN
+                      : field == WG_LF_SUICIDE_BIZ_AFTER ? HP_SPARE0 : -1;
     if (plane < 0) return false;
     const std::vector<uint32_t> h = read_hdr();
     for (int i = 0; i < n; i++)
@@ -2698,6 +2726,14 @@ struct HandelHost : ProtoHost {
   }
   bool read_bits(Engine&, int32_t field, uint64_t* dst, int32_t n, int32_t w) override {
     if (n != st.N || w != st.W) throw WgError(WG_EINVAL, "shape must be [nodeCount][max(1, nodeCount/64)]");
+    if (field == WG_B_BLACKLIST) {  // (id order as it is; all zeros without the attack)
+      memset(dst, 0, 8 * (size_t)n * w);
+      if (st.atk) {
+        WG_HIP(hipStreamSynchronize(eng.stream));
+        WG_HIP(hipMemcpy(dst, st.blacklist, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
+      }
+      return true;
+    }
     int k;
     switch (field) {
       case WG_B_TOTAL_INCOMING: k = HK_TI; break;

@@ -57,6 +57,7 @@ struct ProtoHost {
   virtual bool read_level_i32(Engine&, int32_t, int32_t*, int32_t, int32_t) { return false; }
   virtual bool read_bits(Engine&, int32_t, uint64_t*, int32_t, int32_t) { return false; }
   virtual int levels() const { return 0; }
+  virtual int variant() const { return 0; }  // (a mode that selects other kernels: batch members must agree on it)
   virtual int host_msg_size(uint32_t /*msg*/) const { return 1; }  // Message.size() of a host-side send
   // every message of the protocol has size() 1: Node.bytesReceived == Node.msgReceived, its lane-per-event delivery kernel
   // counts once and the read-back serves both fields from msgReceived

@@ -38,6 +38,7 @@ constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
 constexpr int H_QREC = 72;         // 64-bit words of a queue record: 2 + 64 entries, padded to whole 64-byte lines
+constexpr int H_QBAD = 66;         // word of the record: bit `slot` = that slot's signature is a bad one (SigToVerify.badSig)
 constexpr int H_LANE_NW = 16;      // level blocks of up to this many 64-bit words are worked on by ONE lane, which streams
                                    // them two words a load (levels <= 11); a wavefront per item spends ~ 25 wave-level memory
                                    // instructions on ONE item, and that instruction rate is what bounds those kernels
@@ -59,6 +60,10 @@ struct HandelState {
   int32_t N, L, W, Q;
   GP<uint64_t> rows;                      // [N][W][5], level-major: see h_row
   GP<int32_t> ranks;                      // [N][N]
+  // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
+  // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
+  GP<uint64_t> blacklist;                 // [N][W]
+  int32_t atk;                            // 1 byzantineSuicide
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
   GP<const uint16_t> peers16;
@@ -255,9 +260,16 @@ struct alignas(16) HQHead {
   uint64_t len, used;
 };
 
-struct HandelProto {
+// ATK: the byzantineSuicide paths compiled in (a run without the attack uses the instantiation without them)
+template <bool ATK>
+struct HandelProtoT {
   typedef HandelState State;
   typedef LevelScalars WaveShared;
+  // blacklist.get(id) of `node` (:289)
+  __device__ static bool blk(const State& s, int32_t node, int32_t id) {
+    if (!ATK) return false;
+    return (ld_coherent(s.blacklist + (size_t)node * s.W + (id >> 6)) >> (id & 63)) & 1ULL;
+  }
 
   // node-scoped registers (wave-uniform) live in this struct for the duration of a node's events
   struct NodeRegs {
@@ -425,6 +437,7 @@ struct HandelProto {
       bool in = k < len;
       int32_t p = in ? h_peer(s, peers0 + pos + k) : 0;
       bool ok = in && !((ld_coherent(fp + ((p >> 6) - fbw)) >> (p & 63)) & 1ULL);
+      if (ATK && ok) ok = !blk(s, node, p);  // ... && !blacklist.get(p.nodeId)  :493
       uint64_t okm = __ballot(ok);
       // a rejected peer whose successor position is `start` finishes the level (:499-503)
       int nextPos = pos + k + 1;
@@ -483,6 +496,7 @@ struct HandelProto {
       return;
     }
     if (c.t < r.startAt) return;
+    if (ATK && blk(s, node, from)) return;  // :766
     LevelScalars* ls = r.ls;
     // Everything this event reads from HBM depends only on (node, from, payload): issue it all before the
     // first use so the event costs ONE memory round trip (the path is latency-bound).
@@ -526,6 +540,7 @@ struct HandelProto {
       nh.len = (uint64_t)(len + 1);
       nh.used = used | (1ULL << slot);
       gst((HQHead WG_G*)qr, nh);
+      if (ATK) qr[H_QBAD] &= ~(1ULL << slot);  // badSig = false (ssigs.badSig is never set by a sender :786)
       ls->sc[HH_QMASK] |= 1u << l;
     }
     __builtin_amdgcn_wave_barrier();
@@ -606,6 +621,10 @@ struct HandelProto {
       const uint64_t w2 = two ? ld_coherent(fpRow + ((cand2 >> 6) - fbw)) : ~0ULL;
       fin = (w1 >> (cand & 63)) & 1ULL;
       fin2 = (w2 >> (cand2 & 63)) & 1ULL;
+      if (ATK) {  // a blacklisted peer is passed over like a finished one (:493)
+        fin = fin || blk(s, node, cand);
+        if (two) fin2 = fin2 || blk(s, node, cand2);
+      }
       if (fin && two && !fin2) {  // the first candidate is rejected (no effect but posInLevel++), the second one is taken
         cand = cand2;
         myPos++;
@@ -704,6 +723,14 @@ struct HandelProto {
     const int total0 = (int)WG_READFIRST(ls->sc[HH_TOTAL]);  // the sum of |totalIncoming| over the levels, before this task
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
+    if (ATK) {  // :688-694 a bad signature: its signer is blacklisted, nothing else happens (the entry stays listed)
+      const uint64_t badM = h_qrec(s, node, lv)[H_QBAD];
+      if ((badM >> slot) & 1ULL) {
+        if (lane == 0) atomicOr((unsigned long long*)(s.blacklist + (size_t)node * s.W + (from >> 6)), 1ULL << (from & 63));
+        __builtin_amdgcn_wave_barrier();
+        return;
+      }
+    }
     const Lv v = sib_view(node, lv);
     uint64_t WG_G* ti = h_row(s, node, HK_TI, lv);  // the level's block: word j of it is [j]
     uint64_t WG_G* la = h_row(s, node, HK_LA, lv);
@@ -831,6 +858,7 @@ struct HandelProto {
     if (r.doneAt == 0 && cur >= s.p.threshold) r.doneAt = c.t;
   }
 };
+typedef HandelProtoT<false> HandelProto;
 
 // ------------------------------------------------------------------------------------------------
 // The delivery pass, first kernel: one LANE per node with events (the reference applies an envelope to its `to` node,
@@ -1077,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     // ---- which kernel applies the node's events: this lane, if they are <= 4 SendSigs deliveries and at most one
     // updateVerifiedSignatures — of a narrow level (applied here), or of a wide level as the node's LAST event (handed to
     // k_handel_update: the deliveries before it are this lane's); else a wavefront of k_handel_wave
-    bool mine = have && cnt <= (uint32_t)INBOX_SLOTS;
+    bool mine = have && cnt <= (uint32_t)INBOX_SLOTS && !s.atk;  // (byzantineSuicide: every visit by k_handel_wave)
     int nUpd = 0, wideAt = -1;
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) {
@@ -1512,10 +1540,11 @@ __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict
 // Software-pipelined: while item a runs, the header and the inbox line of item a + nWaves and the descriptor of item
 // a + 2 nWaves are in flight. A visit writes no other node's header (effects on other nodes travel as envelopes, at
 // least one ms later), so fetching the next header early reads what the visit itself would.
-template <int WPE>
+template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
+  typedef HandelProtoT<ATK> HP;
   __shared__ LevelScalars shP[4];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1529,7 +1558,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
     return gld(d.inbox + ((size_t)WG_READFIRST(desc.x) * INBOX_SLOTS + (lane < INBOX_SLOTS ? lane : 0)));
   };
   U4 descCur = gld(work + a);
-  HandelProto::Pre hdrCur = HandelProto::prefetch(s, (int32_t)WG_READFIRST(descCur.x));
+  typename HP::Pre hdrCur = HP::prefetch(s, (int32_t)WG_READFIRST(descCur.x));
   InboxEntry inCur = inbox_of(descCur);
   U4 descNext = descCur;
   if (a + nWaves < nWork) descNext = gld(work + (a + nWaves));
@@ -1538,11 +1567,11 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
     KPROF_COUNT(d.g, 0);
     const uint32_t an = a + nWaves;
     const bool haveNext = an < nWork;
-    HandelProto::Pre hdrNext = hdrCur;
+    typename HP::Pre hdrNext = hdrCur;
     InboxEntry inNext = inCur;
     U4 descNext2 = descNext;
     if (haveNext) {
-      hdrNext = HandelProto::prefetch(s, (int32_t)WG_READFIRST(descNext.x));
+      hdrNext = HP::prefetch(s, (int32_t)WG_READFIRST(descNext.x));
       inNext = inbox_of(descNext);
       if (an + nWaves < nWork) descNext2 = gld(work + (an + nWaves));
     }
@@ -1550,11 +1579,11 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
       const int32_t node = (int32_t)WG_READFIRST(descCur.x);
       const uint32_t kf = WG_READFIRST(descCur.y);
       Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
-      HandelProto::NodeRegs r;
-      HandelProto::node_begin_pre(c, s, r, &shP[w], hdrCur);
+      typename HP::NodeRegs r;
+      HP::node_begin_pre(c, s, r, &shP[w], hdrCur);
       KPROF_MARK(d.g, 31);  // the next item's prefetches issued, this item's descriptor + header arrived
       if ((kf & 0xFFu) == HW_VISIT) {
-        deliver_visit_inbox<HandelProto>(d, s, c, r, node, WG_READFIRST(descCur.z), kf >> 8, inCur, WG_READFIRST(descCur.w));
+        deliver_visit_inbox<HP>(d, s, c, r, node, WG_READFIRST(descCur.z), kf >> 8, inCur, WG_READFIRST(descCur.w));
       } else {
         // the fast path of an updateVerifiedSignatures a lane applied (h_lane_update): its sends are that event's records
         const uint32_t e = WG_READFIRST(descCur.z);
@@ -1562,15 +1591,15 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
         c.ev = e;
         c.outBase = aux.outBase;
         c.outCap = aux.outCap;
-        HandelProto::fast_path(c, s, r.ls, (int)WG_READFIRST(descCur.w));
+        HP::fast_path(c, s, r.ls, (int)WG_READFIRST(descCur.w));
         if (lane == 0) {
           EvRes res;
           res.nrec = c.sub | EV_TASK_RUN;
           res.ndraw = c.draws;
           gst(d.evRes + e, res);
         }
-        HandelProto::node_counters(c, s, r, 0, 0);
-        HandelProto::store_levels(s, node, r.ls);  // posInLevel / outgoingFinished of the levels it sent for, the counters
+        HP::node_counters(c, s, r, 0, 0);
+        HP::store_levels(s, node, r.ls);  // posInLevel / outgoingFinished of the levels it sent for, the counters
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -1629,7 +1658,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     uint32_t mLane = 0, mWave = 0;
     for (uint32_t m = qm; m; m &= m - 1) {
       const int l = __ffs(m) - 1;
-      if (h_nw(l) <= H_LANE_NW)
+      if (h_nw(l) <= H_LANE_NW && !s.atk)  // (byzantineSuicide: every item by a wavefront)
         mLane |= 1u << l;
       else
         mWave |= 1u << l;
@@ -1689,7 +1718,7 @@ __device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node
 // A1: bestToVerify (:570-634) of one (runner, level) item: curates the level's list, records its candidate.
 // Blocks [0, gridDim.x / 4) take the items of the narrow levels one LANE each, the others the wide levels' items one
 // WAVEFRONT each — one launch, both kinds of chains in flight together.
-template <int WPE>
+template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
@@ -1818,7 +1847,13 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     for (int u = 0; u < 2; u++) {
       const int j = 2 * (u * 64 + lane);
       ti2[u].x = ti2[u].y = vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
-      if (wideRound && j < v.nw) {
+      if (ATK && v.nw == 1) {  // (the levels below 8, which only the attack's runs bring here: one masked word)
+        if (j == 0) {
+          ti2[u].x = ti[0] & v.mask;
+          vi2[u].x = vi[0] & v.mask;
+          la2[u].x = la[0] & v.mask;
+        }
+      } else if (wideRound && j < v.nw) {
         ti2[u] = gld((const V2 WG_G*)(ti + j));
         vi2[u] = gld((const V2 WG_G*)(vi + j));
         la2[u] = gld((const V2 WG_G*)(la + j));
@@ -1840,6 +1875,63 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
     KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
     const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
+    uint64_t blkM = 0;  // entries whose signer is blacklisted (:592 `!blacklist.get(stv.from)`)
+    if (ATK) {
+      // ---- createSuicideByzantineSig (:538-559, called by bestToVerify :577-584): the first byzantine (down), not yet
+      // blacklisted peer of the level from suicideBizAfter on whose rank is inside the window sends a bad signature over
+      // the whole block. The scan is the reference's loop, 64 peers a step.
+      const int sba = (int)*h_lv(s, node, HP_SPARE0, l);
+      if (sba >= 0 && len > 0) {
+        const int size = 1 << (l - 1);
+        const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
+        const int maxRank = windowIndex + window;
+        int firstCond = -1, hit = -1, hitRank = 0;
+        for (int i0 = sba; i0 < size && hit < 0; i0 += 64) {
+          const int i = i0 + lane;
+          const bool in = i < size;
+          const int32_t p = in ? h_peer(s, peers0 + i) : 0;
+          const bool cond = in && d.nodes.down[p] && !HandelProtoT<true>::blk(s, node, p);
+          const int32_t rk = cond ? s.ranks[(size_t)node * s.N + p] : 0;
+          const uint64_t cm = __ballot(cond);
+          if (firstCond < 0 && cm) firstCond = i0 + __ffsll((unsigned long long)cm) - 1;
+          const uint64_t hm = __ballot(cond && rk < maxRank);
+          if (hm) {
+            const int src = __ffsll((unsigned long long)hm) - 1;
+            hit = (int)lane_bcast((uint32_t)p, src);
+            hitRank = (int)lane_bcast((uint32_t)rk, src);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *h_lv(s, node, HP_SPARE0, l) = (uint32_t)firstCond;  // (-1: no byzantine nodes left in this level)
+        if (hit >= 0) {  // toVerifyAgg.add(bSig); sigQueueSize++; return bSig — no curation this time
+          const int qc = h_qcap(s, l);
+          const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
+          const unsigned long long freeM = ~qh.used & capMask;
+          if (freeM == 0 || len >= 64) {
+            if (lane == 0) set_err(d.g, ERR_QUEUE_CAP);
+            continue;
+          }
+          const int slot = __ffsll(freeM) - 1;
+          uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
+          H_FOR_WORDS(v, j) dst[j] = v.mask;  // sig = waitedSigs: the whole sibling block
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            ent[len] = h_entry(hitRank, hit, slot);
+            HQHead nh;
+            nh.len = (uint64_t)(len + 1);
+            nh.used = qh.used | (1ULL << slot);
+            gst((HQHead WG_G*)qr, nh);
+            qr[H_QBAD] |= 1ULL << slot;
+            atomicAdd(F((uint32_t WG_G*)hdr + HH_SIGQ), 1u);
+            *h_lv(s, node, HP_CAND, l) = ((uint32_t)hit << 8) | (uint32_t)slot;
+            atomicOr(F(s.candMask + node), 1u << l);
+          }
+          continue;
+        }
+      }
+      const bool myBlk = lane < len && HandelProtoT<true>::blk(s, node, (int32_t)((myEnt >> 8) & 0xFFFFFFu));
+      blkM = __ballot(myBlk);
+    }
     long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
     int bestScore = 0, bestOutsideRank = 0;
     uint64_t keep = 0;
@@ -1858,7 +1950,11 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
         for (int u = 0; u < 2; u++) {
           const int j = 2 * (u * 64 + lane);
           sg[e2][u].x = sg[e2][u].y = 0;
-          if (wideRound && j < v.nw && i0 + e2 < len) sg[e2][u] = gld((const V2 WG_G*)(sig + j));
+          if (ATK && v.nw == 1) {
+            if (j == 0 && i0 + e2 < len) sg[e2][u].x = sig[0];
+          } else if (wideRound && j < v.nw && i0 + e2 < len) {
+            sg[e2][u] = gld((const V2 WG_G*)(sig + j));
+          }
         }
       }
 #pragma unroll
@@ -1884,7 +1980,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
         b = wave_sum64(b);
         const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
         const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
+        HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
+        if (ATK && ((blkM >> i) & 1ULL)) ev.keep = ev.inside = false;
         if (ev.keep) {
           keep |= 1ULL << i;
           if (ev.inside) {
@@ -1945,7 +2042,7 @@ struct CondF {
 
 // A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
 // SH (sharded engine): a drawing node is handled by its owner, the task record goes to the exchange image.
-template <bool SH>
+template <bool SH, bool ATK>
 __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restrict__ tab,
                                                         const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -1987,6 +2084,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       const int32_t from = (int32_t)(who >> 8);
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
       int w = (int)h[HH_WINDOW] * 2;
+      if (ATK && ((h_qrec(s, node, l)[H_QBAD] >> slot) & 1ULL)) w = (int)h[HH_WINDOW] / 4;  // newSize(cur, !best.badSig): floor(cur / 4)
       if (w > s.p.windowMaximum) w = s.p.windowMaximum;
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
       h[HH_WINDOW] = (uint32_t)min(w, 1 << (l - 1));
