@@ -1,10 +1,10 @@
 """Handel (P/Handel.java) written against the reference's own protocol API and run on the engine in host-callback mode
-(wittgenstein_amd.hostnet) — including the two attack scenarios of its parameters that the RESIDENT device form refuses
-(`WG_EUNSUPPORTED`): `byzantineSuicide` (:64-69, 406, 538-559, 577-584, 688-694) and `hiddenByzantine` (:70-71, 303,
-813-817, 840-917). Queue, LIFO / chain ordering, latency sampling and the shared `rd` live in libwittgpu.so on the
+(wittgenstein_amd.hostnet) — including the two attack scenarios of its parameters, `byzantineSuicide` (:64-69, 406,
+538-559, 577-584, 688-694) and `hiddenByzantine` (:70-71, 303, 813-817, 840-917), which the resident device form runs
+too (wittgenstein_amd/csrc/proto_handel.hip.h). Queue, LIFO / chain ordering, latency sampling and the shared `rd` live in libwittgpu.so on the
 MI355X; HNode / HLevel / SigToVerify / SendSigs stay host objects as in the reference. Host-side Python stand-in for the
 Java classes (no JVM in the build image); class, field and method names follow the Java source. BitSets
-are Python ints (bit j = node id j). Checked against oracle/handel.hpp after every chunk: tests/test_zx_gpu_handel_hostmode.py."""
+are Python ints (bit j = node id j). Checked against oracle/handel.hpp after every chunk: tests/test_gpu_handel_hostmode.py."""
 import math
 
 from wittgenstein_amd.core import IllegalArgumentException, IllegalStateException

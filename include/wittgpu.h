@@ -175,9 +175,8 @@ typedef struct {
   int32_t desynchronizedStart;
   int32_t windowInitial, windowMinimum, windowMaximum; /* 16, 1, 128 */
   /* HandelParameters.byzantineSuicide / hiddenByzantine (P/Handel.java:64-71, 108-109): the down nodes are byzantine and
-   * attack. byzantineSuicide (:406, 538-559, 577-584, 688-694) is resident on the device (unsharded engines; every node
-   * visit then takes the wave-per-node kernels); hiddenByzantine (:813-817, 840-917) is not: WG_EUNSUPPORTED (it runs in
-   * host-callback mode). */
+   * attack — byzantineSuicide :406, 538-559, 577-584, 688-694; hiddenByzantine :813-817, 840-917. Both are resident on the
+   * device (unsharded engines; every node visit then takes the wave-per-node kernels); at most one of them (WG_EINVAL). */
   int32_t byzantineSuicide, hiddenByzantine;
 } wg_handel_params;
 

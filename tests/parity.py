@@ -14,13 +14,14 @@ LEVELS = ["posInLevel", "outgoingFinished", "queueLen", "suicideBizAfter"]
 BITS = ["totalIncoming", "lastAggVerified", "verifiedIndSignatures", "toVerifyInd", "finishedPeers", "blacklist"]
 
 
-def handel_pair(params, nb=NB, nl=NL, seed=0, config=None, byzantine_suicide=False):
+def handel_pair(params, nb=NB, nl=NL, seed=0, config=None, byzantine_suicide=False, hidden_byzantine=False):
     """params = (nodeCount, threshold, pairing, levelWait, extraCycle, period, fastPath, nodesDown, desync)"""
     n, thr, pair, lw, ec, per, fp, down, desync = params
-    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, byzantineSuicide=byzantine_suicide),
-                 seed=seed, config=config)
+    g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, byzantineSuicide=byzantine_suicide,
+                                    hiddenByzantine=hidden_byzantine), seed=seed, config=config)
     g.init()
-    c = o.Handel(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, seed=seed, byzantine_suicide=byzantine_suicide)
+    c = o.Handel(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, seed=seed, byzantine_suicide=byzantine_suicide,
+                 hidden_byzantine=hidden_byzantine)
     return g, c
 
 

@@ -97,7 +97,11 @@ def test_handel_reception_ranks_on_the_device(monkeypatch, capfd):  # k_handel_i
 def test_handel_byzantine_suicide_resident():  # P/Handel.java:538-559, 577-584, 688-694 on the device vs the oracle
     th.test_byzantine_suicide_resident(64, 0)
     th.test_byzantine_suicide_resident_hostmode_cases()
-    th.test_hidden_byzantine_is_refused_by_the_resident_engine()
+    th.test_attack_parameter_checks()
+
+
+def test_handel_hidden_byzantine_resident():  # P/Handel.java:813-817, 840-917 on the device vs the oracle
+    th.test_hidden_byzantine_resident((64, 50, 4, 50, 5, 20, 10, 6, 0), 2, 1)
 
 
 def test_handel_chunk_size_is_observable():

@@ -150,11 +150,23 @@ def test_byzantine_suicide_resident_hostmode_cases():
     lockstep((32, 24, 3, 30, 4, 10, 5, 4, 40), step=10, max_ms=4000, seed=5, byzantine_suicide=True)  # desynchronized start
 
 
-def test_hidden_byzantine_is_refused_by_the_resident_engine():
-    with pytest.raises(w.UnsupportedError):
-        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, hiddenByzantine=True)
-    with pytest.raises(w.IllegalArgumentException):
+@pytest.mark.parametrize("params,seed,step", [((64, 50, 4, 50, 5, 20, 10, 6, 0), 2, 1), (None, 3, 5)])
+def test_hidden_byzantine_resident(params, seed, step):
+    """HandelParameters.hiddenByzantine (P/Handel.java:70-71, 813-817, 840-917) resident on the device (k_handel_hidden): the
+    best-ranked byzantine peer plants valid, nearly useless signatures in the last level's queue. The first case is the one
+    tests/test_gpu_handel_hostmode.py runs through host callbacks."""
+    params = params or ratios(256, dead=0.25)
+    g, c = lockstep(params, step=step, max_ms=4000, seed=seed, hidden_byzantine=True)
+    assert not g.network().read_bits("blacklist").any() and not g.cont_if()
+    _, honest = lockstep(params, step=10, max_ms=4000, seed=seed)
+    assert int(c.read("sigsChecked").sum()) != int(honest.read("sigsChecked").sum())  # the attack changed the run
+
+
+def test_attack_parameter_checks():
+    with pytest.raises(w.IllegalArgumentException):  # "Only one attack at a time" :123-125
         w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, byzantineSuicide=True, hiddenByzantine=True)
+    with pytest.raises(w.UnsupportedError):
+        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, badNodes=[3])
 
 
 def test_queue_capacity_overflow_is_loud():

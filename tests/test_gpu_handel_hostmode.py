@@ -1,6 +1,7 @@
 """Handel (P/Handel.java) on the engine in host-callback mode (examples/hostmode/handel.py) vs the CPU oracle
-(oracle/handel.hpp) — the honest parameters and the two attack scenarios the resident device form refuses:
-byzantineSuicide (:538-559, 577-584, 688-694) and hiddenByzantine (:813-817, 840-917). Compared after every chunk: the
+(oracle/handel.hpp) — the honest parameters and the two attack scenarios, byzantineSuicide (:538-559, 577-584, 688-694)
+and hiddenByzantine (:813-817, 840-917), as an unmodified protocol class would run them on the engine (the resident device
+form runs both too: tests/test_gpu_handel.py). Compared after every chunk: the
 node counters and scalars, every level's posInLevel / outgoingFinished / queue length / suicideBizAfter, the five bitsets
 of every level and the blacklist, network.time, msgs.size() and the rd state."""
 import numpy as np

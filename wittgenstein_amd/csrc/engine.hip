@@ -2162,7 +2162,7 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
   h[HH_TOTAL] = 1;  // the sum of |totalIncoming| over the levels: the own signature
   h[HH_WINDOW] = (uint32_t)s.p.windowInitial;
   h[HH_ADDED] = (uint32_t)s.p.extraCycle;
-  for (int l = 0; l < s.L; l++) *h_lv(s, node, HP_SPARE0, l) = s.atk ? 0u : 0xFFFFFFFFu;  // suicideBizAfter :406
+  for (int l = 0; l < s.L; l++) *h_lv(s, node, HP_SPARE0, l) = s.atk == 1 ? 0u : 0xFFFFFFFFu;  // suicideBizAfter :406
   // registerConditionalTask(checkSigs, startAt + 1, nodePairingTime, ...) for live nodes (:979-982)
   s.ct[2 * (size_t)node] = (uint32_t)(down[node] ? INT32_MAX : startAt[node] + 1);
 }
@@ -2245,10 +2245,8 @@ struct HandelHost : ProtoHost {
     if (!init.startAt || !init.nodePairingTime || (!init.receptionRanks && init.peers))
       throw WgError(WG_EINVAL, "wg_handel_init_state has NULL members");
     if (p.byzantineSuicide && p.hiddenByzantine) throw WgError(WG_EINVAL, "Only one attack at a time");  // :123-125
-    if (p.hiddenByzantine)
-      throw WgError(WG_EUNSUPPORTED, "Handel hiddenByzantine (P/Handel.java:840-917) is not resident on the device: run it in host-callback mode");
-    if (p.byzantineSuicide && e.shardCount > 0)
-      throw WgError(WG_EUNSUPPORTED, "Handel byzantineSuicide on a sharded engine");
+    if ((p.byzantineSuicide || p.hiddenByzantine) && e.shardCount > 0)
+      throw WgError(WG_EUNSUPPORTED, "Handel byzantineSuicide / hiddenByzantine on a sharded engine");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N)
     if (L > MAX_LEVELS) throw WgError(WG_EINVAL, "too many levels");
@@ -2328,8 +2326,8 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
-    st.atk = p.byzantineSuicide ? 1 : 0;
-    st.blacklist = st.atk ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
+    st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
+    st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
@@ -2550,7 +2548,7 @@ struct HandelHost : ProtoHost {
   void reset_rows(Engine& e) {
     const size_t nLoc = (size_t)(st.hi - st.lo), at = (size_t)st.lo * st.W;
     WG_HIP(hipMemsetAsync(st.rows + at * HK_COUNT, 0, 8 * nLoc * st.W * HK_COUNT, e.stream));
-    if (st.atk) WG_HIP(hipMemsetAsync(st.blacklist, 0, 8 * (size_t)st.N * st.W, e.stream));
+    if (st.atk == 1) WG_HIP(hipMemsetAsync(st.blacklist, 0, 8 * (size_t)st.N * st.W, e.stream));
     hipLaunchKernelGGL(k_handel_own_bits, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st);
   }
   bool cont_if(Engine& e, int32_t* out) override {
@@ -2600,6 +2598,8 @@ struct HandelHost : ProtoHost {
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<CondF>(g, stab);
+    if (st.atk == 2)  // HiddenByzantine.attack on the drawn candidates of the last level
+      hipLaunchKernelGGL(k_handel_hidden, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     if (st.atk)
       hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
     else
@@ -2728,7 +2728,7 @@ struct HandelHost : ProtoHost {
     if (n != st.N || w != st.W) throw WgError(WG_EINVAL, "shape must be [nodeCount][max(1, nodeCount/64)]");
     if (field == WG_B_BLACKLIST) {  // (id order as it is; all zeros without the attack)
       memset(dst, 0, 8 * (size_t)n * w);
-      if (st.atk) {
+      if (st.atk == 1) {
         WG_HIP(hipStreamSynchronize(eng.stream));
         WG_HIP(hipMemcpy(dst, st.blacklist, 8 * (size_t)n * w, hipMemcpyDeviceToHost));
       }

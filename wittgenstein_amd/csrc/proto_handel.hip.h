@@ -62,8 +62,8 @@ struct HandelState {
   GP<int32_t> ranks;                      // [N][N]
   // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
   // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
-  GP<uint64_t> blacklist;                 // [N][W]
-  int32_t atk;                            // 1 byzantineSuicide
+  GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
+  int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
   GP<const uint16_t> peers16;
@@ -129,7 +129,9 @@ struct HandelState {
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_TOTAL = 7, HH_NRECV = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_BRECV = 12, HH_NSENT = 14,
-                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_BSENT = 30, HH_LV = 32 };
+                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_HB_LAST = 24, HH_HB_NOBYZ = 25, HH_BSENT = 30, HH_LV = 32 };
+// (HH_HB_*: HNode.hiddenByzantine's `last` — 0 = null, else (signer << 8 | slot) + 1 of the entry it planted — and
+// noByzantinePeers, P/Handel.java:840-843)
 // (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
 // updateVerifiedSignatures add to that)
 enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_TV, HK_FP, HK_COUNT };
@@ -267,7 +269,7 @@ struct HandelProtoT {
   typedef LevelScalars WaveShared;
   // blacklist.get(id) of `node` (:289)
   __device__ static bool blk(const State& s, int32_t node, int32_t id) {
-    if (!ATK) return false;
+    if (!ATK || s.atk != 1) return false;
     return (ld_coherent(s.blacklist + (size_t)node * s.W + (id >> 6)) >> (id & 63)) & 1ULL;
   }
 
@@ -723,7 +725,7 @@ struct HandelProtoT {
     const int total0 = (int)WG_READFIRST(ls->sc[HH_TOTAL]);  // the sum of |totalIncoming| over the levels, before this task
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
-    if (ATK) {  // :688-694 a bad signature: its signer is blacklisted, nothing else happens (the entry stays listed)
+    if (ATK && s.atk == 1) {  // :688-694 a bad signature: its signer is blacklisted, nothing else happens (the entry stays listed)
       const uint64_t badM = h_qrec(s, node, lv)[H_QBAD];
       if ((badM >> slot) & 1ULL) {
         if (lane == 0) atomicOr((unsigned long long*)(s.blacklist + (size_t)node * s.W + (from >> 6)), 1ULL << (from & 63));
@@ -1715,6 +1717,205 @@ __device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node
   }
 }
 
+// bestToVerify (:570-634) of (node, l) by one wavefront: lanes = 64-bit words of the level's block. Curates the list and
+// records the level's candidate (h_item_finish); returns it (signer << 8 | slot) or -1.
+template <bool ATK>
+__device__ __forceinline__ long long h_best_wave(const EngineDev& d, const HandelState& s, int32_t node, int l) {
+  const int lane = WG_LANE;
+  KPROF_DECL;
+  KPROF_COUNT(d.g, 16);
+  const uint32_t WG_G* hdr = h_hdr(s, node);
+  const Lv v = sib_view(node, l);
+  const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);  // the level's block: word j of it is [j]
+  const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
+  const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
+  uint64_t WG_G* qr = h_qrec(s, node, l);
+  uint64_t WG_G* ent = qr + 2;
+  // ---- everything the item's address alone decides, before the first use. These kernels are bound by the number of
+  // wave-level memory instructions, so: the four 16-byte pieces (pending table, the header words with the window, the
+  // level's scalars, the record's head) are ONE instruction — lane k fetches piece k —, the list is one (lane i = entry
+  // i), and the rows and signatures move two words a lane (blocks of <= 256 words: two instructions an array at most)
+  const U4 WG_G* piece = lane == 0 ? (const U4 WG_G*)(hdr + HH_PEND)
+                         : lane == 1 ? (const U4 WG_G*)(hdr + 4)
+                         : lane == 2 ? (const U4 WG_G*)h_lv(s, node, HP_POS, l) : (const U4 WG_G*)qr;
+  U4 pg;
+  pg.x = pg.y = pg.z = pg.w = 0;
+  if (lane < 4) pg = gld(piece);
+  const uint64_t entAll = ent[lane];
+  const bool wideRound = v.nw <= 256;  // (levels <= 15; beyond: the word loop below)
+  V2 ti2[2], vi2[2], la2[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int j = 2 * (u * 64 + lane);
+    ti2[u].x = ti2[u].y = vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
+    if (ATK && v.nw == 1) {  // (the levels below 8, which only the attack's runs bring here: one masked word)
+      if (j == 0) {
+        ti2[u].x = ti[0] & v.mask;
+        vi2[u].x = vi[0] & v.mask;
+        la2[u].x = la[0] & v.mask;
+      }
+    } else if (wideRound && j < v.nw) {
+      ti2[u] = gld((const V2 WG_G*)(ti + j));
+      vi2[u] = gld((const V2 WG_G*)(vi + j));
+      la2[u] = gld((const V2 WG_G*)(la + j));
+    }
+  }
+  U4 pend;
+  pend.x = WG_READLANE(pg.x, 0);
+  pend.y = WG_READLANE(pg.y, 0);
+  pend.z = WG_READLANE(pg.z, 0);
+  pend.w = WG_READLANE(pg.w, 0);
+  const int window = (int)WG_READLANE(pg.y, 1);  // HH_WINDOW = word 5
+  const int curSize = (int)WG_READLANE(pg.y, 2), cLA = (int)WG_READLANE(pg.z, 2);
+  HQHead qh;
+  qh.len = (uint64_t)WG_READLANE(pg.x, 3) | ((uint64_t)WG_READLANE(pg.y, 3) << 32);
+  qh.used = (uint64_t)WG_READLANE(pg.z, 3) | ((uint64_t)WG_READLANE(pg.w, 3) << 32);
+  const int len = (int)qh.len;
+  const uint64_t myEnt = lane < len ? entAll : ~0ULL;
+  const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
+  const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+  KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
+  const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
+  uint64_t blkM = 0;  // entries whose signer is blacklisted (:592 `!blacklist.get(stv.from)`)
+  if (ATK) {
+    // ---- createSuicideByzantineSig (:538-559, called by bestToVerify :577-584): the first byzantine (down), not yet
+    // blacklisted peer of the level from suicideBizAfter on whose rank is inside the window sends a bad signature over
+    // the whole block. The scan is the reference's loop, 64 peers a step.
+    const int sba = (int)*h_lv(s, node, HP_SPARE0, l);
+    if (sba >= 0 && len > 0) {
+      const int size = 1 << (l - 1);
+      const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
+      const int maxRank = windowIndex + window;
+      int firstCond = -1, hit = -1, hitRank = 0;
+      for (int i0 = sba; i0 < size && hit < 0; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < size;
+        const int32_t p = in ? h_peer(s, peers0 + i) : 0;
+        const bool cond = in && d.nodes.down[p] && !HandelProtoT<true>::blk(s, node, p);
+        const int32_t rk = cond ? s.ranks[(size_t)node * s.N + p] : 0;
+        const uint64_t cm = __ballot(cond);
+        if (firstCond < 0 && cm) firstCond = i0 + __ffsll((unsigned long long)cm) - 1;
+        const uint64_t hm = __ballot(cond && rk < maxRank);
+        if (hm) {
+          const int src = __ffsll((unsigned long long)hm) - 1;
+          hit = (int)lane_bcast((uint32_t)p, src);
+          hitRank = (int)lane_bcast((uint32_t)rk, src);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) *h_lv(s, node, HP_SPARE0, l) = (uint32_t)firstCond;  // (-1: no byzantine nodes left in this level)
+      if (hit >= 0) {  // toVerifyAgg.add(bSig); sigQueueSize++; return bSig — no curation this time
+        const int qc = h_qcap(s, l);
+        const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
+        const unsigned long long freeM = ~qh.used & capMask;
+        if (freeM == 0 || len >= 64) {
+          if (lane == 0) set_err(d.g, ERR_QUEUE_CAP);
+          return -1;
+        }
+        const int slot = __ffsll(freeM) - 1;
+        uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
+        H_FOR_WORDS(v, j) dst[j] = v.mask;  // sig = waitedSigs: the whole sibling block
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          ent[len] = h_entry(hitRank, hit, slot);
+          HQHead nh;
+          nh.len = (uint64_t)(len + 1);
+          nh.used = qh.used | (1ULL << slot);
+          gst((HQHead WG_G*)qr, nh);
+          qr[H_QBAD] |= 1ULL << slot;
+          atomicAdd(F((uint32_t WG_G*)hdr + HH_SIGQ), 1u);
+          *h_lv(s, node, HP_CAND, l) = ((uint32_t)hit << 8) | (uint32_t)slot;
+          atomicOr(F(s.candMask + node), 1u << l);
+        }
+        return ((long long)hit << 8) | (long long)slot;
+      }
+    }
+    const bool myBlk = lane < len && HandelProtoT<true>::blk(s, node, (int32_t)((myEnt >> 8) & 0xFFFFFFu));
+    blkM = __ballot(myBlk);
+  }
+  long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
+  int bestScore = 0, bestOutsideRank = 0;
+  uint64_t keep = 0;
+  for (int i0 = 0; i0 < len; i0 += 2) {  // two entries' signatures in flight at a time
+    V2 sg[2][2];
+    int slotU[2], rankU[2];
+    uint32_t whoU[2];
+#pragma unroll
+    for (int e2 = 0; e2 < 2; e2++) {
+      const int i = i0 + e2 < len ? i0 + e2 : len - 1;
+      whoU[e2] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
+      slotU[e2] = (int)(whoU[e2] & 0xFFu);
+      rankU[e2] = (int)lane_bcast((uint32_t)myRank, i);
+      const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = 2 * (u * 64 + lane);
+        sg[e2][u].x = sg[e2][u].y = 0;
+        if (ATK && v.nw == 1) {
+          if (j == 0 && i0 + e2 < len) sg[e2][u].x = sig[0];
+        } else if (wideRound && j < v.nw && i0 + e2 < len) {
+          sg[e2][u] = gld((const V2 WG_G*)(sig + j));
+        }
+      }
+    }
+#pragma unroll
+    for (int e2 = 0; e2 < 2; e2++) {
+      const int i = i0 + e2;
+      if (i >= len) break;
+      uint64_t a = 0, b = 0;
+      auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
+        a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
+        b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
+      };
+      if (wideRound) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {  // (words beyond the block are zero in every array: they add nothing)
+          word(sg[e2][u].x, ti2[u].x, vi2[u].x, la2[u].x);
+          word(sg[e2][u].y, ti2[u].y, vi2[u].y, la2[u].y);
+        }
+      } else {
+        const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
+        H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
+      }
+      a = wave_sum64(a);
+      b = wave_sum64(b);
+      const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
+      const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
+      HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
+      if (ATK && ((blkM >> i) & 1ULL)) ev.keep = ev.inside = false;
+      if (ev.keep) {
+        keep |= 1ULL << i;
+        if (ev.inside) {
+          if (ev.score > bestScore) {
+            bestScore = ev.score;
+            bestInside = (long long)whoU[e2];
+          }
+        } else if (bestOutside < 0 || rankU[e2] < bestOutsideRank) {
+          bestOutside = (long long)whoU[e2];
+          bestOutsideRank = rankU[e2];
+        }
+      }
+    }
+  }
+  KPROF_ADD(d.g, 21, len);
+  KPROF_MARK(d.g, 22);  // the entries (kprof21: how many)
+  const int kept = __popcll(keep);
+  unsigned long long relMask = 0;
+  if (kept != len) {  // replaceToVerifyAgg :636-646
+    const int newPos = __popcll(keep & lanes_lt());
+    const bool mineKept = lane < len && ((keep >> lane) & 1ULL);
+    if (mineKept && newPos != lane) ent[newPos] = myEnt;
+    const uint32_t key = h_pend_word(l, mySlot);
+    const bool held = pend.x == key || pend.y == key || pend.z == key || pend.w == key;
+    const uint64_t rel = __ballot(lane < len && !mineKept && !held);
+    for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+  KPROF_MARK(d.g, 23);  // list curation, candidate
+  return bestInside >= 0 ? bestInside : bestOutside;
+}
+
 // A1: bestToVerify (:570-634) of one (runner, level) item: curates the level's list, records its candidate.
 // Blocks [0, gridDim.x / 4) take the items of the narrow levels one LANE each, the others the wide levels' items one
 // WAVEFRONT each — one launch, both kinds of chains in flight together.
@@ -1818,200 +2019,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
   const uint32_t nItems = s.itemCount[1];
   if (nWaves == 0) return;
   for (uint32_t q = wave; q < nItems; q += nWaves) {
-    KPROF_DECL;
-    KPROF_COUNT(d.g, 16);
     const uint32_t it = s.itemsWave[q];
-    const int32_t node = (int32_t)(it & 0x00FFFFFFu);
-    const int l = (int)(it >> 24);
-    const uint32_t WG_G* hdr = h_hdr(s, node);
-    const Lv v = sib_view(node, l);
-    const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);  // the level's block: word j of it is [j]
-    const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
-    const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
-    uint64_t WG_G* qr = h_qrec(s, node, l);
-    uint64_t WG_G* ent = qr + 2;
-    // ---- everything the item's address alone decides, before the first use. These kernels are bound by the number of
-    // wave-level memory instructions, so: the four 16-byte pieces (pending table, the header words with the window, the
-    // level's scalars, the record's head) are ONE instruction — lane k fetches piece k —, the list is one (lane i = entry
-    // i), and the rows and signatures move two words a lane (blocks of <= 256 words: two instructions an array at most)
-    const U4 WG_G* piece = lane == 0 ? (const U4 WG_G*)(hdr + HH_PEND)
-                           : lane == 1 ? (const U4 WG_G*)(hdr + 4)
-                           : lane == 2 ? (const U4 WG_G*)h_lv(s, node, HP_POS, l) : (const U4 WG_G*)qr;
-    U4 pg;
-    pg.x = pg.y = pg.z = pg.w = 0;
-    if (lane < 4) pg = gld(piece);
-    const uint64_t entAll = ent[lane];
-    const bool wideRound = v.nw <= 256;  // (levels <= 15; beyond: the word loop below)
-    V2 ti2[2], vi2[2], la2[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int j = 2 * (u * 64 + lane);
-      ti2[u].x = ti2[u].y = vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
-      if (ATK && v.nw == 1) {  // (the levels below 8, which only the attack's runs bring here: one masked word)
-        if (j == 0) {
-          ti2[u].x = ti[0] & v.mask;
-          vi2[u].x = vi[0] & v.mask;
-          la2[u].x = la[0] & v.mask;
-        }
-      } else if (wideRound && j < v.nw) {
-        ti2[u] = gld((const V2 WG_G*)(ti + j));
-        vi2[u] = gld((const V2 WG_G*)(vi + j));
-        la2[u] = gld((const V2 WG_G*)(la + j));
-      }
-    }
-    U4 pend;
-    pend.x = WG_READLANE(pg.x, 0);
-    pend.y = WG_READLANE(pg.y, 0);
-    pend.z = WG_READLANE(pg.z, 0);
-    pend.w = WG_READLANE(pg.w, 0);
-    const int window = (int)WG_READLANE(pg.y, 1);  // HH_WINDOW = word 5
-    const int curSize = (int)WG_READLANE(pg.y, 2), cLA = (int)WG_READLANE(pg.z, 2);
-    HQHead qh;
-    qh.len = (uint64_t)WG_READLANE(pg.x, 3) | ((uint64_t)WG_READLANE(pg.y, 3) << 32);
-    qh.used = (uint64_t)WG_READLANE(pg.z, 3) | ((uint64_t)WG_READLANE(pg.w, 3) << 32);
-    const int len = (int)qh.len;
-    const uint64_t myEnt = lane < len ? entAll : ~0ULL;
-    const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
-    const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
-    KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
-    const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
-    uint64_t blkM = 0;  // entries whose signer is blacklisted (:592 `!blacklist.get(stv.from)`)
-    if (ATK) {
-      // ---- createSuicideByzantineSig (:538-559, called by bestToVerify :577-584): the first byzantine (down), not yet
-      // blacklisted peer of the level from suicideBizAfter on whose rank is inside the window sends a bad signature over
-      // the whole block. The scan is the reference's loop, 64 peers a step.
-      const int sba = (int)*h_lv(s, node, HP_SPARE0, l);
-      if (sba >= 0 && len > 0) {
-        const int size = 1 << (l - 1);
-        const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
-        const int maxRank = windowIndex + window;
-        int firstCond = -1, hit = -1, hitRank = 0;
-        for (int i0 = sba; i0 < size && hit < 0; i0 += 64) {
-          const int i = i0 + lane;
-          const bool in = i < size;
-          const int32_t p = in ? h_peer(s, peers0 + i) : 0;
-          const bool cond = in && d.nodes.down[p] && !HandelProtoT<true>::blk(s, node, p);
-          const int32_t rk = cond ? s.ranks[(size_t)node * s.N + p] : 0;
-          const uint64_t cm = __ballot(cond);
-          if (firstCond < 0 && cm) firstCond = i0 + __ffsll((unsigned long long)cm) - 1;
-          const uint64_t hm = __ballot(cond && rk < maxRank);
-          if (hm) {
-            const int src = __ffsll((unsigned long long)hm) - 1;
-            hit = (int)lane_bcast((uint32_t)p, src);
-            hitRank = (int)lane_bcast((uint32_t)rk, src);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *h_lv(s, node, HP_SPARE0, l) = (uint32_t)firstCond;  // (-1: no byzantine nodes left in this level)
-        if (hit >= 0) {  // toVerifyAgg.add(bSig); sigQueueSize++; return bSig — no curation this time
-          const int qc = h_qcap(s, l);
-          const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
-          const unsigned long long freeM = ~qh.used & capMask;
-          if (freeM == 0 || len >= 64) {
-            if (lane == 0) set_err(d.g, ERR_QUEUE_CAP);
-            continue;
-          }
-          const int slot = __ffsll(freeM) - 1;
-          uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
-          H_FOR_WORDS(v, j) dst[j] = v.mask;  // sig = waitedSigs: the whole sibling block
-          __builtin_amdgcn_wave_barrier();
-          if (lane == 0) {
-            ent[len] = h_entry(hitRank, hit, slot);
-            HQHead nh;
-            nh.len = (uint64_t)(len + 1);
-            nh.used = qh.used | (1ULL << slot);
-            gst((HQHead WG_G*)qr, nh);
-            qr[H_QBAD] |= 1ULL << slot;
-            atomicAdd(F((uint32_t WG_G*)hdr + HH_SIGQ), 1u);
-            *h_lv(s, node, HP_CAND, l) = ((uint32_t)hit << 8) | (uint32_t)slot;
-            atomicOr(F(s.candMask + node), 1u << l);
-          }
-          continue;
-        }
-      }
-      const bool myBlk = lane < len && HandelProtoT<true>::blk(s, node, (int32_t)((myEnt >> 8) & 0xFFFFFFu));
-      blkM = __ballot(myBlk);
-    }
-    long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
-    int bestScore = 0, bestOutsideRank = 0;
-    uint64_t keep = 0;
-    for (int i0 = 0; i0 < len; i0 += 2) {  // two entries' signatures in flight at a time
-      V2 sg[2][2];
-      int slotU[2], rankU[2];
-      uint32_t whoU[2];
-#pragma unroll
-      for (int e2 = 0; e2 < 2; e2++) {
-        const int i = i0 + e2 < len ? i0 + e2 : len - 1;
-        whoU[e2] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
-        slotU[e2] = (int)(whoU[e2] & 0xFFu);
-        rankU[e2] = (int)lane_bcast((uint32_t)myRank, i);
-        const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int j = 2 * (u * 64 + lane);
-          sg[e2][u].x = sg[e2][u].y = 0;
-          if (ATK && v.nw == 1) {
-            if (j == 0 && i0 + e2 < len) sg[e2][u].x = sig[0];
-          } else if (wideRound && j < v.nw && i0 + e2 < len) {
-            sg[e2][u] = gld((const V2 WG_G*)(sig + j));
-          }
-        }
-      }
-#pragma unroll
-      for (int e2 = 0; e2 < 2; e2++) {
-        const int i = i0 + e2;
-        if (i >= len) break;
-        uint64_t a = 0, b = 0;
-        auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
-          a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
-          b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
-        };
-        if (wideRound) {
-#pragma unroll
-          for (int u = 0; u < 2; u++) {  // (words beyond the block are zero in every array: they add nothing)
-            word(sg[e2][u].x, ti2[u].x, vi2[u].x, la2[u].x);
-            word(sg[e2][u].y, ti2[u].y, vi2[u].y, la2[u].y);
-          }
-        } else {
-          const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
-          H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
-        }
-        a = wave_sum64(a);
-        b = wave_sum64(b);
-        const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
-        const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-        HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
-        if (ATK && ((blkM >> i) & 1ULL)) ev.keep = ev.inside = false;
-        if (ev.keep) {
-          keep |= 1ULL << i;
-          if (ev.inside) {
-            if (ev.score > bestScore) {
-              bestScore = ev.score;
-              bestInside = (long long)whoU[e2];
-            }
-          } else if (bestOutside < 0 || rankU[e2] < bestOutsideRank) {
-            bestOutside = (long long)whoU[e2];
-            bestOutsideRank = rankU[e2];
-          }
-        }
-      }
-    }
-    KPROF_ADD(d.g, 21, len);
-    KPROF_MARK(d.g, 22);  // the entries (kprof21: how many)
-    const int kept = __popcll(keep);
-    unsigned long long relMask = 0;
-    if (kept != len) {  // replaceToVerifyAgg :636-646
-      const int newPos = __popcll(keep & lanes_lt());
-      const bool mineKept = lane < len && ((keep >> lane) & 1ULL);
-      if (mineKept && newPos != lane) ent[newPos] = myEnt;
-      const uint32_t key = h_pend_word(l, mySlot);
-      const bool held = pend.x == key || pend.y == key || pend.z == key || pend.w == key;
-      const uint64_t rel = __ballot(lane < len && !mineKept && !held);
-      for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
-    KPROF_MARK(d.g, 23);  // list curation, candidate
+    h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
   }
 }
 
@@ -2039,6 +2048,119 @@ struct CondF {
     if (consumed != 1) d.g->rejectSeen = 1;
   }
 };
+
+// HiddenByzantine.attack (P/Handel.java:861-916), between the draw among the levels and the rest of checkSigs: for a node
+// whose drawn candidate is of the LAST level, the byzantine peer of best rank that is not in totalIncoming yet plants a
+// valid one-signer signature in that level's list if it outranks the candidate, and the level's bestToVerify runs again
+// (firstByzantine :844-858, the planted entry remembered in `last` until it is verified or pruned). One wavefront per
+// drawing node; k_handel_cond_a2 then reads the level's candidate as this kernel left it.
+__global__ void __launch_bounds__(256) k_handel_hidden(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const int lane = WG_LANE;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t n = d.g->nOut;
+  if (d.g->rejectSeen) {  // (the draws are re-walked by k_handel_cond_a2 only: p < 2^-30 per draw)
+    if (wave == 0 && lane == 0 && n) set_err(d.g, ERR_PROTOCOL);
+    return;
+  }
+  const int top = s.L - 1;
+  if (top < 1) return;
+  for (uint32_t j = wave; j < n; j += nWaves) {
+    const int32_t node = (int32_t)s.condList[j];
+    uint32_t cm = s.candMask[node];
+    for (int q = s.drawVal[node]; q > 0; q--) cm &= cm - 1;
+    if (__ffs(cm) - 1 != top) continue;  // :813 best.level == levels.size() - 1
+    uint32_t WG_G* h = h_hdr(s, node);
+    if (h[HH_HB_NOBYZ]) continue;
+    const uint32_t who = *h_lv(s, node, HP_CAND, top);  // currentBest: signer << 8 | slot
+    const uint32_t last = h[HH_HB_LAST];
+    __builtin_amdgcn_wave_barrier();
+    if (last && last - 1 == who) {  // a previous attack finally worked
+      if (lane == 0) h[HH_HB_LAST] = 0;
+      continue;
+    }
+    uint64_t WG_G* qr = h_qrec(s, node, top);
+    uint64_t WG_G* ent = qr + 2;
+    const int len = (int)qr[0];
+    const unsigned long long used = qr[1];
+    const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
+    const Lv v = sib_view(node, top);
+    const uint64_t WG_G* ti = h_row(s, node, HK_TI, top);
+    if (last) {
+      if (__ballot(lane < len && (uint32_t)myEnt == last - 1)) continue;  // still listed: nothing new
+      const int32_t lf = (int32_t)((last - 1) >> 8);
+      if (!((ld_coherent(ti + ((lf >> 6) - v.bw)) >> (lf & 63)) & 1ULL)) {
+        if (lane == 0) set_err(d.g, ERR_PROTOCOL);  // "byz signature pruned!"
+        continue;
+      }
+      if (lane == 0) h[HH_HB_LAST] = 0;
+    }
+    // firstByzantine: the down peer of the level with the smallest rank (the first of them in list order) not in totalIncoming
+    const int size = 1 << (top - 1);
+    const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
+    unsigned long long key = ~0ULL;
+    for (int i0 = 0; i0 < size; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < size) {
+        const int32_t p = h_peer(s, peers0 + i);
+        if (d.nodes.down[p] && !((ld_coherent(ti + ((p >> 6) - v.bw)) >> (p & 63)) & 1ULL)) {
+          const unsigned long long k2 = ((unsigned long long)(uint32_t)s.ranks[(size_t)node * s.N + p] << 32) | (uint32_t)i;
+          key = k2 < key ? k2 : key;
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = shfl64(key, lane ^ o);
+      key = other < key ? other : key;
+    }
+    key = lane_bcast64(key, 0);
+    if (key == ~0ULL) {
+      if (lane == 0) h[HH_HB_NOBYZ] = 1;
+      continue;
+    }
+    const int fbRank = (int)(uint32_t)(key >> 32);
+    const int32_t fb = h_peer(s, peers0 + (uint32_t)key);
+    const uint64_t hitM = __ballot(lane < len && (uint32_t)myEnt == who);
+    if (!hitM) {
+      if (lane == 0) set_err(d.g, ERR_PROTOCOL);
+      continue;
+    }
+    const int bestRank = (int)lane_bcast((uint32_t)(myEnt >> 32), __ffsll((unsigned long long)hitM) - 1);
+    if (fbRank >= bestRank) continue;  // we can't improve it, we're too far
+    const int qc = h_qcap(s, top);
+    const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
+    const unsigned long long freeM = ~used & capMask;
+    if (freeM == 0 || len >= 64) {
+      if (lane == 0) set_err(d.g, ERR_QUEUE_CAP);
+      continue;
+    }
+    const int slot = __ffsll(freeM) - 1;
+    uint64_t WG_G* dst = h_sig_ptr(s, node, top, slot);
+    H_FOR_WORDS(v, jw) dst[jw] = jw == (fb >> 6) - v.bw ? 1ULL << (fb & 63) : 0ULL;  // sig = { fb }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      ent[len] = h_entry(fbRank, fb, slot);
+      HQHead nh;
+      nh.len = (uint64_t)(len + 1);
+      nh.used = used | (1ULL << slot);
+      gst((HQHead WG_G*)qr, nh);
+      qr[H_QBAD] &= ~(1ULL << slot);  // badSig = false
+      atomicAdd(F(h + HH_SIGQ), 1u);
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    const long long newBest = h_best_wave<true>(d, s, node, top);  // SigToVerify newBest = l.bestToVerify()
+    const uint32_t planted = ((uint32_t)fb << 8) | (uint32_t)slot;
+    if (newBest < 0) {
+      if (lane == 0) set_err(d.g, ERR_PROTOCOL);  // (the reference dereferences null at :819)
+      continue;
+    }
+    if ((uint32_t)newBest != planted && lane == 0) h[HH_HB_LAST] = planted + 1;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 
 // A2: the rest of checkSigs (:816-836) for the drawn candidate, one lane per drawing node.
 // SH (sharded engine): a drawing node is handled by its owner, the task record goes to the exchange image.

@@ -45,9 +45,9 @@ class PingPong:
 
 
 class HandelParameters:
-    """P/Handel.java:97-142 (constructor argument order preserved). byzantineSuicide (:538-559, 577-584, 688-694) is
-    resident on the device; hiddenByzantine (:813-817, 840-917) and explicit badNodes are not — they run in host-callback
-    mode (examples/hostmode/handel.py on wittgenstein_amd.hostnet, checked against the oracle)."""
+    """P/Handel.java:97-142 (constructor argument order preserved). byzantineSuicide (:538-559, 577-584, 688-694) and
+    hiddenByzantine (:813-817, 840-917) are resident on the device; an explicit badNodes set is not — it runs in
+    host-callback mode (examples/hostmode/handel.py on wittgenstein_amd.hostnet, checked against the oracle)."""
 
     def __init__(self, nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath,
                  nodesDown, nodeBuilderName=None, networkLatencyName=None, desynchronizedStart=0,
@@ -55,11 +55,11 @@ class HandelParameters:
         if byzantineSuicide and hiddenByzantine:
             from .core import IllegalArgumentException
             raise IllegalArgumentException("Only one attack at a time")
-        if hiddenByzantine or badNodes is not None:
+        if badNodes is not None:
             from .core import UnsupportedError
-            raise UnsupportedError("hiddenByzantine / explicit badNodes are not resident on the device: run them in "
-                                   "host-callback mode (examples/hostmode/handel.py)")
-        self.byzantineSuicide = bool(byzantineSuicide)
+            raise UnsupportedError("an explicit badNodes set is not resident on the device: run it in host-callback mode "
+                                   "(examples/hostmode/handel.py)")
+        self.byzantineSuicide, self.hiddenByzantine = bool(byzantineSuicide), bool(hiddenByzantine)
         self.nodeCount, self.threshold, self.pairingTime, self.levelWaitTime = nodeCount, threshold, pairingTime, levelWaitTime
         self.extraCycle, self.disseminationPeriodMs, self.fastPath, self.nodesDown = extraCycle, disseminationPeriodMs, fastPath, nodesDown
         self.nodeBuilderName, self.networkLatencyName = nodeBuilderName, networkLatencyName
@@ -81,7 +81,7 @@ class Handel:
         p = self.params
         hp = L.wg_handel_params(p.nodeCount, p.threshold, p.pairingTime, p.levelWaitTime, p.extraCycle,
                                 p.disseminationPeriodMs, p.fastPath, p.nodesDown, p.desynchronizedStart, 0, 0, 0,
-                                int(p.byzantineSuicide), 0)
+                                int(p.byzantineSuicide), int(p.hiddenByzantine))
         h = C.c_void_p()
         cfg = _config(self.config)
         rc = L.lib().wgh_handel_create(C.byref(hp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
