@@ -192,7 +192,7 @@ typedef struct {
  *                                    :510-522 for every live sender: sort by the receivers' rank of the sender, shuffle equal
  *                                    ranks with rd) — rd must be where init() has it at that point (wg_rng_set_state before
  *                                    the load) and comes back advanced by the shuffles' draws; unsharded engines of up to
- *                                    65 536 nodes; WG_EHOSTINIT if a draw was rejected (then load again with host-built lists). */
+ *                                    131 072 nodes; WG_EHOSTINIT if a draw was rejected (then load again with host-built lists). */
 typedef struct {
   const int32_t* startAt;
   const int32_t* nodePairingTime;

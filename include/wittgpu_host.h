@@ -54,7 +54,7 @@ const char* wgh_last_error(void);
 /* seconds spent in the host-side init() of the last wgh_*_create on this thread */
 double wgh_last_init_seconds(void);
 /* 1 when the last wgh_handel_create on this thread left the emission lists (P/Handel.java:991-1013) to the device
- * (wg_handel_init_state.peers == NULL), 0 when the host built them (sharded, < 256 or > 65 536 nodes, WG_HOST_INIT=1, or the
+ * (wg_handel_init_state.peers == NULL), 0 when the host built them (sharded, < 256 or > 131 072 nodes, WG_HOST_INIT=1, or the
  * device answered WG_EHOSTINIT) */
 int32_t wgh_last_init_on_device(void);
 

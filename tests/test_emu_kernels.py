@@ -104,6 +104,11 @@ def test_handel_hidden_byzantine_resident():  # P/Handel.java:813-817, 840-917 o
     th.test_hidden_byzantine_resident((64, 50, 4, 50, 5, 20, 10, 6, 0), 2, 1)
 
 
+def test_handel_device_init_forms_of_big_networks(monkeypatch):
+    th.test_device_init_forms_of_more_than_65536_nodes(monkeypatch, 512, "1")
+    th.test_device_init_forms_of_more_than_65536_nodes(monkeypatch, 1024, "2")
+
+
 def test_handel_chunk_size_is_observable():
     th.test_chunk_size_is_observable_and_matches(7)
 

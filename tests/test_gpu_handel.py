@@ -74,6 +74,18 @@ def test_reception_ranks_shuffled_on_the_device(monkeypatch, capfd):
     assert (g.network().read_ranks() == want).all()
 
 
+@pytest.mark.parametrize("n,mode", [(512, "1"), (1024, "2")])
+def test_device_init_forms_of_more_than_65536_nodes(monkeypatch, n, mode):
+    """the forms init() takes on the device beyond 65 536 nodes — ids wider than 16 bits: the shuffled list in global memory
+    (k_handel_init_chain_big), the last level's emission list sorted by counting (k_handel_init_sort, `bigFrom`) — forced at
+    a size the oracle holds (WG_INIT_BIG; =2: histogram bins of four ranks, as at 131 072 nodes)"""
+    monkeypatch.setenv("WG_INIT_BIG", mode)
+    g, c = parity.handel_pair(ratios(n, dead=0.2), seed=int(mode))
+    assert g.init_on_device and not parity.diff_handel(g, c)
+    assert (g.network().read_ranks() == np.stack([c.read_ranks(i) for i in range(n)])).all()
+    lockstep(ratios(n, dead=0.2), step=10, max_ms=300, seed=int(mode))  # the first disseminations walk every list
+
+
 def test_emission_lists_fall_back_to_the_host(monkeypatch):
     """a rejected nextInt(bound) draw (java.util.Random's loop, probability about bound / 2^31 per draw) makes the draw count
     data dependent: the device reports it (WG_EHOSTINIT) and wgh_handel_create starts over with the host's sequential rd"""

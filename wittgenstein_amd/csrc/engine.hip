@@ -2327,6 +2327,7 @@ struct HandelHost : ProtoHost {
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
+    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 4;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
@@ -2391,6 +2392,8 @@ struct HandelHost : ProtoHost {
     (void)hipFree(dPair);
   }
   // The reception ranks on the device (P/Handel.java:966-989; see k_handel_init_scan). Leaves rd after the last shuffle.
+  // (tests: WG_INIT_BIG=1 the > 65 536-node forms at any size; =2 also histogram bins of four ranks, as 131 072 nodes have)
+  static int init_big() { return getenv("WG_INIT_BIG") ? atoi(getenv("WG_INIT_BIG")) : 0; }
   template <int E>
   void launch_chain(Engine& e, int threads, size_t lds, int B, uint16_t* net, uint16_t* starts) {
 #if !defined(WG_EMU)
@@ -2407,8 +2410,9 @@ struct HandelHost : ProtoHost {
   }
   void build_ranks(Engine& e) {
     const int32_t N = st.N;
-    if (e.shardCount > 0 || N > 65536 || N < 256)
-      throw WgError(WG_EINVAL, "device-built reception ranks: an unsharded engine of 256 .. 65 536 nodes (pass wg_handel_init_state.receptionRanks)");
+    if (e.shardCount > 0 || N > 131072 || N < 256)
+      throw WgError(WG_EINVAL, "device-built reception ranks: an unsharded engine of 256 .. 131 072 nodes (pass wg_handel_init_state.receptionRanks)");
+    const bool big = N > 65536 || init_big();  // (ids beyond 16 bits: the lists in global memory)
     const unsigned long long total0 = (unsigned long long)N * (N - 1);
     const unsigned long long expectRej = ((unsigned long long)N * N * N) >> 33, expectCand = ((unsigned long long)N * N * N) >> 31;
     const unsigned long long slack = 4 * expectRej + 65536;
@@ -2459,6 +2463,14 @@ struct HandelHost : ProtoHost {
     const size_t lds = 2 * (size_t)N;
     const int B = std::max(8, N / 256);  // nodes per chunk: 256 chunks from 2 048 nodes on
     uint16_t* dLists = nullptr;          // [2][N / B][N]: every chunk's net move, then the list it starts from
+    if (big) {                           // (32-bit ids; [2][N / B][N] more: the two buffers of every chunk's list)
+      const size_t C = (size_t)(N / B);
+      WG_HIP(hipMalloc((void**)&dLists, 4 * 4 * C * N));
+      uint32_t *net32 = (uint32_t*)dLists, *starts32 = net32 + C * N, *work = starts32 + C * N;
+      hipLaunchKernelGGL((k_handel_init_chain_big<false>), dim3((int)C), dim3(threads), 0, e.stream, st, B, net32, (const uint32_t*)starts32, work);
+      hipLaunchKernelGGL(k_handel_init_chain_starts_big, dim3(1), dim3(threads), 0, e.stream, N, (int)C, (const uint32_t*)net32, starts32, work);
+      hipLaunchKernelGGL((k_handel_init_chain_big<true>), dim3((int)C), dim3(threads), 0, e.stream, st, B, net32, (const uint32_t*)starts32, work);
+    } else {
     WG_HIP(hipMalloc((void**)&dLists, 2 * 2 * (size_t)(N / B) * N));
     uint16_t *net = dLists, *starts = dLists + (size_t)(N / B) * N;
     switch (N / threads) {
@@ -2469,6 +2481,7 @@ struct HandelHost : ProtoHost {
       case 16: launch_chain<16>(e, threads, lds, B, net, starts); break;
       case 32: launch_chain<32>(e, threads, lds, B, net, starts); break;
       default: launch_chain<64>(e, threads, lds, B, net, starts); break;
+    }
     }
     uint32_t bad = 0;
     const hipError_t rcBad = hipMemcpyAsync(&bad, dFlags + 1, 4, hipMemcpyDeviceToHost, e.stream);
@@ -2485,8 +2498,8 @@ struct HandelHost : ProtoHost {
   // rd advanced by the draws, as init() would.
   void build_peers(Engine& e) {
     const int32_t N = st.N;
-    if (e.shardCount > 0 || N > 65536)
-      throw WgError(WG_EINVAL, "device-built emission lists: an unsharded engine of at most 65 536 nodes (pass wg_handel_init_state.peers)");
+    if (e.shardCount > 0 || N > 131072)
+      throw WgError(WG_EINVAL, "device-built emission lists: an unsharded engine of at most 131 072 nodes (pass wg_handel_init_state.peers)");
     const size_t NL = (size_t)N * st.L;
     uint32_t* dCnt = nullptr;
     unsigned long long* dOffs = nullptr;
@@ -2503,13 +2516,26 @@ struct HandelHost : ProtoHost {
       }
     } guard{dCnt, dOffs, dRej};
     WG_HIP(hipMemsetAsync(dRej, 0, 4, e.stream));
-    const size_t lds = sizeof(uint32_t) * (size_t)std::max(2, N / 2);
+    // levels sorted by counting (k_handel_init_sort): the last one of more than 65 536 nodes — rank (17 bits) and offset (16)
+    // no longer pack into 32 bits and its block (256 KB of keys) no longer fits LDS; WG_INIT_BIG=1: the last level always
+    const int bigFrom = N > 65536 || init_big() ? st.L - 1 : st.L;
+    int shift = 0;
+    while ((N >> shift) > 32768) shift++;  // histogram bins: rank >> shift, at most 32 768 of them (128 KB)
+    if (init_big() >= 2) shift += 2;
+    const size_t ldsWords = bigFrom < st.L ? std::max((size_t)(N >> shift), (size_t)std::max(2, N / 4)) : (size_t)std::max(2, N / 2);
+    const size_t lds = sizeof(uint32_t) * ldsWords;
 #if !defined(WG_EMU)
     if (lds > 48 * 1024)
       WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
     const int grid = std::max(1, std::min(N, 2048 / WG_GRID_DIV));
-    hipLaunchKernelGGL(k_handel_init_sort, dim3(grid), dim3(1024), lds, e.stream, st, e.dev.nodes.down, dCnt);
+    unsigned long long* dPairs = nullptr;
+    if (bigFrom < st.L) WG_HIP(hipMalloc((void**)&dPairs, 8 * (size_t)grid * (size_t)(N / 2)));
+    struct FreePairs {
+      void* p;
+      ~FreePairs() { (void)hipFree(p); }
+    } guardPairs{dPairs};
+    hipLaunchKernelGGL(k_handel_init_sort, dim3(grid), dim3(1024), lds, e.stream, st, e.dev.nodes.down, dCnt, bigFrom, shift, dPairs);
     std::vector<uint32_t> cnt(NL);
     WG_HIP(hipMemcpyAsync(cnt.data(), dCnt, 4 * NL, hipMemcpyDeviceToHost, e.stream));
     WG_HIP(hipStreamSynchronize(e.stream));

@@ -259,7 +259,7 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
 static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
                              const wg_config* cfg, wg_engine** out, bool devicePeers);
 // Handel.init() (P/Handel.java:957-1014). The emission lists (:991-1013) are built on the device where the engine can
-// (unsharded, 256 .. 65 536 nodes: wg_handel_init_state.receptionRanks and .peers == NULL) together with the rank shuffles
+// (unsharded, 256 .. 131 072 nodes: wg_handel_init_state.receptionRanks and .peers == NULL) together with the rank shuffles
 // (:940-948, 966-989) and on the host otherwise — or after all, when
 // the device met a rejected draw (WG_EHOSTINIT); WG_HOST_INIT=1 keeps everything on the host.
 int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName,
@@ -267,7 +267,7 @@ int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderNam
   if (!out || !pp) return WG_EINVAL;
   const bool hostOnly = getenv("WG_HOST_INIT") && atoi(getenv("WG_HOST_INIT")) != 0;
   const bool sharded = cfg && cfg->nshards > 0;
-  if (!hostOnly && !sharded && pp->nodeCount >= 256 && pp->nodeCount <= 65536) {
+  if (!hostOnly && !sharded && pp->nodeCount >= 256 && pp->nodeCount <= 131072) {
     const int32_t rc = handel_create(pp, nodeBuilderName, latencyName, seed, cfg, out, true);
     if (rc != WG_EHOSTINIT) return rc;
   }

@@ -64,6 +64,7 @@ struct HandelState {
   // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
+  int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
   GP<const uint16_t> peers16;
@@ -1924,7 +1925,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
   const int lane = WG_LANE;
-  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x / 4 : 1;
+  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;  // (default 4/16)
   if (blockIdx.x < laneBlocks) {
     // ---------------- one lane per item: blocks of <= H_LANE_NW words ----------------
     const uint32_t nItems = s.itemCount[0];
@@ -2385,6 +2386,54 @@ __global__ void __launch_bounds__(1024) k_handel_init_chain_starts(int N, int C,
   }
 }
 
+// More than 65 536 nodes (or WG_INIT_BIG=1): ids no longer fit 16 bits and the list no longer fits LDS — the same three
+// launches with the list in global memory (two buffers a chunk: a step reads one and writes the other; every word a
+// thread reads was written by another thread of its workgroup before the barrier: L2-coherent loads)
+__device__ __forceinline__ uint32_t ld_coherent32(const uint32_t WG_G* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool ROWS>
+__global__ void __launch_bounds__(1024) k_handel_init_chain_big(HandelState s, int B, uint32_t* __restrict__ net,
+                                                                const uint32_t* __restrict__ starts, uint32_t* __restrict__ work) {
+  const int N = s.N, T = (int)blockDim.x, t = (int)threadIdx.x;
+  const int n0 = (int)blockIdx.x * B;
+  uint32_t* cur = work + (size_t)blockIdx.x * 2 * N;
+  uint32_t* nxt = cur + N;
+  for (int j = t; j < N; j += T) cur[j] = ROWS ? starts[(size_t)blockIdx.x * N + j] : (uint32_t)j;
+  __syncthreads();
+  for (int n = n0; n < n0 + B; n++) {
+    int32_t* row = s.ranks + (size_t)n * N;
+    for (int j = t; j < N; j += T) nxt[j] = ld_coherent32((const uint32_t WG_G*)cur + row[j]);
+    __syncthreads();  // (every read of the old list and of row n is done)
+    if (ROWS)
+      for (int j = t; j < N; j += T) row[nxt[j]] = j;  // (own words of the new list) receptionRanks[id at position j] = j
+    uint32_t* x = cur;
+    cur = nxt;
+    nxt = x;
+  }
+  if (!ROWS)
+    for (int j = t; j < N; j += T) net[(size_t)blockIdx.x * N + j] = cur[j];
+}
+__global__ void __launch_bounds__(1024) k_handel_init_chain_starts_big(int N, int C, const uint32_t* __restrict__ net,
+                                                                       uint32_t* __restrict__ starts, uint32_t* __restrict__ work) {
+  const int T = (int)blockDim.x, t = (int)threadIdx.x;
+  uint32_t* cur = work;
+  uint32_t* nxt = work + N;
+  for (int j = t; j < N; j += T) cur[j] = (uint32_t)j;
+  __syncthreads();
+  for (int c = 0; c < C; c++) {
+    for (int j = t; j < N; j += T) {
+      const uint32_t v = cur[j];  // (own word)
+      starts[(size_t)c * N + j] = v;
+      nxt[j] = ld_coherent32((const uint32_t WG_G*)cur + net[(size_t)c * N + j]);
+    }
+    __syncthreads();
+    uint32_t* x = cur;
+    cur = nxt;
+    nxt = x;
+  }
+}
+
 // ---- init() on the device: the emission lists (P/Handel.java:991-1013, buildEmissionList :510-522) -----------------
 // For sender s and level l the receivers are the sibling block of 2^(l-1) ids; they are bucketed by the RECEIVER's
 // receptionRanks[s], the buckets walked in rank order, a bucket of several receivers shuffled with the shared rd. The
@@ -2400,9 +2449,15 @@ __device__ __forceinline__ void h_peer_store(const HandelState& s, size_t idx, i
   else
     ((int32_t WG_G*)(const int32_t WG_G*)s.peers32)[idx] = v;
 }
-__global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const uint8_t* __restrict__ down, uint32_t* __restrict__ cnt) {
+// A level whose (rank, offset) no longer packs into 32 bits, or whose block no longer fits LDS (the last level of more
+// than 65 536 nodes; `bigFrom`: levels from that one on), is sorted by counting instead: LDS histogram over rank >> shift,
+// the elements scattered to `pairs` (global, [gridDim.x][N / 2] rank << 32 | offset) bin after bin, each bin — a few
+// elements — put in (rank, offset) order by its thread.
+__global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const uint8_t* __restrict__ down, uint32_t* __restrict__ cnt,
+                                                           int bigFrom, int shift, unsigned long long* __restrict__ pairs) {
   WG_DYN_LDS(uint32_t, key);  // [N / 2] (rank << idBits | offset in the block): unique, so any sort is the stable one
   __shared__ uint32_t shGroups;
+  __shared__ uint32_t shScan[16];
   const int N = s.N, L = s.L;
   for (int snd = blockIdx.x; snd < N; snd += gridDim.x) {
     if (down[snd]) {  // (a stopped node gets no levels' peers; its row stays as allocated and is never read)
@@ -2412,6 +2467,60 @@ __global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const 
     if (threadIdx.x == 0) cnt[(size_t)snd * L] = 0;
     for (int l = 1; l < L; l++) {
       const int m = 1 << (l - 1), base = ((snd >> (l - 1)) ^ 1) << (l - 1), idBits = l - 1;
+      if (l >= bigFrom) {
+        const int nbins = N >> shift, T = (int)blockDim.x, t = (int)threadIdx.x;
+        unsigned long long* out = pairs + (size_t)blockIdx.x * (size_t)(N / 2);
+        for (int b = t; b < nbins; b += T) key[b] = 0;
+        if (t == 0) shGroups = 0;
+        __syncthreads();
+        for (int k = t; k < m; k += T) atomicAdd(&key[(uint32_t)s.ranks[(size_t)(base + k) * N + snd] >> shift], 1u);
+        __syncthreads();
+        {  // exclusive prefix over the bins: thread t owns the bins [t * per, (t + 1) * per)
+          const int per = (nbins + T - 1) / T;
+          uint32_t sum = 0;
+          for (int b = t * per; b < (t + 1) * per && b < nbins; b++) sum += key[b];
+          uint32_t total;
+          uint32_t run = block_excl_scan32_1024(sum, shScan, &total);
+          for (int b = t * per; b < (t + 1) * per && b < nbins; b++) {
+            const uint32_t c0 = key[b];
+            key[b] = run;
+            run += c0;
+          }
+        }
+        __syncthreads();
+        for (int k = t; k < m; k += T) {
+          const uint32_t rk = (uint32_t)s.ranks[(size_t)(base + k) * N + snd];
+          out[atomicAdd(&key[rk >> shift], 1u)] = ((unsigned long long)rk << 32) | (uint32_t)k;
+        }
+        __threadfence();
+        __syncthreads();
+        for (int b = t; b < nbins; b += T) {  // key[b] is now the END of bin b
+          const uint32_t lo = b ? key[b - 1] : 0u, hi = key[b];
+          for (uint32_t i = lo + 1; i < hi; i++) {  // insertion sort (bins hold a few elements)
+            const unsigned long long x = ld_coherent((const uint64_t WG_G*)out + i);
+            uint32_t q = i;
+            while (q > lo && ld_coherent((const uint64_t WG_G*)out + (q - 1)) > x) {
+              out[q] = ld_coherent((const uint64_t WG_G*)out + (q - 1));
+              q--;
+            }
+            out[q] = x;
+          }
+        }
+        __threadfence();
+        __syncthreads();
+        uint32_t mineB = 0;
+        for (int pos = t; pos < m; pos += T) {
+          const unsigned long long kv = ld_coherent((const uint64_t WG_G*)out + pos);
+          h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(uint32_t)kv);
+          mineB += pos == 0 || (uint32_t)(kv >> 32) != (uint32_t)(ld_coherent((const uint64_t WG_G*)out + (pos - 1)) >> 32);
+        }
+        mineB = wave_reduce_add32(mineB);
+        if (WG_LANE == 0 && mineB) atomicAdd(&shGroups, mineB);
+        __syncthreads();
+        if (t == 0) cnt[(size_t)snd * L + l] = (uint32_t)m - shGroups;
+        __syncthreads();
+        continue;
+      }
       for (int k = threadIdx.x; k < m; k += blockDim.x)
         key[k] = ((uint32_t)s.ranks[(size_t)(base + k) * N + snd] << idBits) | (uint32_t)k;
       if (threadIdx.x == 0) shGroups = 0;
