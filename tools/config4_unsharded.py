@@ -17,9 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(n=131072, seed=0):
     import wittgenstein_amd as w
     NB, NL = "RANDOM_SPEED=CONSTANT_TOR=0.00", "NetworkLatencyByDistanceWJitter"
     down = int(n * 0.10)
@@ -67,6 +65,12 @@ def main():
            "runMs10_calls": steps, "time": net.time, "delivered": int(delivered),
            "delivered_msgs_per_s": delivered / run_s, "device_bytes": dev_bytes,
            "doneAt_max": int(done.max()), "checks": checks, "ok": all(checks.values())}
+    out["init_on_device"] = bool(g.init_on_device)
+    return out
+
+
+def main():
+    out = run(int(sys.argv[1]) if len(sys.argv) > 1 else 131072, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print(json.dumps(out), flush=True)
     sys.exit(0 if out["ok"] else 1)
 

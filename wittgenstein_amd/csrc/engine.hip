@@ -2443,10 +2443,10 @@ struct HandelHost : ProtoHost {
     std::vector<unsigned long long> offs((size_t)N + 1, 0);  // [n + 1] first: rejected draws of node n
     unsigned long long rej = 0;
     for (unsigned long long c : cand) {
-      const unsigned long long q = (c >> 31) - rej;  // the draw this stream position belongs to
+      const unsigned long long q = (c >> 20) - rej;  // the draw this stream position belongs to
       if (q >= total0) break;
       const int32_t bound = N - (int32_t)(q % (unsigned long long)(N - 1));
-      const int32_t m = bound - 1, u = (int32_t)(c & 0x7fffffffULL);
+      const int32_t m = bound - 1, u = (int32_t)(0x7FFFFFFFu - (uint32_t)(c & 0xFFFFFULL));
       if ((bound & m) == 0) continue;  // (a power of two: no loop, Random.nextInt)
       if ((int32_t)((uint32_t)u - (uint32_t)(u % bound) + (uint32_t)m) < 0) {
         rej++;

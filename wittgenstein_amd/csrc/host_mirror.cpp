@@ -423,7 +423,10 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   {
     const int32_t rc = wg_protocol_load(e, WG_PROTO_HANDEL, &p, &st);
-    if (rc == WG_EHOSTINIT) return rc;  // (the engine is destroyed by the guard; the caller starts over with host-built lists)
+    if (rc == WG_EHOSTINIT) {  // (the engine is destroyed by the guard; the caller starts over with host-built lists)
+      if (verbose) fprintf(stderr, "[wittgpu] handel init(): the device handed init() back to the host: %s\n", wg_last_error(e));
+      return rc;
+    }
     if (rc != WG_OK) {
       g_err = wg_last_error(e);
       return rc;

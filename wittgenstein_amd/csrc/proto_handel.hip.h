@@ -2285,7 +2285,7 @@ __global__ void __launch_bounds__(256) k_handel_init_scan(uint64_t rng0, unsigne
       const uint32_t bits = (uint32_t)(st >> 17);  // next(31)
       if (bits >= 0x80000000u - N) {
         const uint32_t i = atomicAdd(candCount, 1u);
-        if (i < cap) cand[i] = (pos << 31) | bits;
+        if (i < cap) cand[i] = (pos << 20) | (0x7FFFFFFFu - bits);  // (the distance from 2^31 - 1: below N <= 2^20; pos < 2^44)
       }
     }
   }
