@@ -2363,16 +2363,17 @@ struct HandelHost : ProtoHost {
       WG_HIP(hipMemcpy(dPeers32 + (size_t)lo * (N - 1), init.peers + (size_t)lo * (N - 1), 4 * nLoc * (N - 1),
                        hipMemcpyHostToDevice));
     }
-    st.ones = nullptr;
     st.snapIdx = nullptr;
     st.nSnap = nullptr;
     st.xsnap = nullptr;
     st.xsnapRows = 0;
-    if (e.shardCount > 0) {
+    {  // the all-ones block: the payload of a send whose totalOutgoing is complete (dissemination, fast path of a shard)
       std::vector<uint64_t> ones((size_t)W, ~0ULL);
-      uint64_t* dOnes = e.dalloc<uint64_t>(W, false);
+      uint64_t* dOnes = e.dalloc<uint64_t>(W, false, Engine::AC_CONST);
       WG_HIP(hipMemcpy(dOnes, ones.data(), 8 * (size_t)W, hipMemcpyHostToDevice));
       st.ones = dOnes;
+    }
+    if (e.shardCount > 0) {
       st.snapIdx = e.dalloc<uint32_t>(e.dev.maxEvents, false);
       st.nSnap = e.dalloc<uint32_t>(1);
       // every node disseminates once per period; a desynchronised start spreads them, a synchronised one puts all

@@ -597,7 +597,15 @@ struct HandelProtoT {
     // overlap (in the millisecond in which every node disseminates this copy is most of the pass's traffic).
     const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.disseminationPeriodMs) % s.snapNb;
     const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
-    const Lv tv = own_view(node, 63 - __clzll((unsigned long long)openM));
+    // A level whose totalOutgoing is COMPLETE (every id of its block: `below == mySize`) sends the constant all-ones block
+    // instead of a copy (the receiver masks it with its level's mask, as it does a snapshot): complete levels are the low
+    // ones (an incomplete block makes every block above it incomplete), so the copy is of the highest open INCOMPLETE
+    // level's block — none at all for a node that holds its whole half, which is every node for the last third of a run.
+    // Those messages' payload reads then hit 2 KB that never leave L2. (A sharded engine exchanges the snapshots: as before.)
+    const bool complete = !c.d.sharded && mySize != 0 && below == mySize;
+    const uint64_t copyM = __ballot(open && !complete);
+    Lv tv = own_view(node, copyM ? 63 - __clzll((unsigned long long)copyM) : 1);
+    if (!copyM) tv.nw = 0;
     // (two words a lane: the kernel is bound by its wave-level memory instructions. A pair of consecutive block words
     // sits side by side in one level's group — except the pair made of the node's own word and its level-7 sibling)
     V2 sv[2];
@@ -681,7 +689,8 @@ struct HandelProtoT {
       long long bytes = 0;
       for (uint64_t m = sendM; m; m &= m - 1) bytes += h_msg_size(__ffsll((unsigned long long)m) - 1);
       c.send_many((sendM >> lane) & 1ULL, __popcll(sendM & lanes_lt()), __popcll(sendM), cand,
-                  (uint32_t)lane | (lf ? 32u : 0u), refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
+                  (uint32_t)lane | (lf ? 32u : 0u),
+                  complete ? H_REF_ONES : refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
     }
     KPROF_MARK(c.d.g, 10);  // sends
   }
