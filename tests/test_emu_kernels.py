@@ -260,6 +260,10 @@ def test_casper_resident_random_on_ties():  # k_casper_mark / k_casper_seq: ties
     tcr.random_on_ties_cases(long=False)
 
 
+def test_casper_resident_two_blocks_in_one_ms():  # a delayed byzantine build in another producer's ms: k_casper_seq
+    tcr.two_blocks_in_one_ms_cases()
+
+
 def test_casper_resident_stopped_attesters():  # config 5's "+10 %" (SURVEY.md §8d): attesters stop()ped after init()
     tcr.lockstep((2, False, 2, 10, 100, 1), seed=7, chunk=1500, chunks=12, nl="NetworkFixedLatency(20)", stopped=2)
 

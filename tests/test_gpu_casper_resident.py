@@ -203,6 +203,21 @@ def test_random_on_ties_resident():
     random_on_ties_cases()
 
 
+def two_blocks_in_one_ms_cases():
+    """a byzantine producer delayed by exactly one slot builds in the ms of the next producer's periodic task (ByzBlockProducerWF
+    :635-692 with delay = SLOT_DURATION): two blocks in one simulated ms, ids in the order receiveUntil reaches their tasks.
+    The resident engine refused this until round 3 (ERR_SAME_MS_BLOCKS); such ms now go through k_casper_seq."""
+    for params, seed in (((3, False, 3, 8, 1000, 1), 9), ((2, True, 2, 6, 1000, 1), 4)):
+        g, c = lockstep(params, seed=seed, chunk=1000, chunks=60, byz_delay=8000, stopped=0)
+        ids = c.read("headId")
+        assert c.read("headHeight")[0] >= 4 and len(set(ids.tolist())) >= 1
+
+
+@pytest.mark.gpu
+def test_two_blocks_in_one_ms_resident():
+    two_blocks_in_one_ms_cases()
+
+
 @pytest.mark.gpu
 def test_random_on_ties_is_refused_on_a_sharded_engine():
     from wittgenstein_amd import shards

@@ -3222,10 +3222,13 @@ struct CasperHost : ProtoHost {
     st.attestsMask = e.dalloc<uint64_t>((size_t)st.B * st.Aw);
     st.attHead = e.dalloc<int32_t>(st.A);
     st.mixed = e.dalloc<uint8_t>(N);
-    if (p.randomOnTies) st.seqBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
+    // a delayed byzantine producer can build in another producer's ms: such ms go through k_casper_seq (CasperState::builds)
+    st.seqCapable = p.byzDelay != 0 && e.shardCount == 0 ? 1u : 0u;
+    if (p.randomOnTies || st.seqCapable) st.seqBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
     st.forked = e.dalloc<uint32_t>(1);
+    st.builds = e.dalloc<uint32_t>(1);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
-    if (p.randomOnTies) st.laneEvents = 1u;  // (k_casper_seq hands k_deliver an empty set through the mixed flags)
+    if (p.randomOnTies || st.seqCapable) st.laneEvents = 1u;  // (k_casper_seq hands k_deliver an empty set through the mixed flags)
     // sharded: the block / attestation table exchange and the two-blocks-in-one-ms check hang on k_casper_classify's
     // anyTask flag, which only the lane-per-event path launches — the A/B switch does not apply to a sharded engine
     if (e.shardCount > 0) st.laneEvents = 1u;
@@ -3254,7 +3257,8 @@ struct CasperHost : ProtoHost {
       // (a latency-bound pass of scattered atomics: as many wavefronts in flight as the chip holds)
       hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
-    if (st.p.randomOnTies) {  // a tie's nextBoolean() needs the global event order: one wavefront — once the chain has forked
+    if (st.seqCapable) hipLaunchKernelGGL(k_casper_builds, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    if (st.p.randomOnTies || st.seqCapable) {  // a tie's nextBoolean() needs the global event order: one wavefront — once the chain has forked
       // (CasperState::forked, read on the device: both return at once before that and k_deliver below does the visits;
       // after it k_casper_seq has cleared every mixed flag and k_deliver's visit_skip admits no node)
       hipLaunchKernelGGL(k_casper_mark, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
@@ -3265,6 +3269,7 @@ struct CasperHost : ProtoHost {
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
   bool unit_message_size() const override { return true; }  // blocks and attestations: Message.size() default 1
+  int variant() const override { return (int)st.seqCapable | (st.p.randomOnTies ? 2 : 0); }  // (they select launches)
   bool read_i64(Engine&, int32_t field, int64_t* dst, int32_t n) override {
     if (field < WG_F_CASPER_HEAD_HEIGHT || field > WG_F_CASPER_ATTESTATIONS_HELD) return false;
     if (n != st.N) throw WgError(WG_EINVAL, "n must be the node count");

@@ -60,6 +60,12 @@ struct CasperState {
   GP<int32_t> xtab;
   GP<uint32_t> anyTask;    // [1] this ms holds an event that is not an attestation (replicated: the exchange is due)
   GP<uint64_t> seqBits;    // randomOnTies: [maxEvents / 64] bit e = event e belongs to a mixed node (k_casper_mark -> k_casper_seq)
+  // two blocks in one ms (valid in the reference: a delayed byzantine build landing on another producer's slot): block ids
+  // are creation order, which two wavefronts of one launch do not have — in a run whose byzantine producer has a delay
+  // (`seqCapable`) k_casper_builds counts the events of the ms that can build a block (a producer's task; a block arriving at
+  // the byzantine producer, whose onBlock builds at once when it is late), and from two on the ms goes through k_casper_seq
+  GP<uint32_t> builds;     // [1] (reset by k_casper_seq)
+  uint32_t seqCapable;
   GP<uint32_t> forked;     // randomOnTies: [1] some block has two children. best() can reach its tie-break only between two
                            // branches, i.e. never before that: until then the parallel k_deliver is exact (no draw to order),
                            // from the next ms on k_casper_seq takes the mixed nodes
@@ -185,7 +191,8 @@ struct CasperProto {
       idx = (int32_t)atomicAdd(F(s.nBlocks + 0), 1u);
       // two blocks in one ms: valid in the reference (e.g. a delayed byzantine build landing on another producer's slot),
       // not resident — block ids are creation order and two wavefronts of one launch have none: its own error
-      if (atomicExch(F(s.lastBlockMs + 0), c.t) == c.t) set_err(c.d.g, ERR_SAME_MS_BLOCKS);
+      // (not under k_casper_seq: one wavefront in event order creates them in the reference's order)
+      if (atomicExch(F(s.lastBlockMs + 0), c.t) == c.t && !*s.forked && *s.builds < 2u) set_err(c.d.g, ERR_SAME_MS_BLOCKS);
       if (idx >= s.B || height <= 0 || c.t < ldi(s.bTime + base) || ldi(s.bHeight + base) >= height)
         set_err(c.d.g, idx >= s.B ? ERR_PAYLOAD : ERR_PROTOCOL);  // table full / Block's ctor checks :36-47
       if (idx >= s.B) idx = s.B - 1;
@@ -414,6 +421,28 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
   }
 }
 
+// events of this ms that can create a block (CasperState::builds): a task of a block producer (nodes 1 .. blockProducersCount;
+// BlockProducer.periodicTask :381-386, ByzBlockProducerWF.periodicTask :640-649 and its delayed build :667-676), and a
+// block arriving at the byzantine producer (node 1), whose onBlock builds on the spot when it is late (:671-673)
+__global__ void __launch_bounds__(256) k_casper_builds(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nEvents;
+  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+    const uint32_t e = e0 + WG_LANE;
+    bool b = false;
+    if (e < n) {
+      const Rec r = d.ev[e];
+      const int32_t to = (int32_t)r.w1;
+      const uint32_t k = rec_kind(r);
+      b = to >= 1 && to <= s.p.blockProducersCount &&
+          ((k == K_TASK || k == K_PERIODIC) || (k == K_MSG && to == 1 && r.w2 == C_MSG_BLOCK));
+    }
+    const uint64_t m = __ballot(b);
+    if (m && WG_LANE == 0) atomicAdd(F(s.builds + 0), (uint32_t)__popcll(m));
+  }
+}
+
 // randomOnTies (see the header): which events belong to a mixed node, one bit per event (64 consecutive events per
 // wavefront: one ballot, one store), then ONE wavefront delivers exactly those in global event order — receiveUntil's
 // own order (C/Network.java:594-635) — carrying the number of rd draws made so far in the ms, which is the index of a
@@ -421,7 +450,7 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
 __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
   const CasperState& s = stab[blockIdx.y];
-  if (!*s.forked) return;  // one chain so far: no tie-break can be reached, k_deliver takes the mixed nodes in parallel
+  if (!*s.forked && *s.builds < 2u) return;  // one chain so far: no tie-break can be reached, k_deliver takes the mixed nodes in parallel
   const uint32_t n = d.g->nEvents;
   for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
     const uint32_t e = e0 + WG_LANE;
@@ -437,7 +466,10 @@ __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict
 __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
   const CasperState& s = stab[blockIdx.y];
-  if (!*s.forked) return;
+  if (!*s.forked && *s.builds < 2u) {
+    if (WG_LANE == 0) *s.builds = 0;
+    return;
+  }
   __shared__ CasperProto::WaveShared shP;
   const uint32_t n = d.g->nEvents;
   const int32_t t = d.g->now;
@@ -481,6 +513,7 @@ __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__
       }
     }
   }
+  if (lane == 0) *s.builds = 0;
 }
 
 // sharded engine: the summed table image of this ms (CasperState::xtab) -> the block and the votes the other shards'
