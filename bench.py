@@ -693,16 +693,20 @@ def main():
     per_launch_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level_first))) / max(1, dk_spans)
     avg_ns = dk_ns / max(1, dk_spans)
     achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
-    traffic = None
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the rocprofv3 PMC passes
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
             traffic = tj.get("hbm_bytes_per_launch") * n_first / R
+            # the counters cannot be read inside the timed run (rocprofv3 serialises kernels): they come from PMC passes of
+            # the same command; tools/gpu_final_round.sh takes them in the session of the final line and stamps the commit
+            traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, commit %s%s" % (
+                tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_copy + k_handel_update + k_handel_wave (the delivery pass: "
                                                               "one launch of each per simulated ms)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
         "bytes_per_delivered_message": alg_bytes / max(1, delivered if world == 1 else int(by_level.sum())),
         "whole_run_achieved_GBs": alg_bytes / (max(elapsed, 1e-9) * 1e9),

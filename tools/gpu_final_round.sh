@@ -1,0 +1,43 @@
+#!/bin/bash
+# The evidence set of a round's final code, ONE GPU session: the two PMC passes of the bench command -> profiles/traffic.json
+# (stamped with the commit), then the whole GPU suite, smoke(), the driver's literal bench line (which reads that traffic.json),
+# the same command under rocprofv3 --kernel-trace --stats (kernel statistics + per-phase table) and the Casper delivery
+# pass's PMC passes -> profiles/traffic_casper.json.      WG_COMMIT=<hash> bash tools/gpu_final_round.sh <tag>
+set -u
+TAG=${1:-final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$(pwd)
+for f in wittgenstein_amd/csrc/*; do
+  if [ "$f" -nt wittgenstein_amd/libwittgpu.so ]; then echo "STALE libwittgpu.so: $f is newer"; exit 1; fi
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/p_$c -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second > $R/$OUT/pmc_$c.json 2> $R/$OUT/pmc_$c.err)
+  echo "pmc $c rc=$?"
+  python tools/prof_summary.py pmc $OUT/p_$c $OUT/pmc_$c.md && rm -rf $OUT/p_$c
+done
+python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_copy,k_handel_update<,k_handel_wave<" > /dev/null
+cp $OUT/traffic.json profiles/traffic.json; export WG_TRAFFIC_SESSION=1
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/pc_$c -o k --output-format csv -- python $R/bench.py --workload casper --casper-stopped 0.1 --steps 1 --warmup 0 --no-cpu > $R/$OUT/pmc_casper_$c.json 2> $R/$OUT/pmc_casper_$c.err)
+  echo "pmc casper $c rc=$?"
+  python tools/prof_summary.py pmc $OUT/pc_$c $OUT/pmc_casper_$c.md && rm -rf $OUT/pc_$c
+done
+python tools/traffic_from_pmc.py $OUT/pmc_casper_FETCH_SIZE.md $OUT/pmc_casper_WRITE_SIZE.md 262150 1 $OUT/traffic_casper.json "k_casper_classify,k_casper_attestations,k_deliver<CasperProto" > /dev/null
+python - $OUT/traffic_casper.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); d["stopped_fraction"] = 0.1
+json.dump(d, open(sys.argv[1], "w"), indent=1)
+PY
+cp $OUT/traffic_casper.json profiles/traffic_casper.json
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_argv.json 2> $OUT/bench_driver_argv.err; echo "bench rc=$?"; tail -3 $OUT/bench_driver_argv.err
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/p -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)
+python tools/prof_summary.py stats $OUT/p $OUT/kernel_stats.md; python tools/prof_summary.py phases $OUT/p $OUT/phases.md; rm -rf $OUT/p
+python - $OUT/bench_driver_argv.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d["roofline"]
+print("value %.1f M msgs/s  ms_per_step %.1f  delivery pass %.1f us  frac %.4f  traffic %.1f MB (algorithmic %.1f MB)" % (
+    d["value"] / 1e6, d["ms_per_step"], r["avg_launch_us"], r["frac"], (r["traffic"] or 0) / 1e6, r["algorithmic_bytes_per_launch"] / 1e6))
+print(r.get("traffic_source")); print("cpu_baseline", d.get("cpu_baseline", {}).get("value"), "second", (d.get("second_workload") or {}).get("value"))
+PY
+head -12 $OUT/kernel_stats.md

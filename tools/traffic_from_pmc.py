@@ -37,7 +37,8 @@ def main():
     w = per_dispatch(write, "WRITE_SIZE", kernels)
     rd = sum(f.values()) * 1024.0
     wr = sum(w.values()) * 1024.0
-    json.dump({"nodes": nodes, "replicas": replicas,
+    import os
+    json.dump({"nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"),
                "kernels": ("k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (one launch of each per simulated ms)"
                            if len(sys.argv) <= 6 else " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)"),
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
