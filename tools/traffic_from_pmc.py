@@ -4,7 +4,7 @@
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch. MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE =
 TCC_EA0_RDREQ x 64 B and undercounts 128-byte requests by half (calibrated on wide coalesced reads); other widths and
 WRITE_SIZE are "uncalibrated: calibrate on a known byte count in your own access pattern". That calibration is
-tools/micro/pmc_calib.hip (profiles/r02b_pmc_calib.txt), for the access shapes of the delivery kernels:
+tools/micro/pmc_calib.hip (profiles/archive/r02b_pmc_calib.txt), for the access shapes of the delivery kernels:
   reads   one 64-byte line per request (8 lanes x 8 B, or 4 lanes x 16 B): FETCH_SIZE == bytes (x1.00);
           a lane alone in its line (8 or 16 B used): 64 B counted per lane (the line is fetched);
           wide coalesced 16 B/lane streams: x0.50 (the guide's case)
@@ -45,7 +45,7 @@ def main():
                "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,
                "per_kernel_KB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per dispatch means over the run; "
-                       "calibrated on known byte counts in these access shapes (profiles/r02b_pmc_calib.txt): scattered "
+                       "calibrated on known byte counts in these access shapes (profiles/archive/r02b_pmc_calib.txt): scattered "
                        "64-byte-line reads and full-line writes count x1.00, a lane alone in its line counts the 64-byte "
                        "line (read) / a 32-byte granule (write); the guide's x2 (128-byte requests) is kept as "
                        "..._reads_doubled, an upper bound"},
