@@ -150,7 +150,10 @@ def cpu_baseline(n_sample, workload="handel"):
     # the only parallelism the reference admits (C/RunMultipleTimes.java:44-48): independent seeds, one per core
     try:
         avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
-        cores = max(1, min(len(os.sched_getaffinity(0)), int(0.5 * avail / (16.0 * n_sample * n_sample + (1 << 28)))))  # every host core, memory permitting
+        # every host core, memory permitting — and bounded: one oracle copy of n nodes holds ~ 64 n^2 bytes at its peak (ranks,
+        # emission lists as pointers, seven N-bit sets per level and node, the in-flight messages' clones: 18 GB at 16 384
+        # nodes); 256 of them took a 3 TB box down. A quarter of what is available, 64 copies at most
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64, int(0.25 * avail / (64.0 * n_sample * n_sample + (1 << 30)))))
     except Exception:
         cores = 1
     if cores > 1:

@@ -2237,6 +2237,7 @@ struct HandelHost : ProtoHost {
   int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
   int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;  // (k_handel_a1: 110 VGPRs, no scratch; five waves spill)
   int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
+  int wavesDissem = getenv("WG_DISSEM_WAVES") ? atoi(getenv("WG_DISSEM_WAVES")) : 8;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const auto tCtor = std::chrono::steady_clock::now();
     const int32_t N = p.nodeCount;
@@ -2326,6 +2327,9 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
+    st.itemsDis = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
+    st.disCount = e.dalloc<uint32_t>(1);
+    st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
     st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 4;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
@@ -2683,6 +2687,14 @@ struct HandelHost : ProtoHost {
       default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     const dim3 grid(node_grid(g.R), g.R);
+    if (st.disTier && !st.atk) {  // nodes whose first event is their dissemination (appends the rest of their visit to the wave list)
+      switch (wavesDissem) {
+        case 4: hipLaunchKernelGGL(k_handel_dissem<4>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+        case 5: hipLaunchKernelGGL(k_handel_dissem<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+        case 6: hipLaunchKernelGGL(k_handel_dissem<6>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
+        default: hipLaunchKernelGGL(k_handel_dissem<8>, grid, dim3(256), 0, g.stream, g.tab, stab);
+      }
+    }
     if (st.atk) {
       hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab);
       return;

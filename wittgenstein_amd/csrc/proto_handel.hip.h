@@ -114,6 +114,12 @@ struct HandelState {
   // vflags}, applied by k_handel_update one wavefront each (the node's SendSigs before them by k_handel_lane)
   GP<U4> itemsUpd;                        // [N]
   GP<uint32_t> updCount;                  // [1] (reset with jobCount)
+  // nodes whose FIRST event of the ms is their dissemination task: {node, vflags << 8 | events, event, its inbox word 0},
+  // applied by k_handel_dissem one wavefront each (the lean kernel of the millisecond in which every node disseminates);
+  // the node's later events follow in k_handel_wave (skip = 1)
+  GP<U4> itemsDis;                        // [N]
+  GP<uint32_t> disCount;                  // [1] (reset with jobCount)
+  int32_t disTier;                        // 0: off (WG_DIS_TIER=0): those nodes are visits of k_handel_wave as before
   GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> condList;                  // drawing nodes in id order
@@ -1118,6 +1124,26 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     // updateVerifiedSignatures — of a narrow level (applied here), or of a wide level as the node's LAST event (handed to
     // k_handel_update: the deliveries before it are this lane's); else a wavefront of k_handel_wave
     bool mine = have && cnt <= (uint32_t)INBOX_SLOTS && !s.atk;  // (byzantineSuicide: every visit by k_handel_wave)
+    // the node's first event is its dissemination: the lean kernel takes that event, k_handel_wave the rest
+    const bool disFirst = mine && s.disTier && ((E[0].w0 >> 28) & 3u) == K_PERIODIC && E[0].w2 == H_TASK_DISSEMINATION;
+    if (disFirst) mine = false;
+    {
+      const uint64_t m = __ballot(disFirst);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(s.disCount + 0), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (disFirst) {
+          U4 q;
+          q.x = (uint32_t)node;
+          q.y = (vflags << 8) | cnt;
+          q.z = E[0].e;
+          q.w = E[0].w0;
+          gst((U4 WG_G*)s.itemsDis + (bb + __popcll(m & lanes_lt())), q);
+        }
+      }
+    }
     int nUpd = 0, wideAt = -1;
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) {
@@ -1141,7 +1167,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     }
     if (nUpd > 1) mine = false;
     {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
-      const bool toB = have && !mine;
+      const bool toB = have && !mine && !disFirst;
       const uint64_t m = __ballot(toB);
       if (m) {
         uint32_t bb = 0;
@@ -1552,6 +1578,64 @@ __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict
 // Software-pipelined: while item a runs, the header and the inbox line of item a + nWaves and the descriptor of item
 // a + 2 nWaves are in flight. A visit writes no other node's header (effects on other nodes travel as envelopes, at
 // least one ms later), so fetching the next header early reads what the visit itself would.
+// The delivery pass, dissemination tier: one wavefront per node whose first event of the ms is its dissemination task
+// (P/Handel.java:331-343) — in a run with a synchronised start that is every live node once per period, 3/4 of a ms that
+// costs three ordinary ones. Only that event: a kernel that holds nothing of updateVerifiedSignatures / onNewSig fits twice
+// the wavefronts of k_handel_wave. The node's later events of the ms (SendSigs that were sent before the task was
+// re-armed) become a visit of k_handel_wave that skips the first event.
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  __shared__ LevelScalars shP[4];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nItems = *s.disCount;
+  const int32_t t = d.g->now;
+  U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;
+  for (uint32_t a = wave; a < nItems; a += nWaves) {
+    const U4 it = gld((const U4 WG_G*)s.itemsDis + a);
+    const int32_t node = (int32_t)WG_READFIRST(it.x);
+    const uint32_t vflags = WG_READFIRST(it.y) >> 8, cnt = WG_READFIRST(it.y) & 0xFFu;
+    const uint32_t e = WG_READFIRST(it.z), w0 = WG_READFIRST(it.w);
+    const HandelProto::Pre hdr = HandelProto::prefetch(s, node);
+    Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+    HandelProto::NodeRegs r;
+    HandelProto::node_begin_pre(c, s, r, &shP[w], hdr);
+    c.ev = e;
+    c.sub = 0;
+    c.draws = 0;
+    c.outBase = w0 & 0x0FFFFFFFu;
+    c.outCap = d.boundTask[0] + 1u;
+    uint32_t flags = 0;
+    if (!(vflags & VD_DOWN)) {  // (C/Network.java:606: a task's `from` is its own node)
+      flags = EV_TASK_RUN;
+      HandelProto::dissemination(c, s, r);
+      // PeriodicTask.action re-arm (C/messages/PeriodicTask.java:39-47)
+      c.put(O_PERIODIC, node, H_TASK_DISSEMINATION, (uint32_t)s.p.disseminationPeriodMs, t + s.p.disseminationPeriodMs, 0, false);
+    }
+    if (lane == 0) {
+      EvRes res;
+      res.nrec = c.sub | flags;
+      res.ndraw = c.draws;
+      gst(d.evRes + e, res);
+    }
+    HandelProto::node_counters(c, s, r, 0, 0);
+    HandelProto::node_end(c, s, r);
+    if (cnt > 1u && lane == 0) {  // the rest of the node's events: a visit of k_handel_wave from the second event on
+      const uint32_t bb = atomicAdd(F(&d.g->nActiveB), 1u);
+      U4 q;
+      q.x = (uint32_t)node;
+      q.y = HW_VISIT | (vflags << 8);
+      q.z = cnt;
+      q.w = 1u;
+      gst(work + bb, q);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -1640,6 +1724,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the delivery pass's copy jobs and wide updates have been done)
     *s.jobCount = 0;
     *s.updCount = 0;
+    *s.disCount = 0;
   }
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
