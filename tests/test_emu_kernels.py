@@ -100,6 +100,11 @@ def test_handel_byzantine_suicide_resident():  # P/Handel.java:538-559, 577-584,
     th.test_attack_parameter_checks()
 
 
+def test_handel_attack_scenarios_wide_levels():
+    th.test_attack_scenarios_resident_wide_levels(1024, "byzantine_suicide", 300)
+    th.test_attack_scenarios_resident_wide_levels(1024, "hidden_byzantine", 400)
+
+
 def test_handel_hidden_byzantine_resident():  # P/Handel.java:813-817, 840-917 on the device vs the oracle
     th.test_hidden_byzantine_resident((64, 50, 4, 50, 5, 20, 10, 6, 0), 2, 1)
 

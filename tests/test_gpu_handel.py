@@ -174,6 +174,15 @@ def test_hidden_byzantine_resident(params, seed, step):
     assert int(c.read("sigsChecked").sum()) != int(honest.read("sigsChecked").sum())  # the attack changed the run
 
 
+@pytest.mark.parametrize("n,mode,max_ms", [(1024, "byzantine_suicide", 500), (1024, "hidden_byzantine", 700),
+                                           (2048, "byzantine_suicide", 400), (4096, "hidden_byzantine", 300)])
+def test_attack_scenarios_resident_wide_levels(n, mode, max_ms):
+    """both attacks at sizes whose upper levels are wide (blocks of 2 … 32 words: the two-words-a-lane paths of
+    h_best_wave<true>, emission lists of more than 64 peers in createSuicideByzantineSig / firstByzantine), 25 % of the nodes
+    byzantine, in lock-step with the oracle for the first hundreds of ms (the attacks start with the first checkSigs)"""
+    lockstep(ratios(n, dead=0.25), step=10, max_ms=max_ms, seed=3, **{mode: True})
+
+
 def test_attack_parameter_checks():
     with pytest.raises(w.IllegalArgumentException):  # "Only one attack at a time" :123-125
         w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, byzantineSuicide=True, hiddenByzantine=True)
