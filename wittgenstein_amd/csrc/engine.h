@@ -336,6 +336,7 @@ struct EngineDev {
   // where action() code parks the (unsorted) destination list of a multi-destination send until `resolve`:
   // the envelope ring itself, or — sharded, where that ring is replicated state — a private scratch ring
   GP<int32_t> sdests;
+  GP<int32_t> arvTmp;  // [sdestCap] arrivals of the list being sorted at the same entries of sdests (resolve_multi)
   unsigned long long sdestCap;
   // Network.sendAll issued by an action() (O_SENDALL): every node is a destination, so the envelope is resolved by
   // k_sendall_* after `resolve` (one descriptor per call, latency scratch and tile histograms per descriptor);

@@ -625,6 +625,7 @@ void Engine::ensure_device() {
   dev.multiK = dev.multiOff = nullptr;
   dev.sdests = dev.dests;
   dev.sdestCap = dev.chainDests;
+  dev.arvTmp = dalloc<int32_t>(chainDests, false, AC_SCRATCH);
   if (shardCount > 0) {
     dev.shardLo = (int32_t)((int64_t)n * shardIndex / shardCount);
     dev.shardHi = (int32_t)((int64_t)n * (shardIndex + 1) / shardCount);

@@ -638,23 +638,45 @@ constexpr int TILE = 1024;
 
 // createMessageArrivals of a device-side multi-destination send (delaysBetweenMessage == 0): arrivals of the
 // destinations that are reachable, stable-sorted by arrival (C/Network.java:449-467). Returns their number.
-__device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t* dst,
-                                             int32_t* arv) {
+// IN PLACE: the unsorted list lies in the scratch destination ring at o.destOff (EngineDev::sdests — on an unsharded
+// engine the chain ring itself); the sorted destinations end up in the same entries [0, m), their arrivals in the same
+// entries of the parallel ring EngineDev::arvTmp. Entry j is read before anything at or beyond j is written (the sorted
+// prefix is never longer than the entries consumed), so no copy of the list is needed — and no per-lane array, which the
+// compiler could only have kept in scratch memory (528 bytes a lane until round 3).
+__device__ __forceinline__ unsigned long long multi_idx(const EngineDev& d, const Out& o, int k) {
+  return (o.destOff + (unsigned long long)k) % d.sdestCap;
+}
+__device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed) {
   const int nd = o.to;
   const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;  // sendTime += delay + 1 per destination (:459)
   int m = 0;
   for (int j = 0; j < nd && j < 64; j++) {
-    int32_t to = d.sdests[(o.destOff + (unsigned long long)j) % d.sdestCap];
+    const int32_t to = d.sdests[multi_idx(d, o, j)];
     int32_t a;
     if (!arrival_of_send(d, from, to, o.t + j * step, seed, a)) continue;
     int k = m++;
-    while (k > 0 && arv[k - 1] > a) {  // insertion keeps equal arrivals in caller order
-      arv[k] = arv[k - 1];
-      dst[k] = dst[k - 1];
+    while (k > 0 && d.arvTmp[multi_idx(d, o, k - 1)] > a) {  // insertion keeps equal arrivals in caller order
+      d.arvTmp[multi_idx(d, o, k)] = d.arvTmp[multi_idx(d, o, k - 1)];
+      d.sdests[multi_idx(d, o, k)] = d.sdests[multi_idx(d, o, k - 1)];
       k--;
     }
-    arv[k] = a;
-    dst[k] = to;
+    d.arvTmp[multi_idx(d, o, k)] = a;
+    d.sdests[multi_idx(d, o, k)] = to;
+  }
+  return m;
+}
+// ... only how many are reachable and the first arrival (a shard's k_resolve: the envelope itself is created from the
+// exchanged image, k_shard_multi_fill sorts the list)
+__device__ __forceinline__ int count_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t& first) {
+  const int nd = o.to;
+  const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
+  int m = 0;
+  first = INT32_MAX;
+  for (int j = 0; j < nd && j < 64; j++) {
+    int32_t a;
+    if (!arrival_of_send(d, from, d.sdests[multi_idx(d, o, j)], o.t + j * step, seed, a)) continue;
+    m++;
+    first = a < first ? a : first;
   }
   return m;
 }
@@ -728,17 +750,28 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         uint32_t drawIdx = d.evDrawOff[e] + o.drawsub;
         if (o.pad & OUT_SHUFFLE) drawIdx += shuffle_dests(d, o, drawIdx);  // Collections.shuffle(dests, rd) first
         int32_t seed = draw_next_int(d, drawIdx);
-        int32_t dst[64], arv[64];
-        const int m = resolve_multi(d, o, from, seed, dst, arv);
-        if (m == 1) {
-          fin = make_rec(K_MSG, from, (uint32_t)dst[0], o.a, o.b);
-          arrival = arv[0];
+        int32_t first = 0;
+        const int m = SH ? count_multi(d, o, from, seed, first) : resolve_multi(d, o, from, seed);
+        if (m == 1 && !SH) {
+          fin = make_rec(K_MSG, from, (uint32_t)d.sdests[multi_idx(d, o, 0)], o.a, o.b);
+          arrival = d.arvTmp[multi_idx(d, o, 0)];
+        } else if (m == 1) {  // (the one reachable destination: found again, the list is left as it is)
+          const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
+          for (int j = 0; j < o.to && j < 64; j++) {
+            int32_t a;
+            const int32_t to = d.sdests[multi_idx(d, o, j)];
+            if (arrival_of_send(d, from, to, o.t + j * step, seed, a)) {
+              fin = make_rec(K_MSG, from, (uint32_t)to, o.a, o.b);
+              arrival = a;
+              break;
+            }
+          }
         } else if (m > 1 && SH) {
           // the envelope (slot, sorted destinations, explicit arrivals if any) is replicated state: it is created on every
           // shard from the exchanged image by k_shard_multi_fill / k_shard_multi_create; here only its place in the push
           // order (w1 = the entries it takes in the destination ring: MultiF sums them)
           fin = make_rec(K_CHAIN, from, (uint32_t)((o.pad & OUT_DELAYED) ? 2 * m : m), 0, MULTI_FRESH);
-          arrival = arv[0];
+          arrival = first;
           atomicAdd(&d.xbuf[-XB_HEAD], 1);  // header word of the exchange image: envelopes to create (rare)
         } else if (m > 1) {
           uint32_t slot = atomicAdd(&d.g->chainHead, 1u) % d.chainSlots;
@@ -746,9 +779,9 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
             set_err(d.g, ERR_CHAIN_SLOTS);
             break;
           }
-          for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)j) % d.chainDests] = dst[j];
+          // (unsharded: sdests IS the chain ring — the sorted destinations are where the envelope reads them)
           if (o.pad & OUT_DELAYED)  // explicit arrivals follow the destinations (the action reserved 2 n entries)
-            for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)(m + j)) % d.chainDests] = arv[j];
+            for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)(m + j)) % d.chainDests] = d.arvTmp[multi_idx(d, o, j)];
           Chain c;
           c.from = from;
           c.seed = seed;
@@ -760,7 +793,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           c.flags = 1u | ((o.pad & OUT_DELAYED) ? 2u : 0u);
           d.chains[slot] = c;
           fin = make_rec(K_CHAIN, from, slot, 0, 0);
-          arrival = arv[0];
+          arrival = d.arvTmp[multi_idx(d, o, 0)];
         }
         break;
       }
@@ -921,8 +954,7 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
     // (a shuffled list was permuted in the scratch ring by k_resolve<true> already; its draws precede the seed)
     const uint32_t shuffled = (o.pad & OUT_SHUFFLE) && o.to > 1 ? (uint32_t)((o.to < 64 ? o.to : 64) - 1) : 0u;
     const int32_t seed = draw_next_int(d, d.evDrawOff[e] + o.drawsub + shuffled);
-    int32_t dst[64], arv[64];
-    const int m = resolve_multi(d, o, from, seed, dst, arv);
+    const int m = resolve_multi(d, o, from, seed);  // (in the shard's private list ring)
     int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
     x[0] = seed;
     x[1] = o.t;
@@ -930,9 +962,9 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
     x[3] = (int32_t)o.b;
     x[4] = m;
     x[5] = (o.pad & OUT_DELAYED) ? 1 : 0;
-    for (int j = 0; j < m; j++) x[6 + j] = dst[j];
+    for (int j = 0; j < m; j++) x[6 + j] = d.sdests[multi_idx(d, o, j)];
     if (o.pad & OUT_DELAYED)  // MultipleDestWithDelayEnvelope: explicit arrivals (C/Network.java:449-467)
-      for (int j = 0; j < m; j++) x[6 + 64 + j] = arv[j];
+      for (int j = 0; j < m; j++) x[6 + 64 + j] = d.arvTmp[multi_idx(d, o, j)];
   }
 }
 
