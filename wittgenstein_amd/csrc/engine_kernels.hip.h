@@ -665,6 +665,34 @@ __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, i
   }
   return m;
 }
+// Lists of up to MULTI_LDS destinations (Handel's fast path and GSFSignature's accelerated calls send 10) are sorted in LDS
+// instead — entry k of thread t at sh[k][t]: no bank conflicts, no memory round trip per insertion step — and written to
+// the same entries of the two rings at the end; longer lists take the in-place form above.
+constexpr int MULTI_LDS = 10;  // (20 KB a block: eight blocks a CU still fit)
+__device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t* shDst,
+                                                 int32_t* shArv) {
+  const int nd = o.to, T = (int)blockDim.x, t = (int)threadIdx.x;
+  const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
+  int m = 0;
+  for (int j = 0; j < nd; j++) {
+    const int32_t to = d.sdests[multi_idx(d, o, j)];
+    int32_t a;
+    if (!arrival_of_send(d, from, to, o.t + j * step, seed, a)) continue;
+    int k = m++;
+    while (k > 0 && shArv[(k - 1) * T + t] > a) {
+      shArv[k * T + t] = shArv[(k - 1) * T + t];
+      shDst[k * T + t] = shDst[(k - 1) * T + t];
+      k--;
+    }
+    shArv[k * T + t] = a;
+    shDst[k * T + t] = to;
+  }
+  for (int k = 0; k < m; k++) {
+    d.sdests[multi_idx(d, o, k)] = shDst[k * T + t];
+    d.arvTmp[multi_idx(d, o, k)] = shArv[k * T + t];
+  }
+  return m;
+}
 // ... only how many are reachable and the first arrival (a shard's k_resolve: the envelope itself is created from the
 // exchanged image, k_shard_multi_fill sorts the list)
 __device__ __forceinline__ int count_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t& first) {
@@ -724,6 +752,7 @@ __device__ __forceinline__ bool park_far(const EngineDev& d, int32_t t, uint32_t
 // across shards before k_shard_unpack rebuilds fin / arr / the tile histograms on every shard.
 template <bool SH>
 __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ tab) {
+  __shared__ int32_t shMulti[2][MULTI_LDS][256];  // resolve_multi_lds: destinations / arrivals being sorted, [entry][thread]
   WG_ENGINE(tab);
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
@@ -751,7 +780,9 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         if (o.pad & OUT_SHUFFLE) drawIdx += shuffle_dests(d, o, drawIdx);  // Collections.shuffle(dests, rd) first
         int32_t seed = draw_next_int(d, drawIdx);
         int32_t first = 0;
-        const int m = SH ? count_multi(d, o, from, seed, first) : resolve_multi(d, o, from, seed);
+        const int m = SH ? count_multi(d, o, from, seed, first)
+                         : (o.to <= MULTI_LDS ? resolve_multi_lds(d, o, from, seed, &shMulti[0][0][0], &shMulti[1][0][0])
+                                              : resolve_multi(d, o, from, seed));
         if (m == 1 && !SH) {
           fin = make_rec(K_MSG, from, (uint32_t)d.sdests[multi_idx(d, o, 0)], o.a, o.b);
           arrival = d.arvTmp[multi_idx(d, o, 0)];
