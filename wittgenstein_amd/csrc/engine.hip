@@ -154,6 +154,7 @@ Engine::~Engine() {
   delete proto;
   if (rcclComm) (void)rccl().CommDestroy(rcclComm);
   if (mailbox) (void)hipHostFree((void*)mailbox);
+  if (sentBuf) (void)hipFree(sentBuf);
   if (snap) {
     if (snap->arena) (void)hipFree(snap->arena);
     delete snap;
@@ -1042,9 +1043,11 @@ void Engine::flush_staged(int32_t t, bool inRun) {
   if (!inRun) sync_globals_to_device();
   for (auto& sc : stagedChains) {
     if (sc.slot >= dev.chainSlots) throw WgError(WG_ENOMEM, "chain_slots");
-    for (size_t j = 0; j < sc.words.size(); j++) {
-      size_t idx = (sc.c.destOff + j) % dev.chainDests;
-      WG_HIP(hipMemcpy(dev.dests + idx, &sc.words[j], 4, hipMemcpyHostToDevice));
+    {  // the envelope's words into the destination ring: one copy, two where the slice wraps
+      const size_t n = sc.words.size(), at = sc.c.destOff % dev.chainDests;
+      const size_t first = std::min(n, (size_t)(dev.chainDests - at));
+      if (first) WG_HIP(hipMemcpy(dev.dests + at, sc.words.data(), 4 * first, hipMemcpyHostToDevice));
+      if (n > first) WG_HIP(hipMemcpy((int32_t*)dev.dests, sc.words.data() + first, 4 * (n - first), hipMemcpyHostToDevice));
     }
     WG_HIP(hipMemcpy(dev.chains + sc.slot, &sc.c, sizeof(Chain), hipMemcpyHostToDevice));
   }
@@ -1059,21 +1062,24 @@ void Engine::flush_staged(int32_t t, bool inRun) {
       msgs.push_back(p.msgs);
       bytes.push_back(p.msgs * (long long)proto->host_msg_size(p.msg));
     }
-    int n = (int)nodes.size();
-    int32_t* dn;
-    long long *dm, *db;
-    if (n > 0) {
-    WG_HIP(hipMalloc((void**)&dn, 4 * n));
-    WG_HIP(hipMalloc((void**)&dm, 8 * n));
-    WG_HIP(hipMalloc((void**)&db, 8 * n));
-    WG_HIP(hipMemcpy(dn, nodes.data(), 4 * n, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(dm, msgs.data(), 8 * n, hipMemcpyHostToDevice));
-    WG_HIP(hipMemcpy(db, bytes.data(), 8 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_apply_sent, dim3((n + 255) / 256), dim3(256), 0, stream, dev.nodes, n, dn, dm, db);
-    WG_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(dn);
-    (void)hipFree(dm);
-    (void)hipFree(db);
+    const int n = (int)nodes.size();
+    if (n > 0) {  // one grow-only staging buffer {msgs[n], bytes[n], nodes[n]} and one copy (a hipMalloc / hipFree per flush before)
+      const size_t need = 20 * (size_t)n;
+      if (need > sentBufBytes) {
+        if (sentBuf) (void)hipFree(sentBuf);
+        sentBuf = nullptr;
+        sentBufBytes = 0;
+        WG_HIP(hipMalloc((void**)&sentBuf, 2 * need));
+        sentBufBytes = 2 * need;
+      }
+      std::vector<char> host(need);
+      memcpy(host.data(), msgs.data(), 8 * (size_t)n);
+      memcpy(host.data() + 8 * (size_t)n, bytes.data(), 8 * (size_t)n);
+      memcpy(host.data() + 16 * (size_t)n, nodes.data(), 4 * (size_t)n);
+      WG_HIP(hipMemcpyAsync(sentBuf, host.data(), need, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(k_apply_sent, dim3((n + 255) / 256), dim3(256), 0, stream, dev.nodes, n, (int32_t*)(sentBuf + 16 * (size_t)n),
+                         (long long*)sentBuf, (long long*)(sentBuf + 8 * (size_t)n));
+      WG_HIP(hipStreamSynchronize(stream));  // (`host` is pageable: the copy has left it by now)
     }
     pendingSent.clear();
   }

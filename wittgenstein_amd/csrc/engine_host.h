@@ -259,6 +259,8 @@ class Engine {
     uint32_t msg;
   };
   std::vector<PendingSent> pendingSent;
+  char* sentBuf = nullptr;  // flush_staged's staging buffer for Node.msgSent / bytesSent of host-side sends (grow-only)
+  size_t sentBufBytes = 0;
   ProtoHost* proto = nullptr;
   std::vector<void*> allocs;     // everything to hipFree
   // What wg_snapshot / wg_restore do with an allocation (parallel to `allocs`): STATE is copied, SCRATCH holds
