@@ -2178,10 +2178,23 @@ __global__ void k_handel_init(HandelState s, const uint8_t* down, const int32_t*
 __global__ void k_handel_cont_if(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab, uint32_t* out) {
   const EngineDev& d = tab[blockIdx.y];
   const HandelState& s = stab[blockIdx.y];
-  int node = blockIdx.x * blockDim.x + threadIdx.x;  // (sharded: the predicate over this shard's nodes)
-  bool c = node >= s.lo && node < s.hi && !d.nodes.down[node] &&
-           (d.nodes.doneAt[node] == 0 || (int32_t)h_hdr(s, node)[HH_ADDED] > 0);
-  if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
+  // A FEW wavefronts per engine, each walking its share of the nodes 64 at a time and stopping at the first such node: for
+  // most of a run that is the first 64 it looks at. (One wavefront per 64 nodes, each reporting through the same word, was
+  // 12 k same-address atomics — or stores — per call at 24 copies of 32 768 nodes: 100 - 150 us of every tenth ms.)
+  const int stride = (int)(gridDim.x * blockDim.x);
+  for (int n0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u); n0 < s.hi; n0 += stride) {
+    if (__ballot(cont_if_known(out + blockIdx.y))) return;  // (settled by another wavefront; wave-uniform)
+    const int node = n0 + (int)WG_LANE;  // (sharded: the predicate over this shard's nodes)
+    const bool live = node >= s.lo && node < s.hi && !d.nodes.down[node];
+    // doneAt is a dense array; addedCycle sits in the node's 640-byte record (a line per node): it only matters for nodes
+    // that are done, i.e. in the last extraCycle periods of a run
+    bool c = live && d.nodes.doneAt[node] == 0;
+    if (!__ballot(c)) c = live && (int32_t)h_hdr(s, node)[HH_ADDED] > 0;
+    if (__ballot(c)) {
+      if (WG_LANE == 0) cont_if_set(out + blockIdx.y);
+      return;
+    }
+  }
 }
 
 // wg_restore: receptionRanks as init() left them. The only writer is checkSigs' `receptionRanks[from] += nodeCount`
@@ -2715,7 +2728,7 @@ struct HandelHost : ProtoHost {
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
-    hipLaunchKernelGGL(k_handel_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,
+    hipLaunchKernelGGL(k_handel_cont_if, dim3(std::max(1, std::min(8, (st.N + 255) / 256)), g.R), dim3(256), 0, g.stream, g.tab,
                        (const HandelState*)g.stab, dOut);
     return true;
   }
@@ -2854,6 +2867,7 @@ __global__ void k_gsf_init(GsfState s, const uint8_t* down) {
 __global__ void k_gsf_cont_if(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, uint32_t* out) {
   const EngineDev& d = tab[blockIdx.y];
   const GsfState& s = stab[blockIdx.y];
+  if (__ballot(cont_if_known(out + blockIdx.y))) return;
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   bool c = false;
   if (node >= s.lo && node < s.hi && !d.nodes.down[node]) {  // (sharded: the predicate over this shard's nodes)
@@ -2861,7 +2875,7 @@ __global__ void k_gsf_cont_if(const EngineDev* __restrict__ tab, const GsfState*
     for (int l = 0; l < s.L; l++) tot += s.cV[(size_t)node * s.L + l];
     c = tot < s.p.threshold;
   }
-  if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
+  if (__ballot(c) && WG_LANE == 0) cont_if_set(out + blockIdx.y);
 }
 
 struct GsfHost : ProtoHost {

@@ -280,6 +280,16 @@ __device__ __forceinline__ uint32_t block_excl_scan32_1024(uint32_t v, uint32_t*
   return woff + incl - v;
 }
 
+// the "some node still ..." flag of a continuation predicate (newContIf): every wavefront that finds such a node used to
+// atomicOr the same word — 12 k same-address atomics per call at 24 copies of 32 768 nodes, 100 us of every tenth ms
+// (one L2 atomic unit retires ~ 88 of them per us). A plain store of the same value by whoever finds it first is enough.
+__device__ __forceinline__ bool cont_if_known(const uint32_t* out) {
+  return __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+__device__ __forceinline__ void cont_if_set(uint32_t* out) {
+  if (!cont_if_known(out)) __hip_atomic_store(out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Every kernel of the pipeline is launched over a TABLE of engines, blockIdx.y selecting the engine:
 // a batch of independent simulations (the reference's RunMultipleTimes copies, C/RunMultipleTimes.java:
 // 44-48) advances one simulated ms per launch. A stand-alone engine is a table of one.

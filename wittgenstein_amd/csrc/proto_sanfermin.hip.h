@@ -251,7 +251,7 @@ __global__ void k_sf_cont_if(const EngineDev* __restrict__ tab, const SfState* _
   const SfState& s = stab[blockIdx.y];
   int node = blockIdx.x * blockDim.x + threadIdx.x;
   bool c = node < s.N && shard_owns(d, node) && !d.nodes.down[node] && !(s.flags[node] & SF_DONE);  // (sharded: own nodes)
-  if (__ballot(c) && WG_LANE == 0) atomicOr(out + blockIdx.y, 1u);
+  if (__ballot(c) && WG_LANE == 0) cont_if_set(out + blockIdx.y);
 }
 __global__ void k_sf_init(SfState s) {
   int node = blockIdx.x * blockDim.x + threadIdx.x;
