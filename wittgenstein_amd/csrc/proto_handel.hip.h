@@ -1167,7 +1167,9 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     }
     if (nUpd > 1) mine = false;
     {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
-      const bool toB = have && !mine && !disFirst;
+      // (a node whose first event k_handel_dissem applies: the rest of its events, if any, as a visit that skips the first —
+      // listed here, with this wavefront's one atomic, not by k_handel_dissem with one atomic per node on the same word)
+      const bool toB = have && !mine && (!disFirst || cnt > 1u);
       const uint64_t m = __ballot(toB);
       if (m) {
         uint32_t bb = 0;
@@ -1179,7 +1181,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
           q.x = (uint32_t)node;
           q.y = HW_VISIT | (vflags << 8);
           q.z = cnt;
-          q.w = 0;  // (events to skip: none)
+          q.w = disFirst ? 1u : 0u;  // (events to skip)
           gst(work + (bb + __popcll(m & lanes_lt())), q);
         }
       }
@@ -1593,7 +1595,6 @@ __global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __r
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nItems = *s.disCount;
   const int32_t t = d.g->now;
-  U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;
   for (uint32_t a = wave; a < nItems; a += nWaves) {
     const U4 it = gld((const U4 WG_G*)s.itemsDis + a);
     const int32_t node = (int32_t)WG_READFIRST(it.x);
@@ -1623,15 +1624,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __r
     }
     HandelProto::node_counters(c, s, r, 0, 0);
     HandelProto::node_end(c, s, r);
-    if (cnt > 1u && lane == 0) {  // the rest of the node's events: a visit of k_handel_wave from the second event on
-      const uint32_t bb = atomicAdd(F(&d.g->nActiveB), 1u);
-      U4 q;
-      q.x = (uint32_t)node;
-      q.y = HW_VISIT | (vflags << 8);
-      q.z = cnt;
-      q.w = 1u;
-      gst(work + bb, q);
-    }
+    // (the rest of the node's events: k_handel_lane listed them as a visit of k_handel_wave that skips the first event)
     __builtin_amdgcn_wave_barrier();
   }
 }
