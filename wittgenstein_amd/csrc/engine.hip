@@ -2867,15 +2867,22 @@ __global__ void k_gsf_init(GsfState s, const uint8_t* down) {
 __global__ void k_gsf_cont_if(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, uint32_t* out) {
   const EngineDev& d = tab[blockIdx.y];
   const GsfState& s = stab[blockIdx.y];
-  if (__ballot(cont_if_known(out + blockIdx.y))) return;
-  int node = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = false;
-  if (node >= s.lo && node < s.hi && !d.nodes.down[node]) {  // (sharded: the predicate over this shard's nodes)
-    int tot = 0;
-    for (int l = 0; l < s.L; l++) tot += s.cV[(size_t)node * s.L + l];
-    c = tot < s.p.threshold;
+  // (a few wavefronts per engine that stop at the first such node: see k_handel_cont_if)
+  const int stride = (int)(gridDim.x * blockDim.x);
+  for (int n0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u); n0 < s.hi; n0 += stride) {
+    if (__ballot(cont_if_known(out + blockIdx.y))) return;
+    const int node = n0 + (int)WG_LANE;
+    bool c = false;
+    if (node >= s.lo && node < s.hi && !d.nodes.down[node]) {  // (sharded: the predicate over this shard's nodes)
+      int tot = 0;
+      for (int l = 0; l < s.L; l++) tot += s.cV[(size_t)node * s.L + l];
+      c = tot < s.p.threshold;
+    }
+    if (__ballot(c)) {
+      if (WG_LANE == 0) cont_if_set(out + blockIdx.y);
+      return;
+    }
   }
-  if (__ballot(c) && WG_LANE == 0) cont_if_set(out + blockIdx.y);
 }
 
 struct GsfHost : ProtoHost {
@@ -3037,7 +3044,7 @@ struct GsfHost : ProtoHost {
                        (const GsfState*)g.stab);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
-    hipLaunchKernelGGL(k_gsf_cont_if, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab,
+    hipLaunchKernelGGL(k_gsf_cont_if, dim3(std::max(1, std::min(4, (st.N + 255) / 256)), g.R), dim3(256), 0, g.stream, g.tab,
                        (const GsfState*)g.stab, dOut);
     return true;
   }
