@@ -16,19 +16,27 @@
 //             updateVerifiedSignatures task still references it (:833-836).
 //
 // Who runs what (a node visit is a chain of dependent memory round trips — the kernels' throughput is
-// the number of visits IN FLIGHT over the length of that chain, so the work is cut by how many lanes a visit can use):
+// the number of visits IN FLIGHT over the length of that chain, so the work is cut by how many lanes a visit can use and
+// by how many registers a kernel has to hold):
 //   k_handel_lane   one LANE per node: the nodes whose events of the ms (<= 4, read from the node's inbox line) are
 //                   SendSigs messages (onNewSig :757-790, the hops of fast-path envelopes included; payloads wider than
 //                   one word become jobs of k_handel_copy, one wavefront each) and at most one updateVerifiedSignatures
-//                   task (:690-754) of a level whose block is <= 4 words — 64 visits in flight per wavefront. It also
-//                   sorts every other node into the next kernel's list.
-//   k_handel_wave   one WAVEFRONT per node, lanes = 64-bit words of the level block: dissemination (:331-343), the
-//                   wide levels' updateVerifiedSignatures, nodes with a chain hop or more than four events — and the
-//                   fast-path sends (:738-749) the lane kernel deferred (remaining_peers is a wave-parallel scan).
+//                   task (:690-754) — of a level whose block is <= 16 words (applied by the lane), or of a wider level as
+//                   the node's last event (an item of k_handel_update) — 64 visits in flight per wavefront. It also sorts
+//                   every other node into the lists of the kernels below.
+//   k_handel_update one WAVEFRONT per wide updateVerifiedSignatures (blocks of 32 .. 256 words), 6 waves/SIMD.
+//   k_handel_dissem one WAVEFRONT per node whose FIRST event is its dissemination (:331-343): that event only, 8 waves/SIMD.
+//   k_handel_wave   one WAVEFRONT per node, lanes = 64-bit words of the level block: everything else — dissemination
+//                   behind other events, nodes with more than four events, the rest of a visit the kernels above handed
+//                   on (`skip`), the fast-path sends (:738-749) a lane deferred (remaining_peers is a wave-parallel scan),
+//                   and every visit of a run with an attack.
 //   checkSigs (:796-837) runs per (node, LEVEL) item — bestToVerify of one level is independent of the other levels:
 //   k_handel_cond_pre lists the items, k_handel_a1 curates a level's list and records its candidate (one lane per item
-//   for blocks <= 4 words, one wavefront per item beyond), the scan + k_handel_cond_a2 draw among a node's candidates.
-// Honest-node paths only: byzantineSuicide / hiddenByzantine (:538-559, :840-917) are not resident.
+//   for blocks <= 16 words, one wavefront per item beyond: h_best_wave), the scan + k_handel_cond_a2 draw among a
+//   node's candidates.
+// byzantineSuicide / hiddenByzantine (:538-559, 577-584, 688-694, 813-817, 840-917) are resident in separate instantiations
+// (HandelProtoT<true>, k_handel_wave / k_handel_a1 / k_handel_cond_a2 <.., true>, k_handel_hidden): DESIGN.md §3.13.
+// init() (:957-1014) runs on the device too (k_handel_init_*, at the end of this file): DESIGN.md §3.11a.
 #pragma once
 #include "engine_kernels.hip.h"
 
