@@ -102,6 +102,10 @@ struct GsfProto {
     uint32_t pend[G_PEND];
     int32_t pendFrom[G_PEND];
     GLevels* ls;
+    // what the visit's events changed of the node's arrays (1: the per-level scalars, 2: the slot bitmap, 4: pend, 8: doneAt):
+    // node_end writes back only that — a SendSigs delivery touches none of the five per-level arrays
+    uint32_t dirty;
+    long long doneAt0;
   };
 
   __device__ static int msg_size(const State&, uint32_t msg) { return g_msg_size((int)(msg & 31u)); }
@@ -119,21 +123,24 @@ struct GsfProto {
     for (int q = WG_LANE; q < s.Q / 64; q += 64) ls->used[q] = s.tvUsed[(size_t)node * (s.Q / 64) + q];
     __builtin_amdgcn_wave_barrier();
   }
-  __device__ static void store_levels(const State& s, int32_t node, const GLevels* ls) {
+  __device__ static void store_levels(const State& s, int32_t node, const GLevels* ls, uint32_t dirty = 3u) {
     __builtin_amdgcn_wave_barrier();
-    for (int l = WG_LANE; l < s.L; l += 64) {
-      size_t i = (size_t)node * s.L + l;
-      s.pos[i] = ls->pos[l];
-      s.rem[i] = ls->rem[l];
-      s.cV[i] = ls->cV[l];
-      s.cIV[i] = ls->cIV[l];
-      s.cU[i] = ls->cU[l];
-    }
-    for (int q = WG_LANE; q < s.Q / 64; q += 64) s.tvUsed[(size_t)node * (s.Q / 64) + q] = ls->used[q];
+    if (dirty & 1u)
+      for (int l = WG_LANE; l < s.L; l += 64) {
+        size_t i = (size_t)node * s.L + l;
+        s.pos[i] = ls->pos[l];
+        s.rem[i] = ls->rem[l];
+        s.cV[i] = ls->cV[l];
+        s.cIV[i] = ls->cIV[l];
+        s.cU[i] = ls->cU[l];
+      }
+    if (dirty & 2u)
+      for (int q = WG_LANE; q < s.Q / 64; q += 64) s.tvUsed[(size_t)node * (s.Q / 64) + q] = ls->used[q];
   }
   __device__ static void node_begin(Ctx& c, const State& s, NodeRegs& r, GLevels* ls) {
     const int32_t node = c.node;
-    r.doneAt = c.d.nodes.doneAt[node];
+    r.doneAt = r.doneAt0 = c.d.nodes.doneAt[node];
+    r.dirty = 0;
     r.sigQueueSize = s.sigQueueSize[node];
     r.tvLen = s.tvLen[node];
 #pragma unroll
@@ -146,13 +153,15 @@ struct GsfProto {
   }
   __device__ static void node_end(Ctx& c, const State& s, NodeRegs& r) {
     const int32_t node = c.node;
-    store_levels(s, node, r.ls);
+    store_levels(s, node, r.ls, r.dirty);
     if (WG_LANE == 0) {
-      c.d.nodes.doneAt[node] = r.doneAt;
+      if (r.doneAt != r.doneAt0) c.d.nodes.doneAt[node] = r.doneAt;
       s.sigQueueSize[node] = r.sigQueueSize;
       s.tvLen[node] = r.tvLen;
+      if (r.dirty & 4u) {
 #pragma unroll
-      for (int k = 0; k < G_PEND; k++) s.pend[(size_t)node * G_PEND + k] = r.pend[k];
+        for (int k = 0; k < G_PEND; k++) s.pend[(size_t)node * G_PEND + k] = r.pend[k];
+      }
     }
   }
   __device__ static void on_message(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
@@ -211,6 +220,7 @@ struct GsfProto {
       H_FOR_WORDS(v, j) dst[j] = src[j];
       __builtin_amdgcn_wave_barrier();  // every lane has read the slot bitmap before lane 0 changes it
       if (WG_LANE == 0) ls->used[slot >> 6] |= 1ULL << (slot & 63);
+      r.dirty |= 2u;
       aux = (uint32_t)slot;
     }
     if (WG_LANE == 0) {
@@ -227,6 +237,7 @@ struct GsfProto {
   // ---- PeriodicTask: doCycle (:213-225) -> SFLevel.doCycle (:317-327) -------------------------------
   __device__ static void do_cycle(Ctx& c, const State& s, NodeRegs& r) {
     GLevels* ls = r.ls;
+    r.dirty |= 1u;  // (posInLevel / remainingCalls)
     const int32_t node = c.node;
     const int k = first_incomplete(s, ls);
     for (int l = 1; l < s.L; l++) {
@@ -257,6 +268,7 @@ struct GsfProto {
   // ---- Task: updateVerifiedSignatures (:387-460) ------------------------------------------------------
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int lane = WG_LANE;
+    r.dirty |= 1u | 2u | 4u;  // (the level's counts, a PARTIAL message's slot, the pending table)
     const int32_t node = c.node;
     // (selects, not r.pend[arg & 3]: a register array indexed at run time puts the whole NodeRegs — and the LDS pointer in
     // it — in scratch memory; every access to a node scalar is then a memory round trip and every LDS access a FLAT one)
