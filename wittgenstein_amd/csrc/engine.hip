@@ -2898,6 +2898,8 @@ struct GsfHost : ProtoHost {
     if (!init.nodePairingTime || !init.peers) throw WgError(WG_EINVAL, "wg_gsf_init_state has NULL members");
     if (p.acceleratedCallsCount > 64)
       throw WgError(WG_EUNSUPPORTED, "acceleratedCallsCount > 64 (device multi-destination sends hold <= 64 ids)");
+    // a node's events of the ms from its inbox line (k_deliver_inbox) where the engine is not allocated yet; WG_GSF_INBOX=0: the list
+    if (!e.allocated && !(getenv("WG_GSF_INBOX") && atoi(getenv("WG_GSF_INBOX")) == 0)) e.wantInbox = true;
     if (p.periodDurationMs <= 0) throw WgError(WG_EINVAL, "periodDurationMs");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N) (:182-192)
@@ -2907,6 +2909,7 @@ struct GsfHost : ProtoHost {
     Q = (Q + 63) / 64 * 64;
     if (Q > G_MAX_Q) throw WgError(WG_EINVAL, "queue_cap must be <= 512 for GSFSignature");
     e.ensure_device();
+    if (e.dev.inbox && e.dev.maxOut >= (1u << 28)) throw WgError(WG_EINVAL, "outbox_records must be below 2^28 (an inbox entry carries a task's outbox slot in 28 bits)");
     if (p.periodDurationMs >= e.dev.horizon) throw WgError(WG_ENOMEM, "horizon_ms <= period");
     st.p = p;
     st.N = N;
@@ -3040,8 +3043,12 @@ struct GsfHost : ProtoHost {
     return nOut;
   }
   void launch_deliver(const Group& g) override {
-    hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
-                       (const GsfState*)g.stab);
+    if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
+      hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                         (const GsfState*)g.stab);
+    else
+      hipLaunchKernelGGL((k_deliver<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                         (const GsfState*)g.stab);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_gsf_cont_if, dim3(std::max(1, std::min(4, (st.N + 255) / 256)), g.R), dim3(256), 0, g.stream, g.tab,

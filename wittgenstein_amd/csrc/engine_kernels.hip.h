@@ -1978,6 +1978,51 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
   }
 }
 
+// ... the same visit from the node's INBOX LINE (EngineDev::inbox, protocols that ask for it: Engine::wantInbox): the
+// node's <= 4 events are one 64-byte read, not a walk of head[node] -> evNext -> ev / evAux gathers — three dependent
+// round trips per event of the visit's serial chain. The next node's line and event count are in flight during the
+// current visit.
+template <class P, int WPE>
+__global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __restrict__ tab,
+                                                            const typename P::State* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const typename P::State& ps = stab[blockIdx.y];
+  __shared__ typename P::WaveShared shP[4];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  if (wave >= nActive) return;
+  auto line_of = [&](int32_t node) -> InboxEntry {  // lane k < 4: entry k of the node's line
+    return gld(d.inbox + ((size_t)node * INBOX_SLOTS + (lane < INBOX_SLOTS ? lane : 0)));
+  };
+  int32_t node = (int32_t)d.active[wave];
+  InboxEntry in = line_of(node);
+  uint32_t cnt = d.icnt[node];
+  for (uint32_t a = wave; a < nActive; a += nWaves) {
+    const bool haveNext = a + nWaves < nActive;
+    int32_t nodeN = node;
+    InboxEntry inN = in;
+    uint32_t cntN = cnt;
+    if (haveNext) {
+      nodeN = (int32_t)d.active[a + nWaves];
+      inN = line_of(nodeN);
+      cntN = d.icnt[nodeN];
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane has read the node's count (and the next node's) before lane 0 clears it
+    if (lane == 0) d.icnt[node] = 0;  // the line is consumed by this visit
+    const uint32_t vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
+    Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+    typename P::NodeRegs r;
+    P::node_begin(c, ps, r, &shP[w]);
+    deliver_visit_inbox<P>(d, ps, c, r, node, cnt, vflags, in, 0u);
+    node = nodeN;
+    in = inN;
+    cnt = cntN;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // A payload copy a lane-per-node kernel hands to its whole wavefront (k_handel_lane: SendSigs payloads wider than one
 // word are copied coalesced after the lanes' scalar work).
