@@ -683,11 +683,38 @@ __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& 
                                                  int32_t* shArv) {
   const int nd = o.to, T = (int)blockDim.x, t = (int)threadIdx.x;
   const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
+  // The list's arrivals in three ROUNDS of independent loads — every destination, then every destination's flags and
+  // coordinates, then every latency-table entry — instead of one chain of three dependent round trips per destination
+  // (ten destinations: thirty round trips one behind the other; the kernel is one wave-round of lanes, so its duration
+  // IS its longest chain). Static indices throughout: the arrays live in registers.
+  int32_t to_[MULTI_LDS], arv[MULTI_LDS];
+  bool ok[MULTI_LDS];
+#pragma unroll
+  for (int j = 0; j < MULTI_LDS; j++) to_[j] = j < nd ? d.sdests[multi_idx(d, o, j)] : from;
+  const NodeArrays& na = d.nodes;
+  const uint8_t pf = na.part[from], df = na.down[from];
+  const int32_t xf = na.x[from], yf = na.y[from], ef = na.extraLatency[from];
+  uint8_t pt[MULTI_LDS], dt[MULTI_LDS];
+  int32_t xt[MULTI_LDS], yt[MULTI_LDS], et[MULTI_LDS];
+#pragma unroll
+  for (int j = 0; j < MULTI_LDS; j++) {
+    pt[j] = na.part[to_[j]];
+    dt[j] = na.down[to_[j]];
+    xt[j] = na.x[to_[j]];
+    yt[j] = na.y[to_[j]];
+    et[j] = na.extraLatency[to_[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < MULTI_LDS; j++) {  // arrival_of_send, with the loads above
+    ok[j] = j < nd && pf == pt[j] && !df && !dt[j];
+    arv[j] = latency_of(d.lat, from, to_[j], xf, yf, ef, xt[j], yt[j], et[j], pseudo_delta(to_[j], seed));
+  }
   int m = 0;
-  for (int j = 0; j < nd; j++) {
-    const int32_t to = d.sdests[multi_idx(d, o, j)];
-    int32_t a;
-    if (!arrival_of_send(d, from, to, o.t + j * step, seed, a)) continue;
+#pragma unroll
+  for (int j = 0; j < MULTI_LDS; j++) {
+    if (!ok[j] || arv[j] >= d.discardTime) continue;
+    const int32_t to = to_[j];
+    const int32_t a = o.t + j * step + arv[j];
     int k = m++;
     while (k > 0 && shArv[(k - 1) * T + t] > a) {
       shArv[k * T + t] = shArv[(k - 1) * T + t];
