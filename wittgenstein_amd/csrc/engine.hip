@@ -964,8 +964,10 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 
 template <class F>
 void Engine::scan(const Group& g, const typename F::Aux* atab) {
-  hipLaunchKernelGGL(k_scan1<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
-  hipLaunchKernelGGL(k_scan2<F>, dim3(SCAN_GRID, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  static const int total = grid_env("WG_GRID_TOTAL_SCAN", 1024);
+  const int gx = grid_per_engine(SCAN_GRID, g.R, total);
+  hipLaunchKernelGGL(k_scan1<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
+  hipLaunchKernelGGL(k_scan2<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
 template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
@@ -982,9 +984,11 @@ template void Engine::scan<MultiF>(const Group&, const int*);
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
 void Engine::append_phase(const Group& g, bool needHist) {
-  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  static const int total = grid_env("WG_GRID_TOTAL_TILES", 512);
+  const int gx = grid_per_engine(GRID_TILES, g.R, total);
+  if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
-  hipLaunchKernelGGL(k_scatter, dim3(GRID_TILES, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
 }
 void Engine::end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
@@ -1249,7 +1253,8 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
-      hipLaunchKernelGGL(k_resolve<false>, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab);
+      static const int total = grid_env("WG_GRID_TOTAL_RESOLVE", 4096);
+      hipLaunchKernelGGL(k_resolve<false>, dim3(grid_per_engine(GRID_RESOLVE, g.R, total), g.R), dim3(256), 0, g.stream, g.tab);
     }
     if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
       ProfScope ps(lead, Engine::PC_RESOLVE);
@@ -2652,9 +2657,9 @@ struct HandelHost : ProtoHost {
     if (st.atk == 2)  // HiddenByzantine.attack on the drawn candidates of the last level
       hipLaunchKernelGGL(k_handel_hidden, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     if (st.atk)
-      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
     else
-      hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
@@ -2699,7 +2704,7 @@ struct HandelHost : ProtoHost {
   // k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    hipLaunchKernelGGL(k_handel_lane, dim3(GRID_LANE_NODES, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_LANE", 3072), g.R), dim3(256), 0, g.stream, g.tab, stab);
     hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     switch (wavesUpdate) {
       case 8: hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
@@ -3014,7 +3019,7 @@ struct GsfHost : ProtoHost {
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
-    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(GRID_COND_TAIL, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
