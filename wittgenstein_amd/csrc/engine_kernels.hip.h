@@ -222,6 +222,18 @@ __device__ __forceinline__ Rec* rec_ptr(const EngineDev& d, uint32_t bucket, uin
   return d.pool + (((size_t)page << PAGE_SHIFT) | (i & (PAGE_RECS - 1)));
 }
 
+// Entry base + k of a ring of `cap` entries whose base is already reduced and whose step is far below cap: a compare and
+// a subtract. (A 64-bit % by a run-time value is emulated — ~ 100 instructions; a 10-destination list paid thirty of them
+// in k_resolve, every chain hop one in expand. The second test keeps the function exact for any base.)
+__device__ __forceinline__ unsigned long long ring_at(unsigned long long base, unsigned long long k, unsigned long long cap) {
+  unsigned long long i = base + k;
+  if (i >= cap) {
+    i -= cap;
+    if (i >= cap) i %= cap;
+  }
+  return i;
+}
+
 __device__ __forceinline__ int32_t dev_latency(const EngineDev& d, int32_t from, int32_t to, int32_t seed) {
   const NodeArrays& n = d.nodes;
   return latency_of(d.lat, from, to, n.x[from], n.y[from], n.extraLatency[from], n.x[to], n.y[to],
@@ -231,10 +243,10 @@ __device__ __forceinline__ int32_t dev_latency(const EngineDev& d, int32_t from,
 // arrival of the j-th destination of a chain (MultipleDestEnvelope.arrivalTime C/Envelope.java:107-113,
 // MultipleDestWithDelayEnvelope.nextArrivalTime :186-188)
 __device__ __forceinline__ int32_t chain_dest(const EngineDev& d, const Chain& c, int j) {
-  return d.dests[(c.destOff + (unsigned long long)j) % d.chainDests];
+  return d.dests[ring_at(c.destOff, (unsigned long long)j, d.chainDests)];
 }
 __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain& c, int j) {
-  if (c.flags & 2u) return d.dests[(c.destOff + (unsigned long long)c.ndest + j) % d.chainDests];
+  if (c.flags & 2u) return d.dests[ring_at(c.destOff, (unsigned long long)c.ndest + j, d.chainDests)];
   return c.sendTime + dev_latency(d, c.from, chain_dest(d, c, j), c.seed);
 }
 
@@ -654,7 +666,7 @@ constexpr int TILE = 1024;
 // prefix is never longer than the entries consumed), so no copy of the list is needed — and no per-lane array, which the
 // compiler could only have kept in scratch memory (528 bytes a lane until round 3).
 __device__ __forceinline__ unsigned long long multi_idx(const EngineDev& d, const Out& o, int k) {
-  return (o.destOff + (unsigned long long)k) % d.sdestCap;
+  return ring_at(o.destOff, (unsigned long long)k, d.sdestCap);
 }
 __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, int32_t from, int32_t seed) {
   const int nd = o.to;
@@ -759,8 +771,8 @@ __device__ __forceinline__ uint32_t shuffle_dests(const EngineDev& d, const Out&
     int consumed;
     const int32_t j = lcg_next_int_bounded(st, i, &consumed);
     if (consumed != 1) set_err(d.g, ERR_PROTOCOL);
-    const unsigned long long a = (o.destOff + (unsigned long long)(i - 1)) % d.sdestCap;
-    const unsigned long long b = (o.destOff + (unsigned long long)j) % d.sdestCap;
+    const unsigned long long a = ring_at(o.destOff, (unsigned long long)(i - 1), d.sdestCap);
+    const unsigned long long b = ring_at(o.destOff, (unsigned long long)j, d.sdestCap);
     const int32_t x = d.sdests[a];
     d.sdests[a] = d.sdests[b];
     d.sdests[b] = x;
@@ -849,7 +861,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           }
           // (unsharded: sdests IS the chain ring — the sorted destinations are where the envelope reads them)
           if (o.pad & OUT_DELAYED)  // explicit arrivals follow the destinations (the action reserved 2 n entries)
-            for (int j = 0; j < m; j++) d.dests[(o.destOff + (unsigned long long)(m + j)) % d.chainDests] = d.arvTmp[multi_idx(d, o, j)];
+            for (int j = 0; j < m; j++) d.dests[ring_at(o.destOff, (unsigned long long)(m + j), d.chainDests)] = d.arvTmp[multi_idx(d, o, j)];
           Chain c;
           c.from = from;
           c.seed = seed;
@@ -1071,9 +1083,9 @@ __global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __r
       d.fin[p] = make_rec(K_CHAIN, sd.from, slot, 0, 0);
       continue;
     }
-    for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)j) % d.chainDests] = x[6 + j];
+    for (int j = 0; j < m; j++) d.dests[ring_at(off, (unsigned long long)j, d.chainDests)] = x[6 + j];
     if (x[5])  // explicit arrivals follow the destinations (as k_resolve<false> lays them out; Chain::flags bit 1)
-      for (int j = 0; j < m; j++) d.dests[(off + (unsigned long long)(m + j)) % d.chainDests] = x[6 + 64 + j];
+      for (int j = 0; j < m; j++) d.dests[ring_at(off, (unsigned long long)(m + j), d.chainDests)] = x[6 + 64 + j];
     Chain c;
     c.from = rec_from(r);
     c.seed = x[0];
@@ -1325,7 +1337,7 @@ __global__ void __launch_bounds__(TILE) k_send_expand_scatter(const EngineDev* _
     const bool valid = nt >= 0;
     const int bin = valid ? nt : 0;
     const uint32_t rank = tile_rank(hist, bin, valid, binBits);
-    if (valid) d.dests[(x.destOff + x.hist[(size_t)tile * D + bin] + rank) % d.chainDests] = x.in[j];
+    if (valid) d.dests[ring_at(x.destOff, (unsigned long long)x.hist[(size_t)tile * D + bin] + rank, d.chainDests)] = x.in[j];
     __syncthreads();
   }
 }
@@ -1450,7 +1462,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __res
       const bool valid = nt >= 0;
       const int bin = valid ? nt : 0;
       const uint32_t rank = tile_rank(hist, bin, valid, binBits);
-      if (valid) d.dests[(sd.destOff + d.saHist[((size_t)k * nTiles + tile) * D + bin] + rank) % d.chainDests] = (int32_t)to;
+      if (valid) d.dests[ring_at(sd.destOff, (unsigned long long)d.saHist[((size_t)k * nTiles + tile) * D + bin] + rank, d.chainDests)] = (int32_t)to;
       __syncthreads();
     }
   }
@@ -1636,14 +1648,14 @@ struct Ctx {
     return (uint32_t)(off % d.sdestCap);
   }
   __device__ void dest_put(uint32_t destOff, int j, int32_t id) {
-    d.sdests[(destOff + (unsigned long long)j) % d.sdestCap] = id;
+    d.sdests[ring_at(destOff, (unsigned long long)j, d.sdestCap)] = id;
   }
   __device__ void send_list(uint32_t destOff, int n, uint32_t msg, uint32_t payload, int size) {
     if (n == 0) return;
     msgSent += n;
     bytesSent += (long long)n * size;
     if (n == 1) {
-      int32_t to = __hip_atomic_load(&d.sdests[destOff % d.sdestCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int32_t to = __hip_atomic_load(&d.sdests[ring_at(destOff, 0, d.sdestCap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       put(O_SEND, to, msg, payload, t + 1, 0, true);
     } else {
       if (n > 64) {
@@ -1660,7 +1672,7 @@ struct Ctx {
     msgSent += n;
     bytesSent += (long long)n * size;
     if (n == 1) {
-      int32_t to = __hip_atomic_load(&d.sdests[destOff % d.sdestCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int32_t to = __hip_atomic_load(&d.sdests[ring_at(destOff, 0, d.sdestCap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       put(O_SEND, to, msg, payload, t + 1, 0, true);
       return;
     }
