@@ -255,6 +255,8 @@ struct Globals {
   uint32_t nFar;           // records parked in EngineDev::farBuf since the host last collected them
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
+  uint32_t nScatter;       // nOut as k_col_reserve_end saw it: what k_scatter appends after that kernel has reset nOut
+  uint32_t padG;
 };
 constexpr uint32_t KPROF_WAVES = 16384;
 constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)

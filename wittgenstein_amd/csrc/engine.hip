@@ -988,7 +988,20 @@ void Engine::append_phase(const Group& g, bool needHist) {
   const int gx = grid_per_engine(GRID_TILES, g.R, total);
   if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
-  hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
+  hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 0);
+}
+// append + end of the phase in two launches instead of three (k_col_reserve_end, then the scatter); WG_FUSE_END=0 keeps three
+void Engine::append_end_phase(const Group& g, bool drained) {
+  static const bool fuse = !(getenv("WG_FUSE_END") && atoi(getenv("WG_FUSE_END")) == 0);
+  if (!fuse) {
+    append_phase(g, false);
+    end_phase(g, drained);
+    return;
+  }
+  static const int total = grid_env("WG_GRID_TOTAL_TILES", 512);
+  const int gx = grid_per_engine(GRID_TILES, g.R, total);
+  hipLaunchKernelGGL(k_col_reserve_end, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab, drained ? 1 : 0);
+  hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 1);
 }
 void Engine::end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
@@ -1264,22 +1277,14 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
-      Engine::append_phase(g, false);
-    }
-    {
-      ProfScope ps(lead, Engine::PC_END);
-      Engine::end_phase(g, true);
+      Engine::append_end_phase(g, true);
     }
     if (cond) {
       // (running the phase's first kernels on a second stream beside the drain's tail was measured: no gain — the short
       // kernels' latency doubles under the other stream's memory load, profiles/r07e_*)
       proto->launch_cond(lead, g);
-      {
-        ProfScope ps(lead, Engine::PC_APPEND);
-        Engine::append_phase(g, false);
-      }
-      ProfScope ps(lead, Engine::PC_END);
-      Engine::end_phase(g, false);
+      ProfScope ps(lead, Engine::PC_APPEND);
+      Engine::append_end_phase(g, false);
     }
   }
 

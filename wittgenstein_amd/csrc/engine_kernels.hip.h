@@ -1218,10 +1218,10 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
   WG_ENGINE(tab);
   col_reserve_body(d);
 }
-__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits) {
+__global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits, int saved) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
-  uint32_t n = d.g->nOut;
+  uint32_t n = saved ? d.g->nScatter : d.g->nOut;  // (saved: the phase's counters were reset by k_col_reserve_end already)
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
   if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) nTiles = 0;
@@ -1522,6 +1522,18 @@ __device__ __forceinline__ void end_phase_body(const EngineDev& d, int drained) 
 }
 __global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
   WG_ENGINE(tab);
+  end_phase_body(d, drained);
+}
+// k_col_reserve and k_end_phase as ONE launch of one block per engine (both are a single block's short chain of dependent
+// accesses, ~ 5 us of launch + latency each, twice per simulated ms): the end-of-phase bookkeeping touches nothing k_scatter
+// reads — except nOut, which is handed over in nScatter — and the drained bucket's pages go back on the free stack after
+// this phase's reservations were taken from it, as before.
+__global__ void __launch_bounds__(1024) k_col_reserve_end(const EngineDev* __restrict__ tab, int drained) {
+  WG_ENGINE(tab);
+  col_reserve_body(d);
+  __syncthreads();
+  if (threadIdx.x == 0) d.g->nScatter = d.g->nOut;
+  __syncthreads();
   end_phase_body(d, drained);
 }
 
