@@ -2634,12 +2634,12 @@ struct HandelHost : ProtoHost {
   const void* state_host() const override { return &st; }
   template <int W>
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
-    hipLaunchKernelGGL((k_handel_a1<W, false>), dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
+    hipLaunchKernelGGL((k_handel_a1<W, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
   }
   int variant() const override { return st.atk; }
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
     if (st.atk) {  // byzantineSuicide: the instantiations with the attack's paths (every item a wavefront)
-      hipLaunchKernelGGL((k_handel_a1<4, true>), dim3(node_grid(R), R), dim3(256), 0, s, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_a1<4, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
       return;
     }
     switch (wavesCond) {
@@ -2704,12 +2704,17 @@ struct HandelHost : ProtoHost {
     int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
     return b < 16 ? 16 : b;
   }
+  // k_handel_a1 alone wants more blocks than the delivery kernels (its lane-item blocks hold 256 items each and an ordinary
+  // ms has ~ 10 k of them per engine): WG_A1_GRID=<blocks per engine>, default a multiple of node_grid (WG_A1_GRID_MUL)
+  int a1GridEnv = getenv("WG_A1_GRID") ? atoi(getenv("WG_A1_GRID")) : 0;
+  int a1GridMul = getenv("WG_A1_GRID_MUL") && atoi(getenv("WG_A1_GRID_MUL")) > 0 ? atoi(getenv("WG_A1_GRID_MUL")) : 2;
+  int a1_grid(int R) const { return a1GridEnv > 0 ? a1GridEnv : a1GridMul * node_grid(R); }
   // the delivery pass: k_handel_lane (one lane per node: SendSigs deliveries, narrow updateVerifiedSignatures; sorts the
   // other nodes into the next kernel's list), k_handel_copy (the wide payloads it delivered, one wavefront each), then
   // k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    hipLaunchKernelGGL(k_handel_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_LANE", 3072), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_LANE", 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
     hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     switch (wavesUpdate) {
       case 8: hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
