@@ -16,7 +16,9 @@ def ratios(n, dead=0.10):
     return (n, int(n * (1 - dead) * 0.99), 4, 50, 10, 20, 10, down, 0)
 
 
-@pytest.mark.parametrize("n,seeds", [(256, [0, 1, 2, 3, 4]), (1024, [7, 8, 9])])
+# (12 copies: every kernel of the ordering / append chain then runs on a grid scaled by the batch size — engine.h
+# grid_per_engine(): scans from 5 copies, the multisplit from 3, k_resolve from 9 — instead of its per-engine constant)
+@pytest.mark.parametrize("n,seeds", [(256, [0, 1, 2, 3, 4]), (1024, [7, 8, 9]), (512, list(range(20, 32)))])
 def test_handel_batch_matches_oracle_per_seed(n, seeds):
     pairs = [parity.handel_pair(ratios(n), seed=s) for s in seeds]
     batch = w.Batch([g.network() for g, _ in pairs])
