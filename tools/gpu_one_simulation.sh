@@ -1,5 +1,5 @@
 set -u
-OUT=gpurun_out/r09k; mkdir -p $OUT
+OUT=gpurun_out/${1:-r09k}; mkdir -p $OUT
 timeout 600 python bench.py --replicas 1 --steps 3 --warmup 1 --no-cpu --no-second > $OUT/bench_one_copy.json 2> $OUT/one.err; echo "one rc=$?"
 timeout 900 python bench.py --mode shard --gpus 1 --steps 3 --warmup 1 --no-cpu --no-second > $OUT/bench_shard1.json 2> $OUT/shard1.err; echo "shard rc=$?"; tail -3 $OUT/shard1.err
 python - $OUT <<'PY'

@@ -1577,13 +1577,11 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
         hipLaunchKernelGGL(k_sendall_scatter, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab, g.binBits);
       }
     }
-    append_phase(g, false);
-    end_phase(g, true);
+    append_end_phase(g, true);
     if (proto->has_cond()) {  // the conditional tasks of the edge to the new `now` (C/Network.java:543-566)
       const uint32_t nCond = proto->shard_cond(*this, g);
       if (nCond) exchange_outbox(nCond);
-      append_phase(g, false);
-      end_phase(g, false);
+      append_end_phase(g, false);
     }
   }
   WG_HIP(hipStreamSynchronize(stream));
