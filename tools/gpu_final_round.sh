@@ -3,6 +3,8 @@
 # (stamped with the commit), then the whole GPU suite, smoke(), the driver's literal bench line (which reads that traffic.json),
 # the same command under rocprofv3 --kernel-trace --stats (kernel statistics + per-phase table) and the Casper delivery
 # pass's PMC passes -> profiles/traffic_casper.json.      WG_COMMIT=<hash> bash tools/gpu_final_round.sh <tag>
+# (On a gpurun box only gpurun_out/ comes back: afterwards copy gpurun_out/<tag>/traffic.json and traffic_casper.json over
+# profiles/traffic.json / traffic_casper.json in the repo — bench.py reads those — and the other files to profiles/<tag>_*.)
 set -u
 TAG=${1:-final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$(pwd)
 for f in wittgenstein_amd/csrc/*; do
