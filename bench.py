@@ -117,7 +117,7 @@ def split_batches(w, sims, k):
     return [w.Batch([g.network() for g in sims[i:i + per]]) for i in range(0, len(sims), per)]
 
 
-def cpu_baseline(n_sample, workload="handel"):
+def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
     """the C++ oracle (event-for-event restatement of the single-threaded Java path) on one host core"""
     o = _oracle()
     if workload == "gsf":
@@ -137,16 +137,24 @@ def cpu_baseline(n_sample, workload="handel"):
     hp = handel_params(n_sample)
     c = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                  hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0, seed=0)
+    # A BOUNDED sample of the metric's own configuration: the run from t = 0 for `budget_s` seconds of one core (or to the stop
+    # predicate, whichever comes first) — the whole 32 768-node run is 8 minutes of one core (tests/golden/make_golden.py).
+    # init() is outside the bracket, as it is on the GPU side.
     t0 = time.perf_counter()
-    while c.cont_if():
+    while c.cont_if() and time.perf_counter() - t0 < budget_s:
         c.run_ms(10)
     dt = time.perf_counter() - t0
     info = c.info(False)
+    whole = not c.cont_if()
     out = {"value": info["delivered"] / dt, "unit": "delivered messages/s", "cores": 1, "kind": "port",
-           "sample": "Handel %d nodes (same ratios as the GPU workload, seed 0), full run to the stop predicate: "
-                     "%d delivered messages, %d simulated ms in %.2f s on one host core (C++ oracle, upper bound "
-                     "on the JVM path)" % (n_sample, info["delivered"], info["time"], dt),
-           "simulated_ms_per_s": info["time"] / dt}
+           "sample": "Handel %d nodes (the GPU workload's parameters, seed 0), %s: %d delivered messages, %d simulated ms "
+                     "in %.2f s on one host core (C++ oracle, upper bound on the JVM path; init() outside the bracket)"
+                     % (n_sample, "full run to the stop predicate" if whole else
+                        "the first %d simulated ms of the run (bounded at %.0f s of CPU work)" % (info["time"], budget_s),
+                        info["delivered"], info["time"], dt),
+           "simulated_ms_per_s": info["time"] / dt, "sample_nodes": n_sample, "sample_simulated_ms": info["time"]}
+    del c
+    gc.collect()
     # the only parallelism the reference admits (C/RunMultipleTimes.java:44-48): independent seeds, one per core
     try:
         avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
@@ -156,19 +164,20 @@ def cpu_baseline(n_sample, workload="handel"):
         cores = max(1, min(len(os.sched_getaffinity(0)), 64, int(0.25 * avail / (64.0 * n_sample * n_sample + (1 << 30)))))
     except Exception:
         cores = 1
-    if cores > 1:
+    if cores > 1 and all_cores:
         def one(seed):
             cc = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                           hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0, seed=seed)
             t1 = time.perf_counter()
-            while cc.cont_if():
+            while cc.cont_if() and time.perf_counter() - t1 < budget_s:
                 cc.run_ms(10)
             return cc.info(False)["delivered"], t1, time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as ex:  # (ctypes releases the GIL inside the oracle)
             res = list(ex.map(one, range(1, cores + 1)))
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "delivered messages/s", "cores": cores,
-                            "sample": "%d independent seeds of the same %d-node run, one per core, run loops only" % (cores, n_sample)}
+                            "sample": "%d independent seeds of the same %d-node run (each bounded at %.0f s), one per core, run loops only"
+                                      % (cores, n_sample, budget_s)}
     return out
 
 
@@ -379,7 +388,7 @@ def main_shard(args):
                          "whole_run_achieved_GBs": alg_bytes / (elapsed * 1e9)},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes, "handel")
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nodes or n, "handel", args.cpu_sample_s)
         emit(out)
     dist.destroy_process_group()
 
@@ -435,8 +444,10 @@ def main():
                          "the sharing; three and more lose to their smaller launches")
     ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
                     "bounded by the box's cores and host memory)")
-    ap.add_argument("--cpu-sample-nodes", type=int, default=16384,
-                    help="nodes of the cpu_baseline sample run (the oracle on host cores; 16 384 nodes: ~ 20 s of one core, half the GPU workload's node count)")
+    ap.add_argument("--cpu-sample-nodes", type=int, default=0,
+                    help="nodes of the cpu_baseline sample run (the oracle on host cores); 0 = the GPU workload's own node count: the "
+                         "metric's configuration, run from t = 0 for --cpu-sample-s seconds of one core")
+    ap.add_argument("--cpu-sample-s", type=float, default=25.0, help="CPU work of the cpu_baseline sample, seconds per core")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second", action="store_true", help="skip the second_workload object (Casper IMD, config 5's node count)")
     ap.add_argument("--attesters-per-round", type=int, default=4096, help="--workload casper: attesters voting per slot")
@@ -681,10 +692,10 @@ def main():
                    "timed_loop_wall_s_incl_restores": wall_timed_loop,
                    "init_s_per_simulation": init_s, "init_wall_s": init_wall, "init_threads": threads,
                    "init_on_device": on_device,
-                   "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes),
+                   "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes or n, n) if gsf else (args.cpu_sample_nodes or n)),
                    "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WG_")}},
     }
-    # ---- roofline of the delivery pass (Handel: k_handel_lane + _copy + _update + _wave): algorithmic bytes of everything delivered
+    # ---- roofline of the delivery pass (Handel: k_handel_lane + _copy + _update + _dissem + _wave): algorithmic bytes of everything delivered
     # in the timed region / its launches, over its average duration measured with HIP events in the timed region
     if by_level is None:
         import numpy as np
@@ -696,20 +707,31 @@ def main():
     per_launch_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level_first))) / max(1, dk_spans)
     avg_ns = dk_ns / max(1, dk_spans)
     achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
-    traffic = traffic_source = None
+    traffic = traffic_source = whole_step_traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the rocprofv3 PMC passes
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
             traffic = tj.get("hbm_bytes_per_launch") * n_first / R
+            if tj.get("whole_step_hbm_bytes") and K > 0:
+                # every per-ms kernel of a step (not only the delivery pass) against the step's algorithmic bytes: the
+                # conditional-task phase, the ordering / append chain and the scans move bytes SURVEY.md §8d does not price
+                ws = float(tj["whole_step_hbm_bytes"])
+                whole_step_traffic = {"hbm_bytes_per_step": ws, "algorithmic_bytes_per_step": alg_bytes / K,
+                                      "ratio": ws / max(1.0, alg_bytes / K),
+                                      "fetch_bytes_per_step": tj.get("whole_step_fetch_bytes"),
+                                      "write_bytes_per_step": tj.get("whole_step_write_bytes")}
             # the counters cannot be read inside the timed run (rocprofv3 serialises kernels): they come from PMC passes of
             # the same command; tools/gpu_final_round.sh takes them in the session of the final line and stamps the commit
             traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, commit %s%s" % (
                 tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_copy + k_handel_update + k_handel_wave (the delivery pass: "
-                                                              "one launch of each per simulated ms)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_copy + k_handel_update + k_handel_dissem + k_handel_wave "
+                                                              "(the delivery pass: one launch of each per simulated ms, all five inside the HIP-event bracket and "
+                                                              "inside `traffic`)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+        "whole_step_traffic": whole_step_traffic,
+        "whole_step_frac": alg_bytes / (max(elapsed, 1e-9) * 1e9) / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
         "bytes_per_delivered_message": alg_bytes / max(1, delivered if world == 1 else int(by_level.sum())),
         "whole_run_achieved_GBs": alg_bytes / (max(elapsed, 1e-9) * 1e9),
@@ -738,7 +760,7 @@ def main():
                                                 "avg_launch_us": dp["total_ns"] / dp["spans"] / 1000.0,
                                                 "launches": dp["spans"]}
     if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_nodes, n) if gsf else args.cpu_sample_nodes, args.workload)
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_nodes or n, n) if gsf else (args.cpu_sample_nodes or n), args.workload, args.cpu_sample_s)
     log("msgReceived sum of the last step's copies: %d" % check)
     if world == 1 and not args.no_cpu and not args.no_second and not gsf:
         # BASELINE configs[4] beside the metric's own workload, in the same driver-run line: Casper IMD resident at

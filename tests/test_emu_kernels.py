@@ -84,6 +84,10 @@ def test_handel_256_chunks_of_10():
     th.lockstep(th.ratios(256), step=10)
 
 
+def test_handel_incremental_check_sigs_wave_items(monkeypatch):  # cached evaluations on the wave-per-item paths, vs the oracle
+    th.test_incremental_check_sigs_wave_items(monkeypatch, 512, "1", 1, 500, 0)
+
+
 def test_handel_emission_lists_on_the_device(monkeypatch):  # k_handel_init_sort / k_handel_init_shuffle vs the oracle's init()
     th.test_256_every_ms()
     th.test_emission_lists_built_on_the_device(1)

@@ -183,6 +183,17 @@ def test_attack_scenarios_resident_wide_levels(n, mode, max_ms):
     lockstep(ratios(n, dead=0.25), step=10, max_ms=max_ms, seed=3, **{mode: True})
 
 
+@pytest.mark.parametrize("n,lane_nw,step,max_ms,seed", [(512, "1", 1, 700, 0), (1024, "2", 7, 900, 2), (4096, "16", 10, 600, 1)])
+def test_incremental_check_sigs_wave_items(monkeypatch, n, lane_nw, step, max_ms, seed):
+    """checkSigs with cached evaluations (HandelState::qcache, round 4): a level's entries are re-evaluated only after an
+    updateVerifiedSignatures changed that level's sets, a new entry once — every other bestToVerify reads the cached keep /
+    score. WG_LANE_NW lowers the block width from which an item with something to evaluate is a WAVEFRONT's (h_best_wave,
+    k_handel_update, k_handel_copy) so that those paths run on networks whose upper levels are 2 … 8 words; the last case
+    has them at their real width (level 12 of 4096 nodes: 32 words). In lock-step with the oracle, which caches nothing."""
+    monkeypatch.setenv("WG_LANE_NW", lane_nw)
+    lockstep(ratios(n), step=step, max_ms=max_ms, seed=seed)
+
+
 def test_attack_parameter_checks():
     with pytest.raises(w.IllegalArgumentException):  # "Only one attack at a time" :123-125
         w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, byzantineSuicide=True, hiddenByzantine=True)

@@ -14,7 +14,8 @@ So for these kernels (scattered lines and lane-scattered words, no wide streams)
 bytes as they stand: `hbm_bytes_per_launch` = FETCH_SIZE + WRITE_SIZE; `..._reads_doubled` keeps the guide's x2 on
 the reads as the upper bound (it would apply only to the part of the reads that are 128-byte requests).
 usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json> [kernel patterns, comma-separated]
-(default patterns: Handel's delivery pass; Casper's: "k_casper_classify,k_casper_attestations,k_deliver<CasperProto")"""
+(default patterns: Handel's delivery pass — the five kernels bench.py's HIP events bracket; Casper's:
+"k_casper_classify,k_casper_attestations,k_deliver<CasperProto")"""
 import json
 import sys
 
@@ -30,20 +31,38 @@ def per_dispatch(path, counter, kernels):
     return tot
 
 
+def whole_step(path, counter):
+    """memory-side KB of ONE step (the passes run `bench.py --steps 1 --warmup 0`): the `sum` column over every per-ms kernel —
+    everything but init()'s kernels and the runtime's fill / copy kernels (uploads, wg_restore), which sit outside the timed region"""
+    tot, per = 0.0, {}
+    for line in open(path):
+        c = [x.strip() for x in line.strip().strip("|").split("|")]
+        if len(c) == 5 and c[1] == counter and "_init" not in c[0] and "__amd_rocclr" not in c[0]:
+            tot += float(c[3])
+            per[c[0].split("(")[0].replace("void ", "")] = float(c[3])
+    return tot, per
+
+
 def main():
     fetch, write, nodes, replicas, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_deliver_msgs<", "k_deliver<"]
+    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_handel_lane", "k_handel_copy", "k_handel_update<", "k_handel_dissem<", "k_handel_wave<"]
     f = per_dispatch(fetch, "FETCH_SIZE", kernels)
     w = per_dispatch(write, "WRITE_SIZE", kernels)
     rd = sum(f.values()) * 1024.0
     wr = sum(w.values()) * 1024.0
+    ws_f, ws_f_per = whole_step(fetch, "FETCH_SIZE")
+    ws_w, ws_w_per = whole_step(write, "WRITE_SIZE")
     import os
     json.dump({"nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"),
-               "kernels": ("k_deliver_msgs<HandelProto> + k_deliver<HandelProto> (one launch of each per simulated ms)"
-                           if len(sys.argv) <= 6 else " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)"),
+               "kernels": " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)",
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
                "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,
                "per_kernel_KB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
+               "whole_step_hbm_bytes": (ws_f + ws_w) * 1024.0,
+               "whole_step_fetch_bytes": ws_f * 1024.0, "whole_step_write_bytes": ws_w * 1024.0,
+               "whole_step_per_kernel_KB": {"FETCH_SIZE": ws_f_per, "WRITE_SIZE": ws_w_per},
+               "whole_step_note": "every per-ms kernel of one step (one RunMultipleTimes pass of the batch), init() and the "
+                                  "runtime's fill / copy kernels excluded",
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per dispatch means over the run; "
                        "calibrated on known byte counts in these access shapes (profiles/archive/r02b_pmc_calib.txt): scattered "
                        "64-byte-line reads and full-line writes count x1.00, a lane alone in its line counts the 64-byte "

@@ -356,16 +356,16 @@ int32_t wg_profile_read(wg_engine* h, wg_profile_entry* dst, int32_t cap, int32_
     dst[k].total_ns = E.profNs[c];
   }
 #ifdef WG_KPROF
-  static const char* kn[32] = {"kprof00 visits", "kprof01 cyc desc+node_begin", "kprof02 cyc events", "kprof03 cyc node_end",
+  static const char* kn[32] = {"kprof00 visits", "kprof01 a1 cyc lane-part wavefronts", "kprof02 a1 lane-part wavefronts", "kprof03 cyc node_end",
                                "kprof04 n on_message", "kprof05 cyc on_message", "kprof06 n dissemination",
                                "kprof07 cyc dissemination", "kprof08 cyc dissem fin-bits", "kprof09 cyc dissem snapshots",
                                "kprof10 cyc dissem sends", "kprof11 n update", "kprof12 cyc update",
-                               "kprof13 n dissem slow levels", "kprof14", "kprof15",
-                               "kprof16 a1 runners", "kprof17 a1 cyc header image", "kprof18 a1 levels", "kprof19 a1 cyc list entries",
-                               "kprof20 a1 cyc single-word levels", "kprof21 a1 multi-word entries", "kprof22 a1 cyc multi-word levels",
+                               "kprof13 n dissem slow levels", "kprof14 a1 lane items", "kprof15 a1 lane items' entries",
+                               "kprof16 a1 wave items", "kprof17 a1 lane entries evaluated (not cached)", "kprof18 a1 lane items with an evaluation", "kprof19 a1 cyc list entries",
+                               "kprof20 a1 wave items' entries", "kprof21 a1 wave entries evaluated", "kprof22 a1 cyc wave evaluations",
                                "kprof23 a1 cyc curation+store", "kprof24 msgs wave rounds", "kprof25 msgs cyc classify",
-                               "kprof26 msgs cyc lane messages", "kprof27 msgs cyc wide copies", "kprof28 msgs wide jobs",
-                               "kprof29 msgs wide words", "kprof30", "kprof31"};
+                               "kprof26 msgs cyc lane messages", "kprof27 a1 lane items of wide levels (all cached)", "kprof28 a1 lane items",
+                               "kprof29 a1 lane items' entries", "kprof30", "kprof31"};
   for (int c = 0; c < 32 && k < cap; c++, k++) {
     dst[k].name = kn[c];
     dst[k].spans = 1;

@@ -2237,6 +2237,7 @@ __global__ void k_handel_own_bits(HandelState s) {
   for (int l = 0; l < s.L; l++) {
     uint64_t* qr = h_qrec(s, node, l);
     qr[0] = qr[1] = 0;
+    qr[H_QVALID] = 0;
     qr[H_QBAD] = 0;
   }
 }
@@ -2335,6 +2336,9 @@ struct HandelHost : ProtoHost {
       off += (unsigned long long)nLoc * ql * nw;
     }
     st.qsig = e.dalloc<uint64_t>(off, false, Engine::AC_SCRATCH);
+    // the cached evaluations of the listed signatures (HandelState::qcache): read only where the record's valid mask says so
+    st.QC = (Q + 3) & ~3;
+    st.qcache = rows((uint32_t*)nullptr, (size_t)L * st.QC, false, Engine::AC_SCRATCH);
     {
       st.snapStride = N >= 128 ? (uint32_t)(N / 128) : 1u;  // words of the top level's block (N/2 ids)
       st.snapNb = (uint32_t)(e.dev.horizon / p.disseminationPeriodMs) + 2;  // a snapshot is read within < horizon ms
@@ -2359,9 +2363,11 @@ struct HandelHost : ProtoHost {
     st.disCount = e.dalloc<uint32_t>(1);
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
+    st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;
     st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 4;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
+    st.cleanMask = e.dalloc<uint32_t>(N);
     st.condList = e.dalloc<uint32_t>(N, true, Engine::AC_SCRATCH);
     st.drawVal = e.dalloc<int32_t>(N, true, Engine::AC_SCRATCH);
     const bool verbose = getenv("WG_INIT_VERBOSE") && atoi(getenv("WG_INIT_VERBOSE"));
@@ -2791,6 +2797,10 @@ struct HandelHost : ProtoHost {
     const int plane = field == WG_LF_POS_IN_LEVEL ? HP_POS : field == WG_LF_OUTGOING_FINISHED ? HP_OUTFIN
                       : field == WG_LF_SUICIDE_BIZ_AFTER ? HP_SPARE0 : -1;
     if (plane < 0) return false;
+    if (plane == HP_SPARE0 && st.atk != 1) {  // HLevel.suicideBizAfter is -1 without byzantineSuicide (:406); an honest run keeps
+      for (size_t i = 0; i < (size_t)n * L; i++) dst[i] = -1;  // the level's candidate summary in that plane (h_summary_has_candidate)
+      return true;
+    }
     const std::vector<uint32_t> h = read_hdr();
     for (int i = 0; i < n; i++)
       for (int l = 0; l < L; l++) dst[(size_t)i * L + l] = (int32_t)h[(size_t)i * st.hdrStride + HH_LV + l * HP_COUNT + plane];

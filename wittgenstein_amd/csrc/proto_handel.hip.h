@@ -45,8 +45,10 @@ namespace wg {
 constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks per node
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
-constexpr int H_QREC = 72;         // 64-bit words of a queue record: 2 + 64 entries, padded to whole 64-byte lines
-constexpr int H_QBAD = 66;         // word of the record: bit `slot` = that slot's signature is a bad one (SigToVerify.badSig)
+constexpr int H_QREC = 72;         // 64-bit words of a queue record: head, valid mask, 64 entries, bad mask — whole 64-byte lines
+constexpr int H_QVALID = 2;        // word of the record: bit `slot` = the evaluation cached for that slot's entry (qcache) still holds
+constexpr int H_QENT = 3;          // first entry of the list (the head, the valid mask and five entries are ONE 64-byte line)
+constexpr int H_QBAD = 67;         // word of the record: bit `slot` = that slot's signature is a bad one (SigToVerify.badSig)
 constexpr int H_LANE_NW = 16;      // level blocks of up to this many 64-bit words are worked on by ONE lane, which streams
                                    // them two words a load (levels <= 11); a wavefront per item spends ~ 25 wave-level memory
                                    // instructions on ONE item, and that instruction rate is what bounds those kernels
@@ -73,6 +75,7 @@ struct HandelState {
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
   int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
+  int32_t laneNw;                         // H_LANE_NW, or WG_LANE_NW (tests: the wave-per-item paths on networks the emulator can run)
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
   GP<const uint16_t> peers16;
@@ -92,6 +95,7 @@ struct HandelState {
   //                              protocol's deliveries and sends (C/Network.java:476-477,611-612): they change with the words
   //                              above, in the same line — not as four atomics into four more arrays (read back: node_counter)
   //   [HH_QMASK]                 bit l: level l's verification queue is not empty (what k_handel_cond_pre looks at)
+  //   [HH_QDIRTY]                bit l: level l's queue holds an entry whose evaluation is not cached (see qcache)
   //   [HH_LV + l*8 + plane]      level-major: the scalars of HLevel l side by side (32 bytes, two levels a 64-byte line) —
   //                              posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|, checkSigs' candidate of this
   //                              edge (signer << 8 | queue slot; valid where candMask[node] has the level's bit: written by
@@ -102,9 +106,23 @@ struct HandelState {
   // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a line of the record
   GP<uint32_t> ct;
   // toVerifyAgg of (node, level): a queue record of H_QREC 64-bit words — [0] list length, [1] signature slots in use,
-  // [2 + i] entry i in list order: rank << 32 | signer << 8 | slot. Length, slots and the first six entries are ONE
-  // 64-byte line: what a delivery appends to and checkSigs walks (it used to be a line in each of three arrays)
+  // [H_QVALID] slots whose cached evaluation holds, [H_QENT + i] entry i in list order: rank << 32 | signer << 8 | slot.
+  // Length, slots, valid mask and the first five entries are ONE 64-byte line: what a delivery appends to and checkSigs
+  // walks (it used to be a line in each of three arrays)
   GP<uint64_t> qrec;                      // [N][L][H_QREC]
+  // checkSigs made incremental (round 4). bestToVerify (:570-634) asks of every listed signature its sizeIfIncluded
+  // (:532-540) and its score (:655-668): functions of the signature — fixed when onNewSig lists it — and of the level's
+  // totalIncoming / verifiedIndSignatures / lastAggVerified, which change only when an updateVerifiedSignatures of THAT
+  // level runs (:690-754). So an entry's evaluation — keep (sizeIfIncluded > |totalIncoming|) and its score, were it
+  // inside the window — is computed once and kept per queue slot: qcache[(node * L + l) * QC + slot] = keep | score << 1,
+  // valid while bit `slot` of the record's H_QVALID word is set. onNewSig clears the bit of the slot it takes, an
+  // updateVerifiedSignatures that changes one of the level's three sets clears the whole word; the window, the ranks and
+  // the choice among the entries are evaluated afresh at every checkSigs, as before. A node's header word HH_QDIRTY has
+  // bit l set while level l holds an entry without a valid evaluation: k_handel_cond_pre routes the clean levels' items
+  // (every evaluation cached: one record line + one cache line, no row, no signature) to a lane each whatever the width
+  // of their block, and clears the word — k_handel_a1 leaves every entry of the edge's items evaluated.
+  GP<uint32_t> qcache;                    // [N][L][QC]
+  int32_t QC;                             // cache words per (node, level) = queue_cap
   GP<uint64_t> qsig;                      // per level l: [N][Q][nw(l)] at qsigOff[l]
   unsigned long long qsigOff[MAX_LEVELS];
   // dissemination snapshots (SendSigs.sigs = totalOutgoing.clone(), :254): a node disseminates exactly once
@@ -130,6 +148,7 @@ struct HandelState {
   int32_t disTier;                        // 0: off (WG_DIS_TIER=0): those nodes are visits of k_handel_wave as before
   GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
+  GP<uint32_t> cleanMask;                 // [N] ... of which: clean levels, answered from their summary by k_handel_cond_pre (no item)
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
   // node-range sharding (wg_shard_configure): this engine holds the per-node rows above only for the nodes
@@ -144,7 +163,7 @@ struct HandelState {
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_TOTAL = 7, HH_NRECV = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_BRECV = 12, HH_NSENT = 14,
-                       HH_SPARE = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_HB_LAST = 24, HH_HB_NOBYZ = 25, HH_BSENT = 30, HH_LV = 32 };
+                       HH_QDIRTY = 15, HH_PEND = 16, HH_PENDFROM = 20, HH_HB_LAST = 24, HH_HB_NOBYZ = 25, HH_BSENT = 30, HH_LV = 32 };
 // (HH_HB_*: HNode.hiddenByzantine's `last` — 0 = null, else (signer << 8 | slot) + 1 of the entry it planted — and
 // noByzantinePeers, P/Handel.java:840-843)
 // (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
@@ -527,6 +546,7 @@ struct HandelProtoT {
     const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
     uint64_t WG_G* qr = h_qrec(s, node, l);
     const HQHead qh = gld((const HQHead WG_G*)qr);
+    const uint64_t qvalid = qr[H_QVALID];
     const uint64_t WG_G* src = h_payload(c.d, s, payload);
     const int j0 = (int)WG_LANE;
     const bool has0 = j0 < v.nw;
@@ -552,13 +572,15 @@ struct HandelProtoT {
     for (int j = j0 + 64; j < v.nw; j += 64) dst[j] = src[j];
     __builtin_amdgcn_wave_barrier();  // every lane has read the record's head before lane 0 replaces it
     if (WG_LANE == 0) {
-      qr[2 + len] = h_entry(rank, from, slot);
+      qr[H_QENT + len] = h_entry(rank, from, slot);
       HQHead nh;
       nh.len = (uint64_t)(len + 1);
       nh.used = used | (1ULL << slot);
       gst((HQHead WG_G*)qr, nh);
+      if ((qvalid >> slot) & 1ULL) qr[H_QVALID] = qvalid & ~(1ULL << slot);  // the slot's cached evaluation was its previous entry's
       if (ATK) qr[H_QBAD] &= ~(1ULL << slot);  // badSig = false (ssigs.badSig is never set by a sender :786)
       ls->sc[HH_QMASK] |= 1u << l;
+      ls->sc[HH_QDIRTY] |= 1u << l;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -768,9 +790,9 @@ struct HandelProtoT {
     uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     const uint64_t tvv = ld_coherent(tvp);
     uint64_t WG_G* qr = h_qrec(s, node, lv);
-    uint64_t WG_G* ent = qr + 2;
+    uint64_t WG_G* ent = qr + H_QENT;
     const HQHead qh = gld((const HQHead WG_G*)qr);
-    const uint64_t entAll = ent[lane];  // (the whole list, before its length is known)
+    uint64_t entAll = lane < 13 ? ent[lane] : 0ULL;  // (the record's first two lines, before the list's length is known)
     const int j0 = lane;
     const bool has0 = j0 < v.nw;
     uint64_t sg0 = 0, vi0 = 0, la0 = 0, ti0 = 0;
@@ -794,6 +816,7 @@ struct HandelProtoT {
     if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     const int len = (int)qh.len;
+    if (len > 13) entAll = ent[lane];
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
     int newLen = len;
     {
@@ -877,6 +900,8 @@ struct HandelProtoT {
       nh.len = (uint64_t)newLen;
       nh.used = slot_pending(r, lv, slot) ? qh.used : (qh.used & ~(1ULL << slot));
       if (nh.len != qh.len || nh.used != qh.used) gst((HQHead WG_G*)qr, nh);
+      if (improved || !hadVI) qr[H_QVALID] = 0;  // one of the level's three sets changed: every cached evaluation of its entries is void
+      if (newLen > 0) ls->sc[HH_QDIRTY] |= 1u << lv;  // (the list lost an entry: the level's summary is stale either way)
     }
     __builtin_amdgcn_wave_barrier();
     if (!improved) return;
@@ -893,6 +918,7 @@ struct HLaneNode {
   long long doneAt, doneAt0;
   int32_t startAt, sigQueueSize, sigQueueSize0, msgFiltered, msgFiltered0;
   uint32_t qmask, qmask0;
+  uint32_t qdirty;  // levels that got an entry without a cached evaluation (HH_QDIRTY), OR-ed into the header at the end
   int32_t total, total0;
 };
 // work descriptor of the wave-per-node kernel (16 bytes): a node visit {node, vflags << 8, events, events the lane kernel
@@ -921,6 +947,7 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
   uint64_t WG_G* qr = h_qrec(s, node, l);
   const HQHead qh = gld((const HQHead WG_G*)qr);
+  const uint64_t qvalid = qr[H_QVALID];
   const unsigned long long used = qh.used;
   const int len = (int)qh.len;
   const uint64_t WG_G* src = h_payload(d, s, payload);
@@ -938,12 +965,14 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   }
   const int slot = __ffsll(freeM) - 1;
   uint64_t WG_G* dst = h_sig_ptr(s, node, l, slot);
-  qr[2 + len] = h_entry(rank, from, slot);  // (lists of up to six entries: the same line as the head)
+  qr[H_QENT + len] = h_entry(rank, from, slot);  // (lists of up to five entries: the same line as the head)
   HQHead nh;
   nh.len = (uint64_t)(len + 1);
   nh.used = used | (1ULL << slot);
   gst((HQHead WG_G*)qr, nh);
+  if ((qvalid >> slot) & 1ULL) qr[H_QVALID] = qvalid & ~(1ULL << slot);  // the slot's cached evaluation was its previous entry's
   r.qmask |= 1u << l;
+  r.qdirty |= 1u << l;
   if (nw == 1) {
     dst[0] = pw0;
   } else {
@@ -975,7 +1004,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   const uint64_t bit = 1ULL << (from & 63);
   uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
   uint64_t WG_G* qr = h_qrec(s, node, lv);
-  uint64_t WG_G* ent = qr + 2;
+  uint64_t WG_G* ent = qr + H_QENT;
   // ---- the loads that depend on the task's argument only, before the first use
   const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
   const U4 pfrom = gld((const U4 WG_G*)(hdr + HH_PENDFROM));
@@ -1066,6 +1095,8 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
     ti[jF] = tiF | bit;
   }
   if (!hadVI) vi[jF] = viF | bit;
+  if (improved || !hadVI) qr[H_QVALID] = 0;  // one of the level's three sets changed: every cached evaluation of its entries is void
+  if (nh.len > 0) r.qdirty |= 1u << lv;       // (the list lost an entry: the level's summary is stale either way)
   a.y = (uint32_t)cTI;
   a.z = (uint32_t)cLA;
   a.w = (uint32_t)cVI;
@@ -1162,7 +1193,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         } else if (kind == K_TASK && E[k].w2 == H_TASK_UPDATE) {
           nUpd++;
           const int unw = h_nw(H_ARG_LV(E[k].w3));
-          if (unw > H_LANE_NW) {
+          if (unw > s.laneNw) {
             if ((uint32_t)(k + 1) == cnt && unw <= H_UPD_NW)
               wideAt = k;
             else
@@ -1200,6 +1231,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     r.sigQueueSize = r.sigQueueSize0 = (int32_t)h0.y;
     r.msgFiltered = r.msgFiltered0 = (int32_t)h0.z;
     r.qmask = r.qmask0 = h2.w;
+    r.qdirty = 0;
     r.total = r.total0 = (int32_t)total;
     const bool toDown = (vflags & VD_DOWN) != 0;
     const uint8_t toPart = (uint8_t)(vflags >> 8);
@@ -1283,6 +1315,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       if (r.sigQueueSize != r.sigQueueSize0) hdr[HH_SIGQ] = (uint32_t)r.sigQueueSize;
       if (r.msgFiltered != r.msgFiltered0) hdr[HH_FILT] = (uint32_t)r.msgFiltered;
       if (r.qmask != r.qmask0) hdr[HH_QMASK] = r.qmask;
+      if (r.qdirty) atomicOr(F(hdr + HH_QDIRTY), r.qdirty);  // (no value comes back: the word is not among the pieces loaded)
       if (r.total != r.total0) hdr[HH_TOTAL] = (uint32_t)r.total;
       if (r.doneAt != r.doneAt0) {
         hdr[HH_DONE_LO] = (uint32_t)(unsigned long long)r.doneAt;
@@ -1380,7 +1413,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     const uint64_t bit = 1ULL << (from & 63);
     uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     uint64_t WG_G* qr = h_qrec(s, node, lv);
-    uint64_t WG_G* ent = qr + 2;
+    uint64_t WG_G* ent = qr + H_QENT;
     // ---- every load of the task (addresses from its argument alone), before the first use. The kernel is bound by its
     // wave-level memory instructions: the six 16-byte pieces of the header / level / record are ONE instruction (lane k
     // fetches piece k), the rows and the signature move two words a lane.
@@ -1392,7 +1425,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     U4 pg;
     pg.x = pg.y = pg.z = pg.w = 0;
     if (lane < 6) pg = gld(piece);
-    const uint64_t entAll = ent[lane];
+    // (the list: its first 13 entries are the record's first two lines; a longer one is fetched once its length is known)
+    uint64_t entAll = lane < 13 ? ent[lane] : 0ULL;
     const uint64_t tvv = ld_coherent(tvp);
     V2 sg[2], tiw[2], law[2], viw[2];
 #pragma unroll
@@ -1497,6 +1531,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     if (!hadVI && ownerLane) vi[jF] = viF | bit;
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     const int len = (int)qh.len;
+    if (len > 13) entAll = ent[lane];
     const uint64_t myEnt = lane < len ? entAll : ~0ULL;
     int newLen = len;
     bool emptied = false;
@@ -1523,6 +1558,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
       gst(lvA, a);
       if (total != (int)hT.w) hdr[HH_TOTAL] = (uint32_t)total;
       if (emptied) atomicAnd(F(hdr + HH_QMASK), ~(1u << lv));
+      if (improved || !hadVI) qr[H_QVALID] = 0;  // one of the level's three sets changed: every cached evaluation of its entries is void
+      if (newLen > 0) atomicOr(F(hdr + HH_QDIRTY), 1u << lv);  // (the list lost an entry: the level's summary is stale either way)
       // the entry's slot dies with this task unless another registered task still references it
       const uint32_t key = h_pend_word(lv, slot);
       const bool held = (pk != 0 && pend.x == key) || (pk != 1 && pend.y == key) || (pk != 2 && pend.z == key) || (pk != 3 && pend.w == key);
@@ -1709,6 +1746,75 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
   }
 }
 
+// the evaluation of ONE queue entry against the level's state — what bestToVerify (:570-634) asks of it, and what stays
+// true until the level's sets change (HandelState::qcache): bit 0 keep = sizeIfIncluded (:532-540) > |totalIncoming|,
+// bits 1.. its score (:655-668), which counts if the entry's rank is inside the window
+__device__ __forceinline__ uint32_t h_eval_word(int u1, int u2, int cs, bool iTI, bool iLA, int curSize, int cLA, int size) {
+  const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
+  const int score = cLA >= size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));  // score(l, sig) :655-668
+  return (sII > curSize ? 1u : 0u) | ((uint32_t)score << 1);
+}
+// rank <= windowIndex + currWindowSize (:597) in Java's int arithmetic (a saturated rank makes the sum wrap)
+__device__ __forceinline__ bool h_in_window(int rank, int windowIndex, int window) {
+  return rank <= (int)((uint32_t)windowIndex + (uint32_t)window);
+}
+
+// checkSigs looks at every level with a queue (:796-806), but only ONE level's candidate is used — the one the draw among
+// the levels that HAVE a candidate picks (:788-790). Whether a level has one follows from three numbers of its list while
+// the list and the level's sets stay as k_handel_a1 last saw them (the level is "clean", HH_QDIRTY): every listed entry
+// is then one the last curation kept, so windowIndex = the smallest rank, and bestToVerify returns something iff some
+// entry has a positive score (inside the window it is bestInside's, outside it bestOutside exists) or some entry lies
+// outside the window (largest rank > smallest rank + currWindowSize). The summary: HP_SPARE0 = smallest rank | (some
+// score > 0) << 31, HP_SPARE1 = largest rank (the two planes byzantineSuicide uses are free without the attack).
+// k_handel_cond_pre answers "has a candidate" for the clean levels from it; which entry it is is computed only for the
+// level the draw picked (h_pick_cached, k_handel_cond_a2).
+__device__ __forceinline__ bool h_summary_has_candidate(uint32_t sum0, uint32_t sum1, int window) {
+  return (sum0 >> 31) || !h_in_window((int)sum1, (int)(sum0 & 0x7FFFFFFFu), window);
+}
+// bestToVerify (:570-634) of a CLEAN level by one lane: every entry's evaluation is cached and kept. Returns signer << 8 | slot, or -1
+__device__ __forceinline__ long long h_pick_cached(const HandelState& s, int32_t node, int l, int window) {
+  const uint64_t WG_G* qr = h_qrec(s, node, l);
+  const uint64_t WG_G* ent = qr + H_QENT;
+  const uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
+  const HQHead qh = gld((const HQHead WG_G*)qr);
+  const uint64_t valid = qr[H_QVALID];
+  uint64_t e4[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) e4[i] = ent[i];
+  const U4 c4 = gld((const U4 WG_G*)cache);
+  const int len = (int)qh.len;
+  int windowIndex = INT32_MAX;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
+  for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
+  long long bestInside = -1, bestOutside = -1;
+  int bestScore = 0, bestOutsideRank = 0;
+  bool ok = true;
+  auto consider = [&](uint64_t x) {
+    const int slot = (int)(x & 0xFF);
+    const uint32_t cw = slot == 0 ? c4.x : slot == 1 ? c4.y : slot == 2 ? c4.z : slot == 3 ? c4.w : cache[slot];
+    ok = ok && ((valid >> slot) & 1ULL) && (cw & 1u);
+    const int rank = (int)(uint32_t)(x >> 32);
+    if (h_in_window(rank, windowIndex, window)) {
+      const int score = (int)(cw >> 1);
+      if (score > bestScore) {
+        bestScore = score;
+        bestInside = (long long)(uint32_t)x;
+      }
+    } else if (bestOutside < 0 || rank < bestOutsideRank) {
+      bestOutside = (long long)(uint32_t)x;
+      bestOutsideRank = rank;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < len) consider(e4[i]);
+  for (int i = 4; i < len; i++) consider(ent[i]);
+  if (!ok) return -1;  // (not a clean level: the caller reports it)
+  return bestInside >= 0 ? bestInside : bestOutside;
+}
+
 // ---- conditional-task phase (C/Network.java:543-566 driving HNode.checkSigs :796-837) -------------
 // PRE: which conditional tasks run at this edge — one lane per node, coalesced reads of the two dense words that
 // decide it. checkSigs looks at every level with a queue, and bestToVerify of one level (:570-634) depends on nothing
@@ -1733,7 +1839,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
     // at most once per call (epoch); evaluate only when minStartTime <= time.
     bool run = false;
-    uint32_t qm = 0;
+    uint32_t qm = 0, qd = 0;
     if (node < (uint32_t)s.hi) {
       uint32_t WG_G* ct = s.ct + 2 * (size_t)node;
       uint32_t WG_G* h = h_hdr(s, (int32_t)node);
@@ -1750,16 +1856,34 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
         // sigQueueSize drifts above the real queue lengths: checkSigs then runs over empty
         // lists, finds no candidate, draws nothing and changes nothing (:800-806) — such a node has no item
         qm = h[HH_QMASK] & ~1u;
+        // levels holding an entry whose evaluation is not cached: this edge's k_handel_a1 evaluates them all (HandelState::qcache)
+        qd = h[HH_QDIRTY];
+        if (qd) h[HH_QDIRTY] = 0;
       }
-      s.candMask[node] = 0;
+      // the clean levels: whether bestToVerify would return something, from the level's summary — no item, no list read.
+      // Which entry it is is computed for the level the draw picks (k_handel_cond_a2: h_pick_cached)
+      uint32_t cmClean = 0;
+      if (s.atk) qd = qm;  // (an attack's run: every level an item, nothing cached)
+      if (qm & ~qd) {
+        const int window = (int)h[HH_WINDOW];
+        for (uint32_t m = qm & ~qd; m; m &= m - 1) {
+          const int l = __ffs(m) - 1;
+          const U4 b = gld((const U4 WG_G*)h_lv(s, (int32_t)node, HP_CAND, l));  // {candidate, outgoingFinished, summary}
+          if (h_summary_has_candidate(b.z, b.w, window)) cmClean |= 1u << l;
+        }
+      }
+      s.candMask[node] = cmClean;
+      s.cleanMask[node] = cmClean;
+      qm &= qd;  // the items: the levels with something to evaluate
     }
     // the node's items: one per level with a queue, appended BLOCK-aggregated — one atomic per list and block. (One per
     // wavefront was 512 same-address atomics per list and engine in every ms: an L2 atomic unit retires ~ 88 of those per
     // us, and every wavefront waited for its turn: 22 -> 15 us per ordinary ms at 24 copies.)
+    // A level with something to evaluate is a lane's item while its block is <= H_LANE_NW words and a wavefront's beyond.
     uint32_t mLane = 0, mWave = 0;
     for (uint32_t m = qm; m; m &= m - 1) {
       const int l = __ffs(m) - 1;
-      if (h_nw(l) <= H_LANE_NW && !s.atk)  // (byzantineSuicide: every item by a wavefront)
+      if (!s.atk && h_nw(l) <= s.laneNw)  // (an attack's run: every item by a wavefront)
         mLane |= 1u << l;
       else
         mWave |= 1u << l;
@@ -1792,28 +1916,18 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   }
 }
 
-// score / curation of ONE queue entry against the level's state: what bestToVerify (:570-634) needs of it
-struct HEntryEval {
-  bool keep, inside;
-  int score;
-};
-__device__ __forceinline__ HEntryEval h_eval_entry(int u1, int u2, int cs, bool iTI, bool iLA, int curSize, int cLA, int size,
-                                                   int rank, int windowIndex, int window) {
-  HEntryEval ev;
-  const int sII = iTI ? u2 : u1;  // sizeIfIncluded :532-540
-  ev.keep = sII > curSize;
-  ev.inside = ev.keep && rank <= windowIndex + window;
-  ev.score = 0;  // score(l, sig) :655-668
-  if (ev.inside) ev.score = cLA >= size ? 0 : (!iLA ? cLA + cs : max(0, u2 - cLA));
-  return ev;
-}
-
 // the end of an item: the curated list's bookkeeping and the level's candidate (`cand`: signer << 8 | slot of the chosen
 // entry, or -1). `relMask`: queue slots of dropped entries no registered task holds; several items of one node run
 // concurrently (other levels), so the node's shared words are updated with atomics; the record's head is the item's own.
+// `sum0 / sum1`: the level's summary over the entries that stay listed (h_summary) — what the following edges read
+// instead of the list while the level stays clean.
 __device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node, int l, uint64_t WG_G* qr, HQHead qh, int len,
-                                              int kept, unsigned long long relMask, long long cand) {
+                                              int kept, unsigned long long relMask, long long cand, uint32_t sum0, uint32_t sum1) {
   uint32_t WG_G* hdr = h_hdr(s, node);
+  if (!s.atk && kept > 0) {
+    *h_lv(s, node, HP_SPARE0, l) = sum0;
+    *h_lv(s, node, HP_SPARE1, l) = sum1;
+  }
   if (kept != len) {  // replaceToVerifyAgg :636-646
     qh.len = (uint64_t)kept;
     qh.used &= ~relMask;
@@ -1827,8 +1941,10 @@ __device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node
   }
 }
 
-// bestToVerify (:570-634) of (node, l) by one wavefront: lanes = 64-bit words of the level's block. Curates the list and
-// records the level's candidate (h_item_finish); returns it (signer << 8 | slot) or -1.
+// bestToVerify (:570-634) of (node, l) by one wavefront: lanes = 64-bit words of the level's block while an entry is
+// evaluated, lane i = entry i of the list for everything else. Curates the list and records the level's candidate
+// (h_item_finish); returns it (signer << 8 | slot) or -1. Only the entries without a cached evaluation have their
+// signature read (HandelState::qcache; an attack's run caches nothing and evaluates them all).
 template <bool ATK>
 __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const HandelState& s, int32_t node, int l) {
   const int lane = WG_LANE;
@@ -1840,18 +1956,21 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
   const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
   const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
   uint64_t WG_G* qr = h_qrec(s, node, l);
-  uint64_t WG_G* ent = qr + 2;
+  uint64_t WG_G* ent = qr + H_QENT;
+  uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
   // ---- everything the item's address alone decides, before the first use. These kernels are bound by the number of
-  // wave-level memory instructions, so: the four 16-byte pieces (pending table, the header words with the window, the
-  // level's scalars, the record's head) are ONE instruction — lane k fetches piece k —, the list is one (lane i = entry
-  // i), and the rows and signatures move two words a lane (blocks of <= 256 words: two instructions an array at most)
+  // wave-level memory instructions, so: the five 16-byte pieces (pending table, the header words with the window, the
+  // level's scalars, the record's head, its valid mask) are ONE instruction — lane k fetches piece k —, the list is one
+  // (lane i = entry i; the record's first two lines, a longer list is fetched once its length is known), and the rows and
+  // signatures move two words a lane (blocks of <= 256 words: two instructions an array at most)
   const U4 WG_G* piece = lane == 0 ? (const U4 WG_G*)(hdr + HH_PEND)
                          : lane == 1 ? (const U4 WG_G*)(hdr + 4)
-                         : lane == 2 ? (const U4 WG_G*)h_lv(s, node, HP_POS, l) : (const U4 WG_G*)qr;
+                         : lane == 2 ? (const U4 WG_G*)h_lv(s, node, HP_POS, l)
+                         : lane == 3 ? (const U4 WG_G*)qr : (const U4 WG_G*)(qr + H_QVALID);
   U4 pg;
   pg.x = pg.y = pg.z = pg.w = 0;
-  if (lane < 4) pg = gld(piece);
-  const uint64_t entAll = ent[lane];
+  if (lane < 5) pg = gld(piece);
+  uint64_t entAll = lane < 13 ? ent[lane] : 0ULL;
   const bool wideRound = v.nw <= 256;  // (levels <= 15; beyond: the word loop below)
   V2 ti2[2], vi2[2], la2[2];
 #pragma unroll
@@ -1880,10 +1999,14 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
   HQHead qh;
   qh.len = (uint64_t)WG_READLANE(pg.x, 3) | ((uint64_t)WG_READLANE(pg.y, 3) << 32);
   qh.used = (uint64_t)WG_READLANE(pg.z, 3) | ((uint64_t)WG_READLANE(pg.w, 3) << 32);
+  const uint64_t valid0 = ATK ? 0ULL : ((uint64_t)WG_READLANE(pg.x, 4) | ((uint64_t)WG_READLANE(pg.y, 4) << 32));
   const int len = (int)qh.len;
+  if (len > 13) entAll = ent[lane];
   const uint64_t myEnt = lane < len ? entAll : ~0ULL;
   const int mySlot = lane < len ? (int)(myEnt & 0xFF) : 0;
   const int myRank = lane < len ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+  const bool myValid = lane < len && ((valid0 >> mySlot) & 1ULL);
+  uint32_t myCw = myValid ? cache[mySlot] : 0u;  // keep | score << 1 of my entry (the others: evaluated below)
   KPROF_MARK(d.g, 19);  // the item's header pieces, list and row words
   const int windowIndex = wave_reduce_min_i32(myRank);  // Collections.min(rank)
   uint64_t blkM = 0;  // entries whose signer is blacklisted (:592 `!blacklist.get(stv.from)`)
@@ -1943,35 +2066,35 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
     const bool myBlk = lane < len && HandelProtoT<true>::blk(s, node, (int32_t)((myEnt >> 8) & 0xFFFFFFu));
     blkM = __ballot(myBlk);
   }
-  long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
-  int bestScore = 0, bestOutsideRank = 0;
-  uint64_t keep = 0;
-  for (int i0 = 0; i0 < len; i0 += 2) {  // two entries' signatures in flight at a time
+  // ---- the entries without a cached evaluation: their signatures against the level's three sets, two entries in flight
+  const uint64_t inv = __ballot(lane < len && !myValid);
+  uint64_t newValid = valid0;
+  for (uint64_t m = inv; m;) {
     V2 sg[2][2];
-    int slotU[2], rankU[2];
-    uint32_t whoU[2];
+    int posU[2], slotU[2];
+    posU[0] = __ffsll((unsigned long long)m) - 1;
+    m &= m - 1;
+    const bool two = m != 0;
+    posU[1] = two ? __ffsll((unsigned long long)m) - 1 : posU[0];
+    if (two) m &= m - 1;
 #pragma unroll
     for (int e2 = 0; e2 < 2; e2++) {
-      const int i = i0 + e2 < len ? i0 + e2 : len - 1;
-      whoU[e2] = lane_bcast((uint32_t)myEnt, i);  // signer << 8 | slot
-      slotU[e2] = (int)(whoU[e2] & 0xFFu);
-      rankU[e2] = (int)lane_bcast((uint32_t)myRank, i);
+      slotU[e2] = (int)(lane_bcast((uint32_t)myEnt, posU[e2]) & 0xFFu);
       const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = 2 * (u * 64 + lane);
         sg[e2][u].x = sg[e2][u].y = 0;
         if (ATK && v.nw == 1) {
-          if (j == 0 && i0 + e2 < len) sg[e2][u].x = sig[0];
-        } else if (wideRound && j < v.nw && i0 + e2 < len) {
+          if (j == 0 && (e2 == 0 || two)) sg[e2][u].x = sig[0];
+        } else if (wideRound && j < v.nw && (e2 == 0 || two)) {
           sg[e2][u] = gld((const V2 WG_G*)(sig + j));
         }
       }
     }
 #pragma unroll
     for (int e2 = 0; e2 < 2; e2++) {
-      const int i = i0 + e2;
-      if (i >= len) break;
+      if (e2 == 1 && !two) break;
       uint64_t a = 0, b = 0;
       auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
         a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
@@ -1991,24 +2114,38 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
       b = wave_sum64(b);
       const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
       const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-      HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rankU[e2], windowIndex, window);
-      if (ATK && ((blkM >> i) & 1ULL)) ev.keep = ev.inside = false;
-      if (ev.keep) {
-        keep |= 1ULL << i;
-        if (ev.inside) {
-          if (ev.score > bestScore) {
-            bestScore = ev.score;
-            bestInside = (long long)whoU[e2];
-          }
-        } else if (bestOutside < 0 || rankU[e2] < bestOutsideRank) {
-          bestOutside = (long long)whoU[e2];
-          bestOutsideRank = rankU[e2];
-        }
+      const uint32_t cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
+      if (lane == posU[e2]) {
+        myCw = cw;
+        if (!ATK) cache[slotU[e2]] = cw;
       }
+      newValid |= 1ULL << slotU[e2];
     }
   }
-  KPROF_ADD(d.g, 21, len);
-  KPROF_MARK(d.g, 22);  // the entries (kprof21: how many)
+  KPROF_ADD(d.g, 21, __popcll(inv));
+  KPROF_ADD(d.g, 20, len);
+  KPROF_MARK(d.g, 22);  // the entries (kprof21: how many were evaluated)
+  // ---- the choice, lane i = entry i: the curated list keeps the entries that can improve the aggregate (:592); the best
+  // inside the window is the FIRST entry with the strictly greatest positive score, the best outside the FIRST with the
+  // smallest rank (:597-611)
+  const bool myKeep = lane < len && (myCw & 1u) && !(ATK && ((blkM >> lane) & 1ULL));
+  const bool myInside = myKeep && h_in_window(myRank, windowIndex, window);
+  const int myScore = (int)(myCw >> 1);
+  const uint64_t keep = __ballot(myKeep);
+  long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
+  {
+    const int top = wave_reduce_max_i32(myInside ? myScore : 0);
+    if (top > 0) {
+      const uint64_t hm = __ballot(myInside && myScore == top);
+      bestInside = (long long)lane_bcast((uint32_t)myEnt, __ffsll((unsigned long long)hm) - 1);
+    }
+    const uint64_t om = __ballot(myKeep && !myInside);
+    if (bestInside < 0 && om) {
+      const int lo = wave_reduce_min_i32(myKeep && !myInside ? myRank : INT32_MAX);
+      const uint64_t hm = __ballot(myKeep && !myInside && myRank == lo);
+      bestOutside = (long long)lane_bcast((uint32_t)myEnt, __ffsll((unsigned long long)hm) - 1);
+    }
+  }
   const int kept = __popcll(keep);
   unsigned long long relMask = 0;
   if (kept != len) {  // replaceToVerifyAgg :636-646
@@ -2020,15 +2157,24 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
     const uint64_t rel = __ballot(lane < len && !mineKept && !held);
     for (uint64_t m = rel; m; m &= m - 1) relMask |= 1ULL << lane_bcast((uint32_t)mySlot, __ffsll((unsigned long long)m) - 1);
   }
+  uint32_t sum0 = 0, sum1 = 0;
+  if (!ATK && kept > 0) {  // the level's summary over the entries that stay listed (h_summary_has_candidate)
+    sum0 = (uint32_t)wave_reduce_min_i32(myKeep ? myRank : INT32_MAX) | (__ballot(myKeep && myScore > 0) ? 0x80000000u : 0u);
+    sum1 = (uint32_t)wave_reduce_max_i32(myKeep ? myRank : 0);
+  }
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+  if (lane == 0) {
+    if (!ATK && newValid != valid0) qr[H_QVALID] = newValid;
+    h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside, sum0, sum1);
+  }
   KPROF_MARK(d.g, 23);  // list curation, candidate
   return bestInside >= 0 ? bestInside : bestOutside;
 }
 
 // A1: bestToVerify (:570-634) of one (runner, level) item: curates the level's list, records its candidate.
-// Blocks [0, gridDim.x / 4) take the items of the narrow levels one LANE each, the others the wide levels' items one
-// WAVEFRONT each — one launch, both kinds of chains in flight together.
+// Blocks [0, gridDim.x * share / 16) take one LANE per item — the items whose every entry has a cached evaluation
+// (any level) and the items of the narrow levels —, the others one WAVEFRONT per item of a wide level with something to
+// evaluate — one launch, both kinds of chains in flight together.
 template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -2036,7 +2182,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
   const int lane = WG_LANE;
   const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;  // (default 4/16)
   if (blockIdx.x < laneBlocks) {
-    // ---------------- one lane per item: blocks of <= H_LANE_NW words ----------------
+    // ---------------- one lane per item ----------------
+    KPROF_DECL;
     const uint32_t nItems = s.itemCount[0];
     const uint32_t stride = laneBlocks * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nItems; q += stride) {
@@ -2049,15 +2196,18 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
       const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
       uint64_t WG_G* qr = h_qrec(s, node, l);
-      uint64_t WG_G* ent = qr + 2;
-      // ---- everything the item's address alone decides, before the first use
-      const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+      uint64_t WG_G* ent = qr + H_QENT;
+      uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
+      // ---- everything the item's address alone decides, before the first use: the record's first line (head, valid mask,
+      // four entries) and the cached evaluations of the slots 0 .. 3 (slots are taken lowest first: those are the usual ones)
       const int window = (int)hdr[HH_WINDOW];
       const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
       const HQHead qh = gld((const HQHead WG_G*)qr);
+      const uint64_t valid0 = qr[H_QVALID];
       uint64_t e4[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) e4[i] = ent[i];
+      const U4 c4 = gld((const U4 WG_G*)cache);
       const int len = (int)qh.len, curSize = (int)lvA.y, cLA = (int)lvA.z;
       int windowIndex = INT32_MAX;  // Collections.min(rank)
 #pragma unroll
@@ -2067,28 +2217,44 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
       int bestScore = 0, bestOutsideRank = 0;
       unsigned long long keep = 0;
-      // one entry after the other, its signature streamed against the level's three sets (whose lines stay in L1)
+      uint64_t newValid = valid0;
+      int sumMin = INT32_MAX, sumMax = 0;  // the level's summary over the entries that stay listed (h_summary_has_candidate)
+      bool sumPos = false;
+      // one entry after the other: its cached evaluation, or its signature streamed against the level's three sets (whose
+      // lines stay in L1) and the result cached
       auto consider = [&](int i, uint64_t x) {
-        int u1 = 0, u2 = 0, cs = 0;
-        bool iTI = false, iLA = false;
-        h_stream4(h_sig_ptr(s, node, l, (int)(x & 0xFF)), ti, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
-          tiw &= v.mask;
-          viw &= v.mask;
-          law &= v.mask;
-          u1 += __popcll(sg | tiw | viw);
-          u2 += __popcll(sg | viw);
-          cs += __popcll(sg);
-          iTI |= (sg & tiw) != 0;
-          iLA |= (sg & law) != 0;
-        });
+        const int slot = (int)(x & 0xFF);
+        uint32_t cw;
+        if ((valid0 >> slot) & 1ULL) {
+          cw = slot == 0 ? c4.x : slot == 1 ? c4.y : slot == 2 ? c4.z : slot == 3 ? c4.w : cache[slot];
+        } else {
+          int u1 = 0, u2 = 0, cs = 0;
+          bool iTI = false, iLA = false;
+          h_stream4(h_sig_ptr(s, node, l, slot), ti, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
+            tiw &= v.mask;
+            viw &= v.mask;
+            law &= v.mask;
+            u1 += __popcll(sg | tiw | viw);
+            u2 += __popcll(sg | viw);
+            cs += __popcll(sg);
+            iTI |= (sg & tiw) != 0;
+            iLA |= (sg & law) != 0;
+          });
+          cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
+          cache[slot] = cw;
+          newValid |= 1ULL << slot;
+        }
         const long long who = (long long)(uint32_t)x;  // signer << 8 | slot
         const int rank = (int)(uint32_t)(x >> 32);
-        const HEntryEval ev = h_eval_entry(u1, u2, cs, iTI, iLA, curSize, cLA, v.size, rank, windowIndex, window);
-        if (ev.keep) {
+        if (cw & 1u) {  // only signatures that can result in a better aggregate stay listed (:592)
           keep |= 1ULL << i;
-          if (ev.inside) {  // best inside = FIRST entry with the strictly greatest positive score
-            if (ev.score > bestScore) {
-              bestScore = ev.score;
+          sumMin = min(sumMin, rank);
+          sumMax = max(sumMax, rank);
+          sumPos |= (cw >> 1) != 0;
+          if (h_in_window(rank, windowIndex, window)) {  // best inside = FIRST entry with the strictly greatest positive score
+            const int score = (int)(cw >> 1);
+            if (score > bestScore) {
+              bestScore = score;
               bestInside = who;
             }
           } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
@@ -2104,6 +2270,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
       const int kept = __popcll(keep);
       unsigned long long relMask = 0;
       if (kept != len) {
+        const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
         int pos = 0;
         auto curate = [&](int i, uint64_t x) {
           if ((keep >> i) & 1ULL) {
@@ -2119,8 +2286,22 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
           if (i < len) curate(i, e4[i]);
         for (int i = 4; i < len; i++) curate(i, ent[i]);
       }
-      h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside);
+      if (newValid != valid0) qr[H_QVALID] = newValid;
+      h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside,
+                    (uint32_t)sumMin | (sumPos ? 0x80000000u : 0u), (uint32_t)sumMax);
+#ifdef WG_KPROF
+      {  // how much of checkSigs the cached evaluations serve (tools/kprof.sh)
+        const int miss = __popcll(newValid & ~valid0);
+        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 28]), 1ULL);
+        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 29]), (unsigned long long)len);
+        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 17]), (unsigned long long)miss);
+        if (miss) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 18]), 1ULL);
+        if (v.nw > s.laneNw) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 27]), 1ULL);
+      }
+#endif
     }
+    KPROF_MARK(d.g, 1);   // a lane-part wavefront, start to end
+    KPROF_COUNT(d.g, 2);  // ... how many
     return;
   }
   // ---------------- one wavefront per item: lanes = 64-bit words of the level's block ----------------
@@ -2192,7 +2373,7 @@ __global__ void __launch_bounds__(256) k_handel_hidden(const EngineDev* __restri
       continue;
     }
     uint64_t WG_G* qr = h_qrec(s, node, top);
-    uint64_t WG_G* ent = qr + 2;
+    uint64_t WG_G* ent = qr + H_QENT;
     const int len = (int)qr[0];
     const unsigned long long used = qr[1];
     const uint64_t myEnt = lane < len ? ent[lane] : ~0ULL;
@@ -2311,7 +2492,16 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       uint32_t cm = s.candMask[node];
       for (int q = 0; q < k; q++) cm &= cm - 1;
       const int l = __ffs(cm) - 1;
-      const uint32_t who = *h_lv(s, node, HP_CAND, l);  // the level's candidate: signer << 8 | queue slot (h_item_finish)
+      // the level's candidate, signer << 8 | queue slot: recorded by this edge's item (h_item_finish), or — a clean level,
+      // which had no item — picked now from the cached evaluations
+      uint32_t who;
+      if ((s.cleanMask[node] >> l) & 1u) {
+        const long long pick = h_pick_cached(s, node, l, (int)h[HH_WINDOW]);
+        if (pick < 0) set_err(d.g, ERR_PROTOCOL);
+        who = (uint32_t)pick;
+      } else {
+        who = *h_lv(s, node, HP_CAND, l);
+      }
       const int slot = (int)(who & 0xFFu);
       const int32_t from = (int32_t)(who >> 8);
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
