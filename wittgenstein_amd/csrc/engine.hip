@@ -2264,7 +2264,7 @@ struct HandelHost : ProtoHost {
   // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
   // tuning knobs, see DESIGN.md "Occupancy"
   int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
-  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 4;  // (k_handel_a1: 110 VGPRs, no scratch; five waves spill)
+  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 6;  // (k_handel_a1w: 79 VGPRs, no scratch; eight waves spill 44 B)
   int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
   int wavesDissem = getenv("WG_DISSEM_WAVES") ? atoi(getenv("WG_DISSEM_WAVES")) : 8;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
@@ -2364,7 +2364,7 @@ struct HandelHost : ProtoHost {
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
     st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;
-    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 4;
+    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 6;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.cleanMask = e.dalloc<uint32_t>(N);
@@ -2637,21 +2637,26 @@ struct HandelHost : ProtoHost {
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
   template <int W>
-  void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
-    hipLaunchKernelGGL((k_handel_a1<W, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+  void launch_a1w(const Group& g, const HandelState* stab, int R, hipStream_t s) {
+    hipLaunchKernelGGL((k_handel_a1w<W, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
   }
   int variant() const override { return st.atk; }
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
-    if (st.atk) {  // byzantineSuicide: the instantiations with the attack's paths (every item a wavefront)
-      hipLaunchKernelGGL((k_handel_a1<4, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+    if (st.atk) {  // an attack's run: the instantiation with the attack's paths, every item a wavefront
+      hipLaunchKernelGGL((k_handel_a1w<4, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
       return;
     }
+    if (!a1Split) {  // both kinds of items in one launch (4 waves a SIMD: the lane half's registers)
+      hipLaunchKernelGGL((k_handel_a1c<4>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+      return;
+    }
+    // the narrow levels' items, one lane each (~ 5 k an engine in an ordinary ms of config 3), then the wide levels', one wavefront each
+    hipLaunchKernelGGL(k_handel_a1, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
     switch (wavesCond) {
-      case 8: launch_a1<8>(g, stab, R, s); break;
-      case 6: launch_a1<6>(g, stab, R, s); break;
-      case 5: launch_a1<5>(g, stab, R, s); break;
-      case 3: launch_a1<3>(g, stab, R, s); break;
-      default: launch_a1<4>(g, stab, R, s);
+      case 8: launch_a1w<8>(g, stab, R, s); break;
+      case 5: launch_a1w<5>(g, stab, R, s); break;
+      case 4: launch_a1w<4>(g, stab, R, s); break;
+      default: launch_a1w<6>(g, stab, R, s);
     }
   }
   void launch_cond(Engine& profOwner, const Group& g) override {
@@ -2710,6 +2715,9 @@ struct HandelHost : ProtoHost {
   }
   // k_handel_a1 alone wants more blocks than the delivery kernels (its lane-item blocks hold 256 items each and an ordinary
   // ms has ~ 10 k of them per engine): WG_A1_GRID=<blocks per engine>, default a multiple of node_grid (WG_A1_GRID_MUL)
+  // (measured, profiles/r13h_*: as two launches 44 + 33 us per ordinary ms — the lane half is one long chain whatever its grid —
+  // against ~ 70 us for the one launch in which the two halves overlap; WG_A1_SPLIT=1 keeps the two-launch form)
+  bool a1Split = getenv("WG_A1_SPLIT") && atoi(getenv("WG_A1_SPLIT")) != 0;
   int a1GridEnv = getenv("WG_A1_GRID") ? atoi(getenv("WG_A1_GRID")) : 0;
   int a1GridMul = getenv("WG_A1_GRID_MUL") && atoi(getenv("WG_A1_GRID_MUL")) > 0 ? atoi(getenv("WG_A1_GRID_MUL")) : 2;
   int a1_grid(int R) const { return a1GridEnv > 0 ? a1GridEnv : a1GridMul * node_grid(R); }

@@ -2066,61 +2066,48 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
     const bool myBlk = lane < len && HandelProtoT<true>::blk(s, node, (int32_t)((myEnt >> 8) & 0xFFFFFFu));
     blkM = __ballot(myBlk);
   }
-  // ---- the entries without a cached evaluation: their signatures against the level's three sets, two entries in flight
+  // ---- the entries without a cached evaluation: their signatures against the level's three sets, one after the other
+  // (an item usually has ONE: the entry that arrived since the last edge — the kernel's residency is worth more than a
+  // second signature in flight)
   const uint64_t inv = __ballot(lane < len && !myValid);
   uint64_t newValid = valid0;
-  for (uint64_t m = inv; m;) {
-    V2 sg[2][2];
-    int posU[2], slotU[2];
-    posU[0] = __ffsll((unsigned long long)m) - 1;
-    m &= m - 1;
-    const bool two = m != 0;
-    posU[1] = two ? __ffsll((unsigned long long)m) - 1 : posU[0];
-    if (two) m &= m - 1;
-#pragma unroll
-    for (int e2 = 0; e2 < 2; e2++) {
-      slotU[e2] = (int)(lane_bcast((uint32_t)myEnt, posU[e2]) & 0xFFu);
-      const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
+  for (uint64_t m = inv; m; m &= m - 1) {
+    const int pos = __ffsll((unsigned long long)m) - 1;
+    const int slot = (int)(lane_bcast((uint32_t)myEnt, pos) & 0xFFu);
+    const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slot);
+    uint64_t a = 0, b = 0;
+    auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
+      a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
+      b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
+    };
+    if (ATK && v.nw == 1) {
+      if (lane == 0) word(sig[0], ti2[0].x, vi2[0].x, la2[0].x);
+    } else if (wideRound) {
+      V2 sg[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = 2 * (u * 64 + lane);
-        sg[e2][u].x = sg[e2][u].y = 0;
-        if (ATK && v.nw == 1) {
-          if (j == 0 && (e2 == 0 || two)) sg[e2][u].x = sig[0];
-        } else if (wideRound && j < v.nw && (e2 == 0 || two)) {
-          sg[e2][u] = gld((const V2 WG_G*)(sig + j));
-        }
+        sg[u].x = sg[u].y = 0;
+        if (j < v.nw) sg[u] = gld((const V2 WG_G*)(sig + j));
       }
-    }
 #pragma unroll
-    for (int e2 = 0; e2 < 2; e2++) {
-      if (e2 == 1 && !two) break;
-      uint64_t a = 0, b = 0;
-      auto word = [&](uint64_t sgw, uint64_t tiw, uint64_t viw, uint64_t law) {
-        a += (uint64_t)__popcll(sgw | tiw | viw) | ((uint64_t)__popcll(sgw | viw) << 21) | ((uint64_t)__popcll(sgw) << 42);
-        b += (uint64_t)((sgw & tiw) != 0) | ((uint64_t)((sgw & law) != 0) << 21);
-      };
-      if (wideRound) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {  // (words beyond the block are zero in every array: they add nothing)
-          word(sg[e2][u].x, ti2[u].x, vi2[u].x, la2[u].x);
-          word(sg[e2][u].y, ti2[u].y, vi2[u].y, la2[u].y);
-        }
-      } else {
-        const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slotU[e2]);
-        H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
+      for (int u = 0; u < 2; u++) {  // (words beyond the block are zero in every array: they add nothing)
+        word(sg[u].x, ti2[u].x, vi2[u].x, la2[u].x);
+        word(sg[u].y, ti2[u].y, vi2[u].y, la2[u].y);
       }
-      a = wave_sum64(a);
-      b = wave_sum64(b);
-      const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
-      const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
-      const uint32_t cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
-      if (lane == posU[e2]) {
-        myCw = cw;
-        if (!ATK) cache[slotU[e2]] = cw;
-      }
-      newValid |= 1ULL << slotU[e2];
+    } else {
+      H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
     }
+    a = wave_sum64(a);
+    b = wave_sum64(b);
+    const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
+    const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
+    const uint32_t cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
+    if (lane == pos) {
+      myCw = cw;
+      if (!ATK) cache[slot] = cw;
+    }
+    newValid |= 1ULL << slot;
   }
   KPROF_ADD(d.g, 21, __popcll(inv));
   KPROF_ADD(d.g, 20, len);
@@ -2171,22 +2158,18 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
   return bestInside >= 0 ? bestInside : bestOutside;
 }
 
-// A1: bestToVerify (:570-634) of one (runner, level) item: curates the level's list, records its candidate.
-// Blocks [0, gridDim.x * share / 16) take one LANE per item — the items whose every entry has a cached evaluation
-// (any level) and the items of the narrow levels —, the others one WAVEFRONT per item of a wide level with something to
-// evaluate — one launch, both kinds of chains in flight together.
-template <int WPE, bool ATK>
-__global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
-  WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
-  const int lane = WG_LANE;
-  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;  // (default 4/16)
-  if (blockIdx.x < laneBlocks) {
+// A1: bestToVerify (:570-634) of one (runner, level) item with something to evaluate: curates the level's list, records
+// its candidate and summary. k_handel_a1c runs both kinds of items in one launch (the default), k_handel_a1 (one LANE per
+// item of a narrow level) + k_handel_a1w (one WAVEFRONT per item of a wide level; the attack's runs use it alone) are the
+// two-launch form: the wave half alone needs 79 VGPRs (6 waves a SIMD) where the lane half needs 118, but the lane half is
+// one long chain per item — 44 us by itself — which the one-launch form hides behind the wave items (profiles/r13h_*).
+__device__ __forceinline__ void h_a1_lane_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
+  {
     // ---------------- one lane per item ----------------
     KPROF_DECL;
     const uint32_t nItems = s.itemCount[0];
-    const uint32_t stride = laneBlocks * blockDim.x;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nItems; q += stride) {
+    const uint32_t stride = nBlocks * blockDim.x;
+    for (uint32_t q = block * blockDim.x + threadIdx.x; q < nItems; q += stride) {
       const uint32_t it = s.itemsLane[q];
       const int32_t node = (int32_t)(it & 0x00FFFFFFu);
       const int l = (int)(it >> 24);
@@ -2263,10 +2246,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
           }
         }
       };
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (i < len) consider(i, e4[i]);
-      for (int i = 4; i < len; i++) consider(i, ent[i]);
+      // (one copy of the body: the four entries of the head line by selects, not by four inlined copies — registers)
+      for (int i = 0; i < len; i++) consider(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
       const int kept = __popcll(keep);
       unsigned long long relMask = 0;
       if (kept != len) {
@@ -2281,10 +2262,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
             if (!(pend.x == key || pend.y == key || pend.z == key || pend.w == key)) relMask |= 1ULL << (x & 0xFF);
           }
         };
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (i < len) curate(i, e4[i]);
-        for (int i = 4; i < len; i++) curate(i, ent[i]);
+        for (int i = 0; i < len; i++) curate(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
       }
       if (newValid != valid0) qr[H_QVALID] = newValid;
       h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside,
@@ -2302,17 +2280,39 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1(const EngineDev* __restr
     }
     KPROF_MARK(d.g, 1);   // a lane-part wavefront, start to end
     KPROF_COUNT(d.g, 2);  // ... how many
-    return;
   }
-  // ---------------- one wavefront per item: lanes = 64-bit words of the level's block ----------------
-  const uint32_t wave = ((blockIdx.x - laneBlocks) * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = ((gridDim.x - laneBlocks) * blockDim.x) >> 6;
+}
+// ---------------- one wavefront per item: lanes = 64-bit words of the level's block ----------------
+template <bool ATK>
+__device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
+  const uint32_t wave = (block * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (nBlocks * blockDim.x) >> 6;
   const uint32_t nItems = s.itemCount[1];
-  if (nWaves == 0) return;
   for (uint32_t q = wave; q < nItems; q += nWaves) {
-    const uint32_t it = s.itemsWave[q];
+    const uint32_t it = WG_READFIRST(s.itemsWave[q]);  // (wave-uniform: the item's addresses live in SGPRs)
     h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
   }
+}
+__global__ void __launch_bounds__(256) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  h_a1_lane_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
+}
+template <int WPE, bool ATK>
+__global__ void __launch_bounds__(256, WPE) k_handel_a1w(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  h_a1_wave_items<ATK>(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
+}
+// both in ONE launch (WG_A1_SPLIT=0): blocks [0, gridDim.x * share / 16) the lane items, the others the wave items — the two
+// kinds of chains in flight together, at the lane half's register count
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_handel_a1c(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;  // (default 4/16)
+  if (blockIdx.x < laneBlocks)
+    h_a1_lane_items(d, s, blockIdx.x, laneBlocks);
+  else
+    h_a1_wave_items<false>(d, s, blockIdx.x - laneBlocks, gridDim.x - laneBlocks);
 }
 
 // scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate),
