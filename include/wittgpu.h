@@ -23,6 +23,17 @@ extern "C" {
 
 typedef struct wg_engine wg_engine;
 
+/* ABI version of this header. The parameter structs have GROWN across versions (wg_handel_params gained byzantineSuicide /
+ * hiddenByzantine in version 3, wg_config gained queue_cap_wide in version 2): a caller compiled against an older header
+ * would pass shorter structs than the library reads. A binding checks once, at load time, that wg_abi_version() equals the
+ * WG_ABI_VERSION it was compiled with and that wg_abi_struct_size(k) equals its own sizeof — wittgenstein_amd/_lib.py and
+ * jni/wittgpu_jni.c (JNI_OnLoad) do; a mismatch is a load error, not a silent over-read.
+ * which: 0 wg_config, 1 wg_handel_params, 2 wg_gsf_params, 3 wg_casper_params, 4 wg_sanfermin_params,
+ * 5 wg_p2pflood_params, 6 wg_delivery, 7 wg_step_op, 8 wg_run_stats; -1 for an unknown index. */
+#define WG_ABI_VERSION 4
+int32_t wg_abi_version(void);
+int32_t wg_abi_struct_size(int32_t which);
+
 typedef enum {
   WG_OK = 0,
   WG_EINVAL = -1,   /* IllegalArgumentException */
@@ -326,6 +337,10 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
                                     int64_t* simulatedMs);
 
 /* ---- node-range sharding: ONE simulation over several engines (one process per GPU) --------- */
+/* (SURVEY.md 8(b) sketches this group as `wg_config.devices[]` / `.shards` with "a single host thread driving all devices".
+ * What is built is ONE PROCESS PER GPU, each with its own wg_engine and wg_config.{shard, nshards, rccl_id}: it is how
+ * RCCL / torch.distributed address a box's GPUs, it keeps "single caller thread per engine" true, and a Java host starts
+ * one JVM per GPU the way it would start one per seed range. shards.LoopbackGroup is the in-process form for tests.) */
 /* The reference is single-threaded (C/Network.java:7-11); this group has no counterpart there. Every shard is a
  * full wg_engine built by the SAME sequence of calls (nodes, latency, seed, protocol, host-side sends/tasks) in its
  * own process; shard s of S owns the nodes [N*s/S, N*(s+1)/S). The scheduler state (per-ms buckets, multi-destination
@@ -384,6 +399,9 @@ typedef enum {
   WG_F_FLOOD_RECEIVED = 96, WG_F_FLOOD_PEER_COUNT = 97
 } wg_field;
 int32_t wg_read_i64(wg_engine* e, int32_t field, int64_t* dst, int32_t n);
+/* the same fields narrowed to 32 bits, as SURVEY.md 8(b) spells the int-valued read-back (pong, sigsChecked, msgFiltered, ...):
+ * WG_EINVAL if a value does not fit (the long counters of C/Node.java:75-79 can exceed it: use wg_read_i64 for those) */
+int32_t wg_read_i32(wg_engine* e, int32_t field, int32_t* dst, int32_t n);
 typedef enum { /* per (node, level), row-major [node][level] */
   WG_LF_POS_IN_LEVEL = 0, WG_LF_OUTGOING_FINISHED = 1, WG_LF_QUEUE_LEN = 2,
   WG_LF_REMAINING_CALLS = 3, /* GSF SFLevel.remainingCalls (P/GSFSignature.java:257) */

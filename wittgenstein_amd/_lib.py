@@ -84,7 +84,9 @@ class wg_profile_entry(C.Structure):
 
 
 # every symbol include/wittgpu.h and include/wittgpu_host.h declare
+ABI_VERSION = 4  # WG_ABI_VERSION of the include/wittgpu.h these ctypes structures restate
 ABI_SYMBOLS = [
+    "wg_abi_version", "wg_abi_struct_size", "wg_read_i32",
     "wg_create", "wg_destroy", "wg_last_error", "wg_add_nodes", "wg_node_count", "wg_set_latency",
     "wg_set_latency_by_name", "wg_set_latency_city", "wg_latency_probe", "wg_set_partitions", "wg_set_node_down", "wg_set_discard_time",
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_send_arrive_at", "wg_register_task",
@@ -119,5 +121,14 @@ def lib():
         l.wg_batch_last_error.argtypes = [C.c_void_p]
         l.wg_batch_destroy.restype = None
         l.wg_batch_destroy.argtypes = [C.c_void_p]
+        # the structures above must be the library's (they have grown across versions): a stale library is a load error
+        if not hasattr(l, "wg_abi_version") or l.wg_abi_version() != ABI_VERSION:
+            raise ImportError("%s: ABI version %s, this binding is version %d — rebuild it (__graft_entry__.build())"
+                              % (LIB_PATH, l.wg_abi_version() if hasattr(l, "wg_abi_version") else "< 4", ABI_VERSION))
+        for k, t in enumerate((wg_config, wg_handel_params, wg_gsf_params, wg_casper_params, wg_sanfermin_params,
+                               wg_p2pflood_params, wg_delivery, wg_step_op, wg_run_stats)):
+            if l.wg_abi_struct_size(k) != C.sizeof(t):
+                raise ImportError("%s: sizeof(%s) is %d in the library, %d in this binding" % (
+                    LIB_PATH, t.__name__, l.wg_abi_struct_size(k), C.sizeof(t)))
         _lib = l
     return _lib

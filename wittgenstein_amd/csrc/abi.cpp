@@ -1,6 +1,8 @@
 // extern "C" surface of libwittgpu.so (include/wittgpu.h). Thin: argument checks, exception ->
 // status mapping, no engine logic.
+#include <climits>
 #include <cstring>
+#include <vector>
 #include "engine_host.h"
 
 using namespace wg;
@@ -178,6 +180,32 @@ int32_t wg_queue_size_at(wg_engine* h, int32_t t, int64_t* size) {
 int32_t wg_read_i64(wg_engine* h, int32_t field, int64_t* dst, int32_t n) {
   WG_TRY(h) E.read_i64(field, dst, n);
   WG_END
+}
+int32_t wg_read_i32(wg_engine* h, int32_t field, int32_t* dst, int32_t n) {  // the int fields (pong, sigsChecked, ...)
+  WG_TRY(h)
+  if (!dst || n < 0) throw WgError(WG_EINVAL, "dst / n");
+  std::vector<int64_t> tmp((size_t)n);
+  E.read_i64(field, tmp.data(), n);
+  for (int32_t i = 0; i < n; i++) {
+    if (tmp[(size_t)i] < INT32_MIN || tmp[(size_t)i] > INT32_MAX) throw WgError(WG_EINVAL, "wg_read_i32: the field does not fit 32 bits (use wg_read_i64)");
+    dst[i] = (int32_t)tmp[(size_t)i];
+  }
+  WG_END
+}
+int32_t wg_abi_version(void) { return WG_ABI_VERSION; }
+int32_t wg_abi_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(wg_config);
+    case 1: return (int32_t)sizeof(wg_handel_params);
+    case 2: return (int32_t)sizeof(wg_gsf_params);
+    case 3: return (int32_t)sizeof(wg_casper_params);
+    case 4: return (int32_t)sizeof(wg_sanfermin_params);
+    case 5: return (int32_t)sizeof(wg_p2pflood_params);
+    case 6: return (int32_t)sizeof(wg_delivery);
+    case 7: return (int32_t)sizeof(wg_step_op);
+    case 8: return (int32_t)sizeof(wg_run_stats);
+    default: return -1;
+  }
 }
 int32_t wg_read_level_i32(wg_engine* h, int32_t field, int32_t* dst, int32_t n_nodes, int32_t n_levels) {
   WG_TRY(h)
