@@ -181,6 +181,83 @@ def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
     return out
 
 
+def replicas_line(workload, n, R_req, K, W, local=0):
+    """a compact RunMultipleTimes line for ONE more workload inside the default run (outside `value` and its timed region):
+    R copies initialised once, kept as init() images, W warm-up + K timed passes, the delivery pass bracketed by HIP events
+    as in the main line. Used for Handel at the north star's target size (65 536 nodes) and GSFSignature (BASELINE configs[1])."""
+    import torch
+    import numpy as np
+    import wittgenstein_amd as w
+    from wittgenstein_amd import replicas
+    free0 = torch.cuda.mem_get_info()[0]
+    t_init = time.perf_counter()
+    first = make_sim(w, n, 0, local, workload)
+    first.network().snapshot()
+    torch.cuda.synchronize()
+    per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
+    R = replicas.plan_replicas(R_req, free0, per_copy)
+    sims = [first]
+    if R > 1:
+        def init_one(sd):
+            g = make_sim(w, n, sd, local, workload)
+            g.network().snapshot()
+            return g
+        with ThreadPoolExecutor(max_workers=min(R - 1, max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
+            sims += list(ex.map(init_one, range(1, R)))
+    batch = w.Batch([g.network() for g in sims])
+    init_wall = time.perf_counter() - t_init
+    delivered = sim_ms = 0
+    elapsed = dk_ns = 0.0
+    dk_spans = 0
+    by_level = None
+    for i in range(W + K):
+        if i > 0:
+            for g in sims:
+                g.network().restore()
+        sims[0].network().profile(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d, ms = batch.run_multiple_times(chunk=10, maxTime=20000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if i < W:
+            continue
+        elapsed += dt
+        delivered += sum(d)
+        sim_ms += sum(ms)
+        pr = sims[0].network().profile_read()["deliver"]
+        dk_spans += pr["spans"]
+        dk_ns += pr["total_ns"]
+        for g in sims:
+            bl = g.network().delivered_by_level()
+            by_level = bl if by_level is None else by_level + bl
+    del batch, sims, first
+    gc.collect()
+    gsf = workload == "gsf"
+    alg = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level))) if by_level is not None else 0.0
+    per_launch = alg / max(1, dk_spans)
+    avg_ns = dk_ns / max(1, dk_spans)
+    return {
+        "metric": "delivered messages/sec (%s; simulated-ms/sec alongside)" % ("GSFSignature" if gsf else "Handel %dk nodes" % (n // 1024)),
+        "value": delivered / max(elapsed, 1e-9), "unit": "delivered messages/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": elapsed * 1000.0 / max(1, K), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": sim_ms / max(elapsed, 1e-9),
+        "config": {"workload": ("GSFSignature, %d nodes, threshold 0.99, pairing 3, timeoutPerLevel 50, period 10, accelerated calls 10"
+                                if gsf else "Handel aggregation, %d nodes, 10%% dead, threshold 0.99*live, pairing 4, levelWait 50, period 20, "
+                                            "fastPath 10") % n + ", RANDOM nodes, NetworkLatencyByDistanceWJitter; RunMultipleTimes: %d independent "
+                               "copies per step (seeds 0..%d), runMs(10) until each copy's continuation predicate is false" % (R, R - 1),
+                   "nodes": n, "replicas_per_gpu": R, "replicas_requested": R_req, "hbm_bytes_per_copy_incl_init_image": int(per_copy),
+                   "delivered_per_simulation": delivered // max(1, K * R), "init_wall_s": init_wall},
+        "roofline": {"bound": "hbm", "kernel": "k_deliver<GsfProto> (the delivery pass)" if gsf else
+                     "k_handel_lane + k_handel_copy + k_handel_update + k_handel_dissem + k_handel_wave (the delivery pass)",
+                     "achieved": per_launch / max(1.0, avg_ns), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": per_launch / max(1.0, avg_ns) / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
+                     "bytes_per_delivered_message": alg / max(1, delivered),
+                     "whole_step_frac": alg / (max(elapsed, 1e-9) * 1e9) / HBM_PEAK_GBS},
+    }
+
+
 def main_casper(args):
     emit(casper_line(args))
 
@@ -772,6 +849,17 @@ def main():
             out["second_workload"] = casper_line(ca)
         except Exception as x:  # the Handel line stands on its own
             out["second_workload"] = {"error": "%s: %s" % (type(x).__name__, x)}
+        # the north star's TARGET SIZE (Handel 65 536 nodes, same ratios) and BASELINE configs[1]
+        # (GSFSignature 4096 nodes), each as its own compact line — outside `value`, after the main line's copies are freed
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 6), ("third_workload", "gsf", 4096, 64)):
+            if n == nn and args.workload == wl:
+                continue
+            try:
+                gc.collect()
+                torch.cuda.empty_cache()
+                out[key] = replicas_line(wl, nn, rr, 2, 1, local)
+            except Exception as x:
+                out[key] = {"error": "%s: %s" % (type(x).__name__, x)}
     emit(out)
     if world > 1:
         dist.destroy_process_group()

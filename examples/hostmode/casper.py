@@ -8,7 +8,7 @@ sampling, the LIFO / chain ordering and the shared `rd` live in libwittgpu.so on
 This is the host-side Python stand-in for the Java class (no JVM in the build image): class, field
 and method names follow the Java source so that it reads side by side with it. `for (CasperBlock b :
 blocksToReevaluate)` (:352-356) iterates a HashSet in identity-hash order, which the JDK leaves unspecified; like the
-oracle (oracle/casper.hpp) this iterates in ascending block id. ByzBlockProducerSF / NS (:583-633) are not mirrored
+oracle (oracle/casper.hpp) this iterates in ascending block id. ByzBlockProducer / SF / NS (:545-633) are mirrored too (their HashSet pick = the smallest block id, as the oracle)
 (unused by init() and by every reference test)."""
 from wittgenstein_amd.core import IllegalArgumentException, IllegalStateException
 from wittgenstein_amd.hostnet import HostNetwork, Message, Node
@@ -219,6 +219,55 @@ class ByzBlockProducer(BlockProducer):  # :511-581
         self.h = int(slotTime / SLOT_DURATION)  # Java int division truncates toward zero
         if self.h != self.toSend:
             raise IllegalStateException("h=%d, toSend=%d" % (self.h, self.toSend))
+
+
+class ByzBlockProducerPlain(ByzBlockProducer):  # ByzBlockProducer's own periodicTask, :545-563
+    def periodicTask(self):
+        def run():
+            self.reevaluateH(self.network.time)
+            if self.head.height == self.h - 1:
+                self.onDirectFather += 1
+            else:
+                self.onOlderAncestor += 1
+                # blocksReceivedByHeight.get(h - 1).iterator().next(): the reference's HashSet order is the JVM's identity
+                # hashes; the oracle and this mirror take the smallest block id. No block of that height: its NPE
+                possibleFather = min(self.blocksReceivedByHeight[self.h - 1], key=lambda b: b.id)
+                if possibleFather.parent.height != self.h - 1:
+                    self.incNotTheBestFather += 1
+            self.createAndSendBlock(self.toSend)
+            self.toSend += self.p.params.blockProducersCount
+        return run
+
+
+class ByzBlockProducerSF(ByzBlockProducer):  # :583-604 — skip its father's block
+    def periodicTask(self):
+        def run():
+            self.reevaluateH(self.network.time)
+            if self.head.id != 0 and self.head.height == self.h - 1:
+                self.head = self.head.parent
+                self.onDirectFather += 1
+            else:
+                self.onOlderAncestor += 1
+            self.createAndSendBlock(self.toSend)
+            self.toSend += self.p.params.blockProducersCount
+        return run
+
+
+class ByzBlockProducerNS(ByzBlockProducer):  # :610-633 — skip the father if the father skipped the grand father
+    def __init__(self, protocol, delay):
+        super().__init__(protocol, delay)
+        self.skipped = 0
+
+    def periodicTask(self):
+        def run():
+            self.reevaluateH(self.network.time)
+            if self.head.id != 0 and self.head.height == self.h - 1 and self.head.parent.height == self.h - 3:
+                b = min(self.blocksReceivedByHeight[self.h - 2], key=lambda blk: blk.id)
+                self.head = b
+                self.skipped += 1
+            self.createAndSendBlock(self.toSend)
+            self.toSend += self.p.params.blockProducersCount
+        return run
 
 
 class ByzBlockProducerWF(ByzBlockProducer):  # :635-692

@@ -24,6 +24,11 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
                             const wg_config* cfg, wg_engine** out);
 int32_t wgh_handel_create(const wg_handel_params* params, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out);
+/* ... with HandelParameters.badNodes (P/Handel.java:51,110,139): the explicit set init() uses instead of
+ * Network.chooseBadNodes' draws (:960-964) — badNodes[nodeCount], non-zero = that node is down (and byzantine under an attack
+ * flag); NULL = wgh_handel_create. params->nodesDown keeps its role in the constructor's checks (:113-118) only. */
+int32_t wgh_handel_create_bad_nodes(const wg_handel_params* params, const uint8_t* badNodes, const char* nodeBuilderName,
+                                    const char* latencyName, int64_t seed, const wg_config* cfg, wg_engine** out);
 int32_t wgh_gsf_create(const wg_gsf_params* params, const char* nodeBuilderName, const char* latencyName,
                        int64_t seed, const wg_config* cfg, wg_engine** out);
 /* new SanFerminSignature(params) — which builds the nodes from the fresh Network's rd, new Random(0) (:126-131) —

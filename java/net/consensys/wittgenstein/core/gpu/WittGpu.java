@@ -180,6 +180,8 @@ public final class WittGpu {
 
   public static native long hostHandelCreate(int[] params14, String nodeBuilderName, String latencyName, long seed, int[] cfgInts, long[] cfgLongs, byte[] rcclId);
 
+  public static native long hostHandelCreateBadNodes(int[] params14, byte[] badNodes, String nodeBuilderName, String latencyName, long seed, int[] cfgInts, long[] cfgLongs, byte[] rcclId);
+
   public static native long hostGsfCreate(int[] params7, String nodeBuilderName, String latencyName, long seed, int[] cfgInts, long[] cfgLongs, byte[] rcclId);
 
   public static native long hostSanFerminCreate(int[] params6, String nodeBuilderName, String latencyName, long seed, int[] cfgInts, long[] cfgLongs, byte[] rcclId);

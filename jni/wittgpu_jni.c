@@ -530,6 +530,25 @@ HOST_CREATE(hostGsfCreate, wg_gsf_params, wgh_gsf_create)
 HOST_CREATE(hostSanFerminCreate, wg_sanfermin_params, wgh_sanfermin_create)
 HOST_CREATE(hostCasperCreate, wg_casper_params, wgh_casper_create)
 HOST_CREATE(hostP2PFloodCreate, wg_p2pflood_params, wgh_p2pflood_create)
+/* Handel with HandelParameters.badNodes (P/Handel.java:51,110,139): badNodes[nodeCount], non-zero = the BitSet's bit */
+WG_JNI(jlong, hostHandelCreateBadNodes)(JNIEnv* env, jclass c, jintArray params, jbyteArray badNodes, jstring nb, jstring nl, jlong seed,
+                                        jintArray cfgInts, jlongArray cfgLongs, jbyteArray rcclId) {
+  (void)c;
+  if (LEN(params) != (jsize)(sizeof(wg_handel_params) / 4)) { throw_msg(env, WG_EINVAL, "HandelParameters: 14 ints"); return 0; }
+  wg_handel_params p;
+  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof p / 4), (jint*)&p);
+  if (badNodes && LEN(badNodes) != p.nodeCount) { throw_msg(env, WG_EINVAL, "badNodes: one byte per node"); return 0; }
+  wg_config cfg;
+  jbyte id[WG_RCCL_UNIQUE_ID_BYTES];
+  fill_config(env, &cfg, cfgInts, cfgLongs, id, rcclId);
+  const char *snb = STR(nb), *snl = STR(nl);
+  jbyte* pb = PIN_B(badNodes);
+  wg_engine* e = NULL;
+  int32_t rc = wgh_handel_create_bad_nodes(&p, (const uint8_t*)pb, snb, snl, seed, &cfg, &e);
+  UNPIN_B(badNodes, pb); UNSTR(nb, snb); UNSTR(nl, snl);
+  if (ck_host(env, rc) != WG_OK) return 0;
+  return (jlong)(intptr_t)e;
+}
 WG_JNI(jlong, hostPingPongCreate)(JNIEnv* env, jclass c, jint nodeCt, jstring nb, jstring nl, jlong seed, jintArray cfgInts,
                                   jlongArray cfgLongs, jbyteArray rcclId) {  /* PingPong.init() P/PingPong.java:81-87 */
   (void)c;

@@ -257,10 +257,21 @@ int orc_handel_create(const int32_t* ip, const char* nb, const char* nl, int64_t
   return orc_handel_create_byz(ip, nb, nl, seed, 0, 0, out);
 }
 // ... with the attack scenarios of the parameters (P/Handel.java:108-109): byzantineSuicide, hiddenByzantine
+int orc_handel_create_bad(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzSuicide, int hiddenByz,
+                          const uint8_t* bad, void** out);
 int orc_handel_create_byz(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzSuicide, int hiddenByz,
                           void** out) {
-  ORC_TRY Handel::HandelParameters pr(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], nb ? nb : "",
-                                      nl ? nl : "", ip[8], byzSuicide != 0, hiddenByz != 0, nullptr);
+  return orc_handel_create_bad(ip, nb, nl, seed, byzSuicide, hiddenByz, nullptr, out);
+}
+// ... and HandelParameters.badNodes (P/Handel.java:51,110,139): bad[nodeCount], non-zero = the bit is set; NULL = null
+int orc_handel_create_bad(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzSuicide, int hiddenByz,
+                          const uint8_t* bad, void** out) {
+  ORC_TRY BitSet badSet;
+  if (bad)
+    for (int i = 0; i < ip[0]; i++)
+      if (bad[i]) badSet.set(i);
+  Handel::HandelParameters pr(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], nb ? nb : "",
+                              nl ? nl : "", ip[8], byzSuicide != 0, hiddenByz != 0, bad ? &badSet : nullptr);
   auto* h = new OrcHandel();
   h->p = std::make_unique<Handel>(pr);
   h->p->network().rd.setSeed(seed);
@@ -551,13 +562,39 @@ struct OrcCasper {
 //     attestationConstructionTime, delay of the ByzBlockProducerWF that init(badNode) starts with (:475-479 uses 0).
 // As RunMultipleTimes does (C/RunMultipleTimes.java:44-48): new CasperIMD(params) — which already builds the observer
 // node from rd (:80-87) — then rd.setSeed(seed), then init().
+int orc_casper_create_byz(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzKind, void** out);
 int orc_casper_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  return orc_casper_create_byz(ip, nb, nl, seed, 0, out);
+}
+// byzKind: the byzantine producer init(badNode) is given (P/CasperIMD.java:481) — 0 ByzBlockProducerWF (what init() itself
+// installs, :475-479), 1 ByzBlockProducer (:511-581), 2 ByzBlockProducerSF (:583-604), 3 ByzBlockProducerNS (:610-633)
+int orc_casper_create_byz(const int32_t* ip, const char* nb, const char* nl, int64_t seed, int byzKind, void** out) {
   ORC_TRY CasperIMD::CasperParemeters pr(ip[0], ip[1] != 0, ip[2], ip[3], ip[4], ip[5], nb ? nb : "", nl ? nl : "");
   auto* h = new OrcCasper();
   h->p = std::make_unique<CasperIMD>(pr);
   h->p->network().rd.setSeed(seed);
-  h->p->init(h->p->make<CasperIMD::ByzBlockProducerWF>(ip[6]));
+  CasperIMD::ByzBlockProducer* byz = nullptr;
+  switch (byzKind) {
+    case 0: byz = h->p->make<CasperIMD::ByzBlockProducerWF>(ip[6]); break;
+    case 1: byz = h->p->make<CasperIMD::ByzBlockProducerPlain>(ip[6]); break;
+    case 2: byz = h->p->make<CasperIMD::ByzBlockProducerSF>(ip[6]); break;
+    case 3: byz = h->p->make<CasperIMD::ByzBlockProducerNS>(ip[6]); break;
+    default: delete h; throw IllegalArgumentException("byzKind");
+  }
+  h->p->init(byz);
   *out = h;
+  ORC_CATCH
+}
+// counters of the byzantine producer (node 1): onDirectFather, onOlderAncestor, incNotTheBestFather, skipped (NS), toSend
+int orc_casper_byz_counters(void* h, int32_t* out5) {
+  ORC_TRY auto* b = dynamic_cast<CasperIMD::ByzBlockProducer*>(((OrcCasper*)h)->p->network().allNodes[1]);
+  if (!b) throw IllegalStateException("node 1 is not a ByzBlockProducer");
+  auto* ns = dynamic_cast<CasperIMD::ByzBlockProducerNS*>(b);
+  out5[0] = b->onDirectFather;
+  out5[1] = b->onOlderAncestor;
+  out5[2] = b->incNotTheBestFather;
+  out5[3] = ns ? ns->skipped : 0;
+  out5[4] = b->toSend;
   ORC_CATCH
 }
 void orc_casper_destroy(void* h) { delete (OrcCasper*)h; }

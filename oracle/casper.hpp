@@ -10,8 +10,11 @@
 //     own tests exercise it; the oracle iterates in ascending block id.
 //   * Block.blockId (:10) is a JVM-wide static counter: ids depend on what else ran in the JVM, only their order
 //     is meaningful (:best tie-break :261). The oracle counts per protocol instance.
-// ByzBlockProducerSF / NS (:583-633) pick `blocksReceivedByHeight.get(h).iterator().next()` from a HashSet and
-// are not used by init() or any test: not restated.
+//   * ByzBlockProducer / SF / NS (:545-633) take `blocksReceivedByHeight.get(h).iterator().next()` from a HashSet<Block> —
+//     again identity-hash order when a node holds several blocks of one height; the oracle takes the block with the
+//     smallest id (its sets are ordered by block id). No test of the reference uses the three classes (init() installs
+//     a ByzBlockProducerWF, :475-479), so they are pinned by nothing but this restatement of their lines; the host-mode
+//     mirror (examples/hostmode/casper.py) and the engine are checked against it.
 #pragma once
 #include <map>
 #include <set>
@@ -230,6 +233,65 @@ class CasperIMD {
       const int slotTime = time - delay;
       h = slotTime / CasperParemeters::SLOT_DURATION;
       if (h != toSend) throw IllegalStateException("h=" + std::to_string(h) + ", toSend=" + std::to_string(toSend));
+    }
+  };
+
+  // the plain delayed producer (ByzBlockProducer itself, :545-563), "skip father" (:583-604) and "no skip" (:610-633)
+  struct ByzBlockProducerPlain : ByzBlockProducer {
+    ByzBlockProducerPlain(CasperIMD& pp, int d) : ByzBlockProducer(pp, d) {}
+    std::function<void()> periodicTask() override {  // :545-563
+      return [this] {
+        reevaluateH(p.network_.time);
+        if (head->height == h - 1) {
+          onDirectFather++;
+        } else {
+          onOlderAncestor++;
+          // Block possibleFather = blocksReceivedByHeight.get(h - 1).iterator().next(): a NullPointerException when no
+          // block of that height was received, as in the reference
+          auto it = blocksReceivedByHeight.find(h - 1);
+          if (it == blocksReceivedByHeight.end() || it->second.empty()) throw IllegalStateException("NullPointerException (:555)");
+          CasperBlock* possibleFather = *it->second.begin();
+          if (possibleFather != nullptr && possibleFather->parent->height != h - 1) incNotTheBestFather++;
+        }
+        createAndSendBlock(toSend);
+        toSend += p.params.blockProducersCount;
+      };
+    }
+  };
+  struct ByzBlockProducerSF : ByzBlockProducer {  // :583-604 — skip its father's block
+    ByzBlockProducerSF(CasperIMD& pp, int d) : ByzBlockProducer(pp, d) {}
+    std::function<void()> periodicTask() override {
+      return [this] {
+        reevaluateH(p.network_.time);
+        if (head->id != 0 && head->height == h - 1) {
+          head = head->parent;
+          onDirectFather++;
+        } else {
+          onOlderAncestor++;
+        }
+        createAndSendBlock(toSend);
+        toSend += p.params.blockProducersCount;
+      };
+    }
+  };
+  struct ByzBlockProducerNS : ByzBlockProducer {  // :610-633 — skip the father if the father skipped the grand father
+    int skipped = 0;
+    ByzBlockProducerNS(CasperIMD& pp, int d) : ByzBlockProducer(pp, d) {}
+    std::function<void()> periodicTask() override {
+      return [this] {
+        reevaluateH(p.network_.time);
+        if (head->id != 0 && head->height == h - 1 && head->parent->height == h - 3) {
+          auto it = blocksReceivedByHeight.find(h - 2);
+          if (it == blocksReceivedByHeight.end() || it->second.empty()) throw IllegalStateException("NullPointerException (:619)");
+          CasperBlock* b = *it->second.begin();
+          if (b != nullptr) {
+            head = b;
+            skipped++;
+          }
+        }
+        createAndSendBlock(toSend);
+        toSend += p.params.blockProducersCount;
+      };
     }
   };
 

@@ -144,13 +144,18 @@ class Handel:
             "finishedPeers": 4, "totalOutgoingLast": 5, "waitedSigs": 6, "blacklist": 7}
 
     def __init__(self, node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
-                 nodes_down, nb=None, nl=None, desync=0, seed=0, byzantine_suicide=False, hidden_byzantine=False):
+                 nodes_down, nb=None, nl=None, desync=0, seed=0, byzantine_suicide=False, hidden_byzantine=False, bad_nodes=None):
         ip = (C.c_int32 * 9)(node_count, threshold, pairing_time, level_wait_time, extra_cycle, period, fast_path,
                              nodes_down, desync)
         self.h = C.c_void_p()
         self.n = node_count
-        _ck(lib().orc_handel_create_byz(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
-                                        int(byzantine_suicide), int(hidden_byzantine), C.byref(self.h)))
+        bad = None
+        if bad_nodes is not None:  # HandelParameters.badNodes (P/Handel.java:51): the ids of the set bits
+            bad = (C.c_uint8 * node_count)()
+            for i in bad_nodes:
+                bad[i] = 1
+        _ck(lib().orc_handel_create_bad(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                        int(byzantine_suicide), int(hidden_byzantine), bad, C.byref(self.h)))
         self.levels = lib().orc_handel_levels(self.h)
 
     def __del__(self):
@@ -288,17 +293,25 @@ class CasperIMD:
               "headProposalTime": 5, "headId": 6, "attestationsByHeadSize": 7, "x": 8, "y": 9, "blocksReceived": 10,
               "attestationsHeld": 11}
 
-    def __init__(self, params, nb=None, nl=None, seed=0, byz_delay=0):
+    BYZ = {"WF": 0, "plain": 1, "SF": 2, "NS": 3}  # the ByzBlockProducer given to init(badNode), P/CasperIMD.java:481
+
+    def __init__(self, params, nb=None, nl=None, seed=0, byz_delay=0, byz="WF"):
         self.h = C.c_void_p()
         ip = (C.c_int32 * 7)(params[0], int(params[1]), params[2], params[3], params[4], params[5], byz_delay)
-        _ck(lib().orc_casper_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
-                                    C.byref(self.h)))
+        _ck(lib().orc_casper_create_byz(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                        self.BYZ[byz], C.byref(self.h)))
         self.n = lib().orc_casper_node_count(self.h)
 
     def __del__(self):
         if getattr(self, "h", None) and lib is not None:
             lib().orc_casper_destroy(self.h)
             self.h = None
+
+    def byz_counters(self):
+        """onDirectFather, onOlderAncestor, incNotTheBestFather, skipped, toSend of the byzantine producer (node 1)"""
+        out = (C.c_int32 * 5)()
+        _ck(lib().orc_casper_byz_counters(self.h, out))
+        return dict(zip(("onDirectFather", "onOlderAncestor", "incNotTheBestFather", "skipped", "toSend"), list(out)))
 
     def stop(self, ids):
         """Node.stop() on the listed nodes (SURVEY.md §8d's definition of config 5's stopped attesters)"""

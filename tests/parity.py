@@ -14,14 +14,14 @@ LEVELS = ["posInLevel", "outgoingFinished", "queueLen", "suicideBizAfter"]
 BITS = ["totalIncoming", "lastAggVerified", "verifiedIndSignatures", "toVerifyInd", "finishedPeers", "blacklist"]
 
 
-def handel_pair(params, nb=NB, nl=NL, seed=0, config=None, byzantine_suicide=False, hidden_byzantine=False):
+def handel_pair(params, nb=NB, nl=NL, seed=0, config=None, byzantine_suicide=False, hidden_byzantine=False, bad_nodes=None):
     """params = (nodeCount, threshold, pairing, levelWait, extraCycle, period, fastPath, nodesDown, desync)"""
     n, thr, pair, lw, ec, per, fp, down, desync = params
     g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, byzantineSuicide=byzantine_suicide,
-                                    hiddenByzantine=hidden_byzantine), seed=seed, config=config)
+                                    hiddenByzantine=hidden_byzantine, badNodes=bad_nodes), seed=seed, config=config)
     g.init()
     c = o.Handel(n, thr, pair, lw, ec, per, fp, down, nb, nl, desync, seed=seed, byzantine_suicide=byzantine_suicide,
-                 hidden_byzantine=hidden_byzantine)
+                 hidden_byzantine=hidden_byzantine, bad_nodes=bad_nodes)
     return g, c
 
 

@@ -109,6 +109,11 @@ def test_handel_attack_scenarios_wide_levels():
     th.test_attack_scenarios_resident_wide_levels(1024, "hidden_byzantine", 400)
 
 
+@pytest.mark.parametrize("mode", [None, "byzantine_suicide"])
+def test_handel_explicit_bad_nodes_resident(mode):  # HandelParameters.badNodes, P/Handel.java:51, 960-964
+    th.test_explicit_bad_nodes_resident(mode)
+
+
 def test_handel_hidden_byzantine_resident():  # P/Handel.java:813-817, 840-917 on the device vs the oracle
     th.test_hidden_byzantine_resident((64, 50, 4, 50, 5, 20, 10, 6, 0), 2, 1)
 
@@ -219,6 +224,11 @@ def test_host_callback_mode_pingpong():
 
 def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp (the full cases: -m gpu)
     tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
+
+
+@pytest.mark.parametrize("byz", ["SF", "NS"])
+def test_casper_other_byzantine_producers_through_host_callbacks(byz):  # P/CasperIMD.java:583-633 vs oracle/casper.hpp
+    tc.test_casper_other_byzantine_producers(byz, 0, chunks=14)  # (the full cases: -m gpu)
 
 
 @pytest.mark.parametrize("nl", [None, "NetworkNoLatency"])

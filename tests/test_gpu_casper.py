@@ -20,11 +20,15 @@ FIELDS = {
 }
 
 
-def pair(params, seed, nl=None, byz_delay=0):
+BYZ = {"WF": casper.ByzBlockProducerWF, "plain": casper.ByzBlockProducerPlain, "SF": casper.ByzBlockProducerSF,
+       "NS": casper.ByzBlockProducerNS}
+
+
+def pair(params, seed, nl=None, byz_delay=0, byz="WF"):
     g = casper.CasperIMD(casper.CasperParemeters(*params, None, nl))
     g.network.rd.setSeed(seed)                       # RunMultipleTimes: copy, rd.setSeed(i), init()
-    g.init(casper.ByzBlockProducerWF(g, byz_delay))
-    return g, o.CasperIMD(params, None, nl, seed=seed, byz_delay=byz_delay)
+    g.init(BYZ[byz](g, byz_delay))
+    return g, o.CasperIMD(params, None, nl, seed=seed, byz_delay=byz_delay, byz=byz)
 
 
 def diff(g, c):
@@ -67,6 +71,20 @@ def test_casper_reference_test_parameters():  # PT/CasperIMDTest.java:10-11: 5 p
 @pytest.mark.gpu
 def test_casper_byzantine_delay_and_random_ties():  # ByzBlockProducerWF(-2000) (PT/CasperByzantineTest.java:41), rd in best()
     lockstep((3, True, 3, 8, 1000, 1), seed=9, chunk=1000, chunks=50, byz_delay=-2000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("byz,delay", [("plain", 0), ("plain", 1500), ("SF", 0), ("SF", -1000), ("NS", 0), ("NS", 2500)])
+def test_casper_other_byzantine_producers(byz, delay, chunks=40):
+    """init(badNode) with the reference's other byzantine block producers (P/CasperIMD.java:511-633: the plain delayed one,
+    "skip father", "no skip") instead of the ByzBlockProducerWF init() installs: the Java classes mirrored on the engine's
+    host-callback mode, in lock-step with the oracle's restatement of the same lines — incl. the producer's own counters."""
+    g, c = lockstep((3, False, 3, 8, 1000, 1), seed=6, chunk=2000, chunks=chunks, byz=byz, byz_delay=delay)
+    b, oc = g.bps[0], c.byz_counters()
+    assert (b.onDirectFather, b.onOlderAncestor, b.incNotTheBestFather, getattr(b, "skipped", 0), b.toSend) == (
+        oc["onDirectFather"], oc["onOlderAncestor"], oc["incNotTheBestFather"], oc["skipped"], oc["toSend"])
+    assert b.toSend >= 1 + 3 * (chunks // 14)  # it produced its blocks: one per three slots
+    assert g.observer.head.height >= chunks // 5
 
 
 @pytest.mark.gpu

@@ -197,8 +197,26 @@ def test_incremental_check_sigs_wave_items(monkeypatch, n, lane_nw, step, max_ms
 def test_attack_parameter_checks():
     with pytest.raises(w.IllegalArgumentException):  # "Only one attack at a time" :123-125
         w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, byzantineSuicide=True, hiddenByzantine=True)
-    with pytest.raises(w.UnsupportedError):
-        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, badNodes=[3])
+    with pytest.raises(w.IllegalArgumentException):
+        w.HandelParameters(64, 50, 4, 50, 5, 20, 10, 6, parity.NB, parity.NL, 0, badNodes=[64])
+
+
+@pytest.mark.parametrize("mode", [None, "byzantine_suicide", "hidden_byzantine"])
+def test_explicit_bad_nodes_resident(mode):
+    """HandelParameters.badNodes (P/Handel.java:51, 110, 139): init() takes the given BitSet instead of drawing
+    Network.chooseBadNodes (:960-964) — rd is then one nodesDown-draws-loop shorter before the nodes are built, the down
+    (and, with an attack flag, byzantine) nodes are the given ones. Resident on the device since round 4 (it used to be
+    host-callback only); in lock-step with the oracle, honest and under both attacks. The set deliberately differs from
+    nodesDown in size (the constructor only checks nodesDown, :113-118)."""
+    n = 256
+    bad = [1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 250, 251, 252, 253, 254]
+    params = (n, int((n - 25) * 0.99) - 5, 4, 50, 10, 20, 10, 25, 0)
+    kw = {mode: True} if mode else {}
+    g, c = lockstep(params, step=10, max_ms=1500, seed=4, bad_nodes=bad, **kw)
+    down = g.network().read("down")
+    assert sorted(np.nonzero(down)[0].tolist()) == bad
+    if mode is None:
+        assert (g.network().read("doneAt")[down == 0] > 0).all()
 
 
 def test_queue_capacity_overflow_is_loud():

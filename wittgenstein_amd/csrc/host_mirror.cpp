@@ -256,25 +256,31 @@ int32_t wgh_pingpong_create(int32_t nodeCt, const char* nodeBuilderName, const c
   return WG_OK;
 }
 
-static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
-                             const wg_config* cfg, wg_engine** out, bool devicePeers);
+static int32_t handel_create(const wg_handel_params* pp, const uint8_t* badNodes, const char* nodeBuilderName,
+                             const char* latencyName, int64_t seed, const wg_config* cfg, wg_engine** out, bool devicePeers);
 // Handel.init() (P/Handel.java:957-1014). The emission lists (:991-1013) are built on the device where the engine can
 // (unsharded, 256 .. 131 072 nodes: wg_handel_init_state.receptionRanks and .peers == NULL) together with the rank shuffles
 // (:940-948, 966-989) and on the host otherwise — or after all, when
 // the device met a rejected draw (WG_EHOSTINIT); WG_HOST_INIT=1 keeps everything on the host.
 int32_t wgh_handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName,
                           int64_t seed, const wg_config* cfg, wg_engine** out) {
+  return wgh_handel_create_bad_nodes(pp, nullptr, nodeBuilderName, latencyName, seed, cfg, out);
+}
+// ... with HandelParameters.badNodes (P/Handel.java:51, 110, 139): the explicit set init() uses INSTEAD of
+// Network.chooseBadNodes' draws (:960-964) — one byte per node, non-zero = down (and byzantine under an attack flag)
+int32_t wgh_handel_create_bad_nodes(const wg_handel_params* pp, const uint8_t* badNodes, const char* nodeBuilderName,
+                                    const char* latencyName, int64_t seed, const wg_config* cfg, wg_engine** out) {
   if (!out || !pp) return WG_EINVAL;
   const bool hostOnly = getenv("WG_HOST_INIT") && atoi(getenv("WG_HOST_INIT")) != 0;
   const bool sharded = cfg && cfg->nshards > 0;
   if (!hostOnly && !sharded && pp->nodeCount >= 256 && pp->nodeCount <= 131072) {
-    const int32_t rc = handel_create(pp, nodeBuilderName, latencyName, seed, cfg, out, true);
+    const int32_t rc = handel_create(pp, badNodes, nodeBuilderName, latencyName, seed, cfg, out, true);
     if (rc != WG_EHOSTINIT) return rc;
   }
-  return handel_create(pp, nodeBuilderName, latencyName, seed, cfg, out, false);
+  return handel_create(pp, badNodes, nodeBuilderName, latencyName, seed, cfg, out, false);
 }
-static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilderName, const char* latencyName, int64_t seed,
-                             const wg_config* cfg, wg_engine** out, bool devicePeers) {
+static int32_t handel_create(const wg_handel_params* pp, const uint8_t* badNodes, const char* nodeBuilderName,
+                             const char* latencyName, int64_t seed, const wg_config* cfg, wg_engine** out, bool devicePeers) {
   *out = nullptr;
   auto t0 = std::chrono::steady_clock::now();
   wg_handel_params p = *pp;
@@ -310,9 +316,11 @@ static int32_t handel_create(const wg_handel_params* pp, const char* nodeBuilder
   CK(set_latency_early(e, latencyName));  // Handel ctor :208-212
   JavaRandom rd(seed);
 
-  // Network.chooseBadNodes (C/Network.java:52-64)
+  // params.badNodes != null ? params.badNodes : Network.chooseBadNodes(rd, nodeCount, nodesDown)  (:960-964; C/Network.java:52-64)
   std::vector<uint8_t> bad(N, 0);
-  for (int setDown = 0; setDown < p.nodesDown;) {
+  if (badNodes)
+    for (int i = 0; i < N; i++) bad[i] = badNodes[i] != 0;
+  for (int setDown = 0; !badNodes && setDown < p.nodesDown;) {
     int32_t d = rd.nextInt(N);
     if (d != 1 && !bad[d]) {
       bad[d] = 1;

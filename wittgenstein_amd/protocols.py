@@ -46,8 +46,9 @@ class PingPong:
 
 class HandelParameters:
     """P/Handel.java:97-142 (constructor argument order preserved). byzantineSuicide (:538-559, 577-584, 688-694) and
-    hiddenByzantine (:813-817, 840-917) are resident on the device; an explicit badNodes set is not — it runs in
-    host-callback mode (examples/hostmode/handel.py on wittgenstein_amd.hostnet, checked against the oracle)."""
+    hiddenByzantine (:813-817, 840-917) are resident on the device, with the down nodes chosen by Network.chooseBadNodes or
+    given explicitly: badNodes = the ids of the BitSet's set bits (any iterable of ints), used by init() instead of the
+    draws (:960-964)."""
 
     def __init__(self, nodeCount, threshold, pairingTime, levelWaitTime, extraCycle, disseminationPeriodMs, fastPath,
                  nodesDown, nodeBuilderName=None, networkLatencyName=None, desynchronizedStart=0,
@@ -55,10 +56,10 @@ class HandelParameters:
         if byzantineSuicide and hiddenByzantine:
             from .core import IllegalArgumentException
             raise IllegalArgumentException("Only one attack at a time")
-        if badNodes is not None:
-            from .core import UnsupportedError
-            raise UnsupportedError("an explicit badNodes set is not resident on the device: run it in host-callback mode "
-                                   "(examples/hostmode/handel.py)")
+        self.badNodes = None if badNodes is None else sorted(set(int(i) for i in badNodes))
+        if self.badNodes and not (0 <= self.badNodes[0] and self.badNodes[-1] < nodeCount):
+            from .core import IllegalArgumentException
+            raise IllegalArgumentException("badNodes: ids must be in [0, nodeCount)")
         self.byzantineSuicide, self.hiddenByzantine = bool(byzantineSuicide), bool(hiddenByzantine)
         self.nodeCount, self.threshold, self.pairingTime, self.levelWaitTime = nodeCount, threshold, pairingTime, levelWaitTime
         self.extraCycle, self.disseminationPeriodMs, self.fastPath, self.nodesDown = extraCycle, disseminationPeriodMs, fastPath, nodesDown
@@ -84,9 +85,14 @@ class Handel:
                                 int(p.byzantineSuicide), int(p.hiddenByzantine))
         h = C.c_void_p()
         cfg = _config(self.config)
-        rc = L.lib().wgh_handel_create(C.byref(hp), p.nodeBuilderName.encode() if p.nodeBuilderName else None,
-                                       p.networkLatencyName.encode() if p.networkLatencyName else None,
-                                       C.c_int64(self.seed), C.byref(cfg), C.byref(h))
+        bad = None
+        if p.badNodes is not None:
+            bad = (C.c_uint8 * p.nodeCount)()
+            for i in p.badNodes:
+                bad[i] = 1
+        rc = L.lib().wgh_handel_create_bad_nodes(C.byref(hp), bad, p.nodeBuilderName.encode() if p.nodeBuilderName else None,
+                                                 p.networkLatencyName.encode() if p.networkLatencyName else None,
+                                                 C.c_int64(self.seed), C.byref(cfg), C.byref(h))
         if rc != L.WG_OK:
             _raise(rc, L.lib().wgh_last_error().decode())
         self._net = Network(h)
