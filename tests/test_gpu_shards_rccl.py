@@ -31,7 +31,7 @@ def test_pingpong_through_the_engines_own_communicator():
         assert not d, d
     assert shards.shard_range(p.network()) == (0, 1000)
     calls, words = shards.traffic(p.network())
-    assert calls > 0 and words >= 2 * 2000 + 5 * 1000
+    assert calls > 0 and words >= 2000 + 5 * 1000  # one packed word per event + one record image per Pong
 
 
 @pytest.mark.parametrize("params", [(64, 57, 4, 50, 10, 20, 10, 6, 0), (256, 230, 4, 50, 10, 20, 10, 25, 100)])

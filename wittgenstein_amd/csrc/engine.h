@@ -104,6 +104,7 @@ constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;
 constexpr int GRID_TILES = 256 / WG_GRID_DIV;
 constexpr int GRID_EXPAND_RUNS = 1024 / WG_GRID_DIV;  // x 4 wavefronts: one per long chain run
 constexpr int GRID_COND_TAIL = 128 / WG_GRID_DIV;
+constexpr int GRID_SHARD_SMALL = 64 / WG_GRID_DIV > 0 ? 64 / WG_GRID_DIV : 1;  // the per-ms glue kernels of a sharded engine: one engine's ~ 10 k items
 
 enum RecKind : uint32_t { K_MSG = 0, K_TASK = 1, K_PERIODIC = 2, K_CHAIN = 3 };
 
@@ -197,6 +198,30 @@ struct EvRes {
 constexpr uint32_t EV_NREC_MASK = 0xFFFFu;
 constexpr uint32_t EV_DELIVERED = 1u << 16;  // counted in msgReceived (C/Network.java:607-613)
 constexpr uint32_t EV_TASK_RUN = 1u << 17;
+// a periodic task that wrote a payload snapshot other shards will read (sharded engines: Handel's dissemination, GSF's
+// doCycle): code k in bits 18..21 = a row of 2^(k-1) 64-bit words (0: none — e.g. a Handel node whose open levels are all
+// complete sends the constant all-ones block)
+constexpr int EV_SNAP_SHIFT = 18;
+constexpr uint32_t EV_SNAP_MASK = 0xFu << EV_SNAP_SHIFT;
+__host__ __device__ inline uint32_t ev_snap_code(uint32_t words) {  // smallest k with 2^(k-1) >= words (words >= 1)
+  uint32_t k = 1;
+  while ((1u << (k - 1)) < words) k++;
+  return k;
+}
+// exchange 1 of a sharded engine ships ONE int32 per event (the owner's; zeros elsewhere, summed): records 10 bits | delivered
+// | task run | level 5 | snapshot code 4 | draws 11 — an event beyond those ranges stops the run loudly (ERR_OUTBOX)
+__host__ __device__ inline bool evres_packable(const EvRes& r) { return (r.nrec & EV_NREC_MASK) < 1024u && r.ndraw < 2048u; }
+__host__ __device__ inline uint32_t evres_pack(const EvRes& r) {
+  return (r.nrec & 1023u) | ((r.nrec & EV_DELIVERED) ? 1u << 10 : 0u) | ((r.nrec & EV_TASK_RUN) ? 1u << 11 : 0u) |
+         (((r.nrec >> 24) & 31u) << 12) | (((r.nrec & EV_SNAP_MASK) >> EV_SNAP_SHIFT) << 17) | (r.ndraw << 21);
+}
+__host__ __device__ inline EvRes evres_unpack(uint32_t w) {
+  EvRes r;
+  r.nrec = (w & 1023u) | ((w >> 10) & 1u ? EV_DELIVERED : 0u) | ((w >> 11) & 1u ? EV_TASK_RUN : 0u) | (((w >> 12) & 31u) << 24) |
+           (((w >> 17) & 15u) << EV_SNAP_SHIFT);
+  r.ndraw = w >> 21;
+  return r;
+}
 
 enum LatKind : int32_t { LAT_BYDIST = 0, LAT_FIXED = 1, LAT_UNIFORM = 2, LAT_NONE = 3, LAT_MEASURED = 4, LAT_IC3 = 5, LAT_ETHSCAN = 6, LAT_CITY = 7 };
 
@@ -256,7 +281,7 @@ struct Globals {
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
   uint32_t nScatter;       // nOut as k_col_reserve_end saw it: what k_scatter appends after that kernel has reset nOut
-  uint32_t padG;
+  uint32_t nSnapEv;        // sharded engines: events of this ms that wrote a payload snapshot (EV_SNAP_*), counted by the order scan
 };
 constexpr uint32_t KPROF_WAVES = 16384;
 constexpr uint32_t NOTE_RANKS_SATURATED = 1u;  // Handel: a receptionRanks entry hit Integer.MAX_VALUE (P/Handel.java:826-828)
@@ -358,6 +383,7 @@ struct EngineDev {
                             // XB_HEAD header words (xbuf[-XB_HEAD] = multi-destination envelopes among the records),
                             // which travel in the same all-reduce
   GP<int32_t> xmulti;          // [maxMulti][XM_WORDS] exchange image of the multi-destination envelopes of a phase
+  GP<int32_t> xev;             // [maxEvents] exchange image of the events' results: one packed word each (evres_pack)
   uint32_t maxMulti;
   GP<uint32_t> multiK;         // [maxOut] ordinal of a fresh multi-destination record / offset of its destinations
   GP<uint32_t> multiOff;

@@ -622,6 +622,7 @@ void Engine::ensure_device() {
   dev.shardHi = INT32_MAX;
   dev.xbuf = nullptr;
   dev.xmulti = nullptr;
+  dev.xev = nullptr;
   dev.maxMulti = 0;
   dev.multiK = dev.multiOff = nullptr;
   dev.sdests = dev.dests;
@@ -633,6 +634,7 @@ void Engine::ensure_device() {
     dev.xbuf = dalloc<int32_t>((size_t)maxOut * 5 + XB_HEAD) + XB_HEAD;
     dev.maxMulti = std::max<uint32_t>(1024, maxOut / 16);
     dev.xmulti = dalloc<int32_t>((size_t)dev.maxMulti * XM_WORDS);
+    dev.xev = dalloc<int32_t>(maxOut, false, AC_SCRATCH);
     dev.multiK = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
     dev.multiOff = dalloc<uint32_t>(maxOut, false, AC_SCRATCH);
     dev.sdests = dalloc<int32_t>(chainDests, false);  // private scratch for unsorted destination lists
@@ -1452,29 +1454,33 @@ __global__ void k_publish(const uint32_t* a, const uint32_t* b, Engine::Mailbox*
   __threadfence_system();
   mb->seq = seq;
 }
-void Engine::await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb) {
+uint32_t Engine::publish_counts(const uint32_t* a, const uint32_t* b) {
   if (!mailbox) {
-    WG_HIP(hipHostMalloc((void**)&mailbox, sizeof(Mailbox), 0));
-    memset((void*)mailbox, 0, sizeof(Mailbox));
+    WG_HIP(hipHostMalloc((void**)&mailbox, sizeof(Mailbox) * MAILBOXES, 0));
+    memset((void*)mailbox, 0, sizeof(Mailbox) * MAILBOXES);
   }
   const uint32_t seq = ++mailSeq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, a, b, mailbox, seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, a, b, mailbox + (seq % MAILBOXES), seq);
+  return seq;
+}
+void Engine::wait_counts(uint32_t seq, uint32_t* va, uint32_t* vb) {
+  volatile Mailbox* mb = mailbox + (seq % MAILBOXES);
   // acquire on the sequence word: the counts the device wrote before it are read after it, whatever the compiler would
-  // like to hoist; the spin yields its pipeline slots (a host thread per shard polls two or three times per simulated ms)
+  // like to hoist; the spin yields its pipeline slots
   uint64_t spins = 0;
-  while (__atomic_load_n(&mailbox->seq, __ATOMIC_ACQUIRE) != seq) {
+  while (__atomic_load_n(&mb->seq, __ATOMIC_ACQUIRE) != seq) {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
 #endif
     if ((++spins & 0xFFFF) == 0) {  // a failed launch would never publish: ask the runtime now and then
       const hipError_t q = hipStreamQuery(stream);
       if (q != hipSuccess && q != hipErrorNotReady) WG_HIP(q);
-      if (q == hipSuccess && __atomic_load_n(&mailbox->seq, __ATOMIC_ACQUIRE) != seq)
+      if (q == hipSuccess && __atomic_load_n(&mb->seq, __ATOMIC_ACQUIRE) != seq)
         throw WgError(WG_EHIP, "the count mailbox was not written");
     }
   }
-  if (va) *va = __atomic_load_n(&mailbox->v[0], __ATOMIC_RELAXED);
-  if (vb) *vb = __atomic_load_n(&mailbox->v[1], __ATOMIC_RELAXED);
+  if (va) *va = __atomic_load_n(&mb->v[0], __ATOMIC_RELAXED);
+  if (vb) *vb = __atomic_load_n(&mb->v[1], __ATOMIC_RELAXED);
 }
 
 void Engine::shard_allreduce(void* buf, int64_t count) {
@@ -1498,9 +1504,10 @@ void Engine::exchange_outbox(uint32_t nOut) {
   // the header word arrived with the records: how many of them are multi-destination envelopes still to be created
   // (the collective has synchronised; no further stream synchronisation is needed to read it)
   uint32_t nMulti = 0;
-  await_counts((const uint32_t*)(dev.xbuf - XB_HEAD), nullptr, &nMulti, nullptr);
+  const uint32_t seq = publish_counts((const uint32_t*)(dev.xbuf - XB_HEAD), nullptr);
   WG_HIP(hipMemsetAsync(dev.xbuf - XB_HEAD, 0, sizeof(int32_t) * XB_HEAD, stream));  // for the next phase's producers
-  hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+  hipLaunchKernelGGL(k_shard_unpack, dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, stream, g.tab);
+  wait_counts(seq, &nMulti, nullptr);  // (read while k_shard_unpack runs)
   if (!nMulti) return;
   scan<MultiF>(g, nullptr);
   nMulti = std::min(nMulti, dev.maxMulti);
@@ -1555,21 +1562,40 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
       }
     }
     expand(g);
+    const uint32_t seqE = publish_counts(gfield(&Globals::nEvents), nullptr);  // (known after expand: read behind the delivery pass)
     {
       ProfScope ps(*this, PC_DELIVER);
       proto->launch_deliver(g);
     }
-    uint32_t* dSnap = proto->shard_snap_enqueue(g);  // (numbers this ms's payload rows; its count is read with nEvents)
-    uint32_t nEvents = 0, nSnap = 0;
-    await_counts(gfield(&Globals::nEvents), dSnap, &nEvents, &nSnap);
+    uint32_t nEvents = 0;
+    wait_counts(seqE, &nEvents, nullptr);
     idlePrev = nEvents == 0;
-    if (dSnap && nEvents && nSnap) proto->shard_snap_exchange(*this, g, nSnap);
-    shard_allreduce(dev.evRes, 2 * (int64_t)nEvents);
+    // exchange 1: the events' results, one packed word each (records, draws, the two flags, the level, the snapshot code)
+    if (nEvents) {
+      hipLaunchKernelGGL((k_shard_evres<true>), dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, stream, g.tab);
+      shard_allreduce(dev.xev, (int64_t)nEvents);
+      hipLaunchKernelGGL((k_shard_evres<false>), dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, stream, g.tab);
+    }
     scan<RecsF>(g, nullptr);
-    uint32_t nOut = 0;
-    await_counts(gfield(&Globals::nOut), nullptr, &nOut, nullptr);
+    // the payload snapshots of this ms (Handel's disseminations, GSF's doCycles): which events wrote one, and how wide, came
+    // with exchange 1 and the order scan counted them (nSnapEv); only a ms that has any numbers its rows (a second scan)
+    const bool snapScan = proto->shard_snap_is_scan();
+    const uint32_t* dSecond = !nEvents ? nullptr : snapScan ? gfield(&Globals::nSnapEv) : proto->shard_snap_enqueue(g);
+    uint32_t nOut = 0, nSnap = 0;
+    const uint32_t seqO = publish_counts(gfield(&Globals::nOut), dSecond);
+    // (k_resolve takes the record count from the device: enqueued BEFORE the host learns it, so that the poll is not a gap)
+    if (nEvents) hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
+    wait_counts(seqO, &nOut, &nSnap);
+    if (dSecond && nSnap) {
+      if (snapScan) {  // rows packed back to back: their total width sizes the collective
+        uint32_t words = 0;
+        await_counts(proto->shard_snap_enqueue(g), nullptr, &words, nullptr);
+        if (words) proto->shard_snap_exchange(*this, g, words);
+      } else {
+        proto->shard_snap_exchange(*this, g, nSnap);
+      }
+    }
     if (nOut) {
-      hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
       exchange_outbox(nOut);
       if (dev.maxSendAll) {  // the Network.sendAll calls among them: destinations, envelopes, first arrivals — on every shard
         hipLaunchKernelGGL(k_sendall_lat, dim3(GRID_TILES, 1), dim3(TILE), g.histLds, stream, g.tab);
@@ -2405,6 +2431,7 @@ struct HandelHost : ProtoHost {
     st.nSnap = nullptr;
     st.xsnap = nullptr;
     st.xsnapRows = 0;
+    st.xcand = e.shardCount > 0 ? e.dalloc<int32_t>((size_t)N / 4 + 1) : nullptr;
     {  // the all-ones block: the payload of a send whose totalOutgoing is complete (dissemination, fast path of a shard)
       std::vector<uint64_t> ones((size_t)W, ~0ULL);
       uint64_t* dOnes = e.dalloc<uint64_t>(W, false, Engine::AC_CONST);
@@ -2678,6 +2705,7 @@ struct HandelHost : ProtoHost {
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }
   // the dissemination snapshots written in this ms -> every shard's copy of the snapshot ring
+  bool shard_snap_is_scan() const override { return true; }
   uint32_t* shard_snap_enqueue(const Group& g) override {
     Engine::scan<HandelSnapF>(g, (const HandelState*)g.stab);
     return st.nSnap;
@@ -2685,7 +2713,7 @@ struct HandelHost : ProtoHost {
   void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2);  // (nSnap: 64-bit words of the packed rows)
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
   }
   // checkSigs' edge (launch_cond above) with the draw order made global: the per-node candidate counts are summed
@@ -2695,12 +2723,14 @@ struct HandelHost : ProtoHost {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
     launch_a1(g, stab, 1, g.stream);
-    e.shard_allreduce(st.candMask, (int64_t)st.N);  // (a node's candidate levels: its owner's bits, zeros elsewhere)
+    // exchange 5: how many levels of every node have a candidate — a byte per node, its owner's (zeros elsewhere)
+    hipLaunchKernelGGL(k_handel_cand_pack, dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.shard_allreduce(st.xcand, ((int64_t)st.N + 3) / 4);
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
-    e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
+    const uint32_t seq = e.publish_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr);
     hipLaunchKernelGGL((k_handel_cond_a2<true, false>), dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    WG_HIP(hipMemsetAsync(st.candMask, 0, 4 * (size_t)st.N, g.stream));  // the other shards' masks
+    e.wait_counts(seq, &nOut, nullptr);  // (read while the tail runs)
     return nOut;
   }
   // blocks per engine of the wave-per-item kernels. Their pipelined loops want SEVERAL items per wavefront (the next
@@ -3049,6 +3079,7 @@ struct GsfHost : ProtoHost {
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
+  bool shard_snap_is_scan() const override { return true; }
   uint32_t* shard_snap_enqueue(const Group& g) override {  // the doCycle snapshots (PARTIAL payloads) of this ms
     Engine::scan<GsfSnapF>(g, (const GsfState*)g.stab);
     return st.nSnap;
@@ -3056,7 +3087,7 @@ struct GsfHost : ProtoHost {
   void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
     const GsfState* stab = (const GsfState*)g.stab;
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.xsnap, (int64_t)nSnap * st.snapStride * 2);
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2);  // (nSnap: 64-bit words of the packed rows)
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
   }
   // checkSigs' edge: which nodes register a task is summed across shards, so that the registrations keep their
@@ -3068,8 +3099,9 @@ struct GsfHost : ProtoHost {
     e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
     Engine::scan<GsfCondF>(g, stab);
     uint32_t nOut = 0;
-    e.await_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr, &nOut, nullptr);
+    const uint32_t seq = e.publish_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr);
     hipLaunchKernelGGL(k_gsf_cond_a2<true>, dim3(GRID_COND_TAIL, 1), dim3(256), 0, g.stream, g.tab, stab);
+    e.wait_counts(seq, &nOut, nullptr);  // (read while the tail runs)
     WG_HIP(hipMemsetAsync(st.candFlag, 0, ((size_t)st.N + 3) / 4 * 4, g.stream));  // the other shards' flags
     return nOut;
   }

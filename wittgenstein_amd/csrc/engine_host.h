@@ -71,6 +71,10 @@ struct ProtoHost {
   // after the delivery kernels of a ms: payloads written by this shard's action()s that other shards will read.
   // enqueue numbers the rows on the device and returns where their count will be (NULL: the protocol has none);
   // exchange ships `nSnap` rows (called only when there are any)
+  // payload snapshots of this ms that other shards will read. Two forms: rows numbered by a scan over the events that
+  // reported one (shard_snap_is_scan: Handel, GSFSignature — enqueued only in a ms whose order scan counted such events,
+  // Globals::nSnapEv), or a count the delivery pass left behind (Casper's table exchange)
+  virtual bool shard_snap_is_scan() const { return false; }
   virtual uint32_t* shard_snap_enqueue(const Group&) { return nullptr; }
   virtual void shard_snap_exchange(Engine&, const Group&, uint32_t /*nSnap*/) {}
   // the conditional-task phase on a sharded engine: leaves the task records of this shard's nodes in the exchange
@@ -137,9 +141,15 @@ class Engine {
     uint32_t seq;   // written last by k_publish; the host reads it with acquire semantics (await_counts)
     uint32_t v[7];
   };
-  Mailbox* mailbox = nullptr;             // pinned host memory (hipHostMalloc), device-visible
+  Mailbox* mailbox = nullptr;             // pinned host memory (hipHostMalloc), device-visible: a ring of MAILBOXES
+  static constexpr uint32_t MAILBOXES = 8;
   uint32_t mailSeq = 0;
-  void await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb);  // device words -> host
+  // publish_counts enqueues the write of two device words into the next mailbox (in stream order, behind their producers);
+  // wait_counts polls for it. The caller enqueues, between the two, every kernel that needs the counts only as device
+  // values — the host learns a count while the device already works with it, not in an idle gap before the next launch
+  uint32_t publish_counts(const uint32_t* a, const uint32_t* b);
+  void wait_counts(uint32_t seq, uint32_t* va, uint32_t* vb);
+  void await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb) { wait_counts(publish_counts(a, b), va, vb); }
   long long shardCollectives = 0, shardWords = 0;  // all-reduce calls / int32 words summed so far
   int64_t queue_size();
   int64_t queue_size_at(int32_t t);

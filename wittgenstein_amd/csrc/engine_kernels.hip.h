@@ -602,8 +602,8 @@ struct RecsF {
     return ((uint64_t)r.ndraw << 32) | (r.nrec & EV_NREC_MASK);
   }
   __device__ void tally(uint32_t lo, uint32_t hi) const {
-    __shared__ uint32_t shStat[34];  // [0..31] delivered by level, [32] delivered, [33] tasks
-    for (int k = threadIdx.x; k < 34; k += SCAN_BLOCK) shStat[k] = 0;
+    __shared__ uint32_t shStat[35];  // [0..31] delivered by level, [32] delivered, [33] tasks, [34] snapshot rows (sharded)
+    for (int k = threadIdx.x; k < 35; k += SCAN_BLOCK) shStat[k] = 0;
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) {
       const uint32_t f = d.evRes[i].nrec;
@@ -612,6 +612,7 @@ struct RecsF {
         atomicAdd(&shStat[32], 1u);
       }
       if (f & EV_TASK_RUN) atomicAdd(&shStat[33], 1u);
+      if (f & EV_SNAP_MASK) atomicAdd(&shStat[34], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 34 && shStat[threadIdx.x]) {
@@ -619,6 +620,7 @@ struct RecsF {
                                                  : (threadIdx.x == 32 ? &d.g->delivered : &d.g->tasks);
       atomicAdd(dst, (unsigned long long)shStat[threadIdx.x]);
     }
+    if (threadIdx.x == 34 && shStat[34]) atomicAdd(&d.g->nSnapEv, shStat[34]);
   }
   __device__ void total(uint64_t tot) const {
     uint32_t n = (uint32_t)tot;
@@ -637,6 +639,23 @@ struct RecsF {
     for (uint32_t k = 0; k < n && off + k < d.maxOut; k++) d.recEv[off + k] = i;
   }
 };
+
+// exchange 1 of a sharded engine: EvRes (8 bytes) <-> one packed int32 per event in the exchange image
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_shard_evres(const EngineDev* __restrict__ tab) {
+  WG_ENGINE(tab);
+  const uint32_t n = d.g->nEvents;
+  if (PACK && blockIdx.x == 0 && threadIdx.x == 0) d.g->nSnapEv = 0;  // (counted afresh by this ms's order scan)
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    if (PACK) {
+      const EvRes r = d.evRes[e];
+      if (!evres_packable(r)) set_err(d.g, ERR_OUTBOX);
+      d.xev[e] = (int32_t)evres_pack(r);
+    } else {
+      d.evRes[e] = evres_unpack((uint32_t)d.xev[e]);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // resolve: unordered outbox -> ordered outbox (fin, arr). One thread per record.
@@ -1595,6 +1614,7 @@ struct Ctx {
   uint32_t draws;  // rd.nextInt() calls by this event so far
   uint32_t outBase, outCap;      // the event's private outbox slice
   long long msgSent, bytesSent;  // accumulated Node counters (C/Network.java:476-477)
+  uint32_t evFlags;              // OR-ed into the event's EvRes::nrec by whoever writes it (EV_SNAP_* code of a snapshot)
 
   __device__ void put(uint32_t kind, int32_t to, uint32_t a, uint32_t b, int32_t tt, uint32_t destOff, bool draw,
                       uint32_t pad = 0, uint32_t extraDraws = 0) {
@@ -1757,6 +1777,7 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
   c.ev = e;
   c.sub = 0;
   c.draws = 0;
+  c.evFlags = 0;
   c.outBase = aux.outBase;
   c.outCap = aux.outCap;
   uint32_t flags = 0;
@@ -1786,7 +1807,7 @@ __device__ __forceinline__ void deliver_event(const EngineDev& d, const typename
   KPROF_MARK(d.g, 30);  // the action() (+ a periodic task's re-arm, a chain's continuation)
   if (WG_LANE == 0) {
     EvRes res;
-    res.nrec = c.sub | flags;
+    res.nrec = c.sub | flags | c.evFlags;
     res.ndraw = c.draws;
     gst(d.evRes + e, res);
   }

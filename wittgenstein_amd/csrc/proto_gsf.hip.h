@@ -255,6 +255,7 @@ struct GsfProto {
         const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
         ref = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride + s.lvlOff[l];
         H_FOR_WORDS(v, j) s.snap[ref + j] = vr[v.bw + j] & v.mask;
+        c.evFlags = ev_snap_code(s.snapStride) << EV_SNAP_SHIFT;  // (a sharded engine ships the node's row of this window)
       }
       c.send(dest, word, ref, g_msg_size(l));
       if (WG_LANE == 0) {

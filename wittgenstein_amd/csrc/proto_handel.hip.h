@@ -149,6 +149,9 @@ struct HandelState {
   GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> cleanMask;                 // [N] ... of which: clean levels, answered from their summary by k_handel_cond_pre (no item)
+  // sharded engines: how many levels of every node have a candidate at this edge, one BYTE per node (four nodes an int32
+  // word) — what the other shards need of candMask to number the draws (exchange 5: N / 4 words instead of N)
+  GP<int32_t> xcand;                      // [N / 4 + 1]; NULL when not sharded
   GP<uint32_t> condList;                  // drawing nodes in id order
   GP<int32_t> drawVal;                    // [N]
   // node-range sharding (wg_shard_configure): this engine holds the per-node rows above only for the nodes
@@ -637,11 +640,13 @@ struct HandelProtoT {
     // instead of a copy (the receiver masks it with its level's mask, as it does a snapshot): complete levels are the low
     // ones (an incomplete block makes every block above it incomplete), so the copy is of the highest open INCOMPLETE
     // level's block — none at all for a node that holds its whole half, which is every node for the last third of a run.
-    // Those messages' payload reads then hit 2 KB that never leave L2. (A sharded engine exchanges the snapshots: as before.)
-    const bool complete = !c.d.sharded && mySize != 0 && below == mySize;
+    // Those messages' payload reads then hit 2 KB that never leave L2. A sharded engine ships to the other shards only what
+    // was copied: the event's result carries the row's width (EV_SNAP_*), nothing for a node without an incomplete open level.
+    const bool complete = mySize != 0 && below == mySize;
     const uint64_t copyM = __ballot(open && !complete);
     Lv tv = own_view(node, copyM ? 63 - __clzll((unsigned long long)copyM) : 1);
     if (!copyM) tv.nw = 0;
+    c.evFlags = tv.nw ? ev_snap_code((uint32_t)tv.nw) << EV_SNAP_SHIFT : 0u;
     // (two words a lane: the kernel is bound by its wave-level memory instructions. A pair of consecutive block words
     // sits side by side in one level's group — except the pair made of the node's own word and its level-7 sibling)
     V2 sv[2];
@@ -1663,7 +1668,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __r
     }
     if (lane == 0) {
       EvRes res;
-      res.nrec = c.sub | flags;
+      res.nrec = c.sub | flags | c.evFlags;
       res.ndraw = c.draws;
       gst(d.evRes + e, res);
     }
@@ -2318,24 +2323,44 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1c(const EngineDev* __rest
 // scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate),
 // and the draw itself — chooseBestFromLevels: rd.nextInt(byLevels.size()) (:788-790) — by jump-ahead
 // assuming no earlier nextInt(bound) rejection; a rejection anywhere is flagged and re-walked in A2.
+// byLevels.size() of node i at this edge: its own mask's bits, or (sharded) the byte the owner's shard reported
+__device__ __forceinline__ int32_t h_cand_count(const HandelState& s, uint32_t i) {
+  if (s.xcand) return (int32_t)(((uint32_t)s.xcand[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu);
+  return (int32_t)__popc(s.candMask[i]);
+}
+// sharded: the owners' counts into the exchange image (zeros for the nodes of other shards)
+__global__ void __launch_bounds__(256) k_handel_cand_pack(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const uint32_t nw = ((uint32_t)s.N + 3u) >> 2;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += gridDim.x * blockDim.x) {
+    uint32_t w = 0;
+    for (uint32_t q = 0; q < 4; q++) {
+      const uint32_t i = 4 * j + q;
+      if (i >= (uint32_t)s.lo && i < (uint32_t)s.hi) w |= (uint32_t)__popc(s.candMask[i]) << (8 * q);
+    }
+    s.xcand[j] = (int32_t)w;
+  }
+}
 struct CondF {
   typedef HandelState Aux;
   const EngineDev& d;
   const HandelState& s;
   __device__ CondF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
   __device__ uint32_t count() const { return (uint32_t)s.N; }
-  __device__ uint64_t value(uint32_t i) const { return s.candMask[i] != 0; }
+  __device__ uint64_t value(uint32_t i) const { return h_cand_count(s, i) != 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
     d.g->nOut = (uint32_t)tot;  // one registerTask per drawing node
     d.g->nDraws = (uint32_t)tot;
   }
   __device__ void write(uint32_t i, uint64_t excl, bool valid) const {
-    if (!valid || s.candMask[i] == 0) return;
+    const int32_t nc = h_cand_count(s, i);
+    if (!valid || nc == 0) return;
     s.condList[(uint32_t)excl] = i;
     uint64_t st = lcg_skip(d.g->rng, excl);
     int consumed;
-    s.drawVal[i] = lcg_next_int_bounded(st, (int32_t)__popc(s.candMask[i]), &consumed);
+    s.drawVal[i] = lcg_next_int_bounded(st, nc, &consumed);
     if (consumed != 1) d.g->rejectSeen = 1;
   }
 };
@@ -2478,7 +2503,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         uint32_t total = 0;
         for (uint32_t q = 0; q <= j; q++) {
           int consumed;
-          k = lcg_next_int_bounded(st, (int32_t)__popc(s.candMask[s.condList[q]]), &consumed);
+          k = lcg_next_int_bounded(st, h_cand_count(s, s.condList[q]), &consumed);
           total += (uint32_t)consumed;
         }
         if (j + 1 == n) d.g->nDraws = total;
@@ -2917,10 +2942,15 @@ __global__ void __launch_bounds__(256) k_handel_init_shuffle(HandelState s, cons
 // rows are those of the periodic-task events (task word TASK) of the (replicated) event list, numbered in event
 // order by SnapF. S = HandelState / GsfState: snap, snapNb, snapStride, N, snapIdx, nSnap, xsnap, xsnapRows.
 __device__ __forceinline__ int32_t snap_period(const HandelState& s) { return s.p.disseminationPeriodMs; }
-template <uint32_t TASK>
-__device__ __forceinline__ bool is_snapshot_event(const EngineDev& d, uint32_t e) {
+// 64-bit words of the snapshot row event e wrote (0: none): its owner reported the width with the event's result
+// (EV_SNAP_*, exchange 1), so every shard numbers the same rows
+template <uint32_t TASK, class S>
+__device__ __forceinline__ uint32_t snapshot_words(const EngineDev& d, const S& s, uint32_t e) {
+  const uint32_t code = (d.evRes[e].nrec & EV_SNAP_MASK) >> EV_SNAP_SHIFT;
+  if (!code) return 0u;
   const Rec r = d.ev[e];
-  return rec_kind(r) == K_PERIODIC && r.w2 == TASK;
+  if (rec_kind(r) != K_PERIODIC || r.w2 != TASK) return 0u;
+  return min(1u << (code - 1), s.snapStride);
 }
 template <class S, uint32_t TASK>
 struct SnapF {
@@ -2929,14 +2959,16 @@ struct SnapF {
   const S& s;
   __device__ SnapF(const EngineDev& d_, const Aux* a) : d(d_), s(*a) {}
   __device__ uint32_t count() const { return d.g->nEvents; }
-  __device__ uint64_t value(uint32_t e) const { return is_snapshot_event<TASK>(d, e); }
+  // rows are packed back to back: the scan runs over their widths, `nSnap` is the image's size in 64-bit words
+  __device__ uint64_t value(uint32_t e) const { return snapshot_words<TASK>(d, s, e); }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
-    if ((uint32_t)tot > s.xsnapRows) set_err(d.g, ERR_PAYLOAD);
-    *s.nSnap = min((uint32_t)tot, s.xsnapRows);
+    const uint64_t cap = (uint64_t)s.xsnapRows * s.snapStride;
+    if (tot > cap) set_err(d.g, ERR_PAYLOAD);
+    *s.nSnap = (uint32_t)(tot > cap ? cap : tot);
   }
   __device__ void write(uint32_t e, uint64_t excl, bool valid) const {
-    if (valid) s.snapIdx[e] = (uint32_t)excl;
+    if (valid) s.snapIdx[e] = (uint32_t)excl;  // the row's first word in the image
   }
 };
 // one wavefront per snapshot event: pack = owner's ring row -> image (zeros elsewhere); unpack = summed
@@ -2948,13 +2980,15 @@ __global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict_
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t nEv = d.g->nEvents;
   const uint32_t win = ((uint32_t)d.g->now / (uint32_t)snap_period(s)) % s.snapNb;
+  const uint64_t cap = (uint64_t)s.xsnapRows * s.snapStride;
   for (uint32_t e = wave; e < nEv; e += nWaves) {
-    if (!is_snapshot_event<TASK>(d, e) || s.snapIdx[e] >= s.xsnapRows) continue;
+    const uint32_t w = snapshot_words<TASK>(d, s, e);
+    if (!w || (uint64_t)s.snapIdx[e] + w > cap) continue;
     const int32_t node = (int32_t)d.ev[e].w1;
     const bool owned = shard_owns(d, node);
     uint64_t WG_G* row = s.snap + (size_t)(win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
-    uint64_t WG_G* img = (uint64_t WG_G*)(int32_t WG_G*)s.xsnap + (size_t)s.snapIdx[e] * s.snapStride;
-    for (uint32_t j = WG_LANE; j < s.snapStride; j += 64) {
+    uint64_t WG_G* img = (uint64_t WG_G*)(int32_t WG_G*)s.xsnap + (size_t)s.snapIdx[e];
+    for (uint32_t j = WG_LANE; j < w; j += 64) {
       if (PACK)
         img[j] = owned ? row[j] : 0ULL;
       else if (!owned)
