@@ -2290,7 +2290,7 @@ struct HandelHost : ProtoHost {
   // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
   // tuning knobs, see DESIGN.md "Occupancy"
   int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
-  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 6;  // (k_handel_a1w: 79 VGPRs, no scratch; eight waves spill 44 B)
+  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 5;  // (k_handel_a1c with the group form: 82 VGPRs; k_handel_a1w alone: 79)
   int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
   int wavesDissem = getenv("WG_DISSEM_WAVES") ? atoi(getenv("WG_DISSEM_WAVES")) : 8;
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
@@ -2364,7 +2364,8 @@ struct HandelHost : ProtoHost {
     st.qsig = e.dalloc<uint64_t>(off, false, Engine::AC_SCRATCH);
     // the cached evaluations of the listed signatures (HandelState::qcache): read only where the record's valid mask says so
     st.QC = (Q + 3) & ~3;
-    st.qcache = rows((uint32_t*)nullptr, (size_t)L * st.QC, false, Engine::AC_SCRATCH);
+    // (+ 8 words: the group form of k_handel_a1 preloads the words of the slots 0 .. 7 whatever the capacity)
+    st.qcache = e.dalloc<uint32_t>(nLoc * (size_t)L * st.QC + 8, false, Engine::AC_SCRATCH) - (size_t)lo * L * st.QC;
     {
       st.snapStride = N >= 128 ? (uint32_t)(N / 128) : 1u;  // words of the top level's block (N/2 ids)
       st.snapNb = (uint32_t)(e.dev.horizon / p.disseminationPeriodMs) + 2;  // a snapshot is read within < horizon ms
@@ -2389,8 +2390,9 @@ struct HandelHost : ProtoHost {
     st.disCount = e.dalloc<uint32_t>(1);
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
+    st.a1Group = !(getenv("WG_A1_GROUP") && atoi(getenv("WG_A1_GROUP")) == 0);
     st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;
-    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 6;
+    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 8;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.cleanMask = e.dalloc<uint32_t>(N);
@@ -2673,12 +2675,20 @@ struct HandelHost : ProtoHost {
       hipLaunchKernelGGL((k_handel_a1w<4, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
       return;
     }
-    if (!a1Split) {  // both kinds of items in one launch (4 waves a SIMD: the lane half's registers)
-      hipLaunchKernelGGL((k_handel_a1c<4>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+    if (!a1Split) {  // both kinds of items in one launch
+      if (!st.a1Group)
+        hipLaunchKernelGGL((k_handel_a1c<4, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+      else if (wavesCond >= 6)  // (80 VGPRs with 12 bytes of scratch; 82 and five waves a SIMD without)
+        hipLaunchKernelGGL((k_handel_a1c<6, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
+      else
+        hipLaunchKernelGGL((k_handel_a1c<5, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
       return;
     }
     // the narrow levels' items, one lane each (~ 5 k an engine in an ordinary ms of config 3), then the wide levels', one wavefront each
-    hipLaunchKernelGGL(k_handel_a1, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
+    if (st.a1Group)
+      hipLaunchKernelGGL(k_handel_a1<true>, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
+    else
+      hipLaunchKernelGGL(k_handel_a1<false>, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
     switch (wavesCond) {
       case 8: launch_a1w<8>(g, stab, R, s); break;
       case 5: launch_a1w<5>(g, stab, R, s); break;
@@ -2749,7 +2759,9 @@ struct HandelHost : ProtoHost {
   // against ~ 70 us for the one launch in which the two halves overlap; WG_A1_SPLIT=1 keeps the two-launch form)
   bool a1Split = getenv("WG_A1_SPLIT") && atoi(getenv("WG_A1_SPLIT")) != 0;
   int a1GridEnv = getenv("WG_A1_GRID") ? atoi(getenv("WG_A1_GRID")) : 0;
-  int a1GridMul = getenv("WG_A1_GRID_MUL") && atoi(getenv("WG_A1_GRID_MUL")) > 0 ? atoi(getenv("WG_A1_GRID_MUL")) : 2;
+  // (the group form holds 32 items a block where the lane form held 256: 6 x the delivery kernels' blocks, half of them on
+  // the groups — profiles/r13q_sweep_a1_grid.txt)
+  int a1GridMul = getenv("WG_A1_GRID_MUL") && atoi(getenv("WG_A1_GRID_MUL")) > 0 ? atoi(getenv("WG_A1_GRID_MUL")) : 6;
   int a1_grid(int R) const { return a1GridEnv > 0 ? a1GridEnv : a1GridMul * node_grid(R); }
   // the delivery pass: k_handel_lane (one lane per node: SendSigs deliveries, narrow updateVerifiedSignatures; sorts the
   // other nodes into the next kernel's list), k_handel_copy (the wide payloads it delivered, one wavefront each), then

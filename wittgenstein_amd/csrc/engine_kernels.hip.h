@@ -92,6 +92,18 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int delta) {
 // §3.1). The DPP row operations move data between lanes inside the VALU (quad_perm / row_ror inside a row of 16,
 // row_bcast:15 / :31 across rows — gfx9-family encodings), a few cycles a step; the total is read from lane 63 with
 // v_readlane, i.e. it lands in an SGPR. tests/emu (no DPP) takes the generic branch.
+struct OpAdd {
+  template <class T>
+  __device__ static T f(T a, T b) { return a + b; }
+};
+struct OpMin {
+  template <class T>
+  __device__ static T f(T a, T b) { return a < b ? a : b; }
+};
+struct OpMax {
+  template <class T>
+  __device__ static T f(T a, T b) { return a > b ? a : b; }
+};
 #if defined(__HIPCC__) && !defined(WG_NO_DPP)
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v) {
@@ -106,18 +118,6 @@ __device__ __forceinline__ uint64_t dpp_mov64(uint64_t old, uint64_t v) {
 // the six steps: pairs, quads, row_ror:4, row_ror:8 (every lane then holds its row's total), row_bcast:15 into rows 1 and 3,
 // row_bcast:31 into rows 2 and 3 — lane 63 ends with the wave's total. `id` is the operation's identity (what a lane
 // without a source contributes).
-struct OpAdd {
-  template <class T>
-  __device__ static T f(T a, T b) { return a + b; }
-};
-struct OpMin {
-  template <class T>
-  __device__ static T f(T a, T b) { return a < b ? a : b; }
-};
-struct OpMax {
-  template <class T>
-  __device__ static T f(T a, T b) { return a > b ? a : b; }
-};
 template <class OP>
 __device__ __forceinline__ uint32_t dpp_reduce32(uint32_t v, uint32_t id) {
   v = OP::f(v, dpp_mov<0xb1, 0xf>(id, v));

@@ -9,6 +9,10 @@
 //             works on ONE level, so what it touches is one line (levels <= 9) or one contiguous run, not a
 //             line in each of five 134 MB arrays. totalOutgoing of level l is always the union of
 //             totalIncoming of levels < l (:728-731) = the node's OWN aligned block (h_word gathers it).
+//             totalIncoming is never READ as a row by the checkSigs / updateVerifiedSignatures kernels: it always equals
+//             lastAggVerified | verifiedIndSignatures (level 0 starts with the own bit in all three, :413-421; an update
+//             sets `from` in VI and TI together, :705-713, or rebuilds TI as LA | VI, :722-724), so those kernels read two
+//             rows and OR them — a quarter of their row traffic. The row is still WRITTEN (dissemination snapshots it).
 //   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] emission lists (:510-522)
 //   queues    toVerifyAgg (:385): per (node, level) one queue record (h_qrec: length, slots in use, the list
 //             in list order — rank, signer, slot per entry — in ONE line for the usual short list) and up to
@@ -75,6 +79,7 @@ struct HandelState {
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
   int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
+  int32_t a1Group;                        // 1: the narrow levels' items by groups of eight lanes (default), 0: one lane each (WG_A1_GROUP=0)
   int32_t laneNw;                         // H_LANE_NW, or WG_LANE_NW (tests: the wave-per-item paths on networks the emulator can run)
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
@@ -805,7 +810,7 @@ struct HandelProtoT {
       sg0 = sig[j0];
       vi0 = vi[j0];
       la0 = la[j0];
-      ti0 = ti[j0];
+      ti0 = la0 | vi0;  // totalIncoming = lastAggVerified | verifiedIndSignatures: the row is written, never read (file header)
     }
     // the VI / TI words holding `from` are among the block words just loaded (the lane owning block word jF);
     // only beyond the first 64 words of a wide level do they cost memory instructions of their own
@@ -815,7 +820,7 @@ struct HandelProtoT {
       tiF = lane_bcast64(ti0, jF);
     } else {
       viF = ld_coherent(vi + jF);
-      tiF = ld_coherent(ti + jF);
+      tiF = viF | ld_coherent(la + jF);
     }
     const bool owner = lane == (jF & 63);
     if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
@@ -879,7 +884,8 @@ struct HandelProtoT {
       }
       for (int j = j0 + 64; j < v.nw; j += 64) {
         uint64_t sg = sig[j];
-        uint64_t law = la[j], viw = vi[j], tiw = ti[j];
+        uint64_t law = la[j], viw = vi[j];
+        const uint64_t tiw = law | (j == jF ? (viw & ~(hadVI ? 0ULL : bit)) : viw);  // the TI word as it is in memory
         if (j == jF) viw |= bit;  // (this lane stored it above; same-lane order makes the reload see it anyway)
         uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
         uint64_t nti = nla | (viw & v.mask);
@@ -1017,7 +1023,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   U4 a = gld(lvA);
   const HQHead qh = gld((const HQHead WG_G*)qr);
   const uint64_t tvv = *tvp;
-  const uint64_t viF = vi[jF], tiF = ti[jF];
+  const uint64_t viF = vi[jF], tiF = viF | la[jF];  // totalIncoming = lastAggVerified | verifiedInd: the row is not read
   uint64_t e6[6];  // the head of the level's list (the record's first line); longer lists are walked in memory below
 #pragma unroll
   for (int i = 0; i < 6; i++) e6[i] = ent[i];
@@ -1087,7 +1093,8 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   if (replace) {  // (only the words that change are written)
     cLA = 0;
     cTI = 0;
-    h_stream4(sig, vi, la, ti, v.nw, [&](int j, uint64_t sg, uint64_t viw, uint64_t law, uint64_t tiw) {
+    h_stream4(sig, vi, la, la, v.nw, [&](int j, uint64_t sg, uint64_t viw, uint64_t law, uint64_t tiw) {
+      tiw = law | viw;  // the TI word as it is in memory
       const uint64_t viN = viw | (j == jF ? bit : 0ULL);
       const uint64_t nla = (inter ? 0ULL : (law & v.mask)) | sg;
       const uint64_t nti = nla | (viN & v.mask);
@@ -1440,10 +1447,11 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
       sg[u].x = sg[u].y = tiw[u].x = tiw[u].y = law[u].x = law[u].y = viw[u].x = viw[u].y = 0;
       if (j < v.nw) {
         sg[u] = gld((const V2 WG_G*)(sig + j));
-        tiw[u] = gld((const V2 WG_G*)(ti + j));
         law[u] = gld((const V2 WG_G*)(la + j));
         viw[u] = gld((const V2 WG_G*)(vi + j));
       }
+      tiw[u].x = law[u].x | viw[u].x;  // totalIncoming as it is in memory = lastAggVerified | verifiedInd (the row is not read)
+      tiw[u].y = law[u].y | viw[u].y;
     }
     auto bc = [&](uint32_t w, int l_) { return WG_READLANE(w, l_); };
     U4 hT, hD, pend, pfrom, a;
@@ -1977,22 +1985,22 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
   if (lane < 5) pg = gld(piece);
   uint64_t entAll = lane < 13 ? ent[lane] : 0ULL;
   const bool wideRound = v.nw <= 256;  // (levels <= 15; beyond: the word loop below)
-  V2 ti2[2], vi2[2], la2[2];
+  V2 ti2[2], vi2[2], la2[2];  // (ti2 = la2 | vi2: totalIncoming is their union, the row is not read)
 #pragma unroll
   for (int u = 0; u < 2; u++) {
     const int j = 2 * (u * 64 + lane);
-    ti2[u].x = ti2[u].y = vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
+    vi2[u].x = vi2[u].y = la2[u].x = la2[u].y = 0;
     if (ATK && v.nw == 1) {  // (the levels below 8, which only the attack's runs bring here: one masked word)
       if (j == 0) {
-        ti2[u].x = ti[0] & v.mask;
         vi2[u].x = vi[0] & v.mask;
         la2[u].x = la[0] & v.mask;
       }
     } else if (wideRound && j < v.nw) {
-      ti2[u] = gld((const V2 WG_G*)(ti + j));
       vi2[u] = gld((const V2 WG_G*)(vi + j));
       la2[u] = gld((const V2 WG_G*)(la + j));
     }
+    ti2[u].x = la2[u].x | vi2[u].x;
+    ti2[u].y = la2[u].y | vi2[u].y;
   }
   U4 pend;
   pend.x = WG_READLANE(pg.x, 0);
@@ -2101,7 +2109,10 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
         word(sg[u].y, ti2[u].y, vi2[u].y, la2[u].y);
       }
     } else {
-      H_FOR_WORDS(v, j) word(sig[j], ti[j], vi[j], la[j]);
+      H_FOR_WORDS(v, j) {
+        const uint64_t viw = vi[j], law = la[j];
+        word(sig[j], law | viw, viw, law);
+      }
     }
     a = wave_sum64(a);
     b = wave_sum64(b);
@@ -2168,125 +2179,353 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
 // item of a narrow level) + k_handel_a1w (one WAVEFRONT per item of a wide level; the attack's runs use it alone) are the
 // two-launch form: the wave half alone needs 79 VGPRs (6 waves a SIMD) where the lane half needs 118, but the lane half is
 // one long chain per item — 44 us by itself — which the one-launch form hides behind the wave items (profiles/r13h_*).
+// bestToVerify of one (node, level) item by ONE lane: an entry's cached evaluation, or its signature streamed against the
+// level's three sets. The slow path of the group form below (lists of more than eight entries) and the reference form of it.
+__device__ __forceinline__ void h_a1_lane_one(const EngineDev& d, const HandelState& s, int32_t node, int l) {
+  const uint32_t WG_G* hdr = h_hdr(s, node);
+  const Lv v = sib_view(node, l);
+  const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
+  const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
+  const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
+  uint64_t WG_G* qr = h_qrec(s, node, l);
+  uint64_t WG_G* ent = qr + H_QENT;
+  uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
+  // ---- everything the item's address alone decides, before the first use: the record's first line (head, valid mask,
+  // four entries) and the cached evaluations of the slots 0 .. 3 (slots are taken lowest first: those are the usual ones)
+  const int window = (int)hdr[HH_WINDOW];
+  const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
+  const HQHead qh = gld((const HQHead WG_G*)qr);
+  const uint64_t valid0 = qr[H_QVALID];
+  uint64_t e4[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) e4[i] = ent[i];
+  const U4 c4 = gld((const U4 WG_G*)cache);
+  const int len = (int)qh.len, curSize = (int)lvA.y, cLA = (int)lvA.z;
+  int windowIndex = INT32_MAX;  // Collections.min(rank)
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
+  for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
+  long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
+  int bestScore = 0, bestOutsideRank = 0;
+  unsigned long long keep = 0;
+  uint64_t newValid = valid0;
+  int sumMin = INT32_MAX, sumMax = 0;  // the level's summary over the entries that stay listed (h_summary_has_candidate)
+  bool sumPos = false;
+  // one entry after the other: its cached evaluation, or its signature streamed against the level's three sets (whose
+  // lines stay in L1) and the result cached
+  auto consider = [&](int i, uint64_t x) {
+    const int slot = (int)(x & 0xFF);
+    uint32_t cw;
+    if ((valid0 >> slot) & 1ULL) {
+      cw = slot == 0 ? c4.x : slot == 1 ? c4.y : slot == 2 ? c4.z : slot == 3 ? c4.w : cache[slot];
+    } else {
+      int u1 = 0, u2 = 0, cs = 0;
+      bool iTI = false, iLA = false;
+      h_stream4(h_sig_ptr(s, node, l, slot), la, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
+        viw &= v.mask;
+        law &= v.mask;
+        tiw = law | viw;  // totalIncoming = lastAggVerified | verifiedIndSignatures (the row is not read)
+        u1 += __popcll(sg | tiw | viw);
+        u2 += __popcll(sg | viw);
+        cs += __popcll(sg);
+        iTI |= (sg & tiw) != 0;
+        iLA |= (sg & law) != 0;
+      });
+      cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
+      cache[slot] = cw;
+      newValid |= 1ULL << slot;
+    }
+    const long long who = (long long)(uint32_t)x;  // signer << 8 | slot
+    const int rank = (int)(uint32_t)(x >> 32);
+    if (cw & 1u) {  // only signatures that can result in a better aggregate stay listed (:592)
+      keep |= 1ULL << i;
+      sumMin = min(sumMin, rank);
+      sumMax = max(sumMax, rank);
+      sumPos |= (cw >> 1) != 0;
+      if (h_in_window(rank, windowIndex, window)) {  // best inside = FIRST entry with the strictly greatest positive score
+        const int score = (int)(cw >> 1);
+        if (score > bestScore) {
+          bestScore = score;
+          bestInside = who;
+        }
+      } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
+        bestOutside = who;
+        bestOutsideRank = rank;
+      }
+    }
+  };
+  // (one copy of the body: the four entries of the head line by selects, not by four inlined copies — registers)
+  for (int i = 0; i < len; i++) consider(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
+  const int kept = __popcll(keep);
+  unsigned long long relMask = 0;
+  if (kept != len) {
+    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+    int pos = 0;
+    auto curate = [&](int i, uint64_t x) {
+      if ((keep >> i) & 1ULL) {
+        if (pos != i) ent[pos] = x;
+        pos++;
+      } else {  // the slot of a dropped entry is released unless a registered task still holds it
+        const uint32_t key = h_pend_word(l, (int)(x & 0xFF));
+        if (!(pend.x == key || pend.y == key || pend.z == key || pend.w == key)) relMask |= 1ULL << (x & 0xFF);
+      }
+    };
+    for (int i = 0; i < len; i++) curate(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
+  }
+  if (newValid != valid0) qr[H_QVALID] = newValid;
+  h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside,
+                (uint32_t)sumMin | (sumPos ? 0x80000000u : 0u), (uint32_t)sumMax);
+#ifdef WG_KPROF
+  {  // how much of checkSigs the cached evaluations serve (tools/kprof.sh)
+    const int miss = __popcll(newValid & ~valid0);
+    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 28]), 1ULL);
+    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 29]), (unsigned long long)len);
+    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 17]), (unsigned long long)miss);
+    if (miss) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 18]), 1ULL);
+    if (v.nw > s.laneNw) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 27]), 1ULL);
+  }
+#endif
+}
 __device__ __forceinline__ void h_a1_lane_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
-  {
-    // ---------------- one lane per item ----------------
-    KPROF_DECL;
-    const uint32_t nItems = s.itemCount[0];
-    const uint32_t stride = nBlocks * blockDim.x;
-    for (uint32_t q = block * blockDim.x + threadIdx.x; q < nItems; q += stride) {
-      const uint32_t it = s.itemsLane[q];
-      const int32_t node = (int32_t)(it & 0x00FFFFFFu);
-      const int l = (int)(it >> 24);
-      const uint32_t WG_G* hdr = h_hdr(s, node);
-      const Lv v = sib_view(node, l);
-      const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
-      const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
-      const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
-      uint64_t WG_G* qr = h_qrec(s, node, l);
-      uint64_t WG_G* ent = qr + H_QENT;
-      uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
-      // ---- everything the item's address alone decides, before the first use: the record's first line (head, valid mask,
-      // four entries) and the cached evaluations of the slots 0 .. 3 (slots are taken lowest first: those are the usual ones)
-      const int window = (int)hdr[HH_WINDOW];
-      const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
-      const HQHead qh = gld((const HQHead WG_G*)qr);
-      const uint64_t valid0 = qr[H_QVALID];
-      uint64_t e4[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) e4[i] = ent[i];
-      const U4 c4 = gld((const U4 WG_G*)cache);
-      const int len = (int)qh.len, curSize = (int)lvA.y, cLA = (int)lvA.z;
-      int windowIndex = INT32_MAX;  // Collections.min(rank)
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
-      for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
-      long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
-      int bestScore = 0, bestOutsideRank = 0;
-      unsigned long long keep = 0;
-      uint64_t newValid = valid0;
-      int sumMin = INT32_MAX, sumMax = 0;  // the level's summary over the entries that stay listed (h_summary_has_candidate)
-      bool sumPos = false;
-      // one entry after the other: its cached evaluation, or its signature streamed against the level's three sets (whose
-      // lines stay in L1) and the result cached
-      auto consider = [&](int i, uint64_t x) {
-        const int slot = (int)(x & 0xFF);
-        uint32_t cw;
-        if ((valid0 >> slot) & 1ULL) {
-          cw = slot == 0 ? c4.x : slot == 1 ? c4.y : slot == 2 ? c4.z : slot == 3 ? c4.w : cache[slot];
-        } else {
-          int u1 = 0, u2 = 0, cs = 0;
-          bool iTI = false, iLA = false;
-          h_stream4(h_sig_ptr(s, node, l, slot), ti, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
-            tiw &= v.mask;
-            viw &= v.mask;
-            law &= v.mask;
-            u1 += __popcll(sg | tiw | viw);
-            u2 += __popcll(sg | viw);
-            cs += __popcll(sg);
-            iTI |= (sg & tiw) != 0;
-            iLA |= (sg & law) != 0;
-          });
-          cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
-          cache[slot] = cw;
+  // ---------------- one lane per item ----------------
+  KPROF_DECL;
+  const uint32_t nItems = s.itemCount[0];
+  const uint32_t stride = nBlocks * blockDim.x;
+  for (uint32_t q = block * blockDim.x + threadIdx.x; q < nItems; q += stride) {
+    const uint32_t it = s.itemsLane[q];
+    h_a1_lane_one(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
+  }
+  KPROF_MARK(d.g, 1);   // a lane-part wavefront, start to end
+  KPROF_COUNT(d.g, 2);  // ... how many
+}
+// ---------------- one GROUP of eight lanes per item: the narrow levels (blocks of <= 16 words), two words a lane ---------
+// One lane per item walked a block of up to 16 words two words a load, one entry after the other: a chain of up to a dozen
+// dependent round trips that made the lane half of k_handel_a1 the phase's longest (44 us of an ordinary ms for ~ 5 k items an
+// engine, profiles/r13g_*). Eight lanes hold the block's words side by side (lane j: words 2j, 2j + 1), lane j owns entry j of
+// the list, the sums meet by three DPP steps inside the half-row: an item is three round trips whatever its level.
+#if defined(__HIPCC__) && !defined(WG_NO_DPP)
+// xor 1, xor 2 inside a quad, then row_half_mirror (lane i <-> 7 - i of its half-row: the other quad's total)
+template <class OP>
+__device__ __forceinline__ uint32_t group8_reduce32(uint32_t v, uint32_t id) {
+  v = OP::f(v, dpp_mov<0xb1, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x4e, 0xf>(id, v));
+  v = OP::f(v, dpp_mov<0x141, 0xf>(id, v));
+  return v;
+}
+__device__ __forceinline__ uint64_t group8_sum64(uint64_t v) {
+  v = v + dpp_mov64<0xb1, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x4e, 0xf>(0ull, v);
+  v = v + dpp_mov64<0x141, 0xf>(0ull, v);
+  return v;
+}
+__device__ __forceinline__ uint64_t group8_or64(uint64_t v) {
+  v = v | dpp_mov64<0xb1, 0xf>(0ull, v);
+  v = v | dpp_mov64<0x4e, 0xf>(0ull, v);
+  v = v | dpp_mov64<0x141, 0xf>(0ull, v);
+  return v;
+}
+#else
+template <class OP>
+__device__ __forceinline__ uint32_t group8_reduce32(uint32_t v, uint32_t) {
+  for (int o = 1; o < 8; o <<= 1) v = OP::f(v, (uint32_t)__shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ uint64_t group8_sum64(uint64_t v) {
+  for (int o = 1; o < 8; o <<= 1) v += shfl64(v, WG_LANE ^ o);
+  return v;
+}
+__device__ __forceinline__ uint64_t group8_or64(uint64_t v) {
+  for (int o = 1; o < 8; o <<= 1) v |= shfl64(v, WG_LANE ^ o);
+  return v;
+}
+#endif
+__device__ __forceinline__ int32_t group8_min_i32(int32_t v) {
+  return (int32_t)(group8_reduce32<OpMin>((uint32_t)v ^ 0x80000000u, 0xFFFFFFFFu) ^ 0x80000000u);
+}
+__device__ __forceinline__ int32_t group8_max_i32(int32_t v) {
+  return (int32_t)(group8_reduce32<OpMax>((uint32_t)v ^ 0x80000000u, 0u) ^ 0x80000000u);
+}
+
+__device__ __forceinline__ void h_a1_group_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
+  KPROF_DECL;
+  const int lane = WG_LANE, j = lane & 7, gbase = lane & ~7;
+  const uint32_t nItems = s.itemCount[0];
+  const uint32_t stride = nBlocks * (blockDim.x >> 3);
+  // (every lane of the wavefront stays in the loop while any group has an item: the DPP steps read all lanes)
+  for (uint32_t q = block * (blockDim.x >> 3) + (threadIdx.x >> 3); __ballot(q < nItems); q += stride) {
+    const bool have = q < nItems;
+    const uint32_t it = have ? s.itemsLane[q] : 0u;
+    const int32_t node = (int32_t)(it & 0x00FFFFFFu);
+    const int l = have ? (int)(it >> 24) : 1;
+    const uint32_t WG_G* hdr = h_hdr(s, node);
+    const Lv v = sib_view(node, l);
+    const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
+    const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
+    const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
+    uint64_t WG_G* qr = h_qrec(s, node, l);
+    uint64_t WG_G* ent = qr + H_QENT;
+    uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
+    // ---- everything the item's address alone decides, before the first use
+    int window = 0;
+    U4 lvA;
+    lvA.x = lvA.y = lvA.z = lvA.w = 0;
+    HQHead qh;
+    qh.len = qh.used = 0;
+    uint64_t valid0 = 0, myEnt = ~0ULL;
+    uint32_t c8 = 0;
+    V2 tiw, viw, law;
+    tiw.x = tiw.y = viw.x = viw.y = law.x = law.y = 0;
+    if (have) {
+      window = (int)hdr[HH_WINDOW];
+      lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
+      qh = gld((const HQHead WG_G*)qr);
+      valid0 = qr[H_QVALID];
+      myEnt = ent[j];      // entry j of the list's first eight
+      c8 = cache[j];       // the cached evaluation of SLOT j (slots are taken lowest first)
+      if (v.nw == 1) {
+        if (j == 0) {
+          viw.x = vi[0] & v.mask;
+          law.x = la[0] & v.mask;
+        }
+      } else if (2 * j < v.nw) {
+        viw = gld((const V2 WG_G*)(vi + 2 * j));
+        law = gld((const V2 WG_G*)(la + 2 * j));
+      }
+      tiw.x = law.x | viw.x;  // totalIncoming = lastAggVerified | verifiedIndSignatures (the row is not read)
+      tiw.y = law.y | viw.y;
+    }
+    const int len = have ? (int)qh.len : 0, curSize = (int)lvA.y, cLA = (int)lvA.z;
+    uint64_t newValid = valid0;
+    // the evaluations of a chunk of eight entries (lane j: entry 8c + j): cached, or the signature against the three sets
+    auto evaluate = [&](bool mine, uint64_t e, uint32_t cw0, bool valid) -> uint32_t {
+      uint32_t myCw = valid ? cw0 : 0u;
+      uint32_t inv8 = (uint32_t)((__ballot(mine && !valid) >> gbase) & 0xFFu);
+      while (__ballot(inv8 != 0)) {
+        const bool act = inv8 != 0;
+        const int pos = act ? __ffs(inv8) - 1 : 0;
+        inv8 &= inv8 - 1;
+        const int slot = (int)((uint32_t)__shfl((int)(uint32_t)e, gbase | pos, 64) & 0xFFu);
+        const uint64_t WG_G* sig = h_sig_ptr(s, node, l, slot);
+        V2 sg;
+        sg.x = sg.y = 0;
+        if (act) {
+          if (v.nw == 1) {
+            if (j == 0) sg.x = sig[0];
+          } else if (2 * j < v.nw) {
+            sg = gld((const V2 WG_G*)(sig + 2 * j));
+          }
+        }
+        uint64_t a = (uint64_t)(__popcll(sg.x | tiw.x | viw.x) + __popcll(sg.y | tiw.y | viw.y)) |
+                     ((uint64_t)(__popcll(sg.x | viw.x) + __popcll(sg.y | viw.y)) << 21) |
+                     ((uint64_t)(__popcll(sg.x) + __popcll(sg.y)) << 42);
+        uint64_t b = (uint64_t)(((sg.x & tiw.x) | (sg.y & tiw.y)) != 0) | ((uint64_t)(((sg.x & law.x) | (sg.y & law.y)) != 0) << 21);
+        a = group8_sum64(a);
+        b = group8_sum64(b);
+        const int u1 = (int)(a & 0x1FFFFF), u2 = (int)((a >> 21) & 0x1FFFFF), cs = (int)((a >> 42) & 0x1FFFFF);
+        const bool iTI = (b & 0x1FFFFF) != 0, iLA = ((b >> 21) & 0x1FFFFF) != 0;
+        const uint32_t cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
+        if (act) {
+          if (j == pos) {
+            myCw = cw;
+            __hip_atomic_store(cache + slot, cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           newValid |= 1ULL << slot;
         }
-        const long long who = (long long)(uint32_t)x;  // signer << 8 | slot
-        const int rank = (int)(uint32_t)(x >> 32);
-        if (cw & 1u) {  // only signatures that can result in a better aggregate stay listed (:592)
-          keep |= 1ULL << i;
-          sumMin = min(sumMin, rank);
-          sumMax = max(sumMax, rank);
-          sumPos |= (cw >> 1) != 0;
-          if (h_in_window(rank, windowIndex, window)) {  // best inside = FIRST entry with the strictly greatest positive score
-            const int score = (int)(cw >> 1);
-            if (score > bestScore) {
-              bestScore = score;
-              bestInside = who;
-            }
-          } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
-            bestOutside = who;
-            bestOutsideRank = rank;
-          }
-        }
-      };
-      // (one copy of the body: the four entries of the head line by selects, not by four inlined copies — registers)
-      for (int i = 0; i < len; i++) consider(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
-      const int kept = __popcll(keep);
-      unsigned long long relMask = 0;
-      if (kept != len) {
-        const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
-        int pos = 0;
-        auto curate = [&](int i, uint64_t x) {
-          if ((keep >> i) & 1ULL) {
-            if (pos != i) ent[pos] = x;
-            pos++;
-          } else {  // the slot of a dropped entry is released unless a registered task still holds it
-            const uint32_t key = h_pend_word(l, (int)(x & 0xFF));
-            if (!(pend.x == key || pend.y == key || pend.z == key || pend.w == key)) relMask |= 1ULL << (x & 0xFF);
-          }
-        };
-        for (int i = 0; i < len; i++) curate(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
       }
+      return myCw;
+    };
+    // ---- first chunk: entries 0 .. 7 (all there is, but for the rare long list)
+    const bool mine0 = have && j < len;
+    const int slot0 = mine0 ? (int)(myEnt & 0xFF) : 0;
+    const bool valid00 = mine0 && ((valid0 >> slot0) & 1ULL);
+    const uint32_t c8s = (uint32_t)__shfl((int)c8, gbase | (slot0 & 7), 64);
+    uint32_t cw0 = 0;
+    if (valid00) cw0 = slot0 < 8 ? c8s : cache[slot0];
+    uint32_t myCw = evaluate(mine0, myEnt, cw0, valid00);
+    int myRank = mine0 ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+    int windowIndex = group8_min_i32(myRank);  // Collections.min(rank)
+    const bool isLong = len > 8;
+    if (__ballot(isLong)) {  // (rare) the other chunks: their evaluations go to the cache, their ranks into the minimum
+      for (int c = 1; __ballot(isLong && 8 * c < len); c++) {
+        const bool mc = isLong && 8 * c + j < len;
+        const uint64_t e = mc ? ent[8 * c + j] : ~0ULL;
+        const int sl = mc ? (int)(e & 0xFF) : 0;
+        const bool vc = mc && ((valid0 >> sl) & 1ULL);
+        (void)evaluate(mc, e, 0u, vc);
+        windowIndex = min(windowIndex, group8_min_i32(mc ? (int)(uint32_t)(e >> 32) : INT32_MAX));
+      }
+      __threadfence_block();
+    }
+    // ---- the choice (as h_best_wave), a chunk at a time with the best so far carried along: the curated list, the best
+    // inside / outside the window, the level's summary
+    long long bestInside = -1, bestOutside = -1;
+    int bestScore = 0, bestOutsideRank = 0, kept = 0, sumMin = INT32_MAX, sumMax = 0;
+    bool sumPos = false;
+    uint64_t relMask = 0;
+    U4 pend;
+    pend.x = pend.y = pend.z = pend.w = 0;
+    bool pendLoaded = false;
+    for (int c = 0; __ballot(have && 8 * c < len); c++) {
+      const bool mc = have && 8 * c + j < len;
+      if (c > 0) {  // (long lists: entry and evaluation from memory; every entry has one by now)
+        myEnt = mc ? ent[8 * c + j] : ~0ULL;
+        myRank = mc ? (int)(uint32_t)(myEnt >> 32) : INT32_MAX;
+        myCw = mc ? __hip_atomic_load(cache + (myEnt & 0xFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      }
+      const int mySlot = mc ? (int)(myEnt & 0xFF) : 0;
+      const bool myKeep = mc && (myCw & 1u);
+      const bool myInside = myKeep && h_in_window(myRank, windowIndex, window);
+      const int myScore = (int)(myCw >> 1);
+      const uint32_t keep8 = (uint32_t)((__ballot(myKeep) >> gbase) & 0xFFu);
+      const int top = group8_max_i32(myInside ? myScore : 0);
+      if (top > bestScore) {  // the FIRST entry with the strictly greatest positive score
+        const uint32_t hm = (uint32_t)((__ballot(myInside && myScore == top) >> gbase) & 0xFFu);
+        bestScore = top;
+        bestInside = (long long)(uint32_t)__shfl((int)(uint32_t)myEnt, gbase | ((hm ? __ffs(hm) : 1) - 1), 64);
+      }
+      const uint32_t om = (uint32_t)((__ballot(myKeep && !myInside) >> gbase) & 0xFFu);
+      if (om) {  // the FIRST entry with the smallest rank
+        const int lo = group8_min_i32(myKeep && !myInside ? myRank : INT32_MAX);
+        if (bestOutside < 0 || lo < bestOutsideRank) {
+          const uint32_t hm = (uint32_t)((__ballot(myKeep && !myInside && myRank == lo) >> gbase) & 0xFFu);
+          bestOutsideRank = lo;
+          bestOutside = (long long)(uint32_t)__shfl((int)(uint32_t)myEnt, gbase | ((hm ? __ffs(hm) : 1) - 1), 64);
+        }
+      }
+      const int chunkLen = min(8, len - 8 * c), keptC = __popc(keep8);
+      if (__ballot(mc && (keptC != chunkLen || kept != 8 * c))) {  // replaceToVerifyAgg :636-646 (entries move down)
+        const bool cur = have && (keptC != chunkLen || kept != 8 * c);
+        if (cur && !pendLoaded) {
+          pend = gld((const U4 WG_G*)(hdr + HH_PEND));
+          pendLoaded = true;
+        }
+        const int newPos = kept + __popc(keep8 & ((1u << j) - 1u));
+        if (cur && myKeep && newPos != 8 * c + j) ent[newPos] = myEnt;
+        const uint32_t key = h_pend_word(l, mySlot);
+        const bool held = pend.x == key || pend.y == key || pend.z == key || pend.w == key;
+        relMask |= group8_or64(cur && mc && !myKeep && !held ? 1ULL << mySlot : 0ULL);
+      }
+      kept += keptC;
+      sumMin = min(sumMin, group8_min_i32(myKeep ? myRank : INT32_MAX));
+      sumMax = max(sumMax, group8_max_i32(myKeep ? myRank : 0));
+      sumPos = sumPos || ((__ballot(myKeep && myScore > 0) >> gbase) & 0xFFu) != 0;
+    }
+    if (have && j == 0) {
       if (newValid != valid0) qr[H_QVALID] = newValid;
       h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside,
                     (uint32_t)sumMin | (sumPos ? 0x80000000u : 0u), (uint32_t)sumMax);
 #ifdef WG_KPROF
-      {  // how much of checkSigs the cached evaluations serve (tools/kprof.sh)
-        const int miss = __popcll(newValid & ~valid0);
-        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 28]), 1ULL);
-        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 29]), (unsigned long long)len);
-        atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 17]), (unsigned long long)miss);
-        if (miss) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 18]), 1ULL);
-        if (v.nw > s.laneNw) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 27]), 1ULL);
-      }
+      atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 28]), 1ULL);
+      atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 29]), (unsigned long long)len);
+      atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 17]), (unsigned long long)__popcll(newValid & ~valid0));
 #endif
     }
-    KPROF_MARK(d.g, 1);   // a lane-part wavefront, start to end
-    KPROF_COUNT(d.g, 2);  // ... how many
   }
+  KPROF_MARK(d.g, 1);   // a group-part wavefront, start to end
+  KPROF_COUNT(d.g, 2);  // ... how many
 }
+
 // ---------------- one wavefront per item: lanes = 64-bit words of the level's block ----------------
 template <bool ATK>
 __device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
@@ -2298,9 +2537,13 @@ __device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const Handel
     h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
   }
 }
+template <bool GROUP>
 __global__ void __launch_bounds__(256) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  h_a1_lane_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
+  if (GROUP)
+    h_a1_group_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
+  else
+    h_a1_lane_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
 }
 template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1w(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
@@ -2309,14 +2552,17 @@ __global__ void __launch_bounds__(256, WPE) k_handel_a1w(const EngineDev* __rest
 }
 // both in ONE launch (WG_A1_SPLIT=0): blocks [0, gridDim.x * share / 16) the lane items, the others the wave items — the two
 // kinds of chains in flight together, at the lane half's register count
-template <int WPE>
+template <int WPE, bool GROUP>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1c(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;  // (default 4/16)
-  if (blockIdx.x < laneBlocks)
-    h_a1_lane_items(d, s, blockIdx.x, laneBlocks);
-  else
+  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;
+  if (blockIdx.x < laneBlocks) {
+    if (GROUP)
+      h_a1_group_items(d, s, blockIdx.x, laneBlocks);
+    else
+      h_a1_lane_items(d, s, blockIdx.x, laneBlocks);
+  } else
     h_a1_wave_items<false>(d, s, blockIdx.x - laneBlocks, gridDim.x - laneBlocks);
 }
 
