@@ -618,7 +618,7 @@ def main():
     except Exception:
         avail = 0
     # init() of one copy on the host holds ~3 N^2 int32 (ranks, their transpose, emission lists); with the rank shuffles and
-    # the emission lists built on the device (wgh_handel_create: unsharded, 256 .. 65 536 nodes) a thread holds next to nothing
+    # the emission lists built on the device (wgh_handel_create: unsharded, 256 .. 131 072 nodes) a thread holds next to nothing
     on_device = bool(getattr(first, "init_on_device", False))
     threads = replicas.init_threads(args.init_threads, max(1, R - 1), avail, (1 << 28) if on_device else 3.5 * 4 * n * n + (1 << 30),
                                     len(os.sched_getaffinity(0)), world)

@@ -1932,8 +1932,10 @@ Batch::Batch(Engine** es, int n) {
     Engine* l = es[0];
     if (e->cfg.device != l->cfg.device || e->dev.horizon != l->dev.horizon || e->dev.nodes.n != l->dev.nodes.n ||
         e->proto->state_size() != l->proto->state_size() || e->proto->has_cond() != l->proto->has_cond() ||
-        e->proto->levels() != l->proto->levels() || e->proto->variant() != l->proto->variant())
-      throw WgError(WG_EINVAL, "batch members must share device, protocol (and its attack scenario), node count and horizon_ms");
+        e->proto->levels() != l->proto->levels() || e->proto->variant() != l->proto->variant() ||
+        (e->dev.inbox != nullptr) != (l->dev.inbox != nullptr))  // (the leader's delivery kernel reads every member's inbox lines)
+      throw WgError(WG_EINVAL, "batch members must share device, protocol (and its attack scenario), node count, horizon_ms and "
+                               "the inbox-line layout (load the protocol before the first call that allocates the engine)");
     for (int j = 0; j < i; j++)
       if (es[j] == e) throw WgError(WG_EINVAL, "an engine appears twice in the batch");
     members.push_back(e);

@@ -1968,7 +1968,13 @@ __device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const ty
     }
   } else {
     // more events than the line holds: the line's four and the overflow list, in event order — by repeated minimum
-    // search (the list is unordered; such nodes are rare: a PingPong-style origin), records from the event arrays
+    // search (the list is unordered; such nodes are rare: a PingPong-style origin), records from the event arrays.
+    // (`skip` is honoured in the branch above only: a lane-per-node kernel hands a visit over only for nodes whose events
+    // fit the line — anything else here would apply an event twice, so it is an error, not a guess)
+    if (skip != 0) {
+      if (lane == 0) set_err(d.g, ERR_PROTOCOL);
+      return;
+    }
     const uint32_t l0 = lane_bcast(mine.e, 0), l1 = lane_bcast(mine.e, 1), l2 = lane_bcast(mine.e, 2), l3 = lane_bcast(mine.e, 3);
     const int32_t listHead = d.head[node];
     __builtin_amdgcn_wave_barrier();
