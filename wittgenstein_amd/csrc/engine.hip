@@ -962,6 +962,17 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
     throw WgError(WG_EUNSUPPORTED, "host-callback mode: a PeriodicTask re-arms itself from its action() (C/messages/PeriodicTask.java:39-47)");
   if (startAt < time) throw WgError(WG_ESTATE, "Arriving in the past: arrival=" + std::to_string(startAt));
   staged.push_back({startAt, make_rec(K_PERIODIC, node, (uint32_t)node, task, (uint32_t)period)});
+  if (!periodicUnknown) {  // (Group::periodic_may_fire: a handful of phases with a synchronised start, `period` of them without)
+    const int32_t ph = startAt % period;
+    bool seen = false;
+    for (const PeriodicReg& r : periodicRegs) seen = seen || (r.task == task && r.period == period && r.phase % period == ph && r.phase <= startAt);
+    if (!seen) {
+      if (periodicRegs.size() >= 64)
+        periodicUnknown = true;
+      else
+        periodicRegs.push_back({task, period, startAt});
+    }
+  }
 }
 
 template <class F>
@@ -1041,6 +1052,7 @@ Group Engine::self() {
   g.stream = stream;
   g.binBits = binBits;
   g.histLds = sizeof(uint32_t) * (size_t)dev.horizon;
+  g.periodic = periodicUnknown ? nullptr : &periodicRegs;
   return g;
 }
 
@@ -1250,7 +1262,9 @@ void Engine::collect_far() {
 }
 
 // One simulated ms: drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the new `now`.
-static void enqueue_one_ms(Engine& lead, const Group& g) {
+static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
+  Group g = g0;
+  g.now = tNow;
   ProtoHost* proto = lead.proto;
   const bool cond = proto->has_cond();
   typedef Engine::ProfScope ProfScope;
@@ -1290,8 +1304,8 @@ static void enqueue_one_ms(Engine& lead, const Group& g) {
     }
   }
 
-void Engine::enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms) {
-  for (int32_t k = 0; k <= ms; k++) enqueue_one_ms(lead, g);
+void Engine::enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms, int32_t tStart) {
+  for (int32_t k = 0; k <= ms; k++) enqueue_one_ms(lead, g, tStart == INT32_MIN ? INT32_MIN : tStart + k);
 }
 
 // One simulated ms = drain(now) [k_end_phase: now++] + the conditional-task phase of the edge to the
@@ -1348,6 +1362,16 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
     dNb = lead.skipBuf;
   }
   int32_t sinceCheck = 0;
+  int32_t tCommon = INT32_MIN;  // Network.time of the members, if they share it (Group::now)
+  for (int r = 0; r < R; r++)
+    if (on[r]) {
+      if (tCommon == INT32_MIN)
+        tCommon = es[r]->time;
+      else if (tCommon != es[r]->time) {
+        tCommon = INT32_MIN;
+        break;
+      }
+    }
   {
     for (int32_t k = 0; k <= ms; k++) {
       if (k > 0) host_envelopes(k);
@@ -1368,7 +1392,7 @@ void Engine::run_group(Engine** es, int R, const uint8_t* active, const Group& g
           host_envelopes(k);
         }
       }
-      enqueue_one_ms(lead, g);
+      enqueue_one_ms(lead, g, tCommon == INT32_MIN ? INT32_MIN : tCommon + k);
     }
   }
   WG_HIP(hipStreamSynchronize(g.stream));
@@ -1982,6 +2006,19 @@ Group Batch::prepare(const uint8_t* active) {
   g.stream = l.stream;
   g.binBits = l.binBits;
   g.histLds = sizeof(uint32_t) * (size_t)l.dev.horizon;
+  // the periodic tasks registered on ANY member (Group::periodic_may_fire)
+  periodicUnion.clear();
+  bool known = true;
+  for (int r = 0; r < n && known; r++) {
+    known = !members[r]->periodicUnknown;
+    for (const PeriodicReg& x : members[r]->periodicRegs) {
+      bool seen = false;
+      for (const PeriodicReg& y : periodicUnion) seen = seen || (x.task == y.task && x.period == y.period && x.phase == y.phase);
+      if (!seen) periodicUnion.push_back(x);
+    }
+    if (periodicUnion.size() > 256) known = false;
+  }
+  g.periodic = known ? &periodicUnion : nullptr;
   return g;
 }
 void Batch::run_ms(int32_t ms, const uint8_t* active, uint8_t* did, wg_run_stats* stats) {
@@ -2048,9 +2085,13 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
   uint32_t running = (uint32_t)n;
   // one runMs(chunk) of every member: the same launch sequence every time (the kernels read the clock and the loop
   // state from device memory), which is what makes it a graph
+  int32_t tChunk = t0[0];  // Network.time at the head of the next chunk, if the members share a clock (Group::now)
+  for (int r = 1; r < n; r++)
+    if (t0[r] != t0[0]) tChunk = INT32_MIN;
   auto enqueue_chunk = [&]() {
     hipLaunchKernelGGL(k_chunk_begin, dim3(n), dim3(64), 0, g.stream, tab, chunk);
-    Engine::enqueue_ms_sequence(l, g, chunk);
+    Engine::enqueue_ms_sequence(l, g, chunk, tChunk);
+    if (tChunk != INT32_MIN) tChunk += chunk;
     WG_HIP(hipMemsetAsync(dCont, 0, sizeof(uint32_t) * n, g.stream));
     if (!l.proto->launch_cont_if(g, dCont))
       throw WgError(WG_EUNSUPPORTED, "the resident protocol defines no continuation predicate");
@@ -2065,6 +2106,7 @@ void Batch::run_multiple_times(int32_t chunk, int32_t maxTime, int64_t* delivere
   hipGraphExec_t exec = nullptr;
   try {
     if (wantGraph) {
+      tChunk = INT32_MIN;  // (one captured launch sequence serves every chunk: nothing in it may depend on the ms)
       if (l.profiling) l.prof_stamp(2 * Engine::PC_COUNT);  // (allocates the ring outside the capture; an unpaired tag)
       WG_HIP(hipStreamSynchronize(g.stream));
       WG_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeRelaxed));
@@ -2778,7 +2820,12 @@ struct HandelHost : ProtoHost {
       default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
     const dim3 grid(node_grid(g.R), g.R);
-    if (st.disTier && !st.atk) {  // nodes whose first event is their dissemination (appends the rest of their visit to the wave list)
+    // In a ms whose phase no member's dissemination task has (19 of 20 with a synchronised start) the lean dissemination kernel
+    // would find an empty list: not launched (6 us each at 24 copies). k_handel_wave is told, and stops the run loudly should
+    // the list not be empty after all.
+    const bool mayDissem = g.periodic_may_fire(H_TASK_DISSEMINATION);
+    const int disSkipped = st.disTier && !st.atk && !mayDissem;
+    if (st.disTier && !st.atk && mayDissem) {  // nodes whose first event is their dissemination (appends the rest of their visit to the wave list)
       switch (wavesDissem) {
         case 4: hipLaunchKernelGGL(k_handel_dissem<4>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
         case 5: hipLaunchKernelGGL(k_handel_dissem<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
@@ -2787,15 +2834,15 @@ struct HandelHost : ProtoHost {
       }
     }
     if (st.atk) {
-      hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab, 0);
       return;
     }
     switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_handel_wave<8, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 6: hipLaunchKernelGGL((k_handel_wave<6, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 5: hipLaunchKernelGGL((k_handel_wave<5, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      case 3: hipLaunchKernelGGL((k_handel_wave<3, false>), grid, dim3(256), 0, g.stream, g.tab, stab); break;
-      default: hipLaunchKernelGGL((k_handel_wave<4, false>), grid, dim3(256), 0, g.stream, g.tab, stab);
+      case 8: hipLaunchKernelGGL((k_handel_wave<8, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
+      case 6: hipLaunchKernelGGL((k_handel_wave<6, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
+      case 5: hipLaunchKernelGGL((k_handel_wave<5, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
+      case 3: hipLaunchKernelGGL((k_handel_wave<3, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
+      default: hipLaunchKernelGGL((k_handel_wave<4, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped);
     }
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <climits>
 #include <vector>
 #include "../../include/wittgpu.h"
 #include "engine.h"
@@ -29,6 +30,13 @@ class Engine;
 // What a launch addresses: a device table of R engines (blockIdx.y) + the matching table of protocol
 // State structs, on one stream. A stand-alone engine is a group of one; a batch (wg_batch_*) is the
 // device-side form of the reference's RunMultipleTimes loop over independent copies.
+// a PeriodicTask the HOST registered (wg_register_periodic_task): it fires at startAt, startAt + period, ... — the re-arm
+// keeps the phase (C/messages/PeriodicTask.java:39-47), so a protocol host can tell from the simulated ms being enqueued
+// whether a kernel that only serves that task can find work at all
+struct PeriodicReg {
+  uint32_t task;
+  int32_t period, phase;
+};
 struct Group {
   const EngineDev* tab = nullptr;
   const void* stab = nullptr;
@@ -36,6 +44,16 @@ struct Group {
   hipStream_t stream = nullptr;
   int binBits = 0;
   size_t histLds = 0;  // dynamic LDS of the multisplit kernels: horizon words
+  // the simulated ms the launches being enqueued will see as `now` (INT32_MIN: unknown — members on different clocks, a
+  // chunk captured as a graph), and the periodic tasks registered on the members (NULL: unknown): hints, never needed
+  int32_t now = INT32_MIN;
+  const std::vector<PeriodicReg>* periodic = nullptr;
+  bool periodic_may_fire(uint32_t task) const {
+    if (now == INT32_MIN || !periodic) return true;
+    for (const PeriodicReg& r : *periodic)
+      if (r.task == task && now >= r.phase && (now - r.phase) % r.period == 0) return true;
+    return false;
+  }
 };
 
 // A resident protocol: device state + the kernels that run its action()/conditional tasks.
@@ -204,7 +222,10 @@ class Engine {
   static void run_group(Engine** es, int R, const uint8_t* active, const Group& g, int32_t ms, uint8_t* did,
                         wg_run_stats* stats);
   // the kernel sequence of runMs(ms) for a group whose members' globals are set up (begin_run / k_chunk_begin)
-  static void enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms);
+  // tStart: the simulated ms of the sequence's first drain (INT32_MIN: unknown)
+  static void enqueue_ms_sequence(Engine& lead, const Group& g, int32_t ms, int32_t tStart = INT32_MIN);
+  std::vector<PeriodicReg> periodicRegs;  // distinct (task, period, startAt mod period) of the host's registrations
+  bool periodicUnknown = false;           // more distinct ones than worth tracking: the hint is off
   void begin_run(int32_t ms, int32_t* endAt);
   EngineDev* dTab = nullptr;     // device copy of `dev` (table of one)
   void* dStab = nullptr;         // device copy of the protocol State struct
@@ -385,6 +406,7 @@ class Batch {
   uint32_t* dCont = nullptr;
   std::vector<EngineDev> hTab;
   std::vector<char> hStab;
+  std::vector<PeriodicReg> periodicUnion;  // Group::periodic of the batch: the members' registrations
 };
 
 void rccl_unique_id(uint8_t* id128);  // ncclGetUniqueId of the dynamically loaded librccl

@@ -1688,7 +1688,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __r
 }
 
 template <int WPE, bool ATK>
-__global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+__global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab,
+                                                          int disSkipped) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
   typedef HandelProtoT<ATK> HP;
@@ -1696,6 +1697,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __res
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  // (the host did not launch k_handel_dissem for this ms — no member's dissemination task has this phase: its list must be empty)
+  if (disSkipped && wave == 0 && lane == 0 && *s.disCount != 0) set_err(d.g, ERR_PROTOCOL);
   const uint32_t nWork = d.g->nActiveB;
   const int32_t t = d.g->now;
   const U4 WG_G* work = (const U4 WG_G*)(const VisitDesc WG_G*)d.activeB;
