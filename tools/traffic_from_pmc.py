@@ -21,14 +21,20 @@ import sys
 
 
 def per_dispatch(path, counter, kernels):
-    tot = {}
+    """KB per delivery PASS of each kernel: its sum over the run / the number of passes (= the dispatch count of the kernels
+    that are launched in every pass). A kernel that is not launched in every pass — k_handel_dissem since round 4: only in a
+    ms whose phase some node's dissemination has — must not contribute its mean per OWN dispatch: the HIP events of
+    `avg_launch_us` bracket every pass, with or without it."""
+    rows = {}
     for line in open(path):
         c = [x.strip() for x in line.strip().strip("|").split("|")]
         if len(c) == 5 and c[1] == counter:
             for k in kernels:
                 if k in c[0]:
-                    tot[k] = tot.get(k, 0.0) + float(c[4])
-    return tot
+                    n, sm = rows.get(k, (0, 0.0))
+                    rows[k] = (n + int(float(c[2])), sm + float(c[3]))
+    passes = max([n for n, _ in rows.values()] or [1])
+    return {k: sm / passes for k, (n, sm) in rows.items()}
 
 
 def whole_step(path, counter):
