@@ -411,10 +411,6 @@ struct EngineDev {
   // message word + 1 of the K_MSG events the resident protocol delivers one lane per event, without inbox lists
   // (ExpandF::lane_only); 0: every event is threaded onto its node's list
   uint32_t laneMsgPlus1;
-  // a resident protocol whose messages emit nothing and whose statistics bucket is `msg & preResLevelMask` (Handel): expand
-  // writes the result record of a plain message event — delivered (C/Network.java:606-613) or not, its level, no records, no
-  // draws — coalesced in event order, so that the lane-per-node delivery kernel does not scatter 8 bytes per message. 0: off
-  uint32_t preResLevelMask;
 };
 struct RunDesc {  // 32 bytes
   uint32_t chain, pos;      // envelope slot, first hop of the run

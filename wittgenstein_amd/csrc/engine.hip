@@ -2419,7 +2419,6 @@ struct HandelHost : ProtoHost {
       st.snap = e.dalloc<uint64_t>(words, false, Engine::AC_SCRATCH);
     }
     e.dev.boundMsg = 0;            // onNewSig never sends
-    e.dev.preResLevelMask = (getenv("WG_PRE_RES") && atoi(getenv("WG_PRE_RES")) == 0) ? 0u : 31u;  // msg_level = msg & 31
     e.dev.boundTask[0] = L - 1;    // dissemination: one send per level >= 1 (+1 periodic re-arm added by expand)
     e.dev.boundTask[1] = L - 1;    // updateVerifiedSignatures: one fast-path send per higher level
     e.dev.boundTask[2] = e.dev.boundTask[3] = 0;

@@ -497,14 +497,6 @@ struct ExpandF {
           d.evAux[e] = a;
           if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1, r, false, ob);
           firstNode = (int32_t)r.w1;
-          if (k == K_MSG && d.preResLevelMask && !d.hostMode && (!d.sharded || shard_owns(d, (int32_t)r.w1))) {
-            // the result of a plain message event is known here (EngineDev::preResLevelMask): delivered unless the receiver
-            // is down or across a partition (C/Network.java:606), no record, no draw
-            const NodeArrays& nd = d.nodes;
-            const int32_t to = (int32_t)r.w1, from = rec_from(r);
-            const bool dl = !nd.down[to] && (d.nparts == 0 || nd.part[from] == nd.part[to]);
-            d.evRes[e] = EvRes{dl ? (EV_DELIVERED | ((r.w2 & d.preResLevelMask) << 24)) : 0u, 0u};
-          }
         }
       } else {
         const Chain c = d.chains[r.w1];

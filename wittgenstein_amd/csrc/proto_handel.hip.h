@@ -1310,8 +1310,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
             if (st == H_UPD_BAIL) bailAt = k;
           }
         }
-        // (a plain message's result was written by expand, coalesced: EngineDev::preResLevelMask)
-        if (!deferred && !(d.preResLevelMask && ((E[k].w0 >> 28) & 3u) == K_MSG && !(E[k].w0 & INBOX_CHAIN))) gst(d.evRes + e, res);
+        if (!deferred) gst(d.evRes + e, res);
       }
       // a wide payload: a job of k_handel_copy (one atomic per wavefront and event slot)
       const uint64_t jm = __ballot(job.nw > 0);
