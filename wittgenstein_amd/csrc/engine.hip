@@ -2430,11 +2430,14 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
+    st.itemsTrail = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
+    st.trailCount = e.dalloc<uint32_t>(1);
     st.itemsDis = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.disCount = e.dalloc<uint32_t>(1);
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
     st.a1Group = !(getenv("WG_A1_GROUP") && atoi(getenv("WG_A1_GROUP")) == 0);
+    st.updTrail = !(getenv("WG_UPD_TRAIL") && atoi(getenv("WG_UPD_TRAIL")) == 0);
     st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;
     st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 8;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
@@ -2813,12 +2816,17 @@ struct HandelHost : ProtoHost {
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_LANE", 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     switch (wavesUpdate) {
       case 8: hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
       case 4: hipLaunchKernelGGL(k_handel_update<4>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
+      case 5: hipLaunchKernelGGL(k_handel_update<5>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
       default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
+    // the deliveries behind a wide update that was its node's first event, one lane per node (after the update); then every
+    // wide payload the two lane kernels delivered, one wavefront per copy
+    if (st.updTrail && !st.atk)
+      hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2", 512), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     const dim3 grid(node_grid(g.R), g.R);
     // In a ms whose phase no member's dissemination task has (19 of 20 with a synchronised start) the lean dissemination kernel
     // would find an empty list: not launched (6 us each at 24 copies). k_handel_wave is told, and stops the run loudly should

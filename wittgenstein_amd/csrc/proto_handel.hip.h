@@ -80,6 +80,7 @@ struct HandelState {
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
   int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
   int32_t a1Group;                        // 1: the narrow levels' items by groups of eight lanes (default), 0: one lane each (WG_A1_GROUP=0)
+  int32_t updTrail;                       // 1: k_handel_update also takes a wide update FIRST + the deliveries behind it (WG_UPD_TRAIL=0: k_handel_wave)
   int32_t laneNw;                         // H_LANE_NW, or WG_LANE_NW (tests: the wave-per-item paths on networks the emulator can run)
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
@@ -145,6 +146,11 @@ struct HandelState {
   // vflags}, applied by k_handel_update one wavefront each (the node's SendSigs before them by k_handel_lane)
   GP<U4> itemsUpd;                        // [N]
   GP<uint32_t> updCount;                  // [1] (reset with jobCount)
+  // nodes whose first event is a wide update with only plain deliveries behind it: k_handel_update applies the update,
+  // k_handel_lane2 — one lane per node — the deliveries: {node, vflags << 8 | events, the update's event, 1 if k_handel_update
+  // handed the whole visit to k_handel_wave instead}
+  GP<U4> itemsTrail;                      // [N]
+  GP<uint32_t> trailCount;                // [1] (reset with jobCount)
   // nodes whose FIRST event of the ms is their dissemination task: {node, vflags << 8 | events, event, its inbox word 0},
   // applied by k_handel_dissem one wavefront each (the lean kernel of the millisecond in which every node disseminates);
   // the node's later events follow in k_handel_wave (skip = 1)
@@ -1196,10 +1202,17 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       }
     }
     int nUpd = 0, wideAt = -1;
+    // A wide update as the node's FIRST event with only plain SendSigs deliveries behind it (the usual shape: the task was
+    // registered a pairing time ago, most messages of the ms were sent before that and so come after it in the LIFO's
+    // order) is k_handel_update's too since round 4: that kernel applies the update and then the deliveries, in event
+    // order — this lane applies nothing of the node. (Until then such a node was a visit of k_handel_wave: a third of that
+    // kernel's items.)
+    bool updFirst = false, plainBehind = true;
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) {
       if ((uint32_t)k < cnt) {
         const uint32_t kind = (E[k].w0 >> 28) & 3u;
+        if (k > 0 && (kind != K_MSG || (E[k].w0 & INBOX_CHAIN))) plainBehind = false;
         if (kind == K_MSG) {
           // (a hop of a fast-path envelope too: its re-push after the run's last hop is one record, see below)
         } else if (kind == K_TASK && E[k].w2 == H_TASK_UPDATE) {
@@ -1208,8 +1221,10 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
           if (unw > s.laneNw) {
             if ((uint32_t)(k + 1) == cnt && unw <= H_UPD_NW)
               wideAt = k;
-            else
+            else {
               mine = false;
+              updFirst = k == 0 && unw <= H_UPD_NW && s.updTrail;
+            }
           }
         } else {
           mine = false;
@@ -1217,10 +1232,11 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       }
     }
     if (nUpd > 1) mine = false;
+    updFirst = updFirst && have && plainBehind && nUpd == 1 && cnt <= (uint32_t)INBOX_SLOTS && !s.atk && !disFirst;
     {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
       // (a node whose first event k_handel_dissem applies: the rest of its events, if any, as a visit that skips the first —
       // listed here, with this wavefront's one atomic, not by k_handel_dissem with one atomic per node on the same word)
-      const bool toB = have && !mine && (!disFirst || cnt > 1u);
+      const bool toB = have && !mine && !updFirst && (!disFirst || cnt > 1u);
       const uint64_t m = __ballot(toB);
       if (m) {
         uint32_t bb = 0;
@@ -1341,7 +1357,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     }
     {  // the node's wide updateVerifiedSignatures: an item of k_handel_update
       bool upd = false;
-      uint32_t ue = 0, ua = 0;
+      uint32_t ue = 0, ua = 0, trail = 0;
 #pragma unroll
       for (int k = 0; k < INBOX_SLOTS; k++)
         if (mine && !toDown && k == wideAt) {
@@ -1349,6 +1365,28 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
           ue = E[k].e;
           ua = E[k].w3;
         }
+      {  // ... or the first event: the node's other events are k_handel_lane2's, listed here (one atomic per wavefront)
+        const uint64_t tm = __ballot(updFirst);
+        if (tm) {
+          uint32_t tb = 0;
+          const int leader = __ffsll((unsigned long long)tm) - 1;
+          if (lane == leader) tb = atomicAdd(F(s.trailCount + 0), (uint32_t)__popcll(tm));
+          tb = lane_bcast(tb, leader);
+          if (updFirst) {
+            const uint32_t idx = tb + __popcll(tm & lanes_lt());
+            U4 q;
+            q.x = (uint32_t)node;
+            q.y = (vflags << 8) | cnt;
+            q.z = E[0].e;
+            q.w = 0u;
+            gst(s.itemsTrail + idx, q);
+            upd = true;
+            ue = E[0].e;
+            ua = E[0].w3;
+            trail = (idx + 1u) << 16;
+          }
+        }
+      }
       const uint64_t m = __ballot(upd);
       if (m) {
         uint32_t bb = 0;
@@ -1360,7 +1398,8 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
           q.x = (uint32_t)node;
           q.y = ue;
           q.z = ua;
-          q.w = vflags;
+          // (down | partition << 1 | (index of the node's itemsTrail entry + 1) << 9: 0 = nothing behind the update)
+          q.w = (vflags & 1u) | ((vflags >> 8) << 1) | (trail >> 7);
           gst(s.itemsUpd + (bb + __popcll(m & lanes_lt())), q);
         }
       }
@@ -1411,7 +1450,9 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     U4 nxt = cur;
     if (q + nWaves < nItems) nxt = gld(s.itemsUpd + (q + nWaves));
     const int32_t node = (int32_t)WG_READFIRST(cur.x);
-    const uint32_t e = WG_READFIRST(cur.y), arg = WG_READFIRST(cur.z), vflags = WG_READFIRST(cur.w);
+    const uint32_t e = WG_READFIRST(cur.y), arg = WG_READFIRST(cur.z);
+    const uint32_t wq = WG_READFIRST(cur.w);
+    const uint32_t vflags = (wq & 1u) | (((wq >> 1) & 0xFFu) << 8), trailIdx = wq >> 9;  // (itemsTrail index + 1: deliveries wait behind this update)
     cur = nxt;
     const int pk = H_ARG_PK(arg), lv = H_ARG_LV(arg), slot = H_ARG_SLOT(arg);
     const int32_t from = H_ARG_FROM(arg);
@@ -1470,7 +1511,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     const uint32_t pe = pk == 0 ? pend.x : pk == 1 ? pend.y : pk == 2 ? pend.z : pend.w;
     const uint32_t pf = pk == 0 ? pfrom.x : pk == 1 ? pfrom.y : pk == 2 ? pfrom.z : pfrom.w;
     const bool toDown = (vflags & VD_DOWN) != 0;
-    if (toDown) {  // (:606 — a stopped node's task is consumed, not run)
+    if (toDown) {  // (:606 — a stopped node's task is consumed, not run; k_handel_lane2 consumes the deliveries behind it)
       if (lane == 0) gst(d.evRes + e, res);
       continue;
     }
@@ -1518,9 +1559,39 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     acc = wave_sum64(acc);
     const int u2 = (int)(acc & 0xFFFFFFFFu);
     const bool inter = (acc >> 32) != 0;
-    if (u2 > cVI) {  // all.cardinality() > verifiedIndSignatures.cardinality()
+    const bool replace = u2 > cVI;  // all.cardinality() > verifiedIndSignatures.cardinality()
+    if (replace) {  // what the level's sets become — counted before anything is stored
       improved = true;
       uint64_t cnt = 0;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint64_t nlx = (inter ? 0ULL : law[u].x) | sg[u].x, nly = (inter ? 0ULL : law[u].y) | sg[u].y;
+        if (2 * (u * 64 + lane) < v.nw)
+          cnt += (uint64_t)(__popcll(nlx) + __popcll(nly)) | ((uint64_t)(__popcll(nlx | viN[u].x) + __popcll(nly | viN[u].y)) << 32);
+      }
+      cnt = wave_sum64(cnt);
+      cLA = (int)(cnt & 0xFFFFFFFFu);
+      cTI = (int)(cnt >> 32);
+    }
+    // A level that completes lets the levels above take the fast path (:738-749), whose scan of the emission lists reads
+    // finishedPeers — which a delivery BEHIND this update may set. With deliveries behind it (trailCnt) such an update is not
+    // this kernel's: nothing has been stored, the whole visit goes to k_handel_wave, which runs the fast path in its place.
+    if (trailIdx && improved && cTI == v.size && s.p.fastPath > 0 && lv + 1 < s.L) {
+      if (lane == 0) {
+        U4 WG_G* tr = (U4 WG_G*)s.itemsTrail + (trailIdx - 1u);
+        const uint32_t cntAll = gld(tr).y & 0xFFu;
+        tr->w = 1u;  // (k_handel_lane2 leaves the node alone)
+        const uint32_t bb = atomicAdd(F(&d.g->nActiveB), 1u);
+        U4 qd;
+        qd.x = (uint32_t)node;
+        qd.y = HW_VISIT | (vflags << 8);
+        qd.z = cntAll;
+        qd.w = 0u;
+        gst((U4 WG_G*)(VisitDesc WG_G*)d.activeB + bb, qd);
+      }
+      continue;
+    }
+    if (replace) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = 2 * (u * 64 + lane);
@@ -1532,12 +1603,8 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
           nti.y = nla.y | viN[u].y;
           if (nla.x != law[u].x || nla.y != law[u].y) gst((V2 WG_G*)(la + j), nla);
           if (nti.x != tiw[u].x || nti.y != tiw[u].y) gst((V2 WG_G*)(ti + j), nti);
-          cnt += (uint64_t)(__popcll(nla.x) + __popcll(nla.y)) | ((uint64_t)(__popcll(nti.x) + __popcll(nti.y)) << 32);
         }
       }
-      cnt = wave_sum64(cnt);
-      cLA = (int)(cnt & 0xFFFFFFFFu);
-      cTI = (int)(cnt >> 32);
     } else if (!hadTI && ownerLane) {
       ti[jF] = tiF | bit;
     }
@@ -1595,6 +1662,100 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
         gst((U4 WG_G*)(VisitDesc WG_G*)d.activeB + bb, qd);
       } else {
         gst(d.evRes + e, res);
+      }
+    }
+  }
+}
+
+// The SendSigs deliveries BEHIND a wide update that was the node's first event: one LANE per such node, after
+// k_handel_update applied the update (it reads the header as that kernel left it: doneAt, the queue mask). The same
+// h_lane_message as k_handel_lane; wide payloads become jobs of k_handel_copy, which runs next.
+__global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const HandelState& s = stab[blockIdx.y];
+  const int lane = WG_LANE;
+  const uint32_t nItems = *s.trailCount;
+  const int32_t t = d.g->now;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t a0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; a0 < nItems; a0 += stride) {
+    const uint32_t a = a0 + (uint32_t)lane;
+    U4 it;
+    it.x = it.y = it.z = 0;
+    it.w = 1u;
+    if (a < nItems) it = gld((const U4 WG_G*)s.itemsTrail + a);
+    const bool have = a < nItems && it.w == 0u;
+    const int32_t node = (int32_t)it.x;
+    const uint32_t cnt = have ? (it.y & 0xFFu) : 0u, vflags = it.y >> 8, eUpd = it.z;
+    InboxEntry E[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) E[k].e = 0xFFFFFFFFu, E[k].w0 = 0, E[k].w2 = 0, E[k].w3 = 0;
+    U4 h0, h2;
+    h0.x = h0.y = h0.z = h0.w = 0;
+    h2 = h0;
+    if (have) {
+#pragma unroll
+      for (int k = 0; k < INBOX_SLOTS; k++) E[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+      const uint32_t WG_G* hdr = h_hdr(s, node);
+      h0 = gld((const U4 WG_G*)hdr);
+      h2 = gld((const U4 WG_G*)(hdr + 8));
+    }
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++)
+      if ((uint32_t)k >= cnt || E[k].e == eUpd) E[k].e = 0xFFFFFFFFu;  // (the update itself: k_handel_update's)
+#define H_CSWAP(A, B)                  \
+  if (E[B].e < E[A].e) {               \
+    const InboxEntry x = E[A];         \
+    E[A] = E[B];                       \
+    E[B] = x;                          \
+  }
+    H_CSWAP(0, 1) H_CSWAP(2, 3) H_CSWAP(0, 2) H_CSWAP(1, 3) H_CSWAP(1, 2)
+#undef H_CSWAP
+    HLaneNode r;
+    r.doneAt = r.doneAt0 = (long long)((unsigned long long)h2.y | ((unsigned long long)h2.z << 32));
+    r.startAt = (int32_t)h0.w;
+    r.sigQueueSize = r.sigQueueSize0 = (int32_t)h0.y;
+    r.msgFiltered = r.msgFiltered0 = (int32_t)h0.z;
+    r.qmask = r.qmask0 = h2.w;
+    r.qdirty = 0;
+    r.total = r.total0 = 0;
+    const bool toDown = (vflags & VD_DOWN) != 0;
+    const uint8_t toPart = (uint8_t)(vflags >> 8);
+    long long nRecv = 0, bRecv = 0;
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      CopyJob job;
+      job.nw = 0;
+      if (have && E[k].e != 0xFFFFFFFFu) {
+        const int32_t from = (int32_t)(E[k].w0 & 0x0FFFFFFFu);
+        EvRes res;
+        res.nrec = 0;
+        res.ndraw = 0;
+        if (!toDown && (d.nparts == 0 || d.nodes.part[from] == toPart)) {  // C/Network.java:606
+          nRecv++;
+          bRecv += h_msg_size((int)(E[k].w2 & 31u));
+          res.nrec = EV_DELIVERED | ((E[k].w2 & 31u) << 24);
+          h_lane_message(d, s, t, node, r, from, E[k].w2, E[k].w3, job);
+        }
+        gst(d.evRes + E[k].e, res);
+      }
+      const uint64_t jm = __ballot(job.nw > 0);
+      if (jm) {
+        uint32_t jb = 0;
+        const int leader = __ffsll((unsigned long long)jm) - 1;
+        if (lane == leader) jb = atomicAdd(F(s.jobCount + 0), (uint32_t)__popcll(jm));
+        jb = lane_bcast(jb, leader);
+        if (job.nw > 0) gst(s.jobs + (jb + __popcll(jm & lanes_lt())), job);
+      }
+    }
+    if (have) {  // (sigQueueSize / msgFiltered: k_handel_update does not write them; the queue mask it may have cleared a bit of)
+      uint32_t WG_G* hdr = h_hdr(s, node);
+      if (r.sigQueueSize != r.sigQueueSize0) hdr[HH_SIGQ] = (uint32_t)r.sigQueueSize;
+      if (r.msgFiltered != r.msgFiltered0) hdr[HH_FILT] = (uint32_t)r.msgFiltered;
+      if (r.qmask != r.qmask0) hdr[HH_QMASK] = r.qmask;
+      if (r.qdirty) atomicOr(F(hdr + HH_QDIRTY), r.qdirty);
+      if (nRecv) {
+        atomicAdd(F(hdr + HH_NRECV), (uint32_t)nRecv);
+        atomicAdd((unsigned long long*)F(hdr + HH_BRECV), (unsigned long long)bRecv);
       }
     }
   }
@@ -1849,6 +2010,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     *s.jobCount = 0;
     *s.updCount = 0;
     *s.disCount = 0;
+    *s.trailCount = 0;
   }
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
