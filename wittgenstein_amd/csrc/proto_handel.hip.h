@@ -2058,13 +2058,20 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     // wavefront was 512 same-address atomics per list and engine in every ms: an L2 atomic unit retires ~ 88 of those per
     // us, and every wavefront waited for its turn: 22 -> 15 us per ordinary ms at 24 copies.)
     // A level with something to evaluate is a lane's item while its block is <= H_LANE_NW words and a wavefront's beyond.
-    uint32_t mLane = 0, mWave = 0;
+    // A wavefront's level whose verified sets are still empty (|lastAggVerified| = |verifiedInd| = 0, hence totalIncoming
+    // too) says so in its item (bit 31): the evaluation then needs the signatures alone, not the level's rows.
+    uint32_t mLane = 0, mWave = 0, mEmpty = 0;
     for (uint32_t m = qm; m; m &= m - 1) {
       const int l = __ffs(m) - 1;
-      if (!s.atk && h_nw(l) <= s.laneNw)  // (an attack's run: every item by a wavefront)
+      if (!s.atk && h_nw(l) <= s.laneNw) {  // (an attack's run: every item by a wavefront)
         mLane |= 1u << l;
-      else
+      } else {
         mWave |= 1u << l;
+        if (!s.atk) {
+          const U4 a = gld((const U4 WG_G*)h_lv(s, (int32_t)node, HP_POS, l));
+          if ((a.z | a.w) == 0) mEmpty |= 1u << l;
+        }
+      }
     }
     const int w = (int)(threadIdx.x >> 6);
     uint32_t incl2[2], mine2[2];
@@ -2088,7 +2095,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
       for (int k = 0; k < 4; k++)
         if (k < w) base += shTot[which][k];
       uint32_t WG_G* list = which == 0 ? (uint32_t WG_G*)s.itemsLane : (uint32_t WG_G*)s.itemsWave;
-      for (uint32_t m = mm; m; m &= m - 1) list[base++] = node | ((uint32_t)(__ffs(m) - 1) << 24);
+      for (uint32_t m = mm; m; m &= m - 1) {
+        const int l = __ffs(m) - 1;
+        list[base++] = node | ((uint32_t)l << 24) | (which == 1 && ((mEmpty >> l) & 1u) ? 0x80000000u : 0u);
+      }
     }
     __syncthreads();  // (shTot / shBase are rewritten by the next round)
   }
@@ -2124,7 +2134,8 @@ __device__ __forceinline__ void h_item_finish(const HandelState& s, int32_t node
 // (h_item_finish); returns it (signer << 8 | slot) or -1. Only the entries without a cached evaluation have their
 // signature read (HandelState::qcache; an attack's run caches nothing and evaluates them all).
 template <bool ATK>
-__device__ __forceinline__ long long h_best_wave(const EngineDev& d, const HandelState& s, int32_t node, int l) {
+__device__ __forceinline__ long long h_best_wave(const EngineDev& d, const HandelState& s, int32_t node, int l,
+                                                 bool emptySets = false) {
   const int lane = WG_LANE;
   KPROF_DECL;
   KPROF_COUNT(d.g, 16);
@@ -2160,7 +2171,7 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
         vi2[u].x = vi[0] & v.mask;
         la2[u].x = la[0] & v.mask;
       }
-    } else if (wideRound && j < v.nw) {
+    } else if (wideRound && j < v.nw && !emptySets) {  // (emptySets: both rows are zero — cond_pre read their counts)
       vi2[u] = gld((const V2 WG_G*)(vi + j));
       la2[u] = gld((const V2 WG_G*)(la + j));
     }
@@ -2699,7 +2710,7 @@ __device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const Handel
   const uint32_t nItems = s.itemCount[1];
   for (uint32_t q = wave; q < nItems; q += nWaves) {
     const uint32_t it = WG_READFIRST(s.itemsWave[q]);  // (wave-uniform: the item's addresses live in SGPRs)
-    h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
+    h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)((it >> 24) & 31u), !ATK && (it >> 31) != 0);
   }
 }
 template <bool GROUP>
