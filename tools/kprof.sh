@@ -9,7 +9,7 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import bench, wittgenstein_amd as w
 R = int(os.environ.get("KPROF_R", "16")); n = int(os.environ.get("KPROF_N", "32768"))
-sims, batch = bench.make_batch(w, n, range(R), 0, R)
+sims, batch = bench.make_batch(w, n, range(R), 0, R, os.environ.get("KPROF_WORKLOAD", "handel"))
 sims[0].network().profile(1)
 batch.run_multiple_times(chunk=10, maxTime=20000)
 pr = sims[0].network().profile_read()

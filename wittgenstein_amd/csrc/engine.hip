@@ -1282,8 +1282,11 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
     }
     {
       ProfScope ps(lead, Engine::PC_RESOLVE);
-      static const int total = grid_env("WG_GRID_TOTAL_RESOLVE", 4096);
-      hipLaunchKernelGGL(k_resolve<false>, dim3(grid_per_engine(GRID_RESOLVE, g.R, total), g.R), dim3(256), 0, g.stream, g.tab);
+      // (a block that finds no record still costs its launch — ~ 7 ns each, 25 us of GSFSignature's every ms at 4096 blocks,
+      // profiles/r14j —: the wide grid only in a ms in which a periodic task may fire)
+      static const int total = grid_env("WG_GRID_TOTAL_RESOLVE", 4096), totalQuiet = grid_env("WG_GRID_TOTAL_RESOLVE_QUIET", 512);
+      const int gx = grid_per_engine(GRID_RESOLVE, g.R, g.any_periodic_may_fire() ? total : totalQuiet);
+      hipLaunchKernelGGL(k_resolve<false>, dim3(gx, g.R), dim3(256), 0, g.stream, g.tab);
     }
     if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
       ProfScope ps(lead, Engine::PC_RESOLVE);

@@ -54,6 +54,14 @@ struct Group {
       if (r.task == task && now >= r.phase && (now - r.phase) % r.period == 0) return true;
     return false;
   }
+  // ... any of them: the ms in which every node's periodic task sends (Handel's dissemination, GSFSignature's doCycle) has
+  // a hundred times the outbox records of the others
+  bool any_periodic_may_fire() const {
+    if (now == INT32_MIN || !periodic) return true;
+    for (const PeriodicReg& r : *periodic)
+      if (now >= r.phase && (now - r.phase) % r.period == 0) return true;
+    return false;
+  }
 };
 
 // A resident protocol: device state + the kernels that run its action()/conditional tasks.
