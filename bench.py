@@ -249,7 +249,7 @@ def replicas_line(workload, n, R_req, K, W, local=0):
                    "nodes": n, "replicas_per_gpu": R, "replicas_requested": R_req, "hbm_bytes_per_copy_incl_init_image": int(per_copy),
                    "delivered_per_simulation": delivered // max(1, K * R), "init_wall_s": init_wall},
         "roofline": {"bound": "hbm", "kernel": "k_deliver<GsfProto> (the delivery pass)" if gsf else
-                     "k_handel_lane + k_handel_copy + k_handel_update + k_handel_dissem + k_handel_wave (the delivery pass)",
+                     "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave (the delivery pass)",
                      "achieved": per_launch / max(1.0, avg_ns), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": per_launch / max(1.0, avg_ns) / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
@@ -772,7 +772,7 @@ def main():
                    "cpu_baseline_sample_nodes": None if args.no_cpu else (min(args.cpu_sample_nodes or n, n) if gsf else (args.cpu_sample_nodes or n)),
                    "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WG_")}},
     }
-    # ---- roofline of the delivery pass (Handel: k_handel_lane + _copy + _update + _dissem + _wave): algorithmic bytes of everything delivered
+    # ---- roofline of the delivery pass (Handel: k_handel_lane + _update + _lane2 + _copy + _dissem + _wave): algorithmic bytes of everything delivered
     # in the timed region / its launches, over its average duration measured with HIP events in the timed region
     if by_level is None:
         import numpy as np
@@ -803,8 +803,8 @@ def main():
             traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, commit %s%s" % (
                 tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_copy + k_handel_update + k_handel_dissem + k_handel_wave "
-                                                              "(the delivery pass: one launch of each per simulated ms, all five inside the HIP-event bracket and "
+        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave "
+                                                              "(the delivery pass: one launch of each per simulated ms, all six inside the HIP-event bracket and "
                                                               "inside `traffic`)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "whole_step_traffic": whole_step_traffic,

@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c rc=$?"
   python tools/prof_summary.py pmc $OUT/p_$c $OUT/pmc_$c.md && rm -rf $OUT/p_$c
 done
-python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_copy,k_handel_update<,k_handel_dissem<,k_handel_wave<" > /dev/null
+python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_update<,k_handel_lane2,k_handel_copy,k_handel_dissem<,k_handel_wave<" > /dev/null
 cp $OUT/traffic.json profiles/traffic.json; export WG_TRAFFIC_SESSION=1
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/pc_$c -o k --output-format csv -- python $R/bench.py --workload casper --casper-stopped 0.1 --steps 1 --warmup 0 --no-cpu > $R/$OUT/pmc_casper_$c.json 2> $R/$OUT/pmc_casper_$c.err)

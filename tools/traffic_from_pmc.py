@@ -14,9 +14,10 @@ So for these kernels (scattered lines and lane-scattered words, no wide streams)
 bytes as they stand: `hbm_bytes_per_launch` = FETCH_SIZE + WRITE_SIZE; `..._reads_doubled` keeps the guide's x2 on
 the reads as the upper bound (it would apply only to the part of the reads that are 128-byte requests).
 usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json> [kernel patterns, comma-separated]
-(default patterns: Handel's delivery pass — the five kernels bench.py's HIP events bracket; Casper's:
+(default patterns: Handel's delivery pass — the six kernels bench.py's HIP events bracket; Casper's:
 "k_casper_classify,k_casper_attestations,k_deliver<CasperProto")"""
 import json
+import re
 import sys
 
 
@@ -29,8 +30,8 @@ def per_dispatch(path, counter, kernels):
     for line in open(path):
         c = [x.strip() for x in line.strip().strip("|").split("|")]
         if len(c) == 5 and c[1] == counter:
-            for k in kernels:
-                if k in c[0]:
+            for k in kernels:  # (a pattern that ends in a name character matches whole names only: k_handel_lane is not k_handel_lane2)
+                if re.search(re.escape(k) + (r"(?![A-Za-z0-9_])" if re.match(r"[A-Za-z0-9_]", k[-1]) else ""), c[0]):
                     n, sm = rows.get(k, (0, 0.0))
                     rows[k] = (n + int(float(c[2])), sm + float(c[3]))
     passes = max([n for n, _ in rows.values()] or [1])
@@ -51,7 +52,7 @@ def whole_step(path, counter):
 
 def main():
     fetch, write, nodes, replicas, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_handel_lane", "k_handel_copy", "k_handel_update<", "k_handel_dissem<", "k_handel_wave<"]
+    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_handel_lane", "k_handel_update<", "k_handel_lane2", "k_handel_copy", "k_handel_dissem<", "k_handel_wave<"]
     f = per_dispatch(fetch, "FETCH_SIZE", kernels)
     w = per_dispatch(write, "WRITE_SIZE", kernels)
     rd = sum(f.values()) * 1024.0
