@@ -356,7 +356,8 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * RCCL (torch.distributed backend "nccl": wittgenstein_amd/shards.py) — over xGMI the payload is a few bytes per event,
  * so the latency of the collective, not its bandwidth, is what a simulated ms pays.
  * Call before the engine allocates (before wg_protocol_load / the first wg_send). Resident protocols: PingPong, Handel, GSFSignature, San Fermin,
- * P2PFlood, Casper IMD (randomOnTies == 0).
+ * P2PFlood, Casper IMD (with randomOnTies the ms's blocks and tasks are visited in event order round the shards: one two-word
+ * collective per change of owner among them — exact, slow).
  * wg_read_i64 on a shard returns its own nodes' values and zeros for the others (sum across shards for the whole
  * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
  * shard yet, batches, and host-callback mode. */

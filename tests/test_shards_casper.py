@@ -106,3 +106,19 @@ def test_casper_shards_ignore_the_lane_events_switch(monkeypatch):
     monkeypatch.setenv("WG_CASPER_LANE_EVENTS", "0")
     c, _ = casper_loopback(2, (2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=14)
     assert c.read("headHeight")[0] >= 2
+
+
+def test_casper_random_on_ties_on_shards():
+    """randomOnTies (P/CasperIMD.java:250-253, the CasperParemeters() default) on a sharded engine: a tie's rd.nextBoolean() takes
+    its index in the rd sequence from the draws of every earlier event of the ms — other shards' events too — so the ordered
+    visit of the ms's blocks and tasks goes round the shards (k_casper_seq_shard, one two-word collective per change of
+    owner). ByzBlockProducerWF(+7000) forks the chain with equal votes on both branches: ties do draw (the rd state differs
+    from the randomOnTies == false run of the oracle)."""
+    import oracle_lib as o
+    for k, params, seed, chunk, chunks, stopped in ((2, (2, True, 2, 6, 1000, 1), 3, 500, 160, 2), (3, (3, True, 3, 8, 1000, 1), 1, 1000, 80, 0)):
+        c, traffic = casper_loopback(k, params, seed=seed, chunk=chunk, chunks=chunks, byz_delay=7000, stopped=stopped)
+        assert len(set(traffic)) == 1 and c.read("headHeight")[0] >= 4
+        if not stopped:
+            plain = o.CasperIMD((params[0], False) + params[2:], None, None, seed=seed, byz_delay=7000)
+            plain.run_ms(chunk * chunks)
+            assert c.info()["rng"] != plain.info()["rng"]

@@ -338,7 +338,8 @@ dist.destroy_process_group()
 
 @pytest.mark.parametrize("world,params,byz,stopped,chunk,chunks", [
     (2, (5, False, 5, 80, 1000, 1), 0, 40, 4000, 7),       # PT/CasperIMDTest.java:10-11's network, 10 % of the attesters stop()ped
-    (4, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 30)])   # ByzBlockProducerWF(-2000), PT/CasperByzantineTest.java:41
+    (4, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 30),    # ByzBlockProducerWF(-2000), PT/CasperByzantineTest.java:41
+    (2, (2, True, 2, 6, 1000, 1), 7000, 2, 500, 160)])     # randomOnTies with a fork: the ordered visit goes round the ranks
 def test_sharded_casper_matches_the_oracle(oracle, tmp_path, world, params, byz, stopped, chunk, chunks):
     """Casper IMD resident on node-range shards (per-node rows by owner, block / attestation tables replicated and filled by
     exchange, sendAll resolved on every shard, periodic tasks through every shard's far buffer): every observable of
@@ -352,7 +353,7 @@ def test_sharded_casper_matches_the_oracle(oracle, tmp_path, world, params, byz,
     for r in res:
         assert r["bad"] == [], r
         assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"] and r["height"] >= 2
-    assert res[0]["delivered"] > (50000 if world == 2 else 300)
+    assert res[0]["delivered"] > (50000 if world == 2 and not params[1] else 300)
 
 
 FLOOD_WORKER = r'''

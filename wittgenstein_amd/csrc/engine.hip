@@ -1592,7 +1592,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     const uint32_t seqE = publish_counts(gfield(&Globals::nEvents), nullptr);  // (known after expand: read behind the delivery pass)
     {
       ProfScope ps(*this, PC_DELIVER);
-      proto->launch_deliver(g);
+      if (!proto->shard_deliver(*this, g)) proto->launch_deliver(g);  // (a pass with collectives of its own: Casper's randomOnTies)
     }
     uint32_t nEvents = 0;
     wait_counts(seqE, &nEvents, nullptr);
@@ -3346,9 +3346,6 @@ struct CasperHost : ProtoHost {
       throw WgError(WG_EINVAL, "Casper IMD: the network must hold 1 observer + blockProducersCount + cycleLength * attestersPerRound nodes");
     if (p.cycleLength <= 0 || p.blockProducersCount <= 0 || p.attestersPerRound <= 0 || p.maxSlots <= 0)
       throw WgError(WG_EINVAL, "Casper IMD parameters");
-    if (p.randomOnTies && e.shardCount > 0)
-      throw WgError(WG_EUNSUPPORTED, "randomOnTies on a sharded engine: a tie's rd.nextBoolean() takes its place in the rd sequence "
-                                     "from the draws of every earlier event of the ms, network-wide (one wavefront, k_casper_seq)");
     if (p.blockConstructionTime <= 0 || p.attestationConstructionTime <= 0)
       throw WgError(WG_EUNSUPPORTED, "construction times must be >= 1 ms (a sendAll for the current ms would have to be delivered in it)");
     if (!e.allocated) {
@@ -3407,6 +3404,14 @@ struct CasperHost : ProtoHost {
     // a delayed byzantine producer can build in another producer's ms: such ms go through k_casper_seq (CasperState::builds)
     st.seqCapable = p.byzDelay != 0 && e.shardCount == 0 ? 1u : 0u;
     if (p.randomOnTies || st.seqCapable) st.seqBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
+    st.tBits = nullptr;
+    st.seqPos = nullptr;
+    st.xseq = nullptr;
+    if (p.randomOnTies && e.shardCount > 0) {  // the ordered visit goes round the shards (k_casper_seq_shard)
+      st.tBits = e.dalloc<uint64_t>(((size_t)e.dev.maxEvents + 63) / 64 + 64);
+      st.seqPos = e.dalloc<uint32_t>(1);
+      st.xseq = e.dalloc<int32_t>(2);
+    }
     st.forked = e.dalloc<uint32_t>(1);
     st.builds = e.dalloc<uint32_t>(1);
     st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
@@ -3431,6 +3436,31 @@ struct CasperHost : ProtoHost {
   void shard_snap_exchange(Engine& e, const Group& g, uint32_t) override {
     e.shard_allreduce(st.xtab, xtabWords);
     hipLaunchKernelGGL(k_casper_shard_apply, dim3(1, 1), dim3(256), 0, g.stream, g.tab, (const CasperState*)g.stab);
+  }
+  // randomOnTies on a sharded engine: the delivery pass with its rounds of the ordered visit (k_casper_seq_shard) — one
+  // wavefront and one two-word collective per change of owner among the ms's blocks and tasks, one more to find that none is left
+  bool shard_deliver(Engine& e, const Group& g) override {
+    if (!st.p.randomOnTies) return false;
+    const CasperState* stab = (const CasperState*)g.stab;
+    hipLaunchKernelGGL(k_casper_classify, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_casper_attestations, dim3(attGrid, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_casper_mark_shard, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    uint32_t cursor = 0, drawBase = 0;
+    for (int round = 0;; round++) {
+      if (round > (int)e.dev.maxEvents + 1) throw WgError(WG_ESTATE, "the ordered visit of a sharded randomOnTies run does not end");
+      WG_HIP(hipMemsetAsync(st.xseq, 0, 2 * sizeof(int32_t), g.stream));
+      hipLaunchKernelGGL(k_casper_seq_shard, dim3(1, g.R), dim3(64), 0, g.stream, g.tab, stab, cursor, drawBase);
+      e.shard_allreduce(st.xseq, 2);
+      int32_t h[2] = {0, 0};
+      WG_HIP(hipMemcpyAsync(h, st.xseq, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+      WG_HIP(hipStreamSynchronize(g.stream));
+      if (h[0] == 0) break;  // no block or task behind the cursor: every shard has finished its share
+      cursor = (uint32_t)h[0] - 1u;
+      drawBase += (uint32_t)h[1];
+    }
+    // (k_deliver: every node with a block or a task has been visited and unflagged — its visit_skip admits none; it retires the ms's node list)
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    return true;
   }
   void launch_deliver(const Group& g) override {
     const CasperState* stab = (const CasperState*)g.stab;

@@ -74,6 +74,8 @@ struct ProtoHost {
   virtual bool node_counter(Engine&, int32_t field, int64_t* dst, int32_t n) { return false; }
   virtual void launch_cond(Engine& profOwner, const Group&) {}
   virtual void launch_deliver(const Group&) = 0;
+  // a sharded engine's delivery pass when it needs collectives of its own (true = done; false = launch_deliver)
+  virtual bool shard_deliver(Engine&, const Group&) { return false; }
   virtual size_t state_size() const = 0;        // sizeof the device State struct ...
   virtual const void* state_host() const = 0;   // ... and its host copy (what a Group's stab holds)
   // continuation predicate for every member of the group: out[R] on the device

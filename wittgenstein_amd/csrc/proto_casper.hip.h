@@ -66,6 +66,13 @@ struct CasperState {
   // the byzantine producer, whose onBlock builds at once when it is late), and from two on the ms goes through k_casper_seq
   GP<uint32_t> builds;     // [1] (reset by k_casper_seq)
   uint32_t seqCapable;
+  // randomOnTies on a sharded engine (k_casper_mark_shard / k_casper_seq_shard, CasperHost::shard_deliver): the events
+  // that are not attestations are the same on every shard (`tBits`); `seqBits` holds this shard's share of the ordered
+  // visit (its own nodes' such events and the attestations of its nodes that have one); `seqPos` = how far that share is
+  // done; `xseq` = {next cursor + 1, draws made} of a round, summed across shards (only one shard writes it)
+  GP<uint64_t> tBits;
+  GP<uint32_t> seqPos;
+  GP<int32_t> xseq;
   GP<uint32_t> forked;     // randomOnTies: [1] some block has two children. best() can reach its tie-break only between two
                            // branches, i.e. never before that: until then the parallel k_deliver is exact (no draw to order),
                            // from the next ms on k_casper_seq takes the mixed nodes
@@ -443,6 +450,35 @@ __global__ void __launch_bounds__(256) k_casper_builds(const EngineDev* __restri
   }
 }
 
+// one event of an ordered visit (k_casper_seq, k_casper_seq_shard): delivered as k_deliver delivers it, with the number of rd
+// draws of the ms's earlier events; returns the draws it made
+__device__ __forceinline__ uint32_t casper_seq_event(const EngineDev& d, const CasperState& s, CasperProto::WaveShared* shP, uint32_t e,
+                                                     int32_t t, uint32_t drawBase) {
+  const int lane = WG_LANE;
+  const Rec rec = d.ev[e];
+  const EvAux aux = d.evAux[e];
+  const int32_t node = (int32_t)rec.w1;
+  Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+  CasperProto::NodeRegs r;
+  CasperProto::node_begin(c, s, r, shP);
+  r.drawBase = drawBase;
+  long long nRecv = 0, bRecv = 0;
+  deliver_event<CasperProto>(d, s, c, r, e, rec, aux, d.nodes.down[node] != 0, d.nparts ? d.nodes.part[node] : (uint8_t)0, true, nRecv,
+                             bRecv);
+  __builtin_amdgcn_wave_barrier();
+  CasperProto::node_end(c, s, r);
+  if (lane == 0) {
+    if (nRecv) atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);  // (unit_message_size)
+    if (c.msgSent) {
+      atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+      atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+    }
+    d.head[node] = -1;  // (its inbox list, threaded by expand / k_casper_attestations, is not used here)
+    s.mixed[node] = 0;
+  }
+  return c.draws;
+}
+
 // randomOnTies (see the header): which events belong to a mixed node, one bit per event (64 consecutive events per
 // wavefront: one ballot, one store), then ONE wavefront delivers exactly those in global event order — receiveUntil's
 // own order (C/Network.java:594-635) — carrying the number of rd draws made so far in the ms, which is the index of a
@@ -486,34 +522,94 @@ __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__
       while (bits) {
         const uint32_t e = (w0 + (uint32_t)k) * 64 + (uint32_t)(__ffsll((unsigned long long)bits) - 1);
         bits &= bits - 1;
-        const Rec rec = d.ev[e];
-        const EvAux aux = d.evAux[e];
-        const int32_t node = (int32_t)rec.w1;
-        Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
-        CasperProto::NodeRegs r;
-        CasperProto::node_begin(c, s, r, &shP);
-        r.drawBase = drawBase;
-        long long nRecv = 0, bRecv = 0;
-        deliver_event<CasperProto>(d, s, c, r, e, rec, aux, d.nodes.down[node] != 0, d.nparts ? d.nodes.part[node] : (uint8_t)0,
-                                   true, nRecv, bRecv);
-        __builtin_amdgcn_wave_barrier();
-        CasperProto::node_end(c, s, r);
-        if (lane == 0) {
-          if (nRecv) atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nRecv);  // (unit_message_size)
-          if (c.msgSent) {
-            atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
-            atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
-          }
-          d.head[node] = -1;   // (its inbox list, threaded by expand / k_casper_attestations, is not used here)
-          s.mixed[node] = 0;
-        }
-        drawBase += c.draws;
+        drawBase += casper_seq_event(d, s, &shP, e, t, drawBase);
         __threadfence_block();  // the node's next event (another round of this loop) reads what this one wrote
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
   if (lane == 0) *s.builds = 0;
+}
+
+// randomOnTies on a SHARDED engine. A tie's nextBoolean() takes its index in the rd sequence from the draws of every earlier
+// event of the ms, and those events are other shards' too: the ordered visit goes round the shards. The events that are not
+// attestations (blocks, tasks: the only ones that draw) are known to every shard from the replicated event list; a ROUND
+// belongs to the owner of the first of them at or behind the cursor: it delivers its share of the visit — its nodes' such
+// events and the attestations of its nodes that have one, in event order — up to the next such event of another shard,
+// and reports {that event's index + 1, the draws it made}; the sum across shards (nobody else wrote) moves every shard's
+// cursor and draw count. A round that finds no such event is the last one: every shard finishes its share (attestations
+// draw nothing). Exact, and as slow as one wavefront and one small collective per change of owner are.
+__global__ void __launch_bounds__(256) k_casper_mark_shard(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  const uint32_t n = d.g->nEvents;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *s.seqPos = 0;
+  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+    const uint32_t e = e0 + WG_LANE;
+    bool tt = false, own = false;
+    if (e < n) {
+      const Rec r = d.ev[e];
+      tt = !casper_is_attestation(r);
+      own = shard_owns(d, (int32_t)r.w1) && (tt || s.mixed[r.w1] != 0);
+    }
+    const uint64_t mt = __ballot(tt), mo = __ballot(own);
+    if (WG_LANE == 0) {
+      s.tBits[e0 >> 6] = mt;
+      s.seqBits[e0 >> 6] = mo;
+    }
+  }
+}
+// first set bit of `bits` at or behind `from` (< n), or n — the whole wavefront, 64 words a step
+__device__ __forceinline__ uint32_t casper_next_bit(const uint64_t WG_G* bits, uint32_t from, uint32_t n) {
+  for (uint32_t w0 = from >> 6; (uint64_t)w0 * 64 < n; w0 += 64) {
+    const uint32_t wi = w0 + (uint32_t)WG_LANE;
+    uint64_t v = (uint64_t)wi * 64 < n ? bits[wi] : 0ULL;
+    if (wi == (from >> 6)) v &= ~0ULL << (from & 63);
+    const uint64_t any = __ballot(v != 0);
+    if (any) {
+      const int k = __ffsll((unsigned long long)any) - 1;
+      const uint64_t word = lane_bcast64(v, k);
+      const uint32_t e = (w0 + (uint32_t)k) * 64 + (uint32_t)(__ffsll((unsigned long long)word) - 1);
+      return e < n ? e : n;
+    }
+  }
+  return n;
+}
+__global__ void __launch_bounds__(64) k_casper_seq_shard(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab,
+                                                         uint32_t cursor, uint32_t drawBase0) {
+  WG_ENGINE(tab);
+  const CasperState& s = stab[blockIdx.y];
+  __shared__ CasperProto::WaveShared shP;
+  const uint32_t n = d.g->nEvents;
+  const int32_t t = d.g->now;
+  const int lane = WG_LANE;
+  const uint32_t e0 = casper_next_bit(s.tBits, cursor, n);
+  uint32_t stop = n;  // this shard's share is delivered up to here
+  if (e0 < n) {
+    if (!shard_owns(d, (int32_t)d.ev[e0].w1)) return;  // another shard's round
+    for (uint32_t e = e0;;) {  // ... up to the next such event that is another shard's
+      e = casper_next_bit(s.tBits, e + 1, n);
+      if (e >= n) break;
+      if (!shard_owns(d, (int32_t)d.ev[e].w1)) {
+        stop = e;
+        break;
+      }
+    }
+  }
+  uint32_t drawBase = drawBase0;
+  for (uint32_t e = casper_next_bit(s.seqBits, *s.seqPos, stop); e < stop; e = casper_next_bit(s.seqBits, e + 1, stop)) {
+    drawBase += casper_seq_event(d, s, &shP, e, t, drawBase);
+    __threadfence_block();  // the node's next event (another round of this loop) reads what this one wrote
+    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    *s.seqPos = stop;
+    if (e0 < n) {
+      s.xseq[0] = (int32_t)stop + 1;
+      s.xseq[1] = (int32_t)(drawBase - drawBase0);
+    }
+  }
 }
 
 // sharded engine: the summed table image of this ms (CasperState::xtab) -> the block and the votes the other shards'
