@@ -9,6 +9,7 @@
 #include "gsf.hpp"
 #include "handel.hpp"
 #include "p2pflood.hpp"
+#include "optimistic_p2p.hpp"
 #include "pingpong.hpp"
 #include "sanfermin.hpp"
 #include "sanfermin_cappos.hpp"
@@ -900,6 +901,67 @@ int orc_p2pflood_read(void* h, int field, int64_t* out) {
 }
 int orc_p2pflood_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
   auto& p = *((OrcFlood*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  return 0;
+}
+
+// ---- OptimisticP2PSignature (P/OptimisticP2PSignature.java over C/P2PNetwork.java)
+struct OrcOptP2P {
+  std::unique_ptr<OptimisticP2PSignature> p;
+};
+// ip: nodeCount, threshold, connectionCount, pairingTime (:58-71)
+int orc_optp2p_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY OptimisticP2PSignature::Params pr;
+  pr.nodeCount = ip[0];
+  pr.threshold = ip[1];
+  pr.connectionCount = ip[2];
+  pr.pairingTime = ip[3];
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcOptP2P();
+  h->p = std::make_unique<OptimisticP2PSignature>(pr);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_optp2p_destroy(void* h) { delete (OrcOptP2P*)h; }
+int orc_optp2p_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcOptP2P*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 doneAt, 5 done, 6 verifiedSignatures.cardinality(),
+//         7 peers.size(), 8 order-sensitive digest of the peer ids, 9 x, 10 y
+int orc_optp2p_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcOptP2P*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.doneAt; break;
+      case 5: v = n.done; break;
+      case 6: v = n.verifiedSignatures.cardinality(); break;
+      case 7: v = (int64_t)n.peers.size(); break;
+      case 8:
+        for (size_t k = 0; k < n.peers.size(); k++) v += (int64_t)(k + 1) * n.peers[k]->nodeId;
+        break;
+      case 9: v = n.x; break;
+      case 10: v = n.y; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_optp2p_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcOptP2P*)h)->p;
   *time = p.network_.time;
   *queueSize = p.network_.msgs.size();
   *rngState = p.network_.rd.rawState();

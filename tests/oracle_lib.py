@@ -471,6 +471,39 @@ class P2PFlood:
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
 
 
+class OptimisticP2PSignature:
+    """oracle/optimistic_p2p.hpp; params = OptimisticP2PSignatureParameters' ctor order (P/OptimisticP2PSignature.java:58-71):
+    (nodeCount, threshold, connectionCount, pairingTime)."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "doneAt": 4, "done": 5,
+              "sigs": 6, "peerCount": 7, "peerDigest": 8, "x": 9, "y": 10}
+
+    def __init__(self, params, nb=None, nl=None, seed=0):
+        self.h, self.n = C.c_void_p(), params[0]
+        ip = (C.c_int32 * 4)(*params)
+        _ck(lib().orc_optp2p_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed),
+                                    C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_optp2p_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_optp2p_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_optp2p_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_optp2p_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
 # ---- city topology / latency (oracle/geo.hpp): data from tests/golden/city_data.json
 _CITY_LOADED = False
 
