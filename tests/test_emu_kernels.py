@@ -39,6 +39,7 @@ import test_gpu_p2pflood_resident as tfr  # noqa: E402
 import test_gpu_casper_resident as tcr  # noqa: E402
 import test_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_gpu_p2pflood as tpf  # noqa: E402
+import test_gpu_optimistic_p2p as top  # noqa: E402
 import test_gpu_sanfermin as tsf  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -243,6 +244,12 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_optimistic_p2p_signature_through_host_callbacks(monkeypatch):  # P/OptimisticP2PSignature.java over C/P2PNetwork.java
+    top.test_optimistic_p2p_simple()
+    top.test_envelope_ring_overflow_is_loud()
+    top.test_optimistic_p2p_without_latency_batched_steps(monkeypatch)
 
 
 def test_p2pflood_through_host_callbacks():  # C/P2PNetwork.java + FloodMessage + P/P2PFlood.java on the engine

@@ -216,13 +216,3 @@ def two_blocks_in_one_ms_cases():
 @pytest.mark.gpu
 def test_two_blocks_in_one_ms_resident():
     two_blocks_in_one_ms_cases()
-
-
-@pytest.mark.gpu
-def test_random_on_ties_on_logical_shards():
-    """... and on a sharded engine (refused until round 4): the ordered visit goes round the shards (k_casper_seq_shard); two
-    logical shards of the one GPU in lock-step with the oracle, ties drawing"""
-    import test_shards_casper as tc
-    c, traffic = tc.casper_loopback(2, (2, True, 2, 6, 1000, 1), seed=3, chunk=500, chunks=160, byz_delay=7000, stopped=2,
-                                    device_memory=True)
-    assert len(set(traffic)) == 1 and c.read("headHeight")[0] >= 4

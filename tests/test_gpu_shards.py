@@ -130,7 +130,10 @@ def leg8():
     import test_shards_casper as tc
     out["casper"] = []
     for k, params, byz, stopped, chunk, chunks in [(4, (5, False, 5, 80, 1000, 1), 0, 40, 4000, 12),
-                                                   (3, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 40)]:
+                                                   (3, (3, False, 3, 8, 1000, 1), -2000, 3, 1000, 40),
+                                                   # randomOnTies with a fork (ByzBlockProducerWF(+7000)): ties draw, the ordered
+                                                   # visit of the ms's blocks and tasks goes round the shards (k_casper_seq_shard)
+                                                   (2, (2, True, 2, 6, 1000, 1), 7000, 2, 500, 160)]:
         c, traffic = tc.casper_loopback(k, params, seed=3, chunk=chunk, chunks=chunks, byz_delay=byz, stopped=stopped,
                                         device_memory=True)
         out["casper"].append({"k": k, "delivered": int(c.info()["delivered"]), "height": int(c.read("headHeight")[0]),
@@ -257,7 +260,7 @@ def test_config3_as_8_logical_shards_equals_the_oracle_trace(result):
 
 def test_casper_logical_shards_match_the_oracle(result):   # per-node rows by owner, tables by exchange, sendAll on every shard
     assert "leg8" not in result["errors"], result["errors"]["leg8"]
-    assert [r["k"] for r in result["casper"]] == [4, 3]
+    assert [r["k"] for r in result["casper"]] == [4, 3, 2]   # (the last: randomOnTies with ties drawing, refused on shards until round 4)
     for r in result["casper"]:
         assert r["same_collectives"] and r["calls"] > 0 and r["height"] >= 3, r
     assert result["casper"][0]["delivered"] > 100000

@@ -153,3 +153,22 @@ def test_gsf_aliasing_is_unobservable(oracle):
         assert a.stats()["shapeViolations"] == 0
         live = a.read("down") == 0
         assert np.array_equal(a.read_bits("levelVerified")[live], a.read_bits("verifiedSignatures")[live])
+
+
+# ---- OptimisticP2PSignature: PT/OptimisticP2PSignatureTest.java restated against the oracle --------------
+def test_optimistic_p2p_simple(oracle):  # testSimple :14-32
+    n = 100
+    p = o.OptimisticP2PSignature((n, n // 2 + 1, 13, 3), GSF_NB, GSF_NL)
+    p.run_ms(10 * 1000)
+    assert len(p.read("done")) == n
+    assert (p.read("done") == 1).all() and (p.read("doneAt") > 0).all() and (p.read("sigs") > n // 2).all()
+    assert (p.read("peerCount") >= 3).all()  # P2PNetwork.setPeers :48-55 (minimum == false)
+
+
+def test_optimistic_p2p_copy_is_deterministic(oracle):  # testCopy :34-50
+    a = o.OptimisticP2PSignature((200, 160, 10, 2), GSF_NB, GSF_NL)
+    b = o.OptimisticP2PSignature((200, 160, 10, 2), GSF_NB, GSF_NL)
+    a.run_ms(200)
+    b.run_ms(200)
+    assert (a.read("done") == b.read("done")).all() and (a.read("doneAt") == b.read("doneAt")).all()
+    assert a.info() == b.info() and a.info()["delivered"] > 10000

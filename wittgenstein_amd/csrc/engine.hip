@@ -852,6 +852,8 @@ void Engine::send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32
     for (auto& a : da) sc.words.push_back(a.arrival);
   if (dev.hostMode) {  // the host hands the hops out itself: keep the envelope
     if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
+    if (hostChains[sc.slot].live)  // (the ring has gone round onto an envelope that still has destinations to reach)
+      throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
     hostChains[sc.slot].live = true;
     hostChains[sc.slot].c = sc.c;
     hostChains[sc.slot].words = sc.words;
@@ -934,6 +936,8 @@ void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int
   globalsDirty = true;
   if (dev.hostMode) {
     if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
+    if (hostChains[sc.slot].live)
+      throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
     hostChains[sc.slot].live = true;
     hostChains[sc.slot].c = sc.c;
     hostChains[sc.slot].words = sorted;
