@@ -3182,6 +3182,10 @@ struct GsfHost : ProtoHost {
     return nOut;
   }
   void launch_deliver(const Group& g) override {
+    static const bool laneTier = !(getenv("WG_GSF_LANE") && atoi(getenv("WG_GSF_LANE")) == 0);
+    if (eng.dev.inbox && laneTier)  // nodes whose events are all plain SendSigs deliveries, one lane each (k_gsf_lane)
+      hipLaunchKernelGGL(k_gsf_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_GSF_LANE", 1024), g.R), dim3(256), 0, g.stream, g.tab,
+                         (const GsfState*)g.stab);
     if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
       hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab);

@@ -2089,12 +2089,14 @@ __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __r
       cntN = d.icnt[nodeN];
     }
     __builtin_amdgcn_wave_barrier();  // every lane has read the node's count (and the next node's) before lane 0 clears it
-    if (lane == 0) d.icnt[node] = 0;  // the line is consumed by this visit
-    const uint32_t vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
-    Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
-    typename P::NodeRegs r;
-    P::node_begin(c, ps, r, &shP[w]);
-    deliver_visit_inbox<P>(d, ps, c, r, node, cnt, vflags, in, 0u);
+    if (cnt != 0) {  // (0: a lane-per-node kernel of the protocol has delivered the node's events already — k_gsf_lane)
+      if (lane == 0) d.icnt[node] = 0;  // the line is consumed by this visit
+      const uint32_t vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
+      Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
+      typename P::NodeRegs r;
+      P::node_begin(c, ps, r, &shP[w]);
+      deliver_visit_inbox<P>(d, ps, c, r, node, cnt, vflags, in, 0u);
+    }
     node = nodeN;
     in = inN;
     cnt = cntN;

@@ -305,68 +305,104 @@ struct GsfProto {
       return v.mask;  // FULL (and OVER after `sigs = waitedSigs.clone()` :412)
     };
     int cVl = ls->cV[l], cIVl = ls->cIV[l], cUl = ls->cU[l];
-    bool reset = false;
-    if (kind == GK_OVER) {
-      // the sender sent its next levels too (:397-413): every level i <= j whose block the set includes is
-      // completed outright
-      const int jTop = min((int)aux, s.L - 1);
-      uint32_t incomplete = 0;
-      for (int i = 1; i <= jTop; i++)
-        if (ls->cV[i] != (1 << (i - 1))) incomplete |= 1u << i;
-      __builtin_amdgcn_wave_barrier();  // every lane has read the counts before lane 0 replaces them
-      if (incomplete) {
-        reset = true;  // resetRemaining stays true from the first completed level on (:404-408)
-        for (int i = __ffs(incomplete) - 1; i <= jTop; i++) {
-          const int sz = 1 << (i - 1);
-          if ((incomplete >> i) & 1u) {
-            const Lv vi = sib_view(node, i);
-            H_FOR_WORDS(vi, j) vr[vi.bw + j] |= vi.mask;
-            if (lane == 0) {
-              ls->cV[i] = sz;
-              ls->cU[i] = sz;
-            }
-          }
-          if (lane == 0) ls->rem[i] = sz;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      cVl = ls->cV[l];
-      cUl = ls->cU[l];
-    } else {
-      // sigs.cardinality() == 1 -> indivVerifiedSig.set(from) (:388-390)
-      uint64_t a = 0;
-      H_FOR_WORDS(v, j) a += (uint64_t)__popcll(sword(j));
-      const int cs = (int)wave_sum64(a);
-      if (cs == 1) {
-        const uint64_t ivF = ld_coherent(ivr + wF), vF = ld_coherent(vr + wF);
+    bool reset = false, improved = false;
+    if (kind != GK_OVER && v.nw <= 64) {
+      // ---- the usual case, one word of each row per lane (blocks of <= 4096 ids): the signature's, indivVerifiedSig's and
+      // verifiedSignatures' words of the level in ONE round of loads — taken one after the other as the statements of
+      // :388-427 come (the cardinality, the sender's two bits, the merge test, the replacement) they were four dependent
+      // round trips of a visit that is nothing but a chain of those
+      const bool in = lane < v.nw;
+      const uint64_t sgRaw = (kind == GK_PARTIAL && in) ? sig[lane] : 0ULL;
+      uint64_t ivw = in ? ivr[v.bw + lane] : 0ULL;
+      const uint64_t vw = in ? vr[v.bw + lane] : 0ULL;
+      const uint64_t sg = !in ? 0ULL : kind == GK_PARTIAL ? (sgRaw & v.mask) : kind == GK_INDIV ? (lane == jF ? bitF : 0ULL) : v.mask;
+      const int cs = (int)wave_sum64((uint64_t)__popcll(sg));
+      if (cs == 1) {  // sigs.cardinality() == 1 -> indivVerifiedSig.set(from) (:388-390)
+        const uint64_t ivF = lane_bcast64(ivw, jF), vF = lane_bcast64(vw, jF);
         if (!(ivF & bitF)) {
-          if (lane == (wF & 63)) ivr[wF] = ivF | bitF;
+          if (lane == jF) {
+            ivw |= bitF;
+            ivr[wF] = ivw;
+          }
           cIVl++;
           if (!(vF & bitF)) cUl++;
         }
       }
-    }
-    // sigs |= indivVerifiedSig; merge with the level's verified set when disjoint (:390, :415-420)
-    uint64_t acc = 0, flg = 0;
-    H_FOR_WORDS(v, j) {
-      const uint64_t sg = sword(j) | (ivr[v.bw + j] & v.mask), vw = vr[v.bw + j] & v.mask;
-      acc += (uint64_t)__popcll(sg) | ((uint64_t)__popcll(sg | vw) << 24);
-      flg |= (uint64_t)((sg & vw) != 0);
-    }
-    acc = wave_sum64(acc);
-    const bool inter = __ballot(flg != 0) != 0;
-    const bool merge = cVl > 0 && !inter;
-    const int cFinal = merge ? (int)(acc >> 24) : (int)(acc & 0xFFFFFFu);
-    const bool improved = cFinal > cVl || reset;
-    if (improved) {
-      // verifiedSignatures.andNot(waitedSigs); verifiedSignatures.or(sigs) — level and node rows are one (:423-427)
-      H_FOR_WORDS(v, j) {
-        const uint64_t old = vr[v.bw + j];
-        const uint64_t nv = sword(j) | (ivr[v.bw + j] & v.mask) | (merge ? (old & v.mask) : 0ULL);
-        vr[v.bw + j] = (old & ~v.mask) | nv;
+      // sigs |= indivVerifiedSig; merge with the level's verified set when disjoint (:390, :415-420)
+      const uint64_t sgI = sg | (ivw & v.mask), vwm = vw & v.mask;
+      const uint64_t acc = wave_sum64((uint64_t)__popcll(sgI) | ((uint64_t)__popcll(sgI | vwm) << 24));
+      const bool inter = __ballot((sgI & vwm) != 0) != 0;
+      const bool merge = cVl > 0 && !inter;
+      const int cFinal = merge ? (int)(acc >> 24) : (int)(acc & 0xFFFFFFu);
+      improved = cFinal > cVl;
+      if (improved) {  // verifiedSignatures.andNot(waitedSigs); verifiedSignatures.or(sigs) (:423-427)
+        if (in) vr[v.bw + lane] = (vw & ~v.mask) | sgI | (merge ? vwm : 0ULL);
+        cVl = cFinal;
+        cUl = cFinal;  // the new set includes indivVerifiedSig
       }
-      cVl = cFinal;
-      cUl = cFinal;  // the new set includes indivVerifiedSig
+    } else {
+      if (kind == GK_OVER) {
+        // the sender sent its next levels too (:397-413): every level i <= j whose block the set includes is
+        // completed outright
+        const int jTop = min((int)aux, s.L - 1);
+        uint32_t incomplete = 0;
+        for (int i = 1; i <= jTop; i++)
+          if (ls->cV[i] != (1 << (i - 1))) incomplete |= 1u << i;
+        __builtin_amdgcn_wave_barrier();  // every lane has read the counts before lane 0 replaces them
+        if (incomplete) {
+          reset = true;  // resetRemaining stays true from the first completed level on (:404-408)
+          for (int i = __ffs(incomplete) - 1; i <= jTop; i++) {
+            const int sz = 1 << (i - 1);
+            if ((incomplete >> i) & 1u) {
+              const Lv vi = sib_view(node, i);
+              H_FOR_WORDS(vi, j) vr[vi.bw + j] |= vi.mask;
+              if (lane == 0) {
+                ls->cV[i] = sz;
+                ls->cU[i] = sz;
+              }
+            }
+            if (lane == 0) ls->rem[i] = sz;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cVl = ls->cV[l];
+        cUl = ls->cU[l];
+      } else {
+        // sigs.cardinality() == 1 -> indivVerifiedSig.set(from) (:388-390)
+        uint64_t a = 0;
+        H_FOR_WORDS(v, j) a += (uint64_t)__popcll(sword(j));
+        const int cs = (int)wave_sum64(a);
+        if (cs == 1) {
+          const uint64_t ivF = ld_coherent(ivr + wF), vF = ld_coherent(vr + wF);
+          if (!(ivF & bitF)) {
+            if (lane == (wF & 63)) ivr[wF] = ivF | bitF;
+            cIVl++;
+            if (!(vF & bitF)) cUl++;
+          }
+        }
+      }
+      // sigs |= indivVerifiedSig; merge with the level's verified set when disjoint (:390, :415-420)
+      uint64_t acc = 0, flg = 0;
+      H_FOR_WORDS(v, j) {
+        const uint64_t sg = sword(j) | (ivr[v.bw + j] & v.mask), vw = vr[v.bw + j] & v.mask;
+        acc += (uint64_t)__popcll(sg) | ((uint64_t)__popcll(sg | vw) << 24);
+        flg |= (uint64_t)((sg & vw) != 0);
+      }
+      acc = wave_sum64(acc);
+      const bool inter = __ballot(flg != 0) != 0;
+      const bool merge = cVl > 0 && !inter;
+      const int cFinal = merge ? (int)(acc >> 24) : (int)(acc & 0xFFFFFFu);
+      improved = cFinal > cVl || reset;
+      if (improved) {
+        // verifiedSignatures.andNot(waitedSigs); verifiedSignatures.or(sigs) — level and node rows are one (:423-427)
+        H_FOR_WORDS(v, j) {
+          const uint64_t old = vr[v.bw + j];
+          const uint64_t nv = sword(j) | (ivr[v.bw + j] & v.mask) | (merge ? (old & v.mask) : 0ULL);
+          vr[v.bw + j] = (old & ~v.mask) | nv;
+        }
+        cVl = cFinal;
+        cUl = cFinal;  // the new set includes indivVerifiedSig
+      }
     }
     if (lane == 0) {
       ls->cV[l] = cVl;
@@ -586,6 +622,112 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// The delivery pass, lane tier: one LANE per node whose events of the ms are all plain SendSigs deliveries — onNewSig
+// (:538-556) is an append to the node's toVerify list, one bit of individualSignatures and, for a PARTIAL payload, a slot of
+// the node's payload store: four or five lines of the node, where a wavefront's visit loads the node's whole level state
+// (node_begin: thirteen lines) to touch none of it. Left to k_deliver_inbox: nodes with a task (updateVerifiedSignatures,
+// doCycle), with a hop of a multi-destination envelope (its continuation is an outbox record), with more events than the
+// inbox line holds, down nodes, a partitioned network, payloads wider than a lane copies (> 32 words). A node delivered
+// here has its inbox count zeroed: the wavefront kernel passes it over.
+__global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  const uint32_t nActive = d.g->nActive;
+  if (d.nparts || d.boundMsg) return;
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < nActive; a += gridDim.x * blockDim.x) {
+    const int32_t node = (int32_t)d.active[a];
+    const uint32_t cnt = d.icnt[node];
+    if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS || d.nodes.down[node]) continue;
+    InboxEntry in[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) in[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      if ((uint32_t)k >= cnt) continue;
+      const uint32_t w0 = in[k].w0, msg = in[k].w2;
+      ok = ok && ((w0 >> 28) & 3u) == K_MSG && !(w0 & INBOX_CHAIN);
+      if (((msg >> 6) & 3u) == GK_PARTIAL && h_nw((int)(msg & 31u)) > 32) ok = false;
+    }
+    if (!ok) continue;
+    d.icnt[node] = 0;  // the line is consumed by this visit
+    // event order = ascending event index (the line holds them in arrival order of the atomics, not in event order)
+    uint32_t rank[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      rank[k] = 0;
+#pragma unroll
+      for (int j = 0; j < INBOX_SLOTS; j++)
+        if ((uint32_t)j < cnt && in[j].e < in[k].e) rank[k]++;
+    }
+    int len = s.tvLen[node];
+    uint64_t WG_G* isRow = s.IS + (size_t)node * s.W;
+    uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
+    long long bytes = 0;
+    for (uint32_t r = 0; r < cnt; r++) {
+      InboxEntry ev = in[0];
+#pragma unroll
+      for (int k = 1; k < INBOX_SLOTS; k++)
+        if ((uint32_t)k < cnt && rank[k] == r) ev = in[k];
+      const int32_t from = (int32_t)(ev.w0 & 0x0FFFFFFFu);
+      const uint32_t msg = ev.w2, payload = ev.w3;
+      const int l = (int)(msg & 31u);
+      const uint32_t kind = (msg >> 6) & 3u;
+      uint32_t aux = (msg >> 8) & 31u;
+      bytes += g_msg_size(l);
+      EvRes res;
+      res.nrec = EV_DELIVERED | ((uint32_t)l << 24);
+      res.ndraw = 0;
+      gst(d.evRes + ev.e, res);
+      // onNewSig :538-556
+      const uint64_t isw = isRow[from >> 6];
+      const bool hadIS = (isw >> (from & 63)) & 1ULL;
+      const int need = hadIS ? 1 : 2;
+      if (len + need > s.Q) {
+        set_err(d.g, ERR_QUEUE_CAP);
+        continue;
+      }
+      if (kind == GK_PARTIAL) {
+        int slot = -1;
+        uint64_t WG_G* used = s.tvUsed + (size_t)node * (s.Q / 64);
+        for (int q = 0; q < s.Q / 64 && slot < 0; q++) {
+          const unsigned long long u = used[q];
+          if (~u) {
+            slot = q * 64 + __ffsll(~u) - 1;
+            used[q] = u | (1ULL << (slot & 63));
+          }
+        }
+        if (slot < 0) {
+          set_err(d.g, ERR_QUEUE_CAP);
+          continue;
+        }
+        const int nw = h_nw(l);
+        const uint64_t WG_G* src = s.snap + payload;
+        uint64_t WG_G* dst = GsfProto::sig_ptr(s, node, slot);
+        for (int j0 = 0; j0 < nw; j0 += 8) {  // (eight words in flight)
+          uint64_t v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = j0 + u < nw ? src[j0 + u] : 0ULL;
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (j0 + u < nw) dst[j0 + u] = v[u];
+        }
+        aux = (uint32_t)slot;
+      }
+      ent[len] = g_ent(from, l, kind, aux);                    // toVerify.add(ssigs)
+      if (!hadIS) {
+        ent[len + 1] = g_ent(from, l, GK_INDIV, 0);            // the individual signature (:547-553)
+        isRow[from >> 6] = isw | (1ULL << (from & 63));
+      }
+      len += need;
+    }
+    s.tvLen[node] = len;
+    s.sigQueueSize[node] = len;
+    atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)cnt);
+    atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bytes);
   }
 }
 
