@@ -2094,8 +2094,14 @@ __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __r
       const uint32_t vflags = (d.nodes.down[node] ? VD_DOWN : 0u) | (d.nparts ? (uint32_t)d.nodes.part[node] << 8 : 0u);
       Ctx c{d, t, node, 0, 0, 0, 0, 0, 0, 0};
       typename P::NodeRegs r;
+      KPROF_DECL;
+      KPROF_COUNT(d.g, 0);
       P::node_begin(c, ps, r, &shP[w]);
+      KPROF_MARK(d.g, 1);  // node_begin
       deliver_visit_inbox<P>(d, ps, c, r, node, cnt, vflags, in, 0u);
+      KPROF_MARK(d.g, 2);  // the visit (events + node_end)
+    } else {
+      KPROF_COUNT(d.g, 3);  // a node another kernel delivered
     }
     node = nodeN;
     in = inN;

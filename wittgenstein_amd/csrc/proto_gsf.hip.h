@@ -178,10 +178,11 @@ struct GsfProto {
     return s.tvSig + ((size_t)node * s.Q + slot) * (size_t)s.SW;
   }
   // first incomplete level (levels below it form getLastFinishedLevel :194-211); L if every level is complete
-  __device__ static int first_incomplete(const State& s, const GLevels* ls) {
-    int k = 1;
-    while (k < s.L && ls->cV[k] == (1 << (k - 1))) k++;
-    return k;
+  __device__ static int first_incomplete(const State& s, const GLevels* ls) {  // (every lane of the wavefront calls it: lane l looks at level l)
+    const int lane = WG_LANE;
+    const bool inc = lane >= 1 && lane < s.L && ls->cV[lane] != (1 << (lane - 1));
+    const uint64_t m = __ballot(inc);
+    return m ? __ffsll((unsigned long long)m) - 1 : s.L;
   }
   // message word of a SendSigs built at level l while the sender's first incomplete level is k (header comment)
   __device__ static uint32_t msg_word(int l, int k, bool levelFinished) {
@@ -191,6 +192,7 @@ struct GsfProto {
 
   // ---- Message.action: SendSigs -> onNewSig (:538-556) ----------------------------------------------
   __device__ static void on_new_sig(Ctx& c, const State& s, NodeRegs& r, int32_t from, uint32_t msg, uint32_t payload) {
+    KPROF_COUNT(c.d.g, 9);
     const int l = (int)(msg & 31u);
     const uint32_t kind = (msg >> 6) & 3u;
     uint32_t aux = (msg >> 8) & 31u;
@@ -236,32 +238,52 @@ struct GsfProto {
 
   // ---- PeriodicTask: doCycle (:213-225) -> SFLevel.doCycle (:317-327) -------------------------------
   __device__ static void do_cycle(Ctx& c, const State& s, NodeRegs& r) {
+    // The reference walks the levels one after the other (:317-327 inside :213-225); done literally that is one chain of
+    // dependent round trips per level (posInLevel -> the peer's id -> the record, and the snapshot's words for a PARTIAL
+    // payload) — twelve of them at 4096 nodes, in the ms in which every node has this task. Here lane l takes level l: the
+    // peers are one round of loads, the snapshots of all PARTIAL levels one flat copy (the levels' words lie back to back in
+    // the node's snapshot row, lvlOff), the records one send_many in level order.
     GLevels* ls = r.ls;
     r.dirty |= 1u;  // (posInLevel / remainingCalls)
     const int32_t node = c.node;
+    const int lane = WG_LANE;
     const int k = first_incomplete(s, ls);
-    for (int l = 1; l < s.L; l++) {
-      const int rem = ls->rem[l], pos = ls->pos[l], cvl = ls->cV[l];
-      __builtin_amdgcn_wave_barrier();  // every lane has read the level's scalars before lane 0 replaces them
-      if (rem == 0) continue;
-      if (!(c.t >= l * s.p.timeoutPerLevelMs || k >= l)) continue;  // hasStarted :294-315
-      const int size = 1 << (l - 1);
-      const int32_t dest = s.peers[(size_t)node * (s.N - 1) + (size - 1) + pos];  // getRemainingPeers(1)
-      const uint32_t word = msg_word(l, k, cvl == size);
-      uint32_t ref = 0;
-      if (k < l) {  // PARTIAL: snapshot the verified bits of the levels below l (the node's own block)
-        const Lv v = own_view(node, l);
-        const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
-        const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
-        ref = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride + s.lvlOff[l];
-        H_FOR_WORDS(v, j) s.snap[ref + j] = vr[v.bw + j] & v.mask;
-        c.evFlags = ev_snap_code(s.snapStride) << EV_SNAP_SHIFT;  // (a sharded engine ships the node's row of this window)
+    const bool lv = lane >= 1 && lane < s.L;
+    int rem = 0, pos = 0, cvl = 0;
+    if (lv) {
+      rem = ls->rem[lane];
+      pos = ls->pos[lane];
+      cvl = ls->cV[lane];
+    }
+    const int size = lv ? 1 << (lane - 1) : 0;
+    const bool act = lv && rem != 0 && (c.t >= lane * s.p.timeoutPerLevelMs || k >= lane);  // hasStarted :294-315
+    int32_t dest = 0;
+    if (act) dest = s.peers[(size_t)node * (s.N - 1) + (size - 1) + pos];  // getRemainingPeers(1)
+    const uint64_t actM = __ballot(act);
+    if (!actM) return;
+    const uint64_t partM = __ballot(act && k < lane);  // PARTIAL: snapshot the verified bits of the levels below l (the node's own block)
+    const uint32_t win = ((uint32_t)c.t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
+    const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    if (partM) {
+      const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
+      for (uint32_t q = (uint32_t)lane; q < s.snapStride; q += 64) {
+        int l = 1;  // the level whose words hold flat word q (lvlOff is increasing from level 1 on)
+        for (int i = 2; i < s.L; i++)
+          if (s.lvlOff[i] <= q) l = i;
+        if ((partM >> l) & 1ULL) {
+          const Lv v = own_view(node, l);
+          s.snap[refBase + q] = vr[v.bw + (int)(q - s.lvlOff[l])] & v.mask;
+        }
       }
-      c.send(dest, word, ref, g_msg_size(l));
-      if (WG_LANE == 0) {
-        ls->pos[l] = pos + 1 >= size ? 0 : pos + 1;
-        ls->rem[l] = rem - 1;
-      }
+      c.evFlags = ev_snap_code(s.snapStride) << EV_SNAP_SHIFT;  // (a sharded engine ships the node's row of this window)
+    }
+    long long bytes = 0;
+    for (uint64_t m = actM; m; m &= m - 1) bytes += g_msg_size(__ffsll((unsigned long long)m) - 1);
+    c.send_many(act, __popcll(actM & lanes_lt()), __popcll(actM), dest, msg_word(lane, k, cvl == size),
+                act && k < lane ? refBase + s.lvlOff[lane] : 0u, bytes);
+    if (act) {
+      ls->pos[lane] = pos + 1 >= size ? 0 : pos + 1;
+      ls->rem[lane] = rem - 1;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -269,6 +291,8 @@ struct GsfProto {
   // ---- Task: updateVerifiedSignatures (:387-460) ------------------------------------------------------
   __device__ static void update_verified(Ctx& c, const State& s, NodeRegs& r, uint32_t arg) {
     const int lane = WG_LANE;
+    KPROF_DECL;
+    KPROF_COUNT(c.d.g, 11);
     r.dirty |= 1u | 2u | 4u;  // (the level's counts, a PARTIAL message's slot, the pending table)
     const int32_t node = c.node;
     // (selects, not r.pend[arg & 3]: a register array indexed at run time puts the whole NodeRegs — and the LDS pointer in
@@ -404,6 +428,7 @@ struct GsfProto {
         cUl = cFinal;  // the new set includes indivVerifiedSig
       }
     }
+    KPROF_MARK(c.d.g, 4);  // update: the level's rows (loads, counts, stores)
     if (lane == 0) {
       ls->cV[l] = cVl;
       ls->cIV[l] = cIVl;
@@ -412,7 +437,9 @@ struct GsfProto {
     }
     if (improved && lane >= l && lane < s.L) ls->rem[lane] = 1 << (lane - 1);  // :421-425 (L <= 64 lanes)
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(c.d.g, 5);  // update: the level's scalars
     if (!improved) return;
+    KPROF_COUNT(c.d.g, 12);
     if (s.p.acceleratedCallsCount > 0) {  // :429-444
       const int k = first_incomplete(s, ls);
       int cur = l;
@@ -436,11 +463,12 @@ struct GsfProto {
       }
       __builtin_amdgcn_wave_barrier();
     }
+    KPROF_MARK(c.d.g, 6);  // update: the accelerated calls
     if (r.doneAt == 0) {
-      int tot = 0;
-      for (int i = 0; i < s.L; i++) tot += ls->cV[i];
+      const int tot = (int)wave_sum64(lane < s.L ? (uint64_t)ls->cV[lane] : 0ULL);
       if (tot >= s.p.threshold) r.doneAt = c.t;
     }
+    KPROF_MARK(c.d.g, 7);  // update: doneAt
   }
 };
 
@@ -629,7 +657,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
 // (:538-556) is an append to the node's toVerify list, one bit of individualSignatures and, for a PARTIAL payload, a slot of
 // the node's payload store: four or five lines of the node, where a wavefront's visit loads the node's whole level state
 // (node_begin: thirteen lines) to touch none of it. Left to k_deliver_inbox: nodes with a task (updateVerifiedSignatures,
-// doCycle), with a hop of a multi-destination envelope (its continuation is an outbox record), with more events than the
+// doCycle), with more events than the
 // inbox line holds, down nodes, a partitioned network, payloads wider than a lane copies (> 32 words). A node delivered
 // here has its inbox count zeroed: the wavefront kernel passes it over.
 __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
@@ -649,7 +677,7 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
     for (int k = 0; k < INBOX_SLOTS; k++) {
       if ((uint32_t)k >= cnt) continue;
       const uint32_t w0 = in[k].w0, msg = in[k].w2;
-      ok = ok && ((w0 >> 28) & 3u) == K_MSG && !(w0 & INBOX_CHAIN);
+      ok = ok && ((w0 >> 28) & 3u) == K_MSG;
       if (((msg >> 6) & 3u) == GK_PARTIAL && h_nw((int)(msg & 31u)) > 32) ok = false;
     }
     if (!ok) continue;
@@ -681,6 +709,31 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
       EvRes res;
       res.nrec = EV_DELIVERED | ((uint32_t)l << 24);
       res.ndraw = 0;
+      if (ev.w0 & INBOX_CHAIN) {  // a hop of a multi-destination envelope (the accelerated calls :445-449)
+        const EvAux aux = gld(d.evAux + ev.e);
+        if (aux.chain >= 0 && aux.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  C/Network.java:629-632
+          const int32_t next = (aux.cpos & 0x7FFFFFFF) + 1;
+          if (next < d.chains[aux.chain].ndest) {
+            Out o;
+            o.kindfrom = (O_CHAINCONT << 28) | (uint32_t)node;
+            o.to = aux.chain;
+            o.a = (uint32_t)next;
+            o.b = 0;
+            o.t = 0;
+            o.destOff = 0;
+            o.drawsub = 0;
+            o.pad = 0;
+            if (aux.outCap && aux.outBase < d.maxOut) {  // (as Ctx::put: an over-subscribed ms must not write past the outbox)
+              d.outTmp[aux.outBase] = o;
+              res.nrec |= 1u;
+            } else {
+              set_err(d.g, ERR_OUTBOX);
+            }
+          } else {
+            d.chains[aux.chain].flags = 0;  // envelope fully delivered
+          }
+        }
+      }
       gst(d.evRes + ev.e, res);
       // onNewSig :538-556
       const uint64_t isw = isRow[from >> 6];
