@@ -691,15 +691,41 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
       for (int j = 0; j < INBOX_SLOTS; j++)
         if ((uint32_t)j < cnt && in[j].e < in[k].e) rank[k]++;
     }
-    int len = s.tvLen[node];
+    // everything the events' addresses alone decide, in ONE round of loads (the kernel is one wave-round of lanes: its
+    // duration is a lane's chain of dependent round trips): the list's length, per event the sender's word of
+    // individualSignatures and — for a hop of a multi-destination envelope — its EvAux; the envelope's length follows
     uint64_t WG_G* isRow = s.IS + (size_t)node * s.W;
     uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
+    int len = s.tvLen[node];
+    uint64_t iswK[INBOX_SLOTS];
+    EvAux auxK[INBOX_SLOTS];
+    int32_t ndK[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      const bool have = (uint32_t)k < cnt;
+      iswK[k] = have ? isRow[(in[k].w0 & 0x0FFFFFFFu) >> 6] : 0ULL;
+      auxK[k].chain = -1;
+      auxK[k].cpos = 0;
+      auxK[k].outBase = auxK[k].outCap = 0;
+      if (have && (in[k].w0 & INBOX_CHAIN)) auxK[k] = gld(d.evAux + in[k].e);
+    }
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++)
+      ndK[k] = (auxK[k].chain >= 0 && auxK[k].cpos < 0) ? d.chains[auxK[k].chain].ndest : 0;
     long long bytes = 0;
     for (uint32_t r = 0; r < cnt; r++) {
       InboxEntry ev = in[0];
+      uint64_t isw = iswK[0];
+      EvAux aux0 = auxK[0];
+      int32_t nd = ndK[0];
 #pragma unroll
       for (int k = 1; k < INBOX_SLOTS; k++)
-        if ((uint32_t)k < cnt && rank[k] == r) ev = in[k];
+        if ((uint32_t)k < cnt && rank[k] == r) {
+          ev = in[k];
+          isw = iswK[k];
+          aux0 = auxK[k];
+          nd = ndK[k];
+        }
       const int32_t from = (int32_t)(ev.w0 & 0x0FFFFFFFu);
       const uint32_t msg = ev.w2, payload = ev.w3;
       const int l = (int)(msg & 31u);
@@ -709,34 +735,30 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
       EvRes res;
       res.nrec = EV_DELIVERED | ((uint32_t)l << 24);
       res.ndraw = 0;
-      if (ev.w0 & INBOX_CHAIN) {  // a hop of a multi-destination envelope (the accelerated calls :445-449)
-        const EvAux aux = gld(d.evAux + ev.e);
-        if (aux.chain >= 0 && aux.cpos < 0) {  // last hop of the run: markRead(); if (hasNextReader()) msgs.addMsg(m)  C/Network.java:629-632
-          const int32_t next = (aux.cpos & 0x7FFFFFFF) + 1;
-          if (next < d.chains[aux.chain].ndest) {
-            Out o;
-            o.kindfrom = (O_CHAINCONT << 28) | (uint32_t)node;
-            o.to = aux.chain;
-            o.a = (uint32_t)next;
-            o.b = 0;
-            o.t = 0;
-            o.destOff = 0;
-            o.drawsub = 0;
-            o.pad = 0;
-            if (aux.outCap && aux.outBase < d.maxOut) {  // (as Ctx::put: an over-subscribed ms must not write past the outbox)
-              d.outTmp[aux.outBase] = o;
-              res.nrec |= 1u;
-            } else {
-              set_err(d.g, ERR_OUTBOX);
-            }
+      if (aux0.chain >= 0 && aux0.cpos < 0) {  // last hop of a multi-destination envelope's run (the accelerated calls :445-449):
+        const int32_t next = (aux0.cpos & 0x7FFFFFFF) + 1;  // markRead(); if (hasNextReader()) msgs.addMsg(m)  C/Network.java:629-632
+        if (next < nd) {
+          Out o;
+          o.kindfrom = (O_CHAINCONT << 28) | (uint32_t)node;
+          o.to = aux0.chain;
+          o.a = (uint32_t)next;
+          o.b = 0;
+          o.t = 0;
+          o.destOff = 0;
+          o.drawsub = 0;
+          o.pad = 0;
+          if (aux0.outCap && aux0.outBase < d.maxOut) {  // (as Ctx::put: an over-subscribed ms must not write past the outbox)
+            d.outTmp[aux0.outBase] = o;
+            res.nrec |= 1u;
           } else {
-            d.chains[aux.chain].flags = 0;  // envelope fully delivered
+            set_err(d.g, ERR_OUTBOX);
           }
+        } else {
+          d.chains[aux0.chain].flags = 0;  // envelope fully delivered
         }
       }
       gst(d.evRes + ev.e, res);
       // onNewSig :538-556
-      const uint64_t isw = isRow[from >> 6];
       const bool hadIS = (isw >> (from & 63)) & 1ULL;
       const int need = hadIS ? 1 : 2;
       if (len + need > s.Q) {
@@ -774,6 +796,9 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
       if (!hadIS) {
         ent[len + 1] = g_ent(from, l, GK_INDIV, 0);            // the individual signature (:547-553)
         isRow[from >> 6] = isw | (1ULL << (from & 63));
+#pragma unroll
+        for (int k = 0; k < INBOX_SLOTS; k++)  // (a later event of this visit whose sender shares the word: it was loaded before this store)
+          if ((int32_t)((in[k].w0 & 0x0FFFFFFFu) >> 6) == (from >> 6)) iswK[k] |= 1ULL << (from & 63);
       }
       len += need;
     }
