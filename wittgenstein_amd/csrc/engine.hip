@@ -3182,10 +3182,21 @@ struct GsfHost : ProtoHost {
     return nOut;
   }
   void launch_deliver(const Group& g) override {
+    // the lean kernels first: a node's doCycle task (k_gsf_docycle, in the ms in which it can fire) and plain SendSigs
+    // deliveries (k_gsf_lane) — between them every node without an updateVerifiedSignatures task (gsf_split_ok); WG_GSF_LANE=0:
+    // every visit by k_deliver_inbox
     static const bool laneTier = !(getenv("WG_GSF_LANE") && atoi(getenv("WG_GSF_LANE")) == 0);
-    if (eng.dev.inbox && laneTier)  // nodes whose events are all plain SendSigs deliveries, one lane each (k_gsf_lane)
+    static const int cycleTier = getenv("WG_GSF_DOCYCLE") ? atoi(getenv("WG_GSF_DOCYCLE")) : 8;  // wavefronts per SIMD of the doCycle kernel; 0: off
+    const bool cycleRan = eng.dev.inbox && laneTier && cycleTier && g.periodic_may_fire(G_TASK_DOCYCLE);
+    if (cycleRan) {
+      if (cycleTier == 8)
+        hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
+      else
+        hipLaunchKernelGGL(k_gsf_docycle<6>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
+    }
+    if (eng.dev.inbox && laneTier)
       hipLaunchKernelGGL(k_gsf_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_GSF_LANE", 1024), g.R), dim3(256), 0, g.stream, g.tab,
-                         (const GsfState*)g.stab);
+                         (const GsfState*)g.stab, cycleRan ? 1 : 0);
     if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
       hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab);

@@ -653,6 +653,101 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
   }
 }
 
+// Which nodes the two lean kernels of the delivery pass take between them: a node all of whose events of the ms (as many as
+// its inbox line holds) are SendSigs deliveries and, at most once, its doCycle task. onNewSig (:538-556) touches the toVerify
+// list, individualSignatures and the payload store; doCycle (:213-225) reads posInLevel / remainingCalls / the verified
+// counts and writes the first two — disjoint state, and an event's records and draws take their place in the global order
+// from the event's index, not from when it ran: the task goes to k_gsf_docycle, the deliveries to k_gsf_lane, in either
+// order. (updateVerifiedSignatures changes what both read: such a node is visited in event order by k_deliver_inbox.)
+// Both kernels evaluate this one predicate on the same line, so they agree. `cycleRan`: k_gsf_docycle is launched in this ms.
+__device__ __forceinline__ bool gsf_split_ok(const EngineDev& d, int32_t node, uint32_t cnt, const InboxEntry (&in)[INBOX_SLOTS],
+                                             bool cycleRan, int& cycleAt) {
+  cycleAt = -1;
+  if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS || d.nparts || d.boundMsg || d.nodes.down[node]) return false;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < INBOX_SLOTS; k++) {
+    if ((uint32_t)k >= cnt) continue;
+    const uint32_t w0 = in[k].w0, msg = in[k].w2, kind = (w0 >> 28) & 3u;
+    if (kind == K_MSG) {
+      if (((msg >> 6) & 3u) == GK_PARTIAL && h_nw((int)(msg & 31u)) > 32) ok = false;  // (a payload wider than a lane copies)
+    } else if (kind == K_PERIODIC && msg == G_TASK_DOCYCLE && cycleRan && cycleAt < 0) {
+      cycleAt = k;
+    } else {
+      ok = false;
+    }
+  }
+  return ok;
+}
+
+// The delivery pass, doCycle tier: one WAVEFRONT per node whose only event of the ms is its doCycle task (:213-225) — with a
+// synchronised start that is nearly every node, once per period, in a ms that costs several ordinary ones. The task reads
+// posInLevel / remainingCalls / |verifiedSignatures| of the levels and nothing else of the node's state: a kernel that holds
+// neither onNewSig nor updateVerifiedSignatures loads three arrays instead of node_begin's thirteen lines and fits more
+// wavefronts per SIMD. Everything else (a node that also received a message in that ms, down nodes, a partitioned network)
+// stays with k_deliver_inbox; a node delivered here has its inbox count zeroed.
+template <int WPE>
+__global__ void __launch_bounds__(256, WPE) k_gsf_docycle(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {  // (k_gsf_lane must follow)
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  __shared__ GLevels shL[4];
+  const int lane = WG_LANE, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  if (d.nparts) return;
+  GLevels* ls = &shL[w];
+  for (uint32_t a = wave; a < nActive; a += nWaves) {
+    const int32_t node = (int32_t)d.active[a];
+    const uint32_t cnt = d.icnt[node];
+    if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS) continue;
+    InboxEntry line[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) line[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+    int cycleAt;
+    if (!gsf_split_ok(d, node, cnt, line, true, cycleAt) || cycleAt < 0) continue;
+    InboxEntry in = line[0];
+#pragma unroll
+    for (int k = 1; k < INBOX_SLOTS; k++)
+      if (k == cycleAt) in = line[k];
+    // (the inbox count stays: k_gsf_lane, which runs behind this kernel, delivers the node's messages if it has any and zeroes it)
+    for (int l = lane; l < s.L; l += 64) {
+      const size_t i = (size_t)node * s.L + l;
+      ls->pos[l] = s.pos[i];
+      ls->rem[l] = s.rem[i];
+      ls->cV[l] = s.cV[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (a task's `from` is the node itself; its inbox entry carries the event's first outbox slot, deliver_visit_inbox)
+    Ctx c{d, t, node, in.e, 0, 0, in.w0 & 0x0FFFFFFFu, d.boundTask[G_TASK_DOCYCLE] + 1u, 0, 0, 0};
+    GsfProto::NodeRegs r;
+    r.ls = ls;
+    r.dirty = 0;
+    r.doneAt = r.doneAt0 = 0;
+    GsfProto::do_cycle(c, s, r);
+    // PeriodicTask.action re-arm (C/messages/PeriodicTask.java:39-47), as deliver_event
+    c.put(O_PERIODIC, node, in.w2, in.w3, t + (int32_t)in.w3, 0, false);
+    if (lane == 0) {
+      EvRes res;
+      res.nrec = c.sub | EV_TASK_RUN | c.evFlags;
+      res.ndraw = c.draws;
+      gst(d.evRes + in.e, res);
+      if (c.msgSent) {
+        atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)c.msgSent);
+        atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)c.bytesSent);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int l = lane; l < s.L; l += 64) {
+      const size_t i = (size_t)node * s.L + l;
+      s.pos[i] = ls->pos[l];
+      s.rem[i] = ls->rem[l];
+    }
+    __builtin_amdgcn_wave_barrier();  // (the LDS image is the next node's from here on)
+  }
+}
+
 // The delivery pass, lane tier: one LANE per node whose events of the ms are all plain SendSigs deliveries — onNewSig
 // (:538-556) is an append to the node's toVerify list, one bit of individualSignatures and, for a PARTIAL payload, a slot of
 // the node's payload store: four or five lines of the node, where a wavefront's visit loads the node's whole level state
@@ -660,7 +755,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
 // doCycle), with more events than the
 // inbox line holds, down nodes, a partitioned network, payloads wider than a lane copies (> 32 words). A node delivered
 // here has its inbox count zeroed: the wavefront kernel passes it over.
-__global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+__global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int cycleRan) {
   WG_ENGINE(tab);
   const GsfState& s = stab[blockIdx.y];
   const uint32_t nActive = d.g->nActive;
@@ -668,19 +763,12 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < nActive; a += gridDim.x * blockDim.x) {
     const int32_t node = (int32_t)d.active[a];
     const uint32_t cnt = d.icnt[node];
-    if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS || d.nodes.down[node]) continue;
+    if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS) continue;
     InboxEntry in[INBOX_SLOTS];
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) in[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < INBOX_SLOTS; k++) {
-      if ((uint32_t)k >= cnt) continue;
-      const uint32_t w0 = in[k].w0, msg = in[k].w2;
-      ok = ok && ((w0 >> 28) & 3u) == K_MSG;
-      if (((msg >> 6) & 3u) == GK_PARTIAL && h_nw((int)(msg & 31u)) > 32) ok = false;
-    }
-    if (!ok) continue;
+    int cycleAt;
+    if (!gsf_split_ok(d, node, cnt, in, cycleRan != 0, cycleAt)) continue;
     d.icnt[node] = 0;  // the line is consumed by this visit
     // event order = ascending event index (the line holds them in arrival order of the atomics, not in event order)
     uint32_t rank[INBOX_SLOTS];
@@ -702,7 +790,7 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
     int32_t ndK[INBOX_SLOTS];
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) {
-      const bool have = (uint32_t)k < cnt;
+      const bool have = (uint32_t)k < cnt && ((in[k].w0 >> 28) & 3u) == K_MSG;  // (a task's w0 holds an outbox slot, not a sender)
       iswK[k] = have ? isRow[(in[k].w0 & 0x0FFFFFFFu) >> 6] : 0ULL;
       auxK[k].chain = -1;
       auxK[k].cpos = 0;
@@ -713,6 +801,7 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
     for (int k = 0; k < INBOX_SLOTS; k++)
       ndK[k] = (auxK[k].chain >= 0 && auxK[k].cpos < 0) ? d.chains[auxK[k].chain].ndest : 0;
     long long bytes = 0;
+    uint32_t nMsg = 0;
     for (uint32_t r = 0; r < cnt; r++) {
       InboxEntry ev = in[0];
       uint64_t isw = iswK[0];
@@ -726,6 +815,8 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
           aux0 = auxK[k];
           nd = ndK[k];
         }
+      if (((ev.w0 >> 28) & 3u) != K_MSG) continue;  // (the node's doCycle task: k_gsf_docycle has run it)
+      nMsg++;
       const int32_t from = (int32_t)(ev.w0 & 0x0FFFFFFFu);
       const uint32_t msg = ev.w2, payload = ev.w3;
       const int l = (int)(msg & 31u);
@@ -798,14 +889,16 @@ __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ 
         isRow[from >> 6] = isw | (1ULL << (from & 63));
 #pragma unroll
         for (int k = 0; k < INBOX_SLOTS; k++)  // (a later event of this visit whose sender shares the word: it was loaded before this store)
-          if ((int32_t)((in[k].w0 & 0x0FFFFFFFu) >> 6) == (from >> 6)) iswK[k] |= 1ULL << (from & 63);
+          if (((in[k].w0 >> 28) & 3u) == K_MSG && (int32_t)((in[k].w0 & 0x0FFFFFFFu) >> 6) == (from >> 6)) iswK[k] |= 1ULL << (from & 63);
       }
       len += need;
     }
-    s.tvLen[node] = len;
-    s.sigQueueSize[node] = len;
-    atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)cnt);
-    atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bytes);
+    if (nMsg) {
+      s.tvLen[node] = len;
+      s.sigQueueSize[node] = len;
+      atomicAdd((unsigned long long*)&d.nodes.msgReceived[node], (unsigned long long)nMsg);
+      atomicAdd((unsigned long long*)&d.nodes.bytesReceived[node], (unsigned long long)bytes);
+    }
   }
 }
 
