@@ -2439,6 +2439,8 @@ struct HandelHost : ProtoHost {
     st.updCount = e.dalloc<uint32_t>(1);
     st.itemsTrail = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.trailCount = e.dalloc<uint32_t>(1);
+    st.itemsTrail2 = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
+    st.trail2Count = e.dalloc<uint32_t>(1);
     st.itemsDis = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.disCount = e.dalloc<uint32_t>(1);
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
@@ -2829,25 +2831,28 @@ struct HandelHost : ProtoHost {
       case 5: hipLaunchKernelGGL(k_handel_update<5>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
       default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
-    // the deliveries behind a wide update that was its node's first event, one lane per node (after the update); then every
-    // wide payload the two lane kernels delivered, one wavefront per copy
+    // the deliveries behind a wide update that was its node's first event, one lane per node (after the update)
     if (st.updTrail && !st.atk)
-      hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2", 512), g.R), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2", 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
     const dim3 grid(node_grid(g.R), g.R);
     // In a ms whose phase no member's dissemination task has (19 of 20 with a synchronised start) the lean dissemination kernel
     // would find an empty list: not launched (6 us each at 24 copies). k_handel_wave is told, and stops the run loudly should
     // the list not be empty after all.
     const bool mayDissem = g.periodic_may_fire(H_TASK_DISSEMINATION);
     const int disSkipped = st.disTier && !st.atk && !mayDissem;
-    if (st.disTier && !st.atk && mayDissem) {  // nodes whose first event is their dissemination (appends the rest of their visit to the wave list)
+    if (st.disTier && !st.atk && mayDissem) {  // nodes whose first event is their dissemination: that event
       switch (wavesDissem) {
         case 4: hipLaunchKernelGGL(k_handel_dissem<4>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
         case 5: hipLaunchKernelGGL(k_handel_dissem<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
         case 6: hipLaunchKernelGGL(k_handel_dissem<6>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
         default: hipLaunchKernelGGL(k_handel_dissem<8>, grid, dim3(256), 0, g.stream, g.tab, stab);
       }
+      // ... and the plain deliveries behind it, one lane per node (the others' remaining events are visits of k_handel_wave)
+      if (st.updTrail)
+        hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2B", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
+    // every wide payload the lane kernels delivered, one wavefront per copy (behind the dissemination: it reads no queue slot)
+    hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     if (st.atk) {
       hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab, 0);
       return;

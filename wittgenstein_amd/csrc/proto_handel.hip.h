@@ -151,6 +151,10 @@ struct HandelState {
   // handed the whole visit to k_handel_wave instead}
   GP<U4> itemsTrail;                      // [N]
   GP<uint32_t> trailCount;                // [1] (reset with jobCount)
+  // ... and behind a dissemination that was the node's first event (k_handel_dissem applies the task, a second launch of
+  // k_handel_lane2 the deliveries — in the ms in which every node disseminates a quarter of the nodes have some)
+  GP<U4> itemsTrail2;                     // [N]
+  GP<uint32_t> trail2Count;               // [1] (reset with jobCount)
   // nodes whose FIRST event of the ms is their dissemination task: {node, vflags << 8 | events, event, its inbox word 0},
   // applied by k_handel_dissem one wavefront each (the lean kernel of the millisecond in which every node disseminates);
   // the node's later events follow in k_handel_wave (skip = 1)
@@ -1233,10 +1237,29 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     }
     if (nUpd > 1) mine = false;
     updFirst = updFirst && have && plainBehind && nUpd == 1 && cnt <= (uint32_t)INBOX_SLOTS && !s.atk && !disFirst;
+    // the dissemination first and only plain deliveries behind it: those are a lane's (k_handel_lane2's second launch, behind k_handel_dissem)
+    const bool disTrail = disFirst && cnt > 1u && plainBehind && nUpd == 0 && s.updTrail && !s.atk;
+    {
+      const uint64_t tm = __ballot(disTrail);
+      if (tm) {
+        uint32_t tb = 0;
+        const int leader = __ffsll((unsigned long long)tm) - 1;
+        if (lane == leader) tb = atomicAdd(F(s.trail2Count + 0), (uint32_t)__popcll(tm));
+        tb = lane_bcast(tb, leader);
+        if (disTrail) {
+          U4 q;
+          q.x = (uint32_t)node;
+          q.y = (vflags << 8) | cnt;
+          q.z = E[0].e;  // (the dissemination: not this list's)
+          q.w = 0;
+          gst((U4 WG_G*)s.itemsTrail2 + (tb + __popcll(tm & lanes_lt())), q);
+        }
+      }
+    }
     {  // the rest goes to the wave-per-node kernel: one atomic per wavefront
       // (a node whose first event k_handel_dissem applies: the rest of its events, if any, as a visit that skips the first —
       // listed here, with this wavefront's one atomic, not by k_handel_dissem with one atomic per node on the same word)
-      const bool toB = have && !mine && !updFirst && (!disFirst || cnt > 1u);
+      const bool toB = have && !mine && !updFirst && !disTrail && (!disFirst || cnt > 1u);
       const uint64_t m = __ballot(toB);
       if (m) {
         uint32_t bb = 0;
@@ -1670,11 +1693,13 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
 // The SendSigs deliveries BEHIND a wide update that was the node's first event: one LANE per such node, after
 // k_handel_update applied the update (it reads the header as that kernel left it: doneAt, the queue mask). The same
 // h_lane_message as k_handel_lane; wide payloads become jobs of k_handel_copy, which runs next.
-__global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+__global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab, int behindDissem) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
   const int lane = WG_LANE;
-  const uint32_t nItems = *s.trailCount;
+  // (behindDissem: the list of the nodes whose first event was their dissemination, launched behind k_handel_dissem)
+  const U4 WG_G* items = behindDissem ? (const U4 WG_G*)s.itemsTrail2 : (const U4 WG_G*)s.itemsTrail;
+  const uint32_t nItems = behindDissem ? *s.trail2Count : *s.trailCount;
   const int32_t t = d.g->now;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t a0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; a0 < nItems; a0 += stride) {
@@ -1682,7 +1707,7 @@ __global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restric
     U4 it;
     it.x = it.y = it.z = 0;
     it.w = 1u;
-    if (a < nItems) it = gld((const U4 WG_G*)s.itemsTrail + a);
+    if (a < nItems) it = gld(items + a);
     const bool have = a < nItems && it.w == 0u;
     const int32_t node = (int32_t)it.x;
     const uint32_t cnt = have ? (it.y & 0xFFu) : 0u, vflags = it.y >> 8, eUpd = it.z;
@@ -2011,6 +2036,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     *s.updCount = 0;
     *s.disCount = 0;
     *s.trailCount = 0;
+    *s.trail2Count = 0;
   }
   for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
