@@ -279,7 +279,6 @@ def test_sanfermin_resident_fixed_latency():
 def test_casper_resident():  # P/CasperIMD.java resident on the device vs oracle/casper.hpp (two blocks, one WF far task)
     # (block construction 100 ms + a fixed latency keep the bucket ring at 256 ms: the emulator pays per simulated ms)
     tcr.lockstep((2, False, 2, 6, 100, 1), seed=5, chunk=1500, chunks=18, nl="NetworkFixedLatency(20)")
-    tcr.test_random_on_ties_is_refused_on_a_sharded_engine()
 
 
 def test_casper_resident_random_on_ties():  # k_casper_mark / k_casper_seq: ties that draw, vs the oracle after every chunk

@@ -300,8 +300,18 @@ struct LatencyModel {
   int32_t nCities;
 };
 
+// what a send needs of its two ends — position, extra latency, stopped, partition — in ONE 16-byte record per node (a
+// copy of the arrays below, rebuilt by the host whenever one of them changes): five look-ups per destination were what
+// k_resolve's 8 M records cost in the ms in which every node sends
+struct NodeGeo {
+  int16_t x, y;
+  int32_t extraLatency;
+  uint8_t down, part;
+  uint8_t pad[6];
+};
 struct NodeArrays {
   int32_t n;
+  GP<NodeGeo> geo;
   GP<int16_t> x;
   GP<int16_t> y;
   GP<int32_t> extraLatency;

@@ -441,6 +441,27 @@ void Engine::rebuild_partitions() {
   std::vector<uint8_t> part(hx.size());
   for (size_t i = 0; i < hx.size(); i++) part[i] = (uint8_t)part_of(hx[i]);
   WG_HIP(hipMemcpy(dev.nodes.part, part.data(), part.size(), hipMemcpyHostToDevice));
+  geoStale = true;
+  upload_geo();
+}
+
+// NodeArrays::geo from the host's copies of x / y / extraLatency / down and the cuts
+void Engine::upload_geo() {
+  if (!geoStale || !allocated) return;
+  std::vector<NodeGeo> g(hx.size());
+  for (size_t i = 0; i < hx.size(); i++) {
+    NodeGeo q;
+    memset(&q, 0, sizeof(q));
+    q.x = (int16_t)hx[i];
+    q.y = (int16_t)hy[i];
+    q.extraLatency = hextra[i];
+    q.down = hdown[i] ? 1 : 0;
+    q.part = (uint8_t)part_of(hx[i]);
+    g[i] = q;
+  }
+  WG_HIP(hipMemcpyAsync(dev.nodes.geo, g.data(), g.size() * sizeof(NodeGeo), hipMemcpyHostToDevice, stream));
+  WG_HIP(hipStreamSynchronize(stream));
+  geoStale = false;
 }
 
 void Engine::set_partitions(const int32_t* c, int32_t k) {
@@ -456,10 +477,13 @@ void Engine::set_node_down(int32_t id, bool down) {
   downDirty = true;  // uploaded as one array before the next launch (a stop()ped population is thousands of calls)
 }
 void Engine::upload_down() {
-  if (!downDirty || !allocated) return;
-  WG_HIP(hipMemcpyAsync(dev.nodes.down, hdown.data(), hdown.size(), hipMemcpyHostToDevice, stream));
-  WG_HIP(hipStreamSynchronize(stream));
-  downDirty = false;
+  if (downDirty && allocated) {
+    WG_HIP(hipMemcpyAsync(dev.nodes.down, hdown.data(), hdown.size(), hipMemcpyHostToDevice, stream));
+    WG_HIP(hipStreamSynchronize(stream));
+    downDirty = false;
+    geoStale = true;
+  }
+  upload_geo();
 }
 
 // the largest latency the current model can return for these nodes (sizes the bucket ring and the sendAll histograms)
@@ -539,6 +563,8 @@ void Engine::ensure_device() {
   WG_HIP(hipMemcpy(nd.y, y16.data(), n * 2, hipMemcpyHostToDevice));
   WG_HIP(hipMemcpy(nd.extraLatency, hextra.data(), n * 4, hipMemcpyHostToDevice));
   WG_HIP(hipMemcpy(nd.down, hdown.data(), n, hipMemcpyHostToDevice));
+  nd.geo = dalloc<NodeGeo>(n);
+  geoStale = true;  // (uploaded by upload_geo once `allocated` is set: rebuild_partitions / upload_down / self())
 
   dev.discardTime = discardTime;
   dev.horizon = (int32_t)D;

@@ -272,6 +272,8 @@ class Engine {
   std::vector<uint8_t> hdown, hbyz;
   bool downDirty = false;        // hdown changed since its last upload (set_node_down)
   void upload_down();
+  bool geoStale = false;         // NodeArrays::geo is behind x / y / extraLatency / down / the cuts
+  void upload_geo();
   std::vector<double> hspeed;
   std::vector<int32_t> cuts;
   // latency model (host tables mirrored on device)

@@ -665,11 +665,26 @@ __device__ __forceinline__ int32_t draw_next_int(const EngineDev& d, uint32_t dr
   return (int32_t)(int64_t)(s >> 16);
 }
 
+// a node's NodeGeo record as one 16-byte load
+struct GeoRegs {
+  int32_t x, y, extra;
+  uint32_t down, part;
+};
+__device__ __forceinline__ GeoRegs node_geo(const EngineDev& d, int32_t node) {
+  const U4 q = gld((const U4 WG_G*)(const NodeGeo WG_G*)d.nodes.geo + node);
+  GeoRegs g;
+  g.x = (int32_t)(int16_t)(q.x & 0xFFFFu);
+  g.y = (int32_t)(int16_t)(q.x >> 16);
+  g.extra = (int32_t)q.y;
+  g.down = q.z & 0xFFu;
+  g.part = (q.z >> 8) & 0xFFu;
+  return g;
+}
 __device__ __forceinline__ bool arrival_of_send(const EngineDev& d, int32_t from, int32_t to, int32_t sendTime,
                                                int32_t seed, int32_t& arrival) {
-  const NodeArrays& n = d.nodes;
-  if (n.part[from] != n.part[to] || n.down[from] || n.down[to]) return false;
-  int32_t nt = dev_latency(d, from, to, seed);
+  const GeoRegs f = node_geo(d, from), t = node_geo(d, to);  // (both ends in one round of loads)
+  if (f.part != t.part || f.down || t.down) return false;
+  int32_t nt = latency_of(d.lat, from, to, f.x, f.y, f.extra, t.x, t.y, t.extra, pseudo_delta(to, seed));
   if (nt >= d.discardTime) return false;
   arrival = sendTime + nt;
   return true;
@@ -722,18 +737,19 @@ __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& 
   bool ok[MULTI_LDS];
 #pragma unroll
   for (int j = 0; j < MULTI_LDS; j++) to_[j] = j < nd ? d.sdests[multi_idx(d, o, j)] : from;
-  const NodeArrays& na = d.nodes;
-  const uint8_t pf = na.part[from], df = na.down[from];
-  const int32_t xf = na.x[from], yf = na.y[from], ef = na.extraLatency[from];
-  uint8_t pt[MULTI_LDS], dt[MULTI_LDS];
+  const GeoRegs gf = node_geo(d, from);
+  const uint32_t pf = gf.part, df = gf.down;
+  const int32_t xf = gf.x, yf = gf.y, ef = gf.extra;
+  uint32_t pt[MULTI_LDS], dt[MULTI_LDS];
   int32_t xt[MULTI_LDS], yt[MULTI_LDS], et[MULTI_LDS];
 #pragma unroll
   for (int j = 0; j < MULTI_LDS; j++) {
-    pt[j] = na.part[to_[j]];
-    dt[j] = na.down[to_[j]];
-    xt[j] = na.x[to_[j]];
-    yt[j] = na.y[to_[j]];
-    et[j] = na.extraLatency[to_[j]];
+    const GeoRegs g = node_geo(d, to_[j]);
+    pt[j] = g.part;
+    dt[j] = g.down;
+    xt[j] = g.x;
+    yt[j] = g.y;
+    et[j] = g.extra;
   }
 #pragma unroll
   for (int j = 0; j < MULTI_LDS; j++) {  // arrival_of_send, with the loads above
