@@ -803,7 +803,7 @@ def main():
             traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, commit %s%s" % (
                 tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_deliver<GsfProto>" if gsf else "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave "
+        "bound": "hbm", "kernel": "k_gsf_docycle + k_gsf_lane + k_deliver_inbox<GsfProto> (the delivery pass, all inside the HIP-event bracket)" if gsf else "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave "
                                                               "(the delivery pass: one launch of each per simulated ms, all six inside the HIP-event bracket and "
                                                               "inside `traffic`)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
