@@ -3132,6 +3132,8 @@ struct GsfHost : ProtoHost {
     st.pendFrom = e.dalloc<int32_t>((size_t)N * G_PEND);
     st.runList = e.dalloc<uint32_t>(N);
     st.runCount = e.dalloc<uint32_t>(1);
+    st.runList2 = e.dalloc<uint32_t>(N);
+    st.runCount2 = e.dalloc<uint32_t>(1);
     st.candFlag = e.dalloc<uint8_t>(((size_t)N + 3) / 4 * 4);
     st.candPend = e.dalloc<uint8_t>(N);
     st.condList = e.dalloc<uint32_t>(N);
@@ -3178,7 +3180,13 @@ struct GsfHost : ProtoHost {
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      static const bool group = !(getenv("WG_GSF_A1_GROUP") && atoi(getenv("WG_GSF_A1_GROUP")) == 0);
+      if (group) {  // eight lanes per runner for the short lists; what is left over, one wavefront each
+        hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_GSF_A1G", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+        hipLaunchKernelGGL(k_gsf_cond_a1, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_GSF_A1", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
+      } else {
+        hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
+      }
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
@@ -3202,7 +3210,7 @@ struct GsfHost : ProtoHost {
   uint32_t shard_cond(Engine& e, const Group& g) override {
     const GsfState* stab = (const GsfState*)g.stab;
     hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab, 0);
     e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
     Engine::scan<GsfCondF>(g, stab);
     uint32_t nOut = 0;

@@ -54,6 +54,8 @@ struct GsfState {
   // conditional-task phase scratch
   GP<uint32_t> runList;                  // nodes whose checkSigs runs at this edge (unordered)
   GP<uint32_t> runCount;
+  GP<uint32_t> runList2;                 // ... those of them k_gsf_cond_a1g leaves to the wavefront-per-runner kernel
+  GP<uint32_t> runCount2;
   GP<uint8_t> candFlag;                  // [N] checkSigs found a best -> registers a task
   GP<uint8_t> candPend;                  // [N] its pend index
   GP<uint32_t> condList;                 // registering nodes in id order
@@ -504,9 +506,123 @@ __global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restric
   }
 }
 
+// checkSigs (:558-584) of the runners whose list holds at most eight entries — 3.9 on average (profiles/r16d) — none of
+// them a PARTIAL signature of a multi-word level: EIGHT LANES per runner, lane g = entry g; the level's three counts come
+// from memory per entry (no LDS image), maximum and compaction inside the group. One wavefront per runner (k_gsf_cond_a1)
+// ran its 64 lanes for four entries and its duration was one runner's chain of round trips; the runners this kernel cannot
+// take go to that kernel through runList2. Same statements, same order of the entries, same results.
+__global__ void __launch_bounds__(256) k_gsf_cond_a1g(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  const int lane = WG_LANE, g8 = lane & 7, gsh = lane & ~7;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nRun = *s.runCount;
+  for (uint32_t qb = wave * 8; qb < nRun; qb += nWaves * 8) {
+    const uint32_t q = qb + (uint32_t)(lane >> 3);
+    const bool have = q < nRun;
+    const int32_t node = have ? (int32_t)s.runList[q] : 0;
+    const int len = have ? s.tvLen[node] : 0;
+    bool ok = have && len <= 8;
+    const bool mine = ok && g8 < len;
+    uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
+    const uint64_t e = mine ? ent[g8] : 0ULL;
+    const int32_t from = g_ent_from(e);
+    const int l = mine ? g_ent_level(e) : 1;
+    const uint32_t kind = g_ent_kind(e), aux = g_ent_aux(e);
+    const int size = 1 << (l - 1);
+    const size_t li = (size_t)node * s.L + l;
+    const int cVl = mine ? s.cV[li] : 0, cIVl = mine ? s.cIV[li] : 0, cUl = mine ? s.cU[li] : 0;
+    const Lv v = sib_view(node, l);
+    const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
+    const uint64_t WG_G* ivr = s.IV + (size_t)node * s.W;
+    const bool open = mine && cVl < size;  // :490-492
+    // a PARTIAL entry of a multi-word level: the whole runner is the wavefront kernel's
+    const uint32_t wideG = (uint32_t)(__ballot(open && kind == GK_PARTIAL && v.nw > 1) >> gsh) & 0xFFu;
+    if (wideG) ok = false;
+    {  // the runners left over: one atomic per wavefront
+      const bool left = have && !ok && g8 == 0;
+      const uint64_t lm = __ballot(left);
+      if (lm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((unsigned long long)lm) - 1;
+        if (lane == leader) base = atomicAdd(F(s.runCount2 + 0), (uint32_t)__popcll(lm));
+        base = __shfl(base, leader, 64);
+        if (left) s.runList2[base + __popcll(lm & lanes_lt())] = (uint32_t)node;
+      }
+    }
+    int ns = 0;
+    if (ok && open) {
+      if (kind == GK_FULL) {
+        ns = 1000000 - l * 10;  // completes the level
+      } else if (kind == GK_OVER) {
+        ns = 100000 - l * 100 + ((1 << aux) - cVl);  // 2^j ids, a replace or a first set
+      } else if (kind == GK_INDIV) {
+        const uint64_t bit = 1ULL << (from & 63);
+        const bool vHas = (vr[from >> 6] & bit) != 0, ivHas = (ivr[from >> 6] & bit) != 0;
+        int newTotal, added;
+        if (cVl == 0) {
+          newTotal = 1;
+          added = 1;
+        } else if (vHas) {
+          newTotal = cIVl + (ivHas ? 0 : 1);
+          added = newTotal - cVl;
+        } else {
+          newTotal = cUl + (ivHas ? 0 : 1);
+          added = newTotal - cVl;
+        }
+        ns = g_score(l, size, newTotal, added, true, ivHas);
+      } else {  // PARTIAL, one word
+        const uint64_t sg = *GsfProto::sig_ptr(s, node, (int)aux) & v.mask;
+        const uint64_t vw = vr[v.bw] & v.mask, iw = ivr[v.bw] & v.mask;
+        const int cs = __popcll(sg);
+        int newTotal;
+        if (cVl == 0)
+          newTotal = cs;
+        else if (sg & vw)
+          newTotal = __popcll(sg | iw);
+        else
+          newTotal = __popcll(sg | iw | vw);
+        ns = g_score(l, size, newTotal, cVl == 0 ? cs : newTotal - cVl, cs == 1, (sg & iw) != 0);
+      }
+    }
+    // `ns > score` from zero on: the first entry reaching the maximum wins (:565-570)
+    const int mx = group8_max_i32(ns);
+    const uint32_t bm = (uint32_t)(__ballot(ok && mine && mx > 0 && ns == mx) >> gsh) & 0xFFu;
+    const int bestIdx = bm ? __ffs(bm) - 1 : -1;
+    const uint64_t bestEnt = shfl64(e, gsh + (bestIdx < 0 ? 0 : bestIdx));
+    // rewrite the list: zeros are removed (:571-573), the best leaves it (:577)
+    const bool keep = ok && mine && ns != 0 && g8 != bestIdx;
+    const uint32_t km = (uint32_t)(__ballot(keep) >> gsh) & 0xFFu;
+    if (ok && mine && ns == 0 && kind == GK_PARTIAL)  // its payload slot is free again
+      atomicAnd((unsigned long long*)F(s.tvUsed + (size_t)node * (s.Q / 64) + (aux >> 6)), ~(1ULL << (aux & 63)));
+    if (keep) ent[__popc(km & ((1u << g8) - 1u))] = e;  // (every lane of the group read its entry above)
+    const int newLen = __popc(km);
+    if (ok && g8 == 0) {
+      s.tvLen[node] = newLen;
+      if (bestIdx >= 0) {
+        // sigChecked++; sigQueueSize = toVerify.size(); registerTask(updateVerifiedSignatures(best), ...) :576-583.
+        // The task's closure (tBest) is the pend entry; k_gsf_cond_a2 emits the task record in node order.
+        const U4 pd = gld((const U4 WG_G*)(s.pend + (size_t)node * G_PEND));
+        int pe = !(pd.x & 0x80000000u) ? 0 : !(pd.y & 0x80000000u) ? 1 : !(pd.z & 0x80000000u) ? 2 : !(pd.w & 0x80000000u) ? 3 : -1;
+        if (pe < 0) {
+          set_err(d.g, ERR_PENDING);
+          pe = 0;
+        }
+        s.pend[(size_t)node * G_PEND + pe] = 0x80000000u | (g_ent_kind(bestEnt) << 29) | ((uint32_t)g_ent_level(bestEnt) << 24) | g_ent_aux(bestEnt);
+        s.pendFrom[(size_t)node * G_PEND + pe] = g_ent_from(bestEnt);
+        s.candPend[node] = (uint8_t)pe;
+        s.sigChecked[node]++;
+        s.sigQueueSize[node] = newLen;
+        s.candFlag[node] = 1;
+      }
+    }
+  }
+}
+
 // checkSigs (:558-584) of every runner: score every toVerify entry (evaluateSig :482-535), drop the zeros,
 // take the FIRST entry with the greatest score out of the list and park it in the pend table.
-__global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+__global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int second) {
   WG_ENGINE(tab);
   const GsfState& s = stab[blockIdx.y];
   __shared__ GLevels shLevels[4];
@@ -514,11 +630,16 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nRun = *s.runCount;
+  // (second: the runners k_gsf_cond_a1g left — a list of more than eight entries, a PARTIAL entry of a multi-word level)
+  const uint32_t nRun = second ? *s.runCount2 : *s.runCount;
+  const uint32_t WG_G* runList = second ? (const uint32_t WG_G*)s.runList2 : (const uint32_t WG_G*)s.runList;
   GLevels* ls = &shLevels[w];
   for (uint32_t q = wave; q < nRun; q += nWaves) {
-    const int32_t node = (int32_t)s.runList[q];
+    const int32_t node = (int32_t)runList[q];
+    KPROF_DECL;
+    KPROF_COUNT(d.g, 20);
     GsfProto::load_levels(s, node, ls);
+    KPROF_MARK(d.g, 16);  // checkSigs: the level scalars
     const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
     const uint64_t WG_G* ivr = s.IV + (size_t)node * s.W;
     uint64_t WG_G* ent = s.tvEnt + (size_t)node * s.Q;
@@ -574,6 +695,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
         }
       }
       // PARTIAL entries of multi-word levels: the whole wavefront streams the block, one entry at a time
+      KPROF_ADD(d.g, 22, __popcll(__ballot(wide)));
       for (uint64_t m = __ballot(wide); m; m &= m - 1) {
         const int src = __ffsll((unsigned long long)m) - 1;
         const int el = __shfl(l, src, 64);
@@ -606,6 +728,8 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
       }
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_ADD(d.g, 21, len);
+    KPROF_MARK(d.g, 17);  // checkSigs: the entries' scores
     // rewrite the list: zeros are removed (:571-573), the best leaves it (:577)
     int newLen = 0;
     for (int base = 0; base < len; base += 64) {
@@ -624,6 +748,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
       newLen += __popcll(km);
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 18);  // checkSigs: the list rewritten
     for (int k = lane; k < s.Q / 64; k += 64) s.tvUsed[(size_t)node * (s.Q / 64) + k] = ls->used[k];
     if (lane == 0) {
       s.tvLen[node] = newLen;
@@ -650,6 +775,7 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict
       }
     }
     __builtin_amdgcn_wave_barrier();
+    KPROF_MARK(d.g, 19);  // checkSigs: the chosen entry parked (pend table, counters)
   }
 }
 
@@ -930,7 +1056,10 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict
   const int32_t t = d.g->now;
   const uint32_t D = (uint32_t)d.horizon;
   const uint32_t stride = gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *s.runCount = 0;  // for the next edge's k_gsf_cond_pre
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the next edge's k_gsf_cond_pre / k_gsf_cond_a1g
+    *s.runCount = 0;
+    *s.runCount2 = 0;
+  }
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
     const uint32_t j = j0 + threadIdx.x;
     uint32_t histKey = 0xFFFFFFFFu;
