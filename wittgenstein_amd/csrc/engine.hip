@@ -2461,6 +2461,8 @@ struct HandelHost : ProtoHost {
     st.itemCount = e.dalloc<uint32_t>(2);
     st.jobs = e.dalloc<CopyJob>(e.dev.maxEvents, false, Engine::AC_SCRATCH);
     st.jobCount = e.dalloc<uint32_t>(1);
+    st.jobsSmall = e.dalloc<CopyJob>(e.dev.maxEvents, false, Engine::AC_SCRATCH);
+    st.jobSmallCount = e.dalloc<uint32_t>(1);
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
     st.itemsTrail = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);

@@ -162,6 +162,9 @@ struct HandelState {
   GP<uint32_t> disCount;                  // [1] (reset with jobCount)
   int32_t disTier;                        // 0: off (WG_DIS_TIER=0): those nodes are visits of k_handel_wave as before
   GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
+  // ... the payloads of at most H_JOB_SMALL words apart: k_handel_copy moves eight of them per wavefront
+  GP<CopyJob> jobsSmall;                  // [maxEvents]
+  GP<uint32_t> jobSmallCount;             // [1] (reset with jobCount)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> cleanMask;                 // [N] ... of which: clean levels, answered from their summary by k_handel_cond_pre (no item)
   // sharded engines: how many levels of every node have a candidate at this edge, one BYTE per node (four nodes an int32
@@ -293,6 +296,28 @@ struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_SPAR
   uint32_t sc[HH_LV];
   U4 orig[(HH_LV + 8 * 32) / 4];  // the record as it was loaded, 16-byte pieces: store_levels writes back what differs
 };
+constexpr int H_JOB_SMALL = 16;  // words: a payload of a level of up to 1024 ids
+// a wide payload delivered by a lane becomes a job of k_handel_copy, listed by size class — one atomic per wavefront and class
+// (every lane of the wavefront calls it; job.nw == 0: none)
+__device__ __forceinline__ void h_emit_job(const HandelState& s, const CopyJob& job) {
+  const int lane = WG_LANE;
+  const bool small = job.nw > 0 && job.nw <= H_JOB_SMALL, large = job.nw > H_JOB_SMALL;
+  const uint64_t ms = __ballot(small), ml = __ballot(large);
+  if (ms) {
+    uint32_t jb = 0;
+    const int leader = __ffsll((unsigned long long)ms) - 1;
+    if (lane == leader) jb = atomicAdd(F(s.jobSmallCount + 0), (uint32_t)__popcll(ms));
+    jb = lane_bcast(jb, leader);
+    if (small) gst(s.jobsSmall + (jb + __popcll(ms & lanes_lt())), job);
+  }
+  if (ml) {
+    uint32_t jb = 0;
+    const int leader = __ffsll((unsigned long long)ml) - 1;
+    if (lane == leader) jb = atomicAdd(F(s.jobCount + 0), (uint32_t)__popcll(ml));
+    jb = lane_bcast(jb, leader);
+    if (large) gst(s.jobs + (jb + __popcll(ml & lanes_lt())), job);
+  }
+}
 constexpr uint32_t H_REF_RING = 0x80000000u;  // payload ref flag: engine payload ring (fast-path sends)
 constexpr uint32_t H_REF_ONES = 0xFFFFFFFFu;  // payload ref: the all-ones block (fast-path sends of a sharded engine)
 __device__ __forceinline__ const uint64_t WG_G* h_payload(const EngineDev& d, const HandelState& s, uint32_t payload) {
@@ -1351,15 +1376,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
         }
         if (!deferred) gst(d.evRes + e, res);
       }
-      // a wide payload: a job of k_handel_copy (one atomic per wavefront and event slot)
-      const uint64_t jm = __ballot(job.nw > 0);
-      if (jm) {
-        uint32_t jb = 0;
-        const int leader = __ffsll((unsigned long long)jm) - 1;
-        if (lane == leader) jb = atomicAdd(F(s.jobCount + 0), (uint32_t)__popcll(jm));
-        jb = lane_bcast(jb, leader);
-        if (job.nw > 0) gst(s.jobs + (jb + __popcll(jm & lanes_lt())), job);
-      }
+      h_emit_job(s, job);  // a wide payload: a job of k_handel_copy
     }
     if (mine) {
       uint32_t WG_G* hdr = h_hdr(s, node);
@@ -1763,14 +1780,7 @@ __global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restric
         }
         gst(d.evRes + E[k].e, res);
       }
-      const uint64_t jm = __ballot(job.nw > 0);
-      if (jm) {
-        uint32_t jb = 0;
-        const int leader = __ffsll((unsigned long long)jm) - 1;
-        if (lane == leader) jb = atomicAdd(F(s.jobCount + 0), (uint32_t)__popcll(jm));
-        jb = lane_bcast(jb, leader);
-        if (job.nw > 0) gst(s.jobs + (jb + __popcll(jm & lanes_lt())), job);
-      }
+      h_emit_job(s, job);
     }
     if (have) {  // (sigQueueSize / msgFiltered: k_handel_update does not write them; the queue mask it may have cleared a bit of)
       uint32_t WG_G* hdr = h_hdr(s, node);
@@ -1796,6 +1806,22 @@ __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict
   const int lane = WG_LANE;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  // the small payloads (<= H_JOB_SMALL words: levels of up to 1024 ids — half of the jobs): EIGHT LANES per job, two words a
+  // lane, eight jobs per wavefront. (One wavefront per job left 56 of its 64 lanes idle for them, and the kernel's
+  // duration is jobs / resident wavefronts x a round trip.)
+  const uint32_t nSmall = *s.jobSmallCount;
+  for (uint32_t qb = wave * 8; qb < nSmall; qb += nWaves * 8) {
+    const uint32_t q = qb + (uint32_t)(lane >> 3);
+    if (q < nSmall) {
+      const CopyJob job = gld(s.jobsSmall + q);
+      const int j = 2 * (lane & 7);
+      if (j < job.nw) {  // (nw is a power of two >= 2)
+        const uint64_t a = job.src[j], b = job.src[j + 1];
+        job.dst[j] = a;
+        job.dst[j + 1] = b;
+      }
+    }
+  }
   const uint32_t nJobs = *s.jobCount;
   if (wave >= nJobs) return;
   CopyJob cur = gld(s.jobs + wave);
@@ -2033,6 +2059,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
   __shared__ uint32_t shTot[2][4], shBase[2];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the delivery pass's copy jobs and wide updates have been done)
     *s.jobCount = 0;
+    *s.jobSmallCount = 0;
     *s.updCount = 0;
     *s.disCount = 0;
     *s.trailCount = 0;
