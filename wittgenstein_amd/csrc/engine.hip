@@ -2463,6 +2463,7 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.jobsSmall = e.dalloc<CopyJob>(e.dev.maxEvents, false, Engine::AC_SCRATCH);
     st.jobSmallCount = e.dalloc<uint32_t>(1);
+    st.jobSmallMax = getenv("WG_JOB_SMALL") && atoi(getenv("WG_JOB_SMALL")) >= 0 ? atoi(getenv("WG_JOB_SMALL")) : H_JOB_SMALL;
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
     st.itemsTrail = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);

@@ -165,6 +165,7 @@ struct HandelState {
   // ... the payloads of at most H_JOB_SMALL words apart: k_handel_copy moves eight of them per wavefront
   GP<CopyJob> jobsSmall;                  // [maxEvents]
   GP<uint32_t> jobSmallCount;             // [1] (reset with jobCount)
+  int32_t jobSmallMax;                    // words (H_JOB_SMALL; WG_JOB_SMALL)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> cleanMask;                 // [N] ... of which: clean levels, answered from their summary by k_handel_cond_pre (no item)
   // sharded engines: how many levels of every node have a candidate at this edge, one BYTE per node (four nodes an int32
@@ -296,12 +297,12 @@ struct LevelScalars {  // LDS image of a node header: the planes HP_POS..HP_SPAR
   uint32_t sc[HH_LV];
   U4 orig[(HH_LV + 8 * 32) / 4];  // the record as it was loaded, 16-byte pieces: store_levels writes back what differs
 };
-constexpr int H_JOB_SMALL = 16;  // words: a payload of a level of up to 1024 ids
+constexpr int H_JOB_SMALL = 64;  // words: a payload of a level of up to 4096 ids (16 / 32 / 64 / 128 measured: profiles/r16i)
 // a wide payload delivered by a lane becomes a job of k_handel_copy, listed by size class — one atomic per wavefront and class
 // (every lane of the wavefront calls it; job.nw == 0: none)
 __device__ __forceinline__ void h_emit_job(const HandelState& s, const CopyJob& job) {
   const int lane = WG_LANE;
-  const bool small = job.nw > 0 && job.nw <= H_JOB_SMALL, large = job.nw > H_JOB_SMALL;
+  const bool small = job.nw > 0 && job.nw <= s.jobSmallMax, large = job.nw > s.jobSmallMax;
   const uint64_t ms = __ballot(small), ml = __ballot(large);
   if (ms) {
     uint32_t jb = 0;
@@ -1806,16 +1807,15 @@ __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict
   const int lane = WG_LANE;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  // the small payloads (<= H_JOB_SMALL words: levels of up to 1024 ids — half of the jobs): EIGHT LANES per job, two words a
-  // lane, eight jobs per wavefront. (One wavefront per job left 56 of its 64 lanes idle for them, and the kernel's
+  // the small payloads (<= H_JOB_SMALL words: levels of up to 4096 ids — most of the jobs): EIGHT LANES per job, two words a
+  // lane and round, eight jobs per wavefront. (One wavefront per job left most of its lanes idle for them, and the kernel's
   // duration is jobs / resident wavefronts x a round trip.)
   const uint32_t nSmall = *s.jobSmallCount;
   for (uint32_t qb = wave * 8; qb < nSmall; qb += nWaves * 8) {
     const uint32_t q = qb + (uint32_t)(lane >> 3);
     if (q < nSmall) {
       const CopyJob job = gld(s.jobsSmall + q);
-      const int j = 2 * (lane & 7);
-      if (j < job.nw) {  // (nw is a power of two >= 2)
+      for (int j = 2 * (lane & 7); j < job.nw; j += 16) {  // (nw is a power of two >= 2)
         const uint64_t a = job.src[j], b = job.src[j + 1];
         job.dst[j] = a;
         job.dst[j + 1] = b;
