@@ -3230,7 +3230,9 @@ struct GsfHost : ProtoHost {
     static const bool laneTier = !(getenv("WG_GSF_LANE") && atoi(getenv("WG_GSF_LANE")) == 0);
     static const int cycleTier = getenv("WG_GSF_DOCYCLE") ? atoi(getenv("WG_GSF_DOCYCLE")) : 8;  // wavefronts per SIMD of the doCycle kernel; 0: off
     const bool cycleRan = eng.dev.inbox && laneTier && cycleTier && g.periodic_may_fire(G_TASK_DOCYCLE);
-    if (cycleRan) {
+    if (cycleRan && st.L <= 16 && cycleTier != 6) {  // sixteen lanes per node, four nodes per wavefront
+      hipLaunchKernelGGL(k_gsf_docycle16, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
+    } else if (cycleRan) {
       if (cycleTier == 8)
         hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
       else

@@ -874,6 +874,117 @@ __global__ void __launch_bounds__(256, WPE) k_gsf_docycle(const EngineDev* __res
   }
 }
 
+// ... the same with SIXTEEN LANES per node, four nodes per wavefront (networks of up to 32 768 nodes: a level per lane).
+// The task is a level per lane (twelve of them at 4096 nodes): one wavefront per node left three quarters of its lanes idle,
+// and the kernel's duration is nodes / resident wavefronts x the task's chain of round trips. No LDS image: lane l reads
+// level l's three scalars itself; first incomplete level, ranks of the sends and counts are 16-bit pieces of the ballots.
+__global__ void __launch_bounds__(256) k_gsf_docycle16(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
+  WG_ENGINE(tab);
+  const GsfState& s = stab[blockIdx.y];
+  const int lane = WG_LANE, l16 = lane & 15, gsh = lane & ~15;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nActive = d.g->nActive;
+  const int32_t t = d.g->now;
+  if (d.nparts) return;
+  for (uint32_t a0 = wave * 4; a0 < nActive; a0 += nWaves * 4) {
+    const uint32_t a = a0 + (uint32_t)(lane >> 4);
+    const bool have = a < nActive;
+    const int32_t node = have ? (int32_t)d.active[a] : 0;
+    const uint32_t cnt = have ? d.icnt[node] : 0u;
+    InboxEntry line[INBOX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < INBOX_SLOTS; k++) {
+      line[k].e = 0;
+      line[k].w0 = line[k].w2 = line[k].w3 = 0;
+      if (have && cnt != 0 && cnt <= (uint32_t)INBOX_SLOTS) line[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+    }
+    int cycleAt = -1;
+    const bool ok = have && gsf_split_ok(d, node, cnt, line, true, cycleAt) && cycleAt >= 0;
+    InboxEntry in = line[0];
+#pragma unroll
+    for (int k = 1; k < INBOX_SLOTS; k++)
+      if (k == cycleAt) in = line[k];
+    // (the inbox count stays: k_gsf_lane, which runs behind this kernel, delivers the node's messages if it has any and zeroes it)
+    const bool lv = ok && l16 >= 1 && l16 < s.L;
+    const size_t li = (size_t)node * s.L + l16;
+    int pos = 0, rem = 0, cvl = 0;
+    if (lv) {
+      pos = s.pos[li];
+      rem = s.rem[li];
+      cvl = s.cV[li];
+    }
+    const int size = lv ? 1 << (l16 - 1) : 0;
+    const uint32_t incM = (uint32_t)(__ballot(lv && cvl != size) >> gsh) & 0xFFFFu;
+    const int k = incM ? __ffs(incM) - 1 : s.L;  // first incomplete level (levels below it form getLastFinishedLevel :194-211)
+    const bool act = lv && rem != 0 && (t >= l16 * s.p.timeoutPerLevelMs || k >= l16);  // hasStarted :294-315
+    int32_t dest = 0;
+    if (act) dest = s.peers[(size_t)node * (s.N - 1) + (size - 1) + pos];  // getRemainingPeers(1)
+    const uint32_t actM = (uint32_t)(__ballot(act) >> gsh) & 0xFFFFu;
+    const uint32_t partM = (uint32_t)(__ballot(act && k < l16) >> gsh) & 0xFFFFu;  // PARTIAL: the verified bits of the levels below l
+    const uint32_t win = ((uint32_t)t / (uint32_t)s.p.periodDurationMs) % s.snapNb;
+    const uint32_t refBase = (win * (uint32_t)s.N + (uint32_t)node) * s.snapStride;
+    if (partM) {
+      const uint64_t WG_G* vr = s.V + (size_t)node * s.W;
+      for (uint32_t q = (uint32_t)l16; q < s.snapStride; q += 16) {
+        int l = 1;  // the level whose words hold flat word q (lvlOff is increasing from level 1 on)
+        for (int i = 2; i < s.L; i++)
+          if (s.lvlOff[i] <= q) l = i;
+        if ((partM >> l) & 1u) {
+          const Lv v = own_view(node, l);
+          s.snap[refBase + q] = vr[v.bw + (int)(q - s.lvlOff[l])] & v.mask;
+        }
+      }
+    }
+    // the records, in level order: the sends (as Ctx::send_many writes them), then the task's re-arm (PeriodicTask.action,
+    // C/messages/PeriodicTask.java:39-47, as deliver_event's Ctx::put)
+    const uint32_t outBase = in.w0 & 0x0FFFFFFFu, outCap = d.boundTask[G_TASK_DOCYCLE] + 1u;
+    const int n = __popc(actM), rank = __popc(actM & ((1u << l16) - 1u));
+    if (act || (ok && l16 == 0)) {
+      const uint32_t idx = act ? (uint32_t)rank : (uint32_t)n;
+      if (idx < outCap && outBase + idx < d.maxOut) {
+        Out o;
+        if (act) {
+          o.kindfrom = (O_SEND << 28) | (uint32_t)node;
+          o.to = dest;
+          o.a = GsfProto::msg_word(l16, k, cvl == size);
+          o.b = k < l16 ? refBase + s.lvlOff[l16] : 0u;
+          o.t = t + 1;
+          o.drawsub = (uint32_t)rank;
+        } else {
+          o.kindfrom = (O_PERIODIC << 28) | (uint32_t)node;
+          o.to = node;
+          o.a = in.w2;
+          o.b = in.w3;
+          o.t = t + (int32_t)in.w3;
+          o.drawsub = (uint32_t)n;
+        }
+        o.destOff = 0;
+        o.pad = 0;
+        d.outTmp[outBase + idx] = o;
+      } else {
+        set_err(d.g, ERR_OUTBOX);
+      }
+    }
+    if (act) {
+      s.pos[li] = pos + 1 >= size ? 0 : pos + 1;
+      s.rem[li] = rem - 1;
+    }
+    if (ok && l16 == 0) {
+      EvRes res;
+      res.nrec = (uint32_t)(n + 1) | EV_TASK_RUN | (partM ? ev_snap_code(s.snapStride) << EV_SNAP_SHIFT : 0u);
+      res.ndraw = (uint32_t)n;
+      gst(d.evRes + in.e, res);
+      if (n) {
+        long long bytes = 0;
+        for (uint32_t m = actM; m; m &= m - 1) bytes += g_msg_size(__ffs(m) - 1);
+        atomicAdd((unsigned long long*)&d.nodes.msgSent[node], (unsigned long long)n);
+        atomicAdd((unsigned long long*)&d.nodes.bytesSent[node], (unsigned long long)bytes);
+      }
+    }
+  }
+}
+
 // The delivery pass, lane tier: one LANE per node whose events of the ms are all plain SendSigs deliveries — onNewSig
 // (:538-556) is an append to the node's toVerify list, one bit of individualSignatures and, for a PARTIAL payload, a slot of
 // the node's payload store: four or five lines of the node, where a wavefront's visit loads the node's whole level state
