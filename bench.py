@@ -850,8 +850,11 @@ def main():
         except Exception as x:  # the Handel line stands on its own
             out["second_workload"] = {"error": "%s: %s" % (type(x).__name__, x)}
         # the north star's TARGET SIZE (Handel 65 536 nodes, same ratios) and BASELINE configs[1]
-        # (GSFSignature 4096 nodes), each as its own compact line — outside `value`, after the main line's copies are freed
-        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 6), ("third_workload", "gsf", 4096, 64)):
+        # (GSFSignature 4096 nodes), each as its own compact line — outside `value`, after the main line's copies are freed.
+        # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 24 copies that fit the HBM — it takes 256
+        # (64 / 96 / 128 / 192 / 256 / 320 / 360 copies: 349.5 / 393.9 / 439.9 / 476.8 / 502.4 / 507.0 / 509.4 M msgs/s,
+        # profiles/r18a_gsf_copies_sweep.txt: the step is ~ 63 ms + 1.44 ms per copy)
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 6), ("third_workload", "gsf", 4096, 256)):
             if n == nn and args.workload == wl:
                 continue
             try:

@@ -3230,6 +3230,9 @@ struct GsfHost : ProtoHost {
     static const bool laneTier = !(getenv("WG_GSF_LANE") && atoi(getenv("WG_GSF_LANE")) == 0);
     static const int cycleTier = getenv("WG_GSF_DOCYCLE") ? atoi(getenv("WG_GSF_DOCYCLE")) : 8;  // wavefronts per SIMD of the doCycle kernel; 0: off
     const bool cycleRan = eng.dev.inbox && laneTier && cycleTier && g.periodic_may_fire(G_TASK_DOCYCLE);
+    // k_deliver_inbox visits the nodes k_gsf_lane lists (what the lean kernels did not take) instead of looking at every active
+    // node's inbox count; WG_GSF_REST_LIST=0: as before
+    static const bool restList = !(getenv("WG_GSF_REST_LIST") && atoi(getenv("WG_GSF_REST_LIST")) == 0);
     if (cycleRan && st.L <= 16 && cycleTier != 6) {  // sixteen lanes per node, four nodes per wavefront
       hipLaunchKernelGGL(k_gsf_docycle16, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
     } else if (cycleRan) {
@@ -3240,8 +3243,11 @@ struct GsfHost : ProtoHost {
     }
     if (eng.dev.inbox && laneTier)
       hipLaunchKernelGGL(k_gsf_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_GSF_LANE", 1024), g.R), dim3(256), 0, g.stream, g.tab,
-                         (const GsfState*)g.stab, cycleRan ? 1 : 0);
-    if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
+                         (const GsfState*)g.stab, cycleRan ? 1 : 0, restList ? 1 : 0);
+    if (eng.dev.inbox && laneTier && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
+      hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4, true>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+                         (const GsfState*)g.stab);
+    else if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
       hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab);
     else

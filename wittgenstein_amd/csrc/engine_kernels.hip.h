@@ -2076,7 +2076,10 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
 // node's <= 4 events are one 64-byte read, not a walk of head[node] -> evNext -> ev / evAux gathers — three dependent
 // round trips per event of the visit's serial chain. The next node's line and event count are in flight during the
 // current visit.
-template <class P, int WPE>
+// LISTB: the nodes to visit are the ones a lean kernel of the protocol listed in EngineDev::activeB (32-bit node ids,
+// Globals::nActiveB of them) — GSFSignature's k_gsf_lane lists what it and the kernels before it did not take; without the
+// list every active node cost this kernel a wavefront's look at its (zeroed) inbox count: half of its time at 256 copies.
+template <class P, int WPE, bool LISTB = false>
 __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __restrict__ tab,
                                                             const typename P::State* __restrict__ stab) {
   WG_ENGINE(tab);
@@ -2085,13 +2088,14 @@ __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __r
   const int lane = WG_LANE, w = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nActive = d.g->nActive;
+  const uint32_t nActive = LISTB ? d.g->nActiveB : d.g->nActive;
+  const uint32_t WG_G* nodes = LISTB ? (const uint32_t WG_G*)(VisitDesc WG_G*)d.activeB : (const uint32_t WG_G*)(uint32_t WG_G*)d.active;
   const int32_t t = d.g->now;
   if (wave >= nActive) return;
   auto line_of = [&](int32_t node) -> InboxEntry {  // lane k < 4: entry k of the node's line
     return gld(d.inbox + ((size_t)node * INBOX_SLOTS + (lane < INBOX_SLOTS ? lane : 0)));
   };
-  int32_t node = (int32_t)d.active[wave];
+  int32_t node = (int32_t)nodes[wave];
   InboxEntry in = line_of(node);
   uint32_t cnt = d.icnt[node];
   for (uint32_t a = wave; a < nActive; a += nWaves) {
@@ -2100,7 +2104,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __r
     InboxEntry inN = in;
     uint32_t cntN = cnt;
     if (haveNext) {
-      nodeN = (int32_t)d.active[a + nWaves];
+      nodeN = (int32_t)nodes[a + nWaves];
       inN = line_of(nodeN);
       cntN = d.icnt[nodeN];
     }

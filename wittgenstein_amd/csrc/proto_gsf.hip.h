@@ -992,20 +992,40 @@ __global__ void __launch_bounds__(256) k_gsf_docycle16(const EngineDev* __restri
 // doCycle), with more events than the
 // inbox line holds, down nodes, a partitioned network, payloads wider than a lane copies (> 32 words). A node delivered
 // here has its inbox count zeroed: the wavefront kernel passes it over.
-__global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int cycleRan) {
+// `listB`: the nodes this kernel and the ones before it leave to k_deliver_inbox are listed in EngineDev::activeB (one atomic per
+// wavefront) — that kernel then visits those and nothing else (k_deliver_inbox<.., LISTB>).
+__global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int cycleRan, int listB) {
   WG_ENGINE(tab);
   const GsfState& s = stab[blockIdx.y];
   const uint32_t nActive = d.g->nActive;
-  if (d.nparts || d.boundMsg) return;
+  const int lane = WG_LANE;
+  uint32_t WG_G* rest = (uint32_t WG_G*)(VisitDesc WG_G*)d.activeB;
+  const bool lean = !(d.nparts || d.boundMsg);
+  if (!lean && !listB) return;
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < nActive; a += gridDim.x * blockDim.x) {
     const int32_t node = (int32_t)d.active[a];
     const uint32_t cnt = d.icnt[node];
-    if (cnt == 0 || cnt > (uint32_t)INBOX_SLOTS) continue;
     InboxEntry in[INBOX_SLOTS];
 #pragma unroll
-    for (int k = 0; k < INBOX_SLOTS; k++) in[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
-    int cycleAt;
-    if (!gsf_split_ok(d, node, cnt, in, cycleRan != 0, cycleAt)) continue;
+    for (int k = 0; k < INBOX_SLOTS; k++) in[k].e = in[k].w0 = in[k].w2 = in[k].w3 = 0;
+    int cycleAt = -1;
+    bool mine = false;
+    if (lean && cnt != 0 && cnt <= (uint32_t)INBOX_SLOTS) {
+#pragma unroll
+      for (int k = 0; k < INBOX_SLOTS; k++) in[k] = gld(d.inbox + ((size_t)node * INBOX_SLOTS + k));
+      mine = gsf_split_ok(d, node, cnt, in, cycleRan != 0, cycleAt);
+    }
+    if (listB) {
+      const uint64_t m = __ballot(cnt != 0 && !mine);
+      if (m) {
+        uint32_t bb = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) bb = atomicAdd(F(&d.g->nActiveB), (uint32_t)__popcll(m));
+        bb = lane_bcast(bb, leader);
+        if (cnt != 0 && !mine) rest[bb + __popcll(m & lanes_lt())] = (uint32_t)node;
+      }
+    }
+    if (!mine) continue;
     d.icnt[node] = 0;  // the line is consumed by this visit
     // event order = ascending event index (the line holds them in arrival order of the atomics, not in event order)
     uint32_t rank[INBOX_SLOTS];
