@@ -168,6 +168,15 @@ def leg10():
                                                (4, (2000, 10, 50, 1, 1, 10, 30), None, 0, 250, 8)]:
         c, traffic = tl.p2pflood_loopback(k, params, nl, seed, chunk, chunks, device_memory=True)
         out["p2pflood"].append({"k": k, "delivered": int(c.info()["delivered"]), "same_collectives": len(set(traffic)) == 1})
+def leg11():
+    # 11. Casper IMD at 16 390 nodes (BASELINE config 5's shape with 256 attesters per round: 64 x 256 attesters, 5 producers, 1
+    # observer; every vote a sendAll to all of them), a tenth of the attesters stop()ped, as 4 logical shards of the one GPU in
+    # lock-step with the oracle after every chunk — the sharded pipeline against the oracle at forty times leg 8's node count
+    import test_shards_casper as tc
+    c, traffic = tc.casper_loopback(4, (64, False, 5, 256, 1000, 1), seed=2, chunk=4000, chunks=6, stopped=1639, max_slots=8,
+                                    device_memory=True)
+    out["casper_16390"] = {"delivered": int(c.info()["delivered"]), "height": int(c.read("headHeight")[0]),
+                           "same_collectives": len(set(traffic)) == 1}
 import traceback
 out["errors"] = {}
 for _name, _fn in [(k, v) for k, v in sorted(globals().items()) if k.startswith('leg') and callable(v)]:
@@ -264,6 +273,12 @@ def test_casper_logical_shards_match_the_oracle(result):   # per-node rows by ow
     for r in result["casper"]:
         assert r["same_collectives"] and r["calls"] > 0 and r["height"] >= 3, r
     assert result["casper"][0]["delivered"] > 100000
+
+
+def test_casper_16390_nodes_as_four_logical_shards_match_the_oracle(result):
+    assert "leg11" not in result["errors"], result["errors"].get("leg11")
+    r = result["casper_16390"]
+    assert r["same_collectives"] and r["height"] >= 1 and r["delivered"] > 5000000, r
 
 
 def test_casper_four_logical_shards_equal_the_unsharded_engine_at_2051_nodes(result):
