@@ -516,8 +516,9 @@ def main():
                     help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
                          "thread each); 0 = 1: the whole step as one batch on one stream, so that a launch of the delivery kernels "
                          "has the chip to itself and its HIP-event / rocprofv3 duration is the kernel's own (the roofline "
-                         "figure). --batches 2 overlaps two half-batches' chains of dependent latencies: +6 % delivered "
-                         "messages/s (profiles/archive/r04d_sweep_graph_batches.txt), at the price of launch durations inflated by "
+                         "figure). --batches 2 overlaps two half-batches' chains of dependent latencies: +2.7 % delivered "
+                         "messages/s on round 4's code (493.7 -> 506.9 M, profiles/r19f_sweep_batches.txt; it was +6 % before the "
+                         "delivery pass's tiers filled the chip), at the price of launch durations inflated by "
                          "the sharing; three and more lose to their smaller launches")
     ap.add_argument("--init-threads", type=int, default=0, help="host threads for the copies' init() (0 = one per copy, "
                     "bounded by the box's cores and host memory)")
