@@ -175,6 +175,10 @@ def test_gsf_dead_nodes_and_long_lists():
     tg.lockstep((128, 96, 6, 10, 5, 10, 25), tg.NBG, total=300, config={"queue_cap": 256})
 
 
+def test_gsf_without_the_rest_list(monkeypatch):
+    tg.test_event_order_visit_of_every_active_node(monkeypatch)
+
+
 def test_gsf_256_to_convergence():
     tg.test_256_chunks_of_10_to_convergence()
 

@@ -90,6 +90,15 @@ def test_simple_threshold_with_dead_nodes():  # testSimpleThreshold :107-124
 
 
 @pytest.mark.gpu
+def test_event_order_visit_of_every_active_node(monkeypatch):
+    """WG_GSF_REST_LIST=0: k_deliver_inbox looks at every active node's inbox count (the form before k_gsf_lane listed the
+    nodes it leaves) — the same lock-step runs as the default's, dead nodes and multi-word levels included"""
+    monkeypatch.setenv("WG_GSF_REST_LIST", "0")
+    lockstep((64, 32, 3, 20, 10, 10, 12), NBG, total=400)
+    lockstep((512, 500, 3, 50, 10, 10, 0), seed=5, step=10, total=150)
+
+
+@pytest.mark.gpu
 def test_copy_parameters_long_lists():  # testCopy's parameters :126-131; toVerify grows past one wavefront (170 entries)
     lockstep((128, 96, 6, 10, 5, 10, 25), NBG, total=600, config={"queue_cap": 256})
 

@@ -3232,7 +3232,7 @@ struct GsfHost : ProtoHost {
     const bool cycleRan = eng.dev.inbox && laneTier && cycleTier && g.periodic_may_fire(G_TASK_DOCYCLE);
     // k_deliver_inbox visits the nodes k_gsf_lane lists (what the lean kernels did not take) instead of looking at every active
     // node's inbox count; WG_GSF_REST_LIST=0: as before
-    static const bool restList = !(getenv("WG_GSF_REST_LIST") && atoi(getenv("WG_GSF_REST_LIST")) == 0);
+    const bool restList = !(getenv("WG_GSF_REST_LIST") && atoi(getenv("WG_GSF_REST_LIST")) == 0);  // (read per call: tests toggle it)
     if (cycleRan && st.L <= 16 && cycleTier != 6) {  // sixteen lanes per node, four nodes per wavefront
       hipLaunchKernelGGL(k_gsf_docycle16, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
     } else if (cycleRan) {
