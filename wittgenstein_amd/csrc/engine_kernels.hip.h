@@ -2078,7 +2078,7 @@ __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restric
 // current visit.
 // LISTB: the nodes to visit are the ones a lean kernel of the protocol listed in EngineDev::activeB (32-bit node ids,
 // Globals::nActiveB of them) — GSFSignature's k_gsf_lane lists what it and the kernels before it did not take; without the
-// list every active node cost this kernel a wavefront's look at its (zeroed) inbox count: half of its time at 256 copies.
+// list every active node cost this kernel a wavefront's look at its (zeroed) inbox count: 49 of its 221 us per ordinary ms at 256 copies.
 template <class P, int WPE, bool LISTB = false>
 __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __restrict__ tab,
                                                             const typename P::State* __restrict__ stab) {
