@@ -1,0 +1,29 @@
+"""Extra parity evidence beyond the suite's fixed seeds: resident Handel and GSFSignature in lock-step with the oracle, to
+convergence, over a range of seeds and a few shapes (one MI355X; TEST INFRASTRUCTURE — imports tests/ and the oracle).
+    python tools/seed_sweep.py <first seed> <seeds> > gpurun_out/<tag>/seed_sweep.json"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_handel as th  # noqa: E402
+import test_gpu_gsf as tg  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+out = {"handel": [], "gsf": [], "failures": []}
+t0 = time.time()
+for seed in range(first, first + count):
+    for params, step in (((64, 57, 4, 50, 10, 20, 10, 6, 0), 1), ((256, 231, 4, 50, 10, 20, 10, 25, 0), 10),
+                         ((1024, 922, 4, 50, 10, 20, 10, 102, 0), 10)):
+        try:
+            g, c = th.lockstep(params, step, seed=seed)
+            out["handel"].append([params[0], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
+        except Exception as x:  # noqa: BLE001
+            out["failures"].append(["handel", params[0], seed, str(x)[:300]])
+    for params, step in (((32, 32, 3, 20, 10, 10, 0), 1), ((256, 250, 3, 50, 10, 10, 0), 10), ((512, 450, 3, 50, 10, 10, 20), 10)):
+        try:
+            g, c = tg.lockstep(params, seed=seed, step=step, total=0, to_convergence=True)
+            out["gsf"].append([params[0], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
+        except Exception as x:  # noqa: BLE001
+            out["failures"].append(["gsf", params[0], seed, str(x)[:300]])
+out["wall_s"] = time.time() - t0
+print(json.dumps(out))
