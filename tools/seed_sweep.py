@@ -25,5 +25,23 @@ for seed in range(first, first + count):
             out["gsf"].append([params[0], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
         except Exception as x:  # noqa: BLE001
             out["failures"].append(["gsf", params[0], seed, str(x)[:300]])
+if len(sys.argv) > 3 and sys.argv[3] == "attacks":  # ... and both attack scenarios + Casper IMD (with stopped attesters, with a byzantine delay)
+    import test_gpu_casper_resident as tc
+    out["suicide"], out["hidden"], out["casper"] = [], [], []
+    P64 = (64, 50, 4, 50, 5, 20, 10, 6, 0)
+    for seed in range(first, first + count):
+        for key, kw in (("suicide", {"byzantine_suicide": True}), ("hidden", {"hidden_byzantine": True})):
+            for params, step in ((P64, 5), (th.ratios(256, dead=0.25), 10)):
+                try:
+                    g, c = th.lockstep(params, step, max_ms=4000, seed=seed, **kw)
+                    out[key].append([params[0], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
+                except Exception as x:  # noqa: BLE001
+                    out["failures"].append([key, params[0], seed, str(x)[:300]])
+        for params, byz, stopped in (((5, False, 5, 80, 1000, 1), 0, 40), ((3, True, 3, 8, 1000, 1), 7000, 2)):
+            try:
+                g, c = tc.lockstep(params, seed=seed, chunk=2000, chunks=16, byz_delay=byz, stopped=stopped)
+                out["casper"].append([params[3], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
+            except Exception as x:  # noqa: BLE001
+                out["failures"].append(["casper", params[3], seed, str(x)[:300]])
 out["wall_s"] = time.time() - t0
 print(json.dumps(out))
