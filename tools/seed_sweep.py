@@ -43,5 +43,19 @@ if len(sys.argv) > 3 and sys.argv[3] == "attacks":  # ... and both attack scenar
                 out["casper"].append([params[3], seed, int(g.network().read("msgReceived").sum()), int(g.network().time)])
             except Exception as x:  # noqa: BLE001
                 out["failures"].append(["casper", params[3], seed, str(x)[:300]])
+if len(sys.argv) > 3 and sys.argv[3] == "fuzz":  # the scheduler path itself through host-callback mode (tests/test_gpu_fuzz.py's run)
+    import test_gpu_fuzz as tf
+    out["fuzz"] = []
+    OPS = {10: [("partition", 300)], 14: [("stop", 3), ("stop", 7)], 18: [("endPartition", 0), ("setMsgDiscardTime", 150)],
+           24: [("start", 3)], 27: [("setMsgDiscardTime", 1 << 30)], 30: [("partition", 500), ("partition", 200)],
+           36: [("endPartition", 0), ("start", 7)]}
+    NLS = [None, "NetworkNoLatency", "NetworkFixedLatency(3)", "IC3NetworkLatency"]
+    for seed in range(first, first + count):
+        for nl, ops, n in ((NLS[seed % 4], (), 48), (None, OPS, 64)):
+            try:
+                g, c = tf.run(n, 12, nl, seed=seed, chunk=25, chunks=44, ops=ops)
+                out["fuzz"].append([n, seed, str(nl), int(c.info()["delivered"]), int(c.info()["tasks"])])
+            except Exception as x:  # noqa: BLE001
+                out["failures"].append(["fuzz", n, seed, str(nl), str(x)[:300]])
 out["wall_s"] = time.time() - t0
 print(json.dumps(out))
