@@ -24,13 +24,13 @@ extern "C" {
 typedef struct wg_engine wg_engine;
 
 /* ABI version of this header. The parameter structs have GROWN across versions (wg_handel_params gained byzantineSuicide /
- * hiddenByzantine in version 3, wg_config gained queue_cap_wide in version 2): a caller compiled against an older header
+ * hiddenByzantine in version 3, wg_config gained queue_cap_wide in version 2 and rank_bump_cap in version 5): a caller compiled against an older header
  * would pass shorter structs than the library reads. A binding checks once, at load time, that wg_abi_version() equals the
  * WG_ABI_VERSION it was compiled with and that wg_abi_struct_size(k) equals its own sizeof — wittgenstein_amd/_lib.py and
  * jni/wittgpu_jni.c (JNI_OnLoad) do; a mismatch is a load error, not a silent over-read.
  * which: 0 wg_config, 1 wg_handel_params, 2 wg_gsf_params, 3 wg_casper_params, 4 wg_sanfermin_params,
  * 5 wg_p2pflood_params, 6 wg_delivery, 7 wg_step_op, 8 wg_run_stats; -1 for an unknown index. */
-#define WG_ABI_VERSION 4
+#define WG_ABI_VERSION 5
 int32_t wg_abi_version(void);
 int32_t wg_abi_struct_size(int32_t which);
 
@@ -71,6 +71,10 @@ typedef struct {
   int32_t queue_cap_wide;       /* Handel: toVerifyAgg capacity of the levels whose block is >= 16 words (>= 1024 ids), whose
                                    queues stay short and whose slots are large; 0 = min(queue_cap, 16). Overflow is loud
                                    (WG_ENOMEM), as for queue_cap */
+  int32_t rank_bump_cap;        /* Handel with the reception ranks carried by the senders (init() on the device, unsharded, no
+                                   attack, <= 65 536 nodes): senders per node whose rank checkSigs may bump (P/Handel.java:825-828)
+                                   — one per distinct sender a node ever verifies; rounded up to a power of two, at most
+                                   nodeCount. 0 = min(nodeCount, 1024). Overflow is loud (WG_ENOMEM) */
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */

@@ -44,7 +44,7 @@ public final class WittGpu {
 
   public static native int abiStructSize(int which);
 
-  // ---- lifecycle. cfgInts = {device, horizon_ms, queue_cap, queue_cap_wide, chain_slots, shard, nshards} (null / shorter:
+  // ---- lifecycle. cfgInts = {device, horizon_ms, queue_cap, queue_cap_wide, chain_slots, shard, nshards, rank_bump_cap} (null / shorter:
   // zeros = defaults), cfgLongs = {bucket_pool_records, payload_words, outbox_records, chain_dests}, rcclId = null or 128 bytes
   public static native long create(int[] cfgInts, long[] cfgLongs, byte[] rcclId);
 

@@ -65,13 +65,13 @@ static jint ck_batch(JNIEnv* env, wg_batch* b, int32_t rc) {
 #define STR(s) ((s) ? (*env)->GetStringUTFChars(env, (s), NULL) : NULL)
 #define UNSTR(s, p) do { if (s) (*env)->ReleaseStringUTFChars(env, (s), (p)); } while (0)
 
-/* wg_config from int[10]: {device, horizon_ms, queue_cap, queue_cap_wide, chain_slots, shard, nshards} then, as longs in
+/* wg_config from int[8]: {device, horizon_ms, queue_cap, queue_cap_wide, chain_slots, shard, nshards, rank_bump_cap} then, as longs in
  * long[4], {bucket_pool_records, payload_words, outbox_records, chain_dests}; rcclId: the 128 bytes or null */
 static void fill_config(JNIEnv* env, wg_config* c, jintArray ints, jlongArray longs, jbyte* idbuf, jbyteArray rcclId) {
   memset(c, 0, sizeof *c);
-  jint iv[7] = {0, 0, 0, 0, 0, 0, 0};
+  jint iv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   jlong lv[4] = {0, 0, 0, 0};
-  if (ints) (*env)->GetIntArrayRegion(env, ints, 0, LEN(ints) < 7 ? LEN(ints) : 7, iv);
+  if (ints) (*env)->GetIntArrayRegion(env, ints, 0, LEN(ints) < 8 ? LEN(ints) : 8, iv);
   if (longs) (*env)->GetLongArrayRegion(env, longs, 0, LEN(longs) < 4 ? LEN(longs) : 4, lv);
   c->device = iv[0];
   c->horizon_ms = iv[1];
@@ -80,6 +80,7 @@ static void fill_config(JNIEnv* env, wg_config* c, jintArray ints, jlongArray lo
   c->chain_slots = iv[4];
   c->shard = iv[5];
   c->nshards = iv[6];
+  c->rank_bump_cap = iv[7];
   c->bucket_pool_records = lv[0];
   c->payload_words = lv[1];
   c->outbox_records = lv[2];

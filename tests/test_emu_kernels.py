@@ -89,6 +89,17 @@ def test_handel_incremental_check_sigs_wave_items(monkeypatch):  # cached evalua
     th.test_incremental_check_sigs_wave_items(monkeypatch, 512, "1", 1, 500, 0)
 
 
+@pytest.mark.parametrize("cap,seed", [(0, 0), (256, 5)])
+def test_handel_ranks_carried_by_the_senders(monkeypatch, capfd, cap, seed):  # no N x N matrix: initial rank from the sender + the receiver's bumps
+    th.test_reception_ranks_carried_by_the_senders(monkeypatch, capfd, cap, seed)
+
+
+def test_handel_ranks_matrix_form_and_bump_overflow(monkeypatch, capfd):
+    th.test_reception_ranks_matrix_form_still_runs_with_device_init(monkeypatch, capfd)
+    monkeypatch.delenv("WG_HANDEL_RANKS")
+    th.test_rank_bump_table_overflow_is_loud()
+
+
 def test_handel_emission_lists_on_the_device(monkeypatch):  # k_handel_init_sort / k_handel_init_shuffle vs the oracle's init()
     th.test_256_every_ms()
     th.test_emission_lists_built_on_the_device(1)

@@ -74,6 +74,48 @@ def test_reception_ranks_shuffled_on_the_device(monkeypatch, capfd):
     assert (g.network().read_ranks() == want).all()
 
 
+def _ranks_equal_the_oracles(g, c, n):
+    assert (g.network().read_ranks() == np.stack([c.read_ranks(i) for i in range(n)])).all()
+
+
+@pytest.mark.parametrize("cap,seed", [(0, 0), (256, 5)])
+def test_reception_ranks_carried_by_the_senders(monkeypatch, capfd, cap, seed):
+    """Round 5: with init() on the device no N x N receptionRanks matrix is kept — a rank is its initial value (what the
+    emission lists were sorted by, P/Handel.java:991-1013: the SENDER holds it, beside each peer id, and sends it along, in the
+    message word or, for a fast-path envelope, in the destination word) plus nodeCount per bump (:825-828), which the
+    receiver keeps in a small per-node table behind the BUMP bit of the level's delivery piece. Lock-step to convergence at
+    a size where every sender is heard again after a bump (low levels have few peers), then HNode.receptionRanks read back
+    — re-shuffled from init()'s rd state + the bumps — against the oracle's matrix. cap 256 < nodeCount: the table by open
+    addressing instead of by sender id."""
+    monkeypatch.setenv("WG_INIT_VERBOSE", "1")
+    g, c = lockstep(ratios(512, dead=0.2), step=10, max_ms=2500, seed=seed, config={"rank_bump_cap": cap} if cap else None)
+    assert g.init_on_device
+    err = capfd.readouterr().err
+    assert "reception ranks carried by the senders, no matrix (bump table: %d senders per node)" % (cap or 512) in err
+    assert g.network().read("sigsChecked").sum() > 0
+    _ranks_equal_the_oracles(g, c, 512)
+    assert (g.network().read_ranks() >= 512).sum() > 0  # some were bumped
+
+
+def test_reception_ranks_matrix_form_still_runs_with_device_init(monkeypatch, capfd):
+    """WG_HANDEL_RANKS=matrix: the same device-built init() keeping the matrix (the form host-built init(), shards, the attacks'
+    runs and networks beyond 65 536 nodes use) — the same run as the oracle's, and hence as the carried form's"""
+    monkeypatch.setenv("WG_INIT_VERBOSE", "1")
+    monkeypatch.setenv("WG_HANDEL_RANKS", "matrix")
+    g, c = lockstep(ratios(512, dead=0.2), step=10, max_ms=2500)
+    assert g.init_on_device and "reception ranks as an N x N matrix" in capfd.readouterr().err
+    _ranks_equal_the_oracles(g, c, 512)
+
+
+def test_rank_bump_table_overflow_is_loud():
+    """a node that bumps more distinct senders than wg_config.rank_bump_cap holds stops the run (WG_ENOMEM), it does not diverge"""
+    g, c = parity.handel_pair(ratios(512, dead=0.2), config={"rank_bump_cap": 4})
+    with pytest.raises(MemoryError) as ei:  # (core.EngineCapacityError = WG_ENOMEM)
+        for _ in range(300):
+            g.network().runMs(10)
+    assert "rank_bump_cap" in str(ei.value)
+
+
 @pytest.mark.parametrize("n,mode", [(512, "1"), (1024, "2")])
 def test_device_init_forms_of_more_than_65536_nodes(monkeypatch, n, mode):
     """the forms init() takes on the device beyond 65 536 nodes — ids wider than 16 bits: the shuffled list in global memory

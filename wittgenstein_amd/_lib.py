@@ -16,7 +16,7 @@ class wg_config(C.Structure):
                 ("payload_words", C.c_int64), ("outbox_records", C.c_int64), ("chain_dests", C.c_int64),
                 ("chain_slots", C.c_int32), ("queue_cap", C.c_int32),
                 ("shard", C.c_int32), ("nshards", C.c_int32), ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p),
-                ("rccl_id", C.c_void_p), ("queue_cap_wide", C.c_int32)]
+                ("rccl_id", C.c_void_p), ("queue_cap_wide", C.c_int32), ("rank_bump_cap", C.c_int32)]
 
 
 def make_config(cfg):
@@ -84,7 +84,7 @@ class wg_profile_entry(C.Structure):
 
 
 # every symbol include/wittgpu.h and include/wittgpu_host.h declare
-ABI_VERSION = 4  # WG_ABI_VERSION of the include/wittgpu.h these ctypes structures restate
+ABI_VERSION = 5  # WG_ABI_VERSION of the include/wittgpu.h these ctypes structures restate
 ABI_SYMBOLS = [
     "wg_abi_version", "wg_abi_struct_size", "wg_read_i32",
     "wg_create", "wg_destroy", "wg_last_error", "wg_add_nodes", "wg_node_count", "wg_set_latency",
@@ -124,7 +124,7 @@ def lib():
         # the structures above must be the library's (they have grown across versions): a stale library is a load error
         if not hasattr(l, "wg_abi_version") or l.wg_abi_version() != ABI_VERSION:
             raise ImportError("%s: ABI version %s, this binding is version %d — rebuild it (__graft_entry__.build())"
-                              % (LIB_PATH, l.wg_abi_version() if hasattr(l, "wg_abi_version") else "< 4", ABI_VERSION))
+                              % (LIB_PATH, l.wg_abi_version() if hasattr(l, "wg_abi_version") else "< 5", ABI_VERSION))
         for k, t in enumerate((wg_config, wg_handel_params, wg_gsf_params, wg_casper_params, wg_sanfermin_params,
                                wg_p2pflood_params, wg_delivery, wg_step_op, wg_run_stats)):
             if l.wg_abi_struct_size(k) != C.sizeof(t):

@@ -241,7 +241,8 @@ enum ErrBits : uint32_t {
   ERR_EVENTS = 1u << 12,       // events in one ms exceed scratch capacity
   ERR_ARRIVAL_PAST = 1u << 13,
   ERR_SHARD_MULTI = 1u << 14,  // sharded engine: an action() emitted a multi-destination envelope
-  ERR_SAME_MS_BLOCKS = 1u << 15  // Casper resident: two blocks created in one simulated ms (block-id order across wavefronts)
+  ERR_SAME_MS_BLOCKS = 1u << 15,  // Casper resident: two blocks created in one simulated ms (block-id order across wavefronts)
+  ERR_RANK_BUMPS = 1u << 16       // Handel, ranks carried by the senders: a node's table of bumped senders is full
 };
 
 // Device-resident engine globals (one instance).
@@ -421,7 +422,19 @@ struct EngineDev {
   // message word + 1 of the K_MSG events the resident protocol delivers one lane per event, without inbox lists
   // (ExpandF::lane_only); 0: every event is threaded onto its node's list
   uint32_t laneMsgPlus1;
+  // A resident protocol whose node ids fit 16 bits may carry a per-destination TAG in the upper half of the destination
+  // words of its multi-destination envelopes (Handel: the receiver's initial reception rank of the sender, which the
+  // SENDER knows from its emission list — P/Handel.java:991-1013 — so that the receiver need not look it up in an N x N
+  // matrix at delivery). destTagged != 0: a destination word is id | tag << 16 wherever one is read (dest_id), and the
+  // message word a hop is delivered with is the envelope's | tag << destTagMsgShift (dest_msg). The words travel through
+  // the sort by arrival, the envelope ring and a shard's exchange image as they are.
+  uint32_t destTagged;
+  uint32_t destTagMsgShift;
 };
+WG_HD inline int32_t dest_id(const EngineDev& d, int32_t w) { return d.destTagged ? (int32_t)((uint32_t)w & 0xFFFFu) : w; }
+WG_HD inline uint32_t dest_msg(const EngineDev& d, uint32_t msg, int32_t w) {
+  return d.destTagged ? msg | (((uint32_t)w >> 16) << d.destTagMsgShift) : msg;
+}
 struct RunDesc {  // 32 bytes
   uint32_t chain, pos;      // envelope slot, first hop of the run
   uint32_t e, ob;           // its first event index / first outbox slot (the expand scan's exclusive prefix)

@@ -1,6 +1,8 @@
 // Host runtime of the engine + the PingPong resident protocol (P/PingPong.java).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -1187,6 +1189,7 @@ void Engine::check_device_errors() {
   if (e & ERR_PAYLOAD) m += "wg_config.payload_words ring overrun; ";
   if (e & ERR_QUEUE_CAP) m += "toVerify list (Handel toVerifyAgg / GSFSignature toVerify) exceeded wg_config.queue_cap (Handel levels of 1024 ids and more: queue_cap_wide); ";
   if (e & ERR_PENDING) m += "pending-verification table full; ";
+  if (e & ERR_RANK_BUMPS) m += "a Handel node bumped the reception rank of more senders than wg_config.rank_bump_cap holds; ";
   if (e & ERR_MULTI_TOO_BIG) {
     m += "device-side multi-destination send with more than 64 destinations; ";
     code = WG_EUNSUPPORTED;
@@ -2356,9 +2359,71 @@ __global__ void __launch_bounds__(256) k_handel_gather_row(HandelState s, int k,
   const size_t n = (size_t)(s.hi - s.lo) * s.W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int32_t node = s.lo + (int32_t)(i / s.W);
-    dst[i] = *h_word(s, node, k, (int)(i % s.W));
+    const int x = (int)(i % s.W);
+    if (k < HK_COUNT)
+      dst[i] = *h_word(s, node, k, x);
+    else if (k == HK_COUNT + HD_SEEN)  // toVerifyInd
+      dst[i] = h_dword_x(s, node, x)[HD_SEEN] & ~*h_word(s, node, HK_VI, x);
+    else
+      dst[i] = h_dword_x(s, node, x)[k - HK_COUNT];
   }
 }
+// read-back of the receptionRanks of a run whose ranks the senders carry: s.ranks holds the re-shuffled initial matrix;
+// every bumped sender of every node gets its nodeCount per bump (P/Handel.java:825-828)
+__global__ void __launch_bounds__(256) k_handel_ranks_add_bumps(HandelState s) {
+  for (int node = blockIdx.x; node < s.N; node += gridDim.x)
+    for (int i = threadIdx.x; i < s.bumpCap; i += blockDim.x) {
+      const uint32_t e = s.bump[(size_t)node * s.bumpCap + i];
+      if (e >> 16) {
+        int32_t* r = s.ranks + (size_t)node * s.N + (e & 0xFFFFu);
+        *r = h_rank_of(s, (uint32_t)*r, e >> 16);
+      }
+    }
+}
+
+// The N x N matrix a CARRIED init() shuffles its ranks into before the emission lists take them over: 4.3 GB at 32 768
+// nodes, and a batch's copies run their init() on several host threads (bench.py, replicas.init_threads) — a batch sized
+// to fill the HBM with finished copies must not hold one matrix per thread on top. At most four in flight per process;
+// a thread whose allocation fails waits for another's release before it gives up.
+struct TmpMatrix {
+  static std::mutex& mu() {
+    static std::mutex m;
+    return m;
+  }
+  static std::condition_variable& cv() {
+    static std::condition_variable c;
+    return c;
+  }
+  static int& inFlight() {
+    static int n = 0;
+    return n;
+  }
+  static int32_t* acquire(size_t bytes) {
+    std::unique_lock<std::mutex> lk(mu());
+    for (;;) {
+      cv().wait(lk, [] { return inFlight() < 4; });
+      int32_t* p = nullptr;
+      if (hipMalloc((void**)&p, bytes) == hipSuccess) {
+        inFlight()++;
+        return p;
+      }
+      (void)hipGetLastError();
+      if (inFlight() == 0) throw WgError(WG_ENOMEM, "Handel init(): no room for the nodeCount^2 reception-rank matrix the emission lists are built from");
+      const int seen = inFlight();
+      cv().wait(lk, [seen] { return inFlight() < seen; });
+    }
+  }
+  static void release(int32_t*& p) {
+    if (!p) return;
+    (void)hipFree(p);
+    p = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu());
+      inFlight()--;
+    }
+    cv().notify_all();
+  }
+};
 
 struct HandelHost : ProtoHost {
   HandelState st{};
@@ -2415,13 +2480,43 @@ struct HandelHost : ProtoHost {
     // (wg_restore re-creates the five bit rows — zero but for the node's own signature, k_handel_own_bits — instead of
     // keeping a copy: AC_SCRATCH)
     st.rows = rows((uint64_t*)nullptr, (size_t)W * HK_COUNT, true, Engine::AC_SCRATCH);
+    st.drows = rows((uint64_t*)nullptr, (size_t)W * HD_COUNT, true, Engine::AC_SCRATCH);
+    // The reception ranks CARRIED by the senders (proto_handel.hip.h, file header) where init() runs on the device — an
+    // unsharded engine of 256 .. 65 536 nodes without an attack (the attacks read receptionRanks of peers that never sent:
+    // :545, :868); WG_HANDEL_RANKS=matrix keeps the N x N matrix there too (A/B, tests). Host-built init() hands over the
+    // matrix, and so it stays.
+    carried = !init.receptionRanks && !init.peers && !p.byzantineSuicide && !p.hiddenByzantine && e.shardCount == 0 && N >= 256 &&
+              N <= 65536 && !(getenv("WG_HANDEL_RANKS") && !strcmp(getenv("WG_HANDEL_RANKS"), "matrix"));
     // wg_snapshot / wg_restore: the emission lists are never written; receptionRanks only by `+= nodeCount`
-    // (k_handel_cond_a2), which on_restore undoes in place; the verification queues, the dissemination snapshots and the
-    // scratch of the conditional-task phase hold nothing before the first event
-    st.ranks = rows((int32_t*)nullptr, N, false, Engine::AC_SCRATCH);
+    // (k_handel_cond_a2), which on_restore undoes in place (matrix) or forgets (the bump tables); the verification queues,
+    // the dissemination snapshots and the scratch of the conditional-task phase hold nothing before the first event
+    int32_t* tmpRanks = nullptr;  // CARRIED: the matrix lives for the length of init() only
+    struct FreeTmp {
+      int32_t*& p;
+      ~FreeTmp() { TmpMatrix::release(p); }
+    } guardTmp{tmpRanks};
     const bool peers16 = N <= 65536;
-    uint16_t* dPeers16 = peers16 ? rows((uint16_t*)nullptr, N - 1, false, Engine::AC_CONST) : nullptr;
-    int32_t* dPeers32 = peers16 ? nullptr : rows((int32_t*)nullptr, N - 1, false, Engine::AC_CONST);
+    uint16_t* dPeers16 = nullptr;
+    int32_t* dPeers32 = nullptr;
+    if (carried) {
+      tmpRanks = TmpMatrix::acquire(4 * (size_t)N * N);
+      st.ranks = tmpRanks;
+      st.peersR = rows((uint32_t*)nullptr, N - 1, false, Engine::AC_CONST);
+      int cap = e.cfg.rank_bump_cap > 0 ? e.cfg.rank_bump_cap : 1024;
+      int p2 = 1;
+      while (p2 < cap && p2 < N) p2 <<= 1;
+      st.bumpCap = std::min(p2, (int)N);
+      st.bump = rows((uint32_t*)nullptr, (size_t)st.bumpCap, true, Engine::AC_SCRATCH);
+      e.dev.destTagged = 1;  // a fast-path envelope's destination words carry the rank (id | rank << 16)
+      e.dev.destTagMsgShift = H_MSG_RANK_SHIFT;
+    } else {
+      st.ranks = rows((int32_t*)nullptr, N, false, Engine::AC_SCRATCH);
+      dPeers16 = peers16 ? rows((uint16_t*)nullptr, N - 1, false, Engine::AC_CONST) : nullptr;
+      dPeers32 = peers16 ? nullptr : rows((int32_t*)nullptr, N - 1, false, Engine::AC_CONST);
+      st.peersR = nullptr;
+      st.bump = nullptr;
+      st.bumpCap = 0;
+    }
     st.peers16 = dPeers16;
     st.peers32 = dPeers32;
     st.LS = L <= 16 ? 16 : 32;
@@ -2493,14 +2588,24 @@ struct HandelHost : ProtoHost {
       tv = now;
     };
     lap("allocations");
-    if (init.receptionRanks)
+    if (verbose)
+      fprintf(stderr, "[wittgpu] handel load: reception ranks %s (bump table: %d senders per node)\n",
+              carried ? "carried by the senders, no matrix" : "as an N x N matrix", st.bumpCap);
+    if (init.receptionRanks) {
       WG_HIP(hipMemcpy(st.ranks + (size_t)lo * N, init.receptionRanks + (size_t)lo * N, 4 * nLoc * N, hipMemcpyHostToDevice));
-    else
-      build_ranks(e);  // every node's Collections.shuffle on the device (k_handel_init_scan / _perm / _chain)
+    } else {
+      rngAtRanks = e.gh.rng;
+      build_ranks(e, st, true);  // every node's Collections.shuffle on the device (k_handel_init_scan / _perm / _chain)
+    }
     lap("reception ranks");
     if (!init.peers) {
       build_peers(e);  // buildEmissionList on the device (k_handel_init_sort / _shuffle)
       lap("emission lists");
+      if (carried) {  // the lists hold the ranks now
+        WG_HIP(hipStreamSynchronize(e.stream));
+        st.ranks = nullptr;
+        TmpMatrix::release(tmpRanks);
+      }
     } else if (peers16) {  // (narrowed on the host, a slice at a time)
       const size_t total = nLoc * (size_t)(N - 1), step = (size_t)1 << 26;
       std::vector<uint16_t> tmp(std::min(total, step));
@@ -2548,7 +2653,7 @@ struct HandelHost : ProtoHost {
   // (tests: WG_INIT_BIG=1 the > 65 536-node forms at any size; =2 also histogram bins of four ranks, as 131 072 nodes have)
   static int init_big() { return getenv("WG_INIT_BIG") ? atoi(getenv("WG_INIT_BIG")) : 0; }
   template <int E>
-  void launch_chain(Engine& e, int threads, size_t lds, int B, uint16_t* net, uint16_t* starts) {
+  void launch_chain(Engine& e, const HandelState& st, int threads, size_t lds, int B, uint16_t* net, uint16_t* starts) {
 #if !defined(WG_EMU)
     if (lds > 48 * 1024) {
       WG_HIP(hipFuncSetAttribute((const void*)k_handel_init_chain<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2561,7 +2666,12 @@ struct HandelHost : ProtoHost {
     hipLaunchKernelGGL(k_handel_init_chain_starts<E>, dim3(1), dim3(threads), lds, e.stream, st.N, C, (const uint16_t*)net, starts);
     hipLaunchKernelGGL((k_handel_init_chain<E, true>), dim3(C), dim3(threads), lds, e.stream, st, B, net, (const uint16_t*)starts);
   }
-  void build_ranks(Engine& e) {
+  bool carried = false;     // the reception ranks travel with the messages (HandelState::peersR / bump): no matrix
+  uint64_t rngAtRanks = 0;  // rd where setReceivingRanks starts (device-built ranks): the read-back of a CARRIED run re-shuffles from it
+  // (hs: the state whose `ranks` the rows go to — the engine's, or a read-back's scratch copy; advance: leave rd after the shuffles)
+  void build_ranks(Engine& e, const HandelState& hs, bool advance) {
+    const HandelState& st = hs;
+    const uint64_t rng0 = advance ? e.gh.rng : rngAtRanks;
     const int32_t N = st.N;
     if (e.shardCount > 0 || N > 131072 || N < 256)
       throw WgError(WG_EINVAL, "device-built reception ranks: an unsharded engine of 256 .. 131 072 nodes (pass wg_handel_init_state.receptionRanks)");
@@ -2584,7 +2694,7 @@ struct HandelHost : ProtoHost {
       }
     } guard{dCand, dOffs, dFlags};
     WG_HIP(hipMemsetAsync(dFlags, 0, 8, e.stream));
-    hipLaunchKernelGGL(k_handel_init_scan, dim3(2048 / WG_GRID_DIV), dim3(256), 0, e.stream, e.gh.rng, total0 + slack, (uint32_t)N, dCand,
+    hipLaunchKernelGGL(k_handel_init_scan, dim3(2048 / WG_GRID_DIV), dim3(256), 0, e.stream, rng0, total0 + slack, (uint32_t)N, dCand,
                        dFlags, cap);
     uint32_t nCand = 0;
     WG_HIP(hipMemcpyAsync(&nCand, dFlags, 4, hipMemcpyDeviceToHost, e.stream));
@@ -2611,7 +2721,7 @@ struct HandelHost : ProtoHost {
     if (rej > slack) throw WgError(WG_EHOSTINIT, "reception ranks: more rejected draws than the scanned part of rd's stream covers");
     for (int n = 0; n < N; n++) offs[(size_t)n + 1] += offs[n] + (unsigned long long)(N - 1);
     WG_HIP(hipMemcpyAsync(dOffs, offs.data(), 8 * offs.size(), hipMemcpyHostToDevice, e.stream));
-    hipLaunchKernelGGL(k_handel_init_perm, dim3((N + 63) / 64), dim3(64), 0, e.stream, st, dOffs, e.gh.rng, dFlags + 1);
+    hipLaunchKernelGGL(k_handel_init_perm, dim3((N + 63) / 64), dim3(64), 0, e.stream, st, dOffs, rng0, dFlags + 1);
     const int threads = std::min(N, 1024);
     const size_t lds = 2 * (size_t)N;
     const int B = std::max(8, N / 256);  // nodes per chunk: 256 chunks from 2 048 nodes on
@@ -2627,13 +2737,13 @@ struct HandelHost : ProtoHost {
     WG_HIP(hipMalloc((void**)&dLists, 2 * 2 * (size_t)(N / B) * N));
     uint16_t *net = dLists, *starts = dLists + (size_t)(N / B) * N;
     switch (N / threads) {
-      case 1: launch_chain<1>(e, threads, lds, B, net, starts); break;
-      case 2: launch_chain<2>(e, threads, lds, B, net, starts); break;
-      case 4: launch_chain<4>(e, threads, lds, B, net, starts); break;
-      case 8: launch_chain<8>(e, threads, lds, B, net, starts); break;
-      case 16: launch_chain<16>(e, threads, lds, B, net, starts); break;
-      case 32: launch_chain<32>(e, threads, lds, B, net, starts); break;
-      default: launch_chain<64>(e, threads, lds, B, net, starts); break;
+      case 1: launch_chain<1>(e, st, threads, lds, B, net, starts); break;
+      case 2: launch_chain<2>(e, st, threads, lds, B, net, starts); break;
+      case 4: launch_chain<4>(e, st, threads, lds, B, net, starts); break;
+      case 8: launch_chain<8>(e, st, threads, lds, B, net, starts); break;
+      case 16: launch_chain<16>(e, st, threads, lds, B, net, starts); break;
+      case 32: launch_chain<32>(e, st, threads, lds, B, net, starts); break;
+      default: launch_chain<64>(e, st, threads, lds, B, net, starts); break;
     }
     }
     uint32_t bad = 0;
@@ -2643,8 +2753,10 @@ struct HandelHost : ProtoHost {
     WG_HIP(rcBad);
     WG_HIP(rcSync);
     if (bad) throw WgError(WG_EHOSTINIT, "reception ranks: a node drew another number of times than the candidate walk gave it");
-    e.gh.rng = lcg_skip(e.gh.rng, total0 + rej);
-    e.globalsDirty = true;
+    if (advance) {
+      e.gh.rng = lcg_skip(e.gh.rng, total0 + rej);
+      e.globalsDirty = true;
+    }
   }
   // The emission lists of every live sender on the device (P/Handel.java:991-1013): the sort per (sender, level), the draw
   // counts summed on the host in the reference's order, the equal-rank shuffles from jumped rd states. Leaves the engine's
@@ -2711,6 +2823,11 @@ struct HandelHost : ProtoHost {
   bool has_cond() const override { return true; }
   int levels() const override { return st.L; }
   void on_restore(Engine& e) override {
+    if (carried) {  // the ranks as init() left them = no bumps: the tables and the BUMP bits (with the other delivery-side bits) zeroed
+      reset_rows(e);
+      WG_HIP(hipMemsetAsync(st.bump + (size_t)st.lo * st.bumpCap, 0, 4 * (size_t)(st.hi - st.lo) * st.bumpCap, e.stream));
+      return;
+    }
     if (e.gh.notes & NOTE_RANKS_SATURATED)
       throw WgError(WG_EUNSUPPORTED, "wg_restore: a receptionRanks entry saturated at Integer.MAX_VALUE in the last run; "
                                      "the initial ranks cannot be recomputed in place — re-run init()");
@@ -2727,6 +2844,7 @@ struct HandelHost : ProtoHost {
   void reset_rows(Engine& e) {
     const size_t nLoc = (size_t)(st.hi - st.lo), at = (size_t)st.lo * st.W;
     WG_HIP(hipMemsetAsync(st.rows + at * HK_COUNT, 0, 8 * nLoc * st.W * HK_COUNT, e.stream));
+    WG_HIP(hipMemsetAsync(st.drows + at * HD_COUNT, 0, 8 * nLoc * st.W * HD_COUNT, e.stream));
     if (st.atk == 1) WG_HIP(hipMemsetAsync(st.blacklist, 0, 8 * (size_t)st.N * st.W, e.stream));
     hipLaunchKernelGGL(k_handel_own_bits, dim3(((int)nLoc + 255) / 256), dim3(256), 0, e.stream, st);
   }
@@ -2927,6 +3045,26 @@ struct HandelHost : ProtoHost {
       if (n != st.N || L != st.N) throw WgError(WG_EINVAL, "shape must be [nodeCount][nodeCount]");
       memset(dst, 0, 4 * (size_t)n * n);
       WG_HIP(hipStreamSynchronize(e.stream));
+      if (carried) {
+        // No matrix is kept: the initial ranks are shuffled again from the rd state init() had there (they are a function of
+        // it alone), then every node's bumps are added — nodeCount each, saturating (:825-828). Needs 4 N^2 bytes free.
+        int32_t* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, 4 * (size_t)n * n) != hipSuccess) {
+          (void)hipGetLastError();
+          throw WgError(WG_ENOMEM, "read-back of receptionRanks: no room for the 4 * nodeCount^2 bytes the matrix is rebuilt in");
+        }
+        struct Free {
+          void* p;
+          ~Free() { (void)hipFree(p); }
+        } guard{tmp};
+        HandelState hs = st;
+        hs.ranks = tmp;
+        build_ranks(e, hs, false);
+        hipLaunchKernelGGL(k_handel_ranks_add_bumps, dim3(std::max(1, std::min(n, 2048 / WG_GRID_DIV))), dim3(256), 0, e.stream, hs);
+        WG_HIP(hipStreamSynchronize(e.stream));
+        WG_HIP(hipMemcpy(dst, tmp, 4 * (size_t)n * n, hipMemcpyDeviceToHost));
+        return true;
+      }
       WG_HIP(hipMemcpy(dst + (size_t)st.lo * n, st.ranks + (size_t)st.lo * n, 4 * (size_t)(st.hi - st.lo) * n, hipMemcpyDeviceToHost));
       return true;
     }
@@ -2964,13 +3102,13 @@ struct HandelHost : ProtoHost {
       }
       return true;
     }
-    int k;
+    int k;  // (>= HK_COUNT: a delivery-side set — toVerifyInd is computed, SEEN & ~verifiedInd: proto_handel.hip.h, file header)
     switch (field) {
       case WG_B_TOTAL_INCOMING: k = HK_TI; break;
       case WG_B_LAST_AGG_VERIFIED: k = HK_LA; break;
       case WG_B_VERIFIED_IND: k = HK_VI; break;
-      case WG_B_TO_VERIFY_IND: k = HK_TV; break;
-      case WG_B_FINISHED_PEERS: k = HK_FP; break;
+      case WG_B_TO_VERIFY_IND: k = HK_COUNT + HD_SEEN; break;
+      case WG_B_FINISHED_PEERS: k = HK_COUNT + HD_FP; break;
       default: return false;
     }
     memset(dst, 0, 8 * (size_t)n * w);

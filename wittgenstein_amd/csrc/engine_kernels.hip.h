@@ -242,9 +242,10 @@ __device__ __forceinline__ int32_t dev_latency(const EngineDev& d, int32_t from,
 
 // arrival of the j-th destination of a chain (MultipleDestEnvelope.arrivalTime C/Envelope.java:107-113,
 // MultipleDestWithDelayEnvelope.nextArrivalTime :186-188)
-__device__ __forceinline__ int32_t chain_dest(const EngineDev& d, const Chain& c, int j) {
+__device__ __forceinline__ int32_t chain_dest_word(const EngineDev& d, const Chain& c, int j) {  // (id | tag << 16: EngineDev::destTagged)
   return d.dests[ring_at(c.destOff, (unsigned long long)j, d.chainDests)];
 }
+__device__ __forceinline__ int32_t chain_dest(const EngineDev& d, const Chain& c, int j) { return dest_id(d, chain_dest_word(d, c, j)); }
 __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain& c, int j) {
   if (c.flags & 2u) return d.dests[ring_at(c.destOff, (unsigned long long)c.ndest + j, d.chainDests)];
   return c.sendTime + dev_latency(d, c.from, chain_dest(d, c, j), c.seed);
@@ -518,8 +519,8 @@ struct ExpandF {
         } else
         for (uint32_t q = 0; q < len; q++, e++) {
           if (e >= d.maxEvents) break;
-          const int32_t to = chain_dest(d, c, (int)r.w2 + (int)q);
-          const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+          const int32_t tw = chain_dest_word(d, c, (int)r.w2 + (int)q), to = dest_id(d, tw);
+          const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, dest_msg(d, c.msg, tw), c.payload);
           d.ev[e] = hop;
           const bool last = q + 1 == len;
           EvAux a;
@@ -564,8 +565,9 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
       bool first = false;
       int32_t to = 0;
       if (q < rd.len && e < d.maxEvents) {
-        to = chain_dest(d, c, (int)(rd.pos + q));
-        const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, c.msg, c.payload);
+        const int32_t tw = chain_dest_word(d, c, (int)(rd.pos + q));
+        to = dest_id(d, tw);
+        const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, dest_msg(d, c.msg, tw), c.payload);
         d.ev[e] = hop;
         const bool last = q + 1 == rd.len;
         EvAux a;
@@ -707,9 +709,9 @@ __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, i
   const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;  // sendTime += delay + 1 per destination (:459)
   int m = 0;
   for (int j = 0; j < nd && j < 64; j++) {
-    const int32_t to = d.sdests[multi_idx(d, o, j)];
+    const int32_t to = d.sdests[multi_idx(d, o, j)];  // (the whole word moves: id | tag << 16 on a tagged engine)
     int32_t a;
-    if (!arrival_of_send(d, from, to, o.t + j * step, seed, a)) continue;
+    if (!arrival_of_send(d, from, dest_id(d, to), o.t + j * step, seed, a)) continue;
     int k = m++;
     while (k > 0 && d.arvTmp[multi_idx(d, o, k - 1)] > a) {  // insertion keeps equal arrivals in caller order
       d.arvTmp[multi_idx(d, o, k)] = d.arvTmp[multi_idx(d, o, k - 1)];
@@ -733,10 +735,13 @@ __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& 
   // coordinates, then every latency-table entry — instead of one chain of three dependent round trips per destination
   // (ten destinations: thirty round trips one behind the other; the kernel is one wave-round of lanes, so its duration
   // IS its longest chain). Static indices throughout: the arrays live in registers.
-  int32_t to_[MULTI_LDS], arv[MULTI_LDS];
+  int32_t to_[MULTI_LDS], tw_[MULTI_LDS], arv[MULTI_LDS];  // (tw_: the destination words as they travel, to_: the ids)
   bool ok[MULTI_LDS];
 #pragma unroll
-  for (int j = 0; j < MULTI_LDS; j++) to_[j] = j < nd ? d.sdests[multi_idx(d, o, j)] : from;
+  for (int j = 0; j < MULTI_LDS; j++) {
+    tw_[j] = j < nd ? d.sdests[multi_idx(d, o, j)] : from;
+    to_[j] = j < nd ? dest_id(d, tw_[j]) : from;
+  }
   const GeoRegs gf = node_geo(d, from);
   const uint32_t pf = gf.part, df = gf.down;
   const int32_t xf = gf.x, yf = gf.y, ef = gf.extra;
@@ -760,7 +765,7 @@ __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& 
 #pragma unroll
   for (int j = 0; j < MULTI_LDS; j++) {
     if (!ok[j] || arv[j] >= d.discardTime) continue;
-    const int32_t to = to_[j];
+    const int32_t to = tw_[j];
     const int32_t a = o.t + j * step + arv[j];
     int k = m++;
     while (k > 0 && shArv[(k - 1) * T + t] > a) {
@@ -786,7 +791,7 @@ __device__ __forceinline__ int count_multi(const EngineDev& d, const Out& o, int
   first = INT32_MAX;
   for (int j = 0; j < nd && j < 64; j++) {
     int32_t a;
-    if (!arrival_of_send(d, from, d.sdests[multi_idx(d, o, j)], o.t + j * step, seed, a)) continue;
+    if (!arrival_of_send(d, from, dest_id(d, d.sdests[multi_idx(d, o, j)]), o.t + j * step, seed, a)) continue;
     m++;
     first = a < first ? a : first;
   }
@@ -868,15 +873,16 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
                          : (o.to <= MULTI_LDS ? resolve_multi_lds(d, o, from, seed, &shMulti[0][0][0], &shMulti[1][0][0])
                                               : resolve_multi(d, o, from, seed));
         if (m == 1 && !SH) {
-          fin = make_rec(K_MSG, from, (uint32_t)d.sdests[multi_idx(d, o, 0)], o.a, o.b);
+          const int32_t tw = d.sdests[multi_idx(d, o, 0)];
+          fin = make_rec(K_MSG, from, (uint32_t)dest_id(d, tw), dest_msg(d, o.a, tw), o.b);
           arrival = d.arvTmp[multi_idx(d, o, 0)];
         } else if (m == 1) {  // (the one reachable destination: found again, the list is left as it is)
           const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
           for (int j = 0; j < o.to && j < 64; j++) {
             int32_t a;
-            const int32_t to = d.sdests[multi_idx(d, o, j)];
+            const int32_t tw = d.sdests[multi_idx(d, o, j)], to = dest_id(d, tw);
             if (arrival_of_send(d, from, to, o.t + j * step, seed, a)) {
-              fin = make_rec(K_MSG, from, (uint32_t)to, o.a, o.b);
+              fin = make_rec(K_MSG, from, (uint32_t)to, dest_msg(d, o.a, tw), o.b);
               arrival = a;
               break;
             }
@@ -1704,7 +1710,7 @@ struct Ctx {
     bytesSent += (long long)n * size;
     if (n == 1) {
       int32_t to = __hip_atomic_load(&d.sdests[ring_at(destOff, 0, d.sdestCap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      put(O_SEND, to, msg, payload, t + 1, 0, true);
+      put(O_SEND, dest_id(d, to), dest_msg(d, msg, to), payload, t + 1, 0, true);
     } else {
       if (n > 64) {
         if (WG_LANE == 0) set_err(d.g, ERR_MULTI_TOO_BIG);
@@ -1721,7 +1727,7 @@ struct Ctx {
     bytesSent += (long long)n * size;
     if (n == 1) {
       int32_t to = __hip_atomic_load(&d.sdests[ring_at(destOff, 0, d.sdestCap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      put(O_SEND, to, msg, payload, t + 1, 0, true);
+      put(O_SEND, dest_id(d, to), dest_msg(d, msg, to), payload, t + 1, 0, true);
       return;
     }
     if (n > 64) {

@@ -1,19 +1,37 @@
 // Handel (P/Handel.java) as a resident device protocol.
 //
 // State layout (HBM):
-//   bit rows  TI,LA,VI,TV,FP : per node 5 x W uint64, W = N/64. HLevel l's bitsets (totalIncoming,
-//             lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers :373-394) only ever hold
-//             ids of the level's aligned sibling block of 2^(l-1) ids (allSigsAtLevel :671-684), and the
-//             blocks of different levels are disjoint, so W words per kind hold all levels. They are laid
-//             out LEVEL-major, kind-minor (h_row): the five bitsets of one level sit side by side — an event
-//             works on ONE level, so what it touches is one line (levels <= 9) or one contiguous run, not a
-//             line in each of five 134 MB arrays. totalOutgoing of level l is always the union of
+//   bit rows  HLevel l's bitsets (totalIncoming, lastAggVerified, verifiedIndSignatures, toVerifyInd, finishedPeers
+//             :373-394) only ever hold ids of the level's aligned sibling block of 2^(l-1) ids (allSigsAtLevel :671-684),
+//             and the blocks of different levels are disjoint, so W = N/64 words per kind hold all levels. Two arrays,
+//             both LEVEL-major (an event works on ONE level), cut by WHO touches a set (round 5):
+//               rows  [N][W][3]  TI, LA, VI — the sets updateVerifiedSignatures / checkSigs STREAM (a level's three
+//                                side by side, nw words each: h_row);
+//               drows [N][W][4]  what a DELIVERY touches: one bit of `from` in each of SEEN, FP (finishedPeers) and BUMP,
+//                                the three words holding it side by side in one 32-byte piece (h_dword) — one line per
+//                                delivery whatever the level's width, written by no-return atomics, where a level of
+//                                >= 512 ids used to cost a line each for VI, TV and FP.
+//             toVerifyInd is not stored: it is set at a delivery unless verifiedInd has the sender (:779-781) and cleared
+//             by the sender's updateVerifiedSignatures (:701), which sets verifiedInd (:704) for good — so
+//             toVerifyInd = SEEN & ~verifiedInd, SEEN = senders of which a SendSigs was accepted; nothing reads the set but
+//             the read-back, which computes it. BUMP: senders whose reception rank checkSigs has bumped (see ranks).
+//             totalOutgoing of level l is always the union of
 //             totalIncoming of levels < l (:728-731) = the node's OWN aligned block (h_word gathers it).
 //             totalIncoming is never READ as a row by the checkSigs / updateVerifiedSignatures kernels: it always equals
 //             lastAggVerified | verifiedIndSignatures (level 0 starts with the own bit in all three, :413-421; an update
 //             sets `from` in VI and TI together, :705-713, or rebuilds TI as LA | VI, :722-724), so those kernels read two
 //             rows and OR them — a quarter of their row traffic. The row is still WRITTEN (dissemination snapshots it).
-//   ranks     [N][N] int32  receptionRanks (:285)        peers [N][N-1] emission lists (:510-522)
+//   ranks     receptionRanks (:285) and the emission lists (:510-522), in one of two forms:
+//             MATRIX   ranks [N][N] int32 + peers [N][N-1] ids (16-bit up to 65 536 nodes) — host-built init(), sharded
+//                      engines, the attacks' runs, more than 65 536 nodes;
+//             CARRIED  (init() on the device, unsharded, no attack, <= 65 536 nodes; round 5) no matrix: a rank is its
+//                      INITIAL value — a seeded shuffle, fixed by init() — plus nodeCount per time checkSigs chose that
+//                      sender (:825-828). The initial value is what the emission lists were sorted by (:991-1013), so
+//                      the SENDER has it: peersR [N][N-1] = id | rank << 16, the rank travels in the message word
+//                      (bits 6..21) or, for a fast-path envelope, in the destination word's upper half
+//                      (EngineDev::destTagged). The receiver adds its bumps: the BUMP bit of (level, from) in the line
+//                      the delivery touches anyway says whether there are any; the count is in a small per-node table
+//                      (HandelState::bump). One random line of a 4.3 GB matrix less per delivery, 2.1 GB less per copy.
 //   queues    toVerifyAgg (:385): per (node, level) one queue record (h_qrec: length, slots in use, the list
 //             in list order — rank, signer, slot per entry — in ONE line for the usual short list) and up to
 //             Q signature slots sig[2^(l-1) bits] in a private slab; a slot stays allocated while a registered
@@ -72,8 +90,15 @@ __device__ __forceinline__ uint32_t h_update_arg(int pk, int lv, int slot, int32
 struct HandelState {
   wg_handel_params p;
   int32_t N, L, W, Q;
-  GP<uint64_t> rows;                      // [N][W][5], level-major: see h_row
-  GP<int32_t> ranks;                      // [N][N]
+  GP<uint64_t> rows;                      // [N][W][3] TI, LA, VI, level-major: see h_row
+  GP<uint64_t> drows;                     // [N][W][4] SEEN, FP, BUMP, - per 64 ids, level-major: see h_dword
+  GP<int32_t> ranks;                      // [N][N]; NULL: the ranks are CARRIED by the senders (file header)
+  // CARRIED form: the emission lists with the receiver's initial rank of the sender beside each id, and the receivers' bumps:
+  // bump[node][bumpCap] entries count << 16 | from (0: free) — indexed by `from` when bumpCap == N, else open addressing from
+  // h_bump_slot(from); checkSigs adds to it (k_handel_cond_a2), a delivery reads it only when the BUMP bit of its sender is set
+  GP<const uint32_t> peersR;              // [N][N-1] id | rank << 16
+  GP<uint32_t> bump;                      // [N][bumpCap]
+  int32_t bumpCap;                        // a power of two <= N (wg_config.rank_bump_cap; a full table is a loud error)
   // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
   // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
@@ -190,7 +215,8 @@ enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_
 // noByzantinePeers, P/Handel.java:840-843)
 // (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
 // updateVerifiedSignatures add to that)
-enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_TV, HK_FP, HK_COUNT };
+enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_COUNT };          // HandelState::rows
+enum HandelDKind : int { HD_SEEN = 0, HD_FP, HD_BUMP, HD_COUNT = 4 };  // HandelState::drows (the fourth word of a piece is spare)
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_CAND, HP_OUTFIN, HP_SPARE0, HP_SPARE1, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t WG_G* h_lv(const HandelState& s, int32_t node, int plane, int l) {
@@ -226,8 +252,18 @@ __device__ __forceinline__ Lv sib_view(int32_t node, int l) {
 __device__ __forceinline__ Lv own_view(int32_t node, int l) { return block_view((node >> (l - 1)) << (l - 1), 1 << (l - 1)); }
 
 __device__ __forceinline__ int32_t h_peer(const HandelState& s, size_t idx) {
+  if (s.peersR) return (int32_t)(s.peersR[idx] & 0xFFFFu);
   return s.peers16 ? (int32_t)s.peers16[idx] : s.peers32[idx];
 }
+// ... with the peer's initial reception rank of this sender in the upper half (CARRIED form; 0 there in the MATRIX form):
+// what a SendSigs to that peer carries — as it is in a destination word (EngineDev::destTagged), h_msg_rank in a message word
+__device__ __forceinline__ uint32_t h_peer_tagged(const HandelState& s, size_t idx) {
+  if (s.peersR) return s.peersR[idx];
+  return (uint32_t)(s.peers16 ? (int32_t)s.peers16[idx] : s.peers32[idx]);
+}
+constexpr int H_MSG_RANK_SHIFT = 6;  // SendSigs message word: level (5 bits) | levelFinished << 5 | initial rank << 6 (CARRIED form)
+__device__ __forceinline__ uint32_t h_msg_rank(const HandelState& s, uint32_t tagged) { return s.peersR ? (tagged >> 16) << H_MSG_RANK_SHIFT : 0u; }
+__device__ __forceinline__ int32_t h_tag_id(const HandelState& s, uint32_t tagged) { return (int32_t)(s.peersR ? tagged & 0xFFFFu : tagged); }
 __device__ __forceinline__ int h_nw(int l) { return l == 0 ? 1 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1); }
 __device__ __forceinline__ int h_qcap(const HandelState& s, int l) { return h_nw(l) >= 16 ? s.Qw : s.Q; }
 // kind k's words of level l's sibling block: h_nw(l) contiguous words. Per node the W words of a kind are split by level
@@ -236,6 +272,80 @@ __device__ __forceinline__ int h_qcap(const HandelState& s, int l) { return h_nw
 __device__ __forceinline__ uint64_t WG_G* h_row(const HandelState& s, int32_t node, int k, int l) {
   const int nw = h_nw(l), before = l <= 6 ? 0 : nw;
   return s.rows + ((size_t)node * s.W + before) * HK_COUNT + (size_t)k * nw;
+}
+// the delivery-side piece {SEEN, FP, BUMP, -} of word w of level l's sibling block (32 bytes, 32-byte aligned: never across
+// two lines); kind k of it is [k]. The same level-major grouping as the rows.
+__device__ __forceinline__ uint64_t WG_G* h_dword(const HandelState& s, int32_t node, int l, int w) {
+  const int before = l <= 6 ? 0 : h_nw(l);
+  return s.drows + ((size_t)node * s.W + before + w) * HD_COUNT;
+}
+// ... of word x of the N-bit row (any level), as h_word below
+__device__ __forceinline__ uint64_t WG_G* h_dword_x(const HandelState& s, int32_t node, int x) {
+  const uint32_t diff = (uint32_t)x ^ (uint32_t)(node >> 6);
+  if (diff == 0) return s.drows + (size_t)node * s.W * HD_COUNT;
+  const int nw = 1 << (31 - __clz(diff));
+  return s.drows + ((size_t)node * s.W + nw + (x & (nw - 1))) * HD_COUNT;
+}
+// finishedPeers.get(p) of level l whose sibling block starts at word fbw
+__device__ __forceinline__ bool h_finished(const HandelState& s, int32_t node, int l, int fbw, int32_t p) {
+  const uint64_t w = __hip_atomic_load(h_dword(s, node, l, (p >> 6) - fbw) + HD_FP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (w >> (p & 63)) & 1ULL;
+}
+// ---- the receiver's side of a CARRIED rank (h_bump itself: below h_rank_at_delivery): initial value + nodeCount per bump, saturating as :825-828 does
+__device__ __forceinline__ uint32_t h_bump_slot(const HandelState& s, int32_t from) {
+  return s.bumpCap == s.N ? (uint32_t)from : (((uint32_t)from * 0x9E3779B1u) >> 12) & (uint32_t)(s.bumpCap - 1);
+}
+__device__ __forceinline__ uint32_t h_bump_count(const HandelState& s, int32_t node, int32_t from) {
+  const uint32_t WG_G* tab = s.bump + (size_t)node * s.bumpCap;
+  uint32_t h = h_bump_slot(s, from);
+  if (s.bumpCap == s.N) return tab[h] >> 16;
+  for (int probes = 0; probes < s.bumpCap; probes++) {
+    const uint32_t e = tab[h];
+    if (e == 0) return 0;
+    if ((int32_t)(e & 0xFFFFu) == from) return e >> 16;
+    h = (h + 1) & (uint32_t)(s.bumpCap - 1);
+  }
+  return 0;
+}
+__device__ __forceinline__ int32_t h_rank_of(const HandelState& s, uint32_t rank0, uint32_t count) {
+  const unsigned long long r = (unsigned long long)rank0 + (unsigned long long)count * (unsigned long long)(uint32_t)s.N;
+  return r > 0x7FFFFFFFull ? INT32_MAX : (int32_t)r;
+}
+// receptionRanks[from] as a delivery reads it (:784): the matrix entry, or the carried initial rank + this node's bumps of
+// `from` (bumpWord: the BUMP word of the level's piece holding `from`, loaded by the caller with the delivery's other loads)
+__device__ __forceinline__ int32_t h_rank_at_delivery(const HandelState& s, int32_t node, int32_t from, uint32_t msg, uint64_t bumpWord) {
+  const uint32_t rank0 = (msg >> H_MSG_RANK_SHIFT) & 0xFFFFu;
+  if (!((bumpWord >> (from & 63)) & 1ULL)) return (int32_t)rank0;
+  return h_rank_of(s, rank0, h_bump_count(s, node, from));
+}
+// receptionRanks[from] += nodeCount (:825-828) in the CARRIED form: one more bump of (node, from) — by the ONE thread that
+// runs the node's checkSigs at this edge (k_handel_cond_a2) — and the BUMP bit of `from` in level l's delivery piece.
+// A count beyond 16 bits (65 535 bumps of one sender by one node) or a full table stops the run loudly.
+__device__ __forceinline__ void h_bump(const EngineDev& d, const HandelState& s, int32_t node, int l, int32_t from) {
+  uint32_t WG_G* tab = s.bump + (size_t)node * s.bumpCap;
+  uint32_t h = h_bump_slot(s, from);
+  bool done = false;
+  for (int probes = 0; probes < s.bumpCap && !done; probes++) {
+    const uint32_t e = tab[h];
+    if (e == 0 || (int32_t)(e & 0xFFFFu) == from || s.bumpCap == s.N) {
+      const uint32_t c = (e >> 16) + 1u;
+      if (c > 0xFFFFu) {
+        set_err(d.g, ERR_PROTOCOL);
+        return;
+      }
+      tab[h] = (c << 16) | (uint32_t)from;
+      // (saturation :826-828 depends on the initial rank too — any initial rank saturates once count * N alone does)
+      if ((unsigned long long)c * (unsigned long long)(uint32_t)s.N > 0x7FFFFFFFull) atomicOr(&d.g->notes, NOTE_RANKS_SATURATED);
+      done = true;
+    }
+    h = (h + 1) & (uint32_t)(s.bumpCap - 1);
+  }
+  if (!done) {
+    set_err(d.g, ERR_RANK_BUMPS);
+    return;
+  }
+  const int w = (from >> 6) - sib_view(node, l).bw;
+  atomicOr((unsigned long long*)F(h_dword(s, node, l, w) + HD_BUMP), 1ULL << (from & 63));
 }
 // word x (index in the N-bit row of kind k, any level) of `node`: which level's block it is follows from where x
 // differs from the node's own word index
@@ -499,14 +609,14 @@ struct HandelProtoT {
   }
   // ---- getRemainingPeers (:486-508), wave-parallel but sequentially equivalent ------------------
   // Scans the emission list from posInLevel, 64 peers per step. Accepted peers (not finished) are
-  // appended to the dest ring at destOff (want > 1) or returned (want == 1). Returns the count.
+  // appended to the dest ring at destOff (want > 1) or returned (want == 1, wave-uniform in *single) — as the list holds
+  // them (h_peer_tagged: the peer's rank of this node rides in the upper half in the CARRIED form). Returns the count.
   __device__ static int remaining_peers(Ctx& c, const State& s, LevelScalars* ls, int l, int want, uint32_t destOff,
-                                        int32_t* single) {
+                                        uint32_t* single) {
     const int32_t node = c.node;
     const int size = 1 << (l - 1);
     const size_t peers0 = (size_t)node * (s.N - 1) + (size - 1);
-    const uint64_t WG_G* fp = h_row(s, node, HK_FP, l);  // the level's peers are the ids of its sibling block
-    const int fbw = sib_view(node, l).bw;
+    const int fbw = sib_view(node, l).bw;  // the level's peers are the ids of its sibling block
     int pos = ls->pos[l];
     const int start = pos;
     int got = 0;
@@ -515,8 +625,9 @@ struct HandelProtoT {
       int len = min(64, size - pos);
       int k = WG_LANE;
       bool in = k < len;
-      int32_t p = in ? h_peer(s, peers0 + pos + k) : 0;
-      bool ok = in && !((ld_coherent(fp + ((p >> 6) - fbw)) >> (p & 63)) & 1ULL);
+      const uint32_t pt = in ? h_peer_tagged(s, peers0 + pos + k) : 0u;
+      const int32_t p = h_tag_id(s, pt);
+      bool ok = in && !h_finished(s, node, l, fbw, p);
       if (ATK && ok) ok = !blk(s, node, p);  // ... && !blacklist.get(p.nodeId)  :493
       uint64_t okm = __ballot(ok);
       // a rejected peer whose successor position is `start` finishes the level (:499-503)
@@ -534,11 +645,13 @@ struct HandelProtoT {
       int consumed = stop < 64 ? stop + 1 : len;
       uint64_t take = okm & (consumed >= 64 ? ~0ULL : ((1ULL << consumed) - 1ULL));
       int ntake = __popcll(take);
-      if (ok && k < consumed) {
-        int idx = got + __popcll(take & lanes_lt());
-        if (want == 1 && single && ntake >= 1 && idx == 0) *single = p;  // written by exactly one lane
-        if (destOff != 0xFFFFFFFFu) c.dest_put(destOff, idx, p);
+      const int idx = got + __popcll(take & lanes_lt());
+      const bool mine = ok && k < consumed;
+      if (single) {  // (want == 1: the one accepted peer, from the lane that holds it)
+        const uint64_t sm = __ballot(mine && idx == 0);
+        if (sm) *single = lane_bcast(pt, __ffsll((unsigned long long)sm) - 1);
       }
+      if (mine && destOff != 0xFFFFFFFFu) c.dest_put(destOff, idx, (int32_t)pt);
       got += ntake;
       want -= ntake;
       pos += consumed;
@@ -583,11 +696,13 @@ struct HandelProtoT {
     const Lv v = sib_view(node, l);
     const int w = (from >> 6) - v.bw;  // the word of `from` inside the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* fpp = h_row(s, node, HK_FP, l) + w;
-    uint64_t WG_G* vip = h_row(s, node, HK_VI, l) + w;
-    uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
-    const uint64_t fpv = ld_coherent(fpp), viv = ld_coherent(vip), tvv = ld_coherent(tvp);
-    const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+    uint64_t WG_G* dp = h_dword(s, node, l, w);  // {SEEN, FP, BUMP} words holding `from`: one 32-byte piece
+    // receptionRanks[from], read at receive time (:784)
+    int32_t rank;
+    if (s.ranks)
+      rank = s.ranks[(size_t)node * s.N + from];
+    else
+      rank = h_rank_at_delivery(s, node, from, msg, ld_coherent(dp + HD_BUMP));
     uint64_t WG_G* qr = h_qrec(s, node, l);
     const HQHead qh = gld((const HQHead WG_G*)qr);
     const uint64_t qvalid = qr[H_QVALID];
@@ -596,9 +711,10 @@ struct HandelProtoT {
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
     if (has0) pw0 = src[j0] & v.mask;
-    const bool owner = (int)WG_LANE == (w & 63);
-    if (levelFinished && owner) *fpp = fpv | bit;                 // finishedPeers.set(from)
-    if (!(viv & bit) && owner) *tvp = tvv | bit;                  // toVerifyInd.set(from) unless verified
+    if (WG_LANE == 0) {  // (no-return atomics: nothing of the piece but BUMP is waited for)
+      if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);  // finishedPeers.set(from)
+      atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);  // toVerifyInd.set(from) unless verified: SEEN & ~VI (file header)
+    }
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
     const unsigned long long used = qh.used;
@@ -651,6 +767,7 @@ struct HandelProtoT {
     const int below = incl - cti;
     bool open = false, fin = false;
     int32_t cand = 0, cand2 = 0;
+    uint32_t candT = 0, cand2T = 0;  // ... as the list holds them (h_peer_tagged): what the send carries
     int myPos = 0;
     bool two = false, fin2 = true;
     const int mySize = (lane >= 1 && lane < s.L) ? 1 << (lane - 1) : 0;
@@ -659,12 +776,16 @@ struct HandelProtoT {
       if (open) {
         myPos = ls->pos[lane];
         const size_t at = (size_t)node * (s.N - 1) + (mySize - 1) + myPos;
-        cand = h_peer(s, at);
+        candT = h_peer_tagged(s, at);
+        cand = h_tag_id(s, candT);
         // ... and the peer after it, in the same round trip: when the first candidate is a finished peer the scan of
         // getRemainingPeers usually ends at the next one. Only where neither a wrap of posInLevel nor the end-of-scan test
         // (`posInLevel == start`, :499-503) can fall between the two: a level of more than two peers, not at its last position
         two = mySize > 2 && myPos + 1 < mySize;
-        if (two) cand2 = h_peer(s, at + 1);
+        if (two) {
+          cand2T = h_peer_tagged(s, at + 1);
+          cand2 = h_tag_id(s, cand2T);
+        }
       }
     }
     KPROF_DECL;
@@ -708,10 +829,9 @@ struct HandelProtoT {
       }
     }
     if (open) {
-      const uint64_t WG_G* fpRow = h_row(s, node, HK_FP, lane);  // lane = level: the level's sibling block
-      const int fbw = sib_view(node, lane).bw;
-      const uint64_t w1 = ld_coherent(fpRow + ((cand >> 6) - fbw));
-      const uint64_t w2 = two ? ld_coherent(fpRow + ((cand2 >> 6) - fbw)) : ~0ULL;
+      const int fbw = sib_view(node, lane).bw;  // lane = level: the level's sibling block
+      const uint64_t w1 = ld_coherent(h_dword(s, node, lane, (cand >> 6) - fbw) + HD_FP);
+      const uint64_t w2 = two ? ld_coherent(h_dword(s, node, lane, (cand2 >> 6) - fbw) + HD_FP) : ~0ULL;
       fin = (w1 >> (cand & 63)) & 1ULL;
       fin2 = (w2 >> (cand2 & 63)) & 1ULL;
       if (ATK) {  // a blacklisted peer is passed over like a finished one (:493)
@@ -720,6 +840,7 @@ struct HandelProtoT {
       }
       if (fin && two && !fin2) {  // the first candidate is rejected (no effect but posInLevel++), the second one is taken
         cand = cand2;
+        candT = cand2T;
         myPos++;
         fin = false;
       }
@@ -759,19 +880,21 @@ struct HandelProtoT {
     uint64_t sendM = okM;
     for (uint64_t m = openM & ~okM; m; m &= m - 1) {
       const int l = __ffsll((unsigned long long)m) - 1;
-      int32_t dest = -1;
+      uint32_t dest = 0;
       const int got = remaining_peers(c, s, ls, l, 1, 0xFFFFFFFFu, &dest);
       KPROF_COUNT(c.d.g, 13);
       if (got <= 0) continue;
-      dest = (int32_t)lane_bcast((uint32_t)dest, __ffsll((unsigned long long)__ballot(dest >= 0)) - 1);
-      if (lane == l) cand = dest;
+      if (lane == l) {
+        candT = dest;
+        cand = h_tag_id(s, dest);
+      }
       sendM |= 1ULL << l;
     }
     if (sendM) {  // one rd.nextInt() per send, in level order (:374-382): lane l writes level l's record
       long long bytes = 0;
       for (uint64_t m = sendM; m; m &= m - 1) bytes += h_msg_size(__ffsll((unsigned long long)m) - 1);
       c.send_many((sendM >> lane) & 1ULL, __popcll(sendM & lanes_lt()), __popcll(sendM), cand,
-                  (uint32_t)lane | (lf ? 32u : 0u),
+                  (uint32_t)lane | (lf ? 32u : 0u) | h_msg_rank(s, candT),
                   complete ? H_REF_ONES : refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
     }
     KPROF_MARK(c.d.g, 10);  // sends
@@ -833,8 +956,7 @@ struct HandelProtoT {
     // ---- every load of the event, issued before the first use (one memory round trip)
     const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
-    const uint64_t tvv = ld_coherent(tvp);
+    // (toVerifyInd.set(from, false) :701 — the set is SEEN & ~verifiedInd, and verifiedInd gets `from` below: nothing to store)
     uint64_t WG_G* qr = h_qrec(s, node, lv);
     uint64_t WG_G* ent = qr + H_QENT;
     const HQHead qh = gld((const HQHead WG_G*)qr);
@@ -859,7 +981,6 @@ struct HandelProtoT {
       tiF = viF | ld_coherent(la + jF);
     }
     const bool owner = lane == (jF & 63);
-    if (owner) *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
     // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
     const int len = (int)qh.len;
     if (len > 13) entAll = ent[lane];
@@ -984,14 +1105,10 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   if (t < r.startAt) return;
   const int w = (from >> 6) - sib_view(node, l).bw;  // the word of `from` inside the level's block
   const uint64_t bit = 1ULL << (from & 63);
-  uint64_t WG_G* fpp = h_row(s, node, HK_FP, l) + w;  // (the level's five bitsets side by side: one line up to level 9)
-  const uint64_t WG_G* vip = h_row(s, node, HK_VI, l) + w;
-  uint64_t WG_G* tvp = h_row(s, node, HK_TV, l) + w;
-  // every load of the event before the first use
-  const uint64_t viv = *vip;
-  const uint64_t fpv = levelFinished ? *fpp : 0ULL;
-  const uint64_t tvv = *tvp;
-  const int32_t rank = s.ranks[(size_t)node * s.N + from];  // read at receive time (:769)
+  uint64_t WG_G* dp = h_dword(s, node, l, w);  // the {SEEN, FP, BUMP} words holding `from`: one 32-byte piece
+  // every load of the event before the first use: the BUMP word (CARRIED ranks) or the matrix entry, the record's head
+  const uint64_t bumpW = s.ranks ? 0ULL : dp[HD_BUMP];
+  const int32_t rankM = s.ranks ? s.ranks[(size_t)node * s.N + from] : 0;
   uint64_t WG_G* qr = h_qrec(s, node, l);
   const HQHead qh = gld((const HQHead WG_G*)qr);
   const uint64_t qvalid = qr[H_QVALID];
@@ -1000,8 +1117,10 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   const uint64_t WG_G* src = h_payload(d, s, payload);
   const int nw = h_nw(l);
   const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
-  if (levelFinished) *fpp = fpv | bit;         // finishedPeers.set(from)
-  if (!(viv & bit)) *tvp = tvv | bit;          // toVerifyInd.set(from) unless verified
+  // (no-return atomics: the bits are set at L2, no lane waits for the words)
+  if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);  // finishedPeers.set(from)
+  atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);  // toVerifyInd.set(from) unless verified = SEEN & ~VI (file header)
+  const int32_t rank = s.ranks ? rankM : h_rank_at_delivery(s, node, from, msg, bumpW);  // receptionRanks[from], read at receive time (:784)
   r.sigQueueSize++;
   const int qc = h_qcap(s, l);
   const unsigned long long capMask = qc >= 64 ? ~0ULL : ((1ULL << qc) - 1ULL);
@@ -1049,7 +1168,6 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
   const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block: 0 <= jF < nw
   const uint64_t bit = 1ULL << (from & 63);
-  uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
   uint64_t WG_G* qr = h_qrec(s, node, lv);
   uint64_t WG_G* ent = qr + H_QENT;
   // ---- the loads that depend on the task's argument only, before the first use
@@ -1058,7 +1176,6 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   U4 WG_G* lvA = (U4 WG_G*)h_lv(s, node, HP_POS, lv);   // {posInLevel, |totalIncoming|, |lastAggVerified|, |verifiedInd|}
   U4 a = gld(lvA);
   const HQHead qh = gld((const HQHead WG_G*)qr);
-  const uint64_t tvv = *tvp;
   const uint64_t viF = vi[jF], tiF = viF | la[jF];  // totalIncoming = lastAggVerified | verifiedInd: the row is not read
   uint64_t e6[6];  // the head of the level's list (the record's first line); longer lists are walked in memory below
 #pragma unroll
@@ -1105,7 +1222,7 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   }
   // ---- apply
   hdr[HH_PEND + pk] = 0;
-  *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
+  // (toVerifyInd.set(from, false) :701: the set is SEEN & ~verifiedInd — nothing to store)
   // toVerifyAgg.remove(vs): identity remove, sigQueueSize untouched
   const int len = (int)qh.len;
   HQHead nh = qh;
@@ -1505,7 +1622,6 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     const uint64_t WG_G* sig = h_sig_ptr(s, node, lv, slot);
     const int jF = (from >> 6) - v.bw;  // `from` lies in the level's block
     const uint64_t bit = 1ULL << (from & 63);
-    uint64_t WG_G* tvp = h_row(s, node, HK_TV, lv) + jF;
     uint64_t WG_G* qr = h_qrec(s, node, lv);
     uint64_t WG_G* ent = qr + H_QENT;
     // ---- every load of the task (addresses from its argument alone), before the first use. The kernel is bound by its
@@ -1521,7 +1637,6 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     if (lane < 6) pg = gld(piece);
     // (the list: its first 13 entries are the record's first two lines; a longer one is fetched once its length is known)
     uint64_t entAll = lane < 13 ? ent[lane] : 0ULL;
-    const uint64_t tvv = ld_coherent(tvp);
     V2 sg[2], tiw[2], law[2], viw[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -1670,8 +1785,7 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
     long long doneAt = (long long)((unsigned long long)hD.y | ((unsigned long long)hD.z << 32));
     const bool justDone = improved && doneAt == 0 && total >= s.p.threshold;
     const bool fastPathFollows = improved && cTI == v.size && s.p.fastPath > 0 && lv + 1 < s.L;
-    if (lane == 0) {
-      *tvp = tvv & ~bit;  // toVerifyInd.set(from, false)
+    if (lane == 0) {  // (toVerifyInd.set(from, false) :701: the set is SEEN & ~verifiedInd — nothing to store)
       hdr[HH_PEND + pk] = 0;
       a.y = (uint32_t)cTI;
       a.z = (uint32_t)cLA;
@@ -3011,10 +3125,14 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
       h[HH_WINDOW] = (uint32_t)min(w, 1 << (l - 1));
       // receptionRanks[best.from] += nodeCount, saturating (:825-828)
-      int32_t WG_G* rk = s.ranks + (size_t)node * s.N + from;
-      int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
-      *rk = nr < 0 ? INT32_MAX : nr;
-      if (nr < 0) atomicOr(&d.g->notes, NOTE_RANKS_SATURATED);
+      if (s.ranks) {
+        int32_t WG_G* rk = s.ranks + (size_t)node * s.N + from;
+        int32_t nr = (int32_t)((uint32_t)*rk + (uint32_t)s.N);
+        *rk = nr < 0 ? INT32_MAX : nr;
+        if (nr < 0) atomicOr(&d.g->notes, NOTE_RANKS_SATURATED);
+      } else {
+        h_bump(d, s, (int32_t)node, l, from);
+      }
       h[HH_SIGCHK]++;
       int pe = -1;
       for (int q = 0; q < H_PEND; q++)
@@ -3242,8 +3360,11 @@ __global__ void __launch_bounds__(1024) k_handel_init_chain_starts_big(int N, in
 // the list unshuffled and counts its draws (elements - buckets); the host prefix-sums the counts in (sender, level)
 // order; (B) every bucket of several receivers shuffles itself from the rd state jumped to its first draw.
 // The receiver's rank of the sender is receptionRanks[receiver][sender]: a column of the uploaded matrix.
-__device__ __forceinline__ void h_peer_store(const HandelState& s, size_t idx, int32_t v) {
-  if (s.peers16)
+// (rank: the receiver v's reception rank of this sender — kept beside the id in the CARRIED form)
+__device__ __forceinline__ void h_peer_store(const HandelState& s, size_t idx, int32_t v, uint32_t rank) {
+  if (s.peersR)
+    ((uint32_t WG_G*)(const uint32_t WG_G*)s.peersR)[idx] = (uint32_t)v | (rank << 16);
+  else if (s.peers16)
     ((uint16_t WG_G*)(const uint16_t WG_G*)s.peers16)[idx] = (uint16_t)v;
   else
     ((int32_t WG_G*)(const int32_t WG_G*)s.peers32)[idx] = v;
@@ -3310,7 +3431,7 @@ __global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const 
         uint32_t mineB = 0;
         for (int pos = t; pos < m; pos += T) {
           const unsigned long long kv = ld_coherent((const uint64_t WG_G*)out + pos);
-          h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(uint32_t)kv);
+          h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(uint32_t)kv, (uint32_t)(kv >> 32));
           mineB += pos == 0 || (uint32_t)(kv >> 32) != (uint32_t)(ld_coherent((const uint64_t WG_G*)out + (pos - 1)) >> 32);
         }
         mineB = wave_reduce_add32(mineB);
@@ -3341,7 +3462,7 @@ __global__ void __launch_bounds__(1024) k_handel_init_sort(HandelState s, const 
       uint32_t mine = 0;
       for (int pos = threadIdx.x; pos < m; pos += blockDim.x) {
         const uint32_t kv = key[pos];
-        h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(kv & (uint32_t)(m - 1)));
+        h_peer_store(s, (size_t)snd * (N - 1) + (m - 1) + pos, base + (int32_t)(kv & (uint32_t)(m - 1)), kv >> idBits);
         mine += pos == 0 || (kv >> idBits) != (key[pos - 1] >> idBits);  // a bucket starts here
       }
       mine = wave_reduce_add32(mine);
@@ -3399,9 +3520,9 @@ __global__ void __launch_bounds__(256) k_handel_init_shuffle(HandelState s, cons
             int consumed;
             const int32_t j = lcg_next_int_bounded(st, k, &consumed);
             if (consumed != 1) atomicOr(rejected, 1u);
-            const int32_t a = h_peer(s, at + pos + k - 1), b = h_peer(s, at + pos + j);
-            h_peer_store(s, at + pos + k - 1, b);
-            h_peer_store(s, at + pos + j, a);
+            const int32_t a = h_peer(s, at + pos + k - 1), b = h_peer(s, at + pos + j);  // (one bucket: the same rank)
+            h_peer_store(s, at + pos + k - 1, b, (uint32_t)rk);
+            h_peer_store(s, at + pos + j, a, (uint32_t)rk);
           }
         }
         __syncthreads();
