@@ -2569,6 +2569,7 @@ struct HandelHost : ProtoHost {
     st.disCount = e.dalloc<uint32_t>(1);
     st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
+    st.exp = getenv("WG_EXP") ? atoi(getenv("WG_EXP")) : 0;
     st.a1Group = !(getenv("WG_A1_GROUP") && atoi(getenv("WG_A1_GROUP")) == 0);
     st.updTrail = !(getenv("WG_UPD_TRAIL") && atoi(getenv("WG_UPD_TRAIL")) == 0);
     st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;

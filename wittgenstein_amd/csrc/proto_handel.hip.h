@@ -99,6 +99,7 @@ struct HandelState {
   GP<const uint32_t> peersR;              // [N][N-1] id | rank << 16
   GP<uint32_t> bump;                      // [N][bumpCap]
   int32_t bumpCap;                        // a power of two <= N (wg_config.rank_bump_cap; a full table is a loud error)
+  int32_t exp;                            // TEMP experiments (WG_EXP bit mask)
   // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
   // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
@@ -697,6 +698,7 @@ struct HandelProtoT {
     const int w = (from >> 6) - v.bw;  // the word of `from` inside the level's block
     const uint64_t bit = 1ULL << (from & 63);
     uint64_t WG_G* dp = h_dword(s, node, l, w);  // {SEEN, FP, BUMP} words holding `from`: one 32-byte piece
+    const uint64_t seenW = ld_coherent(dp + HD_SEEN), fpW = ld_coherent(dp + HD_FP);
     // receptionRanks[from], read at receive time (:784)
     int32_t rank;
     if (s.ranks)
@@ -711,9 +713,9 @@ struct HandelProtoT {
     const bool has0 = j0 < v.nw;
     uint64_t pw0 = 0;
     if (has0) pw0 = src[j0] & v.mask;
-    if (WG_LANE == 0) {  // (no-return atomics: nothing of the piece but BUMP is waited for)
-      if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);  // finishedPeers.set(from)
-      atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);  // toVerifyInd.set(from) unless verified: SEEN & ~VI (file header)
+    if (WG_LANE == 0) {  // (plain stores: this wavefront is the node's only writer in its launch; an L2 atomic costs several stores)
+      if (levelFinished && !(fpW & bit)) dp[HD_FP] = fpW | bit;  // finishedPeers.set(from)
+      if (!(seenW & bit)) dp[HD_SEEN] = seenW | bit;              // toVerifyInd.set(from) unless verified: SEEN & ~VI (file header)
     }
     r.sigQueueSize++;
     // toVerifyAgg.add(new SigToVerify(from, level, receptionRanks[from], cs, badSig))
@@ -1106,7 +1108,8 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   const int w = (from >> 6) - sib_view(node, l).bw;  // the word of `from` inside the level's block
   const uint64_t bit = 1ULL << (from & 63);
   uint64_t WG_G* dp = h_dword(s, node, l, w);  // the {SEEN, FP, BUMP} words holding `from`: one 32-byte piece
-  // every load of the event before the first use: the BUMP word (CARRIED ranks) or the matrix entry, the record's head
+  // every load of the event before the first use: the piece's words (BUMP: CARRIED ranks only) or the matrix entry, the record's head
+  const V2 sf = gld((const V2 WG_G*)dp);  // {SEEN, FP}
   const uint64_t bumpW = s.ranks ? 0ULL : dp[HD_BUMP];
   const int32_t rankM = s.ranks ? s.ranks[(size_t)node * s.N + from] : 0;
   uint64_t WG_G* qr = h_qrec(s, node, l);
@@ -1117,9 +1120,18 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   const uint64_t WG_G* src = h_payload(d, s, payload);
   const int nw = h_nw(l);
   const uint64_t pw0 = nw == 1 ? src[0] & sib_view(node, l).mask : 0ULL;
-  // (no-return atomics: the bits are set at L2, no lane waits for the words)
-  if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);  // finishedPeers.set(from)
-  atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);  // toVerifyInd.set(from) unless verified = SEEN & ~VI (file header)
+  // finishedPeers.set(from) if levelFinished; toVerifyInd.set(from) unless verified = SEEN & ~VI (file header). Plain stores of
+  // the loaded words: this lane is the node's only writer in its launch, and an L2 atomic costs several stores
+  // (profiles/r20e: three atomics a node were 22 of the kernel's 92 us)
+  if (s.exp & 2) {
+    if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);
+    atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);
+  } else if (!(sf.x & bit) || (levelFinished && !(sf.y & bit))) {
+    V2 nsf;
+    nsf.x = sf.x | bit;
+    nsf.y = levelFinished ? (sf.y | bit) : sf.y;
+    gst((V2 WG_G*)dp, nsf);
+  }
   const int32_t rank = s.ranks ? rankM : h_rank_at_delivery(s, node, from, msg, bumpW);  // receptionRanks[from], read at receive time (:784)
   r.sigQueueSize++;
   const int qc = h_qcap(s, l);
@@ -1278,6 +1290,36 @@ __device__ __forceinline__ int h_lane_update(const EngineDev& d, const HandelSta
   return (cTI == v.size && mayComplete) ? H_UPD_DEFER : H_UPD_DONE;  // justCompleted
 }
 
+// A lane's visit ends: what it changed of the header's first line goes back as the 16-byte pieces it loaded (h0 = words
+// 0..3, h2 = 8..11, h3 = 12..15) — the lane is the node's only writer in its launch, so the counters (Node.msgReceived /
+// bytesReceived, C/Network.java:611-612) and the dirty-level mask are plain stores of loaded value + delta, not three
+// atomics a node (565 k L2 atomics per launch at 24 copies: profiles/r20d_pmc_req.md)
+__device__ __forceinline__ void h_lane_store_header(uint32_t WG_G* hdr, const HLaneNode& r, const U4& h0, const U4& h2, const U4& h3,
+                                                    long long nRecv, long long bRecv) {
+  if (r.sigQueueSize != r.sigQueueSize0 || r.msgFiltered != r.msgFiltered0) {
+    U4 n0 = h0;
+    n0.y = (uint32_t)r.sigQueueSize;
+    n0.z = (uint32_t)r.msgFiltered;
+    gst((U4 WG_G*)hdr, n0);
+  }
+  if (nRecv || r.qmask != r.qmask0 || r.doneAt != r.doneAt0) {
+    U4 n2;
+    n2.x = h2.x + (uint32_t)nRecv;
+    n2.y = (uint32_t)(unsigned long long)r.doneAt;
+    n2.z = (uint32_t)((unsigned long long)r.doneAt >> 32);
+    n2.w = r.qmask;
+    gst((U4 WG_G*)(hdr + 8), n2);
+  }
+  if (nRecv || r.qdirty) {
+    const unsigned long long br = ((unsigned long long)h3.x | ((unsigned long long)h3.y << 32)) + (unsigned long long)bRecv;
+    U4 n3 = h3;
+    n3.x = (uint32_t)br;
+    n3.y = (uint32_t)(br >> 32);
+    n3.w |= r.qdirty;
+    gst((U4 WG_G*)(hdr + 12), n3);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
@@ -1297,7 +1339,9 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     InboxEntry E[INBOX_SLOTS];
 #pragma unroll
     for (int k = 0; k < INBOX_SLOTS; k++) E[k].e = 0xFFFFFFFFu, E[k].w0 = 0, E[k].w2 = 0, E[k].w3 = 0;
-    U4 h0, h2;  // header words 0..3 {addedCycle, sigQueueSize, msgFiltered, startAt} and 8..11 {msgReceived, doneAt lo, hi, queue mask}
+    // header words 0..3 {addedCycle, sigQueueSize, msgFiltered, startAt}, 8..11 {msgReceived, doneAt lo, hi, queue mask} and
+    // 12..15 {bytesReceived lo, hi, msgSent, dirty levels}: pieces of ONE line, written back as pieces (h_lane_store_header)
+    U4 h0, h2;
     h0.x = h0.y = h0.z = h0.w = 0;
     h2 = h0;
     uint32_t total = 0;
@@ -1310,7 +1354,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
       const uint32_t WG_G* hdr = h_hdr(s, node);
       h0 = gld((const U4 WG_G*)hdr);
       h2 = gld((const U4 WG_G*)(hdr + 8));
-      total = gld((const U4 WG_G*)(hdr + 4)).w;  // HH_TOTAL (the three pieces are one 64-byte line)
+      total = gld((const U4 WG_G*)(hdr + 4)).w;  // HH_TOTAL (the four pieces are one 64-byte line)
     }
     // the node's events in event order (the line is in arrival order of the expand lanes)
 #pragma unroll
@@ -1498,20 +1542,14 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     }
     if (mine) {
       uint32_t WG_G* hdr = h_hdr(s, node);
-      if (r.sigQueueSize != r.sigQueueSize0) hdr[HH_SIGQ] = (uint32_t)r.sigQueueSize;
-      if (r.msgFiltered != r.msgFiltered0) hdr[HH_FILT] = (uint32_t)r.msgFiltered;
-      if (r.qmask != r.qmask0) hdr[HH_QMASK] = r.qmask;
-      if (r.qdirty) atomicOr(F(hdr + HH_QDIRTY), r.qdirty);  // (no value comes back: the word is not among the pieces loaded)
       if (r.total != r.total0) hdr[HH_TOTAL] = (uint32_t)r.total;
-      if (r.doneAt != r.doneAt0) {
-        hdr[HH_DONE_LO] = (uint32_t)(unsigned long long)r.doneAt;
-        hdr[HH_DONE_HI] = (uint32_t)((unsigned long long)r.doneAt >> 32);
-        d.nodes.doneAt[node] = r.doneAt;
-      }
-      if (nRecv) {  // Node.msgReceived / bytesReceived (C/Network.java:611-612), kept in the header record
-        atomicAdd(F(hdr + HH_NRECV), (uint32_t)nRecv);
-        atomicAdd((unsigned long long*)F(hdr + HH_BRECV), (unsigned long long)bRecv);
-      }
+      if (r.doneAt != r.doneAt0) d.nodes.doneAt[node] = r.doneAt;
+      // (piece 12..15 is fetched only now — the line is in L2 since the visit's first load — so that it does not hold
+      // four registers through the events: the kernel sits at the edge of three waves per SIMD)
+      U4 h3;
+      h3.x = h3.y = h3.z = h3.w = 0;
+      if (nRecv || r.qdirty) h3 = gld((const U4 WG_G*)(hdr + 12));
+      h_lane_store_header(hdr, r, h0, h2, h3, nRecv, bRecv);
     }
     {  // the node's wide updateVerifiedSignatures: an item of k_handel_update
       bool upd = false;
@@ -1897,16 +1935,12 @@ __global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restric
       }
       h_emit_job(s, job);
     }
-    if (have) {  // (sigQueueSize / msgFiltered: k_handel_update does not write them; the queue mask it may have cleared a bit of)
-      uint32_t WG_G* hdr = h_hdr(s, node);
-      if (r.sigQueueSize != r.sigQueueSize0) hdr[HH_SIGQ] = (uint32_t)r.sigQueueSize;
-      if (r.msgFiltered != r.msgFiltered0) hdr[HH_FILT] = (uint32_t)r.msgFiltered;
-      if (r.qmask != r.qmask0) hdr[HH_QMASK] = r.qmask;
-      if (r.qdirty) atomicOr(F(hdr + HH_QDIRTY), r.qdirty);
-      if (nRecv) {
-        atomicAdd(F(hdr + HH_NRECV), (uint32_t)nRecv);
-        atomicAdd((unsigned long long*)F(hdr + HH_BRECV), (unsigned long long)bRecv);
-      }
+    // (the header as k_handel_update / k_handel_dissem left it — this lane is the node's only writer in this launch)
+    if (have) {
+      U4 h3;
+      h3.x = h3.y = h3.z = h3.w = 0;
+      if (nRecv || r.qdirty) h3 = gld((const U4 WG_G*)(h_hdr(s, node) + 12));
+      h_lane_store_header(h_hdr(s, node), r, h0, h2, h3, nRecv, bRecv);
     }
   }
 }
