@@ -117,6 +117,16 @@ def split_batches(w, sims, k):
     return [w.Batch([g.network() for g in sims[i:i + per]]) for i in range(0, len(sims), per)]
 
 
+def _cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
     """the C++ oracle (event-for-event restatement of the single-threaded Java path) on one host core"""
     o = _oracle()
@@ -133,7 +143,8 @@ def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
                 "sample": "GSFSignature %d nodes (seed 0), full run to the stop predicate: %d delivered messages, %d "
                           "simulated ms in %.2f s on one host core (C++ oracle, upper bound on the JVM path)"
                           % (n_sample, info["delivered"], info["time"], dt),
-                "simulated_ms_per_s": info["time"] / dt}
+                "simulated_ms_per_s": info["time"] / dt, "nproc": len(os.sched_getaffinity(0)), "cpu_model": _cpu_model(),
+                "all_cores": {"skipped": "the side workload's baseline is the one-core figure"}}
     hp = handel_params(n_sample)
     c = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                  hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0, seed=0)
@@ -164,6 +175,12 @@ def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
         cores = max(1, min(len(os.sched_getaffinity(0)), 64, int(0.25 * avail / (64.0 * n_sample * n_sample + (1 << 30)))))
     except Exception:
         cores = 1
+    out["nproc"] = len(os.sched_getaffinity(0))
+    out["cpu_model"] = _cpu_model()
+    if not (cores > 1 and all_cores):
+        out["all_cores"] = {"skipped": "one oracle copy of %d nodes holds ~ %.0f GB at its peak and a quarter of the host's available "
+                                       "memory holds %d of them" % (n_sample, 64.0 * n_sample * n_sample / 1e9, cores)
+                            if all_cores else "not requested"}
     if cores > 1 and all_cores:
         def one(seed):
             cc = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
@@ -511,7 +528,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
-    ap.add_argument("--replicas", type=int, default=24, help="independent simulations per step and per GPU (lowered to what fits the free HBM)")
+    ap.add_argument("--replicas", type=int, default=32, help="independent simulations per step and per GPU (lowered to what fits the free HBM: 28 of config 3 since round 5)")
     ap.add_argument("--batches", type=int, default=0,
                     help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
                          "thread each); 0 = 1: the whole step as one batch on one stream, so that a launch of the delivery kernels "

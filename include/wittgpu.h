@@ -33,6 +33,15 @@ typedef struct wg_engine wg_engine;
 #define WG_ABI_VERSION 5
 int32_t wg_abi_version(void);
 int32_t wg_abi_struct_size(int32_t which);
+/* One wave / block primitive of the device kernels (DPP reductions and scans, the 8-lane group forms, the ballot multisplit
+ * rank) run on the caller's values by a test-only kernel, so that a test can hold it against a host computation — the
+ * primitives have no reference counterpart; they are what the per-ms kernels are built from. op: 0 wave sum (32 bit), 1 wave
+ * sum (64), 2 wave min (int32), 3 wave max, 4 inclusive scan (32), 5 inclusive scan (64), 6 broadcast of lane aux (32), 7 (64),
+ * 8 sum / 9 or (64 bit) / 10 min / 11 max (int32) inside groups of eight lanes, 12 block exclusive scan (32 bit; out[threads]
+ * = the total), 13 stable rank among equal bins (in[i] = bin | valid << 32, aux = bits of a bin; out[threads + b] = bin b's
+ * count), 14 shuffle from lane (i + aux) % 64, 15 block sum (64). in[n], n <= threads (the rest: zeros / the identity);
+ * threads: 64 for the wave forms, a multiple of 64 up to 1024 for the block forms. Needs no engine; wg_last_error(NULL). */
+int32_t wg_selftest(int32_t op, int32_t aux, const uint64_t* in, int32_t n, int32_t threads, uint64_t* out, int32_t n_out);
 
 typedef enum {
   WG_OK = 0,
@@ -168,7 +177,7 @@ typedef struct {
  * 2..blockProducersCount the other producers, then cycleLength * attestersPerRound attesters (:481-509).
  * randomOnTies (:250-253; the reference's default is true) is honoured: the tie's rd.nextBoolean() decides a head inside
  * action(), so once the chain has forked the events that can call best() are delivered by one wavefront in global event
- * order (exact; the parallel path until then) — WG_EUNSUPPORTED only together with node-range sharding. init() =
+ * order (exact; the parallel path until then; on a sharded engine the ordered visit goes round the shards, see wg_shard_configure). init() =
  * wg_register_periodic_task per node in the reference's order: task words 2 (byzantine producer), 0 (producer), 1 (attester). */
 typedef struct {
   int32_t cycleLength, randomOnTies, blockProducersCount, attestersPerRound, blockConstructionTime,
@@ -317,6 +326,14 @@ typedef struct {
 } wg_step_op;
 int32_t wg_step_begin(wg_engine* e, int32_t until, int32_t cond_time, wg_delivery* out, int32_t cap, int32_t* n);
 int32_t wg_step_end(wg_engine* e, const wg_step_op* ops, int32_t nops, const int32_t* dests);
+/* Handles whose envelope has ENDED since the last call, oldest first (at most cap; *n of them): the message / task handle of
+ * every envelope made by wg_send, wg_send_arrive_at, wg_register_task or a step op is reported exactly once — after its one
+ * destination was handed out or consumed (C/Network.java:606), after the last hop of a multi-destination envelope was
+ * (:629-632 finds hasNextReader() false), or at once when no destination was reachable at send time (:469-487). It is where
+ * the reference lets go of its Envelope: a binding that maps handles to Message objects releases them here (a handle sent
+ * k times is reported k times). A handle reported together with its last delivery is released AFTER that delivery is
+ * applied. Host-callback mode only. */
+int32_t wg_host_released(wg_engine* e, uint32_t* msgs, int32_t cap, int32_t* n);
 
 /* ---- batches: RunMultipleTimes on the device ------------------------------------------------ */
 /* The reference's way to run many simulations is C/RunMultipleTimes.java:44-64: for each of runCount
@@ -329,6 +346,7 @@ typedef struct wg_batch wg_batch;
 int32_t wg_batch_create(wg_engine** engines, int32_t n, wg_batch** out);
 void wg_batch_destroy(wg_batch* b);
 const char* wg_batch_last_error(wg_batch* b);       /* b may be NULL: error of a failed wg_batch_create */
+int32_t wg_batch_size(wg_batch* b, int32_t* n);     /* members of the batch: the length of every per-member array below */
 /* Network.runMs(ms) on every member with active[i] != 0 (NULL = all); the others are not advanced
  * (a copy whose predicate turned false stops, C/RunMultipleTimes.java:56-61). didSomething / stats: [n] or NULL. */
 int32_t wg_batch_run_ms(wg_batch* b, int32_t ms, const uint8_t* active, uint8_t* didSomething, wg_run_stats* stats);
@@ -364,7 +382,10 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * collective per change of owner among them — exact, slow).
  * wg_read_i64 on a shard returns its own nodes' values and zeros for the others (sum across shards for the whole
  * network); wg_run_stats counts are whole-network on every shard. WG_EUNSUPPORTED for a protocol that does not
- * shard yet, batches, and host-callback mode. */
+ * shard yet, batches, and host-callback mode.
+ * Limits of a sharded engine (loud, WG_EUNSUPPORTED "sharded engine: one event ..."): an event's result travels as ONE
+ * packed int32 word (records 10 bits, draws 11 bits), so a single action() may emit at most 1023 records and make at
+ * most 2047 rd draws — far beyond what the resident protocols do (Handel: one record per level). */
 int32_t wg_shard_configure(wg_engine* e, int32_t shard, int32_t nshards, wg_allreduce_fn allreduce, void* ctx);
 /* The same with the collective OWNED BY THE ENGINE: an RCCL communicator over the box's GPUs (xGMI), created from a
  * unique id that shard 0's process obtains with wg_rccl_unique_id and hands to the other processes by whatever channel

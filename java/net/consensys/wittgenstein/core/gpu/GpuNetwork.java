@@ -36,7 +36,15 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
 
   private boolean resident = false, ready = false;
   private final String latencyName;
-  private final ArrayList<Message<? extends TN>> byHandle = new ArrayList<>(); // handle -> Message (0 unused)
+  // handle -> Message, for as long as an envelope of it is in flight: the engine reports the end of every envelope
+  // (WittGpu.hostReleased) and the object is let go with its last one — where the reference lets go of its Envelope. (Round 4
+  // kept every Message of a run: 1e7 - 1e8 of them in a Handel run of a few thousand nodes, and an int that overflows.)
+  private final ArrayList<Message<? extends TN>> byHandle = new ArrayList<>(); // (0 unused)
+  private final java.util.IdentityHashMap<Message<? extends TN>, Integer> handleOfObj = new java.util.IdentityHashMap<>();
+  private int[] refs = new int[1024]; // handle -> envelopes in flight (a re-armed PeriodicTask, a Message sent twice: one handle)
+  private int[] free = new int[1024];
+  private int nFree = 0;
+  private final int[] released = new int[1024];
   private final List<ConditionalTask<TN>> condTasks = new ArrayList<>(); // Network.conditionalTasks is private there
 
   // a batched step (wg_step_begin .. wg_step_end): the pushes of the action()s, ten ints an op (wg_step_op)
@@ -134,9 +142,43 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
     ready = true;
   }
 
+  /** the handle an envelope of {@code m} travels under: one more envelope of it in flight */
   private int handleOf(Message<? extends TN> m) {
-    byHandle.add(m);
-    return byHandle.size() - 1;
+    Integer known = handleOfObj.get(m);
+    int h;
+    if (known != null) {
+      h = known;
+    } else {
+      if (nFree > 0) {
+        h = free[--nFree];
+        byHandle.set(h, m);
+      } else {
+        byHandle.add(m);
+        h = byHandle.size() - 1;
+        if (h >= refs.length) refs = java.util.Arrays.copyOf(refs, refs.length * 2);
+      }
+      handleOfObj.put(m, h);
+      refs[h] = 0;
+    }
+    refs[h]++;
+    return h;
+  }
+
+  private void unref(int h) {
+    if (--refs[h] > 0) return;
+    handleOfObj.remove(byHandle.get(h));
+    byHandle.set(h, null);
+    if (nFree == free.length) free = java.util.Arrays.copyOf(free, free.length * 2);
+    free[nFree++] = h;
+  }
+
+  /** envelopes that ended since the last call (wg_host_released): their Messages are forgotten with their last envelope */
+  private void drainReleased() {
+    int n;
+    do {
+      n = WittGpu.hostReleased(handle, released);
+      for (int i = 0; i < n; i++) unref(released[i]);
+    } while (n == released.length);
   }
 
   /** Node.stop() / start() of a node of a running network (C/Node.java:120-131) */
@@ -297,7 +339,9 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
     if (time == 0) for (Node n : allNodes) if (!n.isDown()) n.start();
     int endAt = time + ms;
     if (endAt <= 0) throw new IllegalStateException("Maximum time reached!");
+    drainReleased(); // (sends of init() that reached no destination)
     boolean did = receiveUntilGpu(endAt);
+    drainReleased(); // (envelopes whose last hop was consumed, not delivered: no delivery showed their end)
     time = endAt;
     WittGpu.setTime(handle, endAt);
     return did;
@@ -371,7 +415,17 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
         stepOpen = false;
         WittGpu.rngSetState(handle, stateOf(rd));
       }
-      WittGpu.stepEnd(handle, ops == null ? new int[0] : ops, nops, opDests);
+      try {
+        WittGpu.stepEnd(handle, ops == null ? new int[0] : ops, nops, opDests);
+      } catch (RuntimeException refused) {
+        // wg_step_end refuses a step as a whole and leaves it open (nothing applied): close it without the action()s' pushes —
+        // the multi-destination envelopes' owed re-pushes are kept —, forget the envelopes that were never made, report
+        WittGpu.stepEnd(handle, new int[0], 0, opDests);
+        for (int k = 0; k < nops; k++) unref(ops[10 * k + 2]);
+        drainReleased();
+        throw failed != null ? failed : refused;
+      }
+      drainReleased();
       if (failed != null) throw failed;
     }
     return did;

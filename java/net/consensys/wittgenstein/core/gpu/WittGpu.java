@@ -44,6 +44,9 @@ public final class WittGpu {
 
   public static native int abiStructSize(int which);
 
+  /** wg_selftest: one wave / block primitive of the device kernels run on the caller's values (include/wittgpu.h) */
+  public static native int selfTest(int op, int aux, long[] in, int n, int threads, long[] out);
+
   // ---- lifecycle. cfgInts = {device, horizon_ms, queue_cap, queue_cap_wide, chain_slots, shard, nshards, rank_bump_cap} (null / shorter:
   // zeros = defaults), cfgLongs = {bucket_pool_records, payload_words, outbox_records, chain_dests}, rcclId = null or 128 bytes
   public static native long create(int[] cfgInts, long[] cfgLongs, byte[] rcclId);
@@ -129,12 +132,18 @@ public final class WittGpu {
 
   public static native int stepEnd(long h, int[] ops10, int nops, int[] dests);
 
+  /** wg_host_released: handles whose envelope ended since the last call, oldest first, at most out.length; returns how many */
+  public static native int hostReleased(long h, int[] out);
+
   // ---- batches
   public static native long batchCreate(long[] handles);
 
   public static native void batchDestroy(long batch);
 
   public static native String batchLastError(long batch);
+
+  /** members of the batch: the length every per-member array of the calls below must have */
+  public static native int batchSize(long batch);
 
   public static native int batchRunMs(long batch, int ms, byte[] active, byte[] didSomething, long[] stats7n);
 

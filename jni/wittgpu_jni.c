@@ -46,6 +46,23 @@ static jint ck_batch(JNIEnv* env, wg_batch* b, int32_t rc) {
   return rc;
 }
 
+/* A Java array shorter than what the engine reads or writes through it is an IllegalArgumentException HERE, before anything is
+ * pinned — not a native out-of-bounds access into the JVM heap. NULL arrays are the ABI's "not wanted" and pass. */
+static int need(JNIEnv* env, jarray a, jlong want, const char* what) {
+  if (!a) return 1;
+  if (want >= 0 && (jlong)(*env)->GetArrayLength(env, a) >= want) return 1;
+  throw_msg(env, WG_EINVAL, what);
+  return 0;
+}
+static jlong batch_members(JNIEnv* env, wg_batch* b) {
+  int32_t n = 0;
+  if (wg_batch_size(b, &n) != WG_OK) {
+    throw_msg(env, WG_EINVAL, "not a batch");
+    return -1;
+  }
+  return n;
+}
+
 /* read-only views of Java arrays (NULL array -> NULL pointer) */
 #define PIN_I(a) ((a) ? (*env)->GetIntArrayElements(env, (a), NULL) : NULL)
 #define UNPIN_I(a, p) do { if (a) (*env)->ReleaseIntArrayElements(env, (a), (p), JNI_ABORT); } while (0)
@@ -105,6 +122,19 @@ JNIEXPORT jint JNICALL JNI_OnLoad(JavaVM* vm, void* reserved) {
 }
 WG_JNI(jint, abiVersion)(JNIEnv* env, jclass c) { (void)env; (void)c; return wg_abi_version(); }
 WG_JNI(jint, abiStructSize)(JNIEnv* env, jclass c, jint which) { (void)env; (void)c; return wg_abi_struct_size(which); }
+/* wg_selftest: one wave / block primitive of the device kernels on the caller's values (tests) */
+WG_JNI(jint, selfTest)(JNIEnv* env, jclass c, jint op, jint aux, jlongArray in, jint n, jint threads, jlongArray out) {
+  (void)c;
+  if (!in || !out || n < 0 || !need(env, in, n, "selfTest: in holds fewer than n values")) {
+    if (!in || !out || n < 0) throw_msg(env, WG_EINVAL, "selfTest: in / out / n");
+    return WG_EINVAL;
+  }
+  jlong *pi = PIN_J(in), *po = PIN_J(out);
+  int32_t rc = wg_selftest(op, aux, (const uint64_t*)pi, n, threads, (uint64_t*)po, LEN(out));
+  UNPIN_J(in, pi); COMMIT_J(out, po);
+  if (rc != WG_OK) throw_msg(env, rc, wg_last_error(NULL));
+  return rc;
+}
 
 /* ---- lifecycle: new Network<>() C/Network.java:14-49 ---- */
 WG_JNI(jlong, create)(JNIEnv* env, jclass c, jintArray cfgInts, jlongArray cfgLongs, jbyteArray rcclId) {
@@ -125,6 +155,11 @@ WG_JNI(jint, addNodes)(JNIEnv* env, jclass c, jlong h, jintArray x, jintArray y,
                        jbyteArray byzantine, jdoubleArray speed) {  /* Network.addNode C/Network.java:651-659 */
   (void)c;
   jsize n = LEN(x);
+  if (!x || !y) { throw_msg(env, WG_EINVAL, "addNodes: x and y are required"); return WG_EINVAL; }
+  if (!need(env, y, n, "addNodes: y is shorter than x") || !need(env, extra, n, "addNodes: extraLatency is shorter than x") ||
+      !need(env, down, n, "addNodes: down is shorter than x") || !need(env, byzantine, n, "addNodes: byzantine is shorter than x") ||
+      !need(env, speed, n, "addNodes: speedRatio is shorter than x"))
+    return WG_EINVAL;
   jint *px = PIN_I(x), *py = PIN_I(y), *pe = PIN_I(extra);
   jbyte *pd = PIN_B(down), *pb = PIN_B(byzantine);
   jdouble* ps = PIN_D(speed);
@@ -160,6 +195,10 @@ WG_JNI(jint, setLatencyByName)(JNIEnv* env, jclass c, jlong h, jstring name) {  
 }
 WG_JNI(jint, latencyProbe)(JNIEnv* env, jclass c, jlong h, jintArray from, jintArray to, jintArray delta, jintArray out) {
   (void)c;
+  if (!from || !to || !delta || !out) { throw_msg(env, WG_EINVAL, "latencyProbe: four arrays"); return WG_EINVAL; }
+  if (!need(env, to, LEN(from), "latencyProbe: to is shorter than from") || !need(env, delta, LEN(from), "latencyProbe: delta is shorter than from") ||
+      !need(env, out, LEN(from), "latencyProbe: out is shorter than from"))
+    return WG_EINVAL;
   jint *pf = PIN_I(from), *pt = PIN_I(to), *pd = PIN_I(delta), *po = PIN_I(out);
   int32_t rc = wg_latency_probe(ENG(h), LEN(from), (const int32_t*)pf, (const int32_t*)pt, (const int32_t*)pd, (int32_t*)po);
   UNPIN_I(from, pf); UNPIN_I(to, pt); UNPIN_I(delta, pd); COMMIT_I(out, po);
@@ -350,10 +389,31 @@ WG_JNI(jint, stepBegin)(JNIEnv* env, jclass c, jlong h, jint until, jint condTim
 /* ops10: nops records of 10 ints in wg_step_op's field order; dests: the destination lists the ops index into */
 WG_JNI(jint, stepEnd)(JNIEnv* env, jclass c, jlong h, jintArray ops10, jint nops, jintArray dests) {
   (void)c;
+  if (nops < 0 || (nops > 0 && !ops10) || !need(env, ops10, (jlong)nops * 10, "stepEnd: ops10 holds fewer than nops records"))
+    { if (nops < 0 || (nops > 0 && !ops10)) throw_msg(env, WG_EINVAL, "stepEnd: nops"); return WG_EINVAL; }
   jint *po = PIN_I(ops10), *pd = PIN_I(dests);
+  const jlong nd = LEN(dests);
+  for (jint i = 0; i < nops; i++) {  /* a list send's destinations lie inside `dests` (wg_step_op: to = offset, n = count) */
+    const jint kind = po[i * 10 + 1], to = po[i * 10 + 6], n = po[i * 10 + 7];
+    if (kind == WG_OP_SEND && n > 1 && (to < 0 || (jlong)to + n > nd)) {
+      UNPIN_I(ops10, po); UNPIN_I(dests, pd);
+      throw_msg(env, WG_EINVAL, "stepEnd: an op's destination list lies outside dests");
+      return WG_EINVAL;
+    }
+  }
   int32_t rc = wg_step_end(ENG(h), (const wg_step_op*)po, nops, (const int32_t*)pd);  /* wg_step_op IS ten 32-bit words */
   UNPIN_I(ops10, po); UNPIN_I(dests, pd);
   return ck(env, ENG(h), rc);
+}
+
+WG_JNI(jint, hostReleased)(JNIEnv* env, jclass c, jlong h, jintArray out) {
+  (void)c;
+  if (!out) { throw_msg(env, WG_EINVAL, "hostReleased: out is required"); return -1; }
+  jint* p = PIN_I(out);
+  int32_t n = 0;
+  int32_t rc = wg_host_released(ENG(h), (uint32_t*)p, LEN(out), &n);
+  COMMIT_I(out, p);
+  return ck(env, ENG(h), rc) == WG_OK ? n : -1;
 }
 
 /* ---- batches: RunMultipleTimes on the device (C/RunMultipleTimes.java:44-64) ---- */
@@ -372,8 +432,17 @@ WG_JNI(jlong, batchCreate)(JNIEnv* env, jclass c, jlongArray handles) {
 }
 WG_JNI(void, batchDestroy)(JNIEnv* env, jclass c, jlong b) { (void)env; (void)c; wg_batch_destroy(BAT(b)); }
 WG_JNI(jstring, batchLastError)(JNIEnv* env, jclass c, jlong b) { (void)c; return (*env)->NewStringUTF(env, wg_batch_last_error(BAT(b))); }
+WG_JNI(jint, batchSize)(JNIEnv* env, jclass c, jlong b) {
+  (void)c;
+  return (jint)batch_members(env, BAT(b));
+}
 WG_JNI(jint, batchRunMs)(JNIEnv* env, jclass c, jlong b, jint ms, jbyteArray active, jbyteArray didSomething, jlongArray stats7n) {
   (void)c;
+  const jlong n = batch_members(env, BAT(b));
+  if (n < 0 || !need(env, active, n, "batchRunMs: active is shorter than the batch") ||
+      !need(env, didSomething, n, "batchRunMs: didSomething is shorter than the batch") ||
+      !need(env, stats7n, 7 * n, "batchRunMs: stats7n holds fewer than 7 longs per member"))
+    return WG_EINVAL;
   jbyte *pa = PIN_B(active), *pd = PIN_B(didSomething);
   jlong* ps = PIN_J(stats7n);
   int32_t rc = wg_batch_run_ms(BAT(b), ms, (const uint8_t*)pa, (uint8_t*)pd, (wg_run_stats*)ps);
@@ -382,6 +451,11 @@ WG_JNI(jint, batchRunMs)(JNIEnv* env, jclass c, jlong b, jint ms, jbyteArray act
 }
 WG_JNI(jint, batchContIf)(JNIEnv* env, jclass c, jlong b, jintArray cont) {
   (void)c;
+  const jlong n = batch_members(env, BAT(b));
+  if (n < 0 || !cont || !need(env, cont, n, "batchContIf: cont is shorter than the batch")) {
+    if (n >= 0 && !cont) throw_msg(env, WG_EINVAL, "batchContIf: cont is required");
+    return WG_EINVAL;
+  }
   jint* p = PIN_I(cont);
   int32_t rc = wg_batch_cont_if(BAT(b), (int32_t*)p);
   COMMIT_I(cont, p);
@@ -389,6 +463,10 @@ WG_JNI(jint, batchContIf)(JNIEnv* env, jclass c, jlong b, jintArray cont) {
 }
 WG_JNI(jint, batchRunMultipleTimes)(JNIEnv* env, jclass c, jlong b, jint chunk, jint maxTime, jlongArray delivered, jlongArray simulatedMs) {
   (void)c;
+  const jlong n = batch_members(env, BAT(b));
+  if (n < 0 || !need(env, delivered, n, "batchRunMultipleTimes: delivered is shorter than the batch") ||
+      !need(env, simulatedMs, n, "batchRunMultipleTimes: simulatedMs is shorter than the batch"))
+    return WG_EINVAL;
   jlong *pd = PIN_J(delivered), *ps = PIN_J(simulatedMs);
   int32_t rc = wg_batch_run_multiple_times(BAT(b), chunk, maxTime, (int64_t*)pd, (int64_t*)ps);
   COMMIT_J(delivered, pd); COMMIT_J(simulatedMs, ps);
@@ -446,6 +524,10 @@ WG_JNI(jint, readI32)(JNIEnv* env, jclass c, jlong h, jint field, jintArray dst)
 }
 WG_JNI(jint, readLevelI32)(JNIEnv* env, jclass c, jlong h, jint field, jintArray dst, jint nNodes, jint nLevels) {
   (void)c;
+  if (!dst || nNodes < 0 || nLevels < 0 || !need(env, dst, (jlong)nNodes * nLevels, "readLevelI32: dst holds fewer than nNodes * nLevels ints")) {
+    if (!dst || nNodes < 0 || nLevels < 0) throw_msg(env, WG_EINVAL, "readLevelI32: dst / shape");
+    return WG_EINVAL;
+  }
   jint* p = PIN_I(dst);
   int32_t rc = wg_read_level_i32(ENG(h), field, (int32_t*)p, nNodes, nLevels);
   COMMIT_I(dst, p);
@@ -453,6 +535,10 @@ WG_JNI(jint, readLevelI32)(JNIEnv* env, jclass c, jlong h, jint field, jintArray
 }
 WG_JNI(jint, readBits)(JNIEnv* env, jclass c, jlong h, jint field, jlongArray dst, jint nNodes, jint wordsPerNode) {
   (void)c;
+  if (!dst || nNodes < 0 || wordsPerNode < 0 || !need(env, dst, (jlong)nNodes * wordsPerNode, "readBits: dst holds fewer than nNodes * wordsPerNode longs")) {
+    if (!dst || nNodes < 0 || wordsPerNode < 0) throw_msg(env, WG_EINVAL, "readBits: dst / shape");
+    return WG_EINVAL;
+  }
   jlong* p = PIN_J(dst);
   int32_t rc = wg_read_bits(ENG(h), field, (uint64_t*)p, nNodes, wordsPerNode);
   COMMIT_J(dst, p);

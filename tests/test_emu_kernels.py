@@ -47,6 +47,7 @@ import test_gpu_snapshot as tsn  # noqa: E402
 import test_gpu_city as tcy  # noqa: E402
 import test_gpu_handel_hostmode as thh  # noqa: E402
 import test_gpu_sanfermin_cappos as tsc  # noqa: E402
+import test_gpu_wave_primitives as twp  # noqa: E402
 
 ENGINE = ["test_simple_message_and_time", "test_register_task", "test_all_flavors_of_send",
           "test_multiple_message_with_delays", "test_delays_across_horizon_pages", "test_stats", "test_partitions",
@@ -238,6 +239,10 @@ def test_host_callback_mode_pingpong():
     thm.test_pingpong_through_host_callbacks_matches_oracle(120)
 
 
+def test_host_callback_mode_releases_handles(monkeypatch):  # wg_host_released: a binding forgets a Message with its last envelope
+    thm.test_handles_are_released_for_dropped_and_repeated_sends(monkeypatch)
+
+
 def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp (the full cases: -m gpu)
     tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
 
@@ -331,3 +336,12 @@ def test_city_latency_models_and_builders():  # C/NetworkLatency.java:86-233, C/
     tcy.test_pingpong_on_city_nodes("CITIES_SPEED=CONSTANT_TOR=0.00", "NetworkLatencyByCityWJitter")
     tcy.test_pingpong_on_city_nodes("AWS_SPEED=CONSTANT_TOR=0.00", "AwsRegionNetworkLatency")
     tcy.test_city_latency_needs_city_nodes()
+
+
+def test_wave_primitives_shuffle_forms():  # wg_selftest on the emulator: the non-DPP forms of the reductions / scans / group-of-eight steps
+    twp.test_wave_reductions_and_scans(64)
+    twp.test_wave_reductions_and_scans(17)
+    twp.test_lane_broadcasts_and_shuffles()
+    twp.test_groups_of_eight_lanes(60)
+    twp.test_block_scan_and_sum(256, 200)
+    twp.test_ballot_multisplit_rank(3, 256, 256)

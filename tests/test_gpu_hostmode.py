@@ -161,6 +161,33 @@ def test_pingpong_through_host_callbacks_matches_oracle(n):
         assert net._eng.rng_state() == c.info()["rng"]
         assert net.time == c.info()["time"]
     assert 0 < nodes[0].pong <= n
+    # the binding forgets a Message with its last envelope (wg_host_released): after the run only what is still in flight is held —
+    # the sendAll's Ping while it has destinations to reach, Pongs on their way — not the ~ n Pong objects the run made
+    assert len(net._handles) == len(net._refs) == len(net._handle_of) <= 1 + net.msgs.size()
+    net.runMs(2000)
+    assert net.msgs.size() == 0 and not net._handles and net._next_handle <= n + 2  # freed handles are used again
+
+
+@pytest.mark.gpu
+def test_handles_are_released_for_dropped_and_repeated_sends(monkeypatch):
+    """wg_host_released covers the ends the deliveries do not show: a send that reaches no destination (every destination down),
+    a delivery consumed because the receiver stopped meanwhile (C/Network.java:606), the same Message object under several
+    envelopes (one handle, released once per envelope) — on both forms of the boundary"""
+    for batched in ("0", "1"):
+        monkeypatch.setenv("WG_HOST_BATCH", batched)
+        net, n = net4()
+        log = []
+        m = _Rec(log)
+        net.set_down(n[3])
+        net.send(m, n[0], n[3])                      # dropped at send time (:478)
+        net.send(m, n[0], [n[1], n[2]])              # one envelope, two hops
+        net.send(m, n[0], n[1])                      # the same object again: the same handle
+        assert len(net._handles) == 1 and list(net._refs.values()) == [3]
+        net.runMs(1)
+        assert list(net._refs.values()) == [2]       # the dropped one is gone
+        net.set_down(n[2])                           # its hop will be consumed, not delivered
+        net.runMs(10)
+        assert [to for _, _, to in log] == [1, 1] and not net._handles and not net._refs
 
 
 # ---- the batched form of the same boundary: wg_step_begin / wg_step_end (a ms of deliveries per call, their pushes back in

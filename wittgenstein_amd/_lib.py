@@ -86,13 +86,13 @@ class wg_profile_entry(C.Structure):
 # every symbol include/wittgpu.h and include/wittgpu_host.h declare
 ABI_VERSION = 5  # WG_ABI_VERSION of the include/wittgpu.h these ctypes structures restate
 ABI_SYMBOLS = [
-    "wg_abi_version", "wg_abi_struct_size", "wg_read_i32",
+    "wg_abi_version", "wg_abi_struct_size", "wg_selftest", "wg_read_i32",
     "wg_create", "wg_destroy", "wg_last_error", "wg_add_nodes", "wg_node_count", "wg_set_latency",
     "wg_set_latency_by_name", "wg_set_latency_city", "wg_latency_probe", "wg_set_partitions", "wg_set_node_down", "wg_set_discard_time",
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_send_arrive_at", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_device_bytes", "wg_delivered_by_level",
-    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_configure_rccl", "wg_rccl_unique_id", "wg_shard_info", "wg_next_delivery", "wg_step_begin", "wg_step_end", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error",
+    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_configure_rccl", "wg_rccl_unique_id", "wg_shard_info", "wg_next_delivery", "wg_step_begin", "wg_step_end", "wg_host_released", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error", "wg_batch_size",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_batch_run_multiple_times", "wg_profile_enable", "wg_profile_read", "wg_profile_set_reference", "wg_profile_read_spans",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_handel_create_bad_nodes", "wgh_gsf_create", "wgh_sanfermin_create", "wgh_casper_create", "wgh_p2pflood_create", "wgh_register_city_builder", "wgh_register_city_latency", "wgh_last_error", "wgh_last_init_seconds", "wgh_last_init_on_device", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",

@@ -193,6 +193,18 @@ int32_t wg_read_i32(wg_engine* h, int32_t field, int32_t* dst, int32_t n) {  // 
   WG_END
 }
 int32_t wg_abi_version(void) { return WG_ABI_VERSION; }
+int32_t wg_selftest(int32_t op, int32_t aux, const uint64_t* in, int32_t n, int32_t threads, uint64_t* out, int32_t n_out) {
+  try {
+    selftest(op, aux, in, n, threads, out, n_out);
+  } catch (const WgError& x) {
+    g_createError = x.what();
+    return x.code;
+  } catch (const std::exception& x) {
+    g_createError = x.what();
+    return WG_EHIP;
+  }
+  return WG_OK;
+}
 int32_t wg_abi_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(wg_config);
@@ -276,6 +288,12 @@ int32_t wg_step_end(wg_engine* h, const wg_step_op* ops, int32_t nops, const int
   WG_TRY(h) E.step_end(ops, nops, dests);
   WG_END
 }
+int32_t wg_host_released(wg_engine* h, uint32_t* msgs, int32_t cap, int32_t* n) {
+  WG_TRY(h)
+  if (!n) throw WgError(WG_EINVAL, "n");
+  *n = E.host_released(msgs, cap);
+  WG_END
+}
 int32_t wg_set_time(wg_engine* h, int32_t time) {
   WG_TRY(h) E.host_set_time(time);
   WG_END
@@ -318,6 +336,11 @@ void wg_batch_destroy(wg_batch* b) {
   delete b;
 }
 const char* wg_batch_last_error(wg_batch* b) { return b ? b->b->lastError.c_str() : g_batchError.c_str(); }
+int32_t wg_batch_size(wg_batch* b, int32_t* n) {
+  if (!b || !n) return WG_EINVAL;
+  *n = (int32_t)b->b->members.size();
+  return WG_OK;
+}
 int32_t wg_batch_run_ms(wg_batch* b, int32_t ms, const uint8_t* active, uint8_t* didSomething, wg_run_stats* stats) {
   if (!b) return WG_EINVAL;
   WGB_TRY b->b->run_ms(ms, active, didSomething, stats);

@@ -242,7 +242,8 @@ enum ErrBits : uint32_t {
   ERR_ARRIVAL_PAST = 1u << 13,
   ERR_SHARD_MULTI = 1u << 14,  // sharded engine: an action() emitted a multi-destination envelope
   ERR_SAME_MS_BLOCKS = 1u << 15,  // Casper resident: two blocks created in one simulated ms (block-id order across wavefronts)
-  ERR_RANK_BUMPS = 1u << 16       // Handel, ranks carried by the senders: a node's table of bumped senders is full
+  ERR_RANK_BUMPS = 1u << 16,      // Handel, ranks carried by the senders: a node's table of bumped senders is full
+  ERR_SHARD_EVENT = 1u << 17      // sharded engine: an event's (records, draws) do not fit the packed exchange word (evres_packable)
 };
 
 // Device-resident engine globals (one instance).

@@ -854,14 +854,23 @@ void Engine::send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32
     }
     st += delayBetween + (delayBetween > 0 ? 1 : 0);  // :459
   }
+  if (da.size() > 1) {  // every refusal BEFORE anything is counted or allocated: a caller that catches it finds the engine as it was
+    ensure_device();
+    if (da.size() * (delayBetween == 0 ? 1 : 2) > dev.chainDests) throw WgError(WG_ENOMEM, "chain_dests too small for this multi-destination send");
+    const uint32_t slot = gh.chainHead % dev.chainSlots;
+    if (dev.hostMode && hostChains.size() > slot && hostChains[slot].live)  // (the ring has gone round onto an envelope that still has destinations to reach)
+      throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
+  }
   pendingSent.push_back({from, sentMsgs, msg});
   if (n > 1) std::stable_sort(da.begin(), da.end(), [](const Arr& a, const Arr& b) { return a.arrival < b.arrival; });
-  if (da.empty()) return;
+  if (da.empty()) {
+    if (dev.hostMode) hcReleased.push_back(msg);  // no destination is reachable: the envelope ends here
+    return;
+  }
   if (da.size() == 1) {
     hc_push(da[0].arrival, make_rec(K_MSG, from, (uint32_t)da[0].dest, msg, payload));
     return;
   }
-  ensure_device();
   StagedChain sc;
   sc.slot = gh.chainHead++ % dev.chainSlots;
   sc.c.from = from;
@@ -869,7 +878,6 @@ void Engine::send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32
   sc.c.sendTime = sendTime;
   sc.c.ndest = (int32_t)da.size();
   size_t words = da.size() * (delayBetween == 0 ? 1 : 2);
-  if (words > dev.chainDests) throw WgError(WG_ENOMEM, "chain_dests too small for this multi-destination send");
   sc.c.destOff = (uint32_t)(gh.destHead % dev.chainDests);
   gh.destHead += words;
   sc.c.msg = msg;
@@ -880,8 +888,6 @@ void Engine::send_seeded(uint32_t msg, uint32_t payload, int32_t sendTime, int32
     for (auto& a : da) sc.words.push_back(a.arrival);
   if (dev.hostMode) {  // the host hands the hops out itself: keep the envelope
     if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
-    if (hostChains[sc.slot].live)  // (the ring has gone round onto an envelope that still has destinations to reach)
-      throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
     hostChains[sc.slot].live = true;
     hostChains[sc.slot].c = sc.c;
     hostChains[sc.slot].words = sc.words;
@@ -897,6 +903,8 @@ void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int
   ensure_device();
   if (!allocated || (unsigned long long)n > dev.chainDests)
     throw WgError(WG_ENOMEM, "chain_dests too small for this multi-destination send");
+  if (dev.hostMode && hostChains.size() > gh.chainHead % dev.chainSlots && hostChains[gh.chainHead % dev.chainSlots].live)  // (before anything is counted)
+    throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
   pendingSent.push_back({from, (long long)n, msg});
   Group g = self();
   const uint32_t D = (uint32_t)dev.horizon;
@@ -934,7 +942,10 @@ void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int
     }
   }
   const int32_t m = res[0];
-  if (m <= 0) return;
+  if (m <= 0) {
+    if (dev.hostMode) hcReleased.push_back(msg);
+    return;
+  }
   if (sendTime <= time) throw WgError(WG_ESTATE, "sendTime=" + std::to_string(sendTime) + ", time=" + std::to_string(time));  // :471
   const int32_t firstArrival = sendTime + res[1];
   const bool needIds = m == 1 || dev.hostMode;
@@ -964,8 +975,6 @@ void Engine::send_expanded(uint32_t msg, uint32_t payload, int32_t sendTime, int
   globalsDirty = true;
   if (dev.hostMode) {
     if (hostChains.size() < dev.chainSlots) hostChains.resize(dev.chainSlots);
-    if (hostChains[sc.slot].live)
-      throw WgError(WG_ENOMEM, "chain_slots (" + std::to_string(dev.chainSlots) + ") too small: more multi-destination envelopes are in flight; raise wg_config.chain_slots");
     hostChains[sc.slot].live = true;
     hostChains[sc.slot].c = sc.c;
     hostChains[sc.slot].words = sorted;
@@ -1200,6 +1209,10 @@ void Engine::check_device_errors() {
   }
   if (e & ERR_SAME_MS) {
     m += "an action() registered an envelope for the millisecond being drained; ";
+    code = WG_EUNSUPPORTED;
+  }
+  if (e & ERR_SHARD_EVENT) {
+    m += "sharded engine: one event emitted 1024 or more records or made 2048 or more rd draws (the packed exchange word's limits, include/wittgpu.h); ";
     code = WG_EUNSUPPORTED;
   }
   if (e & ERR_ARRIVAL_PAST) {
@@ -1777,8 +1790,10 @@ bool Engine::next_delivery(int32_t until, int32_t condTime, wg_delivery* out) {
           hcContPos = next;
         } else {
           hostChains[ev.aux.chain].live = false;
+          hcReleased.push_back(hostChains[ev.aux.chain].c.msg);  // the envelope's last hop
         }
       }
+      if (ev.aux.chain < 0) hcReleased.push_back(ev.rec.w2);  // a single-destination envelope / a task ends with this event, delivered or consumed
       const int32_t from = rec_from(ev.rec), to = (int32_t)ev.rec.w1;
       if (hdown[to] || part_of(hx[from]) != part_of(hx[to])) {  // :606 — consumed, not delivered
         hc_stage_continuation();
@@ -1857,8 +1872,10 @@ int32_t Engine::step_begin(int32_t until, int32_t condTime, wg_delivery* out, in
           pl.contPos = next;
         } else {
           hostChains[ev.aux.chain].live = false;
+          hcReleased.push_back(hostChains[ev.aux.chain].c.msg);
         }
       }
+      if (ev.aux.chain < 0) hcReleased.push_back(ev.rec.w2);
       const int32_t from = rec_from(ev.rec), to = (int32_t)ev.rec.w1;
       if (!(hdown[to] || part_of(hx[from]) != part_of(hx[to]))) {  // :606
         wg_delivery& o = out[nOut];
@@ -1898,6 +1915,17 @@ int32_t Engine::step_begin(int32_t until, int32_t condTime, wg_delivery* out, in
     if (time > until) return 0;
     hc_load_ms(until);
   }
+}
+
+int32_t Engine::host_released(uint32_t* msgs, int32_t cap) {
+  if (!dev.hostMode) throw WgError(WG_ESTATE, "load WG_PROTO_HOST first");
+  if (cap < 0 || (cap > 0 && !msgs)) throw WgError(WG_EINVAL, "msgs / cap");
+  const size_t k = std::min((size_t)cap, hcReleased.size());
+  // (oldest first; the handles of a delivery just handed out are reported too: the caller applies the delivery — it holds
+  // the object — and forgets it afterwards)
+  for (size_t i = 0; i < k; i++) msgs[i] = hcReleased[i];
+  hcReleased.erase(hcReleased.begin(), hcReleased.begin() + (long)k);
+  return (int32_t)k;
 }
 
 void Engine::step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests) {
@@ -3794,6 +3822,85 @@ struct FloodHost : ProtoHost {
 
 ProtoHost* make_p2pflood_host(Engine& e, const wg_p2pflood_params& p, const wg_p2pflood_init_state& st) {
   return new FloodHost(e, p, st);
+}
+
+
+// ---- wg_selftest: the wave / block primitives of engine_kernels.hip.h, one at a time, on the caller's inputs -------------
+// The reductions and scans have two forms — DPP row operations (gfx950: what the product runs) and a shuffle form (the CPU
+// wave emulator of tests/emu) — and are otherwise reached only through whole-protocol runs. This kernel calls ONE of them on
+// up to 1024 values so that a test can hold the result against numpy (tests/test_gpu_wave_primitives.py). Their contract is
+// the one every call site keeps: all 64 lanes of the wavefront make the call (a lane without an item contributes the
+// operation's identity) — the result of a reduction is read from lane 63 with v_readlane, whatever EXEC is.
+enum SelfTestOp : int32_t {
+  ST_REDUCE_ADD32 = 0, ST_REDUCE_ADD64, ST_REDUCE_MIN_I32, ST_REDUCE_MAX_I32, ST_INCL_SCAN32, ST_INCL_SCAN64, ST_LANE_BCAST,
+  ST_LANE_BCAST64, ST_GROUP8_SUM64, ST_GROUP8_OR64, ST_GROUP8_MIN_I32, ST_GROUP8_MAX_I32, ST_BLOCK_EXCL_SCAN32, ST_TILE_RANK,
+  ST_SHFL64, ST_BLOCK_SUM64, ST_OPS
+};
+__global__ void __launch_bounds__(1024) k_selftest(int32_t op, int32_t aux, const uint64_t* __restrict__ in, int32_t n, uint64_t* __restrict__ out) {
+  __shared__ uint32_t sh16[16];
+  __shared__ uint64_t sh64[16];
+  WG_DYN_LDS(uint32_t, hist);  // [256] (ST_TILE_RANK)
+  const int i = (int)threadIdx.x;
+  const uint64_t v = i < n ? in[i] : 0ULL;
+  uint64_t r = 0;
+  switch (op) {
+    case ST_REDUCE_ADD32: r = wave_reduce_add32((uint32_t)v); break;
+    case ST_REDUCE_ADD64: r = wave_reduce_add64(v); break;
+    // (lanes beyond n: the identity, as the call sites pass it)
+    case ST_REDUCE_MIN_I32: r = (uint64_t)(uint32_t)wave_reduce_min_i32(i < n ? (int32_t)(uint32_t)v : INT32_MAX); break;
+    case ST_REDUCE_MAX_I32: r = (uint64_t)(uint32_t)wave_reduce_max_i32(i < n ? (int32_t)(uint32_t)v : INT32_MIN); break;
+    case ST_INCL_SCAN32: r = wave_incl_scan32((uint32_t)v); break;
+    case ST_INCL_SCAN64: r = wave_incl_scan64(v); break;
+    case ST_LANE_BCAST: r = lane_bcast((uint32_t)v, aux & 63); break;
+    case ST_LANE_BCAST64: r = lane_bcast64(v, aux & 63); break;
+    case ST_GROUP8_SUM64: r = group8_sum64(v); break;
+    case ST_GROUP8_OR64: r = group8_or64(v); break;
+    case ST_GROUP8_MIN_I32: r = (uint64_t)(uint32_t)group8_min_i32(i < n ? (int32_t)(uint32_t)v : INT32_MAX); break;
+    case ST_GROUP8_MAX_I32: r = (uint64_t)(uint32_t)group8_max_i32(i < n ? (int32_t)(uint32_t)v : INT32_MIN); break;
+    case ST_BLOCK_EXCL_SCAN32: {
+      uint32_t total;
+      r = block_excl_scan32_1024((uint32_t)v, sh16, &total);
+      if (i == 0) out[blockDim.x] = total;
+      break;
+    }
+    case ST_TILE_RANK: {  // in[i] = bin | valid << 32; aux = bits of a bin; out[i] = stable rank among equal bins, then the bin totals
+      const int bins = 1 << aux;
+      for (int b = i; b < bins; b += (int)blockDim.x) hist[b] = 0;
+      __syncthreads();
+      const bool valid = i < n && ((v >> 32) & 1ULL);
+      r = tile_rank(hist, (int)((uint32_t)v & (uint32_t)(bins - 1)), valid, aux);
+      __syncthreads();
+      for (int b = i; b < bins; b += (int)blockDim.x) out[blockDim.x + b] = hist[b];
+      break;
+    }
+    case ST_SHFL64: r = shfl64(v, (i + aux) & 63); break;
+    case ST_BLOCK_SUM64: r = block_sum64(v, sh64); break;
+    default: break;
+  }
+  out[i] = r;
+}
+// (no engine: the call makes its own buffers on the current device; threads = the block the primitive runs in — 64 for
+// the wave forms, up to 1024 for the block forms; out holds threads words, + 1 (ST_BLOCK_EXCL_SCAN32: the total) or
+// + 2^aux (ST_TILE_RANK: the bins' totals))
+void selftest(int32_t op, int32_t aux, const uint64_t* in, int32_t n, int32_t threads, uint64_t* out, int32_t nOut) {
+  if (op < 0 || op >= ST_OPS || !in || !out || n < 0 || n > threads || threads < 64 || threads > 1024 || (threads & 63))
+    throw WgError(WG_EINVAL, "wg_selftest: op / sizes");
+  if (op == ST_TILE_RANK && (aux < 1 || aux > 8)) throw WgError(WG_EINVAL, "wg_selftest: tile_rank takes 1 .. 8 bin bits");
+  const int32_t need = threads + (op == ST_BLOCK_EXCL_SCAN32 ? 1 : op == ST_TILE_RANK ? (1 << aux) : 0);
+  if (nOut < need) throw WgError(WG_EINVAL, "wg_selftest: out is too short");
+  uint64_t *dIn = nullptr, *dOut = nullptr;
+  WG_HIP(hipMalloc((void**)&dIn, 8 * (size_t)std::max(1, n)));
+  struct Free {
+    void*& p;
+    ~Free() { (void)hipFree(p); }
+  } g1{(void*&)dIn};
+  WG_HIP(hipMalloc((void**)&dOut, 8 * (size_t)need));
+  Free g2{(void*&)dOut};
+  if (n) WG_HIP(hipMemcpy(dIn, in, 8 * (size_t)n, hipMemcpyHostToDevice));
+  WG_HIP(hipMemset(dOut, 0, 8 * (size_t)need));
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(threads), sizeof(uint32_t) * 256, 0, op, aux, (const uint64_t*)dIn, n, dOut);
+  WG_HIP(hipDeviceSynchronize());
+  WG_HIP(hipMemcpy(out, dOut, 8 * (size_t)need, hipMemcpyDeviceToHost));
 }
 
 }  // namespace wg

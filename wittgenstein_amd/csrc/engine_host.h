@@ -50,9 +50,15 @@ struct Group {
   const std::vector<PeriodicReg>* periodic = nullptr;
   bool periodic_may_fire(uint32_t task) const {
     if (now == INT32_MIN || !periodic) return true;
+    // (a task of which NO registration is known is not "never fires" but "unknown": an envelope of it that reached the queue
+    // some other way — a restored image, a registration made on the device — must still find its kernel launched)
+    bool known = false;
     for (const PeriodicReg& r : *periodic)
-      if (r.task == task && now >= r.phase && (now - r.phase) % r.period == 0) return true;
-    return false;
+      if (r.task == task) {
+        known = true;
+        if (now >= r.phase && (now - r.phase) % r.period == 0) return true;
+      }
+    return !known;
   }
   // ... any of them: the ms in which every node's periodic task sends (Handel's dissemination, GSFSignature's doCycle) has
   // a hundred times the outbox records of the others
@@ -196,6 +202,12 @@ class Engine {
   };
   std::vector<StepPlan> hcPlan;
   bool hcStepOpen = false;
+  // host-callback mode: message / task handles whose envelope has ENDED since the caller last asked (wg_host_released) — its
+  // one destination was handed out (or consumed, C/Network.java:606), the last hop of a multi-destination envelope was, or no
+  // destination was reachable when it was sent: the caller may forget the object behind the handle (the reference drops
+  // its Envelope there; a binding that kept every Message of a run alive ran out of memory at ~1e7 messages)
+  std::vector<uint32_t> hcReleased;
+  int32_t host_released(uint32_t* msgs, int32_t cap);
   int32_t step_begin(int32_t until, int32_t condTime, wg_delivery* out, int32_t cap);
   void step_end(const wg_step_op* ops, int32_t nops, const int32_t* dests);
   void hc_load_ms(int32_t until);
@@ -421,6 +433,7 @@ class Batch {
   std::vector<PeriodicReg> periodicUnion;  // Group::periodic of the batch: the members' registrations
 };
 
+void selftest(int32_t op, int32_t aux, const uint64_t* in, int32_t n, int32_t threads, uint64_t* out, int32_t nOut);  // wg_selftest
 void rccl_unique_id(uint8_t* id128);  // ncclGetUniqueId of the dynamically loaded librccl
 
 ProtoHost* make_pingpong_host(Engine& e);

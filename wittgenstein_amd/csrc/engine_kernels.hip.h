@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) k_shard_evres(const EngineDev* __restrict
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     if (PACK) {
       const EvRes r = d.evRes[e];
-      if (!evres_packable(r)) set_err(d.g, ERR_OUTBOX);
+      if (!evres_packable(r)) set_err(d.g, ERR_SHARD_EVENT);
       d.xev[e] = (int32_t)evres_pack(r);
     } else {
       d.evRes[e] = evres_unpack((uint32_t)d.xev[e]);

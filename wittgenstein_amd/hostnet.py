@@ -147,7 +147,13 @@ class HostNetwork:
         self.rd = EngineRandom(self)
         self.allNodes = []
         self.conditionalTasks = []
+        # handle -> Message / Task object, for as long as an envelope of it is in flight: the engine reports the end of every
+        # envelope (wg_host_released) and the object is let go with its last one, as the reference lets go of its Envelope
         self._handles = {}
+        self._handle_of = {}   # id(obj) -> handle (a re-armed PeriodicTask, a Message sent twice: one handle)
+        self._refs = {}        # handle -> envelopes in flight
+        self._free = []
+        self._rel = (C.c_uint32 * 1024)()
         self._next_handle = 1
         self._next_id = 0
         self._ready = False
@@ -178,10 +184,38 @@ class HostNetwork:
         self._ready = True
 
     def _handle(self, obj):
-        h = self._next_handle
-        self._next_handle += 1
-        self._handles[h] = obj
+        """the handle an envelope of `obj` travels under (one more envelope of it in flight)"""
+        h = self._handle_of.get(id(obj))
+        if h is None:
+            if self._free:
+                h = self._free.pop()
+            else:
+                h = self._next_handle
+                self._next_handle += 1
+            self._handles[h] = obj
+            self._handle_of[id(obj)] = h
+            self._refs[h] = 0
+        self._refs[h] += 1
         return h
+
+    def _unref(self, h):
+        r = self._refs[h] - 1
+        if r:
+            self._refs[h] = r
+        else:
+            del self._handle_of[id(self._handles.pop(h))]
+            del self._refs[h]
+            self._free.append(h)
+
+    def _drain_released(self):
+        """envelopes that ended since the last call (wg_host_released): their objects are forgotten with their last envelope"""
+        lib, h, n = L.lib(), self._eng._h, C.c_int32()
+        while True:
+            self._eng._ck(lib.wg_host_released(h, self._rel, len(self._rel), C.byref(n)))
+            for i in range(n.value):
+                self._unref(self._rel[i])
+            if n.value < len(self._rel):
+                return
 
     def set_down(self, node, down=True):
         node.down = down
@@ -267,6 +301,7 @@ class HostNetwork:
                 if not n.isDown():
                     n.start()
         endAt = self.time + ms
+        self._drain_released()  # (sends of init() that reached no destination)
         did = self._receiveUntil(endAt)
         self.time = endAt
         self._eng._ck(L.lib().wg_set_time(self._eng._h, endAt))
@@ -288,6 +323,7 @@ class HostNetwork:
         while True:
             self._eng._ck(lib.wg_next_delivery(h, until, self._cond_time(cts, until), C.byref(d), C.byref(got)))
             if not got.value:
+                self._drain_released()  # (envelopes whose last hop was consumed, not delivered: no delivery showed their end)
                 return did
             self.time = d.time
             if d.kind == 2:  # time++ edge: the conditional-task scan of :543-566
@@ -296,6 +332,7 @@ class HostNetwork:
             did = True
             cts = None  # a delivery ends the nextMessage() call
             self._deliver(d)
+            self._drain_released()
 
     def _edge(self, cts, until):
         if cts is None:
@@ -335,6 +372,7 @@ class HostNetwork:
         while True:
             eng._ck(lib.wg_step_begin(h, until, self._cond_time(cts, until), arr, cap, C.byref(n)))
             if not n.value:
+                self._drain_released()
                 return did
             self._rd_held = eng.rng_state()
             self._ops = []
@@ -376,8 +414,12 @@ class HostNetwork:
                 # actions' pushes — the multi-destination envelopes' owed re-pushes are kept — and report the refusal
                 msg = lib.wg_last_error(h).decode()
                 lib.wg_step_end(h, oa, 0, da)
+                for op in ops:  # (their envelopes were never made)
+                    self._unref(op[2])
+                self._drain_released()
                 if failed is None:
                     from .core import _raise
                     _raise(rc, msg)
+            self._drain_released()
             if failed is not None:
                 raise failed
