@@ -246,13 +246,15 @@ def handel_shard_bytes_model(n, k, horizon=256, q=32):
     W = max(1, n // 64)
     own = n // k
     peer = 2 if n <= 65536 else 4   # emission lists: 16-bit ids up to 65 536 nodes
-    rows = own * (5 * W * 8 + n * 4 + (n - 1) * peer + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * 64 * 8 + L * q * 4)
+    # bit rows TI/LA/VI + the delivery-side pieces {SEEN, FP, BUMP, -}; receptionRanks + emission lists (a shard keeps the matrix
+    # form); the header record; the queue records (head, valid mask, q entries, bad mask in whole lines); the cached evaluations
+    rows = own * ((3 + 4) * W * 8 + n * 4 + (n - 1) * peer + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * ((3 + q + 1 + 7) // 8 * 8) * 8 + L * q * 4)
     nw = lambda l: max(1, (1 << (l - 1)) // 64)
     qsig = sum(own * (min(q, 16) if nw(l) >= 16 else q) * nw(l) * 8 for l in range(1, L))   # queue_cap_wide
     snap = (horizon // 20 + 2) * n * max(1, n // 128) * 8           # dissemination snapshots: replicated ring
     maxout = 24 * n
     sched = (max(1 << 20, 256 * n) + horizon * 1024) * 16 + maxout * (16 + 16 + 8 + 4 + 4 + 4 + 32 + 4 + 16 + 4) \
-        + 16 * n * 32 + 2 * max(1 << 20, 256 * n) * 4 + max(1 << 20, 2 * n * (W + L)) * 8 + maxout * 5 * 4 + maxout * 8
+        + 16 * n * 32 + 2 * max(1 << 20, 256 * n) * 4 + (1 << 16) * 8 + maxout * 5 * 4 + maxout * 8
     return rows + qsig + snap + sched + own * 8 * max(1, n // 128) * 2
 
 

@@ -2372,7 +2372,7 @@ __global__ void k_handel_own_bits(HandelState s) {
     uint64_t* qr = h_qrec(s, node, l);
     qr[0] = qr[1] = 0;
     qr[H_QVALID] = 0;
-    qr[H_QBAD] = 0;
+    qr[s.qBad] = 0;
   }
 }
 
@@ -2481,8 +2481,7 @@ struct HandelHost : ProtoHost {
     if (Q > 64) throw WgError(WG_EINVAL, "queue_cap must be <= 64");
     // engine payload ring: only fast-path sends (:738-749) snapshot into it — at most one per (node, level)
     // completion; the periodic dissemination snapshots have computed addresses (HandelState::snap).
-    if (e.cfg.payload_words == 0 && !e.allocated)
-      e.cfg.payload_words = std::max<int64_t>(1 << 20, 2 * (int64_t)N * (W + L));
+    // (the engine's payload ring is not used: a fast-path send's snapshot is the constant all-ones block, snapshot_outgoing)
     if (N > (1 << 19)) throw WgError(WG_EINVAL, "Handel resident: at most 2^19 nodes (the signer's id travels in the task word)");
     if (e.allocated && !e.dev.inbox) throw WgError(WG_ESTATE, "load Handel before the first call that allocates the engine");
     e.wantInbox = true;  // a node's events of the ms are read from its inbox line (k_handel_lane / k_handel_wave)
@@ -2553,7 +2552,10 @@ struct HandelHost : ProtoHost {
     st.hdr = rows((uint32_t*)nullptr, st.hdrStride, true);
     st.ct = rows((uint32_t*)nullptr, 2, true);
     const size_t NL = (size_t)N * L;
-    st.qrec = rows((uint64_t*)nullptr, (size_t)L * H_QREC, true, Engine::AC_SCRATCH);
+    st.qBad = H_QENT + Q;
+    st.qStride = (st.qBad + 1 + 7) & ~7;
+    // (+ 64 words behind the last record: a wavefront reads `ent[lane]` of a long list with every lane before it masks by the length)
+    st.qrec = e.dalloc<uint64_t>(nLoc * (size_t)L * st.qStride + 64, true, Engine::AC_SCRATCH) - (size_t)lo * L * st.qStride;
     unsigned long long off = 0;
     for (int l = 0; l < L; l++) {
       int nw = l == 0 ? 0 : ((1 << (l - 1)) >= 64 ? (1 << (l - 1)) >> 6 : 1);

@@ -402,6 +402,8 @@ class Engine {
     void* p = nullptr;
     WG_HIP(hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
     if (zero) WG_HIP(hipMemsetAsync(p, 0, count * sizeof(T), stream));
+    if (count * sizeof(T) >= (8u << 20) && getenv("WG_INIT_VERBOSE") && atoi(getenv("WG_INIT_VERBOSE")) >= 2)
+      fprintf(stderr, "[wittgpu] alloc #%zu: %.1f MB (class %d, %zu x %zu B)\n", allocs.size(), count * sizeof(T) / 1e6, cls, count, sizeof(T));
     allocs.push_back(p);
     allocInfo.push_back({count * sizeof(T), cls});
     return (T*)p;

@@ -67,10 +67,9 @@ namespace wg {
 constexpr int H_PEND = 4;          // outstanding updateVerifiedSignatures tasks per node
 constexpr uint32_t H_TASK_DISSEMINATION = 0;
 constexpr uint32_t H_TASK_UPDATE = 1;
-constexpr int H_QREC = 72;         // 64-bit words of a queue record: head, valid mask, 64 entries, bad mask — whole 64-byte lines
+// (a queue record — HandelState::qrec — is head, valid mask, Q entries, bad mask in whole 64-byte lines: qStride / qBad)
 constexpr int H_QVALID = 2;        // word of the record: bit `slot` = the evaluation cached for that slot's entry (qcache) still holds
 constexpr int H_QENT = 3;          // first entry of the list (the head, the valid mask and five entries are ONE 64-byte line)
-constexpr int H_QBAD = 67;         // word of the record: bit `slot` = that slot's signature is a bad one (SigToVerify.badSig)
 constexpr int H_LANE_NW = 16;      // level blocks of up to this many 64-bit words are worked on by ONE lane, which streams
                                    // them two words a load (levels <= 11); a wavefront per item spends ~ 25 wave-level memory
                                    // instructions on ONE item, and that instruction rate is what bounds those kernels
@@ -101,7 +100,7 @@ struct HandelState {
   int32_t bumpCap;                        // a power of two <= N (wg_config.rank_bump_cap; a full table is a loud error)
   int32_t exp;                            // TEMP experiments (WG_EXP bit mask)
   // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
-  // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word H_QBAD. atk == 0: none of it is touched
+  // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word qBad. atk == 0: none of it is touched
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
   int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
@@ -137,11 +136,14 @@ struct HandelState {
   // ConditionalTask.minStartTime and the epoch in which the task last left nextMessage()'s copy, two words a node, dense:
   // k_handel_cond_pre looks at every node every ms — 8 bytes of a coalesced stream instead of a line of the record
   GP<uint32_t> ct;
-  // toVerifyAgg of (node, level): a queue record of H_QREC 64-bit words — [0] list length, [1] signature slots in use,
+  // toVerifyAgg of (node, level): a queue record of qStride 64-bit words — [0] list length, [1] signature slots in use,
   // [H_QVALID] slots whose cached evaluation holds, [H_QENT + i] entry i in list order: rank << 32 | signer << 8 | slot.
   // Length, slots, valid mask and the first five entries are ONE 64-byte line: what a delivery appends to and checkSigs
   // walks (it used to be a line in each of three arrays)
-  GP<uint64_t> qrec;                      // [N][L][H_QREC]
+  GP<uint64_t> qrec;                      // [N][L][qStride]
+  // (a listed entry owns one of the level's <= Q signature slots, so a list never holds more than Q entries: the record is
+  // head + valid mask + Q entries + bad mask, in whole 64-byte lines — 40 words at the default Q = 32, not H_QREC = 72)
+  int32_t qStride, qBad;                  // words of a record; the word of the bad-signature mask (H_QENT + Q)
   // checkSigs made incremental (round 4). bestToVerify (:570-634) asks of every listed signature its sizeIfIncluded
   // (:532-540) and its score (:655-668): functions of the signature — fixed when onNewSig lists it — and of the level's
   // totalIncoming / verifiedIndSignatures / lastAggVerified, which change only when an updateVerifiedSignatures of THAT
@@ -441,7 +443,7 @@ __device__ __forceinline__ uint64_t WG_G* h_sig_ptr(const HandelState& s, int32_
 }
 __device__ __forceinline__ uint32_t h_pend_word(int l, int slot) { return 0x80000000u | ((uint32_t)l << 8) | (uint32_t)slot; }
 __device__ __forceinline__ uint64_t WG_G* h_qrec(const HandelState& s, int32_t node, int l) {
-  return s.qrec + ((size_t)node * s.L + l) * H_QREC;
+  return s.qrec + ((size_t)node * s.L + l) * (size_t)s.qStride;
 }
 __device__ __forceinline__ uint64_t h_entry(int32_t rank, int32_t from, int slot) {
   return ((uint64_t)(uint32_t)rank << 32) | ((uint64_t)(uint32_t)from << 8) | (uint32_t)slot;
@@ -669,15 +671,12 @@ struct HandelProtoT {
 
   // snapshot of totalOutgoing of level l (the node's own block of the TI row) for a fast-path send
   // (irregular: engine payload ring); the periodic dissemination has its own computed slot.
-  __device__ static uint32_t snapshot_outgoing(Ctx& c, const State& s, int l) {
-    // A fast-path send happens when totalOutgoing of level l is complete (cur == 2^(l-1), :738-741): its snapshot
-    // is the node's whole own block, i.e. all ones under the receiver's level mask. A sharded engine, whose payload
-    // ring is private to the shard, sends that constant instead of a copy.
-    if (c.d.sharded) return H_REF_ONES;
-    Lv v = own_view(c.node, l);
-    uint32_t ref = c.alloc_payload(v.nw);
-    H_FOR_WORDS(v, j) c.d.payload[ref + j] = *h_word(s, c.node, HK_TI, v.bw + j) & v.mask;
-    return ref | H_REF_RING;
+  __device__ static uint32_t snapshot_outgoing(Ctx&, const State&, int) {
+    // A fast-path send happens when totalOutgoing of level l is COMPLETE (cur == 2^(l-1), :738-741): its snapshot is the
+    // node's whole own block, i.e. all ones under the receiver's level mask — the constant block, as for a complete level's
+    // dissemination. (Until round 5 an unsharded engine copied the block into the engine's payload ring: 277 MB of ring per
+    // copy and its image, for words that are all ones.)
+    return H_REF_ONES;
   }
 
   // ---- Message.action: SendSigs -> onNewSig (:757-790), one wavefront per node ------------------------------
@@ -740,7 +739,7 @@ struct HandelProtoT {
       nh.used = used | (1ULL << slot);
       gst((HQHead WG_G*)qr, nh);
       if ((qvalid >> slot) & 1ULL) qr[H_QVALID] = qvalid & ~(1ULL << slot);  // the slot's cached evaluation was its previous entry's
-      if (ATK) qr[H_QBAD] &= ~(1ULL << slot);  // badSig = false (ssigs.badSig is never set by a sender :786)
+      if (ATK) qr[s.qBad] &= ~(1ULL << slot);  // badSig = false (ssigs.badSig is never set by a sender :786)
       ls->sc[HH_QMASK] |= 1u << l;
       ls->sc[HH_QDIRTY] |= 1u << l;
     }
@@ -943,7 +942,7 @@ struct HandelProtoT {
     __builtin_amdgcn_wave_barrier();  // every lane has read the record before lane 0 clears it
     if (lane == 0) ls->sc[HH_PEND + pk] = 0;
     if (ATK && s.atk == 1) {  // :688-694 a bad signature: its signer is blacklisted, nothing else happens (the entry stays listed)
-      const uint64_t badM = h_qrec(s, node, lv)[H_QBAD];
+      const uint64_t badM = h_qrec(s, node, lv)[s.qBad];
       if ((badM >> slot) & 1ULL) {
         if (lane == 0) atomicOr((unsigned long long*)(s.blacklist + (size_t)node * s.W + (from >> 6)), 1ULL << (from & 63));
         __builtin_amdgcn_wave_barrier();
@@ -2445,7 +2444,7 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
           nh.len = (uint64_t)(len + 1);
           nh.used = qh.used | (1ULL << slot);
           gst((HQHead WG_G*)qr, nh);
-          qr[H_QBAD] |= 1ULL << slot;
+          qr[s.qBad] |= 1ULL << slot;
           atomicAdd(F((uint32_t WG_G*)hdr + HH_SIGQ), 1u);
           *h_lv(s, node, HP_CAND, l) = ((uint32_t)hit << 8) | (uint32_t)slot;
           atomicOr(F(s.candMask + node), 1u << l);
@@ -3085,7 +3084,7 @@ __global__ void __launch_bounds__(256) k_handel_hidden(const EngineDev* __restri
       nh.len = (uint64_t)(len + 1);
       nh.used = used | (1ULL << slot);
       gst((HQHead WG_G*)qr, nh);
-      qr[H_QBAD] &= ~(1ULL << slot);  // badSig = false
+      qr[s.qBad] &= ~(1ULL << slot);  // badSig = false
       atomicAdd(F(h + HH_SIGQ), 1u);
     }
     __threadfence_block();
@@ -3154,7 +3153,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
       const int32_t from = (int32_t)(who >> 8);
       // currWindowSize = min(window.newSize(cur, correct = true), l.size)  (:821-822, ScoringExp :192-200)
       int w = (int)h[HH_WINDOW] * 2;
-      if (ATK && ((h_qrec(s, node, l)[H_QBAD] >> slot) & 1ULL)) w = (int)h[HH_WINDOW] / 4;  // newSize(cur, !best.badSig): floor(cur / 4)
+      if (ATK && ((h_qrec(s, node, l)[s.qBad] >> slot) & 1ULL)) w = (int)h[HH_WINDOW] / 4;  // newSize(cur, !best.badSig): floor(cur / 4)
       if (w > s.p.windowMaximum) w = s.p.windowMaximum;
       if (w < s.p.windowMinimum) w = s.p.windowMinimum;
       h[HH_WINDOW] = (uint32_t)min(w, 1 << (l - 1));
