@@ -86,6 +86,9 @@ def gsf_params(n):
                 acceleratedCallsCount=10, nodesDown=0)
 
 
+ENGINE_CONFIG = {}
+
+
 def make_sim(w, n, seed, device, workload="handel"):
     if workload == "gsf":
         gp = gsf_params(n)
@@ -98,7 +101,9 @@ def make_sim(w, n, seed, device, workload="handel"):
     hp = handel_params(n)
     p = w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
                            hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0)
-    g = w.Handel(p, seed=seed, config={"device": device})
+    cfg = {"device": device}
+    cfg.update(ENGINE_CONFIG)  # (--engine-config: wg_config fields, e.g. queue_cap_wide=12)
+    g = w.Handel(p, seed=seed, config=cfg)
     g.init()
     return g
 
@@ -529,6 +534,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
     ap.add_argument("--replicas", type=int, default=32, help="independent simulations per step and per GPU (lowered to what fits the free HBM: 28 of config 3 since round 5)")
+    ap.add_argument("--engine-config", default="", help="wg_config capacities of the Handel copies as name=value,... "
+                    "(include/wittgpu.h; overflow of any of them is a loud error, never a silent divergence)")
     ap.add_argument("--batches", type=int, default=0,
                     help="split a step's copies into this many concurrently running batches (one HIP stream and one host "
                          "thread each); 0 = 1: the whole step as one batch on one stream, so that a launch of the delivery kernels "
@@ -607,6 +614,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for kv in filter(None, args.engine_config.split(",")):
+        ENGINE_CONFIG[kv.split("=")[0].strip()] = int(kv.split("=")[1])
     K, W, n, R_req = args.steps, args.warmup, args.nodes, args.replicas
     from wittgenstein_amd import replicas
     # ---- init(), ONCE per copy. RunMultipleTimes re-creates and re-initialises the protocol for every run
@@ -872,7 +881,7 @@ def main():
         # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 24 copies that fit the HBM — it takes 256
         # (64 / 96 / 128 / 192 / 256 / 320 / 360 copies: 349.5 / 393.9 / 439.9 / 476.8 / 502.4 / 507.0 / 509.4 M msgs/s,
         # profiles/r18a_gsf_copies_sweep.txt: the step is ~ 63 ms + 1.44 ms per copy)
-        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 6), ("third_workload", "gsf", 4096, 256)):
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 256)):
             if n == nn and args.workload == wl:
                 continue
             try:

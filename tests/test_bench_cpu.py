@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_plan_replicas_degrades_and_never_fails():
     GB = 1 << 30
     assert replicas.plan_replicas(16, 288 * GB, 10 * GB) == 16
-    assert replicas.plan_replicas(32, 288 * GB, 10 * GB) == 26          # int(0.92 * 288 / 10)
+    assert replicas.plan_replicas(32, 288 * GB, 10 * GB) == 27          # int(0.955 * 288 / 10)
     assert replicas.plan_replicas(16, 288 * GB, 16 * GB) == 16
-    assert replicas.plan_replicas(16, 288 * GB, 17 * GB) == 15
+    assert replicas.plan_replicas(16, 288 * GB, 17 * GB) == 16
+    assert replicas.plan_replicas(16, 288 * GB, 18 * GB) == 15
     assert replicas.plan_replicas(16, 288 * GB, 400 * GB) == 1          # does not fit at all: still one copy, no error
     assert replicas.plan_replicas(4, 0, 0) == 4                         # nothing measured: the request stands
     # the number of steps plays no part (round 1: `fit // K` turned --steps 20 into rc=1)

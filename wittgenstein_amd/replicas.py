@@ -34,7 +34,7 @@ def rank_seeds(rank, world, replicas):
     return range(rank * replicas, (rank + 1) * replicas)
 
 
-def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.92):
+def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955):
     """How many resident copies a step runs on one GPU: the request, lowered to what fits `headroom` of the free HBM
     (per_copy_bytes = one copy incl. its init() image, measured on the first copy). Never below 1 and never an
     error: a step that cannot hold the requested batch runs a smaller one and the bench line says so
