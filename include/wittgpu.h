@@ -24,7 +24,7 @@ extern "C" {
 typedef struct wg_engine wg_engine;
 
 /* ABI version of this header. The parameter structs have GROWN across versions (wg_handel_params gained byzantineSuicide /
- * hiddenByzantine in version 3, wg_config gained queue_cap_wide in version 2 and rank_bump_cap in version 5): a caller compiled against an older header
+ * hiddenByzantine in version 3, wg_config gained queue_cap_wide in version 2 and rank_bump_cap, alltoallv, alltoallv_ctx in version 5): a caller compiled against an older header
  * would pass shorter structs than the library reads. A binding checks once, at load time, that wg_abi_version() equals the
  * WG_ABI_VERSION it was compiled with and that wg_abi_struct_size(k) equals its own sizeof — wittgenstein_amd/_lib.py and
  * jni/wittgpu_jni.c (JNI_OnLoad) do; a mismatch is a load error, not a silent over-read.
@@ -84,6 +84,11 @@ typedef struct {
                                    attack, <= 65 536 nodes): senders per node whose rank checkSigs may bump (P/Handel.java:825-828)
                                    — one per distinct sender a node ever verifies; rounded up to a power of two, at most
                                    nodeCount. 0 = min(nodeCount, 1024). Overflow is loud (WG_ENOMEM) */
+  /* the sharded engine's all-to-all (wg_shard_set_alltoallv right after wg_create; with `allreduce`; NULL: none). Declared
+   * below; same calling convention as the typedef there */
+  int32_t (*alltoallv)(void* ctx, const void* sendbuf, const int64_t* send_counts, const int64_t* send_offsets, void* recvbuf,
+                       const int64_t* recv_counts, const int64_t* recv_offsets);
+  void* alltoallv_ctx;
 } wg_config;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -387,6 +392,18 @@ int32_t wg_batch_run_multiple_times(wg_batch* b, int32_t chunk, int32_t maxTime,
  * packed int32 word (records 10 bits, draws 11 bits), so a single action() may emit at most 1023 records and make at
  * most 2047 rd draws — far beyond what the resident protocols do (Handel: one record per level). */
 int32_t wg_shard_configure(wg_engine* e, int32_t shard, int32_t nshards, wg_allreduce_fn allreduce, void* ctx);
+/* The second collective of a sharded engine (round 5): an all-to-all of int32 words — shard s sends send_counts[d] words
+ * starting at word send_offsets[d] of sendbuf to every shard d and receives recv_counts[r] words at word recv_offsets[r] of
+ * recvbuf from every shard r (arrays of nshards entries; both sides know their counts; buffers are DEVICE memory of this
+ * engine's device; the engine's stream is idle during the call). It carries what only ONE shard needs: the payload a
+ * message of a node of one shard brings to a node of another — Handel's dissemination snapshots (SendSigs.sigs,
+ * P/Handel.java:254: up to nodeCount / 16 bytes a message) go to the shard that owns the receiver, not to every shard.
+ * Optional: without it those rows travel inside an all-reduce image, to everybody (the form of rounds 1-4). Call after
+ * wg_shard_configure and before wg_protocol_load. An engine that owns its RCCL communicator (wg_shard_configure_rccl)
+ * does the same with grouped ncclSend / ncclRecv on its own stream and needs no callback. */
+typedef int32_t (*wg_alltoallv_fn)(void* ctx, const void* sendbuf, const int64_t* send_counts, const int64_t* send_offsets,
+                                   void* recvbuf, const int64_t* recv_counts, const int64_t* recv_offsets);
+int32_t wg_shard_set_alltoallv(wg_engine* e, wg_alltoallv_fn fn, void* ctx);
 /* The same with the collective OWNED BY THE ENGINE: an RCCL communicator over the box's GPUs (xGMI), created from a
  * unique id that shard 0's process obtains with wg_rccl_unique_id and hands to the other processes by whatever channel
  * the host application has (the Java host: its own launcher; wittgenstein_amd/shards.py: one torch.distributed

@@ -84,12 +84,19 @@ def leg5():
     out["loopback"] = []
     for k, params in [(2, (64, 57, 4, 50, 10, 20, 10, 6, 0)), (4, (256, 230, 4, 50, 10, 20, 10, 25, 100))]:
         bad, traffic = tl.handel_loopback(k, params, seed=1, device_memory=True)
-        out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len(set(traffic)) == 1,
+        # (the same collectives on every shard; the words a shard RECEIVES differ since round 5: snapshots go to their readers)
+        out["loopback"].append({"k": k, "bad": [str(b) for b in bad[:5]], "same_collectives": len({t[0] for t in traffic}) == 1,
                                 "calls": traffic[0][0]})
 def leg6():
     # 6. at a size the oracle cannot reach inside a test: 4 logical shards == the unsharded engine, bit for bit
-    bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True)
-    out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered}
+    tr = {}
+    bad, done, delivered = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True, traffic=tr)
+    out["vs_unsharded_8192"] = {"bad": bad[:6], "done": done, "delivered": delivered, "words": tr["words"]}
+    # ... and the same four shards with the all-reduce alone (the form of rounds 1-4: every snapshot row to every shard)
+    tr2 = {}
+    bad2, done2, delivered2 = tl.handel_shards_vs_unsharded(4, (8192, 7299, 4, 50, 10, 20, 10, 819, 0), seed=0, device_memory=True,
+                                                            traffic=tr2, alltoall=False)
+    out["vs_unsharded_8192_image"] = {"bad": bad2[:6], "done": done2, "delivered": delivered2, "words": tr2["words"]}
 def leg7():
     # 7. BASELINE config 3's size (Handel 32 768 nodes, 10 percent dead, seed 0) as 8 logical shards — what each GPU of config
     # 4's box runs, one eighth of the rows each — against the ORACLE's golden trace of that run
@@ -123,6 +130,7 @@ def leg7():
     per_shard = [net.device_bytes() for net in nets]
     out["config3_as_8_shards"] = {"bad": {k: [str(x) for x in v] for k, v in bad.items()}, "init_s": t_init,
                                   "run_s": time.time() - t0 - t_init, "device_bytes_per_shard": per_shard,
+                                  "words_received_per_shard": [shards.traffic(net)[1] for net in nets],
                                   "same_rng": len({net.rng_state() for net in nets}) == 1}
 def leg8():
     # 8. Casper IMD on logical shards of the one GPU: PT/CasperIMDTest.java:10-11's network (406 nodes) with 40 attesters
@@ -196,6 +204,8 @@ def result(tmp_path_factory):
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # (kept as evidence: exchange volumes, shard sizes, run times)
+        open(os.path.join(ROOT, "gpurun_out", "shards_result.json"), "w").write(line[len("RESULT "):])
     return json.loads(line[len("RESULT "):])
 
 
@@ -237,6 +247,13 @@ def test_four_logical_shards_equal_the_unsharded_engine_at_8192_nodes(result):
     assert "leg6" not in result["errors"], result["errors"]["leg6"]
     r = result["vs_unsharded_8192"]
     assert r["bad"] == [] and r["done"] == 8192 - 819 and r["delivered"] > 1000000, r
+    # the owner-directed snapshot exchange (round 5) against the all-reduce image of rounds 1-4: the same run, and every
+    # shard receives a fraction of the words (the snapshot rows were most of them)
+    ri = result["vs_unsharded_8192_image"]
+    assert ri["bad"] == [] and ri["done"] == r["done"] and ri["delivered"] == r["delivered"], ri
+    # (8 192 nodes: rows of at most 64 words — the event words and the 5-word records of the replicated scheduler are most of
+    # what is left; at config 3's / config 4's sizes the rows are 4 / 16 times wider: DESIGN.md §7.2 has the table)
+    assert max(r["words"]) < 0.8 * min(ri["words"]), (r["words"], ri["words"])
 
 
 def handel_shard_bytes_model(n, k, horizon=256, q=32):
@@ -255,7 +272,10 @@ def handel_shard_bytes_model(n, k, horizon=256, q=32):
     maxout = 24 * n
     sched = (max(1 << 20, 256 * n) + horizon * 1024) * 16 + maxout * (16 + 16 + 8 + 4 + 4 + 4 + 32 + 4 + 16 + 4) \
         + 16 * n * 32 + 2 * max(1 << 20, 256 * n) * 4 + (1 << 16) * 8 + maxout * 5 * 4 + maxout * 8
-    return rows + qsig + snap + sched + own * 8 * max(1, n // 128) * 2
+    # the owner-directed snapshot exchange (round 5): send and receive regions of 17-word chunks, one per shard each way
+    stride = max(1, n // 128)
+    xch = 2 * k * own * (stride // 8 + L) * 17 * 8
+    return rows + qsig + snap + sched + xch
 
 
 def test_config3_as_8_logical_shards_equals_the_oracle_trace(result):

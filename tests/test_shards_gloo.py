@@ -153,7 +153,9 @@ def test_sharded_handel_matches_the_oracle(oracle, tmp_path, world, params):
     for r in res:
         assert r["bad"] == [], r
         assert r["done"] and r["delivered"] == r["expect"] > 0
-        assert r["calls"] == res[0]["calls"] and r["words"] == res[0]["words"]
+        # (the same collectives on every shard; the words a shard RECEIVES differ since round 5: a dissemination's snapshot goes to
+        # the shards whose nodes read it — an all-to-all over gloo here —, not to every shard inside an all-reduce image)
+        assert r["calls"] == res[0]["calls"]
     live = params[0] - params[7]
     assert res[0]["doneAt"] == live          # every live node reached the threshold (PT/HandelTest.java:36-49)
 

@@ -25,7 +25,7 @@ def emulated_kernels(oracle):
         L._lib, L.LIB_PATH = saved
 
 
-def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=5):
+def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=5, alltoall=True):
     """runs k shards in lock-step with the oracle; returns the list of mismatches (empty = identical)"""
     import wittgenstein_amd as w
     from wittgenstein_amd import shards
@@ -35,7 +35,7 @@ def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=
     sims = []
     for s in range(k):
         g = w.Handel(w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync), seed=seed,
-                     config=grp.config(s, queue_cap=64))
+                     config=grp.config(s, alltoall=alltoall, queue_cap=64))
         g.init()
         sims.append(g)
     c = o.Handel(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync, seed=seed)
@@ -83,10 +83,26 @@ def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=
 def test_handel_logical_shards_match_the_oracle(k, params):
     bad, traffic = handel_loopback(k, params, seed=1, device_memory=False)
     assert bad == []
-    assert len(set(traffic)) == 1 and traffic[0][0] > 0     # every shard issued the same collectives
+    assert len({t[0] for t in traffic}) == 1 and traffic[0][0] > 0     # every shard issued the same collectives (the words a shard RECEIVES differ: the snapshots go to their readers)
 
 
-def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_cap=64):
+@pytest.mark.parametrize("k", [2, 3])
+def test_dissemination_snapshots_go_to_the_shard_that_reads_them(k):
+    """Round 5: with an all-to-all transport a dissemination's snapshot (SendSigs.sigs, P/Handel.java:254) travels as the
+    sub-rows the messages to OTHER shards' nodes point at, to those shards only (HandelState::xout, chunks of 16 words) —
+    not as the whole copied row inside an all-reduce image to every shard. Same run as the oracle's either way (256 nodes:
+    rows of several words; 3 shards: ranges that do not line up with the level blocks)."""
+    params = (256, 228, 4, 50, 10, 20, 10, 25, 0)
+    bad, directed = handel_loopback(k, params, seed=2, device_memory=False, check_every=10)
+    assert bad == []
+    bad, image = handel_loopback(k, params, seed=2, device_memory=False, check_every=10, alltoall=False)
+    assert bad == []
+    assert len({t[0] for t in directed}) == 1 and len(set(image)) == 1
+    # (at 256 nodes a sub-row is two words in a 17-word chunk: the volumes are compared where rows are wide — 8 192 nodes on
+    # the MI355X, tests/test_gpu_shards.py)
+
+
+def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_cap=64, traffic=None, alltoall=True):
     """k logical shards against the UNSHARDED engine (no oracle: usable at sizes the oracle cannot reach in a test).
     Both run RunMultipleTimes' loop; compared at the end: every per-node scalar, the per-level scalars, all five bitset
     rows, time, rd state, delivered count. Returns the list of mismatches."""
@@ -100,7 +116,7 @@ def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_c
     grp = shards.LoopbackGroup(k, device_memory=device_memory)
     sims = []
     for s in range(k):
-        sims.append(w.Handel(hp, seed=seed, config=grp.config(s, queue_cap=queue_cap)))
+        sims.append(w.Handel(hp, seed=seed, config=grp.config(s, alltoall=alltoall, queue_cap=queue_cap)))
         sims[-1].init()
     nets = [g.network() for g in sims]
     delivered = ms = 0
@@ -110,6 +126,8 @@ def handel_shards_vs_unsharded(k, params, seed, device_memory, chunk=10, queue_c
         ms += chunk
         if not (nets[0].time < 20000 and (not did or any(g.cont_if() for g in sims))):
             break
+    if traffic is not None:
+        traffic["words"] = [shards.traffic(net)[1] for net in nets]
     bad = []
     if (delivered, ms) != (rd_[0], rms[0]):
         bad.append("delivered / simulated ms: shards %r unsharded %r" % ((delivered, ms), (rd_[0], rms[0])))

@@ -141,6 +141,10 @@ int32_t wg_shard_configure(wg_engine* h, int32_t shard, int32_t nshards, wg_allr
   WG_TRY(h) E.configure_shard(shard, nshards, fn, ctx);
   WG_END
 }
+int32_t wg_shard_set_alltoallv(wg_engine* h, wg_alltoallv_fn fn, void* ctx) {
+  WG_TRY(h) E.set_alltoallv(fn, ctx);
+  WG_END
+}
 int32_t wg_shard_configure_rccl(wg_engine* h, int32_t shard, int32_t nshards, const uint8_t* id128) {
   WG_TRY(h) E.configure_shard_rccl(shard, nshards, id128);
   WG_END

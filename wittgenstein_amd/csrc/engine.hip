@@ -84,6 +84,10 @@ struct Rccl {
   int (*CommInitRank)(void**, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string err;
 };
@@ -116,6 +120,10 @@ Rccl& rccl() {
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");  // (the all-to-all of shard_alltoallv: optional, has_alltoall())
+  r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.err = "librccl.so.1 lacks the nccl* entry points";
   return r;
 }
@@ -147,7 +155,10 @@ Engine::Engine(const wg_config& c) : cfg(c) {
     if (!cfg.allreduce && cfg.rccl_id)
       configure_shard_rccl(cfg.shard, cfg.nshards, cfg.rccl_id);
     else
+{
       configure_shard(cfg.shard, cfg.nshards, cfg.allreduce, cfg.allreduce_ctx);
+      if (cfg.alltoallv) set_alltoallv(cfg.alltoallv, cfg.alltoallv_ctx);
+    }
     cfg.rccl_id = nullptr;  // (the caller's buffer is not kept)
   }
 }
@@ -1556,6 +1567,41 @@ void Engine::wait_counts(uint32_t seq, uint32_t* va, uint32_t* vb) {
   if (vb) *vb = __atomic_load_n(&mb->v[1], __ATOMIC_RELAXED);
 }
 
+void Engine::set_alltoallv(wg_alltoallv_fn fn, void* ctx) {
+  if (shardCount <= 0) throw WgError(WG_ESTATE, "wg_shard_set_alltoallv: configure the shard first (wg_shard_configure)");
+  if (proto) throw WgError(WG_ESTATE, "wg_shard_set_alltoallv must precede wg_protocol_load");
+  xa2a = fn;
+  xa2aCtx = ctx;
+}
+bool Engine::has_alltoall() const {
+  if (rcclComm) {
+    const Rccl& r = rccl();
+    return r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+  }
+  return xa2a != nullptr;
+}
+void Engine::shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro) {
+  int64_t got = 0;
+  for (int r = 0; r < shardCount; r++) got += r == shardIndex ? 0 : rc[r];
+  if (rcclComm) {  // grouped point-to-point calls on the engine's stream: RCCL's all-to-all
+    Rccl& R = rccl();
+    rccl_check(R.GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < shardCount; p++) {
+      if (p == shardIndex) continue;
+      if (sc[p] > 0) rccl_check(R.Send((const int32_t*)sendbuf + so[p], (size_t)sc[p], /*ncclInt32*/ 2, p, rcclComm, stream), "ncclSend");
+      if (rc[p] > 0) rccl_check(R.Recv((int32_t*)recvbuf + ro[p], (size_t)rc[p], /*ncclInt32*/ 2, p, rcclComm, stream), "ncclRecv");
+    }
+    rccl_check(R.GroupEnd(), "ncclGroupEnd");
+  } else {
+    if (!xa2a) throw WgError(WG_ESTATE, "no all-to-all transport (wg_shard_set_alltoallv)");
+    WG_HIP(hipStreamSynchronize(stream));
+    const int32_t rcod = xa2a(xa2aCtx, sendbuf, sc, so, recvbuf, rc, ro);
+    if (rcod != 0) throw WgError(WG_EHIP, "the shard all-to-all callback failed with " + std::to_string(rcod));
+  }
+  shardCollectives++;
+  shardWords += got;  // (words RECEIVED by this shard: what the exchange costs it — an all-reduce counts its whole buffer)
+}
+
 void Engine::shard_allreduce(void* buf, int64_t count) {
   if (count <= 0) return;
   if (rcclComm) {  // in stream order with the producers and consumers of `buf`: nothing to wait for on the host
@@ -1652,15 +1698,17 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     scan<RecsF>(g, nullptr);
     // the payload snapshots of this ms (Handel's disseminations, GSF's doCycles): which events wrote one, and how wide, came
     // with exchange 1 and the order scan counted them (nSnapEv); only a ms that has any numbers its rows (a second scan)
-    const bool snapScan = proto->shard_snap_is_scan();
-    const uint32_t* dSecond = !nEvents ? nullptr : snapScan ? gfield(&Globals::nSnapEv) : proto->shard_snap_enqueue(g);
+    const bool snapScan = proto->shard_snap_is_scan(), snapDirected = proto->shard_snap_directed();
+    const uint32_t* dSecond = !nEvents ? nullptr : (snapScan || snapDirected) ? gfield(&Globals::nSnapEv) : proto->shard_snap_enqueue(g);
     uint32_t nOut = 0, nSnap = 0;
     const uint32_t seqO = publish_counts(gfield(&Globals::nOut), dSecond);
     // (k_resolve takes the record count from the device: enqueued BEFORE the host learns it, so that the poll is not a gap)
     if (nEvents) hipLaunchKernelGGL(k_resolve<true>, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
     wait_counts(seqO, &nOut, &nSnap);
     if (dSecond && nSnap) {
-      if (snapScan) {  // rows packed back to back: their total width sizes the collective
+      if (snapDirected) {  // the sub-rows other shards' nodes will read, to those shards (all-to-all)
+        proto->shard_snap_exchange(*this, g, nSnap);
+      } else if (snapScan) {  // rows packed back to back: their total width sizes the collective
         uint32_t words = 0;
         await_counts(proto->shard_snap_enqueue(g), nullptr, &words, nullptr);
         if (words) proto->shard_snap_exchange(*this, g, words);
@@ -2661,7 +2709,25 @@ struct HandelHost : ProtoHost {
       WG_HIP(hipMemcpy(dOnes, ones.data(), 8 * (size_t)W, hipMemcpyHostToDevice));
       st.ones = dOnes;
     }
-    if (e.shardCount > 0) {
+    st.xS = st.xMe = 0;
+    st.xChunkCap = 0;
+    st.xout = st.xin = nullptr;
+    st.xoutCount = nullptr;
+    st.xcounts = nullptr;
+    directed = e.shardCount > 0 && e.has_alltoall() && !(getenv("WG_SHARD_SNAP") && !strcmp(getenv("WG_SHARD_SNAP"), "image"));
+    if (directed) {  // the snapshots' sub-rows go to the shard that reads them (HandelState::xout)
+      st.xS = e.shardCount;
+      st.xMe = e.shardIndex;
+      // a node's sub-rows for one destination are nested blocks of its copy: at most twice the copy's width, and a chunk
+      // per level for the narrow ones; all of a shard's nodes may disseminate in one ms
+      st.xChunkCap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull / (H_XCHUNK * 2), (uint64_t)nLoc * (st.snapStride / (H_XWORDS / 2) + (uint32_t)L));
+      if (st.xS > 1) {
+        st.xout = e.dalloc<uint64_t>((size_t)st.xS * st.xChunkCap * H_XCHUNK, false, Engine::AC_SCRATCH);
+        st.xin = e.dalloc<uint64_t>((size_t)st.xS * st.xChunkCap * H_XCHUNK, false, Engine::AC_SCRATCH);
+      }
+      st.xoutCount = e.dalloc<uint32_t>((size_t)st.xS, true, Engine::AC_SCRATCH);
+      st.xcounts = e.dalloc<int32_t>((size_t)st.xS * st.xS, true, Engine::AC_SCRATCH);
+    } else if (e.shardCount > 0) {
       st.snapIdx = e.dalloc<uint32_t>(e.dev.maxEvents, false);
       st.nSnap = e.dalloc<uint32_t>(1);
       // every node disseminates once per period; a desynchronised start spreads them, a synchronised one puts all
@@ -2697,6 +2763,7 @@ struct HandelHost : ProtoHost {
     hipLaunchKernelGGL(k_handel_init_chain_starts<E>, dim3(1), dim3(threads), lds, e.stream, st.N, C, (const uint16_t*)net, starts);
     hipLaunchKernelGGL((k_handel_init_chain<E, true>), dim3(C), dim3(threads), lds, e.stream, st, B, net, (const uint16_t*)starts);
   }
+  bool directed = false;    // sharded: dissemination snapshots go to the shard that reads them (all-to-all), not to every shard
   bool carried = false;     // the reception ranks travel with the messages (HandelState::peersR / bump): no matrix
   uint64_t rngAtRanks = 0;  // rd where setReceivingRanks starts (device-built ranks): the read-back of a CARRIED run re-shuffles from it
   // (hs: the state whose `ranks` the rows go to — the engine's, or a read-back's scratch copy; advance: leave rd after the shuffles)
@@ -2950,11 +3017,40 @@ struct HandelHost : ProtoHost {
   bool supports_shards() const override { return true; }
   // the dissemination snapshots written in this ms -> every shard's copy of the snapshot ring
   bool shard_snap_is_scan() const override { return true; }
+  bool shard_snap_directed() const override { return directed; }
   uint32_t* shard_snap_enqueue(const Group& g) override {
     Engine::scan<HandelSnapF>(g, (const HandelState*)g.stab);
     return st.nSnap;
   }
+  // the owner-directed form: count matrix (a tiny all-reduce: every shard learns what it will receive), the regions by
+  // all-to-all, the received chunks into this shard's ring
+  void shard_snap_directed_exchange(Engine& e, const Group& g) {
+    const int S = st.xS;
+    if (S <= 1) return;  // (one shard: no message leaves it)
+    hipLaunchKernelGGL(k_handel_xcounts, dim3(1), dim3(64), 0, g.stream, st);
+    e.shard_allreduce(st.xcounts, (int64_t)S * S);
+    std::vector<int32_t> cm((size_t)S * S);
+    WG_HIP(hipMemcpyAsync(cm.data(), st.xcounts, 4 * cm.size(), hipMemcpyDeviceToHost, g.stream));
+    WG_HIP(hipStreamSynchronize(g.stream));
+    const int64_t words = 2 * H_XCHUNK;  // int32 words a chunk
+    std::vector<int64_t> sc(S), so(S), rc(S), ro(S);
+    int64_t inChunks = 0;
+    for (int p = 0; p < S; p++) {
+      sc[p] = p == st.xMe ? 0 : (int64_t)cm[(size_t)st.xMe * S + p] * words;
+      so[p] = (int64_t)p * st.xChunkCap * words;
+      rc[p] = p == st.xMe ? 0 : (int64_t)cm[(size_t)p * S + st.xMe] * words;
+      ro[p] = inChunks * words;
+      inChunks += p == st.xMe ? 0 : cm[(size_t)p * S + st.xMe];
+    }
+    if (inChunks > (int64_t)S * st.xChunkCap) throw WgError(WG_ENOMEM, "sharded Handel: more snapshot chunks arrive than the exchange buffer holds");
+    e.shard_alltoallv(st.xout, sc.data(), so.data(), st.xin, rc.data(), ro.data());
+    if (inChunks)
+      hipLaunchKernelGGL(k_handel_xunpack, dim3((unsigned)std::min<int64_t>(1024, (inChunks * 16 + 255) / 256)), dim3(256), 0, g.stream, st, (uint32_t)inChunks);
+    WG_HIP(hipMemsetAsync(st.xoutCount, 0, 4 * (size_t)S, g.stream));
+    WG_HIP(hipMemsetAsync(st.xcounts, 0, 4 * (size_t)S * S, g.stream));
+  }
   void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
+    if (directed) return shard_snap_directed_exchange(e, g);
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
     e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2);  // (nSnap: 64-bit words of the packed rows)

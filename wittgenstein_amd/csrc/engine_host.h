@@ -109,6 +109,9 @@ struct ProtoHost {
   // reported one (shard_snap_is_scan: Handel, GSFSignature — enqueued only in a ms whose order scan counted such events,
   // Globals::nSnapEv), or a count the delivery pass left behind (Casper's table exchange)
   virtual bool shard_snap_is_scan() const { return false; }
+  // ... or goes, row by row, to the shards whose nodes will read it (an all-to-all: Engine::shard_alltoallv) — then
+  // shard_snap_exchange is called in every ms whose order scan counted a snapshot event and nothing is numbered
+  virtual bool shard_snap_directed() const { return false; }
   virtual uint32_t* shard_snap_enqueue(const Group&) { return nullptr; }
   virtual void shard_snap_exchange(Engine&, const Group&, uint32_t /*nSnap*/) {}
   // the conditional-task phase on a sharded engine: leaves the task records of this shard's nodes in the exchange
@@ -166,6 +169,12 @@ class Engine {
   int32_t shardIndex = 0, shardCount = 0;  // shardCount == 0: not sharded
   wg_allreduce_fn xfn = nullptr;          // caller-supplied collective (tests: gloo / in-process loopback) ...
   void* xctx = nullptr;
+  wg_alltoallv_fn xa2a = nullptr;         // ... and its all-to-all (wg_shard_set_alltoallv; optional)
+  void* xa2aCtx = nullptr;
+  bool has_alltoall() const;              // an all-to-all transport exists: the callback, or the engine's RCCL communicator
+  // shard d gets sc[d] int32 words from word so[d] of sendbuf, rc[r] words from shard r land at word ro[r] of recvbuf
+  void shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro);
+  void set_alltoallv(wg_alltoallv_fn fn, void* ctx);
   void* rcclComm = nullptr;               // ... or the engine's own RCCL communicator (wg_shard_configure_rccl):
                                           // ncclAllReduce enqueued on the engine's stream, no host round trip
   void configure_shard_rccl(int32_t shard, int32_t nshards, const uint8_t* uniqueId128);

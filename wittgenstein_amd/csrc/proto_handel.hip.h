@@ -209,7 +209,28 @@ struct HandelState {
   GP<uint32_t> nSnap;                     // [1]
   GP<int32_t> xsnap;                      // [xsnapRows][snapStride * 2] exchange image of this ms's dissemination snapshots
   uint32_t xsnapRows;
+  // ... or OWNER-DIRECTED (round 5; an engine with an all-to-all transport, Engine::has_alltoall): a dissemination's snapshot
+  // is read by the receivers of its messages only, and a level-l receiver sits in the sender's level-l sibling block
+  // (:667-680) — for all but the top log2(shards) levels that is the sender's own shard. The sender appends the sub-row a
+  // message of ANOTHER shard's node points at to that shard's region of xout, in self-describing chunks — word 0 = ring
+  // offset | words << 32, then up to H_XWORDS words — by one atomic per message; the regions travel by all-to-all and the
+  // receiver copies every chunk to the same offset of its own ring (k_handel_xunpack). What used to reach every shard (the
+  // whole copied row, 8 KB at 131 072 nodes) reaches the one shard that reads it, at the width its level needs.
+  int32_t xS, xMe;                        // shards / this shard (xS <= 1: not directed)
+  uint32_t xChunkCap;                     // chunks a destination's region holds (overflow: ERR_PAYLOAD, loud)
+  GP<uint64_t> xout;                      // [xS][xChunkCap][H_XCHUNK]
+  GP<uint32_t> xoutCount;                 // [xS] chunks appended for each destination in this ms
+  GP<uint64_t> xin;                       // [xS * xChunkCap][H_XCHUNK] what the other shards sent, back to back
+  GP<int32_t> xcounts;                    // [xS][xS] chunks from shard r to shard d (summed across shards before the all-to-all)
 };
+constexpr int H_XWORDS = 16, H_XCHUNK = 1 + H_XWORDS;
+// the shard that owns `node`: shard k holds [N * k / S, N * (k + 1) / S) (Engine::ensure_device)
+__device__ __forceinline__ int h_owner(const HandelState& s, int32_t node) {
+  int k = (int)(((long long)node * s.xS) / s.N);
+  while ((long long)s.N * k / s.xS > node) k--;
+  while ((long long)s.N * (k + 1) / s.xS <= node) k++;
+  return k;
+}
 
 enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_PAIR = 4, HH_WINDOW = 5, HH_SIGCHK = 6,
                        HH_TOTAL = 7, HH_NRECV = 8, HH_DONE_LO = 9, HH_DONE_HI = 10, HH_QMASK = 11, HH_BRECV = 12, HH_NSENT = 14,
@@ -897,6 +918,34 @@ struct HandelProtoT {
       c.send_many((sendM >> lane) & 1ULL, __popcll(sendM & lanes_lt()), __popcll(sendM), cand,
                   (uint32_t)lane | (lf ? 32u : 0u) | h_msg_rank(s, candT),
                   complete ? H_REF_ONES : refBase + (uint32_t)(own_view(node, lane >= 1 ? lane : 1).bw - tv.bw), bytes);
+    }
+    if (s.xS > 1 && sendM) {
+      // owner-directed exchange (HandelState::xout): the sub-rows of this snapshot that messages to OTHER shards' nodes point at
+      const bool cross = ((sendM >> lane) & 1ULL) && !complete && h_owner(s, cand) != s.xMe;
+      const uint64_t xm = __ballot(cross);
+      if (xm) __threadfence_block();  // (the words this wavefront stored into the ring above are read back through L2 below)
+      for (uint64_t m = xm; m; m &= m - 1) {
+        const int lv = __ffsll((unsigned long long)m) - 1;
+        const int dst = h_owner(s, (int32_t)lane_bcast((uint32_t)cand, lv));
+        const Lv ov = own_view(node, lv);
+        const uint32_t ref = refBase + (uint32_t)(ov.bw - tv.bw);
+        const int nch = (ov.nw + H_XWORDS - 1) / H_XWORDS;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(F(s.xoutCount + dst), (uint32_t)nch);
+        base = lane_bcast(base, 0);
+        if (base + (uint32_t)nch > s.xChunkCap) {
+          if (lane == 0) set_err(c.d.g, ERR_PAYLOAD);
+          continue;
+        }
+        for (int c0 = 0; c0 < nch; c0 += 64 / H_XWORDS) {  // four chunks a round: lane = chunk * 16 + word
+          const int ch = c0 + (lane >> 4), j = lane & (H_XWORDS - 1), wi = ch * H_XWORDS + j;
+          if (ch < nch) {
+            uint64_t WG_G* o = s.xout + ((size_t)dst * s.xChunkCap + base + (uint32_t)ch) * H_XCHUNK;
+            if (wi < ov.nw) o[1 + j] = ld_coherent(s.snap + ref + wi);
+            if (j == 0) o[0] = (uint64_t)(ref + (uint32_t)(ch * H_XWORDS)) | ((uint64_t)min(H_XWORDS, ov.nw - ch * H_XWORDS) << 32);
+          }
+        }
+      }
     }
     KPROF_MARK(c.d.g, 10);  // sends
   }
@@ -3623,6 +3672,21 @@ __global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict_
       else if (!owned)
         row[j] = img[j];
     }
+  }
+}
+
+// ---- owner-directed snapshot exchange (HandelState::xout / xin): this shard's row of the count matrix, and the chunks
+// the other shards sent copied into this shard's ring at the offset each one names
+__global__ void k_handel_xcounts(HandelState s) {
+  const int d = (int)threadIdx.x;
+  if (d < s.xS) s.xcounts[s.xMe * s.xS + d] = (int32_t)s.xoutCount[d];
+}
+__global__ void __launch_bounds__(256) k_handel_xunpack(HandelState s, uint32_t nChunks) {
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, j = threadIdx.x & 15u, stride = (gridDim.x * blockDim.x) >> 4;
+  for (uint32_t i = g; i < nChunks; i += stride) {
+    const uint64_t WG_G* c = s.xin + (size_t)i * H_XCHUNK;
+    const uint64_t h = c[0];
+    if (j < (uint32_t)(h >> 32)) s.snap[(uint32_t)h + j] = c[1 + j];
   }
 }
 

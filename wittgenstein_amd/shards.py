@@ -47,6 +47,42 @@ def make_allreduce(dist, group=None, device_memory=True):
     return L.ALLREDUCE_FN(fn)
 
 
+def make_alltoallv(dist, group=None, device_memory=True):
+    """wg_alltoallv_fn over a torch.distributed process group (all_to_all_single with split sizes): what carries the rows only
+    ONE shard needs — Handel's dissemination snapshots to the shard that owns the receiver (include/wittgpu.h)."""
+    import torch
+
+    def fn(_ctx, sendbuf, sc, so, recvbuf, rc, ro):
+        try:
+            k = dist.get_world_size(group)
+            sc_, so_, rc_, ro_ = ([int(a[i]) for i in range(k)] for a in (sc, so, rc, ro))
+
+            def words(ptr, off, cnt):
+                if device_memory:
+                    return torch.as_tensor(_DeviceWords(ptr + 4 * off, cnt), device="cuda") if cnt else torch.empty(0, dtype=torch.int32, device="cuda")
+                if not cnt:
+                    return torch.empty(0, dtype=torch.int32)
+                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr + 4 * off, C.POINTER(C.c_int32)), shape=(cnt,)))
+            # (the regions of the send buffer are not back to back: gather them, exchange, scatter what arrived)
+            send = torch.cat([words(sendbuf, so_[d], sc_[d]) for d in range(k)])
+            recv = torch.empty(sum(rc_), dtype=torch.int32, device=send.device)
+            dist.all_to_all_single(recv, send, output_split_sizes=rc_, input_split_sizes=sc_, group=group)
+            at = 0
+            for r in range(k):
+                if rc_[r]:
+                    words(recvbuf, ro_[r], rc_[r]).copy_(recv[at:at + rc_[r]])
+                at += rc_[r]
+            if device_memory:
+                torch.cuda.synchronize()
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return L.ALLTOALLV_FN(fn)
+
+
 _KEEP = []  # the ctypes thunks must outlive every engine that holds their address
 
 
@@ -54,10 +90,11 @@ def config(dist, group=None, device_memory=True, **capacities):
     """wg_config fields (a dict for the `config=` argument of the protocol mirrors / Network.create) that make
     the engine shard `rank` of `world_size`."""
     fn = make_allreduce(dist, group, device_memory)
-    _KEEP.append(fn)
+    a2a = make_alltoallv(dist, group, device_memory)
+    _KEEP.extend([fn, a2a])
     cfg = dict(capacities)
     cfg.update(shard=dist.get_rank(group), nshards=dist.get_world_size(group),
-               allreduce=C.cast(fn, C.c_void_p).value)
+               allreduce=C.cast(fn, C.c_void_p).value, alltoallv=C.cast(a2a, C.c_void_p).value)
     return cfg
 
 
@@ -234,13 +271,56 @@ class LoopbackGroup:
             self._barrier.abort()
             return 1
 
-    def config(self, shard, **capacities):
-        """wg_config fields that make an engine shard `shard` of this group"""
+    def _alltoallv(self, shard, sendbuf, sc, so, recvbuf, rc, ro):
+        """every shard's regions for shard d copied into d's receive buffer (device-to-device on the one GPU)"""
+        import threading
+        try:
+            k = self.k
+            self._bufs[shard] = (sendbuf, [int(sc[i]) for i in range(k)], [int(so[i]) for i in range(k)], recvbuf,
+                                 [int(rc[i]) for i in range(k)], [int(ro[i]) for i in range(k)])
+            leader = self._barrier.wait() == 0
+            if leader:
+                for src in range(k):
+                    sb, scs, sos = self._bufs[src][0], self._bufs[src][1], self._bufs[src][2]
+                    for dst in range(k):
+                        n = scs[dst]
+                        rb, rcs, ros = self._bufs[dst][3], self._bufs[dst][4], self._bufs[dst][5]
+                        if n != rcs[src]:
+                            raise RuntimeError("shards %d -> %d disagree on an all-to-all count: %d sent, %d expected" % (src, dst, n, rcs[src]))
+                        if not n:
+                            continue
+                        if self.device_memory:
+                            import torch
+                            torch.as_tensor(_DeviceWords(rb + 4 * ros[src], n), device="cuda").copy_(
+                                torch.as_tensor(_DeviceWords(sb + 4 * sos[dst], n), device="cuda"))
+                        else:
+                            C.memmove(rb + 4 * ros[src], sb + 4 * sos[dst], 4 * n)
+                if self.device_memory:
+                    import torch
+                    torch.cuda.synchronize()
+            self._barrier.wait()
+            return 0
+        except threading.BrokenBarrierError:
+            return 2
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            self._barrier.abort()
+            return 1
+
+    def config(self, shard, alltoall=True, **capacities):
+        """wg_config fields that make an engine shard `shard` of this group (alltoall=False: the all-reduce alone, the form of
+        rounds 1-4 — every snapshot row to every shard)"""
         fn = L.ALLREDUCE_FN(lambda _ctx, buf, count, s=shard: self._allreduce(s, buf, count))
         self._thunks.append(fn)
         _KEEP.append(fn)
         cfg = dict(capacities)
         cfg.update(shard=shard, nshards=self.k, allreduce=C.cast(fn, C.c_void_p).value)
+        if alltoall:
+            a2a = L.ALLTOALLV_FN(lambda _ctx, sb, sc, so, rb, rc, ro, s=shard: self._alltoallv(s, sb, sc, so, rb, rc, ro))
+            self._thunks.append(a2a)
+            _KEEP.append(a2a)
+            cfg["alltoallv"] = C.cast(a2a, C.c_void_p).value
         return cfg
 
     def run(self, fn):
