@@ -241,7 +241,7 @@ class Engine {
   void sync_globals_to_host();
   void sync_globals_to_device();
   static void append_phase(const Group& g, bool needHist);  // multisplit of the ordered outbox into the buckets
-  static void end_phase(const Group& g, bool drained);
+  static void end_phase(const Group& g, bool drained, bool keep = false);
   static void append_end_phase(const Group& g, bool drained);  // append_phase + end_phase in two launches (k_col_reserve_end)
   template <class F>
   static void scan(const Group& g, const typename F::Aux* atab);

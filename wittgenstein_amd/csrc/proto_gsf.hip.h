@@ -1170,6 +1170,10 @@ struct GsfCondF {
   __device__ uint64_t value(uint32_t i) const { return s.candFlag[i] != 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
+    if (d.g->nOutKeep + (uint32_t)tot > d.maxOut) {  // (the drain's outbox is still in fin / arr: the edge's records follow it)
+      set_err(d.g, ERR_OUTBOX);
+      tot = 0;
+    }
     d.g->nOut = (uint32_t)tot;
     d.g->nDraws = 0;
   }
@@ -1213,9 +1217,10 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict
         x[4] = ok ? arrival + 1 : 0;
         continue;
       }
-      d.fin[j] = fin;
-      d.arr[j] = ok ? arrival : -1;
-      if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
+      const uint32_t jp = d.g->nOutKeep + j;  // (behind the drain's records, if the drain left them to this phase's append)
+      d.fin[jp] = fin;
+      d.arr[jp] = ok ? arrival : -1;
+      if (ok) histKey = (jp / TILE) * D + ((uint32_t)arrival & (D - 1));
     }
     if (SH) continue;  // (k_shard_unpack builds the tile histograms from the summed image)
     uint64_t todo = __ballot(histKey != 0xFFFFFFFFu);

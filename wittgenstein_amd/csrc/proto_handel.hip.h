@@ -3022,6 +3022,10 @@ struct CondF {
   __device__ uint64_t value(uint32_t i) const { return h_cand_count(s, i) != 0; }
   __device__ void tally(uint32_t, uint32_t) const {}
   __device__ void total(uint64_t tot) const {
+    if (d.g->nOutKeep + (uint32_t)tot > d.maxOut) {  // (the drain's outbox is still in fin / arr: the edge's records follow it)
+      set_err(d.g, ERR_OUTBOX);
+      tot = 0;
+    }
     d.g->nOut = (uint32_t)tot;  // one registerTask per drawing node
     d.g->nDraws = (uint32_t)tot;
   }
@@ -3242,9 +3246,10 @@ __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restr
         x[4] = ok ? arrival + 1 : 0;
         continue;
       }
-      d.fin[j] = fin;
-      d.arr[j] = ok ? arrival : -1;
-      if (ok) histKey = (j / TILE) * D + ((uint32_t)arrival & (D - 1));
+      const uint32_t jp = d.g->nOutKeep + j;  // (behind the drain's records, if the drain left them to this phase's append)
+      d.fin[jp] = fin;
+      d.arr[jp] = ok ? arrival : -1;
+      if (ok) histKey = (jp / TILE) * D + ((uint32_t)arrival & (D - 1));
     }
     if (SH) continue;  // (k_shard_unpack builds the tile histograms from the summed image)
     // per-tile arrival histogram of the multisplit; pairing times are nearly uniform, so aggregate equal
