@@ -283,6 +283,8 @@ struct Globals {
   uint32_t nRuns;          // long chain runs of this ms left to k_expand_runs (EngineDev::runs), reset by k_end_phase
   uint32_t notes;          // sticky, non-fatal remarks of the resident protocol (NOTE_*)
   uint32_t nScatter;       // nOut as k_col_reserve_end saw it: what k_scatter appends after that kernel has reset nOut
+  uint32_t nOutKeep;       // the drain's ordered outbox, kept UNFILED over the conditional-task phase of the edge: that phase's
+                           // records follow it in fin / arr (from this index on) and ONE append files both, in push order
   uint32_t nSnapEv;        // sharded engines: events of this ms that wrote a payload snapshot (EV_SNAP_*), counted by the order scan
 };
 constexpr uint32_t KPROF_WAVES = 16384;

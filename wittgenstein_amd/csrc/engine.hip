@@ -1068,8 +1068,8 @@ void Engine::append_end_phase(const Group& g, bool drained) {
   hipLaunchKernelGGL(k_col_reserve_end, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab, drained ? 1 : 0);
   hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 1);
 }
-void Engine::end_phase(const Group& g, bool drained) {
-  hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0);
+void Engine::end_phase(const Group& g, bool drained, bool keep) {
+  hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0, keep ? 1 : 0);
 }
 
 Group Engine::self() {
@@ -1353,7 +1353,14 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
     }
     {
       ProfScope ps(lead, Engine::PC_APPEND);
-      Engine::append_end_phase(g, true);
+      // with a conditional-task phase behind it the drain only ENDS here (clock, rd, the drained bucket's pages): its ordered
+      // outbox stays in fin / arr, the edge's records follow it there, and the phase's append files both — one
+      // k_col_reserve_end + k_scatter per simulated ms instead of two (WG_MERGE_APPEND=0: two)
+      static const bool merge = !(getenv("WG_MERGE_APPEND") && atoi(getenv("WG_MERGE_APPEND")) == 0);
+      if (cond && merge)
+        Engine::end_phase(g, true, true);
+      else
+        Engine::append_end_phase(g, true);
     }
     if (cond) {
       // (running the phase's first kernels on a second stream beside the drain's tail was measured: no gain — the short

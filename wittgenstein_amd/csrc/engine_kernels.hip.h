@@ -1174,7 +1174,7 @@ __device__ __forceinline__ uint32_t tile_rank(uint32_t* hist, int bin, bool vali
 __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict__ tab, int binBits) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
-  uint32_t n = d.g->nOut;
+  uint32_t n = d.g->nOutKeep + d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
   for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -1196,7 +1196,7 @@ __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict_
 __device__ __forceinline__ void col_reserve_body(const EngineDev& d) {
   __shared__ uint32_t shNeed[16];
   __shared__ uint32_t shBase;
-  uint32_t n = d.g->nOut;
+  uint32_t n = d.g->nOutKeep + d.g->nOut;  // (a drain's outbox kept over the edge's conditional phase + that phase's records)
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
   for (uint32_t b0 = 0; b0 < D; b0 += blockDim.x) {
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(1024) k_col_reserve(const EngineDev* __restric
 __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ tab, int binBits, int saved) {
   WG_ENGINE(tab);
   WG_DYN_LDS(uint32_t, hist);
-  uint32_t n = saved ? d.g->nScatter : d.g->nOut;  // (saved: the phase's counters were reset by k_col_reserve_end already)
+  uint32_t n = saved ? d.g->nScatter : d.g->nOutKeep + d.g->nOut;  // (saved: the phase's counters were reset by k_col_reserve_end already)
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
   if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) nTiles = 0;
@@ -1561,9 +1561,16 @@ __device__ __forceinline__ void end_phase_body(const EngineDev& d, int drained) 
     g->rejectSeen = 0;
   }
 }
-__global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained) {
+// keep: the phase's ordered outbox is NOT filed yet — the conditional-task phase of the edge appends its records behind it
+// and one k_col_reserve_end + k_scatter files both (a launch less per simulated ms; the buckets' push order is the same:
+// the drain's records, then the edge's). (Folding this one-block launch into k_resolve as "the last block to finish ends the
+// phase" needs a device-scope fence per block — an L2 write-back on this chip: 563 -> 483 M msgs/s, profiles/r20q_*.)
+__global__ void __launch_bounds__(256) k_end_phase(const EngineDev* __restrict__ tab, int drained, int keep) {
   WG_ENGINE(tab);
+  const uint32_t nOut = d.g->nOut;
+  __syncthreads();
   end_phase_body(d, drained);
+  if (threadIdx.x == 0) d.g->nOutKeep = keep ? nOut : 0u;
 }
 // k_col_reserve and k_end_phase as ONE launch of one block per engine (both are a single block's short chain of dependent
 // accesses, ~ 5 us of launch + latency each, twice per simulated ms): the end-of-phase bookkeeping touches nothing k_scatter
@@ -1573,7 +1580,10 @@ __global__ void __launch_bounds__(1024) k_col_reserve_end(const EngineDev* __res
   WG_ENGINE(tab);
   col_reserve_body(d);
   __syncthreads();
-  if (threadIdx.x == 0) d.g->nScatter = d.g->nOut;
+  if (threadIdx.x == 0) {
+    d.g->nScatter = d.g->nOutKeep + d.g->nOut;
+    d.g->nOutKeep = 0;
+  }
   __syncthreads();
   end_phase_body(d, drained);
 }
