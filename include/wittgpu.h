@@ -83,7 +83,7 @@ typedef struct {
   int32_t rank_bump_cap;        /* Handel with the reception ranks carried by the senders (init() on the device, unsharded, no
                                    attack, <= 65 536 nodes): senders per node whose rank checkSigs may bump (P/Handel.java:825-828)
                                    — one per distinct sender a node ever verifies; rounded up to a power of two, at most
-                                   nodeCount. 0 = min(nodeCount, 1024). Overflow is loud (WG_ENOMEM) */
+                                   nodeCount. 0 = min(nodeCount, 512): a node of config 3 verifies about 100 senders. Overflow is loud (WG_ENOMEM) */
   /* the sharded engine's all-to-all (wg_shard_set_alltoallv right after wg_create; with `allreduce`; NULL: none). Declared
    * below; same calling convention as the typedef there */
   int32_t (*alltoallv)(void* ctx, const void* sendbuf, const int64_t* send_counts, const int64_t* send_offsets, void* recvbuf,

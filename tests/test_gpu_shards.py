@@ -263,9 +263,9 @@ def handel_shard_bytes_model(n, k, horizon=256, q=32):
     W = max(1, n // 64)
     own = n // k
     peer = 2 if n <= 65536 else 4   # emission lists: 16-bit ids up to 65 536 nodes
-    # bit rows TI/LA/VI + the delivery-side pieces {SEEN, FP, BUMP, -}; receptionRanks + emission lists (a shard keeps the matrix
+    # bit rows TI/LA/VI + the delivery-side pieces {SEEN, FP, BUMP}; receptionRanks + emission lists (a shard keeps the matrix
     # form); the header record; the queue records (head, valid mask, q entries, bad mask in whole lines); the cached evaluations
-    rows = own * ((3 + 4) * W * 8 + n * 4 + (n - 1) * peer + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * ((3 + q + 1 + 7) // 8 * 8) * 8 + L * q * 4)
+    rows = own * ((3 + 3) * W * 8 + n * 4 + (n - 1) * peer + (32 + 8 * (16 if L <= 16 else 32)) * 4 + L * ((3 + q + 1 + 7) // 8 * 8) * 8 + L * q * 4)
     nw = lambda l: max(1, (1 << (l - 1)) // 64)
     qsig = sum(own * (min(q, 16) if nw(l) >= 16 else q) * nw(l) * 8 for l in range(1, L))   # queue_cap_wide
     snap = (horizon // 20 + 2) * n * max(1, n // 128) * 8           # dissemination snapshots: replicated ring

@@ -731,9 +731,24 @@ void Engine::snapshot() {
   sn->nAllocs = allocs.size();
   sn->offs.assign(allocs.size(), (size_t)-1);
   size_t total = 0;
+  // the bucket pool by its pages in use: every bucket's page list is its first ceil(count / PAGE_RECS) table entries
+  {
+    const uint32_t D = (uint32_t)dev.horizon;
+    std::vector<uint32_t> cnt(D), tab((size_t)D * dev.maxPagesPerBucket);
+    WG_HIP(hipMemcpy(cnt.data(), dev.bcnt, 4 * (size_t)D, hipMemcpyDeviceToHost));
+    WG_HIP(hipMemcpy(tab.data(), dev.pagetab, 4 * tab.size(), hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; b < D; b++)
+      for (uint32_t k = 0; k < (cnt[b] + PAGE_RECS - 1) / PAGE_RECS; k++) {
+        sn->poolPages.push_back({tab[(size_t)b * dev.maxPagesPerBucket + k], total});
+        total += sizeof(Rec) * (size_t)PAGE_RECS;
+      }
+  }
+  sn->chainsZero = gh.chainHead == 0 && gh.destHead == 0;
   for (size_t i = 0; i < allocs.size(); i++) {
     if (allocInfo[i].cls != AC_STATE) continue;
     if (allocs[i] == (void*)dev.payload && gh.payloadHead == 0) continue;  // nothing allocated in the ring yet
+    if (allocs[i] == (void*)dev.pool) continue;                             // (by pages, above)
+    if (sn->chainsZero && (allocs[i] == (void*)dev.chains || allocs[i] == (void*)dev.dests)) continue;  // no envelope yet
     sn->offs[i] = total;
     total += (allocInfo[i].bytes + 255) & ~(size_t)255;
   }
@@ -745,6 +760,9 @@ void Engine::snapshot() {
   for (size_t i = 0; i < allocs.size(); i++)
     if (sn->offs[i] != (size_t)-1)
       WG_HIP(hipMemcpyAsync(sn->arena + sn->offs[i], allocs[i], allocInfo[i].bytes, hipMemcpyDeviceToDevice, stream));
+  for (const auto& pg : sn->poolPages)
+    WG_HIP(hipMemcpyAsync(sn->arena + pg.second, dev.pool + ((size_t)pg.first << PAGE_SHIFT), sizeof(Rec) * (size_t)PAGE_RECS,
+                          hipMemcpyDeviceToDevice, stream));
   WG_HIP(hipStreamSynchronize(stream));
   sn->gh = gh;
   sn->time = time;
@@ -763,6 +781,11 @@ void Engine::restore() {
   for (size_t i = 0; i < sn.nAllocs; i++)
     if (sn.offs[i] != (size_t)-1)
       WG_HIP(hipMemcpyAsync(allocs[i], sn.arena + sn.offs[i], allocInfo[i].bytes, hipMemcpyDeviceToDevice, stream));
+  for (const auto& pg : sn.poolPages)  // (the page table, the free stack and the bucket counts came back above: the same pages are in use)
+    WG_HIP(hipMemcpyAsync(dev.pool + ((size_t)pg.first << PAGE_SHIFT), sn.arena + pg.second, sizeof(Rec) * (size_t)PAGE_RECS,
+                          hipMemcpyDeviceToDevice, stream));
+  if (sn.chainsZero)  // no envelope existed at the image: none is busy (a run that was cut short leaves busy slots behind)
+    WG_HIP(hipMemsetAsync(dev.chains, 0, sizeof(Chain) * (size_t)dev.chainSlots, stream));
   const uint32_t notes = gh.notes;  // (what the run being undone left: the protocol's on_restore may need it)
   gh = sn.gh;
   gh.notes = notes;
@@ -2584,7 +2607,7 @@ struct HandelHost : ProtoHost {
       tmpRanks = TmpMatrix::acquire(4 * (size_t)N * N);
       st.ranks = tmpRanks;
       st.peersR = rows((uint32_t*)nullptr, N - 1, false, Engine::AC_CONST);
-      int cap = e.cfg.rank_bump_cap > 0 ? e.cfg.rank_bump_cap : 1024;
+      int cap = e.cfg.rank_bump_cap > 0 ? e.cfg.rank_bump_cap : 512;  // (config 3: a node verifies ~ 100 senders, 148 at most)
       int p2 = 1;
       while (p2 < cap && p2 < N) p2 <<= 1;
       st.bumpCap = std::min(p2, (int)N);
@@ -3018,7 +3041,13 @@ struct HandelHost : ProtoHost {
     if (st.atk)
       hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
     else
-      hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    {
+      // one thread per drawing node — about a quarter of the nodes at pairingTime 4 —, ONE round of them: a grid that makes a
+      // thread take a second node doubles the kernel's chain (22 -> 29 us at 32 copies with the batch-wide total alone)
+      const int floorBlocks = std::min(GRID_COND_TAIL, ((st.N / 3 + 255) / 256 + 7) / 8 * 8);
+      const int gx = std::max(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), floorBlocks);
+      hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(gx, g.R), dim3(256), 0, g.stream, g.tab, stab);
+    }
   }
   // ---- node-range sharding (Engine::run_ms_sharded) ----
   bool supports_shards() const override { return true; }

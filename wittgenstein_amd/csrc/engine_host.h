@@ -343,6 +343,10 @@ class Engine {
     char* arena = nullptr;
     size_t bytes = 0;
     std::vector<size_t> offs;    // per allocation: offset in the arena, (size_t)-1 = not copied
+    // the bucket pool is kept by its pages IN USE (after init(): the periodic tasks' records — a few pages of 134 MB); the
+    // envelope table and its destination ring not at all while no envelope was ever made (the table is re-zeroed instead)
+    std::vector<std::pair<uint32_t, size_t>> poolPages;  // page, offset in the arena
+    bool chainsZero = false;
     Globals gh;
     int32_t time = 0, discardTime = 0, stagedMin = 0;
     std::vector<uint8_t> hdown;

@@ -7,8 +7,8 @@
 //             both LEVEL-major (an event works on ONE level), cut by WHO touches a set (round 5):
 //               rows  [N][W][3]  TI, LA, VI — the sets updateVerifiedSignatures / checkSigs STREAM (a level's three
 //                                side by side, nw words each: h_row);
-//               drows [N][W][4]  what a DELIVERY touches: one bit of `from` in each of SEEN, FP (finishedPeers) and BUMP,
-//                                the three words holding it side by side in one 32-byte piece (h_dword) — one line per
+//               drows [N][W][3]  what a DELIVERY touches: one bit of `from` in each of SEEN, FP (finishedPeers) and BUMP,
+//                                the three words holding it side by side in one 24-byte piece (h_dword) — one line per
 //                                delivery whatever the level's width, written by no-return atomics, where a level of
 //                                >= 512 ids used to cost a line each for VI, TV and FP.
 //             toVerifyInd is not stored: it is set at a delivery unless verifiedInd has the sender (:779-781) and cleared
@@ -90,7 +90,7 @@ struct HandelState {
   wg_handel_params p;
   int32_t N, L, W, Q;
   GP<uint64_t> rows;                      // [N][W][3] TI, LA, VI, level-major: see h_row
-  GP<uint64_t> drows;                     // [N][W][4] SEEN, FP, BUMP, - per 64 ids, level-major: see h_dword
+  GP<uint64_t> drows;                     // [N][W][3] SEEN, FP, BUMP per 64 ids, level-major: see h_dword
   GP<int32_t> ranks;                      // [N][N]; NULL: the ranks are CARRIED by the senders (file header)
   // CARRIED form: the emission lists with the receiver's initial rank of the sender beside each id, and the receivers' bumps:
   // bump[node][bumpCap] entries count << 16 | from (0: free) — indexed by `from` when bumpCap == N, else open addressing from
@@ -240,7 +240,7 @@ enum HandelHdr : int { HH_ADDED = 0, HH_SIGQ = 1, HH_FILT = 2, HH_START = 3, HH_
 // (words 0..15, one 64-byte line: everything a SendSigs delivery reads and writes of the node; 16..31: what checkSigs and
 // updateVerifiedSignatures add to that)
 enum HandelKind : int { HK_TI = 0, HK_LA, HK_VI, HK_COUNT };          // HandelState::rows
-enum HandelDKind : int { HD_SEEN = 0, HD_FP, HD_BUMP, HD_COUNT = 4 };  // HandelState::drows (the fourth word of a piece is spare)
+enum HandelDKind : int { HD_SEEN = 0, HD_FP, HD_BUMP, HD_COUNT = 3 };  // HandelState::drows
 enum HandelPlane : int { HP_POS = 0, HP_CTI, HP_CLA, HP_CVI, HP_CAND, HP_OUTFIN, HP_SPARE0, HP_SPARE1, HP_COUNT };
 __device__ __forceinline__ uint32_t WG_G* h_hdr(const HandelState& s, int32_t node) { return s.hdr + (size_t)node * s.hdrStride; }
 __device__ __forceinline__ uint32_t WG_G* h_lv(const HandelState& s, int32_t node, int plane, int l) {
@@ -297,8 +297,8 @@ __device__ __forceinline__ uint64_t WG_G* h_row(const HandelState& s, int32_t no
   const int nw = h_nw(l), before = l <= 6 ? 0 : nw;
   return s.rows + ((size_t)node * s.W + before) * HK_COUNT + (size_t)k * nw;
 }
-// the delivery-side piece {SEEN, FP, BUMP, -} of word w of level l's sibling block (32 bytes, 32-byte aligned: never across
-// two lines); kind k of it is [k]. The same level-major grouping as the rows.
+// the delivery-side piece {SEEN, FP, BUMP} of word w of level l's sibling block (24 bytes: one line, for one piece in four
+// two); kind k of it is [k]. The same level-major grouping as the rows.
 __device__ __forceinline__ uint64_t WG_G* h_dword(const HandelState& s, int32_t node, int l, int w) {
   const int before = l <= 6 ? 0 : h_nw(l);
   return s.drows + ((size_t)node * s.W + before + w) * HD_COUNT;
@@ -1157,7 +1157,9 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   const uint64_t bit = 1ULL << (from & 63);
   uint64_t WG_G* dp = h_dword(s, node, l, w);  // the {SEEN, FP, BUMP} words holding `from`: one 32-byte piece
   // every load of the event before the first use: the piece's words (BUMP: CARRIED ranks only) or the matrix entry, the record's head
-  const V2 sf = gld((const V2 WG_G*)dp);  // {SEEN, FP}
+  V2 sf;  // {SEEN, FP} (pieces are 24 bytes apart: 8-byte loads)
+  sf.x = dp[HD_SEEN];
+  sf.y = dp[HD_FP];
   const uint64_t bumpW = s.ranks ? 0ULL : dp[HD_BUMP];
   const int32_t rankM = s.ranks ? s.ranks[(size_t)node * s.N + from] : 0;
   uint64_t WG_G* qr = h_qrec(s, node, l);
@@ -1171,15 +1173,8 @@ __device__ __forceinline__ void h_lane_message(const EngineDev& d, const HandelS
   // finishedPeers.set(from) if levelFinished; toVerifyInd.set(from) unless verified = SEEN & ~VI (file header). Plain stores of
   // the loaded words: this lane is the node's only writer in its launch, and an L2 atomic costs several stores
   // (profiles/r20e: three atomics a node were 22 of the kernel's 92 us)
-  if (s.exp & 2) {
-    if (levelFinished) atomicOr((unsigned long long*)F(dp + HD_FP), (unsigned long long)bit);
-    atomicOr((unsigned long long*)F(dp + HD_SEEN), (unsigned long long)bit);
-  } else if (!(sf.x & bit) || (levelFinished && !(sf.y & bit))) {
-    V2 nsf;
-    nsf.x = sf.x | bit;
-    nsf.y = levelFinished ? (sf.y | bit) : sf.y;
-    gst((V2 WG_G*)dp, nsf);
-  }
+  if (!(sf.x & bit)) dp[HD_SEEN] = sf.x | bit;
+  if (levelFinished && !(sf.y & bit)) dp[HD_FP] = sf.y | bit;
   const int32_t rank = s.ranks ? rankM : h_rank_at_delivery(s, node, from, msg, bumpW);  // receptionRanks[from], read at receive time (:784)
   r.sigQueueSize++;
   const int qc = h_qcap(s, l);
