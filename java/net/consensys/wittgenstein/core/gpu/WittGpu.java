@@ -158,6 +158,8 @@ public final class WittGpu {
 
   public static native int shardConfigure(long h, int shard, int nshards, long allreduceFnAddress, long ctxAddress);
 
+  /** wg_shard_set_alltoallv: the address of a native wg_alltoallv_fn and its context (after shardConfigure, before protocolLoad) */
+  public static native int shardSetAlltoallv(long h, long alltoallvFnAddress, long ctxAddress);
   public static native int shardInfo(long h, long[] loHiCollectivesWords);
 
   // ---- read-back

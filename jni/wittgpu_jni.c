@@ -496,6 +496,12 @@ WG_JNI(jint, shardConfigure)(JNIEnv* env, jclass c, jlong h, jint shard, jint ns
   (void)c;
   return ck(env, ENG(h), wg_shard_configure(ENG(h), shard, nshards, (wg_allreduce_fn)(intptr_t)fnAddr, (void*)(intptr_t)ctxAddr));
 }
+/* the optional all-to-all of a caller-supplied collective (wg_shard_set_alltoallv): a native-code hook like shardConfigure's;
+ * an engine that owns its RCCL communicator (shardConfigureRccl) needs none */
+WG_JNI(jint, shardSetAlltoallv)(JNIEnv* env, jclass c, jlong h, jlong fnAddr, jlong ctxAddr) {
+  (void)c;
+  return ck(env, ENG(h), wg_shard_set_alltoallv(ENG(h), (wg_alltoallv_fn)(intptr_t)fnAddr, (void*)(intptr_t)ctxAddr));
+}
 /* out4 = {lo, hi, collectives, words} */
 WG_JNI(jint, shardInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out4) {
   (void)c;

@@ -107,6 +107,13 @@ def test_reception_ranks_matrix_form_still_runs_with_device_init(monkeypatch, ca
     _ranks_equal_the_oracles(g, c, 512)
 
 
+def test_two_appends_per_ms_is_the_same_run(monkeypatch):
+    """WG_MERGE_APPEND=0: the drain's outbox and the conditional-task phase's filed by an append each (rounds 1-4) instead of
+    by the one merged append of round 5 (Globals::nOutKeep) — the same run as the oracle's, and hence as the merged form's"""
+    monkeypatch.setenv("WG_MERGE_APPEND", "0")
+    lockstep(ratios(512, dead=0.2), step=7, max_ms=2500)
+
+
 def test_rank_bump_table_overflow_is_loud():
     """a node that bumps more distinct senders than wg_config.rank_bump_cap holds stops the run (WG_ENOMEM), it does not diverge"""
     g, c = parity.handel_pair(ratios(512, dead=0.2), config={"rank_bump_cap": 4})

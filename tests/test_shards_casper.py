@@ -99,15 +99,6 @@ def test_casper_shards_with_chain_runs_one_wavefront_each(monkeypatch):
     casper_loopback(3, (3, False, 3, 8, 1000, 1), seed=2, chunk=500, chunks=40, byz_delay=-2000)
 
 
-def test_casper_shards_ignore_the_lane_events_switch(monkeypatch):
-    """WG_CASPER_LANE_EVENTS=0 (the unsharded A/B switch: every visit ordered) must not reach a sharded engine — the
-    block / attestation table exchange hangs on k_casper_classify's anyTask flag, which only the lane-per-event path
-    launches: without it the other shards never learn a block's height / parent and heads diverge silently"""
-    monkeypatch.setenv("WG_CASPER_LANE_EVENTS", "0")
-    c, _ = casper_loopback(2, (2, False, 2, 6, 1000, 1), seed=5, chunk=2000, chunks=14)
-    assert c.read("headHeight")[0] >= 2
-
-
 def test_casper_random_on_ties_on_shards():
     """randomOnTies (P/CasperIMD.java:250-253, the CasperParemeters() default) on a sharded engine: a tie's rd.nextBoolean() takes
     its index in the rd sequence from the draws of every earlier event of the ms — other shards' events too — so the ordered

@@ -6,7 +6,7 @@ REPO=$(pwd)
 rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ|TCP|TCC|GRBM|TA|TD)_[A-Za-z0-9_]+" | sort -u > $OUT/counters_available.txt
 wc -l $OUT/counters_available.txt
 pass() { name=$1; shift
-  (cd /tmp && WG_DELIVER_WAVES=4 timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/p_$name -o k --output-format csv -- \
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/p_$name -o k --output-format csv -- \
      python $REPO/bench.py --nodes 8192 --replicas 16 --init-threads 16 --warmup 0 --no-cpu > $REPO/$OUT/p_$name.json 2> $REPO/$OUT/p_$name.err)
   echo "pass $name rc=$?"
   python tools/prof_summary.py pmc $OUT/p_$name $OUT/pmc_$name.md && rm -rf $OUT/p_$name

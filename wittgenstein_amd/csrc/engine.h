@@ -67,11 +67,9 @@ constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node
 // ... of a batch of R engines: ~4 rounds of the chip's resident waves in total are enough, and every launched
 // wavefront that finds no work still costs its launch (131 072 waves per launch at R = 16 otherwise)
 inline int grid_node_waves(int R) {
-  static const int total = 4 * GRID_NODE_WAVES, loDiv = 8;
-  static const int totalEnv = getenv("WG_GRID_TOTAL_NODE") && atoi(getenv("WG_GRID_TOTAL_NODE")) > 0 ? atoi(getenv("WG_GRID_TOTAL_NODE")) / WG_GRID_DIV : total;
-  static const int loEnv = getenv("WG_GRID_NODE_LO_DIV") && atoi(getenv("WG_GRID_NODE_LO_DIV")) > 0 ? atoi(getenv("WG_GRID_NODE_LO_DIV")) : loDiv;
-  int b = totalEnv / (R > 0 ? R : 1);
-  const int lo = GRID_NODE_WAVES / loEnv > 0 ? GRID_NODE_WAVES / loEnv : 1;
+  constexpr int total = 4 * GRID_NODE_WAVES, loDiv = 8;
+  int b = total / (R > 0 ? R : 1);
+  const int lo = GRID_NODE_WAVES / loDiv > 0 ? GRID_NODE_WAVES / loDiv : 1;
   if (b < lo) b = lo;
   if (b > GRID_NODE_WAVES) b = GRID_NODE_WAVES;
   return b;
@@ -80,24 +78,13 @@ inline int grid_node_waves(int R) {
 // ENGINE and grid.y the batch, and an engine's share of a ms's records shrinks as the batch grows — at 64 copies a fixed
 // 256 x 1024-thread grid.x of k_scatter launched 262 144 wavefronts of which a few hundred found a tile (31 us a launch,
 // 13 us at 24 copies: the launch of empty wavefronts, not the scatter). `total` = blocks over the whole batch that fill the
-// chip about twice; WG_GRID_FIXED=1 keeps the per-engine constants (A/B), WG_GRID_TOTAL_<SCAN|TILES|RESOLVE> override.
-inline int grid_env(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && atoi(v) > 0 ? atoi(v) : dflt;
-}
+// chip about twice (the values at the call sites are the measured optima of the round-3/4 sweeps, profiles/INDEX.md).
 inline int grid_per_engine(int base, int R, int total) {
-  static const bool fixed = getenv("WG_GRID_FIXED") && atoi(getenv("WG_GRID_FIXED")) != 0;
-  if (fixed || R <= 1) return base;
+  if (R <= 1) return base;
   int b = (total / WG_GRID_DIV + R - 1) / R;
   b = (b + 7) / 8 * 8;  // (a multiple of the 8 XCDs)
   return b > base ? base : b;
 }
-// (the override is read once per call site)
-#define WG_GRID(base, R, NAME, DFLT)               \
-  ([&] {                                           \
-    static const int t_ = grid_env(NAME, DFLT);    \
-    return grid_per_engine(base, R, t_);           \
-  }())
 constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;
 constexpr int GRID_LANE_NODES = 128 / WG_GRID_DIV;   // one lane per node visit (k_handel_lane)
 constexpr int GRID_RESOLVE = 512 / WG_GRID_DIV;

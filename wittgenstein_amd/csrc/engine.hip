@@ -1052,7 +1052,7 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 
 template <class F>
 void Engine::scan(const Group& g, const typename F::Aux* atab) {
-  static const int total = grid_env("WG_GRID_TOTAL_SCAN", 1024);
+  constexpr int total = 1024;
   const int gx = grid_per_engine(SCAN_GRID, g.R, total);
   hipLaunchKernelGGL(k_scan1<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
   hipLaunchKernelGGL(k_scan2<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
@@ -1061,9 +1061,7 @@ template void Engine::scan<ExpandF>(const Group&, const int*);
 // expand: bucket `now` -> events (the pair scan), then the long chain runs it set aside, one wavefront each
 void Engine::expand(const Group& g) {
   scan<ExpandF>(g, nullptr);
-  if (expandRunsGrid < 0)  // (tuning variables are read once per ENGINE, at its first use of them: an in-process A/B builds a new engine)
-    expandRunsGrid = getenv("WG_EXPAND_RUNS_GRID") ? std::max(1, atoi(getenv("WG_EXPAND_RUNS_GRID"))) : GRID_EXPAND_RUNS;
-  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(expandRunsGrid, g.R), dim3(256), 0, g.stream, g.tab);
+  if (dev.runMin) hipLaunchKernelGGL(k_expand_runs, dim3(GRID_EXPAND_RUNS, g.R), dim3(256), 0, g.stream, g.tab);
 }
 template void Engine::scan<RecsF>(const Group&, const int*);
 template void Engine::scan<MultiF>(const Group&, const int*);
@@ -1072,21 +1070,15 @@ template void Engine::scan<MultiF>(const Group&, const int*);
 // built by the producer of the outbox (k_resolve / the protocol's conditional-task kernel); only
 // host-staged envelopes need the standalone histogram kernel.
 void Engine::append_phase(const Group& g, bool needHist) {
-  static const int total = grid_env("WG_GRID_TOTAL_TILES", 512);
+  constexpr int total = 512;
   const int gx = grid_per_engine(GRID_TILES, g.R, total);
   if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
   hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 0);
 }
-// append + end of the phase in two launches instead of three (k_col_reserve_end, then the scatter); WG_FUSE_END=0 keeps three
+// append + end of the phase in two launches instead of three (k_col_reserve_end, then the scatter)
 void Engine::append_end_phase(const Group& g, bool drained) {
-  static const bool fuse = !(getenv("WG_FUSE_END") && atoi(getenv("WG_FUSE_END")) == 0);
-  if (!fuse) {
-    append_phase(g, false);
-    end_phase(g, drained);
-    return;
-  }
-  static const int total = grid_env("WG_GRID_TOTAL_TILES", 512);
+  constexpr int total = 512;
   const int gx = grid_per_engine(GRID_TILES, g.R, total);
   hipLaunchKernelGGL(k_col_reserve_end, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab, drained ? 1 : 0);
   hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 1);
@@ -1364,7 +1356,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
       ProfScope ps(lead, Engine::PC_RESOLVE);
       // (a block that finds no record still costs its launch — ~ 7 ns each, 25 us of GSFSignature's every ms at 4096 blocks,
       // profiles/r14j —: the wide grid only in a ms in which a periodic task may fire)
-      static const int total = grid_env("WG_GRID_TOTAL_RESOLVE", 4096), totalQuiet = grid_env("WG_GRID_TOTAL_RESOLVE_QUIET", 512);
+      constexpr int total = 4096, totalQuiet = 512;
       const int gx = grid_per_engine(GRID_RESOLVE, g.R, g.any_periodic_may_fire() ? total : totalQuiet);
       hipLaunchKernelGGL(k_resolve<false>, dim3(gx, g.R), dim3(256), 0, g.stream, g.tab);
     }
@@ -1379,7 +1371,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
       // with a conditional-task phase behind it the drain only ENDS here (clock, rd, the drained bucket's pages): its ordered
       // outbox stays in fin / arr, the edge's records follow it there, and the phase's append files both — one
       // k_col_reserve_end + k_scatter per simulated ms instead of two (WG_MERGE_APPEND=0: two)
-      static const bool merge = !(getenv("WG_MERGE_APPEND") && atoi(getenv("WG_MERGE_APPEND")) == 0);
+      const bool merge = !(getenv("WG_MERGE_APPEND") && atoi(getenv("WG_MERGE_APPEND")) == 0);  // (read per call: tests toggle it)
       if (cond && merge)
         Engine::end_phase(g, true, true);
       else
@@ -2535,12 +2527,8 @@ struct HandelHost : ProtoHost {
   HandelState st{};
   Engine& eng;
   uint32_t* dCont = nullptr;
-  // register-allocation variants of the two latency-bound kernels (waves per SIMD the allocation admits);
-  // tuning knobs, see DESIGN.md "Occupancy"
-  int wavesDeliver = getenv("WG_DELIVER_WAVES") ? atoi(getenv("WG_DELIVER_WAVES")) : 4;
-  int wavesCond = getenv("WG_COND_WAVES") ? atoi(getenv("WG_COND_WAVES")) : 5;  // (k_handel_a1c with the group form: 82 VGPRs; k_handel_a1w alone: 79)
-  int wavesUpdate = getenv("WG_UPDATE_WAVES") ? atoi(getenv("WG_UPDATE_WAVES")) : 6;
-  int wavesDissem = getenv("WG_DISSEM_WAVES") ? atoi(getenv("WG_DISSEM_WAVES")) : 8;
+  // (the register allocations of the latency-bound kernels — waves per SIMD: k_handel_wave 4, k_handel_a1c 5,
+  // k_handel_update 6, k_handel_dissem 8 — are the measured optima of the sweeps in profiles/INDEX.md; DESIGN.md "Occupancy")
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const auto tCtor = std::chrono::steady_clock::now();
     const int32_t N = p.nodeCount;
@@ -2666,7 +2654,6 @@ struct HandelHost : ProtoHost {
     st.jobCount = e.dalloc<uint32_t>(1);
     st.jobsSmall = e.dalloc<CopyJob>(e.dev.maxEvents, false, Engine::AC_SCRATCH);
     st.jobSmallCount = e.dalloc<uint32_t>(1);
-    st.jobSmallMax = getenv("WG_JOB_SMALL") && atoi(getenv("WG_JOB_SMALL")) >= 0 ? atoi(getenv("WG_JOB_SMALL")) : H_JOB_SMALL;
     st.itemsUpd = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.updCount = e.dalloc<uint32_t>(1);
     st.itemsTrail = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
@@ -2675,13 +2662,8 @@ struct HandelHost : ProtoHost {
     st.trail2Count = e.dalloc<uint32_t>(1);
     st.itemsDis = e.dalloc<U4>(nLoc, false, Engine::AC_SCRATCH);
     st.disCount = e.dalloc<uint32_t>(1);
-    st.disTier = getenv("WG_DIS_TIER") ? (atoi(getenv("WG_DIS_TIER")) != 0) : 1;
     st.atk = p.byzantineSuicide ? 1 : p.hiddenByzantine ? 2 : 0;
-    st.exp = getenv("WG_EXP") ? atoi(getenv("WG_EXP")) : 0;
-    st.a1Group = !(getenv("WG_A1_GROUP") && atoi(getenv("WG_A1_GROUP")) == 0);
-    st.updTrail = !(getenv("WG_UPD_TRAIL") && atoi(getenv("WG_UPD_TRAIL")) == 0);
     st.laneNw = getenv("WG_LANE_NW") ? std::max(1, std::min(H_LANE_NW, atoi(getenv("WG_LANE_NW")))) : H_LANE_NW;
-    st.a1LaneShare = getenv("WG_A1_LANE_SHARE") ? std::max(1, std::min(15, atoi(getenv("WG_A1_LANE_SHARE")))) : 8;
     st.blacklist = st.atk == 1 ? e.dalloc<uint64_t>((size_t)N * W, true, Engine::AC_SCRATCH) : nullptr;
     st.candMask = e.dalloc<uint32_t>(N);
     st.cleanMask = e.dalloc<uint32_t>(N);
@@ -2744,7 +2726,7 @@ struct HandelHost : ProtoHost {
     st.xout = st.xin = nullptr;
     st.xoutCount = nullptr;
     st.xcounts = nullptr;
-    directed = e.shardCount > 0 && e.has_alltoall() && !(getenv("WG_SHARD_SNAP") && !strcmp(getenv("WG_SHARD_SNAP"), "image"));
+    directed = e.shardCount > 0 && e.has_alltoall();  // (no all-to-all callback: the all-reduce image of rounds 1-4)
     if (directed) {  // the snapshots' sub-rows go to the shard that reads them (HandelState::xout)
       st.xS = e.shardCount;
       st.xMe = e.shardIndex;
@@ -2996,36 +2978,15 @@ struct HandelHost : ProtoHost {
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
-  template <int W>
-  void launch_a1w(const Group& g, const HandelState* stab, int R, hipStream_t s) {
-    hipLaunchKernelGGL((k_handel_a1w<W, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
-  }
   int variant() const override { return st.atk; }
   void launch_a1(const Group& g, const HandelState* stab, int R, hipStream_t s) {
     if (st.atk) {  // an attack's run: the instantiation with the attack's paths, every item a wavefront
       hipLaunchKernelGGL((k_handel_a1w<4, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
       return;
     }
-    if (!a1Split) {  // both kinds of items in one launch
-      if (!st.a1Group)
-        hipLaunchKernelGGL((k_handel_a1c<4, false>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
-      else if (wavesCond >= 6)  // (80 VGPRs with 12 bytes of scratch; 82 and five waves a SIMD without)
-        hipLaunchKernelGGL((k_handel_a1c<6, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
-      else
-        hipLaunchKernelGGL((k_handel_a1c<5, true>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
-      return;
-    }
-    // the narrow levels' items, one lane each (~ 5 k an engine in an ordinary ms of config 3), then the wide levels', one wavefront each
-    if (st.a1Group)
-      hipLaunchKernelGGL(k_handel_a1<true>, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
-    else
-      hipLaunchKernelGGL(k_handel_a1<false>, dim3(WG_GRID(GRID_COND_TAIL, R, "WG_GRID_TOTAL_A1L", 1024), R), dim3(256), 0, s, g.tab, stab);
-    switch (wavesCond) {
-      case 8: launch_a1w<8>(g, stab, R, s); break;
-      case 5: launch_a1w<5>(g, stab, R, s); break;
-      case 4: launch_a1w<4>(g, stab, R, s); break;
-      default: launch_a1w<6>(g, stab, R, s);
-    }
+    // both kinds of items in one launch: the narrow levels' by groups of eight lanes, the wide levels' one wavefront each
+    // (as two launches: 44 + 33 us per ordinary ms against ~ 70 us, profiles/r13h_*)
+    hipLaunchKernelGGL((k_handel_a1c<5>), dim3(a1_grid(R), R), dim3(256), 0, s, g.tab, stab);
   }
   void launch_cond(Engine& profOwner, const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
@@ -3039,13 +3000,13 @@ struct HandelHost : ProtoHost {
     if (st.atk == 2)  // HiddenByzantine.attack on the drawn candidates of the last level
       hipLaunchKernelGGL(k_handel_hidden, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     if (st.atk)
-      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
     else
     {
       // one thread per drawing node — about a quarter of the nodes at pairingTime 4 —, ONE round of them: a grid that makes a
       // thread take a second node doubles the kernel's chain (22 -> 29 us at 32 copies with the batch-wide total alone)
       const int floorBlocks = std::min(GRID_COND_TAIL, ((st.N / 3 + 255) / 256 + 7) / 8 * 8);
-      const int gx = std::max(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), floorBlocks);
+      const int gx = std::max(grid_per_engine(GRID_COND_TAIL, g.R, 1024), floorBlocks);
       hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(gx, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
   }
@@ -3112,54 +3073,34 @@ struct HandelHost : ProtoHost {
   // blocks per engine of the wave-per-item kernels. Their pipelined loops want SEVERAL items per wavefront (the next
   // item's header is fetched during the current one), so the grid is about twice the chip's resident waves over the
   // whole batch (the factor lets the blocks of members whose run has ended — they return at once — leave their share to the
-  // others); WG_NODE_GRID=<blocks per engine> overrides
-  int nodeGridEnv = getenv("WG_NODE_GRID") ? atoi(getenv("WG_NODE_GRID")) : 0;
+  // others)
   int node_grid(int R) const {
-    if (nodeGridEnv > 0) return nodeGridEnv;
     int b = (2 * 1024 / WG_GRID_DIV) / (R > 0 ? R : 1);
     return b < 16 ? 16 : b;
   }
-  // k_handel_a1 alone wants more blocks than the delivery kernels (its lane-item blocks hold 256 items each and an ordinary
-  // ms has ~ 10 k of them per engine): WG_A1_GRID=<blocks per engine>, default a multiple of node_grid (WG_A1_GRID_MUL)
-  // (measured, profiles/r13h_*: as two launches 44 + 33 us per ordinary ms — the lane half is one long chain whatever its grid —
-  // against ~ 70 us for the one launch in which the two halves overlap; WG_A1_SPLIT=1 keeps the two-launch form)
-  bool a1Split = getenv("WG_A1_SPLIT") && atoi(getenv("WG_A1_SPLIT")) != 0;
-  int a1GridEnv = getenv("WG_A1_GRID") ? atoi(getenv("WG_A1_GRID")) : 0;
-  // (the group form holds 32 items a block where the lane form held 256: 6 x the delivery kernels' blocks, half of them on
-  // the groups — profiles/r13q_sweep_a1_grid.txt)
-  int a1GridMul = getenv("WG_A1_GRID_MUL") && atoi(getenv("WG_A1_GRID_MUL")) > 0 ? atoi(getenv("WG_A1_GRID_MUL")) : 6;
-  int a1_grid(int R) const { return a1GridEnv > 0 ? a1GridEnv : a1GridMul * node_grid(R); }
+  // k_handel_a1c wants more blocks than the delivery kernels (its group blocks hold 32 items each and an ordinary ms has
+  // ~ 10 k of them per engine): 6 x the delivery kernels' blocks, half of them on the groups (profiles/r13q_sweep_a1_grid.txt)
+  int a1_grid(int R) const { return 6 * node_grid(R); }
   // the delivery pass: k_handel_lane (one lane per node: SendSigs deliveries, narrow updateVerifiedSignatures; sorts the
   // other nodes into the next kernel's list), k_handel_copy (the wide payloads it delivered, one wavefront each), then
   // k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    hipLaunchKernelGGL(k_handel_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_LANE", 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
-    switch (wavesUpdate) {
-      case 8: hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 4: hipLaunchKernelGGL(k_handel_update<4>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      case 5: hipLaunchKernelGGL(k_handel_update<5>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab); break;
-      default: hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
-    }
+    hipLaunchKernelGGL(k_handel_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     // the deliveries behind a wide update that was its node's first event, one lane per node (after the update)
-    if (st.updTrail && !st.atk)
-      hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2", 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
+    if (!st.atk)
+      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
     const dim3 grid(node_grid(g.R), g.R);
     // In a ms whose phase no member's dissemination task has (19 of 20 with a synchronised start) the lean dissemination kernel
     // would find an empty list: not launched (6 us each at 24 copies). k_handel_wave is told, and stops the run loudly should
     // the list not be empty after all.
     const bool mayDissem = g.periodic_may_fire(H_TASK_DISSEMINATION);
-    const int disSkipped = st.disTier && !st.atk && !mayDissem;
-    if (st.disTier && !st.atk && mayDissem) {  // nodes whose first event is their dissemination: that event
-      switch (wavesDissem) {
-        case 4: hipLaunchKernelGGL(k_handel_dissem<4>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-        case 5: hipLaunchKernelGGL(k_handel_dissem<5>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-        case 6: hipLaunchKernelGGL(k_handel_dissem<6>, grid, dim3(256), 0, g.stream, g.tab, stab); break;
-        default: hipLaunchKernelGGL(k_handel_dissem<8>, grid, dim3(256), 0, g.stream, g.tab, stab);
-      }
+    const int disSkipped = !st.atk && !mayDissem;
+    if (!st.atk && mayDissem) {  // nodes whose first event is their dissemination: that event
+      hipLaunchKernelGGL(k_handel_dissem<8>, grid, dim3(256), 0, g.stream, g.tab, stab);
       // ... and the plain deliveries behind it, one lane per node (the others' remaining events are visits of k_handel_wave)
-      if (st.updTrail)
-        hipLaunchKernelGGL(k_handel_lane2, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_LANE2B", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
+      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
     // every wide payload the lane kernels delivered, one wavefront per copy (behind the dissemination: it reads no queue slot)
     hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
@@ -3167,13 +3108,7 @@ struct HandelHost : ProtoHost {
       hipLaunchKernelGGL((k_handel_wave<4, true>), grid, dim3(256), 0, g.stream, g.tab, stab, 0);
       return;
     }
-    switch (wavesDeliver) {
-      case 8: hipLaunchKernelGGL((k_handel_wave<8, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
-      case 6: hipLaunchKernelGGL((k_handel_wave<6, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
-      case 5: hipLaunchKernelGGL((k_handel_wave<5, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
-      case 3: hipLaunchKernelGGL((k_handel_wave<3, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped); break;
-      default: hipLaunchKernelGGL((k_handel_wave<4, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped);
-    }
+    hipLaunchKernelGGL((k_handel_wave<4, false>), grid, dim3(256), 0, g.stream, g.tab, stab, disSkipped);
   }
   bool launch_cont_if(const Group& g, uint32_t* dOut) override {
     hipLaunchKernelGGL(k_handel_cont_if, dim3(std::max(1, std::min(8, (st.N + 255) / 256)), g.R), dim3(256), 0, g.stream, g.tab,
@@ -3370,8 +3305,8 @@ struct GsfHost : ProtoHost {
     if (!init.nodePairingTime || !init.peers) throw WgError(WG_EINVAL, "wg_gsf_init_state has NULL members");
     if (p.acceleratedCallsCount > 64)
       throw WgError(WG_EUNSUPPORTED, "acceleratedCallsCount > 64 (device multi-destination sends hold <= 64 ids)");
-    // a node's events of the ms from its inbox line (k_deliver_inbox) where the engine is not allocated yet; WG_GSF_INBOX=0: the list
-    if (!e.allocated && !(getenv("WG_GSF_INBOX") && atoi(getenv("WG_GSF_INBOX")) == 0)) e.wantInbox = true;
+    // a node's events of the ms from its inbox line (k_deliver_inbox) where the engine is not allocated yet
+    if (!e.allocated) e.wantInbox = true;
     if (p.periodDurationMs <= 0) throw WgError(WG_EINVAL, "periodDurationMs");
     int L = 1;
     while ((1 << L) <= N) L++;  // levels 0..log2(N) (:182-192)
@@ -3484,17 +3419,13 @@ struct GsfHost : ProtoHost {
     {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
-      static const bool group = !(getenv("WG_GSF_A1_GROUP") && atoi(getenv("WG_GSF_A1_GROUP")) == 0);
-      if (group) {  // eight lanes per runner for the short lists; what is left over, one wavefront each
-        hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_GSF_A1G", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
-        hipLaunchKernelGGL(k_gsf_cond_a1, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_GSF_A1", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
-      } else {
-        hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
-      }
+      // eight lanes per runner for the short lists; what is left over, one wavefront each
+      hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
-    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(WG_GRID(GRID_COND_TAIL, g.R, "WG_GRID_TOTAL_TAIL", 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
@@ -3526,26 +3457,19 @@ struct GsfHost : ProtoHost {
   }
   void launch_deliver(const Group& g) override {
     // the lean kernels first: a node's doCycle task (k_gsf_docycle, in the ms in which it can fire) and plain SendSigs
-    // deliveries (k_gsf_lane) — between them every node without an updateVerifiedSignatures task (gsf_split_ok); WG_GSF_LANE=0:
-    // every visit by k_deliver_inbox
-    static const bool laneTier = !(getenv("WG_GSF_LANE") && atoi(getenv("WG_GSF_LANE")) == 0);
-    static const int cycleTier = getenv("WG_GSF_DOCYCLE") ? atoi(getenv("WG_GSF_DOCYCLE")) : 8;  // wavefronts per SIMD of the doCycle kernel; 0: off
-    const bool cycleRan = eng.dev.inbox && laneTier && cycleTier && g.periodic_may_fire(G_TASK_DOCYCLE);
+    // deliveries (k_gsf_lane) — between them every node without an updateVerifiedSignatures task (gsf_split_ok)
+    const bool cycleRan = eng.dev.inbox && g.periodic_may_fire(G_TASK_DOCYCLE);
     // k_deliver_inbox visits the nodes k_gsf_lane lists (what the lean kernels did not take) instead of looking at every active
     // node's inbox count; WG_GSF_REST_LIST=0: as before
     const bool restList = !(getenv("WG_GSF_REST_LIST") && atoi(getenv("WG_GSF_REST_LIST")) == 0);  // (read per call: tests toggle it)
-    if (cycleRan && st.L <= 16 && cycleTier != 6) {  // sixteen lanes per node, four nodes per wavefront
+    if (cycleRan && st.L <= 16)  // sixteen lanes per node, four nodes per wavefront
       hipLaunchKernelGGL(k_gsf_docycle16, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
-    } else if (cycleRan) {
-      if (cycleTier == 8)
-        hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
-      else
-        hipLaunchKernelGGL(k_gsf_docycle<6>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
-    }
-    if (eng.dev.inbox && laneTier)
-      hipLaunchKernelGGL(k_gsf_lane, dim3(WG_GRID(GRID_LANE_NODES, g.R, "WG_GRID_TOTAL_GSF_LANE", 1024), g.R), dim3(256), 0, g.stream, g.tab,
+    else if (cycleRan)
+      hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
+    if (eng.dev.inbox)
+      hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab, cycleRan ? 1 : 0, restList ? 1 : 0);
-    if (eng.dev.inbox && laneTier && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
+    if (eng.dev.inbox && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
       hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4, true>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab);
     else if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
@@ -3784,19 +3708,17 @@ struct CasperHost : ProtoHost {
     }
     st.forked = e.dalloc<uint32_t>(1);
     st.builds = e.dalloc<uint32_t>(1);
-    st.laneEvents = getenv("WG_CASPER_LANE_EVENTS") ? (uint32_t)(atoi(getenv("WG_CASPER_LANE_EVENTS")) != 0) : 1u;
-    if (p.randomOnTies || st.seqCapable) st.laneEvents = 1u;  // (k_casper_seq hands k_deliver an empty set through the mixed flags)
-    // sharded: the block / attestation table exchange and the two-blocks-in-one-ms check hang on k_casper_classify's
-    // anyTask flag, which only the lane-per-event path launches — the A/B switch does not apply to a sharded engine
-    if (e.shardCount > 0) st.laneEvents = 1u;
-    e.dev.laneMsgPlus1 = st.laneEvents ? (uint32_t)C_MSG_ATTESTATION + 1u : 0u;  // attestations are not threaded onto inbox lists
+    // attestation-only nodes are delivered one lane per event (k_casper_attestations): k_casper_seq hands k_deliver an empty
+    // set through the mixed flags, and a sharded engine's table exchange hangs on k_casper_classify's anyTask flag
+    st.laneEvents = 1u;
+    e.dev.laneMsgPlus1 = (uint32_t)C_MSG_ATTESTATION + 1u;  // attestations are not threaded onto inbox lists
     e.dev.boundMsg = 1;  // ByzBlockProducerWF.onBlock: one sendAll or one registerTask
     for (int k = 0; k < 4; k++) e.dev.boundTask[k] = 1;  // one sendAll (+ the periodic re-arm expand adds)
     hipLaunchKernelGGL(k_casper_init, dim3((N + 255) / 256), dim3(256), 0, e.stream, st, lo, hi);
     WG_HIP(hipStreamSynchronize(e.stream));
   }
   int32_t lo = 0, hi = 0, xtabWords = 0;
-  const int attGrid = getenv("WG_CASPER_ATT_GRID") ? std::max(1, atoi(getenv("WG_CASPER_ATT_GRID"))) : GRID_RESOLVE;  // (per engine)
+  const int attGrid = GRID_RESOLVE;  // (per engine)
   // ---- node-range sharding (Engine::run_ms_sharded): a delivery touches the receiver's rows only; sendAll goes through the
   // replicated envelope creation (k_shard_multi_*, k_sendall_*); what the ms's action()s added to the replicated block /
   // attestation tables is exchanged after the delivery pass (CasperState::xtab, k_casper_shard_apply) — in the ms that hold

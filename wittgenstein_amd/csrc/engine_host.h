@@ -283,7 +283,6 @@ class Engine {
   void collect_far();            // FarRec -> staged (host-held) envelopes
   int32_t* skipBuf = nullptr;    // k_next_busy's result, one word per member of the group this engine leads
   int skipCap = 0;
-  int expandRunsGrid = -1;       // WG_EXPAND_RUNS_GRID, read at the engine's first expand
   bool wantInbox = false;        // the resident protocol reads a node's events from its inbox line (EngineDev::inbox)
   int32_t sendAllCapacity = 0;   // Network.sendAll calls per simulated ms a resident protocol's action()s may make
   int32_t horizonFloor = 0;      // a resident protocol's longest task delay (default horizon_ms only)

@@ -98,14 +98,10 @@ struct HandelState {
   GP<const uint32_t> peersR;              // [N][N-1] id | rank << 16
   GP<uint32_t> bump;                      // [N][bumpCap]
   int32_t bumpCap;                        // a power of two <= N (wg_config.rank_bump_cap; a full table is a loud error)
-  int32_t exp;                            // TEMP experiments (WG_EXP bit mask)
   // byzantineSuicide (P/Handel.java:64-69): HNode.blacklist as one N-bit row per node (:289); HLevel.suicideBizAfter
   // (:406) is the header plane HP_SPARE0, SigToVerify.badSig the record word qBad. atk == 0: none of it is touched
   GP<uint64_t> blacklist;                 // [N][W] (byzantineSuicide only)
   int32_t atk;                            // 1 byzantineSuicide, 2 hiddenByzantine
-  int32_t a1LaneShare;                    // sixteenths of k_handel_a1's blocks that take the one-lane items (WG_A1_LANE_SHARE)
-  int32_t a1Group;                        // 1: the narrow levels' items by groups of eight lanes (default), 0: one lane each (WG_A1_GROUP=0)
-  int32_t updTrail;                       // 1: k_handel_update also takes a wide update FIRST + the deliveries behind it (WG_UPD_TRAIL=0: k_handel_wave)
   int32_t laneNw;                         // H_LANE_NW, or WG_LANE_NW (tests: the wave-per-item paths on networks the emulator can run)
   // emission lists [N][N-1] (:510-522), never written after init(): 16-bit ids when N <= 65536 (half the bytes of the
   // second-largest array of a copy — more resident copies per GPU), 32-bit otherwise; read through h_peer()
@@ -188,12 +184,10 @@ struct HandelState {
   // the node's later events follow in k_handel_wave (skip = 1)
   GP<U4> itemsDis;                        // [N]
   GP<uint32_t> disCount;                  // [1] (reset with jobCount)
-  int32_t disTier;                        // 0: off (WG_DIS_TIER=0): those nodes are visits of k_handel_wave as before
   GP<uint32_t> jobCount;                  // [1] (reset by k_handel_cond_pre of the edge that follows)
   // ... the payloads of at most H_JOB_SMALL words apart: k_handel_copy moves eight of them per wavefront
   GP<CopyJob> jobsSmall;                  // [maxEvents]
   GP<uint32_t> jobSmallCount;             // [1] (reset with jobCount)
-  int32_t jobSmallMax;                    // words (H_JOB_SMALL; WG_JOB_SMALL)
   GP<uint32_t> candMask;                  // [N] bit l: level l has a candidate at this edge (0 for a node whose task does not run)
   GP<uint32_t> cleanMask;                 // [N] ... of which: clean levels, answered from their summary by k_handel_cond_pre (no item)
   // sharded engines: how many levels of every node have a candidate at this edge, one BYTE per node (four nodes an int32
@@ -436,7 +430,7 @@ constexpr int H_JOB_SMALL = 64;  // words: a payload of a level of up to 4096 id
 // (every lane of the wavefront calls it; job.nw == 0: none)
 __device__ __forceinline__ void h_emit_job(const HandelState& s, const CopyJob& job) {
   const int lane = WG_LANE;
-  const bool small = job.nw > 0 && job.nw <= s.jobSmallMax, large = job.nw > s.jobSmallMax;
+  const bool small = job.nw > 0 && job.nw <= H_JOB_SMALL, large = job.nw > H_JOB_SMALL;
   const uint64_t ms = __ballot(small), ml = __ballot(large);
   if (ms) {
     uint32_t jb = 0;
@@ -1416,7 +1410,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     // k_handel_update: the deliveries before it are this lane's); else a wavefront of k_handel_wave
     bool mine = have && cnt <= (uint32_t)INBOX_SLOTS && !s.atk;  // (byzantineSuicide: every visit by k_handel_wave)
     // the node's first event is its dissemination: the lean kernel takes that event, k_handel_wave the rest
-    const bool disFirst = mine && s.disTier && ((E[0].w0 >> 28) & 3u) == K_PERIODIC && E[0].w2 == H_TASK_DISSEMINATION;
+    const bool disFirst = mine && ((E[0].w0 >> 28) & 3u) == K_PERIODIC && E[0].w2 == H_TASK_DISSEMINATION;
     if (disFirst) mine = false;
     {
       const uint64_t m = __ballot(disFirst);
@@ -1457,7 +1451,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
               wideAt = k;
             else {
               mine = false;
-              updFirst = k == 0 && unw <= H_UPD_NW && s.updTrail;
+              updFirst = k == 0 && unw <= H_UPD_NW;
             }
           }
         } else {
@@ -1468,7 +1462,7 @@ __global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict
     if (nUpd > 1) mine = false;
     updFirst = updFirst && have && plainBehind && nUpd == 1 && cnt <= (uint32_t)INBOX_SLOTS && !s.atk && !disFirst;
     // the dissemination first and only plain deliveries behind it: those are a lane's (k_handel_lane2's second launch, behind k_handel_dissem)
-    const bool disTrail = disFirst && cnt > 1u && plainBehind && nUpd == 0 && s.updTrail && !s.atk;
+    const bool disTrail = disFirst && cnt > 1u && plainBehind && nUpd == 0 && !s.atk;
     {
       const uint64_t tm = __ballot(disTrail);
       if (tm) {
@@ -2595,130 +2589,9 @@ __device__ __forceinline__ long long h_best_wave(const EngineDev& d, const Hande
 }
 
 // A1: bestToVerify (:570-634) of one (runner, level) item with something to evaluate: curates the level's list, records
-// its candidate and summary. k_handel_a1c runs both kinds of items in one launch (the default), k_handel_a1 (one LANE per
-// item of a narrow level) + k_handel_a1w (one WAVEFRONT per item of a wide level; the attack's runs use it alone) are the
-// two-launch form: the wave half alone needs 79 VGPRs (6 waves a SIMD) where the lane half needs 118, but the lane half is
-// one long chain per item — 44 us by itself — which the one-launch form hides behind the wave items (profiles/r13h_*).
-// bestToVerify of one (node, level) item by ONE lane: an entry's cached evaluation, or its signature streamed against the
-// level's three sets. The slow path of the group form below (lists of more than eight entries) and the reference form of it.
-__device__ __forceinline__ void h_a1_lane_one(const EngineDev& d, const HandelState& s, int32_t node, int l) {
-  const uint32_t WG_G* hdr = h_hdr(s, node);
-  const Lv v = sib_view(node, l);
-  const uint64_t WG_G* ti = h_row(s, node, HK_TI, l);
-  const uint64_t WG_G* la = h_row(s, node, HK_LA, l);
-  const uint64_t WG_G* vi = h_row(s, node, HK_VI, l);
-  uint64_t WG_G* qr = h_qrec(s, node, l);
-  uint64_t WG_G* ent = qr + H_QENT;
-  uint32_t WG_G* cache = s.qcache + ((size_t)node * s.L + l) * (size_t)s.QC;
-  // ---- everything the item's address alone decides, before the first use: the record's first line (head, valid mask,
-  // four entries) and the cached evaluations of the slots 0 .. 3 (slots are taken lowest first: those are the usual ones)
-  const int window = (int)hdr[HH_WINDOW];
-  const U4 lvA = gld((const U4 WG_G*)h_lv(s, node, HP_POS, l));
-  const HQHead qh = gld((const HQHead WG_G*)qr);
-  const uint64_t valid0 = qr[H_QVALID];
-  uint64_t e4[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) e4[i] = ent[i];
-  const U4 c4 = gld((const U4 WG_G*)cache);
-  const int len = (int)qh.len, curSize = (int)lvA.y, cLA = (int)lvA.z;
-  int windowIndex = INT32_MAX;  // Collections.min(rank)
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-    if (i < len) windowIndex = min(windowIndex, (int)(uint32_t)(e4[i] >> 32));
-  for (int i = 4; i < len; i++) windowIndex = min(windowIndex, (int)(uint32_t)(ent[i] >> 32));
-  long long bestInside = -1, bestOutside = -1;  // signer << 8 | slot of the entry
-  int bestScore = 0, bestOutsideRank = 0;
-  unsigned long long keep = 0;
-  uint64_t newValid = valid0;
-  int sumMin = INT32_MAX, sumMax = 0;  // the level's summary over the entries that stay listed (h_summary_has_candidate)
-  bool sumPos = false;
-  // one entry after the other: its cached evaluation, or its signature streamed against the level's three sets (whose
-  // lines stay in L1) and the result cached
-  auto consider = [&](int i, uint64_t x) {
-    const int slot = (int)(x & 0xFF);
-    uint32_t cw;
-    if ((valid0 >> slot) & 1ULL) {
-      cw = slot == 0 ? c4.x : slot == 1 ? c4.y : slot == 2 ? c4.z : slot == 3 ? c4.w : cache[slot];
-    } else {
-      int u1 = 0, u2 = 0, cs = 0;
-      bool iTI = false, iLA = false;
-      h_stream4(h_sig_ptr(s, node, l, slot), la, vi, la, v.nw, [&](int, uint64_t sg, uint64_t tiw, uint64_t viw, uint64_t law) {
-        viw &= v.mask;
-        law &= v.mask;
-        tiw = law | viw;  // totalIncoming = lastAggVerified | verifiedIndSignatures (the row is not read)
-        u1 += __popcll(sg | tiw | viw);
-        u2 += __popcll(sg | viw);
-        cs += __popcll(sg);
-        iTI |= (sg & tiw) != 0;
-        iLA |= (sg & law) != 0;
-      });
-      cw = h_eval_word(u1, u2, cs, iTI, iLA, curSize, cLA, v.size);
-      cache[slot] = cw;
-      newValid |= 1ULL << slot;
-    }
-    const long long who = (long long)(uint32_t)x;  // signer << 8 | slot
-    const int rank = (int)(uint32_t)(x >> 32);
-    if (cw & 1u) {  // only signatures that can result in a better aggregate stay listed (:592)
-      keep |= 1ULL << i;
-      sumMin = min(sumMin, rank);
-      sumMax = max(sumMax, rank);
-      sumPos |= (cw >> 1) != 0;
-      if (h_in_window(rank, windowIndex, window)) {  // best inside = FIRST entry with the strictly greatest positive score
-        const int score = (int)(cw >> 1);
-        if (score > bestScore) {
-          bestScore = score;
-          bestInside = who;
-        }
-      } else if (bestOutside < 0 || rank < bestOutsideRank) {  // best outside = FIRST entry with the smallest rank
-        bestOutside = who;
-        bestOutsideRank = rank;
-      }
-    }
-  };
-  // (one copy of the body: the four entries of the head line by selects, not by four inlined copies — registers)
-  for (int i = 0; i < len; i++) consider(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
-  const int kept = __popcll(keep);
-  unsigned long long relMask = 0;
-  if (kept != len) {
-    const U4 pend = gld((const U4 WG_G*)(hdr + HH_PEND));
-    int pos = 0;
-    auto curate = [&](int i, uint64_t x) {
-      if ((keep >> i) & 1ULL) {
-        if (pos != i) ent[pos] = x;
-        pos++;
-      } else {  // the slot of a dropped entry is released unless a registered task still holds it
-        const uint32_t key = h_pend_word(l, (int)(x & 0xFF));
-        if (!(pend.x == key || pend.y == key || pend.z == key || pend.w == key)) relMask |= 1ULL << (x & 0xFF);
-      }
-    };
-    for (int i = 0; i < len; i++) curate(i, i == 0 ? e4[0] : i == 1 ? e4[1] : i == 2 ? e4[2] : i == 3 ? e4[3] : ent[i]);
-  }
-  if (newValid != valid0) qr[H_QVALID] = newValid;
-  h_item_finish(s, node, l, qr, qh, len, kept, relMask, bestInside >= 0 ? bestInside : bestOutside,
-                (uint32_t)sumMin | (sumPos ? 0x80000000u : 0u), (uint32_t)sumMax);
-#ifdef WG_KPROF
-  {  // how much of checkSigs the cached evaluations serve (tools/kprof.sh)
-    const int miss = __popcll(newValid & ~valid0);
-    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 28]), 1ULL);
-    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 29]), (unsigned long long)len);
-    atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 17]), (unsigned long long)miss);
-    if (miss) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 18]), 1ULL);
-    if (v.nw > s.laneNw) atomicAdd(F(&d.g->kprofBuf[KPROF_WAVE + 27]), 1ULL);
-  }
-#endif
-}
-__device__ __forceinline__ void h_a1_lane_items(const EngineDev& d, const HandelState& s, uint32_t block, uint32_t nBlocks) {
-  // ---------------- one lane per item ----------------
-  KPROF_DECL;
-  const uint32_t nItems = s.itemCount[0];
-  const uint32_t stride = nBlocks * blockDim.x;
-  for (uint32_t q = block * blockDim.x + threadIdx.x; q < nItems; q += stride) {
-    const uint32_t it = s.itemsLane[q];
-    h_a1_lane_one(d, s, (int32_t)(it & 0x00FFFFFFu), (int)(it >> 24));
-  }
-  KPROF_MARK(d.g, 1);   // a lane-part wavefront, start to end
-  KPROF_COUNT(d.g, 2);  // ... how many
-}
+// its candidate and summary. k_handel_a1c runs both kinds of items in one launch — the narrow levels' by groups of eight
+// lanes, the wide levels' one WAVEFRONT each —; k_handel_a1w (wave items only) is what an attack's run uses. (As two launches
+// the narrow half is one long chain per item — 44 us by itself — which the one launch hides behind the wave items: profiles/r13h_*.)
 // ---------------- one GROUP of eight lanes per item: the narrow levels (blocks of <= 16 words), two words a lane ---------
 // One lane per item walked a block of up to 16 words two words a load, one entry after the other: a chain of up to a dozen
 // dependent round trips that made the lane half of k_handel_a1 the phase's longest (44 us of an ordinary ms for ~ 5 k items an
@@ -2957,32 +2830,21 @@ __device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const Handel
     h_best_wave<ATK>(d, s, (int32_t)(it & 0x00FFFFFFu), (int)((it >> 24) & 31u), !ATK && (it >> 31) != 0);
   }
 }
-template <bool GROUP>
-__global__ void __launch_bounds__(256) k_handel_a1(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
-  WG_ENGINE(tab);
-  if (GROUP)
-    h_a1_group_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
-  else
-    h_a1_lane_items(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
-}
 template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1w(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   h_a1_wave_items<ATK>(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
 }
-// both in ONE launch (WG_A1_SPLIT=0): blocks [0, gridDim.x * share / 16) the lane items, the others the wave items — the two
-// kinds of chains in flight together, at the lane half's register count
-template <int WPE, bool GROUP>
+// both in ONE launch: the first half of the blocks the narrow levels' items (groups of eight lanes), the others the wave
+// items — the two kinds of chains in flight together, at the group half's register count
+template <int WPE>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1c(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
-  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x * (uint32_t)s.a1LaneShare / 16u : 1;
-  if (blockIdx.x < laneBlocks) {
-    if (GROUP)
-      h_a1_group_items(d, s, blockIdx.x, laneBlocks);
-    else
-      h_a1_lane_items(d, s, blockIdx.x, laneBlocks);
-  } else
+  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x / 2u : 1;
+  if (blockIdx.x < laneBlocks)
+    h_a1_group_items(d, s, blockIdx.x, laneBlocks);
+  else
     h_a1_wave_items<false>(d, s, blockIdx.x - laneBlocks, gridDim.x - laneBlocks);
 }
 
