@@ -203,6 +203,39 @@ def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
     return out
 
 
+LINE_RATE_CEILING = 21.0e9  # scattered 64-byte reads/s the chip sustains: tools/micro/mlp_probe, profiles/archive/r03b_micro_mlp_probe.txt
+
+
+def pmc_traffic(name, n, R, avg_launch_ns, step_s=None):
+    """(traffic, traffic_source, line_rate, json) of the delivery pass from profiles/<name> — the rocprofv3 PMC passes of the same
+    workload (tools/gpu_final_round.sh); None where the file is of another node / copy count. `line_rate`: the memory-side
+    REQUESTS per second of the pass (TCC_EA0_RDREQ + WRREQ of a request-count pass over the HIP-event duration measured here)
+    against the scattered-line ceiling — `frac` near 1 says the pass runs at the rate the chip serves scattered lines, whatever
+    its bytes are against 8 TB/s."""
+    tpath = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(tpath):
+        return None, None, None, None
+    tj = json.load(open(tpath))
+    if tj.get("replicas") != R or tj.get("nodes") != n:
+        return None, "profiles/%s is of %s copies of %s nodes: not this line's workload" % (name, tj.get("replicas"), tj.get("nodes")), None, None
+    src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload's `bench.py --steps 1`, commit %s%s" % (
+        name, tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
+    lr = None
+    if tj.get("ea_requests_per_launch") and avg_launch_ns > 0:
+        q = float(tj["ea_requests_per_launch"])
+        lr = {"requests_per_launch": q, "read_requests_per_launch": tj.get("ea_read_requests_per_launch"),
+              "write_requests_per_launch": tj.get("ea_write_requests_per_launch"),
+              "requests_per_s": q / (avg_launch_ns * 1e-9), "ceiling_requests_per_s": LINE_RATE_CEILING,
+              "frac": q / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING,
+              "bytes_per_request": float(tj["hbm_bytes_per_launch"]) / q,
+              "source": "TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum (a third PMC pass) per delivery pass / this run's HIP-event duration of "
+                        "the pass; ceiling: tools/micro/mlp_probe, scattered 64-byte reads (profiles/archive/r03b_micro_mlp_probe.txt)"}
+        if step_s and tj.get("whole_step_ea_requests"):
+            lr["whole_step"] = {"requests_per_step": tj["whole_step_ea_requests"], "requests_per_s": tj["whole_step_ea_requests"] / step_s,
+                                "frac": tj["whole_step_ea_requests"] / step_s / LINE_RATE_CEILING}
+    return float(tj["hbm_bytes_per_launch"]), src, lr, tj
+
+
 def replicas_line(workload, n, R_req, K, W, local=0):
     """a compact RunMultipleTimes line for ONE more workload inside the default run (outside `value` and its timed region):
     R copies initialised once, kept as init() images, W warm-up + K timed passes, the delivery pass bracketed by HIP events
@@ -217,7 +250,7 @@ def replicas_line(workload, n, R_req, K, W, local=0):
     first.network().snapshot()
     torch.cuda.synchronize()
     per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
-    R = replicas.plan_replicas(R_req, free0, per_copy)
+    R = replicas.plan_replicas(R_req, free0, per_copy, transient_bytes=0 if workload == "gsf" else replicas.handel_init_transient_bytes(n))
     sims = [first]
     if R > 1:
         def init_one(sd):
@@ -259,6 +292,8 @@ def replicas_line(workload, n, R_req, K, W, local=0):
     alg = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level))) if by_level is not None else 0.0
     per_launch = alg / max(1, dk_spans)
     avg_ns = dk_ns / max(1, dk_spans)
+    traffic, traffic_source, line_rate, _ = pmc_traffic("traffic_gsf.json" if gsf else "traffic_handel%d.json" % n, n, R, avg_ns,
+                                                        elapsed / max(1, K))
     return {
         "metric": "delivered messages/sec (%s; simulated-ms/sec alongside)" % ("GSFSignature" if gsf else "Handel %dk nodes" % (n // 1024)),
         "value": delivered / max(elapsed, 1e-9), "unit": "delivered messages/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -270,10 +305,11 @@ def replicas_line(workload, n, R_req, K, W, local=0):
                                "copies per step (seeds 0..%d), runMs(10) until each copy's continuation predicate is false" % (R, R - 1),
                    "nodes": n, "replicas_per_gpu": R, "replicas_requested": R_req, "hbm_bytes_per_copy_incl_init_image": int(per_copy),
                    "delivered_per_simulation": delivered // max(1, K * R), "init_wall_s": init_wall},
-        "roofline": {"bound": "hbm", "kernel": "k_deliver<GsfProto> (the delivery pass)" if gsf else
+        "roofline": {"bound": "hbm", "kernel": "k_gsf_docycle + k_gsf_lane + k_deliver_inbox<GsfProto> (the delivery pass)" if gsf else
                      "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave (the delivery pass)",
                      "achieved": per_launch / max(1.0, avg_ns), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": per_launch / max(1.0, avg_ns) / HBM_PEAK_GBS, "traffic": None,
+                     "frac": per_launch / max(1.0, avg_ns) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "line_rate": line_rate,
                      "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,
                      "bytes_per_delivered_message": alg / max(1, delivered),
                      "whole_step_frac": alg / (max(elapsed, 1e-9) * 1e9) / HBM_PEAK_GBS},
@@ -633,7 +669,7 @@ def main():
     first.network().snapshot()
     torch.cuda.synchronize()
     per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
-    R = replicas.plan_replicas(R_req, free0, per_copy)
+    R = replicas.plan_replicas(R_req, free0, per_copy, transient_bytes=0 if args.workload == "gsf" else replicas.handel_init_transient_bytes(n))
     if world > 1:  # every rank runs the same batch size (weak scaling: fixed work per GPU)
         rt = torch.tensor([R], device=rdev, dtype=torch.int64)
         dist.all_reduce(rt, op=dist.ReduceOp.MIN)
@@ -813,29 +849,26 @@ def main():
     per_launch_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level_first))) / max(1, dk_spans)
     avg_ns = dk_ns / max(1, dk_spans)
     achieved = per_launch_bytes / max(1.0, avg_ns)  # bytes/ns == GB/s
-    traffic = traffic_source = whole_step_traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the rocprofv3 PMC passes
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("replicas") == R and tj.get("nodes") == n:  # (measured on one batch of R copies: per copy it scales)
-            traffic = tj.get("hbm_bytes_per_launch") * n_first / R
-            if tj.get("whole_step_hbm_bytes") and K > 0:
-                # every per-ms kernel of a step (not only the delivery pass) against the step's algorithmic bytes: the
-                # conditional-task phase, the ordering / append chain and the scans move bytes SURVEY.md §8d does not price
-                ws = float(tj["whole_step_hbm_bytes"])
-                whole_step_traffic = {"hbm_bytes_per_step": ws, "algorithmic_bytes_per_step": alg_bytes / K,
-                                      "ratio": ws / max(1.0, alg_bytes / K),
-                                      "fetch_bytes_per_step": tj.get("whole_step_fetch_bytes"),
-                                      "write_bytes_per_step": tj.get("whole_step_write_bytes")}
-            # the counters cannot be read inside the timed run (rocprofv3 serialises kernels): they come from PMC passes of
-            # the same command; tools/gpu_final_round.sh takes them in the session of the final line and stamps the commit
-            traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, commit %s%s" % (
-                tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
+    whole_step_traffic = None
+    # the counters cannot be read inside the timed run (rocprofv3 serialises kernels): they come from PMC passes of the same
+    # command; tools/gpu_final_round.sh takes them in the session of the final line and stamps the commit
+    traffic, traffic_source, line_rate, tj = pmc_traffic("traffic_gsf.json" if gsf else "traffic.json" if n == 32768 else "traffic_handel%d.json" % n,
+                                                         n, R, avg_ns, elapsed / max(1, K))
+    if tj is not None:  # (measured on one batch of R copies: per copy it scales)
+        traffic = traffic * n_first / R
+        if tj.get("whole_step_hbm_bytes") and K > 0:
+            # every per-ms kernel of a step (not only the delivery pass) against the step's algorithmic bytes: the
+            # conditional-task phase, the ordering / append chain and the scans move bytes SURVEY.md §8d does not price
+            ws = float(tj["whole_step_hbm_bytes"])
+            whole_step_traffic = {"hbm_bytes_per_step": ws, "algorithmic_bytes_per_step": alg_bytes / K,
+                                  "ratio": ws / max(1.0, alg_bytes / K),
+                                  "fetch_bytes_per_step": tj.get("whole_step_fetch_bytes"),
+                                  "write_bytes_per_step": tj.get("whole_step_write_bytes")}
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_gsf_docycle + k_gsf_lane + k_deliver_inbox<GsfProto> (the delivery pass, all inside the HIP-event bracket)" if gsf else "k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + k_handel_dissem + k_handel_wave "
                                                               "(the delivery pass: one launch of each per simulated ms, all six inside the HIP-event bracket and "
                                                               "inside `traffic`)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "line_rate": line_rate,
         "whole_step_traffic": whole_step_traffic,
         "whole_step_frac": alg_bytes / (max(elapsed, 1e-9) * 1e9) / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ns / 1000.0, "launches": dk_spans,

@@ -415,6 +415,12 @@ int32_t wg_rccl_unique_id(uint8_t* id128);
 int32_t wg_shard_configure_rccl(wg_engine* e, int32_t shard, int32_t nshards, const uint8_t* id128);
 /* [lo, hi) of this shard (valid once the nodes are added); collectives / int32 words exchanged so far */
 int32_t wg_shard_info(wg_engine* e, int32_t* lo, int32_t* hi, int64_t* collectives, int64_t* words);
+/* the same two totals split by exchange (eight entries each; no reference counterpart, statistics only): [0] the events'
+ * packed result words, [1] the resolved outbox (record + arrival), [2] multi-destination envelopes, [3] payload snapshots —
+ * words RECEIVED where they travel owner-directed (wg_shard_set_alltoallv / an engine-owned communicator), the all-reduce
+ * image's words otherwise —, [4] the checkSigs edge's candidate counts, [5] the count matrix of the owner-directed
+ * exchange, [6] everything else (Casper's tables, its ordered visit's hand-overs), [7] 0 */
+int32_t wg_shard_traffic(wg_engine* e, int64_t* calls8, int64_t* words8);
 
 /* ---- read-back -------------------------------------------------------------------------- */
 typedef enum {

@@ -161,6 +161,8 @@ public final class WittGpu {
   /** wg_shard_set_alltoallv: the address of a native wg_alltoallv_fn and its context (after shardConfigure, before protocolLoad) */
   public static native int shardSetAlltoallv(long h, long alltoallvFnAddress, long ctxAddress);
   public static native int shardInfo(long h, long[] loHiCollectivesWords);
+  /** wg_shard_traffic: collective calls / int32 words by exchange (eight entries each) */
+  public static native int shardTraffic(long h, long[] calls8, long[] words8);
 
   // ---- read-back
   public static native int readI64(long h, int field, long[] dst);

@@ -502,6 +502,21 @@ WG_JNI(jint, shardSetAlltoallv)(JNIEnv* env, jclass c, jlong h, jlong fnAddr, jl
   (void)c;
   return ck(env, ENG(h), wg_shard_set_alltoallv(ENG(h), (wg_alltoallv_fn)(intptr_t)fnAddr, (void*)(intptr_t)ctxAddr));
 }
+/* calls8 / words8: the totals of shardInfo by exchange (wg_shard_traffic) */
+WG_JNI(jint, shardTraffic)(JNIEnv* env, jclass c, jlong h, jlongArray calls8, jlongArray words8) {
+  (void)c;
+  if (!need(env, calls8, 8, "calls8") || !need(env, words8, 8, "words8")) return WG_EINVAL;
+  int64_t cv[8] = {0}, wv[8] = {0};
+  int32_t rc = wg_shard_traffic(ENG(h), cv, wv);
+  jlong a[8], b[8];
+  for (int k = 0; k < 8; k++) {
+    a[k] = cv[k];
+    b[k] = wv[k];
+  }
+  if (calls8) (*env)->SetLongArrayRegion(env, calls8, 0, 8, a);
+  if (words8) (*env)->SetLongArrayRegion(env, words8, 0, 8, b);
+  return ck(env, ENG(h), rc);
+}
 /* out4 = {lo, hi, collectives, words} */
 WG_JNI(jint, shardInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out4) {
   (void)c;

@@ -23,6 +23,13 @@ def test_plan_replicas_degrades_and_never_fails():
     assert replicas.plan_replicas(16, 288 * GB, 18 * GB) == 15
     assert replicas.plan_replicas(16, 288 * GB, 400 * GB) == 1          # does not fit at all: still one copy, no error
     assert replicas.plan_replicas(4, 0, 0) == 4                         # nothing measured: the request stands
+    # Handel's init() holds nodeCount^2 rank matrices only while it runs (at most 16 GiB of them at a time): the batch leaves that
+    # beside the copies — 31 copies of config 3 still fit, 8 of the 65 536-node target size do not (round 5: they ran out of memory)
+    GiB = 1 << 30
+    assert replicas.handel_init_transient_bytes(32768) == 16 * GiB == replicas.handel_init_transient_bytes(65536)
+    assert replicas.handel_init_transient_bytes(4096) == 4 * 4 * 4096 * 4096 and replicas.handel_init_transient_bytes(131072) == 0
+    assert replicas.plan_replicas(32, 287 * GiB, int(8.56 * GiB), transient_bytes=16 * GiB) == 31
+    assert replicas.plan_replicas(8, 287 * GiB, 35 * GiB, transient_bytes=16 * GiB) == 7
     # the number of steps plays no part (round 1: `fit // K` turned --steps 20 into rc=1)
     with pytest.raises(ValueError):
         replicas.plan_replicas(0, GB, GB)

@@ -107,8 +107,11 @@ def leg7():
     n, thr, pair, lw, ec, per, fp, down, desync = gold["params"]
     hp = w.HandelParameters(n, thr, pair, lw, ec, per, fp, down, parity.NB, parity.NL, desync)
     K = 8
+    # (WG_TEST_SHARD_IMAGE=1: the same run with the snapshots inside the all-reduce image, the form of rounds 1-4 — the
+    # volumes of DESIGN.md section 7.2's table; tools/shard_volume.sh)
+    directed = os.environ.get("WG_TEST_SHARD_IMAGE", "0") != "1"
     grp = shards.LoopbackGroup(K, device_memory=True)
-    sims = [w.Handel(hp, seed=gold["seed"], config=grp.config(s)) for s in range(K)]
+    sims = [w.Handel(hp, seed=gold["seed"], config=grp.config(s, alltoall=directed)) for s in range(K)]
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=K) as ex:  # (init() is host work: ctypes releases the GIL)
         list(ex.map(lambda g: g.init(), sims))
@@ -131,6 +134,9 @@ def leg7():
     out["config3_as_8_shards"] = {"bad": {k: [str(x) for x in v] for k, v in bad.items()}, "init_s": t_init,
                                   "run_s": time.time() - t0 - t_init, "device_bytes_per_shard": per_shard,
                                   "words_received_per_shard": [shards.traffic(net)[1] for net in nets],
+                                  "snapshots": "owner-directed" if directed else "all-reduce image", "simulated_ms": nets[0].time,
+                                  "by_exchange_shard0": shards.traffic_by_exchange(nets[0]),
+                                  "by_exchange_shard7": shards.traffic_by_exchange(nets[7]),
                                   "same_rng": len({net.rng_state() for net in nets}) == 1}
 def leg8():
     # 8. Casper IMD on logical shards of the one GPU: PT/CasperIMDTest.java:10-11's network (406 nodes) with 40 attesters

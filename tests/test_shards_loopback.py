@@ -76,6 +76,7 @@ def handel_loopback(k, params, seed, device_memory, chunks_max=400, check_every=
         bad.append("delivered_by_level")
     if c.cont_if():
         bad.append("did not converge in %d chunks" % chunks_max)
+    handel_loopback.by_exchange = [shards.traffic_by_exchange(net) for net in nets]  # (wg_shard_traffic, of the last call)
     return bad, [shards.traffic(net) for net in nets]
 
 
@@ -95,8 +96,17 @@ def test_dissemination_snapshots_go_to_the_shard_that_reads_them(k):
     params = (256, 228, 4, 50, 10, 20, 10, 25, 0)
     bad, directed = handel_loopback(k, params, seed=2, device_memory=False, check_every=10)
     assert bad == []
+    by_d = handel_loopback.by_exchange
     bad, image = handel_loopback(k, params, seed=2, device_memory=False, check_every=10, alltoall=False)
     assert bad == []
+    by_i = handel_loopback.by_exchange
+    for s in range(k):  # wg_shard_traffic: the totals of wg_shard_info split by exchange; only the snapshots' rows differ between the two forms
+        assert sum(c for c, _ in by_d[s].values()) == directed[s][0] and sum(x for _, x in by_d[s].values()) == directed[s][1]
+        assert sum(c for c, _ in by_i[s].values()) == image[s][0] and sum(x for _, x in by_i[s].values()) == image[s][1]
+        for kind in ("events", "outbox", "envelopes", "candidates"):
+            assert by_d[s][kind] == by_i[s][kind] and by_d[s][kind][0] > 0
+        assert by_i[s]["directed_counts"] == (0, 0) and by_d[s]["directed_counts"][1] == k * k * by_d[s]["directed_counts"][0]
+        assert by_i[s]["snapshots"][1] > 0 and by_d[s]["snapshots"][1] > 0
     assert len({t[0] for t in directed}) == 1 and len(set(image)) == 1
     # (at 256 nodes a sub-row is two words in a 17-word chunk: the volumes are compared where rows are wide — 8 192 nodes on
     # the MI355X, tests/test_gpu_shards.py)

@@ -3,20 +3,33 @@
 # (stamped with the commit), then the whole GPU suite, smoke(), the driver's literal bench line (which reads that traffic.json),
 # the same command under rocprofv3 --kernel-trace --stats (kernel statistics + per-phase table) and the Casper delivery
 # pass's PMC passes -> profiles/traffic_casper.json.      WG_COMMIT=<hash> bash tools/gpu_final_round.sh <tag>
-# (On a gpurun box only gpurun_out/ comes back: afterwards copy gpurun_out/<tag>/traffic.json and traffic_casper.json over
-# profiles/traffic.json / traffic_casper.json in the repo — bench.py reads those — and the other files to profiles/<tag>_*.)
+# (On a gpurun box only gpurun_out/ comes back: afterwards copy gpurun_out/<tag>/traffic*.json over profiles/traffic*.json in
+# the repo — bench.py reads those — and the other files to profiles/<tag>_*. SKIP_SUITE=1 leaves the GPU suite to its own call.)
 set -u
 TAG=${1:-final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$(pwd)
 for f in wittgenstein_amd/csrc/*; do
   if [ "$f" -nt wittgenstein_amd/libwittgpu.so ]; then echo "STALE libwittgpu.so: $f is newer"; exit 1; fi
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/p_$c -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second > $R/$OUT/pmc_$c.json 2> $R/$OUT/pmc_$c.err)
-  echo "pmc $c rc=$?"
-  python tools/prof_summary.py pmc $OUT/p_$c $OUT/pmc_$c.md && rm -rf $OUT/p_$c
-done
-python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 24 $OUT/traffic.json "k_handel_lane,k_handel_update<,k_handel_lane2,k_handel_copy,k_handel_dissem<,k_handel_wave<" > /dev/null
+# three counter passes of one bench command (bytes read, bytes written, request counts), each in its own run
+passes() { pre=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE req; do
+    ctr=$c; [ $c = req ] && ctr="TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum"
+    (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --pmc $ctr -d $R/$OUT/p_$pre$c -o k --output-format csv -- python $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu --no-second > $R/$OUT/pmc_$pre$c.json 2> $R/$OUT/pmc_$pre$c.err)
+    echo "pmc $pre$c rc=$?"
+    python tools/prof_summary.py pmc $OUT/p_$pre$c $OUT/pmc_$pre$c.md && rm -rf $OUT/p_$pre$c
+  done
+}
+HANDEL_PASS="k_handel_lane,k_handel_update<,k_handel_lane2,k_handel_copy,k_handel_dissem<,k_handel_wave<"
+passes ""
+python tools/traffic_from_pmc.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md 32768 $OUT/pmc_FETCH_SIZE.json $OUT/traffic.json "$HANDEL_PASS" $OUT/pmc_req.md > /dev/null
 cp $OUT/traffic.json profiles/traffic.json; export WG_TRAFFIC_SESSION=1
+# the side workloads of the driver's line: Handel at the north star's target size (8 copies) and GSFSignature (256 copies)
+passes h65536_ --nodes 65536 --replicas 8
+python tools/traffic_from_pmc.py $OUT/pmc_h65536_FETCH_SIZE.md $OUT/pmc_h65536_WRITE_SIZE.md 65536 $OUT/pmc_h65536_FETCH_SIZE.json $OUT/traffic_handel65536.json "$HANDEL_PASS" $OUT/pmc_h65536_req.md > /dev/null
+cp $OUT/traffic_handel65536.json profiles/traffic_handel65536.json
+passes gsf_ --workload gsf --nodes 4096 --replicas 256
+python tools/traffic_from_pmc.py $OUT/pmc_gsf_FETCH_SIZE.md $OUT/pmc_gsf_WRITE_SIZE.md 4096 $OUT/pmc_gsf_FETCH_SIZE.json $OUT/traffic_gsf.json "k_gsf_docycle,k_gsf_lane,k_deliver_inbox<GsfProto" $OUT/pmc_gsf_req.md > /dev/null
+cp $OUT/traffic_gsf.json profiles/traffic_gsf.json
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/pc_$c -o k --output-format csv -- python $R/bench.py --workload casper --casper-stopped 0.1 --steps 1 --warmup 0 --no-cpu > $R/$OUT/pmc_casper_$c.json 2> $R/$OUT/pmc_casper_$c.err)
   echo "pmc casper $c rc=$?"
@@ -29,7 +42,7 @@ d = json.load(open(sys.argv[1])); d["stopped_fraction"] = 0.1
 json.dump(d, open(sys.argv[1], "w"), indent=1)
 PY
 cp $OUT/traffic_casper.json profiles/traffic_casper.json
-timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+[ "${SKIP_SUITE:-0}" = 1 ] || { timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log; }
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_argv.json 2> $OUT/bench_driver_argv.err; echo "bench rc=$?"; tail -3 $OUT/bench_driver_argv.err
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/p -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)

@@ -13,9 +13,14 @@ tools/micro/pmc_calib.hip (profiles/archive/r02b_pmc_calib.txt), for the access 
 So for these kernels (scattered lines and lane-scattered words, no wide streams) the counters are the memory-side
 bytes as they stand: `hbm_bytes_per_launch` = FETCH_SIZE + WRITE_SIZE; `..._reads_doubled` keeps the guide's x2 on
 the reads as the upper bound (it would apply only to the part of the reads that are 128-byte requests).
-usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json> [kernel patterns, comma-separated]
+usage: traffic_from_pmc.py <pmc_FETCH_SIZE.md> <pmc_WRITE_SIZE.md> <nodes> <replicas> <out.json> [kernel patterns, comma-separated
+                           [<pmc_req.md>]]
 (default patterns: Handel's delivery pass — the six kernels bench.py's HIP events bracket; Casper's:
-"k_casper_classify,k_casper_attestations,k_deliver<CasperProto")"""
+"k_casper_classify,k_casper_attestations,k_deliver<CasperProto"; GSFSignature's: "k_gsf_docycle,k_gsf_lane,k_deliver_inbox<GsfProto")
+<replicas> may be the JSON line a PMC pass's bench.py printed (its config.replicas_per_gpu is taken).
+<pmc_req.md>: a third pass with TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum (tools/pmc_issue.sh `req`): the memory-side REQUEST
+counts — what the chip's scattered-line ceiling (tools/micro/mlp_probe) is a rate of; FETCH_SIZE / 64 overstates them where a kernel
+streams (a 128-byte request counts once) — as `ea_requests_per_launch` / `whole_step_ea_requests` (reads + writes)."""
 import json
 import re
 import sys
@@ -50,9 +55,16 @@ def whole_step(path, counter):
     return tot, per
 
 
+def replicas_of(arg):
+    if arg.isdigit():
+        return int(arg)
+    line = [l for l in open(arg).read().strip().splitlines() if l.startswith("{")][-1]
+    return int(json.loads(line)["config"]["replicas_per_gpu"])
+
+
 def main():
-    fetch, write, nodes, replicas, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 else ["k_handel_lane", "k_handel_update<", "k_handel_lane2", "k_handel_copy", "k_handel_dissem<", "k_handel_wave<"]
+    fetch, write, nodes, replicas, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), replicas_of(sys.argv[4]), sys.argv[5]
+    kernels = sys.argv[6].split(",") if len(sys.argv) > 6 and sys.argv[6] else ["k_handel_lane", "k_handel_update<", "k_handel_lane2", "k_handel_copy", "k_handel_dissem<", "k_handel_wave<"]
     f = per_dispatch(fetch, "FETCH_SIZE", kernels)
     w = per_dispatch(write, "WRITE_SIZE", kernels)
     rd = sum(f.values()) * 1024.0
@@ -60,7 +72,20 @@ def main():
     ws_f, ws_f_per = whole_step(fetch, "FETCH_SIZE")
     ws_w, ws_w_per = whole_step(write, "WRITE_SIZE")
     import os
-    json.dump({"nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"),
+    req = {}
+    if len(sys.argv) > 7:
+        rq = {c: per_dispatch(sys.argv[7], c, kernels) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_REQ_sum")}
+        ws = {c: whole_step(sys.argv[7], c) for c in rq}
+        req = {"ea_requests_per_launch": sum(rq["TCC_EA0_RDREQ_sum"].values()) + sum(rq["TCC_EA0_WRREQ_sum"].values()),
+               "ea_read_requests_per_launch": sum(rq["TCC_EA0_RDREQ_sum"].values()),
+               "ea_write_requests_per_launch": sum(rq["TCC_EA0_WRREQ_sum"].values()),
+               "l2_requests_per_launch": sum(rq["TCC_REQ_sum"].values()),
+               "whole_step_ea_requests": ws["TCC_EA0_RDREQ_sum"][0] + ws["TCC_EA0_WRREQ_sum"][0],
+               "whole_step_l2_requests": ws["TCC_REQ_sum"][0],
+               "per_kernel_requests": rq,
+               "requests_note": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum in one further pass: requests "
+                                "the L2 sent to the memory side (EA) and requests the L2 received, per delivery pass / per step"}
+    json.dump({**req, "nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"),
                "kernels": " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)",
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
                "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,

@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "wg_rng_set_seed", "wg_rng_get_state", "wg_rng_set_state", "wg_send", "wg_send_arrive_at", "wg_register_task",
     "wg_register_periodic_task", "wg_protocol_load", "wg_run_ms", "wg_time", "wg_queue_size", "wg_queue_size_at",
     "wg_read_i64", "wg_read_level_i32", "wg_read_bits", "wg_levels", "wg_device_bytes", "wg_delivered_by_level",
-    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_set_alltoallv", "wg_shard_configure_rccl", "wg_rccl_unique_id", "wg_shard_info", "wg_next_delivery", "wg_step_begin", "wg_step_end", "wg_host_released", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error", "wg_batch_size",
+    "wg_protocol_cont_if", "wg_snapshot", "wg_restore", "wg_snapshot_bytes", "wg_shard_configure", "wg_shard_set_alltoallv", "wg_shard_configure_rccl", "wg_rccl_unique_id", "wg_shard_info", "wg_shard_traffic", "wg_next_delivery", "wg_step_begin", "wg_step_end", "wg_host_released", "wg_set_time", "wg_batch_create", "wg_batch_destroy", "wg_batch_last_error", "wg_batch_size",
     "wg_batch_run_ms", "wg_batch_cont_if", "wg_batch_run_multiple_times", "wg_profile_enable", "wg_profile_read", "wg_profile_set_reference", "wg_profile_read_spans",
     "wgh_pingpong_create", "wgh_handel_create", "wgh_handel_create_bad_nodes", "wgh_gsf_create", "wgh_sanfermin_create", "wgh_casper_create", "wgh_p2pflood_create", "wgh_register_city_builder", "wgh_register_city_latency", "wgh_last_error", "wgh_last_init_seconds", "wgh_last_init_on_device", "wgh_jrandom_ints",
     "wgh_jrandom_skip_ints", "wgh_jrandom_bounded",

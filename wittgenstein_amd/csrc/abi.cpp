@@ -169,6 +169,15 @@ int32_t wg_shard_info(wg_engine* h, int32_t* lo, int32_t* hi, int64_t* collectiv
   if (words) *words = E.shardWords;
   WG_END
 }
+int32_t wg_shard_traffic(wg_engine* h, int64_t* calls8, int64_t* words8) {
+  WG_TRY(h)
+  if (E.shardCount == 0) throw WgError(WG_ESTATE, "not a sharded engine");
+  for (int k = 0; k < Engine::XK_KINDS; k++) {
+    if (calls8) calls8[k] = E.shardCallsBy[k];
+    if (words8) words8[k] = E.shardWordsBy[k];
+  }
+  WG_END
+}
 int32_t wg_time(wg_engine* h, int32_t* time) {
   WG_TRY(h)* time = E.time;
   WG_END

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <map>
 #include <dlfcn.h>
 #include <type_traits>
 #include "engine_host.h"
@@ -1602,7 +1603,7 @@ bool Engine::has_alltoall() const {
   }
   return xa2a != nullptr;
 }
-void Engine::shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro) {
+void Engine::shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro, int kind) {
   int64_t got = 0;
   for (int r = 0; r < shardCount; r++) got += r == shardIndex ? 0 : rc[r];
   if (rcclComm) {  // grouped point-to-point calls on the engine's stream: RCCL's all-to-all
@@ -1622,9 +1623,11 @@ void Engine::shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64
   }
   shardCollectives++;
   shardWords += got;  // (words RECEIVED by this shard: what the exchange costs it — an all-reduce counts its whole buffer)
+  shardCallsBy[kind]++;
+  shardWordsBy[kind] += got;
 }
 
-void Engine::shard_allreduce(void* buf, int64_t count) {
+void Engine::shard_allreduce(void* buf, int64_t count, int kind) {
   if (count <= 0) return;
   if (rcclComm) {  // in stream order with the producers and consumers of `buf`: nothing to wait for on the host
     rccl_check(rccl().AllReduce(buf, buf, (size_t)count, /*ncclInt32*/ 2, /*ncclSum*/ 0, rcclComm, stream), "ncclAllReduce");
@@ -1635,13 +1638,15 @@ void Engine::shard_allreduce(void* buf, int64_t count) {
   }
   shardCollectives++;
   shardWords += count;
+  shardCallsBy[kind]++;
+  shardWordsBy[kind] += count;
 }
 
 // the exchange image of a phase's ordered outbox (xbuf, written by the owners) -> fin / arr / tile histograms on
 // every shard, then the multi-destination envelopes among them
 void Engine::exchange_outbox(uint32_t nOut) {
   Group g = self();
-  shard_allreduce(dev.xbuf - XB_HEAD, XB_HEAD + 5 * (int64_t)nOut);
+  shard_allreduce(dev.xbuf - XB_HEAD, XB_HEAD + 5 * (int64_t)nOut, XK_OUTBOX);
   // the header word arrived with the records: how many of them are multi-destination envelopes still to be created
   // (the collective has synchronised; no further stream synchronisation is needed to read it)
   uint32_t nMulti = 0;
@@ -1654,7 +1659,7 @@ void Engine::exchange_outbox(uint32_t nOut) {
   nMulti = std::min(nMulti, dev.maxMulti);
   WG_HIP(hipMemsetAsync(dev.xmulti, 0, sizeof(int32_t) * (size_t)nMulti * XM_WORDS, stream));
   hipLaunchKernelGGL(k_shard_multi_fill, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
-  shard_allreduce(dev.xmulti, (int64_t)nMulti * XM_WORDS);
+  shard_allreduce(dev.xmulti, (int64_t)nMulti * XM_WORDS, XK_ENVELOPES);
   hipLaunchKernelGGL(k_shard_multi_create, dim3(GRID_RESOLVE, 1), dim3(256), 0, stream, g.tab);
 }
 
@@ -1714,7 +1719,7 @@ void Engine::run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* sta
     // exchange 1: the events' results, one packed word each (records, draws, the two flags, the level, the snapshot code)
     if (nEvents) {
       hipLaunchKernelGGL((k_shard_evres<true>), dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, stream, g.tab);
-      shard_allreduce(dev.xev, (int64_t)nEvents);
+      shard_allreduce(dev.xev, (int64_t)nEvents, XK_EVENTS);
       hipLaunchKernelGGL((k_shard_evres<false>), dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, stream, g.tab);
     }
     scan<RecsF>(g, nullptr);
@@ -2496,13 +2501,26 @@ struct TmpMatrix {
     static int n = 0;
     return n;
   }
+  static size_t& inFlightBytes() {
+    static size_t n = 0;
+    return n;
+  }
+  // at most four at a time and at most IN_FLIGHT_BYTES between them (one alone may be larger): what a host that sizes a
+  // batch of copies to the free HBM has to leave for init() (wittgenstein_amd/replicas.py::handel_init_transient_bytes)
+  static constexpr size_t IN_FLIGHT_BYTES = 4ull * 4ull * 32768ull * 32768ull;
+  static std::map<int32_t*, size_t>& sizes() {
+    static std::map<int32_t*, size_t> m;
+    return m;
+  }
   static int32_t* acquire(size_t bytes) {
     std::unique_lock<std::mutex> lk(mu());
     for (;;) {
-      cv().wait(lk, [] { return inFlight() < 4; });
+      cv().wait(lk, [bytes] { return inFlight() == 0 || (inFlight() < 4 && inFlightBytes() + bytes <= IN_FLIGHT_BYTES); });
       int32_t* p = nullptr;
       if (hipMalloc((void**)&p, bytes) == hipSuccess) {
         inFlight()++;
+        inFlightBytes() += bytes;
+        sizes()[p] = bytes;
         return p;
       }
       (void)hipGetLastError();
@@ -2514,11 +2532,16 @@ struct TmpMatrix {
   static void release(int32_t*& p) {
     if (!p) return;
     (void)hipFree(p);
-    p = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu());
       inFlight()--;
+      auto it = sizes().find(p);
+      if (it != sizes().end()) {
+        inFlightBytes() -= it->second;
+        sizes().erase(it);
+      }
     }
+    p = nullptr;
     cv().notify_all();
   }
 };
@@ -3025,7 +3048,7 @@ struct HandelHost : ProtoHost {
     const int S = st.xS;
     if (S <= 1) return;  // (one shard: no message leaves it)
     hipLaunchKernelGGL(k_handel_xcounts, dim3(1), dim3(64), 0, g.stream, st);
-    e.shard_allreduce(st.xcounts, (int64_t)S * S);
+    e.shard_allreduce(st.xcounts, (int64_t)S * S, Engine::XK_COUNTS);
     std::vector<int32_t> cm((size_t)S * S);
     WG_HIP(hipMemcpyAsync(cm.data(), st.xcounts, 4 * cm.size(), hipMemcpyDeviceToHost, g.stream));
     WG_HIP(hipStreamSynchronize(g.stream));
@@ -3050,7 +3073,7 @@ struct HandelHost : ProtoHost {
     if (directed) return shard_snap_directed_exchange(e, g);
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2);  // (nSnap: 64-bit words of the packed rows)
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2, Engine::XK_SNAPSHOTS);  // (nSnap: 64-bit words of the packed rows)
     hipLaunchKernelGGL((k_shard_snap<HandelState, H_TASK_DISSEMINATION, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
   }
   // checkSigs' edge (launch_cond above) with the draw order made global: the per-node candidate counts are summed
@@ -3062,7 +3085,7 @@ struct HandelHost : ProtoHost {
     launch_a1(g, stab, 1, g.stream);
     // exchange 5: how many levels of every node have a candidate — a byte per node, its owner's (zeros elsewhere)
     hipLaunchKernelGGL(k_handel_cand_pack, dim3(GRID_SHARD_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.xcand, ((int64_t)st.N + 3) / 4);
+    e.shard_allreduce(st.xcand, ((int64_t)st.N + 3) / 4, Engine::XK_CANDIDATES);
     Engine::scan<CondF>(g, stab);
     uint32_t nOut = 0;
     const uint32_t seq = e.publish_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr);
@@ -3437,7 +3460,7 @@ struct GsfHost : ProtoHost {
   void shard_snap_exchange(Engine& e, const Group& g, uint32_t nSnap) override {
     const GsfState* stab = (const GsfState*)g.stab;
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, true>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
-    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2);  // (nSnap: 64-bit words of the packed rows)
+    e.shard_allreduce(st.xsnap, (int64_t)nSnap * 2, Engine::XK_SNAPSHOTS);  // (nSnap: 64-bit words of the packed rows)
     hipLaunchKernelGGL((k_shard_snap<GsfState, G_TASK_DOCYCLE, false>), dim3(GRID_DELIVER_SMALL, 1), dim3(256), 0, g.stream, g.tab, stab);
   }
   // checkSigs' edge: which nodes register a task is summed across shards, so that the registrations keep their
@@ -3446,7 +3469,7 @@ struct GsfHost : ProtoHost {
     const GsfState* stab = (const GsfState*)g.stab;
     hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.hi - st.lo + 255) / 256, 1), dim3(256), 0, g.stream, g.tab, stab);
     hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_node_waves(1), 1), dim3(256), 0, g.stream, g.tab, stab, 0);
-    e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4);
+    e.shard_allreduce(st.candFlag, ((int64_t)st.N + 3) / 4, Engine::XK_CANDIDATES);
     Engine::scan<GsfCondF>(g, stab);
     uint32_t nOut = 0;
     const uint32_t seq = e.publish_counts((const uint32_t*)((const char*)e.dev.g.raw + offsetof(Globals, nOut)), nullptr);

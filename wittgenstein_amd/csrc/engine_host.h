@@ -164,7 +164,9 @@ class Engine {
   // node-range sharding of one simulation over several engines (one process per GPU), include/wittgpu.h
   void configure_shard(int32_t shard, int32_t nshards, wg_allreduce_fn fn, void* ctx);
   void run_ms_sharded(int32_t ms, uint8_t* didSomething, wg_run_stats* stats);
-  void shard_allreduce(void* buf, int64_t count);
+  // kind: which of the per-ms exchanges this is (wg_shard_traffic's rows, include/wittgpu.h)
+  enum ShardKind { XK_EVENTS = 0, XK_OUTBOX = 1, XK_ENVELOPES = 2, XK_SNAPSHOTS = 3, XK_CANDIDATES = 4, XK_COUNTS = 5, XK_OTHER = 6, XK_KINDS = 8 };
+  void shard_allreduce(void* buf, int64_t count, int kind = XK_OTHER);
   void exchange_outbox(uint32_t nOut);
   int32_t shardIndex = 0, shardCount = 0;  // shardCount == 0: not sharded
   wg_allreduce_fn xfn = nullptr;          // caller-supplied collective (tests: gloo / in-process loopback) ...
@@ -173,7 +175,7 @@ class Engine {
   void* xa2aCtx = nullptr;
   bool has_alltoall() const;              // an all-to-all transport exists: the callback, or the engine's RCCL communicator
   // shard d gets sc[d] int32 words from word so[d] of sendbuf, rc[r] words from shard r land at word ro[r] of recvbuf
-  void shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro);
+  void shard_alltoallv(const void* sendbuf, const int64_t* sc, const int64_t* so, void* recvbuf, const int64_t* rc, const int64_t* ro, int kind = XK_SNAPSHOTS);
   void set_alltoallv(wg_alltoallv_fn fn, void* ctx);
   void* rcclComm = nullptr;               // ... or the engine's own RCCL communicator (wg_shard_configure_rccl):
                                           // ncclAllReduce enqueued on the engine's stream, no host round trip
@@ -194,6 +196,7 @@ class Engine {
   void wait_counts(uint32_t seq, uint32_t* va, uint32_t* vb);
   void await_counts(const uint32_t* a, const uint32_t* b, uint32_t* va, uint32_t* vb) { wait_counts(publish_counts(a, b), va, vb); }
   long long shardCollectives = 0, shardWords = 0;  // all-reduce calls / int32 words summed so far
+  long long shardCallsBy[XK_KINDS] = {}, shardWordsBy[XK_KINDS] = {};  // ... by exchange
   int64_t queue_size();
   int64_t queue_size_at(int32_t t);
   struct StagedChainKeep {

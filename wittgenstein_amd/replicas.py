@@ -34,9 +34,21 @@ def rank_seeds(rank, world, replicas):
     return range(rank * replicas, (rank + 1) * replicas)
 
 
-def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955):
+def handel_init_transient_bytes(nodes):
+    """device bytes Handel's init() holds only while it runs, over ALL the copies being initialised at once: with the
+    reception ranks carried by the senders (unsharded, 256 .. 65 536 nodes, csrc/engine.hip HandelHost) the nodeCount^2
+    int32 rank matrix lives for the length of init() only, and the library admits at most four of them and at most
+    16 GiB between them (one alone may be larger) at a time — TmpMatrix there."""
+    if nodes < 256 or nodes > 65536:
+        return 0
+    one = 4 * nodes * nodes
+    return min(4 * one, max(one, 4 * 4 * 32768 * 32768))
+
+
+def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955, transient_bytes=0):
     """How many resident copies a step runs on one GPU: the request, lowered to what fits `headroom` of the free HBM
-    (per_copy_bytes = one copy incl. its init() image, measured on the first copy). Never below 1 and never an
+    (per_copy_bytes = one copy incl. its init() image, measured on the first copy) — and leaves `transient_bytes` (what the
+    copies' init() holds only while it runs, handel_init_transient_bytes) beside the copies. Never below 1 and never an
     error: a step that cannot hold the requested batch runs a smaller one and the bench line says so
     (config.replicas_per_gpu / config.replicas_requested)."""
     if requested <= 0:
@@ -44,6 +56,8 @@ def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955):
     if per_copy_bytes <= 0 or free_bytes <= 0:
         return requested
     fit = int(headroom * free_bytes) // int(per_copy_bytes)
+    if transient_bytes > 0:
+        fit = min(fit, max(0, int(free_bytes) - int(transient_bytes) - (1 << 30)) // int(per_copy_bytes))
     return max(1, min(requested, fit))
 
 

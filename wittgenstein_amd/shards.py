@@ -138,6 +138,16 @@ def traffic(net):
     return c.value, w.value
 
 
+TRAFFIC_KINDS = ("events", "outbox", "envelopes", "snapshots", "candidates", "directed_counts", "other")
+
+
+def traffic_by_exchange(net):
+    """{exchange: (calls, int32 words)} so far (wg_shard_traffic): the per-ms exchanges of DESIGN.md §7.2, one by one"""
+    c, w = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+    net._ck(L.lib().wg_shard_traffic(net._h, c, w))
+    return {k: (c[i], w[i]) for i, k in enumerate(TRAFFIC_KINDS)}
+
+
 def _host_device(dist, group=None):
     """where a host-side value has to live to be reduced over this group: RCCL ("nccl") only moves device tensors,
     gloo only host tensors"""
