@@ -52,6 +52,51 @@ def test_union_of_launch_intervals():
     assert u([(0, 5), (1, 2)]) == 5 and u([(3, 4), (0, 1)]) == 2
 
 
+def _pmc_md(path, counter_rows):
+    with open(path, "w") as f:
+        f.write("| kernel | counter | dispatches | sum | mean per dispatch |\n|---|---|---|---|---|\n")
+        for k, c, n, sm in counter_rows:
+            f.write("| %s | %s | %d | %.1f | %.3f |\n" % (k, c, n, sm, sm / n))
+
+
+def test_traffic_json_from_the_three_pmc_passes(tmp_path, monkeypatch):
+    """tools/traffic_from_pmc.py (bytes read, bytes written, request counts -> profiles/traffic*.json) and bench.pmc_traffic
+    (that file -> roofline.traffic / roofline.line_rate): per delivery PASS, a kernel that is not launched in every pass counted
+    by its sum over the passes; whole-name patterns; a file of another copy count is not this line's workload"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+    tfp = importlib.import_module("traffic_from_pmc")
+    K = [("k_handel_lane(EngineDev const*, HandelState const*)", 100), ("k_handel_lane2(EngineDev const*, HandelState const*, int)", 110),
+         ("void k_handel_dissem<8>(EngineDev const*, HandelState const*)", 5), ("void k_scan2<ExpandF>(EngineDev const*, int const*)", 100),
+         ("k_handel_init_sort(HandelState)", 4)]
+    _pmc_md(tmp_path / "f.md", [(k, "FETCH_SIZE", n, 1000.0 * n) for k, n in K])        # KB
+    _pmc_md(tmp_path / "w.md", [(k, "WRITE_SIZE", n, 500.0 * n) for k, n in K])
+    _pmc_md(tmp_path / "r.md", [(k, c, n, q * n) for k, n in K for c, q in (("TCC_EA0_RDREQ_sum", 16000.0), ("TCC_EA0_WRREQ_sum", 8000.0), ("TCC_REQ_sum", 30000.0))])
+    line = tmp_path / "bench.json"
+    line.write_text("noise\n" + json.dumps({"config": {"replicas_per_gpu": 31}}) + "\n")
+    out = tmp_path / "traffic.json"
+    monkeypatch.setattr(sys, "argv", ["traffic_from_pmc.py", str(tmp_path / "f.md"), str(tmp_path / "w.md"), "32768", str(line), str(out),
+                                      "k_handel_lane,k_handel_lane2,k_handel_dissem<", str(tmp_path / "r.md")])
+    tfp.main()
+    tj = json.load(open(out))
+    assert tj["replicas"] == 31 and tj["nodes"] == 32768
+    passes = 110  # (the kernel launched most often defines the passes; dissem's 5 launches count 5 / 110 of a launch each)
+    assert abs(tj["fetch_bytes_per_launch_raw"] - 1024.0 * (1000.0 * 100 + 1000.0 * 110 + 1000.0 * 5) / passes) < 1e-6
+    assert abs(tj["ea_requests_per_launch"] - 24000.0 * (100 + 110 + 5) / passes) < 1e-6
+    assert abs(tj["whole_step_ea_requests"] - 24000.0 * (100 + 110 + 5 + 100)) < 1e-6  # init() kernels are not the step's
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.replace(out, tmp_path / "profiles" / "traffic.json")
+    t, src, lr, _ = bench.pmc_traffic("traffic.json", 32768, 31, avg_launch_ns=250000.0, step_s=0.8)
+    assert t == tj["hbm_bytes_per_launch"] and "traffic.json" in src
+    assert abs(lr["requests_per_s"] - tj["ea_requests_per_launch"] / 250e-6) < 1.0 and abs(lr["frac"] - lr["requests_per_s"] / bench.LINE_RATE_CEILING) < 1e-12
+    assert abs(lr["whole_step"]["requests_per_s"] - tj["whole_step_ea_requests"] / 0.8) < 1.0
+    assert bench.pmc_traffic("traffic.json", 32768, 24, 250000.0)[0] is None    # another copy count: no traffic claimed
+    assert bench.pmc_traffic("traffic_gsf.json", 4096, 256, 1.0) == (None, None, None, None)  # no file
+
+
 def test_rank_seeds_disjoint():
     seen = set()
     for rank in range(4):
