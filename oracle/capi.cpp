@@ -10,6 +10,7 @@
 #include "handel.hpp"
 #include "p2pflood.hpp"
 #include "optimistic_p2p.hpp"
+#include "slush.hpp"
 #include "pingpong.hpp"
 #include "sanfermin.hpp"
 #include "sanfermin_cappos.hpp"
@@ -962,6 +963,66 @@ int orc_optp2p_read(void* h, int field, int64_t* out) {
 }
 int orc_optp2p_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
   auto& p = *((OrcOptP2P*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  return 0;
+}
+
+// ---- Slush / Snowflake (P/Slush.java, P/Snowflake.java)
+struct OrcSlush {
+  std::unique_ptr<Slush> p;
+};
+// ip: NODES_AV, M, K, B, snowflake (0 / 1); a: alpha (:37-47 / :36-52)
+int orc_slush_create(const int32_t* ip, double a, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY Slush::Params pr;
+  pr.NODES_AV = ip[0];
+  pr.M = ip[1];
+  pr.K = ip[2];
+  pr.B = ip[3];
+  pr.A = a;
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcSlush();
+  h->p = std::make_unique<Slush>(pr, ip[4] != 0);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_slush_destroy(void* h) { delete (OrcSlush*)h; }
+int orc_slush_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcSlush*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 myColor, 5 myQueryNonce, 6 round, 7 cnt,
+//         8 answerIP.size(), 9 x, 10 y
+int orc_slush_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcSlush*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.myColor; break;
+      case 5: v = n.myQueryNonce; break;
+      case 6: v = n.round; break;
+      case 7: v = n.cnt; break;
+      case 8: v = (int64_t)n.answerIP.size(); break;
+      case 9: v = n.x; break;
+      case 10: v = n.y; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_slush_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcSlush*)h)->p;
   *time = p.network_.time;
   *queueSize = p.network_.msgs.size();
   *rngState = p.network_.rd.rawState();

@@ -504,6 +504,41 @@ class OptimisticP2PSignature:
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
 
 
+class Slush:
+    """oracle/slush.hpp: P/Slush.java, or P/Snowflake.java with snowflake=True; params = (NODES_AV, M, K, A[, B]) in the
+    reference's ctor order (SlushParameters :37-47, SnowflakeParameters :36-52)."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "myColor": 4, "myQueryNonce": 5, "round": 6,
+              "cnt": 7, "answersInProgress": 8, "x": 9, "y": 10}
+
+    def __init__(self, params, nb=None, nl=None, seed=0, snowflake=False):
+        self.h, self.n = C.c_void_p(), params[0]
+        b = params[4] if len(params) > 4 else 0
+        ip = (C.c_int32 * 5)(params[0], params[1], params[2], b, 1 if snowflake else 0)
+        lib().orc_slush_create.argtypes = [C.c_void_p, C.c_double, C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
+        _ck(lib().orc_slush_create(ip, C.c_double(params[3]), nb.encode() if nb else None, nl.encode() if nl else None,
+                                   C.c_int64(seed), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_slush_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_slush_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_slush_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_slush_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
 # ---- city topology / latency (oracle/geo.hpp): data from tests/golden/city_data.json
 _CITY_LOADED = False
 

@@ -40,6 +40,7 @@ import test_gpu_casper_resident as tcr  # noqa: E402
 import test_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_gpu_p2pflood as tpf  # noqa: E402
 import test_gpu_optimistic_p2p as top  # noqa: E402
+import test_gpu_slush as tsl  # noqa: E402
 import test_gpu_sanfermin as tsf  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -264,6 +265,13 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_slush_and_snowflake_through_host_callbacks(monkeypatch):  # P/Slush.java, P/Snowflake.java
+    tsl.test_slush_simple()
+    tsl.test_snowflake_simple()
+    tsl.test_copies_agree_and_match_the_oracle(True, (60, 5, 7, 4.0 / 7.0, 3))
+    tsl.test_slush_batched_steps_without_latency(monkeypatch)
 
 
 def test_optimistic_p2p_signature_through_host_callbacks(monkeypatch):  # P/OptimisticP2PSignature.java over C/P2PNetwork.java

@@ -1,6 +1,7 @@
 """Oracle-level protocol properties the reference's tests pin (PT/PingPongTest, PT/HandelTest) plus
 invariants used as size-independent parity properties on the GPU."""
 import numpy as np
+import pytest
 
 import oracle_lib as o
 
@@ -172,3 +173,28 @@ def test_optimistic_p2p_copy_is_deterministic(oracle):  # testCopy :34-50
     b.run_ms(200)
     assert (a.read("done") == b.read("done")).all() and (a.read("doneAt") == b.read("doneAt")).all()
     assert a.info() == b.info() and a.info()["delivered"] > 10000
+
+
+# ---- Slush / Snowflake: PT/SlushTest.java, PT/SnowflakeTest.java restated against the oracle (oracle/slush.hpp) ----------
+@pytest.mark.parametrize("snow,params", [(False, (100, 7, 7, 4.0 / 7.0)), (True, (100, 5, 7, 4.0 / 7.0, 3))])
+def test_slush_snowflake_simple(oracle, snow, params):  # testSimple (SlushTest :14-25, SnowflakeTest :14-25)
+    p = o.Slush(params, GSF_NB, GSF_NL, snowflake=snow)
+    p.run_ms(10 * 1000)
+    col = p.read("myColor")
+    assert len(col) == 100 and col[0] in (1, 2) and (col == col[0]).all()  # every node ends on node 0's colour
+    assert (p.read("answersInProgress") == 0).all() and p.info()["queue"] == 0  # every query was answered K times
+    if not snow:
+        assert (p.read("round") == 7).all()  # M rounds each (P/Slush.java:165-168)
+    else:
+        assert (p.read("cnt") == 3 + 1).all()  # stops past beta confirmations (P/Snowflake.java:186-191)
+
+
+@pytest.mark.parametrize("snow,params", [(False, (60, 5, 7, 4.0 / 7.0)), (True, (60, 5, 7, 4.0 / 7.0, 3))])
+def test_slush_snowflake_copy_is_deterministic(oracle, snow, params):  # testCopy (SlushTest :27-45, SnowflakeTest :27-47)
+    a = o.Slush(params, GSF_NB, GSF_NL, snowflake=snow)
+    b = o.Slush(params, GSF_NB, GSF_NL, snowflake=snow)
+    a.run_ms(200)
+    b.run_ms(200)
+    for f in ("myColor", "myQueryNonce", "round", "cnt"):
+        assert (a.read(f) == b.read(f)).all()
+    assert a.info() == b.info() and a.info()["delivered"] > 100
