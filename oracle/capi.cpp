@@ -10,6 +10,7 @@
 #include "handel.hpp"
 #include "p2pflood.hpp"
 #include "optimistic_p2p.hpp"
+#include "paxos.hpp"
 #include "slush.hpp"
 #include "pingpong.hpp"
 #include "sanfermin.hpp"
@@ -1023,6 +1024,81 @@ int orc_slush_read(void* h, int field, int64_t* out) {
 }
 int orc_slush_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
   auto& p = *((OrcSlush*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  return 0;
+}
+
+// ---- Paxos (P/Paxos.java)
+struct OrcPaxos {
+  std::unique_ptr<Paxos> p;
+};
+// ip: acceptorCount, proposerCount, timeout (:359-370)
+int orc_paxos_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY Paxos::Params pr;
+  pr.acceptorCount = ip[0];
+  pr.proposerCount = ip[1];
+  pr.timeout = ip[2];
+  pr.nodeBuilder = nb ? nb : "";
+  pr.latency = nl ? nl : "";
+  auto* h = new OrcPaxos();
+  h->p = std::make_unique<Paxos>(pr);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_paxos_destroy(void* h) { delete (OrcPaxos*)h; }
+int orc_paxos_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcPaxos*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+// per node (acceptors first, then proposers; a field of the other kind reads -2; a null Integer reads -1):
+// 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 doneAt, 5 x, 6 y,
+// acceptors: 7 maxAgreed, 8 acceptedSeq, 9 acceptedVal, 10 agreedTo (node id)
+// proposers: 11 valueProposed, 12 valueAccepted, 13 seqIP, 14 seqAccepted, 15 agreeCount, 16 reject1Count, 17 reject2Count,
+//            18 timeoutCount, 19 proposalIP, 20 agreeCountIP, 21 acceptCountIP
+int orc_paxos_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcPaxos*)h)->p;
+  auto opt = [](const std::optional<int>& o) -> int64_t { return o ? *o : -1; };
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    Paxos::PaxosNode* n = p.nodes[i].get();
+    auto* a = dynamic_cast<Paxos::AcceptorNode*>(n);
+    auto* q = dynamic_cast<Paxos::ProposerNode*>(n);
+    int64_t v = -2;
+    switch (field) {
+      case 0: v = n->msgReceived; break;
+      case 1: v = n->msgSent; break;
+      case 2: v = n->bytesSent; break;
+      case 3: v = n->bytesReceived; break;
+      case 4: v = n->doneAt; break;
+      case 5: v = n->x; break;
+      case 6: v = n->y; break;
+      case 7: if (a) v = a->maxAgreed; break;
+      case 8: if (a) v = opt(a->acceptedSeq); break;
+      case 9: if (a) v = opt(a->acceptedVal); break;
+      case 10: if (a) v = a->agreedTo ? a->agreedTo->nodeId : -1; break;
+      case 11: if (q) v = q->valueProposed; break;
+      case 12: if (q) v = opt(q->valueAccepted); break;
+      case 13: if (q) v = q->seqIP; break;
+      case 14: if (q) v = q->seqAccepted; break;
+      case 15: if (q) v = q->agreeCount; break;
+      case 16: if (q) v = q->reject1Count; break;
+      case 17: if (q) v = q->reject2Count; break;
+      case 18: if (q) v = q->timeoutCount; break;
+      case 19: if (q) v = q->proposalIP; break;
+      case 20: if (q) v = q->agreeCountIP; break;
+      case 21: if (q) v = q->acceptCountIP; break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_paxos_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcPaxos*)h)->p;
   *time = p.network_.time;
   *queueSize = p.network_.msgs.size();
   *rngState = p.network_.rd.rawState();

@@ -3,8 +3,8 @@
 // sampling protocols of the Avalanche family in the reference: a coloured node queries K random remotes (one
 // multi-destination send, C/Network.java:353-362,418-447), every remote answers with its colour (adopting the query's when it
 // has none and starting to query itself), and once the K answers of a query are in the node flips when more than alpha * K
-// of them are of the other colour. Slush stops after M rounds per node (:165-168); Snowflake counts consecutive
-// confirmations of its own colour and stops past beta of them (P/Snowflake.java:178-192).
+// of them are of the other colour. Slush stops after M rounds per node (:172-175); Snowflake counts consecutive
+// confirmations of its own colour and stops past beta of them (P/Snowflake.java:175-188).
 // Pinned against PT/SlushTest.java:14-45 and PT/SnowflakeTest.java:14-47 (testSimple: every node ends on node 0's colour after
 // run(10); testCopy: two copies agree) in tests/test_oracle_protocols.py; seed-dependent trajectories are unpinned (no JVM
 // in the image).
@@ -36,16 +36,16 @@ class Slush {  // P/Slush.java; snowflake == true: P/Snowflake.java (the two fil
     AnswerQuery(std::shared_ptr<Query> q, int c) : originalQuery(std::move(q)), color(c) {}
     void action(Network&, Node* from, Node* to) override;
   };
-  struct Answer {  // :215-231
+  struct Answer {  // :205-221
     int round = 0;
     int colorsFound[3] = {0, 0, 0};
     int answerCount() const { return colorsFound[0] + colorsFound[1] + colorsFound[2]; }
   };
-  struct SlushNode : Node {  // :116-213
+  struct SlushNode : Node {  // :116-203
     Slush& p;
     int myColor = 0, myQueryNonce = 0;
     int round = 0;  // Slush :119
-    int cnt = 0;    // Snowflake :120
+    int cnt = 0;    // Snowflake :128
     std::map<int, Answer> answerIP;  // (a HashMap in the reference: get / put / remove only, never iterated)
     explicit SlushNode(Slush& pp) : Node(pp.network_.rd, *pp.nb), p(pp) {}
     std::vector<Node*> randomRemotes() {  // :126-137
@@ -65,7 +65,7 @@ class Slush {  // P/Slush.java; snowflake == true: P/Snowflake.java (the two fil
       }
       p.network_.send(std::make_shared<AnswerQuery>(qa, myColor), this, from);
     }
-    void onAnswer(int queryId, int color) {  // Slush :161-176, Snowflake :173-192
+    void onAnswer(int queryId, int color) {  // Slush :161-176, Snowflake :170-189
       auto it = answerIP.find(queryId);
       if (it == answerIP.end()) throw IllegalStateException("NullPointerException: answerIP.get(queryId)");
       Answer& asw = it->second;
@@ -89,7 +89,7 @@ class Slush {  // P/Slush.java; snowflake == true: P/Snowflake.java (the two fil
         if (cnt <= p.params.B) sendQuery(done.round + 1);
       }
     }
-    void sendQuery(int countInM) {  // :178-182
+    void sendQuery(int countInM) {  // :178-182 (Snowflake :190-194)
       auto q = std::make_shared<Query>(++myQueryNonce, myColor);
       Answer a;
       a.round = countInM;
@@ -107,7 +107,7 @@ class Slush {  // P/Slush.java; snowflake == true: P/Snowflake.java (the two fil
     nb = nodeBuilderByName(params.nodeBuilderName);
     network_.setNetworkLatency(networkLatencyByName(params.networkLatencyName));
   }
-  void init() {  // :62-74
+  void init() {  // :63-75
     for (int i = 0; i < params.NODES_AV; i++) {
       nodes.push_back(std::make_unique<SlushNode>(*this));
       network_.addNode(nodes.back().get());

@@ -504,6 +504,40 @@ class OptimisticP2PSignature:
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
 
 
+class Paxos:
+    """oracle/paxos.hpp: P/Paxos.java; params = PaxosParameters' ctor order (acceptorCount, proposerCount, timeout). Per-node
+    reads cover both kinds of node: a field of the other kind reads -2, a null Integer -1."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "doneAt": 4, "x": 5, "y": 6, "maxAgreed": 7,
+              "acceptedSeq": 8, "acceptedVal": 9, "agreedTo": 10, "valueProposed": 11, "valueAccepted": 12, "seqIP": 13,
+              "seqAccepted": 14, "agreeCount": 15, "reject1Count": 16, "reject2Count": 17, "timeoutCount": 18, "proposalIP": 19,
+              "agreeCountIP": 20, "acceptCountIP": 21}
+
+    def __init__(self, params, nb=None, nl=None, seed=0):
+        self.h, self.n = C.c_void_p(), params[0] + params[1]
+        ip = (C.c_int32 * 3)(*params)
+        _ck(lib().orc_paxos_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_paxos_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_paxos_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_paxos_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_paxos_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
 class Slush:
     """oracle/slush.hpp: P/Slush.java, or P/Snowflake.java with snowflake=True; params = (NODES_AV, M, K, A[, B]) in the
     reference's ctor order (SlushParameters :37-47, SnowflakeParameters :36-52)."""

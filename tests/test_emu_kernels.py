@@ -41,6 +41,7 @@ import test_gpu_sanfermin_resident as tsr  # noqa: E402
 import test_gpu_p2pflood as tpf  # noqa: E402
 import test_gpu_optimistic_p2p as top  # noqa: E402
 import test_gpu_slush as tsl  # noqa: E402
+import test_gpu_paxos as tpx  # noqa: E402
 import test_gpu_sanfermin as tsf  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -265,6 +266,12 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_paxos_through_host_callbacks(monkeypatch):  # P/Paxos.java; init() sends between node constructions (deferred_init)
+    tpx.test_paxos_simple()
+    tpx.test_paxos_contended_and_copy((7, 5, 600), 2)
+    tpx.test_paxos_timeouts_batched_steps(monkeypatch)
 
 
 def test_slush_and_snowflake_through_host_callbacks(monkeypatch):  # P/Slush.java, P/Snowflake.java

@@ -198,3 +198,38 @@ def test_slush_snowflake_copy_is_deterministic(oracle, snow, params):  # testCop
     for f in ("myColor", "myQueryNonce", "round", "cnt"):
         assert (a.read(f) == b.read(f)).all()
     assert a.info() == b.info() and a.info()["delivered"] > 100
+
+
+# ---- Paxos: PT/PaxosTest.java restated against the oracle (oracle/paxos.hpp) ------------------------------------------------
+def test_paxos_simple(oracle):  # testSimple :9-19
+    p = o.Paxos((3, 1, 1000))
+    p.run_ms(10 * 1000)
+    assert len(p.read("seqIP")) == 4                      # 3 acceptors + 1 proposer; majority = 3 / 2 + 1 = 2
+    prop = p.read("seqIP") != -2
+    assert prop.sum() == 1 and (p.read("seqIP")[prop] > 0).all()
+    # one proposer alone: its first proposal is agreed to and accepted by the three acceptors
+    assert (p.read("valueAccepted")[prop] == p.read("valueProposed")[prop]).all() and (p.read("doneAt")[prop] > 0).all()
+    assert (p.read("acceptedVal")[~prop] == p.read("valueProposed")[prop][0]).all() and (p.read("timeoutCount")[prop] == 0).all()
+
+
+def test_paxos_copy_is_deterministic(oracle):  # testCopy :21-32
+    a, b = o.Paxos((3, 2, 1000)), o.Paxos((3, 2, 1000))
+    a.run_ms(2000)
+    b.run_ms(2000)
+    assert (a.read("msgReceived") == b.read("msgReceived")).all() and a.info() == b.info()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_paxos_agreement(oracle, seed):
+    """the final check of Paxos.play() (P/Paxos.java:473-486) on its own parameters (3 acceptors, 3 proposers, timeout 1000) and
+    on a larger contended shape (rejections at both stages): every proposer that is done accepted the same value, and it is one that was proposed"""
+    for params in ((3, 3, 1000), (7, 5, 600)):
+        p = o.Paxos(params, None, "NetworkLatencyByDistanceWJitter", seed=seed)
+        for _ in range(100):  # RunMultipleTimes' loop: runMs(10) while some proposer is not done (:488-497), at most 5 s here
+            p.run_ms(50)
+            prop = p.read("seqIP") != -2
+            if (p.read("doneAt")[prop] > 0).all():
+                break
+        acc = p.read("valueAccepted")[prop]
+        done = acc[acc >= 0]
+        assert len(done) > 0 and (done == done[0]).all() and done[0] in set(p.read("valueProposed")[prop].tolist())

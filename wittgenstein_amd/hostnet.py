@@ -157,6 +157,7 @@ class HostNetwork:
         self._next_handle = 1
         self._next_id = 0
         self._ready = False
+        self._deferred = None  # init()'s sends and tasks while nodes are still being added (deferred_init)
         self.time = 0
 
     # ---- nodes
@@ -182,6 +183,40 @@ class HostNetwork:
                             [n.extraLatency for n in self.allNodes], [1 if n.down else 0 for n in self.allNodes])
         self._eng.load_protocol(0)  # WG_PROTO_HOST
         self._ready = True
+
+    def deferred_init(self):
+        """`with net.deferred_init():` around an init() that sends BETWEEN node constructions (P/Paxos.java:283-296: every
+        ProposerNode starts its first proposal before the next one is built). The engine takes its node table whole, so inside
+        the block rd is drawn on the host (the node constructors' draws, the protocol's, the sends' seed draws, in the
+        reference's order), the sends and tasks are kept, and at the end — the nodes added — they are issued in their order,
+        each send with rd put back to where its seed draw (C/Network.java:377, 430) found it: the same envelopes, the same
+        push order, the same rd afterwards as the interleaved original."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def block():
+            if self._ready:
+                raise IllegalStateException("deferred_init() after the first send / run")
+            self._rd_held = self._eng.rng_state()
+            self._deferred = []
+            try:
+                yield self
+                ops, end = self._deferred, self._rd_held
+            finally:
+                self._deferred, self._rd_held = None, None
+            self._start()
+            lib, h = L.lib(), self._eng._h
+            for op in ops:
+                if op[0] == "send":
+                    _, before, m, sendTime, frm, ids, delay = op
+                    self._eng._ck(lib.wg_rng_set_state(h, C.c_uint64(before)))
+                    self._eng.send(self._handle(m), sendTime, frm, ids, delay)
+                elif op[0] == "arrive":
+                    self._eng._ck(lib.wg_send_arrive_at(h, self._handle(op[1]), 0, op[2], op[3], op[4]))
+                else:
+                    self._eng.registerTask(self._handle(op[1]), op[2], op[3])
+            self._eng._ck(lib.wg_rng_set_state(h, C.c_uint64(end)))
+        return block()
 
     def _handle(self, obj):
         """the handle an envelope of `obj` travels under (one more envelope of it in flight)"""
@@ -227,7 +262,8 @@ class HostNetwork:
         self.send(m, fromNode, self.allNodes, self.time + 1 if sendTime is None else sendTime, _force_multi=True)
 
     def send(self, m, fromNode, dests, sendTime=None, delayBetween=0, _force_multi=False):
-        self._start()
+        if self._deferred is None:
+            self._start()
         if isinstance(dests, Node):
             dests = [dests]
         elif not _force_multi and sendTime is None:
@@ -239,6 +275,11 @@ class HostNetwork:
         # createMessageArrival counts the sender's statistics for every destination, dropped or not (:476-477)
         fromNode.msgSent += len(ids)
         fromNode.bytesSent += len(ids) * m.size()
+        if self._deferred is not None:  # (deferred_init: the seed draw is made now, the send itself at the end of the block)
+            before = self._rd_held
+            self.rd.nextInt()
+            self._deferred.append(("send", before, m, sendTime, fromNode.nodeId, ids, delayBetween))
+            return
         if self._ops is not None:  # inside a batched step: the seed draw (:377 / :430) is made here, in action() order
             seed = self.rd.nextInt()
             if ids:
@@ -247,6 +288,9 @@ class HostNetwork:
         self._eng.send(self._handle(m), sendTime, fromNode.nodeId, ids, delayBetween)
 
     def sendArriveAt(self, m, arriveAt, fromNode, toNode):
+        if self._deferred is not None:
+            self._deferred.append(("arrive", m, int(arriveAt), fromNode.nodeId, toNode.nodeId))
+            return
         self._start()
         if self._ops is not None:
             if arriveAt <= self.time:
@@ -257,6 +301,9 @@ class HostNetwork:
                                                 toNode.nodeId))
 
     def _register(self, obj, startAt, fromNode):
+        if self._deferred is not None:
+            self._deferred.append(("task", obj, int(startAt), fromNode.nodeId))
+            return
         self._start()
         if self._ops is not None:
             self._ops.append((self._cur, 2, self._handle(obj), 0, int(startAt), fromNode.nodeId, [], 0, 0))
