@@ -223,13 +223,17 @@ def pmc_traffic(name, n, R, avg_launch_ns, step_s=None):
     lr = None
     if tj.get("ea_requests_per_launch") and avg_launch_ns > 0:
         q = float(tj["ea_requests_per_launch"])
-        lr = {"requests_per_launch": q, "read_requests_per_launch": tj.get("ea_read_requests_per_launch"),
-              "write_requests_per_launch": tj.get("ea_write_requests_per_launch"),
+        rq, wq = float(tj.get("ea_read_requests_per_launch") or 0.0), float(tj.get("ea_write_requests_per_launch") or 0.0)
+        lr = {"requests_per_launch": q, "read_requests_per_launch": rq, "write_requests_per_launch": wq,
               "requests_per_s": q / (avg_launch_ns * 1e-9), "ceiling_requests_per_s": LINE_RATE_CEILING,
               "frac": q / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING,
+              "read_requests_per_s": rq / (avg_launch_ns * 1e-9), "read_frac": rq / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING,
+              "write_requests_per_s": wq / (avg_launch_ns * 1e-9),
               "bytes_per_request": float(tj["hbm_bytes_per_launch"]) / q,
               "source": "TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum (a third PMC pass) per delivery pass / this run's HIP-event duration of "
-                        "the pass; ceiling: tools/micro/mlp_probe, scattered 64-byte reads (profiles/archive/r03b_micro_mlp_probe.txt)"}
+                        "the pass; ceiling: tools/micro/mlp_probe, scattered 64-byte READS (profiles/archive/r03b_micro_mlp_probe.txt) — "
+                        "`frac` sets reads + writes against it (above 1: the writes ride beside the reads, partly as 32-byte "
+                        "requests), `read_frac` the reads alone"}
         if step_s and tj.get("whole_step_ea_requests"):
             lr["whole_step"] = {"requests_per_step": tj["whole_step_ea_requests"], "requests_per_s": tj["whole_step_ea_requests"] / step_s,
                                 "frac": tj["whole_step_ea_requests"] / step_s / LINE_RATE_CEILING}

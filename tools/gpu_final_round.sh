@@ -28,7 +28,7 @@ passes h65536_ --nodes 65536 --replicas 8
 python tools/traffic_from_pmc.py $OUT/pmc_h65536_FETCH_SIZE.md $OUT/pmc_h65536_WRITE_SIZE.md 65536 $OUT/pmc_h65536_FETCH_SIZE.json $OUT/traffic_handel65536.json "$HANDEL_PASS" $OUT/pmc_h65536_req.md > /dev/null
 cp $OUT/traffic_handel65536.json profiles/traffic_handel65536.json
 passes gsf_ --workload gsf --nodes 4096 --replicas 256
-python tools/traffic_from_pmc.py $OUT/pmc_gsf_FETCH_SIZE.md $OUT/pmc_gsf_WRITE_SIZE.md 4096 $OUT/pmc_gsf_FETCH_SIZE.json $OUT/traffic_gsf.json "k_gsf_docycle,k_gsf_lane,k_deliver_inbox<GsfProto" $OUT/pmc_gsf_req.md > /dev/null
+python tools/traffic_from_pmc.py $OUT/pmc_gsf_FETCH_SIZE.md $OUT/pmc_gsf_WRITE_SIZE.md 4096 $OUT/pmc_gsf_FETCH_SIZE.json $OUT/traffic_gsf.json "k_gsf_docycle16,k_gsf_docycle<,k_gsf_lane,k_deliver_inbox<GsfProto" $OUT/pmc_gsf_req.md > /dev/null
 cp $OUT/traffic_gsf.json profiles/traffic_gsf.json
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$OUT/pc_$c -o k --output-format csv -- python $R/bench.py --workload casper --casper-stopped 0.1 --steps 1 --warmup 0 --no-cpu > $R/$OUT/pmc_casper_$c.json 2> $R/$OUT/pmc_casper_$c.err)
