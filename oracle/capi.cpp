@@ -10,6 +10,7 @@
 #include "handel.hpp"
 #include "p2pflood.hpp"
 #include "optimistic_p2p.hpp"
+#include "dfinity.hpp"
 #include "paxos.hpp"
 #include "slush.hpp"
 #include "pingpong.hpp"
@@ -1099,6 +1100,90 @@ int orc_paxos_read(void* h, int field, int64_t* out) {
 }
 int orc_paxos_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
   auto& p = *((OrcPaxos*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  return 0;
+}
+
+// ---- Dfinity (P/Dfinity.java)
+struct OrcDfinity {
+  std::unique_ptr<Dfinity> p;
+};
+// ip: blockProducersCount, attestersCount, attestersPerRound, blockConstructionTime, attestationConstructionTime,
+// percentageDeadAttester (:34-42). The observer is built by the constructor, BEFORE rd.setSeed(seed) — as `p.copy();
+// rd.setSeed(i); init()` does it (C/RunMultipleTimes.java:44-48)
+int orc_dfinity_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY Dfinity::Params pr;
+  pr.blockProducersCount = ip[0];
+  pr.attestersCount = ip[1];
+  pr.attestersPerRound = ip[2];
+  pr.blockConstructionTime = ip[3];
+  pr.attestationConstructionTime = ip[4];
+  pr.percentageDeadAttester = ip[5];
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcDfinity();
+  h->p = std::make_unique<Dfinity>(pr);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_dfinity_destroy(void* h) { delete (OrcDfinity*)h; }
+int orc_dfinity_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcDfinity*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+int orc_dfinity_node_count(void* h) { return (int)((OrcDfinity*)h)->p->nodes.size(); }
+// per node (observer, attesters, producers, beacon nodes; a field of another kind reads -2):
+// 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 x, 5 y, 6 head.height, 7 head.id, 8 head.proposalTime,
+// 9 lastRandomBeacon, 10 blocks received, 11 |committeeMajorityBlocks|, 12 sum of committeeMajorityHeight,
+// attesters: 13 voteForHeight, 14 proposals.size(), 15 votes.size(); producers: 16 waitForBlockHeight, 17 myRound;
+// beacon nodes: 18 height, 19 lastRDSent, 20 rd, 21 exchanged.size()
+int orc_dfinity_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcDfinity*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    Dfinity::DfinityNode* n = p.nodes[i].get();
+    auto* a = dynamic_cast<Dfinity::AttesterNode*>(n);
+    auto* b = dynamic_cast<Dfinity::BlockProducerNode*>(n);
+    auto* r = dynamic_cast<Dfinity::RandomBeaconNode*>(n);
+    int64_t v = -2;
+    switch (field) {
+      case 0: v = n->msgReceived; break;
+      case 1: v = n->msgSent; break;
+      case 2: v = n->bytesSent; break;
+      case 3: v = n->bytesReceived; break;
+      case 4: v = n->x; break;
+      case 5: v = n->y; break;
+      case 6: v = n->head->height; break;
+      case 7: v = n->head->id; break;
+      case 8: v = n->head->proposalTime; break;
+      case 9: v = n->lastRandomBeacon; break;
+      case 10: v = (int64_t)n->blocksReceivedByBlockId.size(); break;
+      case 11: v = (int64_t)n->committeeMajorityBlocks.size(); break;
+      case 12:
+        v = 0;
+        for (int x : n->committeeMajorityHeight) v += x;
+        break;
+      case 13: if (a) v = a->voteForHeight; break;
+      case 14: if (a) v = (int64_t)a->proposals.size(); break;
+      case 15: if (a) v = (int64_t)a->votes.size(); break;
+      case 16: if (b) v = b->waitForBlockHeight; break;
+      case 17: if (b) v = b->myRound; else if (a) v = a->myRound; break;
+      case 18: if (r) v = r->height; break;
+      case 19: if (r) v = r->lastRDSent; break;
+      case 20: if (r) v = r->rd; break;
+      case 21: if (r) v = (int64_t)r->exchanged.size(); break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_dfinity_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcDfinity*)h)->p;
   *time = p.network_.time;
   *queueSize = p.network_.msgs.size();
   *rngState = p.network_.rd.rawState();

@@ -504,6 +504,42 @@ class OptimisticP2PSignature:
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
 
 
+class Dfinity:
+    """oracle/dfinity.hpp: P/Dfinity.java; params = DfinityParameters' ctor order (blockProducersCount, attestersCount,
+    attestersPerRound, blockConstructionTime, attestationConstructionTime, percentageDeadAttester). Nodes: the observer, the
+    attesters, the producers, the beacon nodes; a field of another kind of node reads -2."""
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "x": 4, "y": 5, "headHeight": 6, "headId": 7,
+              "headTime": 8, "lastRandomBeacon": 9, "blocksReceived": 10, "majorityBlocks": 11, "majorityHeightSum": 12,
+              "voteForHeight": 13, "proposals": 14, "votes": 15, "waitForBlockHeight": 16, "myRound": 17, "rbHeight": 18,
+              "lastRDSent": 19, "rbRd": 20, "exchanged": 21}
+
+    def __init__(self, params, nb=None, nl=None, seed=0):
+        self.h = C.c_void_p()
+        ip = (C.c_int32 * 6)(*params)
+        _ck(lib().orc_dfinity_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed), C.byref(self.h)))
+        self.n = lib().orc_dfinity_node_count(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_dfinity_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_dfinity_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_dfinity_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_dfinity_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+
 class Paxos:
     """oracle/paxos.hpp: P/Paxos.java; params = PaxosParameters' ctor order (acceptorCount, proposerCount, timeout). Per-node
     reads cover both kinds of node: a field of the other kind reads -2, a null Integer -1."""

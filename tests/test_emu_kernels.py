@@ -42,6 +42,7 @@ import test_gpu_p2pflood as tpf  # noqa: E402
 import test_gpu_optimistic_p2p as top  # noqa: E402
 import test_gpu_slush as tsl  # noqa: E402
 import test_gpu_paxos as tpx  # noqa: E402
+import test_gpu_dfinity as tdf  # noqa: E402
 import test_gpu_sanfermin as tsf  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -266,6 +267,12 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_dfinity_through_host_callbacks(monkeypatch):  # P/Dfinity.java over the block-chain classes
+    tdf.test_dfinity_run()
+    tdf.test_dfinity_rounds_of_committees_with_latency()
+    tdf.test_dfinity_batched_steps(monkeypatch)
 
 
 def test_paxos_through_host_callbacks(monkeypatch):  # P/Paxos.java; init() sends between node constructions (deferred_init)

@@ -233,3 +233,24 @@ def test_paxos_agreement(oracle, seed):
         acc = p.read("valueAccepted")[prop]
         done = acc[acc >= 0]
         assert len(done) > 0 and (done == done[0]).all() and done[0] in set(p.read("valueProposed")[prop].tolist())
+
+
+# ---- Dfinity: PT/DfinityTest.java restated against the oracle (oracle/dfinity.hpp) -------------------------------------------
+def test_dfinity_run(oracle):  # testRun :20-24 with the fixture of :10-18 (NetworkNoLatency)
+    p = o.Dfinity((10, 10, 10, 1, 1, 0), GSF_NB, "NetworkNoLatency")
+    assert p.n == 1 + 10 + 10 + 10                      # the observer, the attesters, the producers, the beacon committee
+    p.run_ms(11 * 1000)
+    assert p.read("headHeight")[0] == 3                 # Assert.assertEquals(3, dfinity.network.observer.head.height)
+    assert (p.read("headHeight") == 3).all() and len(set(p.read("headId").tolist())) == 1  # one chain, everywhere
+
+
+def test_dfinity_copy_is_deterministic_and_the_chain_grows(oracle):  # the parameters of the (disabled) testCopy :28-47
+    a = o.Dfinity((10, 50, 25, 100, 1, 5), GSF_NB, "NetworkLatencyByDistanceWJitter", seed=3)
+    b = o.Dfinity((10, 50, 25, 100, 1, 5), GSF_NB, "NetworkLatencyByDistanceWJitter", seed=3)
+    for _ in range(20):
+        a.run_ms(1000)
+        b.run_ms(1000)
+        assert a.info() == b.info()
+        for f in ("headTime", "majorityBlocks", "majorityHeightSum", "lastRandomBeacon"):
+            assert (a.read(f) == b.read(f)).all()
+    assert a.read("headHeight")[0] >= 2 and (a.read("headHeight") >= a.read("headHeight")[0] - 1).all()
