@@ -223,6 +223,42 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
 
   private boolean stepOpen = false;
 
+  // ---- an init() that sends BETWEEN node constructions (P/Paxos.java:374-387: every ProposerNode starts its first proposal
+  // before the next one is built). The engine takes its node table whole, so inside deferredInit rd stays Java's (the node
+  // constructors' draws, the protocol's, the sends' seed draws, in the reference's order), the sends and tasks are kept, and
+  // once the nodes are added they are issued in their order — each send with the engine's rd put to where its seed draw
+  // (:377, :430) found Java's: the same envelopes, the same push order as the interleaved original.
+  // (hostnet.HostNetwork.deferred_init is this method; tests/test_gpu_paxos.py runs it.)
+  private ArrayList<Object[]> deferred = null;
+
+  public void deferredInit(Runnable init) {
+    if (ready) throw new IllegalStateException("deferredInit() after the first send / run");
+    deferred = new ArrayList<>();
+    ArrayList<Object[]> kept;
+    try {
+      init.run();
+      kept = deferred;
+    } finally {
+      deferred = null;
+    }
+    start();
+    for (Object[] o : kept) {
+      @SuppressWarnings("unchecked")
+      Message<? extends TN> m = (Message<? extends TN>) o[1];
+      switch ((Integer) o[0]) {
+        case WittGpu.OP_SEND:
+          WittGpu.rngSetState(handle, (Long) o[2]);
+          WittGpu.send(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4], (int[]) o[5], (Integer) o[6]);
+          break;
+        case WittGpu.OP_SEND_ARRIVE_AT:
+          WittGpu.sendArriveAt(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4], ((int[]) o[5])[0]);
+          break;
+        default:
+          WittGpu.registerTask(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4]);
+      }
+    }
+  }
+
   @Override
   public void send(Message<? extends TN> mc, int sendTime, TN fromNode, TN toNode) { // :369-382
     checkFrom(fromNode);
@@ -240,9 +276,15 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
   }
 
   private void sendIds(Message<? extends TN> m, int sendTime, TN fromNode, int[] ids, int delay) {
-    start();
+    if (deferred == null) start();
     // createMessageArrival counts the sender's statistics for every destination, dropped or not (:476-477)
     GpuNodeAccess.sent(fromNode, ids.length, (long) ids.length * m.size());
+    if (deferred != null) { // (deferredInit: the seed draw is made now, the send itself once the nodes are added)
+      long before = stateOf(rd);
+      rd.nextInt();
+      deferred.add(new Object[] {WittGpu.OP_SEND, m, before, sendTime, fromNode.nodeId, ids, delay});
+      return;
+    }
     if (stepOpen) { // inside a delivery's action(): the seed draw (:377 / :430) is made HERE, in action() order
       int seed = rd.nextInt();
       if (ids.length > 0) op(WittGpu.OP_SEND, handleOf(m), sendTime, fromNode.nodeId, ids, delay, seed);
@@ -255,6 +297,10 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
 
   @Override
   public void sendArriveAt(Message<? extends TN> mc, int arriveAt, TN fromNode, TN toNode) { // :384-390
+    if (deferred != null) {
+      deferred.add(new Object[] {WittGpu.OP_SEND_ARRIVE_AT, mc, 0L, arriveAt, fromNode.nodeId, new int[] {toNode.nodeId}, 0});
+      return;
+    }
     start();
     if (arriveAt <= time) throw new IllegalArgumentException("wrong arrival time: arriveAt=" + arriveAt + ", time=" + time);
     if (stepOpen) op(WittGpu.OP_SEND_ARRIVE_AT, handleOf(mc), arriveAt, fromNode.nodeId, new int[] {toNode.nodeId}, 0, 0);
@@ -262,6 +308,10 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
   }
 
   private void register(Task<TN> t, int startAt, TN fromNode) {
+    if (deferred != null) {
+      deferred.add(new Object[] {WittGpu.OP_TASK, t, 0L, startAt, fromNode.nodeId, new int[0], 0});
+      return;
+    }
     start();
     if (stepOpen) op(WittGpu.OP_TASK, handleOf(t), startAt, fromNode.nodeId, new int[0], 0, 0);
     else WittGpu.registerTask(handle, handleOf(t), 0, startAt, fromNode.nodeId);
