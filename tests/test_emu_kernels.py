@@ -275,6 +275,10 @@ def test_dfinity_through_host_callbacks(monkeypatch):  # P/Dfinity.java over the
     tdf.test_dfinity_batched_steps(monkeypatch)
 
 
+def test_handel_dissemination_phase_registered_late():
+    th.test_dissemination_phase_registered_after_the_first_run()
+
+
 def test_paxos_through_host_callbacks(monkeypatch):  # P/Paxos.java; init() sends between node constructions (deferred_init)
     tpx.test_paxos_simple()
     tpx.test_paxos_contended_and_copy((7, 5, 600), 2)

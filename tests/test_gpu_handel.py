@@ -114,6 +114,25 @@ def test_two_appends_per_ms_is_the_same_run(monkeypatch):
     lockstep(ratios(512, dead=0.2), step=7, max_ms=2500)
 
 
+def test_dissemination_phase_registered_after_the_first_run():
+    """The engine launches k_handel_dissem only in a ms whose phase some registered dissemination task has
+    (Group::periodic_may_fire) and k_handel_wave stops the run should the skipped kernel's list not be empty after all. A task
+    registered through the host API AFTER the first run — another phase — must be seen by that hint: the run goes on, and the
+    node the second task belongs to disseminates twice per period."""
+    def run(extra):
+        g, _ = parity.handel_pair(ratios(256))
+        net = g.network()
+        net.runMs(33)
+        who = int(np.nonzero(net.read("down") == 0)[0][3])  # a live node
+        if extra:  # Handel's dissemination is task word 0 (H_TASK_DISSEMINATION); its own tasks run at phase startAt + 1 = 1 (mod 20)
+            net.registerPeriodicTask(0, net.time + 7, 20, who)
+        for _ in range(12):
+            net.runMs(10)
+        return net.read("msgSent"), who
+    (base, who), (more, _) = run(False), run(True)
+    assert more[who] > base[who] + 10   # (a halted run would raise; the extra task sent its levels' messages)
+
+
 def test_rank_bump_table_overflow_is_loud():
     """a node that bumps more distinct senders than wg_config.rank_bump_cap holds stops the run (WG_ENOMEM), it does not diverge"""
     g, c = parity.handel_pair(ratios(512, dead=0.2), config={"rank_bump_cap": 4})
