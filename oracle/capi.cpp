@@ -11,6 +11,7 @@
 #include "p2pflood.hpp"
 #include "optimistic_p2p.hpp"
 #include "dfinity.hpp"
+#include "p2phandel.hpp"
 #include "paxos.hpp"
 #include "slush.hpp"
 #include "pingpong.hpp"
@@ -1189,6 +1190,120 @@ int orc_dfinity_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngSt
   *rngState = p.network_.rd.rawState();
   *delivered = p.network_.statDelivered;
   return 0;
+}
+
+// ---- P2PHandel (P/P2PHandel.java over C/P2PNetwork.java)
+struct OrcP2PHandel {
+  std::unique_ptr<P2PHandel> p;
+};
+// ip: signingNodeCount, relayingNodeCount, threshold, connectionCount, pairingTime, sigsSendPeriod, doubleAggregateStrategy,
+// sendSigsStrategy (0 all, 1 dif, 2 cmp_all, 3 cmp_diff), sendState (:80-104)
+int orc_p2phandel_create(const int32_t* ip, const char* nb, const char* nl, int64_t seed, void** out) {
+  ORC_TRY P2PHandel::Params pr;
+  pr.signingNodeCount = ip[0];
+  pr.relayingNodeCount = ip[1];
+  pr.threshold = ip[2];
+  pr.connectionCount = ip[3];
+  pr.pairingTime = ip[4];
+  pr.sigsSendPeriod = ip[5];
+  pr.doubleAggregateStrategy = ip[6] != 0;
+  pr.sendSigsStrategy = (P2PHandel::SendSigsStrategy)ip[7];
+  pr.sendState = ip[8] != 0;
+  pr.nodeBuilderName = nb ? nb : "";
+  pr.networkLatencyName = nl ? nl : "";
+  auto* h = new OrcP2PHandel();
+  h->p = std::make_unique<P2PHandel>(pr);
+  h->p->network_.rd.setSeed(seed);
+  h->p->init();
+  *out = h;
+  ORC_CATCH
+}
+void orc_p2phandel_destroy(void* h) { delete (OrcP2PHandel*)h; }
+int orc_p2phandel_run_ms(void* h, int ms, int* didSomething) {
+  ORC_TRY* didSomething = ((OrcP2PHandel*)h)->p->network_.runMs(ms);
+  ORC_CATCH
+}
+static int64_t bits_digest(const BitSet& b) {  // order-sensitive digest of the set bits
+  int64_t v = 0;
+  for (int i = b.nextSetBit(0), k = 1; i >= 0; i = b.nextSetBit(i + 1), k++) v += (int64_t)k * (i + 1);
+  return v;
+}
+// fields: 0 msgReceived, 1 msgSent, 2 bytesSent, 3 bytesReceived, 4 doneAt, 5 x, 6 y, 7 |verifiedSignatures|, 8 its digest,
+//         9 toVerify.size(), 10 the table length of toVerify, 11 a digest of toVerify in ITERATION order, 12 peers.size(),
+//         13 order-sensitive digest of the peer ids, 14 justRelay, 15 sum over the peers of |peersState|
+int orc_p2phandel_read(void* h, int field, int64_t* out) {
+  ORC_TRY auto& p = *((OrcP2PHandel*)h)->p;
+  for (size_t i = 0; i < p.nodes.size(); i++) {
+    auto& n = *p.nodes[i];
+    int64_t v = 0;
+    switch (field) {
+      case 0: v = n.msgReceived; break;
+      case 1: v = n.msgSent; break;
+      case 2: v = n.bytesSent; break;
+      case 3: v = n.bytesReceived; break;
+      case 4: v = n.doneAt; break;
+      case 5: v = n.x; break;
+      case 6: v = n.y; break;
+      case 7: v = n.verifiedSignatures.cardinality(); break;
+      case 8: v = bits_digest(n.verifiedSignatures); break;
+      case 9: v = n.toVerify.size(); break;
+      case 10: v = n.toVerify.capacity(); break;
+      case 11: {
+        int k = 1;
+        for (const auto& b : n.toVerify.items()) v += (int64_t)(k++) * (bits_digest(*b) % 1000003);
+        break;
+      }
+      case 12: v = (int64_t)n.peers.size(); break;
+      case 13:
+        for (size_t k = 0; k < n.peers.size(); k++) v += (int64_t)(k + 1) * n.peers[k]->nodeId;
+        break;
+      case 14: v = n.justRelay; break;
+      case 15:
+        for (const auto& kv : n.peersState) v += kv.second->cardinality();
+        break;
+      default: throw IllegalArgumentException("field");
+    }
+    out[i] = v;
+  }
+  ORC_CATCH
+}
+int orc_p2phandel_info(void* h, int32_t* time, int32_t* queueSize, uint64_t* rngState, uint64_t* delivered) {
+  auto& p = *((OrcP2PHandel*)h)->p;
+  *time = p.network_.time;
+  *queueSize = p.network_.msgs.size();
+  *rngState = p.network_.rd.rawState();
+  *delivered = p.network_.statDelivered;
+  return 0;
+}
+// compressedSize of the set whose bits are the '1' characters of `binary` (PT/P2PHandelTest.testCompressedSize / fromString)
+int orc_p2phandel_compressed_size(void* h, const char* binary) {
+  BitSet b;
+  int i = 0;
+  for (const char* c = binary; *c; c++) {
+    if (*c == ' ') continue;
+    if (*c == '1') b.set(i);
+    i++;
+  }
+  return ((OrcP2PHandel*)h)->p->compressedSize(b);
+}
+// PT/P2PHandelTest.testCheckSigs (out[0] = toVerify.isEmpty(), out[1] = msgs.size()) and testSigUpdate (out[2] = cardinality) on node 1
+int orc_p2phandel_probe(void* h, int32_t* out) {
+  ORC_TRY auto& p = *((OrcP2PHandel*)h)->p;
+  auto& n1 = *p.nodes.at(1);
+  auto sigs = std::make_shared<BitSet>();
+  sigs->set(n1.nodeId);
+  sigs->set(0);
+  n1.toVerify.add(sigs);
+  p.network_.msgs.clear();
+  n1.checkSigs();
+  out[0] = n1.toVerify.isEmpty();
+  out[1] = p.network_.msgs.size();
+  BitSet s2;
+  s2.set(n1.nodeId);
+  s2.set(0);
+  n1.updateVerifiedSignatures(s2);
+  out[2] = n1.verifiedSignatures.cardinality();
+  ORC_CATCH
 }
 
 }  // extern "C"

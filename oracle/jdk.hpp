@@ -14,6 +14,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -189,6 +190,102 @@ class BitSet {
   }
   // raw word access for state dumps (word index in the JDK's from-zero numbering)
   uint64_t wordAt(int wi) const { return word(wi); }
+  // BitSet.length(): the index of the highest set bit + 1
+  int length() const {
+    for (int k = (int)w_.size() - 1; k >= 0; k--)
+      if (w_[k]) return (base_ + k) * 64 + 64 - __builtin_clzll(w_[k]);
+    return 0;
+  }
+  // BitSet.hashCode(): h = 1234; for (i = wordsInUse; --i >= 0;) h ^= words[i] * (i + 1); return (int)((h >> 32) ^ h) — a zero
+  // word contributes nothing, so the window and the JDK's wordsInUse do not matter
+  jint hashCode() const {
+    uint64_t h = 1234;
+    for (int k = 0; k < (int)w_.size(); k++) h ^= w_[k] * (uint64_t)(base_ + k + 1);
+    return (jint)(uint32_t)(((uint64_t)((int64_t)h >> 32)) ^ h);
+  }
+};
+
+// java.util.HashSet<E> (a HashMap underneath, JDK 8+) where the ITERATION ORDER matters: bucket = (h ^ h >>> 16) & (cap - 1) of
+// the hash the element had WHEN IT WAS ADDED (HashMap.Node.hash is final: an element mutated afterwards stays where it is and is
+// found again only by its old hash), insertion order inside a bucket, tables of 16 doubling when the size passes 3/4 of the
+// capacity (resize() splits every bucket into its low and high half, order preserved) or when a bucket would reach nine nodes in
+// a table below 64 (treeifyBin resizes instead of treeifying there); clear() keeps the capacity. A bucket of nine in a table of
+// 64 or more would become a tree (whose root moves to the bucket's front): not restated, an exception says so.
+// E needs hashCode() and equals(const E&); elements are held by shared_ptr (Java references: identity first, as HashMap.putVal).
+template <class E>
+class JHashSet {
+  struct Node {
+    jint hash;
+    std::shared_ptr<E> key;
+  };
+  std::vector<std::vector<Node>> tab_;
+  int size_ = 0;
+  static jint spread(jint h) { return h ^ (jint)((uint32_t)h >> 16); }
+  void resize() {
+    if (tab_.empty()) {
+      tab_.assign(16, {});
+      return;
+    }
+    const size_t oldCap = tab_.size();
+    std::vector<std::vector<Node>> nt(oldCap * 2);
+    for (size_t j = 0; j < oldCap; j++)
+      for (Node& e : tab_[j]) nt[((uint32_t)e.hash & (uint32_t)oldCap) ? j + oldCap : j].push_back(std::move(e));
+    tab_ = std::move(nt);
+  }
+  int threshold() const { return (int)(tab_.size() * 3 / 4); }
+
+ public:
+  int size() const { return size_; }
+  bool isEmpty() const { return size_ == 0; }
+  bool add(const std::shared_ptr<E>& k) {  // HashMap.putVal
+    if (tab_.empty()) resize();
+    const jint h = spread(k->hashCode());
+    std::vector<Node>& b = tab_[(uint32_t)h & (uint32_t)(tab_.size() - 1)];
+    for (const Node& e : b)
+      if (e.hash == h && (e.key == k || k->equals(*e.key))) return false;
+    const size_t before = b.size();
+    b.push_back({h, k});
+    if (before >= 8) {  // binCount >= TREEIFY_THRESHOLD - 1 in putVal's loop: treeifyBin
+      if (tab_.size() >= 64) throw IllegalStateException("JHashSet: a bucket became a tree (not restated)");
+      resize();
+    }
+    if (++size_ > threshold()) resize();
+    return true;
+  }
+  bool remove(const std::shared_ptr<E>& k) {  // HashMap.removeNode: by the element's hash NOW
+    if (tab_.empty()) return false;
+    const jint h = spread(k->hashCode());
+    std::vector<Node>& b = tab_[(uint32_t)h & (uint32_t)(tab_.size() - 1)];
+    for (size_t i = 0; i < b.size(); i++)
+      if (b[i].hash == h && (b[i].key == k || k->equals(*b[i].key))) {
+        b.erase(b.begin() + i);
+        size_--;
+        return true;
+      }
+    return false;
+  }
+  void clear() {
+    for (auto& b : tab_) b.clear();
+    size_ = 0;
+  }
+  // the elements in iteration order (a snapshot: the callers here remove through removeAt / remove while walking a copy)
+  std::vector<std::shared_ptr<E>> items() const {
+    std::vector<std::shared_ptr<E>> out;
+    for (const auto& b : tab_)
+      for (const Node& e : b) out.push_back(e.key);
+    return out;
+  }
+  // Iterator.remove() of the element the iterator just returned: unlinks THAT node (by identity, whatever its hash is now)
+  void removeNode(const std::shared_ptr<E>& k) {
+    for (auto& b : tab_)
+      for (size_t i = 0; i < b.size(); i++)
+        if (b[i].key == k) {
+          b.erase(b.begin() + i);
+          size_--;
+          return;
+        }
+  }
+  int capacity() const { return (int)tab_.size(); }
 };
 
 // BitSetUtils.include (C/utils/BitSetUtils.java:8-13)

@@ -540,6 +540,50 @@ class Dfinity:
         return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
 
 
+class P2PHandel:
+    """oracle/p2phandel.hpp: P/P2PHandel.java; params = P2PHandelParameters' ctor order (signingNodeCount, relayingNodeCount,
+    threshold, connectionCount, pairingTime, sigsSendPeriod, doubleAggregateStrategy, sendSigsStrategy, sendState);
+    sendSigsStrategy: "all" / "dif" / "cmp_all" / "cmp_diff"."""
+    STRATEGY = {"all": 0, "dif": 1, "cmp_all": 2, "cmp_diff": 3}
+    FIELDS = {"msgReceived": 0, "msgSent": 1, "bytesSent": 2, "bytesReceived": 3, "doneAt": 4, "x": 5, "y": 6, "sigs": 7,
+              "sigsDigest": 8, "toVerify": 9, "toVerifyCapacity": 10, "toVerifyOrder": 11, "peerCount": 12, "peerDigest": 13,
+              "justRelay": 14, "peersState": 15}
+
+    def __init__(self, params, nb=None, nl=None, seed=0):
+        self.h, self.n = C.c_void_p(), params[0] + params[1]
+        ip = (C.c_int32 * 9)(params[0], params[1], params[2], params[3], params[4], params[5], int(params[6]),
+                             self.STRATEGY[params[7]], int(params[8]))
+        _ck(lib().orc_p2phandel_create(ip, nb.encode() if nb else None, nl.encode() if nl else None, C.c_int64(seed), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().orc_p2phandel_destroy(self.h)
+            self.h = None
+
+    def run_ms(self, ms):
+        d = C.c_int()
+        _ck(lib().orc_p2phandel_run_ms(self.h, ms, C.byref(d)))
+        return bool(d.value)
+
+    def read(self, field):
+        out = np.zeros(self.n, np.int64)
+        _ck(lib().orc_p2phandel_read(self.h, self.FIELDS[field], _p(out, C.c_int64)))
+        return out
+
+    def info(self):
+        t, q, r, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        lib().orc_p2phandel_info(self.h, C.byref(t), C.byref(q), C.byref(r), C.byref(d))
+        return {"time": t.value, "queue": q.value, "rng": r.value, "delivered": d.value}
+
+    def compressed_size(self, binary):
+        return lib().orc_p2phandel_compressed_size(self.h, binary.encode())
+
+    def probe(self):
+        out = (C.c_int32 * 3)()
+        _ck(lib().orc_p2phandel_probe(self.h, out))
+        return list(out)
+
+
 class Paxos:
     """oracle/paxos.hpp: P/Paxos.java; params = PaxosParameters' ctor order (acceptorCount, proposerCount, timeout). Per-node
     reads cover both kinds of node: a field of the other kind reads -2, a null Integer -1."""

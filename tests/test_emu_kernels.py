@@ -43,6 +43,7 @@ import test_gpu_optimistic_p2p as top  # noqa: E402
 import test_gpu_slush as tsl  # noqa: E402
 import test_gpu_paxos as tpx  # noqa: E402
 import test_gpu_dfinity as tdf  # noqa: E402
+import test_gpu_p2phandel as tph  # noqa: E402
 import test_gpu_sanfermin as tsf  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 import test_gpu_hostmode as thm  # noqa: E402
@@ -267,6 +268,14 @@ def test_scheduler_fuzz_partitions_stops_discard():
 def test_sanfermin_through_host_callbacks():  # P/SanFerminSignature.java on the engine vs oracle/sanfermin.hpp
     tsf.test_sanfermin_64_matches_oracle()
     tsf.test_sanfermin_fixed_latency_short_timeout()
+
+
+def test_p2phandel_through_host_callbacks(monkeypatch):  # P/P2PHandel.java over C/P2PNetwork.java; java.util.HashSet's order
+    tph.test_p2phandel_default_shape()
+    tph.test_p2phandel_runs_to_done_in_lockstep((20, 0, 20, 3, 2, 50, True, "cmp_diff", True))
+    tph.test_p2phandel_runs_to_done_in_lockstep((40, 8, 36, 6, 3, 10, True, "cmp_all", False))
+    tph.test_p2phandel_single_best_strategy_batched_steps(monkeypatch)
+    tph.test_p2phandel_a_treeified_bucket_is_refused_like_the_oracle()
 
 
 def test_dfinity_through_host_callbacks(monkeypatch):  # P/Dfinity.java over the block-chain classes

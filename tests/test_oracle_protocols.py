@@ -254,3 +254,54 @@ def test_dfinity_copy_is_deterministic_and_the_chain_grows(oracle):  # the param
         for f in ("headTime", "majorityBlocks", "majorityHeightSum", "lastRandomBeacon"):
             assert (a.read(f) == b.read(f)).all()
     assert a.read("headHeight")[0] >= 2 and (a.read("headHeight") >= a.read("headHeight")[0] - 1).all()
+
+
+# ---- P2PHandel: PT/P2PHandelTest.java restated against the oracle (oracle/p2phandel.hpp) -------------------------------------
+def _p2phandel_default(nodes=32, cc=4):  # P2PHandelScenarios.defaultParams(32, 0.0, 4, null, null) (:261-277) on the RANDOM builder
+    return (nodes, 0, int(nodes * 0.99), cc, 4, 20, True, "dif", False)
+
+
+def test_p2phandel_setup_checksigs_sigupdate(oracle):  # testSetup :17-25, testCheckSigs :74-83, testSigUpdate :85-91
+    p = o.P2PHandel(_p2phandel_default(), GSF_NB, GSF_NL)
+    assert (p.read("sigs") == 1).all() and (p.read("sigsDigest") == np.arange(32) + 1).all()   # own signature only
+    assert (p.read("peerCount") >= 3).all()
+    empty, queued, card = p.probe()
+    assert empty == 1 and queued == 1 and card == 2
+
+
+def test_p2phandel_compressed_size(oracle):  # testCompressedSize :104-143: the reference's fourteen values
+    p = o.P2PHandel(_p2phandel_default(), GSF_NB, GSF_NL)
+    for want, binary in [(1, "1111"), (1, "1111 1111"), (1, "1111 1111 1111 1111"),
+                         (3, "0000 0000 0000 0000  0000 0000 0000 0000 1111 1111 1111 1111  1111 1111 1111 0000"),
+                         (1, "0000 0000 0000 0000  0000 0000 0000 0000 1111 1111 1111 1111  1111 1111 1111 1111 0000"),
+                         (2, "0000 0000 0000 0000  1111 1111 1111 1111 1111 1111 1111 1111  1111 1111 1111 1111 0000"),
+                         (3, "1111 1111 1111 1111  1111 1111 1111 0000"), (1, "1111 1111 0000"), (3, "0001 1111 1111 0000"),
+                         (3, "0001 1111 1111 1111"), (2, "0000 1111 1111 1111  0000"), (4, "1101 0111"), (3, "1111 1110")]:
+        assert p.compressed_size(binary) == want, binary
+
+
+@pytest.mark.parametrize("params", [(64, 0, 60, 3, 2, 5, True, "all", False), (20, 0, 20, 3, 2, 50, True, "cmp_diff", True)])
+def test_p2phandel_runs_to_done(oracle, params):  # testSimpleRunWithoutState :44-55, testSimpleRunWithState :57-68
+    p = o.P2PHandel(params, GSF_NB, GSF_NL)
+    while (p.read("doneAt") == 0).any() and p.info()["time"] < 20000:   # RunMultipleTimes.contUntilDone()
+        p.run_ms(1000)
+    assert (p.read("doneAt") > 0).all() and (p.read("sigs") >= params[2]).all()
+
+
+@pytest.mark.parametrize("params", [(100, 0, 25, 10, 2, 5, False, "dif", False), (40, 0, 25, 8, 2, 5, False, "dif", True)])
+def test_p2phandel_repeatability(oracle, params):
+    """testRepeatability :27-42 (checkSigs1: the single-best strategy) on its own shape without the state messages, and with them
+    on 40 nodes. The reference's exact parameters (100 nodes WITH state messages) grow a bucket of toVerify's table into a
+    red-black tree (java.util.HashMap.treeifyBin: BitSet hashes of small sets cluster), whose iteration order follows the
+    tree's shape and, for equal hashes, System.identityHashCode: not restatable — the oracle refuses it loudly (next test)."""
+    a, b = o.P2PHandel(params, GSF_NB, GSF_NL), o.P2PHandel(params, GSF_NB, GSF_NL)
+    a.run_ms(10 * 1000)
+    b.run_ms(10 * 1000)
+    assert (a.read("doneAt") == b.read("doneAt")).all() and (a.read("doneAt") > 0).all() and a.info() == b.info()
+
+
+def test_p2phandel_a_treeified_bucket_is_refused(oracle):
+    p = o.P2PHandel((100, 0, 25, 10, 2, 5, False, "dif", True), GSF_NB, GSF_NL)
+    with pytest.raises(o.OracleError) as ei:
+        p.run_ms(10 * 1000)
+    assert "became a tree" in str(ei.value)
