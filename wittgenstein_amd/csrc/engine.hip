@@ -2551,7 +2551,7 @@ struct HandelHost : ProtoHost {
   Engine& eng;
   uint32_t* dCont = nullptr;
   // (the register allocations of the latency-bound kernels — waves per SIMD: k_handel_wave 4, k_handel_a1c 5,
-  // k_handel_update 6, k_handel_dissem 8 — are the measured optima of the sweeps in profiles/INDEX.md; DESIGN.md "Occupancy")
+  // k_handel_update 8, k_handel_dissem 8 — are the measured optima of the sweeps in profiles/INDEX.md; DESIGN.md "Occupancy")
   HandelHost(Engine& e, const wg_handel_params& p, const wg_handel_init_state& init) : eng(e) {
     const auto tCtor = std::chrono::steady_clock::now();
     const int32_t N = p.nodeCount;
@@ -3110,7 +3110,7 @@ struct HandelHost : ProtoHost {
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
     hipLaunchKernelGGL(k_handel_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
-    hipLaunchKernelGGL(k_handel_update<6>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     // the deliveries behind a wide update that was its node's first event, one lane per node (after the update)
     if (!st.atk)
       hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);

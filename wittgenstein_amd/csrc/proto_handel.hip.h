@@ -1357,7 +1357,9 @@ __device__ __forceinline__ void h_lane_store_header(uint32_t WG_G* hdr, const HL
   }
 }
 
-__global__ void __launch_bounds__(256) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
+// (three wavefronts a SIMD: 168 registers without a spill. Left to itself the compiler takes 172 — and the kernel drops to two:
+// 84 -> 81 us per launch at 31 copies, profiles/r22h_*)
+__global__ void __launch_bounds__(256, 3) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
   const HandelState& s = stab[blockIdx.y];
   const int lane = WG_LANE;
