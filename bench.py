@@ -575,7 +575,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=32768)
     ap.add_argument("--replicas", type=int, default=31, help="independent simulations per step and per GPU (lowered to what fits the free HBM). "
                     "31 copies of config 3 (9.19 GB each with their init() image) since round 5: 32 fit too and are SLOWER — 546 against "
-                    "565 M msgs/s, every delivery kernel a tenth longer with the HBM 96 %% full (profiles/r20u_*, r20v_*)")
+                    "565 M msgs/s, and as slow with smaller copies at 90 %% of the HBM: the lane-per-node kernels take 17 %% longer "
+                    "for 3 %% more nodes (profiles/r20u_*, r23b_copies_31_vs_32.txt)")
     ap.add_argument("--engine-config", default="", help="wg_config capacities of the Handel copies as name=value,... "
                     "(include/wittgpu.h; overflow of any of them is a loud error, never a silent divergence)")
     ap.add_argument("--batches", type=int, default=0,
