@@ -3109,7 +3109,10 @@ struct HandelHost : ProtoHost {
   // k_handel_wave (one wavefront per listed node / deferred fast path)
   void launch_deliver(const Group& g) override {
     const HandelState* stab = (const HandelState*)g.stab;
-    hipLaunchKernelGGL(k_handel_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 2048), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    // (workgroups of ONE wavefront: at three wavefronts a SIMD a 256-thread workgroup needs four free slots at once, one per SIMD,
+    // and the kernel's wavefronts end at very different times — 576 -> 579 M msgs/s same-box, and the 32-copy cliff halves:
+    // profiles/r23d_*. The kernels with more resident wavefronts lose with small workgroups.)
+    hipLaunchKernelGGL(k_handel_lane, dim3(4 * grid_per_engine(GRID_LANE_NODES, g.R, 2048), g.R), dim3(64), 0, g.stream, g.tab, stab);
     hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     // the deliveries behind a wide update that was its node's first event, one lane per node (after the update)
     if (!st.atk)
