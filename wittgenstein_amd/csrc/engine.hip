@@ -3496,7 +3496,9 @@ struct GsfHost : ProtoHost {
       hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab, cycleRan ? 1 : 0, restList ? 1 : 0);
     if (eng.dev.inbox && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
-      hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4, true>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
+      // (workgroups of one wavefront: at four wavefronts a SIMD a 256-thread workgroup waits for a free slot on all four SIMDs at
+      // once and the visits end at very different times — 575 -> 602 M msgs/s at 256 copies, same box: profiles/r23f_*)
+      hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4, true>), dim3(4 * grid_node_waves(g.R), g.R), dim3(64), 0, g.stream, g.tab,
                          (const GsfState*)g.stab);
     else if (eng.dev.inbox)  // a node's events from its inbox line (one 64-byte read instead of the list walk)
       hipLaunchKernelGGL((k_deliver_inbox<GsfProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab,
@@ -3777,7 +3779,7 @@ struct CasperHost : ProtoHost {
       drawBase += (uint32_t)h[1];
     }
     // (k_deliver: every node with a block or a task has been visited and unflagged — its visit_skip admits none; it retires the ms's node list)
-    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(4 * grid_node_waves(g.R), g.R), dim3(64), 0, g.stream, g.tab, stab);  // (one-wavefront workgroups: +5 %, profiles/r23f_*)
     return true;
   }
   void launch_deliver(const Group& g) override {
@@ -3794,7 +3796,7 @@ struct CasperHost : ProtoHost {
       hipLaunchKernelGGL(k_casper_mark, dim3(GRID_RESOLVE, g.R), dim3(256), 0, g.stream, g.tab, stab);
       hipLaunchKernelGGL(k_casper_seq, dim3(1, g.R), dim3(64), 0, g.stream, g.tab, stab);
     }
-    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL((k_deliver<CasperProto, 4>), dim3(4 * grid_node_waves(g.R), g.R), dim3(64), 0, g.stream, g.tab, stab);  // (one-wavefront workgroups: +5 %, profiles/r23f_*)
   }
   size_t state_size() const override { return sizeof(st); }
   const void* state_host() const override { return &st; }
