@@ -420,6 +420,9 @@ struct EngineDev {
   // the sort by arrival, the envelope ring and a shard's exchange image as they are.
   uint32_t destTagged;
   uint32_t destTagMsgShift;
+  // batch launches deal their blocks so that an engine stays on ONE XCD (engine_kernels.hip.h: wg_place); read from the
+  // FIRST engine of the table. 0: the plain (blockIdx.x, blockIdx.y) mapping (WG_XCD_PLACE=0, the A/B switch)
+  uint32_t xcdPlace;
 };
 WG_HD inline int32_t dest_id(const EngineDev& d, int32_t w) { return d.destTagged ? (int32_t)((uint32_t)w & 0xFFFFu) : w; }
 WG_HD inline uint32_t dest_msg(const EngineDev& d, uint32_t msg, int32_t w) {

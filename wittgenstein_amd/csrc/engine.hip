@@ -657,6 +657,7 @@ void Engine::ensure_device() {
     dev.maxRuns = dev.chainSlots;
     dev.runs = dalloc<RunDesc>(dev.maxRuns, false, AC_SCRATCH);
   }
+  dev.xcdPlace = !(getenv("WG_XCD_PLACE") && atoi(getenv("WG_XCD_PLACE")) == 0);  // (read once per engine; the A/B switch of wg_place)
   dev.sharded = shardCount > 0 ? 1u : 0u;
   dev.shardLo = 0;
   dev.shardHi = INT32_MAX;

@@ -255,13 +255,13 @@ __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain
 // Device-wide exclusive scan of F(i), i in [0, F.count()): every block owns a contiguous chunk. Values are uint64 so
 // a pair of 32-bit counters can be scanned at once.
 constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_GRID = 240 / WG_GRID_DIV;  // blocks per ENGINE (grid.x; a batch multiplies it by its members in grid.y): a multiple of
+constexpr int SCAN_GRID = 240 / WG_GRID_DIV > 2 ? 240 / WG_GRID_DIV : 2;  // blocks per ENGINE (grid.x; a batch multiplies it by its members in grid.y): a multiple of
                                                // the 8 XCDs that keeps a block's chunk of a typical ms's events at a few SCAN_BLOCK rounds
 
-__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
-  uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+__device__ __forceinline__ void scan_range(uint32_t n, uint32_t bx, uint32_t gx, uint32_t& lo, uint32_t& hi) {  // (bx of gx blocks: WG_ENGINE's)
+  uint32_t chunk = (n + gx - 1) / gx;
   chunk = (chunk + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
-  lo = min(n, blockIdx.x * chunk);
+  lo = min(n, bx * chunk);
   hi = min(n, lo + chunk);
 }
 
@@ -303,11 +303,48 @@ __device__ __forceinline__ void cont_if_set(uint32_t* out) {
   if (!cont_if_known(out)) __hip_atomic_store(out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Every kernel of the pipeline is launched over a TABLE of engines, blockIdx.y selecting the engine:
+// Every kernel of the pipeline is launched over a TABLE of engines — grid (blocks per engine, engines) —:
 // a batch of independent simulations (the reference's RunMultipleTimes copies, C/RunMultipleTimes.java:
 // 44-48) advances one simulated ms per launch. A stand-alone engine is a table of one.
-#define WG_ENGINE(tab)                         \
-  const EngineDev& d = (tab)[blockIdx.y];      \
+//
+// WHICH block works on which engine is XCD-aware. The dispatcher hands workgroup L (linear id, x fastest) to XCD L % 8,
+// each XCD has a private 4 MB L2 (not coherent with the others) and its own TLBs, and an engine is a closed world: its
+// kernels read and write that engine's arrays only. With the plain (blockIdx.x, blockIdx.y) mapping an engine's blocks
+// are dealt round all eight XCDs, so what one kernel of a ms wrote (inbox lines, work lists, queue records, event results)
+// is in another XCD's L2 seven times out of eight when the next kernel reads it, and every XCD's TLBs walk all the batch's
+// 280 GB. wg_place re-deals the launch's blocks so that engine e is worked on by XCD e % 8 only: the blocks that land on
+// XCD k (L % 8 == k) are split evenly over the engines k, k + 8, k + 16, ... — wgBy is the engine, wgBx / wgGx the block's
+// index / count WITHIN that engine (every kernel here is a grid-stride loop over wgGx blocks, so results never depend on
+// the split). A block left over by the division does nothing. Placement is a speed matter only: nothing relies on the
+// dispatcher really behaving this way (MI355X_MICROARCH.md: observed, not contracted). Batches of fewer than 8 engines,
+// and grids of one block per engine, keep the plain mapping (EngineDev::xcdPlace == 0 forces it: WG_XCD_PLACE=0).
+struct WgPos {
+  uint32_t bx, by, gx;
+};
+__device__ __forceinline__ bool wg_place(const EngineDev* __restrict__ tab, WgPos& w) {
+  const uint32_t gx = gridDim.x, R = gridDim.y;
+  w.bx = blockIdx.x;
+  w.by = blockIdx.y;
+  w.gx = gx;
+  if (R < 8u || gx < 2u || !tab[0].xcdPlace) return true;
+  const uint32_t L = blockIdx.x + gx * blockIdx.y, T = gx * R;
+  const uint32_t xcd = L & 7u, j = L >> 3;
+  const uint32_t blocksHere = (T - xcd + 7u) >> 3;    // blocks of this launch with L % 8 == xcd
+  const uint32_t enginesHere = (R - xcd + 7u) >> 3;   // engines xcd, xcd + 8, ...
+  uint32_t per = blocksHere / enginesHere;            // blocks each of them gets (>= 1: T >= 2 R)
+  if (per > gx) per = gx;                             // (never more than the launch's own width: per-block scratch is sized by it)
+  const uint32_t ei = j / per;
+  if (ei >= enginesHere) return false;                // a left-over block
+  w.by = xcd + 8u * ei;
+  w.bx = j - ei * per;
+  w.gx = per;
+  return true;
+}
+#define WG_ENGINE(tab)                                                               \
+  WgPos wgPos_;                                                                      \
+  if (!wg_place((tab), wgPos_)) return;                                              \
+  [[maybe_unused]] const uint32_t wgBx = wgPos_.bx, wgBy = wgPos_.by, wgGx = wgPos_.gx; \
+  const EngineDev& d = (tab)[wgBy];                                                  \
   if (d.halted) return
 
 // k_scan2 re-evaluates F::value(i); a functor whose value is expensive may take a `first` flag and reuse what the
@@ -328,15 +365,15 @@ __device__ __forceinline__ uint64_t scan_value_again(const F& f, uint32_t i, X..
 template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
-  const F f(d, atab ? atab + blockIdx.y : nullptr);
+  const F f(d, atab ? atab + wgBy : nullptr);
   unsigned long long WG_G* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
-  scan_range(n, lo, hi);
+  scan_range(n, wgBx, wgGx, lo, hi);
   uint64_t acc = 0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SCAN_BLOCK) acc += f.value(i);
   uint64_t tot = block_sum64(acc, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+  if (threadIdx.x == 0) partials[wgBx] = tot;
   f.tally(lo, hi);
 }
 
@@ -345,21 +382,21 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const EngineDev* __restric
 template <class F>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan2(const EngineDev* __restrict__ tab, const typename F::Aux* atab) {
   WG_ENGINE(tab);
-  const F f(d, atab ? atab + blockIdx.y : nullptr);
+  const F f(d, atab ? atab + wgBy : nullptr);
   const unsigned long long WG_G* partials = d.scanPartials;
   __shared__ uint64_t sh[SCAN_BLOCK / 64];
   __shared__ uint64_t shw[SCAN_BLOCK / 64];
   uint32_t n = f.count(), lo, hi;
-  scan_range(n, lo, hi);
+  scan_range(n, wgBx, wgGx, lo, hi);
   uint64_t before = 0, all = 0;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += SCAN_BLOCK) {
+  for (uint32_t b = threadIdx.x; b < wgGx; b += SCAN_BLOCK) {
     uint64_t p = partials[b];
     all += p;
-    if (b < blockIdx.x) before += p;
+    if (b < wgBx) before += p;
   }
   uint64_t prefix = block_sum64(before, sh);
   uint64_t total = block_sum64(all, sh);
-  if (blockIdx.x == 0 && threadIdx.x == 0) f.total(total);
+  if (wgBx == 0 && threadIdx.x == 0) f.total(total);
   int w = threadIdx.x >> 6;
   for (uint32_t base = lo; base < hi; base += SCAN_BLOCK) {
     uint32_t i = base + threadIdx.x;
@@ -553,8 +590,8 @@ struct ExpandF {
 __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
   const uint32_t nRuns = min(d.g->nRuns, d.maxRuns);
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t lane = WG_LANE;
   const ExpandF f(d, nullptr);
   for (uint32_t k = wave; k < nRuns; k += nWaves) {
@@ -647,8 +684,8 @@ template <bool PACK>
 __global__ void __launch_bounds__(256) k_shard_evres(const EngineDev* __restrict__ tab) {
   WG_ENGINE(tab);
   const uint32_t n = d.g->nEvents;
-  if (PACK && blockIdx.x == 0 && threadIdx.x == 0) d.g->nSnapEv = 0;  // (counted afresh by this ms's order scan)
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  if (PACK && wgBx == 0 && threadIdx.x == 0) d.g->nSnapEv = 0;  // (counted afresh by this ms's order scan)
+  for (uint32_t e = wgBx * blockDim.x + threadIdx.x; e < n; e += wgGx * blockDim.x) {
     if (PACK) {
       const EvRes r = d.evRes[e];
       if (!evres_packable(r)) set_err(d.g, ERR_SHARD_EVENT);
@@ -846,7 +883,7 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
   const uint32_t D = (uint32_t)d.horizon;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+  for (uint32_t p = wgBx * blockDim.x + threadIdx.x; p < n; p += wgGx * blockDim.x) {
     const uint32_t e = d.recEv[p];
     if (SH && !shard_owns(d, (int32_t)d.ev[e].w1)) {
       for (int k = 0; k < 5; k++) d.xbuf[(size_t)p * 5 + k] = 0;
@@ -1007,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_shard_unpack(const EngineDev* __restric
   const int32_t t = d.g->now;
   const uint32_t n = d.g->nOut;
   const uint32_t D = (uint32_t)d.horizon;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+  for (uint32_t p = wgBx * blockDim.x + threadIdx.x; p < n; p += wgGx * blockDim.x) {
     const int32_t* x = d.xbuf + (size_t)p * 5;
     Rec fin;
     fin.w0 = (uint32_t)x[0];
@@ -1057,7 +1094,7 @@ __global__ void __launch_bounds__(256) k_shard_multi_fill(const EngineDev* __res
   WG_ENGINE(tab);
   const uint32_t n = d.g->nOut;
   const MultiF f(d, nullptr);
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+  for (uint32_t p = wgBx * blockDim.x + threadIdx.x; p < n; p += wgGx * blockDim.x) {
     if (!f.fresh(p) || d.multiK[p] >= d.maxMulti) continue;
     const uint32_t e = d.recEv[p];
     if (!shard_owns(d, (int32_t)d.ev[e].w1)) continue;  // (the image is zero on entry)
@@ -1093,7 +1130,7 @@ __global__ void __launch_bounds__(256) k_shard_multi_create(const EngineDev* __r
   WG_ENGINE(tab);
   const uint32_t n = d.g->nOut;
   const MultiF f(d, nullptr);
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+  for (uint32_t p = wgBx * blockDim.x + threadIdx.x; p < n; p += wgGx * blockDim.x) {
     if (!f.fresh(p) || d.multiK[p] >= d.maxMulti) continue;
     const int32_t* x = d.xmulti + (size_t)d.multiK[p] * XM_WORDS;
     const Rec r = d.fin[p];
@@ -1177,7 +1214,7 @@ __global__ void __launch_bounds__(TILE) k_tile_hist(const EngineDev* __restrict_
   uint32_t n = d.g->nOutKeep + d.g->nOut;
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
-  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+  for (uint32_t tile = wgBx; tile < nTiles; tile += wgGx) {
     for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
     __syncthreads();
     uint32_t i = tile * TILE + threadIdx.x;
@@ -1266,7 +1303,7 @@ __global__ void __launch_bounds__(TILE) k_scatter(const EngineDev* __restrict__ 
   uint32_t nTiles = (n + TILE - 1) / TILE;
   uint32_t D = (uint32_t)d.horizon;
   if (d.g->err & (ERR_BUCKET_POOL | ERR_BUCKET_PAGES)) nTiles = 0;
-  for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+  for (uint32_t tile = wgBx; tile < nTiles; tile += wgGx) {
     for (uint32_t b = threadIdx.x; b < D; b += TILE) hist[b] = 0;
     __syncthreads();
     uint32_t i = tile * TILE + threadIdx.x;
@@ -1392,7 +1429,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_lat(const EngineDev* __restric
   // D: the histograms span the latencies the model can return (saBins <= horizon), not the whole bucket ring
   const uint32_t D = d.saBins, N = (uint32_t)d.nodes.n;
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
-  for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
+  for (uint32_t wi = wgBx; wi < nSA * nTiles; wi += wgGx) {  // work item = (descriptor, tile)
     const uint32_t k = wi / nTiles, tile = wi % nTiles;
     const SendAllDesc sd = d.saDesc[k];
     {
@@ -1428,7 +1465,7 @@ __global__ void __launch_bounds__(1024) k_sendall_scan(const EngineDev* __restri
   const uint32_t RING = (uint32_t)d.horizon;
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
   const int32_t t = d.g->now;
-  for (uint32_t k = blockIdx.x; k < nSA; k += gridDim.x) {
+  for (uint32_t k = wgBx; k < nSA; k += wgGx) {
     const SendAllDesc sd = d.saDesc[k];
     uint32_t* H = d.saHist + (size_t)k * nTiles * D;
     if (threadIdx.x == 0) {
@@ -1492,7 +1529,7 @@ __global__ void __launch_bounds__(TILE) k_sendall_scatter(const EngineDev* __res
   WG_DYN_LDS(uint32_t, hist);
   const uint32_t D = d.saBins, N = (uint32_t)d.nodes.n;  // latency bins (k_sendall_lat)
   const uint32_t nTiles = (N + TILE - 1) / TILE, nSA = min(d.g->nSendAll, d.maxSendAll);
-  for (uint32_t wi = blockIdx.x; wi < nSA * nTiles; wi += gridDim.x) {  // work item = (descriptor, tile)
+  for (uint32_t wi = wgBx; wi < nSA * nTiles; wi += wgGx) {  // work item = (descriptor, tile)
     const uint32_t k = wi / nTiles, tile = wi % nTiles;
     const SendAllDesc sd = d.saDesc[k];
     {
@@ -2056,12 +2093,12 @@ template <class P, int WPE>
 __global__ void __launch_bounds__(256, WPE) k_deliver(const EngineDev* __restrict__ tab,
                                                       const typename P::State* __restrict__ stab) {
   WG_ENGINE(tab);
-  const typename P::State& ps = stab[blockIdx.y];
+  const typename P::State& ps = stab[wgBy];
   __shared__ typename P::WaveShared shP[4];
   __shared__ uint32_t shSort[4][64];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nActive; a += nWaves) {
@@ -2099,11 +2136,11 @@ template <class P, int WPE, bool LISTB = false>
 __global__ void __launch_bounds__(256, WPE) k_deliver_inbox(const EngineDev* __restrict__ tab,
                                                             const typename P::State* __restrict__ stab) {
   WG_ENGINE(tab);
-  const typename P::State& ps = stab[blockIdx.y];
+  const typename P::State& ps = stab[wgBy];
   __shared__ typename P::WaveShared shP[4];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nActive = LISTB ? d.g->nActiveB : d.g->nActive;
   const uint32_t WG_G* nodes = LISTB ? (const uint32_t WG_G*)(VisitDesc WG_G*)d.activeB : (const uint32_t WG_G*)(uint32_t WG_G*)d.active;
   const int32_t t = d.g->now;

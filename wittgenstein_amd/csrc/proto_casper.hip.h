@@ -352,9 +352,9 @@ struct CasperProto {
 __device__ __forceinline__ bool casper_is_attestation(const Rec& r) { return rec_kind(r) == K_MSG && r.w2 == C_MSG_ATTESTATION; }
 __global__ void __launch_bounds__(256) k_casper_classify(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   const uint32_t n = d.g->nEvents;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  for (uint32_t e = wgBx * blockDim.x + threadIdx.x; e < n; e += wgGx * blockDim.x) {
     const Rec r = d.ev[e];
     if (casper_is_attestation(r)) continue;
     if (d.sharded) {  // (the event list is replicated: every shard sees that the table exchange is due; flags for its own nodes)
@@ -366,9 +366,9 @@ __global__ void __launch_bounds__(256) k_casper_classify(const EngineDev* __rest
 }
 __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   const uint32_t n = d.g->nEvents;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  for (uint32_t e = wgBx * blockDim.x + threadIdx.x; e < n; e += wgGx * blockDim.x) {
     const Rec r = d.ev[e];
     if (!casper_is_attestation(r)) continue;
     const int32_t to = (int32_t)r.w1, from = rec_from(r);
@@ -433,9 +433,9 @@ __global__ void __launch_bounds__(256) k_casper_attestations(const EngineDev* __
 // block arriving at the byzantine producer (node 1), whose onBlock builds on the spot when it is late (:671-673)
 __global__ void __launch_bounds__(256) k_casper_builds(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   const uint32_t n = d.g->nEvents;
-  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+  for (uint32_t e0 = (wgBx * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += wgGx * blockDim.x) {
     const uint32_t e = e0 + WG_LANE;
     bool b = false;
     if (e < n) {
@@ -485,10 +485,10 @@ __device__ __forceinline__ uint32_t casper_seq_event(const EngineDev& d, const C
 // tie's nextBoolean() in the rd sequence. Results, counters and records as k_deliver leaves them.
 __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   if (!*s.forked && *s.builds < 2u) return;  // one chain so far: no tie-break can be reached, k_deliver takes the mixed nodes in parallel
   const uint32_t n = d.g->nEvents;
-  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+  for (uint32_t e0 = (wgBx * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += wgGx * blockDim.x) {
     const uint32_t e = e0 + WG_LANE;
     bool mix = false;
     if (e < n) {
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256) k_casper_mark(const EngineDev* __restrict
 }
 __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   if (!*s.forked && *s.builds < 2u) {
     if (WG_LANE == 0) *s.builds = 0;
     return;
@@ -541,10 +541,10 @@ __global__ void __launch_bounds__(64) k_casper_seq(const EngineDev* __restrict__
 // draw nothing). Exact, and as slow as one wavefront and one small collective per change of owner are.
 __global__ void __launch_bounds__(256) k_casper_mark_shard(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   const uint32_t n = d.g->nEvents;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *s.seqPos = 0;
-  for (uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += gridDim.x * blockDim.x) {
+  if (wgBx == 0 && threadIdx.x == 0) *s.seqPos = 0;
+  for (uint32_t e0 = (wgBx * blockDim.x + threadIdx.x) & ~63u; e0 < n; e0 += wgGx * blockDim.x) {
     const uint32_t e = e0 + WG_LANE;
     bool tt = false, own = false;
     if (e < n) {
@@ -578,7 +578,7 @@ __device__ __forceinline__ uint32_t casper_next_bit(const uint64_t WG_G* bits, u
 __global__ void __launch_bounds__(64) k_casper_seq_shard(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab,
                                                          uint32_t cursor, uint32_t drawBase0) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   __shared__ CasperProto::WaveShared shP;
   const uint32_t n = d.g->nEvents;
   const int32_t t = d.g->now;
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(64) k_casper_seq_shard(const EngineDev* __rest
 // nodes created, on every shard; the image is left zeroed for the next ms
 __global__ void __launch_bounds__(256) k_casper_shard_apply(const EngineDev* __restrict__ tab, const CasperState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const CasperState& s = stab[blockIdx.y];
+  const CasperState& s = stab[wgBy];
   const int32_t t = d.g->now;
   const int32_t made = s.xtab[0], height = s.xtab[1], parent = s.xtab[2], producer = s.xtab[3], when = s.xtab[4];
   const bool mine = made == 1 && shard_owns(d, producer);

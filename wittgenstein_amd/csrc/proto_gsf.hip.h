@@ -477,11 +477,11 @@ struct GsfProto {
 // ---- conditional-task phase (C/Network.java:543-566 driving GSFNode.checkSigs :558-584) --------------
 __global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   const int32_t t = d.g->now, until = d.g->until;
   const uint32_t epoch = d.g->epoch;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
+  const uint32_t stride = wgGx * blockDim.x;
+  for (uint32_t n0 = (uint32_t)s.lo + wgBx * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     bool run = false;
     if (node < (uint32_t)s.hi) {
@@ -513,10 +513,10 @@ __global__ void __launch_bounds__(256) k_gsf_cond_pre(const EngineDev* __restric
 // take go to that kernel through runList2. Same statements, same order of the entries, same results.
 __global__ void __launch_bounds__(256) k_gsf_cond_a1g(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   const int lane = WG_LANE, g8 = lane & 7, gsh = lane & ~7;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nRun = *s.runCount;
   for (uint32_t qb = wave * 8; qb < nRun; qb += nWaves * 8) {
     const uint32_t q = qb + (uint32_t)(lane >> 3);
@@ -624,12 +624,12 @@ __global__ void __launch_bounds__(256) k_gsf_cond_a1g(const EngineDev* __restric
 // take the FIRST entry with the greatest score out of the list and park it in the pend table.
 __global__ void __launch_bounds__(256) k_gsf_cond_a1(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int second) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   __shared__ GLevels shLevels[4];
   __shared__ int32_t shNs[4][G_MAX_Q];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   // (second: the runners k_gsf_cond_a1g left — a list of more than eight entries, a PARTIAL entry of a multi-word level)
   const uint32_t nRun = second ? *s.runCount2 : *s.runCount;
   const uint32_t WG_G* runList = second ? (const uint32_t WG_G*)s.runList2 : (const uint32_t WG_G*)s.runList;
@@ -815,11 +815,11 @@ __device__ __forceinline__ bool gsf_split_ok(const EngineDev& d, int32_t node, u
 template <int WPE>
 __global__ void __launch_bounds__(256, WPE) k_gsf_docycle(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {  // (k_gsf_lane must follow)
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   __shared__ GLevels shL[4];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
   if (d.nparts) return;
@@ -880,10 +880,10 @@ __global__ void __launch_bounds__(256, WPE) k_gsf_docycle(const EngineDev* __res
 // level l's three scalars itself; first incomplete level, ranks of the sends and counts are 16-bit pieces of the ballots.
 __global__ void __launch_bounds__(256) k_gsf_docycle16(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   const int lane = WG_LANE, l16 = lane & 15, gsh = lane & ~15;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
   if (d.nparts) return;
@@ -996,13 +996,13 @@ __global__ void __launch_bounds__(256) k_gsf_docycle16(const EngineDev* __restri
 // wavefront) — that kernel then visits those and nothing else (k_deliver_inbox<.., LISTB>).
 __global__ void __launch_bounds__(256) k_gsf_lane(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab, int cycleRan, int listB) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   const uint32_t nActive = d.g->nActive;
   const int lane = WG_LANE;
   uint32_t WG_G* rest = (uint32_t WG_G*)(VisitDesc WG_G*)d.activeB;
   const bool lean = !(d.nparts || d.boundMsg);
   if (!lean && !listB) return;
-  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < nActive; a += gridDim.x * blockDim.x) {
+  for (uint32_t a = wgBx * blockDim.x + threadIdx.x; a < nActive; a += wgGx * blockDim.x) {
     const int32_t node = (int32_t)d.active[a];
     const uint32_t cnt = d.icnt[node];
     InboxEntry in[INBOX_SLOTS];
@@ -1186,16 +1186,16 @@ struct GsfCondF {
 template <bool SH>
 __global__ void __launch_bounds__(256) k_gsf_cond_a2(const EngineDev* __restrict__ tab, const GsfState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const GsfState& s = stab[blockIdx.y];
+  const GsfState& s = stab[wgBy];
   const uint32_t n = d.g->nOut;
   const int32_t t = d.g->now;
   const uint32_t D = (uint32_t)d.horizon;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the next edge's k_gsf_cond_pre / k_gsf_cond_a1g
+  const uint32_t stride = wgGx * blockDim.x;
+  if (wgBx == 0 && threadIdx.x == 0) {  // for the next edge's k_gsf_cond_pre / k_gsf_cond_a1g
     *s.runCount = 0;
     *s.runCount2 = 0;
   }
-  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+  for (uint32_t j0 = wgBx * blockDim.x; j0 < n; j0 += stride) {
     const uint32_t j = j0 + threadIdx.x;
     uint32_t histKey = 0xFFFFFFFFu;
     if (j < n) {

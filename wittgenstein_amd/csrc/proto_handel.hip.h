@@ -1361,10 +1361,10 @@ __device__ __forceinline__ void h_lane_store_header(uint32_t WG_G* hdr, const HL
 // 84 -> 81 us per launch at 31 copies, profiles/r22h_*)
 __global__ void __launch_bounds__(256, 3) k_handel_lane(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nActive = d.g->nActive;
   const int32_t t = d.g->now;
   U4 WG_G* work = (U4 WG_G*)(VisitDesc WG_G*)d.activeB;  // the wave-per-node kernel's list
@@ -1673,10 +1673,10 @@ __global__ void __launch_bounds__(256, 3) k_handel_lane(const EngineDev* __restr
 template <int WPE>
 __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nItems = *s.updCount;
   const int32_t t = d.g->now;
   if (wave >= nItems) return;
@@ -1904,14 +1904,14 @@ __global__ void __launch_bounds__(256, WPE) k_handel_update(const EngineDev* __r
 // h_lane_message as k_handel_lane; wide payloads become jobs of k_handel_copy, which runs next.
 __global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab, int behindDissem) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int lane = WG_LANE;
   // (behindDissem: the list of the nodes whose first event was their dissemination, launched behind k_handel_dissem)
   const U4 WG_G* items = behindDissem ? (const U4 WG_G*)s.itemsTrail2 : (const U4 WG_G*)s.itemsTrail;
   const uint32_t nItems = behindDissem ? *s.trail2Count : *s.trailCount;
   const int32_t t = d.g->now;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t a0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; a0 < nItems; a0 += stride) {
+  const uint32_t stride = wgGx * blockDim.x;
+  for (uint32_t a0 = (wgBx * blockDim.x + threadIdx.x) & ~63u; a0 < nItems; a0 += stride) {
     const uint32_t a = a0 + (uint32_t)lane;
     U4 it;
     it.x = it.y = it.z = 0;
@@ -1990,10 +1990,10 @@ __global__ void __launch_bounds__(256) k_handel_lane2(const EngineDev* __restric
 // one round after the other — the copies were that kernel's longest dependent chain.)
 __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   // the small payloads (<= H_JOB_SMALL words: levels of up to 4096 ids — most of the jobs): EIGHT LANES per job, two words a
   // lane and round, eight jobs per wavefront. (One wavefront per job left most of its lanes idle for them, and the kernel's
   // duration is jobs / resident wavefronts x a round trip.)
@@ -2045,11 +2045,11 @@ __global__ void __launch_bounds__(256) k_handel_copy(const EngineDev* __restrict
 template <int WPE>
 __global__ void __launch_bounds__(256, WPE) k_handel_dissem(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   __shared__ LevelScalars shP[4];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nItems = *s.disCount;
   const int32_t t = d.g->now;
   for (uint32_t a = wave; a < nItems; a += nWaves) {
@@ -2090,12 +2090,12 @@ template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_wave(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab,
                                                           int disSkipped) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   typedef HandelProtoT<ATK> HP;
   __shared__ LevelScalars shP[4];
   const int lane = WG_LANE, w = threadIdx.x >> 6;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   // (the host did not launch k_handel_dissem for this ms — no member's dissemination task has this phase: its list must be empty)
   if (disSkipped && wave == 0 && lane == 0 && *s.disCount != 0) set_err(d.g, ERR_PROTOCOL);
   const uint32_t nWork = d.g->nActiveB;
@@ -2238,13 +2238,13 @@ __device__ __forceinline__ long long h_pick_cached(const HandelState& s, int32_t
 __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __restrict__ tab,
                                                          const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int32_t t = d.g->now, until = d.g->until;
   const uint32_t epoch = d.g->epoch;
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t stride = wgGx * blockDim.x;
   const int lane = WG_LANE;
   __shared__ uint32_t shTot[2][4], shBase[2];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the delivery pass's copy jobs and wide updates have been done)
+  if (wgBx == 0 && threadIdx.x == 0) {  // (the delivery pass's copy jobs and wide updates have been done)
     *s.jobCount = 0;
     *s.jobSmallCount = 0;
     *s.updCount = 0;
@@ -2252,7 +2252,7 @@ __global__ void __launch_bounds__(256) k_handel_cond_pre(const EngineDev* __rest
     *s.trailCount = 0;
     *s.trail2Count = 0;
   }
-  for (uint32_t n0 = (uint32_t)s.lo + blockIdx.x * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
+  for (uint32_t n0 = (uint32_t)s.lo + wgBx * blockDim.x; n0 < (uint32_t)s.hi; n0 += stride) {
     const uint32_t node = n0 + threadIdx.x;
     // nextMessage(): drop from the private copy if minStartTime > until or the node is down; evaluate
     // at most once per call (epoch); evaluate only when minStartTime <= time.
@@ -2835,19 +2835,19 @@ __device__ __forceinline__ void h_a1_wave_items(const EngineDev& d, const Handel
 template <int WPE, bool ATK>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1w(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  h_a1_wave_items<ATK>(d, stab[blockIdx.y], blockIdx.x, gridDim.x);
+  h_a1_wave_items<ATK>(d, stab[wgBy], wgBx, wgGx);
 }
 // both in ONE launch: the first half of the blocks the narrow levels' items (groups of eight lanes), the others the wave
 // items — the two kinds of chains in flight together, at the group half's register count
 template <int WPE>
 __global__ void __launch_bounds__(256, WPE) k_handel_a1c(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
-  const uint32_t laneBlocks = gridDim.x >= 4 ? gridDim.x / 2u : 1;
-  if (blockIdx.x < laneBlocks)
-    h_a1_group_items(d, s, blockIdx.x, laneBlocks);
+  const HandelState& s = stab[wgBy];
+  const uint32_t laneBlocks = wgGx >= 4 ? wgGx / 2u : 1;
+  if (wgBx < laneBlocks)
+    h_a1_group_items(d, s, wgBx, laneBlocks);
   else
-    h_a1_wave_items<false>(d, s, blockIdx.x - laneBlocks, gridDim.x - laneBlocks);
+    h_a1_wave_items<false>(d, s, wgBx - laneBlocks, wgGx - laneBlocks);
 }
 
 // scan over nodes: ordinal of each node that draws (checkSigs draws iff some level has a candidate),
@@ -2861,9 +2861,9 @@ __device__ __forceinline__ int32_t h_cand_count(const HandelState& s, uint32_t i
 // sharded: the owners' counts into the exchange image (zeros for the nodes of other shards)
 __global__ void __launch_bounds__(256) k_handel_cand_pack(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const uint32_t nw = ((uint32_t)s.N + 3u) >> 2;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += gridDim.x * blockDim.x) {
+  for (uint32_t j = wgBx * blockDim.x + threadIdx.x; j < nw; j += wgGx * blockDim.x) {
     uint32_t w = 0;
     for (uint32_t q = 0; q < 4; q++) {
       const uint32_t i = 4 * j + q;
@@ -2906,10 +2906,10 @@ struct CondF {
 // drawing node; k_handel_cond_a2 then reads the level's candidate as this kernel left it.
 __global__ void __launch_bounds__(256) k_handel_hidden(const EngineDev* __restrict__ tab, const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const int lane = WG_LANE;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t n = d.g->nOut;
   if (d.g->rejectSeen) {  // (the draws are re-walked by k_handel_cond_a2 only: p < 2^-30 per draw)
     if (wave == 0 && lane == 0 && n) set_err(d.g, ERR_PROTOCOL);
@@ -3018,14 +3018,14 @@ template <bool SH, bool ATK>
 __global__ void __launch_bounds__(256) k_handel_cond_a2(const EngineDev* __restrict__ tab,
                                                         const HandelState* __restrict__ stab) {
   WG_ENGINE(tab);
-  const HandelState& s = stab[blockIdx.y];
+  const HandelState& s = stab[wgBy];
   const uint32_t n = d.g->nOut;
   const int32_t t = d.g->now;
   const bool rejected = d.g->rejectSeen != 0;
   const uint32_t D = (uint32_t)d.horizon;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && threadIdx.x < 2) s.itemCount[threadIdx.x] = 0;  // for the next edge's k_handel_cond_pre
-  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+  const uint32_t stride = wgGx * blockDim.x;
+  if (wgBx == 0 && threadIdx.x < 2) s.itemCount[threadIdx.x] = 0;  // for the next edge's k_handel_cond_pre
+  for (uint32_t j0 = wgBx * blockDim.x; j0 < n; j0 += stride) {
     const uint32_t j = j0 + threadIdx.x;
     uint32_t histKey = 0xFFFFFFFFu;
     if (j < n) {
@@ -3518,8 +3518,8 @@ struct SnapF {
 template <class S, uint32_t TASK, bool PACK>
 __global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict__ tab, const S* __restrict__ stab) {
   WG_ENGINE(tab);
-  const S& s = stab[blockIdx.y];
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  const S& s = stab[wgBy];
+  const uint32_t wave = (wgBx * blockDim.x + threadIdx.x) >> 6, nWaves = (wgGx * blockDim.x) >> 6;
   const uint32_t nEv = d.g->nEvents;
   const uint32_t win = ((uint32_t)d.g->now / (uint32_t)snap_period(s)) % s.snapNb;
   const uint64_t cap = (uint64_t)s.xsnapRows * s.snapStride;
