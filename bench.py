@@ -218,6 +218,13 @@ def pmc_traffic(name, n, R, avg_launch_ns, step_s=None):
     tj = json.load(open(tpath))
     if tj.get("replicas") != R or tj.get("nodes") != n:
         return None, "profiles/%s is of %s copies of %s nodes: not this line's workload" % (name, tj.get("replicas"), tj.get("nodes")), None, None
+    # the counters must be of THIS code: traffic_from_pmc.py stamps a hash of wittgenstein_amd/csrc/* (a file without the stamp
+    # is of an earlier round's code by definition)
+    from wittgenstein_amd.replicas import csrc_hash
+    have, mine = tj.get("csrc_sha"), csrc_hash()
+    if have != mine:
+        return None, "stale: profiles/%s was taken on csrc %s (commit %s), this tree is csrc %s — run tools/gpu_final_round.sh" % (
+            name, have or "unstamped", tj.get("commit", "unknown"), mine), None, None
     src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload's `bench.py --steps 1`, commit %s%s" % (
         name, tj.get("commit", "unknown"), " (this session)" if os.environ.get("WG_TRAFFIC_SESSION") else "")
     lr = None
@@ -573,7 +580,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
-    ap.add_argument("--replicas", type=int, default=31, help="independent simulations per step and per GPU (lowered to what fits the free HBM). "
+    ap.add_argument("--replicas", type=int, default=32, help="independent simulations per step and per GPU (lowered to what fits the free HBM). "
                     "31 copies of config 3 (9.19 GB each with their init() image) since round 5: 32 fit too and are SLOWER — 546 against "
                     "565 M msgs/s, and as slow with smaller copies at 90 %% of the HBM: the lane-per-node kernels take 17 %% longer "
                     "for 3 %% more nodes (profiles/r20u_*, r23b_copies_31_vs_32.txt)")
@@ -921,7 +928,7 @@ def main():
         # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 24 copies that fit the HBM — it takes 256
         # (64 / 96 / 128 / 192 / 256 / 320 / 360 copies: 349.5 / 393.9 / 439.9 / 476.8 / 502.4 / 507.0 / 509.4 M msgs/s,
         # profiles/r18a_gsf_copies_sweep.txt: the step is ~ 63 ms + 1.44 ms per copy)
-        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 256)):
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 512)):
             if n == nn and args.workload == wl:
                 continue
             try:

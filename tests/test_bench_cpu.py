@@ -23,12 +23,14 @@ def test_plan_replicas_degrades_and_never_fails():
     assert replicas.plan_replicas(16, 288 * GB, 18 * GB) == 15
     assert replicas.plan_replicas(16, 288 * GB, 400 * GB) == 1          # does not fit at all: still one copy, no error
     assert replicas.plan_replicas(4, 0, 0) == 4                         # nothing measured: the request stands
-    # Handel's init() holds nodeCount^2 rank matrices only while it runs (at most 16 GiB of them at a time): the batch leaves that
-    # beside the copies — 31 copies of config 3 still fit, 8 of the 65 536-node target size do not (round 5: they ran out of memory)
+    # Handel's init() holds nodeCount^2 rank matrices only while it runs (at most two and at most 8 GiB of them at a time, one
+    # alone may be larger): the batch leaves that beside the copies — 32 copies of config 3 fit (round 6: 4 per XCD), 8 of the
+    # 65 536-node target size do not (round 5: they ran out of memory)
     GiB = 1 << 30
-    assert replicas.handel_init_transient_bytes(32768) == 16 * GiB == replicas.handel_init_transient_bytes(65536)
-    assert replicas.handel_init_transient_bytes(4096) == 4 * 4 * 4096 * 4096 and replicas.handel_init_transient_bytes(131072) == 0
-    assert replicas.plan_replicas(32, 287 * GiB, int(8.56 * GiB), transient_bytes=16 * GiB) == 31
+    assert replicas.handel_init_transient_bytes(32768) == 8 * GiB and replicas.handel_init_transient_bytes(65536) == 16 * GiB
+    assert replicas.handel_init_transient_bytes(4096) == 2 * 4 * 4096 * 4096 and replicas.handel_init_transient_bytes(131072) == 0
+    assert replicas.plan_replicas(32, 288 * GiB, int(8.56 * GiB), transient_bytes=8 * GiB) == 32
+    assert replicas.plan_replicas(33, 288 * GiB, int(8.56 * GiB), transient_bytes=8 * GiB) == 32
     assert replicas.plan_replicas(8, 287 * GiB, 35 * GiB, transient_bytes=16 * GiB) == 7
     # the number of steps plays no part (round 1: `fit // K` turned --steps 20 into rc=1)
     with pytest.raises(ValueError):
@@ -94,6 +96,18 @@ def test_traffic_json_from_the_three_pmc_passes(tmp_path, monkeypatch):
     assert abs(lr["requests_per_s"] - tj["ea_requests_per_launch"] / 250e-6) < 1.0 and abs(lr["frac"] - lr["requests_per_s"] / bench.LINE_RATE_CEILING) < 1e-12
     assert abs(lr["whole_step"]["requests_per_s"] - tj["whole_step_ea_requests"] / 0.8) < 1.0
     assert bench.pmc_traffic("traffic.json", 32768, 24, 250000.0)[0] is None    # another copy count: no traffic claimed
+    # counters of OTHER code are never this code's traffic: the file carries a hash of wittgenstein_amd/csrc/* and bench.py
+    # compares it with the tree it runs from (a file without the stamp is stale by definition)
+    assert tj["csrc_sha"] == replicas.csrc_hash()
+    for bad in ("0" * 16, None):
+        stale = dict(tj)
+        if bad is None:
+            del stale["csrc_sha"]
+        else:
+            stale["csrc_sha"] = bad
+        json.dump(stale, open(tmp_path / "profiles" / "traffic.json", "w"))
+        t2, src2, lr2, _ = bench.pmc_traffic("traffic.json", 32768, 31, avg_launch_ns=250000.0, step_s=0.8)
+        assert t2 is None and lr2 is None and src2.startswith("stale: ") and replicas.csrc_hash() in src2
     assert bench.pmc_traffic("traffic_gsf.json", 4096, 256, 1.0) == (None, None, None, None)  # no file
 
 

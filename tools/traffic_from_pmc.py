@@ -85,7 +85,9 @@ def main():
                "per_kernel_requests": rq,
                "requests_note": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum in one further pass: requests "
                                 "the L2 sent to the memory side (EA) and requests the L2 received, per delivery pass / per step"}
-    json.dump({**req, "nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"),
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from wittgenstein_amd.replicas import csrc_hash  # (the sources these counters were taken on: bench.py compares it with its own tree)
+    json.dump({**req, "nodes": nodes, "replicas": replicas, "commit": os.environ.get("WG_COMMIT", "unknown"), "csrc_sha": csrc_hash(),
                "kernels": " + ".join(kernels) + " (one launch of each per simulated ms that is not skipped)",
                "fetch_bytes_per_launch_raw": rd, "write_bytes_per_launch_raw": wr,
                "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_launch_reads_doubled": 2.0 * rd + wr,

@@ -2506,9 +2506,12 @@ struct TmpMatrix {
     static size_t n = 0;
     return n;
   }
-  // at most four at a time and at most IN_FLIGHT_BYTES between them (one alone may be larger): what a host that sizes a
-  // batch of copies to the free HBM has to leave for init() (wittgenstein_amd/replicas.py::handel_init_transient_bytes)
-  static constexpr size_t IN_FLIGHT_BYTES = 4ull * 4ull * 32768ull * 32768ull;
+  // at most two at a time and at most IN_FLIGHT_BYTES between them (one alone may be larger): what a host that sizes a
+  // batch of copies to the free HBM has to leave for init() (wittgenstein_amd/replicas.py::handel_init_transient_bytes).
+  // (Four / 16 GiB until round 6: two are what lets the 32nd copy of the default bench line fit — with an engine pinned to
+  // one XCD, engine_kernels.hip.h wg_place, a batch's step time goes by ceil(copies / 8) — for 3 s more of init().)
+  static constexpr int IN_FLIGHT_MAX = 2;
+  static constexpr size_t IN_FLIGHT_BYTES = 2ull * 4ull * 32768ull * 32768ull;
   static std::map<int32_t*, size_t>& sizes() {
     static std::map<int32_t*, size_t> m;
     return m;
@@ -2516,7 +2519,7 @@ struct TmpMatrix {
   static int32_t* acquire(size_t bytes) {
     std::unique_lock<std::mutex> lk(mu());
     for (;;) {
-      cv().wait(lk, [bytes] { return inFlight() == 0 || (inFlight() < 4 && inFlightBytes() + bytes <= IN_FLIGHT_BYTES); });
+      cv().wait(lk, [bytes] { return inFlight() == 0 || (inFlight() < IN_FLIGHT_MAX && inFlightBytes() + bytes <= IN_FLIGHT_BYTES); });
       int32_t* p = nullptr;
       if (hipMalloc((void**)&p, bytes) == hipSuccess) {
         inFlight()++;

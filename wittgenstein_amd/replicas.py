@@ -37,12 +37,12 @@ def rank_seeds(rank, world, replicas):
 def handel_init_transient_bytes(nodes):
     """device bytes Handel's init() holds only while it runs, over ALL the copies being initialised at once: with the
     reception ranks carried by the senders (unsharded, 256 .. 65 536 nodes, csrc/engine.hip HandelHost) the nodeCount^2
-    int32 rank matrix lives for the length of init() only, and the library admits at most four of them and at most
-    16 GiB between them (one alone may be larger) at a time — TmpMatrix there."""
+    int32 rank matrix lives for the length of init() only, and the library admits at most two of them and at most
+    8 GiB between them (one alone may be larger) at a time — TmpMatrix there."""
     if nodes < 256 or nodes > 65536:
         return 0
     one = 4 * nodes * nodes
-    return min(4 * one, max(one, 4 * 4 * 32768 * 32768))
+    return min(2 * one, max(one, 2 * 4 * 32768 * 32768))
 
 
 def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955, transient_bytes=0):
@@ -84,3 +84,19 @@ def union_ns(intervals):
     if cur_b is not None:
         total += cur_b - cur_a
     return total
+
+
+def csrc_hash(root=None):
+    """sha256 over the product's kernel sources (wittgenstein_amd/csrc/*, names and contents, sorted): what
+    tools/traffic_from_pmc.py stamps into profiles/traffic*.json and bench.py compares with the tree it runs from, so that
+    PMC figures of OTHER code are never published as this code's `roofline.traffic`."""
+    import hashlib
+    import os
+    d = os.path.join(root or os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        p = os.path.join(d, name)
+        if os.path.isfile(p):
+            h.update(name.encode() + b"\0")
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
