@@ -122,7 +122,7 @@ struct Chain {  // 32 bytes
   uint32_t destOff;   // into the dest ring; explicit arrivals (WithDelay envelopes) follow at destOff+ndest
   uint32_t msg;
   uint32_t payload;
-  uint32_t flags;     // bit0: busy, bit1: explicit arrivals (MultipleDestWithDelayEnvelope :157-228)
+  uint32_t flags;     // bit0: busy, bit1: explicit arrivals (MultipleDestWithDelayEnvelope :157-228), bit2 (CHAIN_LAT): destination words are id | latency << 16
 };
 
 enum OutKind : uint32_t { O_SEND = 0, O_MULTI = 1, O_TASK = 2, O_PERIODIC = 3, O_CHAINCONT = 4, O_SENDALL = 5 };

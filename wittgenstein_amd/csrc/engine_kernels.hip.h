@@ -242,11 +242,20 @@ __device__ __forceinline__ int32_t dev_latency(const EngineDev& d, int32_t from,
 
 // arrival of the j-th destination of a chain (MultipleDestEnvelope.arrivalTime C/Envelope.java:107-113,
 // MultipleDestWithDelayEnvelope.nextArrivalTime :186-188)
-__device__ __forceinline__ int32_t chain_dest_word(const EngineDev& d, const Chain& c, int j) {  // (id | tag << 16: EngineDev::destTagged)
-  return d.dests[ring_at(c.destOff, (unsigned long long)j, d.chainDests)];
+// An envelope created by k_resolve keeps each destination's LATENCY in the upper half of its destination word
+// (Chain::flags & CHAIN_LAT: id | latency << 16 — engines of <= 65 536 nodes whose destination words carry no protocol tag):
+// arrival j = sendTime + latency j is what MultipleDestEnvelope.nextArrivalTime recomputes at every hop (C/Envelope.java:
+// 107-113) from both ends' positions and the jitter table — four dependent scattered loads per hop, three times per hop
+// (the expand scan's run length, its write, the re-push's arrival in k_resolve), which was 136 bytes fetched per delivered
+// message in GSFSignature's k_scan1<ExpandF>. The value stored is the one createMessageArrivals sorted by (:449-467).
+constexpr uint32_t CHAIN_LAT = 4u;
+__device__ __forceinline__ int32_t chain_dest_word(const EngineDev& d, const Chain& c, int j) {  // (id | tag << 16: EngineDev::destTagged; the id alone otherwise)
+  const int32_t w = d.dests[ring_at(c.destOff, (unsigned long long)j, d.chainDests)];
+  return (c.flags & CHAIN_LAT) ? (int32_t)((uint32_t)w & 0xFFFFu) : w;
 }
 __device__ __forceinline__ int32_t chain_dest(const EngineDev& d, const Chain& c, int j) { return dest_id(d, chain_dest_word(d, c, j)); }
 __device__ __forceinline__ int32_t chain_arrival(const EngineDev& d, const Chain& c, int j) {
+  if (c.flags & CHAIN_LAT) return c.sendTime + (int32_t)((uint32_t)d.dests[ring_at(c.destOff, (unsigned long long)j, d.chainDests)] >> 16);
   if (c.flags & 2u) return d.dests[ring_at(c.destOff, (unsigned long long)c.ndest + j, d.chainDests)];
   return c.sendTime + dev_latency(d, c.from, chain_dest(d, c, j), c.seed);
 }
@@ -765,7 +774,7 @@ __device__ __forceinline__ int resolve_multi(const EngineDev& d, const Out& o, i
 // the same entries of the two rings at the end; longer lists take the in-place form above.
 constexpr int MULTI_LDS = 10;  // (20 KB a block: eight blocks a CU still fit)
 __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& o, int32_t from, int32_t seed, int32_t* shDst,
-                                                 int32_t* shArv) {
+                                                 int32_t* shArv, bool packLat) {
   const int nd = o.to, T = (int)blockDim.x, t = (int)threadIdx.x;
   const int32_t step = (o.pad & OUT_DELAYED) ? (int32_t)(o.pad >> 8) + 1 : 0;
   // The list's arrivals in three ROUNDS of independent loads — every destination, then every destination's flags and
@@ -813,9 +822,11 @@ __device__ __forceinline__ int resolve_multi_lds(const EngineDev& d, const Out& 
     shArv[k * T + t] = a;
     shDst[k * T + t] = to;
   }
+  // (packLat: the envelope's destination words keep the latency beside the id — CHAIN_LAT; one destination is a plain send)
   for (int k = 0; k < m; k++) {
-    d.sdests[multi_idx(d, o, k)] = shDst[k * T + t];
-    d.arvTmp[multi_idx(d, o, k)] = shArv[k * T + t];
+    const int32_t a = shArv[k * T + t];
+    d.sdests[multi_idx(d, o, k)] = packLat && m > 1 ? (int32_t)((uint32_t)shDst[k * T + t] | ((uint32_t)(a - o.t) << 16)) : shDst[k * T + t];
+    d.arvTmp[multi_idx(d, o, k)] = a;
   }
   return m;
 }
@@ -906,8 +917,11 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
         if (o.pad & OUT_SHUFFLE) drawIdx += shuffle_dests(d, o, drawIdx);  // Collections.shuffle(dests, rd) first
         int32_t seed = draw_next_int(d, drawIdx);
         int32_t first = 0;
+        // (latencies beside the ids: undelayed envelopes of an untagged engine whose ids and latencies fit 16 bits each —
+        // a latency is < discardTime and < horizon, or the send is dropped / refused below)
+        const bool packLat = !SH && !d.destTagged && !(o.pad & OUT_DELAYED) && d.nodes.n <= 65536 && d.horizon <= 65536;
         const int m = SH ? count_multi(d, o, from, seed, first)
-                         : (o.to <= MULTI_LDS ? resolve_multi_lds(d, o, from, seed, &shMulti[0][0][0], &shMulti[1][0][0])
+                         : (o.to <= MULTI_LDS ? resolve_multi_lds(d, o, from, seed, &shMulti[0][0][0], &shMulti[1][0][0], packLat)
                                               : resolve_multi(d, o, from, seed));
         if (m == 1 && !SH) {
           const int32_t tw = d.sdests[multi_idx(d, o, 0)];
@@ -940,6 +954,18 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           // (unsharded: sdests IS the chain ring — the sorted destinations are where the envelope reads them)
           if (o.pad & OUT_DELAYED)  // explicit arrivals follow the destinations (the action reserved 2 n entries)
             for (int j = 0; j < m; j++) d.dests[ring_at(o.destOff, (unsigned long long)(m + j), d.chainDests)] = d.arvTmp[multi_idx(d, o, j)];
+          arrival = d.arvTmp[multi_idx(d, o, 0)];
+          bool lat = packLat && d.arvTmp[multi_idx(d, o, m - 1)] - o.t < 65536;  // (sorted: the last is the largest)
+          if (lat && o.to > MULTI_LDS)  // (the in-place sort left plain ids: the latencies go beside them now)
+            for (int j = 0; j < m; j++) {
+              const unsigned long long at = multi_idx(d, o, j);
+              d.sdests[at] = (int32_t)((uint32_t)d.sdests[at] | ((uint32_t)(d.arvTmp[at] - o.t) << 16));
+            }
+          if (packLat && !lat && o.to <= MULTI_LDS)  // (never in practice — a latency of 65 536 ms —: back to plain ids)
+            for (int j = 0; j < m; j++) {
+              const unsigned long long at = multi_idx(d, o, j);
+              d.sdests[at] = (int32_t)((uint32_t)d.sdests[at] & 0xFFFFu);
+            }
           Chain c;
           c.from = from;
           c.seed = seed;
@@ -948,10 +974,9 @@ __global__ void __launch_bounds__(256) k_resolve(const EngineDev* __restrict__ t
           c.destOff = o.destOff;
           c.msg = o.a;
           c.payload = o.b;
-          c.flags = 1u | ((o.pad & OUT_DELAYED) ? 2u : 0u);
+          c.flags = 1u | ((o.pad & OUT_DELAYED) ? 2u : 0u) | (lat ? CHAIN_LAT : 0u);
           d.chains[slot] = c;
           fin = make_rec(K_CHAIN, from, slot, 0, 0);
-          arrival = d.arvTmp[multi_idx(d, o, 0)];
         }
         break;
       }
