@@ -501,7 +501,9 @@ struct ExpandF {
   // threads the few that fall to a node k_deliver visits after all (a node with another kind of event in the same ms).
   __device__ bool lane_only(uint32_t msgWord) const { return d.laneMsgPlus1 != 0 && msgWord + 1u == d.laneMsgPlus1; }
   // thread the event onto its node's inbox list; returns true if it is the node's first event
-  __device__ bool link(uint32_t e, int32_t to, const Rec& r, bool chainHop, uint32_t ob) const {
+  // `inLine`: the event's record went into the node's inbox line (nothing will look for it in ev[])
+  __device__ bool link(uint32_t e, int32_t to, const Rec& r, bool chainHop, uint32_t ob, bool& inLine) const {
+    inLine = false;
     if (d.sharded) {  // the event list is replicated on every shard; a shard applies the events of its own nodes
       d.evRes[e] = EvRes{0u, 0u};  // ... and reports zeros for the others (summed across shards before `order`)
       if (!shard_owns(d, to)) return false;
@@ -509,6 +511,7 @@ struct ExpandF {
     if (d.inbox) {  // the node's inbox line: the event itself lands in the node's 64 bytes, no list to chase at delivery
       const uint32_t k = atomicAdd(&d.icnt[to], 1u);
       if (k < (uint32_t)INBOX_SLOTS) {
+        inLine = true;
         // (a task's `from` is the node itself: its w0 carries the event's first outbox slot instead, so that a visit
         // needs no EvAux read for it; a message's action() gets its slice from EvAux only when boundMsg > 0 or it is a hop)
         InboxEntry ie;
@@ -535,14 +538,22 @@ struct ExpandF {
       const uint32_t k = rec_kind(r);
       if (k != K_CHAIN) {
         if (e < d.maxEvents) {
-          d.ev[e] = r;
-          EvAux a;
-          a.chain = -1;
-          a.cpos = 0;
-          a.outBase = ob;
-          a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
-          d.evAux[e] = a;
-          if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1, r, false, ob);
+          bool inLine = false;
+          if (!d.hostMode && !(k == K_MSG && lane_only(r.w2))) first = link(e, (int32_t)r.w1, r, false, ob, inLine);
+          // The event's 16-byte record + its 16 bytes of side data are what a visit reads when it walks a LIST. An event in its
+          // node's inbox line is read from the line; what is still looked up by event index is the outbox slice of an event
+          // that can emit records (k_resolve: a task's; a message's where the protocol's action() sends, boundMsg > 0) and, on
+          // a sharded engine, the receiver (k_resolve<true>, the snapshot scans). A plain message in a line of an unsharded
+          // engine whose deliveries emit nothing — nine events in ten of Handel and GSFSignature — writes neither.
+          if (!(inLine && k == K_MSG && d.boundMsg == 0 && !d.sharded)) {
+            d.ev[e] = r;
+            EvAux a;
+            a.chain = -1;
+            a.cpos = 0;
+            a.outBase = ob;
+            a.outCap = k == K_MSG ? d.boundMsg : task_bound(r);
+            d.evAux[e] = a;
+          }
           firstNode = (int32_t)r.w1;
         }
       } else {
@@ -567,15 +578,16 @@ struct ExpandF {
           if (e >= d.maxEvents) break;
           const int32_t tw = chain_dest_word(d, c, (int)r.w2 + (int)q), to = dest_id(d, tw);
           const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, dest_msg(d, c.msg, tw), c.payload);
-          d.ev[e] = hop;
           const bool last = q + 1 == len;
           EvAux a;
           a.chain = (int32_t)r.w1;
           a.cpos = (int32_t)(r.w2 + q) | (last ? (int32_t)0x80000000 : 0);
           a.outBase = ob + q * d.boundMsg;
           a.outCap = d.boundMsg + (last ? 1u : 0u);
-          d.evAux[e] = a;
-          if (!d.hostMode && !lane_only(c.msg) && link(e, to, hop, true, ob + q * d.boundMsg)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+          d.evAux[e] = a;  // (a hop's side data is read by its visit: the envelope, its position, the re-push's slot)
+          bool inLine = false;
+          if (!d.hostMode && !lane_only(c.msg) && link(e, to, hop, true, ob + q * d.boundMsg, inLine)) d.active[atomicAdd(&d.g->nActive, 1u)] = (uint32_t)to;  // chains are rare
+          if (!inLine || d.sharded) d.ev[e] = hop;
         }
         // sharded: the envelope's slot is released by every shard (deliver_event's release runs on one shard only)
         if (d.sharded && (int)(r.w2 + len) >= c.ndest) d.chains[r.w1].flags = 0;
@@ -614,7 +626,6 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         const int32_t tw = chain_dest_word(d, c, (int)(rd.pos + q));
         to = dest_id(d, tw);
         const Rec hop = make_rec(K_MSG, c.from, (uint32_t)to, dest_msg(d, c.msg, tw), c.payload);
-        d.ev[e] = hop;
         const bool last = q + 1 == rd.len;
         EvAux a;
         a.chain = (int32_t)rd.chain;
@@ -622,7 +633,9 @@ __global__ void __launch_bounds__(256) k_expand_runs(const EngineDev* __restrict
         a.outBase = rd.ob + q * d.boundMsg;
         a.outCap = d.boundMsg + (last ? 1u : 0u);
         d.evAux[e] = a;
-        if (!d.hostMode && !f.lane_only(c.msg)) first = f.link(e, to, hop, true, rd.ob + q * d.boundMsg);
+        bool inLine = false;
+        if (!d.hostMode && !f.lane_only(c.msg)) first = f.link(e, to, hop, true, rd.ob + q * d.boundMsg, inLine);
+        if (!inLine || d.sharded) d.ev[e] = hop;  // (as ExpandF::write: an event in its node's line is read from the line)
       }
       const uint64_t m = __ballot(first);
       if (m) {
@@ -2069,6 +2082,7 @@ __device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const ty
       if (lane == 0) set_err(d.g, ERR_PROTOCOL);
       return;
     }
+    // (the line's four come from the line — expand wrote no event record for them —, the others from the event arrays)
     const uint32_t l0 = lane_bcast(mine.e, 0), l1 = lane_bcast(mine.e, 1), l2 = lane_bcast(mine.e, 2), l3 = lane_bcast(mine.e, 3);
     const int32_t listHead = d.head[node];
     __builtin_amdgcn_wave_barrier();
@@ -2088,8 +2102,28 @@ __device__ __forceinline__ void deliver_visit_inbox(const EngineDev& d, const ty
       if (best == 0xFFFFFFFFu) break;
       last = best;
       have = true;
-      const Rec rec = d.ev[best];
-      const EvAux aux = d.evAux[best];
+      Rec rec;
+      EvAux aux;
+      const int src = best == l0 ? 0 : best == l1 ? 1 : best == l2 ? 2 : best == l3 ? 3 : -1;
+      if (src >= 0) {  // (as the branch above builds an event from its line entry)
+        const uint32_t w0 = lane_bcast(mine.w0, src), w2 = lane_bcast(mine.w2, src), w3 = lane_bcast(mine.w3, src);
+        const uint32_t kind = (w0 >> 28) & 3u;
+        aux.chain = -1;
+        aux.cpos = 0;
+        if (kind == K_MSG) {
+          rec = make_rec(K_MSG, (int32_t)(w0 & 0x0FFFFFFFu), (uint32_t)node, w2, w3);
+          aux.outBase = 0;
+          aux.outCap = 0;
+          if ((w0 & INBOX_CHAIN) || d.boundMsg) aux = gld(d.evAux + best);
+        } else {
+          rec = make_rec(kind, node, (uint32_t)node, w2, w3);
+          aux.outBase = w0 & 0x0FFFFFFFu;
+          aux.outCap = d.boundTask[w2 < 3u ? w2 : 3u] + (kind == K_PERIODIC ? 1u : 0u);
+        }
+      } else {
+        rec = d.ev[best];
+        aux = d.evAux[best];
+      }
       deliver_event<P>(d, ps, c, r, best, rec, aux, toDown, toPart, true, nRecv, bRecv);
     }
   }
