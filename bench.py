@@ -203,7 +203,13 @@ def cpu_baseline(n_sample, workload="handel", budget_s=25.0, all_cores=True):
     return out
 
 
-LINE_RATE_CEILING = 21.0e9  # scattered 64-byte reads/s the chip sustains: tools/micro/mlp_probe, profiles/archive/r03b_micro_mlp_probe.txt
+# Memory-side (EA) requests per second the chip sustains for SCATTERED lines mixed 53 : 47 reads : writes as the delivery pass
+# mixes them — tools/micro/line_rate_probe (one lane = one random 64-byte line per access, 16-byte loads, 16-byte stores, full
+# occupancy, 128 GiB footprint), counted by the same TCC_EA0_RDREQ / WRREQ counters: 36.2 G/s (19.3 G reads + 16.9 G writes);
+# scattered reads alone 47.2 G/s, 16-byte writes alone 29.1 G/s (profiles/r24m_line_rate_probe.txt). Rounds 1-5 used mlp_probe's
+# 21 G/s — eight lanes per line, reads only — which the pass exceeded: no ceiling.
+LINE_RATE_CEILING = 36.2e9
+LINE_RATE_CEILING_READS = 47.2e9
 
 
 def pmc_traffic(name, n, R, avg_launch_ns, step_s=None):
@@ -234,13 +240,13 @@ def pmc_traffic(name, n, R, avg_launch_ns, step_s=None):
         lr = {"requests_per_launch": q, "read_requests_per_launch": rq, "write_requests_per_launch": wq,
               "requests_per_s": q / (avg_launch_ns * 1e-9), "ceiling_requests_per_s": LINE_RATE_CEILING,
               "frac": q / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING,
-              "read_requests_per_s": rq / (avg_launch_ns * 1e-9), "read_frac": rq / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING,
+              "read_requests_per_s": rq / (avg_launch_ns * 1e-9), "read_frac": rq / (avg_launch_ns * 1e-9) / LINE_RATE_CEILING_READS,
               "write_requests_per_s": wq / (avg_launch_ns * 1e-9),
               "bytes_per_request": float(tj["hbm_bytes_per_launch"]) / q,
               "source": "TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum (a third PMC pass) per delivery pass / this run's HIP-event duration of "
-                        "the pass; ceiling: tools/micro/mlp_probe, scattered 64-byte READS (profiles/archive/r03b_micro_mlp_probe.txt) — "
-                        "`frac` sets reads + writes against it (above 1: the writes ride beside the reads, partly as 32-byte "
-                        "requests), `read_frac` the reads alone"}
+                        "the pass; ceiling: tools/micro/line_rate_probe under the same counters, scattered 64-byte lines at the pass's "
+                        "53 : 47 read : write mix, full occupancy (profiles/r24m_line_rate_probe.txt: 36.2 G requests/s; reads alone "
+                        "47.2 G/s, which `read_frac` sets the pass's reads against)"}
         if step_s and tj.get("whole_step_ea_requests"):
             lr["whole_step"] = {"requests_per_step": tj["whole_step_ea_requests"], "requests_per_s": tj["whole_step_ea_requests"] / step_s,
                                 "frac": tj["whole_step_ea_requests"] / step_s / LINE_RATE_CEILING}
