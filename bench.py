@@ -444,6 +444,86 @@ def casper_line(args):
     return out
 
 
+def sharded_workload(args, dist, rank, world, local, on_gpu):
+    """The `sharded_workload` object of a `--gpus N > 1` line: ONE Handel simulation split by node range
+    over the N ranks — what BASELINE config 4 / the north star's "RCCL all-to-all per simulated ms" describe — beside the line's
+    own value (independent replicas). Every rank calls this; rank 0 gets the object. One timed RunMultipleTimes pass, bracketed
+    as the main line (barrier + synchronize on both sides, MAX over ranks), exchanges over the ENGINE'S OWN RCCL communicator
+    (`--shard-callback`: torch.distributed through the callback hooks; the gloo CPU test always). Nodes: --shard-nodes, default
+    32 768 — a sharded engine takes init() from the host, and config 4's 131 072 nodes are 279 s and 128 GiB of host memory per
+    rank there (profiles/r08i_*): `--shard-nodes 131072` runs it, the default line must finish in minutes.
+    The whole attempt runs under a watchdog (WG_BENCH_SHARD_TIMEOUT seconds, default 420): a collective that never completes
+    must not take the replicas line with it — the object then says {"skipped": ...} and the caller leaves without tearing the
+    process group down."""
+    import threading
+    import torch
+    import wittgenstein_amd as w
+    from wittgenstein_amd import shards
+    n = args.shard_nodes
+    box = {}
+
+    def work():
+        try:
+            hp = handel_params(n)
+            hparams = w.HandelParameters(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
+                                         hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], NB, NL, 0)
+            callback = args.shard_callback or not on_gpu
+            scfg = shards.config(dist, device=local, device_memory=on_gpu) if callback else shards.config_rccl(dist, device=local)
+            t0 = time.perf_counter()
+            g = w.Handel(hparams, seed=0, config=scfg)
+            g.init()
+            init_s = time.perf_counter() - t0
+            g.network().profile(2)
+            dist.barrier()
+            if on_gpu:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d, ms = shards.run_multiple_times(dist, g, chunk=10, maxTime=20000)
+            dist.barrier()
+            if on_gpu:
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            pr = g.network().profile_read()["deliver"]
+            by_level = g.network().delivered_by_level()  # (replicated: the whole network's histogram)
+            alg = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
+            avg_ns = pr["total_ns"] / max(1, pr["spans"])
+            calls, words = shards.traffic(g.network())
+            lo, hi = shards.shard_range(g.network())
+            box["out"] = {
+                "metric": "delivered messages/sec (Handel %s nodes, ONE simulation sharded by node range; simulated-ms/sec alongside)"
+                          % ("32k" if n == 32768 else "%d" % n),
+                "value": d / dt, "unit": "delivered messages/s", "n_gpus": world, "shards": world, "nodes": n, "steps": 1, "warmup": 0,
+                "ms_per_step": dt * 1000.0, "higher_is_better": True, "scaling": "strong", "simulated_ms_per_s": ms / dt,
+                "delivered": int(d), "simulated_ms": int(ms), "init_s": init_s, "rank0_node_range": [lo, hi],
+                "transport": ("torch.distributed (%s) through wg_allreduce_fn / wg_alltoallv_fn" % dist.get_backend()) if callback
+                             else "the engine's own RCCL communicator (wg_shard_configure_rccl): ncclAllReduce + grouped ncclSend / ncclRecv on the engine's stream",
+                "words_by_exchange": {k: {"calls": int(c), "int32_words": int(wd)} for k, (c, wd) in shards.traffic_by_exchange(g.network()).items()},
+                "collective_calls": int(calls), "int32_words_received_by_rank0": int(words),
+                "roofline": {"bound": "hbm", "kernel": "the delivery pass (k_handel_lane + k_handel_update + k_handel_lane2 + k_handel_copy + "
+                                                       "k_handel_dissem + k_handel_wave) on rank 0's node range",
+                             "achieved": (alg / world / max(1, pr["spans"])) / max(1.0, avg_ns), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": (alg / world / max(1, pr["spans"])) / max(1.0, avg_ns) / HBM_PEAK_GBS, "traffic": None,
+                             "avg_launch_us": avg_ns / 1000.0, "launches": pr["spans"], "whole_run_achieved_GBs": alg / (dt * 1e9)},
+                "note": "not part of `value`: the line's value is N ranks of independent copies (weak scaling); this is one simulation's "
+                        "rate when its nodes are split over the N GPUs (capacity, DESIGN.md §7.2)"}
+            del g
+        except BaseException as x:  # noqa: B036 — reported in the object, the replicas line stands on its own
+            box["err"] = "%s: %s" % (type(x).__name__, x)
+
+    limit = float(os.environ.get("WG_BENCH_SHARD_TIMEOUT", "420"))
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(limit)
+    if th.is_alive():
+        return {"skipped": "no answer within %.0f s (a collective or an init() that did not complete)" % limit}, True
+    if "err" in box:
+        return {"error": box["err"]}, True  # (the other ranks may be waiting in a collective: leave without a teardown)
+    return box["out"], False
+
+
 def main_shard(args):
     """one simulation per step, sharded by node range over the ranks (strong scaling)"""
     import torch
@@ -523,7 +603,8 @@ def main_shard(args):
         alg_bytes = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level)))
         avg_ns = dk_ns / max(1, dk_spans)
         out = {
-            "metric": "delivered messages/sec (Handel 32k nodes; simulated-ms/sec alongside)",
+            "metric": "delivered messages/sec (Handel %s nodes, ONE simulation sharded by node range; simulated-ms/sec alongside)"
+                      % ("32k" if n == 32768 else "%d" % n),
             "value": delivered / elapsed, "unit": "delivered messages/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1000.0 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic", "simulated_ms_per_s": sim_ms / elapsed,
@@ -587,9 +668,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=32768)
     ap.add_argument("--replicas", type=int, default=32, help="independent simulations per step and per GPU (lowered to what fits the free HBM). "
-                    "31 copies of config 3 (9.19 GB each with their init() image) since round 5: 32 fit too and are SLOWER — 546 against "
-                    "565 M msgs/s, and as slow with smaller copies at 90 %% of the HBM: the lane-per-node kernels take 17 %% longer "
-                    "for 3 %% more nodes (profiles/r20u_*, r23b_copies_31_vs_32.txt)")
+                    "32 copies of config 3 (9.19 GB each with their init() image) since round 6: a batch launch keeps an engine on ONE XCD "
+                    "(csrc/engine_kernels.hip.h wg_place), so a step's time goes by ceil(copies / 8) and 4 per XCD is what the HBM holds "
+                    "(24 / 28 / 31 / 32 copies: 551 / 541 / 584 / 592 M msgs/s same-box, profiles/r24b_*, r24c_*)")
     ap.add_argument("--engine-config", default="", help="wg_config capacities of the Handel copies as name=value,... "
                     "(include/wittgpu.h; overflow of any of them is a loud error, never a silent divergence)")
     ap.add_argument("--batches", type=int, default=0,
@@ -626,6 +707,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="replicas = independent copies per GPU (default, weak scaling); shard = one simulation per "
                          "step, its nodes split by id range over the ranks (strong scaling)")
+    ap.add_argument("--shard-nodes", type=int, default=32768, help="nodes of the `sharded_workload` object of a --gpus N > 1 line (ONE "
+                    "Handel simulation split over the N ranks); 131072 = BASELINE config 4 (init() on the host: ~ 5 min and 128 GiB per rank)")
+    ap.add_argument("--no-shard-line", action="store_true", help="--gpus N > 1: leave the `sharded_workload` object out")
     ap.add_argument("--shard-callback", action="store_true",
                     help="--mode shard: the per-ms sums through the caller-supplied torch.distributed all-reduce "
                          "(wg_allreduce_fn) instead of the engine's own RCCL communicator")
@@ -818,7 +902,15 @@ def main():
 
     if world > 1:
         elapsed, delivered, sim_ms = replicas.reduce_job(dist, rdev, elapsed, delivered, sim_ms)
+    sharded, hard_exit = None, False
+    if world > 1 and args.workload == "handel" and not args.no_shard_line:
+        gc.collect()
+        if rdev == "cuda":
+            torch.cuda.empty_cache()
+        sharded, hard_exit = sharded_workload(args, dist, rank, world, local, rdev == "cuda")
     if rank != 0:
+        if hard_exit:
+            os._exit(0)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -943,7 +1035,12 @@ def main():
                 out[key] = replicas_line(wl, nn, rr, 2, 1, local)
             except Exception as x:
                 out[key] = {"error": "%s: %s" % (type(x).__name__, x)}
+    if sharded is not None:
+        out["sharded_workload"] = sharded
     emit(out)
+    if hard_exit:
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

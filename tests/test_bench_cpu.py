@@ -207,7 +207,7 @@ def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
                WG_EMU_DEVICES="2")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "16", "--replicas", "2", "--no-cpu", "--no-second"]
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "16", "--replicas", "2", "--no-cpu", "--no-second", "--shard-nodes", "16"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -215,6 +215,13 @@ def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
     assert out["config"]["replicas_per_gpu"] == 2
+    # ... and, beside the replicas' value, ONE simulation split over the two ranks (`sharded_workload`):
+    # it delivers what the oracle delivers for seed 0, by whatever split
+    sw = out["sharded_workload"]
+    assert "error" not in sw and "skipped" not in sw, sw
+    assert sw["shards"] == 2 and sw["nodes"] == 16 and sw["scaling"] == "strong" and sw["rank0_node_range"] == [0, 8]
+    assert sw["words_by_exchange"]["events"]["int32_words"] > 0 and sw["words_by_exchange"]["outbox"]["calls"] > 0
+    assert sw["roofline"]["launches"] > 0 and sw["value"] > 0
     # one rank alone, same argv: seeds 0, 1; the two-rank job ran seeds 0..3 — twice the simulations per step
     one, _ = run_bench(["--gpus", "1"] + argv[2:])
     total2 = round(out["value"] * out["ms_per_step"] * 2 / 1000.0)
@@ -233,3 +240,10 @@ def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
                 break
         want += c.info()["delivered"]
     assert total2 == 2 * want
+    c = o.Handel(hp["nodeCount"], hp["threshold"], hp["pairingTime"], hp["levelWaitTime"], hp["extraCycle"],
+                 hp["disseminationPeriodMs"], hp["fastPath"], hp["nodesDown"], bench.NB, bench.NL, 0, seed=0)
+    while True:
+        did = c.run_ms(10)
+        if c.info()["time"] >= 20000 or (did and not c.cont_if()):
+            break
+    assert sw["delivered"] == c.info()["delivered"] and sw["simulated_ms"] == c.info()["time"]
