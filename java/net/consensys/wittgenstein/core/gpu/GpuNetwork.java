@@ -164,6 +164,22 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
     return h;
   }
 
+  /** A native call that creates ONE envelope of `m`: the reference handleOf took for it is given back if the engine refuses the
+   *  call (IllegalArgumentException / IllegalStateException / OutOfMemoryError mapped from WG_EINVAL / WG_ESTATE / WG_ENOMEM) — no
+   *  envelope exists then, wg_host_released will never report it, and the Message would stay pinned and its handle lost for the
+   *  rest of the run (ADVICE.md round 5; hostnet.HostNetwork._native is the same rule). */
+  private interface NativeCall { void with(int handleOfMessage); }
+
+  private void underHandle(Message<? extends TN> m, NativeCall call) {
+    final int h = handleOf(m);
+    try {
+      call.with(h);
+    } catch (RuntimeException | Error e) {
+      unref(h);
+      throw e;
+    }
+  }
+
   private void unref(int h) {
     if (--refs[h] > 0) return;
     handleOfObj.remove(byHandle.get(h));
@@ -242,21 +258,26 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
       deferred = null;
     }
     start();
-    for (Object[] o : kept) {
+    for (final Object[] o : kept) {
       @SuppressWarnings("unchecked")
       Message<? extends TN> m = (Message<? extends TN>) o[1];
       switch ((Integer) o[0]) {
         case WittGpu.OP_SEND:
           WittGpu.rngSetState(handle, (Long) o[2]);
-          WittGpu.send(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4], (int[]) o[5], (Integer) o[6]);
+          underHandle(m, h -> WittGpu.send(handle, h, 0, (Integer) o[3], (Integer) o[4], (int[]) o[5], (Integer) o[6]));
           break;
         case WittGpu.OP_SEND_ARRIVE_AT:
-          WittGpu.sendArriveAt(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4], ((int[]) o[5])[0]);
+          underHandle(m, h -> WittGpu.sendArriveAt(handle, h, 0, (Integer) o[3], (Integer) o[4], ((int[]) o[5])[0]));
           break;
         default:
-          WittGpu.registerTask(handle, handleOf(m), 0, (Integer) o[3], (Integer) o[4]);
+          underHandle(m, h -> WittGpu.registerTask(handle, h, 0, (Integer) o[3], (Integer) o[4]));
       }
     }
+    // The replay put the engine's rd to each kept send's own state; it must END where init() itself ended — Java's rd, which
+    // went on drawing inside init() (after the last send, or with no send at all: tasks only). The first stepBegin copies the
+    // engine's state into Java's rd, so a stale one here would replace the right stream (ADVICE.md round 5; the Python mirror
+    // ends deferred_init with wg_rng_set_state(end): tests/test_gpu_hostmode.py::test_deferred_init_leaves_rd_where_init_left_it).
+    rdToEngine();
   }
 
   @Override
@@ -291,7 +312,7 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
       return;
     }
     rdToEngine();
-    WittGpu.send(handle, handleOf(m), 0, sendTime, fromNode.nodeId, ids, delay); // draws rd.nextInt(), also for an empty list (:430)
+    underHandle(m, h -> WittGpu.send(handle, h, 0, sendTime, fromNode.nodeId, ids, delay)); // draws rd.nextInt(), also for an empty list (:430)
     rdFromEngine();
   }
 
@@ -304,7 +325,7 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
     start();
     if (arriveAt <= time) throw new IllegalArgumentException("wrong arrival time: arriveAt=" + arriveAt + ", time=" + time);
     if (stepOpen) op(WittGpu.OP_SEND_ARRIVE_AT, handleOf(mc), arriveAt, fromNode.nodeId, new int[] {toNode.nodeId}, 0, 0);
-    else WittGpu.sendArriveAt(handle, handleOf(mc), 0, arriveAt, fromNode.nodeId, toNode.nodeId);
+    else underHandle(mc, h -> WittGpu.sendArriveAt(handle, h, 0, arriveAt, fromNode.nodeId, toNode.nodeId));
   }
 
   private void register(Task<TN> t, int startAt, TN fromNode) {
@@ -314,7 +335,7 @@ public class GpuNetwork<TN extends Node> extends Network<TN> {
     }
     start();
     if (stepOpen) op(WittGpu.OP_TASK, handleOf(t), startAt, fromNode.nodeId, new int[0], 0, 0);
-    else WittGpu.registerTask(handle, handleOf(t), 0, startAt, fromNode.nodeId);
+    else underHandle(t, h -> WittGpu.registerTask(handle, h, 0, startAt, fromNode.nodeId));
   }
 
   @Override

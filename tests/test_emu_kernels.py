@@ -256,6 +256,11 @@ def test_host_callback_mode_releases_handles(monkeypatch):  # wg_host_released: 
     thm.test_handles_are_released_for_dropped_and_repeated_sends(monkeypatch)
 
 
+def test_host_callback_mode_refused_send_and_deferred_init_rd():  # the handle of a refused send, rd at the end of deferred_init
+    thm.test_a_refused_send_gives_its_handle_back()
+    thm.test_deferred_init_leaves_rd_where_init_left_it()
+
+
 def test_casper_through_host_callbacks():  # P/CasperIMD.java on the engine vs oracle/casper.hpp (the full cases: -m gpu)
     tc.lockstep((2, False, 2, 6, 1000, 1), seed=5, chunk=3000, chunks=3)
 

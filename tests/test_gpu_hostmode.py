@@ -190,6 +190,56 @@ def test_handles_are_released_for_dropped_and_repeated_sends(monkeypatch):
         assert [to for _, _, to in log] == [1, 1] and not net._handles and not net._refs
 
 
+@pytest.mark.gpu
+def test_a_refused_send_gives_its_handle_back():
+    """a native call the engine refuses creates no envelope, so wg_host_released never reports one: the binding gives the
+    reference back itself — the Message is not pinned and its handle is reused (the Java binding's
+    try / catch around its native calls is the same rule)"""
+    net, n = net4()
+    log = []
+    m = _Rec(log)
+    net.runMs(5)
+    with pytest.raises(hn.IllegalArgumentException):
+        net.sendArriveAt(m, net.time, n[0], n[1])       # "wrong arrival time" (C/Network.java:386)
+    assert not net._handles and not net._refs and not net._handle_of
+    with pytest.raises(Exception):
+        net.send(m, n[0], [n[1]], sendTime=net.time)    # sendTime <= time is refused (:371)
+    assert not net._handles and not net._refs
+    net.send(m, n[0], n[1])                             # ... and the object can still be sent
+    assert list(net._refs.values()) == [1]
+    net.runMs(2000)
+    assert [to for _, _, to in log] == [1] and not net._handles
+
+
+@pytest.mark.gpu
+def test_deferred_init_leaves_rd_where_init_left_it():
+    """deferred_init replays the kept sends with rd put back to each send's own state — and must END with rd where init()
+    itself ended: an init() that draws AFTER its last send (or only registers tasks) otherwise hands the run a stale stream
+    (the Java GpuNetwork.deferredInit did). Compared with the same init() done without the block."""
+    def build(deferred):
+        net = hn.HostNetwork(None)
+        nodes = []
+        log = []
+        import contextlib
+        with (net.deferred_init() if deferred else contextlib.nullcontext()):
+            for _ in range(4):
+                nodes.append(hn.Node(net))
+                net.addNode(nodes[-1])
+            if deferred:  # (sends between constructions are what the block is for; without it they come after the nodes)
+                pass
+            net.send(_Rec(log), nodes[0], nodes[1])
+            net.send(_Rec(log), nodes[2], [nodes[1], nodes[3]])
+            tail = [net.rd.nextInt() for _ in range(3)]   # init() goes on drawing after its last send
+            net.registerTask(lambda: log.append(("task", net.time, -1)), 7, nodes[0])
+        return net, tail, log
+    a, tail_a, log_a = build(False)
+    b, tail_b, log_b = build(True)
+    assert tail_a == tail_b and a._eng.rng_state() == b._eng.rng_state()
+    for net in (a, b):
+        net.runMs(300)
+    assert log_a == log_b and a._eng.rng_state() == b._eng.rng_state() and a.rd.nextInt() == b.rd.nextInt()
+
+
 # ---- the batched form of the same boundary: wg_step_begin / wg_step_end (a ms of deliveries per call, their pushes back in
 # one call, include/wittgpu.h) must hand out and file everything exactly as wg_next_delivery does
 BATCHED = ["test_register_task", "test_task_and_stopped_node", "test_periodic_task", "test_conditional_task",

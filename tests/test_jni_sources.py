@@ -71,3 +71,22 @@ def test_gpu_network_overrides_the_reference_surface():
                 "public void registerConditionalTask(final Runnable task, int startAt, int duration, TN fromNode, Condition startIf, Condition repeatIf)",
                 "public boolean runMs(int ms)", "public void partition(float part)", "public void endPartition()"]:
         assert sig in src, sig
+
+
+def test_gpu_network_handles_and_deferred_init_rd():
+    """ADVICE.md round 5, at source level (no JDK in the image): every native call that creates an envelope runs under
+    underHandle — the reference handleOf took is given back when the engine refuses the call — and deferredInit ends by putting
+    the engine's rd where init() left Java's (rdToEngine() after the replay loop). The behaviour itself is tested on the Python
+    mirror of the same binding: tests/test_gpu_hostmode.py::test_a_refused_send_gives_its_handle_back,
+    ::test_deferred_init_leaves_rd_where_init_left_it."""
+    src = open(os.path.join(JAVA, "GpuNetwork.java")).read()
+    for call in ("WittGpu.send(", "WittGpu.sendArriveAt(", "WittGpu.registerTask("):
+        sites = [m.start() for m in re.finditer(re.escape(call), src)]
+        assert sites
+        for at in sites:
+            line = src[src.rfind("\n", 0, at) + 1:src.find("\n", at)]
+            assert "underHandle(" in line and "handleOf(" not in line, line
+    body = src[src.index("public void deferredInit(Runnable init)"):]
+    body = body[:body.index("@Override")]
+    assert body.rstrip().endswith("rdToEngine();\n  }".rstrip()) or body.rstrip().rstrip("}").rstrip().endswith("rdToEngine();")
+    assert body.index("for (final Object[] o : kept)") < body.rindex("rdToEngine();")

@@ -1089,6 +1089,12 @@ void Engine::end_phase(const Group& g, bool drained, bool keep) {
   hipLaunchKernelGGL(k_end_phase, dim3(1, g.R), dim3(256), 0, g.stream, g.tab, drained ? 1 : 0, keep ? 1 : 0);
 }
 
+// WG_MERGE_APPEND=0: two appends per simulated ms (rounds 1-4). Read when a group is made — once per runMs of an engine or a
+// batch, so a test can still toggle it between runs — and carried in the Group: the per-ms enqueue path reads no environment.
+static bool merge_append_setting() {
+  const char* v = getenv("WG_MERGE_APPEND");
+  return !(v && atoi(v) == 0);
+}
 Group Engine::self() {
   ensure_device();
   upload_down();
@@ -1121,6 +1127,7 @@ Group Engine::self() {
   g.stream = stream;
   g.binBits = binBits;
   g.histLds = sizeof(uint32_t) * (size_t)dev.horizon;
+  g.mergeAppend = merge_append_setting();
   g.periodic = periodicUnknown ? nullptr : &periodicRegs;
   return g;
 }
@@ -1226,7 +1233,9 @@ void Engine::check_device_errors() {
   if (e & ERR_PAYLOAD) m += "wg_config.payload_words ring overrun; ";
   if (e & ERR_QUEUE_CAP) m += "toVerify list (Handel toVerifyAgg / GSFSignature toVerify) exceeded wg_config.queue_cap (Handel levels of 1024 ids and more: queue_cap_wide); ";
   if (e & ERR_PENDING) m += "pending-verification table full; ";
-  if (e & ERR_RANK_BUMPS) m += "a Handel node bumped the reception rank of more senders than wg_config.rank_bump_cap holds; ";
+  if (e & ERR_RANK_BUMPS) m += "a Handel node bumped the reception rank of more distinct senders than its table holds: raise wg_config.rank_bump_cap "
+                               "(default 512 beyond 4096 nodes; nodeCount = a direct-indexed table that cannot overflow) or keep the N x N matrix "
+                               "with WG_HANDEL_RANKS=matrix; ";
   if (e & ERR_MULTI_TOO_BIG) {
     m += "device-side multi-destination send with more than 64 destinations; ";
     code = WG_EUNSUPPORTED;
@@ -1373,8 +1382,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
       // with a conditional-task phase behind it the drain only ENDS here (clock, rd, the drained bucket's pages): its ordered
       // outbox stays in fin / arr, the edge's records follow it there, and the phase's append files both — one
       // k_col_reserve_end + k_scatter per simulated ms instead of two (WG_MERGE_APPEND=0: two)
-      const bool merge = !(getenv("WG_MERGE_APPEND") && atoi(getenv("WG_MERGE_APPEND")) == 0);  // (read per call: tests toggle it)
-      if (cond && merge)
+      if (cond && g.mergeAppend)
         Engine::end_phase(g, true, true);
       else
         Engine::append_end_phase(g, true);
@@ -2146,6 +2154,7 @@ Group Batch::prepare(const uint8_t* active) {
   g.stream = l.stream;
   g.binBits = l.binBits;
   g.histLds = sizeof(uint32_t) * (size_t)l.dev.horizon;
+  g.mergeAppend = merge_append_setting();
   // the periodic tasks registered on ANY member (Group::periodic_may_fire)
   periodicUnion.clear();
   bool known = true;
@@ -2622,7 +2631,10 @@ struct HandelHost : ProtoHost {
       tmpRanks = TmpMatrix::acquire(4 * (size_t)N * N);
       st.ranks = tmpRanks;
       st.peersR = rows((uint32_t*)nullptr, N - 1, false, Engine::AC_CONST);
-      int cap = e.cfg.rank_bump_cap > 0 ? e.cfg.rank_bump_cap : 512;  // (config 3: a node verifies ~ 100 senders, 148 at most)
+      // (config 3: a node verifies ~ 100 distinct senders, 148 at most — 512 entries; a network of up to 4096 nodes gets the
+      // direct-indexed table of N entries, <= 64 MB, which cannot overflow: small networks with many nodesDown or long horizons
+      // verify far more senders per node than the big run does, and the matrix form ran them out of the box — ADVICE.md round 5)
+      int cap = e.cfg.rank_bump_cap > 0 ? e.cfg.rank_bump_cap : (N <= 4096 ? N : 512);
       int p2 = 1;
       while (p2 < cap && p2 < N) p2 <<= 1;
       st.bumpCap = std::min(p2, (int)N);

@@ -47,6 +47,9 @@ struct Group {
   // the simulated ms the launches being enqueued will see as `now` (INT32_MIN: unknown — members on different clocks, a
   // chunk captured as a graph), and the periodic tasks registered on the members (NULL: unknown): hints, never needed
   int32_t now = INT32_MIN;
+  // one append per simulated ms (the drain's outbox kept over the conditional-task phase, Globals::nOutKeep) or two
+  // (WG_MERGE_APPEND=0, the A/B and test switch): read once when the group is made, not per enqueued ms
+  bool mergeAppend = true;
   const std::vector<PeriodicReg>* periodic = nullptr;
   bool periodic_may_fire(uint32_t task) const {
     if (now == INT32_MIN || !periodic) return true;

@@ -347,8 +347,8 @@ __device__ __forceinline__ void h_bump(const EngineDev& d, const HandelState& s,
     const uint32_t e = tab[h];
     if (e == 0 || (int32_t)(e & 0xFFFFu) == from || s.bumpCap == s.N) {
       const uint32_t c = (e >> 16) + 1u;
-      if (c > 0xFFFFu) {
-        set_err(d.g, ERR_PROTOCOL);
+      if (c > 0xFFFFu) {  // (65 535 bumps of one sender by one node: the count's 16 bits — the rank table's own error, not a generic one)
+        set_err(d.g, ERR_RANK_BUMPS);
         return;
       }
       tab[h] = (c << 16) | (uint32_t)from;
@@ -3541,9 +3541,11 @@ __global__ void __launch_bounds__(256) k_shard_snap(const EngineDev* __restrict_
 
 // ---- owner-directed snapshot exchange (HandelState::xout / xin): this shard's row of the count matrix, and the chunks
 // the other shards sent copied into this shard's ring at the offset each one names
+// (a region that overflowed — ERR_PAYLOAD, reported at the end of the ms — publishes its capacity, not the count the atomic ran
+// up to: the all-to-all must never be sized past the region, let alone past the allocation behind the last one)
 __global__ void k_handel_xcounts(HandelState s) {
   const int d = (int)threadIdx.x;
-  if (d < s.xS) s.xcounts[s.xMe * s.xS + d] = (int32_t)s.xoutCount[d];
+  if (d < s.xS) s.xcounts[s.xMe * s.xS + d] = (int32_t)min(s.xoutCount[d], s.xChunkCap);
 }
 __global__ void __launch_bounds__(256) k_handel_xunpack(HandelState s, uint32_t nChunks) {
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, j = threadIdx.x & 15u, stride = (gridDim.x * blockDim.x) >> 4;

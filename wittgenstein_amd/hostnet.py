@@ -210,11 +210,11 @@ class HostNetwork:
                 if op[0] == "send":
                     _, before, m, sendTime, frm, ids, delay = op
                     self._eng._ck(lib.wg_rng_set_state(h, C.c_uint64(before)))
-                    self._eng.send(self._handle(m), sendTime, frm, ids, delay)
+                    self._native(m, lambda hm: self._eng.send(hm, sendTime, frm, ids, delay))
                 elif op[0] == "arrive":
-                    self._eng._ck(lib.wg_send_arrive_at(h, self._handle(op[1]), 0, op[2], op[3], op[4]))
+                    self._native(op[1], lambda hm: self._eng._ck(lib.wg_send_arrive_at(h, hm, 0, op[2], op[3], op[4])))
                 else:
-                    self._eng.registerTask(self._handle(op[1]), op[2], op[3])
+                    self._native(op[1], lambda hm: self._eng.registerTask(hm, op[2], op[3]))
             self._eng._ck(lib.wg_rng_set_state(h, C.c_uint64(end)))
         return block()
 
@@ -232,6 +232,17 @@ class HostNetwork:
             self._refs[h] = 0
         self._refs[h] += 1
         return h
+
+    def _native(self, obj, call):
+        """call(handle) with a reference taken on `obj`'s handle for the envelope the call creates — given back if the engine
+        refuses the call (WG_ENOMEM for chain_slots / chain_dests, "Arriving in the past", ...): no envelope exists then, so
+        wg_host_released would never report it and the object would stay pinned for the rest of the run"""
+        h = self._handle(obj)
+        try:
+            return call(h)
+        except BaseException:
+            self._unref(h)
+            raise
 
     def _unref(self, h):
         r = self._refs[h] - 1
@@ -285,7 +296,7 @@ class HostNetwork:
             if ids:
                 self._ops.append((self._cur, 0, self._handle(m), 0, sendTime, fromNode.nodeId, ids, delayBetween, seed))
             return
-        self._eng.send(self._handle(m), sendTime, fromNode.nodeId, ids, delayBetween)
+        self._native(m, lambda h: self._eng.send(h, sendTime, fromNode.nodeId, ids, delayBetween))
 
     def sendArriveAt(self, m, arriveAt, fromNode, toNode):
         if self._deferred is not None:
@@ -297,8 +308,8 @@ class HostNetwork:
                 raise IllegalArgumentException("wrong arrival time: arriveAt=%d, time=%d" % (arriveAt, self.time))
             self._ops.append((self._cur, 1, self._handle(m), 0, int(arriveAt), fromNode.nodeId, [toNode.nodeId], 0, 0))
             return
-        self._eng._ck(L.lib().wg_send_arrive_at(self._eng._h, self._handle(m), 0, int(arriveAt), fromNode.nodeId,
-                                                toNode.nodeId))
+        self._native(m, lambda h: self._eng._ck(L.lib().wg_send_arrive_at(self._eng._h, h, 0, int(arriveAt), fromNode.nodeId,
+                                                                          toNode.nodeId)))
 
     def _register(self, obj, startAt, fromNode):
         if self._deferred is not None:
@@ -308,7 +319,7 @@ class HostNetwork:
         if self._ops is not None:
             self._ops.append((self._cur, 2, self._handle(obj), 0, int(startAt), fromNode.nodeId, [], 0, 0))
             return
-        self._eng.registerTask(self._handle(obj), startAt, fromNode.nodeId)
+        self._native(obj, lambda h: self._eng.registerTask(h, startAt, fromNode.nodeId))
 
     def registerTask(self, task, startAt, fromNode):  # :505-508
         self._register(Task(task), startAt, fromNode)
