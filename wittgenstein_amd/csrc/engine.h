@@ -69,20 +69,32 @@ constexpr int GRID_NODE_WAVES = 2048 / WG_GRID_DIV;    // one wavefront per node
 inline int grid_node_waves(int R) {
   constexpr int total = 4 * GRID_NODE_WAVES, loDiv = 8;
   int b = total / (R > 0 ? R : 1);
-  const int lo = GRID_NODE_WAVES / loDiv > 0 ? GRID_NODE_WAVES / loDiv : 1;
+  // (the floor: 16 blocks an engine. It was GRID_NODE_WAVES / 8 = 256 until round 6 — at 512 copies of GSFSignature that
+  // launched 131 072 blocks per kernel for a few hundred node visits per engine, and the launch of the empty ones was 10 % of
+  // the run: 712 -> 784 M msgs/s, profiles/r24n_*)
+  const int lo = GRID_NODE_WAVES / loDiv > 16 ? 16 : (GRID_NODE_WAVES / loDiv > 0 ? GRID_NODE_WAVES / loDiv : 1);
   if (b < lo) b = lo;
   if (b > GRID_NODE_WAVES) b = GRID_NODE_WAVES;
   return b;
 }
-// The same for the kernels of the ordering / append chain (scans, k_resolve, the multisplit): their grid.x is blocks per
-// ENGINE and grid.y the batch, and an engine's share of a ms's records shrinks as the batch grows — at 64 copies a fixed
-// 256 x 1024-thread grid.x of k_scatter launched 262 144 wavefronts of which a few hundred found a tile (31 us a launch,
-// 13 us at 24 copies: the launch of empty wavefronts, not the scatter). `total` = blocks over the whole batch that fill the
-// chip about twice (the values at the call sites are the measured optima of the round-3/4 sweeps, profiles/INDEX.md).
-inline int grid_per_engine(int base, int R, int total) {
+// The same for the kernels of the ordering / append chain (scans, k_resolve, the multisplit) and the lane-per-item kernels:
+// their grid.x is blocks per ENGINE and grid.y the batch. Two needs set it, and the larger wins:
+//   * the CHIP wants `total` blocks over the whole batch (about twice its resident blocks: the call sites' values are the
+//     measured optima of the round-3/4 sweeps) — total / R per engine, what a small batch is sized by;
+//   * an ENGINE needs blocks for ITS work whatever the batch — a ms's events, records, runners, all proportional to its node
+//     count: n / perBlock (`perBlock` = nodes of the network per block of this kernel).
+// Until round 6 the rule was total / R alone, rounded up to a multiple of the 8 XCDs: at 512 copies of a 4096-node GSFSignature
+// that is 8 blocks an engine where 2 - 4 have work, and the launch of the empty ones was 10 % of the run (a block that finds
+// nothing still costs ~ 7 ns; 726 -> 805 M msgs/s, profiles/r24n_* .. r24s_*); n / perBlock alone starves a 64-copy batch
+// (-8 %, r24r). The rounding is kept only below 8 engines: from 8 on a batch deals its blocks to the XCDs by ENGINE
+// (engine_kernels.hip.h wg_place), whatever the blocks per engine are.
+inline int grid_per_engine(int base, int R, int total, int n, int perBlock) {
   if (R <= 1) return base;
   int b = (total / WG_GRID_DIV + R - 1) / R;
-  b = (b + 7) / 8 * 8;  // (a multiple of the 8 XCDs)
+  const int own = (n + perBlock - 1) / perBlock / WG_GRID_DIV;
+  if (b < own) b = own;
+  if (b < 2) b = 2;
+  if (R < 8) b = (b + 7) / 8 * 8;  // (the plain block mapping: a multiple of the 8 XCDs)
   return b > base ? base : b;
 }
 constexpr int GRID_DELIVER_SMALL = 512 / WG_GRID_DIV;

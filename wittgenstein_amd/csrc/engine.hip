@@ -1055,7 +1055,7 @@ void Engine::register_periodic_task(uint32_t task, int32_t startAt, int32_t peri
 template <class F>
 void Engine::scan(const Group& g, const typename F::Aux* atab) {
   constexpr int total = 1024;
-  const int gx = grid_per_engine(SCAN_GRID, g.R, total);
+  const int gx = grid_per_engine(SCAN_GRID, g.R, total, g.nodes, 1024);
   hipLaunchKernelGGL(k_scan1<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
   hipLaunchKernelGGL(k_scan2<F>, dim3(gx, g.R), dim3(SCAN_BLOCK), 0, g.stream, g.tab, atab);
 }
@@ -1073,7 +1073,7 @@ template void Engine::scan<MultiF>(const Group&, const int*);
 // host-staged envelopes need the standalone histogram kernel.
 void Engine::append_phase(const Group& g, bool needHist) {
   constexpr int total = 512;
-  const int gx = grid_per_engine(GRID_TILES, g.R, total);
+  const int gx = grid_per_engine(GRID_TILES, g.R, total, g.nodes, 2048);
   if (needHist) hipLaunchKernelGGL(k_tile_hist, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits);
   hipLaunchKernelGGL(k_col_reserve, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab);
   hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 0);
@@ -1081,7 +1081,7 @@ void Engine::append_phase(const Group& g, bool needHist) {
 // append + end of the phase in two launches instead of three (k_col_reserve_end, then the scatter)
 void Engine::append_end_phase(const Group& g, bool drained) {
   constexpr int total = 512;
-  const int gx = grid_per_engine(GRID_TILES, g.R, total);
+  const int gx = grid_per_engine(GRID_TILES, g.R, total, g.nodes, 2048);
   hipLaunchKernelGGL(k_col_reserve_end, dim3(1, g.R), dim3(1024), 0, g.stream, g.tab, drained ? 1 : 0);
   hipLaunchKernelGGL(k_scatter, dim3(gx, g.R), dim3(TILE), g.histLds, g.stream, g.tab, g.binBits, 1);
 }
@@ -1128,6 +1128,7 @@ Group Engine::self() {
   g.binBits = binBits;
   g.histLds = sizeof(uint32_t) * (size_t)dev.horizon;
   g.mergeAppend = merge_append_setting();
+  g.nodes = dev.nodes.n;
   g.periodic = periodicUnknown ? nullptr : &periodicRegs;
   return g;
 }
@@ -1368,7 +1369,7 @@ static void enqueue_one_ms(Engine& lead, const Group& g0, int32_t tNow) {
       // (a block that finds no record still costs its launch — ~ 7 ns each, 25 us of GSFSignature's every ms at 4096 blocks,
       // profiles/r14j —: the wide grid only in a ms in which a periodic task may fire)
       constexpr int total = 4096, totalQuiet = 512;
-      const int gx = grid_per_engine(GRID_RESOLVE, g.R, g.any_periodic_may_fire() ? total : totalQuiet);
+      const int gx = grid_per_engine(GRID_RESOLVE, g.R, g.any_periodic_may_fire() ? total : totalQuiet, g.nodes, g.any_periodic_may_fire() ? 256 : 2048);
       hipLaunchKernelGGL(k_resolve<false>, dim3(gx, g.R), dim3(256), 0, g.stream, g.tab);
     }
     if (lead.dev.maxSendAll) {  // Network.sendAll calls of this ms's action()s: destinations, envelopes, first arrivals
@@ -2155,6 +2156,7 @@ Group Batch::prepare(const uint8_t* active) {
   g.binBits = l.binBits;
   g.histLds = sizeof(uint32_t) * (size_t)l.dev.horizon;
   g.mergeAppend = merge_append_setting();
+  g.nodes = l.dev.nodes.n;
   // the periodic tasks registered on ANY member (Group::periodic_may_fire)
   periodicUnion.clear();
   bool known = true;
@@ -3039,13 +3041,13 @@ struct HandelHost : ProtoHost {
     if (st.atk == 2)  // HiddenByzantine.attack on the drawn candidates of the last level
       hipLaunchKernelGGL(k_handel_hidden, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     if (st.atk)
-      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL((k_handel_cond_a2<false, true>), dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
     else
     {
       // one thread per drawing node — about a quarter of the nodes at pairingTime 4 —, ONE round of them: a grid that makes a
       // thread take a second node doubles the kernel's chain (22 -> 29 us at 32 copies with the batch-wide total alone)
       const int floorBlocks = std::min(GRID_COND_TAIL, ((st.N / 3 + 255) / 256 + 7) / 8 * 8);
-      const int gx = std::max(grid_per_engine(GRID_COND_TAIL, g.R, 1024), floorBlocks);
+      const int gx = std::max(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), floorBlocks);
       hipLaunchKernelGGL((k_handel_cond_a2<false, false>), dim3(gx, g.R), dim3(256), 0, g.stream, g.tab, stab);
     }
   }
@@ -3128,11 +3130,11 @@ struct HandelHost : ProtoHost {
     // (workgroups of ONE wavefront: at three wavefronts a SIMD a 256-thread workgroup needs four free slots at once, one per SIMD,
     // and the kernel's wavefronts end at very different times — 576 -> 579 M msgs/s same-box, and the 32-copy cliff halves:
     // profiles/r23d_*. The kernels with more resident wavefronts lose with small workgroups.)
-    hipLaunchKernelGGL(k_handel_lane, dim3(4 * grid_per_engine(GRID_LANE_NODES, g.R, 2048), g.R), dim3(64), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_handel_lane, dim3(4 * grid_per_engine(GRID_LANE_NODES, g.R, 2048, st.N, 512), g.R), dim3(64), 0, g.stream, g.tab, stab);
     hipLaunchKernelGGL(k_handel_update<8>, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
     // the deliveries behind a wide update that was its node's first event, one lane per node (after the update)
     if (!st.atk)
-      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
+      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 512, st.N, 2048), g.R), dim3(256), 0, g.stream, g.tab, stab, 0);
     const dim3 grid(node_grid(g.R), g.R);
     // In a ms whose phase no member's dissemination task has (19 of 20 with a synchronised start) the lean dissemination kernel
     // would find an empty list: not launched (6 us each at 24 copies). k_handel_wave is told, and stops the run loudly should
@@ -3142,7 +3144,7 @@ struct HandelHost : ProtoHost {
     if (!st.atk && mayDissem) {  // nodes whose first event is their dissemination: that event
       hipLaunchKernelGGL(k_handel_dissem<8>, grid, dim3(256), 0, g.stream, g.tab, stab);
       // ... and the plain deliveries behind it, one lane per node (the others' remaining events are visits of k_handel_wave)
-      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
+      hipLaunchKernelGGL(k_handel_lane2, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
     // every wide payload the lane kernels delivered, one wavefront per copy (behind the dissemination: it reads no queue slot)
     hipLaunchKernelGGL(k_handel_copy, dim3(node_grid(g.R), g.R), dim3(256), 0, g.stream, g.tab, stab);
@@ -3462,12 +3464,12 @@ struct GsfHost : ProtoHost {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
       // eight lanes per runner for the short lists; what is left over, one wavefront each
-      hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
-      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
+      hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
-    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
+    hipLaunchKernelGGL(k_gsf_cond_a2<false>, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
   }
   // ---- node-range sharding (Engine::run_ms_sharded; the recipe of HandelHost) ----
   bool supports_shards() const override { return true; }
@@ -3509,7 +3511,7 @@ struct GsfHost : ProtoHost {
     else if (cycleRan)
       hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
     if (eng.dev.inbox)
-      hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024), g.R), dim3(256), 0, g.stream, g.tab,
+      hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab, cycleRan ? 1 : 0, restList ? 1 : 0);
     if (eng.dev.inbox && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
       // (workgroups of one wavefront: at four wavefronts a SIMD a 256-thread workgroup waits for a free slot on all four SIMDs at

@@ -41,6 +41,7 @@ struct Group {
   const EngineDev* tab = nullptr;
   const void* stab = nullptr;
   int R = 1;
+  int nodes = 0;  // node count of the members (they share it): what sizes the per-engine grids (engine.h grid_per_engine)
   hipStream_t stream = nullptr;
   int binBits = 0;
   size_t histLds = 0;  // dynamic LDS of the multisplit kernels: horizon words
