@@ -3464,8 +3464,8 @@ struct GsfHost : ProtoHost {
       Engine::ProfScope ps(profOwner, Engine::PC_COND_SELECT);
       hipLaunchKernelGGL(k_gsf_cond_pre, dim3((st.N + 255) / 256, g.R), dim3(256), 0, g.stream, g.tab, stab);
       // eight lanes per runner for the short lists; what is left over, one wavefront each
-      hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab);
-      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
+      hipLaunchKernelGGL(k_gsf_cond_a1g, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 512), g.R), dim3(256), 0, g.stream, g.tab, stab);
+      hipLaunchKernelGGL(k_gsf_cond_a1, dim3(grid_per_engine(GRID_COND_TAIL, g.R, 1024, st.N, 512), g.R), dim3(256), 0, g.stream, g.tab, stab, 1);
     }
     Engine::ProfScope ps(profOwner, Engine::PC_COND_REST);
     Engine::scan<GsfCondF>(g, stab);
@@ -3511,7 +3511,7 @@ struct GsfHost : ProtoHost {
     else if (cycleRan)
       hipLaunchKernelGGL(k_gsf_docycle<8>, dim3(grid_node_waves(g.R), g.R), dim3(256), 0, g.stream, g.tab, (const GsfState*)g.stab);
     if (eng.dev.inbox)
-      hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024, st.N, 1024), g.R), dim3(256), 0, g.stream, g.tab,
+      hipLaunchKernelGGL(k_gsf_lane, dim3(grid_per_engine(GRID_LANE_NODES, g.R, 1024, st.N, 512), g.R), dim3(256), 0, g.stream, g.tab,
                          (const GsfState*)g.stab, cycleRan ? 1 : 0, restList ? 1 : 0);
     if (eng.dev.inbox && restList)  // ... and only the nodes k_gsf_lane listed (EngineDev::activeB)
       // (workgroups of one wavefront: at four wavefronts a SIMD a 256-thread workgroup waits for a free slot on all four SIMDs at
