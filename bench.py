@@ -1032,7 +1032,7 @@ def main():
             try:
                 gc.collect()
                 torch.cuda.empty_cache()
-                out[key] = replicas_line(wl, nn, rr, 2, 1, local)
+                out[key] = replicas_line(wl, nn, rr, 3, 1, local)
             except Exception as x:
                 out[key] = {"error": "%s: %s" % (type(x).__name__, x)}
     if sharded is not None:
