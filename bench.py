@@ -263,19 +263,23 @@ def replicas_line(workload, n, R_req, K, W, local=0):
     from wittgenstein_amd import replicas
     free0 = torch.cuda.mem_get_info()[0]
     t_init = time.perf_counter()
-    first = make_sim(w, n, 0, local, workload)
-    first.network().snapshot()
+    def init_one(sd):
+        g = make_sim(w, n, sd, local, workload)
+        g.network().snapshot()
+        return g
+    sims = [init_one(0)]
     torch.cuda.synchronize()
-    per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
-    R = replicas.plan_replicas(R_req, free0, per_copy, transient_bytes=0 if workload == "gsf" else replicas.handel_init_transient_bytes(n))
-    sims = [first]
-    if R > 1:
-        def init_one(sd):
-            g = make_sim(w, n, sd, local, workload)
-            g.network().snapshot()
-            return g
-        with ThreadPoolExecutor(max_workers=min(R - 1, max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
-            sims += list(ex.map(init_one, range(1, R)))
+    free1 = torch.cuda.mem_get_info()[0]
+    per_copy, once = max(1, free0 - free1), 0
+    if R_req > 1:  # what a FURTHER copy takes (the first one also pays what the process allocates once: code objects, tables)
+        sims.append(init_one(1))
+        torch.cuda.synchronize()
+        per_copy, once = replicas.marginal_copy_bytes(free0 - free1, free1 - torch.cuda.mem_get_info()[0])
+    R = replicas.plan_replicas(R_req, free0 - once, per_copy, transient_bytes=0 if workload == "gsf" else replicas.handel_init_transient_bytes(n))
+    if R > 2:
+        with ThreadPoolExecutor(max_workers=min(R - 2, max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
+            sims += list(ex.map(init_one, range(2, R)))
+    sims = sims[:R]
     batch = w.Batch([g.network() for g in sims])
     init_wall = time.perf_counter() - t_init
     delivered = sim_ms = 0
@@ -770,8 +774,14 @@ def main():
     first = make_sim(w, n, seeds[0], local, args.workload)
     first.network().snapshot()
     torch.cuda.synchronize()
-    per_copy = max(1, free0 - torch.cuda.mem_get_info()[0])
-    R = replicas.plan_replicas(R_req, free0, per_copy, transient_bytes=0 if args.workload == "gsf" else replicas.handel_init_transient_bytes(n))
+    free1 = torch.cuda.mem_get_info()[0]
+    per_copy, once, second = max(1, free0 - free1), 0, None
+    if R_req > 1:  # what a FURTHER copy takes: the first one also pays what the process allocates once (code objects, tables) —
+        second = make_sim(w, n, seeds[1], local, args.workload)  # 0.17 GB, a quarter of a GSFSignature copy
+        second.network().snapshot()
+        torch.cuda.synchronize()
+        per_copy, once = replicas.marginal_copy_bytes(free0 - free1, free1 - torch.cuda.mem_get_info()[0])
+    R = replicas.plan_replicas(R_req, free0 - once, per_copy, transient_bytes=0 if args.workload == "gsf" else replicas.handel_init_transient_bytes(n))
     if world > 1:  # every rank runs the same batch size (weak scaling: fixed work per GPU)
         rt = torch.tensor([R], device=rdev, dtype=torch.int64)
         dist.all_reduce(rt, op=dist.ReduceOp.MIN)
@@ -794,10 +804,11 @@ def main():
         g = make_sim(w, n, s, local, args.workload)
         g.network().snapshot()
         return g
-    sims = [first]
-    if R > 1:
+    sims = [first] + ([second] if second is not None and R > 1 else [])
+    second = None
+    if R > 2:
         with ThreadPoolExecutor(max_workers=threads) as ex:
-            sims += list(ex.map(init_one, seeds[1:]))
+            sims += list(ex.map(init_one, seeds[2:]))
     batch = w.Batch([g.network() for g in sims])
     init_wall = time.perf_counter() - t_init
     init_s = init_wall / R
@@ -1026,7 +1037,7 @@ def main():
         # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 24 copies that fit the HBM — it takes 256
         # (64 / 96 / 128 / 192 / 256 / 320 / 360 copies: 349.5 / 393.9 / 439.9 / 476.8 / 502.4 / 507.0 / 509.4 M msgs/s,
         # profiles/r18a_gsf_copies_sweep.txt: the step is ~ 63 ms + 1.44 ms per copy)
-        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 512)):
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 496)):
             if n == nn and args.workload == wl:
                 continue
             try:

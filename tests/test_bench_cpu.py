@@ -32,6 +32,10 @@ def test_plan_replicas_degrades_and_never_fails():
     assert replicas.plan_replicas(32, 288 * GiB, int(8.56 * GiB), transient_bytes=8 * GiB) == 32
     assert replicas.plan_replicas(33, 288 * GiB, int(8.56 * GiB), transient_bytes=8 * GiB) == 32
     assert replicas.plan_replicas(8, 287 * GiB, 35 * GiB, transient_bytes=16 * GiB) == 7
+    # a batch is sized by what a FURTHER copy takes: the first one also pays the process's one-time allocations
+    assert replicas.marginal_copy_bytes(760 << 20, 590 << 20) == (590 << 20, 170 << 20)
+    assert replicas.marginal_copy_bytes(590 << 20, 600 << 20) == (600 << 20, 0)
+    assert replicas.plan_replicas(512, 288 * GiB - (170 << 20), 590 << 20) == 477
     # the number of steps plays no part (round 1: `fit // K` turned --steps 20 into rc=1)
     with pytest.raises(ValueError):
         replicas.plan_replicas(0, GB, GB)

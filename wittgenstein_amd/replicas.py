@@ -61,6 +61,16 @@ def plan_replicas(requested, free_bytes, per_copy_bytes, headroom=0.955, transie
     return max(1, min(requested, fit))
 
 
+def marginal_copy_bytes(first_bytes, second_bytes):
+    """(bytes per further copy, bytes the process pays once) from what the first and the second copy took of the free HBM: the
+    first also pays the one-time allocations (code objects, latency tables, runtime pools), so sizing a batch by it alone gives
+    up copies — a quarter of them for GSFSignature's 0.6 GB copies. Never below the second copy's own size, never negative."""
+    per = max(1, int(second_bytes))
+    if per > first_bytes:  # (allocator granularity can make the second look larger: then nothing was paid once)
+        return max(1, int(first_bytes), per), 0
+    return per, int(first_bytes) - per
+
+
 def init_threads(requested, copies, host_avail_bytes, per_init_bytes, cores, world=1):
     """host threads for the copies' init() (sequential host work per copy, C/RunMultipleTimes.java:44-48): one per copy,
     bounded by the cores of this rank's share of the box and by host memory (per_init_bytes per running init())."""
