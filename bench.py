@@ -1034,10 +1034,10 @@ def main():
             out["second_workload"] = {"error": "%s: %s" % (type(x).__name__, x)}
         # the north star's TARGET SIZE (Handel 65 536 nodes, same ratios) and BASELINE configs[1]
         # (GSFSignature 4096 nodes), each as its own compact line — outside `value`, after the main line's copies are freed.
-        # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 24 copies that fit the HBM — it takes 256
-        # (64 / 96 / 128 / 192 / 256 / 320 / 360 copies: 349.5 / 393.9 / 439.9 / 476.8 / 502.4 / 507.0 / 509.4 M msgs/s,
-        # profiles/r18a_gsf_copies_sweep.txt: the step is ~ 63 ms + 1.44 ms per copy)
-        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 496)):
+        # GSFSignature's copies are 0.6 GB each, so — as the Handel line takes the 32 copies that fit the HBM — it takes 480, 60 per
+        # XCD (489 fit; 256 / 384 / 489 copies: 668 / 712 / 855 M msgs/s on round 6's code, profiles/r24b_*, r25b_*; the last with
+        # the per-engine grids of engine.h grid_per_engine)
+        for key, wl, nn, rr in (("target_size_workload", "handel", 65536, 8), ("third_workload", "gsf", 4096, 480)):
             if n == nn and args.workload == wl:
                 continue
             try:

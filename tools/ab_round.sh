@@ -5,7 +5,7 @@
 # AB_WORKLOADS: bench argument strings separated by ';' (default: the headline, GSFSignature 4096 x 256).
 TAG=$1; ROUNDS=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-IFS=';' read -ra WLS <<< "${AB_WORKLOADS:-;--workload gsf --nodes 4096 --replicas 496}"
+IFS=';' read -ra WLS <<< "${AB_WORKLOADS:-;--workload gsf --nodes 4096 --replicas 480}"
 [ ${#WLS[@]} -eq 0 ] && WLS=("")
 for r in $(seq 1 $ROUNDS); do
   for wl in "${WLS[@]}"; do

@@ -31,7 +31,7 @@ cp $OUT/traffic.json profiles/traffic.json; export WG_TRAFFIC_SESSION=1
 passes h65536_ --nodes 65536 --replicas 8
 python tools/traffic_from_pmc.py $OUT/pmc_h65536_FETCH_SIZE.md $OUT/pmc_h65536_WRITE_SIZE.md 65536 $OUT/pmc_h65536_FETCH_SIZE.json $OUT/traffic_handel65536.json "$HANDEL_PASS" $OUT/pmc_h65536_req.md > /dev/null
 cp $OUT/traffic_handel65536.json profiles/traffic_handel65536.json
-passes gsf_ --workload gsf --nodes 4096 --replicas 496
+passes gsf_ --workload gsf --nodes 4096 --replicas 480
 python tools/traffic_from_pmc.py $OUT/pmc_gsf_FETCH_SIZE.md $OUT/pmc_gsf_WRITE_SIZE.md 4096 $OUT/pmc_gsf_FETCH_SIZE.json $OUT/traffic_gsf.json "k_gsf_docycle16,k_gsf_docycle<,k_gsf_lane,k_deliver_inbox<GsfProto" $OUT/pmc_gsf_req.md > /dev/null
 cp $OUT/traffic_gsf.json profiles/traffic_gsf.json
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -57,7 +57,7 @@ side() { pre=$1; shift
   python tools/prof_summary.py stats $OUT/p_$pre $OUT/kernel_stats_$pre.md; python tools/prof_summary.py phases $OUT/p_$pre $OUT/phases_$pre.md; rm -rf $OUT/p_$pre
 }
 side h65536 --nodes 65536 --replicas 8
-side gsf --workload gsf --nodes 4096 --replicas 496
+side gsf --workload gsf --nodes 4096 --replicas 480
 python - $OUT/bench_driver_argv.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
