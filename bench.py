@@ -307,7 +307,7 @@ def replicas_line(workload, n, R_req, K, W, local=0):
         for g in sims:
             bl = g.network().delivered_by_level()
             by_level = bl if by_level is None else by_level + bl
-    del batch, sims, first
+    del batch, sims
     gc.collect()
     gsf = workload == "gsf"
     alg = float(sum(int(c) * b_msg(l) for l, c in enumerate(by_level))) if by_level is not None else 0.0

@@ -53,7 +53,10 @@ timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_
 python tools/prof_summary.py stats $OUT/p $OUT/kernel_stats.md; python tools/prof_summary.py phases $OUT/p $OUT/phases.md; rm -rf $OUT/p
 # ... and of the two side workloads of the driver's line (their avg_launch_us is then checkable from rocprof too)
 side() { pre=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/p_$pre -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second "$@" > $R/$OUT/prof_bench_$pre.json 2> $R/$OUT/prof_bench_$pre.err)
+  for try in 1 2 3; do
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/p_$pre -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-second "$@" > $R/$OUT/prof_bench_$pre.json 2> $R/$OUT/prof_bench_$pre.err)
+    rc=$?; echo "prof $pre try $try rc=$rc"; [ $rc = 0 ] && break; rm -rf $OUT/p_$pre
+  done
   python tools/prof_summary.py stats $OUT/p_$pre $OUT/kernel_stats_$pre.md; python tools/prof_summary.py phases $OUT/p_$pre $OUT/phases_$pre.md; rm -rf $OUT/p_$pre
 }
 side h65536 --nodes 65536 --replicas 8
