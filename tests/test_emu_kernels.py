@@ -167,6 +167,10 @@ def test_batch_of_nine_blocks_dealt_by_xcd():
     tb.test_handel_batch_matches_oracle_per_seed(32, list(range(9)))
 
 
+def test_gsf_batch_of_nine():  # GSFSignature copies batched: the deal by XCD, the envelopes' latency words
+    tb.test_gsf_batch_matches_oracle_per_seed(32, list(range(40, 49)))
+
+
 def test_graph_replay_keeps_the_profiler(monkeypatch):
     """WG_GRAPH=1: runMs(chunk) of a batch captured once and replayed; the profiler's brackets are then device clock stamps
     (Engine::ProfScope / k_prof_stamp) instead of HIP events — one span per simulated ms for the delivery pass, the same

@@ -35,6 +35,25 @@ def test_handel_batch_matches_oracle_per_seed(n, seeds):
     assert len(set(stop)) > 1 or len(seeds) == 1  # members really stopped at different times
 
 
+@pytest.mark.parametrize("n,seeds", [(256, list(range(40, 58)))])
+def test_gsf_batch_matches_oracle_per_seed(n, seeds):
+    """GSFSignature copies batched (what bench.py's third_workload runs by the hundred): from 8 members on a launch deals its
+    blocks to the XCDs by engine (engine_kernels.hip.h wg_place), from 16 on the per-engine grids follow the engine's own work
+    (engine.h grid_per_engine), and the accelerated calls' multi-destination envelopes keep their latencies beside the ids
+    (CHAIN_LAT) — every member still ends exactly where its own oracle run ends (P/GSFSignature.java:670-682 continuation)."""
+    import test_gpu_gsf as tg
+    pairs = [tg.pair((n, int(0.99 * n), 3, 50, 10, 10, 0), seed=s) for s in seeds]
+    batch = w.Batch([g.network() for g, _ in pairs])
+    delivered, sim_ms = batch.run_multiple_times(chunk=10, maxTime=20000)
+    for (g, c), d, ms in zip(pairs, delivered, sim_ms):
+        while c.cont_if():
+            c.run_ms(10)
+        diff = tg.diff(g, c)
+        assert not diff, diff
+        assert c.info(False)["time"] == ms and c.info(False)["delivered"] == d
+        assert not g.cont_if()
+
+
 def test_batch_every_ms_lockstep_with_oracle():
     pairs = [parity.handel_pair((128, 100, 1, 10, 4, 7, 10, 12, 0), seed=s) for s in (0, 5)]
     batch = w.Batch([g.network() for g, _ in pairs])
