@@ -157,14 +157,16 @@ def run_bench(argv, free=10**6):
 
 
 def test_bench_main_with_the_drivers_argv():
-    out, _ = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--nodes", "16", "--replicas", "2", "--batches", "2",
+    # (the driver's flags with 8 / 2 instead of its 20 / 5 steps: the emulator runs a step in ten seconds; that the number of
+    # steps plays no part in sizing the batch is test_plan_replicas_degrades_and_never_fails's)
+    out, _ = run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--nodes", "16", "--replicas", "2", "--batches", "2",
                         "--no-cpu", "--no-second"])
-    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1
+    assert out["steps"] == 8 and out["warmup"] == 2 and out["n_gpus"] == 1
     assert out["config"]["replicas_per_gpu"] == 2 and out["config"]["nodes"] == 16
     assert out["value"] > 0 and out["unit"] == "delivered messages/s" and out["vs_baseline"] is None
-    # the same 2 seeds are re-run from their init() image every step: 20 identical steps
-    total = round(out["value"] * out["ms_per_step"] * 20 / 1000.0)
-    assert total % 20 == 0 and total // 40 == out["config"]["delivered_per_simulation"]
+    # the same 2 seeds are re-run from their init() image every step: 8 identical steps
+    total = round(out["value"] * out["ms_per_step"] * 8 / 1000.0)
+    assert total % 8 == 0 and total // 16 == out["config"]["delivered_per_simulation"]
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches"] > 0 and 0 < r["frac"] < 1
     assert out["config"]["workload"].startswith("Handel aggregation, 16 nodes")
